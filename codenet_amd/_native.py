@@ -1,0 +1,78 @@
+"""ctypes binding of libcodenet_dcn.so (include/codenet_dcn.h).
+
+The library is the product: if it is missing this module raises -- there is no CPU or PyTorch
+fallback anywhere in codenet_amd (the reference has none either: its functions raise
+NotImplementedError for non-CUDA tensors, functions/dcn_deform_conv.py:43-45).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libcodenet_dcn.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CDN_F32, CDN_F64 = 0, 1
+_lib = None
+
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+_SIGNATURES = {
+    "cdn_abi_version": (ctypes.c_int, []),
+    "cdn_last_error": (ctypes.c_char_p, []),
+    "cdn_deform_conv_forward": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp]),
+    "cdn_deform_conv_backward_input": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp]),
+    "cdn_deform_conv_backward_parameters": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_f, _vp]),
+    "cdn_modulated_deform_conv_forward": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),
+    "cdn_modulated_deform_conv_backward": (_i, [_vp] * 11 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),
+    "cdn_codenet_scale_forward": (_i, [_vp] * 4 + [_i64] * 4 + [_f, _f, _vp]),
+    "cdn_codenet_dw_forward": (_i, [_vp] * 4 + [_i64] * 4 + [_vp]),
+    "cdn_codenet_dw_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
+    "cdn_codenet_pointwise_forward": (_i, [_vp] * 6 + [_i64] * 4 + [_i, _vp]),
+    "cdn_quantact_state_bytes": (ctypes.c_size_t, []),
+    "cdn_quantact_forward": (_i, [_vp] * 3 + [_i64] + [_vp] * 5 + [_i, _d, _i, _vp]),
+}
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 in-tree (codenet_amd/csrc/Makefile)."""
+    cmd = ["make", "-C", CSRC, "-s", "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib():
+    """Load the native library or fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "codenet_amd: native library %s is missing -- run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). There is no "
+                "fallback path." % SO_PATH)
+        l = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.cdn_abi_version() != 1:
+            raise RuntimeError("codenet_amd: ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def last_error():
+    return lib().cdn_last_error().decode("utf-8", "replace")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    """Map a cdn_status to the exception types the reference raises
+    (AT_CHECK/AT_ERROR -> RuntimeError, dcn_deform_conv_cuda.cpp:61-149)."""
+    if rc != 0:
+        raise NativeError("%s failed (cdn_status %d): %s" % (what, rc, last_error()))

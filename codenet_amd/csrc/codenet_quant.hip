@@ -1,0 +1,183 @@
+// codenet_quant.hip -- activation fake-quantisation (QuantAct) for gfx950, entirely on device.
+//
+// Restates, without any host round trip, what the reference's QuantAct.forward does per call
+// (portable_quantizer/quant_modules.py:202-225 + quantization_utils/quant_utils.py:33-75,172-200):
+//   1. batch-global min / max of the activation tensor            (quant_modules.py:205-206)
+//   2. range tracking: "+=" initialisation while x_min == x_max, else EMA with m = 0.99 (:211-219)
+//   3. scale = (2^k - 1) / clamp(x_max - x_min, 1e-10); zp = round(scale*x_min) + 2^(k-1)
+//                                                                  (quant_utils.py:60-75)
+//   4. q = round(scale*x - zp) (NOT clamped); out = (q + zp) / scale  (quant_utils.py:33-52,193-200)
+// Every fp32 operation is issued with explicit _rn intrinsics in the reference's order so the
+// compiler cannot contract them into FMAs: identical fp32 inputs give identical integer codes.
+#include "cdn_common.h"
+
+namespace {
+
+// Order-preserving float <-> uint map so min/max can use integer atomics.
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// state layout (device, 8 x 4 bytes):
+//   [0] ordered-uint running batch min   [1] ordered-uint running batch max
+//   [2] scale  [3] zero_point  [4] batch min (float)  [5] batch max (float)  [6..7] reserved
+constexpr int kStateWords = 8;
+
+__global__ void minmax_init_kernel(unsigned *state) {
+  state[0] = 0xffffffffu;  // +inf side for min
+  state[1] = 0u;           // -inf side for max
+}
+
+__global__ void __launch_bounds__(256)
+minmax_kernel(const float *__restrict__ x, long n, unsigned *state) {
+  float mn = INFINITY, mx = -INFINITY;
+  const long n4 = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+    mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    mn = fminf(mn, x[i]);
+    mx = fmaxf(mx, x[i]);
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  }
+  __shared__ float smn[4], smx[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    smn[wave] = mn;
+    smx[wave] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    atomicMin(&state[0], f2ord(mn));
+    atomicMax(&state[1], f2ord(mx));
+  }
+}
+
+// One thread: range tracking + quantisation parameters (steps 2 and 3 above).
+// running != 0: update x_min/x_max from the batch statistics (reference behaviour even in
+// eval()); running == 0: frozen ranges, only derive scale / zp.
+__global__ void quantact_update_kernel(float *x_min, float *x_max, unsigned *state,
+                                       const float *ext_min, const float *ext_max, int bits,
+                                       float m_minus_1, float one_minus_m, int running) {
+  float lo = x_min[0], hi = x_max[0];
+  if (running) {
+    const float bmin = ext_min ? ext_min[0] : ord2f(state[0]);
+    const float bmax = ext_max ? ext_max[0] : ord2f(state[1]);
+    reinterpret_cast<float *>(state)[4] = bmin;
+    reinterpret_cast<float *>(state)[5] = bmax;
+    if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
+      lo = __fadd_rn(lo, bmin);
+      hi = __fadd_rn(hi, bmax);
+    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219)
+      lo = __fadd_rn(lo, __fadd_rn(__fmul_rn(m_minus_1, lo), __fmul_rn(one_minus_m, bmin)));
+      hi = __fadd_rn(hi, __fadd_rn(__fmul_rn(m_minus_1, hi), __fmul_rn(one_minus_m, bmax)));
+    }
+    x_min[0] = lo;
+    x_max[0] = hi;
+  }
+  const float nlev = (float)((1 << bits) - 1);
+  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);          // torch.clamp(min=1e-10)
+  const float scale = __fdiv_rn(nlev, range);
+  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (bits - 1)));
+  reinterpret_cast<float *>(state)[2] = scale;
+  reinterpret_cast<float *>(state)[3] = zp;
+}
+
+__device__ __forceinline__ float quant_code(float x, float scale, float zp) {
+  return rintf(__fsub_rn(__fmul_rn(scale, x), zp));  // torch.round = half-to-even
+}
+
+// out = (q + zp) / scale; optionally also the integer codes (int16: codes are NOT clamped to
+// int8 by the reference, quant_utils.py:193-200, so int8 alone could not hold them).
+__global__ void __launch_bounds__(256)
+fake_quant_kernel(const float *__restrict__ x, float *__restrict__ out, int16_t *__restrict__ codes,
+                  long n, const unsigned *__restrict__ state) {
+  const float scale = reinterpret_cast<const float *>(state)[2];
+  const float zp = reinterpret_cast<const float *>(state)[3];
+  const long n4 = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  float4 *o4 = reinterpret_cast<float4 *>(out);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    const float q0 = quant_code(v.x, scale, zp), q1 = quant_code(v.y, scale, zp);
+    const float q2 = quant_code(v.z, scale, zp), q3 = quant_code(v.w, scale, zp);
+    if (out) {
+      float4 r;
+      r.x = __fdiv_rn(__fadd_rn(q0, zp), scale);
+      r.y = __fdiv_rn(__fadd_rn(q1, zp), scale);
+      r.z = __fdiv_rn(__fadd_rn(q2, zp), scale);
+      r.w = __fdiv_rn(__fadd_rn(q3, zp), scale);
+      o4[i] = r;
+    }
+    if (codes) {
+      short4 c;
+      c.x = (short)fminf(fmaxf(q0, -32768.f), 32767.f);
+      c.y = (short)fminf(fmaxf(q1, -32768.f), 32767.f);
+      c.z = (short)fminf(fmaxf(q2, -32768.f), 32767.f);
+      c.w = (short)fminf(fmaxf(q3, -32768.f), 32767.f);
+      reinterpret_cast<short4 *>(codes)[i] = c;
+    }
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float q = quant_code(x[i], scale, zp);
+    if (out) out[i] = __fdiv_rn(__fadd_rn(q, zp), scale);
+    if (codes) codes[i] = (int16_t)fminf(fmaxf(q, -32768.f), 32767.f);
+  }
+}
+
+inline int stream_grid(long n) {
+  long b = cdn::ceil_div(n >> 2 > 0 ? n >> 2 : 1, 256);
+  const long cap = (long)cdn::kCUs * 8;
+  return (int)(b < cap ? b : cap);
+}
+
+}  // namespace
+
+extern "C" size_t cdn_quantact_state_bytes(void) { return kStateWords * sizeof(unsigned); }
+
+extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t numel,
+                                    float *x_min, float *x_max, void *state,
+                                    const float *batch_min, const float *batch_max, int bits,
+                                    double momentum, int running, void *stream) {
+  CDN_REQUIRE(x && x_min && x_max && state, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(numel > 0, CDN_ERR_ARG, "empty tensor");
+  CDN_REQUIRE((batch_min == nullptr) == (batch_max == nullptr), CDN_ERR_ARG,
+              "batch_min and batch_max must both be set or both be NULL");
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                  (!out || (reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                  (!codes || (reinterpret_cast<uintptr_t>(codes) & 7) == 0),
+              CDN_ERR_ARG, "tensors must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  unsigned *stt = static_cast<unsigned *>(state);
+  if (running && !batch_min) {
+    minmax_init_kernel<<<1, 1, 0, st>>>(stt);
+    minmax_kernel<<<stream_grid(numel), 256, 0, st>>>(x, (long)numel, stt);
+  }
+  // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
+  // the scalar to fp32 (quant_modules.py:217-219).
+  quantact_update_kernel<<<1, 1, 0, st>>>(x_min, x_max, stt, batch_min, batch_max, bits,
+                                          (float)(momentum - 1.0),
+                                          (float)(1.0 - momentum), running);
+  if (out || codes)
+    fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, codes, (long)numel, stt);
+  return cdn::check_launch("quantact forward");
+}

@@ -1,0 +1,466 @@
+// codenet_stage.hip -- CoDeNet fast paths for gfx950 (MI355X), f32.
+//
+// The co-designed deformable convolution
+// (lib/models/external/modules/dcn_deform_conv.py:285-330) is
+//     s = Hardtanh(-7,8)(conv1x1(x; C->1)+b) ; offset = anchor*(s-1)
+//     d = depthwise 3x3 deformable conv(x, offset) ; y = conv1x1(d; C->Co)
+// so all C channels of a pixel share ONE scalar s: the 3x3 stencil is dilated by s.  The
+// kernels here exploit that: the 18-channel offset tensor and the im2col
+// column buffer of the reference (dcn_deform_conv_cuda.cpp:196-235) never exist.
+//
+//   scale_kernel      HBM-bound C->1 reduction, lanes along pixels (coalesced), C split over
+//                     the 4 waves of a workgroup, reduced through LDS.
+//   dw_kernel         bilinear gather + depthwise 3x3: whole (n,c) planes staged in LDS with a
+//                     one-pixel zero border (per-corner zeroing == border reads), tap
+//                     geometry computed once per pixel and reused over the staged channels.
+//   pointwise_kernel  Y[n] = Wp . D[n] on v_mfma_f32_32x32x2_f32 (exact f32), LDS-tiled.
+#include "cdn_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Tap geometry shared by forward and backward.  For row class r in {0,2} (i = 0 / i = 2):
+//   pos = float(h - 1 + i) + (i-1) * t,  t = s - 1   (bit-identical to the reference's
+//   `h_in + i*dilation_h + offset_h` with offset = anchor*(s-1), _kernel.cu:226)
+// ------------------------------------------------------------------------------------------
+struct Axis {
+  int i0;      // floor(pos)
+  float w0;    // weight of i0   (1 - frac), zeroed when the sample is out of range
+  float w1;    // weight of i0+1 (frac)
+  bool ok;     // pos > -1 && pos < size   (_kernel.cu:228, per axis)
+};
+
+__device__ __forceinline__ Axis make_axis(int base, float off, int size) {
+  Axis a;
+  const float pos = (float)base + off;
+  a.ok = pos > -1.0f && pos < (float)size;
+  const float fl = floorf(pos);
+  a.i0 = (int)fl;
+  const float l = pos - fl;
+  a.w1 = l;
+  a.w0 = 1.0f - l;
+  if (!a.ok) {  // park out-of-range samples on a readable location with zero weight
+    a.i0 = 0;
+    a.w0 = 0.0f;
+    a.w1 = 0.0f;
+  }
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------
+// scale_kernel: s[n,p] = clamp(b + sum_c w[c] * x[n,c,p], lo, hi)
+// grid = (ceil(HW/64), N), block = 256 (4 waves); wave v reduces channels v, v+4, ...
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
+             const float *__restrict__ b, float *__restrict__ s, int C, int HW, float lo,
+             float hi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const int n = blockIdx.y;
+  const bool live = p < HW;
+  const float *xp = x + (long)n * C * HW + (live ? p : 0);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int c = wave;
+  for (; c + 12 < C; c += 16) {
+    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + 4) * HW];
+    const float v2 = xp[(long)(c + 8) * HW], v3 = xp[(long)(c + 12) * HW];
+    acc0 = fmaf(w[c], v0, acc0);
+    acc1 = fmaf(w[c + 4], v1, acc1);
+    acc2 = fmaf(w[c + 8], v2, acc2);
+    acc3 = fmaf(w[c + 12], v3, acc3);
+  }
+  for (; c < C; c += 4) acc0 = fmaf(w[c], xp[(long)c * HW], acc0);
+  __shared__ float red[4][64];
+  red[wave][lane] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (wave == 0 && live) {
+    float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    v += b ? b[0] : 0.0f;
+    v = fminf(fmaxf(v, lo), hi);  // Hardtanh(lo, hi), modules/dcn_deform_conv.py:304-305
+    s[(long)n * HW + p] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dw_kernel: d[n,c,h,w] = sum_{i,j} wd[c,i,j] * bilinear(x[n,c], h+(i-1)+(i-1)t, w+(j-1)+(j-1)t)
+// One workgroup = (n, CC consecutive channels, whole HxW plane).  Planes live in LDS as
+// (H+2)x(W+2) with a zero border, so the four corner reads never need a bounds test.
+// ------------------------------------------------------------------------------------------
+constexpr int kDwThreads = 256;
+
+template <bool LDS>
+__global__ void __launch_bounds__(kDwThreads)
+dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
+          float *__restrict__ d, int C, int H, int W, int CC) {
+  extern __shared__ float smem[];
+  const int HW = H * W;
+  const int Wp = W + 2, Hp = H + 2;
+  const int pstride = Hp * Wp;
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * CC;
+  const int cc = min(CC, C - c0);
+  const float *xg = x + ((long)n * C + c0) * HW;
+  float *wl = smem;                       // [CC][9] depthwise weights
+  float *planes = smem + ((CC * 9 + 3) & ~3);  // [CC][Hp][Wp]
+  for (int q = threadIdx.x; q < cc * 9; q += kDwThreads) wl[q] = wd[(long)c0 * 9 + q];
+  if (LDS) {
+    for (int q = threadIdx.x; q < cc * pstride; q += kDwThreads) planes[q] = 0.0f;
+    __syncthreads();
+    for (int q = threadIdx.x; q < cc * HW; q += kDwThreads) {
+      const int ch = q / HW, r = q - ch * HW;
+      const int yy = r / W, xx = r - yy * W;
+      planes[ch * pstride + (yy + 1) * Wp + xx + 1] = xg[q];
+    }
+  }
+  __syncthreads();
+
+  for (int p = threadIdx.x; p < HW; p += kDwThreads) {
+    const int h = p / W, w = p - h * W;
+    const float t = s[(long)n * HW + p] - 1.0f;
+    // anchor * (s-1): -t for i=0 / j=0, +t for i=2 / j=2, exactly 0 for the middle row/column
+    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    // corner taps: k = 0 (ya,xa), 2 (ya,xb), 6 (yb,xa), 8 (yb,xb)
+    const int b00 = (ya.i0 + 1) * Wp + xa.i0 + 1, b02 = (ya.i0 + 1) * Wp + xb.i0 + 1;
+    const int b20 = (yb.i0 + 1) * Wp + xa.i0 + 1, b22 = (yb.i0 + 1) * Wp + xb.i0 + 1;
+    // edge taps: k = 1 (ya, w), 7 (yb, w), 3 (h, xa), 5 (h, xb); centre k = 4 (h, w)
+    const int b01 = (ya.i0 + 1) * Wp + w + 1, b21 = (yb.i0 + 1) * Wp + w + 1;
+    const int b10 = (h + 1) * Wp + xa.i0 + 1, b12 = (h + 1) * Wp + xb.i0 + 1;
+    const int b11 = (h + 1) * Wp + w + 1;
+    for (int ch = 0; ch < cc; ++ch) {
+      const float *wk = wl + ch * 9;
+      float acc;
+      if (LDS) {
+        const float *pl = planes + ch * pstride;
+#define CDN_CORNER(B, Y, X)                                                        \
+  (((Y.w0 * X.w0) * pl[B] + (Y.w0 * X.w1) * pl[B + 1]) + (Y.w1 * X.w0) * pl[B + Wp] + \
+   (Y.w1 * X.w1) * pl[B + Wp + 1])
+        const float v0 = CDN_CORNER(b00, ya, xa);
+        const float v2 = CDN_CORNER(b02, ya, xb);
+        const float v6 = CDN_CORNER(b20, yb, xa);
+        const float v8 = CDN_CORNER(b22, yb, xb);
+#undef CDN_CORNER
+        const float v1 = ya.w0 * pl[b01] + ya.w1 * pl[b01 + Wp];
+        const float v7 = yb.w0 * pl[b21] + yb.w1 * pl[b21 + Wp];
+        const float v3 = xa.w0 * pl[b10] + xa.w1 * pl[b10 + 1];
+        const float v5 = xb.w0 * pl[b12] + xb.w1 * pl[b12 + 1];
+        const float v4 = pl[b11];
+        acc = wk[0] * v0;
+        acc = fmaf(wk[1], v1, acc);
+        acc = fmaf(wk[2], v2, acc);
+        acc = fmaf(wk[3], v3, acc);
+        acc = fmaf(wk[4], v4, acc);
+        acc = fmaf(wk[5], v5, acc);
+        acc = fmaf(wk[6], v6, acc);
+        acc = fmaf(wk[7], v7, acc);
+        acc = fmaf(wk[8], v8, acc);
+      } else {
+        // planes too large for LDS: gather straight from global / L2 with bounds tests
+        const float *pl = xg + (long)ch * HW;
+        auto rd = [&](int yy, int xx) -> float {
+          return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? pl[yy * W + xx] : 0.0f;
+        };
+        auto tap = [&](const Axis &Y, const Axis &X) -> float {
+          return ((Y.w0 * X.w0) * rd(Y.i0, X.i0) + (Y.w0 * X.w1) * rd(Y.i0, X.i0 + 1)) +
+                 (Y.w1 * X.w0) * rd(Y.i0 + 1, X.i0) + (Y.w1 * X.w1) * rd(Y.i0 + 1, X.i0 + 1);
+        };
+        Axis ym, xm;
+        ym.i0 = h; ym.w0 = 1.0f; ym.w1 = 0.0f; ym.ok = true;
+        xm.i0 = w; xm.w0 = 1.0f; xm.w1 = 0.0f; xm.ok = true;
+        acc = wk[0] * tap(ya, xa);
+        acc = fmaf(wk[1], tap(ya, xm), acc);
+        acc = fmaf(wk[2], tap(ya, xb), acc);
+        acc = fmaf(wk[3], tap(ym, xa), acc);
+        acc = fmaf(wk[4], pl[p], acc);
+        acc = fmaf(wk[5], tap(ym, xb), acc);
+        acc = fmaf(wk[6], tap(yb, xa), acc);
+        acc = fmaf(wk[7], tap(yb, xm), acc);
+        acc = fmaf(wk[8], tap(yb, xb), acc);
+      }
+      d[((long)n * C + c0 + ch) * HW + p] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dw_bwd_kernel: backward of dw_kernel for one (n, CC channels, plane) workgroup.
+//   grad_x : the <=25 bilinear corner contributions of every (pixel, channel) are summed
+//            with LDS float atomics into a zero-bordered LDS image of the plane (the border
+//            absorbs out-of-image corners), then stored once -- no global atomics, no
+//            5x5 window scan (reference: _kernel.cu:278-334, global atomicAdd :329).
+//   grad_s : dL/ds = sum_c sum_k g*wd[c,k] * ((i-1)*dS/dy + (j-1)*dS/dx), i.e. the reference's
+//            18-channel grad_offset (_kernel.cu:372-435) contracted with anchor_offset
+//            (autograd of modules/dcn_deform_conv.py:325); one global atomic per
+//            (pixel, channel-chunk).
+//   grad_w : sum_{n,p} g * S_k  (cpp:456-462), wave-reduced, LDS-accumulated, then one global
+//            atomic per (workgroup, c, k).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(kDwThreads)
+dw_bwd_kernel(const float *__restrict__ x, const float *__restrict__ s,
+              const float *__restrict__ wd, const float *__restrict__ gd,
+              float *__restrict__ gx, float *__restrict__ gs, float *__restrict__ gw, int C, int H,
+              int W, int CC) {
+  extern __shared__ float smem[];
+  const int HW = H * W;
+  const int Wp = W + 2, Hp = H + 2;
+  const int pstride = Hp * Wp;
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * CC;
+  const int cc = min(CC, C - c0);
+  const int lane = threadIdx.x & 63;
+  const float *xg = x + ((long)n * C + c0) * HW;
+  const float *gdg = gd + ((long)n * C + c0) * HW;
+  const int wsz = (CC * 9 + 3) & ~3;
+  float *wl = smem;                 // [CC][9] weights
+  float *gwl = smem + wsz;          // [CC][9] grad_w accumulators
+  float *xpl = smem + 2 * wsz;      // [CC][Hp][Wp] x, zero border
+  float *gpl = xpl + CC * pstride;  // [CC][Hp][Wp] grad_x accumulators
+  for (int q = threadIdx.x; q < cc * 9; q += kDwThreads) {
+    wl[q] = wd[(long)c0 * 9 + q];
+    gwl[q] = 0.0f;
+  }
+  for (int q = threadIdx.x; q < cc * pstride; q += kDwThreads) {
+    xpl[q] = 0.0f;
+    gpl[q] = 0.0f;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < cc * HW; q += kDwThreads) {
+    const int ch = q / HW, r = q - ch * HW;
+    const int yy = r / W, xx = r - yy * W;
+    xpl[ch * pstride + (yy + 1) * Wp + xx + 1] = xg[q];
+  }
+  __syncthreads();
+
+  const int iters = (HW + kDwThreads - 1) / kDwThreads;
+  for (int it = 0; it < iters; ++it) {
+    const int p = it * kDwThreads + threadIdx.x;
+    const bool live = p < HW;
+    const int pp = live ? p : 0;
+    const int h = pp / W, w = pp - h * W;
+    const float t = s[(long)n * HW + pp] - 1.0f;
+    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    Axis ym, xm;
+    ym.i0 = h; ym.w0 = 1.0f; ym.w1 = 0.0f; ym.ok = true;
+    xm.i0 = w; xm.w0 = 1.0f; xm.w1 = 0.0f; xm.ok = true;
+    float gs_acc = 0.0f;
+    for (int ch = 0; ch < cc; ++ch) {
+      const float *pl = xpl + ch * pstride;
+      float *gl = gpl + ch * pstride;
+      const float *wk = wl + ch * 9;
+      const float g = live ? gdg[(long)ch * HW + pp] : 0.0f;
+      // tap(Y, X, ay, ax, k): value S, scatter g*wk*weights, accumulate ds and grad_w
+      auto tap = [&](const Axis &Y, const Axis &X, float ay, float ax, int k) {
+        const int b = (Y.i0 + 1) * Wp + X.i0 + 1;
+        const float v00 = pl[b], v01 = pl[b + 1], v10 = pl[b + Wp], v11 = pl[b + Wp + 1];
+        const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1, w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;
+        const float S = (w00 * v00 + w01 * v01) + w10 * v10 + w11 * v11;
+        const float gk = g * wk[k];
+        if (gx != nullptr && gk != 0.0f) {
+          atomicAdd(&gl[b], w00 * gk);
+          atomicAdd(&gl[b + 1], w01 * gk);
+          atomicAdd(&gl[b + Wp], w10 * gk);
+          atomicAdd(&gl[b + Wp + 1], w11 * gk);
+        }
+        const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
+        const float dSdy = X.w0 * (v10 - v00) + X.w1 * (v11 - v01);
+        const float dSdx = Y.w0 * (v01 - v00) + Y.w1 * (v11 - v10);
+        gs_acc += okf * gk * (ay * dSdy + ax * dSdx);
+        return S;
+      };
+      float S[9];
+      S[0] = tap(ya, xa, -1.f, -1.f, 0);
+      S[1] = tap(ya, xm, -1.f, 0.f, 1);
+      S[2] = tap(ya, xb, -1.f, 1.f, 2);
+      S[3] = tap(ym, xa, 0.f, -1.f, 3);
+      S[4] = tap(ym, xm, 0.f, 0.f, 4);
+      S[5] = tap(ym, xb, 0.f, 1.f, 5);
+      S[6] = tap(yb, xa, 1.f, -1.f, 6);
+      S[7] = tap(yb, xm, 1.f, 0.f, 7);
+      S[8] = tap(yb, xb, 1.f, 1.f, 8);
+      if (gw != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float r = wave_sum(g * S[k]);
+          if (lane == 0) atomicAdd(&gwl[ch * 9 + k], r);
+        }
+      }
+    }
+    if (gs != nullptr && live) atomicAdd(&gs[(long)n * HW + p], gs_acc);
+  }
+  __syncthreads();
+  if (gx != nullptr) {
+    float *gxg = gx + ((long)n * C + c0) * HW;
+    for (int q = threadIdx.x; q < cc * HW; q += kDwThreads) {
+      const int ch = q / HW, r = q - ch * HW;
+      const int yy = r / W, xx = r - yy * W;
+      gxg[q] = gpl[ch * pstride + (yy + 1) * Wp + xx + 1];
+    }
+  }
+  if (gw != nullptr)
+    for (int q = threadIdx.x; q < cc * 9; q += kDwThreads) atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+}
+
+// ------------------------------------------------------------------------------------------
+// pointwise_kernel: Y[n] (Co x HW) = Wp (Co x C) . D[n] (C x HW) on v_mfma_f32_32x32x2_f32.
+// Workgroup tile 64 (co) x 64 (pixels), 4 waves, each owning one 32x32 accumulator tile;
+// K tiles of 16 staged through LDS as As[k][m] / Bs[k][n] so both operand reads are
+// conflict-free (lane l reads [k = l>>5][l & 31]).
+// Operand maps (cdna_hip_programming.md section 3): A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+// ------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kPwBM = 64, kPwBN = 64, kPwBK = 16;
+
+__global__ void __launch_bounds__(256)
+pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
+                 const float *__restrict__ bias, const float *__restrict__ ep_scale,
+                 const float *__restrict__ ep_shift, float *__restrict__ Y, int C, int Co, int HW,
+                 int relu) {
+  __shared__ float As[kPwBK][kPwBM + 4];
+  __shared__ float Bs[kPwBK][kPwBN + 4];
+  const int n = blockIdx.z;
+  const int m0 = blockIdx.y * kPwBM, p0 = blockIdx.x * kPwBN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const float *Dn = D + (long)n * C * HW;
+  f32x16 acc = {0};
+  // staging assignments: A tile 64(m) x 16(k): thread -> (m = tid>>2, k4 = (tid&3)*4)
+  //                      B tile 16(k) x 64(n): thread -> (k = tid>>4, n4 = (tid&15)*4)
+  const int am = tid >> 2, ak = (tid & 3) * 4;
+  const int bk = tid >> 4, bn = (tid & 15) * 4;
+  const bool hw4 = (HW & 3) == 0;
+  for (int k0 = 0; k0 < C; k0 += kPwBK) {
+    float a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + am, k = k0 + ak + q;
+      a[q] = (m < Co && k < C) ? Wp[(long)m * C + k] : 0.0f;
+    }
+    {
+      const int k = k0 + bk, p = p0 + bn;
+      if (k < C && hw4 && p + 3 < HW) {
+        const float4 v = *reinterpret_cast<const float4 *>(Dn + (long)k * HW + p);
+        b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = (k < C && p + q < HW) ? Dn[(long)k * HW + p + q] : 0.0f;
+      }
+    }
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int q = 0; q < 4; ++q) As[ak + q][am] = a[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Bs[bk][bn + q] = b[q];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kPwBK; kk += 2) {
+      const float av = As[kk + (lane >> 5)][wm + (lane & 31)];
+      const float bv = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  const int col = p0 + wn + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < Co && col < HW) {
+      float v = acc[r];
+      if (bias) v += bias[row];
+      if (ep_scale) v = fmaf(v, ep_scale[row], ep_shift[row]);
+      if (relu) v = fmaxf(v, 0.0f);
+      Y[((long)n * Co + row) * HW + col] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cdn_codenet_scale_forward(const float *x, const float *w_scale,
+                                         const float *b_scale, float *s, int64_t N, int64_t C,
+                                         int64_t H, int64_t W, float lo, float hi, void *stream) {
+  CDN_REQUIRE(x && w_scale && s, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N <= 65535 && C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  const int HW = (int)(H * W);
+  dim3 grid((unsigned)cdn::ceil_div(HW, 64), (unsigned)N);
+  scale_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo,
+                                                         hi);
+  return cdn::check_launch("codenet scale forward");
+}
+
+extern "C" int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, float *d,
+                                      int64_t N, int64_t C, int64_t H, int64_t W, void *stream) {
+  CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  const int pstride = (int)((H + 2) * (W + 2));
+  const int budget = 64 * 1024 / 4;  // floats of LDS per workgroup (2 workgroups per CU)
+  int CC = (budget - 64) / (pstride + 9);
+  hipStream_t st = cdn::as_stream(stream);
+  if (CC >= 1) {
+    if (CC > 32) CC = 32;
+    if (CC > C) CC = (int)C;
+    const size_t lds = (size_t)(((CC * 9 + 3) & ~3) + CC * pstride) * sizeof(float);
+    dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
+    dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC);
+  } else {
+    CC = 4;
+    const size_t lds = (size_t)((CC * 9 + 3) & ~3) * sizeof(float);
+    dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
+    dw_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC);
+  }
+  return cdn::check_launch("codenet dw forward");
+}
+
+extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, const float *bias,
+                                             const float *ep_scale, const float *ep_shift,
+                                             float *y, int64_t N, int64_t C, int64_t Co,
+                                             int64_t HW, int relu, void *stream) {
+  CDN_REQUIRE(d && w_pw && y, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
+              "ep_scale and ep_shift must both be set or both be NULL");
+  CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && HW > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N <= 65535 && C * HW < (1ll << 31) && Co * HW < (1ll << 31) && Co * C < (1ll << 31),
+              CDN_ERR_UNSUPPORTED, "shape too large");
+  dim3 grid((unsigned)cdn::ceil_div(HW, kPwBN), (unsigned)cdn::ceil_div(Co, kPwBM), (unsigned)N);
+  pointwise_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(d, w_pw, bias, ep_scale, ep_shift, y,
+                                                             (int)C, (int)Co, (int)HW, relu);
+  return cdn::check_launch("codenet pointwise forward");
+}
+
+extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
+                                       const float *grad_d, float *grad_x, float *grad_s,
+                                       float *grad_w, int64_t N, int64_t C, int64_t H, int64_t W,
+                                       void *stream) {
+  CDN_REQUIRE(x && s && w_dw && grad_d, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  const int pstride = (int)((H + 2) * (W + 2));
+  const int budget = 150 * 1024 / 4;  // floats of LDS per workgroup
+  int CC = (budget - 64) / (2 * pstride + 18);
+  CDN_REQUIRE(CC >= 1, CDN_ERR_UNSUPPORTED,
+              "plane %lldx%lld too large for the LDS-resident backward (use the generic path)",
+              (long long)H, (long long)W);
+  if (CC > 16) CC = 16;
+  if (CC > C) CC = (int)C;
+  hipStream_t st = cdn::as_stream(stream);
+  if (grad_s) {
+    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)(N * H * W), st);
+    if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
+  }
+  const size_t lds = (size_t)(2 * ((CC * 9 + 3) & ~3) + 2 * CC * pstride) * sizeof(float);
+  dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
+  (void)hipFuncSetAttribute((const void *)dw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)lds);
+  dw_bwd_kernel<<<grid, kDwThreads, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C,
+                                               (int)H, (int)W, CC);
+  return cdn::check_launch("codenet dw backward");
+}

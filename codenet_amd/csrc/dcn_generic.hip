@@ -1,0 +1,405 @@
+// dcn_generic.hip -- generic (modulated) deformable convolution for gfx950, forward and
+// backward, any kernel/stride/pad/dilation/groups/deformable_groups, f32 and f64.
+//
+// API-parity path behind deform_conv / modulated_deform_conv
+// (lib/models/external/functions/dcn_deform_conv.py:185-186).  Unlike the reference
+// (im2col column buffer + `group` sequential cuBLAS calls, dcn_deform_conv_cuda.cpp:196-235)
+// nothing is materialised: every kernel samples and contracts directly.
+// The CoDeNet stages themselves run on the specialised kernels in codenet_stage.hip.
+#include "cdn_common.h"
+
+namespace {
+
+using cdn::Geom;
+
+// Bilinear sample with per-corner zeroing; same arithmetic as the reference helper
+// (dcn_deform_conv_cuda_kernel.cu:83-114), written for this kernel set.
+template <typename T>
+__device__ __forceinline__ T bilinear(const T *__restrict__ p, int H, int W, T h, T w) {
+  const int hl = (int)floor(h), wl = (int)floor(w);
+  const int hh = hl + 1, wh = wl + 1;
+  const T lh = h - (T)hl, lw = w - (T)wl;
+  const T uh = (T)1 - lh, uw = (T)1 - lw;
+  const bool top = hl >= 0, bot = hh <= H - 1, lef = wl >= 0, rig = wh <= W - 1;
+  const T v1 = (top && lef) ? p[hl * W + wl] : (T)0;
+  const T v2 = (top && rig) ? p[hl * W + wh] : (T)0;
+  const T v3 = (bot && lef) ? p[hh * W + wl] : (T)0;
+  const T v4 = (bot && rig) ? p[hh * W + wh] : (T)0;
+  return ((uh * uw) * v1 + (uh * lw) * v2) + (lh * uw) * v3 + (lh * lw) * v4;
+}
+
+template <typename T>
+__device__ __forceinline__ bool inside(T h, T w, int H, int W) {
+  return h > (T)-1 && w > (T)-1 && h < (T)H && w < (T)W;  // _kernel.cu:228
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward: one thread per output element (n, co, ho, wo); wo fastest -> coalesced offset /
+// mask reads and output stores.  out = sum_{cl,k} W[co,cl,k] * mask * sample.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool MOD>
+__global__ void __launch_bounds__(256)
+fwd_kernel(const T *__restrict__ x, const T *__restrict__ offset, const T *__restrict__ mask,
+           const T *__restrict__ weight, const T *__restrict__ bias, T *__restrict__ out, Geom g) {
+  const int K = g.kH * g.kW, Cg = g.C / g.G, Cog = g.Co / g.G, cpdg = g.C / g.DG;
+  const int P = g.Ho * g.Wo;
+  const long total = (long)g.N * g.Co * P;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % P);
+    const int co = (int)((idx / P) % g.Co);
+    const int n = (int)(idx / ((long)P * g.Co));
+    const int ho = p / g.Wo, wo = p % g.Wo;
+    const int grp = co / Cog;
+    const int h_in = ho * g.sH - g.pH, w_in = wo * g.sW - g.pW;
+    T acc = 0;
+    for (int cl = 0; cl < Cg; ++cl) {
+      const int c = grp * Cg + cl;
+      const int dgi = c / cpdg;
+      const T *xp = x + ((long)n * g.C + c) * g.H * g.W;
+      const T *op = offset + ((long)n * g.DG + dgi) * 2 * K * P + p;
+      const T *mp = MOD ? mask + ((long)n * g.DG + dgi) * K * P + p : nullptr;
+      const T *wp = weight + ((long)co * Cg + cl) * K;
+      for (int i = 0; i < g.kH; ++i)
+        for (int j = 0; j < g.kW; ++j) {
+          const int k = i * g.kW + j;
+          const T hi = (T)(h_in + i * g.dH) + op[(long)(2 * k) * P];
+          const T wi = (T)(w_in + j * g.dW) + op[(long)(2 * k + 1) * P];
+          T v = 0;
+          if (inside(hi, wi, g.H, g.W)) v = bilinear(xp, g.H, g.W, hi, wi);
+          if (MOD) v *= mp[(long)k * P];
+          acc += wp[k] * v;
+        }
+    }
+    if (MOD && bias) acc += bias[co];
+    out[idx] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward wrt input: one thread per (n, c, k, ho, wo).  Column gradient
+// gc = sum_m W[g*Cog+m, cl, k] * gO[n, g*Cog+m, p]  (cpp:329-332), then scattered to the <= 4
+// bilinear corners (same weights as get_gradient_weight, _kernel.cu:116-142) with HW float
+// atomics -- the reference does the same (_kernel.cu:329).
+// ---------------------------------------------------------------------------------------
+template <typename T, bool MOD>
+__global__ void __launch_bounds__(256)
+bwd_input_kernel(const T *__restrict__ offset, const T *__restrict__ mask,
+                 const T *__restrict__ weight, const T *__restrict__ gout, T *__restrict__ gx,
+                 Geom g) {
+  const int K = g.kH * g.kW, Cg = g.C / g.G, Cog = g.Co / g.G, cpdg = g.C / g.DG;
+  const int P = g.Ho * g.Wo;
+  const long total = (long)g.N * g.C * K * P;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % P);
+    const int k = (int)((idx / P) % K);
+    const int c = (int)((idx / ((long)P * K)) % g.C);
+    const int n = (int)(idx / ((long)P * K * g.C));
+    const int ho = p / g.Wo, wo = p % g.Wo, i = k / g.kW, j = k % g.kW;
+    const int grp = c / Cg, cl = c % Cg, dgi = c / cpdg;
+    const T *op = offset + ((long)n * g.DG + dgi) * 2 * K * P + p;
+    const T hi = (T)(ho * g.sH - g.pH + i * g.dH) + op[(long)(2 * k) * P];
+    const T wi = (T)(wo * g.sW - g.pW + j * g.dW) + op[(long)(2 * k + 1) * P];
+    if (!inside(hi, wi, g.H, g.W)) continue;
+    T gc = 0;
+    for (int m = 0; m < Cog; ++m)
+      gc += weight[((long)(grp * Cog + m) * Cg + cl) * K + k] *
+            gout[((long)n * g.Co + grp * Cog + m) * P + p];
+    if (MOD) gc *= mask[((long)n * g.DG + dgi) * K * P + (long)k * P + p];
+    const int hl = (int)floor(hi), wl = (int)floor(wi);
+    const int hh = hl + 1, wh = wl + 1;
+    const T lh = hi - (T)hl, lw = wi - (T)wl;
+    const T uh = (T)1 - lh, uw = (T)1 - lw;
+    T *gp = gx + ((long)n * g.C + c) * g.H * g.W;
+    if (hl >= 0 && wl >= 0) atomicAdd(gp + hl * g.W + wl, uh * uw * gc);
+    if (hl >= 0 && wh <= g.W - 1) atomicAdd(gp + hl * g.W + wh, uh * lw * gc);
+    if (hh <= g.H - 1 && wl >= 0) atomicAdd(gp + hh * g.W + wl, lh * uw * gc);
+    if (hh <= g.H - 1 && wh <= g.W - 1) atomicAdd(gp + hh * g.W + wh, lh * lw * gc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward wrt offset (and mask): one thread per (n, dg, k, ho, wo); loops over the channels
+// of the deformable group (_kernel.cu:405-431, :731-764) and writes dy, dx (and dmask).
+// ---------------------------------------------------------------------------------------
+template <typename T, bool MOD>
+__global__ void __launch_bounds__(256)
+bwd_offset_kernel(const T *__restrict__ x, const T *__restrict__ offset,
+                  const T *__restrict__ mask, const T *__restrict__ weight,
+                  const T *__restrict__ gout, T *__restrict__ goffset, T *__restrict__ gmask,
+                  Geom g) {
+  const int K = g.kH * g.kW, Cg = g.C / g.G, Cog = g.Co / g.G, cpdg = g.C / g.DG;
+  const int P = g.Ho * g.Wo;
+  const long total = (long)g.N * g.DG * K * P;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % P);
+    const int k = (int)((idx / P) % K);
+    const int dgi = (int)((idx / ((long)P * K)) % g.DG);
+    const int n = (int)(idx / ((long)P * K * g.DG));
+    const int ho = p / g.Wo, wo = p % g.Wo, i = k / g.kW, j = k % g.kW;
+    const long obase = ((long)n * g.DG + dgi) * 2 * K * P;
+    const T hi = (T)(ho * g.sH - g.pH + i * g.dH) + offset[obase + (long)(2 * k) * P + p];
+    const T wi = (T)(wo * g.sW - g.pW + j * g.dW) + offset[obase + (long)(2 * k + 1) * P + p];
+    T vh = 0, vw = 0, mv = 0;
+    if (inside(hi, wi, g.H, g.W)) {
+      const int hl = (int)floor(hi), wl = (int)floor(wi);
+      const int hh = hl + 1, wh = wl + 1;
+      const T lh = hi - (T)hl, lw = wi - (T)wl;
+      const T uh = (T)1 - lh, uw = (T)1 - lw;
+      const bool top = hl >= 0, bot = hh <= g.H - 1, lef = wl >= 0, rig = wh <= g.W - 1;
+      const T m = MOD ? mask[((long)n * g.DG + dgi) * K * P + (long)k * P + p] : (T)1;
+      for (int cc = 0; cc < cpdg; ++cc) {
+        const int c = dgi * cpdg + cc;
+        const int grp = c / Cg, cl = c % Cg;
+        T gc = 0;
+        for (int mm = 0; mm < Cog; ++mm)
+          gc += weight[((long)(grp * Cog + mm) * Cg + cl) * K + k] *
+                gout[((long)n * g.Co + grp * Cog + mm) * P + p];
+        const T *xp = x + ((long)n * g.C + c) * g.H * g.W;
+        const T v1 = (top && lef) ? xp[hl * g.W + wl] : (T)0;
+        const T v2 = (top && rig) ? xp[hl * g.W + wh] : (T)0;
+        const T v3 = (bot && lef) ? xp[hh * g.W + wl] : (T)0;
+        const T v4 = (bot && rig) ? xp[hh * g.W + wh] : (T)0;
+        // d(sample)/dh and d(sample)/dw  (get_coordinate_weight, _kernel.cu:144-187)
+        const T dh = uw * (v3 - v1) + lw * (v4 - v2);
+        const T dw = uh * (v2 - v1) + lh * (v4 - v3);
+        vh += dh * gc * m;
+        vw += dw * gc * m;
+        if (MOD) mv += gc * ((uh * uw) * v1 + (uh * lw) * v2 + (lh * uw) * v3 + (lh * lw) * v4);
+      }
+    }
+    goffset[obase + (long)(2 * k) * P + p] = vh;
+    goffset[obase + (long)(2 * k + 1) * P + p] = vw;
+    if (MOD) gmask[((long)n * g.DG + dgi) * K * P + (long)k * P + p] = mv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward wrt weight: one 256-thread workgroup per (co, cl, k); block-reduces
+// sum_{n,p} gO[n,co,p] * mask * sample over N*Ho*Wo, then gradW += scale * sum
+// (cpp:456-462, accumulate semantics).  With k == K (extra slot) the block reduces grad_bias.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool MOD>
+__global__ void __launch_bounds__(256)
+bwd_weight_kernel(const T *__restrict__ x, const T *__restrict__ offset,
+                  const T *__restrict__ mask, const T *__restrict__ gout, T *__restrict__ gweight,
+                  T scale, Geom g) {
+  const int K = g.kH * g.kW, Cg = g.C / g.G, Cog = g.Co / g.G, cpdg = g.C / g.DG;
+  const int P = g.Ho * g.Wo;
+  const int k = blockIdx.x % K;
+  const int cl = (blockIdx.x / K) % Cg;
+  const int co = blockIdx.x / (K * Cg);
+  const int c = (co / Cog) * Cg + cl;
+  const int dgi = c / cpdg, i = k / g.kW, j = k % g.kW;
+  T acc = 0;
+  for (long q = threadIdx.x; q < (long)g.N * P; q += blockDim.x) {
+    const int n = (int)(q / P), p = (int)(q % P);
+    const int ho = p / g.Wo, wo = p % g.Wo;
+    const long obase = ((long)n * g.DG + dgi) * 2 * K * P;
+    const T hi = (T)(ho * g.sH - g.pH + i * g.dH) + offset[obase + (long)(2 * k) * P + p];
+    const T wi = (T)(wo * g.sW - g.pW + j * g.dW) + offset[obase + (long)(2 * k + 1) * P + p];
+    if (!inside(hi, wi, g.H, g.W)) continue;
+    T v = bilinear(x + ((long)n * g.C + c) * g.H * g.W, g.H, g.W, hi, wi);
+    if (MOD) v *= mask[((long)n * g.DG + dgi) * K * P + (long)k * P + p];
+    acc += v * gout[((long)n * g.Co + co) * P + p];
+  }
+  __shared__ T red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gweight[blockIdx.x] += scale * red[0];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bwd_bias_kernel(const T *__restrict__ gout, T *__restrict__ gbias, int N, int Co, int P) {
+  const int co = blockIdx.x;
+  T acc = 0;
+  for (long q = threadIdx.x; q < (long)N * P; q += blockDim.x)
+    acc += gout[((long)(q / P) * Co + co) * P + (q % P)];
+  __shared__ T red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gbias[co] += red[0];
+}
+
+inline int grid_for(long total) {
+  long b = cdn::ceil_div(total, 256);
+  long cap = (long)cdn::kCUs * 16;  // grid-stride beyond 16 workgroups per CU
+  return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
+template <typename T>
+int run_forward(const void *x, const void *w, const void *b, const void *off, const void *m,
+                void *out, const Geom &g, hipStream_t st) {
+  const long total = (long)g.N * g.Co * g.Ho * g.Wo;
+  if (m)
+    fwd_kernel<T, true><<<grid_for(total), 256, 0, st>>>((const T *)x, (const T *)off,
+                                                         (const T *)m, (const T *)w,
+                                                         (const T *)b, (T *)out, g);
+  else
+    fwd_kernel<T, false><<<grid_for(total), 256, 0, st>>>((const T *)x, (const T *)off, nullptr,
+                                                          (const T *)w, nullptr, (T *)out, g);
+  return cdn::check_launch("deform_conv forward");
+}
+
+template <typename T>
+int run_backward_input(const void *x, const void *off, const void *m, const void *w,
+                       const void *go, void *gx, void *goff, void *gm, const Geom &g,
+                       hipStream_t st) {
+  const int K = g.kH * g.kW;
+  const long P = (long)g.Ho * g.Wo;
+  const long t1 = (long)g.N * g.DG * K * P;
+  const long t2 = (long)g.N * g.C * K * P;
+  if (m) {
+    bwd_offset_kernel<T, true><<<grid_for(t1), 256, 0, st>>>(
+        (const T *)x, (const T *)off, (const T *)m, (const T *)w, (const T *)go, (T *)goff,
+        (T *)gm, g);
+    bwd_input_kernel<T, true><<<grid_for(t2), 256, 0, st>>>(
+        (const T *)off, (const T *)m, (const T *)w, (const T *)go, (T *)gx, g);
+  } else {
+    bwd_offset_kernel<T, false><<<grid_for(t1), 256, 0, st>>>(
+        (const T *)x, (const T *)off, nullptr, (const T *)w, (const T *)go, (T *)goff, nullptr, g);
+    bwd_input_kernel<T, false><<<grid_for(t2), 256, 0, st>>>(
+        (const T *)off, nullptr, (const T *)w, (const T *)go, (T *)gx, g);
+  }
+  return cdn::check_launch("deform_conv backward_input");
+}
+
+template <typename T>
+int run_backward_weight(const void *x, const void *off, const void *m, const void *go, void *gw,
+                        void *gb, double scale, const Geom &g, hipStream_t st) {
+  const int K = g.kH * g.kW, Cg = g.C / g.G;
+  const int blocks = g.Co * Cg * K;
+  if (m)
+    bwd_weight_kernel<T, true><<<blocks, 256, 0, st>>>((const T *)x, (const T *)off,
+                                                       (const T *)m, (const T *)go, (T *)gw,
+                                                       (T)scale, g);
+  else
+    bwd_weight_kernel<T, false><<<blocks, 256, 0, st>>>((const T *)x, (const T *)off, nullptr,
+                                                        (const T *)go, (T *)gw, (T)scale, g);
+  if (gb) bwd_bias_kernel<T><<<g.Co, 256, 0, st>>>((const T *)go, (T *)gb, g.N, g.Co, g.Ho * g.Wo);
+  return cdn::check_launch("deform_conv backward_parameters");
+}
+
+}  // namespace
+
+#define CDN_DISPATCH(dtype, CALL_F32, CALL_F64)                                   \
+  switch (dtype) {                                                                \
+    case CDN_F32: return CALL_F32;                                                \
+    case CDN_F64: return CALL_F64;                                                \
+    default: return cdn::fail(CDN_ERR_DTYPE, "unsupported dtype enum %d", dtype); \
+  }
+
+extern "C" int cdn_deform_conv_forward(const void *input, const void *weight, const void *offset,
+                                       void *output, int dtype, int64_t N, int64_t C, int64_t H,
+                                       int64_t W, int64_t Co, int kW, int kH, int dW, int dH,
+                                       int padW, int padH, int dilationW, int dilationH,
+                                       int group, int deformable_group, void *stream) {
+  CDN_REQUIRE(input && weight && offset && output, CDN_ERR_ARG, "null tensor pointer");
+  Geom g;
+  int rc = cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
+                          group, deformable_group);
+  if (rc) return rc;
+  hipStream_t st = cdn::as_stream(stream);
+  CDN_DISPATCH(dtype, run_forward<float>(input, weight, nullptr, offset, nullptr, output, g, st),
+               run_forward<double>(input, weight, nullptr, offset, nullptr, output, g, st));
+}
+
+extern "C" int cdn_deform_conv_backward_input(const void *input, const void *offset,
+                                              const void *gradOutput, void *gradInput,
+                                              void *gradOffset, const void *weight, int dtype,
+                                              int64_t N, int64_t C, int64_t H, int64_t W,
+                                              int64_t Co, int kW, int kH, int dW, int dH,
+                                              int padW, int padH, int dilationW, int dilationH,
+                                              int group, int deformable_group, void *stream) {
+  CDN_REQUIRE(input && offset && gradOutput && gradInput && gradOffset && weight, CDN_ERR_ARG,
+              "null tensor pointer");
+  Geom g;
+  int rc = cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
+                          group, deformable_group);
+  if (rc) return rc;
+  hipStream_t st = cdn::as_stream(stream);
+  CDN_DISPATCH(dtype,
+               run_backward_input<float>(input, offset, nullptr, weight, gradOutput, gradInput,
+                                         gradOffset, nullptr, g, st),
+               run_backward_input<double>(input, offset, nullptr, weight, gradOutput, gradInput,
+                                          gradOffset, nullptr, g, st));
+}
+
+extern "C" int cdn_deform_conv_backward_parameters(
+    const void *input, const void *offset, const void *gradOutput, void *gradWeight, int dtype,
+    int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kW, int kH, int dW, int dH,
+    int padW, int padH, int dilationW, int dilationH, int group, int deformable_group,
+    float scale, void *stream) {
+  CDN_REQUIRE(input && offset && gradOutput && gradWeight, CDN_ERR_ARG, "null tensor pointer");
+  Geom g;
+  int rc = cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
+                          group, deformable_group);
+  if (rc) return rc;
+  hipStream_t st = cdn::as_stream(stream);
+  CDN_DISPATCH(dtype,
+               run_backward_weight<float>(input, offset, nullptr, gradOutput, gradWeight, nullptr,
+                                          scale, g, st),
+               run_backward_weight<double>(input, offset, nullptr, gradOutput, gradWeight,
+                                           nullptr, scale, g, st));
+}
+
+extern "C" int cdn_modulated_deform_conv_forward(
+    const void *input, const void *weight, const void *bias, const void *offset, const void *mask,
+    void *output, int dtype, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kernel_h,
+    int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+    int dilation_w, int group, int deformable_group, int with_bias, void *stream) {
+  CDN_REQUIRE(input && weight && offset && mask && output, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(!with_bias || bias, CDN_ERR_ARG, "with_bias set but bias is NULL");
+  Geom g;
+  int rc = cdn::make_geom(&g, N, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+                          pad_w, dilation_h, dilation_w, group, deformable_group);
+  if (rc) return rc;
+  hipStream_t st = cdn::as_stream(stream);
+  const void *b = with_bias ? bias : nullptr;
+  CDN_DISPATCH(dtype, run_forward<float>(input, weight, b, offset, mask, output, g, st),
+               run_forward<double>(input, weight, b, offset, mask, output, g, st));
+}
+
+extern "C" int cdn_modulated_deform_conv_backward(
+    const void *input, const void *weight, const void *bias, const void *offset, const void *mask,
+    void *grad_input, void *grad_weight, void *grad_bias, void *grad_offset, void *grad_mask,
+    const void *grad_output, int dtype, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co,
+    int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+    int dilation_w, int group, int deformable_group, int with_bias, void *stream) {
+  (void)bias;
+  CDN_REQUIRE(input && weight && offset && mask && grad_input && grad_weight && grad_offset &&
+                  grad_mask && grad_output,
+              CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(!with_bias || grad_bias, CDN_ERR_ARG, "with_bias set but grad_bias is NULL");
+  Geom g;
+  int rc = cdn::make_geom(&g, N, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+                          pad_w, dilation_h, dilation_w, group, deformable_group);
+  if (rc) return rc;
+  hipStream_t st = cdn::as_stream(stream);
+  void *gb = with_bias ? grad_bias : nullptr;
+  if (dtype == CDN_F32) {
+    rc = run_backward_input<float>(input, offset, mask, weight, grad_output, grad_input,
+                                   grad_offset, grad_mask, g, st);
+    if (rc) return rc;
+    return run_backward_weight<float>(input, offset, mask, grad_output, grad_weight, gb, 1.0, g,
+                                      st);
+  } else if (dtype == CDN_F64) {
+    rc = run_backward_input<double>(input, offset, mask, weight, grad_output, grad_input,
+                                    grad_offset, grad_mask, g, st);
+    if (rc) return rc;
+    return run_backward_weight<double>(input, offset, mask, grad_output, grad_weight, gb, 1.0, g,
+                                       st);
+  }
+  return cdn::fail(CDN_ERR_DTYPE, "unsupported dtype enum %d", dtype);
+}

@@ -1,0 +1,118 @@
+"""CoDeNet fast-path operators (f32) over the C ABI: the three steps of
+``DeformConvWithOffsetScaleBoundPositive.forward`` (modules/dcn_deform_conv.py:323-330 of the
+reference) without the 18-channel offset tensor, plus the on-device QuantAct.  GPU tensors only."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _native as N_
+
+
+def _gpu_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError("codenet_amd runs on the GPU only (got a %s tensor)" % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("codenet fast paths are float32, got %s" % t.dtype)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def codenet_scale(x, w_scale, b_scale, lo, hi):
+    """s = Hardtanh(lo,hi)(conv1x1(x; C->1) + b): [N,C,H,W] -> [N,1,H,W]."""
+    _gpu_f32(x, w_scale, b_scale)
+    x = x.contiguous()
+    Nb, C, H, W = x.shape
+    w = w_scale.contiguous().view(-1)
+    if w.numel() != C:
+        raise RuntimeError("conv_scale weight must have %d elements, got %d" % (C, w.numel()))
+    b = b_scale.contiguous().view(-1) if b_scale is not None else None
+    s = x.new_empty(Nb, 1, H, W)
+    rc = N_.lib().cdn_codenet_scale_forward(_p(x), _p(w), _p(b), _p(s), Nb, C, H, W, float(lo),
+                                            float(hi), _stream(x))
+    N_.check(rc, "cdn_codenet_scale_forward")
+    return s
+
+
+class _CodenetDW(Function):
+    """d = depthwise 3x3 deformable conv of x dilated per pixel by s."""
+
+    @staticmethod
+    def forward(ctx, x, s, w_dw):
+        _gpu_f32(x, s, w_dw)
+        x, s, w_dw = x.contiguous(), s.contiguous(), w_dw.contiguous()
+        Nb, C, H, W = x.shape
+        if tuple(s.shape) != (Nb, 1, H, W):
+            raise RuntimeError("s must be [%d,1,%d,%d], got %s" % (Nb, H, W, tuple(s.shape)))
+        if tuple(w_dw.shape) != (C, 1, 3, 3):
+            raise RuntimeError("depthwise weight must be [%d,1,3,3], got %s" % (C, tuple(w_dw.shape)))
+        d = torch.empty_like(x)
+        rc = N_.lib().cdn_codenet_dw_forward(_p(x), _p(s), _p(w_dw), _p(d), Nb, C, H, W, _stream(x))
+        N_.check(rc, "cdn_codenet_dw_forward")
+        ctx.save_for_backward(x, s, w_dw)
+        return d
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gd):
+        x, s, w_dw = ctx.saved_tensors
+        gd = gd.contiguous()
+        Nb, C, H, W = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(s) if ctx.needs_input_grad[1] else None
+        gw = torch.zeros_like(w_dw) if ctx.needs_input_grad[2] else None
+        rc = N_.lib().cdn_codenet_dw_backward(_p(x), _p(s), _p(w_dw), _p(gd), _p(gx), _p(gs), _p(gw),
+                                              Nb, C, H, W, _stream(x))
+        N_.check(rc, "cdn_codenet_dw_backward")
+        return gx, gs, gw
+
+
+codenet_dw = _CodenetDW.apply
+
+
+def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False):
+    """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA."""
+    _gpu_f32(d, w_pw, bias, ep_scale, ep_shift)
+    d = d.contiguous()
+    Nb, C, H, W = d.shape
+    w = w_pw.contiguous().view(w_pw.size(0), -1)
+    if w.size(1) != C:
+        raise RuntimeError("pointwise weight must be [Co,%d,1,1], got %s" % (C, tuple(w_pw.shape)))
+    Co = w.size(0)
+    y = d.new_empty(Nb, Co, H, W)
+    rc = N_.lib().cdn_codenet_pointwise_forward(
+        _p(d), _p(w), _p(bias.contiguous() if bias is not None else None),
+        _p(ep_scale.contiguous() if ep_scale is not None else None),
+        _p(ep_shift.contiguous() if ep_shift is not None else None), _p(y), Nb, C, Co, H * W,
+        int(bool(relu)), _stream(d))
+    N_.check(rc, "cdn_codenet_pointwise_forward")
+    return y
+
+
+def quantact_state(device):
+    """Device scratch for cdn_quantact_forward (holds scale / zero-point after a call)."""
+    nbytes = N_.lib().cdn_quantact_state_bytes()
+    return torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
+
+
+def quantact_forward(x, x_min, x_max, state, bits=8, momentum=0.99, running=True,
+                     batch_min=None, batch_max=None, want_codes=False, want_out=True):
+    """On-device QuantAct (quant_modules.py:202-225).  Updates x_min / x_max IN PLACE when
+    `running`; returns (fake-quantised fp32 tensor or None, int16 codes or None)."""
+    _gpu_f32(x, x_min, x_max, batch_min, batch_max)
+    x = x.contiguous()
+    out = torch.empty_like(x) if want_out else None
+    codes = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_codes else None
+    rc = N_.lib().cdn_quantact_forward(_p(x), _p(out), _p(codes), x.numel(), _p(x_min), _p(x_max),
+                                       _p(state), _p(batch_min), _p(batch_max), int(bits),
+                                       float(momentum), int(bool(running)), _stream(x))
+    N_.check(rc, "cdn_quantact_forward")
+    return out, codes

@@ -1,0 +1,424 @@
+"""Fake-quantisation nn.Modules of the CoDeNet deform stage with the class names, ``set_param``
+protocol, sub-module / buffer names (checkpoint keys) and arithmetic of
+the reference's portable_quantizer/quant_modules.py:
+
+    QuantAct :163-225          Quant_Conv2d :228-321        QuantBnConv2d :324-419
+    QuantDeformConv2d :422-517 QuantDeformConvWithOffsetScaleBoundPositive :621-671
+
+MI355X specifics
+  * QuantAct on a GPU tensor is one C-ABI call (batch min/max reduction, range tracking with
+    the reference's "+=" / EMA semantics, quantise + de-quantise) with no host round trip.
+  * Weight fake-quantisation (tiny tensors) is derived with torch ops in the reference's fp32
+    expression order; in inference the result is cached per weight version instead of being
+    recomputed every forward (reference: quant_modules.py:278-321,364-419,473-517).
+  * The compound stage module runs scale -> QuantAct -> LDS gather/depthwise -> QuantAct ->
+    f32-MFMA pointwise (+ folded BN bias) on the HIP kernels; under autograd it composes the
+    same sub-modules so gradients are the reference's (straight-through estimators).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Module, Parameter
+
+from .. import ops
+from ..functions.dcn_deform_conv import deform_conv
+from .quantization_utils.quant_utils import (AsymmetricQuantFunction, SymmetricQuantFunction,
+                                             get_percentile_min_max)
+
+__all__ = ["QuantAct", "Quant_Conv2d", "QuantBnConv2d", "QuantDeformConv2d",
+           "QuantDeformConvWithOffsetScaleBoundPositive", "QuantBaseNode", "QuantDepthwiseNode",
+           "channel_shuffle"]
+
+
+def _quant_function(mode):
+    if mode == "symmetric":
+        return SymmetricQuantFunction.apply
+    if mode == "asymmetric":
+        return AsymmetricQuantFunction.apply
+    raise ValueError("unknown quant mode: {}".format(mode))
+
+
+def _channel_range(w2d, percentile):
+    """Per-output-channel (w_min, w_max): plain min/max, or with --wt-percentile the
+    0.1 / 99.9 percentile k-th values (0.95*min/max when a channel has < 10 weights, e.g. every
+    depthwise 3x3) -- reference :281-300."""
+    if not percentile:
+        return w2d.min(dim=1).values, w2d.max(dim=1).values
+    length = w2d.shape[1]
+    if length < 10:
+        return w2d.min(dim=1).values * 0.95, w2d.max(dim=1).values * 0.95
+    lo = math.ceil(length * 0.1 * 0.01)
+    hi = math.ceil(length * 99.9 * 0.01)
+    return (torch.kthvalue(w2d, k=lo, dim=1).values, torch.kthvalue(w2d, k=hi, dim=1).values)
+
+
+class _WeightQuantizer:
+    """Shared weight fake-quantisation of the three Quant*Conv modules + an inference cache."""
+
+    def _init_weight_quant(self, weight_bit, bias_bit, full_precision_flag, quant_mode, per_channel,
+                           weight_percentile):
+        self.full_precision_flag = full_precision_flag
+        self.weight_bit = weight_bit
+        self.quant_mode = quant_mode
+        self.per_channel = per_channel
+        self.weight_percentile = weight_percentile
+        self.bias_bit = bias_bit
+        self.quantize_bias = bias_bit is not None
+        self.weight_function = _quant_function(quant_mode)
+        self._wq_cache = None
+
+    def _fake_quant_weight(self, w, out_channels):
+        if self.full_precision_flag:
+            return w
+        if self.per_channel:
+            if self.quantize_bias:
+                raise NotImplementedError("channel-wise quantize bias is not supported")
+            w_min, w_max = _channel_range(w.data.contiguous().view(out_channels, -1),
+                                          self.weight_percentile)
+        else:
+            if self.quantize_bias:
+                raise NotImplementedError("bias quantisation is outside the hot path")
+            if self.weight_percentile:
+                w_min, w_max = get_percentile_min_max(w.view(-1), 0.1, 99.9, output_tensor=True)
+            else:
+                w_min, w_max = w.data.min(), w.data.max()
+        return self.weight_function(w, self.weight_bit, w_min, w_max, self.per_channel,
+                                    self.weight_percentile)
+
+    def _cached(self, key_tensors, compute):
+        """In inference (no grad) reuse the derived tensors until a source tensor changes."""
+        if torch.is_grad_enabled():
+            return compute()
+        key = tuple((t.data_ptr(), t._version, t.device) for t in key_tensors)
+        if self._wq_cache is None or self._wq_cache[0] != key:
+            with torch.no_grad():
+                self._wq_cache = (key, compute())
+        return self._wq_cache[1]
+
+
+class QuantAct(Module):
+    """Activation fake-quantiser with tracked range (reference :163-225).  `running_stat` stays
+    True in eval() exactly as in the reference (nothing ever clears it); set it to False for
+    frozen-range inference."""
+
+    def __init__(self, activation_bit, momentum=0.99, full_precision_flag=False, running_stat=True,
+                 quant_mode="symmetric", show_flag=False, percentile=False):
+        super().__init__()
+        self.activation_bit = activation_bit
+        self.momentum = momentum
+        self.full_precision_flag = full_precision_flag
+        self.running_stat = running_stat
+        self.quant_mode = quant_mode
+        self.show_flag = show_flag
+        self.percentile = percentile
+        self.register_buffer("x_min", torch.zeros(1))
+        self.register_buffer("x_max", torch.zeros(1))
+        self.act_function = _quant_function(quant_mode)
+        self._state = None
+
+    def __repr__(self):
+        return "{0}(activation_bit={1}, full_precision_flag={2}, Act_min: {3:.2f}, " \
+               "Act_max: {4:.2f})".format(self.__class__.__name__, self.activation_bit,
+                                          self.full_precision_flag, self.x_min.item(),
+                                          self.x_max.item())
+
+    def _device_state(self, device):
+        if self._state is None or self._state.device != device:
+            self._state = ops.quantact_state(device)
+        return self._state
+
+    def _native_ok(self, x):
+        return (x.is_cuda and x.dtype == torch.float32 and self.quant_mode == "asymmetric"
+                and not self.full_precision_flag
+                and not (torch.is_grad_enabled() and x.requires_grad))
+
+    def forward(self, x):
+        if self._native_ok(x):
+            bmin = bmax = None
+            if self.running_stat and self.percentile:
+                bmin, bmax = get_percentile_min_max(x.detach().view(-1), 0.1, 99.9,
+                                                    output_tensor=True)
+                bmin, bmax = bmin.reshape(1).contiguous(), bmax.reshape(1).contiguous()
+            out, _ = ops.quantact_forward(x, self.x_min, self.x_max, self._device_state(x.device),
+                                          bits=self.activation_bit, momentum=self.momentum,
+                                          running=self.running_stat, batch_min=bmin, batch_max=bmax)
+            return out
+        # autograd / CPU tensors / symmetric mode: the reference's torch composition
+        if self.running_stat:
+            if not self.percentile:
+                x_min, x_max = x.data.min(), x.data.max()
+            else:
+                x_min, x_max = get_percentile_min_max(x.detach().view(-1), 0.1, 99.9,
+                                                      output_tensor=True)
+            if self.x_min == self.x_max:     # "initialisation": += (reference :211-213)
+                self.x_min += x_min
+                self.x_max += x_max
+            else:                            # EMA (reference :217-219)
+                self.x_min += (self.momentum - 1.) * self.x_min + (1. - self.momentum) * x_min
+                self.x_max += (self.momentum - 1.) * self.x_max + (1. - self.momentum) * x_max
+        if self.full_precision_flag:
+            return x
+        return self.act_function(x, self.activation_bit, self.x_min, self.x_max)
+
+
+class Quant_Conv2d(Module, _WeightQuantizer):
+    """Conv2d with fake-quantised weights, fp32 bias (reference :228-321)."""
+
+    def __init__(self, weight_bit, bias_bit=None, full_precision_flag=False, quant_mode="symmetric",
+                 per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.momentum = 0.99
+        self._init_weight_quant(weight_bit, bias_bit, full_precision_flag, quant_mode, per_channel,
+                                weight_percentile)
+
+    def set_param(self, conv):
+        for name in ("in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation",
+                     "groups"):
+            setattr(self, name, getattr(conv, name))
+        self.weight = Parameter(conv.weight.data.clone())
+        self.bias = Parameter(conv.bias.data.clone()) if getattr(conv, "bias", None) is not None \
+            else None
+
+    def quantized_weight(self):
+        return self._cached((self.weight,),
+                            lambda: self._fake_quant_weight(self.weight, self.out_channels))
+
+    def forward(self, x):
+        return F.conv2d(x, self.quantized_weight(), self.bias, self.stride, self.padding,
+                        self.dilation, self.groups)
+
+
+class QuantBnConv2d(Module, _WeightQuantizer):
+    """Conv2d + BatchNorm folded from the BN running statistics, then weight fake-quantisation;
+    the folded bias stays fp32 (reference :324-419).  The BN module is never *called*."""
+
+    def __init__(self, weight_bit, bias_bit=None, full_precision_flag=False, running_stat=True,
+                 quant_mode="asymmetric", per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.running_stat = running_stat
+        self._init_weight_quant(weight_bit, bias_bit, full_precision_flag, quant_mode, per_channel,
+                                weight_percentile)
+
+    def set_param(self, conv, bn):
+        self.conv = conv
+        self.bn = bn
+
+    def folded(self):
+        """(fake-quantised folded weight, fp32 folded bias)."""
+        def compute():
+            running_std = torch.sqrt(self.bn.running_var + self.bn.eps)
+            scale_factor = self.bn.weight / running_std
+            w = self.conv.weight * scale_factor.reshape([self.conv.out_channels, 1, 1, 1])
+            b = self.conv.bias if self.conv.bias is not None \
+                else torch.zeros_like(self.bn.running_mean)
+            b = (b - self.bn.running_mean) * scale_factor + self.bn.bias
+            return self._fake_quant_weight(w, self.conv.out_channels), b
+        keys = [self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean,
+                self.bn.running_var]
+        if self.conv.bias is not None:
+            keys.append(self.conv.bias)
+        return self._cached(tuple(keys), compute)
+
+    def forward(self, x):
+        w, b = self.folded()
+        return F.conv2d(x, w, b, self.conv.stride, self.conv.padding, self.conv.dilation,
+                        self.conv.groups)
+
+
+class QuantDeformConv2d(Module, _WeightQuantizer):
+    """DeformConv with fake-quantised weights; forward(x, offset) (reference :422-517)."""
+
+    def __init__(self, weight_bit, bias_bit=None, full_precision_flag=False, quant_mode="symmetric",
+                 per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.momentum = 0.99
+        self._init_weight_quant(weight_bit, bias_bit, full_precision_flag, quant_mode, per_channel,
+                                weight_percentile)
+
+    def set_param(self, conv):
+        for name in ("in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation",
+                     "groups", "deformable_groups"):
+            setattr(self, name, getattr(conv, name))
+        self.weight = Parameter(conv.weight.data.clone())
+        self.bias = Parameter(conv.bias.data.clone()) if getattr(conv, "bias", None) is not None \
+            else None
+
+    def quantized_weight(self):
+        return self._cached((self.weight,),
+                            lambda: self._fake_quant_weight(self.weight, self.out_channels))
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.quantized_weight(), self.stride, self.padding,
+                           self.dilation, self.groups, self.deformable_groups)
+
+    def forward_scaled(self, x, s):
+        """Same operator given the per-pixel scale s instead of offset = anchor*(s-1): the
+        CoDeNet fast path (LDS gather kernel, no offset tensor)."""
+        return ops.codenet_dw(x, s, self.quantized_weight())
+
+
+class QuantDeformConvWithOffsetScaleBoundPositive(Module):
+    """W4A8 counterpart of DeformConvWithOffsetScaleBoundPositive; absorbs the BatchNorm that
+    follows the stage into the pointwise conv (reference :621-671)."""
+
+    def __init__(self, weight_bit, act_bit, full_precision_flag=False, bias_bit=None,
+                 act_percentile=False, wt_quant_mode="symmetric", act_quant_mode="symmetric",
+                 per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.act_bit = act_bit
+        self.weight_bit = weight_bit
+        self.bias_bit = bias_bit
+        self.quantize_bias = bias_bit is not None
+        self.wt_quant_mode = wt_quant_mode
+        self.act_quant_mode = act_quant_mode
+        self.full_precision_flag = full_precision_flag
+        self.act_percentile = act_percentile
+        self.per_channel = per_channel
+        self.weight_percentile = weight_percentile
+
+    def set_param(self, deform_conv, bn):
+        wkw = dict(quant_mode=self.wt_quant_mode, per_channel=self.per_channel,
+                   weight_percentile=self.weight_percentile)
+        self.quant_conv_scale = Quant_Conv2d(self.weight_bit, **wkw)
+        self.quant_conv_scale.set_param(deform_conv.conv_scale)
+        self.quant_act = nn.Sequential(deform_conv.conv_bound,
+                                       QuantAct(self.act_bit, quant_mode="asymmetric",
+                                                percentile=self.act_percentile))
+        self.quant_deform_conv = QuantDeformConv2d(self.weight_bit, **wkw)
+        self.quant_deform_conv.set_param(deform_conv.conv)
+        self.quant_identity_deform = QuantAct(self.act_bit, quant_mode=self.act_quant_mode,
+                                              percentile=self.act_percentile)
+        self.anchor_offset = deform_conv.anchor_offset.clone()
+        self.quant_conv_channel_bn = QuantBnConv2d(self.weight_bit, **wkw)
+        self.quant_conv_channel_bn.set_param(deform_conv.conv_channel, bn)
+
+    def _fast_path_ok(self, x):
+        dc = self.quant_deform_conv
+        cs = self.quant_conv_scale
+        pw = self.quant_conv_channel_bn.conv
+        return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and not (torch.is_grad_enabled() and (x.requires_grad or any(
+                    p.requires_grad for p in self.parameters())))
+                and tuple(dc.kernel_size) == (3, 3) and tuple(dc.stride) == (1, 1)
+                and tuple(dc.padding) == (1, 1) and tuple(dc.dilation) == (1, 1)
+                and dc.deformable_groups == 1 and dc.groups == dc.in_channels == dc.out_channels
+                and cs.out_channels == 1 and tuple(cs.kernel_size) == (1, 1)
+                and tuple(cs.stride) == (1, 1) and tuple(pw.kernel_size) == (1, 1)
+                and pw.groups == 1 and self.act_quant_mode == "asymmetric")
+
+    def forward(self, x):
+        if self._fast_path_ok(x):
+            bound = self.quant_act[0]
+            s_raw = ops.codenet_scale(x, self.quant_conv_scale.quantized_weight(),
+                                      self.quant_conv_scale.bias, bound.min_val, bound.max_val)
+            s = self.quant_act[1](s_raw)
+            d = self.quant_deform_conv.forward_scaled(x, s)
+            d_q = self.quant_identity_deform(d)
+            w, b = self.quant_conv_channel_bn.folded()
+            return ops.codenet_pointwise(d_q, w, b)
+        s = self.quant_act(self.quant_conv_scale(x))
+        dc = self.quant_deform_conv
+        if (x.is_cuda and x.dtype == torch.float32 and s.shape[1] == 1
+                and tuple(dc.kernel_size) == (3, 3) and tuple(dc.stride) == (1, 1)
+                and tuple(dc.padding) == (1, 1) and tuple(dc.dilation) == (1, 1)
+                and dc.deformable_groups == 1 and dc.groups == dc.in_channels == dc.out_channels):
+            d = dc.forward_scaled(x, s)
+        else:
+            d = self.quant_deform_conv(x, self.anchor_offset.to(x.device) * (s - 1))
+        return self.quant_conv_channel_bn(self.quant_identity_deform(d))
+
+
+# ---- callers either side of the stage -----------------------
+# Plain compositions of the modules above; their convolutions run on PyTorch-ROCm.
+
+def channel_shuffle(x, G):
+    """lib/models/networks/shufflenetv2_dcn.py:29-34."""
+    N, C, H, W = x.size()
+    return x.view(N, G, C // G, H, W).transpose(1, 2).contiguous().view(N, C, H, W)
+
+
+class _CompoundQuant(Module):
+    def __init__(self, weight_bit, act_bit, full_precision_flag=False, bias_bit=None,
+                 act_percentile=False, wt_quant_mode="symmetric", act_quant_mode="symmetric",
+                 per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.act_bit = act_bit
+        self.weight_bit = weight_bit
+        self.bias_bit = bias_bit
+        self.quantize_bias = bias_bit is not None
+        self.wt_quant_mode = wt_quant_mode
+        self.act_quant_mode = act_quant_mode
+        self.full_precision_flag = full_precision_flag
+        self.act_percentile = act_percentile
+        self.per_channel = per_channel
+        self.weight_percentile = weight_percentile
+
+    def _convbn(self, conv, bn):
+        m = QuantBnConv2d(self.weight_bit, quant_mode=self.wt_quant_mode,
+                          per_channel=self.per_channel, weight_percentile=self.weight_percentile)
+        m.set_param(conv, bn)
+        return m
+
+    def _act(self, mode=None):
+        return QuantAct(self.act_bit, quant_mode=mode or self.act_quant_mode,
+                        percentile=self.act_percentile)
+
+
+class QuantBaseNode(_CompoundQuant):
+    """W4A8 ShuffleNetV2 BaseNode; the block-output QuantAct is shared across the nodes of a
+    layer via set_act (reference :809-907)."""
+
+    def set_param(self, base_node):
+        self.stride = base_node.stride
+        b2 = base_node.b2
+        assert type(b2[3]) == nn.Conv2d
+        self.quant_convbn1 = self._convbn(b2[0], b2[1])
+        self.quant_act1 = self._act("asymmetric")
+        self.quant_convbn2 = self._convbn(b2[3], b2[4])
+        self.quant_act2 = self._act()
+        self.quant_convbn3 = self._convbn(b2[5], b2[6])
+        if base_node.stride == 2:
+            b1 = base_node.b1
+            assert type(b1[0]) == nn.Conv2d
+            self.quant_convbn4 = self._convbn(b1[0], b1[1])
+            self.quant_act4 = self._act()
+            self.quant_convbn5 = self._convbn(b1[2], b1[3])
+
+    def set_act(self, share_quant_act):
+        self.quant_act = share_quant_act
+
+    def forward(self, x):
+        if self.stride == 1:
+            half = x.shape[1] // 2
+            x1, x2 = x[:, :half], x[:, half:]
+        else:
+            x1 = self.quant_act4(self.quant_convbn4(x))
+            x1 = self.quant_act(F.relu(self.quant_convbn5(x1)))
+            x2 = x
+        x2 = self.quant_act1(F.relu(self.quant_convbn1(x2)))
+        x2 = self.quant_act2(self.quant_convbn2(x2))
+        x2 = self.quant_act(F.relu(self.quant_convbn3(x2)))
+        return channel_shuffle(torch.cat((x1, x2), dim=1), 2)
+
+
+class QuantDepthwiseNode(_CompoundQuant):
+    """W4A8 detection head: pw -> ReLU/QuantAct -> dw 3x3 -> ReLU/QuantAct -> pw(+bias)
+    (reference :1013-1071)."""
+
+    def set_param(self, head_node):
+        assert type(head_node[3]) == nn.Conv2d
+        self.quant_convbn1 = self._convbn(head_node[0], head_node[1])
+        self.quant_act1 = nn.Sequential(head_node[2], self._act("asymmetric"))
+        self.quant_convbn2 = self._convbn(head_node[3], head_node[4])
+        self.quant_act3 = nn.Sequential(head_node[5], self._act("asymmetric"))
+        self.quant_conv = Quant_Conv2d(self.weight_bit, quant_mode=self.wt_quant_mode,
+                                       per_channel=self.per_channel,
+                                       weight_percentile=self.weight_percentile)
+        self.quant_conv.set_param(head_node[6])
+
+    def forward(self, x):
+        x = self.quant_act1(self.quant_convbn1(x))
+        x = self.quant_act3(self.quant_convbn2(x))
+        return self.quant_conv(x)

@@ -1,0 +1,179 @@
+/*
+ * codenet_dcn.h -- C ABI of libcodenet_dcn.so, the MI355X (gfx950) implementation of
+ * CoDeNet's deformable-convolution hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one function of the reference's
+ * pybind11 module `dcn_deform_conv_cuda`
+ * (lib/models/external/src/dcn_deform_conv_cuda.cpp:681-695) or one fused step of the
+ * Python composition above it (lib/models/external/modules/dcn_deform_conv.py:285-330,
+ * portable_quantizer/quant_modules.py:163-225,621-671).  Citations are relative to the
+ * reference checkout.
+ *
+ * Conventions
+ *   - All tensor arguments are DEVICE pointers to contiguous NCHW buffers owned by the
+ *     caller; the library never allocates, frees or retains tensor memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
+ *     enqueued asynchronously on it; no entry point synchronises the device or the host.
+ *   - Every function returns 0 (CDN_OK) or a negative cdn_status; cdn_last_error() gives a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - dtype: CDN_F32 or CDN_F64 for the generic entry points; the CoDeNet fast paths are f32
+ *     (activations) with int8 code paths where stated.
+ *   - Re-entrant, no global mutable state; safe to call concurrently from several host
+ *     threads on different streams / devices (the current HIP device must be the one that
+ *     owns the pointers).
+ */
+#ifndef CODENET_DCN_H_
+#define CODENET_DCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDN_ABI_VERSION 1
+
+enum cdn_dtype { CDN_F32 = 0, CDN_F64 = 1 };
+
+enum cdn_status {
+  CDN_OK = 0,
+  CDN_ERR_ARG = -1,         /* null pointer / bad enum / non-positive size            */
+  CDN_ERR_SHAPE = -2,       /* inconsistent shapes (reference: AT_CHECK in shape_check) */
+  CDN_ERR_DTYPE = -3,
+  CDN_ERR_HIP = -4,         /* a HIP runtime call or kernel launch failed             */
+  CDN_ERR_UNSUPPORTED = -5, /* valid request outside what a fast path implements      */
+  CDN_ERR_WORKSPACE = -6    /* workspace too small                                    */
+};
+
+int cdn_abi_version(void);
+const char *cdn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic deformable convolution -- the five roles of the reference extension.
+ * Argument ORDER follows the reference (W before H in the three deform_conv_* functions,
+ * H before W in the modulated ones; functions/dcn_deform_conv.py:51-56 vs :143-147).
+ * Shapes: input [N,C,H,W]; offset [N, dg*2*kH*kW, Ho, Wo]; mask [N, dg*kH*kW, Ho, Wo];
+ *         weight [Co, C/group, kH, kW]; output/gradOutput [N, Co, Ho, Wo],
+ *         Ho = (H + 2*padH - (dilH*(kH-1)+1))/dH + 1  (cpp:187-190).
+ * The reference's vestigial `columns` / `ones` buffer arguments and `im2col_step` are gone:
+ * no column buffer is ever materialised.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces deform_conv_forward_cuda (dcn_deform_conv_cuda.cpp:151-258).
+ * `output` is fully overwritten. */
+int cdn_deform_conv_forward(const void *input, const void *weight, const void *offset,
+                            void *output, int dtype, int64_t N, int64_t C, int64_t H, int64_t W,
+                            int64_t Co, int kW, int kH, int dW, int dH, int padW, int padH,
+                            int dilationW, int dilationH, int group, int deformable_group,
+                            void *stream);
+
+/* Replaces deform_conv_backward_input_cuda (cpp:260-371).
+ * gradInput is ACCUMULATED into (caller zero-fills, as functions/dcn_deform_conv.py:73 does);
+ * gradOffset is fully overwritten. */
+int cdn_deform_conv_backward_input(const void *input, const void *offset, const void *gradOutput,
+                                   void *gradInput, void *gradOffset, const void *weight,
+                                   int dtype, int64_t N, int64_t C, int64_t H, int64_t W,
+                                   int64_t Co, int kW, int kH, int dW, int dH, int padW, int padH,
+                                   int dilationW, int dilationH, int group, int deformable_group,
+                                   void *stream);
+
+/* Replaces deform_conv_backward_parameters_cuda (cpp:373-484).
+ * gradWeight += scale * dL/dW  (accumulated, cpp:456-462; caller zero-fills). */
+int cdn_deform_conv_backward_parameters(const void *input, const void *offset,
+                                        const void *gradOutput, void *gradWeight, int dtype,
+                                        int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co,
+                                        int kW, int kH, int dW, int dH, int padW, int padH,
+                                        int dilationW, int dilationH, int group,
+                                        int deformable_group, float scale, void *stream);
+
+/* Replaces modulated_deform_conv_cuda_forward (cpp:486-564).  bias may be NULL iff
+ * with_bias == 0.  `output` is fully overwritten. */
+int cdn_modulated_deform_conv_forward(const void *input, const void *weight, const void *bias,
+                                      const void *offset, const void *mask, void *output,
+                                      int dtype, int64_t N, int64_t C, int64_t H, int64_t W,
+                                      int64_t Co, int kernel_h, int kernel_w, int stride_h,
+                                      int stride_w, int pad_h, int pad_w, int dilation_h,
+                                      int dilation_w, int group, int deformable_group,
+                                      int with_bias, void *stream);
+
+/* Replaces modulated_deform_conv_cuda_backward (cpp:566-679).
+ * grad_input, grad_weight, grad_bias are ACCUMULATED into (caller zero-fills,
+ * functions/dcn_deform_conv.py:157-161); grad_offset and grad_mask are overwritten.
+ * Unlike the reference launcher (_kernel.cu:821, pad_h passed twice) pad_w is honoured. */
+int cdn_modulated_deform_conv_backward(const void *input, const void *weight, const void *bias,
+                                       const void *offset, const void *mask, void *grad_input,
+                                       void *grad_weight, void *grad_bias, void *grad_offset,
+                                       void *grad_mask, const void *grad_output, int dtype,
+                                       int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co,
+                                       int kernel_h, int kernel_w, int stride_h, int stride_w,
+                                       int pad_h, int pad_w, int dilation_h, int dilation_w,
+                                       int group, int deformable_group, int with_bias,
+                                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CoDeNet fast paths (f32): the three steps of DeformConvWithOffsetScaleBoundPositive.forward
+ * (modules/dcn_deform_conv.py:323-330) with the 18-channel offset tensor never materialised:
+ *   s = Hardtanh(lo, hi)(conv1x1(x; C->1) + bias)                      :295,304-305,324
+ *   d = depthwise 3x3 deformable conv sampling tap (i,j) at
+ *       (h + (i-1) + (i-1)*(s-1),  w + (j-1) + (j-1)*(s-1))            :319-321,325 + :56-58
+ *   y = conv1x1(d; C->Co)                                              :311-312,328
+ * Tap positions are computed with exactly the reference's fp32 operation order
+ * (t = s - 1; off = a*t; pos = float(h-1+i) + off), so they are bit-identical to the
+ * positions the reference's im2col kernel derives from `anchor_offset * (s - 1)`.
+ * ---------------------------------------------------------------------------------------- */
+
+/* s[N,1,H,W] = clamp(sum_c w_scale[c]*x[n,c,h,w] + b_scale[0], lo, hi).
+ * w_scale: [C] device floats, b_scale: device pointer to 1 float (may be NULL = 0). */
+int cdn_codenet_scale_forward(const float *x, const float *w_scale, const float *b_scale,
+                              float *s, int64_t N, int64_t C, int64_t H, int64_t W, float lo,
+                              float hi, void *stream);
+
+/* d[N,C,H,W] = depthwise deformable 3x3 of x with per-pixel scale s[N,1,H,W],
+ * w_dw: [C,1,3,3].  stride 1, pad 1, dilation 1, groups = C, deformable_groups = 1. */
+int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, float *d,
+                           int64_t N, int64_t C, int64_t H, int64_t W, void *stream);
+
+/* Backward of cdn_codenet_dw_forward.  grad_x [N,C,H,W] and grad_s [N,1,H,W] are fully
+ * overwritten (grad_x is summed in LDS and stored once -- no global atomics; grad_s is
+ * zeroed on `stream` and summed with one global float atomic per pixel and channel chunk);
+ * grad_w [C,1,3,3] is ACCUMULATED into (caller zero-fills).  Any of grad_x / grad_s / grad_w
+ * may be NULL.  Requires the (H+2)x(W+2) plane to fit LDS twice (H*W up to ~17k pixels).
+ * grad_s is dL/ds = sum_k (i-1)*dL/doff_y,k + (j-1)*dL/doff_x,k. */
+int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
+                            const float *grad_d, float *grad_x, float *grad_s, float *grad_w,
+                            int64_t N, int64_t C, int64_t H, int64_t W, void *stream);
+
+/* y[N,Co,HW] = sum_c w_pw[co,c] * d[n,c,p] (+ bias[co]) on f32 MFMA (exact f32 products,
+ * f32 accumulate).  Optional epilogue: per-channel affine y*ep_scale[co] + ep_shift[co]
+ * (a folded BatchNorm; either both NULL or both set), then ReLU if relu != 0. */
+int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, const float *bias,
+                                  const float *ep_scale, const float *ep_shift, float *y,
+                                  int64_t N, int64_t C, int64_t Co, int64_t HW, int relu,
+                                  void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * QuantAct on device (portable_quantizer/quant_modules.py:163-225, asymmetric per-tensor branch
+ * of AsymmetricQuantFunction, quantization_utils/quant_utils.py:172-200).  One call does, with
+ * no host synchronisation:
+ *   running != 0: batch min/max of x (or the caller's batch_min/batch_max device scalars, e.g.
+ *                 the 0.1 / 99.9 percentiles of --act-percentile), then the reference's range
+ *                 tracking on the x_min / x_max buffers IN PLACE ("+=" initialisation while
+ *                 x_min == x_max, else EMA with `momentum`);
+ *   always:       scale = (2^bits-1)/clamp(x_max-x_min,1e-10), zp = round(scale*x_min)+2^(bits-1),
+ *                 q = round(scale*x - zp) (round-half-even, NOT clamped),
+ *                 out = (q + zp)/scale (fp32, may alias x) and/or codes = q as int16.
+ * `state` is a caller-owned device scratch of cdn_quantact_state_bytes() bytes; after the call
+ * it holds {.., .., scale, zp, batch_min, batch_max} as fp32 words 2..5.
+ * x, out must be 16-byte aligned, codes 8-byte aligned.  out and codes may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+size_t cdn_quantact_state_bytes(void);
+int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t numel, float *x_min,
+                         float *x_max, void *state, const float *batch_min,
+                         const float *batch_max, int bits, double momentum, int running,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODENET_DCN_H_ */

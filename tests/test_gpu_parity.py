@@ -1,0 +1,260 @@
+"""GPU parity tests proper (-m gpu): the HIP library, called through the C ABI / the reference-
+shaped Python API, against the CPU oracle on identical seeded inputs.  Tolerances are stated per
+test; positions / integer codes are required to be exact where the domain allows."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dcn as O
+from oracle import quant as Q
+
+GENERIC_CASES = [
+    # N, C, H, W, Co, k, stride, pad, dil, G, DG
+    (2, 4, 7, 9, 6, 3, 1, 1, 1, 1, 1),
+    (2, 8, 9, 9, 8, 3, 1, 1, 1, 8, 1),
+    (1, 6, 8, 10, 4, 3, 2, 1, 1, 2, 3),
+    (2, 4, 9, 8, 4, 3, 1, 2, 2, 2, 2),
+    (1, 4, 6, 6, 8, (1, 3), (1, 2), (0, 1), 1, 1, 1),
+    (3, 16, 12, 12, 16, 3, 1, 1, 1, 16, 1),
+]
+
+
+def _mk(case, dtype, modulated=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W, Co, k, s, p, d, G, DG = case
+    kH, kW = (k, k) if isinstance(k, int) else k
+    Ho, Wo = O.out_size(H, W, kH, kW, s, p, d)
+    x = torch.randn(N, C, H, W, dtype=dtype, generator=g)
+    off = torch.randn(N, DG * 2 * kH * kW, Ho, Wo, dtype=dtype, generator=g) * 2
+    w = torch.randn(Co, C // G, kH, kW, dtype=dtype, generator=g)
+    m = torch.rand(N, DG * kH * kW, Ho, Wo, dtype=dtype, generator=g) if modulated else None
+    return x, off, w, m, (s, p, d, G, DG)
+
+
+def _tol(dtype):
+    return 1e-10 if dtype == torch.float64 else 1e-4
+
+
+@pytest.mark.parametrize("case", GENERIC_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_deform_conv_forward_backward(case, dtype):
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    x, off, w, _, cfg = _mk(case, dtype)
+    ref = O.deform_conv_forward(x, off, w, *cfg)
+    xg, og, wg = (t.cuda().requires_grad_(True) for t in (x, off, w))
+    out = deform_conv(xg, og, wg, *cfg)
+    assert out.shape == ref.shape
+    assert (out.detach().cpu() - ref).abs().max().item() < _tol(dtype)
+    go = torch.randn(ref.shape, dtype=dtype, generator=torch.Generator().manual_seed(1))
+    out.backward(go.cuda())
+    gx, goff = O.deform_conv_backward_input(x, off, w, go, *cfg)
+    gw = O.deform_conv_backward_params(x, off, tuple(w.shape), go, *cfg)
+    sc = 10.0  # gradients sum O(10-100) terms of O(1); tolerance scaled accordingly
+    assert (xg.grad.cpu() - gx).abs().max().item() < sc * _tol(dtype)
+    assert (og.grad.cpu() - goff).abs().max().item() < sc * _tol(dtype)
+    assert (wg.grad.cpu() - gw).abs().max().item() < sc * _tol(dtype)
+
+
+@pytest.mark.parametrize("case", GENERIC_CASES[:4])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_modulated_deform_conv_forward_backward(case, dtype, with_bias):
+    from codenet_amd.functions.dcn_deform_conv import modulated_deform_conv
+    x, off, w, m, (s, p, d, G, DG) = _mk(case, dtype, modulated=True)
+    if not isinstance(s, int) or not isinstance(p, int):
+        pytest.skip("modulated API takes int stride/padding")
+    b = torch.randn(w.shape[0], dtype=dtype) if with_bias else None
+    ref = O.deform_conv_forward(x, off, w, s, p, d, G, DG, mask=m, bias=b)
+    xg, og, mg, wg = (t.cuda().requires_grad_(True) for t in (x, off, m, w))
+    bg = b.cuda().requires_grad_(True) if with_bias else None
+    out = modulated_deform_conv(xg, og, mg, wg, bg, s, p, d, G, DG)
+    assert (out.detach().cpu() - ref).abs().max().item() < _tol(dtype)
+    go = torch.randn(ref.shape, dtype=dtype)
+    out.backward(go.cuda())
+    gx, goff, gm = O.deform_conv_backward_input(x, off, w, go, s, p, d, G, DG, mask=m)
+    res = O.deform_conv_backward_params(x, off, tuple(w.shape), go, s, p, d, G, DG, mask=m,
+                                        with_bias=with_bias)
+    gw, gb = res if with_bias else (res, None)
+    sc = 10.0
+    assert (xg.grad.cpu() - gx).abs().max().item() < sc * _tol(dtype)
+    assert (og.grad.cpu() - goff).abs().max().item() < sc * _tol(dtype)
+    assert (mg.grad.cpu() - gm).abs().max().item() < sc * _tol(dtype)
+    assert (wg.grad.cpu() - gw).abs().max().item() < sc * _tol(dtype)
+    if with_bias:
+        assert (bg.grad.cpu() - gb).abs().max().item() < sc * _tol(dtype)
+
+
+def test_cpu_tensor_raises_like_reference():
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    x, off, w, _, cfg = _mk(GENERIC_CASES[0], torch.float32)
+    with pytest.raises(NotImplementedError):
+        deform_conv(x, off, w, *cfg)
+    with pytest.raises(ValueError):
+        deform_conv(x[0].cuda(), off.cuda(), w.cuda(), *cfg)
+
+
+def test_shape_errors_raise_runtime_error():
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    x, off, w, _, cfg = _mk(GENERIC_CASES[0], torch.float32)
+    with pytest.raises(RuntimeError):
+        deform_conv(x.cuda(), off[:, :16].contiguous().cuda(), w.cuda(), *cfg)
+    with pytest.raises(RuntimeError):
+        deform_conv(x.cuda(), off.cuda(), w[:, :3].contiguous().cuda(), *cfg)
+
+
+# ---- CoDeNet fast paths -------------------------------------------------------------------------
+
+STAGE_SHAPES = [
+    # N, C, Co, H, W
+    (2, 16, 8, 12, 12),
+    (2, 5, 3, 9, 11),        # odd everything (w2 has C = 2153: no divisibility assumptions)
+    (2, 1024, 256, 8, 8),    # config-a stages
+    (2, 256, 128, 16, 16),
+    (2, 128, 64, 32, 32),
+    (1, 128, 64, 64, 64),    # config-c stage 2
+    (1, 2153, 256, 16, 16),  # CoDeNet2x stage 0
+    (1, 3, 2, 150, 140),     # plane too large for LDS -> global-gather variant
+]
+
+
+def _stage_inputs(N, C, Co, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g)
+    w_scale = torch.randn(1, C, 1, 1, generator=g) * (3.0 / C ** 0.5)   # s ~ N(1, 3): clamps hit
+    b_scale = torch.ones(1)
+    w_dw = torch.empty(C, 1, 3, 3).uniform_(-1, 1, generator=g) / 3.0
+    w_pw = torch.randn(Co, C, 1, 1, generator=g) * (2.0 / C) ** 0.5
+    return x, w_scale, b_scale, w_dw, w_pw
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES)
+def test_codenet_scale(shape):
+    from codenet_amd import ops
+    N, C, Co, H, W = shape
+    x, w_scale, b_scale, _, _ = _stage_inputs(*shape)
+    ref = torch.clamp(F.conv2d(x.double(), w_scale.double(), b_scale.double()), -7, 8)
+    got = ops.codenet_scale(x.cuda(), w_scale.cuda(), b_scale.cuda(), -7.0, 8.0).cpu()
+    assert got.shape == (N, 1, H, W)
+    assert (got.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES)
+def test_codenet_dw_forward(shape):
+    from codenet_amd import ops
+    N, C, Co, H, W = shape
+    x, _, _, w_dw, _ = _stage_inputs(*shape)
+    s = torch.empty(N, 1, H, W).uniform_(-7, 8, generator=torch.Generator().manual_seed(3))
+    s[0, 0, 0, :4] = torch.tensor([-7.0, 8.0, 1.0, 0.0])      # clamp values, identity, collapse
+    s[0, 0, 1, :3] = torch.tensor([2.0, -3.0, 0.5])
+    off = Q.ANCHOR * (s - 1)                                    # fp32, as the reference builds it
+    ref = O.deform_conv_forward(x, off, w_dw, 1, 1, 1, C, 1)
+    got = ops.codenet_dw(x.cuda(), s.cuda(), w_dw.cuda()).cpu()
+    assert (got - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES[:7])
+def test_codenet_dw_backward(shape):
+    from codenet_amd import ops
+    N, C, Co, H, W = shape
+    x, _, _, w_dw, _ = _stage_inputs(*shape)
+    g = torch.Generator().manual_seed(4)
+    # keep samples away from the bilinear kinks: ds is only piecewise defined there
+    s = torch.randint(-6, 7, (N, 1, H, W), generator=g).float() + \
+        torch.empty(N, 1, H, W).uniform_(0.2, 0.8, generator=g)
+    off = Q.ANCHOR * (s - 1)
+    go = torch.randn(N, C, H, W, generator=g)
+    gx_ref, goff_ref = O.deform_conv_backward_input(x, off, w_dw, go, 1, 1, 1, C, 1)
+    gw_ref = O.deform_conv_backward_params(x, off, tuple(w_dw.shape), go, 1, 1, 1, C, 1)
+    gs_ref = (goff_ref * Q.ANCHOR).sum(dim=1, keepdim=True)     # autograd of anchor*(s-1)
+    xg, sg, wg = (t.cuda().requires_grad_(True) for t in (x, s, w_dw))
+    d = ops.codenet_dw(xg, sg, wg)
+    d.backward(go.cuda())
+    scale = max(1.0, gs_ref.abs().max().item())
+    assert (xg.grad.cpu() - gx_ref).abs().max().item() < 1e-4
+    assert (sg.grad.cpu() - gs_ref).abs().max().item() < 2e-4 * scale
+    assert (wg.grad.cpu() - gw_ref).abs().max().item() < 2e-4 * max(1.0, gw_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES[:7])
+def test_codenet_pointwise(shape):
+    from codenet_amd import ops
+    N, C, Co, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    d = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(Co, C, 1, 1, generator=g) / C ** 0.5
+    # asymmetric weights catch a transposed / mis-mapped MFMA operand
+    ref = F.conv2d(d.double(), w.double())
+    got = ops.codenet_pointwise(d.cuda(), w.cuda()).cpu()
+    assert (got.double() - ref).abs().max().item() < 1e-4
+    b = torch.randn(Co, generator=g)
+    es, eh = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g)
+    ref2 = torch.relu((ref + b.double().view(1, -1, 1, 1)) * es.double().view(1, -1, 1, 1)
+                      + eh.double().view(1, -1, 1, 1))
+    got2 = ops.codenet_pointwise(d.cuda(), w.cuda(), b.cuda(), es.cuda(), eh.cuda(), relu=True).cpu()
+    assert (got2.double() - ref2).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES[:7])
+def test_module_stage_fp32(shape):
+    """DeformConvWithOffsetScaleBoundPositive (fast path) == oracle composition, <= 1e-3 (north star)."""
+    from codenet_amd.modules.dcn_deform_conv import DeformConvWithOffsetScaleBoundPositive
+    N, C, Co, H, W = shape
+    x, w_scale, b_scale, w_dw, w_pw = _stage_inputs(*shape)
+    mod = DeformConvWithOffsetScaleBoundPositive(C, Co, 3, 1, 1, groups=Co, hidden_state=128)
+    with torch.no_grad():
+        mod.conv_scale.weight.copy_(w_scale)
+        mod.conv_scale.bias.copy_(b_scale)
+        mod.conv.weight.copy_(w_dw)
+        mod.conv_channel.weight.copy_(w_pw)
+    mod = mod.cuda().eval()
+    ref = Q.stage_fp32(x, w_scale, b_scale, w_dw, w_pw)
+    with torch.no_grad():
+        y = mod(x.cuda()).cpu()
+    assert (y - ref["y"]).abs().max().item() < 1e-3
+    # training-mode path (autograd) gives the same forward
+    y2 = mod(x.cuda().requires_grad_(True))
+    assert (y2.detach().cpu() - ref["y"]).abs().max().item() < 1e-3
+    y2.sum().backward()
+    assert mod.conv_scale.weight.grad is not None and mod.conv.weight.grad is not None
+
+
+def test_module_generic_equals_fast_path():
+    """The generic deform_conv with explicit 18-channel offsets and the fused fast path agree."""
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    from codenet_amd import ops
+    N, C, H, W = 2, 32, 16, 16
+    x, _, _, w_dw, _ = _stage_inputs(N, C, 8, H, W)
+    s = torch.empty(N, 1, H, W).uniform_(-7, 8)
+    off = (Q.ANCHOR * (s - 1)).cuda()
+    a = deform_conv(x.cuda(), off, w_dw.cuda(), 1, 1, 1, C, 1)
+    b = ops.codenet_dw(x.cuda(), s.cuda(), w_dw.cuda())
+    assert (a - b).abs().max().item() < 1e-5
+
+
+# ---- QuantAct on device: identical codes for identical fp32 inputs ------------------------------
+
+@pytest.mark.parametrize("numel_shape", [(2, 1, 12, 12), (3, 16, 9, 11), (2, 128, 32, 32)])
+def test_quantact_codes_bit_exact(numel_shape):
+    from codenet_amd import ops
+    g = torch.Generator().manual_seed(7)
+    st = Q.QuantActState(bits=8)
+    x_min = torch.zeros(1, device="cuda")
+    x_max = torch.zeros(1, device="cuda")
+    state = ops.quantact_state("cuda")
+    for it in range(4):                     # first call: "+=" init; then EMA
+        x = torch.randn(numel_shape, generator=g) * (1.0 + it) + 0.3 * it
+        ref_out, ref_q = st(x, running=True, return_codes=True)
+        out, codes = ops.quantact_forward(x.cuda(), x_min, x_max, state, bits=8, momentum=0.99,
+                                          running=True, want_codes=True)
+        assert x_min.cpu().item() == st.x_min.item() and x_max.cpu().item() == st.x_max.item()
+        assert torch.equal(codes.cpu().float(), ref_q)
+        assert torch.equal(out.cpu(), ref_out)
+    # frozen ranges: state untouched, same codes as the oracle with running=False
+    x = torch.randn(numel_shape, generator=g) * 3
+    ref_out, ref_q = st(x, running=False, return_codes=True)
+    lo, hi = x_min.clone(), x_max.clone()
+    out, codes = ops.quantact_forward(x.cuda(), x_min, x_max, state, running=False, want_codes=True)
+    assert torch.equal(x_min, lo) and torch.equal(x_max, hi)
+    assert torch.equal(codes.cpu().float(), ref_q) and torch.equal(out.cpu(), ref_out)
