@@ -52,6 +52,10 @@ def lib():
                 "codenet_amd: native library %s is missing -- run `python -c 'import "
                 "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). There is no "
                 "fallback path." % SO_PATH)
+        # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process, so
+        # make sure it is loaded BEFORE our library resolves the same SONAME (otherwise /opt/rocm's
+        # copy is pulled in as a second runtime and every launch fails with hipErrorNoDevice).
+        import torch  # noqa: F401
         l = ctypes.CDLL(SO_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)

@@ -93,7 +93,8 @@ __global__ void quantact_update_kernel(float *x_min, float *x_max, unsigned *sta
   }
   const float nlev = (float)((1 << bits) - 1);
   const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);          // torch.clamp(min=1e-10)
-  const float scale = __fdiv_rn(nlev, range);
+  // `n / tensor` in torch is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
+  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);
   const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (bits - 1)));
   reinterpret_cast<float *>(state)[2] = scale;
   reinterpret_cast<float *>(state)[3] = zp;

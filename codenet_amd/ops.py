@@ -8,6 +8,47 @@ from torch.autograd.function import once_differentiable
 from . import _native as N_
 
 
+class KernelTimer:
+    """Optional HIP-event timing of named fast-path launches on the stream they are issued on
+    (bench.py's live roofline measurement).  Usage: ``with KernelTimer({"dw"}) as kt: ...`` then
+    ``kt.durations_ms()`` after a device synchronise."""
+    active = None
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []          # (name, tag, start_event, end_event)
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def durations_ms(self):
+        out = {}
+        for name, tag, e0, e1 in self.records:
+            out.setdefault((name, tag), []).append(e0.elapsed_time(e1))
+        return out
+
+
+def _tic(name, tag):
+    kt = KernelTimer.active
+    if kt is None or name not in kt.names:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return (kt, name, tag, e0)
+
+
+def _toc(rec):
+    if rec is not None:
+        kt, name, tag, e0 = rec
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        kt.records.append((name, tag, e0, e1))
+
+
 def _gpu_f32(*ts):
     for t in ts:
         if t is None:
@@ -36,8 +77,10 @@ def codenet_scale(x, w_scale, b_scale, lo, hi):
         raise RuntimeError("conv_scale weight must have %d elements, got %d" % (C, w.numel()))
     b = b_scale.contiguous().view(-1) if b_scale is not None else None
     s = x.new_empty(Nb, 1, H, W)
+    rec = _tic("scale", (C, H, W))
     rc = N_.lib().cdn_codenet_scale_forward(_p(x), _p(w), _p(b), _p(s), Nb, C, H, W, float(lo),
                                             float(hi), _stream(x))
+    _toc(rec)
     N_.check(rc, "cdn_codenet_scale_forward")
     return s
 
@@ -55,7 +98,9 @@ class _CodenetDW(Function):
         if tuple(w_dw.shape) != (C, 1, 3, 3):
             raise RuntimeError("depthwise weight must be [%d,1,3,3], got %s" % (C, tuple(w_dw.shape)))
         d = torch.empty_like(x)
+        rec = _tic("dw", (C, H, W))
         rc = N_.lib().cdn_codenet_dw_forward(_p(x), _p(s), _p(w_dw), _p(d), Nb, C, H, W, _stream(x))
+        _toc(rec)
         N_.check(rc, "cdn_codenet_dw_forward")
         ctx.save_for_backward(x, s, w_dw)
         return d
@@ -88,11 +133,13 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
         raise RuntimeError("pointwise weight must be [Co,%d,1,1], got %s" % (C, tuple(w_pw.shape)))
     Co = w.size(0)
     y = d.new_empty(Nb, Co, H, W)
+    rec = _tic("pointwise", (C, H, W))
     rc = N_.lib().cdn_codenet_pointwise_forward(
         _p(d), _p(w), _p(bias.contiguous() if bias is not None else None),
         _p(ep_scale.contiguous() if ep_scale is not None else None),
         _p(ep_shift.contiguous() if ep_shift is not None else None), _p(y), Nb, C, Co, H * W,
         int(bool(relu)), _stream(d))
+    _toc(rec)
     N_.check(rc, "cdn_codenet_pointwise_forward")
     return y
 
@@ -111,8 +158,10 @@ def quantact_forward(x, x_min, x_max, state, bits=8, momentum=0.99, running=True
     x = x.contiguous()
     out = torch.empty_like(x) if want_out else None
     codes = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_codes else None
+    rec = _tic("quantact", (x.numel(),))
     rc = N_.lib().cdn_quantact_forward(_p(x), _p(out), _p(codes), x.numel(), _p(x_min), _p(x_max),
                                        _p(state), _p(batch_min), _p(batch_max), int(bits),
                                        float(momentum), int(bool(running)), _stream(x))
+    _toc(rec)
     N_.check(rc, "cdn_quantact_forward")
     return out, codes

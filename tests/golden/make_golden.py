@@ -1,0 +1,259 @@
+"""Generates tests/golden/*.npz.  RUNS IN THE BUILD CONTAINER ONLY (needs /root/reference).
+
+The reference's own Python modules are imported from /root/reference (nothing is copied): stubs
+are installed for its missing third-party imports (pytorchcv, thop) and for the CUDA extension
+``_ext.dcn.dcn_deform_conv_cuda`` (absent: .MISSING_LARGE_BLOBS), and the module-level name
+``deform_conv`` is rebound to the CPU oracle (oracle/dcn.py) -- the only thing of the reference
+that cannot run here is its native arithmetic.
+
+Fixtures
+  quant_ref.npz     PURE reference (no oracle involved): QuantAct state/codes over 4 calls,
+                    Quant_Conv2d / QuantBnConv2d / QuantDeformConv2d weight fake-quantisation
+                    (with and without --wt-percentile), AsymmetricQuantFunction outputs.
+  stage_fp32.npz    reference DeformConvWithOffsetScaleBoundPositive (native call -> oracle).
+  stage_w4a8.npz    reference QuantDeformConvWithOffsetScaleBoundPositive + following
+                    Sequential(ReLU, QuantAct), 3 consecutive forwards (EMA state pinned).
+  deform_raw.npz    oracle-only regression vectors for the generic op (fwd + all grads, plain
+                    and modulated); the reference cannot produce these (CUDA-only).
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import dcn as O  # noqa: E402
+
+
+def import_reference():
+    """Import the reference's hot-path Python modules with stubs for what is missing."""
+    for name in ["pytorchcv", "pytorchcv.model_provider", "pytorchcv.models",
+                 "pytorchcv.models.shufflenetv2", "pytorchcv.models.common", "thop", "_ext",
+                 "_ext.dcn", "_ext.dcn.dcn_deform_conv_cuda"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pytorchcv.model_provider"].get_model = lambda *a, **k: None
+    sys.modules["pytorchcv.models.shufflenetv2"].ShuffleUnit = type("ShuffleUnit", (), {})
+    sys.modules["pytorchcv.models.common"].ChannelShuffle = type("ChannelShuffle", (), {})
+    sys.modules["thop"].profile = lambda *a, **k: (0, 0)
+    sys.modules["_ext"].dcn = sys.modules["_ext.dcn"]
+    sys.modules["_ext.dcn"].dcn_deform_conv_cuda = sys.modules["_ext.dcn.dcn_deform_conv_cuda"]
+    sys.path.insert(0, os.path.join(REF, "lib"))
+    sys.path.insert(0, REF)
+    import models.external.modules.dcn_deform_conv as ref_mod
+    import portable_quantizer.quant_modules as ref_qm
+    import portable_quantizer.quantization_utils.quant_utils as ref_qu
+    ref_mod.deform_conv = O.deform_conv      # native symbol -> CPU oracle
+    ref_qm.deform_conv = O.deform_conv
+    return ref_mod, ref_qm, ref_qu
+
+
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+            for k, v in d.items()}
+
+
+def make_quant_ref(ref_qm, ref_qu):
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    # QuantAct: 4 calls (first: "+=" initialisation, then EMA), asymmetric 8 bit
+    qa = ref_qm.QuantAct(8, quant_mode="asymmetric")
+    qa.eval()
+    for it in range(4):
+        x = torch.randn(2, 6, 7, 5, generator=g) * (1.0 + 0.7 * it) + 0.25 * it
+        y = qa(x)
+        scale, zp = ref_qu.asymmetric_linear_quantization_params(8, qa.x_min, qa.x_max)
+        q = ref_qu.linear_quantize(x, scale, zp)
+        out["act_x%d" % it] = x
+        out["act_y%d" % it] = y
+        out["act_q%d" % it] = q
+        out["act_min%d" % it] = qa.x_min.clone()
+        out["act_max%d" % it] = qa.x_max.clone()
+    # percentile-mode QuantAct, 2 calls
+    qp = ref_qm.QuantAct(8, quant_mode="asymmetric", percentile=True)
+    for it in range(2):
+        x = torch.randn(2, 8, 16, 16, generator=g) * 2
+        out["pact_x%d" % it] = x
+        out["pact_y%d" % it] = qp(x)
+        out["pact_min%d" % it] = qp.x_min.clone()
+        out["pact_max%d" % it] = qp.x_max.clone()
+    # weight fake-quantisation through the three conv wrappers
+    for pct in (False, True):
+        tag = "p" if pct else "n"
+        conv = torch.nn.Conv2d(40, 6, 1, bias=True)
+        conv.weight.data = torch.randn(6, 40, 1, 1, generator=g) * 0.3
+        conv.bias.data = torch.randn(6, generator=g)
+        qc = ref_qm.Quant_Conv2d(4, quant_mode="symmetric", per_channel=True, weight_percentile=pct)
+        qc.set_param(conv)
+        x = torch.randn(2, 40, 5, 5, generator=g)
+        out["qconv_%s_w" % tag] = conv.weight.data
+        out["qconv_%s_b" % tag] = conv.bias.data
+        out["qconv_%s_x" % tag] = x
+        out["qconv_%s_y" % tag] = qc(x)
+        # big-L channel so the kthvalue branch (L >= 10, and k > 1 at L = 1200) is exercised
+        conv2 = torch.nn.Conv2d(1200, 3, 1, bias=False)
+        conv2.weight.data = torch.randn(3, 1200, 1, 1, generator=g) * 0.1
+        bn = torch.nn.BatchNorm2d(3)
+        bn.weight.data = torch.rand(3, generator=g) + 0.5
+        bn.bias.data = torch.randn(3, generator=g) * 0.1
+        bn.running_mean = torch.randn(3, generator=g) * 0.1
+        bn.running_var = torch.rand(3, generator=g) + 0.5
+        qb = ref_qm.QuantBnConv2d(4, quant_mode="symmetric", per_channel=True, weight_percentile=pct)
+        qb.set_param(conv2, bn)
+        x2 = torch.randn(2, 1200, 3, 3, generator=g)
+        out["qbn_%s_w" % tag] = conv2.weight.data
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            out["qbn_%s_bn_%s" % (tag, k)] = getattr(bn, k).data if k in ("weight", "bias") else getattr(bn, k)
+        out["qbn_%s_x" % tag] = x2
+        out["qbn_%s_y" % tag] = qb(x2)
+        # depthwise 3x3 weights: L = 9 < 10 -> the 0.95 rule under --wt-percentile
+        wd = torch.randn(5, 1, 3, 3, generator=g) * 0.2
+        w_min = wd.view(5, -1).min(dim=1).values * (0.95 if pct else 1.0)
+        w_max = wd.view(5, -1).max(dim=1).values * (0.95 if pct else 1.0)
+        out["qdw_%s_w" % tag] = wd
+        out["qdw_%s_wq" % tag] = ref_qu.SymmetricQuantFunction.apply(wd, 4, w_min, w_max, True, pct)
+    return t2n(out)
+
+
+def _stage_params(C, Co, g):
+    return dict(
+        w_scale=torch.randn(1, C, 1, 1, generator=g) * (5.0 / C ** 0.5),   # s ~ N(1, 5): both clamps hit
+        b_scale=torch.ones(1),
+        w_dw=torch.empty(C, 1, 3, 3).uniform_(-1, 1, generator=g) / 3.0,
+        w_pw=torch.randn(Co, C, 1, 1, generator=g) * (2.0 / C) ** 0.5,
+    )
+
+
+def _ref_stage(ref_mod, C, Co, p):
+    m = ref_mod.DeformConvWithOffsetScaleBoundPositive(C, Co, 3, 1, 1, groups=Co, hidden_state=128)
+    with torch.no_grad():
+        m.conv_scale.weight.copy_(p["w_scale"])
+        m.conv_scale.bias.copy_(p["b_scale"])
+        m.conv.weight.copy_(p["w_dw"])
+        m.conv_channel.weight.copy_(p["w_pw"])
+    return m
+
+
+def make_stage_fp32(ref_mod):
+    g = torch.Generator().manual_seed(21)
+    N, C, Co, H, W = 2, 16, 8, 12, 12
+    p = _stage_params(C, Co, g)
+    m = _ref_stage(ref_mod, C, Co, p).eval()
+    x = torch.randn(N, C, H, W, generator=g)
+    with torch.no_grad():
+        y = m(x)
+        s = m.conv_bound(m.conv_scale(x))
+    # gradients through the reference composition (oracle backward under it)
+    xg = x.clone().requires_grad_(True)
+    m.zero_grad()
+    yo = m(xg)
+    go = torch.randn(yo.shape, generator=g)
+    yo.backward(go)
+    out = dict(p, x=x, y=y, s=s, go=go, gx=xg.grad, g_w_scale=m.conv_scale.weight.grad,
+               g_b_scale=m.conv_scale.bias.grad, g_w_dw=m.conv.weight.grad,
+               g_w_pw=m.conv_channel.weight.grad)
+    return t2n(out)
+
+
+def make_stage_w4a8(ref_mod, ref_qm):
+    g = torch.Generator().manual_seed(31)
+    N, C, Co, H, W = 2, 16, 8, 12, 12
+    out = {}
+    for pct in (False, True):
+        tag = "p" if pct else "n"
+        p = _stage_params(C, Co, g)
+        m = _ref_stage(ref_mod, C, Co, p)
+        bn = torch.nn.BatchNorm2d(Co)
+        bn.weight.data = torch.rand(Co, generator=g) + 0.5
+        bn.bias.data = torch.randn(Co, generator=g) * 0.1
+        bn.running_mean = torch.randn(Co, generator=g) * 0.1
+        bn.running_var = torch.rand(Co, generator=g) + 0.5
+        q = ref_qm.QuantDeformConvWithOffsetScaleBoundPositive(
+            4, 8, act_percentile=False, wt_quant_mode="symmetric", act_quant_mode="asymmetric",
+            per_channel=True, weight_percentile=pct)
+        q.set_param(m, bn)
+        post = torch.nn.Sequential(torch.nn.ReLU(inplace=True),
+                                   ref_qm.QuantAct(8, quant_mode="asymmetric"))
+        q.eval()
+        for k, v in p.items():
+            out["%s_%s" % (tag, k)] = v
+        for k in ("weight", "bias"):
+            out["%s_bn_%s" % (tag, k)] = getattr(bn, k).data
+        out["%s_bn_running_mean" % tag] = bn.running_mean
+        out["%s_bn_running_var" % tag] = bn.running_var
+        cap = {}
+        q.quant_act.register_forward_hook(lambda mod, i, o: cap.__setitem__("s", o.clone()))
+        q.quant_deform_conv.register_forward_hook(lambda mod, i, o: cap.__setitem__("d", o.clone()))
+        q.quant_identity_deform.register_forward_hook(lambda mod, i, o: cap.__setitem__("dq", o.clone()))
+        for it in range(3):
+            x = torch.randn(N, C, H, W, generator=g) * (1.0 + 0.3 * it)
+            with torch.no_grad():
+                y = q(x)
+                r = post(y.clone())
+            out["%s_x%d" % (tag, it)] = x
+            out["%s_y%d" % (tag, it)] = y
+            out["%s_r%d" % (tag, it)] = r
+            for k in ("s", "d", "dq"):
+                out["%s_%s%d" % (tag, k, it)] = cap[k]
+            out["%s_smin%d" % (tag, it)] = q.quant_act[1].x_min.clone()
+            out["%s_smax%d" % (tag, it)] = q.quant_act[1].x_max.clone()
+            out["%s_dmin%d" % (tag, it)] = q.quant_identity_deform.x_min.clone()
+            out["%s_dmax%d" % (tag, it)] = q.quant_identity_deform.x_max.clone()
+            out["%s_rmin%d" % (tag, it)] = post[1].x_min.clone()
+            out["%s_rmax%d" % (tag, it)] = post[1].x_max.clone()
+    return t2n(out)
+
+
+def make_deform_raw():
+    g = torch.Generator().manual_seed(41)
+    out = {}
+    cases = {"a": (2, 8, 9, 9, 8, 3, 1, 1, 1, 8, 1), "b": (1, 6, 8, 10, 4, 3, 2, 1, 1, 2, 3)}
+    for tag, (N, C, H, W, Co, k, s, p, d, G, DG) in cases.items():
+        Ho, Wo = O.out_size(H, W, k, k, s, p, d)
+        x = torch.randn(N, C, H, W, generator=g)
+        off = torch.randn(N, DG * 2 * k * k, Ho, Wo, generator=g) * 2
+        off[0, :, 0, 0] = 50.0          # far out of range -> zero samples, zero grads
+        w = torch.randn(Co, C // G, k, k, generator=g)
+        m = torch.rand(N, DG * k * k, Ho, Wo, generator=g)
+        b = torch.randn(Co, generator=g)
+        go = torch.randn(N, Co, Ho, Wo, generator=g)
+        cfg = (s, p, d, G, DG)
+        out[tag + "_cfg"] = np.array([N, C, H, W, Co, k, s, p, d, G, DG])
+        out.update({tag + "_x": x, tag + "_off": off, tag + "_w": w, tag + "_m": m, tag + "_b": b,
+                    tag + "_go": go})
+        out[tag + "_y"] = O.deform_conv_forward(x, off, w, *cfg)
+        gx, goff = O.deform_conv_backward_input(x, off, w, go, *cfg)
+        out[tag + "_gx"], out[tag + "_goff"] = gx, goff
+        out[tag + "_gw"] = O.deform_conv_backward_params(x, off, tuple(w.shape), go, *cfg)
+        out[tag + "_my"] = O.deform_conv_forward(x, off, w, *cfg, mask=m, bias=b)
+        mgx, mgoff, mgm = O.deform_conv_backward_input(x, off, w, go, *cfg, mask=m)
+        mgw, mgb = O.deform_conv_backward_params(x, off, tuple(w.shape), go, *cfg, mask=m,
+                                                 with_bias=True)
+        out.update({tag + "_mgx": mgx, tag + "_mgoff": mgoff, tag + "_mgm": mgm, tag + "_mgw": mgw,
+                    tag + "_mgb": mgb})
+    return t2n(out)
+
+
+def main():
+    assert os.path.isdir(REF), "needs the reference checkout at /root/reference"
+    torch.manual_seed(317)
+    torch.set_num_threads(1)
+    ref_mod, ref_qm, ref_qu = import_reference()
+    np.savez_compressed(os.path.join(HERE, "quant_ref.npz"), **make_quant_ref(ref_qm, ref_qu))
+    np.savez_compressed(os.path.join(HERE, "stage_fp32.npz"), **make_stage_fp32(ref_mod))
+    np.savez_compressed(os.path.join(HERE, "stage_w4a8.npz"), **make_stage_w4a8(ref_mod, ref_qm))
+    np.savez_compressed(os.path.join(HERE, "deform_raw.npz"), **make_deform_raw())
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,246 @@
+"""CPU-side checks (-m "not gpu"): the C-ABI library loads and exports every symbol the header
+declares, the Python operator API has the reference's surface (names, ctor signatures, parameter
+/ buffer names), the device-agnostic quantiser code reproduces the reference's golden vectors, and
+the product refuses CPU tensors exactly like the reference.  No GPU compute here."""
+import inspect
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "codenet_dcn.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cdn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from codenet_amd import _native
+    if not os.path.exists(_native.SO_PATH):
+        _native.build()
+    lib = _native.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 13
+    for s in syms:
+        assert hasattr(lib, s), "libcodenet_dcn.so does not export %s" % s
+        assert s in _native._SIGNATURES, "no ctypes signature for %s" % s
+    assert set(_native._SIGNATURES) == set(syms)
+    assert lib.cdn_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Shape / argument errors are detected before any HIP call, so they can be checked here."""
+    from codenet_amd import _native
+    lib = _native.lib()
+    one = 4096  # any non-null fake pointer: validation must fail before it is dereferenced
+    rc = lib.cdn_deform_conv_forward(one, one, one, one, 0, 1, 4, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, 1,
+                                     3, 1, None)       # 4 channels not divisible by group 3
+    assert rc == -2 and b"group" in lib.cdn_last_error()
+    rc = lib.cdn_deform_conv_forward(None, one, one, one, 0, 1, 4, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, 1,
+                                     1, 1, None)
+    assert rc == -1
+    rc = lib.cdn_deform_conv_forward(one, one, one, one, 7, 1, 4, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, 1,
+                                     1, 1, None)
+    assert rc == -3
+    rc = lib.cdn_deform_conv_forward(one, one, one, one, 0, 1, 4, 2, 2, 4, 3, 3, 1, 1, 0, 0, 1, 1,
+                                     1, 1, None)       # 2x2 input, 3x3 kernel, no padding
+    assert rc == -2 and b"too small" in lib.cdn_last_error()
+    rc = lib.cdn_codenet_pointwise_forward(one, one, None, one, None, one, 1, 4, 4, 16, 0, None)
+    assert rc == -1                                     # ep_scale without ep_shift
+
+
+def test_cpu_tensors_raise_not_implemented():
+    from codenet_amd.functions.dcn_deform_conv import deform_conv, modulated_deform_conv
+    from codenet_amd import ops
+    x = torch.randn(1, 4, 6, 6)
+    off = torch.zeros(1, 18, 6, 6)
+    w = torch.randn(4, 1, 3, 3)
+    with pytest.raises(NotImplementedError):      # functions/dcn_deform_conv.py:43-45
+        deform_conv(x, off, w, 1, 1, 1, 4, 1)
+    with pytest.raises(NotImplementedError):
+        modulated_deform_conv(x, off, torch.ones(1, 9, 6, 6), w, None, 1, 1, 1, 4, 1)
+    with pytest.raises(NotImplementedError):
+        ops.codenet_dw(x, torch.ones(1, 1, 6, 6), w)
+    with pytest.raises(ValueError):               # :24-27
+        deform_conv(x[0], off, w, 1, 1, 1, 4, 1)
+
+
+def test_module_surface_and_checkpoint_keys():
+    from codenet_amd.modules import dcn_deform_conv as M
+    m = M.DeformConvWithOffsetScaleBoundPositive(32, 16, 3, 1, 1, groups=16, bias=False,
+                                                  hidden_state=128, BN_MOMENTUM=0.1)
+    assert sorted(m.state_dict().keys()) == sorted(
+        ["conv_scale.weight", "conv_scale.bias", "conv.weight", "conv_channel.weight"])
+    assert tuple(m.conv_scale.weight.shape) == (1, 32, 1, 1)
+    assert tuple(m.conv.weight.shape) == (32, 1, 3, 3) and m.conv.groups == 32
+    assert tuple(m.conv_channel.weight.shape) == (16, 32, 1, 1)
+    assert m.conv_scale.weight.abs().max().item() == 0 and m.conv_scale.bias.item() == 1.0
+    assert (m.conv_bound.min_val, m.conv_bound.max_val) == (-7, 8)
+    assert tuple(m.anchor_offset.shape) == (1, 18, 1, 1)
+    assert m.anchor_offset.view(-1).tolist() == [-1, -1, -1, 0, -1, 1, 0, -1, 0, 0, 0, 1, 1, -1, 1, 0, 1, 1]
+    # C == Co: no conv_channel (reference :327-330)
+    m2 = M.DeformConvWithOffsetScaleBoundPositive(8, 8)
+    assert "conv_channel.weight" not in m2.state_dict()
+    sig = inspect.signature(M.DeformConv.__init__)
+    assert list(sig.parameters)[1:] == ["in_channels", "out_channels", "kernel_size", "stride",
+                                        "padding", "dilation", "groups", "deformable_groups", "bias"]
+    sig = inspect.signature(M.ModulatedDeformConv.__init__)
+    assert sig.parameters["padding"].default == 0 and sig.parameters["kernel_size"].default is inspect._empty
+    for name in ["DeformConvPack", "DeformConvPack1x1", "DeformConvPackDW", "ModulatedDeformConvPack",
+                 "DeformConvWithOffsetBound", "DeformConvWithOffsetRound", "DeformConvWithOffsetScale",
+                 "DeformConvWithOffsetScaleBound", "ModulatedDeformConvWithOffsetScaleBoundPositive",
+                 "ModulatedDeformConvWithOffset1x1ScaleBoundPositive"]:
+        assert hasattr(M, name)
+    p = M.ModulatedDeformConvPack(4, 6, 3, stride=1, padding=1, bias=True)
+    assert sorted(p.state_dict()) == sorted(["weight", "bias", "conv_offset_mask.weight",
+                                             "conv_offset_mask.bias"])
+
+
+def _toy_stage_stack():
+    from codenet_amd.modules import dcn_deform_conv as M
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            layers = []
+            for cin, cout in ((32, 16), (16, 8), (8, 4)):
+                layers += [M.DeformConvWithOffsetScaleBoundPositive(cin, cout, 3, 1, 1, groups=cout),
+                           nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                           nn.Upsample(scale_factor=2, mode="nearest")]
+            self.deconv_layers = nn.Sequential(*layers)
+    return Net()
+
+
+def test_quantized_stage_checkpoint_keys():
+    from codenet_amd.portable_quantizer import quantize_deform_stages
+    net = _toy_stage_stack()
+    quantize_deform_stages(net, 4, 8, "symmetric", "asymmetric", True, False, False)
+    keys = set(net.state_dict().keys())
+    for i, j in ((0, 1), (3, 4), (6, 7)):
+        pre = "deconv_layers.%d." % i
+        for k in ["quant_conv_scale.weight", "quant_conv_scale.bias", "quant_act.1.x_min",
+                  "quant_act.1.x_max", "quant_deform_conv.weight", "quant_identity_deform.x_min",
+                  "quant_identity_deform.x_max", "quant_conv_channel_bn.conv.weight",
+                  "quant_conv_channel_bn.bn.weight", "quant_conv_channel_bn.bn.bias",
+                  "quant_conv_channel_bn.bn.running_mean", "quant_conv_channel_bn.bn.running_var",
+                  "quant_conv_channel_bn.bn.num_batches_tracked"]:
+            assert pre + k in keys, pre + k
+        assert "deconv_layers.%d.1.x_min" % j in keys and "deconv_layers.%d.1.x_max" % j in keys
+    assert len(net.deconv_layers) == 9
+
+
+def test_quantizer_torch_path_matches_reference_golden():
+    """The device-agnostic quantiser code (used for weights everywhere and for autograd) against
+    vectors from the reference's own modules."""
+    from codenet_amd.portable_quantizer import quant_modules as QM
+    from codenet_amd.portable_quantizer.quantization_utils import quant_utils as QU
+    z = load("quant_ref.npz")
+    qa = QM.QuantAct(8, quant_mode="asymmetric")
+    for it in range(4):
+        y = qa(z["act_x%d" % it])
+        assert torch.equal(qa.x_min, z["act_min%d" % it]) and torch.equal(qa.x_max, z["act_max%d" % it])
+        assert torch.equal(y, z["act_y%d" % it])
+    qp = QM.QuantAct(8, quant_mode="asymmetric", percentile=True)
+    for it in range(2):
+        y = qp(z["pact_x%d" % it])
+        assert torch.equal(qp.x_min, z["pact_min%d" % it]) and torch.equal(y, z["pact_y%d" % it])
+    for tag, pct in (("n", False), ("p", True)):
+        conv = nn.Conv2d(40, 6, 1, bias=True)
+        conv.weight.data, conv.bias.data = z["qconv_%s_w" % tag], z["qconv_%s_b" % tag]
+        qc = QM.Quant_Conv2d(4, quant_mode="symmetric", per_channel=True, weight_percentile=pct)
+        qc.set_param(conv)
+        with torch.no_grad():
+            assert (qc(z["qconv_%s_x" % tag]) - z["qconv_%s_y" % tag]).abs().max().item() < 1e-5
+            assert qc.quantized_weight() is qc.quantized_weight()          # inference cache
+        conv2 = nn.Conv2d(1200, 3, 1, bias=False)
+        conv2.weight.data = z["qbn_%s_w" % tag]
+        bn = nn.BatchNorm2d(3)
+        bn.weight.data, bn.bias.data = z["qbn_%s_bn_weight" % tag], z["qbn_%s_bn_bias" % tag]
+        bn.running_mean, bn.running_var = z["qbn_%s_bn_running_mean" % tag], z["qbn_%s_bn_running_var" % tag]
+        qb = QM.QuantBnConv2d(4, quant_mode="symmetric", per_channel=True, weight_percentile=pct)
+        qb.set_param(conv2, bn)
+        with torch.no_grad():
+            assert (qb(z["qbn_%s_x" % tag]) - z["qbn_%s_y" % tag]).abs().max().item() < 1e-4
+        wd = z["qdw_%s_w" % tag]
+        lo, hi = QM._channel_range(wd.view(5, -1), pct)
+        assert torch.equal(QU.SymmetricQuantFunction.apply(wd, 4, lo, hi, True, pct), z["qdw_%s_wq" % tag])
+
+
+def test_weight_cache_invalidated_by_in_place_update():
+    from codenet_amd.portable_quantizer import quant_modules as QM
+    conv = nn.Conv2d(12, 3, 1, bias=False)
+    qc = QM.Quant_Conv2d(4, quant_mode="symmetric", per_channel=True)
+    qc.set_param(conv)
+    with torch.no_grad():
+        a = qc.quantized_weight()
+        qc.weight.mul_(2.0)
+        b = qc.quantized_weight()
+    assert a is not b and torch.allclose(b, 2 * a)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_drop_in_under_reference_network():
+    """The reference's own PoseShuffleNetV2 (imported from /root/reference, not copied) builds on
+    OUR operator module when it is installed at the reference's import path, and our quantiser
+    rewrites it to the same module tree / checkpoint keys as the reference's quantiser."""
+    code = r'''
+import sys, types, os
+ROOT, REF = sys.argv[1], sys.argv[2]
+sys.path.insert(0, ROOT)
+for name in ["pytorchcv", "pytorchcv.model_provider", "pytorchcv.models", "pytorchcv.models.shufflenetv2",
+             "pytorchcv.models.common", "thop", "_ext", "_ext.dcn", "_ext.dcn.dcn_deform_conv_cuda"]:
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["pytorchcv.model_provider"].get_model = lambda *a, **k: None
+sys.modules["pytorchcv.models.shufflenetv2"].ShuffleUnit = type("ShuffleUnit", (), {})
+sys.modules["pytorchcv.models.common"].ChannelShuffle = type("ChannelShuffle", (), {})
+sys.modules["thop"].profile = lambda *a, **k: (0, 0)
+sys.path.insert(0, os.path.join(REF, "lib")); sys.path.insert(0, REF)
+import torch
+mode = sys.argv[3]
+if mode == "ours":
+    import codenet_amd.modules.dcn_deform_conv as ours
+    import models, models.external                      # reference packages (namespace)
+    pkg = types.ModuleType("models.external.modules"); pkg.__path__ = []
+    pkg.dcn_deform_conv = ours
+    sys.modules["models.external.modules"] = pkg
+    sys.modules["models.external.modules.dcn_deform_conv"] = ours
+    from codenet_amd.portable_quantizer import quantize_shufflenetv2_dcn
+else:
+    from portable_quantizer import quantize_shufflenetv2_dcn
+from models.networks.shufflenetv2_dcn import PoseShuffleNetV2
+torch.manual_seed(0)
+net = PoseShuffleNetV2({"hm": 20, "wh": 2, "reg": 2}, 64)
+k_fp = sorted((k, tuple(v.shape)) for k, v in net.state_dict().items())
+cls = type(net.deconv_layers[0]).__module__
+quantize_shufflenetv2_dcn(net, 4, None, 8, "symmetric", "asymmetric", True, False, False, False)
+k_q = sorted((k, tuple(v.shape)) for k, v in net.state_dict().items())
+import json
+print(json.dumps({"cls": cls, "fp": k_fp, "q": k_q}))
+'''
+    import json
+    import subprocess
+    outs = {}
+    for mode in ("ours", "ref"):
+        r = subprocess.run([sys.executable, "-c", code, ROOT, REF, mode], capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert outs["ours"]["cls"] == "codenet_amd.modules.dcn_deform_conv"
+    assert outs["ours"]["fp"] == outs["ref"]["fp"]
+    assert outs["ours"]["q"] == outs["ref"]["q"]
+    assert len(outs["ours"]["q"]) > 300

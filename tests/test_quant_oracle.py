@@ -1,0 +1,96 @@
+"""Pins oracle/quant.py (the restatement of the reference's quantisation arithmetic and stage
+compositions) against golden vectors produced by the REFERENCE'S OWN Python modules
+(tests/golden/make_golden.py).  quant_ref.npz involves no oracle code at all.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import quant as Q
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def test_quantact_state_and_codes_exact():
+    z = load("quant_ref.npz")
+    st = Q.QuantActState(bits=8)
+    for it in range(4):
+        y, q = st(z["act_x%d" % it], running=True, return_codes=True)
+        assert torch.equal(st.x_min, z["act_min%d" % it]) and torch.equal(st.x_max, z["act_max%d" % it])
+        assert torch.equal(q, z["act_q%d" % it])
+        assert torch.equal(y, z["act_y%d" % it])
+    # codes really leave the int8 range (unclamped asymmetric branch)
+    assert z["act_q1"].max() > 127 or z["act_q1"].min() < -128
+
+
+def test_quantact_percentile_exact():
+    z = load("quant_ref.npz")
+    st = Q.QuantActState(bits=8)
+    for it in range(2):
+        y = st(z["pact_x%d" % it], running=True, percentile=True)
+        assert torch.equal(st.x_min, z["pact_min%d" % it]) and torch.equal(st.x_max, z["pact_max%d" % it])
+        assert torch.equal(y, z["pact_y%d" % it])
+
+
+@pytest.mark.parametrize("tag,pct", [("n", False), ("p", True)])
+def test_weight_quant_exact(tag, pct):
+    z = load("quant_ref.npz")
+    wq = Q.weight_fake_quant(z["qconv_%s_w" % tag], 4, pct)
+    y = torch.nn.functional.conv2d(z["qconv_%s_x" % tag], wq, z["qconv_%s_b" % tag])
+    # conv outputs: summation order depends on the CPU thread count, so compare to 1e-5 -- a single
+    # wrong 4-bit weight code would move y by >= |w|/7 * |x| ~ 1e-2
+    assert (y - z["qconv_%s_y" % tag]).abs().max().item() < 1e-5
+    wf, bf = Q.fold_bn(z["qbn_%s_w" % tag], None, z["qbn_%s_bn_weight" % tag], z["qbn_%s_bn_bias" % tag],
+                       z["qbn_%s_bn_running_mean" % tag], z["qbn_%s_bn_running_var" % tag], 1e-5)
+    y2 = torch.nn.functional.conv2d(z["qbn_%s_x" % tag], Q.weight_fake_quant(wf, 4, pct), bf)
+    assert (y2 - z["qbn_%s_y" % tag]).abs().max().item() < 1e-4
+    assert torch.equal(Q.weight_fake_quant(z["qdw_%s_w" % tag], 4, pct), z["qdw_%s_wq" % tag])
+
+
+def test_stage_fp32_matches_reference_module():
+    z = load("stage_fp32.npz")
+    r = Q.stage_fp32(z["x"], z["w_scale"], z["b_scale"], z["w_dw"], z["w_pw"])
+    assert (r["s"] - z["s"]).abs().max().item() < 5e-6     # conv summation order (threads)
+    assert (r["y"] - z["y"]).abs().max().item() < 1e-4
+    assert z["s"].min().item() == -7.0 and z["s"].max().item() == 8.0   # both clamps exercised
+
+
+@pytest.mark.parametrize("tag,pct", [("n", False), ("p", True)])
+def test_stage_w4a8_matches_reference_module(tag, pct):
+    z = load("stage_w4a8.npz")
+    bn = (z[tag + "_bn_weight"], z[tag + "_bn_bias"], z[tag + "_bn_running_mean"],
+          z[tag + "_bn_running_var"], 1e-5)
+    act_s, act_d, act_r = Q.QuantActState(), Q.QuantActState(), Q.QuantActState()
+    for it in range(3):
+        r = Q.stage_w4a8(z["%s_x%d" % (tag, it)], z[tag + "_w_scale"], z[tag + "_b_scale"],
+                         z[tag + "_w_dw"], z[tag + "_w_pw"], bn, act_s, act_d, wt_percentile=pct)
+        # (conv summation order may differ by thread count: ranges to 1e-6 rel, values to 1 LSB)
+        def close(a, b, tol):
+            return (a - b).abs().max().item() <= tol
+        assert close(act_s.x_min, z["%s_smin%d" % (tag, it)], 5e-6)
+        assert close(act_s.x_max, z["%s_smax%d" % (tag, it)], 5e-6)
+        assert close(r["s"], z["%s_s%d" % (tag, it)], 5e-6)
+        assert close(r["d"], z["%s_d%d" % (tag, it)], 1e-5)
+        assert close(act_d.x_min, z["%s_dmin%d" % (tag, it)], 1e-5)
+        assert close(r["d_q"], z["%s_dq%d" % (tag, it)], 1e-5)
+        assert close(r["y"], z["%s_y%d" % (tag, it)], 1e-4)
+        post = act_r(torch.relu(r["y"]))
+        assert close(post, z["%s_r%d" % (tag, it)], 1e-4)
+        assert close(act_r.x_max, z["%s_rmax%d" % (tag, it)], 1e-4)
+
+
+def test_deform_raw_regression():
+    """oracle-only vectors: guards the C oracle against accidental change."""
+    from oracle import dcn as O
+    z = load("deform_raw.npz")
+    for tag in ("a", "b"):
+        N, C, H, W, Co, k, s, p, d, Gr, DG = [int(v) for v in z[tag + "_cfg"]]
+        cfg = (s, p, d, Gr, DG)
+        y = O.deform_conv_forward(z[tag + "_x"], z[tag + "_off"], z[tag + "_w"], *cfg)
+        assert torch.equal(y, z[tag + "_y"])
+        assert y[0, :, 0, 0].abs().max().item() == 0.0      # out-of-range samples
