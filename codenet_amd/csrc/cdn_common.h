@@ -37,7 +37,53 @@ struct Geom {
 int make_geom(Geom *g, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kH, int kW,
               int sH, int sW, int pH, int pW, int dH, int dW, int group, int dg);
 
+// ---- QuantAct device state (codenet_quant.hip) --------------------------------------------------
+// 8 x 4-byte words: [0] ordered-uint batch min, [1] ordered-uint batch max, [2] scale (f32),
+// [3] zero-point (f32), [4] batch min (f32), [5] batch max (f32), [6..7] reserved.
+constexpr int kQStateWords = 8;
+
+// Reset the running batch min/max of up to three states (null entries skipped): 1 launch.
+void launch_minmax_init(unsigned *s0, unsigned *s1, unsigned *s2, hipStream_t st);
+// Range tracking + scale / zero-point derivation (1 thread), see quantact_update_kernel.
+void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
+                            const float *ext_max, int bits, double momentum, int running,
+                            hipStream_t st);
+
 }  // namespace cdn
+
+#ifdef __HIPCC__
+namespace cdn {
+// Order-preserving float <-> uint map so min/max can use integer atomics.
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+// q = round(scale*x - zp) (half-even), no FMA contraction: quant_utils.py:33-41
+__device__ __forceinline__ float quant_code(float x, float scale, float zp) {
+  return rintf(__fsub_rn(__fmul_rn(scale, x), zp));
+}
+// (q + zp) / scale, true division: quant_utils.py:44-52
+__device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
+  return __fdiv_rn(__fadd_rn(quant_code(x, scale, zp), zp), scale);
+}
+// Block-level min/max -> two integer atomics on the state words.  All threads must call it.
+__device__ __forceinline__ void block_minmax_commit(float mn, float mx, unsigned *state) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&state[0], f2ord(mn));
+    atomicMax(&state[1], f2ord(mx));
+  }
+}
+}  // namespace cdn
+#endif
 
 #define CDN_REQUIRE(cond, code, ...) \
   do {                               \

@@ -1,0 +1,653 @@
+// codenet_fused.hip -- one CoDeNet up-sampling stage as a fused kernel schedule (gfx950).
+//
+// What the reference runs per stage (W4A8: quant_modules.py:668-671 + quantize_model.py:79-81;
+// fp32: modules/dcn_deform_conv.py:323-330 + shufflenetv2_dcn.py:303-308):
+//     conv_scale -> Hardtanh -> [QuantAct] -> deform depthwise 3x3 -> [QuantAct] ->
+//     conv_channel (+BN) -> ReLU -> [QuantAct] -> Upsample x2
+// as ~12 framework ops with every tensor round-tripping through memory.  Here a stage is
+//     scale (+min/max)  ->  [range update]  ->  gather/depthwise (+min/max)  ->  [range update]
+//     ->  pointwise MFMA (+bias/BN, ReLU, min/max)  ->  [range update]
+// with * QuantAct min/max reductions folded into the producing kernel's epilogue,
+//      * fake-quantisation applied by the CONSUMER while it loads (same fp32 expression, so the
+//        values are bit-identical to materialising them),
+//      * the nearest x2 up-sampling folded into the consumer's addressing (the stage input is
+//        kept at half resolution; scale prediction runs at half resolution: 4x less work),
+//      * channels-last intermediates so every wave access is a contiguous row.
+//
+// gather/depthwise kernel (dw2): lane <-> 4 channels, 16 (or 8) lanes <-> one output pixel.
+// The low-resolution input plane of CCH channels lives in LDS as [cell][CCH] rows with a zero
+// border; a tap corner is ONE ds_read_b128 per lane.  With CCH = 64 a row is exactly the 64 LDS
+// banks, so bank == channel and the read is conflict-free for ANY data-dependent cell -- the
+// per-lane-column conflicts of the NCHW kernel (codenet_stage.hip) cannot occur.
+#include "cdn_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using cdn::fake_quant;
+
+struct Axis {
+  int i0;
+  float w0, w1;
+  bool ok;
+};
+
+// Same fp32 position arithmetic as the reference pipeline `h_in + i*dil + anchor*(s-1)`
+// (_kernel.cu:226 with modules/dcn_deform_conv.py:325); see codenet_stage.hip.
+__device__ __forceinline__ Axis make_axis(int base, float off, int size) {
+  Axis a;
+  const float pos = (float)base + off;
+  a.ok = pos > -1.0f && pos < (float)size;
+  const float fl = floorf(pos);
+  a.i0 = (int)fl;
+  const float l = pos - fl;
+  a.w1 = l;
+  a.w0 = 1.0f - l;
+  if (!a.ok) {
+    a.i0 = 0;
+    a.w0 = 0.0f;
+    a.w1 = 0.0f;
+  }
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------
+// scale, NCHW input (stage 0 of the model: x comes from the PyTorch backbone).
+// s[n,p] = clamp(b + sum_c w[c]*x[n,c,p]); block min/max -> state.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                  const float *__restrict__ b, float *__restrict__ s, unsigned *mm, int C, int HW,
+                  float lo, float hi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  const int n = blockIdx.y;
+  const bool live = p < HW;
+  const float *xp = x + (long)n * C * HW + (live ? p : 0);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int c = wave;
+  for (; c + 12 < C; c += 16) {
+    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + 4) * HW];
+    const float v2 = xp[(long)(c + 8) * HW], v3 = xp[(long)(c + 12) * HW];
+    a0 = fmaf(w[c], v0, a0);
+    a1 = fmaf(w[c + 4], v1, a1);
+    a2 = fmaf(w[c + 8], v2, a2);
+    a3 = fmaf(w[c + 12], v3, a3);
+  }
+  for (; c < C; c += 4) a0 = fmaf(w[c], xp[(long)c * HW], a0);
+  __shared__ float red[4][64];
+  red[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0) {
+    float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    v += b ? b[0] : 0.0f;
+    v = fminf(fmaxf(v, lo), hi);
+    if (live) s[(long)n * HW + p] = v;
+    if (mm) {
+      float mn = live ? v : INFINITY, mx = live ? v : -INFINITY;
+      cdn::block_minmax_commit(mn, mx, mm);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// scale, channels-last input x[pix][C] (stored resolution), optional fake-quant on load.
+// One wave per pixel step; lane covers channels 4*lane + 256*j (float4 loads: C % 4 == 0).
+// ------------------------------------------------------------------------------------------
+template <bool XQ>
+__global__ void __launch_bounds__(256)
+scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+                  const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ s,
+                  unsigned *mm, int C, long npix, float lo, float hi) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  float qs = 1.f, qz = 0.f;
+  if (XQ) {
+    qs = reinterpret_cast<const float *>(xq)[2];
+    qz = reinterpret_cast<const float *>(xq)[3];
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  for (long p = wave; p < npix; p += nwaves) {
+    const float *xp = x + p * C;
+    float acc = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 v = *reinterpret_cast<const float4 *>(xp + c);
+      const float4 ww = *reinterpret_cast<const float4 *>(w + c);
+      if (XQ) {
+        v.x = fake_quant(v.x, qs, qz);
+        v.y = fake_quant(v.y, qs, qz);
+        v.z = fake_quant(v.z, qs, qz);
+        v.w = fake_quant(v.w, qs, qz);
+      }
+      acc = fmaf(ww.x, v.x, acc);
+      acc = fmaf(ww.y, v.y, acc);
+      acc = fmaf(ww.z, v.z, acc);
+      acc = fmaf(ww.w, v.w, acc);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    float v = acc + (b ? b[0] : 0.0f);
+    v = fminf(fmaxf(v, lo), hi);
+    if (lane == 0) s[p] = v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  if (mm) cdn::block_minmax_commit(mn, mx, mm);
+}
+
+// ------------------------------------------------------------------------------------------
+// dw2: gather + depthwise 3x3, lanes <-> channels.  See file header.
+//   x        stage input at STORED resolution (Hl x Wl = (H>>up) x (W>>up)):
+//            NHWC_IN ? [n][Hl*Wl][C] : [n][C][Hl*Wl]
+//   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
+//   d        [n][H*W][C] channels-last output at stage resolution
+// ------------------------------------------------------------------------------------------
+constexpr int kDw2Threads = 512;
+
+template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
+__global__ void __launch_bounds__(kDw2Threads)
+dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+           const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
+           const float *__restrict__ wd, float *__restrict__ d, unsigned *dmm, int C, int H, int W,
+           int up) {
+  extern __shared__ float4 img[];  // [cells][LPP] float4
+  constexpr int LPP = CCH / 4;     // lanes per pixel
+  constexpr int PPW = 64 / LPP;    // pixels per wave step
+  const int Hl = H >> up, Wl = W >> up, Wp = Wl + 2;
+  const int cells = (Hl + 2) * Wp;
+  const int HWl = Hl * Wl, HW = H * W;
+  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  const int tid = threadIdx.x;
+  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
+  if (XQ) {
+    xs = reinterpret_cast<const float *>(xq)[2];
+    xz = reinterpret_cast<const float *>(xq)[3];
+  }
+  if (SQ) {
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
+  }
+
+  // ---- zero border: top/bottom rows, left/right columns ---------------------------------
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = tid; q < 2 * Wp * LPP; q += kDw2Threads) {
+    const int cell = (q / LPP) < Wp ? (q / LPP) : (cells - 2 * Wp + q / LPP);
+    img[cell * LPP + (q % LPP)] = z4;
+  }
+  for (int q = tid; q < 2 * Hl * LPP; q += kDw2Threads) {
+    const int r = (q / LPP) >> 1, side = (q / LPP) & 1;
+    img[((r + 1) * Wp + (side ? Wp - 1 : 0)) * LPP + (q % LPP)] = z4;
+  }
+  // ---- stage the interior ----------------------------------------------------------------
+  if (NHWC_IN) {
+    const float *xg = x + (long)n * HWl * C + c0;
+    for (int q = tid; q < HWl * LPP; q += kDw2Threads) {
+      const int pix = q / LPP, cq = q % LPP;
+      float4 v = z4;
+      if (c0 + cq * 4 + 3 < C) v = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq * 4);
+      if (XQ) {
+        v.x = fake_quant(v.x, xs, xz);
+        v.y = fake_quant(v.y, xs, xz);
+        v.z = fake_quant(v.z, xs, xz);
+        v.w = fake_quant(v.w, xs, xz);
+      }
+      const int yy = pix / Wl, xx = pix - yy * Wl;
+      img[((yy + 1) * Wp + xx + 1) * LPP + cq] = v;
+    }
+  } else {
+    // lane <-> channel so the four scalar LDS stores of a wave hit consecutive banks
+    float *imgf = reinterpret_cast<float *>(img);
+    const int quads = (HWl + 3) >> 2;
+    for (int q = tid; q < quads * CCH; q += kDw2Threads) {
+      const int cl = q % CCH, j = q / CCH;
+      const int c = c0 + cl;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        const float *xp = x + ((long)n * C + c) * HWl + j * 4;
+        if ((HWl & 3) == 0) {
+          const float4 t = *reinterpret_cast<const float4 *>(xp);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j * 4 + e < HWl) v[e] = xp[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pix = j * 4 + e;
+        if (pix < HWl) {
+          const int yy = pix / Wl, xx = pix - yy * Wl;
+          float t = v[e];
+          if (XQ) t = fake_quant(t, xs, xz);
+          imgf[((yy + 1) * Wp + xx + 1) * CCH + cl] = t;
+        }
+      }
+    }
+  }
+  // ---- this lane's depthwise weights: 4 channels x 9 taps ----------------------------------
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cq = lane % LPP, sub = lane / LPP;
+  float wk[9][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + cq * 4 + e;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = (c < C) ? wd[(long)c * 9 + k] : 0.0f;
+  }
+  __syncthreads();
+
+  float mn = INFINITY, mx = -INFINITY;
+  const bool vec_store = ((C & 3) == 0);
+  constexpr int kWaves = kDw2Threads / 64;
+  for (int p0 = wave * PPW; p0 < HW; p0 += kWaves * PPW) {
+    const int p = p0 + sub;
+    if (p >= HW) continue;
+    const int h = p / W, w = p - h * W;
+    float sv = s_raw[(long)n * HWl + (h >> up) * Wl + (w >> up)];
+    if (SQ) sv = fake_quant(sv, ss, sz);
+    const float t = sv - 1.0f;
+    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    // LDS row (in float4 units) of hi-res coordinate pair (yy, xx); yy, xx in [-1, size]
+#define CDN_CELL(yy, xx) (((((yy) >> up) + 1) * Wp + ((xx) >> up) + 1) * LPP + cq)
+#define CDN_ACC4(A, WT, V)            \
+  A.x = fmaf(WT, V.x, A.x);           \
+  A.y = fmaf(WT, V.y, A.y);           \
+  A.z = fmaf(WT, V.z, A.z);           \
+  A.w = fmaf(WT, V.w, A.w);
+    float4 acc = z4;
+    // corner taps (4 reads each)
+#define CDN_TAP4(Y, X, K)                                        \
+  {                                                              \
+    const float4 v00 = img[CDN_CELL(Y.i0, X.i0)];                \
+    const float4 v01 = img[CDN_CELL(Y.i0, X.i0 + 1)];            \
+    const float4 v10 = img[CDN_CELL(Y.i0 + 1, X.i0)];            \
+    const float4 v11 = img[CDN_CELL(Y.i0 + 1, X.i0 + 1)];        \
+    const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1;            \
+    const float w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;            \
+    float4 tv;                                                   \
+    tv.x = ((w00 * v00.x + w01 * v01.x) + w10 * v10.x) + w11 * v11.x; \
+    tv.y = ((w00 * v00.y + w01 * v01.y) + w10 * v10.y) + w11 * v11.y; \
+    tv.z = ((w00 * v00.z + w01 * v01.z) + w10 * v10.z) + w11 * v11.z; \
+    tv.w = ((w00 * v00.w + w01 * v01.w) + w10 * v10.w) + w11 * v11.w; \
+    acc.x = fmaf(wk[K][0], tv.x, acc.x);                         \
+    acc.y = fmaf(wk[K][1], tv.y, acc.y);                         \
+    acc.z = fmaf(wk[K][2], tv.z, acc.z);                         \
+    acc.w = fmaf(wk[K][3], tv.w, acc.w);                         \
+  }
+    // vertical edge taps (column exact): 2 reads
+#define CDN_TAPV(Y, K)                                           \
+  {                                                              \
+    const float4 v0 = img[CDN_CELL(Y.i0, w)];                    \
+    const float4 v1 = img[CDN_CELL(Y.i0 + 1, w)];                \
+    float4 tv;                                                   \
+    tv.x = Y.w0 * v0.x + Y.w1 * v1.x;                            \
+    tv.y = Y.w0 * v0.y + Y.w1 * v1.y;                            \
+    tv.z = Y.w0 * v0.z + Y.w1 * v1.z;                            \
+    tv.w = Y.w0 * v0.w + Y.w1 * v1.w;                            \
+    acc.x = fmaf(wk[K][0], tv.x, acc.x);                         \
+    acc.y = fmaf(wk[K][1], tv.y, acc.y);                         \
+    acc.z = fmaf(wk[K][2], tv.z, acc.z);                         \
+    acc.w = fmaf(wk[K][3], tv.w, acc.w);                         \
+  }
+    // horizontal edge taps (row exact): 2 reads
+#define CDN_TAPH(X, K)                                           \
+  {                                                              \
+    const float4 v0 = img[CDN_CELL(h, X.i0)];                    \
+    const float4 v1 = img[CDN_CELL(h, X.i0 + 1)];                \
+    float4 tv;                                                   \
+    tv.x = X.w0 * v0.x + X.w1 * v1.x;                            \
+    tv.y = X.w0 * v0.y + X.w1 * v1.y;                            \
+    tv.z = X.w0 * v0.z + X.w1 * v1.z;                            \
+    tv.w = X.w0 * v0.w + X.w1 * v1.w;                            \
+    acc.x = fmaf(wk[K][0], tv.x, acc.x);                         \
+    acc.y = fmaf(wk[K][1], tv.y, acc.y);                         \
+    acc.z = fmaf(wk[K][2], tv.z, acc.z);                         \
+    acc.w = fmaf(wk[K][3], tv.w, acc.w);                         \
+  }
+    CDN_TAP4(ya, xa, 0)
+    CDN_TAPV(ya, 1)
+    CDN_TAP4(ya, xb, 2)
+    CDN_TAPH(xa, 3)
+    {
+      const float4 vc = img[CDN_CELL(h, w)];
+      acc.x = fmaf(wk[4][0], vc.x, acc.x);
+      acc.y = fmaf(wk[4][1], vc.y, acc.y);
+      acc.z = fmaf(wk[4][2], vc.z, acc.z);
+      acc.w = fmaf(wk[4][3], vc.w, acc.w);
+    }
+    CDN_TAPH(xb, 5)
+    CDN_TAP4(yb, xa, 6)
+    CDN_TAPV(yb, 7)
+    CDN_TAP4(yb, xb, 8)
+#undef CDN_TAP4
+#undef CDN_TAPV
+#undef CDN_TAPH
+#undef CDN_ACC4
+#undef CDN_CELL
+    float *dp = d + ((long)n * HW + p) * C + c0 + cq * 4;
+    const int cbase = c0 + cq * 4;
+    if (vec_store && cbase + 3 < C) {
+      *reinterpret_cast<float4 *>(dp) = acc;
+      mn = fminf(mn, fminf(fminf(acc.x, acc.y), fminf(acc.z, acc.w)));
+      mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
+    } else {
+      const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (cbase + e < C) {
+          dp[e] = a[e];
+          mn = fminf(mn, a[e]);
+          mx = fmaxf(mx, a[e]);
+        }
+    }
+  }
+  if (dmm) cdn::block_minmax_commit(mn, mx, dmm);
+}
+
+// ------------------------------------------------------------------------------------------
+// pw2: R[m][co] = act( sum_c Aq[m][c] * Wp[co][c] + ... ),  m = n*HW + p  (channels-last both
+// sides, the batch folds into M).  f32 MFMA 32x32x2 (exact f32).  A is optionally
+// fake-quantised while it is staged.  Tile 128 (m) x BN (co) x 16 (k); 4 waves stacked in m,
+// each holding BN/32 accumulators.  LDS rows have an odd stride (17) so the operand read
+// `[row = lane&31][k = lane>>5]` is conflict-free with K-contiguous global loads on both sides.
+// MFMA maps: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
+// Here i <-> pixel, j <-> co, so every accumulator register stores 128 contiguous bytes.
+// ------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kPw2BM = 128, kPw2BK = 16, kPw2LD = 17;
+
+template <int BN, bool AQ>
+__global__ void __launch_bounds__(256)
+pw2_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+           const float *__restrict__ Wp, const float *__restrict__ bias,
+           const float *__restrict__ ep_scale, const float *__restrict__ ep_shift,
+           float *__restrict__ R, unsigned *rmm, long M, int C, int Co, int relu) {
+  __shared__ float As[kPw2BM * kPw2LD];
+  __shared__ float Bs[BN * kPw2LD];
+  constexpr int NT = BN / 32;
+  const long m0 = (long)blockIdx.x * kPw2BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float qs = 1.f, qz = 0.f;
+  if (AQ) {
+    qs = reinterpret_cast<const float *>(aq)[2];
+    qz = reinterpret_cast<const float *>(aq)[3];
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+  const bool vec = (C & 3) == 0;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;  // staging: row lr (+64), k quad lk
+  for (int k0 = 0; k0 < C; k0 += kPw2BK) {
+    float a[2][4], b[(BN + 63) / 64][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = m0 + lr + 64 * i;
+      const int k = k0 + lk;
+      if (m < M && vec && k + 3 < C) {
+        const float4 v = *reinterpret_cast<const float4 *>(A + m * C + k);
+        a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[i][e] = (m < M && k + e < C) ? A[m * C + k + e] : 0.0f;
+      }
+      if (AQ) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (m < M && k + e < C) a[i][e] = fake_quant(a[i][e], qs, qz);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (BN + 63) / 64; ++i) {
+      const int co = n0 + lr + 64 * i;
+      const int k = k0 + lk;
+      const bool rowok = (lr + 64 * i < BN) && co < Co;
+      if (rowok && vec && k + 3 < C) {
+        const float4 v = *reinterpret_cast<const float4 *>(Wp + (long)co * C + k);
+        b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[i][e] = (rowok && k + e < C) ? Wp[(long)co * C + k + e] : 0.0f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[(lr + 64 * i) * kPw2LD + lk + e] = a[i][e];
+#pragma unroll
+    for (int i = 0; i < (BN + 63) / 64; ++i)
+      if (lr + 64 * i < BN)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(lr + 64 * i) * kPw2LD + lk + e] = b[i][e];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kPw2BK; kk += 2) {
+      const float av = As[(wave * 32 + (lane & 31)) * kPw2LD + kk + (lane >> 5)];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = Bs[(t * 32 + (lane & 31)) * kPw2LD + kk + (lane >> 5)];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int co = n0 + t * 32 + (lane & 31);
+    float bsv = 0.f, es = 1.f, eh = 0.f;
+    if (co < Co) {
+      if (bias) bsv = bias[co];
+      if (ep_scale) {
+        es = ep_scale[co];
+        eh = ep_shift[co];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < M && co < Co) {
+        float v = acc[t][r] + bsv;
+        if (ep_scale) v = fmaf(v, es, eh);
+        if (relu) v = fmaxf(v, 0.0f);
+        R[m * Co + co] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  if (rmm) cdn::block_minmax_commit(mn, mx, rmm);
+}
+
+// ------------------------------------------------------------------------------------------
+// Final materialisation for the consumer outside the fused path (the detection heads):
+// out[n][c][2h+dy][2w+dx] = fq(r[n][h*W+w][c])   (nearest x2, NCHW, optional fake-quant).
+// One workgroup = (n, one stored row h): reads W*C contiguous floats, transposes through LDS,
+// writes 2 output rows per channel.  up == 0 writes the same resolution (plain NHWC -> NCHW).
+// ------------------------------------------------------------------------------------------
+template <bool RQ>
+__global__ void __launch_bounds__(256)
+unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, float *__restrict__ out,
+              int C, int H, int W, int up) {
+  extern __shared__ float tile[];  // [W][C+1]
+  const int n = blockIdx.y, h = blockIdx.x;
+  const int ld = C + 1;
+  float qs = 1.f, qz = 0.f;
+  if (RQ) {
+    qs = reinterpret_cast<const float *>(rq)[2];
+    qz = reinterpret_cast<const float *>(rq)[3];
+  }
+  const float *rp = r + ((long)n * H + h) * W * C;
+  for (int q = threadIdx.x; q < W * C; q += 256) {
+    const int px = q / C, c = q - px * C;
+    float v = rp[q];
+    if (RQ) v = fake_quant(v, qs, qz);
+    tile[px * ld + c] = v;
+  }
+  __syncthreads();
+  const int f = 1 << up;
+  const int Wo = W * f, Ho = H * f;
+  const int per_c = f * Wo;  // output floats per channel from this row
+  for (int q = threadIdx.x; q < C * per_c; q += 256) {
+    const int c = q / per_c, rem = q - c * per_c;
+    const int dy = rem / Wo, xo = rem - dy * Wo;
+    out[(((long)n * C + c) * Ho + h * f + dy) * Wo + xo] = tile[(xo >> up) * ld + c];
+  }
+}
+
+template <int CCH>
+int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
+               const unsigned *sq, const float *wd, float *d, unsigned *dmm, int N, int C, int H,
+               int W, int up, hipStream_t st) {
+  const int Hl = H >> up, Wl = W >> up;
+  const size_t lds = (size_t)(Hl + 2) * (Wl + 2) * CCH * sizeof(float);
+  dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
+#define CDN_GO(NH, XQ_, SQ_)                                                                  \
+  {                                                                                           \
+    auto kern = dw2_kernel<CCH, NH, XQ_, SQ_>;                                                \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                      \
+    kern<<<grid, kDw2Threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, C, H, W, up);          \
+  }
+  const bool XQ = xq != nullptr, SQ = sq != nullptr;
+  if (nhwc) {
+    if (XQ && SQ) CDN_GO(true, true, true)
+    else if (XQ) CDN_GO(true, true, false)
+    else if (SQ) CDN_GO(true, false, true)
+    else CDN_GO(true, false, false)
+  } else {
+    if (XQ && SQ) CDN_GO(false, true, true)
+    else if (XQ) CDN_GO(false, true, false)
+    else if (SQ) CDN_GO(false, false, true)
+    else CDN_GO(false, false, false)
+  }
+#undef CDN_GO
+  return cdn::check_launch("codenet fused dw");
+}
+
+}  // namespace
+
+extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W,
+                                                    int x_up) {
+  const int64_t HWl = (H >> x_up) * (W >> x_up);
+  // s_raw [N*HWl] + d [N*H*W*C], each rounded up to 256 bytes
+  auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
+  return (size_t)(r(N * HWl * 4) + r(N * H * W * C * 4));
+}
+
+extern "C" int cdn_codenet_stage_fused_forward(
+    const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
+    int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
+    const float *w_dw, const float *w_pw, const float *bias_pw, const float *ep_scale,
+    const float *ep_shift, int relu, float *s_min, float *s_max, void *s_state, float *d_min,
+    float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
+    void *stream) {
+  CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(x_up == 0 || x_up == 1, CDN_ERR_ARG, "x_up must be 0 or 1");
+  CDN_REQUIRE(!x_up || ((H & 1) == 0 && (W & 1) == 0), CDN_ERR_SHAPE,
+              "x_up needs even H, W (got %lld x %lld)", (long long)H, (long long)W);
+  CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
+              "ep_scale / ep_shift must both be set or both be NULL");
+  CDN_REQUIRE((s_state == nullptr) == (s_min == nullptr) && (s_state == nullptr) == (s_max == nullptr) &&
+                  (d_state == nullptr) == (d_min == nullptr) && (d_state == nullptr) == (d_max == nullptr) &&
+                  (r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "each QuantAct needs x_min, x_max and state together");
+  CDN_REQUIRE(!x_nhwc || (C & 3) == 0, CDN_ERR_UNSUPPORTED,
+              "channels-last input needs C %% 4 == 0 (got %lld)", (long long)C);
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31) && N * Co * H * W < (1ll << 31),
+              CDN_ERR_UNSUPPORTED, "shape too large");
+  CDN_REQUIRE(workspace_bytes >= cdn_codenet_stage_workspace_bytes(N, C, H, W, x_up),
+              CDN_ERR_WORKSPACE, "workspace too small");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(r_out) & 15) == 0,
+              CDN_ERR_ARG, "x / r_out must be 16-byte and workspace 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const int Hl = (int)(H >> x_up), Wl = (int)(W >> x_up);
+  const int64_t HWl = (int64_t)Hl * Wl;
+  float *s_raw = static_cast<float *>(workspace);
+  float *d = reinterpret_cast<float *>(static_cast<char *>(workspace) + (N * HWl * 4 + 255) / 256 * 256);
+  unsigned *sst = static_cast<unsigned *>(s_state), *dst = static_cast<unsigned *>(d_state),
+           *rst = static_cast<unsigned *>(r_state);
+  const unsigned *xq = static_cast<const unsigned *>(x_qstate);
+
+  // LDS budget of the gather kernel decides the channel chunk
+  const size_t cells = (size_t)(Hl + 2) * (Wl + 2);
+  const size_t lds_max = 160 * 1024;
+  int cch = 0;
+  if (cells * 64 * 4 <= lds_max) cch = 64;
+  else if (cells * 32 * 4 <= lds_max) cch = 32;
+  CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
+              "stored plane %dx%d too large for the LDS-resident gather (max ~1270 cells)", Hl, Wl);
+
+  if (running && (sst || dst || rst)) cdn::launch_minmax_init(sst, dst, rst, st);
+  // 1. scale prediction at stored resolution (+ min/max of s)
+  unsigned *smm = running ? sst : nullptr;
+  if (x_nhwc) {
+    const long npix = (long)(N * HWl);
+    const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
+    if (xq)
+      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, (int)C,
+                                                      npix, lo, hi);
+    else
+      scale_nhwc_kernel<false><<<blocks, 256, 0, st>>>(x, nullptr, w_scale, b_scale, s_raw, smm,
+                                                       (int)C, npix, lo, hi);
+  } else {
+    CDN_REQUIRE(xq == nullptr, CDN_ERR_UNSUPPORTED, "quant-on-load needs a channels-last input");
+    dim3 grid((unsigned)cdn::ceil_div(HWl, 64), (unsigned)N);
+    scale_nchw_kernel<<<grid, 256, 0, st>>>(x, w_scale, b_scale, s_raw, smm, (int)C, (int)HWl, lo, hi);
+  }
+  int rc = cdn::check_launch("codenet fused scale");
+  if (rc) return rc;
+  if (sst) cdn::launch_quantact_update(s_min, s_max, sst, nullptr, nullptr, bits, momentum, running, st);
+  // 2. gather + depthwise (+ min/max of d)
+  unsigned *dmm = running ? dst : nullptr;
+  if (cch == 64)
+    rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+  else
+    rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+  if (rc) return rc;
+  if (dst) cdn::launch_quantact_update(d_min, d_max, dst, nullptr, nullptr, bits, momentum, running, st);
+  // 3. pointwise on f32 MFMA (+ bias / affine / ReLU, min/max of the result)
+  unsigned *rmm = running ? rst : nullptr;
+  const long M = (long)(N * H * W);
+#define CDN_PW(BN, AQ_)                                                                          \
+  pw2_kernel<BN, AQ_><<<dim3((unsigned)cdn::ceil_div(M, kPw2BM), (unsigned)cdn::ceil_div(Co, BN)), \
+                        256, 0, st>>>(d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M,   \
+                                      (int)C, (int)Co, relu)
+  if (Co > 64) {
+    if (dst) CDN_PW(128, true); else CDN_PW(128, false);
+  } else {
+    if (dst) CDN_PW(64, true); else CDN_PW(64, false);
+  }
+#undef CDN_PW
+  rc = cdn::check_launch("codenet fused pointwise");
+  if (rc) return rc;
+  if (rst) cdn::launch_quantact_update(r_min, r_max, rst, nullptr, nullptr, bits, momentum, running, st);
+  return CDN_OK;
+}
+
+extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw,
+                                       int64_t N, int64_t C, int64_t H, int64_t W, int up,
+                                       void *stream) {
+  CDN_REQUIRE(r_nhwc && out_nchw, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(N <= 65535 && H <= 65535 && (size_t)W * (C + 1) * 4 <= 64 * 1024, CDN_ERR_UNSUPPORTED,
+              "row of %lld pixels x %lld channels does not fit the LDS transpose tile", (long long)W,
+              (long long)C);
+  hipStream_t st = cdn::as_stream(stream);
+  const size_t lds = (size_t)W * (C + 1) * sizeof(float);
+  dim3 grid((unsigned)H, (unsigned)N);
+  if (r_qstate)
+    unpack_kernel<true><<<grid, 256, lds, st>>>(r_nhwc, static_cast<const unsigned *>(r_qstate),
+                                               out_nchw, (int)C, (int)H, (int)W, up);
+  else
+    unpack_kernel<false><<<grid, 256, lds, st>>>(r_nhwc, nullptr, out_nchw, (int)C, (int)H, (int)W, up);
+  return cdn::check_launch("codenet unpack");
+}

@@ -13,24 +13,22 @@
 
 namespace {
 
-// Order-preserving float <-> uint map so min/max can use integer atomics.
-__device__ __forceinline__ unsigned f2ord(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) {
-  const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-  return __uint_as_float(u);
-}
+using cdn::f2ord;
+using cdn::ord2f;
+using cdn::quant_code;
 
 // state layout (device, 8 x 4 bytes):
 //   [0] ordered-uint running batch min   [1] ordered-uint running batch max
 //   [2] scale  [3] zero_point  [4] batch min (float)  [5] batch max (float)  [6..7] reserved
-constexpr int kStateWords = 8;
+constexpr int kStateWords = cdn::kQStateWords;
 
-__global__ void minmax_init_kernel(unsigned *state) {
-  state[0] = 0xffffffffu;  // +inf side for min
-  state[1] = 0u;           // -inf side for max
+__global__ void minmax_init_kernel(unsigned *s0, unsigned *s1, unsigned *s2) {
+  unsigned *st[3] = {s0, s1, s2};
+  for (int i = 0; i < 3; ++i)
+    if (st[i]) {
+      st[i][0] = 0xffffffffu;  // +inf side for min
+      st[i][1] = 0u;           // -inf side for max
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -100,10 +98,6 @@ __global__ void quantact_update_kernel(float *x_min, float *x_max, unsigned *sta
   reinterpret_cast<float *>(state)[3] = zp;
 }
 
-__device__ __forceinline__ float quant_code(float x, float scale, float zp) {
-  return rintf(__fsub_rn(__fmul_rn(scale, x), zp));  // torch.round = half-to-even
-}
-
 // out = (q + zp) / scale; optionally also the integer codes (int16: codes are NOT clamped to
 // int8 by the reference, quant_utils.py:193-200, so int8 alone could not hold them).
 __global__ void __launch_bounds__(256)
@@ -152,6 +146,20 @@ inline int stream_grid(long n) {
 
 }  // namespace
 
+namespace cdn {
+void launch_minmax_init(unsigned *s0, unsigned *s1, unsigned *s2, hipStream_t st) {
+  minmax_init_kernel<<<1, 1, 0, st>>>(s0, s1, s2);
+}
+void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
+                            const float *ext_max, int bits, double momentum, int running,
+                            hipStream_t st) {
+  // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
+  // the scalar to fp32 (quant_modules.py:217-219).
+  quantact_update_kernel<<<1, 1, 0, st>>>(x_min, x_max, state, ext_min, ext_max, bits,
+                                          (float)(momentum - 1.0), (float)(1.0 - momentum), running);
+}
+}  // namespace cdn
+
 extern "C" size_t cdn_quantact_state_bytes(void) { return kStateWords * sizeof(unsigned); }
 
 extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t numel,
@@ -170,7 +178,7 @@ extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, 
   hipStream_t st = cdn::as_stream(stream);
   unsigned *stt = static_cast<unsigned *>(state);
   if (running && !batch_min) {
-    minmax_init_kernel<<<1, 1, 0, st>>>(stt);
+    cdn::launch_minmax_init(stt, nullptr, nullptr, st);
     minmax_kernel<<<stream_grid(numel), 256, 0, st>>>(x, (long)numel, stt);
   }
   // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds

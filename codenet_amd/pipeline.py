@@ -28,11 +28,11 @@ def stage_shapes(input_res=512, w2=False):
 class DeconvLayers(nn.Module):
     """Container with the reference's attribute name so the quantiser's surgery applies."""
 
-    def __init__(self, w2=False):
+    def __init__(self, w2=False, planes=None):
         super().__init__()
-        planes_in = [2153 if w2 else 1024, 256, 128]
+        planes = planes or [2153 if w2 else 1024, 256, 128, 64]   # C_in of stage 0, then every C_out
         layers = []
-        for cin, cout in zip(planes_in, [256, 128, 64]):
+        for cin, cout in zip(planes[:-1], planes[1:]):
             layers += [
                 DeformConvWithOffsetScaleBoundPositive(cin, cout, 3, 1, 1, groups=cout, bias=False,
                                                         hidden_state=128, BN_MOMENTUM=BN_MOMENTUM),
@@ -46,12 +46,12 @@ class DeconvLayers(nn.Module):
         return self.deconv_layers(x)
 
 
-def build_hot_path(w2=False, quantized=True, seed=317, scale_std=3.0):
+def build_hot_path(w2=False, quantized=True, seed=317, scale_std=3.0, planes=None):
     """Seeded synthetic weights: reference initialisers, except a non-degenerate
     conv_scale (weight ~ N(0, scale_std/sqrt(C)), bias 1 => s ~ N(1, scale_std) on unit-power inputs,
     clipped to [-7, 8] with ~1 % of pixels at each clamp) and non-trivial BN running statistics."""
     g = torch.Generator().manual_seed(seed)
-    net = DeconvLayers(w2=w2)
+    net = DeconvLayers(w2=w2, planes=planes)
     with torch.no_grad():
         for m in net.modules():
             if isinstance(m, DeformConvWithOffsetScaleBoundPositive):
@@ -132,3 +132,134 @@ def algorithmic_bytes(batch, input_res=512, w2=False, fused=False, act_bytes=4):
             per[(C, Co, H)] = {"scale": sc * batch, "dw": ga * batch, "pointwise": pw * batch}
         tot += b * batch
     return tot, per
+
+
+class FusedHotPath:
+    """Runs a ``deconv_layers`` Sequential (fp32 or W4A8, built from the modules of this package)
+    as the fused per-stage kernel schedule of codenet_fused.hip: one C-ABI call per stage, then one
+    unpack (fake-quant + nearest x2 + NCHW) for the consumer.  Same parameters, same QuantAct
+    buffers (updated in place), same results as calling the Sequential module by module.
+
+    All device buffers are allocated once per input shape, so a call issues only kernel launches
+    and can be captured into a HIP graph (``capture()``)."""
+
+    def __init__(self, deconv_layers):
+        from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
+        self.seq = deconv_layers
+        mods = list(deconv_layers)
+        self.quantized = isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive)
+        step = 3 if self.quantized else 4
+        assert len(mods) % step == 0
+        self.stages = [mods[i:i + step] for i in range(0, len(mods), step)]
+        for st in self.stages:
+            assert isinstance(st[-1], nn.Upsample) and st[-1].scale_factor in (2, 2.0)
+        self._bufs = None
+        self._graph = None
+        self._affine = {}
+
+    # -- per-stage parameter views -------------------------------------------------------------
+    def _stage_params(self, st):
+        if self.quantized:
+            q, post = st[0], st[1]
+            w_pw, b_pw = q.quant_conv_channel_bn.folded()
+            return dict(
+                w_scale=q.quant_conv_scale.quantized_weight().reshape(-1),
+                b_scale=q.quant_conv_scale.bias, lo=q.quant_act[0].min_val, hi=q.quant_act[0].max_val,
+                w_dw=q.quant_deform_conv.quantized_weight(), w_pw=w_pw.reshape(w_pw.size(0), -1),
+                bias=b_pw, ep_scale=None, ep_shift=None,
+                acts=(q.quant_act[1], q.quant_identity_deform, post[1]))
+        op, bn = st[0], st[1]
+        key = id(st[0])
+        if key not in self._affine:      # BN as a per-channel affine (inference: derived once)
+            inv = torch.rsqrt(bn.running_var + bn.eps)
+            es = (bn.weight * inv).contiguous()
+            self._affine[key] = (es, (bn.bias - bn.running_mean * es).contiguous())
+        es, eh = self._affine[key]
+        return dict(w_scale=op.conv_scale.weight.reshape(-1), b_scale=op.conv_scale.bias,
+                    lo=op.conv_bound.min_val, hi=op.conv_bound.max_val, w_dw=op.conv.weight,
+                    w_pw=op.conv_channel.weight.reshape(op.out_channels, -1), bias=None,
+                    ep_scale=es, ep_shift=eh, acts=(None, None, None))
+
+    def _alloc(self, x):
+        from . import _native as N_
+        Nb, C, H, W = x.shape
+        dev = x.device
+        bufs, ws_bytes = [], 0
+        for i, st in enumerate(self.stages):
+            op = st[0]
+            cin = op.quant_deform_conv.in_channels if self.quantized else op.in_channels
+            cout = (op.quant_conv_channel_bn.conv.out_channels if self.quantized
+                    else op.out_channels)
+            up = 0 if i == 0 else 1
+            Hs, Ws = (H, W) if i == 0 else (bufs[-1]["H"] * 2, bufs[-1]["W"] * 2)
+            ws_bytes = max(ws_bytes, N_.lib().cdn_codenet_stage_workspace_bytes(Nb, cin, Hs, Ws, up))
+            bufs.append(dict(C=cin, Co=cout, H=Hs, W=Ws, up=up,
+                             r=torch.empty(Nb, Hs * Ws, cout, device=dev)))
+        last = bufs[-1]
+        out = torch.empty(Nb, last["Co"], last["H"] * 2, last["W"] * 2, device=dev)
+        ws = torch.empty(ws_bytes // 4 + 64, device=dev)
+        self._bufs = dict(shape=tuple(x.shape), dev=dev, stages=bufs, ws=ws, out=out)
+
+    def __call__(self, x):
+        from . import _native as N_
+        from . import ops
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            raise NotImplementedError("FusedHotPath needs a 4-D float32 GPU tensor")
+        x = x.contiguous()
+        if self._bufs is None or self._bufs["shape"] != tuple(x.shape) or self._bufs["dev"] != x.device:
+            self._alloc(x)
+        B = self._bufs
+        Nb = x.shape[0]
+        lib = N_.lib()
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        ws = B["ws"]
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        ws_bytes = ws.numel() * 4 - (ws_ptr - ws.data_ptr())
+        cur, cur_nhwc, cur_q = x, 0, None
+        with torch.no_grad():
+            for st, sb in zip(self.stages, B["stages"]):
+                p = self._stage_params(st)
+                ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+                a = []
+                bits, mom, running = 8, 0.99, 0
+                for act in p["acts"]:
+                    if act is None:
+                        a += [None, None, None]
+                    else:
+                        a += [act.x_min.data_ptr(), act.x_max.data_ptr(),
+                              act._device_state(x.device).data_ptr()]
+                        bits, mom, running = act.activation_bit, act.momentum, int(act.running_stat)
+                rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
+                rc = lib.cdn_codenet_stage_fused_forward(
+                    cur.data_ptr(), cur_nhwc, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                    ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
+                    ptr(p["w_dw"]), ptr(p["w_pw"]), ptr(p["bias"]), ptr(p["ep_scale"]),
+                    ptr(p["ep_shift"]), 1, *a, bits, mom, running, ws_ptr, ws_bytes,
+                    sb["r"].data_ptr(), stream)
+                ops._toc(rec)
+                N_.check(rc, "cdn_codenet_stage_fused_forward")
+                cur, cur_nhwc = sb["r"], 1
+                cur_q = a[8]          # r_state of this stage (None in fp32)
+            last = B["stages"][-1]
+            rec = ops._tic("unpack", (last["Co"], last["H"], last["W"]))
+            rc = lib.cdn_codenet_unpack_nchw(cur.data_ptr(), cur_q, B["out"].data_ptr(), Nb,
+                                             last["Co"], last["H"], last["W"], 1, stream)
+            ops._toc(rec)
+            N_.check(rc, "cdn_codenet_unpack_nchw")
+        return B["out"]
+
+    # -- HIP graph -----------------------------------------------------------------------------
+    def capture(self, x):
+        """Capture one pass over the static input buffer `x` into a HIP graph; returns a callable
+        replaying it (the output tensor is static too)."""
+        self(x)                       # allocate + warm (also derives cached weights)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self(x)
+        self._graph = g
+
+        def replay():
+            g.replay()
+            return out
+        return replay

@@ -173,6 +173,47 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
                          const float *batch_max, int bits, double momentum, int running,
                          void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One whole up-sampling stage of the head as a fused kernel schedule (codenet_fused.hip):
+ *   fp32 : DeformConvWithOffsetScaleBoundPositive -> BatchNorm2d -> ReLU            [-> Upsample]
+ *          (modules/dcn_deform_conv.py:323-330, shufflenetv2_dcn.py:303-308)
+ *   W4A8 : QuantDeformConvWithOffsetScaleBoundPositive -> ReLU -> QuantAct          [-> Upsample]
+ *          (quant_modules.py:668-671, quantize_model.py:79-81)
+ * The nearest x2 Upsample that FOLLOWS a stage is not executed: the next stage (x_up = 1) reads
+ * its input at half resolution, and cdn_codenet_unpack_nchw materialises it for consumers outside
+ * the fused path.  QuantAct min/max reductions run in the producing kernels' epilogues, the
+ * fake-quantisation (same fp32 expression as cdn_quantact_forward) is applied by the consumer while
+ * loading, so results equal the module-by-module composition.
+ *
+ *   x         stage input at STORED resolution (H>>x_up) x (W>>x_up); x_nhwc ? [N][pix][C] : [N][C][pix]
+ *   x_qstate  NULL, or the QuantAct state of the producer: x then holds PRE-quantisation values
+ *             (channels-last only) and is fake-quantised on load
+ *   H, W      stage (output) resolution;  C -> Co channels
+ *   w_scale [C], b_scale [1] (device, may be NULL), lo/hi: Hardtanh bounds
+ *   w_dw [C,1,3,3], w_pw [Co,C], bias_pw [Co] or NULL; ep_scale/ep_shift [Co] or both NULL
+ *             (W4A8: the already fake-quantised weights and the folded BN bias; fp32: BN as affine)
+ *   {s,d,r}_{min,max,state}: the three QuantAct of the stage (x_min/x_max buffers updated in place
+ *             when running != 0; state as in cdn_quantact_forward); pass all three of a group NULL to
+ *             disable that quantiser (fp32 path: all NULL)
+ *   workspace cdn_codenet_stage_workspace_bytes(N,C,H,W,x_up) bytes, 256-byte aligned
+ *   r_out     [N][H*W][Co] channels-last: act(pointwise(...)) BEFORE the output QuantAct (its
+ *             parameters are left in r_state for the consumer)
+ * ---------------------------------------------------------------------------------------- */
+size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up);
+int cdn_codenet_stage_fused_forward(
+    const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
+    int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
+    const float *w_dw, const float *w_pw, const float *bias_pw, const float *ep_scale,
+    const float *ep_shift, int relu, float *s_min, float *s_max, void *s_state, float *d_min,
+    float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
+    void *stream);
+
+/* out_nchw[n][c][(h<<up)+dy][(w<<up)+dx] = fq(r_nhwc[n][h*W+w][c]): channels-last -> NCHW with the
+ * nearest x2 up-sampling (up = 1) and, if r_qstate != NULL, the fake-quantisation applied. */
+int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw, int64_t N,
+                            int64_t C, int64_t H, int64_t W, int up, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

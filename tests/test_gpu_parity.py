@@ -362,3 +362,94 @@ def test_golden_deform_raw():
         y.backward(z[tag + "_go"].cuda())
         for got, name in ((xg, "_mgx"), (og, "_mgoff"), (mg, "_mgm"), (wg, "_mgw"), (bg, "_mgb")):
             assert (got.grad.cpu() - z[tag + name]).abs().max().item() < 1e-3, name
+
+
+# ---- fused per-stage schedule (codenet_fused.hip) == module-by-module == oracle -----------------
+
+def _oracle_chain(net_cpu, x, quantized, n_forwards=1, xs=None):
+    """CPU oracle of the whole deconv_layers chain; returns the list of outputs."""
+    import torch.nn.functional as F
+    mods = list(net_cpu.deconv_layers)
+    outs = []
+    if quantized:
+        acts = [[Q.QuantActState(), Q.QuantActState(), Q.QuantActState()] for _ in range(len(mods) // 3)]
+    for it in range(n_forwards):
+        cur = xs[it] if xs is not None else x
+        if not quantized:
+            for i in range(0, len(mods), 4):
+                op, bn = mods[i], mods[i + 1]
+                r = Q.stage_fp32(cur, op.conv_scale.weight.detach(), op.conv_scale.bias.detach(),
+                                 op.conv.weight.detach(), op.conv_channel.weight.detach())
+                with torch.no_grad():
+                    cur = F.interpolate(torch.relu(bn(r["y"])), scale_factor=2, mode="nearest")
+        else:
+            for k, i in enumerate(range(0, len(mods), 3)):
+                q = mods[i]
+                bnm = q.quant_conv_channel_bn.bn
+                bn = (bnm.weight.detach(), bnm.bias.detach(), bnm.running_mean, bnm.running_var, bnm.eps)
+                r = Q.stage_w4a8(cur, q.quant_conv_scale.weight.detach(), q.quant_conv_scale.bias.detach(),
+                                 q.quant_deform_conv.weight.detach(),
+                                 q.quant_conv_channel_bn.conv.weight.detach(), bn, acts[k][0], acts[k][1])
+                cur = F.interpolate(acts[k][2](torch.relu(r["y"])), scale_factor=2, mode="nearest")
+        outs.append(cur)
+    return outs
+
+
+@pytest.mark.parametrize("quantized", [False, True])
+@pytest.mark.parametrize("planes,res", [([24, 16, 8, 4], 6), ([40, 12, 8, 4], 5), ([128, 64, 32, 16], 8)])
+def test_fused_hot_path_matches_modules_and_oracle(quantized, planes, res):
+    import copy
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=quantized, planes=planes, seed=5)
+    net_cpu = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(2, planes[0], res, res, generator=g).abs() * (1.0 + 0.2 * i) for i in range(3)]
+    ref = _oracle_chain(net_cpu, None, quantized, 3, xs)
+    net_a = copy.deepcopy(net).cuda()
+    net_b = copy.deepcopy(net).cuda()
+    fused = pipeline.FusedHotPath(net_b.deconv_layers)
+    for it in range(3):
+        with torch.no_grad():
+            ya = net_a(xs[it].cuda())
+        yb = fused(xs[it].cuda()).clone()
+        assert ya.shape == yb.shape == ref[it].shape
+        # fused vs module-by-module on the GPU: same arithmetic, only the scale reduction order of
+        # stages >= 1 differs (half-resolution channels-last kernel)
+        assert (ya - yb).abs().max().item() < 2e-4
+        # both vs the CPU oracle: north-star 1e-3
+        assert (yb.cpu() - ref[it]).abs().max().item() < 1e-3
+        assert (ya.cpu() - ref[it]).abs().max().item() < 1e-3
+    if quantized:
+        for ma, mb in zip(net_a.modules(), net_b.modules()):
+            if hasattr(ma, "x_min") and isinstance(ma.x_min, torch.Tensor):
+                assert (ma.x_min - mb.x_min).abs().item() < 1e-5
+                assert (ma.x_max - mb.x_max).abs().item() < 1e-5
+
+
+def test_fused_hot_path_graph_replay_matches_eager():
+    import copy
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[64, 32, 16, 8], seed=6).cuda()
+    pipeline.set_running_stat(net, True)
+    x = torch.randn(4, 64, 8, 8, device="cuda").abs()
+    net2 = copy.deepcopy(net)
+    eager = pipeline.FusedHotPath(net.deconv_layers)
+    graphed = pipeline.FusedHotPath(net2.deconv_layers)
+    replay = graphed.capture(x)          # capture() runs one eager pass (warm-up) + one captured pass
+    eager(x); eager(x)
+    for _ in range(3):
+        a = eager(x).clone()
+        b = replay().clone()
+        assert torch.equal(a, b)
+
+
+def test_fused_stage_real_shapes_w2():
+    """CoDeNet2x stage 0 (C = 2153: odd channel count, scalar tail paths) through the fused schedule."""
+    import copy
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[2153, 256, 128, 64], seed=7)
+    net_cpu = copy.deepcopy(net)
+    x = torch.randn(1, 2153, 8, 8, generator=torch.Generator().manual_seed(3)).abs()
+    ref = _oracle_chain(net_cpu, x, True)[0]
+    y = pipeline.FusedHotPath(net.cuda().deconv_layers)(x.cuda())
+    assert (y.cpu() - ref).abs().max().item() < 1e-3
