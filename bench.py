@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 hot path instead of W4A8")
     ap.add_argument("--frozen", action="store_true",
                     help="freeze QuantAct ranges (default: reference-faithful running ranges)")
+    ap.add_argument("--path", choices=["fused", "modules"], default="fused",
+                    help="fused: per-stage fused kernel schedule (codenet_fused.hip); modules: the "
+                         "reference-shaped nn.Module chain, one op at a time")
+    ap.add_argument("--no-graph", action="store_true", help="fused path: launch eagerly instead of "
+                    "replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=2)
     return ap.parse_args()
@@ -121,7 +126,13 @@ def main():
         pipeline.set_running_stat(net, not args.frozen)
     x = pipeline.make_input(args.batch, args.res, args.w2, seed=rank, device=dev)
 
-    def step():
+    import ctypes
+    from codenet_amd import _native
+    fused = pipeline.FusedHotPath(net.deconv_layers) if args.path == "fused" else None
+
+    def eager_step():
+        if fused is not None:
+            return fused(x)
         with torch.no_grad():
             return net(x)
 
@@ -132,13 +143,18 @@ def main():
 
     if quantized and args.frozen:          # ranges must exist before they can be frozen
         pipeline.set_running_stat(net, True)
-        step()
+        eager_step()
         pipeline.set_running_stat(net, False)
+    for _ in range(max(1, args.warmup // 2)):
+        eager_step()
+    use_graph = fused is not None and not args.no_graph
+    step = fused.capture(x) if use_graph else eager_step
     for _ in range(args.warmup):
         step()
     barrier()
+    # ---- timed region: exactly K steps ---------------------------------------------------------
     names = {"scale", "dw", "pointwise", "quantact"}
-    with ops.KernelTimer(names) as kt:
+    with ops.KernelTimer(names if fused is None else set()) as kt:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
@@ -150,8 +166,28 @@ def main():
     dt = tmax.item()
     assert torch.isfinite(out).all()
 
-    if rank == 0:
+    # ---- per-kernel durations: HIP events on the launch stream (fused path: the library's own
+    #      event pairs around every kernel, K eager steps right after the timed region) ------------
+    durs = {}
+    if fused is not None and rank == 0:
+        lib = _native.lib()
+        lib.cdn_profile_enable(1)
+        for _ in range(args.steps):
+            eager_step()
+        torch.cuda.synchronize()
+        cap = args.steps * 16
+        ids = (ctypes.c_int * cap)()
+        tags = (ctypes.c_int * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = lib.cdn_profile_read(cap, ids, tags, ms)
+        lib.cdn_profile_enable(0)
+        kname = {0: "scale", 1: "dw", 2: "pointwise", 3: "unpack"}
+        for i in range(n):
+            durs.setdefault((kname.get(ids[i], "other"), (tags[i],)), []).append(ms[i])
+    elif rank == 0:
         durs = kt.durations_ms()
+
+    if rank == 0:
         per_kernel = {}
         for (name, tag), v in durs.items():
             per_kernel.setdefault(name, 0.0)
@@ -162,12 +198,24 @@ def main():
         for v in per_stage.values():
             for k in alg:
                 alg[k] += v[k]
+        shapes = pipeline.stage_shapes(args.res, args.w2)
+        if fused is not None:
+            # fused schedule: stages >= 1 read their input at half resolution (up-sampling folded)
+            alg = {"scale": 0, "dw": 0, "pointwise": 0, "unpack": 0}
+            for i, (C, Co, H, W) in enumerate(shapes):
+                HWs = H * W // (1 if i == 0 else 4)
+                alg["scale"] += (C + 1) * HWs * 4 * args.batch
+                alg["dw"] += (C * HWs + HWs + C * H * W) * 4 * args.batch
+                alg["pointwise"] += (C + Co) * H * W * 4 * args.batch
+            C, Co, H, W = shapes[-1]
+            alg["unpack"] = (Co * H * W + 4 * Co * H * W) * 4 * args.batch
         flops_pw = sum(2.0 * C * Co * H * W * args.batch
                        for (C, Co, H, W) in pipeline.stage_shapes(args.res, args.w2))
         if dominant == "pointwise":
             ach = flops_pw / (per_kernel["pointwise"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": ach / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "pointwise_kernel"}
+                    "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
+                    "kernel": "pw2_kernel" if fused is not None else "pointwise_kernel"}
         else:
             key = dominant if dominant in alg else "dw"
             nbytes = alg.get(key, 0)
@@ -176,8 +224,10 @@ def main():
             ach = nbytes / (per_kernel[dominant] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": {"dw": "dw_kernel", "scale": "scale_kernel",
-                               "quantact": "minmax_kernel+fake_quant_kernel"}[dominant]}
+                    "kernel": ({"dw": "dw2_kernel", "scale": "scale_*_kernel", "unpack": "unpack_kernel"}
+                               if fused is not None else
+                               {"dw": "dw_kernel", "scale": "scale_kernel",
+                                "quantact": "minmax_kernel+fake_quant_kernel"})[dominant]}
         roof["launches_per_step"] = sum(1 for (nm, _t) in durs if nm == dominant)
         roof["ms_per_step_in_kernel"] = per_kernel[dominant]
         res = {
@@ -197,11 +247,13 @@ def main():
             "config": {
                 "workload": "CoDeNet%s config-%s %dx%d %s, batch %d per GPU, 3 deform stages "
                             "(scale 1x1 -> QuantAct -> bilinear-gather depthwise 3x3 -> QuantAct -> "
-                            "pointwise 1x1 + folded BN -> ReLU -> QuantAct -> upsample x2), %s"
+                            "pointwise 1x1 + folded BN -> ReLU -> QuantAct -> upsample x2), %s, %s"
                             % ("2x" if args.w2 else "1x", "d" if args.w2 else "c", args.res, args.res,
                                "fp32" if args.fp32 else "W4A8", args.batch,
                                "frozen QuantAct ranges" if args.frozen else
-                               "running QuantAct ranges (reference-faithful)"),
+                               "running QuantAct ranges (reference-faithful)",
+                               ("fused per-stage schedule" + (", HIP-graph replay" if use_graph else ", eager launches"))
+                               if fused is not None else "module-by-module"),
                 "global_batch": world * args.batch,
                 "parallelism": "dp%d (independent image shards, start-up RCCL broadcast of %d bytes)"
                                % (world, bcast_bytes),

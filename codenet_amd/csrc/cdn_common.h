@@ -37,6 +37,17 @@ struct Geom {
 int make_geom(Geom *g, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kH, int kW,
               int sH, int sW, int pH, int pW, int dH, int dW, int group, int dg);
 
+// ---- optional per-kernel HIP-event profiler (bench.py's live roofline numbers) -----------------
+// Off by default (zero overhead beyond one thread-local bool test per launch).  When enabled on
+// the calling thread, every ProfScope records a start/end event pair on the launch stream.
+enum ProfKernel { kProfScale = 0, kProfDw = 1, kProfPointwise = 2, kProfUnpack = 3, kProfUpdate = 4 };
+struct ProfScope {
+  ProfScope(int kernel_id, int tag, hipStream_t st);
+  ~ProfScope();
+  int slot_;
+  hipStream_t st_;
+};
+
 // ---- QuantAct device state (codenet_quant.hip) --------------------------------------------------
 // 8 x 4-byte words: [0] ordered-uint batch min, [1] ordered-uint batch max, [2] scale (f32),
 // [3] zero-point (f32), [4] batch min (f32), [5] batch max (f32), [6..7] reserved.

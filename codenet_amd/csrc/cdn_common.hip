@@ -2,6 +2,7 @@
 #include "cdn_common.h"
 
 #include <climits>
+#include <vector>
 
 namespace cdn {
 
@@ -55,7 +56,64 @@ int make_geom(Geom *g, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, i
   return CDN_OK;
 }
 
+namespace {
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // 2 per record
+  std::vector<int> kid, tag;
+  size_t used = 0;              // records
+};
+Prof &prof() {
+  static thread_local Prof p;
+  return p;
+}
+}  // namespace
+
+ProfScope::ProfScope(int kernel_id, int tag, hipStream_t st) : slot_(-1), st_(st) {
+  Prof &p = prof();
+  if (!p.on) return;
+  if (p.ev.size() < 2 * (p.used + 1)) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    p.ev.push_back(a);
+    p.ev.push_back(b);
+    p.kid.push_back(0);
+    p.tag.push_back(0);
+  }
+  slot_ = (int)p.used++;
+  p.kid[slot_] = kernel_id;
+  p.tag[slot_] = tag;
+  (void)hipEventRecord(p.ev[2 * slot_], st);
+}
+
+ProfScope::~ProfScope() {
+  if (slot_ >= 0) (void)hipEventRecord(prof().ev[2 * slot_ + 1], st_);
+}
+
 }  // namespace cdn
+
+extern "C" int cdn_profile_enable(int on) {
+  auto &p = cdn::prof();
+  p.on = on != 0;
+  p.used = 0;
+  return CDN_OK;
+}
+
+extern "C" int cdn_profile_read(int max_records, int *kernel_ids, int *tags, float *ms) {
+  auto &p = cdn::prof();
+  int n = 0;
+  for (size_t i = 0; i < p.used && n < max_records; ++i) {
+    if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) continue;
+    kernel_ids[n] = p.kid[i];
+    tags[n] = p.tag[i];
+    ms[n] = t;
+    ++n;
+  }
+  p.used = 0;
+  return n;
+}
 
 extern "C" int cdn_abi_version(void) { return CDN_ABI_VERSION; }
 extern "C" const char *cdn_last_error(void) { return cdn::err_buf(); }

@@ -587,8 +587,11 @@ extern "C" int cdn_codenet_stage_fused_forward(
               "stored plane %dx%d too large for the LDS-resident gather (max ~1270 cells)", Hl, Wl);
 
   if (running && (sst || dst || rst)) cdn::launch_minmax_init(sst, dst, rst, st);
+  const int ptag = (int)(H > 0xffff ? 0xffff : H);
   // 1. scale prediction at stored resolution (+ min/max of s)
   unsigned *smm = running ? sst : nullptr;
+  {
+  cdn::ProfScope ps(cdn::kProfScale, ptag, st);
   if (x_nhwc) {
     const long npix = (long)(N * HWl);
     const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
@@ -603,15 +606,19 @@ extern "C" int cdn_codenet_stage_fused_forward(
     dim3 grid((unsigned)cdn::ceil_div(HWl, 64), (unsigned)N);
     scale_nchw_kernel<<<grid, 256, 0, st>>>(x, w_scale, b_scale, s_raw, smm, (int)C, (int)HWl, lo, hi);
   }
+  }
   int rc = cdn::check_launch("codenet fused scale");
   if (rc) return rc;
   if (sst) cdn::launch_quantact_update(s_min, s_max, sst, nullptr, nullptr, bits, momentum, running, st);
   // 2. gather + depthwise (+ min/max of d)
   unsigned *dmm = running ? dst : nullptr;
-  if (cch == 64)
-    rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
-  else
-    rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+  {
+    cdn::ProfScope ps(cdn::kProfDw, ptag, st);
+    if (cch == 64)
+      rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+    else
+      rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+  }
   if (rc) return rc;
   if (dst) cdn::launch_quantact_update(d_min, d_max, dst, nullptr, nullptr, bits, momentum, running, st);
   // 3. pointwise on f32 MFMA (+ bias / affine / ReLU, min/max of the result)
@@ -621,10 +628,13 @@ extern "C" int cdn_codenet_stage_fused_forward(
   pw2_kernel<BN, AQ_><<<dim3((unsigned)cdn::ceil_div(M, kPw2BM), (unsigned)cdn::ceil_div(Co, BN)), \
                         256, 0, st>>>(d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M,   \
                                       (int)C, (int)Co, relu)
-  if (Co > 64) {
-    if (dst) CDN_PW(128, true); else CDN_PW(128, false);
-  } else {
-    if (dst) CDN_PW(64, true); else CDN_PW(64, false);
+  {
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+    if (Co > 64) {
+      if (dst) CDN_PW(128, true); else CDN_PW(128, false);
+    } else {
+      if (dst) CDN_PW(64, true); else CDN_PW(64, false);
+    }
   }
 #undef CDN_PW
   rc = cdn::check_launch("codenet fused pointwise");
@@ -644,6 +654,7 @@ extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate
   hipStream_t st = cdn::as_stream(stream);
   const size_t lds = (size_t)W * (C + 1) * sizeof(float);
   dim3 grid((unsigned)H, (unsigned)N);
+  cdn::ProfScope ps(cdn::kProfUnpack, (int)(H > 0xffff ? 0xffff : H), st);
   if (r_qstate)
     unpack_kernel<true><<<grid, 256, lds, st>>>(r_nhwc, static_cast<const unsigned *>(r_qstate),
                                                out_nchw, (int)C, (int)H, (int)W, up);

@@ -214,6 +214,16 @@ int cdn_codenet_stage_fused_forward(
 int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw, int64_t N,
                             int64_t C, int64_t H, int64_t W, int up, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events on the launch stream (thread-local; off by default).
+ * While enabled, each kernel of cdn_codenet_stage_fused_forward / cdn_codenet_unpack_nchw records
+ * an event pair.  cdn_profile_read synchronises the recorded events and returns up to max_records
+ * {kernel id (0 scale, 1 gather/depthwise, 2 pointwise, 3 unpack), tag (stage height), ms}, then
+ * clears the list.  Not to be enabled while the stream is being captured into a HIP graph.
+ * ---------------------------------------------------------------------------------------- */
+int cdn_profile_enable(int on);
+int cdn_profile_read(int max_records, int *kernel_ids, int *tags, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -416,9 +416,19 @@ def test_fused_hot_path_matches_modules_and_oracle(quantized, planes, res):
         # fused vs module-by-module on the GPU: same arithmetic, only the scale reduction order of
         # stages >= 1 differs (half-resolution channels-last kernel)
         assert (ya - yb).abs().max().item() < 2e-4
-        # both vs the CPU oracle: north-star 1e-3
-        assert (yb.cpu() - ref[it]).abs().max().item() < 1e-3
-        assert (ya.cpu() - ref[it]).abs().max().item() < 1e-3
+        # both vs the CPU oracle: north-star 1e-3.  In W4A8 the outputs are 8-bit fake-quantised
+        # values: fp32 re-association between CPU and GPU (~1e-6) can move a pre-quantisation value
+        # across a rounding boundary, i.e. flip a code by ONE LSB (measured
+        # ~1 in 262144).  Allowed: <= 1 LSB, on < 0.2 % of the elements.
+        for y in (ya, yb):
+            diff = (y.cpu() - ref[it]).abs()
+            if not quantized:
+                assert diff.max().item() < 1e-3
+            else:
+                last = [m for m in net_b.modules() if hasattr(m, "x_min")][-1]
+                lsb = (last.x_max - last.x_min).item() / 255.0
+                assert diff.max().item() <= 1.05 * lsb + 1e-3
+                assert (diff > 1e-3).float().mean().item() < 2e-3
     if quantized:
         for ma, mb in zip(net_a.modules(), net_b.modules()):
             if hasattr(ma, "x_min") and isinstance(ma.x_min, torch.Tensor):
