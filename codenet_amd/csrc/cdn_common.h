@@ -55,10 +55,13 @@ constexpr int kQStateWords = 8;
 
 // Reset the running batch min/max of up to three states (null entries skipped): 1 launch.
 void launch_minmax_init(unsigned *s0, unsigned *s1, unsigned *s2, hipStream_t st);
-// Range tracking + scale / zero-point derivation (1 thread), see quantact_update_kernel.
+// Range tracking + scale / zero-point derivation, see quantact_update_kernel.  Batch statistics
+// come from (in this order of precedence) ext_min/ext_max device scalars, `partials`
+// ([n_partials] {min,max} pairs written by producer workgroups, reduced here -- no atomics), or
+// the ordered-uint words state[0..1].
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
-                            const float *ext_max, int bits, double momentum, int running,
-                            hipStream_t st);
+                            const float *ext_max, const float2 *partials, int n_partials, int bits,
+                            double momentum, int running, hipStream_t st);
 
 }  // namespace cdn
 
@@ -81,16 +84,27 @@ __device__ __forceinline__ float quant_code(float x, float scale, float zp) {
 __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
   return __fdiv_rn(__fadd_rn(quant_code(x, scale, zp), zp), scale);
 }
-// Block-level min/max -> two integer atomics on the state words.  All threads must call it.
-__device__ __forceinline__ void block_minmax_commit(float mn, float mx, unsigned *state) {
+// Workgroup-level min/max -> ONE {min,max} pair stored at out[0] (plain store, no atomics: a
+// single contended word sustains only ~88 atomics/us on MI355X).  Every thread of the workgroup
+// must call it; `red` is >= 2*nwaves floats of LDS that nobody else is using.
+__device__ __forceinline__ void block_minmax_store(float mn, float mx, float2 *out, float *red) {
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
     mn = fminf(mn, __shfl_xor(mn, m, 64));
     mx = fmaxf(mx, __shfl_xor(mx, m, 64));
   }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&state[0], f2ord(mn));
-    atomicMax(&state[1], f2ord(mx));
+    red[2 * wave] = mn;
+    red[2 * wave + 1] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) {
+      mn = fminf(mn, red[2 * i]);
+      mx = fmaxf(mx, red[2 * i + 1]);
+    }
+    *out = make_float2(mn, mx);
   }
 }
 }  // namespace cdn

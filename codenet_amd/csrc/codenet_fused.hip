@@ -58,7 +58,7 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                  const float *__restrict__ b, float *__restrict__ s, unsigned *mm, int C, int HW,
+                  const float *__restrict__ b, float *__restrict__ s, float2 *mm, int C, int HW,
                   float lo, float hi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
@@ -84,9 +84,14 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
     v += b ? b[0] : 0.0f;
     v = fminf(fmaxf(v, lo), hi);
     if (live) s[(long)n * HW + p] = v;
-    if (mm) {
+    if (mm) {   // one wave holds the whole workgroup's outputs: wave reduce, one plain store
       float mn = live ? v : INFINITY, mx = live ? v : -INFINITY;
-      cdn::block_minmax_commit(mn, mx, mm);
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, m, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+      }
+      if (lane == 0) mm[(long)blockIdx.y * gridDim.x + blockIdx.x] = make_float2(mn, mx);
     }
   }
 }
@@ -99,7 +104,8 @@ template <bool XQ>
 __global__ void __launch_bounds__(256)
 scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                   const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ s,
-                  unsigned *mm, int C, long npix, float lo, float hi) {
+                  float2 *mm, int C, long npix, float lo, float hi) {
+  __shared__ float red[8];
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
@@ -134,7 +140,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
-  if (mm) cdn::block_minmax_commit(mn, mx, mm);
+  if (mm) cdn::block_minmax_store(mn, mx, mm + blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -150,9 +156,10 @@ template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
 __global__ void __launch_bounds__(kDw2Threads)
 dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
-           const float *__restrict__ wd, float *__restrict__ d, unsigned *dmm, int C, int H, int W,
+           const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, int C, int H, int W,
            int up) {
   extern __shared__ float4 img[];  // [cells][LPP] float4
+  __shared__ float red[2 * kDw2Threads / 64];
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
   const int Hl = H >> up, Wl = W >> up, Wp = Wl + 2;
@@ -345,7 +352,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         }
     }
   }
-  if (dmm) cdn::block_minmax_commit(mn, mx, dmm);
+  if (dmm) cdn::block_minmax_store(mn, mx, dmm + (long)blockIdx.y * gridDim.x + blockIdx.x, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(256)
 pw2_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            const float *__restrict__ Wp, const float *__restrict__ bias,
            const float *__restrict__ ep_scale, const float *__restrict__ ep_shift,
-           float *__restrict__ R, unsigned *rmm, long M, int C, int Co, int relu) {
+           float *__restrict__ R, float2 *rmm, long M, int C, int Co, int relu) {
   __shared__ float As[kPw2BM * kPw2LD];
   __shared__ float Bs[BN * kPw2LD];
   constexpr int NT = BN / 32;
@@ -460,7 +467,10 @@ pw2_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
     }
   }
-  if (rmm) cdn::block_minmax_commit(mn, mx, rmm);
+  if (rmm) {
+    __syncthreads();   // As is free again: reuse its first words as the reduction scratch
+    cdn::block_minmax_store(mn, mx, rmm + (long)blockIdx.y * gridDim.x + blockIdx.x, As);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -499,9 +509,11 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
   }
 }
 
+constexpr int kMaxPartials = 16384;  // per kernel; grids are clamped / checked against it
+
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
-               const unsigned *sq, const float *wd, float *d, unsigned *dmm, int N, int C, int H,
+               const unsigned *sq, const float *wd, float *d, float2 *dmm, int N, int C, int H,
                int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = (size_t)(Hl + 2) * (Wl + 2) * CCH * sizeof(float);
@@ -534,9 +546,10 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
 extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W,
                                                     int x_up) {
   const int64_t HWl = (H >> x_up) * (W >> x_up);
-  // s_raw [N*HWl] + d [N*H*W*C], each rounded up to 256 bytes
+  // s_raw [N*HWl] + d [N*H*W*C] + 3 regions of per-workgroup {min,max} partials, each rounded
+  // up to 256 bytes
   auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
-  return (size_t)(r(N * HWl * 4) + r(N * H * W * C * 4));
+  return (size_t)(r(N * HWl * 4) + r(N * H * W * C * 4) + 3 * r(kMaxPartials * 8));
 }
 
 extern "C" int cdn_codenet_stage_fused_forward(
@@ -571,8 +584,13 @@ extern "C" int cdn_codenet_stage_fused_forward(
   hipStream_t st = cdn::as_stream(stream);
   const int Hl = (int)(H >> x_up), Wl = (int)(W >> x_up);
   const int64_t HWl = (int64_t)Hl * Wl;
-  float *s_raw = static_cast<float *>(workspace);
-  float *d = reinterpret_cast<float *>(static_cast<char *>(workspace) + (N * HWl * 4 + 255) / 256 * 256);
+  auto r256 = [](int64_t b) { return (b + 255) / 256 * 256; };
+  char *wsp = static_cast<char *>(workspace);
+  float *s_raw = reinterpret_cast<float *>(wsp);
+  float *d = reinterpret_cast<float *>(wsp + r256(N * HWl * 4));
+  float2 *part_s = reinterpret_cast<float2 *>(wsp + r256(N * HWl * 4) + r256(N * H * W * C * 4));
+  float2 *part_d = part_s + kMaxPartials;
+  float2 *part_r = part_d + kMaxPartials;
   unsigned *sst = static_cast<unsigned *>(s_state), *dst = static_cast<unsigned *>(d_state),
            *rst = static_cast<unsigned *>(r_state);
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
@@ -589,12 +607,14 @@ extern "C" int cdn_codenet_stage_fused_forward(
   if (running && (sst || dst || rst)) cdn::launch_minmax_init(sst, dst, rst, st);
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
   // 1. scale prediction at stored resolution (+ min/max of s)
-  unsigned *smm = running ? sst : nullptr;
+  float2 *smm = (running && sst) ? part_s : nullptr;
+  int n_part_s = 0;
   {
   cdn::ProfScope ps(cdn::kProfScale, ptag, st);
   if (x_nhwc) {
     const long npix = (long)(N * HWl);
     const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
+    n_part_s = blocks;
     if (xq)
       scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, (int)C,
                                                       npix, lo, hi);
@@ -604,14 +624,20 @@ extern "C" int cdn_codenet_stage_fused_forward(
   } else {
     CDN_REQUIRE(xq == nullptr, CDN_ERR_UNSUPPORTED, "quant-on-load needs a channels-last input");
     dim3 grid((unsigned)cdn::ceil_div(HWl, 64), (unsigned)N);
+    n_part_s = (int)(grid.x * grid.y);
+    CDN_REQUIRE(n_part_s <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many scale workgroups");
     scale_nchw_kernel<<<grid, 256, 0, st>>>(x, w_scale, b_scale, s_raw, smm, (int)C, (int)HWl, lo, hi);
   }
   }
   int rc = cdn::check_launch("codenet fused scale");
   if (rc) return rc;
-  if (sst) cdn::launch_quantact_update(s_min, s_max, sst, nullptr, nullptr, bits, momentum, running, st);
+  if (sst)
+    cdn::launch_quantact_update(s_min, s_max, sst, nullptr, nullptr, smm, n_part_s, bits, momentum,
+                                running, st);
   // 2. gather + depthwise (+ min/max of d)
-  unsigned *dmm = running ? dst : nullptr;
+  float2 *dmm = (running && dst) ? part_d : nullptr;
+  const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
+  CDN_REQUIRE(n_part_d <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many gather workgroups");
   {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     if (cch == 64)
@@ -620,10 +646,15 @@ extern "C" int cdn_codenet_stage_fused_forward(
       rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
   }
   if (rc) return rc;
-  if (dst) cdn::launch_quantact_update(d_min, d_max, dst, nullptr, nullptr, bits, momentum, running, st);
+  if (dst)
+    cdn::launch_quantact_update(d_min, d_max, dst, nullptr, nullptr, dmm, n_part_d, bits, momentum,
+                                running, st);
   // 3. pointwise on f32 MFMA (+ bias / affine / ReLU, min/max of the result)
-  unsigned *rmm = running ? rst : nullptr;
+  float2 *rmm = (running && rst) ? part_r : nullptr;
   const long M = (long)(N * H * W);
+  const int pw_bn = Co > 64 ? 128 : 64;
+  const int n_part_r = (int)(cdn::ceil_div(M, kPw2BM) * cdn::ceil_div(Co, pw_bn));
+  CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
 #define CDN_PW(BN, AQ_)                                                                          \
   pw2_kernel<BN, AQ_><<<dim3((unsigned)cdn::ceil_div(M, kPw2BM), (unsigned)cdn::ceil_div(Co, BN)), \
                         256, 0, st>>>(d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M,   \
@@ -639,7 +670,9 @@ extern "C" int cdn_codenet_stage_fused_forward(
 #undef CDN_PW
   rc = cdn::check_launch("codenet fused pointwise");
   if (rc) return rc;
-  if (rst) cdn::launch_quantact_update(r_min, r_max, rst, nullptr, nullptr, bits, momentum, running, st);
+  if (rst)
+    cdn::launch_quantact_update(r_min, r_max, rst, nullptr, nullptr, rmm, n_part_r, bits, momentum,
+                                running, st);
   return CDN_OK;
 }
 

@@ -70,13 +70,27 @@ minmax_kernel(const float *__restrict__ x, long n, unsigned *state) {
 // One thread: range tracking + quantisation parameters (steps 2 and 3 above).
 // running != 0: update x_min/x_max from the batch statistics (reference behaviour even in
 // eval()); running == 0: frozen ranges, only derive scale / zp.
-__global__ void quantact_update_kernel(float *x_min, float *x_max, unsigned *state,
-                                       const float *ext_min, const float *ext_max, int bits,
-                                       float m_minus_1, float one_minus_m, int running) {
+__global__ void __launch_bounds__(256)
+quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float *ext_min,
+                       const float *ext_max, const float2 *partials, int n_partials, int bits,
+                       float m_minus_1, float one_minus_m, int running) {
+  __shared__ float red[8];
+  __shared__ float2 pr;
+  if (running && !ext_min && partials) {   // reduce the producers' per-workgroup {min,max}
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
+      const float2 v = partials[i];
+      mn = fminf(mn, v.x);
+      mx = fmaxf(mx, v.y);
+    }
+    cdn::block_minmax_store(mn, mx, &pr, red);
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
   float lo = x_min[0], hi = x_max[0];
   if (running) {
-    const float bmin = ext_min ? ext_min[0] : ord2f(state[0]);
-    const float bmax = ext_max ? ext_max[0] : ord2f(state[1]);
+    const float bmin = ext_min ? ext_min[0] : (partials ? pr.x : ord2f(state[0]));
+    const float bmax = ext_max ? ext_max[0] : (partials ? pr.y : ord2f(state[1]));
     reinterpret_cast<float *>(state)[4] = bmin;
     reinterpret_cast<float *>(state)[5] = bmax;
     if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
@@ -151,12 +165,14 @@ void launch_minmax_init(unsigned *s0, unsigned *s1, unsigned *s2, hipStream_t st
   minmax_init_kernel<<<1, 1, 0, st>>>(s0, s1, s2);
 }
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
-                            const float *ext_max, int bits, double momentum, int running,
-                            hipStream_t st) {
+                            const float *ext_max, const float2 *partials, int n_partials, int bits,
+                            double momentum, int running, hipStream_t st) {
   // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
   // the scalar to fp32 (quant_modules.py:217-219).
-  quantact_update_kernel<<<1, 1, 0, st>>>(x_min, x_max, state, ext_min, ext_max, bits,
-                                          (float)(momentum - 1.0), (float)(1.0 - momentum), running);
+  const int threads = (running && !ext_min && partials) ? 256 : 64;
+  quantact_update_kernel<<<1, threads, 0, st>>>(x_min, x_max, state, ext_min, ext_max, partials,
+                                                n_partials, bits, (float)(momentum - 1.0),
+                                                (float)(1.0 - momentum), running);
 }
 }  // namespace cdn
 
@@ -181,11 +197,8 @@ extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, 
     cdn::launch_minmax_init(stt, nullptr, nullptr, st);
     minmax_kernel<<<stream_grid(numel), 256, 0, st>>>(x, (long)numel, stt);
   }
-  // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
-  // the scalar to fp32 (quant_modules.py:217-219).
-  quantact_update_kernel<<<1, 1, 0, st>>>(x_min, x_max, stt, batch_min, batch_max, bits,
-                                          (float)(momentum - 1.0),
-                                          (float)(1.0 - momentum), running);
+  cdn::launch_quantact_update(x_min, x_max, stt, batch_min, batch_max, nullptr, 0, bits, momentum,
+                              running, st);
   if (out || codes)
     fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, codes, (long)numel, stt);
   return cdn::check_launch("quantact forward");
