@@ -192,6 +192,8 @@ def main():
         for (name, tag), v in durs.items():
             per_kernel.setdefault(name, 0.0)
             per_kernel[name] += sum(v) / args.steps          # ms per step in this kernel
+        per_launch = {"%s@%s" % (name, "x".join(str(t) for t in tag)): round(sum(v) / len(v), 5)
+                      for (name, tag), v in sorted(durs.items())}
         dominant = max(per_kernel, key=per_kernel.get)
         _, per_stage = pipeline.algorithmic_bytes(args.batch, args.res, args.w2)
         alg = {"scale": 0, "dw": 0, "pointwise": 0}
@@ -260,6 +262,7 @@ def main():
             },
             "roofline": roof,
             "kernel_ms_per_step": per_kernel,
+            "kernel_ms_per_launch": per_launch,
         }
         if net_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(args, net_cpu)

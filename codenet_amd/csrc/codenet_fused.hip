@@ -56,10 +56,13 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
 // scale, NCHW input (stage 0 of the model: x comes from the PyTorch backbone).
 // s[n,p] = clamp(b + sum_c w[c]*x[n,c,p]); block min/max -> state.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kScaleWaves = 16;
+__global__ void __launch_bounds__(kScaleWaves * 64)
 scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
                   const float *__restrict__ b, float *__restrict__ s, float2 *mm, int C, int HW,
                   float lo, float hi) {
+  // 16 waves x 64 pixels: wave v reduces channels v, v+16, ... with 4 loads in flight per lane
+  // (~16 KB of 256-byte rows in flight per workgroup) -- the HBM-bound C -> 1 reduction.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
   const int n = blockIdx.y;
@@ -67,20 +70,23 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
   const float *xp = x + (long)n * C * HW + (live ? p : 0);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int c = wave;
-  for (; c + 12 < C; c += 16) {
-    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + 4) * HW];
-    const float v2 = xp[(long)(c + 8) * HW], v3 = xp[(long)(c + 12) * HW];
+  constexpr int S = kScaleWaves;
+  for (; c + 3 * S < C; c += 4 * S) {
+    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + S) * HW];
+    const float v2 = xp[(long)(c + 2 * S) * HW], v3 = xp[(long)(c + 3 * S) * HW];
     a0 = fmaf(w[c], v0, a0);
-    a1 = fmaf(w[c + 4], v1, a1);
-    a2 = fmaf(w[c + 8], v2, a2);
-    a3 = fmaf(w[c + 12], v3, a3);
+    a1 = fmaf(w[c + S], v1, a1);
+    a2 = fmaf(w[c + 2 * S], v2, a2);
+    a3 = fmaf(w[c + 3 * S], v3, a3);
   }
-  for (; c < C; c += 4) a0 = fmaf(w[c], xp[(long)c * HW], a0);
-  __shared__ float red[4][64];
+  for (; c < C; c += S) a0 = fmaf(w[c], xp[(long)c * HW], a0);
+  __shared__ float red[kScaleWaves][64];
   red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (wave == 0) {
-    float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kScaleWaves; ++i) v += red[i][lane];
     v += b ? b[0] : 0.0f;
     v = fminf(fmaxf(v, lo), hi);
     if (live) s[(long)n * HW + p] = v;
@@ -150,7 +156,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-constexpr int kDw2Threads = 512;
+constexpr int kDw2Threads = 1024;
 
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
 __global__ void __launch_bounds__(kDw2Threads)
@@ -234,6 +240,13 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       }
     }
   }
+  // ---- the (fake-quantised) scale plane, once per workgroup --------------------------------
+  float *sl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
+  for (int q = tid; q < HWl; q += kDw2Threads) {
+    float sv = s_raw[(long)n * HWl + q];
+    if (SQ) sv = fake_quant(sv, ss, sz);
+    sl[q] = sv;
+  }
   // ---- this lane's depthwise weights: 4 channels x 9 taps ----------------------------------
   const int lane = tid & 63, wave = tid >> 6;
   const int cq = lane % LPP, sub = lane / LPP;
@@ -253,9 +266,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     const int p = p0 + sub;
     if (p >= HW) continue;
     const int h = p / W, w = p - h * W;
-    float sv = s_raw[(long)n * HWl + (h >> up) * Wl + (w >> up)];
-    if (SQ) sv = fake_quant(sv, ss, sz);
-    const float t = sv - 1.0f;
+    const float t = sl[(h >> up) * Wl + (w >> up)] - 1.0f;
     const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
     const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
     // LDS row (in float4 units) of hi-res coordinate pair (yy, xx); yy, xx in [-1, size]
@@ -365,34 +376,46 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 // Here i <-> pixel, j <-> co, so every accumulator register stores 128 contiguous bytes.
 // ------------------------------------------------------------------------------------------
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kPw2BM = 128, kPw2BK = 16, kPw2LD = 17;
+constexpr int kPwBK = 16, kPwLD = 17;
 
-template <int BN, bool AQ>
+// Software-pipelined: while the MFMAs of k-tile t run out of LDS buffer t&1, the global loads of
+// k-tile t+1 are in flight into registers; they are fake-quantised (A) and written to buffer
+// (t+1)&1 after the MFMAs, so there is ONE barrier per k-tile and the load latency, the
+// quantisation VALU work and the LDS writes all sit behind matrix work.
+// Workgroup = 4 waves arranged WGM (m) x 4/WGM (n); every wave owns TM x TN accumulators of 32x32.
+template <int BM, int BN, int WGM, bool AQ>
 __global__ void __launch_bounds__(256)
-pw2_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            const float *__restrict__ Wp, const float *__restrict__ bias,
            const float *__restrict__ ep_scale, const float *__restrict__ ep_shift,
            float *__restrict__ R, float2 *rmm, long M, int C, int Co, int relu) {
-  __shared__ float As[kPw2BM * kPw2LD];
-  __shared__ float Bs[BN * kPw2LD];
-  constexpr int NT = BN / 32;
-  const long m0 = (long)blockIdx.x * kPw2BM;
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+  constexpr int AI = BM * 4 / 256, BI = BN * 4 / 256;   // float4 loads per thread per k-tile
+  static_assert(TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1, "tile too small for 256 threads");
+  __shared__ float As[2][BM * kPwLD];
+  __shared__ float Bs[2][BN * kPwLD];
+  const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
   float qs = 1.f, qz = 0.f;
   if (AQ) {
     qs = reinterpret_cast<const float *>(aq)[2];
     qz = reinterpret_cast<const float *>(aq)[3];
   }
-  f32x16 acc[NT];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
   const bool vec = (C & 3) == 0;
-  const int lr = tid >> 2, lk = (tid & 3) * 4;  // staging: row lr (+64), k quad lk
-  for (int k0 = 0; k0 < C; k0 += kPw2BK) {
-    float a[2][4], b[(BN + 63) / 64][4];
+  const int lr = tid >> 2, lk = (tid & 3) * 4;   // staging: row lr + 64*i, k quad lk
+  float a[AI][4], b[BI][4];
+
+  auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AI; ++i) {
       const long m = m0 + lr + 64 * i;
       const int k = k0 + lk;
       if (m < M && vec && k + 3 < C) {
@@ -402,50 +425,66 @@ pw2_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[i][e] = (m < M && k + e < C) ? A[m * C + k + e] : 0.0f;
       }
-      if (AQ) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (m < M && k + e < C) a[i][e] = fake_quant(a[i][e], qs, qz);
-      }
     }
 #pragma unroll
-    for (int i = 0; i < (BN + 63) / 64; ++i) {
+    for (int i = 0; i < BI; ++i) {
       const int co = n0 + lr + 64 * i;
       const int k = k0 + lk;
-      const bool rowok = (lr + 64 * i < BN) && co < Co;
-      if (rowok && vec && k + 3 < C) {
+      if (co < Co && vec && k + 3 < C) {
         const float4 v = *reinterpret_cast<const float4 *>(Wp + (long)co * C + k);
         b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[i][e] = (rowok && k + e < C) ? Wp[(long)co * C + k + e] : 0.0f;
+        for (int e = 0; e < 4; ++e) b[i][e] = (co < Co && k + e < C) ? Wp[(long)co * C + k + e] : 0.0f;
       }
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < AI; ++i) {
+      const bool rowok = (m0 + lr + 64 * i) < M;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) As[(lr + 64 * i) * kPw2LD + lk + e] = a[i][e];
-#pragma unroll
-    for (int i = 0; i < (BN + 63) / 64; ++i)
-      if (lr + 64 * i < BN)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[(lr + 64 * i) * kPw2LD + lk + e] = b[i][e];
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < kPw2BK; kk += 2) {
-      const float av = As[(wave * 32 + (lane & 31)) * kPw2LD + kk + (lane >> 5)];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float bv = Bs[(t * 32 + (lane & 31)) * kPw2LD + kk + (lane >> 5)];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+        float v = a[i][e];
+        if (AQ) v = (rowok && k0 + lk + e < C) ? fake_quant(v, qs, qz) : 0.0f;
+        As[buf][(lr + 64 * i) * kPwLD + lk + e] = v;
       }
     }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bs[buf][(lr + 64 * i) * kPwLD + lk + e] = b[i][e];
+  };
+
+  load_tile(0);
+  store_tile(0, 0);
+  __syncthreads();
+  const int nk = (C + kPwBK - 1) / kPwBK;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) load_tile((t + 1) * kPwBK);
+#pragma unroll
+    for (int kk = 0; kk < kPwBK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        av[i] = As[buf][(wm + i * 32 + (lane & 31)) * kPwLD + kk + (lane >> 5)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bv[j] = Bs[buf][(wn + j * 32 + (lane & 31)) * kPwLD + kk + (lane >> 5)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * kPwBK);
+    __syncthreads();
   }
   float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int co = n0 + t * 32 + (lane & 31);
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
     float bsv = 0.f, es = 1.f, eh = 0.f;
     if (co < Co) {
       if (bias) bsv = bias[co];
@@ -455,22 +494,22 @@ pw2_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m < M && co < Co) {
-        float v = acc[t][r] + bsv;
-        if (ep_scale) v = fmaf(v, es, eh);
-        if (relu) v = fmaxf(v, 0.0f);
-        R[m * Co + co] = v;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && co < Co) {
+          float v = acc[i][j][r] + bsv;
+          if (ep_scale) v = fmaf(v, es, eh);
+          if (relu) v = fmaxf(v, 0.0f);
+          R[m * Co + co] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
       }
-    }
   }
-  if (rmm) {
-    __syncthreads();   // As is free again: reuse its first words as the reduction scratch
-    cdn::block_minmax_store(mn, mx, rmm + (long)blockIdx.y * gridDim.x + blockIdx.x, As);
-  }
+  if (rmm)   // (the loop's trailing barrier freed As)
+    cdn::block_minmax_store(mn, mx, rmm + (long)blockIdx.y * gridDim.x + blockIdx.x, &As[0][0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,20 +531,49 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
     qz = reinterpret_cast<const float *>(rq)[3];
   }
   const float *rp = r + ((long)n * H + h) * W * C;
-  for (int q = threadIdx.x; q < W * C; q += 256) {
-    const int px = q / C, c = q - px * C;
-    float v = rp[q];
-    if (RQ) v = fake_quant(v, qs, qz);
-    tile[px * ld + c] = v;
+  if ((C & 3) == 0) {
+    for (int q = threadIdx.x; q < W * C / 4; q += 256) {
+      const int px = (q * 4) / C, c = q * 4 - px * C;
+      float4 v = *reinterpret_cast<const float4 *>(rp + (long)q * 4);
+      if (RQ) {
+        v.x = fake_quant(v.x, qs, qz);
+        v.y = fake_quant(v.y, qs, qz);
+        v.z = fake_quant(v.z, qs, qz);
+        v.w = fake_quant(v.w, qs, qz);
+      }
+      float *tp = tile + px * ld + c;
+      tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
+    }
+  } else {
+    for (int q = threadIdx.x; q < W * C; q += 256) {
+      const int px = q / C, c = q - px * C;
+      float v = rp[q];
+      if (RQ) v = fake_quant(v, qs, qz);
+      tile[px * ld + c] = v;
+    }
   }
   __syncthreads();
   const int f = 1 << up;
   const int Wo = W * f, Ho = H * f;
-  const int per_c = f * Wo;  // output floats per channel from this row
-  for (int q = threadIdx.x; q < C * per_c; q += 256) {
-    const int c = q / per_c, rem = q - c * per_c;
-    const int dy = rem / Wo, xo = rem - dy * Wo;
-    out[(((long)n * C + c) * Ho + h * f + dy) * Wo + xo] = tile[(xo >> up) * ld + c];
+  if ((Wo & 3) == 0) {   // 16-byte stores: 4 consecutive output columns per thread
+    const int wq = Wo >> 2, per_c = f * wq;
+    for (int q = threadIdx.x; q < C * per_c; q += 256) {
+      const int c = q / per_c, rem = q - c * per_c;
+      const int dy = rem / wq, xo = (rem - dy * wq) * 4;
+      float4 v;
+      v.x = tile[((xo + 0) >> up) * ld + c];
+      v.y = tile[((xo + 1) >> up) * ld + c];
+      v.z = tile[((xo + 2) >> up) * ld + c];
+      v.w = tile[((xo + 3) >> up) * ld + c];
+      *reinterpret_cast<float4 *>(out + (((long)n * C + c) * Ho + h * f + dy) * Wo + xo) = v;
+    }
+  } else {
+    const int per_c = f * Wo;
+    for (int q = threadIdx.x; q < C * per_c; q += 256) {
+      const int c = q / per_c, rem = q - c * per_c;
+      const int dy = rem / Wo, xo = rem - dy * Wo;
+      out[(((long)n * C + c) * Ho + h * f + dy) * Wo + xo] = tile[(xo >> up) * ld + c];
+    }
   }
 }
 
@@ -516,7 +584,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
                const unsigned *sq, const float *wd, float *d, float2 *dmm, int N, int C, int H,
                int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
-  const size_t lds = (size_t)(Hl + 2) * (Wl + 2) * CCH * sizeof(float);
+  const size_t lds = ((size_t)(Hl + 2) * (Wl + 2) * CCH + (size_t)Hl * Wl) * sizeof(float);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
@@ -597,7 +665,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
 
   // LDS budget of the gather kernel decides the channel chunk
   const size_t cells = (size_t)(Hl + 2) * (Wl + 2);
-  const size_t lds_max = 160 * 1024;
+  const size_t lds_max = 160 * 1024 - 256 - (size_t)HWl * 4;   // scale plane + reduction scratch
   int cch = 0;
   if (cells * 64 * 4 <= lds_max) cch = 64;
   else if (cells * 32 * 4 <= lds_max) cch = 32;
@@ -626,7 +694,8 @@ extern "C" int cdn_codenet_stage_fused_forward(
     dim3 grid((unsigned)cdn::ceil_div(HWl, 64), (unsigned)N);
     n_part_s = (int)(grid.x * grid.y);
     CDN_REQUIRE(n_part_s <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many scale workgroups");
-    scale_nchw_kernel<<<grid, 256, 0, st>>>(x, w_scale, b_scale, s_raw, smm, (int)C, (int)HWl, lo, hi);
+    scale_nchw_kernel<<<grid, kScaleWaves * 64, 0, st>>>(x, w_scale, b_scale, s_raw, smm, (int)C,
+                                                          (int)HWl, lo, hi);
   }
   }
   int rc = cdn::check_launch("codenet fused scale");
@@ -652,19 +721,23 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // 3. pointwise on f32 MFMA (+ bias / affine / ReLU, min/max of the result)
   float2 *rmm = (running && rst) ? part_r : nullptr;
   const long M = (long)(N * H * W);
+  // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
   const int pw_bn = Co > 64 ? 128 : 64;
-  const int n_part_r = (int)(cdn::ceil_div(M, kPw2BM) * cdn::ceil_div(Co, pw_bn));
+  const int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) < 4 * cdn::kCUs) ? 64 : 128;
+  const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-#define CDN_PW(BN, AQ_)                                                                          \
-  pw2_kernel<BN, AQ_><<<dim3((unsigned)cdn::ceil_div(M, kPw2BM), (unsigned)cdn::ceil_div(Co, BN)), \
-                        256, 0, st>>>(d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M,   \
-                                      (int)C, (int)Co, relu)
+#define CDN_PW(BM_, BN_, WGM_, AQ_)                                                              \
+  pw3_kernel<BM_, BN_, WGM_, AQ_><<<dim3((unsigned)cdn::ceil_div(M, BM_),                        \
+                                         (unsigned)cdn::ceil_div(Co, BN_)), 256, 0, st>>>(       \
+      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M, (int)C, (int)Co, relu)
   {
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
-    if (Co > 64) {
-      if (dst) CDN_PW(128, true); else CDN_PW(128, false);
+    if (pw_bn == 128 && pw_bm == 64) {
+      if (dst) CDN_PW(64, 128, 2, true); else CDN_PW(64, 128, 2, false);
+    } else if (pw_bn == 128) {
+      if (dst) CDN_PW(128, 128, 4, true); else CDN_PW(128, 128, 4, false);
     } else {
-      if (dst) CDN_PW(64, true); else CDN_PW(64, false);
+      if (dst) CDN_PW(128, 64, 4, true); else CDN_PW(128, 64, 4, false);
     }
   }
 #undef CDN_PW
