@@ -376,14 +376,16 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 // Here i <-> pixel, j <-> co, so every accumulator register stores 128 contiguous bytes.
 // ------------------------------------------------------------------------------------------
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kPwBK = 16, kPwLD = 17;
+constexpr int kPwBK = 32, kPwLD = 33;
 
 // Software-pipelined: while the MFMAs of k-tile t run out of LDS buffer t&1, the global loads of
 // k-tile t+1 are in flight into registers; they are fake-quantised (A) and written to buffer
-// (t+1)&1 after the MFMAs, so there is ONE barrier per k-tile and the load latency, the
-// quantisation VALU work and the LDS writes all sit behind matrix work.
+// (t+1)&1 after the MFMAs, so there is ONE barrier per 32-deep k-tile and the load latency, the
+// quantisation VALU work and the LDS writes all sit behind matrix work.  All operand fragments
+// of a k-tile are read from LDS up front, then the MFMAs issue back to back.
 // Workgroup = 4 waves arranged WGM (m) x 4/WGM (n); every wave owns TM x TN accumulators of 32x32.
-template <int BM, int BN, int WGM, bool AQ>
+// FAST: C % 32 == 0 (no k guards, 16-byte loads); otherwise guarded scalar loads.
+template <int BM, int BN, int WGM, bool AQ, bool FAST>
 __global__ void __launch_bounds__(256)
 pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            const float *__restrict__ Wp, const float *__restrict__ bias,
@@ -391,7 +393,7 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            float *__restrict__ R, float2 *rmm, long M, int C, int Co, int relu) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
-  constexpr int AI = BM * 4 / 256, BI = BN * 4 / 256;   // float4 loads per thread per k-tile
+  constexpr int AI = BM * 8 / 256, BI = BN * 8 / 256;   // float4 loads per thread per k-tile
   static_assert(TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1, "tile too small for 256 threads");
   __shared__ float As[2][BM * kPwLD];
   __shared__ float Bs[2][BN * kPwLD];
@@ -409,51 +411,75 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
-  const bool vec = (C & 3) == 0;
-  const int lr = tid >> 2, lk = (tid & 3) * 4;   // staging: row lr + 64*i, k quad lk
-  float a[AI][4], b[BI][4];
+  const int lr = tid >> 3, lk = (tid & 7) * 4;   // staging: row lr + 32*i, k quad lk
+  float4 a[AI], b[BI];
+  // FAST path: rows beyond M / Co are clamped to a valid row (their results are never stored)
+  const float *arow[AI];
+  const float *brow[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    long m = m0 + lr + 32 * i;
+    if (m > M - 1) m = M - 1;
+    arow[i] = A + m * C + lk;
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int co = n0 + lr + 32 * i;
+    if (co > Co - 1) co = Co - 1;
+    brow[i] = Wp + (long)co * C + lk;
+  }
 
   auto load_tile = [&](int k0) {
+    if (FAST) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const long m = m0 + lr + 64 * i;
-      const int k = k0 + lk;
-      if (m < M && vec && k + 3 < C) {
-        const float4 v = *reinterpret_cast<const float4 *>(A + m * C + k);
-        a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-      } else {
+      for (int i = 0; i < AI; ++i) a[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[i][e] = (m < M && k + e < C) ? A[m * C + k + e] : 0.0f;
+      for (int i = 0; i < BI; ++i) b[i] = *reinterpret_cast<const float4 *>(brow[i] + k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int k = k0 + lk;
+        a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
+        a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
+        a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
+        a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
       }
-    }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int co = n0 + lr + 64 * i;
-      const int k = k0 + lk;
-      if (co < Co && vec && k + 3 < C) {
-        const float4 v = *reinterpret_cast<const float4 *>(Wp + (long)co * C + k);
-        b[i][0] = v.x; b[i][1] = v.y; b[i][2] = v.z; b[i][3] = v.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b[i][e] = (co < Co && k + e < C) ? Wp[(long)co * C + k + e] : 0.0f;
+      for (int i = 0; i < BI; ++i) {
+        const int k = k0 + lk;
+        b[i].x = (k + 0 < C) ? brow[i][k0 + 0] : 0.0f;
+        b[i].y = (k + 1 < C) ? brow[i][k0 + 1] : 0.0f;
+        b[i].z = (k + 2 < C) ? brow[i][k0 + 2] : 0.0f;
+        b[i].w = (k + 3 < C) ? brow[i][k0 + 3] : 0.0f;
       }
     }
   };
   auto store_tile = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const bool rowok = (m0 + lr + 64 * i) < M;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = a[i][e];
-        if (AQ) v = (rowok && k0 + lk + e < C) ? fake_quant(v, qs, qz) : 0.0f;
-        As[buf][(lr + 64 * i) * kPwLD + lk + e] = v;
+      float4 v = a[i];
+      if (AQ) {
+        if (FAST) {
+          v.x = fake_quant(v.x, qs, qz);
+          v.y = fake_quant(v.y, qs, qz);
+          v.z = fake_quant(v.z, qs, qz);
+          v.w = fake_quant(v.w, qs, qz);
+        } else {   // keep the zero padding of the k tail exact
+          const int k = k0 + lk;
+          v.x = (k + 0 < C) ? fake_quant(v.x, qs, qz) : 0.0f;
+          v.y = (k + 1 < C) ? fake_quant(v.y, qs, qz) : 0.0f;
+          v.z = (k + 2 < C) ? fake_quant(v.z, qs, qz) : 0.0f;
+          v.w = (k + 3 < C) ? fake_quant(v.w, qs, qz) : 0.0f;
+        }
       }
+      float *p = &As[buf][(lr + 32 * i) * kPwLD + lk];
+      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < BI; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) Bs[buf][(lr + 64 * i) * kPwLD + lk + e] = b[i][e];
+    for (int i = 0; i < BI; ++i) {
+      float *p = &Bs[buf][(lr + 32 * i) * kPwLD + lk];
+      p[0] = b[i].x; p[1] = b[i].y; p[2] = b[i].z; p[3] = b[i].w;
+    }
   };
 
   load_tile(0);
@@ -463,21 +489,24 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     if (t + 1 < nk) load_tile((t + 1) * kPwBK);
+    // all fragments of this k-tile, then the MFMAs back to back
+    float av[kPwBK / 2][TM], bv[kPwBK / 2][TN];
 #pragma unroll
-    for (int kk = 0; kk < kPwBK; kk += 2) {
-      float av[TM], bv[TN];
+    for (int kk = 0; kk < kPwBK / 2; ++kk) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        av[i] = As[buf][(wm + i * 32 + (lane & 31)) * kPwLD + kk + (lane >> 5)];
+        av[kk][i] = As[buf][(wm + i * 32 + (lane & 31)) * kPwLD + 2 * kk + (lane >> 5)];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bv[j] = Bs[buf][(wn + j * 32 + (lane & 31)) * kPwLD + kk + (lane >> 5)];
+        bv[kk][j] = Bs[buf][(wn + j * 32 + (lane & 31)) * kPwLD + 2 * kk + (lane >> 5)];
+    }
+#pragma unroll
+    for (int kk = 0; kk < kPwBK / 2; ++kk)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], bv[kk][j], acc[i][j], 0, 0, 0);
     if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * kPwBK);
     __syncthreads();
   }
@@ -726,10 +755,16 @@ extern "C" int cdn_codenet_stage_fused_forward(
   const int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) < 4 * cdn::kCUs) ? 64 : 128;
   const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-#define CDN_PW(BM_, BN_, WGM_, AQ_)                                                              \
-  pw3_kernel<BM_, BN_, WGM_, AQ_><<<dim3((unsigned)cdn::ceil_div(M, BM_),                        \
-                                         (unsigned)cdn::ceil_div(Co, BN_)), 256, 0, st>>>(       \
+  const bool pw_fast = (C % 32) == 0;
+#define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
+  pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<dim3((unsigned)cdn::ceil_div(M, BM_),                 \
+                                                (unsigned)cdn::ceil_div(Co, BN_)), 256, 0, st>>>( \
       d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M, (int)C, (int)Co, relu)
+#define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
+  do {                                                                    \
+    if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
+    else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
+  } while (0)
   {
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {
@@ -741,6 +776,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
     }
   }
 #undef CDN_PW
+#undef CDN_PW1
   rc = cdn::check_launch("codenet fused pointwise");
   if (rc) return rc;
   if (rst)
