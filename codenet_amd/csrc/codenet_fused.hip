@@ -156,7 +156,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-constexpr int kDw2Threads = 1024;
+constexpr int kDw2Threads = 512;
 
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
 __global__ void __launch_bounds__(kDw2Threads)
@@ -164,15 +164,20 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, int C, int H, int W,
            int up) {
-  extern __shared__ float4 img[];  // [cells][LPP] float4
-  __shared__ float red[2 * kDw2Threads / 64];
+  // LDS: [Hl*Wl + 1][CCH] image rows (the last row is the shared ZERO cell that every
+  // out-of-image corner maps to -- per-corner zeroing of the reference, _kernel.cu:97-108),
+  // then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
+  extern __shared__ float4 img[];
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
-  const int Hl = H >> up, Wl = W >> up, Wp = Wl + 2;
-  const int cells = (Hl + 2) * Wp;
+  constexpr int kWaves = kDw2Threads / 64;
+  const int Hl = H >> up, Wl = W >> up;
   const int HWl = Hl * Wl, HW = H * W;
   const int n = blockIdx.y, c0 = blockIdx.x * CCH;
   const int tid = threadIdx.x;
+  float *wl = reinterpret_cast<float *>(img + (size_t)(HWl + 1) * LPP);
+  float *sl = wl + CCH * 9;
+  float *red = sl + HWl;
   float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
   if (XQ) {
     xs = reinterpret_cast<const float *>(xq)[2];
@@ -182,18 +187,9 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     ss = reinterpret_cast<const float *>(sq)[2];
     sz = reinterpret_cast<const float *>(sq)[3];
   }
-
-  // ---- zero border: top/bottom rows, left/right columns ---------------------------------
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int q = tid; q < 2 * Wp * LPP; q += kDw2Threads) {
-    const int cell = (q / LPP) < Wp ? (q / LPP) : (cells - 2 * Wp + q / LPP);
-    img[cell * LPP + (q % LPP)] = z4;
-  }
-  for (int q = tid; q < 2 * Hl * LPP; q += kDw2Threads) {
-    const int r = (q / LPP) >> 1, side = (q / LPP) & 1;
-    img[((r + 1) * Wp + (side ? Wp - 1 : 0)) * LPP + (q % LPP)] = z4;
-  }
-  // ---- stage the interior ----------------------------------------------------------------
+  if (tid < LPP) img[HWl * LPP + tid] = z4;
+  // ---- stage the image -------------------------------------------------------------------
   if (NHWC_IN) {
     const float *xg = x + (long)n * HWl * C + c0;
     for (int q = tid; q < HWl * LPP; q += kDw2Threads) {
@@ -206,8 +202,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         v.z = fake_quant(v.z, xs, xz);
         v.w = fake_quant(v.w, xs, xz);
       }
-      const int yy = pix / Wl, xx = pix - yy * Wl;
-      img[((yy + 1) * Wp + xx + 1) * LPP + cq] = v;
+      img[q] = v;
     }
   } else {
     // lane <-> channel so the four scalar LDS stores of a wave hit consecutive banks
@@ -231,37 +226,43 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int pix = j * 4 + e;
-        if (pix < HWl) {
-          const int yy = pix / Wl, xx = pix - yy * Wl;
-          float t = v[e];
-          if (XQ) t = fake_quant(t, xs, xz);
-          imgf[((yy + 1) * Wp + xx + 1) * CCH + cl] = t;
-        }
+        if (pix < HWl) imgf[pix * CCH + cl] = XQ ? fake_quant(v[e], xs, xz) : v[e];
       }
     }
   }
-  // ---- the (fake-quantised) scale plane, once per workgroup --------------------------------
-  float *sl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
+  // ---- chunk weights (coalesced) and the (fake-quantised) scale plane ------------------------
+  for (int q = tid; q < CCH * 9; q += kDw2Threads)
+    wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
   for (int q = tid; q < HWl; q += kDw2Threads) {
     float sv = s_raw[(long)n * HWl + q];
     if (SQ) sv = fake_quant(sv, ss, sz);
     sl[q] = sv;
   }
-  // ---- this lane's depthwise weights: 4 channels x 9 taps ----------------------------------
+  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int cq = lane % LPP, sub = lane / LPP;
   float wk[9][4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = c0 + cq * 4 + e;
+  for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k][e] = (c < C) ? wd[(long)c * 9 + k] : 0.0f;
-  }
-  __syncthreads();
+    for (int k = 0; k < 9; ++k) wk[k][e] = wl[(cq * 4 + e) * 9 + k];
+
+  // byte offsets: row part + column part; invalid parts are hugely negative so that the unsigned
+  // min with the ZERO cell's offset redirects every out-of-image corner there.
+  constexpr int kBad = -(1 << 28);
+  const unsigned zero_off = (unsigned)((HWl * LPP + cq) * 16);
+  auto row_off = [&](int yy) { return ((unsigned)yy < (unsigned)H) ? ((yy >> up) * Wl) * LPP * 16 : kBad; };
+  auto col_off = [&](int xx) {
+    return ((unsigned)xx < (unsigned)W) ? ((xx >> up) * LPP + cq) * 16 : kBad;
+  };
+  const char *imgb = reinterpret_cast<const char *>(img);
+  auto rd = [&](int ro, int co) -> float4 {
+    const unsigned off = min((unsigned)(ro + co), zero_off);
+    return *reinterpret_cast<const float4 *>(imgb + off);
+  };
 
   float mn = INFINITY, mx = -INFINITY;
   const bool vec_store = ((C & 3) == 0);
-  constexpr int kWaves = kDw2Threads / 64;
   for (int p0 = wave * PPW; p0 < HW; p0 += kWaves * PPW) {
     const int p = p0 + sub;
     if (p >= HW) continue;
@@ -269,83 +270,58 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     const float t = sl[(h >> up) * Wl + (w >> up)] - 1.0f;
     const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
     const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
-    // LDS row (in float4 units) of hi-res coordinate pair (yy, xx); yy, xx in [-1, size]
-#define CDN_CELL(yy, xx) (((((yy) >> up) + 1) * Wp + ((xx) >> up) + 1) * LPP + cq)
-#define CDN_ACC4(A, WT, V)            \
-  A.x = fmaf(WT, V.x, A.x);           \
-  A.y = fmaf(WT, V.y, A.y);           \
-  A.z = fmaf(WT, V.z, A.z);           \
-  A.w = fmaf(WT, V.w, A.w);
+    const int rya0 = row_off(ya.i0), rya1 = row_off(ya.i0 + 1);
+    const int ryb0 = row_off(yb.i0), ryb1 = row_off(yb.i0 + 1);
+    const int rh = row_off(h);
+    const int cxa0 = col_off(xa.i0), cxa1 = col_off(xa.i0 + 1);
+    const int cxb0 = col_off(xb.i0), cxb1 = col_off(xb.i0 + 1);
+    const int cw = col_off(w);
     float4 acc = z4;
-    // corner taps (4 reads each)
-#define CDN_TAP4(Y, X, K)                                        \
-  {                                                              \
-    const float4 v00 = img[CDN_CELL(Y.i0, X.i0)];                \
-    const float4 v01 = img[CDN_CELL(Y.i0, X.i0 + 1)];            \
-    const float4 v10 = img[CDN_CELL(Y.i0 + 1, X.i0)];            \
-    const float4 v11 = img[CDN_CELL(Y.i0 + 1, X.i0 + 1)];        \
-    const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1;            \
-    const float w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;            \
-    float4 tv;                                                   \
+#define CDN_WACC(K, TV)                     \
+  acc.x = fmaf(wk[K][0], TV.x, acc.x);      \
+  acc.y = fmaf(wk[K][1], TV.y, acc.y);      \
+  acc.z = fmaf(wk[K][2], TV.z, acc.z);      \
+  acc.w = fmaf(wk[K][3], TV.w, acc.w);
+    // corner taps: 4 reads
+#define CDN_TAP4(Y, X, R0, R1, C0, C1, K)                             \
+  {                                                                   \
+    const float4 v00 = rd(R0, C0), v01 = rd(R0, C1);                  \
+    const float4 v10 = rd(R1, C0), v11 = rd(R1, C1);                  \
+    const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1;                 \
+    const float w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;                 \
+    float4 tv;                                                        \
     tv.x = ((w00 * v00.x + w01 * v01.x) + w10 * v10.x) + w11 * v11.x; \
     tv.y = ((w00 * v00.y + w01 * v01.y) + w10 * v10.y) + w11 * v11.y; \
     tv.z = ((w00 * v00.z + w01 * v01.z) + w10 * v10.z) + w11 * v11.z; \
     tv.w = ((w00 * v00.w + w01 * v01.w) + w10 * v10.w) + w11 * v11.w; \
-    acc.x = fmaf(wk[K][0], tv.x, acc.x);                         \
-    acc.y = fmaf(wk[K][1], tv.y, acc.y);                         \
-    acc.z = fmaf(wk[K][2], tv.z, acc.z);                         \
-    acc.w = fmaf(wk[K][3], tv.w, acc.w);                         \
+    CDN_WACC(K, tv)                                                   \
   }
-    // vertical edge taps (column exact): 2 reads
-#define CDN_TAPV(Y, K)                                           \
-  {                                                              \
-    const float4 v0 = img[CDN_CELL(Y.i0, w)];                    \
-    const float4 v1 = img[CDN_CELL(Y.i0 + 1, w)];                \
-    float4 tv;                                                   \
-    tv.x = Y.w0 * v0.x + Y.w1 * v1.x;                            \
-    tv.y = Y.w0 * v0.y + Y.w1 * v1.y;                            \
-    tv.z = Y.w0 * v0.z + Y.w1 * v1.z;                            \
-    tv.w = Y.w0 * v0.w + Y.w1 * v1.w;                            \
-    acc.x = fmaf(wk[K][0], tv.x, acc.x);                         \
-    acc.y = fmaf(wk[K][1], tv.y, acc.y);                         \
-    acc.z = fmaf(wk[K][2], tv.z, acc.z);                         \
-    acc.w = fmaf(wk[K][3], tv.w, acc.w);                         \
+    // edge taps: one axis exact, 2 reads
+#define CDN_TAP2(A, RA, CA, RB, CB, K)            \
+  {                                               \
+    const float4 v0 = rd(RA, CA), v1 = rd(RB, CB); \
+    float4 tv;                                    \
+    tv.x = A.w0 * v0.x + A.w1 * v1.x;             \
+    tv.y = A.w0 * v0.y + A.w1 * v1.y;             \
+    tv.z = A.w0 * v0.z + A.w1 * v1.z;             \
+    tv.w = A.w0 * v0.w + A.w1 * v1.w;             \
+    CDN_WACC(K, tv)                               \
   }
-    // horizontal edge taps (row exact): 2 reads
-#define CDN_TAPH(X, K)                                           \
-  {                                                              \
-    const float4 v0 = img[CDN_CELL(h, X.i0)];                    \
-    const float4 v1 = img[CDN_CELL(h, X.i0 + 1)];                \
-    float4 tv;                                                   \
-    tv.x = X.w0 * v0.x + X.w1 * v1.x;                            \
-    tv.y = X.w0 * v0.y + X.w1 * v1.y;                            \
-    tv.z = X.w0 * v0.z + X.w1 * v1.z;                            \
-    tv.w = X.w0 * v0.w + X.w1 * v1.w;                            \
-    acc.x = fmaf(wk[K][0], tv.x, acc.x);                         \
-    acc.y = fmaf(wk[K][1], tv.y, acc.y);                         \
-    acc.z = fmaf(wk[K][2], tv.z, acc.z);                         \
-    acc.w = fmaf(wk[K][3], tv.w, acc.w);                         \
-  }
-    CDN_TAP4(ya, xa, 0)
-    CDN_TAPV(ya, 1)
-    CDN_TAP4(ya, xb, 2)
-    CDN_TAPH(xa, 3)
+    CDN_TAP4(ya, xa, rya0, rya1, cxa0, cxa1, 0)
+    CDN_TAP2(ya, rya0, cw, rya1, cw, 1)
+    CDN_TAP4(ya, xb, rya0, rya1, cxb0, cxb1, 2)
+    CDN_TAP2(xa, rh, cxa0, rh, cxa1, 3)
     {
-      const float4 vc = img[CDN_CELL(h, w)];
-      acc.x = fmaf(wk[4][0], vc.x, acc.x);
-      acc.y = fmaf(wk[4][1], vc.y, acc.y);
-      acc.z = fmaf(wk[4][2], vc.z, acc.z);
-      acc.w = fmaf(wk[4][3], vc.w, acc.w);
+      const float4 vc = rd(rh, cw);
+      CDN_WACC(4, vc)
     }
-    CDN_TAPH(xb, 5)
-    CDN_TAP4(yb, xa, 6)
-    CDN_TAPV(yb, 7)
-    CDN_TAP4(yb, xb, 8)
+    CDN_TAP2(xb, rh, cxb0, rh, cxb1, 5)
+    CDN_TAP4(yb, xa, ryb0, ryb1, cxa0, cxa1, 6)
+    CDN_TAP2(yb, ryb0, cw, ryb1, cw, 7)
+    CDN_TAP4(yb, xb, ryb0, ryb1, cxb0, cxb1, 8)
 #undef CDN_TAP4
-#undef CDN_TAPV
-#undef CDN_TAPH
-#undef CDN_ACC4
-#undef CDN_CELL
+#undef CDN_TAP2
+#undef CDN_WACC
     float *dp = d + ((long)n * HW + p) * C + c0 + cq * 4;
     const int cbase = c0 + cq * 4;
     if (vec_store && cbase + 3 < C) {
@@ -613,7 +589,8 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
                const unsigned *sq, const float *wd, float *d, float2 *dmm, int N, int C, int H,
                int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
-  const size_t lds = ((size_t)(Hl + 2) * (Wl + 2) * CCH + (size_t)Hl * Wl) * sizeof(float);
+  const size_t lds = ((size_t)(Hl * Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl + 2 * kDw2Threads / 64) *
+                     sizeof(float);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
@@ -693,13 +670,14 @@ extern "C" int cdn_codenet_stage_fused_forward(
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
 
   // LDS budget of the gather kernel decides the channel chunk
-  const size_t cells = (size_t)(Hl + 2) * (Wl + 2);
-  const size_t lds_max = 160 * 1024 - 256 - (size_t)HWl * 4;   // scale plane + reduction scratch
+  const size_t cells = (size_t)Hl * Wl + 1;   // + the shared zero cell
+  // scale plane, weights and reduction scratch share the 160 KiB
+  const size_t lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (size_t)HWl * 4;
   int cch = 0;
   if (cells * 64 * 4 <= lds_max) cch = 64;
   else if (cells * 32 * 4 <= lds_max) cch = 32;
   CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
-              "stored plane %dx%d too large for the LDS-resident gather (max ~1270 cells)", Hl, Wl);
+              "stored plane %dx%d too large for the LDS-resident gather (max ~1250 pixels)", Hl, Wl);
 
   if (running && (sst || dst || rst)) cdn::launch_minmax_init(sst, dst, rst, st);
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
