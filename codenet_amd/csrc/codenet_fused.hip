@@ -22,6 +22,7 @@
 #include "cdn_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -156,10 +157,10 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-constexpr int kDw2Threads = 512;
+constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (512 or 1024)
 
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
-__global__ void __launch_bounds__(kDw2Threads)
+__global__ void __launch_bounds__(kDw2MaxThreads)
 dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, int C, int H, int W,
@@ -170,7 +171,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   extern __shared__ float4 img[];
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
-  constexpr int kWaves = kDw2Threads / 64;
+  const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
   const int Hl = H >> up, Wl = W >> up;
   const int HWl = Hl * Wl, HW = H * W;
   const int n = blockIdx.y, c0 = blockIdx.x * CCH;
@@ -589,15 +590,19 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
                const unsigned *sq, const float *wd, float *d, float2 *dmm, int N, int C, int H,
                int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
-  const size_t lds = ((size_t)(Hl * Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl + 2 * kDw2Threads / 64) *
+  const size_t lds = ((size_t)(Hl * Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl + 2 * kDw2MaxThreads / 64) *
                      sizeof(float);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
+  // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
+  // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
+  const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
+  const int threads = two_per_cu ? 512 : 1024;
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
     auto kern = dw2_kernel<CCH, NH, XQ_, SQ_>;                                                \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, kDw2Threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, C, H, W, up);          \
+    kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, C, H, W, up);              \
   }
   const bool XQ = xq != nullptr, SQ = sq != nullptr;
   if (nhwc) {
@@ -730,7 +735,8 @@ extern "C" int cdn_codenet_stage_fused_forward(
   const long M = (long)(N * H * W);
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
   const int pw_bn = Co > 64 ? 128 : 64;
-  const int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) < 4 * cdn::kCUs) ? 64 : 128;
+  int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
+  if (const char *e = getenv("CDN_PW_BM")) pw_bm = (atoi(e) == 64 && Co > 64) ? 64 : 128;   // tuning knob
   const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
   const bool pw_fast = (C % 32) == 0;
