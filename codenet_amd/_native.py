@@ -33,7 +33,7 @@ _SIGNATURES = {
     "cdn_quantact_forward": (_i, [_vp] * 3 + [_i64] + [_vp] * 5 + [_i, _d, _i, _vp]),
     "cdn_codenet_stage_workspace_bytes": (ctypes.c_size_t, [_i64] * 4 + [_i]),
     "cdn_codenet_stage_fused_forward": (
-        _i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 5 + [_i] + [_vp] * 9
+        _i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 8 + [_i] + [_vp] * 9
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_unpack_nchw": (_i, [_vp] * 3 + [_i64] * 4 + [_i, _vp]),
     "cdn_profile_enable": (_i, [_i]),

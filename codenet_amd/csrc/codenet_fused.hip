@@ -519,6 +519,173 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 }
 
 // ------------------------------------------------------------------------------------------
+// pwi8: the W4A8 pointwise conv on INTEGER CODES with v_mfma_i32_32x32x32_i8.
+//   levels   L = q + zp,  q = round(sc*d - zp)  (QuantAct codes, NOT clamped by the reference)
+//   weights  qw in [-8, 7], W' = qw / sw[co]     (per-channel symmetric 4 bit)
+//   y[m][co] = sum_c (L/sc)*(qw/sw) + b = (sum_c L*qw) / (sc*sw[co]) + b      -- exact integer sum
+// a = L - 128 is in [-128,127] for in-range data but the tracked range lags the batch, so codes a
+// few LSB outside int8 are routine.  Instead of a second accumulator the K dimension is doubled:
+//   a = 16*a1 + a0,  a0 in [-8,7], a1 in [-128,127]   (|a| <= 2039: x up to 8x outside the range;
+//                                                     beyond that the code saturates)
+//   sum a*qw = sum a0*qw + sum a1*(16*qw),   16*qw in [-128,112] is still int8.
+// sum L*qw = sum a*qw + 128*colsum(qw).  All integer arithmetic is exact; the only roundings are
+// the final fp32 scale and bias add.  Operand lane map: lane (r = l&31, h = l>>5) supplies 16
+// consecutive k bytes [16h, 16h+16) of row r for BOTH operands (any k order works as long as A
+// and B agree; checked with exact integer data, tools/probes/probe_i8.hip); C/D map as f32.
+// ------------------------------------------------------------------------------------------
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+constexpr int kI8LD = 48;   // bytes per LDS row: 32 k + 16 pad -> conflict-free ds_read_b128
+
+template <int BM, int BN, int WGM, bool FAST>
+__global__ void __launch_bounds__(256)
+pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+            const signed char *__restrict__ Wq, const float *__restrict__ wscale,
+            const int *__restrict__ wsum, const float *__restrict__ bias, float *__restrict__ R,
+            float2 *rmm, long M, int C, int Cpad, int Co, int relu) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+  constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
+  constexpr int BI = (BN * 2 + 255) / 256;  // 16-byte loads of W per thread per k-tile
+  __shared__ __attribute__((aligned(16))) unsigned char A0[2][BM * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char A1[2][BM * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char B0[2][BN * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char B1[2][BN * kI8LD];
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
+  const float qs = reinterpret_cast<const float *>(aq)[2];
+  const float qz = reinterpret_cast<const float *>(aq)[3];
+  const float zoff = qz - 128.0f;
+  i32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (i32x16){0};
+  const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
+  const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16-byte half bh
+  float4 a[AI];
+  i32x4 b[BI];
+  const float *arow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    long m = m0 + lr + 32 * i;
+    if (m > M - 1) m = M - 1;
+    arow[i] = A + m * C + lk;
+  }
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      if (FAST) {
+        a[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
+      } else {
+        const int k = k0 + lk;
+        a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
+        a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
+        a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
+        a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int co = n0 + br + 128 * i;
+      if (co > Co - 1) co = Co - 1;
+      b[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + bh);
+    }
+  };
+  auto code = [&](float v, bool live) -> int {
+    // a = round(sc*d - zp) + zp - 128, clamped to what the nibble split can carry
+    float q = rintf(__fsub_rn(__fmul_rn(qs, v), qz)) + zoff;
+    q = fminf(fmaxf(q, -2040.0f), 2039.0f);   // keeps a1 = (a - a0) >> 4 inside int8
+    return live ? (int)q : 0;
+  };
+  auto store_tile = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int k = k0 + lk;
+      const int c0 = code(a[i].x, FAST || k + 0 < C), c1 = code(a[i].y, FAST || k + 1 < C);
+      const int c2 = code(a[i].z, FAST || k + 2 < C), c3 = code(a[i].w, FAST || k + 3 < C);
+      // low nibble (signed) and the rest
+      const int l0 = ((c0 + 8) & 15) - 8, l1 = ((c1 + 8) & 15) - 8;
+      const int l2 = ((c2 + 8) & 15) - 8, l3 = ((c3 + 8) & 15) - 8;
+      const int h0 = (c0 - l0) >> 4, h1 = (c1 - l1) >> 4, h2 = (c2 - l2) >> 4, h3 = (c3 - l3) >> 4;
+      const unsigned lo = (l0 & 255) | ((l1 & 255) << 8) | ((l2 & 255) << 16) | ((unsigned)(l3 & 255) << 24);
+      const unsigned hi = (h0 & 255) | ((h1 & 255) << 8) | ((h2 & 255) << 16) | ((unsigned)(h3 & 255) << 24);
+      *reinterpret_cast<unsigned *>(&A0[buf][(lr + 32 * i) * kI8LD + lk]) = lo;
+      *reinterpret_cast<unsigned *>(&A1[buf][(lr + 32 * i) * kI8LD + lk]) = hi;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (br + 128 * i < BN) {
+        i32x4 s16;   // 16*qw per byte: shift each byte left by 4 (qw in [-8,7] -> no carry loss)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)b[i][e] << 4) & 0xF0F0F0F0u);
+        *reinterpret_cast<i32x4 *>(&B0[buf][(br + 128 * i) * kI8LD + bh]) = b[i];
+        *reinterpret_cast<i32x4 *>(&B1[buf][(br + 128 * i) * kI8LD + bh]) = s16;
+      }
+  };
+
+  load_tile(0);
+  store_tile(0, 0);
+  __syncthreads();
+  const int nk = Cpad / 32;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nk) load_tile((t + 1) * 32);
+    i32x4 a0[TM], a1[TM], b0[TN], b1[TN];
+    const int fo = (lane & 31) * kI8LD + (lane >> 5) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      a0[i] = *reinterpret_cast<const i32x4 *>(&A0[buf][(wm + i * 32) * kI8LD + fo]);
+      a1[i] = *reinterpret_cast<const i32x4 *>(&A1[buf][(wm + i * 32) * kI8LD + fo]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      b0[j] = *reinterpret_cast<const i32x4 *>(&B0[buf][(wn + j * 32) * kI8LD + fo]);
+      b1[j] = *reinterpret_cast<const i32x4 *>(&B1[buf][(wn + j * 32) * kI8LD + fo]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      }
+    if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * 32);
+    __syncthreads();
+  }
+  float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    float bsv = 0.f, rinv = 0.f;
+    int t128 = 0;
+    if (co < Co) {
+      if (bias) bsv = bias[co];
+      rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
+      t128 = 128 * wsum[co];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && co < Co) {
+          float v = fmaf((float)(acc[i][j][r] + t128), rinv, bsv);
+          if (relu) v = fmaxf(v, 0.0f);
+          R[m * Co + co] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
+      }
+  }
+  if (rmm)
+    cdn::block_minmax_store(mn, mx, rmm + (long)blockIdx.y * gridDim.x + blockIdx.x,
+                            reinterpret_cast<float *>(&A0[0][0]));
+}
+
+// ------------------------------------------------------------------------------------------
 // Final materialisation for the consumer outside the fused path (the detection heads):
 // out[n][c][2h+dy][2w+dx] = fq(r[n][h*W+w][c])   (nearest x2, NCHW, optional fake-quant).
 // One workgroup = (n, one stored row h): reads W*C contiguous floats, transposes through LDS,
@@ -634,8 +801,9 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
 extern "C" int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
-    const float *w_dw, const float *w_pw, const float *bias_pw, const float *ep_scale,
-    const float *ep_shift, int relu, float *s_min, float *s_max, void *s_state, float *d_min,
+    const float *w_dw, const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
+    const int *w_pw_colsum, const float *bias_pw, const float *ep_scale, const float *ep_shift,
+    int relu, float *s_min, float *s_max, void *s_state, float *d_min,
     float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
     void *stream) {
@@ -749,7 +917,30 @@ extern "C" int cdn_codenet_stage_fused_forward(
     if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
     else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
   } while (0)
-  {
+  const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
+  if (use_i8) {
+    CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
+    CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
+                "w_pw_codes must be 16-byte aligned");
+    const int Cpad = (int)((C + 31) / 32 * 32);
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+#define CDN_PWI(BM_, BN_, WGM_)                                                                  \
+  do {                                                                                           \
+    dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
+    if (pw_fast)                                                                                 \
+      pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
+                                                            w_pw_colsum, bias_pw, r_out, rmm, M,  \
+                                                            (int)C, Cpad, (int)Co, relu);        \
+    else                                                                                         \
+      pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
+                                                             w_pw_colsum, bias_pw, r_out, rmm, M, \
+                                                             (int)C, Cpad, (int)Co, relu);       \
+  } while (0)
+    if (pw_bn == 128 && pw_bm == 64) CDN_PWI(64, 128, 2);
+    else if (pw_bn == 128) CDN_PWI(128, 128, 4);
+    else CDN_PWI(128, 64, 4);
+#undef CDN_PWI
+  } else {
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {
       if (dst) CDN_PW(64, 128, 2, true); else CDN_PW(64, 128, 2, false);

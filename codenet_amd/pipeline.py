@@ -143,9 +143,10 @@ class FusedHotPath:
     All device buffers are allocated once per input shape, so a call issues only kernel launches
     and can be captured into a HIP graph (``capture()``)."""
 
-    def __init__(self, deconv_layers):
+    def __init__(self, deconv_layers, int8_pointwise=True):
         from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
         self.seq = deconv_layers
+        self.int8_pointwise = int8_pointwise
         mods = list(deconv_layers)
         self.quantized = isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive)
         step = 3 if self.quantized else 4
@@ -162,7 +163,9 @@ class FusedHotPath:
         if self.quantized:
             q, post = st[0], st[1]
             w_pw, b_pw = q.quant_conv_channel_bn.folded()
+            i8 = q.quant_conv_channel_bn.folded_int8() if self.int8_pointwise else None
             return dict(
+                i8=i8,
                 w_scale=q.quant_conv_scale.quantized_weight().reshape(-1),
                 b_scale=q.quant_conv_scale.bias, lo=q.quant_act[0].min_val, hi=q.quant_act[0].max_val,
                 w_dw=q.quant_deform_conv.quantized_weight(), w_pw=w_pw.reshape(w_pw.size(0), -1),
@@ -178,7 +181,7 @@ class FusedHotPath:
         return dict(w_scale=op.conv_scale.weight.reshape(-1), b_scale=op.conv_scale.bias,
                     lo=op.conv_bound.min_val, hi=op.conv_bound.max_val, w_dw=op.conv.weight,
                     w_pw=op.conv_channel.weight.reshape(op.out_channels, -1), bias=None,
-                    ep_scale=es, ep_shift=eh, acts=(None, None, None))
+                    ep_scale=es, ep_shift=eh, acts=(None, None, None), i8=None)
 
     def _alloc(self, x):
         from . import _native as N_
@@ -233,7 +236,9 @@ class FusedHotPath:
                 rc = lib.cdn_codenet_stage_fused_forward(
                     cur.data_ptr(), cur_nhwc, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
                     ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
-                    ptr(p["w_dw"]), ptr(p["w_pw"]), ptr(p["bias"]), ptr(p["ep_scale"]),
+                    ptr(p["w_dw"]), ptr(p["w_pw"]),
+                    *([ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]),
+                    ptr(p["bias"]), ptr(p["ep_scale"]),
                     ptr(p["ep_shift"]), 1, *a, bits, mom, running, ws_ptr, ws_bytes,
                     sb["r"].data_ptr(), stream)
                 ops._toc(rec)

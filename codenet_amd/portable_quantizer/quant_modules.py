@@ -221,6 +221,41 @@ class QuantBnConv2d(Module, _WeightQuantizer):
             keys.append(self.conv.bias)
         return self._cached(tuple(keys), compute)
 
+    def folded_int8(self):
+        """Integer form of the folded, fake-quantised 1x1 weights for the int8-MFMA pointwise kernel:
+        (codes int8 [Co, round_up(C,32)] zero padded, scale fp32 [Co] with w' = codes / scale,
+        column sums int32 [Co]); None when this layer is not per-channel symmetric <= 4 bit."""
+        if (self.full_precision_flag or not self.per_channel or self.weight_bit > 4
+                or self.weight_function is not _quant_function("symmetric")
+                or tuple(self.conv.kernel_size) != (1, 1) or self.conv.groups != 1):
+            return None
+
+        def compute():
+            running_std = torch.sqrt(self.bn.running_var + self.bn.eps)
+            scale_factor = self.bn.weight / running_std
+            w = self.conv.weight * scale_factor.reshape([self.conv.out_channels, 1, 1, 1])
+            co = self.conv.out_channels
+            w_min, w_max = _channel_range(w.data.contiguous().view(co, -1), self.weight_percentile)
+            # same expressions as SymmetricQuantFunction.forward (quant_utils.py:207-225)
+            mag = torch.max(torch.stack([w_min.abs(), w_max.abs()], dim=1), dim=1).values
+            n = 2 ** (self.weight_bit - 1) - 1
+            scale = n / torch.clamp(mag, min=1e-10)
+            q = torch.clamp(torch.round(scale.view(-1, 1, 1, 1) * w), -(n + 1), n).view(co, -1)
+            cpad = (q.shape[1] + 31) // 32 * 32
+            codes = torch.zeros(co, cpad, dtype=torch.int8, device=q.device)
+            codes[:, :q.shape[1]] = q.to(torch.int8)
+            return codes.contiguous(), scale.contiguous(), q.sum(dim=1).to(torch.int32).contiguous()
+        keys = (self.conv.weight, self.bn.weight, self.bn.running_var)
+        if torch.is_grad_enabled():
+            with torch.no_grad():
+                return compute()
+        key = tuple((t.data_ptr(), t._version, t.device) for t in keys)
+        cache = getattr(self, "_i8_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                self._i8_cache = (key, compute())
+        return self._i8_cache[1]
+
     def forward(self, x):
         w, b = self.folded()
         return F.conv2d(x, w, b, self.conv.stride, self.conv.padding, self.conv.dilation,

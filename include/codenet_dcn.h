@@ -192,6 +192,12 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
  *   w_scale [C], b_scale [1] (device, may be NULL), lo/hi: Hardtanh bounds
  *   w_dw [C,1,3,3], w_pw [Co,C], bias_pw [Co] or NULL; ep_scale/ep_shift [Co] or both NULL
  *             (W4A8: the already fake-quantised weights and the folded BN bias; fp32: BN as affine)
+ *   w_pw_codes / w_pw_scale / w_pw_colsum: optional INTEGER form of the pointwise weights for the
+ *             int8-MFMA path (used when the d quantiser is enabled): codes qw in [-8,7] as int8
+ *             [Co][round_up(C,32)] zero padded and 16-byte aligned, per-channel scale sw[Co]
+ *             (w' = qw / sw), column sums sum_c qw [Co] as int32.  NULL -> f32 MFMA on w_pw.
+ *             The integer path computes sum_c (q_d + zp) * qw exactly and scales once; activation
+ *             codes are NOT clamped to int8 (the reference does not clamp them).
  *   {s,d,r}_{min,max,state}: the three QuantAct of the stage (x_min/x_max buffers updated in place
  *             when running != 0; state as in cdn_quantact_forward); pass all three of a group NULL to
  *             disable that quantiser (fp32 path: all NULL)
@@ -203,8 +209,9 @@ size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
-    const float *w_dw, const float *w_pw, const float *bias_pw, const float *ep_scale,
-    const float *ep_shift, int relu, float *s_min, float *s_max, void *s_state, float *d_min,
+    const float *w_dw, const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
+    const int *w_pw_colsum, const float *bias_pw, const float *ep_scale, const float *ep_shift,
+    int relu, float *s_min, float *s_max, void *s_state, float *d_min,
     float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
     void *stream);

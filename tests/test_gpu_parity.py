@@ -463,3 +463,32 @@ def test_fused_stage_real_shapes_w2():
     ref = _oracle_chain(net_cpu, x, True)[0]
     y = pipeline.FusedHotPath(net.cuda().deconv_layers)(x.cuda())
     assert (y.cpu() - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("shrink", [1.0, 0.25, 0.05])
+def test_int8_pointwise_equals_f32_pointwise_incl_codes_outside_int8(shrink):
+    """The int8-MFMA pointwise (exact integer sum over codes, nibble-split so codes outside int8
+    stay exact) against the f32-MFMA pointwise on fake-quantised values -- also with the d-range
+    frozen far too narrow so that activation codes reach +-500 / +-2000 (the reference does not
+    clamp them, quant_utils.py:193-200)."""
+    import copy
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[96, 64, 32, 16], seed=11).cuda()
+    x = torch.randn(3, 96, 8, 8, device="cuda").abs()
+    warm = pipeline.FusedHotPath(net.deconv_layers, int8_pointwise=False)
+    warm(x)
+    pipeline.set_running_stat(net, False)
+    for st in warm.stages:
+        qd = st[0].quant_identity_deform
+        mid = (qd.x_max + qd.x_min) / 2
+        half = (qd.x_max - qd.x_min) / 2 * shrink
+        qd.x_min.copy_(mid - half)
+        qd.x_max.copy_(mid + half)
+    net2 = copy.deepcopy(net)
+    y_f32 = pipeline.FusedHotPath(net.deconv_layers, int8_pointwise=False)(x).clone()
+    y_i8 = pipeline.FusedHotPath(net2.deconv_layers, int8_pointwise=True)(x).clone()
+    last = [m for m in net.modules() if hasattr(m, "x_min")][-1]
+    lsb = (last.x_max - last.x_min).item() / 255.0
+    diff = (y_f32 - y_i8).abs()
+    assert diff.max().item() <= 1.05 * lsb + 1e-4          # at most one output code apart
+    assert (diff > 1e-4).float().mean().item() < 2e-3       # and only on a handful of elements
