@@ -226,7 +226,7 @@ class QuantBnConv2d(Module, _WeightQuantizer):
         (codes int8 [Co, round_up(C,32)] zero padded, scale fp32 [Co] with w' = codes / scale,
         column sums int32 [Co]); None when this layer is not per-channel symmetric <= 4 bit."""
         if (self.full_precision_flag or not self.per_channel or self.weight_bit > 4
-                or self.weight_function is not _quant_function("symmetric")
+                or self.quant_mode != "symmetric"
                 or tuple(self.conv.kernel_size) != (1, 1) or self.conv.groups != 1):
             return None
 
