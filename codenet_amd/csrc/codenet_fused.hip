@@ -367,7 +367,8 @@ __global__ void __launch_bounds__(256)
 pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            const float *__restrict__ Wp, const float *__restrict__ bias,
            const float *__restrict__ ep_scale, const float *__restrict__ ep_shift,
-           float *__restrict__ R, float2 *rmm, long M, int C, int Co, int relu) {
+           float *__restrict__ R, float2 *rmm, long M, int C, int Co, int relu, int only_if_wide) {
+  if (only_if_wide && !aq[6]) return;   // fallback launch behind pwi8_kernel: nothing to do
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int AI = BM * 8 / 256, BI = BN * 8 / 256;   // float4 loads per thread per k-tile
@@ -555,6 +556,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
+  if (aq[6]) return;   // codes too wide for the nibble split: the f32 kernel behind us does this batch
   const float qs = reinterpret_cast<const float *>(aq)[2];
   const float qz = reinterpret_cast<const float *>(aq)[3];
   const float zoff = qz - 128.0f;
@@ -884,7 +886,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
     cdn::launch_quantact_update(s_min, s_max, sst, nullptr, nullptr, smm, n_part_s, bits, momentum,
                                 running, st);
   // 2. gather + depthwise (+ min/max of d)
-  float2 *dmm = (running && dst) ? part_d : nullptr;
+  float2 *dmm = dst ? part_d : nullptr;   // always: the batch extremes also gate the int8 path
   const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
   CDN_REQUIRE(n_part_d <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many gather workgroups");
   {
@@ -911,13 +913,14 @@ extern "C" int cdn_codenet_stage_fused_forward(
 #define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
   pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<dim3((unsigned)cdn::ceil_div(M, BM_),                 \
                                                 (unsigned)cdn::ceil_div(Co, BN_)), 256, 0, st>>>( \
-      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M, (int)C, (int)Co, relu)
+      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M, (int)C, (int)Co, relu, only_if_wide)
 #define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
   do {                                                                    \
     if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
     else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
   } while (0)
   const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
+  int only_if_wide = 0;
   if (use_i8) {
     CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
     CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
@@ -940,8 +943,10 @@ extern "C" int cdn_codenet_stage_fused_forward(
     else if (pw_bn == 128) CDN_PWI(128, 128, 4);
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI
-  } else {
-    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+    only_if_wide = 1;   // the f32 kernel below runs only when state[6] says the codes are too wide
+  }
+  {
+    cdn::ProfScope ps(only_if_wide ? cdn::kProfUpdate : cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {
       if (dst) CDN_PW(64, 128, 2, true); else CDN_PW(64, 128, 2, false);
     } else if (pw_bn == 128) {

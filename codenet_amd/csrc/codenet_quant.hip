@@ -76,7 +76,8 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
                        float m_minus_1, float one_minus_m, int running) {
   __shared__ float red[8];
   __shared__ float2 pr;
-  if (running && !ext_min && partials) {   // reduce the producers' per-workgroup {min,max}
+  const bool from_partials = !ext_min && partials;
+  if (from_partials) {   // reduce the producers' per-workgroup {min,max}
     float mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
       const float2 v = partials[i];
@@ -88,11 +89,15 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
   }
   if (threadIdx.x != 0) return;
   float lo = x_min[0], hi = x_max[0];
-  if (running) {
-    const float bmin = ext_min ? ext_min[0] : (partials ? pr.x : ord2f(state[0]));
-    const float bmax = ext_max ? ext_max[0] : (partials ? pr.y : ord2f(state[1]));
+  const bool have_stats = ext_min || from_partials || running;
+  float bmin = 0.f, bmax = 0.f;
+  if (have_stats) {
+    bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : ord2f(state[0]));
+    bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : ord2f(state[1]));
     reinterpret_cast<float *>(state)[4] = bmin;
     reinterpret_cast<float *>(state)[5] = bmax;
+  }
+  if (running) {
     if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
       lo = __fadd_rn(lo, bmin);
       hi = __fadd_rn(hi, bmax);
@@ -110,6 +115,16 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
   const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (bits - 1)));
   reinterpret_cast<float *>(state)[2] = scale;
   reinterpret_cast<float *>(state)[3] = zp;
+  // state[6]: 1 when some level L - 128 = round(scale*x - zp) + zp - 128 of this batch cannot be
+  // carried by the int8 kernels' nibble split (|.| > 2039) or the batch extremes are unknown --
+  // consumers then take their f32 path.  Codes are monotone in x, so the extremes decide.
+  unsigned wide = 1u;
+  if (have_stats && bits == 8) {
+    const float a0 = quant_code(bmin, scale, zp) + (zp - 128.0f);
+    const float a1 = quant_code(bmax, scale, zp) + (zp - 128.0f);
+    wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1)) ? 1u : 0u;
+  }
+  state[6] = wide;
 }
 
 // out = (q + zp) / scale; optionally also the integer codes (int16: codes are NOT clamped to
@@ -169,7 +184,7 @@ void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const f
                             double momentum, int running, hipStream_t st) {
   // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
   // the scalar to fp32 (quant_modules.py:217-219).
-  const int threads = (running && !ext_min && partials) ? 256 : 64;
+  const int threads = (!ext_min && partials) ? 256 : 64;
   quantact_update_kernel<<<1, threads, 0, st>>>(x_min, x_max, state, ext_min, ext_max, partials,
                                                 n_partials, bits, (float)(momentum - 1.0),
                                                 (float)(1.0 - momentum), running);
