@@ -165,9 +165,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, int C, int H, int W,
            int up) {
-  // LDS: [Hl*Wl + 1][CCH] image rows (the last row is the shared ZERO cell that every
-  // out-of-image corner maps to -- per-corner zeroing of the reference, _kernel.cu:97-108),
-  // then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
+  // LDS: [(Hl+1)*(Wl+1)][CCH] image cells; row Hl and column Wl are ZERO and every out-of-image
+  // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
+  // cell address is just row offset + column offset, no bounds test and no clamp per corner.
+  // Then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
   extern __shared__ float4 img[];
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
@@ -176,7 +177,9 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int HWl = Hl * Wl, HW = H * W;
   const int n = blockIdx.y, c0 = blockIdx.x * CCH;
   const int tid = threadIdx.x;
-  float *wl = reinterpret_cast<float *>(img + (size_t)(HWl + 1) * LPP);
+  const int Wc = Wl + 1;                       // cells per LDS row
+  const int cells = (Hl + 1) * Wc;
+  float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
   float *sl = wl + CCH * 9;
   float *red = sl + HWl;
   float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
@@ -189,7 +192,11 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     sz = reinterpret_cast<const float *>(sq)[3];
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid < LPP) img[HWl * LPP + tid] = z4;
+  for (int q = tid; q < (Wc + Hl) * LPP; q += kDw2Threads) {   // zero row, then zero column
+    const int i = q / LPP;
+    const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
+    img[cell * LPP + (q % LPP)] = z4;
+  }
   // ---- stage the image -------------------------------------------------------------------
   if (NHWC_IN) {
     const float *xg = x + (long)n * HWl * C + c0;
@@ -203,7 +210,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         v.z = fake_quant(v.z, xs, xz);
         v.w = fake_quant(v.w, xs, xz);
       }
-      img[q] = v;
+      img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] = v;
     }
   } else {
     // lane <-> channel so the four scalar LDS stores of a wave hit consecutive banks
@@ -227,7 +234,8 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int pix = j * 4 + e;
-        if (pix < HWl) imgf[pix * CCH + cl] = XQ ? fake_quant(v[e], xs, xz) : v[e];
+        if (pix < HWl)
+          imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = XQ ? fake_quant(v[e], xs, xz) : v[e];
       }
     }
   }
@@ -248,18 +256,15 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k][e] = wl[(cq * 4 + e) * 9 + k];
 
-  // byte offsets: row part + column part; invalid parts are hugely negative so that the unsigned
-  // min with the ZERO cell's offset redirects every out-of-image corner there.
-  constexpr int kBad = -(1 << 28);
-  const unsigned zero_off = (unsigned)((HWl * LPP + cq) * 16);
-  auto row_off = [&](int yy) { return ((unsigned)yy < (unsigned)H) ? ((yy >> up) * Wl) * LPP * 16 : kBad; };
+  // byte offsets: row part + column part; out-of-image coordinates select the zero row / column
+  const int rstride = Wc * LPP * 16;
+  auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? (yy >> up) : Hl) * rstride; };
   auto col_off = [&](int xx) {
-    return ((unsigned)xx < (unsigned)W) ? ((xx >> up) * LPP + cq) * 16 : kBad;
+    return ((((unsigned)xx < (unsigned)W) ? (xx >> up) : Wl) * LPP + cq) * 16;
   };
   const char *imgb = reinterpret_cast<const char *>(img);
   auto rd = [&](int ro, int co) -> float4 {
-    const unsigned off = min((unsigned)(ro + co), zero_off);
-    return *reinterpret_cast<const float4 *>(imgb + off);
+    return *reinterpret_cast<const float4 *>(imgb + (ro + co));
   };
 
   float mn = INFINITY, mx = -INFINITY;
@@ -759,8 +764,8 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
                const unsigned *sq, const float *wd, float *d, float2 *dmm, int N, int C, int H,
                int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
-  const size_t lds = ((size_t)(Hl * Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl + 2 * kDw2MaxThreads / 64) *
-                     sizeof(float);
+  const size_t lds = ((size_t)(Hl + 1) * (Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl +
+                      2 * kDw2MaxThreads / 64) * sizeof(float);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
@@ -845,7 +850,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
 
   // LDS budget of the gather kernel decides the channel chunk
-  const size_t cells = (size_t)Hl * Wl + 1;   // + the shared zero cell
+  const size_t cells = (size_t)(Hl + 1) * (Wl + 1);   // + the zero row and zero column
   // scale plane, weights and reduction scratch share the 160 KiB
   const size_t lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (size_t)HWl * 4;
   int cch = 0;
