@@ -157,7 +157,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-constexpr int kDw2MaxThreads = 768;   // 3 waves/SIMD -> up to 168 VGPRs; workgroup size chosen per launch
+constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (512 or 1024)
 
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
 __global__ void __launch_bounds__(kDw2MaxThreads)
@@ -169,16 +169,8 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
   // cell address is just row offset + column offset, no bounds test and no clamp per corner.
   // Then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
-  //
-  // Compute mapping: LPP = CCH/8 lanes per output pixel, every lane owns TWO channel quads
-  // (A and B, CCH/2 channels apart) so the tap geometry and the cell addresses -- most of the
-  // VALU work, the kernel is VALU-issue bound -- are shared by 8 channels; quad B is read at
-  // `offset ^ (CCH*2 bytes)`.  With CCH = 64 odd pixels swap A and B, so the four pixels that
-  // meet in one ds_read_b128 lane group cover the four 64-byte quarters of the 256-byte bank row:
-  // conflict-free for any data-dependent cell.
   extern __shared__ float4 img[];
-  constexpr int QPC = CCH / 4;     // float4 per cell
-  constexpr int LPP = CCH / 8;     // lanes per pixel
+  constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
   const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
   const int Hl = H >> up, Wl = W >> up;
@@ -187,7 +179,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int tid = threadIdx.x;
   const int Wc = Wl + 1;                       // cells per LDS row
   const int cells = (Hl + 1) * Wc;
-  float *wl = reinterpret_cast<float *>(img + (size_t)cells * QPC);
+  float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
   float *sl = wl + CCH * 9;
   float *red = sl + HWl;
   float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
@@ -200,25 +192,25 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     sz = reinterpret_cast<const float *>(sq)[3];
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int q = tid; q < (Wc + Hl) * QPC; q += kDw2Threads) {   // zero row, then zero column
-    const int i = q / QPC;
+  for (int q = tid; q < (Wc + Hl) * LPP; q += kDw2Threads) {   // zero row, then zero column
+    const int i = q / LPP;
     const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
-    img[cell * QPC + (q % QPC)] = z4;
+    img[cell * LPP + (q % LPP)] = z4;
   }
   // ---- stage the image -------------------------------------------------------------------
   if (NHWC_IN) {
     const float *xg = x + (long)n * HWl * C + c0;
-    for (int q = tid; q < HWl * QPC; q += kDw2Threads) {
-      const int pix = q / QPC, cq4 = q % QPC;
+    for (int q = tid; q < HWl * LPP; q += kDw2Threads) {
+      const int pix = q / LPP, cq = q % LPP;
       float4 v = z4;
-      if (c0 + cq4 * 4 + 3 < C) v = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq4 * 4);
+      if (c0 + cq * 4 + 3 < C) v = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq * 4);
       if (XQ) {
         v.x = fake_quant(v.x, xs, xz);
         v.y = fake_quant(v.y, xs, xz);
         v.z = fake_quant(v.z, xs, xz);
         v.w = fake_quant(v.w, xs, xz);
       }
-      img[((pix / Wl) * Wc + (pix % Wl)) * QPC + cq4] = v;
+      img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] = v;
     }
   } else {
     // lane <-> channel so the four scalar LDS stores of a wave hit consecutive banks
@@ -258,135 +250,123 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int cq = lane % LPP, sub = lane / LPP;
-  const int swap = (CCH == 64) ? (sub & 1) : 0;
-  const int chA = (swap ? CCH / 2 : 0) + cq * 4;      // first channel of quad A (within the chunk)
-  const int chB = chA ^ (CCH / 2);                    // quad B: CCH/2 channels away
-  float wkA[9][4], wkB[9][4];
+  float wk[9][4];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      wkA[k][e] = wl[(chA + e) * 9 + k];
-      wkB[k][e] = wl[(chB + e) * 9 + k];
-    }
+    for (int k = 0; k < 9; ++k) wk[k][e] = wl[(cq * 4 + e) * 9 + k];
 
   // byte offsets: row part + column part; out-of-image coordinates select the zero row / column
-  const int rstride = Wc * CCH * 4;
+  const int rstride = Wc * LPP * 16;
   auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? (yy >> up) : Hl) * rstride; };
-  auto col_off = [&](int xx) {
-    return (((unsigned)xx < (unsigned)W) ? (xx >> up) : Wl) * (CCH * 4) + chA * 4;
-  };
-  const char *imgb = reinterpret_cast<const char *>(img);
-  constexpr int kFlipB = CCH * 2;   // bytes between quad A and quad B
+  auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? (xx >> up) : Wl) * (LPP * 16); };
+  const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
 
   float mn = INFINITY, mx = -INFINITY;
   const bool vec_store = ((C & 3) == 0);
-  for (int p0 = wave * PPW; p0 < HW; p0 += kWaves * PPW) {
-    const int p = p0 + sub;
-    if (p >= HW) continue;
-    const int h = p / W, w = p - h * W;
-    const float t = sl[(h >> up) * Wl + (w >> up)] - 1.0f;
-    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
-    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
-    const int rya0 = row_off(ya.i0), rya1 = row_off(ya.i0 + 1);
-    const int ryb0 = row_off(yb.i0), ryb1 = row_off(yb.i0 + 1);
-    const int rh = row_off(h);
-    const int cxa0 = col_off(xa.i0), cxa1 = col_off(xa.i0 + 1);
-    const int cxb0 = col_off(xb.i0), cxb1 = col_off(xb.i0 + 1);
-    const int cw = col_off(w);
-    float4 accA = z4, accB = z4;
-#define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
-#define CDN_WACC(ACC, WK, K, TV)            \
-  ACC.x = fmaf(WK[K][0], TV.x, ACC.x);      \
-  ACC.y = fmaf(WK[K][1], TV.y, ACC.y);      \
-  ACC.z = fmaf(WK[K][2], TV.z, ACC.z);      \
-  ACC.w = fmaf(WK[K][3], TV.w, ACC.w);
-#define CDN_MIX4(TV, V00, V01, V10, V11)                                 \
-  TV.x = ((w00 * V00.x + w01 * V01.x) + w10 * V10.x) + w11 * V11.x;      \
-  TV.y = ((w00 * V00.y + w01 * V01.y) + w10 * V10.y) + w11 * V11.y;      \
-  TV.z = ((w00 * V00.z + w01 * V01.z) + w10 * V10.z) + w11 * V11.z;      \
-  TV.w = ((w00 * V00.w + w01 * V01.w) + w10 * V10.w) + w11 * V11.w;
-    // corner taps: 4 cells, both channel quads
-#define CDN_TAP4(Y, X, R0, R1, C0, C1, K)                                   \
-  {                                                                         \
-    const int o00 = R0 + C0, o01 = R0 + C1, o10 = R1 + C0, o11 = R1 + C1;   \
-    const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1;                       \
-    const float w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;                       \
-    float4 tv;                                                              \
-    {                                                                       \
-      const float4 a00 = CDN_RD(o00), a01 = CDN_RD(o01);                    \
-      const float4 a10 = CDN_RD(o10), a11 = CDN_RD(o11);                    \
-      CDN_MIX4(tv, a00, a01, a10, a11)                                      \
-      CDN_WACC(accA, wkA, K, tv)                                            \
-    }                                                                       \
-    {                                                                       \
-      const float4 b00 = CDN_RD(o00 ^ kFlipB), b01 = CDN_RD(o01 ^ kFlipB);  \
-      const float4 b10 = CDN_RD(o10 ^ kFlipB), b11 = CDN_RD(o11 ^ kFlipB);  \
-      CDN_MIX4(tv, b00, b01, b10, b11)                                      \
-      CDN_WACC(accB, wkB, K, tv)                                            \
-    }                                                                       \
-  }
-    // edge taps: one axis exact, 2 cells
-#define CDN_TAP2(AX, RA, CA, RB, CB, K)                                     \
-  {                                                                         \
-    const int o0 = RA + CA, o1 = RB + CB;                                   \
-    float4 tv;                                                              \
-    {                                                                       \
-      const float4 v0 = CDN_RD(o0), v1 = CDN_RD(o1);                        \
-      tv.x = AX.w0 * v0.x + AX.w1 * v1.x;                                   \
-      tv.y = AX.w0 * v0.y + AX.w1 * v1.y;                                   \
-      tv.z = AX.w0 * v0.z + AX.w1 * v1.z;                                   \
-      tv.w = AX.w0 * v0.w + AX.w1 * v1.w;                                   \
-      CDN_WACC(accA, wkA, K, tv)                                            \
-    }                                                                       \
-    {                                                                       \
-      const float4 v0 = CDN_RD(o0 ^ kFlipB), v1 = CDN_RD(o1 ^ kFlipB);      \
-      tv.x = AX.w0 * v0.x + AX.w1 * v1.x;                                   \
-      tv.y = AX.w0 * v0.y + AX.w1 * v1.y;                                   \
-      tv.z = AX.w0 * v0.z + AX.w1 * v1.z;                                   \
-      tv.w = AX.w0 * v0.w + AX.w1 * v1.w;                                   \
-      CDN_WACC(accB, wkB, K, tv)                                            \
-    }                                                                       \
-  }
-    CDN_TAP4(ya, xa, rya0, rya1, cxa0, cxa1, 0)
-    CDN_TAP2(ya, rya0, cw, rya1, cw, 1)
-    CDN_TAP4(ya, xb, rya0, rya1, cxb0, cxb1, 2)
-    CDN_TAP2(xa, rh, cxa0, rh, cxa1, 3)
+  // The kernel is VALU-issue bound and the tap geometry is the bulk of the VALU work, so it is
+  // computed ONCE per pixel: in the geometry phase lane i owns pixel pb+i (64 different pixels
+  // per wave instruction instead of 16 lanes repeating the same pixel); in the gather phase the
+  // LPP lanes of an output pixel fetch that pixel's 18-word record from its owner lane with
+  // ds_bpermute (no LDS storage) and only add offsets, mix and accumulate.
+  for (int pb = wave * 64; pb < HW; pb += kWaves * 64) {
+    // ---- geometry phase ------------------------------------------------------------------
+    int g_r[5], g_c[5];
+    float g_w[8];
     {
-      const int oc = rh + cw;
-      const float4 va = CDN_RD(oc), vb = CDN_RD(oc ^ kFlipB);
-      CDN_WACC(accA, wkA, 4, va)
-      CDN_WACC(accB, wkB, 4, vb)
+      const int p = min(pb + lane, HW - 1);
+      const int h = p / W, w = p - h * W;
+      const float t = sl[(h >> up) * Wl + (w >> up)] - 1.0f;
+      const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+      const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+      g_r[0] = row_off(ya.i0); g_r[1] = row_off(ya.i0 + 1);
+      g_r[2] = row_off(yb.i0); g_r[3] = row_off(yb.i0 + 1);
+      g_r[4] = row_off(h);
+      g_c[0] = col_off(xa.i0); g_c[1] = col_off(xa.i0 + 1);
+      g_c[2] = col_off(xb.i0); g_c[3] = col_off(xb.i0 + 1);
+      g_c[4] = col_off(w);
+      g_w[0] = ya.w0; g_w[1] = ya.w1; g_w[2] = yb.w0; g_w[3] = yb.w1;
+      g_w[4] = xa.w0; g_w[5] = xa.w1; g_w[6] = xb.w0; g_w[7] = xb.w1;
     }
-    CDN_TAP2(xb, rh, cxb0, rh, cxb1, 5)
-    CDN_TAP4(yb, xa, ryb0, ryb1, cxa0, cxa1, 6)
-    CDN_TAP2(yb, ryb0, cw, ryb1, cw, 7)
-    CDN_TAP4(yb, xb, ryb0, ryb1, cxb0, cxb1, 8)
+    // ---- gather phase: PPW pixels per step ---------------------------------------------------
+#pragma unroll 1
+    for (int j = 0; j < 64 / PPW; ++j) {
+      const int src = j * PPW + sub;          // owner lane of this lane's pixel
+      const int p = pb + src;
+      int r[5], c[5];
+      float wt[8];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        r[q] = __shfl(g_r[q], src, 64);
+        c[q] = __shfl(g_c[q], src, 64);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wt[q] = __shfl(g_w[q], src, 64);
+      if (pb + j * PPW >= HW) break;          // wave-uniform: whole step beyond the plane
+      float4 acc = z4;
+#define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
+#define CDN_WACC(K, TV)                     \
+  acc.x = fmaf(wk[K][0], TV.x, acc.x);      \
+  acc.y = fmaf(wk[K][1], TV.y, acc.y);      \
+  acc.z = fmaf(wk[K][2], TV.z, acc.z);      \
+  acc.w = fmaf(wk[K][3], TV.w, acc.w);
+      // corner taps: rows (R0,R1) x cols (C0,C1), axis weights (Y0,Y1) x (X0,X1)
+#define CDN_TAP4(R0, R1, C0, C1, Y0, Y1, X0, X1, K)                       \
+  {                                                                       \
+    const float4 v00 = CDN_RD(R0 + C0), v01 = CDN_RD(R0 + C1);            \
+    const float4 v10 = CDN_RD(R1 + C0), v11 = CDN_RD(R1 + C1);            \
+    const float w00 = Y0 * X0, w01 = Y0 * X1, w10 = Y1 * X0, w11 = Y1 * X1; \
+    float4 tv;                                                            \
+    tv.x = ((w00 * v00.x + w01 * v01.x) + w10 * v10.x) + w11 * v11.x;     \
+    tv.y = ((w00 * v00.y + w01 * v01.y) + w10 * v10.y) + w11 * v11.y;     \
+    tv.z = ((w00 * v00.z + w01 * v01.z) + w10 * v10.z) + w11 * v11.z;     \
+    tv.w = ((w00 * v00.w + w01 * v01.w) + w10 * v10.w) + w11 * v11.w;     \
+    CDN_WACC(K, tv)                                                       \
+  }
+      // edge taps: one axis exact, 2 cells with weights (A0, A1)
+#define CDN_TAP2(OA, OB, A0, A1, K)                 \
+  {                                                 \
+    const float4 v0 = CDN_RD(OA), v1 = CDN_RD(OB);  \
+    float4 tv;                                      \
+    tv.x = A0 * v0.x + A1 * v1.x;                   \
+    tv.y = A0 * v0.y + A1 * v1.y;                   \
+    tv.z = A0 * v0.z + A1 * v1.z;                   \
+    tv.w = A0 * v0.w + A1 * v1.w;                   \
+    CDN_WACC(K, tv)                                 \
+  }
+      CDN_TAP4(r[0], r[1], c[0], c[1], wt[0], wt[1], wt[4], wt[5], 0)
+      CDN_TAP2(r[0] + c[4], r[1] + c[4], wt[0], wt[1], 1)
+      CDN_TAP4(r[0], r[1], c[2], c[3], wt[0], wt[1], wt[6], wt[7], 2)
+      CDN_TAP2(r[4] + c[0], r[4] + c[1], wt[4], wt[5], 3)
+      {
+        const float4 vc = CDN_RD(r[4] + c[4]);
+        CDN_WACC(4, vc)
+      }
+      CDN_TAP2(r[4] + c[2], r[4] + c[3], wt[6], wt[7], 5)
+      CDN_TAP4(r[2], r[3], c[0], c[1], wt[2], wt[3], wt[4], wt[5], 6)
+      CDN_TAP2(r[2] + c[4], r[3] + c[4], wt[2], wt[3], 7)
+      CDN_TAP4(r[2], r[3], c[2], c[3], wt[2], wt[3], wt[6], wt[7], 8)
 #undef CDN_TAP4
 #undef CDN_TAP2
-#undef CDN_MIX4
 #undef CDN_WACC
 #undef CDN_RD
-    float *dpix = d + ((long)n * HW + p) * C + c0;
+      if (p < HW) {
+        float *dp = d + ((long)n * HW + p) * C + c0 + cq * 4;
+        const int cbase = c0 + cq * 4;
+        if (vec_store && cbase + 3 < C) {
+          *reinterpret_cast<float4 *>(dp) = acc;
+          mn = fminf(mn, fminf(fminf(acc.x, acc.y), fminf(acc.z, acc.w)));
+          mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
+        } else {
+          const float av[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const float4 acc = half ? accB : accA;
-      const int ch = half ? chB : chA;
-      float *dp = dpix + ch;
-      const int cbase = c0 + ch;
-      if (vec_store && cbase + 3 < C) {
-        *reinterpret_cast<float4 *>(dp) = acc;
-        mn = fminf(mn, fminf(fminf(acc.x, acc.y), fminf(acc.z, acc.w)));
-        mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
-      } else {
-        const float a[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (cbase + e < C) {
-            dp[e] = a[e];
-            mn = fminf(mn, a[e]);
-            mx = fmaxf(mx, a[e]);
-          }
+          for (int e = 0; e < 4; ++e)
+            if (cbase + e < C) {
+              dp[e] = av[e];
+              mn = fminf(mn, av[e]);
+              mx = fmaxf(mx, av[e]);
+            }
+        }
       }
     }
   }
@@ -815,7 +795,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
-  int threads = two_per_cu ? 384 : 768;
+  int threads = two_per_cu ? 512 : 1024;
   if (const char *e = getenv("CDN_DW_THREADS")) threads = atoi(e);   // tuning knob
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
