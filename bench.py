@@ -229,7 +229,7 @@ def main():
                     "kernel": ({"dw": "dw2_kernel", "scale": "scale_*_kernel", "unpack": "unpack_kernel"}
                                if fused is not None else
                                {"dw": "dw_kernel", "scale": "scale_kernel",
-                                "quantact": "minmax_kernel+fake_quant_kernel"})[dominant]}
+                                "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}
         roof["launches_per_step"] = sum(1 for (nm, _t) in durs if nm == dominant)
         roof["ms_per_step_in_kernel"] = per_kernel[dominant]
         res = {
