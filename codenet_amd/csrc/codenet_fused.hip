@@ -157,7 +157,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-constexpr int kDw2MaxThreads = 512;   // 2 waves/SIMD: room for all 25 cell reads of a step in flight
+constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (512 or 1024)
 
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
 __global__ void __launch_bounds__(kDw2MaxThreads)
@@ -304,62 +304,52 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       for (int q = 0; q < 8; ++q) wt[q] = __shfl(g_w[q], src, 64);
       if (pb + j * PPW >= HW) break;          // wave-uniform: whole step beyond the plane
       float4 acc = z4;
-      // All 25 cell reads are issued before any of them is consumed: the step is otherwise a chain
-      // of ~24 dependent LDS round trips (hundreds of cycles each with 16 waves queued on the
-      // LDS), which is what bounded this kernel -- not VALU issue and not LDS bandwidth.
 #define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
-      float4 q0[4], q1[2], q2[4], q3[2], q4, q5[2], q6[4], q7[2], q8[4];
-      q0[0] = CDN_RD(r[0] + c[0]); q0[1] = CDN_RD(r[0] + c[1]);
-      q0[2] = CDN_RD(r[1] + c[0]); q0[3] = CDN_RD(r[1] + c[1]);
-      q1[0] = CDN_RD(r[0] + c[4]); q1[1] = CDN_RD(r[1] + c[4]);
-      q2[0] = CDN_RD(r[0] + c[2]); q2[1] = CDN_RD(r[0] + c[3]);
-      q2[2] = CDN_RD(r[1] + c[2]); q2[3] = CDN_RD(r[1] + c[3]);
-      q3[0] = CDN_RD(r[4] + c[0]); q3[1] = CDN_RD(r[4] + c[1]);
-      q4 = CDN_RD(r[4] + c[4]);
-      q5[0] = CDN_RD(r[4] + c[2]); q5[1] = CDN_RD(r[4] + c[3]);
-      q6[0] = CDN_RD(r[2] + c[0]); q6[1] = CDN_RD(r[2] + c[1]);
-      q6[2] = CDN_RD(r[3] + c[0]); q6[3] = CDN_RD(r[3] + c[1]);
-      q7[0] = CDN_RD(r[2] + c[4]); q7[1] = CDN_RD(r[3] + c[4]);
-      q8[0] = CDN_RD(r[2] + c[2]); q8[1] = CDN_RD(r[2] + c[3]);
-      q8[2] = CDN_RD(r[3] + c[2]); q8[3] = CDN_RD(r[3] + c[3]);
-#undef CDN_RD
-      __builtin_amdgcn_sched_barrier(0);   // keep the reads clustered ahead of the math
 #define CDN_WACC(K, TV)                     \
   acc.x = fmaf(wk[K][0], TV.x, acc.x);      \
   acc.y = fmaf(wk[K][1], TV.y, acc.y);      \
   acc.z = fmaf(wk[K][2], TV.z, acc.z);      \
   acc.w = fmaf(wk[K][3], TV.w, acc.w);
-#define CDN_TAP4(Q, Y0, Y1, X0, X1, K)                                            \
-  {                                                                               \
-    const float w00 = Y0 * X0, w01 = Y0 * X1, w10 = Y1 * X0, w11 = Y1 * X1;       \
-    float4 tv;                                                                    \
-    tv.x = ((w00 * Q[0].x + w01 * Q[1].x) + w10 * Q[2].x) + w11 * Q[3].x;         \
-    tv.y = ((w00 * Q[0].y + w01 * Q[1].y) + w10 * Q[2].y) + w11 * Q[3].y;         \
-    tv.z = ((w00 * Q[0].z + w01 * Q[1].z) + w10 * Q[2].z) + w11 * Q[3].z;         \
-    tv.w = ((w00 * Q[0].w + w01 * Q[1].w) + w10 * Q[2].w) + w11 * Q[3].w;         \
-    CDN_WACC(K, tv)                                                               \
+      // corner taps: rows (R0,R1) x cols (C0,C1), axis weights (Y0,Y1) x (X0,X1)
+#define CDN_TAP4(R0, R1, C0, C1, Y0, Y1, X0, X1, K)                       \
+  {                                                                       \
+    const float4 v00 = CDN_RD(R0 + C0), v01 = CDN_RD(R0 + C1);            \
+    const float4 v10 = CDN_RD(R1 + C0), v11 = CDN_RD(R1 + C1);            \
+    const float w00 = Y0 * X0, w01 = Y0 * X1, w10 = Y1 * X0, w11 = Y1 * X1; \
+    float4 tv;                                                            \
+    tv.x = ((w00 * v00.x + w01 * v01.x) + w10 * v10.x) + w11 * v11.x;     \
+    tv.y = ((w00 * v00.y + w01 * v01.y) + w10 * v10.y) + w11 * v11.y;     \
+    tv.z = ((w00 * v00.z + w01 * v01.z) + w10 * v10.z) + w11 * v11.z;     \
+    tv.w = ((w00 * v00.w + w01 * v01.w) + w10 * v10.w) + w11 * v11.w;     \
+    CDN_WACC(K, tv)                                                       \
   }
-#define CDN_TAP2(Q, A0, A1, K)                      \
+      // edge taps: one axis exact, 2 cells with weights (A0, A1)
+#define CDN_TAP2(OA, OB, A0, A1, K)                 \
   {                                                 \
+    const float4 v0 = CDN_RD(OA), v1 = CDN_RD(OB);  \
     float4 tv;                                      \
-    tv.x = A0 * Q[0].x + A1 * Q[1].x;               \
-    tv.y = A0 * Q[0].y + A1 * Q[1].y;               \
-    tv.z = A0 * Q[0].z + A1 * Q[1].z;               \
-    tv.w = A0 * Q[0].w + A1 * Q[1].w;               \
+    tv.x = A0 * v0.x + A1 * v1.x;                   \
+    tv.y = A0 * v0.y + A1 * v1.y;                   \
+    tv.z = A0 * v0.z + A1 * v1.z;                   \
+    tv.w = A0 * v0.w + A1 * v1.w;                   \
     CDN_WACC(K, tv)                                 \
   }
-      CDN_TAP4(q0, wt[0], wt[1], wt[4], wt[5], 0)
-      CDN_TAP2(q1, wt[0], wt[1], 1)
-      CDN_TAP4(q2, wt[0], wt[1], wt[6], wt[7], 2)
-      CDN_TAP2(q3, wt[4], wt[5], 3)
-      CDN_WACC(4, q4)
-      CDN_TAP2(q5, wt[6], wt[7], 5)
-      CDN_TAP4(q6, wt[2], wt[3], wt[4], wt[5], 6)
-      CDN_TAP2(q7, wt[2], wt[3], 7)
-      CDN_TAP4(q8, wt[2], wt[3], wt[6], wt[7], 8)
+      CDN_TAP4(r[0], r[1], c[0], c[1], wt[0], wt[1], wt[4], wt[5], 0)
+      CDN_TAP2(r[0] + c[4], r[1] + c[4], wt[0], wt[1], 1)
+      CDN_TAP4(r[0], r[1], c[2], c[3], wt[0], wt[1], wt[6], wt[7], 2)
+      CDN_TAP2(r[4] + c[0], r[4] + c[1], wt[4], wt[5], 3)
+      {
+        const float4 vc = CDN_RD(r[4] + c[4]);
+        CDN_WACC(4, vc)
+      }
+      CDN_TAP2(r[4] + c[2], r[4] + c[3], wt[6], wt[7], 5)
+      CDN_TAP4(r[2], r[3], c[0], c[1], wt[2], wt[3], wt[4], wt[5], 6)
+      CDN_TAP2(r[2] + c[4], r[3] + c[4], wt[2], wt[3], 7)
+      CDN_TAP4(r[2], r[3], c[2], c[3], wt[2], wt[3], wt[6], wt[7], 8)
 #undef CDN_TAP4
 #undef CDN_TAP2
 #undef CDN_WACC
+#undef CDN_RD
       if (p < HW) {
         float *dp = d + ((long)n * HW + p) * C + c0 + cq * 4;
         const int cbase = c0 + cq * 4;
@@ -805,8 +795,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
-  (void)two_per_cu;
-  int threads = 512;
+  int threads = two_per_cu ? 512 : 1024;
   if (const char *e = getenv("CDN_DW_THREADS")) threads = atoi(e);   // tuning knob
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
