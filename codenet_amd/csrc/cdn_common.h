@@ -84,6 +84,122 @@ __device__ __forceinline__ float quant_code(float x, float scale, float zp) {
 __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
   return __fdiv_rn(__fadd_rn(quant_code(x, scale, zp), zp), scale);
 }
+// ---- QuantAct range tracking + parameters, one thread (quant_modules.py:211-219,
+// quant_utils.py:60-75); shared by the stand-alone update kernel and the in-kernel
+// "last workgroup" update of the fused schedule.  have_stats: bmin/bmax are this batch's extremes.
+struct QUpdate {
+  float *x_min, *x_max;
+  unsigned *state;       // kQStateWords words; [7] is the arrival counter of the fused schedule
+  float m_minus_1, one_minus_m;
+  int bits, running;
+};
+
+__device__ __forceinline__ void quantact_update_device(const QUpdate &u, float bmin, float bmax,
+                                                       bool have_stats) {
+  float lo = u.x_min[0], hi = u.x_max[0];
+  float *sf = reinterpret_cast<float *>(u.state);
+  if (have_stats) {
+    sf[4] = bmin;
+    sf[5] = bmax;
+  }
+  if (u.running) {
+    if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
+      lo = __fadd_rn(lo, bmin);
+      hi = __fadd_rn(hi, bmax);
+    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219)
+      lo = __fadd_rn(lo, __fadd_rn(__fmul_rn(u.m_minus_1, lo), __fmul_rn(u.one_minus_m, bmin)));
+      hi = __fadd_rn(hi, __fadd_rn(__fmul_rn(u.m_minus_1, hi), __fmul_rn(u.one_minus_m, bmax)));
+    }
+    u.x_min[0] = lo;
+    u.x_max[0] = hi;
+  }
+  const float nlev = (float)((1 << u.bits) - 1);
+  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);          // torch.clamp(min=1e-10)
+  // `n / tensor` in torch is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
+  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);
+  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (u.bits - 1)));
+  sf[2] = scale;
+  sf[3] = zp;
+  // state[6]: 1 when some level L - 128 = round(scale*x - zp) + zp - 128 of this batch cannot be
+  // carried by the int8 kernels' nibble split (|.| > 2039) or the batch extremes are unknown --
+  // consumers then take their f32 path.  Codes are monotone in x, so the extremes decide.
+  unsigned wide = 1u;
+  if (have_stats && u.bits == 8) {
+    const float a0 = quant_code(bmin, scale, zp) + (zp - 128.0f);
+    const float a1 = quant_code(bmax, scale, zp) + (zp - 128.0f);
+    wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1)) ? 1u : 0u;
+  }
+  u.state[6] = wide;
+}
+
+// Epilogue of a producer kernel in the fused schedule: workgroup min/max -> partials[bid] ->
+// arrival ticket; the LAST workgroup to arrive reduces all partials and runs the range update, so
+// no separate update launch (~4.4 us each inside a graph) and no contended atomics are needed.
+// Cross-workgroup visibility: the 8-byte partial is written and read with agent-scope atomics
+// (sc1, bypassing the non-coherent L1s; MI355X_MICROARCH.md "Valid forms": 8-B agent atomics on both
+// sides), the ticket is an agent-scope fetch-add issued after the store has drained.  The counter
+// (state[7]) is reset by the last arriver; it starts at zero (state is allocated zeroed).
+// Every thread of the workgroup must call this; `red` is >= 2*nwaves + 2 floats of free LDS.
+__device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *partials, int bid,
+                                                    int nblocks, const QUpdate &u, float *red) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();   // `red` may alias tiles other waves are still reading
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * wave] = mn;
+    red[2 * wave + 1] = mx;
+  }
+  __syncthreads();
+  unsigned long long *pp = reinterpret_cast<unsigned long long *>(partials);
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) {
+      mn = fminf(mn, red[2 * i]);
+      mx = fmaxf(mx, red[2 * i + 1]);
+    }
+    const unsigned long long bits = (unsigned long long)__float_as_uint(mn) |
+                                    ((unsigned long long)__float_as_uint(mx) << 32);
+    __hip_atomic_store(pp + bid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket =
+        __hip_atomic_fetch_add(&u.state[7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[2 * nw] = (ticket == (unsigned)(nblocks - 1)) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (red[2 * nw] == 0.0f) return;
+  // ---- last workgroup: reduce every partial, update ranges and parameters -------------------
+  mn = INFINITY;
+  mx = -INFINITY;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+    const unsigned long long b =
+        __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mn = fminf(mn, __uint_as_float((unsigned)(b & 0xffffffffull)));
+    mx = fmaxf(mx, __uint_as_float((unsigned)(b >> 32)));
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * wave] = mn;
+    red[2 * wave + 1] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) {
+      mn = fminf(mn, red[2 * i]);
+      mx = fmaxf(mx, red[2 * i + 1]);
+    }
+    quantact_update_device(u, mn, mx, true);
+    __hip_atomic_store(&u.state[7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Workgroup-level min/max -> ONE {min,max} pair stored at out[0] (plain store, no atomics: a
 // single contended word sustains only ~88 atomics/us on MI355X).  Every thread of the workgroup
 // must call it; `red` is >= 2*nwaves floats of LDS that nobody else is using.

@@ -60,8 +60,8 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
 constexpr int kScaleWaves = 16;
 __global__ void __launch_bounds__(kScaleWaves * 64)
 scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                  const float *__restrict__ b, float *__restrict__ s, float2 *mm, int C, int HW,
-                  float lo, float hi) {
+                  const float *__restrict__ b, float *__restrict__ s, float2 *mm, cdn::QUpdate qu,
+                  int C, int HW, float lo, float hi) {
   // 16 waves x 64 pixels: wave v reduces channels v, v+16, ... with 4 loads in flight per lane
   // (~16 KB of 256-byte rows in flight per workgroup) -- the HBM-bound C -> 1 reduction.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,23 +84,21 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
   __shared__ float red[kScaleWaves][64];
   red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
+  float mn = INFINITY, mx = -INFINITY;
   if (wave == 0) {
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < kScaleWaves; ++i) v += red[i][lane];
     v += b ? b[0] : 0.0f;
     v = fminf(fmaxf(v, lo), hi);
-    if (live) s[(long)n * HW + p] = v;
-    if (mm) {   // one wave holds the whole workgroup's outputs: wave reduce, one plain store
-      float mn = live ? v : INFINITY, mx = live ? v : -INFINITY;
-#pragma unroll
-      for (int m = 32; m > 0; m >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, m, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-      }
-      if (lane == 0) mm[(long)blockIdx.y * gridDim.x + blockIdx.x] = make_float2(mn, mx);
+    if (live) {
+      s[(long)n * HW + p] = v;
+      mn = mx = v;
     }
   }
+  if (mm)
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, &red[0][0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -111,8 +109,8 @@ template <bool XQ>
 __global__ void __launch_bounds__(256)
 scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                   const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ s,
-                  float2 *mm, int C, long npix, float lo, float hi) {
-  __shared__ float red[8];
+                  float2 *mm, cdn::QUpdate qu, int C, long npix, float lo, float hi) {
+  __shared__ float red[12];
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
@@ -147,7 +145,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
-  if (mm) cdn::block_minmax_store(mn, mx, mm + blockIdx.x, red);
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -163,8 +161,8 @@ template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
 __global__ void __launch_bounds__(kDw2MaxThreads)
 dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
-           const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, int C, int H, int W,
-           int up) {
+           const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
+           int C, int H, int W, int up) {
   // LDS: [(Hl+1)*(Wl+1)][CCH] image cells; row Hl and column Wl are ZERO and every out-of-image
   // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
   // cell address is just row offset + column offset, no bounds test and no clamp per corner.
@@ -370,7 +368,9 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       }
     }
   }
-  if (dmm) cdn::block_minmax_store(mn, mx, dmm + (long)blockIdx.y * gridDim.x + blockIdx.x, red);
+  if (dmm)
+    cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -397,7 +397,8 @@ __global__ void __launch_bounds__(256)
 pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            const float *__restrict__ Wp, const float *__restrict__ bias,
            const float *__restrict__ ep_scale, const float *__restrict__ ep_shift,
-           float *__restrict__ R, float2 *rmm, long M, int C, int Co, int relu, int only_if_wide) {
+           float *__restrict__ R, float2 *rmm, cdn::QUpdate qu, long M, int C, int Co, int relu,
+           int only_if_wide) {
   if (only_if_wide && !aq[6]) return;   // fallback launch behind pwi8_kernel: nothing to do
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
@@ -545,8 +546,9 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         }
       }
   }
-  if (rmm)   // (the loop's trailing barrier freed As)
-    cdn::block_minmax_store(mn, mx, rmm + (long)blockIdx.y * gridDim.x + blockIdx.x, &As[0][0]);
+  if (rmm)   // (block_minmax_finish syncs before reusing As as scratch)
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, &As[0][0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,7 +575,7 @@ __global__ void __launch_bounds__(256)
 pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const int *__restrict__ wsum, const float *__restrict__ bias, float *__restrict__ R,
-            float2 *rmm, long M, int C, int Cpad, int Co, int relu) {
+            float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
@@ -713,8 +715,8 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
   }
   if (rmm)
-    cdn::block_minmax_store(mn, mx, rmm + (long)blockIdx.y * gridDim.x + blockIdx.x,
-                            reinterpret_cast<float *>(&A0[0][0]));
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -786,11 +788,11 @@ constexpr int kMaxPartials = 16384;  // per kernel; grids are clamped / checked 
 
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
-               const unsigned *sq, const float *wd, float *d, float2 *dmm, int N, int C, int H,
-               int W, int up, hipStream_t st) {
+               const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
+               int C, int H, int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = ((size_t)(Hl + 1) * (Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl +
-                      2 * kDw2MaxThreads / 64) * sizeof(float);
+                      2 * kDw2MaxThreads / 64 + 4) * sizeof(float);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
@@ -802,7 +804,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
     auto kern = dw2_kernel<CCH, NH, XQ_, SQ_>;                                                \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, C, H, W, up);              \
+    kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up);              \
   }
   const bool XQ = xq != nullptr, SQ = sq != nullptr;
   if (nhwc) {
@@ -885,10 +887,16 @@ extern "C" int cdn_codenet_stage_fused_forward(
   CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
               "stored plane %dx%d too large for the LDS-resident gather (max ~1250 pixels)", Hl, Wl);
 
-  if (running && (sst || dst || rst)) cdn::launch_minmax_init(sst, dst, rst, st);
+  // Range tracking runs inside the producing kernels (last workgroup to finish), see
+  // cdn::block_minmax_finish: no separate update launches.  Python evaluates (momentum - 1.) and
+  // (1. - momentum) in double, then the tensor op rounds the scalar to fp32 (quant_modules.py:217-219).
+  const float mm1 = (float)(momentum - 1.0), omm = (float)(1.0 - momentum);
+  const cdn::QUpdate qu_s{s_min, s_max, sst, mm1, omm, bits, running};
+  const cdn::QUpdate qu_d{d_min, d_max, dst, mm1, omm, bits, running};
+  const cdn::QUpdate qu_r{r_min, r_max, rst, mm1, omm, bits, running};
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
   // 1. scale prediction at stored resolution (+ min/max of s)
-  float2 *smm = (running && sst) ? part_s : nullptr;
+  float2 *smm = sst ? part_s : nullptr;
   int n_part_s = 0;
   {
   cdn::ProfScope ps(cdn::kProfScale, ptag, st);
@@ -897,25 +905,23 @@ extern "C" int cdn_codenet_stage_fused_forward(
     const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
     n_part_s = blocks;
     if (xq)
-      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, (int)C,
-                                                      npix, lo, hi);
+      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, qu_s,
+                                                      (int)C, npix, lo, hi);
     else
       scale_nhwc_kernel<false><<<blocks, 256, 0, st>>>(x, nullptr, w_scale, b_scale, s_raw, smm,
-                                                       (int)C, npix, lo, hi);
+                                                       qu_s, (int)C, npix, lo, hi);
   } else {
     CDN_REQUIRE(xq == nullptr, CDN_ERR_UNSUPPORTED, "quant-on-load needs a channels-last input");
     dim3 grid((unsigned)cdn::ceil_div(HWl, 64), (unsigned)N);
     n_part_s = (int)(grid.x * grid.y);
     CDN_REQUIRE(n_part_s <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many scale workgroups");
-    scale_nchw_kernel<<<grid, kScaleWaves * 64, 0, st>>>(x, w_scale, b_scale, s_raw, smm, (int)C,
-                                                          (int)HWl, lo, hi);
+    scale_nchw_kernel<<<grid, kScaleWaves * 64, 0, st>>>(x, w_scale, b_scale, s_raw, smm, qu_s,
+                                                          (int)C, (int)HWl, lo, hi);
   }
   }
   int rc = cdn::check_launch("codenet fused scale");
   if (rc) return rc;
-  if (sst)
-    cdn::launch_quantact_update(s_min, s_max, sst, nullptr, nullptr, smm, n_part_s, bits, momentum,
-                                running, st);
+  (void)n_part_s;
   // 2. gather + depthwise (+ min/max of d)
   float2 *dmm = dst ? part_d : nullptr;   // always: the batch extremes also gate the int8 path
   const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
@@ -923,16 +929,13 @@ extern "C" int cdn_codenet_stage_fused_forward(
   {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     if (cch == 64)
-      rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+      rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
     else
-      rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, (int)N, (int)C, (int)H, (int)W, x_up, st);
+      rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
   }
   if (rc) return rc;
-  if (dst)
-    cdn::launch_quantact_update(d_min, d_max, dst, nullptr, nullptr, dmm, n_part_d, bits, momentum,
-                                running, st);
   // 3. pointwise on f32 MFMA (+ bias / affine / ReLU, min/max of the result)
-  float2 *rmm = (running && rst) ? part_r : nullptr;
+  float2 *rmm = rst ? part_r : nullptr;
   const long M = (long)(N * H * W);
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
   const int pw_bn = Co > 64 ? 128 : 64;
@@ -944,7 +947,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
 #define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
   pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<dim3((unsigned)cdn::ceil_div(M, BM_),                 \
                                                 (unsigned)cdn::ceil_div(Co, BN_)), 256, 0, st>>>( \
-      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, M, (int)C, (int)Co, relu, only_if_wide)
+      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, only_if_wide)
 #define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
   do {                                                                    \
     if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
@@ -963,12 +966,12 @@ extern "C" int cdn_codenet_stage_fused_forward(
     dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
     if (pw_fast)                                                                                 \
       pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
-                                                            w_pw_colsum, bias_pw, r_out, rmm, M,  \
-                                                            (int)C, Cpad, (int)Co, relu);        \
+                                                            w_pw_colsum, bias_pw, r_out, rmm,     \
+                                                            qu_r, M, (int)C, Cpad, (int)Co, relu); \
     else                                                                                         \
       pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
-                                                             w_pw_colsum, bias_pw, r_out, rmm, M, \
-                                                             (int)C, Cpad, (int)Co, relu);       \
+                                                             w_pw_colsum, bias_pw, r_out, rmm,    \
+                                                             qu_r, M, (int)C, Cpad, (int)Co, relu); \
   } while (0)
     if (pw_bn == 128 && pw_bm == 64) CDN_PWI(64, 128, 2);
     else if (pw_bn == 128) CDN_PWI(128, 128, 4);
@@ -990,9 +993,6 @@ extern "C" int cdn_codenet_stage_fused_forward(
 #undef CDN_PW1
   rc = cdn::check_launch("codenet fused pointwise");
   if (rc) return rc;
-  if (rst)
-    cdn::launch_quantact_update(r_min, r_max, rst, nullptr, nullptr, rmm, n_part_r, bits, momentum,
-                                running, st);
   return CDN_OK;
 }
 

@@ -88,43 +88,14 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
-  float lo = x_min[0], hi = x_max[0];
   const bool have_stats = ext_min || from_partials || running;
   float bmin = 0.f, bmax = 0.f;
   if (have_stats) {
     bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : ord2f(state[0]));
     bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : ord2f(state[1]));
-    reinterpret_cast<float *>(state)[4] = bmin;
-    reinterpret_cast<float *>(state)[5] = bmax;
   }
-  if (running) {
-    if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
-      lo = __fadd_rn(lo, bmin);
-      hi = __fadd_rn(hi, bmax);
-    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219)
-      lo = __fadd_rn(lo, __fadd_rn(__fmul_rn(m_minus_1, lo), __fmul_rn(one_minus_m, bmin)));
-      hi = __fadd_rn(hi, __fadd_rn(__fmul_rn(m_minus_1, hi), __fmul_rn(one_minus_m, bmax)));
-    }
-    x_min[0] = lo;
-    x_max[0] = hi;
-  }
-  const float nlev = (float)((1 << bits) - 1);
-  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);          // torch.clamp(min=1e-10)
-  // `n / tensor` in torch is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
-  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);
-  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (bits - 1)));
-  reinterpret_cast<float *>(state)[2] = scale;
-  reinterpret_cast<float *>(state)[3] = zp;
-  // state[6]: 1 when some level L - 128 = round(scale*x - zp) + zp - 128 of this batch cannot be
-  // carried by the int8 kernels' nibble split (|.| > 2039) or the batch extremes are unknown --
-  // consumers then take their f32 path.  Codes are monotone in x, so the extremes decide.
-  unsigned wide = 1u;
-  if (have_stats && bits == 8) {
-    const float a0 = quant_code(bmin, scale, zp) + (zp - 128.0f);
-    const float a1 = quant_code(bmax, scale, zp) + (zp - 128.0f);
-    wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1)) ? 1u : 0u;
-  }
-  state[6] = wide;
+  cdn::QUpdate u{x_min, x_max, state, m_minus_1, one_minus_m, bits, running};
+  cdn::quantact_update_device(u, bmin, bmax, have_stats);
 }
 
 // out = (q + zp) / scale; optionally also the integer codes (int16: codes are NOT clamped to
