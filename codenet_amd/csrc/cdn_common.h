@@ -89,10 +89,15 @@ __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
 // "last workgroup" update of the fused schedule.  have_stats: bmin/bmax are this batch's extremes.
 struct QUpdate {
   float *x_min, *x_max;
-  unsigned *state;       // kQStateWords words; [7] is the arrival counter of the fused schedule
+  unsigned *state;       // kQStateWords words
+  unsigned *counters;    // fused schedule only: kArriveWords zero-initialised arrival counters
   float m_minus_1, one_minus_m;
   int bits, running;
 };
+// Arrival counters: 64 group counters + 1 top counter, one per 64-byte line (a single contended
+// word sustains only ~88 atomics/us; 2048 workgroups on one word cost ~25 us).
+constexpr int kArriveGroups = 64;
+constexpr int kArriveWords = (kArriveGroups + 1) * 16;
 
 __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float bmin, float bmax,
                                                        bool have_stats) {
@@ -137,8 +142,9 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
 // no separate update launch (~4.4 us each inside a graph) and no contended atomics are needed.
 // Cross-workgroup visibility: the 8-byte partial is written and read with agent-scope atomics
 // (sc1, bypassing the non-coherent L1s; MI355X_MICROARCH.md "Valid forms": 8-B agent atomics on both
-// sides), the ticket is an agent-scope fetch-add issued after the store has drained.  The counter
-// (state[7]) is reset by the last arriver; it starts at zero (state is allocated zeroed).
+// sides), the ticket is an agent-scope fetch-add issued after the store has drained.  Tickets are
+// two-level (workgroup -> one of 64 group counters -> top counter) so no word sees more than
+// max(64, nblocks/64) arrivals.  The counters start at zero and the last arriver resets them.
 // Every thread of the workgroup must call this; `red` is >= 2*nwaves + 2 floats of free LDS.
 __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *partials, int bid,
                                                     int nblocks, const QUpdate &u, float *red) {
@@ -164,9 +170,18 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
                                     ((unsigned long long)__float_as_uint(mx) << 32);
     __hip_atomic_store(pp + bid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket =
-        __hip_atomic_fetch_add(&u.state[7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[2 * nw] = (ticket == (unsigned)(nblocks - 1)) ? 1.0f : 0.0f;
+    const int ngroups = nblocks < kArriveGroups ? nblocks : kArriveGroups;
+    const int g = bid % kArriveGroups;
+    const unsigned gsize = (unsigned)((nblocks - g + kArriveGroups - 1) / kArriveGroups);
+    bool last = false;
+    const unsigned t1 = __hip_atomic_fetch_add(&u.counters[16 * g], 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    if (t1 == gsize - 1) {
+      const unsigned t2 = __hip_atomic_fetch_add(&u.counters[16 * kArriveGroups], 1u,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t2 == (unsigned)(ngroups - 1));
+    }
+    red[2 * nw] = last ? 1.0f : 0.0f;
   }
   __syncthreads();
   if (red[2 * nw] == 0.0f) return;
@@ -196,8 +211,10 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
       mx = fmaxf(mx, red[2 * i + 1]);
     }
     quantact_update_device(u, mn, mx, true);
-    __hip_atomic_store(&u.state[7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (threadIdx.x <= kArriveGroups)   // everybody has arrived: leave the counters zero again
+    __hip_atomic_store(&u.counters[16 * threadIdx.x], 0u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Workgroup-level min/max -> ONE {min,max} pair stored at out[0] (plain store, no atomics: a

@@ -830,7 +830,8 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
   // s_raw [N*HWl] + d [N*H*W*C] + 3 regions of per-workgroup {min,max} partials, each rounded
   // up to 256 bytes
   auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
-  return (size_t)(r(N * HWl * 4) + r(N * H * W * C * 4) + 3 * r(kMaxPartials * 8));
+  return (size_t)(r(N * HWl * 4) + r(N * H * W * C * 4) + 3 * r(kMaxPartials * 8) +
+                  3 * r(cdn::kArriveWords * 4));
 }
 
 extern "C" int cdn_codenet_stage_fused_forward(
@@ -873,6 +874,10 @@ extern "C" int cdn_codenet_stage_fused_forward(
   float2 *part_s = reinterpret_cast<float2 *>(wsp + r256(N * HWl * 4) + r256(N * H * W * C * 4));
   float2 *part_d = part_s + kMaxPartials;
   float2 *part_r = part_d + kMaxPartials;
+  // arrival counters: the LAST bytes of the workspace (the caller zeroes them once)
+  unsigned *arrive = reinterpret_cast<unsigned *>(wsp + workspace_bytes / 256 * 256 -
+                                                  3 * r256(cdn::kArriveWords * 4));
+  const int arr_stride = (int)(r256(cdn::kArriveWords * 4) / 4);
   unsigned *sst = static_cast<unsigned *>(s_state), *dst = static_cast<unsigned *>(d_state),
            *rst = static_cast<unsigned *>(r_state);
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
@@ -891,9 +896,9 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // cdn::block_minmax_finish: no separate update launches.  Python evaluates (momentum - 1.) and
   // (1. - momentum) in double, then the tensor op rounds the scalar to fp32 (quant_modules.py:217-219).
   const float mm1 = (float)(momentum - 1.0), omm = (float)(1.0 - momentum);
-  const cdn::QUpdate qu_s{s_min, s_max, sst, mm1, omm, bits, running};
-  const cdn::QUpdate qu_d{d_min, d_max, dst, mm1, omm, bits, running};
-  const cdn::QUpdate qu_r{r_min, r_max, rst, mm1, omm, bits, running};
+  const cdn::QUpdate qu_s{s_min, s_max, sst, arrive, mm1, omm, bits, running};
+  const cdn::QUpdate qu_d{d_min, d_max, dst, arrive + arr_stride, mm1, omm, bits, running};
+  const cdn::QUpdate qu_r{r_min, r_max, rst, arrive + 2 * arr_stride, mm1, omm, bits, running};
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
   // 1. scale prediction at stored resolution (+ min/max of s)
   float2 *smm = sst ? part_s : nullptr;

@@ -94,7 +94,7 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
     bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : ord2f(state[0]));
     bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : ord2f(state[1]));
   }
-  cdn::QUpdate u{x_min, x_max, state, m_minus_1, one_minus_m, bits, running};
+  cdn::QUpdate u{x_min, x_max, state, nullptr, m_minus_1, one_minus_m, bits, running};
   cdn::quantact_update_device(u, bmin, bmax, have_stats);
 }
 

@@ -200,7 +200,7 @@ class FusedHotPath:
                              r=torch.empty(Nb, Hs * Ws, cout, device=dev)))
         last = bufs[-1]
         out = torch.empty(Nb, last["Co"], last["H"] * 2, last["W"] * 2, device=dev)
-        ws = torch.empty(ws_bytes // 4 + 64, device=dev)
+        ws = torch.zeros(ws_bytes // 4 + 64, device=dev)   # arrival counters must start at zero
         self._bufs = dict(shape=tuple(x.shape), dev=dev, stages=bufs, ws=ws, out=out)
 
     def __call__(self, x):
@@ -217,7 +217,7 @@ class FusedHotPath:
         stream = torch.cuda.current_stream(x.device).cuda_stream
         ws = B["ws"]
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
-        ws_bytes = ws.numel() * 4 - (ws_ptr - ws.data_ptr())
+        ws_bytes = (ws.numel() * 4 - (ws_ptr - ws.data_ptr())) // 256 * 256
         cur, cur_nhwc, cur_q = x, 0, None
         with torch.no_grad():
             for st, sb in zip(self.stages, B["stages"]):

@@ -201,7 +201,10 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
  *   {s,d,r}_{min,max,state}: the three QuantAct of the stage (x_min/x_max buffers updated in place
  *             when running != 0; state as in cdn_quantact_forward); pass all three of a group NULL to
  *             disable that quantiser (fp32 path: all NULL)
- *   workspace cdn_codenet_stage_workspace_bytes(N,C,H,W,x_up) bytes, 256-byte aligned
+ *   workspace cdn_codenet_stage_workspace_bytes(N,C,H,W,x_up) bytes (or more), 256-byte aligned.
+ *             Its LAST 16 KiB hold workgroup arrival counters: zero them ONCE before the first call;
+ *             every completed call leaves them zero again (QuantAct ranges are updated by the last
+ *             workgroup of each producing kernel, no separate update launch).
  *   r_out     [N][H*W][Co] channels-last: act(pointwise(...)) BEFORE the output QuantAct (its
  *             parameters are left in r_state for the consumer)
  * ---------------------------------------------------------------------------------------- */
