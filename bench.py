@@ -230,6 +230,18 @@ def main():
                                if fused is not None else
                                {"dw": "dw_kernel", "scale": "scale_kernel",
                                 "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (only valid for
+        # the workload they were collected on; null otherwise)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+            w = pm["workload"]
+            if (w["res"], w["batch"], w["w2"], w["fp32"], w["path"]) == \
+                    (args.res, args.batch, args.w2, args.fp32, args.path) and roof["bound"] == "hbm":
+                roof["traffic"] = pm["bytes_per_step"].get(dominant)
+                roof["traffic_note"] = "bytes per step (sum over the kernel's launches), PMC FETCH_SIZE*2 + WRITE_SIZE"
+                roof["algorithmic_bytes_per_step"] = nbytes
+        except Exception:
+            pass
         roof["launches_per_step"] = sum(1 for (nm, _t) in durs if nm == dominant)
         roof["ms_per_step_in_kernel"] = per_kernel[dominant]
         res = {
