@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libcodenet_dcn.so")
+SO_PATH = os.environ.get("CDN_LIB") or os.path.join(_HERE, "lib", "libcodenet_dcn.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CDN_F32, CDN_F64 = 0, 1
