@@ -23,7 +23,6 @@
 
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 namespace {
 
@@ -156,27 +155,6 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-// compile-time loop (DPP controls must be immediates)
-template <int J, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-  if constexpr (J < N) {
-    f(std::integral_constant<int, J>{});
-    static_for<J + 1, N>(f);
-  }
-}
-
-// Fetch the value held by lane (row base + J [+8 for the upper half]) of each 16-lane DPP row:
-// v_mov_b32 dpp row_share (VALU, no LDS traffic).  HALVES: the two 8-lane halves of a row fetch
-// from different lanes (J and 8+J), written with complementary bank masks.
-template <int J, bool HALVES>
-__device__ __forceinline__ int row_fetch(int v) {
-  if (HALVES) {
-    int a = __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0x3, false);
-    return __builtin_amdgcn_update_dpp(a, v, 0x150 + 8 + J, 0xf, 0xc, false);
-  }
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);
-}
-
 constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (512 or 1024)
 
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
@@ -294,11 +272,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     int g_r[5], g_c[5];
     float g_w[8];
     {
-      // lane -> pixel map such that the record of (step J, pixel slot `sub`) sits in the DPP row of
-      // the lanes that will consume it: row lane J (CCH = 64) or half-row lane J (CCH = 32)
-      const int gl = (LPP == 16) ? ((lane & 15) * 4 + (lane >> 4))
-                                 : ((lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1)));
-      const int p = min(pb + gl, HW - 1);
+      const int p = min(pb + lane, HW - 1);
       const int h = p / W, w = p - h * W;
       const float t = sl[(h >> up) * Wl + (w >> up)] - 1.0f;
       const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
@@ -313,10 +287,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       g_w[4] = xa.w0; g_w[5] = xa.w1; g_w[6] = xb.w0; g_w[7] = xb.w1;
     }
     // ---- gather phase: PPW pixels per step ---------------------------------------------------
-    static_for<0, 64 / PPW>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if (pb + j * PPW >= HW) return;         // wave-uniform: whole step beyond the plane
-      const int p = pb + j * PPW + sub;
+#pragma unroll 1
+    for (int j = 0; j < 64 / PPW; ++j) {
+      const int src = j * PPW + sub;          // owner lane of this lane's pixel
+      const int p = pb + src;
       int r[5], c[5];
       float wt[8];
 #if defined(CDN_DIAG) && CDN_DIAG == 1   // diagnostic build: no cross-lane fetch (wrong results)
@@ -324,16 +298,18 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       for (int q = 0; q < 5; ++q) { r[q] = g_r[q]; c[q] = g_c[q]; }
 #pragma unroll
       for (int q = 0; q < 8; ++q) wt[q] = g_w[q];
+      (void)src;
 #else
+      // (a DPP row_share variant with fully unrolled steps measured slower: spills at 128 VGPRs)
 #pragma unroll
       for (int q = 0; q < 5; ++q) {
-        r[q] = row_fetch<j, LPP == 8>(g_r[q]);
-        c[q] = row_fetch<j, LPP == 8>(g_c[q]);
+        r[q] = __shfl(g_r[q], src, 64);
+        c[q] = __shfl(g_c[q], src, 64);
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        wt[q] = __int_as_float(row_fetch<j, LPP == 8>(__float_as_int(g_w[q])));
+      for (int q = 0; q < 8; ++q) wt[q] = __shfl(g_w[q], src, 64);
 #endif
+      if (pb + j * PPW >= HW) break;          // wave-uniform: whole step beyond the plane
       float4 acc = z4;
 #if defined(CDN_DIAG) && CDN_DIAG == 2   // diagnostic build: no LDS cell reads (wrong results)
 #define CDN_RD(O) make_float4(__int_as_float(O), 1.f, 2.f, 3.f)
@@ -403,7 +379,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             }
         }
       }
-    });
+    }
   }
   if (dmm)
     cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
