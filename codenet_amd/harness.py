@@ -1,0 +1,223 @@
+"""The caller side of the hot path, kept on
+PyTorch-ROCm: a ``PoseShuffleNetV2`` with the reference's module tree / state-dict keys
+(lib/models/networks/shufflenetv2_dcn.py:57-114,189-330) whose ``deconv_layers`` are this
+package's deform modules, ``ctdet_decode`` (lib/models/decode.py:10-16,110-127,474-505) and the
+body of ``CtdetDetector.process`` (lib/detectors/ctdet.py:29-46).  Only the three deform stages run
+on hand-written kernels; backbone and heads are stock torch ops (out of scope).
+"""
+import hashlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .modules import dcn_deform_conv
+from .portable_quantizer.quant_modules import channel_shuffle
+
+BN_MOMENTUM = 0.1
+
+
+class BaseNode(nn.Module):
+    """ShuffleNetV2 unit: stride 1 = split / transform one half / concat / shuffle; stride 2 = two
+    transformed branches (reference :57-114)."""
+
+    def __init__(self, inp, oup, stride, batch_norm=nn.BatchNorm2d, conv_kernel=nn.Conv2d):
+        super().__init__()
+        self.stride = stride
+        half = oup // 2
+
+        def pw(i, o):
+            return [nn.Conv2d(i, o, 1, 1, 0, bias=False), batch_norm(o, momentum=BN_MOMENTUM)]
+
+        def dw(c, s):
+            return [conv_kernel(c, c, 3, s, 1, groups=c, bias=False), batch_norm(c, momentum=BN_MOMENTUM)]
+
+        if stride == 1:
+            self.b2 = nn.Sequential(*pw(half, half), nn.ReLU(inplace=True), *dw(half, 1),
+                                    *pw(half, half), nn.ReLU(inplace=True))
+        elif stride == 2:
+            self.b1 = nn.Sequential(*dw(inp, 2), *pw(inp, half), nn.ReLU(inplace=True))
+            self.b2 = nn.Sequential(*pw(inp, half), nn.ReLU(inplace=True), *dw(half, 2),
+                                    *pw(half, half), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if self.stride == 1:
+            half = x.shape[1] // 2
+            x1, x2 = x[:, :half], self.b2(x[:, half:])
+        else:
+            x1, x2 = self.b1(x), self.b2(x)
+        return channel_shuffle(torch.cat((x1, x2), 1), 2)
+
+
+class PoseShuffleNetV2(nn.Module):
+    """Backbone (stride 32) -> three deform up-sampling stages -> heads (reference :189-330).
+    forward returns ``[ {head: tensor} ]`` like the reference."""
+
+    def __init__(self, heads, head_conv, w2=None, deform=False, maxpool=False):
+        super().__init__()
+        if deform:
+            raise NotImplementedError("deform backbone is dead code in the reference")
+        self.w2 = w2
+        self.deform_backbone = deform
+        self.heads = heads
+        self.deconv_with_bias = False
+        self.channels = [24, 244, 488, 976, 2153] if w2 else [24, 116, 232, 464, 1024]
+        c = self.channels
+        stem = [nn.Conv2d(3, c[0], 3, 2 if maxpool else 4, 1, bias=False),
+                nn.BatchNorm2d(c[0], momentum=BN_MOMENTUM), nn.ReLU(inplace=True)]
+        if maxpool:
+            stem.append(nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+        self.layer0 = nn.Sequential(*stem)
+        for idx, reps in enumerate([3, 7, 3]):
+            nodes = [BaseNode(c[idx], c[idx + 1], 2)]
+            nodes += [BaseNode(c[idx], c[idx + 1], 1) for _ in range(reps)]
+            setattr(self, "layer%d" % (idx + 1), nn.Sequential(*nodes))
+        self.layer4 = nn.Sequential(nn.Conv2d(c[3], c[4], 1, 1, 0, bias=False),
+                                    nn.BatchNorm2d(c[4], momentum=BN_MOMENTUM), nn.ReLU(inplace=True))
+        layers = []
+        planes_in = [c[4], 256, 128]
+        for cin, cout in zip(planes_in, [256, 128, 64]):
+            layers += [dcn_deform_conv.DeformConvWithOffsetScaleBoundPositive(
+                           cin, cout, 3, 1, 1, groups=cout, bias=False, hidden_state=128,
+                           BN_MOMENTUM=BN_MOMENTUM),
+                       nn.BatchNorm2d(cout, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                       nn.Upsample(scale_factor=2, mode="nearest")]
+        self.deconv_layers = nn.Sequential(*layers)
+        for head, classes in heads.items():
+            if head_conv > 0:
+                fc = nn.Sequential(
+                    nn.Conv2d(64, head_conv, 1, 1, 0, bias=False),
+                    nn.BatchNorm2d(head_conv, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                    nn.Conv2d(head_conv, head_conv, 3, 1, 1, groups=head_conv, bias=False),
+                    nn.BatchNorm2d(head_conv, momentum=BN_MOMENTUM), nn.ReLU(inplace=True),
+                    nn.Conv2d(head_conv, classes, kernel_size=1, stride=1, padding=0, bias=True))
+            else:
+                fc = nn.Conv2d(64, classes, kernel_size=1, stride=1, padding=0, bias=True)
+            setattr(self, head, fc)
+
+    def forward(self, x):
+        x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
+        x = self.deconv_layers(x)
+        return [{head: getattr(self, head)(x) for head in self.heads}]
+
+
+def fill_state_dict_(model, seed=317):
+    """Deterministic, construction-order independent synthetic weights: every tensor is drawn from a
+    generator seeded by (seed, state-dict key), so two models with the same keys (this package's
+    and the reference's) get identical values.  Scales keep activations O(1) through the net and
+    make conv_scale non-degenerate."""
+    sd = model.state_dict()
+    with torch.no_grad():
+        for key in sorted(sd):
+            t = sd[key]
+            if not t.dtype.is_floating_point:
+                continue
+            h = int(hashlib.sha256(("%d:%s" % (seed, key)).encode()).hexdigest()[:12], 16)
+            g = torch.Generator().manual_seed(h)
+            shape = tuple(t.shape)
+            if key.endswith("running_var"):
+                v = torch.rand(shape, generator=g) + 0.5
+            elif key.endswith("running_mean"):
+                v = torch.randn(shape, generator=g) * 0.1
+            elif key.endswith(("x_min", "x_max")):
+                v = torch.zeros(shape)
+            elif "conv_scale" in key and key.endswith("weight"):
+                v = torch.randn(shape, generator=g) * (3.0 / max(1, t[0].numel()) ** 0.5)
+            elif "conv_scale" in key and key.endswith("bias"):
+                v = torch.ones(shape)
+            elif t.dim() == 4:                       # conv weight: variance preserving
+                fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+                v = torch.randn(shape, generator=g) * (1.2 / fan_in) ** 0.5
+            elif key.endswith("weight"):             # BN gamma
+                v = torch.rand(shape, generator=g) + 0.5
+            elif key in ("hm.6.bias", "hm.quant_conv.bias", "hm.bias"):   # CenterNet focal-loss prior
+                v = torch.full(shape, -2.19)
+            else:                                    # BN beta / conv bias
+                v = torch.randn(shape, generator=g) * 0.1
+            t.copy_(v.to(t.device))
+    return model
+
+
+# ---- decode (lib/models/decode.py, lib/models/utils.py) ---------------------------------------
+
+def _nms(heat, kernel=3):
+    hmax = F.max_pool2d(heat, (kernel, kernel), stride=1, padding=(kernel - 1) // 2)
+    return heat * (hmax == heat).float()
+
+
+def _gather_feat(feat, ind):
+    return feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), feat.size(2)))
+
+
+def _transpose_and_gather_feat(feat, ind):
+    feat = feat.permute(0, 2, 3, 1).contiguous()
+    return _gather_feat(feat.view(feat.size(0), -1, feat.size(3)), ind)
+
+
+def _topk(scores, K=40):
+    batch, cat, height, width = scores.size()
+    topk_scores, topk_inds = torch.topk(scores.view(batch, cat, -1), K)
+    topk_inds = topk_inds % (height * width)
+    topk_ys = torch.div(topk_inds, width, rounding_mode="floor").float()
+    topk_xs = (topk_inds % width).float()
+    topk_score, topk_ind = torch.topk(topk_scores.view(batch, -1), K)
+    topk_clses = torch.div(topk_ind, K, rounding_mode="floor").int()
+    topk_inds = _gather_feat(topk_inds.view(batch, -1, 1), topk_ind).view(batch, K)
+    topk_ys = _gather_feat(topk_ys.view(batch, -1, 1), topk_ind).view(batch, K)
+    topk_xs = _gather_feat(topk_xs.view(batch, -1, 1), topk_ind).view(batch, K)
+    return topk_score, topk_inds, topk_clses, topk_ys, topk_xs
+
+
+def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100):
+    """3x3 max-pool peak filter -> two-level top-K -> boxes [x1,y1,x2,y2,score,class]."""
+    batch, cat, height, width = heat.size()
+    heat = _nms(heat)
+    scores, inds, clses, ys, xs = _topk(heat, K=K)
+    if reg is not None:
+        reg = _transpose_and_gather_feat(reg, inds).view(batch, K, 2)
+        xs = xs.view(batch, K, 1) + reg[:, :, 0:1]
+        ys = ys.view(batch, K, 1) + reg[:, :, 1:2]
+    else:
+        xs = xs.view(batch, K, 1) + 0.5
+        ys = ys.view(batch, K, 1) + 0.5
+    wh = _transpose_and_gather_feat(wh, inds)
+    if cat_spec_wh:
+        wh = wh.view(batch, K, cat, 2)
+        wh = wh.gather(2, clses.view(batch, K, 1, 1).expand(batch, K, 1, 2).long()).view(batch, K, 2)
+    else:
+        wh = wh.view(batch, K, 2)
+    clses = clses.view(batch, K, 1).float()
+    scores = scores.view(batch, K, 1)
+    bboxes = torch.cat([xs - wh[..., 0:1] / 2, ys - wh[..., 1:2] / 2,
+                        xs + wh[..., 0:1] / 2, ys + wh[..., 1:2] / 2], dim=2)
+    return torch.cat([bboxes, scores, clses], dim=2)
+
+
+def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K=100):
+    """CtdetDetector.process (lib/detectors/ctdet.py:29-46): images [2,3,R,R] = image + its W-flip
+    when flip_test.  Returns (output dict, dets [1,K,6])."""
+    with torch.no_grad():
+        output = model(images)[-1]
+        hm = output["hm"].sigmoid_()
+        wh = output["wh"]
+        reg = output["reg"] if reg_offset else None
+        if flip_test:
+            hm = (hm[0:1] + torch.flip(hm[1:2], [3])) / 2
+            wh = (wh[0:1] + torch.flip(wh[1:2], [3])) / 2
+            reg = reg[0:1] if reg is not None else None
+        dets = ctdet_decode(hm, wh, reg=reg, cat_spec_wh=cat_spec_wh, K=K)
+    return output, dets
+
+
+def create_model(heads=None, head_conv=64, w2=False, maxpool=False, quantize=False, seed=317,
+                 w_bit=4, a_bit=8, wt_percentile=False, act_percentile=False):
+    """PoseShuffleNetV2 with synthetic weights, optionally rewritten to W4A8 like
+    lib/detectors/base_detector.py:28-34 does."""
+    from .portable_quantizer import quantize_shufflenetv2_dcn
+    heads = heads or {"hm": 20, "wh": 2, "reg": 2}
+    model = PoseShuffleNetV2(heads, head_conv, w2=w2, maxpool=maxpool)
+    fill_state_dict_(model, seed)
+    if quantize:
+        quantize_shufflenetv2_dcn(model, w_bit, None, a_bit, "symmetric", "asymmetric", True,
+                                  wt_percentile, act_percentile, False, w2=w2, maxpool=maxpool)
+    return model.eval()
