@@ -387,6 +387,273 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 }
 
 // ------------------------------------------------------------------------------------------
+// dw2u: the gather + depthwise kernel for an UP-SAMPLED input (up = 1, channels-last, stages >= 1),
+// processing one 2x2 block of output pixels -- one stored pixel (Y,X) -- per lane group.
+//
+// The four output pixels of a block share the scale s (it is predicted at the stored resolution),
+// so their tap positions are translates of each other by one output pixel = half a stored cell.
+// Along one axis the 2+2 bilinear corners of the two pixels fall into at most TWO consecutive
+// stored cells {cb, cb+1}: a corner tap needs 2x2 = 4 cell reads for the WHOLE block instead of 16,
+// an edge tap 2 instead of 8, the centre tap 1 instead of 4 -- 25 ds_read_b128 per 16 outputs/lane
+// instead of 100, and one geometry record per block instead of four.  Each pixel keeps its own
+// fp32 corner weights (positions bit-identical to the reference pipeline); they are folded onto the
+// two cells per axis, W[slot] = sum of the corner weights that land in that cell.  (If fp32 rounding
+// makes a pixel's far corner land one cell further -- its weight is then ~1 ulp -- it is folded
+// into slot 1; the effect is below 1e-6 of the value.)
+// ------------------------------------------------------------------------------------------
+struct AxisRaw {
+  int fl;      // floor(pos), NOT parked
+  float w0, w1;  // corner weights, zero when the sample is out of range on this axis
+};
+
+__device__ __forceinline__ AxisRaw make_axis_raw(int base, float off, int size) {
+  AxisRaw a;
+  const float pos = (float)base + off;
+  const bool ok = pos > -1.0f && pos < (float)size;
+  const float fl = floorf(pos);
+  // clamp the index so far-out-of-range positions (|s| is not bounded by this kernel) stay sane
+  a.fl = (int)fminf(fmaxf(fl, -4.0f), (float)size + 4.0f);
+  const float l = pos - fl;
+  a.w1 = ok ? l : 0.0f;
+  a.w0 = ok ? 1.0f - l : 0.0f;
+  return a;
+}
+
+// Fold the two pixels (a: lower coordinate, b = a + 1) of one axis class onto cells {cb, cb+1}.
+// out[0..1] = pixel a's slot weights, out[2..3] = pixel b's.  Returns cb (stored-cell index).
+__device__ __forceinline__ int fold_axis(const AxisRaw &a, const AxisRaw &b, float *out) {
+  const int cb = a.fl >> 1;
+  const int sa1 = min(max(((a.fl + 1) >> 1) - cb, 0), 1);
+  const int sb0 = min(max((b.fl >> 1) - cb, 0), 1);
+  const int sb1 = min(max(((b.fl + 1) >> 1) - cb, 0), 1);
+  out[0] = a.w0 + (sa1 == 0 ? a.w1 : 0.0f);
+  out[1] = (sa1 == 1 ? a.w1 : 0.0f);
+  out[2] = (sb0 == 0 ? b.w0 : 0.0f) + (sb1 == 0 ? b.w1 : 0.0f);
+  out[3] = (sb0 == 1 ? b.w0 : 0.0f) + (sb1 == 1 ? b.w1 : 0.0f);
+  return cb;
+}
+
+template <int CCH, bool XQ, bool SQ>
+__global__ void __launch_bounds__(512)
+dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
+            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
+            int C, int H, int W) {
+  extern __shared__ float4 img[];
+  constexpr int LPP = CCH / 4;     // lanes per block (one float4 of channels each)
+  constexpr int PPW = 64 / LPP;    // blocks per wave step
+  const int nthreads = blockDim.x, nwaves = nthreads / 64;
+  const int Hl = H >> 1, Wl = W >> 1;
+  const int HWl = Hl * Wl, HW = H * W;
+  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  const int tid = threadIdx.x;
+  const int Wc = Wl + 1;
+  const int cells = (Hl + 1) * Wc;
+  float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
+  float *sl = wl + CCH * 9;
+  float *red = sl + HWl;
+  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
+  if (XQ) {
+    xs = reinterpret_cast<const float *>(xq)[2];
+    xz = reinterpret_cast<const float *>(xq)[3];
+  }
+  if (SQ) {
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = tid; q < (Wc + Hl) * LPP; q += nthreads) {   // zero row, then zero column
+    const int i = q / LPP;
+    const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
+    img[cell * LPP + (q % LPP)] = z4;
+  }
+  {
+    const float *xg = x + (long)n * HWl * C + c0;
+    for (int q = tid; q < HWl * LPP; q += nthreads) {
+      const int pix = q / LPP, cq4 = q % LPP;
+      float4 v = z4;
+      if (c0 + cq4 * 4 + 3 < C) v = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq4 * 4);
+      if (XQ) {
+        v.x = fake_quant(v.x, xs, xz);
+        v.y = fake_quant(v.y, xs, xz);
+        v.z = fake_quant(v.z, xs, xz);
+        v.w = fake_quant(v.w, xs, xz);
+      }
+      img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq4] = v;
+    }
+  }
+  for (int q = tid; q < CCH * 9; q += nthreads)
+    wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
+  for (int q = tid; q < HWl; q += nthreads) {
+    float sv = s_raw[(long)n * HWl + q];
+    if (SQ) sv = fake_quant(sv, ss, sz);
+    sl[q] = sv;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cq = lane % LPP, sub = lane / LPP;
+  float wk[9][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = wl[(cq * 4 + e) * 9 + k];
+
+  const int rstride = Wc * LPP * 16;
+  // stored-cell index -> byte offset (out-of-image cells select the zero row / column)
+  auto row_off = [&](int cy) { return (((unsigned)cy < (unsigned)Hl) ? cy : Hl) * rstride; };
+  auto col_off = [&](int cx) { return (((unsigned)cx < (unsigned)Wl) ? cx : Wl) * (LPP * 16); };
+  const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
+#define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
+
+  float mn = INFINITY, mx = -INFINITY;
+  const bool vec_store = ((C & 3) == 0);
+  // every wave owns a contiguous range of blocks (= stored pixels)
+  const int bpw = (HWl + nwaves - 1) / nwaves;
+  const int b_begin = wave * bpw, b_end = min(HWl, b_begin + bpw);
+  for (int bb = b_begin; bb < b_end; bb += 64) {
+    // ---- geometry phase: lane i owns block bb + i -----------------------------------------------
+    int g_o[10];      // byte offsets: rows {ya: r0,r1; yb: r0,r1; mid}, cols {xa: c0,c1; xb: c0,c1; mid}
+    float g_w[16];    // slot weights [class ya,yb,xa,xb][pixel a/b][slot 0/1]
+    {
+      const int blk = min(bb + lane, HWl - 1);
+      const int Y = blk / Wl, X = blk - Y * Wl;
+      const int h0 = 2 * Y, w0 = 2 * X;
+      const float t = sl[blk] - 1.0f;
+      // tap row i = 0: pos = (h - 1) - t ; i = 2: pos = (h + 1) + t ; pixel rows h0 and h0 + 1
+      const AxisRaw ya_a = make_axis_raw(h0 - 1, -t, H), ya_b = make_axis_raw(h0, -t, H);
+      const AxisRaw yb_a = make_axis_raw(h0 + 1, t, H), yb_b = make_axis_raw(h0 + 2, t, H);
+      const AxisRaw xa_a = make_axis_raw(w0 - 1, -t, W), xa_b = make_axis_raw(w0, -t, W);
+      const AxisRaw xb_a = make_axis_raw(w0 + 1, t, W), xb_b = make_axis_raw(w0 + 2, t, W);
+      const int rya = fold_axis(ya_a, ya_b, &g_w[0]);
+      const int ryb = fold_axis(yb_a, yb_b, &g_w[4]);
+      const int cxa = fold_axis(xa_a, xa_b, &g_w[8]);
+      const int cxb = fold_axis(xb_a, xb_b, &g_w[12]);
+      g_o[0] = row_off(rya); g_o[1] = row_off(rya + 1);
+      g_o[2] = row_off(ryb); g_o[3] = row_off(ryb + 1);
+      g_o[4] = row_off(Y);
+      g_o[5] = col_off(cxa); g_o[6] = col_off(cxa + 1);
+      g_o[7] = col_off(cxb); g_o[8] = col_off(cxb + 1);
+      g_o[9] = col_off(X);
+    }
+    // ---- gather phase: PPW blocks per step -----------------------------------------------------
+#pragma unroll 1
+    for (int j = 0; j < 64 / PPW; ++j) {
+      const int src = j * PPW + sub;
+      const int blk = bb + src;
+      int o[10];
+      float w[16];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) o[q] = __shfl(g_o[q], src, 64);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) w[q] = __shfl(g_w[q], src, 64);
+      if (bb + j * PPW >= b_end) break;     // wave-uniform
+      float4 acc[2][2] = {{z4, z4}, {z4, z4}};     // [py][px]
+#define CDN_WACC(A, K, TV)                \
+  A.x = fmaf(wk[K][0], TV.x, A.x);        \
+  A.y = fmaf(wk[K][1], TV.y, A.y);        \
+  A.z = fmaf(wk[K][2], TV.z, A.z);        \
+  A.w = fmaf(wk[K][3], TV.w, A.w);
+      // corner tap: row class RC (offset slots o[RO], o[RO+1], weights w[RW..RW+3]),
+      //             col class (o[CO], o[CO+1], w[CW..CW+3])
+#define CDN_TAP4(RO, RW, CO, CW, K)                                                         \
+  {                                                                                         \
+    const float4 v00 = CDN_RD(o[RO] + o[CO]), v01 = CDN_RD(o[RO] + o[CO + 1]);              \
+    const float4 v10 = CDN_RD(o[RO + 1] + o[CO]), v11 = CDN_RD(o[RO + 1] + o[CO + 1]);      \
+    _Pragma("unroll") for (int py = 0; py < 2; ++py)                                        \
+      _Pragma("unroll") for (int px = 0; px < 2; ++px) {                                    \
+        const float a00 = w[RW + 2 * py] * w[CW + 2 * px];                                  \
+        const float a01 = w[RW + 2 * py] * w[CW + 2 * px + 1];                              \
+        const float a10 = w[RW + 2 * py + 1] * w[CW + 2 * px];                              \
+        const float a11 = w[RW + 2 * py + 1] * w[CW + 2 * px + 1];                          \
+        float4 tv;                                                                          \
+        tv.x = ((a00 * v00.x + a01 * v01.x) + a10 * v10.x) + a11 * v11.x;                   \
+        tv.y = ((a00 * v00.y + a01 * v01.y) + a10 * v10.y) + a11 * v11.y;                   \
+        tv.z = ((a00 * v00.z + a01 * v01.z) + a10 * v10.z) + a11 * v11.z;                   \
+        tv.w = ((a00 * v00.w + a01 * v01.w) + a10 * v10.w) + a11 * v11.w;                   \
+        CDN_WACC(acc[py][px], K, tv)                                                        \
+      }                                                                                     \
+  }
+      // vertical edge tap (column exact = X): rows class (o[RO], o[RO+1], w[RW..])
+#define CDN_TAPV(RO, RW, K)                                                                 \
+  {                                                                                         \
+    const float4 v0 = CDN_RD(o[RO] + o[9]), v1 = CDN_RD(o[RO + 1] + o[9]);                  \
+    _Pragma("unroll") for (int py = 0; py < 2; ++py) {                                      \
+      float4 tv;                                                                            \
+      tv.x = w[RW + 2 * py] * v0.x + w[RW + 2 * py + 1] * v1.x;                             \
+      tv.y = w[RW + 2 * py] * v0.y + w[RW + 2 * py + 1] * v1.y;                             \
+      tv.z = w[RW + 2 * py] * v0.z + w[RW + 2 * py + 1] * v1.z;                             \
+      tv.w = w[RW + 2 * py] * v0.w + w[RW + 2 * py + 1] * v1.w;                             \
+      CDN_WACC(acc[py][0], K, tv)                                                           \
+      CDN_WACC(acc[py][1], K, tv)                                                           \
+    }                                                                                       \
+  }
+      // horizontal edge tap (row exact = Y): cols class (o[CO], o[CO+1], w[CW..])
+#define CDN_TAPH(CO, CW, K)                                                                 \
+  {                                                                                         \
+    const float4 v0 = CDN_RD(o[4] + o[CO]), v1 = CDN_RD(o[4] + o[CO + 1]);                  \
+    _Pragma("unroll") for (int px = 0; px < 2; ++px) {                                      \
+      float4 tv;                                                                            \
+      tv.x = w[CW + 2 * px] * v0.x + w[CW + 2 * px + 1] * v1.x;                             \
+      tv.y = w[CW + 2 * px] * v0.y + w[CW + 2 * px + 1] * v1.y;                             \
+      tv.z = w[CW + 2 * px] * v0.z + w[CW + 2 * px + 1] * v1.z;                             \
+      tv.w = w[CW + 2 * px] * v0.w + w[CW + 2 * px + 1] * v1.w;                             \
+      CDN_WACC(acc[0][px], K, tv)                                                           \
+      CDN_WACC(acc[1][px], K, tv)                                                           \
+    }                                                                                       \
+  }
+      CDN_TAP4(0, 0, 5, 8, 0)      // (ya, xa)
+      CDN_TAPV(0, 0, 1)            // (ya, w)
+      CDN_TAP4(0, 0, 7, 12, 2)     // (ya, xb)
+      CDN_TAPH(5, 8, 3)            // (h, xa)
+      {
+        const float4 vc = CDN_RD(o[4] + o[9]);
+        CDN_WACC(acc[0][0], 4, vc)
+        CDN_WACC(acc[0][1], 4, vc)
+        CDN_WACC(acc[1][0], 4, vc)
+        CDN_WACC(acc[1][1], 4, vc)
+      }
+      CDN_TAPH(7, 12, 5)           // (h, xb)
+      CDN_TAP4(2, 4, 5, 8, 6)      // (yb, xa)
+      CDN_TAPV(2, 4, 7)            // (yb, w)
+      CDN_TAP4(2, 4, 7, 12, 8)     // (yb, xb)
+#undef CDN_TAP4
+#undef CDN_TAPV
+#undef CDN_TAPH
+#undef CDN_WACC
+      if (blk < b_end) {
+        const int Y = blk / Wl, X = blk - Y * Wl;
+        const int cbase = c0 + cq * 4;
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const float4 a = acc[py][px];
+            float *dp = d + ((long)n * HW + (long)(2 * Y + py) * W + 2 * X + px) * C + cbase;
+            if (vec_store && cbase + 3 < C) {
+              *reinterpret_cast<float4 *>(dp) = a;
+              mn = fminf(mn, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+              mx = fmaxf(mx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+            } else {
+              const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (cbase + e < C) {
+                  dp[e] = av[e];
+                  mn = fminf(mn, av[e]);
+                  mx = fmaxf(mx, av[e]);
+                }
+            }
+          }
+      }
+    }
+  }
+#undef CDN_RD
+  if (dmm)
+    cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, red);
+}
+
+// ------------------------------------------------------------------------------------------
 // pw2: R[m][co] = act( sum_c Aq[m][c] * Wp[co][c] + ... ),  m = n*HW + p  (channels-last both
 // sides, the batch folds into M).  f32 MFMA 32x32x2 (exact f32).  A is optionally
 // fake-quantised while it is staged.  Tile 128 (m) x BN (co) x 16 (k); 4 waves stacked in m,
@@ -820,7 +1087,21 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
     kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up);              \
   }
   const bool XQ = xq != nullptr, SQ = sq != nullptr;
-  if (nhwc) {
+  const bool blocks = nhwc && up == 1 && !getenv("CDN_DW_NO_BLOCKS");
+  if (blocks) {   // 2x2-block kernel for up-sampled inputs
+#define CDN_GOU(XQ_, SQ_)                                                                     \
+  {                                                                                           \
+    auto kern = dw2u_kernel<CCH, XQ_, SQ_>;                                                   \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                      \
+    kern<<<grid, 512, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W);                  \
+  }
+    if (XQ && SQ) CDN_GOU(true, true)
+    else if (XQ) CDN_GOU(true, false)
+    else if (SQ) CDN_GOU(false, true)
+    else CDN_GOU(false, false)
+#undef CDN_GOU
+  } else if (nhwc) {
     if (XQ && SQ) CDN_GO(true, true, true)
     else if (XQ) CDN_GO(true, true, false)
     else if (SQ) CDN_GO(true, false, true)
