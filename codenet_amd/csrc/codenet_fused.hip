@@ -434,7 +434,7 @@ __device__ __forceinline__ int fold_axis(const AxisRaw &a, const AxisRaw &b, flo
 }
 
 template <int CCH, bool XQ, bool SQ>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512)   // ~250 VGPRs: 2 waves/SIMD (168 spills and is 2.5x slower)
 dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
