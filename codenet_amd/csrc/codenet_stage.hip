@@ -16,6 +16,8 @@
 //   pointwise_kernel  Y[n] = Wp . D[n] on v_mfma_f32_32x32x2_f32 (exact f32), LDS-tiled.
 #include "cdn_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -309,6 +311,173 @@ dw_bwd_kernel(const float *__restrict__ x, const float *__restrict__ s,
 }
 
 // ------------------------------------------------------------------------------------------
+// dw_bwd2_kernel: backward of the gather/depthwise with lanes <-> channels (the mapping of the
+// fused forward kernel, codenet_fused.hip): workgroup = (n, CCH channels, whole plane).
+//   * x and the grad_x accumulator live in LDS as [(H+1)(W+1) cells][CCH] with a zero row / zero
+//     column that absorbs every out-of-image corner; a corner is one ds_read_b32 / ds_add_f32 per
+//     lane and consecutive lanes are consecutive channels -> bank-conflict free for CCH >= 32;
+//   * grad_w accumulates in lane-private registers over all pixels (a lane IS a channel): no
+//     per-element cross-lane reduction, one LDS add per lane at the end;
+//   * grad_s is reduced over the CCH lanes of a pixel with xor shuffles, one global atomic per
+//     (pixel, channel chunk).
+// CCH is the largest of {64,32,16,8,4} whose two images fit the 160 KiB LDS.
+// ------------------------------------------------------------------------------------------
+template <int CCH>
+__global__ void __launch_bounds__(512)
+dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
+               const float *__restrict__ wd, const float *__restrict__ gd, float *__restrict__ gx,
+               float *__restrict__ gs, float *__restrict__ gw, int C, int H, int W) {
+  extern __shared__ float smem[];
+  constexpr int PPW = 64 / CCH;                  // pixels per wave step
+  const int nthreads = blockDim.x, nwaves = nthreads / 64;
+  const int HW = H * W, Wc = W + 1;
+  const int cells = (H + 1) * Wc;
+  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  const int tid = threadIdx.x;
+  float *ximg = smem;                            // [cells][CCH]
+  float *gimg = smem + (size_t)cells * CCH;      // [cells][CCH]
+  float *gwl = gimg + (size_t)cells * CCH;       // [CCH][9]
+  for (int q = tid; q < cells * CCH; q += nthreads) {
+    ximg[q] = 0.0f;
+    gimg[q] = 0.0f;
+  }
+  for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
+  __syncthreads();
+  {   // stage x: lane <-> channel, 4 pixels per thread, conflict-free scalar LDS stores
+    const int quads = (HW + 3) >> 2;
+    for (int q = tid; q < quads * CCH; q += nthreads) {
+      const int cl = q % CCH, j = q / CCH;
+      if (c0 + cl < C) {
+        const float *xp = x + ((long)n * C + c0 + cl) * HW + j * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pix = j * 4 + e;
+          if (pix < HW) ximg[((pix / W) * Wc + (pix % W)) * CCH + cl] = xp[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cl = lane % CCH, sub = lane / CCH;
+  const bool ch_ok = c0 + cl < C;
+  float wk[9], gwa[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    wk[k] = ch_ok ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;
+    gwa[k] = 0.0f;
+  }
+  auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? yy : H) * Wc * CCH; };
+  auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH + cl; };
+
+  for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) {
+    const int p = p0 + sub;
+    const bool live = p < HW;
+    const int pp = live ? p : 0;
+    const int h = pp / W, w = pp - h * W;
+    const float t = s[(long)n * HW + pp] - 1.0f;
+    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    Axis ym, xm;
+    ym.i0 = h; ym.w0 = 1.0f; ym.w1 = 0.0f; ym.ok = true;
+    xm.i0 = w; xm.w0 = 1.0f; xm.w1 = 0.0f; xm.ok = true;
+    const float g = (live && ch_ok) ? gd[((long)n * C + c0 + cl) * HW + pp] : 0.0f;
+    float gs_acc = 0.0f;
+    auto tap = [&](const Axis &Y, const Axis &X, float ay, float ax, int k) {
+      const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1);
+      const int q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
+      const float v00 = ximg[r0 + q0], v01 = ximg[r0 + q1], v10 = ximg[r1 + q0], v11 = ximg[r1 + q1];
+      const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1, w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;
+      const float S = (w00 * v00 + w01 * v01) + w10 * v10 + w11 * v11;
+      const float gk = g * wk[k];
+      if (gx != nullptr) {
+        atomicAdd(&gimg[r0 + q0], w00 * gk);
+        atomicAdd(&gimg[r0 + q1], w01 * gk);
+        atomicAdd(&gimg[r1 + q0], w10 * gk);
+        atomicAdd(&gimg[r1 + q1], w11 * gk);
+      }
+      const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
+      const float dSdy = X.w0 * (v10 - v00) + X.w1 * (v11 - v01);
+      const float dSdx = Y.w0 * (v01 - v00) + Y.w1 * (v11 - v10);
+      gs_acc += okf * gk * (ay * dSdy + ax * dSdx);
+      gwa[k] = fmaf(g, S, gwa[k]);
+    };
+    // edge / centre taps touch only the cells with non-zero weight
+    auto tap_v = [&](const Axis &Y, float ay, int k) {     // column exact
+      const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1), q0 = col_off(w);
+      const float v0 = ximg[r0 + q0], v1 = ximg[r1 + q0];
+      const float gk = g * wk[k];
+      if (gx != nullptr) {
+        atomicAdd(&gimg[r0 + q0], Y.w0 * gk);
+        atomicAdd(&gimg[r1 + q0], Y.w1 * gk);
+      }
+      gs_acc += (Y.ok ? 1.0f : 0.0f) * gk * ay * (v1 - v0);
+      gwa[k] = fmaf(g, Y.w0 * v0 + Y.w1 * v1, gwa[k]);
+    };
+    auto tap_h = [&](const Axis &X, float ax, int k) {     // row exact
+      const int r0 = row_off(h), q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
+      const float v0 = ximg[r0 + q0], v1 = ximg[r0 + q1];
+      const float gk = g * wk[k];
+      if (gx != nullptr) {
+        atomicAdd(&gimg[r0 + q0], X.w0 * gk);
+        atomicAdd(&gimg[r0 + q1], X.w1 * gk);
+      }
+      gs_acc += (X.ok ? 1.0f : 0.0f) * gk * ax * (v1 - v0);
+      gwa[k] = fmaf(g, X.w0 * v0 + X.w1 * v1, gwa[k]);
+    };
+    tap(ya, xa, -1.f, -1.f, 0);
+    tap_v(ya, -1.f, 1);
+    tap(ya, xb, -1.f, 1.f, 2);
+    tap_h(xa, -1.f, 3);
+    {
+      const int o = row_off(h) + col_off(w);
+      const float gk = g * wk[4];
+      if (gx != nullptr) atomicAdd(&gimg[o], gk);
+      gwa[4] = fmaf(g, ximg[o], gwa[4]);
+    }
+    tap_h(xb, 1.f, 5);
+    tap(yb, xa, 1.f, -1.f, 6);
+    tap_v(yb, 1.f, 7);
+    tap(yb, xb, 1.f, 1.f, 8);
+    if (gs != nullptr) {
+#pragma unroll
+      for (int m = CCH / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
+      if (cl == 0 && live) atomicAdd(&gs[(long)n * HW + p], gs_acc);
+    }
+  }
+  if (gw != nullptr && ch_ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);
+  }
+  __syncthreads();
+  if (gx != nullptr) {
+    const int quads = (HW + 3) >> 2;
+    const bool vec = (HW & 3) == 0;
+    for (int q = tid; q < quads * CCH; q += nthreads) {
+      const int c = q % CCH, j = q / CCH;
+      if (c0 + c >= C) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pix = min(j * 4 + e, HW - 1);
+        v[e] = gimg[((pix / W) * Wc + (pix % W)) * CCH + c];
+      }
+      float *gp = gx + ((long)n * C + c0 + c) * HW + j * 4;
+      if (vec) {
+        *reinterpret_cast<float4 *>(gp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (j * 4 + e < HW) gp[e] = v[e];
+      }
+    }
+  }
+  if (gw != nullptr)
+    for (int q = tid; q < CCH * 9; q += nthreads)
+      if (c0 + q / 9 < C) atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+}
+
+// ------------------------------------------------------------------------------------------
 // pointwise_kernel: Y[n] (Co x HW) = Wp (Co x C) . D[n] (C x HW) on v_mfma_f32_32x32x2_f32.
 // Workgroup tile 64 (co) x 64 (pixels), 4 waves, each owning one 32x32 accumulator tile;
 // K tiles of 16 staged through LDS as As[k][m] / Bs[k][n] so both operand reads are
@@ -443,6 +612,42 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   CDN_REQUIRE(x && s && w_dw && grad_d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  hipStream_t st = cdn::as_stream(stream);
+  if (grad_s) {
+    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)(N * H * W), st);
+    if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
+  }
+  // lanes <-> channels kernel: the largest channel chunk whose two LDS images fit
+  const size_t cells = (size_t)(H + 1) * (W + 1);
+  const size_t lds_max = 160 * 1024 - 512;
+  int cch = 0;
+  for (int c : {64, 32, 16, 8, 4})
+    if ((2 * cells * c + (size_t)c * 9) * sizeof(float) <= lds_max) {
+      cch = c;
+      break;
+    }
+  if (cch != 0 && !getenv("CDN_BWD_OLD")) {
+    const size_t lds = (2 * cells * cch + (size_t)cch * 9) * sizeof(float);
+    dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
+#define CDN_BWD(CCH_)                                                                          \
+  {                                                                                            \
+    auto kern = dw_bwd2_kernel<CCH_>;                                                          \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                              (int)lds);                                                       \
+    kern<<<grid, 512, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H,   \
+                                 (int)W);                                                      \
+  }
+    switch (cch) {
+      case 64: CDN_BWD(64) break;
+      case 32: CDN_BWD(32) break;
+      case 16: CDN_BWD(16) break;
+      case 8: CDN_BWD(8) break;
+      default: CDN_BWD(4) break;
+    }
+#undef CDN_BWD
+    return cdn::check_launch("codenet dw backward");
+  }
+  // fallback for very large planes: lanes <-> pixels kernel with bordered planes
   const int pstride = (int)((H + 2) * (W + 2));
   const int budget = 150 * 1024 / 4;  // floats of LDS per workgroup
   int CC = (budget - 64) / (2 * pstride + 18);
@@ -451,11 +656,6 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
               (long long)H, (long long)W);
   if (CC > 16) CC = 16;
   if (CC > C) CC = (int)C;
-  hipStream_t st = cdn::as_stream(stream);
-  if (grad_s) {
-    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)(N * H * W), st);
-    if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
-  }
   const size_t lds = (size_t)(2 * ((CC * 9 + 3) & ~3) + 2 * CC * pstride) * sizeof(float);
   dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
   (void)hipFuncSetAttribute((const void *)dw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
