@@ -313,36 +313,74 @@ dw_bwd_kernel(const float *__restrict__ x, const float *__restrict__ s,
 // ------------------------------------------------------------------------------------------
 // dw_bwd2_kernel: backward of the gather/depthwise with lanes <-> channels (the mapping of the
 // fused forward kernel, codenet_fused.hip): workgroup = (n, CCH channels, whole plane).
-//   * x and the grad_x accumulator live in LDS as [(H+1)(W+1) cells][CCH] with a zero row / zero
-//     column that absorbs every out-of-image corner; a corner is one ds_read_b32 / ds_add_f32 per
-//     lane and consecutive lanes are consecutive channels -> bank-conflict free for CCH >= 32;
+//   * x (fp32) and the grad_x accumulator live in LDS as [(H+1)(W+1) cells][CCH] with a zero row /
+//     zero column that absorbs every out-of-image corner;
+//   * grad_x is scattered with INTEGER LDS atomics on 64-bit fixed point: on gfx950 ds_add_f32
+//     sustains only 0.33 lane-ops/clk/CU against 9.1 for ds_add_u64 and 13.2 for ds_add_u32
+//     (tools/probes/probe_lds_atomics.hip), and the float version of this kernel spent 88 % of
+//     its time in them.  Contributions are scaled by 2^S with S chosen per workgroup from
+//     max|grad_d| * max|w| so that the largest one is ~2^40 (>= 2^22 adds of headroom, resolution
+//     2^-40 of the workgroup maximum -- finer than fp32), summed exactly and converted back once:
+//     the sum is order-independent, so grad_x is bitwise reproducible (the reference's float
+//     atomics, _kernel.cu:329, are not);
 //   * grad_w accumulates in lane-private registers over all pixels (a lane IS a channel): no
 //     per-element cross-lane reduction, one LDS add per lane at the end;
 //   * grad_s is reduced over the CCH lanes of a pixel with xor shuffles, one global atomic per
 //     (pixel, channel chunk).
-// CCH is the largest of {64,32,16,8,4} whose two images fit the 160 KiB LDS.
+// CCH is the largest of {32,16,8,4,2} whose images (4 + 8 bytes per cell and channel) fit LDS.
 // ------------------------------------------------------------------------------------------
 template <int CCH>
 __global__ void __launch_bounds__(512)
 dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
                const float *__restrict__ wd, const float *__restrict__ gd, float *__restrict__ gx,
                float *__restrict__ gs, float *__restrict__ gw, int C, int H, int W) {
-  extern __shared__ float smem[];
+  extern __shared__ unsigned long long smem64[];
   constexpr int PPW = 64 / CCH;                  // pixels per wave step
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
   const int HW = H * W, Wc = W + 1;
   const int cells = (H + 1) * Wc;
   const int n = blockIdx.y, c0 = blockIdx.x * CCH;
   const int tid = threadIdx.x;
-  float *ximg = smem;                            // [cells][CCH]
-  float *gimg = smem + (size_t)cells * CCH;      // [cells][CCH]
-  float *gwl = gimg + (size_t)cells * CCH;       // [CCH][9]
+  unsigned long long *gimg = smem64;                                   // [cells][CCH] fixed point
+  float *ximg = reinterpret_cast<float *>(smem64 + (size_t)cells * CCH);  // [cells][CCH]
+  float *gwl = ximg + (size_t)cells * CCH;                             // [CCH][9]
+  float *red = gwl + CCH * 9;                                          // [nwaves + 1]
   for (int q = tid; q < cells * CCH; q += nthreads) {
     ximg[q] = 0.0f;
-    gimg[q] = 0.0f;
+    gimg[q] = 0ull;
   }
   for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
-  __syncthreads();
+  // ---- fixed-point scale of this workgroup: max |grad_d| over its slice, max |w| over its chunk --
+  float gmax = 0.0f;
+  {
+    const int cc = min(CCH, C - c0);
+    const float *gp = gd + ((long)n * C + c0) * HW;
+    for (int q = tid; q < cc * HW; q += nthreads) gmax = fmaxf(gmax, fabsf(gp[q]));
+    float wmax = 0.0f;
+    for (int q = tid; q < cc * 9; q += nthreads) wmax = fmaxf(wmax, fabsf(wd[(long)c0 * 9 + q]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
+      wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64));
+    }
+    __syncthreads();   // (also orders the zero fill above)
+    if ((tid & 63) == 0) {
+      red[2 * (tid >> 6)] = gmax;
+      red[2 * (tid >> 6) + 1] = wmax;
+    }
+    __syncthreads();
+    gmax = 0.0f;
+    wmax = 0.0f;
+    for (int i = 0; i < nwaves; ++i) {
+      gmax = fmaxf(gmax, red[2 * i]);
+      wmax = fmaxf(wmax, red[2 * i + 1]);
+    }
+    gmax *= wmax;      // bound of |bilinear weight * g * w|
+  }
+  int e = 0;
+  (void)frexpf(gmax, &e);                 // gmax < 2^e
+  if (!(gmax > 0.0f) || !(gmax < INFINITY)) e = 0;
+  const float scale = ldexpf(1.0f, 40 - e), inv_scale = ldexpf(1.0f, e - 40);
   {   // stage x: lane <-> channel, 4 pixels per thread, conflict-free scalar LDS stores
     const int quads = (HW + 3) >> 2;
     for (int q = tid; q < quads * CCH; q += nthreads) {
@@ -350,14 +388,17 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
       if (c0 + cl < C) {
         const float *xp = x + ((long)n * C + c0 + cl) * HW + j * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int pix = j * 4 + e;
-          if (pix < HW) ximg[((pix / W) * Wc + (pix % W)) * CCH + cl] = xp[e];
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int pix = j * 4 + e4;
+          if (pix < HW) ximg[((pix / W) * Wc + (pix % W)) * CCH + cl] = xp[e4];
         }
       }
     }
   }
   __syncthreads();
+#if defined(CDN_DIAG) && CDN_DIAG == 3   // diagnostic build: no LDS atomics (wrong grad_x)
+  float *gx_ = gx; gx = nullptr;
+#endif
   const int lane = tid & 63, wave = tid >> 6;
   const int cl = lane % CCH, sub = lane / CCH;
   const bool ch_ok = c0 + cl < C;
@@ -369,6 +410,9 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   }
   auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? yy : H) * Wc * CCH; };
   auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH + cl; };
+  auto scatter = [&](int o, float c) {
+    atomicAdd(&gimg[o], (unsigned long long)__float2ll_rn(c * scale));
+  };
 
   for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) {
     const int p = p0 + sub;
@@ -378,9 +422,6 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     const float t = s[(long)n * HW + pp] - 1.0f;
     const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
     const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
-    Axis ym, xm;
-    ym.i0 = h; ym.w0 = 1.0f; ym.w1 = 0.0f; ym.ok = true;
-    xm.i0 = w; xm.w0 = 1.0f; xm.w1 = 0.0f; xm.ok = true;
     const float g = (live && ch_ok) ? gd[((long)n * C + c0 + cl) * HW + pp] : 0.0f;
     float gs_acc = 0.0f;
     auto tap = [&](const Axis &Y, const Axis &X, float ay, float ax, int k) {
@@ -391,10 +432,10 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
       const float S = (w00 * v00 + w01 * v01) + w10 * v10 + w11 * v11;
       const float gk = g * wk[k];
       if (gx != nullptr) {
-        atomicAdd(&gimg[r0 + q0], w00 * gk);
-        atomicAdd(&gimg[r0 + q1], w01 * gk);
-        atomicAdd(&gimg[r1 + q0], w10 * gk);
-        atomicAdd(&gimg[r1 + q1], w11 * gk);
+        scatter(r0 + q0, w00 * gk);
+        scatter(r0 + q1, w01 * gk);
+        scatter(r1 + q0, w10 * gk);
+        scatter(r1 + q1, w11 * gk);
       }
       const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
       const float dSdy = X.w0 * (v10 - v00) + X.w1 * (v11 - v01);
@@ -408,8 +449,8 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
       const float v0 = ximg[r0 + q0], v1 = ximg[r1 + q0];
       const float gk = g * wk[k];
       if (gx != nullptr) {
-        atomicAdd(&gimg[r0 + q0], Y.w0 * gk);
-        atomicAdd(&gimg[r1 + q0], Y.w1 * gk);
+        scatter(r0 + q0, Y.w0 * gk);
+        scatter(r1 + q0, Y.w1 * gk);
       }
       gs_acc += (Y.ok ? 1.0f : 0.0f) * gk * ay * (v1 - v0);
       gwa[k] = fmaf(g, Y.w0 * v0 + Y.w1 * v1, gwa[k]);
@@ -419,8 +460,8 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
       const float v0 = ximg[r0 + q0], v1 = ximg[r0 + q1];
       const float gk = g * wk[k];
       if (gx != nullptr) {
-        atomicAdd(&gimg[r0 + q0], X.w0 * gk);
-        atomicAdd(&gimg[r0 + q1], X.w1 * gk);
+        scatter(r0 + q0, X.w0 * gk);
+        scatter(r0 + q1, X.w1 * gk);
       }
       gs_acc += (X.ok ? 1.0f : 0.0f) * gk * ax * (v1 - v0);
       gwa[k] = fmaf(g, X.w0 * v0 + X.w1 * v1, gwa[k]);
@@ -431,8 +472,7 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     tap_h(xa, -1.f, 3);
     {
       const int o = row_off(h) + col_off(w);
-      const float gk = g * wk[4];
-      if (gx != nullptr) atomicAdd(&gimg[o], gk);
+      if (gx != nullptr) scatter(o, g * wk[4]);
       gwa[4] = fmaf(g, ximg[o], gwa[4]);
     }
     tap_h(xb, 1.f, 5);
@@ -447,8 +487,11 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   }
   if (gw != nullptr && ch_ok) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);
+    for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);   // 9 per lane, once
   }
+#if defined(CDN_DIAG) && CDN_DIAG == 3
+  gx = gx_;
+#endif
   __syncthreads();
   if (gx != nullptr) {
     const int quads = (HW + 3) >> 2;
@@ -458,17 +501,17 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
       if (c0 + c >= C) continue;
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pix = min(j * 4 + e, HW - 1);
-        v[e] = gimg[((pix / W) * Wc + (pix % W)) * CCH + c];
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int pix = min(j * 4 + e4, HW - 1);
+        v[e4] = __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
       }
       float *gp = gx + ((long)n * C + c0 + c) * HW + j * 4;
       if (vec) {
         *reinterpret_cast<float4 *>(gp) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (j * 4 + e < HW) gp[e] = v[e];
+        for (int e4 = 0; e4 < 4; ++e4)
+          if (j * 4 + e4 < HW) gp[e4] = v[e4];
       }
     }
   }
@@ -621,13 +664,14 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   const size_t cells = (size_t)(H + 1) * (W + 1);
   const size_t lds_max = 160 * 1024 - 512;
   int cch = 0;
-  for (int c : {64, 32, 16, 8, 4})
-    if ((2 * cells * c + (size_t)c * 9) * sizeof(float) <= lds_max) {
+  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 128; };
+  for (int c : {32, 16, 8, 4, 2})
+    if (bwd_lds(c) <= lds_max) {
       cch = c;
       break;
     }
   if (cch != 0 && !getenv("CDN_BWD_OLD")) {
-    const size_t lds = (2 * cells * cch + (size_t)cch * 9) * sizeof(float);
+    const size_t lds = bwd_lds(cch);
     dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
 #define CDN_BWD(CCH_)                                                                          \
   {                                                                                            \
@@ -638,11 +682,11 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
                                  (int)W);                                                      \
   }
     switch (cch) {
-      case 64: CDN_BWD(64) break;
       case 32: CDN_BWD(32) break;
       case 16: CDN_BWD(16) break;
       case 8: CDN_BWD(8) break;
-      default: CDN_BWD(4) break;
+      case 4: CDN_BWD(4) break;
+      default: CDN_BWD(2) break;
     }
 #undef CDN_BWD
     return cdn::check_launch("codenet dw backward");
