@@ -492,3 +492,21 @@ def test_int8_pointwise_equals_f32_pointwise_incl_codes_outside_int8(shrink):
     diff = (y_f32 - y_i8).abs()
     assert diff.max().item() <= 1.05 * lsb + 1e-4          # at most one output code apart
     assert (diff > 1e-4).float().mean().item() < 2e-3       # and only on a handful of elements
+
+
+def test_codenet_dw_backward_grad_x_is_bitwise_reproducible():
+    """grad_x is accumulated with exact integer (fixed-point) LDS atomics, so -- unlike the
+    reference's float atomicAdd (_kernel.cu:329) -- it does not depend on the arrival order."""
+    from codenet_amd import ops
+    N, C, H, W = 2, 64, 32, 32
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    s = torch.empty(N, 1, H, W).uniform_(-7, 8, generator=g).cuda()
+    w = (torch.randn(C, 1, 3, 3, generator=g) / 3).cuda()
+    go = torch.randn(N, C, H, W, generator=g).cuda()
+    outs = []
+    for _ in range(3):
+        xg = x.clone().requires_grad_(True)
+        ops.codenet_dw(xg, s, w).backward(go)
+        outs.append(xg.grad.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
