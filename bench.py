@@ -226,7 +226,7 @@ def main():
             ach = nbytes / (per_kernel[dominant] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": ({"dw": "dw2_kernel", "scale": "scale_*_kernel", "unpack": "unpack_kernel"}
+                    "kernel": ({"dw": "dw2_kernel+dw2u_kernel", "scale": "scale_*_kernel", "unpack": "unpack_kernel"}
                                if fused is not None else
                                {"dw": "dw_kernel", "scale": "scale_kernel",
                                 "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}
