@@ -132,7 +132,8 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
   if (have_stats && u.bits == 8) {
     const float a0 = quant_code(bmin, scale, zp) + (zp - 128.0f);
     const float a1 = quant_code(bmax, scale, zp) + (zp - 128.0f);
-    wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1)) ? 1u : 0u;
+    wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1) ||
+            !(fabsf(zp) < 4.0e6f)) ? 1u : 0u;   // (the int8 kernels do integer arithmetic on zp)
   }
   u.state[6] = wide;
 }

@@ -24,6 +24,39 @@
 #include <algorithm>
 #include <cstdlib>
 
+// In-kernel phase stamps for tools/probes/probe_dw.hip (which includes this file with
+// -DCDN_STAMPS): thread 0 of every workgroup records s_memrealtime (100 MHz) at phase boundaries.
+#ifdef CDN_STAMPS
+// regions: 0 scale, 1 gather, 2 pointwise; 2048 workgroups x 8 stamps each
+__device__ unsigned long long cdn_stamps[3 * 2048 * 8 + 64];   // + per-wave gather end times of workgroup 0
+#define CDN_STAMPR(R, I)                                                                 \
+  do {                                                                                   \
+    if (threadIdx.x == 0)                                                                \
+      cdn_stamps[(R) * 16384 + (((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 8 + (I))] = \
+          __builtin_amdgcn_s_memrealtime();                                              \
+  } while (0)
+extern "C" int cdn_debug_read_stamps(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(cdn_stamps), sizeof(unsigned long long) * (3 * 2048 * 8 + 64));
+}
+extern "C" int cdn_debug_clear_stamps(void) {
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(cdn_stamps)) != hipSuccess) return 1;
+  return (int)hipMemset(p, 0, sizeof(unsigned long long) * (3 * 2048 * 8 + 64));
+}
+#else
+#define CDN_STAMPR(R, I) do { } while (0)
+#endif
+#ifdef CDN_STAMPS
+#define CDN_STAMP_WAVE()                                                                   \
+  do {                                                                                     \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0)                     \
+      cdn_stamps[3 * 16384 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();       \
+  } while (0)
+#else
+#define CDN_STAMP_WAVE() do { } while (0)
+#endif
+#define CDN_STAMP(I) CDN_STAMPR(1, I)
+
 namespace {
 
 using cdn::fake_quant;
@@ -62,6 +95,7 @@ __global__ void __launch_bounds__(kScaleWaves * 64)
 scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
                   const float *__restrict__ b, float *__restrict__ s, float2 *mm, cdn::QUpdate qu,
                   int C, int HW, float lo, float hi) {
+  CDN_STAMPR(0, 0);
   // 16 waves x 64 pixels: wave v reduces channels v, v+16, ... with 4 loads in flight per lane
   // (~16 KB of 256-byte rows in flight per workgroup) -- the HBM-bound C -> 1 reduction.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,9 +130,11 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
       mn = mx = v;
     }
   }
+  CDN_STAMPR(0, 2);
   if (mm)
     cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, &red[0][0]);
+  CDN_STAMPR(0, 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -111,6 +147,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                   const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ s,
                   float2 *mm, cdn::QUpdate qu, int C, long npix, float lo, float hi) {
   __shared__ float red[12];
+  CDN_STAMPR(0, 0);
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
@@ -145,6 +182,77 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
   }
+  CDN_STAMPR(0, 2);
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  CDN_STAMPR(0, 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// scale, channels-last input, C <= 256: one workgroup = 64 consecutive pixels.  Phase 1 streams the
+// tile's 64*C floats as fully coalesced 16-byte loads, ALL of a thread's loads (C/16 <= 16) in flight
+// before the first use; each is fake-quantised, dotted with its 4 weights and parked in LDS
+// part[pixel][C/4].  Phase 2: 4 threads per pixel sum the partials (conflict-free: row stride
+// = 4 mod 32 banks).  Used for large planes only (see the launch site).
+// ------------------------------------------------------------------------------------------
+constexpr int kScaleTilePix = 64;
+template <bool XQ>
+__global__ void __launch_bounds__(256)
+scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+                       const float *__restrict__ w, const float *__restrict__ b,
+                       float *__restrict__ s, float2 *mm, cdn::QUpdate qu, int C, long npix,
+                       float lo, float hi) {
+  extern __shared__ float part[];     // [64][LD], then 16 floats of reduction scratch
+  CDN_STAMPR(0, 0);
+  const int CQ = C >> 2;
+  const int LD = ((CQ + 31) & ~31) + 4;
+  float *red = part + kScaleTilePix * LD;
+  const long pix0 = (long)blockIdx.x * kScaleTilePix;
+  const int tile_pix = (int)min((long)kScaleTilePix, npix - pix0);
+  const int total = tile_pix * CQ;    // float4 items of this tile
+  float qs = 1.f, qz = 0.f;
+  if (XQ) {
+    qs = reinterpret_cast<const float *>(xq)[2];
+    qz = reinterpret_cast<const float *>(xq)[3];
+  }
+  const float4 *xt = reinterpret_cast<const float4 *>(x + pix0 * C);
+  const float4 *w4 = reinterpret_cast<const float4 *>(w);
+  constexpr int U = 16;               // 64 * 64 / 256: every load of a C = 256 tile in flight
+  float4 v[U];
+#pragma unroll
+  for (int i = 0; i < U; ++i) {
+    const int q = threadIdx.x + 256 * i;
+    v[i] = q < total ? xt[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < U; ++i) {
+    const int q = threadIdx.x + 256 * i;
+    if (q < total) {
+      const int pix = q / CQ, cq = q - pix * CQ;
+      const float4 ww = w4[cq];
+      float4 t = v[i];
+      if (XQ) {
+        t.x = fake_quant(t.x, qs, qz);
+        t.y = fake_quant(t.y, qs, qz);
+        t.z = fake_quant(t.z, qs, qz);
+        t.w = fake_quant(t.w, qs, qz);
+      }
+      part[pix * LD + cq] = fmaf(ww.w, t.w, fmaf(ww.z, t.z, fmaf(ww.y, t.y, ww.x * t.x)));
+    }
+  }
+  __syncthreads();
+  const int pix = threadIdx.x >> 2, k = threadIdx.x & 3;
+  float acc = 0.f;
+  if (pix < tile_pix)
+    for (int i = k; i < CQ; i += 4) acc += part[pix * LD + i];
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  float mn = INFINITY, mx = -INFINITY;
+  if (pix < tile_pix) {
+    float r = acc + (b ? b[0] : 0.0f);
+    r = fminf(fmaxf(r, lo), hi);
+    if (k == 0) s[pix0 + pix] = r;
+    mn = mx = r;
+  }
   if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
 }
 
@@ -155,97 +263,73 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
+// Cross-lane fetch of a tap-geometry record WITHOUT the LDS pipeline: v_mov_b32 dpp row_newbcast:J
+// copies the value held by lane J of each 16-lane row to every lane of that row (VALU only; the
+// compiler folds single-use movs into the consuming instruction's DPP operand).  ds_bpermute costs
+// ~8 LDS-pipeline cycles per instruction: with 18 (dw2) / 26 (dw2u) of them next to 25 ds_read_b128
+// (4 cycles each) per step the gather was LDS-issue bound on the bpermutes (in-kernel stamps,
+// tools/probes/probe_dw.hip).  The DPP control is an immediate, so the step index is dispatched
+// through a (wave-uniform) switch; HALVES: the two 8-lane halves of a row fetch different lanes
+// (J and 8 + J) with complementary bank masks.
+template <int J, bool HALVES>
+__device__ __forceinline__ int row_fetch(int v) {
+  // (mov_dpp: no defined "old" value, so no zero-initialising v_mov per fetch)
+  if (HALVES) {
+    const int a = __builtin_amdgcn_mov_dpp(v, 0x150 + J, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(a, v, 0x150 + 8 + J, 0xf, 0xc, false);
+  }
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + J, 0xf, 0xf, false);
+}
+template <bool HALVES, int NI, int NF>
+__device__ __forceinline__ void fetch_record(int j, const int (&gi)[NI], const float (&gf)[NF],
+                                             int (&oi)[NI], float (&of)[NF]) {
+#define CDN_CASE(J)                                                                          \
+  case J: {                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NI; ++q) oi[q] = row_fetch<J, HALVES>(gi[q]);       \
+    _Pragma("unroll") for (int q = 0; q < NF; ++q)                                           \
+        of[q] = __int_as_float(row_fetch<J, HALVES>(__float_as_int(gf[q])));                 \
+  } break;
+  if (HALVES) {
+    switch (j) { CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) CDN_CASE(4) CDN_CASE(5) CDN_CASE(6) CDN_CASE(7) }
+  } else {
+    switch (j) {
+      CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) CDN_CASE(4) CDN_CASE(5) CDN_CASE(6) CDN_CASE(7)
+      CDN_CASE(8) CDN_CASE(9) CDN_CASE(10) CDN_CASE(11) CDN_CASE(12) CDN_CASE(13) CDN_CASE(14) CDN_CASE(15)
+    }
+  }
+#undef CDN_CASE
+}
+// lane -> owned item of a 64-item batch such that the record of (step j, group g) sits in the DPP row
+// of the lanes that consume it: row lane j (16 lanes per item) or half-row lane j (8 lanes per item)
+template <int LPP>
+__device__ __forceinline__ int owner_item(int lane) {
+  return LPP == 16 ? (lane & 15) * 4 + (lane >> 4)
+                   : (lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1));
+}
+#ifndef CDN_DPP16
+#define CDN_DPP16 1      // DPP fetch when an item spans a whole 16-lane row (CCH = 64)
+#endif
+#ifndef CDN_DPP8
+#define CDN_DPP8 0       // DPP fetch for 8-lane items (CCH = 32): two movs per value
+#endif
+template <int LPP>
+constexpr bool use_dpp() { return (LPP == 16 && CDN_DPP16) || (LPP == 8 && CDN_DPP8); }
+
 constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (512 or 1024)
 
-template <int CCH, bool NHWC_IN, bool XQ, bool SQ>
-__global__ void __launch_bounds__(kDw2MaxThreads)
-dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
-           const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
-           const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
-           int C, int H, int W, int up) {
-  // LDS: [(Hl+1)*(Wl+1)][CCH] image cells; row Hl and column Wl are ZERO and every out-of-image
-  // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
-  // cell address is just row offset + column offset, no bounds test and no clamp per corner.
-  // Then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
-  extern __shared__ float4 img[];
+// The gather + depthwise of one staged plane (shared by dw2_kernel and the persistent dw2p_kernel):
+// img = [(Hl+1)*(Wl+1)][CCH] cells with the zero row / column, wl = [CCH][9] weights, sl = scale plane.
+template <int CCH, int DEEP>
+__device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, const float *sl,
+                                           float *__restrict__ d, int n, int c0, int C, int H, int W,
+                                           int up, int kWaves, float &mn, float &mx) {
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
-  const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
-  const int Hl = H >> up, Wl = W >> up;
-  const int HWl = Hl * Wl, HW = H * W;
-  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
   const int tid = threadIdx.x;
-  const int Wc = Wl + 1;                       // cells per LDS row
-  const int cells = (Hl + 1) * Wc;
-  float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
-  float *sl = wl + CCH * 9;
-  float *red = sl + HWl;
-  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
-  if (XQ) {
-    xs = reinterpret_cast<const float *>(xq)[2];
-    xz = reinterpret_cast<const float *>(xq)[3];
-  }
-  if (SQ) {
-    ss = reinterpret_cast<const float *>(sq)[2];
-    sz = reinterpret_cast<const float *>(sq)[3];
-  }
+  const int Hl = H >> up, Wl = W >> up;
+  const int HW = H * W;
+  const int Wc = Wl + 1;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int q = tid; q < (Wc + Hl) * LPP; q += kDw2Threads) {   // zero row, then zero column
-    const int i = q / LPP;
-    const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
-    img[cell * LPP + (q % LPP)] = z4;
-  }
-  // ---- stage the image -------------------------------------------------------------------
-  if (NHWC_IN) {
-    const float *xg = x + (long)n * HWl * C + c0;
-    for (int q = tid; q < HWl * LPP; q += kDw2Threads) {
-      const int pix = q / LPP, cq = q % LPP;
-      float4 v = z4;
-      if (c0 + cq * 4 + 3 < C) v = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq * 4);
-      if (XQ) {
-        v.x = fake_quant(v.x, xs, xz);
-        v.y = fake_quant(v.y, xs, xz);
-        v.z = fake_quant(v.z, xs, xz);
-        v.w = fake_quant(v.w, xs, xz);
-      }
-      img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] = v;
-    }
-  } else {
-    // lane <-> channel so the four scalar LDS stores of a wave hit consecutive banks
-    float *imgf = reinterpret_cast<float *>(img);
-    const int quads = (HWl + 3) >> 2;
-    for (int q = tid; q < quads * CCH; q += kDw2Threads) {
-      const int cl = q % CCH, j = q / CCH;
-      const int c = c0 + cl;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c < C) {
-        const float *xp = x + ((long)n * C + c) * HWl + j * 4;
-        if ((HWl & 3) == 0) {
-          const float4 t = *reinterpret_cast<const float4 *>(xp);
-          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (j * 4 + e < HWl) v[e] = xp[e];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int pix = j * 4 + e;
-        if (pix < HWl)
-          imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = XQ ? fake_quant(v[e], xs, xz) : v[e];
-      }
-    }
-  }
-  // ---- chunk weights (coalesced) and the (fake-quantised) scale plane ------------------------
-  for (int q = tid; q < CCH * 9; q += kDw2Threads)
-    wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
-  for (int q = tid; q < HWl; q += kDw2Threads) {
-    float sv = s_raw[(long)n * HWl + q];
-    if (SQ) sv = fake_quant(sv, ss, sz);
-    sl[q] = sv;
-  }
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int cq = lane % LPP, sub = lane / LPP;
   float wk[9][4];
@@ -260,19 +344,22 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? (xx >> up) : Wl) * (LPP * 16); };
   const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
 
-  float mn = INFINITY, mx = -INFINITY;
   const bool vec_store = ((C & 3) == 0);
   // The kernel is VALU-issue bound and the tap geometry is the bulk of the VALU work, so it is
   // computed ONCE per pixel: in the geometry phase lane i owns pixel pb+i (64 different pixels
   // per wave instruction instead of 16 lanes repeating the same pixel); in the gather phase the
   // LPP lanes of an output pixel fetch that pixel's 18-word record from its owner lane with
   // ds_bpermute (no LDS storage) and only add offsets, mix and accumulate.
-  for (int pb = wave * 64; pb < HW; pb += kWaves * 64) {
+  // every wave owns a contiguous pixel range (a multiple of PPW), so all waves gather even when the
+  // plane has fewer than 64 pixels per wave (stage 0: 256 pixels over 8 waves)
+  const int ppw = ((HW + kWaves - 1) / kWaves + PPW - 1) / PPW * PPW;
+  const int p_begin = wave * ppw, p_end = min(HW, p_begin + ppw);
+  for (int pb = p_begin; pb < p_end; pb += 64) {
     // ---- geometry phase ------------------------------------------------------------------
     int g_r[5], g_c[5];
     float g_w[8];
     {
-      const int p = min(pb + lane, HW - 1);
+      const int p = min(pb + (use_dpp<LPP>() ? owner_item<LPP>(lane) : lane), HW - 1);
       const int h = p / W, w = p - h * W;
       const float t = sl[(h >> up) * Wl + (w >> up)] - 1.0f;
       const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
@@ -300,16 +387,24 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       for (int q = 0; q < 8; ++q) wt[q] = g_w[q];
       (void)src;
 #else
-      // (a DPP row_share variant with fully unrolled steps measured slower: spills at 128 VGPRs)
+      if (use_dpp<LPP>()) {
+        int gi[10], oi[10];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        r[q] = __shfl(g_r[q], src, 64);
-        c[q] = __shfl(g_c[q], src, 64);
+        for (int q = 0; q < 5; ++q) { gi[q] = g_r[q]; gi[5 + q] = g_c[q]; }
+        fetch_record<LPP == 8>(j, gi, g_w, oi, wt);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { r[q] = oi[q]; c[q] = oi[5 + q]; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          r[q] = __shfl(g_r[q], src, 64);
+          c[q] = __shfl(g_c[q], src, 64);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wt[q] = __shfl(g_w[q], src, 64);
       }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) wt[q] = __shfl(g_w[q], src, 64);
 #endif
-      if (pb + j * PPW >= HW) break;          // wave-uniform: whole step beyond the plane
+      if (pb + j * PPW >= p_end) break;       // wave-uniform: whole step beyond this wave's range
       float4 acc = z4;
 #if defined(CDN_DIAG) && CDN_DIAG == 2   // diagnostic build: no LDS cell reads (wrong results)
 #define CDN_RD(O) make_float4(__int_as_float(O), 1.f, 2.f, 3.f)
@@ -321,11 +416,38 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   acc.y = fmaf(wk[K][1], TV.y, acc.y);      \
   acc.z = fmaf(wk[K][2], TV.z, acc.z);      \
   acc.w = fmaf(wk[K][3], TV.w, acc.w);
-      // corner taps: rows (R0,R1) x cols (C0,C1), axis weights (Y0,Y1) x (X0,X1)
-#define CDN_TAP4(R0, R1, C0, C1, Y0, Y1, X0, X1, K)                       \
+      // the 25 cell offsets of the step: taps 0..8 in order, corner taps (r0c0, r0c1, r1c0, r1c1)
+      const int o[25] = {r[0] + c[0], r[0] + c[1], r[1] + c[0], r[1] + c[1],      // tap 0
+                         r[0] + c[4], r[1] + c[4],                                // tap 1
+                         r[0] + c[2], r[0] + c[3], r[1] + c[2], r[1] + c[3],      // tap 2
+                         r[4] + c[0], r[4] + c[1],                                // tap 3
+                         r[4] + c[4],                                             // tap 4
+                         r[4] + c[2], r[4] + c[3],                                // tap 5
+                         r[2] + c[0], r[2] + c[1], r[3] + c[0], r[3] + c[1],      // tap 6
+                         r[2] + c[4], r[3] + c[4],                                // tap 7
+                         r[2] + c[2], r[2] + c[3], r[3] + c[2], r[3] + c[3]};     // tap 8
+      // DEEP 1 (<= 256 threads, up to 256 VGPRs): every read of the step is in flight before the first
+      // use.  DEEP 2: a rolling window of 13 reads (52 VGPRs): the reads of taps 5..8 are issued into
+      // the registers taps 0..3 free up.  DEEP 0: reads at their use; under the 128-VGPR cap the
+      // compiler then keeps 2-4 reads in flight and drains the queue (lgkmcnt(0)) 5 times per step:
+      // 17 waits x ~250 cycles of loaded LDS latency per step.
+      float4 v[DEEP ? 25 : 1];
+#define CDN_ISSUE(A, B)                                                       \
+  {                                                                           \
+    /* the accumulator passes through the asm: the taps before it cannot sink below the reads */ \
+    asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) :: "memory");           \
+    _Pragma("unroll") for (int i = (A); i <= (B); ++i) v[DEEP ? i : 0] = CDN_RD(o[i]); \
+    asm volatile("" ::: "memory");                                            \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+  }
+      if (DEEP == 1) CDN_ISSUE(0, 24)
+      if (DEEP == 2) CDN_ISSUE(0, 12)
+#define CDN_VAL(I) (DEEP ? v[DEEP ? (I) : 0] : CDN_RD(o[I]))
+      // corner taps: cells I..I+3, axis weights (Y0,Y1) x (X0,X1)
+#define CDN_TAP4(I, Y0, Y1, X0, X1, K)                                    \
   {                                                                       \
-    const float4 v00 = CDN_RD(R0 + C0), v01 = CDN_RD(R0 + C1);            \
-    const float4 v10 = CDN_RD(R1 + C0), v11 = CDN_RD(R1 + C1);            \
+    const float4 v00 = CDN_VAL(I), v01 = CDN_VAL(I + 1);                  \
+    const float4 v10 = CDN_VAL(I + 2), v11 = CDN_VAL(I + 3);              \
     const float w00 = Y0 * X0, w01 = Y0 * X1, w10 = Y1 * X0, w11 = Y1 * X1; \
     float4 tv;                                                            \
     tv.x = ((w00 * v00.x + w01 * v01.x) + w10 * v10.x) + w11 * v11.x;     \
@@ -334,10 +456,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     tv.w = ((w00 * v00.w + w01 * v01.w) + w10 * v10.w) + w11 * v11.w;     \
     CDN_WACC(K, tv)                                                       \
   }
-      // edge taps: one axis exact, 2 cells with weights (A0, A1)
-#define CDN_TAP2(OA, OB, A0, A1, K)                 \
+      // edge taps: one axis exact, cells I, I+1 with weights (A0, A1)
+#define CDN_TAP2(I, A0, A1, K)                      \
   {                                                 \
-    const float4 v0 = CDN_RD(OA), v1 = CDN_RD(OB);  \
+    const float4 v0 = CDN_VAL(I), v1 = CDN_VAL(I + 1); \
     float4 tv;                                      \
     tv.x = A0 * v0.x + A1 * v1.x;                   \
     tv.y = A0 * v0.y + A1 * v1.y;                   \
@@ -345,26 +467,35 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     tv.w = A0 * v0.w + A1 * v1.w;                   \
     CDN_WACC(K, tv)                                 \
   }
-      CDN_TAP4(r[0], r[1], c[0], c[1], wt[0], wt[1], wt[4], wt[5], 0)
-      CDN_TAP2(r[0] + c[4], r[1] + c[4], wt[0], wt[1], 1)
-      CDN_TAP4(r[0], r[1], c[2], c[3], wt[0], wt[1], wt[6], wt[7], 2)
-      CDN_TAP2(r[4] + c[0], r[4] + c[1], wt[4], wt[5], 3)
+      CDN_TAP4(0, wt[0], wt[1], wt[4], wt[5], 0)
+      if (DEEP == 2) CDN_ISSUE(13, 16)
+      CDN_TAP2(4, wt[0], wt[1], 1)
+      if (DEEP == 2) CDN_ISSUE(17, 18)
+      CDN_TAP4(6, wt[0], wt[1], wt[6], wt[7], 2)
+      if (DEEP == 2) CDN_ISSUE(19, 22)
+      CDN_TAP2(10, wt[4], wt[5], 3)
+      if (DEEP == 2) CDN_ISSUE(23, 24)
       {
-        const float4 vc = CDN_RD(r[4] + c[4]);
+        const float4 vc = CDN_VAL(12);
         CDN_WACC(4, vc)
       }
-      CDN_TAP2(r[4] + c[2], r[4] + c[3], wt[6], wt[7], 5)
-      CDN_TAP4(r[2], r[3], c[0], c[1], wt[2], wt[3], wt[4], wt[5], 6)
-      CDN_TAP2(r[2] + c[4], r[3] + c[4], wt[2], wt[3], 7)
-      CDN_TAP4(r[2], r[3], c[2], c[3], wt[2], wt[3], wt[6], wt[7], 8)
+      CDN_TAP2(13, wt[6], wt[7], 5)
+      CDN_TAP4(15, wt[2], wt[3], wt[4], wt[5], 6)
+      CDN_TAP2(19, wt[2], wt[3], 7)
+      CDN_TAP4(21, wt[2], wt[3], wt[6], wt[7], 8)
+#undef CDN_ISSUE
+#undef CDN_VAL
 #undef CDN_TAP4
 #undef CDN_TAP2
 #undef CDN_WACC
 #undef CDN_RD
-      if (p < HW) {
+      if (p < p_end) {
         float *dp = d + ((long)n * HW + p) * C + c0 + cq * 4;
         const int cbase = c0 + cq * 4;
         if (vec_store && cbase + 3 < C) {
+#if defined(CDN_DIAG) && CDN_DIAG == 5   // diagnostic build: no global store of d (wrong results)
+          if (acc.x == 1234.5f)
+#endif
           *reinterpret_cast<float4 *>(dp) = acc;
           mn = fminf(mn, fminf(fminf(acc.x, acc.y), fminf(acc.z, acc.w)));
           mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
@@ -381,9 +512,151 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       }
     }
   }
+}
+
+template <int CCH, bool NHWC_IN, bool XQ, bool SQ, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+           const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
+           const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
+           int C, int H, int W, int up) {
+  // LDS: [(Hl+1)*(Wl+1)][CCH] image cells; row Hl and column Wl are ZERO and every out-of-image
+  // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
+  // cell address is just row offset + column offset, no bounds test and no clamp per corner.
+  // Then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
+  extern __shared__ float4 img[];
+  CDN_STAMP(0);
+  constexpr int LPP = CCH / 4;     // lanes per pixel
+  constexpr int DEEP = MAXT <= 256 ? 1 : 0;
+  const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
+  const int Hl = H >> up, Wl = W >> up;
+  const int HWl = Hl * Wl;
+  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  const int tid = threadIdx.x;
+  const int Wc = Wl + 1;                       // cells per LDS row
+  const int cells = (Hl + 1) * Wc;
+  float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
+  float *sl = wl + CCH * 9;
+  float *red = sl + HWl;
+  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
+  if (XQ) {
+    xs = reinterpret_cast<const float *>(xq)[2];
+    xz = reinterpret_cast<const float *>(xq)[3];
+  }
+  if (SQ) {
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = tid; q < (Wc + Hl) * LPP; q += kDw2Threads) {   // zero row, then zero column
+    const int i = q / LPP;
+    const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
+    img[cell * LPP + (q % LPP)] = z4;
+  }
+  // ---- stage the image -------------------------------------------------------------------
+  // All of a thread's global loads of a batch are issued before the first one is used (kStageU in
+  // flight per thread); a plain loop leaves ONE dependent load per thread in flight and the
+  // staging then costs a full HBM round trip per iteration (measured: 21 of 58 us at stage 0).
+  constexpr int kStageU = 8;
+  if (NHWC_IN) {
+    const float *xg = x + (long)n * HWl * C + c0;
+    const int total = HWl * LPP;
+    for (int base = 0; base < total; base += kDw2Threads * kStageU) {
+      float4 v[kStageU];
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * kDw2Threads + tid;
+        const int pix = q / LPP, cq = q % LPP;
+        v[u] = z4;
+        if (q < total && c0 + cq * 4 + 3 < C)
+          v[u] = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * kDw2Threads + tid;
+        const int pix = q / LPP, cq = q % LPP;
+        if (q < total) {
+          float4 t = v[u];
+          if (XQ) {
+            t.x = fake_quant(t.x, xs, xz);
+            t.y = fake_quant(t.y, xs, xz);
+            t.z = fake_quant(t.z, xs, xz);
+            t.w = fake_quant(t.w, xs, xz);
+          }
+          img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] = t;
+        }
+      }
+    }
+  } else {
+    // lane <-> channel so the four scalar LDS stores of a wave hit consecutive banks
+    float *imgf = reinterpret_cast<float *>(img);
+    const int quads = (HWl + 3) >> 2;
+    const int total = quads * CCH;
+    if ((HWl & 3) == 0) {
+      for (int base = 0; base < total; base += kDw2Threads * kStageU) {
+        float4 v[kStageU];
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u) {
+          const int q = base + u * kDw2Threads + tid;
+          const int cl = q % CCH, j = q / CCH;
+          const int c = min(c0 + cl, C - 1), jj = min(j, quads - 1);   // clamped: always a valid load
+          v[u] = *reinterpret_cast<const float4 *>(x + ((long)n * C + c) * HWl + jj * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u) {
+          const int q = base + u * kDw2Threads + tid;
+          const int cl = q % CCH, j = q / CCH;
+          if (q < total) {
+            const bool live = c0 + cl < C;
+            const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int pix = j * 4 + e;
+              const float t = XQ ? fake_quant(e4[e], xs, xz) : e4[e];
+              imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = live ? t : 0.0f;
+            }
+          }
+        }
+      }
+    } else {
+      for (int q = tid; q < total; q += kDw2Threads) {
+        const int cl = q % CCH, j = q / CCH;
+        const int c = c0 + cl;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+          const float *xp = x + ((long)n * C + c) * HWl + j * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j * 4 + e < HWl) v[e] = xp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pix = j * 4 + e;
+          if (pix < HWl)
+            imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = XQ ? fake_quant(v[e], xs, xz) : v[e];
+        }
+      }
+    }
+  }
+  // ---- chunk weights (coalesced) and the (fake-quantised) scale plane ------------------------
+  for (int q = tid; q < CCH * 9; q += kDw2Threads)
+    wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
+  for (int q = tid; q < HWl; q += kDw2Threads) {
+    float sv = s_raw[(long)n * HWl + q];
+    if (SQ) sv = fake_quant(sv, ss, sz);
+    sl[q] = sv;
+  }
+  CDN_STAMP(1);
+  __syncthreads();
+  CDN_STAMP(2);
+  float mn = INFINITY, mx = -INFINITY;
+  dw2_gather<CCH, DEEP>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx);
+  CDN_STAMP_WAVE();
+  CDN_STAMP(3);
   if (dmm)
     cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red);
+  CDN_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -440,6 +713,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
             int C, int H, int W) {
   extern __shared__ float4 img[];
+  CDN_STAMP(0);
   constexpr int LPP = CCH / 4;     // lanes per block (one float4 of channels each)
   constexpr int PPW = 64 / LPP;    // blocks per wave step
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
@@ -468,18 +742,35 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     img[cell * LPP + (q % LPP)] = z4;
   }
   {
+    // batched: kStageU loads per thread in flight (see dw2_kernel)
+    constexpr int kStageU = 8;
     const float *xg = x + (long)n * HWl * C + c0;
-    for (int q = tid; q < HWl * LPP; q += nthreads) {
-      const int pix = q / LPP, cq4 = q % LPP;
-      float4 v = z4;
-      if (c0 + cq4 * 4 + 3 < C) v = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq4 * 4);
-      if (XQ) {
-        v.x = fake_quant(v.x, xs, xz);
-        v.y = fake_quant(v.y, xs, xz);
-        v.z = fake_quant(v.z, xs, xz);
-        v.w = fake_quant(v.w, xs, xz);
+    const int total = HWl * LPP;
+    for (int base = 0; base < total; base += nthreads * kStageU) {
+      float4 v[kStageU];
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * nthreads + tid;
+        const int pix = q / LPP, cq4 = q % LPP;
+        v[u] = z4;
+        if (q < total && c0 + cq4 * 4 + 3 < C)
+          v[u] = *reinterpret_cast<const float4 *>(xg + (long)pix * C + cq4 * 4);
       }
-      img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq4] = v;
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * nthreads + tid;
+        const int pix = q / LPP, cq4 = q % LPP;
+        if (q < total) {
+          float4 t = v[u];
+          if (XQ) {
+            t.x = fake_quant(t.x, xs, xz);
+            t.y = fake_quant(t.y, xs, xz);
+            t.z = fake_quant(t.z, xs, xz);
+            t.w = fake_quant(t.w, xs, xz);
+          }
+          img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq4] = t;
+        }
+      }
     }
   }
   for (int q = tid; q < CCH * 9; q += nthreads)
@@ -489,7 +780,9 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     if (SQ) sv = fake_quant(sv, ss, sz);
     sl[q] = sv;
   }
+  CDN_STAMP(1);
   __syncthreads();
+  CDN_STAMP(2);
   const int lane = tid & 63, wave = tid >> 6;
   const int cq = lane % LPP, sub = lane / LPP;
   float wk[9][4];
@@ -515,7 +808,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     int g_o[10];      // byte offsets: rows {ya: r0,r1; yb: r0,r1; mid}, cols {xa: c0,c1; xb: c0,c1; mid}
     float g_w[16];    // slot weights [class ya,yb,xa,xb][pixel a/b][slot 0/1]
     {
-      const int blk = min(bb + lane, HWl - 1);
+      const int blk = min(bb + (use_dpp<LPP>() ? owner_item<LPP>(lane) : lane), HWl - 1);
       const int Y = blk / Wl, X = blk - Y * Wl;
       const int h0 = 2 * Y, w0 = 2 * X;
       const float t = sl[blk] - 1.0f;
@@ -542,10 +835,14 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       const int blk = bb + src;
       int o[10];
       float w[16];
+      if (use_dpp<LPP>()) {
+        fetch_record<LPP == 8>(j, g_o, g_w, o, w);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 10; ++q) o[q] = __shfl(g_o[q], src, 64);
+        for (int q = 0; q < 10; ++q) o[q] = __shfl(g_o[q], src, 64);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) w[q] = __shfl(g_w[q], src, 64);
+        for (int q = 0; q < 16; ++q) w[q] = __shfl(g_w[q], src, 64);
+      }
       if (bb + j * PPW >= b_end) break;     // wave-uniform
       float4 acc[2][2] = {{z4, z4}, {z4, z4}};     // [py][px]
 #define CDN_WACC(A, K, TV)                \
@@ -648,9 +945,12 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     }
   }
 #undef CDN_RD
+  CDN_STAMP_WAVE();
+  CDN_STAMP(3);
   if (dmm)
     cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red);
+  CDN_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -686,8 +986,6 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   static_assert(TM >= 1 && TN >= 1 && AI >= 1 && BI >= 1, "tile too small for 256 threads");
   __shared__ float As[2][BM * kPwLD];
   __shared__ float Bs[2][BN * kPwLD];
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
   float qs = 1.f, qz = 0.f;
@@ -695,6 +993,14 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     qs = reinterpret_cast<const float *>(aq)[2];
     qz = reinterpret_cast<const float *>(aq)[3];
   }
+  // workgroups walk the (m, n) tiles with a grid stride: the full-size launch visits one tile each,
+  // the fallback launch behind pwi8_kernel is a small grid (an EMPTY full-size launch still costs
+  // 4.3 us of workgroup dispatch inside the graph)
+  const long ntm = (M + BM - 1) / BM, ntiles = ntm * ((Co + BN - 1) / BN);
+  float mn = INFINITY, mx = -INFINITY;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const long m0 = (tile % ntm) * BM;
+  const int n0 = (int)(tile / ntm) * BN;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -799,7 +1105,6 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * kPwBK);
     __syncthreads();
   }
-  float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
@@ -826,9 +1131,9 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         }
       }
   }
+  }   // tile loop
   if (rmm)   // (block_minmax_finish syncs before reusing As as scratch)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
-                             gridDim.x * gridDim.y, qu, &As[0][0]);
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.x, gridDim.x, qu, &As[0][0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -838,12 +1143,12 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 //   y[m][co] = sum_c (L/sc)*(qw/sw) + b = (sum_c L*qw) / (sc*sw[co]) + b      -- exact integer sum
 // a = L - 128 is in [-128,127] for in-range data but the tracked range lags the batch, so codes a
 // few LSB outside int8 are routine.  Instead of a second accumulator the K dimension is doubled:
-//   a = 16*a1 + a0,  a0 in [-8,7], a1 in [-128,127]   (|a| <= 2039: x up to 8x outside the range;
+//   a = 16*a1 + a0,  a0 in [0,15], a1 in [-128,127]   (|a| <= 2039: x up to 8x outside the range;
 //                                                     beyond that the code saturates)
 //   sum a*qw = sum a0*qw + sum a1*(16*qw),   16*qw in [-128,112] is still int8.
 // sum L*qw = sum a*qw + 128*colsum(qw).  All integer arithmetic is exact; the only roundings are
 // the final fp32 scale and bias add.  Operand lane map: lane (r = l&31, h = l>>5) supplies 16
-// consecutive k bytes [16h, 16h+16) of row r for BOTH operands (any k order works as long as A
+// consecutive k bytes [16h, 16h+16) of its row's 32-byte k-step for BOTH operands (any k order works as long as A
 // and B agree; checked with exact integer data, tools/probes/probe_i8.hip); C/D map as f32.
 // ------------------------------------------------------------------------------------------
 using i32x4 = __attribute__((ext_vector_type(4))) int;
@@ -854,7 +1159,8 @@ template <int BM, int BN, int WGM, bool FAST>
 __global__ void __launch_bounds__(256)
 pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
-            const int *__restrict__ wsum, const float *__restrict__ bias, float *__restrict__ R,
+            const int *__restrict__ wsum, const float *__restrict__ Wp,
+            const float *__restrict__ bias, float *__restrict__ R,
             float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
@@ -868,10 +1174,84 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
-  if (aq[6]) return;   // codes too wide for the nibble split: the f32 kernel behind us does this batch
   const float qs = reinterpret_cast<const float *>(aq)[2];
   const float qz = reinterpret_cast<const float *>(aq)[3];
-  const float zoff = qz - 128.0f;
+  if (aq[6]) {
+    // Codes too wide for the nibble split (the tracked range is far narrower than the batch: the first
+    // ~100 calls of a fresh EMA): this batch runs on f32 MFMA with the fake-quantised weights, inside
+    // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
+    // do).  Simple single-buffered 16-deep k-tiles in the int8 path's LDS arrays: the rare path.
+    constexpr int LDF = 17;
+    static_assert(BM * LDF * 4 <= 2 * BM * kI8LD && BN * LDF * 4 <= 2 * BN * kI8LD, "LDS reuse");
+    float *As = reinterpret_cast<float *>(&A0[0][0]);
+    float *Bs = reinterpret_cast<float *>(&B0[0][0]);
+    f32x16 accf[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) accf[i][j] = (f32x16){0};
+    for (int k0 = 0; k0 < C; k0 += 16) {
+      for (int q = tid; q < (BM + BN) * 4; q += 256) {     // one k quad of one row per item
+        const bool isA = q < BM * 4;
+        const int row = (isA ? q : q - BM * 4) >> 2, kq = (q & 3) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (isA) {
+          const long m = min(m0 + row, M - 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + kq + e < C) v[e] = fake_quant(A[m * C + k0 + kq + e], qs, qz);
+        } else {
+          const int co = min(n0 + row, Co - 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + kq + e < C) v[e] = Wp[(long)co * C + k0 + kq + e];
+        }
+        float *dst = (isA ? As : Bs) + row * LDF + kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = v[e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = As[(wm + i * 32 + (lane & 31)) * LDF + 2 * kk + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn + j * 32 + (lane & 31)) * LDF + 2 * kk + (lane >> 5)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            accf[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], accf[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + wn + j * 32 + (lane & 31);
+      const float bsv = (co < Co && bias) ? bias[co] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M && co < Co) {
+            float v = accf[i][j][r] + bsv;
+            if (relu) v = fmaxf(v, 0.0f);
+            R[m * Co + co] = v;
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+          }
+        }
+    }
+    if (rmm)
+      cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                               gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A1[0][0]));
+    return;
+  }
+  // as_uint(t + 1.5*2^23) = 0x4B400000 + rint(t) for |t| < 2^22 (guaranteed when state[6] == 0)
+  const int ioff = (int)qz + (2048 - 128) - 0x4B400000;
   i32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -908,24 +1288,24 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       b[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + bh);
     }
   };
-  auto code = [&](float v, bool live) -> int {
-    // a = round(sc*d - zp) + zp - 128, clamped to what the nibble split can carry
-    float q = rintf(__fsub_rn(__fmul_rn(qs, v), qz)) + zoff;
-    q = fminf(fmaxf(q, -2040.0f), 2039.0f);   // keeps a1 = (a - a0) >> 4 inside int8
-    return live ? (int)q : 0;
+  auto ucode = [&](float v, bool live) -> unsigned {
+    // t = sc*d - zp (two roundings, as the reference); rint(t) by the 1.5*2^23 trick; then integer:
+    // u = rint(t) + zp - 128 + 2048 in [8, 4087]
+    const float y = __fadd_rn(__fsub_rn(__fmul_rn(qs, v), qz), 12582912.0f);
+    int u = (int)__float_as_uint(y) + ioff;
+    u = min(max(u, 8), 4087);       // |L - 128| <= 2040: never active unless state[6] lied
+    return live ? (unsigned)u : 2048u;
   };
   auto store_tile = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int k = k0 + lk;
-      const int c0 = code(a[i].x, FAST || k + 0 < C), c1 = code(a[i].y, FAST || k + 1 < C);
-      const int c2 = code(a[i].z, FAST || k + 2 < C), c3 = code(a[i].w, FAST || k + 3 < C);
-      // low nibble (signed) and the rest
-      const int l0 = ((c0 + 8) & 15) - 8, l1 = ((c1 + 8) & 15) - 8;
-      const int l2 = ((c2 + 8) & 15) - 8, l3 = ((c3 + 8) & 15) - 8;
-      const int h0 = (c0 - l0) >> 4, h1 = (c1 - l1) >> 4, h2 = (c2 - l2) >> 4, h3 = (c3 - l3) >> 4;
-      const unsigned lo = (l0 & 255) | ((l1 & 255) << 8) | ((l2 & 255) << 16) | ((unsigned)(l3 & 255) << 24);
-      const unsigned hi = (h0 & 255) | ((h1 & 255) << 8) | ((h2 & 255) << 16) | ((unsigned)(h3 & 255) << 24);
+      const unsigned u0 = ucode(a[i].x, FAST || k + 0 < C), u1 = ucode(a[i].y, FAST || k + 1 < C);
+      const unsigned u2 = ucode(a[i].z, FAST || k + 2 < C), u3 = ucode(a[i].w, FAST || k + 3 < C);
+      const unsigned p01 = u0 | (u1 << 16), p23 = u2 | (u3 << 16);
+      // a0 = u & 15 in [0,15];  a1 = (u >> 4) - 128 (byte ^ 0x80);  bytes {p01.b0, p01.b2, p23.b0, p23.b2}
+      const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu;
+      const unsigned hi = __builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u;
       *reinterpret_cast<unsigned *>(&A0[buf][(lr + 32 * i) * kI8LD + lk]) = lo;
       *reinterpret_cast<unsigned *>(&A1[buf][(lr + 32 * i) * kI8LD + lk]) = hi;
     }
@@ -943,7 +1323,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   load_tile(0);
   store_tile(0, 0);
   __syncthreads();
-  const int nk = Cpad / 32;
+  const int nk = (C + 31) / 32;   // (Cpad >= 32 * nk: the weight rows are zero padded to 64)
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
     if (t + 1 < nk) load_tile((t + 1) * 32);
@@ -1078,13 +1458,20 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
   int threads = two_per_cu ? 512 : 1024;
+  // deep variant: two 256-thread workgroups per CU at up to 256 VGPRs, all 25 reads of a step in flight
+  // (measured at stage 0: 62 us vs 56 us for the 512-thread kernel; a persistent, double-buffered form
+  // -- next item's global loads in flight during the gather -- measured 66 us: at 2 waves/SIMD the
+  // per-step LDS latency chain is exposed.  Opt-in for experiments.)
+  static const bool want_deep = getenv("CDN_DW_DEEP") != nullptr;   // tuning knob
+  const bool deep = two_per_cu && want_deep;
+  if (deep) threads = 256;
   if (const char *e = getenv("CDN_DW_THREADS")) threads = atoi(e);   // tuning knob
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
-    auto kern = dw2_kernel<CCH, NH, XQ_, SQ_>;                                                \
+    auto kern = deep ? dw2_kernel<CCH, NH, XQ_, SQ_, 256> : dw2_kernel<CCH, NH, XQ_, SQ_, kDw2MaxThreads>; \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up);              \
+    kern<<<grid, deep ? std::min(threads, 256) : threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up); \
   }
   const bool XQ = xq != nullptr, SQ = sq != nullptr;
   const bool blocks = nhwc && up == 1 && !getenv("CDN_DW_NO_BLOCKS");
@@ -1199,7 +1586,23 @@ extern "C" int cdn_codenet_stage_fused_forward(
   int n_part_s = 0;
   {
   cdn::ProfScope ps(cdn::kProfScale, ptag, st);
-  if (x_nhwc) {
+  static const bool scale_old = getenv("CDN_SCALE_OLD") != nullptr;   // tuning knob
+  // tiled kernel for large planes (measured: 18 vs 22 us at 65536 pixels x 128 channels; the
+  // wave-per-pixel kernel is ahead at 16384 x 256: 13.7 vs 15.0 us)
+  if (x_nhwc && C <= 256 && !scale_old && N * HWl >= 32768 &&
+      cdn::ceil_div(N * HWl, kScaleTilePix) <= kMaxPartials) {
+    const long npix = (long)(N * HWl);
+    const int blocks = (int)cdn::ceil_div(npix, kScaleTilePix);
+    n_part_s = blocks;
+    const int CQ = (int)C >> 2, LD = ((CQ + 31) & ~31) + 4;
+    const size_t lds = ((size_t)kScaleTilePix * LD + 16) * sizeof(float);
+    if (xq)
+      scale_nhwc_tile_kernel<true><<<blocks, 256, lds, st>>>(x, xq, w_scale, b_scale, s_raw, smm,
+                                                             qu_s, (int)C, npix, lo, hi);
+    else
+      scale_nhwc_tile_kernel<false><<<blocks, 256, lds, st>>>(x, nullptr, w_scale, b_scale, s_raw,
+                                                              smm, qu_s, (int)C, npix, lo, hi);
+  } else if (x_nhwc) {
     const long npix = (long)(N * HWl);
     const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
     n_part_s = blocks;
@@ -1244,8 +1647,8 @@ extern "C" int cdn_codenet_stage_fused_forward(
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
   const bool pw_fast = (C % 32) == 0;
 #define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
-  pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<dim3((unsigned)cdn::ceil_div(M, BM_),                 \
-                                                (unsigned)cdn::ceil_div(Co, BN_)), 256, 0, st>>>( \
+  pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<(unsigned)std::min<long>(                             \
+      cdn::ceil_div(M, BM_) * cdn::ceil_div(Co, BN_), only_if_wide ? 2L * cdn::kCUs : (1L << 30)), 256, 0, st>>>( \
       d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, only_if_wide)
 #define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
   do {                                                                    \
@@ -1253,33 +1656,32 @@ extern "C" int cdn_codenet_stage_fused_forward(
     else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
   } while (0)
   const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
-  int only_if_wide = 0;
+  const int only_if_wide = 0;
   if (use_i8) {
     CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
     CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
                 "w_pw_codes must be 16-byte aligned");
-    const int Cpad = (int)((C + 31) / 32 * 32);
+    const int Cpad = (int)((C + 63) / 64 * 64);
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
 #define CDN_PWI(BM_, BN_, WGM_)                                                                  \
   do {                                                                                           \
     dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
     if (pw_fast)                                                                                 \
       pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
-                                                            w_pw_colsum, bias_pw, r_out, rmm,     \
+                                                            w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
                                                             qu_r, M, (int)C, Cpad, (int)Co, relu); \
     else                                                                                         \
       pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
-                                                             w_pw_colsum, bias_pw, r_out, rmm,    \
+                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
                                                              qu_r, M, (int)C, Cpad, (int)Co, relu); \
   } while (0)
     if (pw_bn == 128 && pw_bm == 64) CDN_PWI(64, 128, 2);
     else if (pw_bn == 128) CDN_PWI(128, 128, 4);
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI
-    only_if_wide = 1;   // the f32 kernel below runs only when state[6] says the codes are too wide
-  }
-  {
-    cdn::ProfScope ps(only_if_wide ? cdn::kProfUpdate : cdn::kProfPointwise, ptag, st);
+    // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)
+  } else {
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {
       if (dst) CDN_PW(64, 128, 2, true); else CDN_PW(64, 128, 2, false);
     } else if (pw_bn == 128) {

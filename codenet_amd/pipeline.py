@@ -157,6 +157,7 @@ class FusedHotPath:
         self._bufs = None
         self._graph = None
         self._affine = {}
+        self.stage_hook = None        # diagnostics: called as stage_hook(stage_shape_dict) after each stage
 
     # -- per-stage parameter views -------------------------------------------------------------
     def _stage_params(self, st):
@@ -243,6 +244,8 @@ class FusedHotPath:
                     sb["r"].data_ptr(), stream)
                 ops._toc(rec)
                 N_.check(rc, "cdn_codenet_stage_fused_forward")
+                if self.stage_hook is not None:
+                    self.stage_hook(sb)
                 cur, cur_nhwc = sb["r"], 1
                 cur_q = a[8]          # r_state of this stage (None in fp32)
             last = B["stages"][-1]

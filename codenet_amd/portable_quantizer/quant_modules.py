@@ -223,7 +223,7 @@ class QuantBnConv2d(Module, _WeightQuantizer):
 
     def folded_int8(self):
         """Integer form of the folded, fake-quantised 1x1 weights for the int8-MFMA pointwise kernel:
-        (codes int8 [Co, round_up(C,32)] zero padded, scale fp32 [Co] with w' = codes / scale,
+        (codes int8 [Co, round_up(C,64)] zero padded, scale fp32 [Co] with w' = codes / scale,
         column sums int32 [Co]); None when this layer is not per-channel symmetric <= 4 bit."""
         if (self.full_precision_flag or not self.per_channel or self.weight_bit > 4
                 or self.quant_mode != "symmetric"
@@ -241,7 +241,7 @@ class QuantBnConv2d(Module, _WeightQuantizer):
             n = 2 ** (self.weight_bit - 1) - 1
             scale = n / torch.clamp(mag, min=1e-10)
             q = torch.clamp(torch.round(scale.view(-1, 1, 1, 1) * w), -(n + 1), n).view(co, -1)
-            cpad = (q.shape[1] + 31) // 32 * 32
+            cpad = (q.shape[1] + 63) // 64 * 64
             codes = torch.zeros(co, cpad, dtype=torch.int8, device=q.device)
             codes[:, :q.shape[1]] = q.to(torch.int8)
             return codes.contiguous(), scale.contiguous(), q.sum(dim=1).to(torch.int32).contiguous()

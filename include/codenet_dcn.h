@@ -194,7 +194,7 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
  *             (W4A8: the already fake-quantised weights and the folded BN bias; fp32: BN as affine)
  *   w_pw_codes / w_pw_scale / w_pw_colsum: optional INTEGER form of the pointwise weights for the
  *             int8-MFMA path (used when the d quantiser is enabled): codes qw in [-8,7] as int8
- *             [Co][round_up(C,32)] zero padded and 16-byte aligned, per-channel scale sw[Co]
+ *             [Co][round_up(C,64)] zero padded and 16-byte aligned, per-channel scale sw[Co]
  *             (w' = qw / sw), column sums sum_c qw [Co] as int32.  NULL -> f32 MFMA on w_pw.
  *             The integer path computes sum_c (q_d + zp) * qw exactly and scales once; activation
  *             codes are NOT clamped to int8 (the reference does not clamp them).
