@@ -253,7 +253,9 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
     if (k == 0) s[pix0 + pix] = r;
     mn = mx = r;
   }
+  CDN_STAMPR(0, 2);
   if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  CDN_STAMPR(0, 3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1675,8 +1677,11 @@ extern "C" int cdn_codenet_stage_fused_forward(
                                                              w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
                                                              qu_r, M, (int)C, Cpad, (int)Co, relu); \
   } while (0)
-    if (pw_bn == 128 && pw_bm == 64) CDN_PWI(64, 128, 2);
-    else if (pw_bn == 128) CDN_PWI(128, 128, 4);
+    // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
+    // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
+    static const int i8_bm = getenv("CDN_PWI_BM") ? atoi(getenv("CDN_PWI_BM")) : 0;   // tuning knob
+    if (pw_bn == 128 && i8_bm == 128) CDN_PWI(128, 128, 4);
+    else if (pw_bn == 128) CDN_PWI(64, 128, 2);
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI
     // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)
