@@ -36,6 +36,12 @@ _SIGNATURES = {
         _i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 8 + [_i] + [_vp] * 9
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_unpack_nchw": (_i, [_vp] * 3 + [_i64] * 4 + [_i, _vp]),
+    "cdn_codenet_aux_workspace_bytes": (ctypes.c_size_t, []),
+    "cdn_codenet_pointwise_nhwc_forward": (
+        _i, [_vp, _vp] + [_i64] * 3 + [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
+    "cdn_codenet_dw3x3_nhwc_forward": (
+        _i, [_vp, _vp] + [_i64] * 4 + [_i] + [_vp] * 4 + [_i] + [_vp] * 3
+        + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_profile_enable": (_i, [_i]),
     "cdn_profile_read": (_i, [_i, _vp, _vp, _vp]),
 }

@@ -1446,6 +1446,141 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// dw3: plain depthwise 3x3 (pad 1, stride 1) on a channels-last activation that is optionally
+// nearest x2 up-sampled on the fly -- the detection heads' second layer (shufflenetv2_dcn.py:247-262,
+// quant_modules.py:1059-1066) applied to the hot path's half-resolution output.
+//   a   [n][Hs*Ws][C]   stored resolution (Hs = H >> up), fake-quantised while staged when aq != NULL
+//   out [n][H*W][C]     v = sum_{dy,dx} w[c][dy][dx] * U[h+dy-1][w+dx-1]  (+ bias) (* es + eh) (ReLU)
+// Workgroup = (image, band of kDw3Band stored rows, CCH = 32 channels): the band plus one halo row
+// on each side and one halo column on each side sit in LDS as [row][col][32] with zero halos; a lane
+// owns (stored pixel, channel quad), reads its 3x3 stored neighbourhood (9 ds_read_b128) and
+// produces the 2x2 (up = 1) or 1 (up = 0) output pixels of that stored pixel -- each of them as the
+// nine products of the reference's conv in (dy, dx) order, the up-sampling only decides which of the
+// nine cells a tap reads.
+// ------------------------------------------------------------------------------------------
+constexpr int kDw3Band = 2, kDw3CCH = 32;
+template <bool XQ, int UP>
+__global__ void __launch_bounds__(256)
+dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const float *__restrict__ w,
+           const float *__restrict__ bias, const float *__restrict__ ep_scale,
+           const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
+           int C, int Hs, int Ws, int relu, int nbands) {
+  extern __shared__ float4 band4[];         // [(kDw3Band + 2)][Ws + 2][8 quads]
+  constexpr int LPP = kDw3CCH / 4;
+  const int band = blockIdx.x % nbands, c0 = (blockIdx.x / nbands) * kDw3CCH, n = blockIdx.y;
+  const int y0 = band * kDw3Band;
+  const int Wc = Ws + 2;
+  const int tid = threadIdx.x;
+  float qs = 1.f, qz = 0.f;
+  if (XQ) {
+    qs = reinterpret_cast<const float *>(aq)[2];
+    qz = reinterpret_cast<const float *>(aq)[3];
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // stage rows y0-1 .. y0+band, columns -1 .. Ws (zeros outside the image / beyond C)
+  const int items = (kDw3Band + 2) * Wc * LPP;
+  for (int base = 0; base < items; base += 256 * 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = base + u * 256 + tid;
+      const int cq = q % LPP, cell = q / LPP;
+      const int r = cell / Wc, col = cell - r * Wc;
+      const int y = y0 - 1 + r, x = col - 1;
+      v[u] = z4;
+      if (q < items && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws && c0 + cq * 4 + 3 < C)
+        v[u] = *reinterpret_cast<const float4 *>(a + ((long)n * Hs * Ws + (long)y * Ws + x) * C + c0 + cq * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = base + u * 256 + tid;
+      if (q < items) {
+        float4 t = v[u];
+        const int cq = q % LPP, cell = q / LPP;
+        const int r = cell / Wc, col = cell - r * Wc;
+        const bool inside = (unsigned)(y0 - 1 + r) < (unsigned)Hs && (unsigned)(col - 1) < (unsigned)Ws &&
+                            c0 + cq * 4 + 3 < C;
+        if (XQ && inside) {      // (the zero halo is a zero of the conv padding, not a quantised value)
+          t.x = fake_quant(t.x, qs, qz);
+          t.y = fake_quant(t.y, qs, qz);
+          t.z = fake_quant(t.z, qs, qz);
+          t.w = fake_quant(t.w, qs, qz);
+        }
+        band4[q] = t;
+      }
+    }
+  }
+  __syncthreads();
+  const int H = Hs << UP, W = Ws << UP;
+  float mn = INFINITY, mx = -INFINITY;
+  const int work = kDw3Band * Ws * LPP;          // (stored pixel, channel quad) items of the band
+  for (int q = tid; q < work; q += 256) {
+    const int cq = q % LPP, pix = q / LPP;
+    const int ry = pix / Ws, X = pix - ry * Ws;
+    const int Y = y0 + ry;
+    const int cb = c0 + cq * 4;
+    if (Y >= Hs || cb >= C) continue;
+    float wk[9][4], bs[4], es[4], eh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = min(cb + e, C - 1);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wk[k][e] = w[(long)c * 9 + k];
+      bs[e] = bias ? bias[c] : 0.0f;
+      es[e] = ep_scale ? ep_scale[c] : 1.0f;
+      eh[e] = ep_scale ? ep_shift[c] : 0.0f;
+    }
+    float4 V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) V[i][j] = band4[((ry + i) * Wc + (X + j)) * LPP + cq];
+#pragma unroll
+    for (int py = 0; py < (1 << UP); ++py)
+#pragma unroll
+      for (int px = 0; px < (1 << UP); ++px) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            // full-resolution neighbour (2Y+py+dy-1, 2X+px+dx-1) -> stored cell relative to (Y-1, X-1)
+            const int i = UP ? ((py + dy + 1) >> 1) : dy;
+            const int j = UP ? ((px + dx + 1) >> 1) : dx;
+            const float4 t = V[i][j];
+            acc[0] = fmaf(wk[dy * 3 + dx][0], t.x, acc[0]);
+            acc[1] = fmaf(wk[dy * 3 + dx][1], t.y, acc[1]);
+            acc[2] = fmaf(wk[dy * 3 + dx][2], t.z, acc[2]);
+            acc[3] = fmaf(wk[dy * 3 + dx][3], t.w, acc[3]);
+          }
+        float *op = out + ((long)n * H * W + (long)((Y << UP) + py) * W + (X << UP) + px) * C + cb;
+        float r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[e] + bs[e];
+          if (ep_scale) v = fmaf(v, es[e], eh[e]);
+          if (relu) v = fmaxf(v, 0.0f);
+          r4[e] = v;
+        }
+        if (cb + 3 < C) {
+          *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { mn = fminf(mn, r4[e]); mx = fmaxf(mx, r4[e]); }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (cb + e < C) { op[e] = r4[e]; mn = fminf(mn, r4[e]); mx = fmaxf(mx, r4[e]); }
+        }
+      }
+  }
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+                             reinterpret_cast<float *>(band4));
+  }
+}
+
 constexpr int kMaxPartials = 16384;  // per kernel; grids are clamped / checked against it
 
 template <int CCH>
@@ -1506,6 +1641,73 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
 }
 
 }  // namespace
+
+// Pointwise (1x1) convolution on a channels-last activation A [M][C] -> R [M][Co]: int8 MFMA on codes
+// when the A quantiser state and the integer weights are given, f32 MFMA otherwise.  Shared by the
+// stage schedule and the stand-alone entry point (detection heads).
+static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, int64_t Co,
+                            const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
+                            const int *w_pw_colsum, const float *bias_pw, const float *ep_scale,
+                            const float *ep_shift, int relu, float *r_out, float2 *rmm,
+                            const cdn::QUpdate &qu_r, int ptag, hipStream_t st) {
+  // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
+  const int pw_bn = Co > 64 ? 128 : 64;
+  int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
+  if (const char *e = getenv("CDN_PW_BM")) pw_bm = (atoi(e) == 64 && Co > 64) ? 64 : 128;   // tuning knob
+  const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
+  CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
+  const bool pw_fast = (C % 32) == 0;
+#define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
+  pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<(unsigned)std::min<long>(                             \
+      cdn::ceil_div(M, BM_) * cdn::ceil_div(Co, BN_), only_if_wide ? 2L * cdn::kCUs : (1L << 30)), 256, 0, st>>>( \
+      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, only_if_wide)
+#define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
+  do {                                                                    \
+    if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
+    else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
+  } while (0)
+  const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
+  const int only_if_wide = 0;
+  if (use_i8) {
+    CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
+    CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
+                "w_pw_codes must be 16-byte aligned");
+    const int Cpad = (int)((C + 63) / 64 * 64);
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+#define CDN_PWI(BM_, BN_, WGM_)                                                                  \
+  do {                                                                                           \
+    dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
+    if (pw_fast)                                                                                 \
+      pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
+                                                            w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
+                                                            qu_r, M, (int)C, Cpad, (int)Co, relu); \
+    else                                                                                         \
+      pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
+                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
+                                                             qu_r, M, (int)C, Cpad, (int)Co, relu); \
+  } while (0)
+    // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
+    // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
+    static const int i8_bm = getenv("CDN_PWI_BM") ? atoi(getenv("CDN_PWI_BM")) : 0;   // tuning knob
+    if (pw_bn == 128 && i8_bm == 128) CDN_PWI(128, 128, 4);
+    else if (pw_bn == 128) CDN_PWI(64, 128, 2);
+    else CDN_PWI(128, 64, 4);
+#undef CDN_PWI
+    // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)
+  } else {
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+    if (pw_bn == 128 && pw_bm == 64) {
+      if (dst) CDN_PW(64, 128, 2, true); else CDN_PW(64, 128, 2, false);
+    } else if (pw_bn == 128) {
+      if (dst) CDN_PW(128, 128, 4, true); else CDN_PW(128, 128, 4, false);
+    } else {
+      if (dst) CDN_PW(128, 64, 4, true); else CDN_PW(128, 64, 4, false);
+    }
+  }
+#undef CDN_PW
+#undef CDN_PW1
+  return cdn::check_launch("codenet fused pointwise");
+}
 
 extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W,
                                                     int x_up) {
@@ -1638,68 +1840,10 @@ extern "C" int cdn_codenet_stage_fused_forward(
       rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
   }
   if (rc) return rc;
-  // 3. pointwise on f32 MFMA (+ bias / affine / ReLU, min/max of the result)
-  float2 *rmm = rst ? part_r : nullptr;
-  const long M = (long)(N * H * W);
-  // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
-  const int pw_bn = Co > 64 ? 128 : 64;
-  int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
-  if (const char *e = getenv("CDN_PW_BM")) pw_bm = (atoi(e) == 64 && Co > 64) ? 64 : 128;   // tuning knob
-  const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
-  CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-  const bool pw_fast = (C % 32) == 0;
-#define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
-  pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<(unsigned)std::min<long>(                             \
-      cdn::ceil_div(M, BM_) * cdn::ceil_div(Co, BN_), only_if_wide ? 2L * cdn::kCUs : (1L << 30)), 256, 0, st>>>( \
-      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, only_if_wide)
-#define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
-  do {                                                                    \
-    if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
-    else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
-  } while (0)
-  const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
-  const int only_if_wide = 0;
-  if (use_i8) {
-    CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
-    CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
-                "w_pw_codes must be 16-byte aligned");
-    const int Cpad = (int)((C + 63) / 64 * 64);
-    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
-#define CDN_PWI(BM_, BN_, WGM_)                                                                  \
-  do {                                                                                           \
-    dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
-    if (pw_fast)                                                                                 \
-      pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
-                                                            w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                            qu_r, M, (int)C, Cpad, (int)Co, relu); \
-    else                                                                                         \
-      pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
-                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                             qu_r, M, (int)C, Cpad, (int)Co, relu); \
-  } while (0)
-    // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
-    // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
-    static const int i8_bm = getenv("CDN_PWI_BM") ? atoi(getenv("CDN_PWI_BM")) : 0;   // tuning knob
-    if (pw_bn == 128 && i8_bm == 128) CDN_PWI(128, 128, 4);
-    else if (pw_bn == 128) CDN_PWI(64, 128, 2);
-    else CDN_PWI(128, 64, 4);
-#undef CDN_PWI
-    // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)
-  } else {
-    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
-    if (pw_bn == 128 && pw_bm == 64) {
-      if (dst) CDN_PW(64, 128, 2, true); else CDN_PW(64, 128, 2, false);
-    } else if (pw_bn == 128) {
-      if (dst) CDN_PW(128, 128, 4, true); else CDN_PW(128, 128, 4, false);
-    } else {
-      if (dst) CDN_PW(128, 64, 4, true); else CDN_PW(128, 64, 4, false);
-    }
-  }
-#undef CDN_PW
-#undef CDN_PW1
-  rc = cdn::check_launch("codenet fused pointwise");
-  if (rc) return rc;
-  return CDN_OK;
+  // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
+  return launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
+                          bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
+                          st);
 }
 
 extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw,
@@ -1720,4 +1864,95 @@ extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate
   else
     unpack_kernel<false><<<grid, 256, lds, st>>>(r_nhwc, nullptr, out_nchw, (int)C, (int)H, (int)W, up);
   return cdn::check_launch("codenet unpack");
+}
+
+// ---- stand-alone entry points for the layers around the hot path (detection heads) ------------
+extern "C" size_t cdn_codenet_aux_workspace_bytes(void) {
+  auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+  return r((size_t)kMaxPartials * 8) + r((size_t)cdn::kArriveWords * 4);
+}
+
+namespace {
+struct AuxWs {
+  float2 *partials;
+  unsigned *arrive;
+};
+// partials first, arrival counters in the LAST bytes (zeroed once by the caller)
+inline bool aux_workspace(void *workspace, size_t bytes, AuxWs *w) {
+  if (!workspace || bytes < cdn_codenet_aux_workspace_bytes() ||
+      (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
+    return false;
+  char *p = static_cast<char *>(workspace);
+  const size_t cnt = ((size_t)cdn::kArriveWords * 4 + 255) / 256 * 256;
+  w->partials = reinterpret_cast<float2 *>(p);
+  w->arrive = reinterpret_cast<unsigned *>(p + bytes / 256 * 256 - cnt);
+  return true;
+}
+}  // namespace
+
+extern "C" int cdn_codenet_pointwise_nhwc_forward(
+    const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, const float *w,
+    const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias,
+    const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
+    int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
+    void *stream) {
+  CDN_REQUIRE(a && w && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && M * std::max(C, Co) < (1ll << 31), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
+              "ep_scale / ep_shift must both be set or both be NULL");
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+              CDN_ERR_ARG, "a / out must be 16-byte aligned");
+  AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+  return launch_pointwise(a, static_cast<unsigned *>(const_cast<void *>(a_qstate)), (long)M, C, Co, w,
+                          w_codes, w_scale, w_colsum, bias, ep_scale, ep_shift, relu, out,
+                          r_state ? ws.partials : nullptr, qu, 0, st);
+}
+
+extern "C" int cdn_codenet_dw3x3_nhwc_forward(
+    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up,
+    const float *w, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
+    float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream) {
+  CDN_REQUIRE(a && w && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(!up || ((H & 1) == 0 && (W & 1) == 0), CDN_ERR_SHAPE, "up needs even H, W");
+  CDN_REQUIRE((C & 3) == 0, CDN_ERR_UNSUPPORTED, "channels-last depthwise needs C %% 4 == 0");
+  CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
+              "ep_scale / ep_shift must both be set or both be NULL");
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  const int Hs = (int)(H >> up), Ws = (int)(W >> up);
+  const size_t lds = (size_t)(kDw3Band + 2) * (Ws + 2) * kDw3CCH * sizeof(float);
+  CDN_REQUIRE(lds <= 64 * 1024, CDN_ERR_UNSUPPORTED, "stored row of %d pixels too wide", Ws);
+  const int nbands = (int)cdn::ceil_div(Hs, kDw3Band), nchunks = (int)cdn::ceil_div(C, kDw3CCH);
+  CDN_REQUIRE((long)nbands * nchunks * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
+  AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+  float2 *mm = r_state ? ws.partials : nullptr;
+  const unsigned *aq = static_cast<const unsigned *>(a_qstate);
+  dim3 grid((unsigned)(nbands * nchunks), (unsigned)N);
+  cdn::ProfScope ps(cdn::kProfDw, (int)(H > 0xffff ? 0xffff : H), st);
+#define CDN_GO(XQ_, UP_)                                                                          \
+  dw3_kernel<XQ_, UP_><<<grid, 256, lds, st>>>(a, aq, w, bias, ep_scale, ep_shift, out, mm, qu, (int)C, \
+                                               Hs, Ws, relu, nbands)
+  if (aq && up) CDN_GO(true, 1);
+  else if (aq) CDN_GO(true, 0);
+  else if (up) CDN_GO(false, 1);
+  else CDN_GO(false, 0);
+#undef CDN_GO
+  return cdn::check_launch("codenet dw3x3");
 }

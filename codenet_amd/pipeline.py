@@ -205,6 +205,25 @@ class FusedHotPath:
         self._bufs = dict(shape=tuple(x.shape), dev=dev, stages=bufs, ws=ws, out=out)
 
     def __call__(self, x):
+        """Stages + unpack: the Sequential's output tensor (NCHW, up-sampled, fake-quantised)."""
+        from . import _native as N_
+        from . import ops
+        cur, cur_q, last = self.forward_nhwc(x)
+        B = self._bufs
+        rec = ops._tic("unpack", (last["Co"], last["H"], last["W"]))
+        rc = N_.lib().cdn_codenet_unpack_nchw(cur.data_ptr(), cur_q, B["out"].data_ptr(), x.shape[0],
+                                              last["Co"], last["H"], last["W"], 1,
+                                              torch.cuda.current_stream(x.device).cuda_stream)
+        ops._toc(rec)
+        N_.check(rc, "cdn_codenet_unpack_nchw")
+        return B["out"]
+
+    def forward_nhwc(self, x):
+        """The three stages WITHOUT the final materialisation: returns (r, r_qstate, shape) with r the
+        last stage's output [N, H*W, Co] channels-last at stage resolution, pre-quantisation and not yet
+        up-sampled, r_qstate the device pointer of its QuantAct state (None in fp32) and shape the
+        stage's dict (Co, H, W).  Consumers (FusedHeads) fake-quantise on load and up-sample by
+        addressing."""
         from . import _native as N_
         from . import ops
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
@@ -248,13 +267,7 @@ class FusedHotPath:
                     self.stage_hook(sb)
                 cur, cur_nhwc = sb["r"], 1
                 cur_q = a[8]          # r_state of this stage (None in fp32)
-            last = B["stages"][-1]
-            rec = ops._tic("unpack", (last["Co"], last["H"], last["W"]))
-            rc = lib.cdn_codenet_unpack_nchw(cur.data_ptr(), cur_q, B["out"].data_ptr(), Nb,
-                                             last["Co"], last["H"], last["W"], 1, stream)
-            ops._toc(rec)
-            N_.check(rc, "cdn_codenet_unpack_nchw")
-        return B["out"]
+        return cur, cur_q, B["stages"][-1]
 
     # -- HIP graph -----------------------------------------------------------------------------
     def capture(self, x):
@@ -271,3 +284,144 @@ class FusedHotPath:
             g.replay()
             return out
         return replay
+
+
+class FusedHeads:
+    """The detection heads on the stage kernels, fed by
+    ``FusedHotPath.forward_nhwc``: per head
+        1x1 conv (+BN) -> ReLU [-> QuantAct] -> depthwise 3x3 (+BN) -> ReLU [-> QuantAct] -> 1x1 conv + bias
+    (fp32: shufflenetv2_dcn.py:244-271 nn.Sequential; W4A8: QuantDepthwiseNode, quant_modules.py:1013-1071).
+    The first 1x1 conv runs at HALF resolution (a 1x1 conv commutes with the nearest up-sampling and the
+    QuantAct extremes of a replicated tensor are those of the original), the depthwise kernel up-samples
+    by addressing, so the up-sampled 64-channel tensor is never built.  Same parameters and QuantAct
+    buffers (updated in place) as calling the head modules on the unpacked tensor."""
+
+    def __init__(self, heads, int8_pointwise=True):
+        self.heads = dict(heads)
+        self.int8_pointwise = int8_pointwise
+        self._bufs = None
+        self._affine = {}
+
+    def _bn_affine(self, bn):
+        key = id(bn)
+        if key not in self._affine:
+            inv = torch.rsqrt(bn.running_var + bn.eps)
+            es = (bn.weight * inv).contiguous()
+            self._affine[key] = (es, (bn.bias - bn.running_mean * es).contiguous())
+        return self._affine[key]
+
+    def _params(self, mod):
+        """-> list of layer dicts in execution order."""
+        from .portable_quantizer.quant_modules import QuantDepthwiseNode
+        if isinstance(mod, QuantDepthwiseNode):
+            w1, b1 = mod.quant_convbn1.folded()
+            w2, b2 = mod.quant_convbn2.folded()
+            i8 = self.int8_pointwise
+            return [
+                dict(kind="pw", w=w1.reshape(w1.size(0), -1), bias=b1, ep=None, relu=1,
+                     i8=mod.quant_convbn1.folded_int8() if i8 else None, act=mod.quant_act1[1]),
+                dict(kind="dw", w=w2.reshape(w2.size(0), 9), bias=b2, ep=None, relu=1,
+                     act=mod.quant_act3[1]),
+                dict(kind="pw", w=mod.quant_conv.quantized_weight().reshape(mod.quant_conv.out_channels, -1),
+                     bias=mod.quant_conv.bias, ep=None, relu=0,
+                     i8=mod.quant_conv.int8_form() if i8 else None, act=None)]
+        if isinstance(mod, nn.Conv2d):
+            return [dict(kind="pw", w=mod.weight.reshape(mod.out_channels, -1), bias=mod.bias, ep=None,
+                         relu=0, i8=None, act=None)]
+        conv1, bn1, _, conv2, bn2, _, conv3 = list(mod)
+        return [
+            dict(kind="pw", w=conv1.weight.reshape(conv1.out_channels, -1), bias=conv1.bias,
+                 ep=self._bn_affine(bn1), relu=1, i8=None, act=None),
+            dict(kind="dw", w=conv2.weight.reshape(conv2.out_channels, 9), bias=conv2.bias,
+                 ep=self._bn_affine(bn2), relu=1, act=None),
+            dict(kind="pw", w=conv3.weight.reshape(conv3.out_channels, -1), bias=conv3.bias, ep=None,
+                 relu=0, i8=None, act=None)]
+
+    def _alloc(self, r, shape):
+        from . import _native as N_
+        Nb = r.shape[0]
+        dev = r.device
+        C, Hs, Ws = shape["Co"], shape["H"], shape["W"]
+        M = Nb * Hs * Ws
+        aux = N_.lib().cdn_codenet_aux_workspace_bytes()
+        self._bufs = dict(
+            key=(tuple(r.shape), dev), y1=torch.empty(M, C, device=dev),
+            y2=torch.empty(4 * M, C, device=dev),
+            ws=torch.zeros(aux // 4 + 64, device=dev),        # arrival counters start at zero
+            o={name: torch.empty(4 * M, self._out_channels(m), device=dev)
+               for name, m in self.heads.items()},
+            out={name: torch.empty(Nb, self._out_channels(m), 2 * Hs, 2 * Ws, device=dev)
+                 for name, m in self.heads.items()})
+
+    @staticmethod
+    def _out_channels(mod):
+        from .portable_quantizer.quant_modules import QuantDepthwiseNode
+        if isinstance(mod, QuantDepthwiseNode):
+            return mod.quant_conv.out_channels
+        if isinstance(mod, nn.Conv2d):
+            return mod.out_channels
+        return list(mod)[-1].out_channels
+
+    def __call__(self, r, r_qstate, shape):
+        from . import _native as N_
+        from . import ops
+        if self._bufs is None or self._bufs["key"] != (tuple(r.shape), r.device):
+            self._alloc(r, shape)
+        B = self._bufs
+        lib = N_.lib()
+        Nb = r.shape[0]
+        C, Hs, Ws = shape["Co"], shape["H"], shape["W"]
+        M = Nb * Hs * Ws
+        stream = torch.cuda.current_stream(r.device).cuda_stream
+        ws_ptr = (B["ws"].data_ptr() + 255) // 256 * 256
+        ws_bytes = (B["ws"].numel() * 4 - (ws_ptr - B["ws"].data_ptr())) // 256 * 256
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+
+        def act_args(act):
+            if act is None:
+                return [None, None, None, 8, 0.99, 0]
+            return [act.x_min.data_ptr(), act.x_max.data_ptr(), act._device_state(r.device).data_ptr(),
+                    act.activation_bit, act.momentum, int(act.running_stat)]
+
+        def pw(a, aq, m, layer, out):
+            i8 = layer["i8"] if layer["i8"] is not None else (None, None, None)
+            ep = layer["ep"] or (None, None)
+            rec = ops._tic("head_pw", (layer["w"].shape[1], layer["w"].shape[0], m))
+            rc = lib.cdn_codenet_pointwise_nhwc_forward(
+                a.data_ptr(), aq, m, layer["w"].shape[1], layer["w"].shape[0], ptr(layer["w"]),
+                ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(layer["bias"]), ptr(ep[0]), ptr(ep[1]),
+                layer["relu"], *act_args(layer["act"]), ws_ptr, ws_bytes, out.data_ptr(), stream)
+            ops._toc(rec)
+            N_.check(rc, "cdn_codenet_pointwise_nhwc_forward")
+
+        outs = {}
+        with torch.no_grad():
+            for name, mod in self.heads.items():
+                layers = self._params(mod)
+                if len(layers) == 1:          # head_conv == 0: one 1x1 conv, up-sampled afterwards
+                    o = B["o"][name][:M]
+                    pw(r, r_qstate, M, layers[0], o)
+                    rc = lib.cdn_codenet_unpack_nchw(o.data_ptr(), None, B["out"][name].data_ptr(), Nb,
+                                                     o.shape[1], Hs, Ws, 1, stream)
+                    N_.check(rc, "cdn_codenet_unpack_nchw")
+                    outs[name] = B["out"][name]
+                    continue
+                l1, l2, l3 = layers
+                pw(r, r_qstate, M, l1, B["y1"])
+                q1 = l1["act"]._device_state(r.device).data_ptr() if l1["act"] is not None else None
+                ep = l2["ep"] or (None, None)
+                rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
+                rc = lib.cdn_codenet_dw3x3_nhwc_forward(
+                    B["y1"].data_ptr(), q1, Nb, C, 2 * Hs, 2 * Ws, 1, ptr(l2["w"]), ptr(l2["bias"]),
+                    ptr(ep[0]), ptr(ep[1]), l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes,
+                    B["y2"].data_ptr(), stream)
+                ops._toc(rec)
+                N_.check(rc, "cdn_codenet_dw3x3_nhwc_forward")
+                q2 = l2["act"]._device_state(r.device).data_ptr() if l2["act"] is not None else None
+                o = B["o"][name]
+                pw(B["y2"], q2, 4 * M, l3, o)
+                rc = lib.cdn_codenet_unpack_nchw(o.data_ptr(), None, B["out"][name].data_ptr(), Nb,
+                                                 o.shape[1], 2 * Hs, 2 * Ws, 0, stream)
+                N_.check(rc, "cdn_codenet_unpack_nchw")
+                outs[name] = B["out"][name]
+        return outs

@@ -87,6 +87,37 @@ class _WeightQuantizer:
         return self.weight_function(w, self.weight_bit, w_min, w_max, self.per_channel,
                                     self.weight_percentile)
 
+    def _int8_ok(self, kernel_size, groups):
+        return not (self.full_precision_flag or not self.per_channel or self.weight_bit > 4
+                    or self.quant_mode != "symmetric" or tuple(kernel_size) != (1, 1) or groups != 1)
+
+    def _int8_codes(self, w):
+        """Integer form of per-channel symmetric <= 4-bit 1x1 weights for the int8-MFMA pointwise
+        kernel: (codes int8 [Co, round_up(C,64)] zero padded, scale fp32 [Co] with w' = codes / scale,
+        column sums int32 [Co]).  Same expressions as SymmetricQuantFunction.forward
+        (quant_utils.py:207-225)."""
+        co = w.shape[0]
+        w_min, w_max = _channel_range(w.data.contiguous().view(co, -1), self.weight_percentile)
+        mag = torch.max(torch.stack([w_min.abs(), w_max.abs()], dim=1), dim=1).values
+        n = 2 ** (self.weight_bit - 1) - 1
+        scale = n / torch.clamp(mag, min=1e-10)
+        q = torch.clamp(torch.round(scale.view(-1, 1, 1, 1) * w), -(n + 1), n).view(co, -1)
+        cpad = (q.shape[1] + 63) // 64 * 64
+        codes = torch.zeros(co, cpad, dtype=torch.int8, device=q.device)
+        codes[:, :q.shape[1]] = q.to(torch.int8)
+        return codes.contiguous(), scale.contiguous(), q.sum(dim=1).to(torch.int32).contiguous()
+
+    def _cached_i8(self, key_tensors, compute):
+        if torch.is_grad_enabled():
+            with torch.no_grad():
+                return compute()
+        key = tuple((t.data_ptr(), t._version, t.device) for t in key_tensors)
+        cache = getattr(self, "_i8_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                self._i8_cache = (key, compute())
+        return self._i8_cache[1]
+
     def _cached(self, key_tensors, compute):
         """In inference (no grad) reuse the derived tensors until a source tensor changes."""
         if torch.is_grad_enabled():
@@ -125,6 +156,9 @@ class QuantAct(Module):
                                           self.x_max.item())
 
     def _device_state(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:     # "cuda" == the current device
+            device = torch.device("cuda", torch.cuda.current_device())
         if self._state is None or self._state.device != device:
             self._state = ops.quantact_state(device)
         return self._state
@@ -185,6 +219,13 @@ class Quant_Conv2d(Module, _WeightQuantizer):
         return self._cached((self.weight,),
                             lambda: self._fake_quant_weight(self.weight, self.out_channels))
 
+    def int8_form(self):
+        """Integer form of the fake-quantised 1x1 weights (see _int8_codes); None when this layer is
+        not per-channel symmetric <= 4 bit."""
+        if not self._int8_ok(self.kernel_size, self.groups):
+            return None
+        return self._cached_i8((self.weight,), lambda: self._int8_codes(self.weight))
+
     def forward(self, x):
         return F.conv2d(x, self.quantized_weight(), self.bias, self.stride, self.padding,
                         self.dilation, self.groups)
@@ -222,39 +263,17 @@ class QuantBnConv2d(Module, _WeightQuantizer):
         return self._cached(tuple(keys), compute)
 
     def folded_int8(self):
-        """Integer form of the folded, fake-quantised 1x1 weights for the int8-MFMA pointwise kernel:
-        (codes int8 [Co, round_up(C,64)] zero padded, scale fp32 [Co] with w' = codes / scale,
-        column sums int32 [Co]); None when this layer is not per-channel symmetric <= 4 bit."""
-        if (self.full_precision_flag or not self.per_channel or self.weight_bit > 4
-                or self.quant_mode != "symmetric"
-                or tuple(self.conv.kernel_size) != (1, 1) or self.conv.groups != 1):
+        """Integer form of the folded, fake-quantised 1x1 weights for the int8-MFMA pointwise kernel
+        (see _int8_codes); None when this layer is not per-channel symmetric <= 4 bit."""
+        if not self._int8_ok(self.conv.kernel_size, self.conv.groups):
             return None
 
         def compute():
             running_std = torch.sqrt(self.bn.running_var + self.bn.eps)
             scale_factor = self.bn.weight / running_std
             w = self.conv.weight * scale_factor.reshape([self.conv.out_channels, 1, 1, 1])
-            co = self.conv.out_channels
-            w_min, w_max = _channel_range(w.data.contiguous().view(co, -1), self.weight_percentile)
-            # same expressions as SymmetricQuantFunction.forward (quant_utils.py:207-225)
-            mag = torch.max(torch.stack([w_min.abs(), w_max.abs()], dim=1), dim=1).values
-            n = 2 ** (self.weight_bit - 1) - 1
-            scale = n / torch.clamp(mag, min=1e-10)
-            q = torch.clamp(torch.round(scale.view(-1, 1, 1, 1) * w), -(n + 1), n).view(co, -1)
-            cpad = (q.shape[1] + 63) // 64 * 64
-            codes = torch.zeros(co, cpad, dtype=torch.int8, device=q.device)
-            codes[:, :q.shape[1]] = q.to(torch.int8)
-            return codes.contiguous(), scale.contiguous(), q.sum(dim=1).to(torch.int32).contiguous()
-        keys = (self.conv.weight, self.bn.weight, self.bn.running_var)
-        if torch.is_grad_enabled():
-            with torch.no_grad():
-                return compute()
-        key = tuple((t.data_ptr(), t._version, t.device) for t in keys)
-        cache = getattr(self, "_i8_cache", None)
-        if cache is None or cache[0] != key:
-            with torch.no_grad():
-                self._i8_cache = (key, compute())
-        return self._i8_cache[1]
+            return self._int8_codes(w)
+        return self._cached_i8((self.conv.weight, self.bn.weight, self.bn.running_var), compute)
 
     def forward(self, x):
         w, b = self.folded()

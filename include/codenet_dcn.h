@@ -225,6 +225,41 @@ int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *ou
                             int64_t C, int64_t H, int64_t W, int up, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The layers that consume the hot path's output: the detection heads
+ *   fp32 : Conv2d 1x1 -> BN -> ReLU -> Conv2d 3x3 depthwise -> BN -> ReLU -> Conv2d 1x1 (+bias)
+ *          (lib/models/networks/shufflenetv2_dcn.py:244-271)
+ *   W4A8 : QuantDepthwiseNode = QuantBnConv2d -> ReLU -> QuantAct -> QuantBnConv2d (depthwise) ->
+ *          ReLU -> QuantAct -> Quant_Conv2d            (portable_quantizer/quant_modules.py:1013-1071)
+ * run on the same kernels as the stages, on channels-last activations, so the heads read the last
+ * stage's output at HALF resolution (the 1x1 conv of a nearest-up-sampled tensor is the up-sampled
+ * 1x1 conv; the depthwise kernel up-samples by addressing) and cdn_codenet_unpack_nchw is not needed.
+ * Range tracking of the output QuantAct (r_min / r_max / r_state, all three or none) runs in the
+ * kernel's epilogue as in the stage schedule; a_qstate != NULL fake-quantises the input while loading.
+ * workspace: cdn_codenet_aux_workspace_bytes() bytes, 256-byte aligned, required when r_state != NULL;
+ * its LAST 16 KiB are arrival counters: zero them once, every call leaves them zero.
+ * ---------------------------------------------------------------------------------------- */
+size_t cdn_codenet_aux_workspace_bytes(void);
+
+/* out[m][co] = act( sum_c fq(a[m][c]) * w[co][c] + bias[co] ) (* ep_scale + ep_shift before act),
+ * a [M][C], w [Co][C] fp32 (fake-quantised already for W4A8).  w_codes / w_scale / w_colsum: optional
+ * integer form as in cdn_codenet_stage_fused_forward (int8 MFMA when a_qstate is given too). */
+int cdn_codenet_pointwise_nhwc_forward(
+    const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, const float *w,
+    const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias,
+    const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
+    int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
+    void *stream);
+
+/* Depthwise 3x3, pad 1, stride 1, channels-last: a [N][(H>>up)*(W>>up)][C] (nearest x2 up-sampled on
+ * the fly when up = 1), w [C][9], bias / ep_scale / ep_shift [C] or NULL, out [N][H*W][C].
+ * C % 4 == 0. */
+int cdn_codenet_dw3x3_nhwc_forward(
+    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up,
+    const float *w, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
+    float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (thread-local; off by default).
  * While enabled, each kernel of cdn_codenet_stage_fused_forward / cdn_codenet_unpack_nchw records
  * an event pair.  cdn_profile_read synchronises the recorded events and returns up to max_records

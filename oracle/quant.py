@@ -8,7 +8,7 @@ composition of the CoDeNet deform stage, each function citing what it follows:
         AsymmetricQuantFunction :172-200, SymmetricQuantFunction :207-225)
     portable_quantizer/quant_modules.py  (QuantAct :163-225, Quant_Conv2d :228-321,
         QuantBnConv2d :324-419, QuantDeformConv2d :422-517,
-        QuantDeformConvWithOffsetScaleBoundPositive :621-671)
+        QuantDeformConvWithOffsetScaleBoundPositive :621-671, QuantDepthwiseNode :1013-1071)
 
 Pinned against the reference's own Python modules (imported in the build container only) by
 tests/golden/make_golden.py -> tests/golden/*.npz, checked in tests/test_quant_oracle.py.
@@ -143,3 +143,31 @@ def stage_w4a8(x, w_scale, b_scale, w_dw, w_pw, bn, act_s, act_d, w_bits=4, runn
     wq_p = weight_fake_quant(wf, w_bits, wt_percentile)
     y = F.conv2d(d_q, wq_p, bf)
     return {"s": s_q, "s_codes": s_codes, "d": d, "d_q": d_q, "d_codes": d_codes, "y": y}
+
+
+# ---- detection heads ------------------------------------------------
+
+def head_fp32(x, w1, bn1, w2, bn2, w3, b3, eps=1e-5):
+    """The fp32 head nn.Sequential of lib/models/networks/shufflenetv2_dcn.py:244-262:
+    conv1x1 -> BN -> ReLU -> depthwise 3x3 -> BN -> ReLU -> conv1x1 + bias (BN in eval mode).
+    bn = (weight, bias, running_mean, running_var)."""
+    def bn_eval(t, bn):
+        w, b, m, v = bn
+        return F.batch_norm(t, m, v, w, b, False, 0.0, eps)
+    y1 = torch.relu(bn_eval(F.conv2d(x, w1), bn1))
+    y2 = torch.relu(bn_eval(F.conv2d(y1, w2, None, 1, 1, 1, w2.shape[0]), bn2))
+    return {"y1": y1, "y2": y2, "out": F.conv2d(y2, w3, b3)}
+
+
+def head_w4a8(x, w1, bn1, w2, bn2, w3, b3, act1, act3, w_bits=4, running=True, wt_percentile=False,
+              act_percentile=False, eps=1e-5):
+    """QuantDepthwiseNode.forward (quant_modules.py:1059-1071): QuantBnConv2d -> ReLU -> QuantAct ->
+    QuantBnConv2d (depthwise) -> ReLU -> QuantAct -> Quant_Conv2d.  act1 / act3 are QuantActState."""
+    wf1, bf1 = fold_bn(w1, None, *bn1, eps)
+    y1 = F.conv2d(x, weight_fake_quant(wf1, w_bits, wt_percentile), bf1)
+    y1q, c1 = act1(torch.relu(y1), running, act_percentile, return_codes=True)
+    wf2, bf2 = fold_bn(w2, None, *bn2, eps)
+    y2 = F.conv2d(y1q, weight_fake_quant(wf2, w_bits, wt_percentile), bf2, 1, 1, 1, w2.shape[0])
+    y2q, c2 = act3(torch.relu(y2), running, act_percentile, return_codes=True)
+    out = F.conv2d(y2q, weight_fake_quant(w3, w_bits, wt_percentile), b3)
+    return {"y1": y1, "y1q": y1q, "y1_codes": c1, "y2": y2, "y2q": y2q, "y2_codes": c2, "out": out}

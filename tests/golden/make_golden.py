@@ -214,6 +214,63 @@ def make_stage_w4a8(ref_mod, ref_qm):
     return t2n(out)
 
 
+def make_head_w4a8(ref_qm):
+    """The reference's QuantDepthwiseNode (quant_modules.py:1013-1071) on a head-shaped nn.Sequential
+    (shufflenetv2_dcn.py:244-262), 3 consecutive forwards (EMA state), plus the fp32 Sequential."""
+    g = torch.Generator().manual_seed(57)
+    N, C, classes, H, W = 2, 16, 5, 10, 12
+    nn = torch.nn
+
+    def bn(c):
+        b = nn.BatchNorm2d(c)
+        b.weight.data = torch.rand(c, generator=g) + 0.5
+        b.bias.data = torch.randn(c, generator=g) * 0.1
+        b.running_mean = torch.randn(c, generator=g) * 0.1
+        b.running_var = torch.rand(c, generator=g) + 0.5
+        return b
+    head = nn.Sequential(
+        nn.Conv2d(C, C, 1, bias=False), bn(C), nn.ReLU(inplace=True),
+        nn.Conv2d(C, C, 3, 1, 1, groups=C, bias=False), bn(C), nn.ReLU(inplace=True),
+        nn.Conv2d(C, classes, 1, bias=True)).eval()
+    head[0].weight.data = torch.randn(C, C, 1, 1, generator=g) * (1.5 / C) ** 0.5
+    head[3].weight.data = torch.randn(C, 1, 3, 3, generator=g) / 3
+    head[6].weight.data = torch.randn(classes, C, 1, 1, generator=g) * (1.0 / C) ** 0.5
+    head[6].bias.data = torch.randn(classes, generator=g) * 0.1
+    out = {"w1": head[0].weight.data, "w2": head[3].weight.data, "w3": head[6].weight.data,
+           "b3": head[6].bias.data}
+    for i, k in ((1, "bn1"), (4, "bn2")):
+        out[k + "_weight"] = head[i].weight.data
+        out[k + "_bias"] = head[i].bias.data
+        out[k + "_mean"] = head[i].running_mean
+        out[k + "_var"] = head[i].running_var
+    xs = [torch.randn(N, C, H, W, generator=g).abs() * (1.0 + 0.3 * it) for it in range(3)]
+    with torch.no_grad():
+        out["fp32_out"] = head(xs[0].clone())
+    for pct in (False, True):
+        tag = "p" if pct else "n"
+        import copy
+        q = ref_qm.QuantDepthwiseNode(4, 8, act_percentile=False, wt_quant_mode="symmetric",
+                                      act_quant_mode="asymmetric", per_channel=True,
+                                      weight_percentile=pct)
+        q.set_param(copy.deepcopy(head))
+        q.eval()
+        cap = {}
+        q.quant_act1.register_forward_hook(lambda mod, i, o: cap.__setitem__("y1q", o.clone()))
+        q.quant_act3.register_forward_hook(lambda mod, i, o: cap.__setitem__("y2q", o.clone()))
+        for it in range(3):
+            with torch.no_grad():
+                y = q(xs[it].clone())
+            out["x%d" % it] = xs[it]
+            out["%s_out%d" % (tag, it)] = y
+            out["%s_y1q%d" % (tag, it)] = cap["y1q"]
+            out["%s_y2q%d" % (tag, it)] = cap["y2q"]
+            out["%s_a1min%d" % (tag, it)] = q.quant_act1[1].x_min.clone()
+            out["%s_a1max%d" % (tag, it)] = q.quant_act1[1].x_max.clone()
+            out["%s_a3min%d" % (tag, it)] = q.quant_act3[1].x_min.clone()
+            out["%s_a3max%d" % (tag, it)] = q.quant_act3[1].x_max.clone()
+    return t2n(out)
+
+
 def make_deform_raw():
     g = torch.Generator().manual_seed(41)
     out = {}
@@ -292,6 +349,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stage_w4a8.npz"), **make_stage_w4a8(ref_mod, ref_qm))
     np.savez_compressed(os.path.join(HERE, "deform_raw.npz"), **make_deform_raw())
     np.savez_compressed(os.path.join(HERE, "model_io.npz"), **make_model_io(ref_qm))
+    np.savez_compressed(os.path.join(HERE, "head_w4a8.npz"), **make_head_w4a8(ref_qm))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -94,3 +94,37 @@ def test_deform_raw_regression():
         y = O.deform_conv_forward(z[tag + "_x"], z[tag + "_off"], z[tag + "_w"], *cfg)
         assert torch.equal(y, z[tag + "_y"])
         assert y[0, :, 0, 0].abs().max().item() == 0.0      # out-of-range samples
+
+
+def _head_params(z):
+    bn1 = (z["bn1_weight"], z["bn1_bias"], z["bn1_mean"], z["bn1_var"])
+    bn2 = (z["bn2_weight"], z["bn2_bias"], z["bn2_mean"], z["bn2_var"])
+    return z["w1"], bn1, z["w2"], bn2, z["w3"], z["b3"]
+
+
+def test_head_fp32_matches_reference_sequential():
+    z = load("head_w4a8.npz")
+    r = Q.head_fp32(z["x0"], *_head_params(z))
+    assert (r["out"] - z["fp32_out"]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("tag,pct", [("n", False), ("p", True)])
+def test_head_w4a8_matches_reference_module(tag, pct):
+    """oracle/quant.py head_w4a8 vs the reference's QuantDepthwiseNode over 3 forwards (EMA state)."""
+    torch.set_num_threads(1)
+    z = load("head_w4a8.npz")
+    a1, a3 = Q.QuantActState(bits=8), Q.QuantActState(bits=8)
+    for it in range(3):
+        r = Q.head_w4a8(z["x%d" % it], *_head_params(z), a1, a3, wt_percentile=pct)
+        assert (a1.x_min - z["%s_a1min%d" % (tag, it)]).abs().item() < 1e-5
+        assert (a1.x_max - z["%s_a1max%d" % (tag, it)]).abs().item() < 1e-5
+        assert (a3.x_min - z["%s_a3min%d" % (tag, it)]).abs().item() < 1e-5
+        assert (a3.x_max - z["%s_a3max%d" % (tag, it)]).abs().item() < 1e-5
+        lsb1 = (a1.x_max - a1.x_min).item() / 255.0
+        lsb3 = (a3.x_max - a3.x_min).item() / 255.0
+        d1 = (r["y1q"] - z["%s_y1q%d" % (tag, it)]).abs()
+        d3 = (r["y2q"] - z["%s_y2q%d" % (tag, it)]).abs()
+        # same ops, same thread count: identical up to a rare one-LSB code flip
+        assert d1.max().item() <= 1.01 * lsb1 and (d1 > 1e-6).float().mean().item() < 1e-3
+        assert d3.max().item() <= 1.01 * lsb3 and (d3 > 1e-6).float().mean().item() < 5e-3
+        assert (r["out"] - z["%s_out%d" % (tag, it)]).abs().max().item() < 0.05

@@ -37,6 +37,7 @@ def main():
     model = harness.create_model(w2=a.w2, quantize=not a.fp32).to(dev)
     x = torch.randn(a.batch, 3, a.res, a.res, device=dev)
     fused = pipeline.FusedHotPath(model.deconv_layers)
+    fheads = pipeline.FusedHeads({h: getattr(model, h) for h in model.heads})
 
     def backbone(inp):
         return model.layer4(model.layer3(model.layer2(model.layer1(model.layer0(inp)))))
@@ -45,6 +46,13 @@ def main():
         out = {h: getattr(model, h)(f) for h in model.heads}
         hm = out["hm"].sigmoid_()
         return harness.ctdet_decode(hm, out["wh"], reg=out["reg"], K=100)
+
+    def decode(out):
+        hm = out["hm"].sigmoid_()
+        return harness.ctdet_decode(hm, out["wh"], reg=out["reg"], K=100)
+
+    def path_heads_fused(f):          # stages + heads on the HIP kernels, no NCHW materialisation between
+        return fheads(*fused.forward_nhwc(f))
 
     with torch.no_grad():
         feat = backbone(x)
@@ -56,6 +64,11 @@ def main():
         res["heads_decode_ms"] = timed(lambda: heads(up), a.steps, 5) * 1e3
         res["e2e_modules_ms"] = timed(lambda: heads(model.deconv_layers(backbone(x))), a.steps, 5) * 1e3
         res["e2e_fused_ms"] = timed(lambda: heads(fused(backbone(x))), a.steps, 5) * 1e3
+        res["path_plus_heads_fused_ms"] = timed(lambda: path_heads_fused(feat), a.steps, 5) * 1e3
+        res["decode_ms"] = timed(lambda: decode({k: v.clone() for k, v in path_heads_fused(feat).items()}),
+                                 a.steps, 5) * 1e3 - res["path_plus_heads_fused_ms"]
+        res["e2e_fused_heads_ms"] = timed(lambda: decode(path_heads_fused(backbone(x))), a.steps, 5) * 1e3
+        res["e2e_fused_heads_img_s"] = a.batch / res["e2e_fused_heads_ms"] * 1e3
     # whole forward captured into one HIP graph (static input buffer)
     try:
         with torch.no_grad():
