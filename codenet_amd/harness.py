@@ -2,8 +2,9 @@
 PyTorch-ROCm: a ``PoseShuffleNetV2`` with the reference's module tree / state-dict keys
 (lib/models/networks/shufflenetv2_dcn.py:57-114,189-330) whose ``deconv_layers`` are this
 package's deform modules, ``ctdet_decode`` (lib/models/decode.py:10-16,110-127,474-505) and the
-body of ``CtdetDetector.process`` (lib/detectors/ctdet.py:29-46).  Only the three deform stages run
-on hand-written kernels; backbone and heads are stock torch ops (out of scope).
+body of ``CtdetDetector.process`` (lib/detectors/ctdet.py:29-46).  The three deform stages run on the
+hand-written kernels; with ``enable_fused()`` so do the detection heads (SURVEY.md section 8f row 1);
+the backbone and the decode are stock torch ops (rows 2-3, not built yet).
 """
 import hashlib
 
@@ -95,8 +96,22 @@ class PoseShuffleNetV2(nn.Module):
                 fc = nn.Conv2d(64, classes, kernel_size=1, stride=1, padding=0, bias=True)
             setattr(self, head, fc)
 
+    def enable_fused(self, flag=True):
+        """Inference on GPU tensors: run deconv_layers AND the heads on the fused HIP schedules
+        (pipeline.FusedHotPath.forward_nhwc -> pipeline.FusedHeads; nothing is materialised between
+        them).  The returned tensors are static buffers, overwritten by the next call."""
+        self._fused = bool(flag)
+        self._fpath = self._fheads = None
+        return self
+
     def forward(self, x):
         x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
+        if getattr(self, "_fused", False) and x.is_cuda and not torch.is_grad_enabled():
+            from . import pipeline
+            if self._fpath is None:
+                self._fpath = pipeline.FusedHotPath(self.deconv_layers)
+                self._fheads = pipeline.FusedHeads({h: getattr(self, h) for h in self.heads})
+            return [self._fheads(*self._fpath.forward_nhwc(x))]
         x = self.deconv_layers(x)
         return [{head: getattr(self, head)(x) for head in self.heads}]
 
