@@ -1,0 +1,336 @@
+// codenet_decode.hip -- ctdet_decode as two kernels.
+//
+// Reference (lib/models/decode.py:10-16 _nms, :110-127 _topk, :474-505 ctdet_decode; lib/models/
+// utils.py _gather_feat / _transpose_and_gather_feat):
+//     heat = heat * (max_pool2d(heat, 3, 1, 1) == heat)              3x3 peak filter, non-peaks -> 0
+//     per class top-K of heat.view(B, cat, H*W), then top-K of the cat*K survivors
+//     xs, ys = index % W, index / W (+ reg at that pixel, or + 0.5); wh at that pixel
+//     dets[b][k] = [xs - w/2, ys - h/2, xs + w/2, ys + h/2, score, class]
+// as ~25 framework launches incl. two sorts.  The two-level top-K equals the global top-K of the
+// masked map (the global top K can hold at most K entries of one class), so here:
+//   decode_keys_kernel   one workgroup per (image, class) plane: plane -> LDS, (sigmoid,) 3x3 peak test,
+//                        32-bit order-preserving key of the masked score for every pixel + per-image
+//                        histogram of the keys' top 12 bits
+//   decode_select_kernel one workgroup per image: radix refinement of the K-th key (12 + 12 + 8 bits,
+//                        re-histogramming only the threshold group), one collect pass, bitonic sort of
+//                        the <= 4096 collected (key, index) pairs in LDS, gather of reg / wh, boxes.
+// Ties (equal scores) are ordered by ascending flat index class*H*W + y*W + x; torch.topk leaves that
+// order unspecified (lib/models/decode.py:114,120), the oracle states the same rule.
+#include "cdn_common.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int kSelThreads = 1024;
+constexpr int kCap = 4096;          // capacity of the LDS candidate list
+constexpr int kBins = 2048;         // level-0 histogram: top 11 bits of the key
+constexpr int kKeyThreads = 512;
+
+__device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(kKeyThreads)
+decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
+                   unsigned *__restrict__ hist, float *__restrict__ heat_out, int cat, int H, int W,
+                   int apply_sigmoid) {
+  extern __shared__ float plane[];              // [(H + 2)][(W + 2)] with a -inf border
+  __shared__ unsigned lh[kBins];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int HW = H * W, Wp = W + 2;
+  const float *hp = heat + ((long)b * cat + c) * HW;
+  unsigned *kp = keys + ((long)b * cat + c) * HW;
+  float *op = heat_out ? heat_out + ((long)b * cat + c) * HW : nullptr;
+  for (int i = tid; i < kBins; i += kKeyThreads) lh[i] = 0;
+  for (int i = tid; i < 2 * (Wp + H); i += kKeyThreads) {      // the -inf border (max_pool2d padding)
+    int cell;
+    if (i < Wp) cell = i;
+    else if (i < 2 * Wp) cell = (H + 1) * Wp + (i - Wp);
+    else if (i < 2 * Wp + H) cell = (i - 2 * Wp + 1) * Wp;
+    else cell = (i - 2 * Wp - H + 1) * Wp + W + 1;
+    plane[cell] = -INFINITY;
+  }
+  const bool vec = (W & 3) == 0;
+  if (vec) {                                    // 16-byte loads, 8 in flight per thread
+    const int quads = HW >> 2;
+    for (int base = 0; base < quads; base += kKeyThreads * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = base + u * kKeyThreads + tid;
+        v[u] = q < quads ? reinterpret_cast<const float4 *>(hp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = base + u * kKeyThreads + tid;
+        if (q < quads) {
+          float4 t = v[u];
+          if (apply_sigmoid) {
+            t.x = sigmoidf_ref(t.x); t.y = sigmoidf_ref(t.y); t.z = sigmoidf_ref(t.z); t.w = sigmoidf_ref(t.w);
+          }
+          const int p = q * 4, y = p / W, x = p - y * W;
+          float *d = plane + (y + 1) * Wp + (x + 1);
+          d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+          if (op) reinterpret_cast<float4 *>(op)[q] = t;
+        }
+      }
+    }
+  } else {
+    for (int p = tid; p < HW; p += kKeyThreads) {
+      float v = hp[p];
+      if (apply_sigmoid) v = sigmoidf_ref(v);
+      plane[(p / W + 1) * Wp + (p % W + 1)] = v;
+      if (op) op[p] = v;
+    }
+  }
+  __syncthreads();
+  // non-peaks all carry the key of 0.0: counted per thread, ONE histogram atomic per thread at the end
+  // (16384 same-address LDS atomics per plane cost 250 us per launch)
+  const unsigned zkey = cdn::f2ord(0.0f);
+  unsigned zeros = 0;
+  auto key_of = [&](int p) -> unsigned {
+    const int y = p / W, x = p - y * W;
+    const float *q = plane + (y + 1) * Wp + (x + 1);
+    const float v = q[0];
+    float m = fmaxf(fmaxf(q[-Wp - 1], q[-Wp]), fmaxf(q[-Wp + 1], q[-1]));
+    m = fmaxf(m, fmaxf(fmaxf(q[1], q[Wp - 1]), fmaxf(q[Wp], q[Wp + 1])));
+    // hmax == heat  <=>  v >= every neighbour (NaN compares false, as in the reference)
+    const float s = (fmaxf(m, v) == v) ? v : v * 0.0f;
+    const unsigned k = cdn::f2ord(s + 0.0f);    // (+0.0f: -0 and +0 get the same key)
+    if (k == zkey) ++zeros;
+    else atomicAdd(&lh[k >> (32 - 11)], 1u);
+    return k;
+  };
+  if (vec) {
+    for (int q = tid; q < (HW >> 2); q += kKeyThreads) {
+      uint4 k4;
+      k4.x = key_of(q * 4); k4.y = key_of(q * 4 + 1); k4.z = key_of(q * 4 + 2); k4.w = key_of(q * 4 + 3);
+      reinterpret_cast<uint4 *>(kp)[q] = k4;
+    }
+  } else {
+    for (int p = tid; p < HW; p += kKeyThreads) kp[p] = key_of(p);
+  }
+  if (zeros) atomicAdd(&lh[zkey >> (32 - 11)], zeros);
+  __syncthreads();
+  for (int i = tid; i < kBins; i += kKeyThreads)
+    if (lh[i]) atomicAdd(&hist[(long)b * kBins + i], lh[i]);
+}
+
+// From the top bin down: the bin D with (count of bins > D) < need <= (count of bins >= D), by a block-wide
+// suffix scan over bin pairs (a single thread walking 2048 LDS words costs ~55 us per level).
+// Every thread of the workgroup calls it; nbins <= 2 * kSelThreads.  Results in *digit / *above (LDS).
+__device__ void find_digit(const unsigned *h, int nbins, unsigned need, unsigned *scan, int *digit,
+                           unsigned *above) {
+  const int tid = threadIdx.x, np = nbins >> 1;
+  const unsigned lo = tid < np ? h[2 * tid] : 0u, hi = tid < np ? h[2 * tid + 1] : 0u;
+  scan[tid] = lo + hi;
+  __syncthreads();
+  for (int off = 1; off < kSelThreads; off <<= 1) {       // inclusive suffix sums
+    const unsigned v = tid + off < kSelThreads ? scan[tid + off] : 0u;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  const unsigned mine = scan[tid], next = tid + 1 < kSelThreads ? scan[tid + 1] : 0u;
+  if (tid < np && mine >= need && next < need) {           // the pair that crosses `need`
+    if (next + hi >= need) {
+      *digit = 2 * tid + 1;
+      *above = next;
+    } else {
+      *digit = 2 * tid;
+      *above = next + hi;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kSelThreads)
+decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ hist,
+                     const float *__restrict__ wh, const float *__restrict__ reg,
+                     float *__restrict__ dets, int cat, int H, int W, int wh_ch, int K) {
+  __shared__ unsigned h[2048];
+  __shared__ unsigned long long list[kCap];
+  __shared__ unsigned scan[kSelThreads];
+  __shared__ int s_digit;
+  __shared__ unsigned s_above, s_n;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int HW = H * W;
+  const long total = (long)cat * HW;
+  const unsigned *kb = keys + (long)b * total;
+  const bool vec4 = (total & 3) == 0;            // (the key planes of an image are then 16-byte aligned)
+  unsigned *gh = hist + (long)b * kBins;
+  for (int i = tid; i < kBins; i += kSelThreads) {
+    h[i] = gh[i];
+    gh[i] = 0;                                   // leave the global histogram zero for the next call
+  }
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  unsigned need = (unsigned)K, pmask = 0, pval = 0;
+  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+  bool exhausted = false;
+  for (int lvl = 0;; ++lvl) {
+    find_digit(h, 1 << widths[lvl], need, scan, &s_digit, &s_above);
+    const unsigned digit = (unsigned)s_digit, group = h[digit];
+    need -= s_above;
+    pmask |= ((1u << widths[lvl]) - 1u) << shifts[lvl];
+    pval |= digit << shifts[lvl];
+    __syncthreads();
+    if (group + (unsigned)K <= (unsigned)kCap) break;      // the threshold group fits the list
+    if (lvl == 2) { exhausted = true; break; }             // a huge group of IDENTICAL keys
+    for (int i = tid; i < 2048; i += kSelThreads) h[i] = 0;
+    __syncthreads();
+    const int sh = shifts[lvl + 1];
+    const unsigned wm = (1u << widths[lvl + 1]) - 1u;
+    if (vec4) {
+      for (long q = tid; q < (total >> 2); q += kSelThreads) {
+        const uint4 k4 = reinterpret_cast<const uint4 *>(kb)[q];
+        if ((k4.x & pmask) == pval) atomicAdd(&h[(k4.x >> sh) & wm], 1u);
+        if ((k4.y & pmask) == pval) atomicAdd(&h[(k4.y >> sh) & wm], 1u);
+        if ((k4.z & pmask) == pval) atomicAdd(&h[(k4.z >> sh) & wm], 1u);
+        if ((k4.w & pmask) == pval) atomicAdd(&h[(k4.w >> sh) & wm], 1u);
+      }
+    } else {
+      for (long i = tid; i < total; i += kSelThreads) {
+        const unsigned k = kb[i];
+        if ((k & pmask) == pval) atomicAdd(&h[(k >> sh) & wm], 1u);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- collect: everything above the threshold group, and the group (or its first `need` by index)
+  if (!exhausted) {
+    auto take = [&](unsigned k, long i) {
+      if ((k & pmask) >= pval) {
+        const unsigned slot = atomicAdd(&s_n, 1u);
+        if (slot < (unsigned)kCap)
+          list[slot] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+      }
+    };
+    if (vec4) {
+      for (long q = tid; q < (total >> 2); q += kSelThreads) {
+        const uint4 k4 = reinterpret_cast<const uint4 *>(kb)[q];
+        take(k4.x, q * 4); take(k4.y, q * 4 + 1); take(k4.z, q * 4 + 2); take(k4.w, q * 4 + 3);
+      }
+    } else {
+      for (long i = tid; i < total; i += kSelThreads) take(kb[i], i);
+    }
+  } else {
+    // every thread owns a contiguous index range, so a block scan gives each group member its rank
+    const long chunk = (total + kSelThreads - 1) / kSelThreads;
+    const long i0 = (long)tid * chunk, i1 = min(total, i0 + chunk);
+    unsigned cnt = 0;
+    for (long i = i0; i < i1; ++i) {
+      const unsigned k = kb[i];
+      if (k > pval) {
+        const unsigned slot = atomicAdd(&s_n, 1u);
+        if (slot < (unsigned)kCap)
+          list[slot] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+      } else if (k == pval) {
+        ++cnt;
+      }
+    }
+    scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < kSelThreads; off <<= 1) {     // inclusive Hillis-Steele scan
+      const unsigned v = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    unsigned rank = scan[tid] - cnt;                      // exclusive
+    for (long i = i0; i < i1 && rank < need; ++i)
+      if (kb[i] == pval) {
+        const unsigned slot = atomicAdd(&s_n, 1u);
+        if (slot < (unsigned)kCap)
+          list[slot] = ((unsigned long long)pval << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        ++rank;
+      }
+  }
+  __syncthreads();
+  const unsigned n = min(s_n, (unsigned)kCap);
+  int nsort = 2;
+  while ((unsigned)nsort < n) nsort <<= 1;               // sort only as much as was collected
+  for (int i = tid; i < nsort; i += kSelThreads)
+    if ((unsigned)i >= n) list[i] = 0ull;                 // below every real entry
+  __syncthreads();
+  // ---- bitonic sort, descending (score desc, index asc through the inverted index) -------------
+  for (int k2 = 2; k2 <= nsort; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < nsort; i += kSelThreads) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = list[i], c = list[ixj];
+          const bool up = (i & k2) == 0;                  // descending blocks first
+          if (up ? (a < c) : (a > c)) {
+            list[i] = c;
+            list[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // ---- boxes ---------------------------------------------------------------------------------
+  for (int k = tid; k < K; k += kSelThreads) {
+    const unsigned long long e = list[k];
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull);
+    const float score = cdn::ord2f((unsigned)(e >> 32));
+    const int cls = (int)(idx / (unsigned)HW), pix = (int)(idx % (unsigned)HW);
+    float xs = (float)(pix % W), ys = (float)(pix / W);
+    if (reg) {
+      xs += reg[((long)b * 2 + 0) * HW + pix];
+      ys += reg[((long)b * 2 + 1) * HW + pix];
+    } else {
+      xs += 0.5f;
+      ys += 0.5f;
+    }
+    const int wc = wh_ch == 2 ? 0 : 2 * cls;              // cat_spec_wh: channel pair of the class
+    const float w = wh[((long)b * wh_ch + wc) * HW + pix];
+    const float hh = wh[((long)b * wh_ch + wc + 1) * HW + pix];
+    float *o = dets + ((long)b * K + k) * 6;
+    o[0] = xs - w / 2;
+    o[1] = ys - hh / 2;
+    o[2] = xs + w / 2;
+    o[3] = ys + hh / 2;
+    o[4] = score;
+    o[5] = (float)cls;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t cdn_ctdet_decode_workspace_bytes(int64_t B, int64_t cat, int64_t H, int64_t W) {
+  auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+  return r((size_t)(B * cat * H * W) * 4) + r((size_t)B * kBins * 4);
+}
+
+extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float *reg, int64_t B,
+                                int64_t cat, int64_t H, int64_t W, int cat_spec_wh, int K,
+                                int apply_sigmoid, float *heat_out, float *dets, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  CDN_REQUIRE(heat && wh && dets && workspace, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(B > 0 && cat > 0 && H > 0 && W > 0 && K > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(K <= 1024 && K <= cat * H * W, CDN_ERR_UNSUPPORTED, "K = %d unsupported", K);
+  CDN_REQUIRE(B <= 65535 && cat <= 65535 && cat * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED,
+              "shape too large");
+  CDN_REQUIRE((size_t)(H + 2) * (W + 2) * 4 <= 128 * 1024, CDN_ERR_UNSUPPORTED,
+              "heat-map plane %lldx%lld does not fit LDS", (long long)H, (long long)W);
+  CDN_REQUIRE(workspace_bytes >= cdn_ctdet_decode_workspace_bytes(B, cat, H, W) &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+              CDN_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+  unsigned *keys = static_cast<unsigned *>(workspace);
+  // the per-image histograms live in the LAST bytes: zero them once, every call leaves them zero
+  unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + workspace_bytes / 256 * 256 -
+                                                r((size_t)B * kBins * 4));
+  const size_t lds = (size_t)(H + 2) * (W + 2) * sizeof(float);
+  (void)hipFuncSetAttribute((const void *)decode_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  decode_keys_kernel<<<dim3((unsigned)cat, (unsigned)B), kKeyThreads, lds, st>>>(heat, keys, hist, heat_out,
+                                                                         (int)cat, (int)H, (int)W,
+                                                                         apply_sigmoid);
+  int rc = cdn::check_launch("ctdet decode keys");
+  if (rc) return rc;
+  decode_select_kernel<<<(unsigned)B, kSelThreads, 0, st>>>(keys, hist, wh, reg, dets, (int)cat, (int)H,
+                                                           (int)W, cat_spec_wh ? (int)(2 * cat) : 2, K);
+  return cdn::check_launch("ctdet decode select");
+}

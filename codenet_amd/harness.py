@@ -208,19 +208,59 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100):
     return torch.cat([bboxes, scores, clses], dim=2)
 
 
-def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K=100):
+_decode_ws = {}
+
+
+def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=False,
+                        heat_out=None):
+    """ctdet_decode on the HIP kernels (codenet_decode.hip, cdn_ctdet_decode): same arguments and result
+    as ``ctdet_decode``; apply_sigmoid=True takes logits (heat_out, if given, receives the sigmoid).
+    Equal scores are ordered by ascending flat index.  GPU float32 tensors only."""
+    from . import _native as N_
+    if not (heat.is_cuda and heat.dtype == torch.float32):
+        raise NotImplementedError("ctdet_decode_native needs float32 GPU tensors")
+    heat, wh = heat.contiguous(), wh.contiguous()
+    reg = reg.contiguous() if reg is not None else None
+    B, cat, H, W = heat.shape
+    lib = N_.lib()
+    need = lib.cdn_ctdet_decode_workspace_bytes(B, cat, H, W)
+    key = (heat.device, need)
+    if key not in _decode_ws:
+        _decode_ws.clear()
+        _decode_ws[key] = torch.zeros(need // 4 + 64, dtype=torch.int32, device=heat.device)
+    ws = _decode_ws[key]
+    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+    dets = torch.empty(B, K, 6, device=heat.device)
+    rc = lib.cdn_ctdet_decode(heat.data_ptr(), wh.data_ptr(), reg.data_ptr() if reg is not None else None,
+                              B, cat, H, W, int(bool(cat_spec_wh)), K, int(bool(apply_sigmoid)),
+                              heat_out.data_ptr() if heat_out is not None else None, dets.data_ptr(),
+                              ws_ptr, need, torch.cuda.current_stream(heat.device).cuda_stream)
+    N_.check(rc, "cdn_ctdet_decode")
+    return dets
+
+
+def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K=100, native_decode=None):
     """CtdetDetector.process (lib/detectors/ctdet.py:29-46): images [2,3,R,R] = image + its W-flip
-    when flip_test.  Returns (output dict, dets [1,K,6])."""
+    when flip_test.  Returns (output dict, dets [B,K,6]).  native_decode (default: on GPU tensors) runs
+    the peak filter / top-K / box assembly on the HIP kernels, without flip_test fused with the sigmoid."""
     with torch.no_grad():
         output = model(images)[-1]
+        if native_decode is None:
+            native_decode = output["hm"].is_cuda
+        reg = output["reg"] if reg_offset else None
+        if native_decode and not flip_test:
+            hm = output["hm"]
+            dets = ctdet_decode_native(hm, output["wh"], reg=reg, cat_spec_wh=cat_spec_wh, K=K,
+                                       apply_sigmoid=True, heat_out=hm)      # in place, like sigmoid_()
+            return output, dets
         hm = output["hm"].sigmoid_()
         wh = output["wh"]
-        reg = output["reg"] if reg_offset else None
         if flip_test:
             hm = (hm[0:1] + torch.flip(hm[1:2], [3])) / 2
             wh = (wh[0:1] + torch.flip(wh[1:2], [3])) / 2
             reg = reg[0:1] if reg is not None else None
-        dets = ctdet_decode(hm, wh, reg=reg, cat_spec_wh=cat_spec_wh, K=K)
+        decode = ctdet_decode_native if native_decode else ctdet_decode
+        dets = decode(hm, wh, reg=reg, cat_spec_wh=cat_spec_wh, K=K)
     return output, dets
 
 

@@ -260,6 +260,23 @@ int cdn_codenet_dw3x3_nhwc_forward(
     size_t workspace_bytes, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ctdet_decode (lib/models/decode.py:474-505 with _nms :10-16 and _topk :110-127; SURVEY.md section
+ * 8f row 2): 3x3 peak filter, top-K over all classes, reg / wh gather, boxes.
+ *   heat [B][cat][H][W]  scores (after sigmoid), or logits with apply_sigmoid != 0
+ *   wh   [B][2][H][W]    (cat_spec_wh != 0: [B][2*cat][H][W]);  reg [B][2][H][W] or NULL (-> +0.5)
+ *   heat_out  NULL, or [B][cat][H][W] receiving the (sigmoid of the) input -- may alias heat: the
+ *             in-place sigmoid_ of lib/detectors/ctdet.py:32
+ *   dets [B][K][6] = x1, y1, x2, y2, score, class;  K <= 1024
+ * Equal scores are ordered by ascending index class*H*W + y*W + x (torch.topk leaves it unspecified).
+ * workspace: cdn_ctdet_decode_workspace_bytes(B,cat,H,W) bytes, 256-byte aligned; its LAST
+ * round_up(B*8192, 256) bytes are histograms: zero them once, every call leaves them zero.
+ * ---------------------------------------------------------------------------------------- */
+size_t cdn_ctdet_decode_workspace_bytes(int64_t B, int64_t cat, int64_t H, int64_t W);
+int cdn_ctdet_decode(const float *heat, const float *wh, const float *reg, int64_t B, int64_t cat,
+                     int64_t H, int64_t W, int cat_spec_wh, int K, int apply_sigmoid, float *heat_out,
+                     float *dets, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (thread-local; off by default).
  * While enabled, each kernel of cdn_codenet_stage_fused_forward / cdn_codenet_unpack_nchw records
  * an event pair.  cdn_profile_read synchronises the recorded events and returns up to max_records

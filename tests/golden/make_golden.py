@@ -271,6 +271,26 @@ def make_head_w4a8(ref_qm):
     return t2n(out)
 
 
+def make_decode():
+    """The reference's ctdet_decode (lib/models/decode.py:474-505) on random score maps; the selected
+    scores are distinct floats, so torch.topk's unspecified tie order does not matter."""
+    from models.decode import ctdet_decode as ref_decode
+    g = torch.Generator().manual_seed(91)
+    out = {}
+    for tag, (B, cat, H, W, K, spec, use_reg) in {
+            "a": (2, 20, 32, 32, 100, False, True), "b": (1, 3, 17, 23, 40, True, False),
+            "c": (3, 5, 8, 8, 10, False, True)}.items():
+        heat = torch.sigmoid(torch.randn(B, cat, H, W, generator=g) * 2 - 2)
+        wh = torch.rand(B, 2 * cat if spec else 2, H, W, generator=g) * 10
+        reg = torch.rand(B, 2, H, W, generator=g) if use_reg else None
+        dets = ref_decode(heat.clone(), wh, reg=reg, cat_spec_wh=spec, K=K)
+        out[tag + "_cfg"] = np.array([B, cat, H, W, K, int(spec), int(use_reg)])
+        out[tag + "_heat"], out[tag + "_wh"], out[tag + "_dets"] = heat, wh, dets
+        if use_reg:
+            out[tag + "_reg"] = reg
+    return t2n(out)
+
+
 def make_deform_raw():
     g = torch.Generator().manual_seed(41)
     out = {}
@@ -350,6 +370,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "deform_raw.npz"), **make_deform_raw())
     np.savez_compressed(os.path.join(HERE, "model_io.npz"), **make_model_io(ref_qm))
     np.savez_compressed(os.path.join(HERE, "head_w4a8.npz"), **make_head_w4a8(ref_qm))
+    np.savez_compressed(os.path.join(HERE, "decode_ref.npz"), **make_decode())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,94 @@
+"""oracle/decode.py (numpy restatement of ctdet_decode) against the reference's own function
+(tests/golden/decode_ref.npz) and against the harness mirror; GPU: the HIP decode against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode as OD
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    z = np.load(os.path.join(G, "decode_ref.npz"))
+    for tag in ("a", "b", "c"):
+        B, cat, H, W, K, spec, use_reg = [int(v) for v in z[tag + "_cfg"]]
+        yield tag, z[tag + "_heat"], z[tag + "_wh"], (z[tag + "_reg"] if use_reg else None), bool(spec), K, \
+            z[tag + "_dets"]
+
+
+def test_decode_oracle_matches_reference_exactly():
+    for tag, heat, wh, reg, spec, K, ref in _cases():
+        d = OD.ctdet_decode(heat, wh, reg, spec, K)
+        assert d.shape == ref.shape
+        assert np.array_equal(d[..., 5], ref[..., 5]), tag          # classes (index work): exact
+        assert np.array_equal(d[..., 4], ref[..., 4]), tag          # scores are copies: exact
+        assert np.abs(d[..., :4] - ref[..., :4]).max() < 1e-5, tag  # box arithmetic
+
+
+def test_decode_oracle_matches_harness_mirror_and_tie_rule():
+    from codenet_amd import harness
+    g = torch.Generator().manual_seed(4)
+    heat = torch.sigmoid(torch.randn(2, 4, 12, 12, generator=g))
+    wh, reg = torch.rand(2, 2, 12, 12, generator=g) * 5, torch.rand(2, 2, 12, 12, generator=g)
+    ref = harness.ctdet_decode(heat.clone(), wh, reg=reg, K=20).numpy()
+    d = OD.ctdet_decode(heat.numpy(), wh.numpy(), reg.numpy(), False, 20)
+    assert np.array_equal(d[..., 4:], ref[..., 4:]) and np.abs(d - ref).max() < 1e-5
+    # ties: a constant map has one plateau -> every pixel is a peak with the same score; the rule is
+    # ascending flat index
+    flat = np.full((1, 2, 4, 4), 0.25, dtype=np.float32)
+    d = OD.ctdet_decode(flat, np.ones((1, 2, 4, 4), np.float32), None, False, 20)
+    assert np.array_equal(d[0, :, 5], np.array([0] * 16 + [1] * 4, dtype=np.float32))
+    assert np.array_equal(d[0, :4, 0], np.array([0, 1, 2, 3], np.float32) + 0.5 - 0.5)
+
+
+@pytest.mark.gpu
+def test_hip_decode_matches_oracle_and_reference():
+    from codenet_amd import harness
+    for tag, heat, wh, reg, spec, K, ref in _cases():
+        d = harness.ctdet_decode_native(torch.from_numpy(heat).cuda(), torch.from_numpy(wh).cuda(),
+                                        torch.from_numpy(reg).cuda() if reg is not None else None,
+                                        cat_spec_wh=spec, K=K).cpu().numpy()
+        o = OD.ctdet_decode(heat, wh, reg, spec, K)
+        assert np.array_equal(d[..., 4:], o[..., 4:]), tag            # scores + classes: bit-exact
+        assert np.abs(d[..., :4] - o[..., :4]).max() < 1e-5, tag
+        assert np.array_equal(d[..., 5], ref[..., 5]), tag            # and the reference's own output
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["full", "ties", "plateau", "few_peaks", "sigmoid"])
+def test_hip_decode_edge_cases(case):
+    from codenet_amd import harness
+    g = torch.Generator().manual_seed(12)
+    B, cat, H, W, K = 3, 20, 128, 128, 100
+    if case == "full":                       # the BASELINE shape, scores concentrated in a narrow band
+        heat = 0.15 + 0.01 * torch.rand(B, cat, H, W, generator=g)
+    elif case == "ties":                     # 8-bit quantised scores: thousands of equal peaks
+        heat = torch.round(torch.rand(B, cat, H, W, generator=g) * 255) / 255
+    elif case == "plateau":                  # one constant map: every key identical
+        heat = torch.full((B, cat, H, W), 0.5)
+    elif case == "few_peaks":                # fewer than K positive peaks: zeros fill up, by index
+        heat = torch.zeros(B, cat, H, W)
+        heat[:, 3, 5::40, 7::40] = torch.rand(B, 4, 4, generator=g) + 0.1
+        B, cat, H, W, K = 3, 20, 128, 128, 50
+    else:
+        heat = torch.randn(B, cat, H, W, generator=g) * 2
+    wh, reg = torch.rand(B, 2, H, W, generator=g) * 9, torch.rand(B, 2, H, W, generator=g)
+    if case == "sigmoid":
+        out = torch.empty_like(heat).cuda()
+        d = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda(), K=K, apply_sigmoid=True,
+                                        heat_out=out).cpu().numpy()
+        sg = out.cpu()
+        assert (sg - torch.sigmoid(heat)).abs().max().item() < 1e-6
+        o = OD.ctdet_decode(sg.numpy(), wh.numpy(), reg.numpy(), False, K)
+    else:
+        d = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda(), K=K).cpu().numpy()
+        o = OD.ctdet_decode(heat.numpy(), wh.numpy(), reg.numpy(), False, K)
+    assert np.array_equal(d[..., 4:], o[..., 4:])
+    assert np.abs(d[..., :4] - o[..., :4]).max() < 1e-4
+    # a second call re-uses the workspace (histograms must have been left zero)
+    d2 = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda(), K=K,
+                                     apply_sigmoid=(case == "sigmoid")).cpu().numpy()
+    assert np.array_equal(d, d2)

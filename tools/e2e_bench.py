@@ -69,6 +69,15 @@ def main():
                                  a.steps, 5) * 1e3 - res["path_plus_heads_fused_ms"]
         res["e2e_fused_heads_ms"] = timed(lambda: decode(path_heads_fused(backbone(x))), a.steps, 5) * 1e3
         res["e2e_fused_heads_img_s"] = a.batch / res["e2e_fused_heads_ms"] * 1e3
+
+        def decode_native(out):
+            return harness.ctdet_decode_native(out["hm"], out["wh"], reg=out["reg"], K=100,
+                                               apply_sigmoid=True, heat_out=out["hm"])
+        res["decode_native_ms"] = timed(lambda: decode_native(path_heads_fused(feat)), a.steps, 5) * 1e3 \
+            - res["path_plus_heads_fused_ms"]
+        res["e2e_all_native_tail_ms"] = timed(lambda: decode_native(path_heads_fused(backbone(x))),
+                                              a.steps, 5) * 1e3
+        res["e2e_all_native_tail_img_s"] = a.batch / res["e2e_all_native_tail_ms"] * 1e3
     # whole forward captured into one HIP graph (static input buffer)
     try:
         with torch.no_grad():
