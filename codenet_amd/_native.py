@@ -38,10 +38,14 @@ _SIGNATURES = {
     "cdn_codenet_unpack_nchw": (_i, [_vp] * 3 + [_i64] * 4 + [_i, _vp]),
     "cdn_codenet_aux_workspace_bytes": (ctypes.c_size_t, []),
     "cdn_codenet_pointwise_nhwc_forward": (
-        _i, [_vp, _vp] + [_i64] * 3 + [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
+        _i, [_vp, _vp] + [_i64] * 5 + [_vp] * 7 + [_i] + [_vp] * 3 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_dw3x3_nhwc_forward": (
-        _i, [_vp, _vp] + [_i64] * 4 + [_i] + [_vp] * 4 + [_i] + [_vp] * 3
+        _i, [_vp, _vp] + [_i64] * 4 + [_i, _i] + [_i64] * 2 + [_vp] * 4 + [_i] + [_vp] * 3
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
+    "cdn_codenet_interleave_forward": (
+        _i, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "cdn_codenet_stem_forward": (
+        _i, [_vp] + [_i64] * 4 + [_i] + [_vp, _vp, _i] + [_vp] * 3 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_ctdet_decode_workspace_bytes": (ctypes.c_size_t, [_i64] * 4),
     "cdn_ctdet_decode": (_i, [_vp] * 3 + [_i64] * 4 + [_i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "cdn_profile_enable": (_i, [_i]),

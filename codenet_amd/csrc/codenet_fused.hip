@@ -980,7 +980,7 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
            const float *__restrict__ Wp, const float *__restrict__ bias,
            const float *__restrict__ ep_scale, const float *__restrict__ ep_shift,
            float *__restrict__ R, float2 *rmm, cdn::QUpdate qu, long M, int C, int Co, int relu,
-           int only_if_wide) {
+           int only_if_wide, int lda, int ldo) {
   if (only_if_wide && !aq[6]) return;   // fallback launch behind pwi8_kernel: nothing to do
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
@@ -1017,7 +1017,7 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int i = 0; i < AI; ++i) {
     long m = m0 + lr + 32 * i;
     if (m > M - 1) m = M - 1;
-    arow[i] = A + m * C + lk;
+    arow[i] = A + m * lda + lk;
   }
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
@@ -1127,7 +1127,7 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
           float v = acc[i][j][r] + bsv;
           if (ep_scale) v = fmaf(v, es, eh);
           if (relu) v = fmaxf(v, 0.0f);
-          R[m * Co + co] = v;
+          R[m * ldo + co] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
         }
@@ -1163,7 +1163,8 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const int *__restrict__ wsum, const float *__restrict__ Wp,
             const float *__restrict__ bias, float *__restrict__ R,
-            float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu) {
+            float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu, int lda,
+            int ldo) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
@@ -1201,7 +1202,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
           const long m = min(m0 + row, M - 1);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (k0 + kq + e < C) v[e] = fake_quant(A[m * C + k0 + kq + e], qs, qz);
+            if (k0 + kq + e < C) v[e] = fake_quant(A[m * lda + k0 + kq + e], qs, qz);
         } else {
           const int co = min(n0 + row, Co - 1);
 #pragma unroll
@@ -1241,7 +1242,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
           if (m < M && co < Co) {
             float v = accf[i][j][r] + bsv;
             if (relu) v = fmaxf(v, 0.0f);
-            R[m * Co + co] = v;
+            R[m * ldo + co] = v;
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
           }
@@ -1268,7 +1269,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int i = 0; i < AI; ++i) {
     long m = m0 + lr + 32 * i;
     if (m > M - 1) m = M - 1;
-    arow[i] = A + m * C + lk;
+    arow[i] = A + m * lda + lk;
   }
   auto load_tile = [&](int k0) {
 #pragma unroll
@@ -1370,7 +1371,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         if (m < M && co < Co) {
           float v = fmaf((float)(acc[i][j][r] + t128), rinv, bsv);
           if (relu) v = fmaxf(v, 0.0f);
-          R[m * Co + co] = v;
+          R[m * ldo + co] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
         }
@@ -1447,29 +1448,32 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
 }
 
 // ------------------------------------------------------------------------------------------
-// dw3: plain depthwise 3x3 (pad 1, stride 1) on a channels-last activation that is optionally
-// nearest x2 up-sampled on the fly -- the detection heads' second layer (shufflenetv2_dcn.py:247-262,
-// quant_modules.py:1059-1066) applied to the hot path's half-resolution output.
-//   a   [n][Hs*Ws][C]   stored resolution (Hs = H >> up), fake-quantised while staged when aq != NULL
-//   out [n][H*W][C]     v = sum_{dy,dx} w[c][dy][dx] * U[h+dy-1][w+dx-1]  (+ bias) (* es + eh) (ReLU)
-// Workgroup = (image, band of kDw3Band stored rows, CCH = 32 channels): the band plus one halo row
-// on each side and one halo column on each side sit in LDS as [row][col][32] with zero halos; a lane
-// owns (stored pixel, channel quad), reads its 3x3 stored neighbourhood (9 ds_read_b128) and
-// produces the 2x2 (up = 1) or 1 (up = 0) output pixels of that stored pixel -- each of them as the
-// nine products of the reference's conv in (dy, dx) order, the up-sampling only decides which of the
-// nine cells a tap reads.
+// dw3: plain depthwise 3x3 (pad 1, stride 1 or 2) on a channels-last activation, optionally nearest x2
+// up-sampled on the fly -- the detection heads' second layer applied to the hot path's
+// half-resolution output (shufflenetv2_dcn.py:247-262, quant_modules.py:1059-1066) and the depthwise
+// convs of the ShuffleNetV2 units (shufflenetv2_dcn.py:57-114; stride 2 in the down-sampling units).
+//   a   [n][Hs*Ws][ld_in]   stored resolution, fake-quantised while staged when aq != NULL
+//   out [n][Ho*Wo][ld_out]  v = sum_{dy,dx} w[c][dy][dx] * U[s*oy+dy-1][s*ox+dx-1] (+ bias) (* es + eh) (ReLU)
+//        UP: U = nearest x2 of a (Ho = 2 Hs);  STRIDE 2: Ho = (Hs - 1) / 2 + 1
+// ld_in / ld_out >= C are the row strides; channels [C, ld) of a are read (must be finite) and ignored.
+// Workgroup = (image, band of kDw3Band output-side rows, 32 channels): the input rows of the band plus
+// halo sit in LDS as [row][col][32] with zero halos; a lane owns (pixel, channel quad), reads its 3x3
+// neighbourhood (9 ds_read_b128) and produces the 2x2 (UP) or 1 output pixels -- each as the nine
+// products of the reference's conv in (dy, dx) order; up-sampling only decides which cell a tap reads.
 // ------------------------------------------------------------------------------------------
 constexpr int kDw3Band = 2, kDw3CCH = 32;
-template <bool XQ, int UP>
+template <bool XQ, int UP, int STRIDE>
 __global__ void __launch_bounds__(256)
 dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const float *__restrict__ w,
            const float *__restrict__ bias, const float *__restrict__ ep_scale,
            const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
-           int C, int Hs, int Ws, int relu, int nbands) {
-  extern __shared__ float4 band4[];         // [(kDw3Band + 2)][Ws + 2][8 quads]
+           int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nbands) {
+  extern __shared__ float4 band4[];         // [rows][Ws + 2][8 quads]
   constexpr int LPP = kDw3CCH / 4;
+  constexpr int ROWS = STRIDE == 2 ? 2 * kDw3Band + 1 : kDw3Band + 2;
   const int band = blockIdx.x % nbands, c0 = (blockIdx.x / nbands) * kDw3CCH, n = blockIdx.y;
-  const int y0 = band * kDw3Band;
+  const int y0 = band * kDw3Band;                              // first row of the band (pixel-item space)
+  const int iy0 = STRIDE == 2 ? 2 * y0 - 1 : y0 - 1;           // first staged input row
   const int Wc = Ws + 2;
   const int tid = threadIdx.x;
   float qs = 1.f, qz = 0.f;
@@ -1478,30 +1482,28 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
     qz = reinterpret_cast<const float *>(aq)[3];
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // stage rows y0-1 .. y0+band, columns -1 .. Ws (zeros outside the image / beyond C)
-  const int items = (kDw3Band + 2) * Wc * LPP;
+  const int items = ROWS * Wc * LPP;
   for (int base = 0; base < items; base += 256 * 4) {
     float4 v[4];
+    bool in[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = base + u * 256 + tid;
       const int cq = q % LPP, cell = q / LPP;
       const int r = cell / Wc, col = cell - r * Wc;
-      const int y = y0 - 1 + r, x = col - 1;
+      const int y = iy0 + r, x = col - 1;
       v[u] = z4;
-      if (q < items && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws && c0 + cq * 4 + 3 < C)
-        v[u] = *reinterpret_cast<const float4 *>(a + ((long)n * Hs * Ws + (long)y * Ws + x) * C + c0 + cq * 4);
+      in[u] = q < items && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws &&
+              c0 + cq * 4 + 3 < ld_in;
+      if (in[u])
+        v[u] = *reinterpret_cast<const float4 *>(a + ((long)n * Hs * Ws + (long)y * Ws + x) * ld_in + c0 + cq * 4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = base + u * 256 + tid;
       if (q < items) {
         float4 t = v[u];
-        const int cq = q % LPP, cell = q / LPP;
-        const int r = cell / Wc, col = cell - r * Wc;
-        const bool inside = (unsigned)(y0 - 1 + r) < (unsigned)Hs && (unsigned)(col - 1) < (unsigned)Ws &&
-                            c0 + cq * 4 + 3 < C;
-        if (XQ && inside) {      // (the zero halo is a zero of the conv padding, not a quantised value)
+        if (XQ && in[u]) {       // (the zero halo is a zero of the conv padding, not a quantised value)
           t.x = fake_quant(t.x, qs, qz);
           t.y = fake_quant(t.y, qs, qz);
           t.z = fake_quant(t.z, qs, qz);
@@ -1512,30 +1514,34 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
     }
   }
   __syncthreads();
-  const int H = Hs << UP, W = Ws << UP;
+  // pixel items: stored pixels (UP / stride 1) or output pixels (stride 2)
+  const int Hi = STRIDE == 2 ? (Hs - 1) / 2 + 1 : Hs, Wi = STRIDE == 2 ? (Ws - 1) / 2 + 1 : Ws;
+  const int Ho = Hi << UP, Wo = Wi << UP;
   float mn = INFINITY, mx = -INFINITY;
-  const int work = kDw3Band * Ws * LPP;          // (stored pixel, channel quad) items of the band
+  const int work = kDw3Band * Wi * LPP;
   for (int q = tid; q < work; q += 256) {
     const int cq = q % LPP, pix = q / LPP;
-    const int ry = pix / Ws, X = pix - ry * Ws;
+    const int ry = pix / Wi, X = pix - ry * Wi;
     const int Y = y0 + ry;
     const int cb = c0 + cq * 4;
-    if (Y >= Hs || cb >= C) continue;
+    if (Y >= Hi || cb >= C) continue;
     float wk[9][4], bs[4], es[4], eh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      const bool live = cb + e < C;
       const int c = min(cb + e, C - 1);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) wk[k][e] = w[(long)c * 9 + k];
-      bs[e] = bias ? bias[c] : 0.0f;
-      es[e] = ep_scale ? ep_scale[c] : 1.0f;
-      eh[e] = ep_scale ? ep_shift[c] : 0.0f;
+      for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
+      bs[e] = (bias && live) ? bias[c] : 0.0f;
+      es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
+      eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
     }
     float4 V[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) V[i][j] = band4[((ry + i) * Wc + (X + j)) * LPP + cq];
+      for (int j = 0; j < 3; ++j)
+        V[i][j] = band4[((STRIDE * ry + i) * Wc + (STRIDE * X + j)) * LPP + cq];
 #pragma unroll
     for (int py = 0; py < (1 << UP); ++py)
 #pragma unroll
@@ -1554,7 +1560,7 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
             acc[2] = fmaf(wk[dy * 3 + dx][2], t.z, acc[2]);
             acc[3] = fmaf(wk[dy * 3 + dx][3], t.w, acc[3]);
           }
-        float *op = out + ((long)n * H * W + (long)((Y << UP) + py) * W + (X << UP) + px) * C + cb;
+        float *op = out + ((long)n * Ho * Wo + (long)((Y << UP) + py) * Wo + (X << UP) + px) * ld_out + cb;
         float r4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1563,15 +1569,18 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
           if (relu) v = fmaxf(v, 0.0f);
           r4[e] = v;
         }
-        if (cb + 3 < C) {
+        if (cb + 3 < ld_out && (ld_out & 3) == 0)
           *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { mn = fminf(mn, r4[e]); mx = fmaxf(mx, r4[e]); }
-        } else {
+        else
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (cb + e < C) { op[e] = r4[e]; mn = fminf(mn, r4[e]); mx = fmaxf(mx, r4[e]); }
-        }
+            if (cb + e < C) op[e] = r4[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + e < C) {          // padding channels do not take part in the range
+            mn = fminf(mn, r4[e]);
+            mx = fmaxf(mx, r4[e]);
+          }
       }
   }
   if (mm) {
@@ -1579,6 +1588,88 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
     cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
                              reinterpret_cast<float *>(band4));
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// interleave: the concat + channel_shuffle(groups = 2) that ends a ShuffleNetV2 unit
+// (shufflenetv2_dcn.py:43-49; quant_modules.py:905-907), with the block-output QuantAct applied:
+//     dst[m][2 i + 0] = fq_A(srcA[m][i])      dst[m][2 i + 1] = fq_B(srcB[m][i])        i < h
+// Either source may be NULL (its slots are left untouched: the two branches of a stride-2 unit are
+// quantised with DIFFERENT states of the shared QuantAct, so each is written right after its own range
+// update); a NULL state copies the values (the pass-through half of a stride-1 unit is already
+// quantised).  Elementwise, 8 bytes per lane, rows of any stride.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+interleave_kernel(const float *__restrict__ srcA, int ldA, const unsigned *__restrict__ qA,
+                  const float *__restrict__ srcB, int ldB, const unsigned *__restrict__ qB,
+                  float *__restrict__ dst, int ld_dst, long M, int h) {
+  float as = 1.f, az = 0.f, bs = 1.f, bz = 0.f;
+  if (qA) {
+    as = reinterpret_cast<const float *>(qA)[2];
+    az = reinterpret_cast<const float *>(qA)[3];
+  }
+  if (qB) {
+    bs = reinterpret_cast<const float *>(qB)[2];
+    bz = reinterpret_cast<const float *>(qB)[3];
+  }
+  const long total = M * h;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const long m = q / h;
+    const int i = (int)(q - m * h);
+    float *d = dst + m * ld_dst + 2 * i;
+    if (srcA) {
+      const float v = srcA[m * ldA + i];
+      d[0] = qA ? fake_quant(v, as, az) : v;
+    }
+    if (srcB) {
+      const float v = srcB[m * ldB + i];
+      d[1] = qB ? fake_quant(v, bs, bz) : v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stem: the network's first layer, a dense 3x3 conv 3 -> Co (stride 4 or 2, pad 1) + folded BN + ReLU on
+// the NCHW image (shufflenetv2_dcn.py:205-214; W4A8: QuantBnConv2d(8) quantize_model.py:26-34), output
+// channels-last.  One lane per output pixel: 27 inputs in registers, the Co x 27 weights read as
+// wave-uniform (scalar) loads, Co accumulators; min/max of the output in the epilogue.
+// ------------------------------------------------------------------------------------------
+template <int CO>
+__global__ void __launch_bounds__(256)
+stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const float *__restrict__ bias,
+            float *__restrict__ out, float2 *mm, cdn::QUpdate qu, int H, int W, int Ho, int Wo, int stride,
+            int relu) {
+  __shared__ float red[16];
+  const int n = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  float mn = INFINITY, mx = -INFINITY;
+  if (p < (long)Ho * Wo) {
+    const int oy = (int)(p / Wo), ox = (int)(p - (long)oy * Wo);
+    float v[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int y = oy * stride + dy - 1, x = ox * stride + dx - 1;
+          v[(c * 3 + dy) * 3 + dx] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                                         ? img[(((long)n * 3 + c) * H + y) * W + x] : 0.0f;
+        }
+    float *op = out + ((long)n * Ho * Wo + p) * CO;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+      acc += bias ? bias[co] : 0.0f;
+      if (relu) acc = fmaxf(acc, 0.0f);
+      op[co] = acc;
+      mn = fminf(mn, acc);
+      mx = fmaxf(mx, acc);
+    }
+  }
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu, red);
 }
 
 constexpr int kMaxPartials = 16384;  // per kernel; grids are clamped / checked against it
@@ -1649,18 +1740,22 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                             const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
                             const int *w_pw_colsum, const float *bias_pw, const float *ep_scale,
                             const float *ep_shift, int relu, float *r_out, float2 *rmm,
-                            const cdn::QUpdate &qu_r, int ptag, hipStream_t st) {
+                            const cdn::QUpdate &qu_r, int ptag, hipStream_t st, int64_t lda = 0,
+                            int64_t ldo = 0) {
+  if (lda == 0) lda = C;      // row strides of A / R in floats (views into wider channels-last tensors)
+  if (ldo == 0) ldo = Co;
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
   const int pw_bn = Co > 64 ? 128 : 64;
   int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
   if (const char *e = getenv("CDN_PW_BM")) pw_bm = (atoi(e) == 64 && Co > 64) ? 64 : 128;   // tuning knob
   const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-  const bool pw_fast = (C % 32) == 0;
+  const bool pw_fast = (C % 32) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
 #define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
   pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<(unsigned)std::min<long>(                             \
       cdn::ceil_div(M, BM_) * cdn::ceil_div(Co, BN_), only_if_wide ? 2L * cdn::kCUs : (1L << 30)), 256, 0, st>>>( \
-      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, only_if_wide)
+      d, dst, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, only_if_wide, \
+      (int)lda, (int)ldo)
 #define CDN_PW(BM_, BN_, WGM_, AQ_)                                       \
   do {                                                                    \
     if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
@@ -1680,11 +1775,11 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     if (pw_fast)                                                                                 \
       pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                            qu_r, M, (int)C, Cpad, (int)Co, relu); \
+                                                            qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo); \
     else                                                                                         \
       pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
                                                              w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                             qu_r, M, (int)C, Cpad, (int)Co, relu); \
+                                                             qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo); \
   } while (0)
     // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
     // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
@@ -1891,7 +1986,8 @@ inline bool aux_workspace(void *workspace, size_t bytes, AuxWs *w) {
 }  // namespace
 
 extern "C" int cdn_codenet_pointwise_nhwc_forward(
-    const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, const float *w,
+    const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, int64_t lda, int64_t ldo,
+    const float *w,
     const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias,
     const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
     int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
@@ -1902,8 +1998,11 @@ extern "C" int cdn_codenet_pointwise_nhwc_forward(
               "ep_scale / ep_shift must both be set or both be NULL");
   CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
               CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
-  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
-              CDN_ERR_ARG, "a / out must be 16-byte aligned");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0,
+              CDN_ERR_ARG, "a / out must be 4-byte aligned");
+  CDN_REQUIRE((lda == 0 || lda >= C) && (ldo == 0 || ldo >= Co), CDN_ERR_ARG,
+              "row strides must be 0 (dense) or >= the channel counts");
+  CDN_REQUIRE(M * std::max(lda, ldo) < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   AuxWs ws{nullptr, nullptr};
   if (r_state)
     CDN_REQUIRE(aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
@@ -1913,27 +2012,37 @@ extern "C" int cdn_codenet_pointwise_nhwc_forward(
                         (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
   return launch_pointwise(a, static_cast<unsigned *>(const_cast<void *>(a_qstate)), (long)M, C, Co, w,
                           w_codes, w_scale, w_colsum, bias, ep_scale, ep_shift, relu, out,
-                          r_state ? ws.partials : nullptr, qu, 0, st);
+                          r_state ? ws.partials : nullptr, qu, 0, st, lda, ldo);
 }
 
 extern "C" int cdn_codenet_dw3x3_nhwc_forward(
-    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up,
-    const float *w, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
-    float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
-    size_t workspace_bytes, float *out, void *stream) {
+    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up, int stride,
+    int64_t ld_in, int64_t ld_out, const float *w, const float *bias, const float *ep_scale,
+    const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream) {
   CDN_REQUIRE(a && w && out, CDN_ERR_ARG, "null pointer");
-  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1), CDN_ERR_ARG, "bad size");
-  CDN_REQUIRE(!up || ((H & 1) == 0 && (W & 1) == 0), CDN_ERR_SHAPE, "up needs even H, W");
-  CDN_REQUIRE((C & 3) == 0, CDN_ERR_UNSUPPORTED, "channels-last depthwise needs C %% 4 == 0");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1) && (stride == 1 || stride == 2),
+              CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(!(up && stride == 2), CDN_ERR_UNSUPPORTED, "up-sampling with stride 2");
+  if (ld_in == 0) ld_in = C;
+  if (ld_out == 0) ld_out = C;
+  CDN_REQUIRE(ld_in >= C && ld_out >= C && (ld_in & 3) == 0, CDN_ERR_UNSUPPORTED,
+              "channels-last depthwise needs row strides >= C and ld_in %% 4 == 0 (got %lld, %lld)",
+              (long long)ld_in, (long long)ld_out);
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0, CDN_ERR_ARG, "a must be 16-byte aligned");
   CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
               "ep_scale / ep_shift must both be set or both be NULL");
   CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
               CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
-  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
-  const int Hs = (int)(H >> up), Ws = (int)(W >> up);
-  const size_t lds = (size_t)(kDw3Band + 2) * (Ws + 2) * kDw3CCH * sizeof(float);
-  CDN_REQUIRE(lds <= 64 * 1024, CDN_ERR_UNSUPPORTED, "stored row of %d pixels too wide", Ws);
-  const int nbands = (int)cdn::ceil_div(Hs, kDw3Band), nchunks = (int)cdn::ceil_div(C, kDw3CCH);
+  // H, W: INPUT (stored) resolution; output = 2H x 2W (up), (H-1)/2+1 x (W-1)/2+1 (stride 2) or H x W
+  const int Hs = (int)H, Ws = (int)W;
+  const int Hi = stride == 2 ? (Hs - 1) / 2 + 1 : Hs;
+  CDN_REQUIRE(N <= 65535 && N * std::max(ld_in, ld_out) * H * W * (up ? 4 : 1) < (1ll << 31),
+              CDN_ERR_UNSUPPORTED, "shape too large");
+  const int rows = stride == 2 ? 2 * kDw3Band + 1 : kDw3Band + 2;
+  const size_t lds = (size_t)rows * (Ws + 2) * kDw3CCH * sizeof(float);
+  CDN_REQUIRE(lds <= 96 * 1024, CDN_ERR_UNSUPPORTED, "stored row of %d pixels too wide", Ws);
+  const int nbands = (int)cdn::ceil_div(Hi, kDw3Band), nchunks = (int)cdn::ceil_div(C, kDw3CCH);
   CDN_REQUIRE((long)nbands * nchunks * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
   AuxWs ws{nullptr, nullptr};
   if (r_state)
@@ -1946,13 +2055,65 @@ extern "C" int cdn_codenet_dw3x3_nhwc_forward(
   const unsigned *aq = static_cast<const unsigned *>(a_qstate);
   dim3 grid((unsigned)(nbands * nchunks), (unsigned)N);
   cdn::ProfScope ps(cdn::kProfDw, (int)(H > 0xffff ? 0xffff : H), st);
-#define CDN_GO(XQ_, UP_)                                                                          \
-  dw3_kernel<XQ_, UP_><<<grid, 256, lds, st>>>(a, aq, w, bias, ep_scale, ep_shift, out, mm, qu, (int)C, \
-                                               Hs, Ws, relu, nbands)
-  if (aq && up) CDN_GO(true, 1);
-  else if (aq) CDN_GO(true, 0);
-  else if (up) CDN_GO(false, 1);
-  else CDN_GO(false, 0);
+#define CDN_GO(XQ_, UP_, ST_)                                                                      \
+  {                                                                                                \
+    auto kern = dw3_kernel<XQ_, UP_, ST_>;                                                         \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)lds);                                                           \
+    kern<<<grid, 256, lds, st>>>(a, aq, w, bias, ep_scale, ep_shift, out, mm, qu, (int)C, (int)ld_in, \
+                                 (int)ld_out, Hs, Ws, relu, nbands);                               \
+  }
+  if (aq && up) CDN_GO(true, 1, 1)
+  else if (aq && stride == 2) CDN_GO(true, 0, 2)
+  else if (aq) CDN_GO(true, 0, 1)
+  else if (up) CDN_GO(false, 1, 1)
+  else if (stride == 2) CDN_GO(false, 0, 2)
+  else CDN_GO(false, 0, 1)
 #undef CDN_GO
   return cdn::check_launch("codenet dw3x3");
+}
+
+// dst[m][2i] = fq_A(srcA[m][i]), dst[m][2i+1] = fq_B(srcB[m][i]): see interleave_kernel.
+extern "C" int cdn_codenet_interleave_forward(const float *srcA, int64_t ldA, const void *qA,
+                                              const float *srcB, int64_t ldB, const void *qB,
+                                              int64_t M, int64_t h, float *dst, int64_t ld_dst,
+                                              void *stream) {
+  CDN_REQUIRE(dst && (srcA || srcB), CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(M > 0 && h > 0 && ld_dst >= 2 * h && (!srcA || ldA >= h) && (!srcB || ldB >= h),
+              CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(M * ld_dst < (1ll << 40), CDN_ERR_UNSUPPORTED, "shape too large");
+  hipStream_t st = cdn::as_stream(stream);
+  const long total = (long)(M * h);
+  const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(total, 256), (long)cdn::kCUs * 32);
+  interleave_kernel<<<blocks, 256, 0, st>>>(srcA, (int)ldA, static_cast<const unsigned *>(qA), srcB,
+                                            (int)ldB, static_cast<const unsigned *>(qB), dst,
+                                            (int)ld_dst, (long)M, (int)h);
+  return cdn::check_launch("codenet interleave");
+}
+
+// Dense 3x3 conv 3 -> Co on the NCHW image, channels-last output: see stem_kernel.
+extern "C" int cdn_codenet_stem_forward(const float *img, int64_t N, int64_t H, int64_t W, int64_t Co,
+                                        int stride, const float *w, const float *bias, int relu,
+                                        float *r_min, float *r_max, void *r_state, int bits,
+                                        double momentum, int running, void *workspace,
+                                        size_t workspace_bytes, float *out, void *stream) {
+  CDN_REQUIRE(img && w && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && H > 0 && W > 0 && stride >= 1, CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(Co == 24, CDN_ERR_UNSUPPORTED, "stem kernel is instantiated for 24 output channels (got %lld)",
+              (long long)Co);
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
+  const int Ho = (int)((H + 2 - 3) / stride + 1), Wo = (int)((W + 2 - 3) / stride + 1);
+  dim3 grid((unsigned)cdn::ceil_div((long)Ho * Wo, 256), (unsigned)N);
+  CDN_REQUIRE(N <= 65535 && (long)grid.x * grid.y <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
+  AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+  stem_kernel<24><<<grid, 256, 0, st>>>(img, w, bias, out, r_state ? ws.partials : nullptr, qu, (int)H,
+                                        (int)W, Ho, Wo, stride, relu);
+  return cdn::check_launch("codenet stem");
 }

@@ -96,22 +96,30 @@ class PoseShuffleNetV2(nn.Module):
                 fc = nn.Conv2d(64, classes, kernel_size=1, stride=1, padding=0, bias=True)
             setattr(self, head, fc)
 
-    def enable_fused(self, flag=True):
+    def enable_fused(self, flag=True, backbone=True):
         """Inference on GPU tensors: run deconv_layers AND the heads on the fused HIP schedules
         (pipeline.FusedHotPath.forward_nhwc -> pipeline.FusedHeads; nothing is materialised between
-        them).  The returned tensors are static buffers, overwritten by the next call."""
+        them) and, for a W4A8 model (backbone=True), layer0..layer4 on pipeline.FusedBackbone.  The
+        returned tensors are static buffers, overwritten by the next call."""
         self._fused = bool(flag)
-        self._fpath = self._fheads = None
+        self._fused_backbone = bool(backbone)
+        self._fpath = self._fheads = self._fbackbone = None
         return self
 
     def forward(self, x):
-        x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
         if getattr(self, "_fused", False) and x.is_cuda and not torch.is_grad_enabled():
             from . import pipeline
             if self._fpath is None:
                 self._fpath = pipeline.FusedHotPath(self.deconv_layers)
                 self._fheads = pipeline.FusedHeads({h: getattr(self, h) for h in self.heads})
+                self._fbackbone = (pipeline.FusedBackbone(self)
+                                   if self._fused_backbone and pipeline.FusedBackbone.supported(self) else None)
+            if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
+                feat, fq, hw = self._fbackbone(x)
+                return [self._fheads(*self._fpath.forward_nhwc(feat, fq, hw))]
+            x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
             return [self._fheads(*self._fpath.forward_nhwc(x))]
+        x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
         x = self.deconv_layers(x)
         return [{head: getattr(self, head)(x) for head in self.heads}]
 

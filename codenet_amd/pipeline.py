@@ -218,17 +218,22 @@ class FusedHotPath:
         N_.check(rc, "cdn_codenet_unpack_nchw")
         return B["out"]
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, x_qstate=None, hw=None):
         """The three stages WITHOUT the final materialisation: returns (r, r_qstate, shape) with r the
         last stage's output [N, H*W, Co] channels-last at stage resolution, pre-quantisation and not yet
         up-sampled, r_qstate the device pointer of its QuantAct state (None in fp32) and shape the
         stage's dict (Co, H, W).  Consumers (FusedHeads) fake-quantise on load and up-sample by
-        addressing."""
+        addressing.
+        x: the NCHW tensor the backbone hands over, or -- with hw=(H, W) -- a channels-last [N, H*W, C]
+        tensor holding PRE-quantisation values whose QuantAct state pointer is x_qstate (FusedBackbone)."""
         from . import _native as N_
         from . import ops
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
-            raise NotImplementedError("FusedHotPath needs a 4-D float32 GPU tensor")
+        nhwc_in = hw is not None
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == (3 if nhwc_in else 4)):
+            raise NotImplementedError("FusedHotPath needs a float32 GPU tensor: NCHW, or [N, H*W, C] with hw")
         x = x.contiguous()
+        if nhwc_in:
+            x = x.view(x.shape[0], hw[0], hw[1], x.shape[2]).permute(0, 3, 1, 2)   # logical NCHW view
         if self._bufs is None or self._bufs["shape"] != tuple(x.shape) or self._bufs["dev"] != x.device:
             self._alloc(x)
         B = self._bufs
@@ -238,7 +243,7 @@ class FusedHotPath:
         ws = B["ws"]
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         ws_bytes = (ws.numel() * 4 - (ws_ptr - ws.data_ptr())) // 256 * 256
-        cur, cur_nhwc, cur_q = x, 0, None
+        cur, cur_nhwc, cur_q = x, int(nhwc_in), (x_qstate if nhwc_in else None)
         with torch.no_grad():
             for st, sb in zip(self.stages, B["stages"]):
                 p = self._stage_params(st)
@@ -388,7 +393,7 @@ class FusedHeads:
             ep = layer["ep"] or (None, None)
             rec = ops._tic("head_pw", (layer["w"].shape[1], layer["w"].shape[0], m))
             rc = lib.cdn_codenet_pointwise_nhwc_forward(
-                a.data_ptr(), aq, m, layer["w"].shape[1], layer["w"].shape[0], ptr(layer["w"]),
+                a.data_ptr(), aq, m, layer["w"].shape[1], layer["w"].shape[0], 0, 0, ptr(layer["w"]),
                 ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(layer["bias"]), ptr(ep[0]), ptr(ep[1]),
                 layer["relu"], *act_args(layer["act"]), ws_ptr, ws_bytes, out.data_ptr(), stream)
             ops._toc(rec)
@@ -412,7 +417,7 @@ class FusedHeads:
                 ep = l2["ep"] or (None, None)
                 rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
                 rc = lib.cdn_codenet_dw3x3_nhwc_forward(
-                    B["y1"].data_ptr(), q1, Nb, C, 2 * Hs, 2 * Ws, 1, ptr(l2["w"]), ptr(l2["bias"]),
+                    B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
                     ptr(ep[0]), ptr(ep[1]), l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes,
                     B["y2"].data_ptr(), stream)
                 ops._toc(rec)
@@ -425,3 +430,173 @@ class FusedHeads:
                 N_.check(rc, "cdn_codenet_unpack_nchw")
                 outs[name] = B["out"][name]
         return outs
+
+
+class FusedBackbone:
+    """layer0 .. layer4 of a W4A8 ``PoseShuffleNetV2`` on the HIP kernels:
+    the reference's module tree after ``quantize_shufflenetv2_dcn`` (quantize_model.py:26-60) --
+    layer0 = QuantBnConv2d(8) + ReLU + QuantAct, layers 1-3 = QuantBaseNode units sharing one block-output
+    QuantAct per layer (quant_modules.py:809-907), layer4 = QuantBnConv2d + ReLU + QuantAct -- with the
+    same parameters and QuantAct buffers (updated in place, in the reference's order).
+
+    Activations are channels-last fp32.  A unit's three convolutions run on ONE half of the channels
+    through row-strided views (no split copy); intermediates hold pre-quantisation values and are
+    fake-quantised by their consumer while loading; concat + channel_shuffle is one interleave kernel
+    that also applies the shared block-output QuantAct, so a unit's output tensor holds final values.
+    Returns what ``FusedHotPath.forward_nhwc(x, x_qstate, hw)`` takes."""
+
+    def __init__(self, model, int8_pointwise=True):
+        self.model = model
+        self.int8 = int8_pointwise
+        self._bufs = None
+
+    @staticmethod
+    def supported(model):
+        from .portable_quantizer.quant_modules import QuantAct, QuantBaseNode, QuantBnConv2d
+        try:
+            l0, l4 = model.layer0, model.layer4
+            ok = (isinstance(l0[0], QuantBnConv2d) and len(l0[1]) == 2 and isinstance(l0[1][1], QuantAct)
+                  and l0[0].conv.out_channels == 24 and l0[0].conv.in_channels == 3
+                  and tuple(l0[0].conv.kernel_size) == (3, 3) and tuple(l0[0].conv.padding) == (1, 1)
+                  and isinstance(l4[0], QuantBnConv2d) and isinstance(l4[1][1], QuantAct))
+            for name in ("layer1", "layer2", "layer3"):
+                for node in getattr(model, name):
+                    ok = ok and isinstance(node, QuantBaseNode) and node.quant_act.quant_mode == "asymmetric" \
+                        and node.quant_act2.quant_mode == "asymmetric"
+            return bool(ok)
+        except (AttributeError, IndexError, TypeError):
+            return False
+
+    # -- low-level launches ----------------------------------------------------------------------
+    def _act_args(self, act, dev):
+        if act is None:
+            return [None, None, None, 8, 0.99, 0]
+        return [act.x_min.data_ptr(), act.x_max.data_ptr(), act._device_state(dev).data_ptr(),
+                act.activation_bit, act.momentum, int(act.running_stat)]
+
+    def _pw(self, a_ptr, a_q, M, lda, convbn, relu, act, out, ldo):
+        from . import _native as N_
+        w, b = convbn.folded()
+        Co, C = w.shape[0], w.shape[1]
+        i8 = convbn.folded_int8() if (self.int8 and a_q is not None) else None
+        i8 = i8 if i8 is not None else (None, None, None)
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        w2 = w.reshape(Co, C)
+        rc = N_.lib().cdn_codenet_pointwise_nhwc_forward(
+            a_ptr, a_q, M, C, Co, lda, ldo, w2.data_ptr(), ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(b),
+            None, None, int(relu), *self._act_args(act, out.device), self._ws_ptr, self._ws_bytes,
+            out.data_ptr(), self._stream)
+        N_.check(rc, "cdn_codenet_pointwise_nhwc_forward")
+
+    def _dw(self, a, a_q, N, C, H, W, stride, ld_in, convbn, act, out, ld_out):
+        from . import _native as N_
+        w, b = convbn.folded()
+        rc = N_.lib().cdn_codenet_dw3x3_nhwc_forward(
+            a.data_ptr(), a_q, N, C, H, W, 0, stride, ld_in, ld_out, w.reshape(C, 9).data_ptr(), b.data_ptr(),
+            None, None, 0, *self._act_args(act, out.device), self._ws_ptr, self._ws_bytes, out.data_ptr(),
+            self._stream)
+        N_.check(rc, "cdn_codenet_dw3x3_nhwc_forward")
+
+    def _il(self, srcA, ldA, qA, srcB, ldB, qB, M, h, dst, ld_dst):
+        from . import _native as N_
+        rc = N_.lib().cdn_codenet_interleave_forward(srcA, ldA, qA, srcB, ldB, qB, M, h, dst.data_ptr(),
+                                                     ld_dst, self._stream)
+        N_.check(rc, "cdn_codenet_interleave_forward")
+
+    # -- buffers -----------------------------------------------------------------------------------
+    def _alloc(self, images):
+        from . import _native as N_
+        m = self.model
+        Nb, _, R, R2 = images.shape
+        dev = images.device
+        s0 = m.layer0[0].conv.stride[0]
+        H, W = (R + 2 - 3) // s0 + 1, (R2 + 2 - 3) // s0 + 1
+        pad4 = lambda c: (c + 3) // 4 * 4   # noqa: E731
+        bufs = dict(key=(tuple(images.shape), dev), t0=torch.empty(Nb, H * W, 24, device=dev), hw0=(H, W))
+        layers = []
+        cin = 24
+        for name in ("layer1", "layer2", "layer3"):
+            nodes = list(getattr(m, name))
+            oup = 2 * nodes[0].quant_convbn3.conv.out_channels
+            h = oup // 2
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            Mi, Mo = Nb * H * W, Nb * Ho * Wo
+            layers.append(dict(
+                nodes=nodes, cin=cin, C=oup, h=h, ldh=pad4(h), Hin=H, Win=W, H=Ho, W=Wo,
+                t4=torch.zeros(Mo, pad4(cin), device=dev), t5=torch.zeros(Mo, pad4(h), device=dev),
+                t1s2=torch.zeros(Mi, pad4(h), device=dev),             # pw1 of the stride-2 unit: input res
+                t1=torch.zeros(Mo, pad4(h), device=dev), t2=torch.zeros(Mo, pad4(h), device=dev),
+                t3=torch.zeros(Mo, pad4(h), device=dev),
+                ya=torch.zeros(Mo, oup, device=dev), yb=torch.zeros(Mo, oup, device=dev)))
+            cin, H, W = oup, Ho, Wo
+        bufs["layers"] = layers
+        c4 = m.layer4[0].conv.out_channels
+        bufs["out"] = torch.empty(Nb, H * W, c4, device=dev)
+        bufs["hw4"] = (H, W)
+        aux = N_.lib().cdn_codenet_aux_workspace_bytes()
+        bufs["ws"] = torch.zeros(aux // 4 + 64, device=dev)             # arrival counters start at zero
+        self._bufs = bufs
+
+    def __call__(self, images):
+        from . import _native as N_
+        if not (images.is_cuda and images.dtype == torch.float32 and images.dim() == 4
+                and images.shape[1] == 3):
+            raise NotImplementedError("FusedBackbone needs a [N,3,H,W] float32 GPU tensor")
+        images = images.contiguous()
+        if self._bufs is None or self._bufs["key"] != (tuple(images.shape), images.device):
+            self._alloc(images)
+        B, m, dev = self._bufs, self.model, images.device
+        ws = B["ws"]
+        self._ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        self._ws_bytes = (ws.numel() * 4 - (self._ws_ptr - ws.data_ptr())) // 256 * 256
+        self._stream = torch.cuda.current_stream(dev).cuda_stream
+        Nb = images.shape[0]
+        qptr = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
+        with torch.no_grad():
+            # ---- layer0: dense 3x3 conv + folded BN + ReLU, range of its QuantAct ------------------
+            q0, act0 = m.layer0[0], m.layer0[1][1]
+            w0, b0 = q0.folded()
+            rc = N_.lib().cdn_codenet_stem_forward(
+                images.data_ptr(), Nb, images.shape[2], images.shape[3], 24, q0.conv.stride[0],
+                w0.reshape(24, 27).data_ptr(), b0.data_ptr(), 1, *self._act_args(act0, dev), self._ws_ptr,
+                self._ws_bytes, B["t0"].data_ptr(), self._stream)
+            N_.check(rc, "cdn_codenet_stem_forward")
+            x, x_ld, x_q = B["t0"], 24, qptr(act0)          # pre-quantisation values + state
+            for L in B["layers"]:
+                h, ldh, C = L["h"], L["ldh"], L["C"]
+                Mi, Mo = Nb * L["Hin"] * L["Win"], Nb * L["H"] * L["W"]
+                y, y_other = L["ya"], L["yb"]
+                for node in L["nodes"]:
+                    sh = node.quant_act                       # the layer's shared block-output QuantAct
+                    if node.stride == 2:
+                        cin = L["cin"]
+                        # branch 1 (reference order: first): dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
+                        self._dw(x, x_q, Nb, cin, L["Hin"], L["Win"], 2, x_ld, node.quant_convbn4,
+                                 node.quant_act4, L["t4"], L["t4"].shape[1])
+                        self._pw(L["t4"].data_ptr(), qptr(node.quant_act4), Mo, L["t4"].shape[1],
+                                 node.quant_convbn5, True, sh, L["t5"], ldh)
+                        self._il(L["t5"].data_ptr(), ldh, qptr(sh), None, 0, None, Mo, h, y, C)
+                        # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
+                        self._pw(x.data_ptr(), x_q, Mi, x_ld, node.quant_convbn1, True, node.quant_act1,
+                                 L["t1s2"], ldh)
+                        self._dw(L["t1s2"], qptr(node.quant_act1), Nb, h, L["Hin"], L["Win"], 2, ldh,
+                                 node.quant_convbn2, node.quant_act2, L["t2"], ldh)
+                        self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
+                                 sh, L["t3"], ldh)
+                        self._il(None, 0, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
+                    else:
+                        # x holds FINAL values; x1 = x[:, :h] passes through, x2 = x[:, h:] is a strided view
+                        self._pw(x.data_ptr() + 4 * h, None, Mo, C, node.quant_convbn1, True,
+                                 node.quant_act1, L["t1"], ldh)
+                        self._dw(L["t1"], qptr(node.quant_act1), Nb, h, L["H"], L["W"], 1, ldh,
+                                 node.quant_convbn2, node.quant_act2, L["t2"], ldh)
+                        self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
+                                 sh, L["t3"], ldh)
+                        self._il(x.data_ptr(), C, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
+                    x, x_ld, x_q = y, C, None
+                    y, y_other = y_other, y
+            # ---- layer4: 1x1 conv + folded BN + ReLU, range of its QuantAct ---------------------------
+            q4, act4 = m.layer4[0], m.layer4[1][1]
+            M4 = Nb * B["hw4"][0] * B["hw4"][1]
+            self._pw(x.data_ptr(), x_q, M4, x_ld, q4, True, act4, B["out"], 0)
+        return B["out"], qptr(act4), B["hw4"]

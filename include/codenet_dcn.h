@@ -241,23 +241,52 @@ int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *ou
 size_t cdn_codenet_aux_workspace_bytes(void);
 
 /* out[m][co] = act( sum_c fq(a[m][c]) * w[co][c] + bias[co] ) (* ep_scale + ep_shift before act),
- * a [M][C], w [Co][C] fp32 (fake-quantised already for W4A8).  w_codes / w_scale / w_colsum: optional
- * integer form as in cdn_codenet_stage_fused_forward (int8 MFMA when a_qstate is given too). */
+ * a [M][C] with row stride lda floats, out [M][Co] with row stride ldo (0 = dense; strides let a and
+ * out be channel ranges of wider channels-last tensors: the split halves of a ShuffleNetV2 unit),
+ * w [Co][C] fp32 (fake-quantised already for W4A8).  w_codes / w_scale / w_colsum: optional integer
+ * form as in cdn_codenet_stage_fused_forward (int8 MFMA when a_qstate is given too). */
 int cdn_codenet_pointwise_nhwc_forward(
-    const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, const float *w,
+    const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, int64_t lda, int64_t ldo,
+    const float *w,
     const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias,
     const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
     int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
     void *stream);
 
-/* Depthwise 3x3, pad 1, stride 1, channels-last: a [N][(H>>up)*(W>>up)][C] (nearest x2 up-sampled on
- * the fly when up = 1), w [C][9], bias / ep_scale / ep_shift [C] or NULL, out [N][H*W][C].
- * C % 4 == 0. */
+/* Depthwise 3x3, pad 1, stride 1 or 2, channels-last: a [N][H*W][ld_in] at its STORED resolution H x W,
+ * w [C][9], bias / ep_scale / ep_shift [C] or NULL, out [N][Ho*Wo][ld_out] with
+ *   up = 1 (stride 1 only): the input is nearest x2 up-sampled on the fly, Ho x Wo = 2H x 2W
+ *   stride = 2:             Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1);      otherwise Ho x Wo = H x W.
+ * ld_in / ld_out: row strides in floats (0 = C), >= C, ld_in % 4 == 0; channels [C, ld_in) of a are read
+ * and ignored (padding of an internal buffer: must be finite); they take no part in the range. */
 int cdn_codenet_dw3x3_nhwc_forward(
-    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up,
-    const float *w, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
-    float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
-    size_t workspace_bytes, float *out, void *stream);
+    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up, int stride,
+    int64_t ld_in, int64_t ld_out, const float *w, const float *bias, const float *ep_scale,
+    const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The backbone's remaining layer types (lib/models/networks/
+ * shufflenetv2_dcn.py:57-114,205-240; W4A8: QuantBaseNode quant_modules.py:809-907, layer0 / layer4
+ * quantize_model.py:26-34,56-60).  A ShuffleNetV2 unit is pointwise -> depthwise 3x3 -> pointwise on
+ * one half of the channels (cdn_codenet_pointwise_nhwc_forward with row strides,
+ * cdn_codenet_dw3x3_nhwc_forward) followed by concat + channel_shuffle(2), which is
+ *   dst[m][2i] = fq_A(srcA[m][i]),  dst[m][2i+1] = fq_B(srcB[m][i]),  i < h
+ * with the block-output QuantAct applied (qA / qB: QuantAct state, NULL = copy).  Either source may be
+ * NULL: its slots stay untouched (the two branches of a stride-2 unit are quantised with different
+ * states of the layer's shared QuantAct, so each is written right after its own range update).
+ * ---------------------------------------------------------------------------------------- */
+int cdn_codenet_interleave_forward(const float *srcA, int64_t ldA, const void *qA, const float *srcB,
+                                   int64_t ldB, const void *qB, int64_t M, int64_t h, float *dst,
+                                   int64_t ld_dst, void *stream);
+
+/* layer0: dense 3x3 conv 3 -> Co (Co = 24), pad 1, on the NCHW image img [N][3][H][W]; w [Co][27]
+ * (BN folded, fake-quantised for W4A8), bias [Co] or NULL; out [N][Ho*Wo][Co] channels-last,
+ * Ho = (H + 2 - 3) / stride + 1.  Range tracking of the following QuantAct as above. */
+int cdn_codenet_stem_forward(const float *img, int64_t N, int64_t H, int64_t W, int64_t Co, int stride,
+                             const float *w, const float *bias, int relu, float *r_min, float *r_max,
+                             void *r_state, int bits, double momentum, int running, void *workspace,
+                             size_t workspace_bytes, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * ctdet_decode (lib/models/decode.py:474-505 with _nms :10-16 and _topk :110-127; SURVEY.md section

@@ -1,0 +1,135 @@
+"""GPU parity of the backbone building blocks against plain PyTorch fp32
+references of the same ops, then of the whole fused backbone against the module path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ws(lib, dev):
+    aux = lib.cdn_codenet_aux_workspace_bytes()
+    ws = torch.zeros(aux // 4 + 64, device=dev)
+    ptr = (ws.data_ptr() + 255) // 256 * 256
+    return ws, ptr, (ws.numel() * 4 - (ptr - ws.data_ptr())) // 256 * 256
+
+
+@pytest.mark.parametrize("N,C,H,W,up,stride,ld", [
+    (2, 58, 12, 10, 0, 1, 60), (2, 58, 12, 10, 0, 2, 60), (1, 24, 9, 7, 0, 2, 24), (2, 116, 8, 8, 0, 1, 116),
+    (2, 16, 6, 6, 1, 1, 16), (1, 232, 5, 5, 0, 2, 232)])
+def test_dw3x3_strides_and_row_strides(N, C, H, W, up, stride, ld):
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(C * 7 + stride)
+    x = torch.randn(N, C, H, W, generator=g).to(dev)
+    a = torch.full((N, H * W, ld), 3.0, device=dev)              # padding channels: finite garbage
+    a[:, :, :C] = x.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    w = torch.randn(C, 1, 3, 3, generator=g).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    xu = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xu, w, b, stride, 1, 1, C)
+    Ho, Wo = ref.shape[2:]
+    out = torch.full((N, Ho * Wo, ld), -7.0, device=dev)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    rc = lib.cdn_codenet_dw3x3_nhwc_forward(
+        a.data_ptr(), None, N, C, H, W, up, stride, ld, ld, w.data_ptr(), b.data_ptr(), None, None, 0,
+        xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(),
+        torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "dw3")
+    got = out[:, :, :C].reshape(N, Ho, Wo, C).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 1e-5
+    # the range covers the real channels only (first call: += initialisation)
+    assert abs(xmin.item() - ref.min().item()) < 1e-5 and abs(xmax.item() - ref.max().item()) < 1e-5
+
+
+def test_pointwise_row_strides_and_interleave():
+    from codenet_amd import _native as N_
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    M, C, h = 300, 116, 58
+    y = torch.randn(M, C, generator=g).to(dev)                  # a unit input: x1 = y[:, :h], x2 = y[:, h:]
+    w = torch.randn(h, h, generator=g).to(dev)
+    b = torch.randn(h, generator=g).to(dev)
+    t = torch.zeros(M, 60, device=dev)                           # padded intermediate (ld 60)
+    x2 = y[:, h:]
+    rc = lib.cdn_codenet_pointwise_nhwc_forward(
+        x2.data_ptr(), None, M, h, h, C, 60, w.data_ptr(), None, None, None, b.data_ptr(), None, None, 1,
+        None, None, None, 8, 0.99, 0, None, 0, t.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "pw")
+    ref = torch.relu(x2 @ w.t() + b)
+    assert (t[:, :h] - ref).abs().max().item() < 1e-4 and t[:, h:].abs().max().item() == 0.0
+    out = torch.zeros(M, C, device=dev)
+    rc = lib.cdn_codenet_interleave_forward(y.data_ptr(), C, None, t.data_ptr(), 60, None, M, h,
+                                            out.data_ptr(), C, torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "interleave")
+    from codenet_amd.portable_quantizer.quant_modules import channel_shuffle
+    exp = channel_shuffle(torch.cat((y[:, :h], ref), 1).view(M, C, 1, 1), 2).view(M, C)
+    assert (out - exp).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("stride,R", [(4, 64), (2, 50), (4, 37)])
+def test_stem_conv(stride, R):
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(R)
+    img = torch.randn(2, 3, R, R, generator=g).to(dev)
+    w = (torch.randn(24, 3, 3, 3, generator=g) * 0.3).to(dev)
+    b = torch.randn(24, generator=g).to(dev)
+    ref = torch.relu(F.conv2d(img, w, b, stride, 1))
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty(2, Ho * Wo, 24, device=dev)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    rc = lib.cdn_codenet_stem_forward(img.data_ptr(), 2, R, R, 24, stride, w.data_ptr(), b.data_ptr(), 1,
+                                      xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb,
+                                      out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "stem")
+    got = out.view(2, Ho, Wo, 24).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 1e-5
+    assert abs(xmax.item() - ref.max().item()) < 1e-5 and xmin.item() == 0.0
+
+
+@pytest.mark.parametrize("res,batch", [(64, 2), (96, 3)])
+def test_fused_backbone_matches_modules(res, batch):
+    """FusedBackbone (stem, 16 ShuffleNetV2 units, layer4 on the HIP kernels) vs the mirrored modules on
+    PyTorch-ROCm over 3 forwards: every QuantAct range, and the layer4 output after its QuantAct."""
+    import copy
+    from codenet_amd import harness, pipeline
+    model = harness.create_model(quantize=True)
+    ma, mb = copy.deepcopy(model).cuda(), copy.deepcopy(model).cuda()
+    assert pipeline.FusedBackbone.supported(mb)
+    fb = pipeline.FusedBackbone(mb)
+    g = torch.Generator().manual_seed(res)
+    for it in range(3):
+        x = (torch.randn(batch, 3, res, res, generator=g) * (1.0 + 0.3 * it)).cuda()
+        with torch.no_grad():
+            ref = ma.layer4(ma.layer3(ma.layer2(ma.layer1(ma.layer0(x)))))
+        feat, fq, hw = fb(x)
+        act4 = mb.layer4[1][1]
+        from codenet_amd import ops
+        got, _ = ops.quantact_forward(feat.clone(), act4.x_min.clone(), act4.x_max.clone(),
+                                      act4._device_state(x.device).clone(), bits=8, momentum=0.99, running=False)
+        got = got.view(batch, hw[0], hw[1], -1).permute(0, 3, 1, 2)
+        assert got.shape == ref.shape
+        diff = (got - ref).abs()
+        lsb = (act4.x_max - act4.x_min).item() / 255.0
+        # The int8 pointwise sums are exact integers, the module path's fp32 convs round: pre-quantisation
+        # values differ at 1e-7 relative, so about one value per 1e5 crosses a rounding boundary.  Such a
+        # one-LSB code flip is re-amplified by every following unit (observed: one flip in layer1 unit 3
+        # -> 11 % of the layer4 outputs off by more than 1.5 LSB, ranges off by 3e-4 relative; with no
+        # flip -- e.g. seed 64, 128x128 -- all 40 ranges agree to 6e-7 and the output is identical).
+        # Bounded, not exact; the whole-model test in test_harness.py checks the end result against the
+        # reference model at the reference's own re-association floor.
+        assert diff.max().item() < 16 * lsb + 1e-4, (diff.max().item(), lsb)
+        assert diff.mean().item() < 0.6 * lsb
+    acts_a = [m for m in ma.modules() if hasattr(m, "x_min") and isinstance(m.x_min, torch.Tensor)]
+    acts_b = [m for m in mb.modules() if hasattr(m, "x_min") and isinstance(m.x_min, torch.Tensor)]
+    checked = 0
+    for a, b in zip(acts_a, acts_b):
+        if a.x_max.item() == 0.0 and a.x_min.item() == 0.0:
+            continue                      # heads / deform stages were not run
+        tol = 3e-2 * (a.x_max.abs().item() + a.x_min.abs().item()) + 1e-4
+        assert (a.x_min - b.x_min).abs().item() < tol and (a.x_max - b.x_max).abs().item() < tol
+        checked += 1
+    assert checked >= 16 * 2 + 3

@@ -634,14 +634,14 @@ def test_fused_heads_match_reference_golden():
                     act.activation_bit, act.momentum, int(act.running_stat)]
         i8 = l1["i8"]
         N_.check(lib.cdn_codenet_pointwise_nhwc_forward(
-            a.data_ptr(), None, M, C, C, ptr(l1["w"]), ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(l1["bias"]),
+            a.data_ptr(), None, M, C, C, 0, 0, ptr(l1["w"]), ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(l1["bias"]),
             None, None, 1, *act_args(a1), ws_ptr, ws_bytes, y1.data_ptr(), st), "pw1")
         N_.check(lib.cdn_codenet_dw3x3_nhwc_forward(
-            y1.data_ptr(), a1._device_state(dev).data_ptr(), Nb, C, H, W, 0, ptr(l2["w"]), ptr(l2["bias"]),
+            y1.data_ptr(), a1._device_state(dev).data_ptr(), Nb, C, H, W, 0, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
             None, None, 1, *act_args(a3), ws_ptr, ws_bytes, y2.data_ptr(), st), "dw")
         i8 = l3["i8"]
         N_.check(lib.cdn_codenet_pointwise_nhwc_forward(
-            y2.data_ptr(), a3._device_state(dev).data_ptr(), M, C, classes, ptr(l3["w"]), ptr(i8[0]),
+            y2.data_ptr(), a3._device_state(dev).data_ptr(), M, C, classes, 0, 0, ptr(l3["w"]), ptr(i8[0]),
             ptr(i8[1]), ptr(i8[2]), ptr(l3["bias"]), None, None, 0, None, None, None, 8, 0.99, 0,
             ws_ptr, ws_bytes, o.data_ptr(), st), "pw2")
         out = o.view(Nb, H, W, classes).permute(0, 3, 1, 2).cpu()

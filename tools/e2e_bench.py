@@ -78,6 +78,29 @@ def main():
         res["e2e_all_native_tail_ms"] = timed(lambda: decode_native(path_heads_fused(backbone(x))),
                                               a.steps, 5) * 1e3
         res["e2e_all_native_tail_img_s"] = a.batch / res["e2e_all_native_tail_ms"] * 1e3
+        if pipeline.FusedBackbone.supported(model):
+            fb = pipeline.FusedBackbone(model)
+
+            def all_native():
+                feat_, fq_, hw_ = fb(x)
+                return decode_native(fheads(*fused.forward_nhwc(feat_, fq_, hw_)))
+            res["backbone_fused_ms"] = timed(lambda: fb(x), a.steps, 5) * 1e3
+            res["e2e_all_native_ms"] = timed(all_native, a.steps, 5) * 1e3
+            res["e2e_all_native_img_s"] = a.batch / res["e2e_all_native_ms"] * 1e3
+            try:
+                g2 = torch.cuda.CUDAGraph()
+                s2 = torch.cuda.Stream()
+                s2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s2):
+                    for _ in range(3):
+                        all_native()
+                torch.cuda.current_stream().wait_stream(s2)
+                with torch.cuda.graph(g2):
+                    all_native()
+                res["e2e_all_native_graph_ms"] = timed(g2.replay, a.steps, 5) * 1e3
+                res["e2e_all_native_graph_img_s"] = a.batch / res["e2e_all_native_graph_ms"] * 1e3
+            except Exception as e:     # noqa: BLE001
+                res["e2e_all_native_graph_error"] = repr(e)[:200]
     # whole forward captured into one HIP graph (static input buffer)
     try:
         with torch.no_grad():
