@@ -1009,6 +1009,10 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
   const int lr = tid >> 3, lk = (tid & 7) * 4;   // staging: row lr + 32*i, k quad lk
+  const bool vec4 = !FAST && (C & 3) == 0 && (lda & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Wp)) & 15) == 0;
+  const bool vec2 = !FAST && !vec4 && (C & 1) == 0 && (lda & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(A) & 7) == 0;
   float4 a[AI], b[BI];
   // FAST path: rows beyond M / Co are clamped to a valid row (their results are never stored)
   const float *arow[AI];
@@ -1032,14 +1036,32 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       for (int i = 0; i < AI; ++i) a[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
 #pragma unroll
       for (int i = 0; i < BI; ++i) b[i] = *reinterpret_cast<const float4 *>(brow[i] + k0);
-    } else {
+    } else if (vec4) {      // C % 4 == 0, 16-byte aligned rows: whole quads are in or out of the k range
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool in = k0 + lk < C;
 #pragma unroll
-      for (int i = 0; i < AI; ++i) {
+      for (int i = 0; i < AI; ++i) a[i] = in ? *reinterpret_cast<const float4 *>(arow[i] + k0) : z;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) b[i] = in ? *reinterpret_cast<const float4 *>(brow[i] + k0) : z;
+    } else {
+      if (vec2) {           // C % 2 == 0, 8-byte aligned rows (a unit's second half at channel 58)
+        const float2 z = make_float2(0.f, 0.f);
         const int k = k0 + lk;
-        a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
-        a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
-        a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
-        a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+          const float2 lo = (k < C) ? *reinterpret_cast<const float2 *>(arow[i] + k0) : z;
+          const float2 hi = (k + 2 < C) ? *reinterpret_cast<const float2 *>(arow[i] + k0 + 2) : z;
+          a[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+          const int k = k0 + lk;
+          a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
+          a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
+          a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
+          a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
@@ -1261,6 +1283,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (i32x16){0};
   const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
+  const bool vec4 = !FAST && (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16-byte half bh
   float4 a[AI];
   i32x4 b[BI];
@@ -1276,6 +1299,9 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     for (int i = 0; i < AI; ++i) {
       if (FAST) {
         a[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
+      } else if (vec4) {
+        a[i] = (k0 + lk < C) ? *reinterpret_cast<const float4 *>(arow[i] + k0)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         const int k = k0 + lk;
         a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
@@ -1456,23 +1482,24 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
 //   out [n][Ho*Wo][ld_out]  v = sum_{dy,dx} w[c][dy][dx] * U[s*oy+dy-1][s*ox+dx-1] (+ bias) (* es + eh) (ReLU)
 //        UP: U = nearest x2 of a (Ho = 2 Hs);  STRIDE 2: Ho = (Hs - 1) / 2 + 1
 // ld_in / ld_out >= C are the row strides; channels [C, ld) of a are read (must be finite) and ignored.
-// Workgroup = (image, band of kDw3Band output-side rows, 32 channels): the input rows of the band plus
+// Workgroup = (image, band of 4 (stride 2: 2) output-side rows, 32 channels): the input rows of the band plus
 // halo sit in LDS as [row][col][32] with zero halos; a lane owns (pixel, channel quad), reads its 3x3
 // neighbourhood (9 ds_read_b128) and produces the 2x2 (UP) or 1 output pixels -- each as the nine
 // products of the reference's conv in (dy, dx) order; up-sampling only decides which cell a tap reads.
 // ------------------------------------------------------------------------------------------
-constexpr int kDw3Band = 2, kDw3CCH = 32;
-template <bool XQ, int UP, int STRIDE>
+constexpr int dw3_band(int stride) { return stride == 2 ? 2 : 4; }   // output-side rows per workgroup
+template <bool XQ, int UP, int STRIDE, int CCH>
 __global__ void __launch_bounds__(256)
 dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const float *__restrict__ w,
            const float *__restrict__ bias, const float *__restrict__ ep_scale,
            const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
            int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nbands) {
-  extern __shared__ float4 band4[];         // [rows][Ws + 2][8 quads]
-  constexpr int LPP = kDw3CCH / 4;
-  constexpr int ROWS = STRIDE == 2 ? 2 * kDw3Band + 1 : kDw3Band + 2;
-  const int band = blockIdx.x % nbands, c0 = (blockIdx.x / nbands) * kDw3CCH, n = blockIdx.y;
-  const int y0 = band * kDw3Band;                              // first row of the band (pixel-item space)
+  extern __shared__ float4 band4[];         // [rows][Ws + 2][CCH / 4 quads]
+  constexpr int LPP = CCH / 4;
+  constexpr int BAND = dw3_band(STRIDE);
+  constexpr int ROWS = STRIDE == 2 ? 2 * BAND + 1 : BAND + 2;
+  const int band = blockIdx.x % nbands, c0 = (blockIdx.x / nbands) * CCH, n = blockIdx.y;
+  const int y0 = band * BAND;                                  // first row of the band (pixel-item space)
   const int iy0 = STRIDE == 2 ? 2 * y0 - 1 : y0 - 1;           // first staged input row
   const int Wc = Ws + 2;
   const int tid = threadIdx.x;
@@ -1518,24 +1545,27 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
   const int Hi = STRIDE == 2 ? (Hs - 1) / 2 + 1 : Hs, Wi = STRIDE == 2 ? (Ws - 1) / 2 + 1 : Ws;
   const int Ho = Hi << UP, Wo = Wi << UP;
   float mn = INFINITY, mx = -INFINITY;
-  const int work = kDw3Band * Wi * LPP;
+  const int work = BAND * Wi * LPP;
+  // 256 threads = 256 / LPP pixels x LPP channel quads per pass: a thread keeps ONE channel quad, so its weights
+  // are loaded once (not per item: 45 global loads per 9 LDS reads otherwise)
+  const int cq = tid % LPP;
+  const int cb = c0 + cq * 4;
+  float wk[9][4], bs[4], es[4], eh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool live = cb + e < C;
+    const int c = min(cb + e, C - 1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
+    bs[e] = (bias && live) ? bias[c] : 0.0f;
+    es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
+    eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
+  }
   for (int q = tid; q < work; q += 256) {
-    const int cq = q % LPP, pix = q / LPP;
+    const int pix = q / LPP;
     const int ry = pix / Wi, X = pix - ry * Wi;
     const int Y = y0 + ry;
-    const int cb = c0 + cq * 4;
     if (Y >= Hi || cb >= C) continue;
-    float wk[9][4], bs[4], es[4], eh[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool live = cb + e < C;
-      const int c = min(cb + e, C - 1);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
-      bs[e] = (bias && live) ? bias[c] : 0.0f;
-      es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
-      eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
-    }
     float4 V[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -1611,6 +1641,30 @@ interleave_kernel(const float *__restrict__ srcA, int ldA, const unsigned *__res
   if (qB) {
     bs = reinterpret_cast<const float *>(qB)[2];
     bz = reinterpret_cast<const float *>(qB)[3];
+  }
+  // both sources present, even h, 8 / 16-byte aligned rows: two channel pairs per lane (float2 in, float4 out)
+  const bool vec = srcA && srcB && (h & 1) == 0 && (ldA & 1) == 0 && (ldB & 1) == 0 && (ld_dst & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(srcA) | reinterpret_cast<uintptr_t>(srcB)) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  if (vec) {
+    const int h2 = h >> 1;
+    const long total = M * h2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+      const long m = q / h2;
+      const int i = (int)(q - m * h2) * 2;
+      float2 va = *reinterpret_cast<const float2 *>(srcA + m * ldA + i);
+      float2 vb = *reinterpret_cast<const float2 *>(srcB + m * ldB + i);
+      if (qA) {
+        va.x = fake_quant(va.x, as, az);
+        va.y = fake_quant(va.y, as, az);
+      }
+      if (qB) {
+        vb.x = fake_quant(vb.x, bs, bz);
+        vb.y = fake_quant(vb.y, bs, bz);
+      }
+      *reinterpret_cast<float4 *>(dst + m * ld_dst + 2 * i) = make_float4(va.x, vb.x, va.y, vb.y);
+    }
+    return;
   }
   const long total = M * h;
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
@@ -2039,10 +2093,14 @@ extern "C" int cdn_codenet_dw3x3_nhwc_forward(
   const int Hi = stride == 2 ? (Hs - 1) / 2 + 1 : Hs;
   CDN_REQUIRE(N <= 65535 && N * std::max(ld_in, ld_out) * H * W * (up ? 4 : 1) < (1ll << 31),
               CDN_ERR_UNSUPPORTED, "shape too large");
-  const int rows = stride == 2 ? 2 * kDw3Band + 1 : kDw3Band + 2;
-  const size_t lds = (size_t)rows * (Ws + 2) * kDw3CCH * sizeof(float);
-  CDN_REQUIRE(lds <= 96 * 1024, CDN_ERR_UNSUPPORTED, "stored row of %d pixels too wide", Ws);
-  const int nbands = (int)cdn::ceil_div(Hi, kDw3Band), nchunks = (int)cdn::ceil_div(C, kDw3CCH);
+  const int bandr = dw3_band(stride);
+  const int rows = stride == 2 ? 2 * bandr + 1 : bandr + 2;
+  // 32 channels per workgroup; 16 when the band of a wide plane would leave one workgroup per CU
+  // (layer1's stride-2 depthwise at 128 px per row: 83 KiB -> 220 us for 315 MB)
+  const int cch = (size_t)rows * (Ws + 2) * 32 * sizeof(float) > 52 * 1024 ? 16 : 32;
+  const size_t lds = (size_t)rows * (Ws + 2) * cch * sizeof(float);
+  CDN_REQUIRE(lds <= 128 * 1024, CDN_ERR_UNSUPPORTED, "stored row of %d pixels too wide", Ws);
+  const int nbands = (int)cdn::ceil_div(Hi, bandr), nchunks = (int)cdn::ceil_div(C, cch);
   CDN_REQUIRE((long)nbands * nchunks * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
   AuxWs ws{nullptr, nullptr};
   if (r_state)
@@ -2057,7 +2115,7 @@ extern "C" int cdn_codenet_dw3x3_nhwc_forward(
   cdn::ProfScope ps(cdn::kProfDw, (int)(H > 0xffff ? 0xffff : H), st);
 #define CDN_GO(XQ_, UP_, ST_)                                                                      \
   {                                                                                                \
-    auto kern = dw3_kernel<XQ_, UP_, ST_>;                                                         \
+    auto kern = cch == 32 ? dw3_kernel<XQ_, UP_, ST_, 32> : dw3_kernel<XQ_, UP_, ST_, 16>;         \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)lds);                                                           \
     kern<<<grid, 256, lds, st>>>(a, aq, w, bias, ep_scale, ep_shift, out, mm, qu, (int)C, (int)ld_in, \
