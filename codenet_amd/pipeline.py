@@ -504,38 +504,76 @@ class FusedBackbone:
         N_.check(rc, "cdn_codenet_interleave_forward")
 
     # -- buffers -----------------------------------------------------------------------------------
-    def _alloc(self, images):
-        from . import _native as N_
-        m = self.model
-        Nb, _, R, R2 = images.shape
-        dev = images.device
-        s0 = m.layer0[0].conv.stride[0]
-        H, W = (R + 2 - 3) // s0 + 1, (R2 + 2 - 3) // s0 + 1
-        pad4 = lambda c: (c + 3) // 4 * 4   # noqa: E731
-        bufs = dict(key=(tuple(images.shape), dev), t0=torch.empty(Nb, H * W, 24, device=dev), hw0=(H, W))
-        layers = []
-        cin = 24
-        for name in ("layer1", "layer2", "layer3"):
-            nodes = list(getattr(m, name))
+    def _layer_bufs(self, nodes, cin, Nb, H, W, dev):
+        """Scratch for one layer (a stride-2 unit followed by stride-1 units), cached per shape."""
+        key = (id(nodes[0]), Nb, H, W, dev)
+        cache = self.__dict__.setdefault("_layer_cache", {})
+        if key not in cache:
+            pad4 = lambda c: (c + 3) // 4 * 4   # noqa: E731
             oup = 2 * nodes[0].quant_convbn3.conv.out_channels
             h = oup // 2
-            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            s = nodes[0].stride
+            Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if s == 2 else (H, W)
             Mi, Mo = Nb * H * W, Nb * Ho * Wo
-            layers.append(dict(
-                nodes=nodes, cin=cin, C=oup, h=h, ldh=pad4(h), Hin=H, Win=W, H=Ho, W=Wo,
-                t4=torch.zeros(Mo, pad4(cin), device=dev), t5=torch.zeros(Mo, pad4(h), device=dev),
-                t1s2=torch.zeros(Mi, pad4(h), device=dev),             # pw1 of the stride-2 unit: input res
-                t1=torch.zeros(Mo, pad4(h), device=dev), t2=torch.zeros(Mo, pad4(h), device=dev),
-                t3=torch.zeros(Mo, pad4(h), device=dev),
-                ya=torch.zeros(Mo, oup, device=dev), yb=torch.zeros(Mo, oup, device=dev)))
-            cin, H, W = oup, Ho, Wo
-        bufs["layers"] = layers
-        c4 = m.layer4[0].conv.out_channels
-        bufs["out"] = torch.empty(Nb, H * W, c4, device=dev)
-        bufs["hw4"] = (H, W)
-        aux = N_.lib().cdn_codenet_aux_workspace_bytes()
-        bufs["ws"] = torch.zeros(aux // 4 + 64, device=dev)             # arrival counters start at zero
-        self._bufs = bufs
+            z = lambda m, c: torch.zeros(m, c, device=dev)   # noqa: E731  (padding channels stay finite)
+            cache[key] = dict(
+                cin=cin, C=oup, h=h, ldh=pad4(h), Hin=H, Win=W, H=Ho, W=Wo,
+                t4=z(Mo, pad4(cin)) if s == 2 else None, t5=z(Mo, pad4(h)) if s == 2 else None,
+                t1s2=z(Mi, pad4(h)) if s == 2 else None,       # pw1 of the stride-2 unit: input resolution
+                t1=z(Mo, pad4(h)), t2=z(Mo, pad4(h)), t3=z(Mo, pad4(h)), ya=z(Mo, oup), yb=z(Mo, oup))
+        return cache[key]
+
+    def _prepare(self, dev):
+        from . import _native as N_
+        if self.__dict__.get("_ws") is None or self._ws.device != dev:
+            aux = N_.lib().cdn_codenet_aux_workspace_bytes()
+            self._ws = torch.zeros(aux // 4 + 64, device=dev)          # arrival counters start at zero
+        self._ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
+        self._ws_bytes = (self._ws.numel() * 4 - (self._ws_ptr - self._ws.data_ptr())) // 256 * 256
+        self._stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run_units(self, nodes, x, x_ld, x_q, Nb, H, W):
+        """A chain of QuantBaseNode units (first one may be stride 2) sharing their block-output QuantAct.
+        x: channels-last [Nb*H*W, x_ld] holding PRE-quantisation values with QuantAct state pointer x_q,
+        or final values (x_q None).  Returns (y [Nb*Ho*Wo, C] final values, C, Ho, Wo)."""
+        dev = x.device
+        self._prepare(dev)
+        cin = nodes[0].quant_convbn1.conv.in_channels if nodes[0].stride == 2 else x_ld
+        L = self._layer_bufs(nodes, cin, Nb, H, W, dev)
+        h, ldh, C = L["h"], L["ldh"], L["C"]
+        Mi, Mo = Nb * L["Hin"] * L["Win"], Nb * L["H"] * L["W"]
+        qptr = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
+        y, y_other = L["ya"], L["yb"]
+        with torch.no_grad():
+            for node in nodes:
+                sh = node.quant_act                       # the layer's shared block-output QuantAct
+                if node.stride == 2:
+                    # branch 1 (reference order: first): dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
+                    self._dw(x, x_q, Nb, cin, L["Hin"], L["Win"], 2, x_ld, node.quant_convbn4,
+                             node.quant_act4, L["t4"], L["t4"].shape[1])
+                    self._pw(L["t4"].data_ptr(), qptr(node.quant_act4), Mo, L["t4"].shape[1],
+                             node.quant_convbn5, True, sh, L["t5"], ldh)
+                    self._il(L["t5"].data_ptr(), ldh, qptr(sh), None, 0, None, Mo, h, y, C)
+                    # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
+                    self._pw(x.data_ptr(), x_q, Mi, x_ld, node.quant_convbn1, True, node.quant_act1,
+                             L["t1s2"], ldh)
+                    self._dw(L["t1s2"], qptr(node.quant_act1), Nb, h, L["Hin"], L["Win"], 2, ldh,
+                             node.quant_convbn2, node.quant_act2, L["t2"], ldh)
+                    self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
+                             sh, L["t3"], ldh)
+                    self._il(None, 0, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
+                else:
+                    # x holds FINAL values; x1 = x[:, :h] passes through, x2 = x[:, h:] is a strided view
+                    self._pw(x.data_ptr() + 4 * h, None, Mo, C, node.quant_convbn1, True,
+                             node.quant_act1, L["t1"], ldh)
+                    self._dw(L["t1"], qptr(node.quant_act1), Nb, h, L["H"], L["W"], 1, ldh,
+                             node.quant_convbn2, node.quant_act2, L["t2"], ldh)
+                    self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
+                             sh, L["t3"], ldh)
+                    self._il(x.data_ptr(), C, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
+                x, x_ld, x_q = y, C, None
+                y, y_other = y_other, y
+        return x, C, L["H"], L["W"]
 
     def __call__(self, images):
         from . import _native as N_
@@ -543,60 +581,32 @@ class FusedBackbone:
                 and images.shape[1] == 3):
             raise NotImplementedError("FusedBackbone needs a [N,3,H,W] float32 GPU tensor")
         images = images.contiguous()
-        if self._bufs is None or self._bufs["key"] != (tuple(images.shape), images.device):
-            self._alloc(images)
-        B, m, dev = self._bufs, self.model, images.device
-        ws = B["ws"]
-        self._ws_ptr = (ws.data_ptr() + 255) // 256 * 256
-        self._ws_bytes = (ws.numel() * 4 - (self._ws_ptr - ws.data_ptr())) // 256 * 256
-        self._stream = torch.cuda.current_stream(dev).cuda_stream
-        Nb = images.shape[0]
+        m, dev = self.model, images.device
+        self._prepare(dev)
+        Nb, _, R, R2 = images.shape
         qptr = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
+        q0, act0 = m.layer0[0], m.layer0[1][1]
+        s0 = q0.conv.stride[0]
+        H, W = (R + 2 - 3) // s0 + 1, (R2 + 2 - 3) // s0 + 1
+        key = (tuple(images.shape), dev)
+        if self._bufs is None or self._bufs["key"] != key:
+            self._bufs = dict(key=key, t0=torch.empty(Nb, H * W, 24, device=dev))
+        B = self._bufs
         with torch.no_grad():
             # ---- layer0: dense 3x3 conv + folded BN + ReLU, range of its QuantAct ------------------
-            q0, act0 = m.layer0[0], m.layer0[1][1]
             w0, b0 = q0.folded()
             rc = N_.lib().cdn_codenet_stem_forward(
-                images.data_ptr(), Nb, images.shape[2], images.shape[3], 24, q0.conv.stride[0],
-                w0.reshape(24, 27).data_ptr(), b0.data_ptr(), 1, *self._act_args(act0, dev), self._ws_ptr,
-                self._ws_bytes, B["t0"].data_ptr(), self._stream)
+                images.data_ptr(), Nb, R, R2, 24, s0, w0.reshape(24, 27).data_ptr(), b0.data_ptr(), 1,
+                *self._act_args(act0, dev), self._ws_ptr, self._ws_bytes, B["t0"].data_ptr(), self._stream)
             N_.check(rc, "cdn_codenet_stem_forward")
             x, x_ld, x_q = B["t0"], 24, qptr(act0)          # pre-quantisation values + state
-            for L in B["layers"]:
-                h, ldh, C = L["h"], L["ldh"], L["C"]
-                Mi, Mo = Nb * L["Hin"] * L["Win"], Nb * L["H"] * L["W"]
-                y, y_other = L["ya"], L["yb"]
-                for node in L["nodes"]:
-                    sh = node.quant_act                       # the layer's shared block-output QuantAct
-                    if node.stride == 2:
-                        cin = L["cin"]
-                        # branch 1 (reference order: first): dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
-                        self._dw(x, x_q, Nb, cin, L["Hin"], L["Win"], 2, x_ld, node.quant_convbn4,
-                                 node.quant_act4, L["t4"], L["t4"].shape[1])
-                        self._pw(L["t4"].data_ptr(), qptr(node.quant_act4), Mo, L["t4"].shape[1],
-                                 node.quant_convbn5, True, sh, L["t5"], ldh)
-                        self._il(L["t5"].data_ptr(), ldh, qptr(sh), None, 0, None, Mo, h, y, C)
-                        # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
-                        self._pw(x.data_ptr(), x_q, Mi, x_ld, node.quant_convbn1, True, node.quant_act1,
-                                 L["t1s2"], ldh)
-                        self._dw(L["t1s2"], qptr(node.quant_act1), Nb, h, L["Hin"], L["Win"], 2, ldh,
-                                 node.quant_convbn2, node.quant_act2, L["t2"], ldh)
-                        self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
-                                 sh, L["t3"], ldh)
-                        self._il(None, 0, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
-                    else:
-                        # x holds FINAL values; x1 = x[:, :h] passes through, x2 = x[:, h:] is a strided view
-                        self._pw(x.data_ptr() + 4 * h, None, Mo, C, node.quant_convbn1, True,
-                                 node.quant_act1, L["t1"], ldh)
-                        self._dw(L["t1"], qptr(node.quant_act1), Nb, h, L["H"], L["W"], 1, ldh,
-                                 node.quant_convbn2, node.quant_act2, L["t2"], ldh)
-                        self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
-                                 sh, L["t3"], ldh)
-                        self._il(x.data_ptr(), C, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
-                    x, x_ld, x_q = y, C, None
-                    y, y_other = y_other, y
+            for name in ("layer1", "layer2", "layer3"):
+                x, x_ld, H, W = self.run_units(list(getattr(m, name)), x, x_ld, x_q, Nb, H, W)
+                x_q = None
             # ---- layer4: 1x1 conv + folded BN + ReLU, range of its QuantAct ---------------------------
             q4, act4 = m.layer4[0], m.layer4[1][1]
-            M4 = Nb * B["hw4"][0] * B["hw4"][1]
-            self._pw(x.data_ptr(), x_q, M4, x_ld, q4, True, act4, B["out"], 0)
-        return B["out"], qptr(act4), B["hw4"]
+            c4 = q4.conv.out_channels
+            if B.get("out") is None or B["out"].shape != (Nb, H * W, c4):
+                B["out"] = torch.empty(Nb, H * W, c4, device=dev)
+            self._pw(x.data_ptr(), None, Nb * H * W, x_ld, q4, True, act4, B["out"], 0)
+        return B["out"], qptr(act4), (H, W)

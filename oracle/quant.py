@@ -8,7 +8,8 @@ composition of the CoDeNet deform stage, each function citing what it follows:
         AsymmetricQuantFunction :172-200, SymmetricQuantFunction :207-225)
     portable_quantizer/quant_modules.py  (QuantAct :163-225, Quant_Conv2d :228-321,
         QuantBnConv2d :324-419, QuantDeformConv2d :422-517,
-        QuantDeformConvWithOffsetScaleBoundPositive :621-671, QuantDepthwiseNode :1013-1071)
+        QuantDeformConvWithOffsetScaleBoundPositive :621-671, QuantBaseNode :809-907,
+        QuantDepthwiseNode :1013-1071)
 
 Pinned against the reference's own Python modules (imported in the build container only) by
 tests/golden/make_golden.py -> tests/golden/*.npz, checked in tests/test_quant_oracle.py.
@@ -171,3 +172,31 @@ def head_w4a8(x, w1, bn1, w2, bn2, w3, b3, act1, act3, w_bits=4, running=True, w
     y2q, c2 = act3(torch.relu(y2), running, act_percentile, return_codes=True)
     out = F.conv2d(y2q, weight_fake_quant(w3, w_bits, wt_percentile), b3)
     return {"y1": y1, "y1q": y1q, "y1_codes": c1, "y2": y2, "y2q": y2q, "y2_codes": c2, "out": out}
+
+
+# ---- backbone unit -----------------------------------------------------
+
+def channel_shuffle(x, groups=2):
+    """lib/models/networks/shufflenetv2_dcn.py:43-54."""
+    n, c, h, w = x.shape
+    return x.view(n, groups, c // groups, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+
+
+def base_node_w4a8(x, p, acts, shared, stride, w_bits=4, running=True, wt_percentile=False, eps=1e-5):
+    """QuantBaseNode.forward (quant_modules.py:880-907).  p: dict of conv weights w1..w5 and BN tuples
+    bn1..bn5 (weight, bias, mean, var); acts: dict of QuantActState act1, act2 (, act4); shared: the
+    layer's block-output QuantActState.  Order of the shared QuantAct's updates: branch 1, then branch 2."""
+    def convbn(t, w, bn, stride_=1, groups=1, pad=0):
+        wf, bf = fold_bn(w, None, *bn, eps)
+        return F.conv2d(t, weight_fake_quant(wf, w_bits, wt_percentile), bf, stride_, pad, 1, groups)
+    if stride == 1:
+        half = x.shape[1] // 2
+        x1, x2 = x[:, :half], x[:, half:]
+    else:
+        x1 = acts["act4"](convbn(x, p["w4"], p["bn4"], 2, x.shape[1], 1), running)
+        x1 = shared(torch.relu(convbn(x1, p["w5"], p["bn5"])), running)
+        x2 = x
+    x2 = acts["act1"](torch.relu(convbn(x2, p["w1"], p["bn1"])), running)
+    x2 = acts["act2"](convbn(x2, p["w2"], p["bn2"], stride, x2.shape[1], 1), running)
+    x2 = shared(torch.relu(convbn(x2, p["w3"], p["bn3"])), running)
+    return channel_shuffle(torch.cat((x1, x2), 1), 2)

@@ -271,6 +271,73 @@ def make_head_w4a8(ref_qm):
     return t2n(out)
 
 
+def make_base_nodes(ref_qm):
+    """Two chained reference QuantBaseNode units (stride 2 then stride 1, quant_modules.py:809-907) sharing
+    one block-output QuantAct, 3 consecutive forwards.  The reference BaseNode container
+    (shufflenetv2_dcn.py:57-114) is rebuilt from plain nn layers with the same b1 / b2 layout."""
+    nn = torch.nn
+    g = torch.Generator().manual_seed(73)
+
+    def bn(c):
+        b = nn.BatchNorm2d(c)
+        b.weight.data = torch.rand(c, generator=g) + 0.5
+        b.bias.data = torch.randn(c, generator=g) * 0.1
+        b.running_mean = torch.randn(c, generator=g) * 0.1
+        b.running_var = torch.rand(c, generator=g) + 0.5
+        return b
+
+    def conv(i, o, k=1, s=1, groups=1):
+        c = nn.Conv2d(i, o, k, s, k // 2, groups=groups, bias=False)
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * (1.5 / (i // groups * k * k)) ** 0.5
+        return c
+
+    class Node(nn.Module):
+        def __init__(self, inp, oup, stride):
+            super().__init__()
+            self.stride = stride
+            h = oup // 2
+            cin = inp if stride == 2 else h
+            self.b2 = nn.Sequential(conv(cin, h), bn(h), nn.ReLU(inplace=True), conv(h, h, 3, stride, h), bn(h),
+                                    conv(h, h), bn(h), nn.ReLU(inplace=True))
+            if stride == 2:
+                self.b1 = nn.Sequential(conv(inp, inp, 3, 2, inp), bn(inp), conv(inp, h), bn(h),
+                                        nn.ReLU(inplace=True))
+    inp, oup = 8, 20
+    nodes = [Node(inp, oup, 2).eval(), Node(oup, oup, 1).eval()]
+    out = {}
+    for u, nd in enumerate(nodes):
+        for i, k in ((0, "1"), (3, "2"), (5, "3")):
+            out["u%d_w%s" % (u, k)] = nd.b2[i].weight.data
+        for i, k in ((1, "1"), (4, "2"), (6, "3")):
+            b = nd.b2[i]
+            out["u%d_bn%s" % (u, k)] = torch.stack([b.weight.data, b.bias.data, b.running_mean, b.running_var])
+        if nd.stride == 2:
+            out["u%d_w4" % u], out["u%d_w5" % u] = nd.b1[0].weight.data, nd.b1[2].weight.data
+            for i, k in ((1, "4"), (3, "5")):
+                b = nd.b1[i]
+                out["u%d_bn%s" % (u, k)] = torch.stack([b.weight.data, b.bias.data, b.running_mean, b.running_var])
+    shared = ref_qm.QuantAct(8, quant_mode="asymmetric")
+    qn = []
+    for nd in nodes:
+        q = ref_qm.QuantBaseNode(4, 8, act_percentile=False, wt_quant_mode="symmetric",
+                                 act_quant_mode="asymmetric", per_channel=True, weight_percentile=False)
+        q.set_param(nd)
+        q.set_act(shared)
+        qn.append(q.eval())
+    for it in range(3):
+        x = torch.randn(2, inp, 12, 10, generator=g).abs() * (1.0 + 0.3 * it)
+        with torch.no_grad():
+            y0 = qn[0](x.clone())
+            y1 = qn[1](y0.clone())
+        out["x%d" % it], out["y0_%d" % it], out["y1_%d" % it] = x, y0, y1
+        out["shared_min%d" % it], out["shared_max%d" % it] = shared.x_min.clone(), shared.x_max.clone()
+        for u, q in enumerate(qn):
+            for k in ("quant_act1", "quant_act2") + (("quant_act4",) if q.stride == 2 else ()):
+                a = getattr(q, k)
+                out["u%d_%s_min%d" % (u, k, it)], out["u%d_%s_max%d" % (u, k, it)] = a.x_min.clone(), a.x_max.clone()
+    return t2n(out)
+
+
 def make_decode():
     """The reference's ctdet_decode (lib/models/decode.py:474-505) on random score maps; the selected
     scores are distinct floats, so torch.topk's unspecified tie order does not matter."""
@@ -371,6 +438,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "model_io.npz"), **make_model_io(ref_qm))
     np.savez_compressed(os.path.join(HERE, "head_w4a8.npz"), **make_head_w4a8(ref_qm))
     np.savez_compressed(os.path.join(HERE, "decode_ref.npz"), **make_decode())
+    np.savez_compressed(os.path.join(HERE, "base_nodes.npz"), **make_base_nodes(ref_qm))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -133,3 +133,64 @@ def test_fused_backbone_matches_modules(res, batch):
         assert (a.x_min - b.x_min).abs().item() < tol and (a.x_max - b.x_max).abs().item() < tol
         checked += 1
     assert checked >= 16 * 2 + 3
+
+
+def test_fused_units_match_reference_golden():
+    """Two chained ShuffleNetV2 units (stride 2, stride 1; shared block-output QuantAct) on the HIP kernels
+    against the reference's own QuantBaseNode outputs over 3 forwards (tests/golden/base_nodes.npz)."""
+    import numpy as np
+    import os
+    import torch.nn as nn
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer import quant_modules as qm
+    z = {k: torch.from_numpy(v) for k, v in
+         np.load(os.path.join(os.path.dirname(__file__), "golden", "base_nodes.npz")).items()}
+
+    def bn(t):
+        b = nn.BatchNorm2d(t.shape[1])
+        b.weight.data, b.bias.data, b.running_mean, b.running_var = t[0].clone(), t[1].clone(), t[2].clone(), t[3].clone()
+        return b
+
+    def conv(w, s=1, groups=1):
+        c = nn.Conv2d(w.shape[1] * groups, w.shape[0], w.shape[2], s, w.shape[2] // 2, groups=groups, bias=False)
+        c.weight.data = w.clone()
+        return c
+
+    class Node(nn.Module):
+        def __init__(self, u, stride):
+            super().__init__()
+            self.stride = stride
+            h = z["u%d_w1" % u].shape[0]
+            self.b2 = nn.Sequential(conv(z["u%d_w1" % u]), bn(z["u%d_bn1" % u]), nn.ReLU(inplace=True),
+                                    conv(z["u%d_w2" % u], stride, h), bn(z["u%d_bn2" % u]),
+                                    conv(z["u%d_w3" % u]), bn(z["u%d_bn3" % u]), nn.ReLU(inplace=True))
+            if stride == 2:
+                inp = z["u%d_w4" % u].shape[0]
+                self.b1 = nn.Sequential(conv(z["u%d_w4" % u], 2, inp), bn(z["u%d_bn4" % u]),
+                                        conv(z["u%d_w5" % u]), bn(z["u%d_bn5" % u]), nn.ReLU(inplace=True))
+    shared = qm.QuantAct(8, quant_mode="asymmetric")
+    nodes = []
+    for u, stride in ((0, 2), (1, 1)):
+        q = qm.QuantBaseNode(4, 8, act_percentile=False, wt_quant_mode="symmetric", act_quant_mode="asymmetric",
+                             per_channel=True, weight_percentile=False)
+        q.set_param(Node(u, stride).eval())
+        q.set_act(shared)
+        nodes.append(q.eval().cuda())
+    fb = pipeline.FusedBackbone(None)
+    for it in range(3):
+        x = z["x%d" % it].cuda()
+        Nb, C, H, W = x.shape
+        a = x.permute(0, 2, 3, 1).contiguous().view(-1, C)
+        y, Co, Ho, Wo = fb.run_units(nodes, a, C, None, Nb, H, W)
+        got = y.view(Nb, Ho, Wo, Co).permute(0, 3, 1, 2).cpu()
+        sh = nodes[0].quant_act
+        assert (sh.x_min.cpu() - z["shared_min%d" % it]).abs().item() < 1e-4
+        assert (sh.x_max.cpu() - z["shared_max%d" % it]).abs().item() < 1e-4
+        for u, names in ((0, ("quant_act1", "quant_act2", "quant_act4")), (1, ("quant_act1", "quant_act2"))):
+            for k in names:
+                a_ = getattr(nodes[u], k)
+                assert (a_.x_max.cpu() - z["u%d_%s_max%d" % (u, k, it)]).abs().item() < 1e-4
+                assert (a_.x_min.cpu() - z["u%d_%s_min%d" % (u, k, it)]).abs().item() < 1e-4
+        lsb = (sh.x_max - sh.x_min).item() / 255.0
+        d = (got - z["y1_%d" % it]).abs()
+        assert d.max().item() <= 2.05 * lsb and (d > 1e-5).float().mean().item() < 0.02

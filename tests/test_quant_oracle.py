@@ -128,3 +128,34 @@ def test_head_w4a8_matches_reference_module(tag, pct):
         assert d1.max().item() <= 1.01 * lsb1 and (d1 > 1e-6).float().mean().item() < 1e-3
         assert d3.max().item() <= 1.01 * lsb3 and (d3 > 1e-6).float().mean().item() < 5e-3
         assert (r["out"] - z["%s_out%d" % (tag, it)]).abs().max().item() < 0.05
+
+
+def _unit_params(z, u, stride):
+    p = {}
+    for k in ("1", "2", "3") + (("4", "5") if stride == 2 else ()):
+        p["w" + k] = z["u%d_w%s" % (u, k)]
+        p["bn" + k] = tuple(z["u%d_bn%s" % (u, k)][i] for i in range(4))
+    return p
+
+
+def test_base_node_oracle_matches_reference_units():
+    """oracle/quant.py base_node_w4a8 vs two chained reference QuantBaseNode units (stride 2, stride 1)
+    sharing one block-output QuantAct, 3 forwards (tests/golden/base_nodes.npz)."""
+    torch.set_num_threads(1)
+    z = load("base_nodes.npz")
+    shared = Q.QuantActState(bits=8)
+    acts = [{k: Q.QuantActState(bits=8) for k in ("act1", "act2", "act4")},
+            {k: Q.QuantActState(bits=8) for k in ("act1", "act2")}]
+    for it in range(3):
+        y0 = Q.base_node_w4a8(z["x%d" % it], _unit_params(z, 0, 2), acts[0], shared, 2)
+        y1 = Q.base_node_w4a8(y0, _unit_params(z, 1, 1), acts[1], shared, 1)
+        assert (shared.x_min - z["shared_min%d" % it]).abs().item() < 1e-5
+        assert (shared.x_max - z["shared_max%d" % it]).abs().item() < 1e-5
+        for u, names in ((0, ("act1", "act2", "act4")), (1, ("act1", "act2"))):
+            for k in names:
+                assert (acts[u][k].x_max - z["u%d_quant_%s_max%d" % (u, k, it)]).abs().item() < 1e-5
+                assert (acts[u][k].x_min - z["u%d_quant_%s_min%d" % (u, k, it)]).abs().item() < 1e-5
+        lsb = (shared.x_max - shared.x_min).item() / 255.0
+        for got, ref in ((y0, z["y0_%d" % it]), (y1, z["y1_%d" % it])):
+            d = (got - ref).abs()
+            assert d.max().item() <= 1.01 * lsb and (d > 1e-6).float().mean().item() < 5e-3
