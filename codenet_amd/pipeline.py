@@ -433,11 +433,13 @@ class FusedHeads:
 
 
 class FusedBackbone:
-    """layer0 .. layer4 of a W4A8 ``PoseShuffleNetV2`` on the HIP kernels:
-    the reference's module tree after ``quantize_shufflenetv2_dcn`` (quantize_model.py:26-60) --
+    """layer0 .. layer4 of a ``PoseShuffleNetV2`` on the HIP kernels.
+    W4A8: the reference's module tree after ``quantize_shufflenetv2_dcn`` (quantize_model.py:26-60) --
     layer0 = QuantBnConv2d(8) + ReLU + QuantAct, layers 1-3 = QuantBaseNode units sharing one block-output
     QuantAct per layer (quant_modules.py:809-907), layer4 = QuantBnConv2d + ReLU + QuantAct -- with the
     same parameters and QuantAct buffers (updated in place, in the reference's order).
+    fp32: the un-quantised tree (shufflenetv2_dcn.py:57-114,205-240) in eval mode, BatchNorm folded into
+    the convolutions, same kernels without quantisers.
 
     Activations are channels-last fp32.  A unit's three convolutions run on ONE half of the channels
     through row-strided views (no split copy); intermediates hold pre-quantisation values and are
@@ -455,6 +457,15 @@ class FusedBackbone:
         from .portable_quantizer.quant_modules import QuantAct, QuantBaseNode, QuantBnConv2d
         try:
             l0, l4 = model.layer0, model.layer4
+            if isinstance(l0[0], nn.Conv2d):          # fp32 model: conv, bn, relu stem without max-pool
+                c = l0[0]
+                ok = (len(l0) == 3 and c.out_channels == 24 and c.in_channels == 3 and c.bias is None
+                      and tuple(c.kernel_size) == (3, 3) and tuple(c.padding) == (1, 1)
+                      and isinstance(l4[0], nn.Conv2d))
+                for name in ("layer1", "layer2", "layer3"):
+                    for node in getattr(model, name):
+                        ok = ok and hasattr(node, "b2") and len(node.b2) == 8
+                return bool(ok)
             ok = (isinstance(l0[0], QuantBnConv2d) and len(l0[1]) == 2 and isinstance(l0[1][1], QuantAct)
                   and l0[0].conv.out_channels == 24 and l0[0].conv.in_channels == 3
                   and tuple(l0[0].conv.kernel_size) == (3, 3) and tuple(l0[0].conv.padding) == (1, 1)
@@ -474,11 +485,27 @@ class FusedBackbone:
         return [act.x_min.data_ptr(), act.x_max.data_ptr(), act._device_state(dev).data_ptr(),
                 act.activation_bit, act.momentum, int(act.running_stat)]
 
+    def _folded(self, convbn):
+        """(weight, bias) of a QuantBnConv2d (fake-quantised, BN folded) or of an fp32 (conv, bn) pair with
+        the BatchNorm folded into the convolution (eval mode; derived once)."""
+        if not isinstance(convbn, tuple):
+            return convbn.folded()
+        conv, bn = convbn
+        cache = self.__dict__.setdefault("_fp32_fold", {})
+        key = (id(conv), conv.weight._version, bn.weight._version, bn.running_var._version)
+        if key not in cache:
+            with torch.no_grad():
+                sf = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                w = (conv.weight * sf.reshape(-1, 1, 1, 1)).contiguous()
+                b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+                cache[key] = (w, ((b0 - bn.running_mean) * sf + bn.bias).contiguous())
+        return cache[key]
+
     def _pw(self, a_ptr, a_q, M, lda, convbn, relu, act, out, ldo):
         from . import _native as N_
-        w, b = convbn.folded()
+        w, b = self._folded(convbn)
         Co, C = w.shape[0], w.shape[1]
-        i8 = convbn.folded_int8() if (self.int8 and a_q is not None) else None
+        i8 = convbn.folded_int8() if (self.int8 and a_q is not None and not isinstance(convbn, tuple)) else None
         i8 = i8 if i8 is not None else (None, None, None)
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         w2 = w.reshape(Co, C)
@@ -490,7 +517,7 @@ class FusedBackbone:
 
     def _dw(self, a, a_q, N, C, H, W, stride, ld_in, convbn, act, out, ld_out):
         from . import _native as N_
-        w, b = convbn.folded()
+        w, b = self._folded(convbn)
         rc = N_.lib().cdn_codenet_dw3x3_nhwc_forward(
             a.data_ptr(), a_q, N, C, H, W, 0, stride, ld_in, ld_out, w.reshape(C, 9).data_ptr(), b.data_ptr(),
             None, None, 0, *self._act_args(act, out.device), self._ws_ptr, self._ws_bytes, out.data_ptr(),
@@ -504,14 +531,33 @@ class FusedBackbone:
         N_.check(rc, "cdn_codenet_interleave_forward")
 
     # -- buffers -----------------------------------------------------------------------------------
-    def _layer_bufs(self, nodes, cin, Nb, H, W, dev):
+    @staticmethod
+    def _unit(node):
+        """Layers of a ShuffleNetV2 unit: W4A8 QuantBaseNode (QuantBnConv2d + QuantAct objects) or the fp32
+        BaseNode (shufflenetv2_dcn.py:57-114: b2 = pw, bn, relu, dw, bn, pw, bn, relu; b1 = dw, bn, pw, bn,
+        relu) as (conv, bn) pairs with no quantisers."""
+        if hasattr(node, "quant_convbn1"):
+            u = dict(c1=node.quant_convbn1, a1=node.quant_act1, c2=node.quant_convbn2, a2=node.quant_act2,
+                     c3=node.quant_convbn3, sh=node.quant_act, h=node.quant_convbn3.conv.out_channels,
+                     cin=node.quant_convbn1.conv.in_channels)
+            if node.stride == 2:
+                u.update(c4=node.quant_convbn4, a4=node.quant_act4, c5=node.quant_convbn5)
+            return u
+        b2 = node.b2
+        u = dict(c1=(b2[0], b2[1]), a1=None, c2=(b2[3], b2[4]), a2=None, c3=(b2[5], b2[6]), sh=None,
+                 h=b2[5].out_channels, cin=b2[0].in_channels)
+        if node.stride == 2:
+            b1 = node.b1
+            u.update(c4=(b1[0], b1[1]), a4=None, c5=(b1[2], b1[3]))
+        return u
+
+    def _layer_bufs(self, nodes, h, cin, Nb, H, W, dev):
         """Scratch for one layer (a stride-2 unit followed by stride-1 units), cached per shape."""
         key = (id(nodes[0]), Nb, H, W, dev)
         cache = self.__dict__.setdefault("_layer_cache", {})
         if key not in cache:
             pad4 = lambda c: (c + 3) // 4 * 4   # noqa: E731
-            oup = 2 * nodes[0].quant_convbn3.conv.out_channels
-            h = oup // 2
+            oup = 2 * h
             s = nodes[0].stride
             Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if s == 2 else (H, W)
             Mi, Mo = Nb * H * W, Nb * Ho * Wo
@@ -538,38 +584,35 @@ class FusedBackbone:
         or final values (x_q None).  Returns (y [Nb*Ho*Wo, C] final values, C, Ho, Wo)."""
         dev = x.device
         self._prepare(dev)
-        cin = nodes[0].quant_convbn1.conv.in_channels if nodes[0].stride == 2 else x_ld
-        L = self._layer_bufs(nodes, cin, Nb, H, W, dev)
+        units = [self._unit(n) for n in nodes]
+        cin = units[0]["cin"] if nodes[0].stride == 2 else x_ld
+        L = self._layer_bufs(nodes, units[0]["h"], cin, Nb, H, W, dev)
         h, ldh, C = L["h"], L["ldh"], L["C"]
         Mi, Mo = Nb * L["Hin"] * L["Win"], Nb * L["H"] * L["W"]
-        qptr = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
+        qptr = lambda act: act._device_state(dev).data_ptr() if act is not None else None   # noqa: E731
         y, y_other = L["ya"], L["yb"]
         with torch.no_grad():
-            for node in nodes:
-                sh = node.quant_act                       # the layer's shared block-output QuantAct
+            for node, u in zip(nodes, units):
+                sh = u["sh"]                              # the layer's shared block-output QuantAct (W4A8)
                 if node.stride == 2:
                     # branch 1 (reference order: first): dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
-                    self._dw(x, x_q, Nb, cin, L["Hin"], L["Win"], 2, x_ld, node.quant_convbn4,
-                             node.quant_act4, L["t4"], L["t4"].shape[1])
-                    self._pw(L["t4"].data_ptr(), qptr(node.quant_act4), Mo, L["t4"].shape[1],
-                             node.quant_convbn5, True, sh, L["t5"], ldh)
+                    self._dw(x, x_q, Nb, cin, L["Hin"], L["Win"], 2, x_ld, u["c4"], u["a4"], L["t4"],
+                             L["t4"].shape[1])
+                    self._pw(L["t4"].data_ptr(), qptr(u["a4"]), Mo, L["t4"].shape[1], u["c5"], True, sh,
+                             L["t5"], ldh)
                     self._il(L["t5"].data_ptr(), ldh, qptr(sh), None, 0, None, Mo, h, y, C)
                     # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
-                    self._pw(x.data_ptr(), x_q, Mi, x_ld, node.quant_convbn1, True, node.quant_act1,
-                             L["t1s2"], ldh)
-                    self._dw(L["t1s2"], qptr(node.quant_act1), Nb, h, L["Hin"], L["Win"], 2, ldh,
-                             node.quant_convbn2, node.quant_act2, L["t2"], ldh)
-                    self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
-                             sh, L["t3"], ldh)
+                    self._pw(x.data_ptr(), x_q, Mi, x_ld, u["c1"], True, u["a1"], L["t1s2"], ldh)
+                    self._dw(L["t1s2"], qptr(u["a1"]), Nb, h, L["Hin"], L["Win"], 2, ldh, u["c2"], u["a2"],
+                             L["t2"], ldh)
+                    self._pw(L["t2"].data_ptr(), qptr(u["a2"]), Mo, ldh, u["c3"], True, sh, L["t3"], ldh)
                     self._il(None, 0, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
                 else:
                     # x holds FINAL values; x1 = x[:, :h] passes through, x2 = x[:, h:] is a strided view
-                    self._pw(x.data_ptr() + 4 * h, None, Mo, C, node.quant_convbn1, True,
-                             node.quant_act1, L["t1"], ldh)
-                    self._dw(L["t1"], qptr(node.quant_act1), Nb, h, L["H"], L["W"], 1, ldh,
-                             node.quant_convbn2, node.quant_act2, L["t2"], ldh)
-                    self._pw(L["t2"].data_ptr(), qptr(node.quant_act2), Mo, ldh, node.quant_convbn3, True,
-                             sh, L["t3"], ldh)
+                    self._pw(x.data_ptr() + 4 * h, None, Mo, C, u["c1"], True, u["a1"], L["t1"], ldh)
+                    self._dw(L["t1"], qptr(u["a1"]), Nb, h, L["H"], L["W"], 1, ldh, u["c2"], u["a2"], L["t2"],
+                             ldh)
+                    self._pw(L["t2"].data_ptr(), qptr(u["a2"]), Mo, ldh, u["c3"], True, sh, L["t3"], ldh)
                     self._il(x.data_ptr(), C, None, L["t3"].data_ptr(), ldh, qptr(sh), Mo, h, y, C)
                 x, x_ld, x_q = y, C, None
                 y, y_other = y_other, y
@@ -584,9 +627,18 @@ class FusedBackbone:
         m, dev = self.model, images.device
         self._prepare(dev)
         Nb, _, R, R2 = images.shape
-        qptr = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
-        q0, act0 = m.layer0[0], m.layer0[1][1]
-        s0 = q0.conv.stride[0]
+        qptr = lambda act: act._device_state(dev).data_ptr() if act is not None else None   # noqa: E731
+        quant = hasattr(m.layer0[0], "folded")
+        if quant:
+            q0, act0 = m.layer0[0], m.layer0[1][1]
+            conv0 = q0.conv
+            q4, act4 = m.layer4[0], m.layer4[1][1]
+            c4 = q4.conv.out_channels
+        else:                                            # fp32: Sequential(conv, bn, relu)
+            q0, act0, conv0 = (m.layer0[0], m.layer0[1]), None, m.layer0[0]
+            q4, act4 = (m.layer4[0], m.layer4[1]), None
+            c4 = m.layer4[0].out_channels
+        s0 = conv0.stride[0]
         H, W = (R + 2 - 3) // s0 + 1, (R2 + 2 - 3) // s0 + 1
         key = (tuple(images.shape), dev)
         if self._bufs is None or self._bufs["key"] != key:
@@ -594,7 +646,7 @@ class FusedBackbone:
         B = self._bufs
         with torch.no_grad():
             # ---- layer0: dense 3x3 conv + folded BN + ReLU, range of its QuantAct ------------------
-            w0, b0 = q0.folded()
+            w0, b0 = self._folded(q0)
             rc = N_.lib().cdn_codenet_stem_forward(
                 images.data_ptr(), Nb, R, R2, 24, s0, w0.reshape(24, 27).data_ptr(), b0.data_ptr(), 1,
                 *self._act_args(act0, dev), self._ws_ptr, self._ws_bytes, B["t0"].data_ptr(), self._stream)
@@ -604,8 +656,6 @@ class FusedBackbone:
                 x, x_ld, H, W = self.run_units(list(getattr(m, name)), x, x_ld, x_q, Nb, H, W)
                 x_q = None
             # ---- layer4: 1x1 conv + folded BN + ReLU, range of its QuantAct ---------------------------
-            q4, act4 = m.layer4[0], m.layer4[1][1]
-            c4 = q4.conv.out_channels
             if B.get("out") is None or B["out"].shape != (Nb, H * W, c4):
                 B["out"] = torch.empty(Nb, H * W, c4, device=dev)
             self._pw(x.data_ptr(), None, Nb * H * W, x_ld, q4, True, act4, B["out"], 0)
