@@ -301,9 +301,13 @@ class FusedHeads:
     by addressing, so the up-sampled 64-channel tensor is never built.  Same parameters and QuantAct
     buffers (updated in place) as calling the head modules on the unpacked tensor."""
 
-    def __init__(self, heads, int8_pointwise=True):
+    def __init__(self, heads, int8_pointwise=True, fuse_tail=False):
         self.heads = dict(heads)
         self.int8_pointwise = int8_pointwise
+        # W4A8 option: range-only depthwise pass, then depthwise + QuantAct + last 1x1 conv in ONE kernel
+        # (cdn_codenet_head_tail_forward): the 268 MB depthwise output is never stored.  Parity-tested, but
+        # measured slower at batch 64 (3 heads 0.75 ms vs 0.66 ms: the recompute is VALU-bound), so off.
+        self.fuse_tail = fuse_tail
         self._bufs = None
         self._affine = {}
 
@@ -351,10 +355,8 @@ class FusedHeads:
         aux = N_.lib().cdn_codenet_aux_workspace_bytes()
         self._bufs = dict(
             key=(tuple(r.shape), dev), y1=torch.empty(M, C, device=dev),
-            y2=torch.empty(4 * M, C, device=dev),
+            y2=None, o={},                                    # unfused tail only: allocated on first use
             ws=torch.zeros(aux // 4 + 64, device=dev),        # arrival counters start at zero
-            o={name: torch.empty(4 * M, self._out_channels(m), device=dev)
-               for name, m in self.heads.items()},
             out={name: torch.empty(Nb, self._out_channels(m), 2 * Hs, 2 * Ws, device=dev)
                  for name, m in self.heads.items()})
 
@@ -403,6 +405,14 @@ class FusedHeads:
         with torch.no_grad():
             for name, mod in self.heads.items():
                 layers = self._params(mod)
+                fuse = (self.fuse_tail and len(layers) == 3 and layers[0]["act"] is not None
+                        and layers[1]["act"] is not None and layers[1]["ep"] is None
+                        and layers[2]["i8"] is not None and layers[2]["w"].shape[0] <= 32
+                        and Ws % 8 == 0 and Ws <= 128 and C % 4 == 0)
+                if not fuse and name not in B["o"]:
+                    B["o"][name] = torch.empty(4 * M, self._out_channels(mod), device=r.device)
+                    if B["y2"] is None and len(layers) == 3:
+                        B["y2"] = torch.empty(4 * M, C, device=r.device)
                 if len(layers) == 1:          # head_conv == 0: one 1x1 conv, up-sampled afterwards
                     o = B["o"][name][:M]
                     pw(r, r_qstate, M, layers[0], o)
@@ -415,6 +425,26 @@ class FusedHeads:
                 pw(r, r_qstate, M, l1, B["y1"])
                 q1 = l1["act"]._device_state(r.device).data_ptr() if l1["act"] is not None else None
                 ep = l2["ep"] or (None, None)
+                if fuse:
+                    # W4A8: range-only depthwise pass, then depthwise -> quantise -> int8 1x1 -> NCHW in one
+                    # kernel: the 64-channel full-resolution tensor is never stored
+                    rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
+                    rc = lib.cdn_codenet_dw3x3_nhwc_forward(
+                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
+                        None, None, l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes, None, stream)
+                    ops._toc(rec)
+                    N_.check(rc, "cdn_codenet_dw3x3_nhwc_forward")
+                    q2 = l2["act"]._device_state(r.device).data_ptr()
+                    i8 = l3["i8"]
+                    rec = ops._tic("head_tail", (C, l3["w"].shape[0], 4 * M))
+                    rc = lib.cdn_codenet_head_tail_forward(
+                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2,
+                        ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(l3["w"]), ptr(l3["bias"]),
+                        l3["w"].shape[0], B["out"][name].data_ptr(), stream)
+                    ops._toc(rec)
+                    N_.check(rc, "cdn_codenet_head_tail_forward")
+                    outs[name] = B["out"][name]
+                    continue
                 rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
                 rc = lib.cdn_codenet_dw3x3_nhwc_forward(
                     B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),

@@ -258,12 +258,27 @@ int cdn_codenet_pointwise_nhwc_forward(
  *   up = 1 (stride 1 only): the input is nearest x2 up-sampled on the fly, Ho x Wo = 2H x 2W
  *   stride = 2:             Ho x Wo = ((H-1)/2+1) x ((W-1)/2+1);      otherwise Ho x Wo = H x W.
  * ld_in / ld_out: row strides in floats (0 = C), >= C, ld_in % 4 == 0; channels [C, ld_in) of a are read
- * and ignored (padding of an internal buffer: must be finite); they take no part in the range. */
+ * and ignored (padding of an internal buffer: must be finite); they take no part in the range.
+ * out = NULL (with r_state set): range-only pass, nothing is stored. */
 int cdn_codenet_dw3x3_nhwc_forward(
     const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up, int stride,
     int64_t ld_in, int64_t ld_out, const float *w, const float *bias, const float *ep_scale,
     const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream);
+
+/* The tail of a W4A8 detection head in ONE kernel (quant_modules.py:1062-1069): depthwise 3x3 on the nearest
+ * x2 up-sampled y1 (+ folded-BN bias) -> ReLU -> QuantAct -> 1x1 conv C -> classes (+ bias), NCHW output.
+ * The QuantAct range must be known: call cdn_codenet_dw3x3_nhwc_forward with out = NULL first (range-only
+ * pass: tracks r_min / r_max / r_state without storing), then this with that state as y2_qstate.
+ *   y1 [N][Hs*Ws][C] pre-quantisation values + y1_qstate;  w_dw [C][9], b_dw [C] or NULL
+ *   w_codes / w_scale / w_colsum: integer form of the 1x1 weights ([classes][round_up(C,64)] int8, ...) and
+ *   w [classes][C] their fake-quantised fp32 form (used when the codes are too wide for int8 MFMA)
+ *   out_nchw [N][classes][2Hs][2Ws];  C % 4 == 0, classes <= 32, Ws % 8 == 0, Ws <= 128. */
+int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
+                                  int64_t Ws, const float *w_dw, const float *b_dw, const void *y2_qstate,
+                                  const signed char *w_codes, const float *w_scale, const int *w_colsum,
+                                  const float *w, const float *bias, int64_t classes, float *out_nchw,
+                                  void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * The backbone's remaining layer types (lib/models/networks/
