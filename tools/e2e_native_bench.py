@@ -1,0 +1,43 @@
+"""Whole network + decode on the HIP kernels only (harness.enable_fused + ctdet_decode_native), for timing
+and for `rocprofv3 --kernel-trace --stats -- python3 tools/e2e_native_bench.py`.  GPU only."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from codenet_amd import harness
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--fp32", action="store_true")
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    model = harness.create_model(quantize=not a.fp32).to(dev).enable_fused()
+    x = torch.randn(a.batch, 3, a.res, a.res, device=dev)
+
+    def step():
+        return harness.process(model, x, flip_test=False)[1]
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dets = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.steps * 1e3
+    assert torch.isfinite(dets).all()
+    print(json.dumps({"config": "CoDeNet1x %dx%d %s batch %d, whole network + ctdet_decode native" % (
+        a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch), "ms_per_batch": round(ms, 4),
+        "images_per_s": round(a.batch / ms * 1e3)}))
+
+
+if __name__ == "__main__":
+    main()
