@@ -244,6 +244,19 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2 *o
 }  // namespace cdn
 #endif
 
+namespace cdn {
+// per-kernel capacity of the {min,max} partial arrays; grids are clamped / checked against it
+constexpr int kMaxPartials = 16384;
+// Workspace of the stand-alone layer entry points: partials first, arrival counters in the LAST bytes
+// (zeroed once by the caller); size = cdn_codenet_aux_workspace_bytes().
+struct AuxWs {
+  float2 *partials;
+  unsigned *arrive;
+};
+size_t aux_workspace_bytes();
+bool aux_workspace(void *workspace, size_t bytes, AuxWs *w);
+}  // namespace cdn
+
 #define CDN_REQUIRE(cond, code, ...) \
   do {                               \
     if (!(cond)) return cdn::fail(code, __VA_ARGS__); \

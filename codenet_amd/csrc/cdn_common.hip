@@ -117,3 +117,19 @@ extern "C" int cdn_profile_read(int max_records, int *kernel_ids, int *tags, flo
 
 extern "C" int cdn_abi_version(void) { return CDN_ABI_VERSION; }
 extern "C" const char *cdn_last_error(void) { return cdn::err_buf(); }
+
+namespace cdn {
+size_t aux_workspace_bytes() {
+  auto r = [](size_t b) { return (b + 255) / 256 * 256; };
+  return r((size_t)kMaxPartials * 8) + r((size_t)kArriveWords * 4);
+}
+bool aux_workspace(void *workspace, size_t bytes, AuxWs *w) {
+  if (!workspace || bytes < aux_workspace_bytes() || (reinterpret_cast<uintptr_t>(workspace) & 255) != 0)
+    return false;
+  char *p = static_cast<char *>(workspace);
+  const size_t cnt = ((size_t)kArriveWords * 4 + 255) / 256 * 256;
+  w->partials = reinterpret_cast<float2 *>(p);
+  w->arrive = reinterpret_cast<unsigned *>(p + bytes / 256 * 256 - cnt);
+  return true;
+}
+}  // namespace cdn

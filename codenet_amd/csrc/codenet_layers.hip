@@ -1,0 +1,619 @@
+// codenet_layers.hip -- the layers AROUND the deform stages on the same kernel conventions (channels-last
+// fp32 activations, fake-quantisation applied by the consumer while loading, QuantAct range tracking in the
+// producer's epilogue by the last-arriving workgroup; cdn_common.h):
+//   dw3_kernel         plain depthwise 3x3, stride 1 / 2, optional nearest x2 up-sampling by addressing
+//                      (detection heads: SURVEY.md section 8f row 1; ShuffleNetV2 units: row 3)
+//   interleave_kernel  concat + channel_shuffle(2) + the shared block-output QuantAct of a unit
+//   stem_kernel        layer0: dense 3x3 conv 3 -> 24 on the NCHW image
+//   head_tail_kernel   depthwise -> QuantAct -> last 1x1 conv of a W4A8 head in one kernel (opt-in)
+// The pointwise convolutions of these layers are the stage's pointwise kernels (codenet_fused.hip,
+// cdn_codenet_pointwise_nhwc_forward).
+#include "cdn_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using cdn::fake_quant;
+using cdn::kMaxPartials;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+#define CDN_STAMPR(R, I) do { } while (0)
+
+// ------------------------------------------------------------------------------------------
+// dw3: plain depthwise 3x3 (pad 1, stride 1 or 2) on a channels-last activation, optionally nearest x2
+// up-sampled on the fly -- the detection heads' second layer applied to the hot path's
+// half-resolution output (shufflenetv2_dcn.py:247-262, quant_modules.py:1059-1066) and the depthwise
+// convs of the ShuffleNetV2 units (shufflenetv2_dcn.py:57-114; stride 2 in the down-sampling units).
+//   a   [n][Hs*Ws][ld_in]   stored resolution, fake-quantised while staged when aq != NULL
+//   out [n][Ho*Wo][ld_out]  v = sum_{dy,dx} w[c][dy][dx] * U[s*oy+dy-1][s*ox+dx-1] (+ bias) (* es + eh) (ReLU)
+//        UP: U = nearest x2 of a (Ho = 2 Hs);  STRIDE 2: Ho = (Hs - 1) / 2 + 1
+// ld_in / ld_out >= C are the row strides; channels [C, ld) of a are read (must be finite) and ignored.
+// Workgroup = (image, band of 4 (stride 2: 2) output-side rows, 32 channels): the input rows of the band plus
+// halo sit in LDS as [row][col][32] with zero halos; a lane owns (pixel, channel quad), reads its 3x3
+// neighbourhood (9 ds_read_b128) and produces the 2x2 (UP) or 1 output pixels -- each as the nine
+// products of the reference's conv in (dy, dx) order; up-sampling only decides which cell a tap reads.
+// ------------------------------------------------------------------------------------------
+constexpr int dw3_band(int stride) { return stride == 2 ? 2 : 4; }   // output-side rows per workgroup
+template <bool XQ, int UP, int STRIDE, int CCH>
+__global__ void __launch_bounds__(256)
+dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const float *__restrict__ w,
+           const float *__restrict__ bias, const float *__restrict__ ep_scale,
+           const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
+           int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nbands) {
+  extern __shared__ float4 band4[];         // [rows][Ws + 2][CCH / 4 quads]
+  constexpr int LPP = CCH / 4;
+  constexpr int BAND = dw3_band(STRIDE);
+  constexpr int ROWS = STRIDE == 2 ? 2 * BAND + 1 : BAND + 2;
+  const int band = blockIdx.x % nbands, c0 = (blockIdx.x / nbands) * CCH, n = blockIdx.y;
+  const int y0 = band * BAND;                                  // first row of the band (pixel-item space)
+  const int iy0 = STRIDE == 2 ? 2 * y0 - 1 : y0 - 1;           // first staged input row
+  const int Wc = Ws + 2;
+  const int tid = threadIdx.x;
+  float qs = 1.f, qz = 0.f;
+  if (XQ) {
+    qs = reinterpret_cast<const float *>(aq)[2];
+    qz = reinterpret_cast<const float *>(aq)[3];
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int items = ROWS * Wc * LPP;
+  for (int base = 0; base < items; base += 256 * 4) {
+    float4 v[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = base + u * 256 + tid;
+      const int cq = q % LPP, cell = q / LPP;
+      const int r = cell / Wc, col = cell - r * Wc;
+      const int y = iy0 + r, x = col - 1;
+      v[u] = z4;
+      in[u] = q < items && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws &&
+              c0 + cq * 4 + 3 < ld_in;
+      if (in[u])
+        v[u] = *reinterpret_cast<const float4 *>(a + ((long)n * Hs * Ws + (long)y * Ws + x) * ld_in + c0 + cq * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = base + u * 256 + tid;
+      if (q < items) {
+        float4 t = v[u];
+        if (XQ && in[u]) {       // (the zero halo is a zero of the conv padding, not a quantised value)
+          t.x = fake_quant(t.x, qs, qz);
+          t.y = fake_quant(t.y, qs, qz);
+          t.z = fake_quant(t.z, qs, qz);
+          t.w = fake_quant(t.w, qs, qz);
+        }
+        band4[q] = t;
+      }
+    }
+  }
+  __syncthreads();
+  // pixel items: stored pixels (UP / stride 1) or output pixels (stride 2)
+  const int Hi = STRIDE == 2 ? (Hs - 1) / 2 + 1 : Hs, Wi = STRIDE == 2 ? (Ws - 1) / 2 + 1 : Ws;
+  const int Ho = Hi << UP, Wo = Wi << UP;
+  float mn = INFINITY, mx = -INFINITY;
+  const int work = BAND * Wi * LPP;
+  // 256 threads = 256 / LPP pixels x LPP channel quads per pass: a thread keeps ONE channel quad, so its weights
+  // are loaded once (not per item: 45 global loads per 9 LDS reads otherwise)
+  const int cq = tid % LPP;
+  const int cb = c0 + cq * 4;
+  float wk[9][4], bs[4], es[4], eh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool live = cb + e < C;
+    const int c = min(cb + e, C - 1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
+    bs[e] = (bias && live) ? bias[c] : 0.0f;
+    es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
+    eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
+  }
+  for (int q = tid; q < work; q += 256) {
+    const int pix = q / LPP;
+    const int ry = pix / Wi, X = pix - ry * Wi;
+    const int Y = y0 + ry;
+    if (Y >= Hi || cb >= C) continue;
+    float4 V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        V[i][j] = band4[((STRIDE * ry + i) * Wc + (STRIDE * X + j)) * LPP + cq];
+#pragma unroll
+    for (int py = 0; py < (1 << UP); ++py)
+#pragma unroll
+      for (int px = 0; px < (1 << UP); ++px) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            // full-resolution neighbour (2Y+py+dy-1, 2X+px+dx-1) -> stored cell relative to (Y-1, X-1)
+            const int i = UP ? ((py + dy + 1) >> 1) : dy;
+            const int j = UP ? ((px + dx + 1) >> 1) : dx;
+            const float4 t = V[i][j];
+            acc[0] = fmaf(wk[dy * 3 + dx][0], t.x, acc[0]);
+            acc[1] = fmaf(wk[dy * 3 + dx][1], t.y, acc[1]);
+            acc[2] = fmaf(wk[dy * 3 + dx][2], t.z, acc[2]);
+            acc[3] = fmaf(wk[dy * 3 + dx][3], t.w, acc[3]);
+          }
+        float *op = out + ((long)n * Ho * Wo + (long)((Y << UP) + py) * Wo + (X << UP) + px) * ld_out + cb;
+        float r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[e] + bs[e];
+          if (ep_scale) v = fmaf(v, es[e], eh[e]);
+          if (relu) v = fmaxf(v, 0.0f);
+          r4[e] = v;
+        }
+        if (out == nullptr) {
+          // range-only pass (the fused head tail recomputes the values once the range is known)
+        } else if (cb + 3 < ld_out && (ld_out & 3) == 0) {
+          *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (cb + e < C) op[e] = r4[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + e < C) {          // padding channels do not take part in the range
+            mn = fminf(mn, r4[e]);
+            mx = fmaxf(mx, r4[e]);
+          }
+      }
+  }
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+                             reinterpret_cast<float *>(band4));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// interleave: the concat + channel_shuffle(groups = 2) that ends a ShuffleNetV2 unit
+// (shufflenetv2_dcn.py:43-49; quant_modules.py:905-907), with the block-output QuantAct applied:
+//     dst[m][2 i + 0] = fq_A(srcA[m][i])      dst[m][2 i + 1] = fq_B(srcB[m][i])        i < h
+// Either source may be NULL (its slots are left untouched: the two branches of a stride-2 unit are
+// quantised with DIFFERENT states of the shared QuantAct, so each is written right after its own range
+// update); a NULL state copies the values (the pass-through half of a stride-1 unit is already
+// quantised).  Elementwise, 8 bytes per lane, rows of any stride.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+interleave_kernel(const float *__restrict__ srcA, int ldA, const unsigned *__restrict__ qA,
+                  const float *__restrict__ srcB, int ldB, const unsigned *__restrict__ qB,
+                  float *__restrict__ dst, int ld_dst, long M, int h) {
+  float as = 1.f, az = 0.f, bs = 1.f, bz = 0.f;
+  if (qA) {
+    as = reinterpret_cast<const float *>(qA)[2];
+    az = reinterpret_cast<const float *>(qA)[3];
+  }
+  if (qB) {
+    bs = reinterpret_cast<const float *>(qB)[2];
+    bz = reinterpret_cast<const float *>(qB)[3];
+  }
+  // both sources present, even h, 8 / 16-byte aligned rows: two channel pairs per lane (float2 in, float4 out)
+  const bool vec = srcA && srcB && (h & 1) == 0 && (ldA & 1) == 0 && (ldB & 1) == 0 && (ld_dst & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(srcA) | reinterpret_cast<uintptr_t>(srcB)) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  if (vec) {
+    const int h2 = h >> 1;
+    const long total = M * h2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+      const long m = q / h2;
+      const int i = (int)(q - m * h2) * 2;
+      float2 va = *reinterpret_cast<const float2 *>(srcA + m * ldA + i);
+      float2 vb = *reinterpret_cast<const float2 *>(srcB + m * ldB + i);
+      if (qA) {
+        va.x = fake_quant(va.x, as, az);
+        va.y = fake_quant(va.y, as, az);
+      }
+      if (qB) {
+        vb.x = fake_quant(vb.x, bs, bz);
+        vb.y = fake_quant(vb.y, bs, bz);
+      }
+      *reinterpret_cast<float4 *>(dst + m * ld_dst + 2 * i) = make_float4(va.x, vb.x, va.y, vb.y);
+    }
+    return;
+  }
+  const long total = M * h;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const long m = q / h;
+    const int i = (int)(q - m * h);
+    float *d = dst + m * ld_dst + 2 * i;
+    if (srcA) {
+      const float v = srcA[m * ldA + i];
+      d[0] = qA ? fake_quant(v, as, az) : v;
+    }
+    if (srcB) {
+      const float v = srcB[m * ldB + i];
+      d[1] = qB ? fake_quant(v, bs, bz) : v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stem: the network's first layer, a dense 3x3 conv 3 -> Co (stride 4 or 2, pad 1) + folded BN + ReLU on
+// the NCHW image (shufflenetv2_dcn.py:205-214; W4A8: QuantBnConv2d(8) quantize_model.py:26-34), output
+// channels-last.  One lane per output pixel: 27 inputs in registers, the Co x 27 weights read as
+// wave-uniform (scalar) loads, Co accumulators; min/max of the output in the epilogue.
+// ------------------------------------------------------------------------------------------
+template <int CO>
+__global__ void __launch_bounds__(256)
+stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const float *__restrict__ bias,
+            float *__restrict__ out, float2 *mm, cdn::QUpdate qu, int H, int W, int Ho, int Wo, int stride,
+            int relu) {
+  __shared__ float red[16];
+  const int n = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  float mn = INFINITY, mx = -INFINITY;
+  if (p < (long)Ho * Wo) {
+    const int oy = (int)(p / Wo), ox = (int)(p - (long)oy * Wo);
+    float v[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int y = oy * stride + dy - 1, x = ox * stride + dx - 1;
+          v[(c * 3 + dy) * 3 + dx] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                                         ? img[(((long)n * 3 + c) * H + y) * W + x] : 0.0f;
+        }
+    float *op = out + ((long)n * Ho * Wo + p) * CO;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+      acc += bias ? bias[co] : 0.0f;
+      if (relu) acc = fmaxf(acc, 0.0f);
+      op[co] = acc;
+      mn = fminf(mn, acc);
+      mx = fmaxf(mx, acc);
+    }
+  }
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu, red);
+}
+
+// ------------------------------------------------------------------------------------------
+// head_tail: the second half of a W4A8 detection head in ONE kernel (quant_modules.py:1062-1069):
+//     depthwise 3x3 on the up-sampled y1 (+ folded BN bias) -> ReLU -> QuantAct -> 1x1 conv C -> classes + bias
+// once the QuantAct range is known (a range-only pass of dw3_kernel tracks it first).  The depthwise
+// output -- 268 MB per head at batch 64, written and re-read by the unfused schedule -- never leaves the CU:
+// workgroup = (image, stored row): for each 32-channel half, stage 3 stored rows of y1 (fake-quantised on
+// load), compute the 2 x 2*Ws output pixels of the row exactly like dw3_kernel<UP>, quantise them to integer
+// codes and park the nibble-split codes in LDS as the A operand of v_mfma_i32_32x32x32_i8 (pwi8_kernel's
+// layout); B = the 4-bit weight codes of up to 32 classes; the int32 sums are scaled / biased, transposed
+// through LDS and stored as NCHW rows.  Codes too wide for the nibble split (state[6]) take an f32-MFMA
+// branch on the fake-quantised values, like pwi8_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kHtLD = 48;      // bytes per A / B row of one 32-channel k-step (32 + 16 pad)
+constexpr int kHtLDF = 33;     // floats per row in the f32 branch
+template <int NB>    // 32-pixel row blocks per wave: 2 (Ws <= 64) or 4 (Ws <= 128)
+__global__ void __launch_bounds__(256, 2)   // <= 256 VGPRs: two workgroups per CU (LDS allows two)
+head_tail_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
+                 const float *__restrict__ wdw, const float *__restrict__ bdw,
+                 const unsigned *__restrict__ q2, const signed char *__restrict__ Wq,
+                 const float *__restrict__ wscale, const int *__restrict__ wsum,
+                 const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
+                 int C, int Cpad, int Hs, int Ws, int classes) {
+  extern __shared__ float4 ht_lds[];
+  const int n = blockIdx.y, Y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Wc = Ws + 2, Wo = 2 * Ws, Ho = 2 * Hs, npix = 2 * Wo;           // output pixels of this row pair
+  // LDS: [3][Wc][8] float4 depthwise tile | A region | B region ; the output transpose re-uses the front
+  float4 *tile = ht_lds;
+  unsigned char *Areg = reinterpret_cast<unsigned char *>(ht_lds + 3 * Wc * 8);
+  const size_t a_bytes = (size_t)npix * (kHtLDF * 4);                        // sized for the f32 branch
+  unsigned char *Breg = Areg + a_bytes;
+  const float s1 = reinterpret_cast<const float *>(q1)[2], z1 = reinterpret_cast<const float *>(q1)[3];
+  const float s2 = reinterpret_cast<const float *>(q2)[2], z2 = reinterpret_cast<const float *>(q2)[3];
+  const bool wide = q2[6] != 0;
+  const int ioff = (int)z2 + (2048 - 128) - 0x4B400000;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nblk = npix / 32;                       // 32-pixel row blocks of the MFMA; npix % 32 == 0
+  i32x16 acc[NB];        // the f32 branch keeps its sums in the same registers (bit casts)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = (i32x16){0};
+  const int cq = tid & 7;                           // channel quad of the 32-channel half
+  for (int half = 0; half * 32 < C; ++half) {
+    const int c0 = half * 32;
+    // ---- stage stored rows Y-1 .. Y+1 (zero halo), fake-quantised -----------------------------------
+    for (int q = tid; q < 3 * Wc * 8; q += 256) {
+      const int cqq = q & 7, cell = q >> 3;
+      const int r = cell / Wc, col = cell - r * Wc;
+      const int y = Y - 1 + r, x = col - 1;
+      float4 v = z4;
+      if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws && c0 + cqq * 4 + 3 < C) {
+        v = *reinterpret_cast<const float4 *>(y1 + ((long)n * Hs * Ws + (long)y * Ws + x) * C + c0 + cqq * 4);
+        v.x = fake_quant(v.x, s1, z1);
+        v.y = fake_quant(v.y, s1, z1);
+        v.z = fake_quant(v.z, s1, z1);
+        v.w = fake_quant(v.w, s1, z1);
+      }
+      tile[q] = v;
+    }
+    // ---- B operand of this half: weight codes (and 16x codes), or f32 weights in the wide branch -------
+    if (!wide) {
+      for (int q = tid; q < 32 * 2; q += 256) {     // 32 class rows x two 16-byte pieces
+        const int cls = q >> 1, part = (q & 1) * 16;
+        i32x4 b = (i32x4){0, 0, 0, 0};
+        if (cls < classes) b = *reinterpret_cast<const i32x4 *>(Wq + (long)cls * Cpad + c0 + part);
+        i32x4 s16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)b[e] << 4) & 0xF0F0F0F0u);
+        *reinterpret_cast<i32x4 *>(Breg + cls * kHtLD + part) = b;
+        *reinterpret_cast<i32x4 *>(Breg + 32 * kHtLD + cls * kHtLD + part) = s16;
+      }
+    } else {
+      float *Bf = reinterpret_cast<float *>(Breg);
+      for (int q = tid; q < 32 * 32; q += 256) {
+        const int cls = q >> 5, k = q & 31;
+        Bf[cls * kHtLDF + k] = (cls < classes && c0 + k < C) ? Wp[(long)cls * C + c0 + k] : 0.0f;
+      }
+    }
+    __syncthreads();
+    // ---- depthwise 3x3 on the up-sampled tile, ReLU, quantise, park as the A operand ------------------
+    {
+      const int cb = c0 + cq * 4;
+      float wk[9][4], bs[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool live = cb + e < C;
+        const int c = min(cb + e, C - 1);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k][e] = live ? wdw[(long)c * 9 + k] : 0.0f;
+        bs[e] = (bdw && live) ? bdw[c] : 0.0f;
+      }
+      for (int X = tid >> 3; X < Ws; X += 32) {
+        float4 V[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) V[i][j] = tile[(i * Wc + (X + j)) * 8 + cq];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const float4 t = V[(py + dy + 1) >> 1][(px + dx + 1) >> 1];
+                a4[0] = fmaf(wk[dy * 3 + dx][0], t.x, a4[0]);
+                a4[1] = fmaf(wk[dy * 3 + dx][1], t.y, a4[1]);
+                a4[2] = fmaf(wk[dy * 3 + dx][2], t.z, a4[2]);
+                a4[3] = fmaf(wk[dy * 3 + dx][3], t.w, a4[3]);
+              }
+            const int row = py * Wo + 2 * X + px;
+            if (!wide) {
+              unsigned u[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = fmaxf(a4[e] + bs[e], 0.0f);
+                const float yv = __fadd_rn(__fsub_rn(__fmul_rn(s2, v), z2), 12582912.0f);
+                int uu = (int)__float_as_uint(yv) + ioff;
+                uu = min(max(uu, 8), 4087);
+                u[e] = (cb + e < C) ? (unsigned)uu : 2048u;
+              }
+              const unsigned p01 = u[0] | (u[1] << 16), p23 = u[2] | (u[3] << 16);
+              const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu;
+              const unsigned hi = __builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u;
+              *reinterpret_cast<unsigned *>(Areg + row * kHtLD + cq * 4) = lo;
+              *reinterpret_cast<unsigned *>(Areg + (size_t)npix * kHtLD + row * kHtLD + cq * 4) = hi;
+            } else {
+              float *Af = reinterpret_cast<float *>(Areg) + row * kHtLDF + cq * 4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                Af[e] = (cb + e < C) ? fake_quant(fmaxf(a4[e] + bs[e], 0.0f), s2, z2) : 0.0f;
+            }
+          }
+      }
+    }
+    __syncthreads();
+    // ---- this half's k-step: wave w owns the row blocks w, w + 4, ... -----------------------------------
+    if (!wide) {
+      const int fo = (lane & 31) * kHtLD + (lane >> 5) * 16;
+      const i32x4 b0 = *reinterpret_cast<const i32x4 *>(Breg + fo);
+      const i32x4 b1 = *reinterpret_cast<const i32x4 *>(Breg + 32 * kHtLD + fo);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int blk = wave + 4 * i;
+        if (blk < nblk) {
+          const i32x4 a0 = *reinterpret_cast<const i32x4 *>(Areg + blk * 32 * kHtLD + fo);
+          const i32x4 a1 = *reinterpret_cast<const i32x4 *>(Areg + (size_t)npix * kHtLD + blk * 32 * kHtLD + fo);
+          acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[i], 0, 0, 0);
+        }
+      }
+    } else {
+      const float *Af = reinterpret_cast<const float *>(Areg), *Bf = reinterpret_cast<const float *>(Breg);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float bv = Bf[(lane & 31) * kHtLDF + 2 * kk + (lane >> 5)];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int blk = wave + 4 * i;
+          if (blk < nblk) {
+            const float av = Af[(blk * 32 + (lane & 31)) * kHtLDF + 2 * kk + (lane >> 5)];
+            acc[i] = __builtin_bit_cast(i32x16, __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                                    av, bv, __builtin_bit_cast(f32x16, acc[i]), 0, 0, 0));
+          }
+        }
+      }
+    }
+    __syncthreads();                                // the next half overwrites tile / A / B
+  }
+  // ---- scale, bias, transpose through LDS ([class][pixel]), NCHW rows --------------------------------
+  float *ot = reinterpret_cast<float *>(ht_lds);    // [32][npix + 1]
+  {
+    const int cls = lane & 31;
+    float bsv = 0.f, rinv = 0.f;
+    int t128 = 0;
+    if (cls < classes) {
+      if (bias) bsv = bias[cls];
+      rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[cls]));
+      t128 = 128 * wsum[cls];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int blk = wave + 4 * i;
+      if (blk < nblk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float v = wide ? __int_as_float(acc[i][r]) + bsv : fmaf((float)(acc[i][r] + t128), rinv, bsv);
+          ot[cls * (npix + 1) + m] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < classes * npix; q += 256) {
+    const int cls = q / npix, m = q - cls * npix;
+    const int py = m / Wo, x = m - py * Wo;
+    out[(((long)n * classes + cls) * Ho + 2 * Y + py) * Wo + x] = ot[cls * (npix + 1) + m];
+  }
+}
+
+}  // namespace
+
+extern "C" int cdn_codenet_dw3x3_nhwc_forward(
+    const float *a, const void *a_qstate, int64_t N, int64_t C, int64_t H, int64_t W, int up, int stride,
+    int64_t ld_in, int64_t ld_out, const float *w, const float *bias, const float *ep_scale,
+    const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  CDN_REQUIRE(a && w && (out || r_state), CDN_ERR_ARG, "null pointer (out may be NULL only for a range-only pass)");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1) && (stride == 1 || stride == 2),
+              CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(!(up && stride == 2), CDN_ERR_UNSUPPORTED, "up-sampling with stride 2");
+  if (ld_in == 0) ld_in = C;
+  if (ld_out == 0) ld_out = C;
+  CDN_REQUIRE(ld_in >= C && ld_out >= C && (ld_in & 3) == 0, CDN_ERR_UNSUPPORTED,
+              "channels-last depthwise needs row strides >= C and ld_in %% 4 == 0 (got %lld, %lld)",
+              (long long)ld_in, (long long)ld_out);
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0, CDN_ERR_ARG, "a must be 16-byte aligned");
+  CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
+              "ep_scale / ep_shift must both be set or both be NULL");
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
+  // H, W: INPUT (stored) resolution; output = 2H x 2W (up), (H-1)/2+1 x (W-1)/2+1 (stride 2) or H x W
+  const int Hs = (int)H, Ws = (int)W;
+  const int Hi = stride == 2 ? (Hs - 1) / 2 + 1 : Hs;
+  CDN_REQUIRE(N <= 65535 && N * std::max(ld_in, ld_out) * H * W * (up ? 4 : 1) < (1ll << 31),
+              CDN_ERR_UNSUPPORTED, "shape too large");
+  const int bandr = dw3_band(stride);
+  const int rows = stride == 2 ? 2 * bandr + 1 : bandr + 2;
+  // 32 channels per workgroup; 16 when the band of a wide plane would leave one workgroup per CU
+  // (layer1's stride-2 depthwise at 128 px per row: 83 KiB -> 220 us for 315 MB)
+  const int cch = (size_t)rows * (Ws + 2) * 32 * sizeof(float) > 52 * 1024 ? 16 : 32;
+  const size_t lds = (size_t)rows * (Ws + 2) * cch * sizeof(float);
+  CDN_REQUIRE(lds <= 128 * 1024, CDN_ERR_UNSUPPORTED, "stored row of %d pixels too wide", Ws);
+  const int nbands = (int)cdn::ceil_div(Hi, bandr), nchunks = (int)cdn::ceil_div(C, cch);
+  CDN_REQUIRE((long)nbands * nchunks * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
+  cdn::AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+  float2 *mm = r_state ? ws.partials : nullptr;
+  const unsigned *aq = static_cast<const unsigned *>(a_qstate);
+  dim3 grid((unsigned)(nbands * nchunks), (unsigned)N);
+  cdn::ProfScope ps(cdn::kProfDw, (int)(H > 0xffff ? 0xffff : H), st);
+#define CDN_GO(XQ_, UP_, ST_)                                                                      \
+  {                                                                                                \
+    auto kern = cch == 32 ? dw3_kernel<XQ_, UP_, ST_, 32> : dw3_kernel<XQ_, UP_, ST_, 16>;         \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)lds);                                                           \
+    kern<<<grid, 256, lds, st>>>(a, aq, w, bias, ep_scale, ep_shift, out, mm, qu, (int)C, (int)ld_in, \
+                                 (int)ld_out, Hs, Ws, relu, nbands);                               \
+  }
+  if (aq && up) CDN_GO(true, 1, 1)
+  else if (aq && stride == 2) CDN_GO(true, 0, 2)
+  else if (aq) CDN_GO(true, 0, 1)
+  else if (up) CDN_GO(false, 1, 1)
+  else if (stride == 2) CDN_GO(false, 0, 2)
+  else CDN_GO(false, 0, 1)
+#undef CDN_GO
+  return cdn::check_launch("codenet dw3x3");
+}
+
+// dst[m][2i] = fq_A(srcA[m][i]), dst[m][2i+1] = fq_B(srcB[m][i]): see interleave_kernel.
+extern "C" int cdn_codenet_interleave_forward(const float *srcA, int64_t ldA, const void *qA,
+                                              const float *srcB, int64_t ldB, const void *qB,
+                                              int64_t M, int64_t h, float *dst, int64_t ld_dst,
+                                              void *stream) {
+  CDN_REQUIRE(dst && (srcA || srcB), CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(M > 0 && h > 0 && ld_dst >= 2 * h && (!srcA || ldA >= h) && (!srcB || ldB >= h),
+              CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(M * ld_dst < (1ll << 40), CDN_ERR_UNSUPPORTED, "shape too large");
+  hipStream_t st = cdn::as_stream(stream);
+  const long total = (long)(M * h);
+  const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(total, 256), (long)cdn::kCUs * 32);
+  interleave_kernel<<<blocks, 256, 0, st>>>(srcA, (int)ldA, static_cast<const unsigned *>(qA), srcB,
+                                            (int)ldB, static_cast<const unsigned *>(qB), dst,
+                                            (int)ld_dst, (long)M, (int)h);
+  return cdn::check_launch("codenet interleave");
+}
+
+// Dense 3x3 conv 3 -> Co on the NCHW image, channels-last output: see stem_kernel.
+extern "C" int cdn_codenet_stem_forward(const float *img, int64_t N, int64_t H, int64_t W, int64_t Co,
+                                        int stride, const float *w, const float *bias, int relu,
+                                        float *r_min, float *r_max, void *r_state, int bits,
+                                        double momentum, int running, void *workspace,
+                                        size_t workspace_bytes, float *out, void *stream) {
+  CDN_REQUIRE(img && w && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && H > 0 && W > 0 && stride >= 1, CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(Co == 24, CDN_ERR_UNSUPPORTED, "stem kernel is instantiated for 24 output channels (got %lld)",
+              (long long)Co);
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
+  const int Ho = (int)((H + 2 - 3) / stride + 1), Wo = (int)((W + 2 - 3) / stride + 1);
+  dim3 grid((unsigned)cdn::ceil_div((long)Ho * Wo, 256), (unsigned)N);
+  CDN_REQUIRE(N <= 65535 && (long)grid.x * grid.y <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
+  cdn::AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+  stem_kernel<24><<<grid, 256, 0, st>>>(img, w, bias, out, r_state ? ws.partials : nullptr, qu, (int)H,
+                                        (int)W, Ho, Wo, stride, relu);
+  return cdn::check_launch("codenet stem");
+}
+
+// The tail of a W4A8 detection head in one kernel: see head_tail_kernel.
+extern "C" int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
+                                             int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
+                                             const void *y2_qstate, const signed char *w_codes,
+                                             const float *w_scale, const int *w_colsum, const float *w,
+                                             const float *bias, int64_t classes, float *out_nchw,
+                                             void *stream) {
+  CDN_REQUIRE(y1 && y1_qstate && w_dw && y2_qstate && w_codes && w_scale && w_colsum && w && out_nchw,
+              CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && Hs > 0 && Ws > 0 && classes > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE((C & 3) == 0 && classes <= 32 && (Ws & 7) == 0 && 4 * Ws <= 512 && N <= 65535 && Hs <= 65535,
+              CDN_ERR_UNSUPPORTED, "head tail needs C %% 4 == 0, <= 32 classes, Ws %% 8 == 0, Ws <= 128");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_codes) & 15) == 0,
+              CDN_ERR_ARG, "y1 / w_codes must be 16-byte aligned");
+  const int Cpad = (int)((C + 63) / 64 * 64);
+  const int npix = (int)(4 * Ws);
+  const size_t tile = (size_t)3 * (Ws + 2) * 8 * 16, a_bytes = (size_t)npix * kHtLDF * 4,
+               b_bytes = (size_t)32 * kHtLDF * 4;
+  const size_t lds = std::max(tile + a_bytes + b_bytes, (size_t)32 * (npix + 1) * 4);
+  CDN_REQUIRE(lds <= 160 * 1024, CDN_ERR_UNSUPPORTED, "row too wide for LDS");
+  hipStream_t st = cdn::as_stream(stream);
+  cdn::ProfScope ps(cdn::kProfDw, (int)Hs, st);
+  auto kern = Ws <= 64 ? head_tail_kernel<2> : head_tail_kernel<4>;
+  (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<dim3((unsigned)Hs, (unsigned)N), 256, lds, st>>>(
+      y1, static_cast<const unsigned *>(y1_qstate), w_dw, b_dw, static_cast<const unsigned *>(y2_qstate),
+      w_codes, w_scale, w_colsum, w, bias, out_nchw, (int)C, Cpad, (int)Hs, (int)Ws, (int)classes);
+  return cdn::check_launch("codenet head tail");
+}
+
