@@ -272,6 +272,30 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
     return output, dets
 
 
+def capture_process(model, images, reg_offset=True, cat_spec_wh=False, K=100):
+    """Capture ``process(model, images, flip_test=False)`` -- the whole fused network + native decode -- over the
+    static `images` buffer into one HIP graph (about 110 kernel launches; at small batches the Python /
+    launch overhead of issuing them one by one dominates).  Returns replay() -> (output dict, dets); copy
+    new images into `images` before each replay.  Needs model.enable_fused() and a GPU tensor."""
+    assert getattr(model, "_fused", False) and images.is_cuda
+    kw = dict(flip_test=False, reg_offset=reg_offset, cat_spec_wh=cat_spec_wh, K=K)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                 # warm-up: buffers, cached weights, kernel attributes
+        for _ in range(3):
+            process(model, images, **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        result = process(model, images, **kw)
+
+    def replay():
+        graph.replay()
+        return result
+    return replay
+
+
 def create_model(heads=None, head_conv=64, w2=False, maxpool=False, quantize=False, seed=317,
                  w_bit=4, a_bit=8, wt_percentile=False, act_percentile=False):
     """PoseShuffleNetV2 with synthetic weights, optionally rewritten to W4A8 like

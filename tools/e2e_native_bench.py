@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one HIP graph")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = harness.create_model(quantize=not a.fp32).to(dev).enable_fused()
@@ -25,6 +26,11 @@ def main():
 
     def step():
         return harness.process(model, x, flip_test=False)[1]
+    if a.graph:
+        replay = harness.capture_process(model, x)
+
+        def step():   # noqa: F811
+            return replay()[1]
     for _ in range(5):
         step()
     torch.cuda.synchronize()
@@ -35,7 +41,8 @@ def main():
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     assert torch.isfinite(dets).all()
     print(json.dumps({"config": "CoDeNet1x %dx%d %s batch %d, whole network + ctdet_decode native" % (
-        a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch), "ms_per_batch": round(ms, 4),
+        a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch) + (", HIP graph" if a.graph else ""),
+        "ms_per_batch": round(ms, 4),
         "images_per_s": round(a.batch / ms * 1e3)}))
 
 
