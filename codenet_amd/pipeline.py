@@ -495,7 +495,7 @@ class FusedBackbone:
                 for name in ("layer1", "layer2", "layer3"):
                     for node in getattr(model, name):
                         ok = ok and hasattr(node, "b2") and len(node.b2) == 8
-                return bool(ok)
+                return bool(ok) and l4[0].out_channels % 4 == 0
             ok = (isinstance(l0[0], QuantBnConv2d) and len(l0[1]) == 2 and isinstance(l0[1][1], QuantAct)
                   and l0[0].conv.out_channels == 24 and l0[0].conv.in_channels == 3
                   and tuple(l0[0].conv.kernel_size) == (3, 3) and tuple(l0[0].conv.padding) == (1, 1)
@@ -504,7 +504,9 @@ class FusedBackbone:
                 for node in getattr(model, name):
                     ok = ok and isinstance(node, QuantBaseNode) and node.quant_act.quant_mode == "asymmetric" \
                         and node.quant_act2.quant_mode == "asymmetric"
-            return bool(ok)
+            # the channels-last hand-over into stage 0 needs C % 4 == 0 (CoDeNet2x: 2153 -> PyTorch backbone)
+            c4 = l4[0].conv.out_channels if hasattr(l4[0], "conv") else l4[0].out_channels
+            return bool(ok) and c4 % 4 == 0
         except (AttributeError, IndexError, TypeError):
             return False
 
