@@ -194,3 +194,37 @@ def test_fused_units_match_reference_golden():
         lsb = (sh.x_max - sh.x_min).item() / 255.0
         d = (got - z["y1_%d" % it]).abs()
         assert d.max().item() <= 2.05 * lsb and (d > 1e-5).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dw3x3_random_shapes_with_quant_on_load(seed):
+    """Random shapes / strides / paddings of the row strides, WITH fake-quantisation on load, against
+    conv2d on the fake-quantised input (cdn_quantact_forward gives the same expression)."""
+    import random
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    rnd = random.Random(seed)
+    N, C = rnd.randint(1, 3), rnd.choice([4, 12, 20, 58, 64, 100])
+    H, W = rnd.randint(3, 20), rnd.randint(3, 20)
+    stride = rnd.choice([1, 2])
+    up = rnd.choice([0, 1]) if stride == 1 else 0
+    ld = (C + 3) // 4 * 4 + rnd.choice([0, 4])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g).to(dev) * 2
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    xq, _ = ops.quantact_forward(x, xmin, xmax, st)                      # tracks the range, returns fq(x)
+    a = torch.zeros(N, H * W, ld, device=dev)
+    a[:, :, :C] = x.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    w = torch.randn(C, 1, 3, 3, generator=g).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    xu = F.interpolate(xq, scale_factor=2, mode="nearest") if up else xq
+    ref = torch.relu(F.conv2d(xu, w, b, stride, 1, 1, C))
+    Ho, Wo = ref.shape[2:]
+    out = torch.zeros(N, Ho * Wo, ld, device=dev)
+    rc = lib.cdn_codenet_dw3x3_nhwc_forward(
+        a.data_ptr(), st.data_ptr(), N, C, H, W, up, stride, ld, ld, w.data_ptr(), b.data_ptr(), None, None, 1,
+        None, None, None, 8, 0.99, 0, None, 0, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "dw3")
+    got = out[:, :, :C].reshape(N, Ho, Wo, C).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 2e-5 * (1 + ref.abs().max().item())

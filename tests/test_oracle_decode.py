@@ -92,3 +92,21 @@ def test_hip_decode_edge_cases(case):
     d2 = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda(), K=K,
                                      apply_sigmoid=(case == "sigmoid")).cpu().numpy()
     assert np.array_equal(d, d2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cat,H,W,K,spec,use_reg", [
+    (1, 1, 5, 7, 1, False, False), (2, 3, 9, 13, 40, True, True), (1, 20, 128, 128, 1024, False, True),
+    (4, 2, 16, 16, 512, False, False), (1, 80, 32, 48, 100, True, True)])
+def test_hip_decode_random_shapes(B, cat, H, W, K, spec, use_reg):
+    """Odd widths (scalar key stores), K = 1 and K = 1024, cat_spec_wh, no reg."""
+    from codenet_amd import harness
+    g = torch.Generator().manual_seed(B * 1000 + cat * 10 + K)
+    heat = torch.sigmoid(torch.randn(B, cat, H, W, generator=g) * 3)
+    wh = torch.rand(B, 2 * cat if spec else 2, H, W, generator=g) * 7
+    reg = torch.rand(B, 2, H, W, generator=g) if use_reg else None
+    d = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda() if use_reg else None,
+                                    cat_spec_wh=spec, K=K).cpu().numpy()
+    o = OD.ctdet_decode(heat.numpy(), wh.numpy(), reg.numpy() if use_reg else None, spec, K)
+    assert np.array_equal(d[..., 4:], o[..., 4:])
+    assert np.abs(d[..., :4] - o[..., :4]).max() < 1e-4
