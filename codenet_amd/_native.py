@@ -46,6 +46,7 @@ _SIGNATURES = {
         _i, [_vp, _vp] + [_i64] * 4 + [_vp] * 8 + [_i64, _vp, _vp]),
     "cdn_codenet_interleave_forward": (
         _i, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "cdn_codenet_maxpool3x3s2_nhwc_forward": (_i, [_vp, _vp] + [_i64] * 4 + [_vp, _vp]),
     "cdn_codenet_stem_forward": (
         _i, [_vp] + [_i64] * 4 + [_i] + [_vp, _vp, _i] + [_vp] * 3 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_ctdet_decode_workspace_bytes": (ctypes.c_size_t, [_i64] * 4),

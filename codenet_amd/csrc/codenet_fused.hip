@@ -1747,11 +1747,15 @@ extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate
                                        void *stream) {
   CDN_REQUIRE(r_nhwc && out_nchw, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1), CDN_ERR_ARG, "bad size");
-  CDN_REQUIRE(N <= 65535 && H <= 65535 && (size_t)W * (C + 1) * 4 <= 64 * 1024, CDN_ERR_UNSUPPORTED,
+  CDN_REQUIRE(N <= 65535 && H <= 65535 && (size_t)W * (C + 1) * 4 <= 150 * 1024, CDN_ERR_UNSUPPORTED,
               "row of %lld pixels x %lld channels does not fit the LDS transpose tile", (long long)W,
               (long long)C);
   hipStream_t st = cdn::as_stream(stream);
   const size_t lds = (size_t)W * (C + 1) * sizeof(float);
+  if (lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void *)unpack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)unpack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   dim3 grid((unsigned)H, (unsigned)N);
   cdn::ProfScope ps(cdn::kProfUnpack, (int)(H > 0xffff ? 0xffff : H), st);
   if (r_qstate)

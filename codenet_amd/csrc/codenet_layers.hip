@@ -478,6 +478,46 @@ head_tail_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// maxpool: MaxPool2d(3, stride 2, padding 1) of the "S2 + MaxPool" stems (shufflenetv2_dcn.py:209-214;
+// W4A8: after ReLU + QuantAct, quantize_model.py:30-33), channels-last, one float4 of channels per lane.
+// Fake-quantisation is monotone, so it is applied once to the window maximum (max fq(x) = fq(max x)).
+// ------------------------------------------------------------------------------------------
+template <bool XQ>
+__global__ void __launch_bounds__(256)
+maxpool_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, float *__restrict__ out, int C,
+               int H, int W, int Ho, int Wo, long total) {
+  float qs = 1.f, qz = 0.f;
+  if (XQ) {
+    qs = reinterpret_cast<const float *>(aq)[2];
+    qz = reinterpret_cast<const float *>(aq)[3];
+  }
+  const int CQ = C >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const int cq = (int)(q % CQ);
+    long pix = q / CQ;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho), n = (int)(pix / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int y = 2 * oy + dy - 1, x = 2 * ox + dx - 1;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+          const float4 v = *reinterpret_cast<const float4 *>(a + (((long)n * H + y) * W + x) * C + cq * 4);
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+      }
+    if (XQ) {
+      m.x = fake_quant(m.x, qs, qz); m.y = fake_quant(m.y, qs, qz);
+      m.z = fake_quant(m.z, qs, qz); m.w = fake_quant(m.w, qs, qz);
+    }
+    *reinterpret_cast<float4 *>(out + (((long)n * Ho + oy) * Wo + ox) * C + cq * 4) = m;
+  }
+}
+
 }  // namespace
 
 extern "C" int cdn_codenet_dw3x3_nhwc_forward(
@@ -617,3 +657,22 @@ extern "C" int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qst
   return cdn::check_launch("codenet head tail");
 }
 
+
+// out[n][oy*Wo+ox][c] = max_{3x3, stride 2, pad 1} fq(a[n][..][c]): see maxpool_kernel.
+extern "C" int cdn_codenet_maxpool3x3s2_nhwc_forward(const float *a, const void *a_qstate, int64_t N, int64_t C,
+                                                     int64_t H, int64_t W, float *out, void *stream) {
+  CDN_REQUIRE(a && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (C & 3) == 0, CDN_ERR_ARG, "bad size (C %% 4 == 0)");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+              CDN_ERR_ARG, "a / out must be 16-byte aligned");
+  const int Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipStream_t st = cdn::as_stream(stream);
+  const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(total, 256), (long)cdn::kCUs * 32);
+  if (a_qstate)
+    maxpool_kernel<true><<<blocks, 256, 0, st>>>(a, static_cast<const unsigned *>(a_qstate), out, (int)C, (int)H,
+                                                 (int)W, Ho, Wo, total);
+  else
+    maxpool_kernel<false><<<blocks, 256, 0, st>>>(a, nullptr, out, (int)C, (int)H, (int)W, Ho, Wo, total);
+  return cdn::check_launch("codenet maxpool");
+}

@@ -115,7 +115,7 @@ class PoseShuffleNetV2(nn.Module):
                 self._fbackbone = (pipeline.FusedBackbone(self)
                                    if self._fused_backbone and pipeline.FusedBackbone.supported(self) else None)
             if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
-                feat, fq, hw = self._fbackbone(x)
+                feat, fq, hw = self._fbackbone(x)       # hw None: an NCHW tensor (odd channel count)
                 return [self._fheads(*self._fpath.forward_nhwc(feat, fq, hw))]
             x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
             return [self._fheads(*self._fpath.forward_nhwc(x))]

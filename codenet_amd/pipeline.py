@@ -489,14 +489,16 @@ class FusedBackbone:
             l0, l4 = model.layer0, model.layer4
             if isinstance(l0[0], nn.Conv2d):          # fp32 model: conv, bn, relu stem without max-pool
                 c = l0[0]
-                ok = (len(l0) == 3 and c.out_channels == 24 and c.in_channels == 3 and c.bias is None
+                ok = ((len(l0) == 3 or (len(l0) == 4 and FusedBackbone._is_pool(l0[3])))
+                      and c.out_channels == 24 and c.in_channels == 3 and c.bias is None
                       and tuple(c.kernel_size) == (3, 3) and tuple(c.padding) == (1, 1)
                       and isinstance(l4[0], nn.Conv2d))
                 for name in ("layer1", "layer2", "layer3"):
                     for node in getattr(model, name):
                         ok = ok and hasattr(node, "b2") and len(node.b2) == 8
-                return bool(ok) and l4[0].out_channels % 4 == 0
-            ok = (isinstance(l0[0], QuantBnConv2d) and len(l0[1]) == 2 and isinstance(l0[1][1], QuantAct)
+                return bool(ok)
+            ok = (isinstance(l0[0], QuantBnConv2d) and len(l0[1]) in (2, 3) and isinstance(l0[1][1], QuantAct)
+                  and (len(l0[1]) == 2 or FusedBackbone._is_pool(l0[1][2]))
                   and l0[0].conv.out_channels == 24 and l0[0].conv.in_channels == 3
                   and tuple(l0[0].conv.kernel_size) == (3, 3) and tuple(l0[0].conv.padding) == (1, 1)
                   and isinstance(l4[0], QuantBnConv2d) and isinstance(l4[1][1], QuantAct))
@@ -504,11 +506,16 @@ class FusedBackbone:
                 for node in getattr(model, name):
                     ok = ok and isinstance(node, QuantBaseNode) and node.quant_act.quant_mode == "asymmetric" \
                         and node.quant_act2.quant_mode == "asymmetric"
-            # the channels-last hand-over into stage 0 needs C % 4 == 0 (CoDeNet2x: 2153 -> PyTorch backbone)
-            c4 = l4[0].conv.out_channels if hasattr(l4[0], "conv") else l4[0].out_channels
-            return bool(ok) and c4 % 4 == 0
+            return bool(ok)
         except (AttributeError, IndexError, TypeError):
             return False
+
+    @staticmethod
+    def _is_pool(m):
+        def two(v):
+            return (v, v) if isinstance(v, int) else tuple(v)
+        return (isinstance(m, nn.MaxPool2d) and two(m.kernel_size) == (3, 3) and two(m.stride) == (2, 2)
+                and two(m.padding) == (1, 1) and two(m.dilation) == (1, 1) and not m.ceil_mode)
 
     # -- low-level launches ----------------------------------------------------------------------
     def _act_args(self, act, dev):
@@ -684,6 +691,15 @@ class FusedBackbone:
                 *self._act_args(act0, dev), self._ws_ptr, self._ws_bytes, B["t0"].data_ptr(), self._stream)
             N_.check(rc, "cdn_codenet_stem_forward")
             x, x_ld, x_q = B["t0"], 24, qptr(act0)          # pre-quantisation values + state
+            pooled = (len(m.layer0[1]) == 3) if quant else (len(m.layer0) == 4)
+            if pooled:                                      # "S2 + MaxPool" stems (configs b, e)
+                Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                if B.get("tp") is None or B["tp"].shape != (Nb, Hp * Wp, 24):
+                    B["tp"] = torch.empty(Nb, Hp * Wp, 24, device=dev)
+                rc = N_.lib().cdn_codenet_maxpool3x3s2_nhwc_forward(x.data_ptr(), x_q, Nb, 24, H, W,
+                                                                    B["tp"].data_ptr(), self._stream)
+                N_.check(rc, "cdn_codenet_maxpool3x3s2_nhwc_forward")
+                x, x_q, H, W = B["tp"], None, Hp, Wp         # final values from here on
             for name in ("layer1", "layer2", "layer3"):
                 x, x_ld, H, W = self.run_units(list(getattr(m, name)), x, x_ld, x_q, Nb, H, W)
                 x_q = None
@@ -691,4 +707,13 @@ class FusedBackbone:
             if B.get("out") is None or B["out"].shape != (Nb, H * W, c4):
                 B["out"] = torch.empty(Nb, H * W, c4, device=dev)
             self._pw(x.data_ptr(), None, Nb * H * W, x_ld, q4, True, act4, B["out"], 0)
+            if c4 % 4:
+                # the channels-last hand-over into stage 0 needs C % 4 == 0; CoDeNet2x's 2153 channels are
+                # materialised as the NCHW tensor the stage takes from a PyTorch backbone (fake-quantised)
+                if B.get("out_nchw") is None or B["out_nchw"].shape != (Nb, c4, H, W):
+                    B["out_nchw"] = torch.empty(Nb, c4, H, W, device=dev)
+                rc = N_.lib().cdn_codenet_unpack_nchw(B["out"].data_ptr(), qptr(act4), B["out_nchw"].data_ptr(),
+                                                      Nb, c4, H, W, 0, self._stream)
+                N_.check(rc, "cdn_codenet_unpack_nchw")
+                return B["out_nchw"], None, None
         return B["out"], qptr(act4), (H, W)

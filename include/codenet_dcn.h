@@ -303,6 +303,12 @@ int cdn_codenet_stem_forward(const float *img, int64_t N, int64_t H, int64_t W, 
                              void *r_state, int bits, double momentum, int running, void *workspace,
                              size_t workspace_bytes, float *out, void *stream);
 
+/* MaxPool2d(3, stride 2, padding 1) of the "S2 + MaxPool" stems (shufflenetv2_dcn.py:209-214; configs b / e),
+ * channels-last: out[n][oy*Wo+ox][c] = max over the window of fq(a[n][y*W+x][c]) (a_qstate NULL: no
+ * quantiser); Ho = (H-1)/2+1.  C % 4 == 0. */
+int cdn_codenet_maxpool3x3s2_nhwc_forward(const float *a, const void *a_qstate, int64_t N, int64_t C,
+                                          int64_t H, int64_t W, float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * ctdet_decode (lib/models/decode.py:474-505 with _nms :10-16 and _topk :110-127; SURVEY.md section
  * 8f row 2): 3x3 peak filter, top-K over all classes, reg / wh gather, boxes.
