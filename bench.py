@@ -104,12 +104,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)          # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     from codenet_amd import ops, pipeline
 
@@ -138,7 +138,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     if quantized and args.frozen:          # ranges must exist before they can be frozen
