@@ -1704,7 +1704,8 @@ extern "C" int cdn_codenet_stage_fused_forward(
                                                               smm, qu_s, (int)C, npix, lo, hi);
   } else if (x_nhwc) {
     const long npix = (long)(N * HWl);
-    const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
+    static const int bpc = getenv("CDN_SCALE_BPC") ? atoi(getenv("CDN_SCALE_BPC")) : 8;   // tuning knob
+    const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * bpc);
     n_part_s = blocks;
     if (xq)
       scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, qu_s,

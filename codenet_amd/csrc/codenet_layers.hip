@@ -262,16 +262,23 @@ stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const fl
                                          ? img[(((long)n * 3 + c) * H + y) * W + x] : 0.0f;
         }
     float *op = out + ((long)n * Ho * Wo + p) * CO;
+    static_assert(CO % 4 == 0, "16-byte stores");
 #pragma unroll
-    for (int co = 0; co < CO; ++co) {
-      float acc = 0.f;
+    for (int c4 = 0; c4 < CO; c4 += 4) {
+      float r4[4];
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
-      acc += bias ? bias[co] : 0.0f;
-      if (relu) acc = fmaxf(acc, 0.0f);
-      op[co] = acc;
-      mn = fminf(mn, acc);
-      mx = fmaxf(mx, acc);
+      for (int e = 0; e < 4; ++e) {
+        const int co = c4 + e;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+        acc += bias ? bias[co] : 0.0f;
+        if (relu) acc = fmaxf(acc, 0.0f);
+        r4[e] = acc;
+        mn = fminf(mn, acc);
+        mx = fmaxf(mx, acc);
+      }
+      *reinterpret_cast<float4 *>(op + c4) = make_float4(r4[0], r4[1], r4[2], r4[3]);   // 96-byte pixel rows
     }
   }
   if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu, red);
