@@ -63,6 +63,48 @@ def test_argument_validation_without_gpu():
     assert rc == -1                                     # ep_scale without ep_shift
 
 
+def test_argument_validation_of_the_layer_entry_points_without_gpu():
+    """The entry points around the hot path (heads, backbone layers, decode) validate before any HIP call."""
+    from codenet_amd import _native
+    lib = _native.lib()
+    one = 4096
+    assert lib.cdn_codenet_aux_workspace_bytes() >= 16384 * 8
+    # pointwise: output QuantAct given without a workspace
+    rc = lib.cdn_codenet_pointwise_nhwc_forward(one, None, 64, 16, 16, 0, 0, one, None, None, None, None,
+                                                None, None, 1, one, one, one, 8, 0.99, 1, None, 0, one, None)
+    assert rc != 0 and b"workspace" in lib.cdn_last_error()
+    # pointwise: row stride smaller than the channel count
+    rc = lib.cdn_codenet_pointwise_nhwc_forward(one, None, 64, 16, 16, 8, 0, one, None, None, None, None,
+                                                None, None, 1, None, None, None, 8, 0.99, 0, None, 0, one, None)
+    assert rc != 0 and b"stride" in lib.cdn_last_error()
+    # depthwise: up-sampling together with stride 2; row stride not a multiple of 4
+    rc = lib.cdn_codenet_dw3x3_nhwc_forward(one * 4, None, 1, 8, 8, 8, 1, 2, 0, 0, one, None, None, None, 1,
+                                            None, None, None, 8, 0.99, 0, None, 0, one, None)
+    assert rc != 0
+    rc = lib.cdn_codenet_dw3x3_nhwc_forward(one * 4, None, 1, 6, 8, 8, 0, 1, 6, 6, one, None, None, None, 1,
+                                            None, None, None, 8, 0.99, 0, None, 0, one, None)
+    assert rc != 0 and b"ld_in" in lib.cdn_last_error()
+    # interleave: destination row narrower than 2 h
+    rc = lib.cdn_codenet_interleave_forward(one, 8, None, one, 8, None, 10, 8, one, 12, None)
+    assert rc != 0
+    # stem: only the 24-channel instantiation exists
+    rc = lib.cdn_codenet_stem_forward(one, 1, 32, 32, 16, 4, one, None, 1, None, None, None, 8, 0.99, 0,
+                                      None, 0, one, None)
+    assert rc != 0 and b"24" in lib.cdn_last_error()
+    # head tail: more than 32 classes
+    rc = lib.cdn_codenet_head_tail_forward(one * 4, one, 1, 64, 8, 8, one, None, one, one * 4, one, one, one,
+                                           None, 80, one, None)
+    assert rc != 0
+    # decode: K larger than the map, missing workspace
+    assert lib.cdn_ctdet_decode_workspace_bytes(2, 20, 128, 128) >= 2 * 20 * 128 * 128 * 4
+    rc = lib.cdn_ctdet_decode(one, one, None, 1, 2, 4, 4, 0, 100, 0, None, one, one * 64, 1 << 20, None)
+    assert rc != 0
+    rc = lib.cdn_ctdet_decode(one, one, None, 1, 2, 8, 8, 0, 10, 0, None, one, None, 0, None)
+    assert rc != 0
+    rc = lib.cdn_codenet_maxpool3x3s2_nhwc_forward(one * 4, None, 1, 6, 8, 8, one * 4, None)
+    assert rc != 0      # C % 4
+
+
 def test_cpu_tensors_raise_not_implemented():
     from codenet_amd.functions.dcn_deform_conv import deform_conv, modulated_deform_conv
     from codenet_amd import ops
