@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(512) k(float *out, const int *cells, int iters
 #pragma unroll
     for (int r = 0; r < NREAD; ++r) {
       int c = cell + (r * 5) % 31;
-      if (MODE == 1) c = (c + cells[(it + r) & 63]) % ncell;   // data-dependent (uniform per wave)
+      // scattered: every 16-lane pixel group reads a different pseudo-random cell each time (2 VALU ops)
+      if (MODE == 1) c = (cell * 37 + r * 53 + it * 11 + sub * 101) & 255;
       o[r] = c * 256;
     }
 #pragma unroll
@@ -59,9 +60,11 @@ int main() {
            us * 1e3 / (reads / 256), us * 1e3 / (reads / 256) * 2.4, 1024.0 / (us * 1e3 / (reads / 256) * 2.4));
   };
   rep("25 reads/iter, 2 WG x 512 thr, static cells", run<0, 25>(d, cells, 2, 512, iters), 2, 512, 25);
-  rep("25 reads/iter, 2 WG x 512 thr, dynamic cells", run<1, 25>(d, cells, 2, 512, iters), 2, 512, 25);
+  rep("25 reads/iter, 2 WG x 512 thr, scattered cells", run<1, 25>(d, cells, 2, 512, iters), 2, 512, 25);
   rep("25 reads/iter, 1 WG x 512 thr, static cells", run<0, 25>(d, cells, 1, 512, iters), 1, 512, 25);
   rep("25 reads/iter, 1 WG x 256 thr, static cells", run<0, 25>(d, cells, 1, 256, iters), 1, 256, 25);
   rep("8 reads/iter, 2 WG x 512 thr, static cells", run<0, 8>(d, cells, 2, 512, iters), 2, 512, 8);
+  rep("4 reads/iter, 2 WG x 512 thr, scattered cells", run<1, 4>(d, cells, 2, 512, iters), 2, 512, 4);
+  rep("25 reads/iter, 1 WG x 256 thr, scattered cells", run<1, 25>(d, cells, 1, 256, iters), 1, 256, 25);
   return 0;
 }
