@@ -105,6 +105,15 @@ def test_argument_validation_of_the_layer_entry_points_without_gpu():
     assert rc != 0      # C % 4
 
 
+def test_hot_kernels_stay_inside_their_register_budget():
+    """hipcc -S metadata (no GPU): no spills / scratch in the hot kernels and the occupancy-defining VGPR
+    budgets hold -- the stage-0 gather sits at 127 of 128 VGPRs and a spill costs 20-150 us per launch."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_resources
+    res, problems = check_resources.check()
+    assert not problems, "\n".join(problems)
+
+
 def test_cpu_tensors_raise_not_implemented():
     from codenet_amd.functions.dcn_deform_conv import deform_conv, modulated_deform_conv
     from codenet_amd import ops

@@ -1,0 +1,65 @@
+"""Register / scratch budget of the hot kernels, from the compiler's own metadata (hipcc -S, no GPU needed).
+The stage-0 gather runs at 127 of the 128 VGPRs its 16-waves-per-CU launch allows: one more live value and
+the compiler spills, which costs 20-150 us per launch (seen with the stamp instrumentation, 56 -> 78 us, and
+with an extra kernel argument, 56 -> 202 us).  tests/test_host_api.py runs this as a regression guard."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "codenet_amd", "csrc")
+# kernel name fragment -> (max VGPRs incl. AGPRs, or None) ; spills / scratch must be zero for all of them
+BUDGET = {
+    "dw2_kernelILi64ELb0ELb0ELb1ELi1024": 128,    # stage 0, W4A8 (NCHW input, s quantised)
+    "dw2_kernelILi64ELb0ELb0ELb0ELi1024": 128,    # stage 0, fp32
+    "dw2u_kernelILi64ELb1ELb1": 256,              # stage 1
+    "dw2u_kernelILi32ELb1ELb1": 256,              # stage 2
+    "pwi8_kernelILi64ELi128ELi2ELb1": 128,        # stages 0-1: four workgroups per CU
+    "pwi8_kernelILi128ELi64ELi4ELb1": 128,        # stage 2
+    "scale_nchw_kernel": 128, "scale_nhwc_kernelILb1": 128, "unpack_kernelILb1": 128,
+}
+
+
+def kernel_resources(src="codenet_fused.hip"):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+                        "-munsafe-fp-atomics", "-S", "--cuda-device-only", "-o", out, src],
+                       cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    res = {}
+    for blk in re.findall(r"- \.agpr_count:.*?\.wavefront_size: \d+", txt, re.S):
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))   # noqa: E731
+        res[name] = dict(vgpr=g("vgpr_count"), spill=g("vgpr_spill_count"), sgpr_spill=g("sgpr_spill_count"),
+                         scratch=g("private_segment_fixed_size"), lds=g("group_segment_fixed_size"))
+    return res
+
+
+def check():
+    res = kernel_resources()
+    problems = []
+    for frag, cap in BUDGET.items():
+        hits = [(n, r) for n, r in res.items() if frag in n]
+        if not hits:
+            problems.append("kernel %s not found" % frag)
+        for n, r in hits:
+            if r["spill"] or r["scratch"] or r["sgpr_spill"]:
+                problems.append("%s spills: %s" % (n, r))
+            if cap is not None and r["vgpr"] > cap:
+                problems.append("%s uses %d VGPRs (budget %d)" % (n, r["vgpr"], cap))
+    return res, problems
+
+
+if __name__ == "__main__":
+    res, problems = check()
+    for frag in BUDGET:
+        for n, r in res.items():
+            if frag in n:
+                print("%-70s %s" % (n[18:88], r))
+    if problems:
+        print("\n".join(problems))
+        sys.exit(1)
+    print("ok")
