@@ -100,8 +100,9 @@ constexpr int kArriveGroups = 64;
 constexpr int kArriveWords = (kArriveGroups + 1) * 16;
 
 __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float bmin, float bmax,
-                                                       bool have_stats) {
-  float lo = u.x_min[0], hi = u.x_max[0];
+                                                       bool have_stats, bool preloaded = false,
+                                                       float pre_lo = 0.f, float pre_hi = 0.f) {
+  float lo = preloaded ? pre_lo : u.x_min[0], hi = preloaded ? pre_hi : u.x_max[0];
   float *sf = reinterpret_cast<float *>(u.state);
   if (have_stats) {
     sf[4] = bmin;
@@ -138,17 +139,22 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
   u.state[6] = wide;
 }
 
-// Epilogue of a producer kernel in the fused schedule: workgroup min/max -> partials[bid] ->
-// arrival ticket; the LAST workgroup to arrive reduces all partials and runs the range update, so
-// no separate update launch (~4.4 us each inside a graph) and no contended atomics are needed.
-// Cross-workgroup visibility: the 8-byte partial is written and read with agent-scope atomics
-// (sc1, bypassing the non-coherent L1s; MI355X_MICROARCH.md "Valid forms": 8-B agent atomics on both
-// sides), the ticket is an agent-scope fetch-add issued after the store has drained.  Tickets are
-// two-level (workgroup -> one of 64 group counters -> top counter) so no word sees more than
-// max(64, nblocks/64) arrivals.  The counters start at zero and the last arriver resets them.
-// Every thread of the workgroup must call this; `red` is >= 2*nwaves + 2 floats of free LDS.
+// Epilogue of a producer kernel in the fused schedule: workgroup min/max -> the workgroup's GROUP LINE ->
+// arrival ticket; the LAST workgroup to arrive reads the 64 group lines and runs the range update, so no
+// separate update launch (~4.4 us each inside a graph) and no heavily contended atomics are needed.
+// A group line is one 64-byte line {count, max of ~ord(min), max of ord(max)} (ordered-uint images, so both
+// extremes are integer atomicMax starting from 0).  A workgroup issues atomicMax, atomicMax, fetch-add to
+// ITS line back to back: the three go to the same L2 channel in issue order, so when a line's count is
+// complete every member's extremes are in it -- ONE round trip per workgroup instead of store / wait /
+// ticket (measured: the epilogue is the tail of every producing kernel, 9 per step).  Tickets are two-level
+// (workgroup -> one of 64 group lines -> top counter) so no word sees more than max(64, nblocks/64)
+// arrivals (a single contended word sustains only ~88 atomics/us).  Lines start at zero and the last
+// arriver zeroes them again.  Cross-workgroup visibility: agent-scope atomics on both sides (sc1,
+// bypassing the non-coherent L1s).  Every thread of the workgroup must call this; `red` is
+// >= 2*nwaves + 2 floats of free LDS.  (`partials` is unused by this protocol.)
 __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *partials, int bid,
                                                     int nblocks, const QUpdate &u, float *red) {
+  (void)partials;
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
     mn = fminf(mn, __shfl_xor(mn, m, 64));
@@ -161,22 +167,22 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
     red[2 * wave + 1] = mx;
   }
   __syncthreads();
-  unsigned long long *pp = reinterpret_cast<unsigned long long *>(partials);
+  float pre_lo = 0.f, pre_hi = 0.f;
   if (threadIdx.x == 0) {
+    pre_lo = u.x_min[0];      // in flight during the ticket round trip (only the last arriver uses them)
+    pre_hi = u.x_max[0];
     for (int i = 1; i < nw; ++i) {
       mn = fminf(mn, red[2 * i]);
       mx = fmaxf(mx, red[2 * i + 1]);
     }
-    const unsigned long long bits = (unsigned long long)__float_as_uint(mn) |
-                                    ((unsigned long long)__float_as_uint(mx) << 32);
-    __hip_atomic_store(pp + bid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ngroups = nblocks < kArriveGroups ? nblocks : kArriveGroups;
     const int g = bid % kArriveGroups;
     const unsigned gsize = (unsigned)((nblocks - g + kArriveGroups - 1) / kArriveGroups);
+    unsigned *line = u.counters + 16 * g;
     bool last = false;
-    const unsigned t1 = __hip_atomic_fetch_add(&u.counters[16 * g], 1u, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(line + 1, ~f2ord(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(line + 2, f2ord(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t1 = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t1 == gsize - 1) {
       const unsigned t2 = __hip_atomic_fetch_add(&u.counters[16 * kArriveGroups], 1u,
                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -186,36 +192,29 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
   }
   __syncthreads();
   if (red[2 * nw] == 0.0f) return;
-  // ---- last workgroup: reduce every partial, update ranges and parameters -------------------
-  mn = INFINITY;
-  mx = -INFINITY;
-  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
-    const unsigned long long b =
-        __hip_atomic_load(pp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mn = fminf(mn, __uint_as_float((unsigned)(b & 0xffffffffull)));
-    mx = fmaxf(mx, __uint_as_float((unsigned)(b >> 32)));
-  }
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, m, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
-    red[2 * wave] = mn;
-    red[2 * wave + 1] = mx;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < nw; ++i) {
-      mn = fminf(mn, red[2 * i]);
-      mx = fmaxf(mx, red[2 * i + 1]);
+  // ---- last workgroup: wave 0 reads the group lines, updates ranges and parameters ---------------
+  if (threadIdx.x < 64) {
+    const int ngroups = nblocks < kArriveGroups ? nblocks : kArriveGroups;
+    mn = INFINITY;
+    mx = -INFINITY;
+    if ((int)threadIdx.x < ngroups) {
+      unsigned *line = u.counters + 16 * threadIdx.x;
+      mn = ord2f(~__hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      mx = ord2f(__hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
-    quantact_update_device(u, mn, mx, true);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, m, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    }
+    if (threadIdx.x == 0) quantact_update_device(u, mn, mx, true, true, pre_lo, pre_hi);
+    // everybody has arrived: leave the lines zero again
+    __hip_atomic_store(&u.counters[16 * threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&u.counters[16 * threadIdx.x + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&u.counters[16 * threadIdx.x + 2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (threadIdx.x <= kArriveGroups)   // everybody has arrived: leave the counters zero again
-    __hip_atomic_store(&u.counters[16 * threadIdx.x], 0u, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 64)
+    __hip_atomic_store(&u.counters[16 * kArriveGroups], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Workgroup-level min/max -> ONE {min,max} pair stored at out[0] (plain store, no atomics: a

@@ -228,3 +228,43 @@ def test_dw3x3_random_shapes_with_quant_on_load(seed):
     N_.check(rc, "dw3")
     got = out[:, :, :C].reshape(N, Ho, Wo, C).permute(0, 3, 1, 2)
     assert (got - ref).abs().max().item() < 2e-5 * (1 + ref.abs().max().item())
+
+
+def test_range_epilogue_stress_exact_extremes():
+    """The producers' range epilogue (workgroup extremes + arrival ticket on one group line, last arriver
+    reduces) must see EVERY workgroup's extremes: identity depthwise pass over planes whose minimum and
+    maximum sit in single random elements, back-to-back launches, batch extremes compared bit for bit."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(11)
+    shapes = [(8, 64, 64, 64), (2, 116, 40, 40), (1, 32, 7, 9), (16, 24, 48, 48)]
+    stream = torch.cuda.current_stream().cuda_stream
+    got, exp = [], []
+    for it in range(240):
+        N, C, H, W = shapes[it % len(shapes)]
+        x = torch.rand(N, H * W, C, generator=g)
+        flat = x.view(-1)
+        i0, i1 = torch.randint(0, flat.numel(), (2,), generator=g).tolist()
+        flat[i0], flat[i1] = -3.0 - it, 5.0 + it
+        a = x.to(dev)
+        w = torch.zeros(C, 1, 3, 3)
+        w[:, 0, 1, 1] = 1.0
+        w = w.to(dev)
+        b = torch.zeros(C, device=dev)
+        out = torch.empty_like(a)
+        xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+        rc = lib.cdn_codenet_dw3x3_nhwc_forward(
+            a.data_ptr(), None, N, C, H, W, 0, 1, C, C, w.data_ptr(), b.data_ptr(), None, None, 0,
+            xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(), stream)
+        N_.check(rc, "dw3")
+        got.append((xmin, xmax, st, out, a))
+        exp.append((min(-3.0 - it, flat.min().item()), 5.0 + it))
+    torch.cuda.synchronize()
+    for (xmin, xmax, st, out, a), (lo, hi) in zip(got, exp):
+        assert torch.equal(out, a)
+        assert xmin.item() == lo and xmax.item() == hi
+        sf = st.view(torch.float32)
+        assert sf[4].item() == lo and sf[5].item() == hi
+    # the arrival lines are left zeroed for the next producer
+    assert int((ws.view(torch.int32) != 0).sum().item()) == 0
