@@ -1409,6 +1409,189 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 }
 
 // ------------------------------------------------------------------------------------------
+// pwb3: the W4 pointwise conv on FINAL (already fake-quantised, or fp32) activations -- the first 1x1 of a
+// ShuffleNetV2 unit, whose input channels carry different generations of the layer's running QuantAct and
+// so have no common integer grid.  Exact products on the bf16 matrix cores:
+//   x = hi + mid + lo   (three bf16 terms by truncation: 8 + 8 + 8 significant bits, the split is EXACT)
+//   weights  qw in [-8, 7] are exact in bf16,  W' = qw / sw[co]
+//   y[m][co] = (sum_c hi*qw + sum_c mid*qw + sum_c lo*qw) / sw[co] + b
+// every product is exact in fp32 and the accumulation is fp32, as in the f32 MFMA kernel, at 3 of the
+// 16x faster v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 v_mfma_f32_32x32x2f32 (measured: the f32 form
+// was matrix-core bound at conv5, 191 us for 15.6 GFLOP).  Operand lane map: lane (r = l&31, h = l>>5)
+// holds k = 8h..8h+7 of row r.  LDS rows: 32 k (64 B) + 16 B pad = 80 B, conflict-free ds_read_b128.
+// One LDS buffer + register prefetch of the next k-tile (two barriers per tile; 35-40 KiB per workgroup).
+// ------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int kB3LD = 80;
+
+template <int BM, int BN, int WGM>
+__global__ void __launch_bounds__(256)
+pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+            const signed char *__restrict__ Wq, const float *__restrict__ wscale,
+            const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu,
+            long M, int C, int Cpad, int Co, int relu, int lda, int ldo) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+  constexpr int AI = BM * 8 / 256;          // float4 loads of A per thread per k-tile
+  constexpr int BI = (BN * 2 + 255) / 256;  // 16-byte loads of W per thread per k-tile
+  __shared__ __attribute__((aligned(16))) unsigned char Ah[BM * kB3LD];
+  __shared__ __attribute__((aligned(16))) unsigned char Am[BM * kB3LD];
+  __shared__ __attribute__((aligned(16))) unsigned char Al[BM * kB3LD];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * kB3LD];
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
+  const bool has_q = aq != nullptr;
+  float qs = 1.f, qz = 0.f;
+  if (has_q) {
+    qs = reinterpret_cast<const float *>(aq)[2];
+    qz = reinterpret_cast<const float *>(aq)[3];
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
+  const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
+  const bool vec4 = (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const bool vec2 = !vec4 && (C & 1) == 0 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 7) == 0;
+  const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16 codes from bh
+  float4 a[AI];
+  i32x4 b[BI];
+  const float *arow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    long m = m0 + lr + 32 * i;
+    if (m > M - 1) m = M - 1;
+    arow[i] = A + m * lda + lk;
+  }
+  auto load_tile = [&](int k0) {
+    const int k = k0 + lk;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      if (vec4) {
+        a[i] = (k < C) ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (vec2) {
+        const float2 z = make_float2(0.f, 0.f);
+        const float2 lo = (k < C) ? *reinterpret_cast<const float2 *>(arow[i] + k0) : z;
+        const float2 hi = (k + 2 < C) ? *reinterpret_cast<const float2 *>(arow[i] + k0 + 2) : z;
+        a[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      } else {
+        a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
+        a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
+        a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
+        a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int co = n0 + br + 128 * i;
+      if (co > Co - 1) co = Co - 1;
+      b[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + bh);
+    }
+  };
+  // (a.hi16 << 16) | b.hi16
+  auto pack_hi = [](unsigned a_, unsigned b_) -> unsigned { return __builtin_amdgcn_perm(a_, b_, 0x07060302u); };
+  auto store_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      float v[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+      unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (has_q) v[e] = (k0 + lk + e < C) ? fake_quant(v[e], qs, qz) : 0.0f;
+        hb[e] = __float_as_uint(v[e]);
+        const float r1 = __fsub_rn(v[e], __uint_as_float(hb[e] & 0xFFFF0000u));   // exact
+        mb[e] = __float_as_uint(r1);
+        lb[e] = __float_as_uint(__fsub_rn(r1, __uint_as_float(mb[e] & 0xFFFF0000u)));   // exact, <= 8 bits
+      }
+      const int o = (lr + 32 * i) * kB3LD + lk * 2;
+      *reinterpret_cast<uint2 *>(&Ah[o]) = make_uint2(pack_hi(hb[1], hb[0]), pack_hi(hb[3], hb[2]));
+      *reinterpret_cast<uint2 *>(&Am[o]) = make_uint2(pack_hi(mb[1], mb[0]), pack_hi(mb[3], mb[2]));
+      *reinterpret_cast<uint2 *>(&Al[o]) = make_uint2(pack_hi(lb[1], lb[0]), pack_hi(lb[3], lb[2]));
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (br + 128 * i < BN) {
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int word = b[i][e];
+          const unsigned f0 = __float_as_uint((float)((word << 24) >> 24));
+          const unsigned f1 = __float_as_uint((float)((word << 16) >> 24));
+          const unsigned f2 = __float_as_uint((float)((word << 8) >> 24));
+          const unsigned f3 = __float_as_uint((float)(word >> 24));
+          w[2 * e] = pack_hi(f1, f0);
+          w[2 * e + 1] = pack_hi(f3, f2);
+        }
+        unsigned char *dstp = &Bs[(br + 128 * i) * kB3LD + bh * 2];
+        *reinterpret_cast<i32x4 *>(dstp) = (i32x4){(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+        *reinterpret_cast<i32x4 *>(dstp + 16) = (i32x4){(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
+      }
+  };
+
+  const int nk = (C + 31) / 32;   // (Cpad >= 32 * nk: the weight rows are zero padded to 64)
+  load_tile(0);
+  for (int t = 0; t < nk; ++t) {
+    if (t) __syncthreads();       // the previous tile's fragment reads are done
+    store_tile(t * 32);
+    __syncthreads();
+    if (t + 1 < nk) load_tile((t + 1) * 32);
+    const int fo = (lane & 31) * kB3LD + (lane >> 5) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fh[TM], fm[TM], fl[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = (wm + i * 32) * kB3LD + fo + ks * 32;
+        fh[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(&Ah[o]));
+        fm[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(&Am[o]));
+        fl[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(&Al[o]));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4 *>(&Bs[(wn + j * 32) * kB3LD + fo + ks * 32]));
+      // smallest terms first
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    float bsv = 0.f, rinv = 0.f;
+    if (co < Co) {
+      if (bias) bsv = bias[co];
+      rinv = __fdiv_rn(1.0f, wscale[co]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && co < Co) {
+          float v = fmaf(acc[i][j][r], rinv, bsv);
+          if (relu) v = fmaxf(v, 0.0f);
+          R[m * ldo + co] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
+      }
+  }
+  if (rmm)
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&Ah[0]));
+}
+
+// ------------------------------------------------------------------------------------------
 // Final materialisation for the consumer outside the fused path (the detection heads):
 // out[n][c][2h+dy][2w+dx] = fq(r[n][h*W+w][c])   (nearest x2, NCHW, optional fake-quant).
 // One workgroup = (n, one stored row h): reads W*C contiguous floats, transposes through LDS,
@@ -1563,6 +1746,11 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
   } while (0)
   const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
+  // final-valued input (no QuantAct state to derive integer codes from) with 4-bit weight codes: exact
+  // bf16 x 3 split instead of f32 MFMA
+  static const bool no_b3 = getenv("CDN_NO_B3") != nullptr;   // tuning knob
+  const bool use_b3 = !no_b3 && w_pw_codes != nullptr && dst == nullptr && ep_scale == nullptr &&
+                      w_pw_scale != nullptr;
   const int only_if_wide = 0;
   if (use_i8) {
     CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
@@ -1590,6 +1778,22 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI
     // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)
+  } else if (use_b3) {
+    CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
+                "w_pw_codes must be 16-byte aligned");
+    const int Cpad = (int)((C + 63) / 64 * 64);
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+#define CDN_PWB(BM_, BN_, WGM_)                                                                  \
+  do {                                                                                           \
+    dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
+    pwb3_kernel<BM_, BN_, WGM_><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale, bias_pw, r_out, \
+                                                   rmm, qu_r, M, (int)C, Cpad, (int)Co, relu,    \
+                                                   (int)lda, (int)ldo);                          \
+  } while (0)
+    if (pw_bn == 128 && pw_bm == 64) CDN_PWB(64, 128, 2);
+    else if (pw_bn == 128) CDN_PWB(128, 128, 4);
+    else CDN_PWB(128, 64, 4);
+#undef CDN_PWB
   } else {
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {

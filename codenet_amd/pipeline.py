@@ -544,7 +544,8 @@ class FusedBackbone:
         from . import _native as N_
         w, b = self._folded(convbn)
         Co, C = w.shape[0], w.shape[1]
-        i8 = convbn.folded_int8() if (self.int8 and a_q is not None and not isinstance(convbn, tuple)) else None
+        # 4-bit codes: integer MFMA when the input carries a QuantAct state, exact bf16 split otherwise
+        i8 = convbn.folded_int8() if (self.int8 and not isinstance(convbn, tuple)) else None
         i8 = i8 if i8 is not None else (None, None, None)
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         w2 = w.reshape(Co, C)

@@ -244,7 +244,10 @@ size_t cdn_codenet_aux_workspace_bytes(void);
  * a [M][C] with row stride lda floats, out [M][Co] with row stride ldo (0 = dense; strides let a and
  * out be channel ranges of wider channels-last tensors: the split halves of a ShuffleNetV2 unit),
  * w [Co][C] fp32 (fake-quantised already for W4A8).  w_codes / w_scale / w_colsum: optional integer
- * form as in cdn_codenet_stage_fused_forward (int8 MFMA when a_qstate is given too). */
+ * form as in cdn_codenet_stage_fused_forward: int8 MFMA on integer codes when a_qstate is given too;
+ * with a_qstate NULL (final-valued input, e.g. a ShuffleNetV2 unit's first 1x1 whose channels carry
+ * different generations of the running QuantAct) the exact-product bf16 x 3 split kernel: a = hi + mid + lo
+ * in bf16 (exact), weight codes exact in bf16, fp32 accumulation, scaled by 1 / w_scale[co]. */
 int cdn_codenet_pointwise_nhwc_forward(
     const float *a, const void *a_qstate, int64_t M, int64_t C, int64_t Co, int64_t lda, int64_t ldo,
     const float *w,

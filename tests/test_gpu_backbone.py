@@ -268,3 +268,46 @@ def test_range_epilogue_stress_exact_extremes():
         assert sf[4].item() == lo and sf[5].item() == hi
     # the arrival lines are left zeroed for the next producer
     assert int((ws.view(torch.int32) != 0).sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,C,Co,lda,off,ldo,relu", [
+    (4099, 58, 58, 116, 58, 60, 1), (1500, 116, 116, 232, 116, 116, 1), (700, 232, 232, 464, 232, 232, 1),
+    (300, 464, 1024, 464, 0, 1024, 1), (257, 24, 58, 24, 0, 60, 0), (130, 37, 70, 37, 0, 70, 1)])
+def test_pointwise_bf16_split_is_exact_product(M, C, Co, lda, off, ldo, relu):
+    """Final-valued input + 4-bit weight codes runs on the bf16 x 3 split kernel: products are exact, so the
+    result matches a float64 reference to fp32 accumulation rounding (and the f32-MFMA kernel)."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(M + C)
+    full = (torch.randn(M, lda, generator=g) * 3.0).to(dev)
+    a = full[:, off:off + C]
+    cpad = (C + 63) // 64 * 64
+    q = torch.randint(-8, 8, (Co, C), generator=g)
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = q.to(torch.int8)
+    codes = codes.to(dev)
+    scale = (torch.rand(Co, generator=g) * 20 + 1).to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    w = (q.to(dev).float() / scale[:, None]).contiguous()
+    colsum = q.sum(1).to(torch.int32).to(dev)
+    outs = []
+    for use_codes in (True, False):
+        out = torch.full((M, ldo), -7.0, device=dev)
+        xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+        rc = lib.cdn_codenet_pointwise_nhwc_forward(
+            a.data_ptr(), None, M, C, Co, lda, ldo, w.data_ptr(), codes.data_ptr() if use_codes else None,
+            scale.data_ptr() if use_codes else None, colsum.data_ptr() if use_codes else None, bias.data_ptr(),
+            None, None, relu, xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb,
+            out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        N_.check(rc, "pw")
+        outs.append((out, xmin.item(), xmax.item()))
+    ref = a.double() @ (q.to(dev).double() / scale.double()[:, None]).t() + bias.double()
+    ref = torch.relu(ref) if relu else ref
+    mag = (a.double().abs() @ (q.to(dev).double().abs() / scale.double()[:, None]).t()).max().item()
+    for out, lo, hi in outs:
+        got = out[:, :Co].double()
+        assert (got - ref).abs().max().item() < 2e-6 * mag
+        assert (out[:, Co:] == -7.0).all()
+        assert lo == out[:, :Co].min().item() and hi == out[:, :Co].max().item()
+    assert (outs[0][0][:, :Co] - outs[1][0][:, :Co]).abs().max().item() < 2e-6 * mag
