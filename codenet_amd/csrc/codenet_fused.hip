@@ -1186,7 +1186,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const int *__restrict__ wsum, const float *__restrict__ Wp,
             const float *__restrict__ bias, float *__restrict__ R,
             float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu, int lda,
-            int ldo) {
+            int ldo, const int *__restrict__ omap) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
@@ -1256,6 +1256,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     for (int j = 0; j < TN; ++j) {
       const int co = n0 + wn + j * 32 + (lane & 31);
       const float bsv = (co < Co && bias) ? bias[co] : 0.f;
+      const int oc = (co < Co && omap) ? omap[co] : co;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1264,7 +1265,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
           if (m < M && co < Co) {
             float v = accf[i][j][r] + bsv;
             if (relu) v = fmaxf(v, 0.0f);
-            R[m * ldo + co] = v;
+            R[m * ldo + oc] = v;
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
           }
@@ -1383,11 +1384,12 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
     float bsv = 0.f, rinv = 0.f;
-    int t128 = 0;
+    int t128 = 0, oc = co;
     if (co < Co) {
       if (bias) bsv = bias[co];
       rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
       t128 = 128 * wsum[co];
+      if (omap) oc = omap[co];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1397,7 +1399,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         if (m < M && co < Co) {
           float v = fmaf((float)(acc[i][j][r] + t128), rinv, bsv);
           if (relu) v = fmaxf(v, 0.0f);
-          R[m * ldo + co] = v;
+          R[m * ldo + oc] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
         }
@@ -1423,17 +1425,22 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 // ------------------------------------------------------------------------------------------
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kB3LD = 80;
+constexpr int kMixedMaxC = 512;   // channels of a mixed-generation input (per-channel state table in LDS)
 
 template <int BM, int BN, int WGM>
 __global__ void __launch_bounds__(256)
 pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu,
-            long M, int C, int Cpad, int Co, int relu, int lda, int ldo) {
+            long M, int C, int Cpad, int Co, int relu, int lda, int ldo,
+            const unsigned char *__restrict__ agen, const int *__restrict__ omap) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int AI = BM * 8 / 256;          // float4 loads of A per thread per k-tile
   constexpr int BI = (BN * 2 + 255) / 256;  // 16-byte loads of W per thread per k-tile
+  // agen != NULL: channel c of A is fake-quantised with the QuantAct state aq + 8 * agen[c] (the
+  // generations of a layer's running block-output QuantAct)
+  __shared__ float2 qt[kMixedMaxC];
   __shared__ __attribute__((aligned(16))) unsigned char Ah[BM * kB3LD];
   __shared__ __attribute__((aligned(16))) unsigned char Am[BM * kB3LD];
   __shared__ __attribute__((aligned(16))) unsigned char Al[BM * kB3LD];
@@ -1443,8 +1450,9 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
   const bool has_q = aq != nullptr;
+  const bool mixed = agen != nullptr;
   float qs = 1.f, qz = 0.f;
-  if (has_q) {
+  if (has_q && !mixed) {
     qs = reinterpret_cast<const float *>(aq)[2];
     qz = reinterpret_cast<const float *>(aq)[3];
   }
@@ -1500,7 +1508,12 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       unsigned hb[4], mb[4], lb[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (has_q) v[e] = (k0 + lk + e < C) ? fake_quant(v[e], qs, qz) : 0.0f;
+        if (mixed) {
+          const float2 q2 = qt[min(k0 + lk + e, C - 1)];
+          v[e] = (k0 + lk + e < C) ? fake_quant(v[e], q2.x, q2.y) : 0.0f;
+        } else if (has_q) {
+          v[e] = (k0 + lk + e < C) ? fake_quant(v[e], qs, qz) : 0.0f;
+        }
         hb[e] = __float_as_uint(v[e]);
         const float r1 = __fsub_rn(v[e], __uint_as_float(hb[e] & 0xFFFF0000u));   // exact
         mb[e] = __float_as_uint(r1);
@@ -1533,6 +1546,13 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 
   const int nk = (C + 31) / 32;   // (Cpad >= 32 * nk: the weight rows are zero padded to 64)
   load_tile(0);
+  if (mixed) {
+    for (int c = tid; c < C; c += 256) {
+      const float *sp = reinterpret_cast<const float *>(aq) + cdn::kQStateWords * agen[c];
+      qt[c] = make_float2(sp[2], sp[3]);
+    }
+    __syncthreads();
+  }
   for (int t = 0; t < nk; ++t) {
     if (t) __syncthreads();       // the previous tile's fragment reads are done
     store_tile(t * 32);
@@ -1568,9 +1588,11 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
     float bsv = 0.f, rinv = 0.f;
+    int oc = co;
     if (co < Co) {
       if (bias) bsv = bias[co];
       rinv = __fdiv_rn(1.0f, wscale[co]);
+      if (omap) oc = omap[co];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1580,7 +1602,7 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         if (m < M && co < Co) {
           float v = fmaf(acc[i][j][r], rinv, bsv);
           if (relu) v = fmaxf(v, 0.0f);
-          R[m * ldo + co] = v;
+          R[m * ldo + oc] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
         }
@@ -1589,6 +1611,186 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   if (rmm)
     cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&Ah[0]));
+}
+
+// ------------------------------------------------------------------------------------------
+// pwd3: the same arithmetic as pwb3 (exact bf16 x 3 split against 4-bit weight codes) as a STREAMING
+// kernel for the shapes of the ShuffleNetV2 units (Co <= a few hundred, C <= 512): in pwb3 no two waves
+// share a row of A (each wave owns 32 rows x the whole N tile), so staging A through LDS only re-shapes it
+// -- and costs two barriers per 32 k with the load latency exposed between them (measured 44 us for
+// 91 MB at layer 2).  Here a lane loads its MFMA operand straight from global memory: lane (r = l&31,
+// h = l>>5) owns k = 32w + 16h .. + 15 of row r in window w -- 64 contiguous bytes, four dwordx4 loads
+// (the k order inside a window is free as long as B agrees) -- two windows ahead in registers, no LDS,
+// no barrier in the k loop.  B (the N tile's codes as bf16, [n][k]) and the per-channel quantiser table
+// are staged in LDS once per workgroup.  A workgroup = 4 waves = 4 x 32 rows, one N tile of 32*TN columns.
+// Fake-quantisation while loading: n = rint(s*x - z) + z (integer valued), x' = n / s by Markstein's
+// sequence q0 = n*r, q = fma(fma(-q0, s, n), r, q0) with r = RN(1/s): the correctly rounded quotient in
+// 3 instructions instead of the ~10 of the IEEE expansion (this loop is VALU-bound next to the MFMAs).
+// ------------------------------------------------------------------------------------------
+template <int TN>
+__global__ void __launch_bounds__(256)
+pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+            const signed char *__restrict__ Wq, const float *__restrict__ wscale,
+            const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu,
+            long M, int C, int Cpad, int Co, int relu, int lda, int ldo,
+            const unsigned char *__restrict__ agen, const int *__restrict__ omap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nwin = (C + 31) >> 5, Kp = nwin * 32;
+  const int ldb = Kp * 2 + 16;                               // bytes per B row: conflict-free ds_read_b128
+  float4 *qtab = reinterpret_cast<float4 *>(smem + (size_t)32 * TN * ldb);   // [Kp] {s, z, 1/s, -}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * 32 * TN;
+  const bool has_q = aq != nullptr;
+  auto pack_hi = [](unsigned a_, unsigned b_) -> unsigned { return __builtin_amdgcn_perm(a_, b_, 0x07060302u); };
+
+  // ---- A stream: a wave walks the 32-row blocks rb = first, first + stride, ...; its windows (rb, w) form
+  // one sequence that is prefetched PF windows ahead across block boundaries -------------------------
+  const long nrb = (M + 31) >> 5;
+  const long rb_first = (long)blockIdx.x * 4 + wave, rb_stride = (long)gridDim.x * 4;
+  constexpr int PF = 2;
+  float4 buf[PF][4];
+  long prb = rb_first;         // block and window of the NEXT prefetch
+  int pw_ = 0;
+  auto load_next = [&](float4 (&d)[4]) {
+    const bool live = prb < nrb;
+    const long row = min(prb * 32 + (lane & 31), M - 1);
+    const int k = 32 * pw_ + 16 * (lane >> 5);
+    const float *src = A + row * lda + k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      d[i] = (live && k + 4 * i < C) ? *reinterpret_cast<const float4 *>(src + 4 * i)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (++pw_ == nwin) {
+      pw_ = 0;
+      prb += rb_stride;
+    }
+  };
+#pragma unroll
+  for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
+
+  // ---- B tile and quantiser table -> LDS ----------------------------------------------------------
+  const int chunks = Kp >> 4;                                // 16-code chunks per row
+  for (int q = tid; q < 32 * TN * chunks; q += 256) {
+    const int r_ = q / chunks, ch = q - r_ * chunks;
+    i32x4 cw = (i32x4){0, 0, 0, 0};
+    if (n0 + r_ < Co) cw = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
+    unsigned w8[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int word = cw[e];
+      const unsigned f0 = __float_as_uint((float)((word << 24) >> 24));
+      const unsigned f1 = __float_as_uint((float)((word << 16) >> 24));
+      const unsigned f2 = __float_as_uint((float)((word << 8) >> 24));
+      const unsigned f3 = __float_as_uint((float)(word >> 24));
+      w8[2 * e] = pack_hi(f1, f0);
+      w8[2 * e + 1] = pack_hi(f3, f2);
+    }
+    unsigned char *dp = smem + (size_t)r_ * ldb + ch * 32;
+    *reinterpret_cast<i32x4 *>(dp) = (i32x4){(int)w8[0], (int)w8[1], (int)w8[2], (int)w8[3]};
+    *reinterpret_cast<i32x4 *>(dp + 16) = (i32x4){(int)w8[4], (int)w8[5], (int)w8[6], (int)w8[7]};
+  }
+  if (has_q)
+    for (int c = tid; c < Kp; c += 256) {
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) {
+        const float *sp = reinterpret_cast<const float *>(aq) + (agen ? cdn::kQStateWords * agen[c] : 0);
+        e = make_float4(sp[2], sp[3], __fdiv_rn(1.0f, sp[2]), 0.f);
+      }
+      qtab[c] = e;
+    }
+  // epilogue constants of this lane's TN output columns
+  float bsv[TN], rinv[TN];
+  int oc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + j * 32 + (lane & 31);
+    bsv[j] = 0.f;
+    rinv[j] = 0.f;
+    oc[j] = -1;                                               // dead column
+    if (co < Co) {
+      if (bias) bsv[j] = bias[co];
+      rinv[j] = __fdiv_rn(1.0f, wscale[co]);
+      oc[j] = omap ? omap[co] : co;
+    }
+  }
+  __syncthreads();
+
+  const unsigned char *bbase = smem + (size_t)(lane & 31) * ldb + 32 * (lane >> 5);
+  const float4 *qrow = qtab + 16 * (lane >> 5);
+  float mn = INFINITY, mx = -INFINITY;
+
+  for (long rb = rb_first; rb < nrb; rb += rb_stride) {
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = (f32x16){0};
+    for (int w0 = 0; w0 < nwin; w0 += PF) {
+#pragma unroll
+      for (int p_ = 0; p_ < PF; ++p_) {
+        const int w = w0 + p_;
+        if (w < nwin) {                                         // wave-uniform
+          float v[16];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[4 * i] = buf[p_][i].x; v[4 * i + 1] = buf[p_][i].y;
+            v[4 * i + 2] = buf[p_][i].z; v[4 * i + 3] = buf[p_][i].w;
+          }
+          load_next(buf[p_]);
+          unsigned hb[16], mb[16], lb[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float x = v[e];
+            if (has_q) {
+              const float4 t4 = qrow[32 * w + e];               // {s, z, 1/s}: same address in a half-wave
+              const float n = __fadd_rn(rintf(__fsub_rn(__fmul_rn(t4.x, x), t4.y)), t4.y);
+              const float q0 = __fmul_rn(n, t4.z);
+              x = fmaf(fmaf(-q0, t4.x, n), t4.z, q0);
+            }
+            hb[e] = __float_as_uint(x);
+            const float r1 = __fsub_rn(x, __uint_as_float(hb[e] & 0xFFFF0000u));
+            mb[e] = __float_as_uint(r1);
+            lb[e] = __float_as_uint(__fsub_rn(r1, __uint_as_float(mb[e] & 0xFFFF0000u)));
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            i32x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ph[e] = (int)pack_hi(hb[8 * ks + 2 * e + 1], hb[8 * ks + 2 * e]);
+              pm[e] = (int)pack_hi(mb[8 * ks + 2 * e + 1], mb[8 * ks + 2 * e]);
+              pl[e] = (int)pack_hi(lb[8 * ks + 2 * e + 1], lb[8 * ks + 2 * e]);
+            }
+            const bf16x8 fh = __builtin_bit_cast(bf16x8, ph), fm = __builtin_bit_cast(bf16x8, pm),
+                         fl = __builtin_bit_cast(bf16x8, pl);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const bf16x8 fb = __builtin_bit_cast(
+                  bf16x8, *reinterpret_cast<const i32x4 *>(bbase + (size_t)j * 32 * ldb + 64 * w + 16 * ks));
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fb, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, fb, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fb, acc[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    const long mb0 = rb * 32;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = mb0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && oc[j] >= 0) {
+          float v = fmaf(acc[j][r], rinv[j], bsv[j]);
+          if (relu) v = fmaxf(v, 0.0f);
+          R[m * ldo + oc[j]] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
+      }
+  }
+  if (rmm)
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(smem));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1725,7 +1927,8 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                             const int *w_pw_colsum, const float *bias_pw, const float *ep_scale,
                             const float *ep_shift, int relu, float *r_out, float2 *rmm,
                             const cdn::QUpdate &qu_r, int ptag, hipStream_t st, int64_t lda = 0,
-                            int64_t ldo = 0) {
+                            int64_t ldo = 0, const unsigned char *a_gen = nullptr,
+                            const int *out_map = nullptr) {
   if (lda == 0) lda = C;      // row strides of A / R in floats (views into wider channels-last tensors)
   if (ldo == 0) ldo = Co;
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
@@ -1745,12 +1948,16 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     if (pw_fast) CDN_PW1(BM_, BN_, WGM_, AQ_, true);                      \
     else CDN_PW1(BM_, BN_, WGM_, AQ_, false);                             \
   } while (0)
-  const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr;
+  const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr && a_gen == nullptr;
   // final-valued input (no QuantAct state to derive integer codes from) with 4-bit weight codes: exact
   // bf16 x 3 split instead of f32 MFMA
   static const bool no_b3 = getenv("CDN_NO_B3") != nullptr;   // tuning knob
-  const bool use_b3 = !no_b3 && w_pw_codes != nullptr && dst == nullptr && ep_scale == nullptr &&
-                      w_pw_scale != nullptr;
+  const bool use_b3 = w_pw_codes != nullptr && ep_scale == nullptr && w_pw_scale != nullptr &&
+                      (a_gen != nullptr || (!no_b3 && dst == nullptr));
+  CDN_REQUIRE(a_gen == nullptr || (use_b3 && dst != nullptr && C <= kMixedMaxC), CDN_ERR_UNSUPPORTED,
+              "a mixed-generation input needs the states, 4-bit weight codes and C <= %d", kMixedMaxC);
+  CDN_REQUIRE(out_map == nullptr || use_i8 || use_b3, CDN_ERR_UNSUPPORTED,
+              "an output channel map needs the 4-bit weight codes");
   const int only_if_wide = 0;
   if (use_i8) {
     CDN_REQUIRE(w_pw_scale && w_pw_colsum, CDN_ERR_ARG, "int8 pointwise needs scale and colsum");
@@ -1764,11 +1971,11 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     if (pw_fast)                                                                                 \
       pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                            qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo); \
+                                                            qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map); \
     else                                                                                         \
       pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
                                                              w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                             qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo); \
+                                                             qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map); \
   } while (0)
     // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
     // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
@@ -1788,9 +1995,28 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
     pwb3_kernel<BM_, BN_, WGM_><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale, bias_pw, r_out, \
                                                    rmm, qu_r, M, (int)C, Cpad, (int)Co, relu,    \
-                                                   (int)lda, (int)ldo);                          \
+                                                   (int)lda, (int)ldo, a_gen, out_map);          \
   } while (0)
-    if (pw_bn == 128 && pw_bm == 64) CDN_PWB(64, 128, 2);
+    // streaming form when the rows are 16-byte aligned quads and the N tile's weights fit in LDS
+    static const bool no_d3 = getenv("CDN_NO_D3") != nullptr;   // tuning knob
+    const int tn = Co > 64 ? 4 : 2;
+    const int Kp = (int)((C + 31) / 32 * 32);
+    const size_t lds_d3 = (size_t)32 * tn * (Kp * 2 + 16) + (size_t)Kp * 16;
+    const long nblk_d3 = cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 32 * tn);
+    if (!no_d3 && (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
+        lds_d3 <= 150 * 1024 && nblk_d3 <= kMaxPartials) {
+      // persistent: as many workgroups as stay resident (VGPRs, LDS), each walks row blocks
+      const unsigned ny = (unsigned)cdn::ceil_div(Co, 32 * tn);
+      static const int d3_occ = getenv("CDN_D3_OCC") ? atoi(getenv("CDN_D3_OCC")) : 0;   // tuning knob
+      long per_cu = std::min<long>(2, (long)(160 * 1024 / (lds_d3 + 512)));   // 172 / 256 VGPRs: 2 waves per SIMD
+      if (d3_occ > 0) per_cu = d3_occ;
+      const long gx = std::max<long>(1, std::min<long>(cdn::ceil_div(M, 128), per_cu * cdn::kCUs / ny));
+      dim3 g((unsigned)gx, ny);
+      auto kern = tn == 4 ? pwd3_kernel<4> : pwd3_kernel<2>;
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d3);
+      kern<<<g, 256, lds_d3, st>>>(d, dst, w_pw_codes, w_pw_scale, bias_pw, r_out, rmm, qu_r, M, (int)C, Cpad,
+                                   (int)Co, relu, (int)lda, (int)ldo, a_gen, out_map);
+    } else if (pw_bn == 128 && pw_bm == 64) CDN_PWB(64, 128, 2);
     else if (pw_bn == 128) CDN_PWB(128, 128, 4);
     else CDN_PWB(128, 64, 4);
 #undef CDN_PWB
@@ -1982,7 +2208,20 @@ extern "C" int cdn_codenet_pointwise_nhwc_forward(
     const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
     int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
     void *stream) {
+  return cdn_codenet_pointwise_mixed_forward(a, a_qstate, nullptr, M, C, Co, lda, ldo, w, w_codes, w_scale,
+                                             w_colsum, bias, ep_scale, ep_shift, relu, nullptr, r_min, r_max,
+                                             r_state, bits, momentum, running, workspace, workspace_bytes,
+                                             out, stream);
+}
+
+extern "C" int cdn_codenet_pointwise_mixed_forward(
+    const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
+    int64_t lda, int64_t ldo, const float *w, const signed char *w_codes, const float *w_scale,
+    const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
+    const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
+    void *workspace, size_t workspace_bytes, float *out, void *stream) {
   CDN_REQUIRE(a && w && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(a_gen == nullptr || a_qstate != nullptr, CDN_ERR_ARG, "a_gen needs the states in a_qstate");
   CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && M * std::max(C, Co) < (1ll << 31), CDN_ERR_ARG, "bad size");
   CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
               "ep_scale / ep_shift must both be set or both be NULL");
@@ -2002,5 +2241,5 @@ extern "C" int cdn_codenet_pointwise_nhwc_forward(
                         (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
   return launch_pointwise(a, static_cast<unsigned *>(const_cast<void *>(a_qstate)), (long)M, C, Co, w,
                           w_codes, w_scale, w_colsum, bias, ep_scale, ep_shift, relu, out,
-                          r_state ? ws.partials : nullptr, qu, 0, st, lda, ldo);
+                          r_state ? ws.partials : nullptr, qu, 0, st, lda, ldo, a_gen, out_map);
 }

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256)
 dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const float *__restrict__ w,
            const float *__restrict__ bias, const float *__restrict__ ep_scale,
            const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
-           int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nbands) {
+           int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nbands,
+           const unsigned char *__restrict__ agen) {
   extern __shared__ float4 band4[];         // [rows][Ws + 2][CCH / 4 quads]
   constexpr int LPP = CCH / 4;
   constexpr int BAND = dw3_band(STRIDE);
@@ -51,10 +52,17 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
   const int iy0 = STRIDE == 2 ? 2 * y0 - 1 : y0 - 1;           // first staged input row
   const int Wc = Ws + 2;
   const int tid = threadIdx.x;
-  float qs = 1.f, qz = 0.f;
+  // a thread stages ONE channel quad (256 % LPP == 0), so its four quantiser parameters are loaded once;
+  // agen != NULL: channel c uses the QuantAct state aq + 8 * agen[c] (mixed generations)
+  float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f};
   if (XQ) {
-    qs = reinterpret_cast<const float *>(aq)[2];
-    qz = reinterpret_cast<const float *>(aq)[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float *sp = reinterpret_cast<const float *>(aq);
+      if (agen) sp += cdn::kQStateWords * agen[min(c0 + (tid % LPP) * 4 + e, C - 1)];
+      qs[e] = sp[2];
+      qz[e] = sp[3];
+    }
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int items = ROWS * Wc * LPP;
@@ -79,10 +87,10 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
       if (q < items) {
         float4 t = v[u];
         if (XQ && in[u]) {       // (the zero halo is a zero of the conv padding, not a quantised value)
-          t.x = fake_quant(t.x, qs, qz);
-          t.y = fake_quant(t.y, qs, qz);
-          t.z = fake_quant(t.z, qs, qz);
-          t.w = fake_quant(t.w, qs, qz);
+          t.x = fake_quant(t.x, qs[0], qz[0]);
+          t.y = fake_quant(t.y, qs[1], qz[1]);
+          t.z = fake_quant(t.z, qs[2], qz[2]);
+          t.w = fake_quant(t.w, qs[3], qz[3]);
         }
         band4[q] = t;
       }
@@ -532,7 +540,19 @@ extern "C" int cdn_codenet_dw3x3_nhwc_forward(
     int64_t ld_in, int64_t ld_out, const float *w, const float *bias, const float *ep_scale,
     const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  return cdn_codenet_dw3x3_mixed_forward(a, a_qstate, nullptr, N, C, H, W, up, stride, ld_in, ld_out, w, bias,
+                                         ep_scale, ep_shift, relu, r_min, r_max, r_state, bits, momentum,
+                                         running, workspace, workspace_bytes, out, stream);
+}
+
+extern "C" int cdn_codenet_dw3x3_mixed_forward(
+    const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t N, int64_t C, int64_t H,
+    int64_t W, int up, int stride, int64_t ld_in, int64_t ld_out, const float *w, const float *bias,
+    const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
+    int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
+    void *stream) {
   CDN_REQUIRE(a && w && (out || r_state), CDN_ERR_ARG, "null pointer (out may be NULL only for a range-only pass)");
+  CDN_REQUIRE(a_gen == nullptr || a_qstate != nullptr, CDN_ERR_ARG, "a_gen needs the states in a_qstate");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (up == 0 || up == 1) && (stride == 1 || stride == 2),
               CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(!(up && stride == 2), CDN_ERR_UNSUPPORTED, "up-sampling with stride 2");
@@ -577,7 +597,7 @@ extern "C" int cdn_codenet_dw3x3_nhwc_forward(
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                               (int)lds);                                                           \
     kern<<<grid, 256, lds, st>>>(a, aq, w, bias, ep_scale, ep_shift, out, mm, qu, (int)C, (int)ld_in, \
-                                 (int)ld_out, Hs, Ws, relu, nbands);                               \
+                                 (int)ld_out, Hs, Ws, relu, nbands, a_gen);                        \
   }
   if (aq && up) CDN_GO(true, 1, 1)
   else if (aq && stride == 2) CDN_GO(true, 0, 2)

@@ -477,10 +477,27 @@ class FusedBackbone:
     that also applies the shared block-output QuantAct, so a unit's output tensor holds final values.
     Returns what ``FusedHotPath.forward_nhwc(x, x_qstate, hw)`` takes."""
 
-    def __init__(self, model, int8_pointwise=True):
+    def __init__(self, model, int8_pointwise=True, shuffle_free=True):
         self.model = model
         self.int8 = int8_pointwise
+        self.shuffle_free = shuffle_free and int8_pointwise
         self._bufs = None
+
+    def _l4_weights(self, q4, logical, dev):
+        """layer4's 1x1 weights with the input columns in the physical order of the last layer."""
+        key = (q4.conv.weight.data_ptr(), q4.conv.weight._version, q4.bn.weight._version,
+               q4.bn.running_var._version, tuple(logical), dev)
+        c = self.__dict__.get("_l4_cache")
+        if c is None or c[0] != key:
+            w, b = q4.folded()
+            codes, scale, colsum = q4.folded_int8()
+            cols = torch.tensor(logical, device=dev, dtype=torch.long)
+            K, Co = len(logical), w.shape[0]
+            cp = torch.zeros(Co, (K + 63) // 64 * 64, dtype=torch.int8, device=dev)
+            cp[:, :K] = codes[:, cols]
+            self._l4_cache = (key, dict(w=w.reshape(Co, -1)[:, cols].contiguous(), codes=cp, scale=scale,
+                                        colsum=colsum, bias=b.contiguous(), Co=Co, K=K))
+        return self._l4_cache[1]
 
     @staticmethod
     def supported(model):
@@ -617,6 +634,7 @@ class FusedBackbone:
         self._ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
         self._ws_bytes = (self._ws.numel() * 4 - (self._ws_ptr - self._ws.data_ptr())) // 256 * 256
         self._stream = torch.cuda.current_stream(dev).cuda_stream
+        self._dev = dev
 
     def run_units(self, nodes, x, x_ld, x_q, Nb, H, W):
         """A chain of QuantBaseNode units (first one may be stride 2) sharing their block-output QuantAct.
@@ -657,6 +675,195 @@ class FusedBackbone:
                 x, x_ld, x_q = y, C, None
                 y, y_other = y_other, y
         return x, C, L["H"], L["W"]
+
+    # -- layers without a physical channel shuffle -----------------------------------------------------
+    # concat + channel_shuffle(2) only renames channels, so a layer keeps ONE activation tensor whose
+    # physical channel slots never move: the pass-through half of a stride-1 unit stays where it is, the
+    # unit's branch writes its (pre-quantisation) output into the slots its input half occupied, and the
+    # renaming is folded into the weights on the host (columns permuted to the physical order, zero columns
+    # for the pass-through half; `out_map` names the slot of each output channel).  The layer's shared
+    # block-output QuantAct moves at every call, so each call writes its state to its own slot of a state
+    # array and slot p remembers which call ("generation") produced it: consumers fake-quantise channel p
+    # with state gen[p] while loading -- the values every reader sees are the ones the reference
+    # materialised at that call.  No interleave kernel, no copy of the pass-through half.
+    _MIXED_MAX_C = 512
+
+    def mixed_supported(self, nodes):
+        if not self.int8 or not all(hasattr(n, "quant_convbn1") for n in nodes) or nodes[0].stride != 2:
+            return False
+        if any(n.stride != 1 for n in nodes[1:]):
+            return False
+        h = nodes[0].quant_convbn3.conv.out_channels
+        cin = nodes[0].quant_convbn1.conv.in_channels
+        if (2 * h) % 4 or 2 * h > self._MIXED_MAX_C or cin > self._MIXED_MAX_C or len(nodes) + 1 > 250:
+            return False
+        convs = [n.quant_convbn1 for n in nodes] + [n.quant_convbn3 for n in nodes] + [nodes[0].quant_convbn5]
+        return all(c.folded_int8() is not None for c in convs)
+
+    @staticmethod
+    def _death(L, h):
+        """Units until logical channel L sits in the consumed half (logical index >= h)."""
+        d = 1
+        while L < h:
+            if L == 0:
+                return 1 << 20
+            L, d = 2 * L, d + 1
+        return d
+
+    def _mixed_plan(self, nodes, in_logical, dev):
+        """Host bookkeeping of one layer: slot assignment, generations, permuted weights (cached until a
+        weight changes).  in_logical: logical index of every physical input channel (None: identity)."""
+        units = [self._unit(n) for n in nodes]
+        convs = []
+        for u in units:
+            convs += [u[k] for k in ("c1", "c2", "c3", "c4", "c5") if k in u]
+        key = (tuple((c.conv.weight.data_ptr(), c.conv.weight._version, c.bn.weight._version,
+                      c.bn.running_var._version, c.bn.running_mean._version, c.bn.bias._version) for c in convs),
+               tuple(in_logical) if in_logical is not None else None, dev)
+        cache = self.__dict__.setdefault("_mixed_cache", {})
+        ck = id(nodes[0])
+        if ck in cache and cache[ck]["key"] == key:
+            return cache[ck]
+        h, cin = units[0]["h"], units[0]["cin"]
+        C = 2 * h
+        lin = list(in_logical) if in_logical is not None else list(range(cin))
+        lin_t = torch.tensor(lin, device=dev, dtype=torch.long)
+        i32 = lambda v: torch.tensor(v, device=dev, dtype=torch.int32)   # noqa: E731
+        u8 = lambda v: torch.tensor(v, device=dev, dtype=torch.uint8)    # noqa: E731
+
+        def pw_weights(convbn, cols, K):
+            """1x1 weights with input columns re-ordered: column p of the result is logical column cols[p]
+            (-1: zero column).  Returns dict(w fp32 [Co,K], codes int8 [Co,Kpad], scale, colsum, bias)."""
+            w, b = convbn.folded()
+            codes, scale, colsum = convbn.folded_int8()
+            Co = w.shape[0]
+            cols_t = torch.tensor(cols, device=dev, dtype=torch.long)
+            live = cols_t >= 0
+            src = cols_t.clamp(min=0)
+            w2 = w.reshape(Co, -1)[:, src] * live.to(w.dtype)
+            kpad = (K + 63) // 64 * 64
+            cp = torch.zeros(Co, kpad, dtype=torch.int8, device=dev)
+            cp[:, :K] = codes[:, src] * live.to(torch.int8)
+            return dict(w=w2.contiguous(), codes=cp.contiguous(), scale=scale, colsum=colsum, bias=b.contiguous(),
+                        Co=Co, K=K)
+
+        plan = dict(key=key, h=h, cin=cin, C=C, units=[])
+        logical, gen = [0] * C, [0] * C
+        ngen = 0
+        for k, (node, u) in enumerate(zip(nodes, units)):
+            P = {}
+            if k == 0:
+                order = sorted(range(C), key=lambda L: (self._death(L, h), L))
+                slot_of = {L: s_ for s_, L in enumerate(order)}
+                w4, b4 = u["c4"].folded()
+                P["w4"] = w4.reshape(cin, 9)[lin_t].contiguous()
+                P["b4"] = b4[lin_t].contiguous()
+                P["c5"] = pw_weights(u["c5"], lin, cin)
+                P["c1"] = pw_weights(u["c1"], lin, cin)
+                P["c3"] = pw_weights(u["c3"], list(range(h)), h)
+                P["omapA"] = i32([slot_of[2 * i] for i in range(h)])
+                P["omapB"] = i32([slot_of[2 * i + 1] for i in range(h)])
+                P["genA"], P["genB"] = ngen, ngen + 1
+                for L, s_ in slot_of.items():
+                    logical[s_] = L
+                    gen[s_] = ngen + (L & 1)
+                ngen += 2
+            else:
+                P2 = [p_ for p_ in range(C) if logical[p_] >= h]
+                P["gen_in"] = u8(gen)
+                P["c1"] = pw_weights(u["c1"], [logical[p_] - h if logical[p_] >= h else -1 for p_ in range(C)], C)
+                P["c3"] = pw_weights(u["c3"], list(range(h)), h)
+                fresh = sorted(range(h), key=lambda i: (self._death(2 * i + 1, h), i))
+                omap = [0] * h
+                for p_ in range(C):
+                    if logical[p_] < h:
+                        logical[p_] *= 2
+                for i, p_ in zip(fresh, P2):
+                    omap[i] = p_
+                    logical[p_] = 2 * i + 1
+                    gen[p_] = ngen
+                P["omapB"] = i32(omap)
+                P["genB"] = ngen
+                ngen += 1
+            w2, b2 = u["c2"].folded()
+            P["w2"], P["b2"] = w2.reshape(h, 9).contiguous(), b2.contiguous()
+            plan["units"].append(P)
+        assert sorted(logical) == list(range(C))
+        plan.update(logical=list(logical), gen=u8(gen), ngen=ngen,
+                    states=torch.zeros(ngen * 8, dtype=torch.int32, device=dev))
+        cache[ck] = plan
+        return plan
+
+    def _pw_raw(self, a_ptr, a_q, a_gen, M, lda, Wt, relu, act, state_ptr, out_map, out_ptr, ldo):
+        from . import _native as N_
+        aa = self._act_args(act, self._dev)
+        if state_ptr is not None:
+            aa[2] = state_ptr
+        rc = N_.lib().cdn_codenet_pointwise_mixed_forward(
+            a_ptr, a_q, a_gen, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), Wt["codes"].data_ptr(),
+            Wt["scale"].data_ptr(), Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), None, None, int(relu),
+            out_map, *aa, self._ws_ptr, self._ws_bytes, out_ptr, self._stream)
+        N_.check(rc, "cdn_codenet_pointwise_mixed_forward")
+
+    def _dw_raw(self, a_ptr, a_q, a_gen, N, C, H, W, stride, ld_in, w, b, act, out, ld_out):
+        from . import _native as N_
+        rc = N_.lib().cdn_codenet_dw3x3_mixed_forward(
+            a_ptr, a_q, a_gen, N, C, H, W, 0, stride, ld_in, ld_out, w.data_ptr(), b.data_ptr(), None, None, 0,
+            *self._act_args(act, out.device), self._ws_ptr, self._ws_bytes, out.data_ptr(), self._stream)
+        N_.check(rc, "cdn_codenet_dw3x3_mixed_forward")
+
+    def run_units_mixed(self, nodes, x, x_ld, x_in, Nb, H, W):
+        """A layer (stride-2 unit + stride-1 units) without a physical shuffle.  x: channels-last
+        [Nb*H*W, x_ld]; x_in: None (final values), an int (pointer of the ONE QuantAct state its
+        pre-quantisation values are loaded with) or the layout dict of the previous layer.  Returns the
+        layout dict(t=[M, C] pre-quantisation values, logical, gen (device uint8), states, C, H, W)."""
+        dev = x.device
+        self._prepare(dev)
+        mixed_in = isinstance(x_in, dict)
+        plan = self._mixed_plan(nodes, x_in["logical"] if mixed_in else None, dev)
+        units = [self._unit(n) for n in nodes]
+        h, cin, C = plan["h"], plan["cin"], plan["C"]
+        L = self._layer_bufs(nodes, h, cin, Nb, H, W, dev)
+        ldh = L["ldh"]
+        Mi, Mo = Nb * L["Hin"] * L["Win"], Nb * L["H"] * L["W"]
+        qptr = lambda act: act._device_state(dev).data_ptr() if act is not None else None   # noqa: E731
+        Y, S = L["ya"], plan["states"]
+        sp = lambda g: S.data_ptr() + 32 * g   # noqa: E731
+        a_q = (x_in["states"].data_ptr() if mixed_in else x_in)
+        a_gen = x_in["gen"].data_ptr() if mixed_in else None
+        with torch.no_grad():
+            for k, (u, P) in enumerate(zip(units, plan["units"])):
+                sh = u["sh"]
+                if k == 0:
+                    t4 = L["t4"]
+                    self._dw_raw(x.data_ptr(), a_q, a_gen, Nb, cin, L["Hin"], L["Win"], 2, x_ld, P["w4"], P["b4"],
+                                 u["a4"], t4, t4.shape[1])
+                    self._pw_raw(t4.data_ptr(), qptr(u["a4"]), None, Mo, t4.shape[1], P["c5"], True, sh,
+                                 sp(P["genA"]), P["omapA"].data_ptr(), Y.data_ptr(), C)
+                    self._pw_raw(x.data_ptr(), a_q, a_gen, Mi, x_ld, P["c1"], True, u["a1"], None, None,
+                                 L["t1s2"].data_ptr(), ldh)
+                    self._dw_raw(L["t1s2"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["Hin"], L["Win"], 2, ldh,
+                                 P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                else:
+                    self._pw_raw(Y.data_ptr(), S.data_ptr(), P["gen_in"].data_ptr(), Mo, C, P["c1"], True,
+                                 u["a1"], None, None, L["t1"].data_ptr(), ldh)
+                    self._dw_raw(L["t1"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["H"], L["W"], 1, ldh,
+                                 P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                self._pw_raw(L["t2"].data_ptr(), qptr(u["a2"]), None, Mo, ldh, P["c3"], True, sh, sp(P["genB"]),
+                             P["omapB"].data_ptr(), Y.data_ptr(), C)
+        return dict(t=Y, logical=plan["logical"], gen=plan["gen"], states=S, C=C, H=L["H"], W=L["W"])
+
+    @staticmethod
+    def materialize(layout):
+        """The layer output in the reference's (logical) channel order with every channel fake-quantised by
+        its generation's state -- what the module path holds; plain torch, for tests and hand-overs."""
+        t, S = layout["t"], layout["states"].view(torch.float32).view(-1, 8)
+        g = layout["gen"].long()
+        scale, zp = S[g, 2], S[g, 3]
+        q = (torch.round(scale * t - zp) + zp) / scale
+        inv = torch.empty(len(layout["logical"]), dtype=torch.long, device=t.device)
+        inv[torch.tensor(layout["logical"], device=t.device)] = torch.arange(len(layout["logical"]), device=t.device)
+        return q[:, inv]
 
     def __call__(self, images):
         from . import _native as N_
@@ -701,13 +908,29 @@ class FusedBackbone:
                                                                     B["tp"].data_ptr(), self._stream)
                 N_.check(rc, "cdn_codenet_maxpool3x3s2_nhwc_forward")
                 x, x_q, H, W = B["tp"], None, Hp, Wp         # final values from here on
+            lay = None                                       # layout dict while the layers run unshuffled
             for name in ("layer1", "layer2", "layer3"):
-                x, x_ld, H, W = self.run_units(list(getattr(m, name)), x, x_ld, x_q, Nb, H, W)
+                nodes = list(getattr(m, name))
+                if quant and self.shuffle_free and self.mixed_supported(nodes):
+                    lay = self.run_units_mixed(nodes, x, x_ld, lay if lay is not None else x_q, Nb, H, W)
+                    x, x_ld, H, W = lay["t"], lay["C"], lay["H"], lay["W"]
+                else:
+                    if lay is not None:                      # hand-over into the interleaving path
+                        x, lay = self.materialize(lay).contiguous(), None
+                        x_q = None
+                    x, x_ld, H, W = self.run_units(nodes, x, x_ld, x_q, Nb, H, W)
                 x_q = None
             # ---- layer4: 1x1 conv + folded BN + ReLU, range of its QuantAct ---------------------------
             if B.get("out") is None or B["out"].shape != (Nb, H * W, c4):
                 B["out"] = torch.empty(Nb, H * W, c4, device=dev)
-            self._pw(x.data_ptr(), None, Nb * H * W, x_ld, q4, True, act4, B["out"], 0)
+            if lay is not None and q4.folded_int8() is not None and x_ld <= self._MIXED_MAX_C:
+                W4 = self._l4_weights(q4, lay["logical"], dev)
+                self._pw_raw(x.data_ptr(), lay["states"].data_ptr(), lay["gen"].data_ptr(), Nb * H * W, x_ld, W4,
+                             True, act4, None, None, B["out"].data_ptr(), c4)
+            else:
+                if lay is not None:
+                    x = self.materialize(lay).contiguous()
+                self._pw(x.data_ptr(), None, Nb * H * W, x_ld, q4, True, act4, B["out"], 0)
             if c4 % 4:
                 # the channels-last hand-over into stage 0 needs C % 4 == 0; CoDeNet2x's 2153 channels are
                 # materialised as the NCHW tensor the stage takes from a PyTorch backbone (fake-quantised)

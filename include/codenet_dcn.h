@@ -256,6 +256,29 @@ int cdn_codenet_pointwise_nhwc_forward(
     int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
     void *stream);
 
+/* Mixed-generation variants (ShuffleNetV2 layers WITHOUT a physical channel shuffle):
+ * the activation tensor of a layer keeps every channel in a fixed physical slot, pre-quantisation values,
+ * and channel c was produced under generation a_gen[c] of the layer's running block-output QuantAct
+ * (quant_modules.py:809-907 calls that one QuantAct once per branch, so its range moves between calls).
+ * a_qstate then points at an ARRAY of QuantAct states, cdn_quantact_state_bytes() apart; a consumer
+ * fake-quantises channel c with state a_gen[c] while loading.  concat + channel_shuffle become index
+ * bookkeeping on the host: weight columns are permuted to the physical order (zero columns for the
+ * pass-through half of a unit) and out_map[co] names the slot output channel co is written to (NULL:
+ * slot co).  a_gen == NULL: exactly cdn_codenet_pointwise_nhwc_forward / cdn_codenet_dw3x3_nhwc_forward.
+ * The pointwise form needs the 4-bit weight codes (bf16 split kernel) and C <= 512. */
+int cdn_codenet_pointwise_mixed_forward(
+    const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
+    int64_t lda, int64_t ldo, const float *w, const signed char *w_codes, const float *w_scale,
+    const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
+    const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
+    void *workspace, size_t workspace_bytes, float *out, void *stream);
+int cdn_codenet_dw3x3_mixed_forward(
+    const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t N, int64_t C, int64_t H,
+    int64_t W, int up, int stride, int64_t ld_in, int64_t ld_out, const float *w, const float *bias,
+    const float *ep_scale, const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state,
+    int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
+    void *stream);
+
 /* Depthwise 3x3, pad 1, stride 1 or 2, channels-last: a [N][H*W][ld_in] at its STORED resolution H x W,
  * w [C][9], bias / ep_scale / ep_shift [C] or NULL, out [N][Ho*Wo][ld_out] with
  *   up = 1 (stride 1 only): the input is nearest x2 up-sampled on the fly, Ho x Wo = 2H x 2W

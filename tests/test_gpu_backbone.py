@@ -90,8 +90,8 @@ def test_stem_conv(stride, R):
     assert abs(xmax.item() - ref.max().item()) < 1e-5 and xmin.item() == 0.0
 
 
-@pytest.mark.parametrize("res,batch", [(64, 2), (96, 3)])
-def test_fused_backbone_matches_modules(res, batch):
+@pytest.mark.parametrize("res,batch,shuffle_free", [(64, 2, True), (96, 3, True), (64, 2, False)])
+def test_fused_backbone_matches_modules(res, batch, shuffle_free):
     """FusedBackbone (stem, 16 ShuffleNetV2 units, layer4 on the HIP kernels) vs the mirrored modules on
     PyTorch-ROCm over 3 forwards: every QuantAct range, and the layer4 output after its QuantAct."""
     import copy
@@ -99,7 +99,7 @@ def test_fused_backbone_matches_modules(res, batch):
     model = harness.create_model(quantize=True)
     ma, mb = copy.deepcopy(model).cuda(), copy.deepcopy(model).cuda()
     assert pipeline.FusedBackbone.supported(mb)
-    fb = pipeline.FusedBackbone(mb)
+    fb = pipeline.FusedBackbone(mb, shuffle_free=shuffle_free)
     g = torch.Generator().manual_seed(res)
     for it in range(3):
         x = (torch.randn(batch, 3, res, res, generator=g) * (1.0 + 0.3 * it)).cuda()
@@ -135,7 +135,8 @@ def test_fused_backbone_matches_modules(res, batch):
     assert checked >= 16 * 2 + 3
 
 
-def test_fused_units_match_reference_golden():
+@pytest.mark.parametrize("shuffle_free", [False, True])
+def test_fused_units_match_reference_golden(shuffle_free):
     """Two chained ShuffleNetV2 units (stride 2, stride 1; shared block-output QuantAct) on the HIP kernels
     against the reference's own QuantBaseNode outputs over 3 forwards (tests/golden/base_nodes.npz)."""
     import numpy as np
@@ -177,11 +178,16 @@ def test_fused_units_match_reference_golden():
         q.set_act(shared)
         nodes.append(q.eval().cuda())
     fb = pipeline.FusedBackbone(None)
+    assert fb.mixed_supported(nodes) or not shuffle_free
     for it in range(3):
         x = z["x%d" % it].cuda()
         Nb, C, H, W = x.shape
         a = x.permute(0, 2, 3, 1).contiguous().view(-1, C)
-        y, Co, Ho, Wo = fb.run_units(nodes, a, C, None, Nb, H, W)
+        if shuffle_free:
+            lay = fb.run_units_mixed(nodes, a, C, None, Nb, H, W)
+            y, Co, Ho, Wo = fb.materialize(lay), lay["C"], lay["H"], lay["W"]
+        else:
+            y, Co, Ho, Wo = fb.run_units(nodes, a, C, None, Nb, H, W)
         got = y.view(Nb, Ho, Wo, Co).permute(0, 3, 1, 2).cpu()
         sh = nodes[0].quant_act
         assert (sh.x_min.cpu() - z["shared_min%d" % it]).abs().item() < 1e-4

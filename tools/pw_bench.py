@@ -1,0 +1,67 @@
+"""Isolated timing of the pointwise kernels at the ShuffleNetV2 unit shapes (GPU only):
+python tools/pw_bench.py [M C Co lda]  -- modes: final / single-state / mixed input, dense or mapped output."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from codenet_amd import _native as N_, ops
+
+
+def main():
+    M, C, Co, lda = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (262144, 116, 58, 116)
+    dev = torch.device("cuda", 0)
+    lib = N_.lib()
+    aux = lib.cdn_codenet_aux_workspace_bytes()
+    ws = torch.zeros(aux // 4 + 64, device=dev)
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    wb = (ws.numel() * 4 - (wp - ws.data_ptr())) // 256 * 256
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(M, lda, generator=g).to(dev)
+    cpad = (C + 63) // 64 * 64
+    q = torch.randint(-8, 8, (Co, C), generator=g)
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = q.to(torch.int8)
+    codes = codes.to(dev)
+    scale = (torch.rand(Co, generator=g) * 20 + 1).to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    w = (q.float() / scale.cpu()[:, None]).contiguous().to(dev)
+    colsum = q.sum(1).to(torch.int32).to(dev)
+    ldo = (Co + 3) // 4 * 4
+    out = torch.empty(M, max(ldo, 2 * Co), device=dev)
+    states = torch.zeros(8 * 8, dtype=torch.int32, device=dev)
+    sf = states.view(torch.float32).view(8, 8)
+    sf[:, 2] = 255.0 / 8.0
+    sf[:, 3] = -100.0
+    gen = (torch.arange(C) % 5).to(torch.uint8).to(dev)
+    omap = (torch.arange(Co) * 2 + 1).to(torch.int32).to(dev)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for name, aq, ag, om, ld_o in (("final", None, None, None, ldo), ("single", states.data_ptr(), None, None, ldo),
+                                   ("mixed", states.data_ptr(), gen.data_ptr(), None, ldo),
+                                   ("mixed_mapped", states.data_ptr(), gen.data_ptr(), omap.data_ptr(), 2 * Co)):
+        def run():
+            rc = lib.cdn_codenet_pointwise_mixed_forward(
+                a.data_ptr(), aq, ag, M, C, Co, lda, ld_o, w.data_ptr(), codes.data_ptr(), scale.data_ptr(),
+                colsum.data_ptr(), bias.data_ptr(), None, None, 1, om, xmin.data_ptr(), xmax.data_ptr(),
+                st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(), stream)
+            N_.check(rc, "pw")
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            run()
+        torch.cuda.synchronize()
+        res[name] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    res["shape"] = [M, C, Co, lda]
+    res["MB"] = round((M * C * 4 + M * Co * 4) / 1e6, 1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
