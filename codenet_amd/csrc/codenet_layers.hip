@@ -180,6 +180,175 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
 }
 
 // ------------------------------------------------------------------------------------------
+// dws: the same depthwise 3x3 (stride 1 / 2, no up-sampling) as a ROW-STREAMING kernel for the backbone.
+// dw3_kernel stages a band of 4 output rows + halo (6 input rows: 1.5x read amplification, 50 KiB of LDS at
+// 64 px, three workgroups per CU) and runs load -> barrier -> compute -> store once per workgroup, so the
+// memory pipe idles while it computes (measured 2.5 TB/s).  Here a workgroup = (image, CCH channels, strip
+// of output rows) walks DOWN its strip: the input rows it needs next are in flight in registers while it
+// computes the current output row from a ring of 3 + STRIDE rows in LDS -- every input row is read once
+// (plus 2 halo rows per strip), one barrier per output row, 17-42 KiB of LDS.
+// A thread owns one channel quad (weights and quantiser parameters in registers) and the pixels
+// x = x_l + u * (256 / LPP) of a row, for loading and for computing alike.
+// ------------------------------------------------------------------------------------------
+template <bool XQ, int STRIDE, int CCH, int MAXL>
+__global__ void __launch_bounds__(256)
+dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const unsigned char *__restrict__ agen,
+           const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ ep_scale,
+           const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
+           int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nstrips, int rps) {
+  extern __shared__ float4 ring4[];         // [RING][Ws + 2][LPP]
+  constexpr int LPP = CCH / 4, RING = 3 + STRIDE, XPT = 256 / LPP;
+  constexpr int DEPTH = 3;                  // output rows whose input rows are in flight in registers
+  const int strip = blockIdx.x % nstrips, c0 = (blockIdx.x / nstrips) * CCH, n = blockIdx.y;
+  const int Ho = STRIDE == 2 ? (Hs - 1) / 2 + 1 : Hs, Wo = STRIDE == 2 ? (Ws - 1) / 2 + 1 : Ws;
+  const int oy0 = strip * rps, oy1 = min(oy0 + rps, Ho);
+  const int Wc = Ws + 2;
+  const int tid = threadIdx.x, cq = tid % LPP, cb = c0 + cq * 4, x_l = tid / LPP;
+  const bool quad_in = cb + 3 < ld_in;       // the quad can be loaded (channels >= C are finite padding)
+  float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f};
+  if (XQ) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float *sp = reinterpret_cast<const float *>(aq);
+      if (agen) sp += cdn::kQStateWords * agen[min(cb + e, C - 1)];
+      qs[e] = sp[2];
+      qz[e] = sp[3];
+    }
+  }
+  float wk[9][4], bs[4], es[4], eh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool live = cb + e < C;
+    const int c = min(cb + e, C - 1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
+    bs[e] = (bias && live) ? bias[c] : 0.0f;
+    es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
+    eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < RING * 2 * LPP; i += 256) {          // the zero halo columns of every ring slot
+    const int slot = i / (2 * LPP), side = (i / LPP) & 1, q = i % LPP;
+    ring4[(slot * Wc + (side ? Ws + 1 : 0)) * LPP + q] = z4;
+  }
+  const int r_first = STRIDE * oy0 - 1;                       // first input row of the strip (may be -1)
+  const float *abase = a + (long)n * Hs * Ws * ld_in + cb;
+  auto load_row = [&](int r, float4 (&d)[MAXL]) {
+    const bool row_in = (unsigned)r < (unsigned)Hs && quad_in;
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int x = x_l + u * XPT;
+      d[u] = (row_in && x < Ws) ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * ld_in) : z4;
+    }
+  };
+  auto write_row = [&](int r, int slot, const float4 (&d)[MAXL]) {
+    const bool row_in = (unsigned)r < (unsigned)Hs && quad_in;   // rows outside are the conv's zero padding
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int x = x_l + u * XPT;
+      if (x < Ws) {
+        float4 t = d[u];
+        if (XQ && row_in) {
+          t.x = fake_quant(t.x, qs[0], qz[0]);
+          t.y = fake_quant(t.y, qs[1], qz[1]);
+          t.z = fake_quant(t.z, qs[2], qz[2]);
+          t.w = fake_quant(t.w, qs[3], qz[3]);
+        }
+        ring4[(slot * Wc + x + 1) * LPP + cq] = t;
+      }
+    }
+  };
+  float4 pre[DEPTH][STRIDE][MAXL];
+  int wslot = 0;                                              // ring slot of the next row to write
+  // step k (output row oy0 + k) consumes input rows r_first + (3 - STRIDE) + STRIDE * k + s, s < STRIDE
+  const int r_step0 = r_first + (3 - STRIDE);
+  if (oy0 < oy1) {
+#pragma unroll
+    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) {
+      load_row(r_first + p_, pre[0][0]);
+      write_row(r_first + p_, wslot, pre[0][0]);
+      wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    }
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_)
+      if (oy0 + d_ < oy1) {
+#pragma unroll
+        for (int s_ = 0; s_ < STRIDE; ++s_) load_row(r_step0 + STRIDE * d_ + s_, pre[d_][s_]);
+      }
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  int cslot = 0;                                              // ring slot of the first row of the 3x3 window
+  for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_) {
+      const int oy = oyb + d_;
+      if (oy < oy1) {                                         // workgroup-uniform
+        const int base_r = r_step0 + STRIDE * (oy - oy0);
+#pragma unroll
+        for (int s_ = 0; s_ < STRIDE; ++s_) {
+          write_row(base_r + s_, wslot, pre[d_][s_]);
+          wslot = wslot + 1 == RING ? 0 : wslot + 1;
+        }
+        __syncthreads();
+        if (oy + DEPTH < oy1) {
+#pragma unroll
+          for (int s_ = 0; s_ < STRIDE; ++s_) load_row(base_r + STRIDE * DEPTH + s_, pre[d_][s_]);
+        }
+        int rs[3];
+        rs[0] = cslot;
+        rs[1] = cslot + 1 >= RING ? cslot + 1 - RING : cslot + 1;
+        rs[2] = cslot + 2 >= RING ? cslot + 2 - RING : cslot + 2;
+        cslot = cslot + STRIDE >= RING ? cslot + STRIDE - RING : cslot + STRIDE;
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u) {
+          const int ox = x_l + u * XPT;
+          if (ox < Wo && cb < C) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const float4 t = ring4[(rs[dy] * Wc + STRIDE * ox + dx) * LPP + cq];
+                acc[0] = fmaf(wk[dy * 3 + dx][0], t.x, acc[0]);
+                acc[1] = fmaf(wk[dy * 3 + dx][1], t.y, acc[1]);
+                acc[2] = fmaf(wk[dy * 3 + dx][2], t.z, acc[2]);
+                acc[3] = fmaf(wk[dy * 3 + dx][3], t.w, acc[3]);
+              }
+            float r4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[e] + bs[e];
+              if (ep_scale) v = fmaf(v, es[e], eh[e]);
+              if (relu) v = fmaxf(v, 0.0f);
+              r4[e] = v;
+            }
+            float *op = out + ((long)n * Ho * Wo + (long)oy * Wo + ox) * ld_out + cb;
+            if (cb + 3 < ld_out && (ld_out & 3) == 0) {
+              *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (cb + e < C) op[e] = r4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cb + e < C) {
+                mn = fminf(mn, r4[e]);
+                mx = fmaxf(mx, r4[e]);
+              }
+          }
+        }
+      }
+    }
+  }
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+                             reinterpret_cast<float *>(ring4));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // interleave: the concat + channel_shuffle(groups = 2) that ends a ShuffleNetV2 unit
 // (shufflenetv2_dcn.py:43-49; quant_modules.py:905-907), with the block-output QuantAct applied:
 //     dst[m][2 i + 0] = fq_A(srcA[m][i])      dst[m][2 i + 1] = fq_B(srcB[m][i])        i < h
@@ -571,6 +740,66 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
   const int Hi = stride == 2 ? (Hs - 1) / 2 + 1 : Hs;
   CDN_REQUIRE(N <= 65535 && N * std::max(ld_in, ld_out) * H * W * (up ? 4 : 1) < (1ll << 31),
               CDN_ERR_UNSUPPORTED, "shape too large");
+  // ---- backbone form: row-streaming kernel (no up-sampling, values are written) ----------------------
+  static const bool no_dws = getenv("CDN_NO_DWS") != nullptr;   // tuning knob
+  if (!up && out && !no_dws && (out == nullptr || (reinterpret_cast<uintptr_t>(out) & 15) == 0 || (ld_out & 3))) {
+    const int Ho_ = Hi;
+    // channels per workgroup: a thread covers pixels x_l + u * (256 / LPP), u < 4
+    int cch = Ws <= 16 ? 64 : (Ws <= 128 ? 32 : 16);
+    if (cch == 32 && Ws > 64) cch = 16;                           // keep the ring under ~42 KiB
+    if (cch == 64 && C <= 32) cch = 32;
+    const int xpt = 256 / (cch / 4);
+    if (Ws <= 4 * xpt) {
+      const int ring = 3 + stride;
+      const size_t lds = (size_t)ring * (Ws + 2) * cch * sizeof(float);
+      const int nchunks = (int)cdn::ceil_div(C, cch);
+      // strips: enough workgroups to fill the chip twice, at least 8 output rows each
+      static const int wg_per_cu = getenv("CDN_DWS_WGS") ? atoi(getenv("CDN_DWS_WGS")) : 2;   // tuning knob
+      long want = cdn::ceil_div((long)wg_per_cu * cdn::kCUs, (long)N * nchunks);
+      int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho_ / 8)));
+      const int rps = (int)cdn::ceil_div(Ho_, nstrips);
+      nstrips = (int)cdn::ceil_div(Ho_, rps);
+      if ((long)nstrips * nchunks * N <= kMaxPartials && lds <= 64 * 1024) {
+        cdn::AuxWs ws{nullptr, nullptr};
+        if (r_state)
+          CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                      "workspace missing, too small or not 256-byte aligned");
+        hipStream_t st = cdn::as_stream(stream);
+        const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                              (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+        float2 *mm = r_state ? ws.partials : nullptr;
+        const unsigned *aq = static_cast<const unsigned *>(a_qstate);
+        dim3 grid((unsigned)(nstrips * nchunks), (unsigned)N);
+        cdn::ProfScope ps(cdn::kProfDw, (int)(H > 0xffff ? 0xffff : H), st);
+        const int maxl = (int)cdn::ceil_div(Ws, xpt);       // pixels of a row per thread: 1, 2 or 4
+#define CDN_GOS(XQ_, ST_, CCH_)                                                                       \
+  do {                                                                                                \
+    if (maxl <= 1)                                                                                    \
+      dws_kernel<XQ_, ST_, CCH_, 1><<<grid, 256, lds, st>>>(a, aq, a_gen, w, bias, ep_scale, ep_shift, out, mm, \
+          qu, (int)C, (int)ld_in, (int)ld_out, Hs, Ws, relu, nstrips, rps);                           \
+    else if (maxl == 2)                                                                               \
+      dws_kernel<XQ_, ST_, CCH_, 2><<<grid, 256, lds, st>>>(a, aq, a_gen, w, bias, ep_scale, ep_shift, out, mm, \
+          qu, (int)C, (int)ld_in, (int)ld_out, Hs, Ws, relu, nstrips, rps);                           \
+    else                                                                                              \
+      dws_kernel<XQ_, ST_, CCH_, 4><<<grid, 256, lds, st>>>(a, aq, a_gen, w, bias, ep_scale, ep_shift, out, mm, \
+          qu, (int)C, (int)ld_in, (int)ld_out, Hs, Ws, relu, nstrips, rps);                           \
+  } while (0)
+#define CDN_GOS2(XQ_, ST_)                                                                            \
+  do {                                                                                                \
+    if (cch == 64) CDN_GOS(XQ_, ST_, 64);                                                             \
+    else if (cch == 32) CDN_GOS(XQ_, ST_, 32);                                                        \
+    else CDN_GOS(XQ_, ST_, 16);                                                                       \
+  } while (0)
+        if (aq && stride == 2) CDN_GOS2(true, 2);
+        else if (aq) CDN_GOS2(true, 1);
+        else if (stride == 2) CDN_GOS2(false, 2);
+        else CDN_GOS2(false, 1);
+#undef CDN_GOS2
+#undef CDN_GOS
+        return cdn::check_launch("codenet dw3x3 (row streaming)");
+      }
+    }
+  }
   const int bandr = dw3_band(stride);
   const int rows = stride == 2 ? 2 * bandr + 1 : bandr + 2;
   // 32 channels per workgroup; 16 when the band of a wide plane would leave one workgroup per CU
