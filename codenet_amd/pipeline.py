@@ -477,10 +477,11 @@ class FusedBackbone:
     that also applies the shared block-output QuantAct, so a unit's output tensor holds final values.
     Returns what ``FusedHotPath.forward_nhwc(x, x_qstate, hw)`` takes."""
 
-    def __init__(self, model, int8_pointwise=True, shuffle_free=True):
+    def __init__(self, model, int8_pointwise=True, shuffle_free=True, two_streams=True):
         self.model = model
         self.int8 = int8_pointwise
         self.shuffle_free = shuffle_free and int8_pointwise
+        self.two_streams = two_streams
         self._bufs = None
 
     def _l4_weights(self, q4, logical, dev):
@@ -794,6 +795,28 @@ class FusedBackbone:
         cache[ck] = plan
         return plan
 
+    def _fork_side(self, dev):
+        """Route the following launches to the side stream (forked from the current stream), with the
+        second set of arrival counters."""
+        from . import _native as N_
+        if self.__dict__.get("_side") is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(dev)
+            aux = N_.lib().cdn_codenet_aux_workspace_bytes()
+            self._ws2 = torch.zeros(aux // 4 + 64, device=dev)
+        self._side.wait_stream(torch.cuda.current_stream(dev))
+        self._main_launch = (self._stream, self._ws_ptr, self._ws_bytes)
+        p2 = (self._ws2.data_ptr() + 255) // 256 * 256
+        self._stream, self._ws_ptr = self._side.cuda_stream, p2
+        self._ws_bytes = (self._ws2.numel() * 4 - (p2 - self._ws2.data_ptr())) // 256 * 256
+        return True
+
+    def _leave_side(self, dev):
+        """Back to the main stream; returns the event that marks the end of the side-stream work."""
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        self._stream, self._ws_ptr, self._ws_bytes = self._main_launch
+        return ev
+
     def _pw_raw(self, a_ptr, a_q, a_gen, M, lda, Wt, relu, act, state_ptr, out_map, out_ptr, ldo):
         from . import _native as N_
         aa = self._act_args(act, self._dev)
@@ -835,15 +858,23 @@ class FusedBackbone:
             for k, (u, P) in enumerate(zip(units, plan["units"])):
                 sh = u["sh"]
                 if k == 0:
+                    # the two branches of the stride-2 unit are independent until the shared QuantAct: branch 1
+                    # (reference order: first) runs on a side stream with its own arrival counters, and branch
+                    # 2's last conv -- the second call of the shared QuantAct -- waits for it
                     t4 = L["t4"]
+                    ev = self._fork_side(dev) if self.two_streams else None
                     self._dw_raw(x.data_ptr(), a_q, a_gen, Nb, cin, L["Hin"], L["Win"], 2, x_ld, P["w4"], P["b4"],
                                  u["a4"], t4, t4.shape[1])
                     self._pw_raw(t4.data_ptr(), qptr(u["a4"]), None, Mo, t4.shape[1], P["c5"], True, sh,
                                  sp(P["genA"]), P["omapA"].data_ptr(), Y.data_ptr(), C)
+                    if ev is not None:
+                        ev = self._leave_side(dev)
                     self._pw_raw(x.data_ptr(), a_q, a_gen, Mi, x_ld, P["c1"], True, u["a1"], None, None,
                                  L["t1s2"].data_ptr(), ldh)
                     self._dw_raw(L["t1s2"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["Hin"], L["Win"], 2, ldh,
                                  P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                    if ev is not None:
+                        torch.cuda.current_stream(dev).wait_event(ev)
                 else:
                     self._pw_raw(Y.data_ptr(), S.data_ptr(), P["gen_in"].data_ptr(), Mo, C, P["c1"], True,
                                  u["a1"], None, None, L["t1"].data_ptr(), ldh)
