@@ -1635,6 +1635,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             long M, int C, int Cpad, int Co, int relu, int lda, int ldo,
             const unsigned char *__restrict__ agen, const int *__restrict__ omap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CDN_STAMPR(2, 0);
   const int nwin = (C + 31) >> 5, Kp = nwin * 32;
   const int ldb = Kp * 2 + 16;                               // bytes per B row: conflict-free ds_read_b128
   float4 *qtab = reinterpret_cast<float4 *>(smem + (size_t)32 * TN * ldb);   // [Kp] {s, z, 1/s, -}
@@ -1668,29 +1669,27 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 #pragma unroll
   for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
 
-  // ---- B tile and quantiser table -> LDS ----------------------------------------------------------
-  const int chunks = Kp >> 4;                                // 16-code chunks per row
-  for (int q = tid; q < 32 * TN * chunks; q += 256) {
-    const int r_ = q / chunks, ch = q - r_ * chunks;
-    i32x4 cw = (i32x4){0, 0, 0, 0};
-    if (n0 + r_ < Co) cw = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
-    unsigned w8[8];
+  // ---- quantiser table and B tile -> LDS (loads batched: the prologue is latency, not work) -----------
+  if (has_q) {
+    float4 te[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int word = cw[e];
-      const unsigned f0 = __float_as_uint((float)((word << 24) >> 24));
-      const unsigned f1 = __float_as_uint((float)((word << 16) >> 24));
-      const unsigned f2 = __float_as_uint((float)((word << 8) >> 24));
-      const unsigned f3 = __float_as_uint((float)(word >> 24));
-      w8[2 * e] = pack_hi(f1, f0);
-      w8[2 * e + 1] = pack_hi(f3, f2);
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      te[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) {
+        const float *sp = reinterpret_cast<const float *>(aq) + (agen ? cdn::kQStateWords * agen[c] : 0);
+        te[u] = make_float4(sp[2], sp[3], 0.f, 0.f);
+      }
     }
-    unsigned char *dp = smem + (size_t)r_ * ldb + ch * 32;
-    *reinterpret_cast<i32x4 *>(dp) = (i32x4){(int)w8[0], (int)w8[1], (int)w8[2], (int)w8[3]};
-    *reinterpret_cast<i32x4 *>(dp + 16) = (i32x4){(int)w8[4], (int)w8[5], (int)w8[6], (int)w8[7]};
-  }
-  if (has_q)
-    for (int c = tid; c < Kp; c += 256) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u;
+      if (c < Kp) {
+        if (c < C) te[u].z = __fdiv_rn(1.0f, te[u].x);
+        qtab[c] = te[u];
+      }
+    }
+    for (int c = tid + 512; c < Kp; c += 256) {                // (C > 512: not reached by the dispatcher)
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < C) {
         const float *sp = reinterpret_cast<const float *>(aq) + (agen ? cdn::kQStateWords * agen[c] : 0);
@@ -1698,6 +1697,41 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
       qtab[c] = e;
     }
+  }
+  const int chunks = Kp >> 4;                                // 16-code chunks per row
+  const int nitems = 32 * TN * chunks;
+  for (int q0 = tid; q0 < nitems; q0 += 256 * 4) {
+    i32x4 cw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + 256 * u;
+      const int r_ = q / chunks, ch = q - r_ * chunks;
+      cw[u] = (i32x4){0, 0, 0, 0};
+      if (q < nitems && n0 + r_ < Co)
+        cw[u] = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + 256 * u;
+      if (q < nitems) {
+        const int r_ = q / chunks, ch = q - r_ * chunks;
+        unsigned w8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int word = cw[u][e];
+          const unsigned f0 = __float_as_uint((float)((word << 24) >> 24));
+          const unsigned f1 = __float_as_uint((float)((word << 16) >> 24));
+          const unsigned f2 = __float_as_uint((float)((word << 8) >> 24));
+          const unsigned f3 = __float_as_uint((float)(word >> 24));
+          w8[2 * e] = pack_hi(f1, f0);
+          w8[2 * e + 1] = pack_hi(f3, f2);
+        }
+        unsigned char *dp = smem + (size_t)r_ * ldb + ch * 32;
+        *reinterpret_cast<i32x4 *>(dp) = (i32x4){(int)w8[0], (int)w8[1], (int)w8[2], (int)w8[3]};
+        *reinterpret_cast<i32x4 *>(dp + 16) = (i32x4){(int)w8[4], (int)w8[5], (int)w8[6], (int)w8[7]};
+      }
+    }
+  }
   // epilogue constants of this lane's TN output columns
   float bsv[TN], rinv[TN];
   int oc[TN];
@@ -1714,6 +1748,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     }
   }
   __syncthreads();
+  CDN_STAMPR(2, 1);
 
   const unsigned char *bbase = smem + (size_t)(lane & 31) * ldb + 32 * (lane >> 5);
   const float4 *qrow = qtab + 16 * (lane >> 5);
@@ -1773,6 +1808,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         }
       }
     }
+    if (rb == rb_first) CDN_STAMPR(2, 2);
     const long mb0 = rb * 32;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -1788,9 +1824,11 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         }
       }
   }
+  CDN_STAMPR(2, 3);
   if (rmm)
     cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(smem));
+  CDN_STAMPR(2, 4);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -205,7 +205,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   const int Wc = Ws + 2;
   const int tid = threadIdx.x, cq = tid % LPP, cb = c0 + cq * 4, x_l = tid / LPP;
   const bool quad_in = cb + 3 < ld_in;       // the quad can be loaded (channels >= C are finite padding)
-  float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f};
+  float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f}, qr[4] = {1.f, 1.f, 1.f, 1.f};
   if (XQ) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -213,6 +213,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
       if (agen) sp += cdn::kQStateWords * agen[min(cb + e, C - 1)];
       qs[e] = sp[2];
       qz[e] = sp[3];
+      qr[e] = __fdiv_rn(1.0f, sp[2]);
     }
   }
   float wk[9][4], bs[4], es[4], eh[4];
@@ -249,10 +250,10 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
       if (x < Ws) {
         float4 t = d[u];
         if (XQ && row_in) {
-          t.x = fake_quant(t.x, qs[0], qz[0]);
-          t.y = fake_quant(t.y, qs[1], qz[1]);
-          t.z = fake_quant(t.z, qs[2], qz[2]);
-          t.w = fake_quant(t.w, qs[3], qz[3]);
+          t.x = cdn::fake_quant_r(t.x, qs[0], qz[0], qr[0]);
+          t.y = cdn::fake_quant_r(t.y, qs[1], qz[1], qr[1]);
+          t.z = cdn::fake_quant_r(t.z, qs[2], qz[2], qr[2]);
+          t.w = cdn::fake_quant_r(t.w, qs[3], qz[3], qr[3]);
         }
         ring4[(slot * Wc + x + 1) * LPP + cq] = t;
       }
@@ -323,6 +324,173 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
               r4[e] = v;
             }
             float *op = out + ((long)n * Ho * Wo + (long)oy * Wo + ox) * ld_out + cb;
+            if (cb + 3 < ld_out && (ld_out & 3) == 0) {
+              *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (cb + e < C) op[e] = r4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cb + e < C) {
+                mn = fminf(mn, r4[e]);
+                mx = fmaxf(mx, r4[e]);
+              }
+          }
+        }
+      }
+    }
+  }
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+                             reinterpret_cast<float *>(ring4));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// dwx: the row-streaming depthwise with the workgroup cut along x instead of along the channels.  With few
+// channels per pixel (58 + 2 padding = 240 B, 116 = 464 B) a 16- or 32-channel chunk is a 64- or 128-byte
+// piece of every pixel: the chunks of one pixel belong to different workgroups -- on different XCDs, i.e.
+// different L2s -- so every cache line is fetched from HBM several times (measured 2.4 TB/s of algorithmic
+// bytes at C = 58, 128 x 128, stride 2).  Here a workgroup = (image, strip of output columns, strip of output
+// rows) takes ALL channels of its pixels: its loads are whole contiguous pixels, the only shared lines are
+// the one halo column on each side.  LPP = ceil(C / 4) quads per pixel and XPT = 256 / LPP pixels per pass
+// are run-time values (blockDim = XPT * LPP); a thread still owns one channel quad.  C <= 128.
+// ------------------------------------------------------------------------------------------
+template <bool XQ, int STRIDE, int MAXL>
+__global__ void __launch_bounds__(256)
+dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const unsigned char *__restrict__ agen,
+           const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ ep_scale,
+           const float *__restrict__ ep_shift, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
+           int C, int ld_in, int ld_out, int Hs, int Ws, int relu, int nxs, int XSo, int nstrips, int rps,
+           int LPP, int XPT) {
+  extern __shared__ float4 ring4[];         // [RING][Wc][LPP]
+  constexpr int RING = 3 + STRIDE, DEPTH = 3;
+  const int xs = blockIdx.x % nxs, strip = blockIdx.x / nxs, n = blockIdx.y;
+  const int Ho = STRIDE == 2 ? (Hs - 1) / 2 + 1 : Hs, Wo = STRIDE == 2 ? (Ws - 1) / 2 + 1 : Ws;
+  const int oy0 = strip * rps, oy1 = min(oy0 + rps, Ho);
+  const int ox0 = xs * XSo, nxo = min(XSo, Wo - ox0);          // output columns of this workgroup
+  const int Wc = STRIDE * (XSo - 1) + 3;                       // staged input columns (ring row width)
+  const int ix0 = STRIDE * ox0 - 1;                            // first staged input column (may be -1)
+  const int tid = threadIdx.x, cq = tid % LPP, cb = cq * 4, x_l = tid / LPP;
+  const bool quad_in = cb + 3 < ld_in;
+  float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f}, qr[4] = {1.f, 1.f, 1.f, 1.f};
+  if (XQ) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float *sp = reinterpret_cast<const float *>(aq);
+      if (agen) sp += cdn::kQStateWords * agen[min(cb + e, C - 1)];
+      qs[e] = sp[2];
+      qz[e] = sp[3];
+      qr[e] = __fdiv_rn(1.0f, sp[2]);
+    }
+  }
+  float wk[9][4], bs[4], es[4], eh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool live = cb + e < C;
+    const int c = min(cb + e, C - 1);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
+    bs[e] = (bias && live) ? bias[c] : 0.0f;
+    es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
+    eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int r_first = STRIDE * oy0 - 1;
+  const float *abase = a + (long)n * Hs * Ws * ld_in + cb;
+  auto load_row = [&](int r, float4 (&d)[MAXL]) {
+    const bool row_in = (unsigned)r < (unsigned)Hs && quad_in;
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int col = x_l + u * XPT, x = ix0 + col;
+      d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws)
+                 ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * ld_in) : z4;
+    }
+  };
+  auto write_row = [&](int r, int slot, const float4 (&d)[MAXL]) {
+    const bool row_in = (unsigned)r < (unsigned)Hs && quad_in;   // rows / columns outside: the conv's zero padding
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int col = x_l + u * XPT, x = ix0 + col;
+      if (col < Wc) {
+        float4 t = d[u];
+        if (XQ && row_in && (unsigned)x < (unsigned)Ws) {
+          t.x = cdn::fake_quant_r(t.x, qs[0], qz[0], qr[0]);
+          t.y = cdn::fake_quant_r(t.y, qs[1], qz[1], qr[1]);
+          t.z = cdn::fake_quant_r(t.z, qs[2], qz[2], qr[2]);
+          t.w = cdn::fake_quant_r(t.w, qs[3], qz[3], qr[3]);
+        }
+        ring4[(slot * Wc + col) * LPP + cq] = t;
+      }
+    }
+  };
+  float4 pre[DEPTH][STRIDE][MAXL];
+  int wslot = 0;
+  const int r_step0 = r_first + (3 - STRIDE);
+  if (oy0 < oy1) {
+#pragma unroll
+    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) {
+      load_row(r_first + p_, pre[0][0]);
+      write_row(r_first + p_, wslot, pre[0][0]);
+      wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    }
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_)
+      if (oy0 + d_ < oy1) {
+#pragma unroll
+        for (int s_ = 0; s_ < STRIDE; ++s_) load_row(r_step0 + STRIDE * d_ + s_, pre[d_][s_]);
+      }
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  int cslot = 0;
+  for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_) {
+      const int oy = oyb + d_;
+      if (oy < oy1) {                                         // workgroup-uniform
+        const int base_r = r_step0 + STRIDE * (oy - oy0);
+#pragma unroll
+        for (int s_ = 0; s_ < STRIDE; ++s_) {
+          write_row(base_r + s_, wslot, pre[d_][s_]);
+          wslot = wslot + 1 == RING ? 0 : wslot + 1;
+        }
+        __syncthreads();
+        if (oy + DEPTH < oy1) {
+#pragma unroll
+          for (int s_ = 0; s_ < STRIDE; ++s_) load_row(base_r + STRIDE * DEPTH + s_, pre[d_][s_]);
+        }
+        int rs[3];
+        rs[0] = cslot;
+        rs[1] = cslot + 1 >= RING ? cslot + 1 - RING : cslot + 1;
+        rs[2] = cslot + 2 >= RING ? cslot + 2 - RING : cslot + 2;
+        cslot = cslot + STRIDE >= RING ? cslot + STRIDE - RING : cslot + STRIDE;
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u) {
+          const int oxl = x_l + u * XPT;
+          if (oxl < nxo && cb < C) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const float4 t = ring4[(rs[dy] * Wc + STRIDE * oxl + dx) * LPP + cq];
+                acc[0] = fmaf(wk[dy * 3 + dx][0], t.x, acc[0]);
+                acc[1] = fmaf(wk[dy * 3 + dx][1], t.y, acc[1]);
+                acc[2] = fmaf(wk[dy * 3 + dx][2], t.z, acc[2]);
+                acc[3] = fmaf(wk[dy * 3 + dx][3], t.w, acc[3]);
+              }
+            float r4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[e] + bs[e];
+              if (ep_scale) v = fmaf(v, es[e], eh[e]);
+              if (relu) v = fmaxf(v, 0.0f);
+              r4[e] = v;
+            }
+            float *op = out + ((long)n * Ho * Wo + (long)oy * Wo + ox0 + oxl) * ld_out + cb;
             if (cb + 3 < ld_out && (ld_out & 3) == 0) {
               *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
             } else {
@@ -744,6 +912,67 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
   static const bool no_dws = getenv("CDN_NO_DWS") != nullptr;   // tuning knob
   if (!up && out && !no_dws && (out == nullptr || (reinterpret_cast<uintptr_t>(out) & 15) == 0 || (ld_out & 3))) {
     const int Ho_ = Hi;
+    static const bool no_dwx = getenv("CDN_NO_DWX") != nullptr;   // tuning knob
+    if (!no_dwx && C <= 128) {
+      // x-strip form: all channels of a pixel in one workgroup
+      const int LPP = (int)cdn::ceil_div(C, 4), XPT = 256 / LPP;
+      const int Wo_ = stride == 2 ? (Ws - 1) / 2 + 1 : Ws;
+      const int ring = 3 + stride;
+      // widest strip whose staged columns fit MAXL passes and ~40 KiB of LDS
+      int best_maxl = 0, best_xso = 0;
+      for (int maxl = 4; maxl >= 1; --maxl) {
+        int xso = stride == 2 ? (maxl * XPT - 1) / 2 : maxl * XPT - 2;
+        if (xso < 1) continue;
+        xso = std::min(xso, Wo_);
+        const int nxs_ = (int)cdn::ceil_div(Wo_, xso);
+        xso = (int)cdn::ceil_div(Wo_, nxs_);                    // balanced strips
+        const int wc = stride * (xso - 1) + 3;
+        if ((size_t)ring * wc * LPP * 16 <= 40 * 1024 && cdn::ceil_div(wc, XPT) <= maxl) {
+          best_maxl = (int)cdn::ceil_div(wc, XPT);
+          best_xso = xso;
+          break;
+        }
+      }
+      if (best_maxl) {
+        const int XSo = best_xso, nxs = (int)cdn::ceil_div(Wo_, XSo), wc = stride * (XSo - 1) + 3;
+        const size_t lds = (size_t)ring * wc * LPP * 16;
+        static const int wg_per_cu = getenv("CDN_DWS_WGS") ? atoi(getenv("CDN_DWS_WGS")) : 2;
+        long want = cdn::ceil_div((long)wg_per_cu * cdn::kCUs, (long)N * nxs);
+        int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho_ / 8)));
+        const int rps = (int)cdn::ceil_div(Ho_, nstrips);
+        nstrips = (int)cdn::ceil_div(Ho_, rps);
+        if ((long)nstrips * nxs * N <= kMaxPartials) {
+          cdn::AuxWs ws{nullptr, nullptr};
+          if (r_state)
+            CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                        "workspace missing, too small or not 256-byte aligned");
+          hipStream_t st = cdn::as_stream(stream);
+          const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                                (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+          float2 *mm = r_state ? ws.partials : nullptr;
+          const unsigned *aq = static_cast<const unsigned *>(a_qstate);
+          dim3 grid((unsigned)(nstrips * nxs), (unsigned)N);
+          cdn::ProfScope ps(cdn::kProfDw, (int)(H > 0xffff ? 0xffff : H), st);
+#define CDN_GOX(XQ_, ST_, ML_)                                                                          \
+  dwx_kernel<XQ_, ST_, ML_><<<grid, XPT * LPP, lds, st>>>(a, aq, a_gen, w, bias, ep_scale, ep_shift, out, mm, \
+      qu, (int)C, (int)ld_in, (int)ld_out, Hs, Ws, relu, nxs, XSo, nstrips, rps, LPP, XPT)
+#define CDN_GOX2(XQ_, ST_)                                                                              \
+  do {                                                                                                  \
+    if (best_maxl == 1) CDN_GOX(XQ_, ST_, 1);                                                           \
+    else if (best_maxl == 2) CDN_GOX(XQ_, ST_, 2);                                                      \
+    else if (best_maxl == 3) CDN_GOX(XQ_, ST_, 3);                                                      \
+    else CDN_GOX(XQ_, ST_, 4);                                                                          \
+  } while (0)
+          if (aq && stride == 2) CDN_GOX2(true, 2);
+          else if (aq) CDN_GOX2(true, 1);
+          else if (stride == 2) CDN_GOX2(false, 2);
+          else CDN_GOX2(false, 1);
+#undef CDN_GOX2
+#undef CDN_GOX
+          return cdn::check_launch("codenet dw3x3 (x strips)");
+        }
+      }
+    }
     // channels per workgroup: a thread covers pixels x_l + u * (256 / LPP), u < 4
     int cch = Ws <= 16 ? 64 : (Ws <= 128 ? 32 : 16);
     if (cch == 32 && Ws > 64) cch = 16;                           // keep the ring under ~42 KiB

@@ -77,6 +77,26 @@ def main():
                 st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(), stream)
             N_.check(rc, "pw")
         res[name] = graph_time(run)
+        if hasattr(lib, "cdn_debug_read_stamps") and os.environ.get("CDN_STAMP_MODE", "mixed") == name:
+            import ctypes
+            import numpy as np
+            lib.cdn_debug_clear_stamps()
+            stream = torch.cuda.current_stream().cuda_stream
+            run()
+            torch.cuda.synchronize()
+            buf = np.zeros(3 * 2048 * 8 + 64, dtype=np.uint64)
+            lib.cdn_debug_read_stamps.argtypes = [ctypes.c_void_p]
+            lib.cdn_debug_read_stamps(buf.ctypes.data)
+            sd = buf[:3 * 2048 * 8].reshape(3, 2048, 8)[2].astype(np.float64) / 100.0
+            sd = sd[sd[:, 0] > 0]
+            t0 = sd[:, 0].min()
+            ph = ["prologue", "first block k-loop", "remaining blocks + stores", "finish"]
+            print("workgroups %d, span %.1f us; starts: p50 %.1f p90 %.1f max %.1f us" % (
+                len(sd), sd[:, 4].max() - t0, *np.percentile(sd[:, 0] - t0, [50, 90, 100])))
+            print("  start deciles:", np.round(np.percentile(sd[:, 0] - t0, range(0, 101, 10)), 1).tolist())
+            for i, nm in enumerate(ph):
+                d = sd[:, i + 1] - sd[:, i]
+                print("  %-28s mean %.2f  p90 %.2f us" % (nm, d.mean(), np.percentile(d, 90)))
     res["shape"] = [M, C, Co, lda]
     res["MB"] = round((M * C * 4 + M * Co * 4) / 1e6, 1)
     print(json.dumps(res))
