@@ -14,6 +14,8 @@ src, dst = "gpurun_out/" + R, "profiles/" + R
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(src + "/*.json"):
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+for f in glob.glob(src + "/*kernel_stats.csv") + glob.glob(src + "/backbone_kernel_order.txt"):
+    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 st = glob.glob(src + "/stats/*/*kernel_stats.csv")
 if st:
     shutil.copy(st[0], dst + "/bench_w4a8_fused_kernel_stats.csv")
