@@ -317,3 +317,114 @@ def test_pointwise_bf16_split_is_exact_product(M, C, Co, lda, off, ldo, relu):
         assert (out[:, Co:] == -7.0).all()
         assert lo == out[:, :Co].min().item() and hi == out[:, :Co].max().item()
     assert (outs[0][0][:, :Co] - outs[1][0][:, :Co]).abs().max().item() < 2e-6 * mag
+
+
+def _states(dev, ngen, g):
+    """An array of QuantAct states (scale, zero point at words 2, 3) with different grids."""
+    S = torch.zeros(ngen, 8)
+    S[:, 2] = torch.rand(ngen, generator=g) * 40 + 5
+    S[:, 3] = torch.round(torch.rand(ngen, generator=g) * 200 - 100)
+    return S.to(dev)
+
+
+def _avoid_ties(x, sc, zp):
+    """Nudge the values whose code sc*x - zp lies within 1e-3 of a rounding tie (x.5): there the fp32 rounding
+    of the product decides the code, and a torch composition is no reference for a single kernel."""
+    t = sc.double() * x.double() - zp.double()
+    near = ((t - torch.floor(t)) - 0.5).abs() < 1e-3
+    return torch.where(near, x + 0.05 / sc, x)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_depthwise_mixed_generations_random_shapes(seed):
+    """Row-streaming depthwise kernels (x strips: C <= 128; channel chunks: wider) with per-channel QuantAct
+    generations applied on load, stride 1 / 2, odd sizes, padded rows -- vs conv2d on the per-channel
+    fake-quantised input."""
+    import random
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    N = rnd.choice([1, 2, 3])
+    C = rnd.choice([3, 8, 24, 58, 116, 130, 232, 260])
+    H, W = rnd.choice([5, 8, 16, 33, 64]), rnd.choice([4, 9, 16, 31, 64, 130])
+    stride = rnd.choice([1, 2])
+    ld_in = (C + 3) // 4 * 4 + rnd.choice([0, 4])
+    ld_out = (C + 3) // 4 * 4 + rnd.choice([0, 4])
+    ngen = rnd.choice([1, 3, 7])
+    S = _states(dev, ngen, g)
+    gen = torch.randint(0, ngen, (C,), generator=g).to(torch.uint8).to(dev)
+    x = (torch.randn(N, C, H, W, generator=g) * 2).to(dev)
+    sc, zp = S[gen.long(), 2].view(1, C, 1, 1), S[gen.long(), 3].view(1, C, 1, 1)
+    x = _avoid_ties(x, sc, zp)
+    xq = (torch.round(sc * x - zp) + zp) / sc
+    a = torch.full((N, H * W, ld_in), 1.5, device=dev)
+    a[:, :, :C] = x.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    w = torch.randn(C, 1, 3, 3, generator=g).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    ref = torch.relu(F.conv2d(xq, w, b, stride, 1, 1, C))
+    Ho, Wo = ref.shape[2:]
+    out = torch.full((N, Ho * Wo, ld_out), -7.0, device=dev)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    rc = lib.cdn_codenet_dw3x3_mixed_forward(
+        a.data_ptr(), S.data_ptr(), gen.data_ptr(), N, C, H, W, 0, stride, ld_in, ld_out, w.data_ptr(),
+        b.data_ptr(), None, None, 1, xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb,
+        out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "dw mixed")
+    got = out[:, :, :C].reshape(N, Ho, Wo, C).permute(0, 3, 1, 2)
+    tol = 2e-5 * (1 + ref.abs().max().item())
+    assert (got - ref).abs().max().item() < tol
+    assert (out[:, :, C:] == -7.0).all() or ld_out % 4 == 0          # padding is written only by whole-quad stores
+    assert abs(xmin.item() - got.min().item()) < 1e-6 and abs(xmax.item() - got.max().item()) < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_pointwise_mixed_generations_and_output_map(seed):
+    """Mixed-generation pointwise (streaming and LDS-tiled bf16-split kernels) with an output channel map
+    vs a float64 matmul on the per-channel fake-quantised input; untouched output slots stay untouched."""
+    import random
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    rnd = random.Random(seed)
+    g = torch.Generator().manual_seed(200 + seed)
+    M = rnd.choice([1, 31, 129, 1000, 4100])
+    C = rnd.choice([4, 24, 58, 116, 232, 464])
+    Co = rnd.choice([1, 2, 29, 58, 116, 130, 300])
+    lda = C + rnd.choice([0, 4, 6]) if C % 4 == 0 else C + 3
+    ldo = Co * 2 + rnd.choice([0, 1])
+    ngen = rnd.choice([1, 2, 9])
+    S = _states(dev, ngen, g)
+    gen = torch.randint(0, ngen, (C,), generator=g).to(torch.uint8).to(dev)
+    a = (torch.randn(M, lda, generator=g) * 2).to(dev)
+    sc, zp = S[gen.long(), 2].view(1, C), S[gen.long(), 3].view(1, C)
+    a[:, :C] = _avoid_ties(a[:, :C], sc, zp)
+    aq = (torch.round(sc * a[:, :C] - zp) + zp) / sc
+    cpad = (C + 63) // 64 * 64
+    q = torch.randint(-8, 8, (Co, C), generator=g)
+    q[:, torch.rand(C, generator=g) < 0.4] = 0                       # pass-through columns
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = q.to(torch.int8)
+    codes = codes.to(dev)
+    scale = (torch.rand(Co, generator=g) * 20 + 1).to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    wf = (q.to(dev).float() / scale[:, None]).contiguous()
+    colsum = q.sum(1).to(torch.int32).to(dev)
+    omap = torch.randperm(ldo, generator=g)[:Co].to(torch.int32).to(dev)
+    out = torch.full((M, ldo), -7.0, device=dev)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    rc = lib.cdn_codenet_pointwise_mixed_forward(
+        a.data_ptr(), S.data_ptr(), gen.data_ptr(), M, C, Co, lda, ldo, wf.data_ptr(), codes.data_ptr(),
+        scale.data_ptr(), colsum.data_ptr(), bias.data_ptr(), None, None, 1, omap.data_ptr(), xmin.data_ptr(),
+        xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(),
+        torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "pw mixed")
+    ref = torch.relu(aq.double() @ (q.to(dev).double() / scale.double()[:, None]).t() + bias.double())
+    mag = (aq.double().abs() @ (q.to(dev).double().abs() / scale.double()[:, None]).t()).max().item() + 1.0
+    got = out[:, omap.long()].double()
+    assert (got - ref).abs().max().item() < 3e-6 * mag
+    untouched = torch.ones(ldo, dtype=torch.bool, device=dev)
+    untouched[omap.long()] = False
+    assert (out[:, untouched] == -7.0).all()
+    assert xmin.item() == out[:, omap.long()].min().item() and xmax.item() == out[:, omap.long()].max().item()
