@@ -357,7 +357,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
 // bytes at C = 58, 128 x 128, stride 2).  Here a workgroup = (image, strip of output columns, strip of output
 // rows) takes ALL channels of its pixels: its loads are whole contiguous pixels, the only shared lines are
 // the one halo column on each side.  LPP = ceil(C / 4) quads per pixel and XPT = 256 / LPP pixels per pass
-// are run-time values (blockDim = XPT * LPP); a thread still owns one channel quad.  C <= 128.
+// are run-time values (blockDim = XPT * LPP); a thread still owns one channel quad.  C <= 128 (used up to 64).
 // ------------------------------------------------------------------------------------------
 template <bool XQ, int STRIDE, int MAXL>
 __global__ void __launch_bounds__(256)
@@ -913,7 +913,10 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
   if (!up && out && !no_dws && (out == nullptr || (reinterpret_cast<uintptr_t>(out) & 15) == 0 || (ld_out & 3))) {
     const int Ho_ = Hi;
     static const bool no_dwx = getenv("CDN_NO_DWX") != nullptr;   // tuning knob
-    if (!no_dwx && C <= 128) {
+    // measured (fake-quantising input): x strips win at 24 and 58 channels (76 vs 124 us at 58 ch, 128 x 128,
+    // stride 2), channel chunks at 116 (128-byte pieces of 464-byte pixels: 27 vs 29 us, 53 vs 60 us)
+    static const int dwx_max_c = getenv("CDN_DWX_MAXC") ? atoi(getenv("CDN_DWX_MAXC")) : 64;
+    if (!no_dwx && C <= dwx_max_c && C <= 128) {
       // x-strip form: all channels of a pixel in one workgroup
       const int LPP = (int)cdn::ceil_div(C, 4), XPT = 256 / LPP;
       const int Wo_ = stride == 2 ? (Ws - 1) / 2 + 1 : Ws;
