@@ -19,6 +19,7 @@ using cdn::kMaxPartials;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v2f = __attribute__((ext_vector_type(2))) float;
 #define CDN_STAMPR(R, I) do { } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -870,6 +871,218 @@ maxpool_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, flo
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// head_small: the tail of a W4A8 detection head with FEW output channels (wh, reg: 2) as a row-streaming
+// VALU kernel, and the range pass in front of it (quant_modules.py:1062-1069):
+//   MODE 0  range of ReLU(depthwise 3x3 on the nearest x2 up-sampled fq(y1) + b)      (the QuantAct's batch extremes)
+//   MODE 1  the same values -> integer levels L = round(s*v - z) + z -> out[cls] = (sum_c L_c * qw[cls][c]) /
+//           (s * sw[cls]) + b[cls], NCHW
+// The 64-channel full-resolution tensor (268 MB per head at batch 64, written by dw3_kernel and re-read by
+// the pointwise kernel in the unfused schedule) never exists.  head_tail_kernel does this on the int8 matrix
+// cores for up to 32 classes, one stored row per workgroup with 3x re-staging (150 us); for <= 4 outputs the
+// dot products are 4 FMAs per pixel and class on the VALU: exact (|L * qw| sums stay below 2^24, so the fp32
+// sum IS the integer sum of pwi8_kernel and the result is bit-identical to the unfused path), reduced over
+// the 16 lanes of a pixel with a 15-shuffle transpose-reduce.  Workgroup = (image, strip of 32 stored
+// columns, strip of stored rows), ring of 4 stored rows in LDS (fake-quantised once), two rows in flight.
+// C == 64: lane = (pixel x_l = tid / 16, channel quad cq = tid % 16).
+// ------------------------------------------------------------------------------------------
+template <int MODE, int NCLS>
+__global__ void __launch_bounds__(256)
+head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1, const float *__restrict__ wdw,
+                  const float *__restrict__ bdw, const unsigned *__restrict__ q2,
+                  const signed char *__restrict__ Wq, const float *__restrict__ wscale,
+                  const float *__restrict__ bias, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
+                  int Hs, int Ws, int classes, int Cpad, int nxs, int XS, int nstrips, int rps) {
+  extern __shared__ float4 ring4[];          // [4][XS + 2][16]
+  constexpr int LPP = 16, XPT = 16, MAXL = 3, DEPTH = 2, NV = 4 * NCLS, C = 64;   // ring of 4 rows
+  const int xs = blockIdx.x % nxs, strip = blockIdx.x / nxs, n = blockIdx.y;
+  const int Y0 = strip * rps, Y1 = min(Y0 + rps, Hs);
+  const int x0 = xs * XS, nx = min(XS, Ws - x0), Wc = XS + 2, ix0 = x0 - 1;
+  const int tid = threadIdx.x, cq = tid & 15, x_l = tid >> 4, cb = cq * 4;
+  const float s1 = reinterpret_cast<const float *>(q1)[2], z1 = reinterpret_cast<const float *>(q1)[3];
+  const float r1 = __fdiv_rn(1.0f, s1);
+  float s2 = 1.f, z2 = 0.f;
+  if (MODE == 1) {
+    s2 = reinterpret_cast<const float *>(q2)[2];
+    z2 = reinterpret_cast<const float *>(q2)[3];
+  }
+  v2f wlo[9], whi[9], blo, bhi;               // depthwise weights / bias of channels (0,1) and (2,3)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    wlo[k] = (v2f){wdw[(long)(cb + 0) * 9 + k], wdw[(long)(cb + 1) * 9 + k]};
+    whi[k] = (v2f){wdw[(long)(cb + 2) * 9 + k], wdw[(long)(cb + 3) * 9 + k]};
+  }
+  blo = (v2f){bdw ? bdw[cb + 0] : 0.0f, bdw ? bdw[cb + 1] : 0.0f};
+  bhi = (v2f){bdw ? bdw[cb + 2] : 0.0f, bdw ? bdw[cb + 3] : 0.0f};
+  float wq[NCLS][4];                          // this lane's 4 channels of every class's weight codes
+  v2f wq2[NCLS / 2][4];                       // the same, classes paired: {qw[2p][e], qw[2p+1][e]}
+  float my_rinv = 0.f, my_bias = 0.f;
+  const int my_idx = cq & (NV - 1), my_cls = my_idx >> 2;
+  if (MODE == 1) {
+#pragma unroll
+    for (int c_ = 0; c_ < NCLS; ++c_) {
+      const int word = c_ < classes ? *reinterpret_cast<const int *>(Wq + (long)c_ * Cpad + cb) : 0;
+      wq[c_][0] = (float)((word << 24) >> 24);
+      wq[c_][1] = (float)((word << 16) >> 24);
+      wq[c_][2] = (float)((word << 8) >> 24);
+      wq[c_][3] = (float)(word >> 24);
+    }
+#pragma unroll
+    for (int cp = 0; cp < NCLS / 2; ++cp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wq2[cp][e] = (v2f){wq[2 * cp][e], wq[2 * cp + 1][e]};
+    if (my_cls < classes) {
+      my_rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[my_cls]));
+      my_bias = bias ? bias[my_cls] : 0.0f;
+    }
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float *abase = y1 + (long)n * Hs * Ws * C + cb;
+  auto load_row = [&](int r, float4 (&d)[MAXL]) {
+    const bool row_in = (unsigned)r < (unsigned)Hs;
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int col = x_l + u * XPT, x = ix0 + col;
+      d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws)
+                 ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * C) : z4;
+    }
+  };
+  auto write_row = [&](int r, int slot, const float4 (&d)[MAXL]) {
+    const bool row_in = (unsigned)r < (unsigned)Hs;
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int col = x_l + u * XPT, x = ix0 + col;
+      if (col < Wc) {
+        float4 t = d[u];
+        if (row_in && (unsigned)x < (unsigned)Ws) {
+          t.x = cdn::fake_quant_r(t.x, s1, z1, r1);
+          t.y = cdn::fake_quant_r(t.y, s1, z1, r1);
+          t.z = cdn::fake_quant_r(t.z, s1, z1, r1);
+          t.w = cdn::fake_quant_r(t.w, s1, z1, r1);
+        }
+        ring4[(slot * Wc + col) * LPP + cq] = t;
+      }
+    }
+  };
+  float4 pre[DEPTH][MAXL];
+  int wslot = 0;
+  if (Y0 < Y1) {
+#pragma unroll
+    for (int p_ = 0; p_ < 2; ++p_) {          // stored rows Y0 - 1, Y0
+      load_row(Y0 - 1 + p_, pre[0]);
+      write_row(Y0 - 1 + p_, wslot, pre[0]);
+      wslot = (wslot + 1) & 3;
+    }
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_)
+      if (Y0 + d_ < Y1) load_row(Y0 + 1 + d_, pre[d_]);
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  int cslot = 0;
+  const int Ho = 2 * Hs, Wo = 2 * Ws;
+  for (int Yb = Y0; Yb < Y1; Yb += DEPTH) {
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_) {
+      const int Y = Yb + d_;
+      if (Y < Y1) {                                           // workgroup-uniform
+        write_row(Y + 1, wslot, pre[d_]);
+        wslot = (wslot + 1) & 3;
+        __syncthreads();
+        if (Y + DEPTH < Y1) load_row(Y + 1 + DEPTH, pre[d_]);
+        const int rs0 = cslot, rs1 = (cslot + 1) & 3, rs2 = (cslot + 2) & 3;
+        cslot = (cslot + 1) & 3;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int X = x_l + u * XPT;
+          if (X < nx) {                                       // uniform over the 16 lanes of a pixel
+            float4 V[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              V[0][j] = ring4[(rs0 * Wc + X + j) * LPP + cq];
+              V[1][j] = ring4[(rs1 * Wc + X + j) * LPP + cq];
+              V[2][j] = ring4[(rs2 * Wc + X + j) * LPP + cq];
+            }
+            // packed fp32 math (v_pk_fma_f32: two FMAs per lane and instruction): channel pairs (0,1), (2,3);
+            // the per-class dot products pair the classes (2c, 2c+1) against a broadcast level
+            v2f part2[NV / 2];                 // [(cls pair) * 4 + py * 2 + px] -> {cls 2p, cls 2p + 1}
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i) part2[i] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+              for (int px = 0; px < 2; ++px) {
+                v2f alo = (v2f){0.f, 0.f}, ahi = (v2f){0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                  for (int dx = 0; dx < 3; ++dx) {
+                    const float4 t = V[(py + dy + 1) >> 1][(px + dx + 1) >> 1];
+                    alo = __builtin_elementwise_fma(wlo[dy * 3 + dx], (v2f){t.x, t.y}, alo);
+                    ahi = __builtin_elementwise_fma(whi[dy * 3 + dx], (v2f){t.z, t.w}, ahi);
+                  }
+                const v2f zero2 = (v2f){0.f, 0.f};
+                const v2f vlo = __builtin_elementwise_max(alo + blo, zero2);
+                const v2f vhi = __builtin_elementwise_max(ahi + bhi, zero2);
+                if (MODE == 0) {
+                  mn = fminf(mn, fminf(fminf(vlo.x, vlo.y), fminf(vhi.x, vhi.y)));
+                  mx = fmaxf(mx, fmaxf(fmaxf(vlo.x, vlo.y), fmaxf(vhi.x, vhi.y)));
+                } else {
+                  const float v4[4] = {vlo.x, vlo.y, vhi.x, vhi.y};
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float L = __fadd_rn(cdn::quant_code(v4[e], s2, z2), z2);
+#pragma unroll
+                    for (int cp = 0; cp < NCLS / 2; ++cp)
+                      part2[cp * 4 + py * 2 + px] =
+                          __builtin_elementwise_fma((v2f){L, L}, wq2[cp][e], part2[cp * 4 + py * 2 + px]);
+                  }
+                }
+              }
+            float part[NV];
+#pragma unroll
+            for (int cp = 0; cp < NCLS / 2; ++cp)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                part[(2 * cp) * 4 + i] = part2[cp * 4 + i].x;
+                part[(2 * cp + 1) * 4 + i] = part2[cp * 4 + i].y;
+              }
+            if (MODE == 1) {
+              // transpose-reduce over the pixel's 16 lanes: after the step with mask m a lane keeps the half
+              // of its values selected by (cq & m); lane cq ends with the total of value cq & (NV - 1)
+              float cur[NV];
+#pragma unroll
+              for (int i = 0; i < NV; ++i) cur[i] = part[i];
+              if (NV == 8) {                                  // 8 values on 16 lanes: fold the two halves first
+#pragma unroll
+                for (int i = 0; i < NV; ++i) cur[i] += __shfl_xor(cur[i], 8, 64);
+              }
+#pragma unroll
+              for (int hb = NV / 2; hb >= 1; hb >>= 1) {
+                const bool up = (cq & hb) != 0;
+#pragma unroll
+                for (int i = 0; i < hb; ++i) {
+                  const float send = up ? cur[i] : cur[i + hb];
+                  const float keep = up ? cur[i + hb] : cur[i];
+                  cur[i] = keep + __shfl_xor(send, hb, 64);
+                }
+              }
+              const int py = (my_idx >> 1) & 1, px = my_idx & 1;
+              if (my_cls < classes && cq < NV)
+                out[(((long)n * classes + my_cls) * Ho + 2 * Y + py) * Wo + 2 * (x0 + X) + px] =
+                    fmaf(cur[0], my_rinv, my_bias);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 0 && mm) {
+    __syncthreads();
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+                             reinterpret_cast<float *>(ring4));
+  }
+}
+
 }  // namespace
 
 extern "C" int cdn_codenet_dw3x3_nhwc_forward(
@@ -1113,6 +1326,75 @@ extern "C" int cdn_codenet_stem_forward(const float *img, int64_t N, int64_t H, 
   stem_kernel<24><<<grid, 256, 0, st>>>(img, w, bias, out, r_state ? ws.partials : nullptr, qu, (int)H,
                                         (int)W, Ho, Wo, stride, relu);
   return cdn::check_launch("codenet stem");
+}
+
+// Range pass and tail of a W4A8 detection head with <= 4 output channels: see head_small_kernel.
+static int launch_head_small(int mode, const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
+                             int64_t Ws, const float *w_dw, const float *b_dw, const void *y2_qstate,
+                             const signed char *w_codes, const float *w_scale, const float *bias,
+                             int64_t classes, float *out_nchw, float *r_min, float *r_max, void *r_state,
+                             int bits, double momentum, int running, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+  CDN_REQUIRE(y1 && y1_qstate && w_dw, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && N <= 65535, CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0, CDN_ERR_ARG, "y1 must be 16-byte aligned");
+  const int XS = (int)std::min<int64_t>(32, Ws), nxs = (int)cdn::ceil_div(Ws, XS);
+  static const int hs_wgs = getenv("CDN_HS_WGS") ? atoi(getenv("CDN_HS_WGS")) : 2;     // tuning knobs
+  static const int hs_minrows = getenv("CDN_HS_MINROWS") ? atoi(getenv("CDN_HS_MINROWS")) : 8;
+  long want = cdn::ceil_div((long)hs_wgs * cdn::kCUs, (long)N * nxs);
+  int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max<long>(1, Hs / hs_minrows)));
+  const int rps = (int)cdn::ceil_div(Hs, nstrips);
+  nstrips = (int)cdn::ceil_div(Hs, rps);
+  CDN_REQUIRE((long)nstrips * nxs * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
+  const size_t lds = (size_t)4 * (XS + 2) * 16 * 16;
+  hipStream_t st = cdn::as_stream(stream);
+  dim3 grid((unsigned)(nstrips * nxs), (unsigned)N);
+  const unsigned *q1 = static_cast<const unsigned *>(y1_qstate);
+  cdn::ProfScope ps(cdn::kProfDw, (int)Hs, st);
+  if (mode == 0) {
+    CDN_REQUIRE(r_min && r_max && r_state, CDN_ERR_ARG, "the range pass needs x_min, x_max and state");
+    cdn::AuxWs ws{nullptr, nullptr};
+    CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+    const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                          (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+    head_small_kernel<0, 2><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                    ws.partials, qu, (int)Hs, (int)Ws, 0, 0, nxs, XS, nstrips, rps);
+    return cdn::check_launch("codenet head range");
+  }
+  CDN_REQUIRE(y2_qstate && w_codes && w_scale && out_nchw, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(classes >= 1 && classes <= 4, CDN_ERR_UNSUPPORTED, "head_small handles 1..4 output channels");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_codes) & 3) == 0, CDN_ERR_ARG, "w_codes must be 4-byte aligned");
+  const int Cpad = (int)((C + 63) / 64 * 64);
+  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
+  const unsigned *q2 = static_cast<const unsigned *>(y2_qstate);
+  if (classes <= 2)
+    head_small_kernel<1, 2><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, bias, out_nchw,
+                                                    nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS,
+                                                    nstrips, rps);
+  else
+    head_small_kernel<1, 4><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, bias, out_nchw,
+                                                    nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS,
+                                                    nstrips, rps);
+  return cdn::check_launch("codenet head tail (small)");
+}
+
+extern "C" int cdn_codenet_head_range_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
+                                              int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
+                                              float *r_min, float *r_max, void *r_state, int bits, double momentum,
+                                              int running, void *workspace, size_t workspace_bytes, void *stream) {
+  return launch_head_small(0, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                           r_min, r_max, r_state, bits, momentum, running, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cdn_codenet_head_tail_small_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
+                                                   int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
+                                                   const void *y2_qstate, const signed char *w_codes,
+                                                   const float *w_scale, const float *bias, int64_t classes,
+                                                   float *out_nchw, void *stream) {
+  return launch_head_small(1, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate, w_codes, w_scale, bias, classes,
+                           out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0, nullptr, 0, stream);
 }
 
 // The tail of a W4A8 detection head in one kernel: see head_tail_kernel.

@@ -301,9 +301,12 @@ class FusedHeads:
     by addressing, so the up-sampled 64-channel tensor is never built.  Same parameters and QuantAct
     buffers (updated in place) as calling the head modules on the unpacked tensor."""
 
-    def __init__(self, heads, int8_pointwise=True, fuse_tail=False):
+    def __init__(self, heads, int8_pointwise=True, fuse_tail=False, small_tail=True):
         self.heads = dict(heads)
         self.int8_pointwise = int8_pointwise
+        # W4A8 heads with <= 4 output channels (wh, reg): range pass + depthwise -> quantise -> 1x1 conv as exact
+        # integer dot products on the VALU (cdn_codenet_head_range_forward / _head_tail_small_forward)
+        self.small_tail = small_tail and int8_pointwise
         # W4A8 option: range-only depthwise pass, then depthwise + QuantAct + last 1x1 conv in ONE kernel
         # (cdn_codenet_head_tail_forward): the 268 MB depthwise output is never stored.  Parity-tested, but
         # measured slower at batch 64 (3 heads 0.75 ms vs 0.66 ms: the recompute is VALU-bound), so off.
@@ -409,7 +412,11 @@ class FusedHeads:
                         and layers[1]["act"] is not None and layers[1]["ep"] is None
                         and layers[2]["i8"] is not None and layers[2]["w"].shape[0] <= 32
                         and Ws % 8 == 0 and Ws <= 128 and C % 4 == 0)
-                if not fuse and name not in B["o"]:
+                small = (self.small_tail and not fuse and len(layers) == 3 and layers[0]["act"] is not None
+                         and layers[1]["act"] is not None and layers[1]["ep"] is None and layers[1]["relu"]
+                         and layers[2]["i8"] is not None and layers[2]["w"].shape[0] <= 4 and C == 64
+                         and layers[2]["act"] is None and not layers[2]["relu"])
+                if not fuse and not small and name not in B["o"]:
                     B["o"][name] = torch.empty(4 * M, self._out_channels(mod), device=r.device)
                     if B["y2"] is None and len(layers) == 3:
                         B["y2"] = torch.empty(4 * M, C, device=r.device)
@@ -425,6 +432,26 @@ class FusedHeads:
                 pw(r, r_qstate, M, l1, B["y1"])
                 q1 = l1["act"]._device_state(r.device).data_ptr() if l1["act"] is not None else None
                 ep = l2["ep"] or (None, None)
+                if small:
+                    # W4A8 heads with <= 4 outputs (wh, reg): streaming range pass, then depthwise -> quantise ->
+                    # exact integer dot products on the VALU -> NCHW; the 64-channel full-resolution tensor is
+                    # never stored (bit-identical to the unfused schedule)
+                    rec = ops._tic("head_range", (C, 2 * Hs, 2 * Ws))
+                    rc = lib.cdn_codenet_head_range_forward(
+                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]),
+                        *act_args(l2["act"]), ws_ptr, ws_bytes, stream)
+                    ops._toc(rec)
+                    N_.check(rc, "cdn_codenet_head_range_forward")
+                    q2 = l2["act"]._device_state(r.device).data_ptr()
+                    i8 = l3["i8"]
+                    rec = ops._tic("head_tail_small", (C, l3["w"].shape[0], 4 * M))
+                    rc = lib.cdn_codenet_head_tail_small_forward(
+                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]),
+                        ptr(i8[1]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), stream)
+                    ops._toc(rec)
+                    N_.check(rc, "cdn_codenet_head_tail_small_forward")
+                    outs[name] = B["out"][name]
+                    continue
                 if fuse:
                     # W4A8: range-only depthwise pass, then depthwise -> quantise -> int8 1x1 -> NCHW in one
                     # kernel: the 64-channel full-resolution tensor is never stored

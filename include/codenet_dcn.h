@@ -306,6 +306,24 @@ int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qstate, int64_
                                   const float *w, const float *bias, int64_t classes, float *out_nchw,
                                   void *stream);
 
+/* The same tail for heads with <= 4 output channels (wh, reg) without the matrix cores, and its range pass --
+ * row-streaming kernels, C == 64 (head_conv of every reference configuration):
+ *   cdn_codenet_head_range_forward       tracks the QuantAct after the depthwise conv (r_min / r_max / r_state)
+ *                                        from ReLU(dw3x3(up2(fq(y1))) + b_dw) without storing it;
+ *   cdn_codenet_head_tail_small_forward  recomputes those values, quantises them with y2_qstate and applies the
+ *                                        1x1 conv as exact integer dot products on the VALU: bit-identical to
+ *                                        cdn_codenet_dw3x3_nhwc_forward (up = 1) + the int8 pointwise + unpack.
+ *   w_codes [classes][64] int8 (4-byte aligned rows), w_scale [classes], bias [classes] or NULL,
+ *   out_nchw [N][classes][2Hs][2Ws]. */
+int cdn_codenet_head_range_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
+                                   int64_t Ws, const float *w_dw, const float *b_dw, float *r_min, float *r_max,
+                                   void *r_state, int bits, double momentum, int running, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+int cdn_codenet_head_tail_small_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
+                                        int64_t Ws, const float *w_dw, const float *b_dw, const void *y2_qstate,
+                                        const signed char *w_codes, const float *w_scale, const float *bias,
+                                        int64_t classes, float *out_nchw, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * The backbone's remaining layer types (lib/models/networks/
  * shufflenetv2_dcn.py:57-114,205-240; W4A8: QuantBaseNode quant_modules.py:809-907, layer0 / layer4

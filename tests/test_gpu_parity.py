@@ -585,6 +585,41 @@ def test_fused_heads_match_modules(quantized, fuse_tail, planes, res):
                 assert (aa.x_max - bb.x_max).abs().item() < 1e-4 * (1 + aa.x_max.abs().item())
 
 
+@pytest.mark.parametrize("res,batch", [(4, 2), (9, 3), (16, 1)])
+def test_head_small_tail_is_bit_identical_to_unfused_schedule(res, batch):
+    """wh / reg heads (2 outputs, 64 channels): streaming range pass + VALU tail vs the unfused schedule
+    (up-sampling depthwise -> int8 pointwise -> unpack): identical outputs and QuantAct buffers, 4 forwards
+    (the first ones run with codes too wide for int8, where both are fp32-rounded)."""
+    import copy
+    from codenet_amd import pipeline
+    planes = [64, 32, 16, 64]
+    net = pipeline.build_hot_path(quantized=True, planes=planes, seed=5).cuda()
+    g = torch.Generator().manual_seed(res)
+    heads = _head_modules(64, {"wh": 2, "reg": 2, "off4": 4}, g, True)
+    ha = {k: copy.deepcopy(v).cuda() for k, v in heads.items()}
+    hb = {k: copy.deepcopy(v).cuda() for k, v in heads.items()}
+    path = pipeline.FusedHotPath(net.deconv_layers)
+    fa = pipeline.FusedHeads(ha, small_tail=True)
+    fb = pipeline.FusedHeads(hb, small_tail=False)
+    exact = 0
+    for it in range(4):
+        x = (torch.randn(batch, planes[0], res, res, generator=g).abs() * (1.0 + 0.2 * it)).cuda()
+        r, rq, shape = path.forward_nhwc(x)
+        oa = {k: v.clone() for k, v in fa(r, rq, shape).items()}
+        ob = fb(r, rq, shape)
+        for k in oa:
+            wide = hb[k].quant_act3[1]._device_state(x.device)[6].item() != 0
+            if wide:       # f32-MFMA branch of the pointwise kernel on one side: fp32 rounding of the same sums
+                assert (oa[k] - ob[k]).abs().max().item() < 1e-4 * (1 + ob[k].abs().max().item())
+            else:
+                assert torch.equal(oa[k], ob[k]), (k, it, (oa[k] - ob[k]).abs().max().item())
+                exact += 1
+    assert exact >= 3
+    for k in ha:
+        for aa, bb in ((ha[k].quant_act1[1], hb[k].quant_act1[1]), (ha[k].quant_act3[1], hb[k].quant_act3[1])):
+            assert torch.equal(aa.x_min, bb.x_min) and torch.equal(aa.x_max, bb.x_max)
+
+
 def test_fused_heads_match_reference_golden():
     """The head kernels against the reference's own QuantDepthwiseNode outputs (tests/golden/
     head_w4a8.npz): the golden input is treated as an already materialised full-resolution

@@ -34,7 +34,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     total = e0.elapsed_time(e1) / a.steps
-    with ops.KernelTimer({"head_pw", "head_dw"}) as kt:
+    with ops.KernelTimer({"head_pw", "head_dw", "head_range", "head_tail_small", "head_tail"}) as kt:
         for _ in range(a.steps):
             heads(r, rq, shape)
     torch.cuda.synchronize()
