@@ -891,18 +891,24 @@ __global__ void __launch_bounds__(256)
 head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1, const float *__restrict__ wdw,
                   const float *__restrict__ bdw, const unsigned *__restrict__ q2,
                   const signed char *__restrict__ Wq, const float *__restrict__ wscale,
-                  const float *__restrict__ bias, float *__restrict__ out, float2 *mm, cdn::QUpdate qu,
-                  int Hs, int Ws, int classes, int Cpad, int nxs, int XS, int nstrips, int rps) {
-  extern __shared__ float4 ring4[];          // [4][XS + 2][16]
+                  const int *__restrict__ wsum, const float *__restrict__ bias, float *__restrict__ out,
+                  float2 *mm, cdn::QUpdate qu, int Hs, int Ws, int classes, int Cpad, int nxs, int XS,
+                  int nstrips, int rps, int only_if_wide) {
+  // MODE 2 (up to 32 classes on the int8 matrix cores) handles codes that fit the nibble split; a batch with
+  // wider codes (state[6], the first calls of a fresh running range) is left to the MODE 1 launch behind it
+  if (MODE == 2 && q2[6]) return;
+  if (MODE == 1 && only_if_wide && !q2[6]) return;
+  extern __shared__ float4 ring4[];          // [4][XS + 2][16]  (MODE 2: + A0 | A1 | B0 | B1 byte planes)
   constexpr int LPP = 16, XPT = 16, MAXL = 3, DEPTH = 2, NV = 4 * NCLS, C = 64;   // ring of 4 rows
   const int xs = blockIdx.x % nxs, strip = blockIdx.x / nxs, n = blockIdx.y;
   const int Y0 = strip * rps, Y1 = min(Y0 + rps, Hs);
   const int x0 = xs * XS, nx = min(XS, Ws - x0), Wc = XS + 2, ix0 = x0 - 1;
   const int tid = threadIdx.x, cq = tid & 15, x_l = tid >> 4, cb = cq * 4;
+  const int lane = tid & 63, wave = tid >> 6;
   const float s1 = reinterpret_cast<const float *>(q1)[2], z1 = reinterpret_cast<const float *>(q1)[3];
   const float r1 = __fdiv_rn(1.0f, s1);
   float s2 = 1.f, z2 = 0.f;
-  if (MODE == 1) {
+  if (MODE != 0) {
     s2 = reinterpret_cast<const float *>(q2)[2];
     z2 = reinterpret_cast<const float *>(q2)[3];
   }
@@ -914,14 +920,16 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   }
   blo = (v2f){bdw ? bdw[cb + 0] : 0.0f, bdw ? bdw[cb + 1] : 0.0f};
   bhi = (v2f){bdw ? bdw[cb + 2] : 0.0f, bdw ? bdw[cb + 3] : 0.0f};
-  float wq[NCLS][4];                          // this lane's 4 channels of every class's weight codes
-  v2f wq2[NCLS / 2][4];                       // the same, classes paired: {qw[2p][e], qw[2p+1][e]}
-  float my_rinv = 0.f, my_bias = 0.f;
+  // MODE 1: this lane's 4 channels of NCLS classes' weight codes, classes paired {qw[2p][e], qw[2p+1][e]};
+  // lane cq stores value (cq & (NV-1)) = class (..>>2), pixel (py, px) of the class group being reduced
+  v2f wq2[NCLS / 2][4];
   const int my_idx = cq & (NV - 1), my_cls = my_idx >> 2;
-  if (MODE == 1) {
+  const int ngroups = MODE == 1 ? (classes + NCLS - 1) / NCLS : 0;
+  auto load_group = [&](int g0) {
+    float wq[NCLS][4];
 #pragma unroll
     for (int c_ = 0; c_ < NCLS; ++c_) {
-      const int word = c_ < classes ? *reinterpret_cast<const int *>(Wq + (long)c_ * Cpad + cb) : 0;
+      const int word = g0 + c_ < classes ? *reinterpret_cast<const int *>(Wq + (long)(g0 + c_) * Cpad + cb) : 0;
       wq[c_][0] = (float)((word << 24) >> 24);
       wq[c_][1] = (float)((word << 16) >> 24);
       wq[c_][2] = (float)((word << 8) >> 24);
@@ -931,9 +939,38 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
     for (int cp = 0; cp < NCLS / 2; ++cp)
 #pragma unroll
       for (int e = 0; e < 4; ++e) wq2[cp][e] = (v2f){wq[2 * cp][e], wq[2 * cp + 1][e]};
-    if (my_cls < classes) {
-      my_rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[my_cls]));
-      my_bias = bias ? bias[my_cls] : 0.0f;
+  };
+  if (MODE == 1) load_group(0);
+  float my_rinv = 0.f, my_bias = 0.f;                           // single class group: this lane's class
+  if (MODE == 1 && ngroups == 1 && my_cls < classes) {
+    my_rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[my_cls]));
+    my_bias = bias ? bias[my_cls] : 0.0f;
+  }
+  // MODE 2: byte planes behind the ring; rows of one 32-channel k-step are kHtLD = 48 bytes (pwi8's layout)
+  const int nrows = 4 * XS;                                     // output pixels of a stored row: 2 x 2 XS
+  unsigned char *A0 = reinterpret_cast<unsigned char *>(ring4 + 4 * Wc * LPP);
+  unsigned char *A1 = A0 + (size_t)2 * nrows * kHtLD;
+  unsigned char *B0 = A1 + (size_t)2 * nrows * kHtLD;
+  unsigned char *B1 = B0 + (size_t)2 * 32 * kHtLD;
+  const int ioff = (int)z2 + (2048 - 128) - 0x4B400000;
+  float e_rinv = 0.f, e_bias = 0.f;                             // MODE 2 epilogue: this lane's class
+  int e_t128 = 0;
+  if (MODE == 2) {
+    for (int q = tid; q < 2 * 32 * 2; q += 256) {               // k-step x class row x 16-byte piece
+      const int ks = q >> 6, cls = (q >> 1) & 31, part = (q & 1) * 16;
+      i32x4 bq = (i32x4){0, 0, 0, 0};
+      if (cls < classes) bq = *reinterpret_cast<const i32x4 *>(Wq + (long)cls * Cpad + ks * 32 + part);
+      i32x4 s16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)bq[e] << 4) & 0xF0F0F0F0u);
+      *reinterpret_cast<i32x4 *>(B0 + (ks * 32 + cls) * kHtLD + part) = bq;
+      *reinterpret_cast<i32x4 *>(B1 + (ks * 32 + cls) * kHtLD + part) = s16;
+    }
+    const int cls = lane & 31;
+    if (cls < classes) {
+      e_rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[cls]));
+      e_bias = bias ? bias[cls] : 0.0f;
+      e_t128 = 128 * wsum[cls];
     }
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -980,6 +1017,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   float mn = INFINITY, mx = -INFINITY;
   int cslot = 0;
   const int Ho = 2 * Hs, Wo = 2 * Ws;
+  constexpr int NPASS = MODE == 2 ? 1 : 2;                      // MODE 2 runs on 16-column strips
   for (int Yb = Y0; Yb < Y1; Yb += DEPTH) {
 #pragma unroll
     for (int d_ = 0; d_ < DEPTH; ++d_) {
@@ -992,7 +1030,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
         const int rs0 = cslot, rs1 = (cslot + 1) & 3, rs2 = (cslot + 2) & 3;
         cslot = (cslot + 1) & 3;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NPASS; ++u) {
           const int X = x_l + u * XPT;
           if (X < nx) {                                       // uniform over the 16 lanes of a pixel
             float4 V[3][3];
@@ -1002,11 +1040,8 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
               V[1][j] = ring4[(rs1 * Wc + X + j) * LPP + cq];
               V[2][j] = ring4[(rs2 * Wc + X + j) * LPP + cq];
             }
-            // packed fp32 math (v_pk_fma_f32: two FMAs per lane and instruction): channel pairs (0,1), (2,3);
-            // the per-class dot products pair the classes (2c, 2c+1) against a broadcast level
-            v2f part2[NV / 2];                 // [(cls pair) * 4 + py * 2 + px] -> {cls 2p, cls 2p + 1}
-#pragma unroll
-            for (int i = 0; i < NV / 2; ++i) part2[i] = (v2f){0.f, 0.f};
+            // packed fp32 math (v_pk_fma_f32: two FMAs per lane and instruction): channel pairs (0,1), (2,3)
+            float Lv[4][4];                    // MODE 1: integer levels [py * 2 + px][channel]
 #pragma unroll
             for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -1023,53 +1058,112 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
                 const v2f zero2 = (v2f){0.f, 0.f};
                 const v2f vlo = __builtin_elementwise_max(alo + blo, zero2);
                 const v2f vhi = __builtin_elementwise_max(ahi + bhi, zero2);
+                const float v4[4] = {vlo.x, vlo.y, vhi.x, vhi.y};
                 if (MODE == 0) {
-                  mn = fminf(mn, fminf(fminf(vlo.x, vlo.y), fminf(vhi.x, vhi.y)));
-                  mx = fmaxf(mx, fmaxf(fmaxf(vlo.x, vlo.y), fmaxf(vhi.x, vhi.y)));
+                  mn = fminf(mn, fminf(fminf(v4[0], v4[1]), fminf(v4[2], v4[3])));
+                  mx = fmaxf(mx, fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])));
+                } else if (MODE == 1) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) Lv[py * 2 + px][e] = __fadd_rn(cdn::quant_code(v4[e], s2, z2), z2);
                 } else {
-                  const float v4[4] = {vlo.x, vlo.y, vhi.x, vhi.y};
+                  // codes as in pwi8_kernel: u = rint(s*v - z) + z - 128 + 2048, nibble split, k = channel
+                  unsigned uc[4];
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
-                    const float L = __fadd_rn(cdn::quant_code(v4[e], s2, z2), z2);
-#pragma unroll
-                    for (int cp = 0; cp < NCLS / 2; ++cp)
-                      part2[cp * 4 + py * 2 + px] =
-                          __builtin_elementwise_fma((v2f){L, L}, wq2[cp][e], part2[cp * 4 + py * 2 + px]);
+                    const float yv = __fadd_rn(__fsub_rn(__fmul_rn(s2, v4[e]), z2), 12582912.0f);
+                    int uu = (int)__float_as_uint(yv) + ioff;
+                    uc[e] = (unsigned)min(max(uu, 8), 4087);
                   }
+                  const unsigned p01 = uc[0] | (uc[1] << 16), p23 = uc[2] | (uc[3] << 16);
+                  const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu;
+                  const unsigned hi = __builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u;
+                  const int row = py * 2 * XS + 2 * X + px;
+                  const int off = ((cq >> 3) * nrows + row) * kHtLD + (cq & 7) * 4;
+                  *reinterpret_cast<unsigned *>(A0 + off) = lo;
+                  *reinterpret_cast<unsigned *>(A1 + off) = hi;
                 }
-              }
-            float part[NV];
-#pragma unroll
-            for (int cp = 0; cp < NCLS / 2; ++cp)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                part[(2 * cp) * 4 + i] = part2[cp * 4 + i].x;
-                part[(2 * cp + 1) * 4 + i] = part2[cp * 4 + i].y;
               }
             if (MODE == 1) {
-              // transpose-reduce over the pixel's 16 lanes: after the step with mask m a lane keeps the half
-              // of its values selected by (cq & m); lane cq ends with the total of value cq & (NV - 1)
-              float cur[NV];
+              for (int g = 0; g < ngroups; ++g) {
+                if (ngroups > 1) load_group(g * NCLS);
+                v2f part2[NV / 2];             // [(cls pair) * 4 + py * 2 + px] -> {cls 2p, cls 2p + 1}
 #pragma unroll
-              for (int i = 0; i < NV; ++i) cur[i] = part[i];
-              if (NV == 8) {                                  // 8 values on 16 lanes: fold the two halves first
+                for (int i = 0; i < NV / 2; ++i) part2[i] = (v2f){0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < NV; ++i) cur[i] += __shfl_xor(cur[i], 8, 64);
-              }
+                for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
-              for (int hb = NV / 2; hb >= 1; hb >>= 1) {
-                const bool up = (cq & hb) != 0;
+                  for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < hb; ++i) {
-                  const float send = up ? cur[i] : cur[i + hb];
-                  const float keep = up ? cur[i + hb] : cur[i];
-                  cur[i] = keep + __shfl_xor(send, hb, 64);
+                    for (int cp = 0; cp < NCLS / 2; ++cp)
+                      part2[cp * 4 + pp] = __builtin_elementwise_fma((v2f){Lv[pp][e], Lv[pp][e]}, wq2[cp][e],
+                                                                     part2[cp * 4 + pp]);
+                // transpose-reduce over the pixel's 16 lanes: after the step with mask m a lane keeps the half
+                // of its values selected by (cq & m); lane cq ends with the total of value cq & (NV - 1)
+                float cur[NV];
+#pragma unroll
+                for (int cp = 0; cp < NCLS / 2; ++cp)
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    cur[(2 * cp) * 4 + i] = part2[cp * 4 + i].x;
+                    cur[(2 * cp + 1) * 4 + i] = part2[cp * 4 + i].y;
+                  }
+                if (NV == 8) {                                // 8 values on 16 lanes: fold the two halves first
+#pragma unroll
+                  for (int i = 0; i < NV; ++i) cur[i] += __shfl_xor(cur[i], 8, 64);
+                }
+#pragma unroll
+                for (int hb = NV / 2; hb >= 1; hb >>= 1) {
+                  const bool up = (cq & hb) != 0;
+#pragma unroll
+                  for (int i = 0; i < hb; ++i) {
+                    const float send = up ? cur[i] : cur[i + hb];
+                    const float keep = up ? cur[i + hb] : cur[i];
+                    cur[i] = keep + __shfl_xor(send, hb, 64);
+                  }
+                }
+                const int cls = g * NCLS + my_cls, py = (my_idx >> 1) & 1, px = my_idx & 1;
+                if (cls < classes && cq < NV) {
+                  float rinv = my_rinv, bv = my_bias;
+                  if (ngroups > 1) {
+                    rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[cls]));
+                    bv = bias ? bias[cls] : 0.0f;
+                  }
+                  out[(((long)n * classes + cls) * Ho + 2 * Y + py) * Wo + 2 * (x0 + X) + px] =
+                      fmaf(cur[0], rinv, bv);
                 }
               }
-              const int py = (my_idx >> 1) & 1, px = my_idx & 1;
-              if (my_cls < classes && cq < NV)
-                out[(((long)n * classes + my_cls) * Ho + 2 * Y + py) * Wo + 2 * (x0 + X) + px] =
-                    fmaf(cur[0], my_rinv, my_bias);
+            }
+          }
+        }
+        if (MODE == 2) {
+          __syncthreads();                                    // the codes of this stored row are parked
+          if (wave < 2) {                                     // row block = output row py = wave
+            const int fo = (lane & 31) * kHtLD + (lane >> 5) * 16;
+            i32x16 acc = (i32x16){0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const i32x4 a0 = *reinterpret_cast<const i32x4 *>(A0 + (ks * nrows + wave * 2 * XS) * kHtLD + fo);
+              const i32x4 a1 = *reinterpret_cast<const i32x4 *>(A1 + (ks * nrows + wave * 2 * XS) * kHtLD + fo);
+              const i32x4 b0 = *reinterpret_cast<const i32x4 *>(B0 + (ks * 32) * kHtLD + fo);
+              const i32x4 b1 = *reinterpret_cast<const i32x4 *>(B1 + (ks * 32) * kHtLD + fo);
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
+            }
+            const int cls = lane & 31;
+            if (cls < classes) {
+              float *orow = out + (((long)n * classes + cls) * Ho + 2 * Y + wave) * Wo + 2 * x0;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int px0 = 8 * g + 4 * (lane >> 5);
+                if (px0 < 2 * nx) {
+                  float4 o;
+                  o.x = fmaf((float)(acc[4 * g + 0] + e_t128), e_rinv, e_bias);
+                  o.y = fmaf((float)(acc[4 * g + 1] + e_t128), e_rinv, e_bias);
+                  o.z = fmaf((float)(acc[4 * g + 2] + e_t128), e_rinv, e_bias);
+                  o.w = fmaf((float)(acc[4 * g + 3] + e_t128), e_rinv, e_bias);
+                  *reinterpret_cast<float4 *>(orow + px0) = o;
+                }
+              }
             }
           }
         }
@@ -1328,29 +1422,37 @@ extern "C" int cdn_codenet_stem_forward(const float *img, int64_t N, int64_t H, 
   return cdn::check_launch("codenet stem");
 }
 
-// Range pass and tail of a W4A8 detection head with <= 4 output channels: see head_small_kernel.
+// Range pass and tail of a W4A8 detection head: see head_small_kernel.
 static int launch_head_small(int mode, const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
                              int64_t Ws, const float *w_dw, const float *b_dw, const void *y2_qstate,
-                             const signed char *w_codes, const float *w_scale, const float *bias,
-                             int64_t classes, float *out_nchw, float *r_min, float *r_max, void *r_state,
-                             int bits, double momentum, int running, void *workspace, size_t workspace_bytes,
-                             void *stream) {
+                             const signed char *w_codes, const float *w_scale, const int *w_colsum,
+                             const float *bias, int64_t classes, float *out_nchw, float *r_min, float *r_max,
+                             void *r_state, int bits, double momentum, int running, void *workspace,
+                             size_t workspace_bytes, void *stream) {
   CDN_REQUIRE(y1 && y1_qstate && w_dw, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && N <= 65535, CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0, CDN_ERR_ARG, "y1 must be 16-byte aligned");
-  const int XS = (int)std::min<int64_t>(32, Ws), nxs = (int)cdn::ceil_div(Ws, XS);
   static const int hs_wgs = getenv("CDN_HS_WGS") ? atoi(getenv("CDN_HS_WGS")) : 2;     // tuning knobs
   static const int hs_minrows = getenv("CDN_HS_MINROWS") ? atoi(getenv("CDN_HS_MINROWS")) : 8;
-  long want = cdn::ceil_div((long)hs_wgs * cdn::kCUs, (long)N * nxs);
-  int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max<long>(1, Hs / hs_minrows)));
-  const int rps = (int)cdn::ceil_div(Hs, nstrips);
-  nstrips = (int)cdn::ceil_div(Hs, rps);
-  CDN_REQUIRE((long)nstrips * nxs * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
-  const size_t lds = (size_t)4 * (XS + 2) * 16 * 16;
   hipStream_t st = cdn::as_stream(stream);
-  dim3 grid((unsigned)(nstrips * nxs), (unsigned)N);
   const unsigned *q1 = static_cast<const unsigned *>(y1_qstate);
+  // geometry for strips of XS stored columns
+  auto geom = [&](int XS, int *nxs, int *nstrips, int *rps, size_t *lds, dim3 *grid) {
+    *nxs = (int)cdn::ceil_div(Ws, XS);
+    long want = cdn::ceil_div((long)hs_wgs * cdn::kCUs, (long)N * *nxs);
+    *nstrips = (int)std::max<long>(1, std::min<long>(want, std::max<long>(1, Hs / hs_minrows)));
+    *rps = (int)cdn::ceil_div(Hs, *nstrips);
+    *nstrips = (int)cdn::ceil_div(Hs, *rps);
+    *lds = (size_t)4 * (XS + 2) * 16 * 16;
+    *grid = dim3((unsigned)(*nstrips * *nxs), (unsigned)N);
+    return (long)*nstrips * *nxs * N <= kMaxPartials;
+  };
+  int nxs, nstrips, rps;
+  size_t lds;
+  dim3 grid;
+  const int XS = (int)std::min<int64_t>(32, Ws);
+  CDN_REQUIRE(geom(XS, &nxs, &nstrips, &rps, &lds, &grid), CDN_ERR_UNSUPPORTED, "too many workgroups");
   cdn::ProfScope ps(cdn::kProfDw, (int)Hs, st);
   if (mode == 0) {
     CDN_REQUIRE(r_min && r_max && r_state, CDN_ERR_ARG, "the range pass needs x_min, x_max and state");
@@ -1360,41 +1462,70 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
     const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
                           (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
     head_small_kernel<0, 2><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                    ws.partials, qu, (int)Hs, (int)Ws, 0, 0, nxs, XS, nstrips, rps);
+                                                    nullptr, ws.partials, qu, (int)Hs, (int)Ws, 0, 0, nxs, XS, nstrips,
+                                                    rps, 0);
     return cdn::check_launch("codenet head range");
   }
   CDN_REQUIRE(y2_qstate && w_codes && w_scale && out_nchw, CDN_ERR_ARG, "null pointer");
-  CDN_REQUIRE(classes >= 1 && classes <= 4, CDN_ERR_UNSUPPORTED, "head_small handles 1..4 output channels");
-  CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_codes) & 3) == 0, CDN_ERR_ARG, "w_codes must be 4-byte aligned");
+  CDN_REQUIRE(classes >= 1 && classes <= 32, CDN_ERR_UNSUPPORTED, "head tail handles 1..32 output channels");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_codes) & 15) == 0, CDN_ERR_ARG, "w_codes must be 16-byte aligned");
   const int Cpad = (int)((C + 63) / 64 * 64);
   const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
   const unsigned *q2 = static_cast<const unsigned *>(y2_qstate);
-  if (classes <= 2)
-    head_small_kernel<1, 2><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, bias, out_nchw,
+  // matrix cores whenever the shape allows (measured at 2 classes: 64 us vs 74 us for the VALU form, which
+  // remains for other widths and as the wide-code fallback)
+  static const bool hs_no_mfma = getenv("CDN_HS_NO_MFMA") != nullptr;   // tuning knob
+  const bool mfma_ok = !hs_no_mfma && w_colsum && (Ws & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(out_nchw) & 15) == 0;
+  if (mfma_ok) {
+  } else if (classes <= 2) {
+    head_small_kernel<1, 2><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias, out_nchw,
                                                     nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS,
-                                                    nstrips, rps);
-  else
-    head_small_kernel<1, 4><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, bias, out_nchw,
+                                                    nstrips, rps, 0);
+    return cdn::check_launch("codenet head tail (small)");
+  }
+  if (classes <= 4 && !mfma_ok) {
+    head_small_kernel<1, 4><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias, out_nchw,
                                                     nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS,
-                                                    nstrips, rps);
-  return cdn::check_launch("codenet head tail (small)");
+                                                    nstrips, rps, 0);
+    return cdn::check_launch("codenet head tail (small)");
+  }
+  // int8 matrix cores on 16-column strips; a batch whose codes are too wide for the nibble
+  // split (state[6]) is computed by the VALU kernel launched behind it (4 classes at a time)
+  CDN_REQUIRE(mfma_ok, CDN_ERR_UNSUPPORTED,
+              "more than 4 classes need w_colsum, Ws %% 16 == 0 and a 16-byte aligned output");
+  {
+    int nxs2, nstrips2, rps2;
+    size_t lds2;
+    dim3 grid2;
+    CDN_REQUIRE(geom(16, &nxs2, &nstrips2, &rps2, &lds2, &grid2), CDN_ERR_UNSUPPORTED, "too many workgroups");
+    lds2 += (size_t)2 * 2 * (4 * 16) * kHtLD + (size_t)2 * 2 * 32 * kHtLD;
+    head_small_kernel<2, 2><<<grid2, 256, lds2, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, w_colsum, bias,
+                                                      out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
+                                                      nxs2, 16, nstrips2, rps2, 0);
+  }
+  head_small_kernel<1, 4><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias, out_nchw,
+                                                  nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS, nstrips,
+                                                  rps, 1);
+  return cdn::check_launch("codenet head tail (matrix cores)");
 }
 
 extern "C" int cdn_codenet_head_range_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
                                               int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
                                               float *r_min, float *r_max, void *r_state, int bits, double momentum,
                                               int running, void *workspace, size_t workspace_bytes, void *stream) {
-  return launch_head_small(0, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
-                           r_min, r_max, r_state, bits, momentum, running, workspace, workspace_bytes, stream);
+  return launch_head_small(0, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           0, nullptr, r_min, r_max, r_state, bits, momentum, running, workspace, workspace_bytes,
+                           stream);
 }
 
 extern "C" int cdn_codenet_head_tail_small_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
                                                    int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
                                                    const void *y2_qstate, const signed char *w_codes,
-                                                   const float *w_scale, const float *bias, int64_t classes,
-                                                   float *out_nchw, void *stream) {
-  return launch_head_small(1, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate, w_codes, w_scale, bias, classes,
-                           out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0, nullptr, 0, stream);
+                                                   const float *w_scale, const int *w_colsum, const float *bias,
+                                                   int64_t classes, float *out_nchw, void *stream) {
+  return launch_head_small(1, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate, w_codes, w_scale, w_colsum, bias,
+                           classes, out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0, nullptr, 0, stream);
 }
 
 // The tail of a W4A8 detection head in one kernel: see head_tail_kernel.

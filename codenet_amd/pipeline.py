@@ -414,7 +414,8 @@ class FusedHeads:
                         and Ws % 8 == 0 and Ws <= 128 and C % 4 == 0)
                 small = (self.small_tail and not fuse and len(layers) == 3 and layers[0]["act"] is not None
                          and layers[1]["act"] is not None and layers[1]["ep"] is None and layers[1]["relu"]
-                         and layers[2]["i8"] is not None and layers[2]["w"].shape[0] <= 4 and C == 64
+                         and layers[2]["i8"] is not None and C == 64
+                         and (layers[2]["w"].shape[0] <= 4 or (layers[2]["w"].shape[0] <= 32 and Ws % 16 == 0))
                          and layers[2]["act"] is None and not layers[2]["relu"])
                 if not fuse and not small and name not in B["o"]:
                     B["o"][name] = torch.empty(4 * M, self._out_channels(mod), device=r.device)
@@ -433,9 +434,9 @@ class FusedHeads:
                 q1 = l1["act"]._device_state(r.device).data_ptr() if l1["act"] is not None else None
                 ep = l2["ep"] or (None, None)
                 if small:
-                    # W4A8 heads with <= 4 outputs (wh, reg): streaming range pass, then depthwise -> quantise ->
-                    # exact integer dot products on the VALU -> NCHW; the 64-channel full-resolution tensor is
-                    # never stored (bit-identical to the unfused schedule)
+                    # W4A8 heads: streaming range pass, then depthwise -> quantise -> 1x1 conv (<= 4 outputs: exact
+                    # integer dot products on the VALU; up to 32: int8 matrix cores) -> NCHW; the 64-channel
+                    # full-resolution tensor is never stored (bit-identical to the unfused schedule)
                     rec = ops._tic("head_range", (C, 2 * Hs, 2 * Ws))
                     rc = lib.cdn_codenet_head_range_forward(
                         B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]),
@@ -447,7 +448,8 @@ class FusedHeads:
                     rec = ops._tic("head_tail_small", (C, l3["w"].shape[0], 4 * M))
                     rc = lib.cdn_codenet_head_tail_small_forward(
                         B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]),
-                        ptr(i8[1]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), stream)
+                        ptr(i8[1]), ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(),
+                        stream)
                     ops._toc(rec)
                     N_.check(rc, "cdn_codenet_head_tail_small_forward")
                     outs[name] = B["out"][name]

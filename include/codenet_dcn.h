@@ -306,23 +306,27 @@ int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qstate, int64_
                                   const float *w, const float *bias, int64_t classes, float *out_nchw,
                                   void *stream);
 
-/* The same tail for heads with <= 4 output channels (wh, reg) without the matrix cores, and its range pass --
- * row-streaming kernels, C == 64 (head_conv of every reference configuration):
+/* The same tail as ROW-STREAMING kernels (every stored row staged and fake-quantised once), and its range
+ * pass; C == 64 (head_conv of every reference configuration):
  *   cdn_codenet_head_range_forward       tracks the QuantAct after the depthwise conv (r_min / r_max / r_state)
  *                                        from ReLU(dw3x3(up2(fq(y1))) + b_dw) without storing it;
  *   cdn_codenet_head_tail_small_forward  recomputes those values, quantises them with y2_qstate and applies the
- *                                        1x1 conv as exact integer dot products on the VALU: bit-identical to
- *                                        cdn_codenet_dw3x3_nhwc_forward (up = 1) + the int8 pointwise + unpack.
- *   w_codes [classes][64] int8 (4-byte aligned rows), w_scale [classes], bias [classes] or NULL,
- *   out_nchw [N][classes][2Hs][2Ws]. */
+ *                                        1x1 conv on the int8 matrix cores (up to 32 classes; needs w_colsum,
+ *                                        Ws % 16 == 0 and a 16-byte aligned output), with a VALU launch behind it
+ *                                        for batches whose codes are too wide for int8; other shapes with
+ *                                        classes <= 4 run on the VALU form (exact integer dot products).
+ *                                        Bit-identical to cdn_codenet_dw3x3_nhwc_forward (up = 1) + the int8
+ *                                        pointwise + unpack whenever that path runs on integer codes.
+ *   w_codes [classes][64] int8 (16-byte aligned), w_scale / w_colsum / bias [classes] (w_colsum may be NULL for
+ *   classes <= 4, bias may be NULL), out_nchw [N][classes][2Hs][2Ws]. */
 int cdn_codenet_head_range_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
                                    int64_t Ws, const float *w_dw, const float *b_dw, float *r_min, float *r_max,
                                    void *r_state, int bits, double momentum, int running, void *workspace,
                                    size_t workspace_bytes, void *stream);
 int cdn_codenet_head_tail_small_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
                                         int64_t Ws, const float *w_dw, const float *b_dw, const void *y2_qstate,
-                                        const signed char *w_codes, const float *w_scale, const float *bias,
-                                        int64_t classes, float *out_nchw, void *stream);
+                                        const signed char *w_codes, const float *w_scale, const int *w_colsum,
+                                        const float *bias, int64_t classes, float *out_nchw, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * The backbone's remaining layer types (lib/models/networks/
