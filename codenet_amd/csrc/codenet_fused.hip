@@ -151,9 +151,10 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * 4;
-  float qs = 1.f, qz = 0.f;
+  float qs = 1.f, qz = 0.f, qr_ = 1.f;
   if (XQ) {
     qs = reinterpret_cast<const float *>(xq)[2];
+    qr_ = __fdiv_rn(1.0f, qs);   // Markstein division in fake_quant_r
     qz = reinterpret_cast<const float *>(xq)[3];
   }
   float mn = INFINITY, mx = -INFINITY;
@@ -164,10 +165,10 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       float4 v = *reinterpret_cast<const float4 *>(xp + c);
       const float4 ww = *reinterpret_cast<const float4 *>(w + c);
       if (XQ) {
-        v.x = fake_quant(v.x, qs, qz);
-        v.y = fake_quant(v.y, qs, qz);
-        v.z = fake_quant(v.z, qs, qz);
-        v.w = fake_quant(v.w, qs, qz);
+        v.x = cdn::fake_quant_r(v.x, qs, qz, qr_);
+        v.y = cdn::fake_quant_r(v.y, qs, qz, qr_);
+        v.z = cdn::fake_quant_r(v.z, qs, qz, qr_);
+        v.w = cdn::fake_quant_r(v.w, qs, qz, qr_);
       }
       acc = fmaf(ww.x, v.x, acc);
       acc = fmaf(ww.y, v.y, acc);
@@ -209,9 +210,10 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
   const long pix0 = (long)blockIdx.x * kScaleTilePix;
   const int tile_pix = (int)min((long)kScaleTilePix, npix - pix0);
   const int total = tile_pix * CQ;    // float4 items of this tile
-  float qs = 1.f, qz = 0.f;
+  float qs = 1.f, qz = 0.f, qr_ = 1.f;
   if (XQ) {
     qs = reinterpret_cast<const float *>(xq)[2];
+    qr_ = __fdiv_rn(1.0f, qs);   // Markstein division in fake_quant_r
     qz = reinterpret_cast<const float *>(xq)[3];
   }
   const float4 *xt = reinterpret_cast<const float4 *>(x + pix0 * C);
@@ -231,10 +233,10 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
       const float4 ww = w4[cq];
       float4 t = v[i];
       if (XQ) {
-        t.x = fake_quant(t.x, qs, qz);
-        t.y = fake_quant(t.y, qs, qz);
-        t.z = fake_quant(t.z, qs, qz);
-        t.w = fake_quant(t.w, qs, qz);
+        t.x = cdn::fake_quant_r(t.x, qs, qz, qr_);
+        t.y = cdn::fake_quant_r(t.y, qs, qz, qr_);
+        t.z = cdn::fake_quant_r(t.z, qs, qz, qr_);
+        t.w = cdn::fake_quant_r(t.w, qs, qz, qr_);
       }
       part[pix * LD + cq] = fmaf(ww.w, t.w, fmaf(ww.z, t.z, fmaf(ww.y, t.y, ww.x * t.x)));
     }
@@ -728,9 +730,10 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
   float *sl = wl + CCH * 9;
   float *red = sl + HWl;
-  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
+  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f, xr_ = 1.f;
   if (XQ) {
     xs = reinterpret_cast<const float *>(xq)[2];
+    xr_ = __fdiv_rn(1.0f, xs);   // Markstein division in fake_quant_r
     xz = reinterpret_cast<const float *>(xq)[3];
   }
   if (SQ) {
@@ -765,10 +768,10 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         if (q < total) {
           float4 t = v[u];
           if (XQ) {
-            t.x = fake_quant(t.x, xs, xz);
-            t.y = fake_quant(t.y, xs, xz);
-            t.z = fake_quant(t.z, xs, xz);
-            t.w = fake_quant(t.w, xs, xz);
+            t.x = cdn::fake_quant_r(t.x, xs, xz, xr_);
+            t.y = cdn::fake_quant_r(t.y, xs, xz, xr_);
+            t.z = cdn::fake_quant_r(t.z, xs, xz, xr_);
+            t.w = cdn::fake_quant_r(t.w, xs, xz, xr_);
           }
           img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq4] = t;
         }
@@ -1844,9 +1847,10 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
   extern __shared__ float tile[];  // [W][C+1]
   const int n = blockIdx.y, h = blockIdx.x;
   const int ld = C + 1;
-  float qs = 1.f, qz = 0.f;
+  float qs = 1.f, qz = 0.f, qr_ = 1.f;
   if (RQ) {
     qs = reinterpret_cast<const float *>(rq)[2];
+    qr_ = __fdiv_rn(1.0f, qs);   // Markstein division in fake_quant_r
     qz = reinterpret_cast<const float *>(rq)[3];
   }
   const float *rp = r + ((long)n * H + h) * W * C;
@@ -1855,10 +1859,10 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
       const int px = (q * 4) / C, c = q * 4 - px * C;
       float4 v = *reinterpret_cast<const float4 *>(rp + (long)q * 4);
       if (RQ) {
-        v.x = fake_quant(v.x, qs, qz);
-        v.y = fake_quant(v.y, qs, qz);
-        v.z = fake_quant(v.z, qs, qz);
-        v.w = fake_quant(v.w, qs, qz);
+        v.x = cdn::fake_quant_r(v.x, qs, qz, qr_);
+        v.y = cdn::fake_quant_r(v.y, qs, qz, qr_);
+        v.z = cdn::fake_quant_r(v.z, qs, qz, qr_);
+        v.w = cdn::fake_quant_r(v.w, qs, qz, qr_);
       }
       float *tp = tile + px * ld + c;
       tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
@@ -1867,7 +1871,7 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
     for (int q = threadIdx.x; q < W * C; q += 256) {
       const int px = q / C, c = q - px * C;
       float v = rp[q];
-      if (RQ) v = fake_quant(v, qs, qz);
+      if (RQ) v = cdn::fake_quant_r(v, qs, qz, qr_);
       tile[px * ld + c] = v;
     }
   }
