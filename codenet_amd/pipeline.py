@@ -301,12 +301,13 @@ class FusedHeads:
     by addressing, so the up-sampled 64-channel tensor is never built.  Same parameters and QuantAct
     buffers (updated in place) as calling the head modules on the unpacked tensor."""
 
-    def __init__(self, heads, int8_pointwise=True, fuse_tail=False, small_tail=True):
+    def __init__(self, heads, int8_pointwise=True, fuse_tail=False, small_tail=True, streams=True):
         self.heads = dict(heads)
         self.int8_pointwise = int8_pointwise
         # W4A8 heads with <= 4 output channels (wh, reg): range pass + depthwise -> quantise -> 1x1 conv as exact
         # integer dot products on the VALU (cdn_codenet_head_range_forward / _head_tail_small_forward)
         self.small_tail = small_tail and int8_pointwise
+        self.streams = streams
         # W4A8 option: range-only depthwise pass, then depthwise + QuantAct + last 1x1 conv in ONE kernel
         # (cdn_codenet_head_tail_forward): the 268 MB depthwise output is never stored.  Parity-tested, but
         # measured slower at batch 64 (3 heads 0.75 ms vs 0.66 ms: the recompute is VALU-bound), so off.
@@ -382,9 +383,20 @@ class FusedHeads:
         Nb = r.shape[0]
         C, Hs, Ws = shape["Co"], shape["H"], shape["W"]
         M = Nb * Hs * Ws
-        stream = torch.cuda.current_stream(r.device).cuda_stream
+        main = torch.cuda.current_stream(r.device)
+        stream = main.cuda_stream
         ws_ptr = (B["ws"].data_ptr() + 255) // 256 * 256
         ws_bytes = (B["ws"].numel() * 4 - (ws_ptr - B["ws"].data_ptr())) // 256 * 256
+        main_launch = (stream, ws_ptr, ws_bytes)
+        # the heads are independent chains (1x1 -> range pass -> tail) of kernels that do not fill the chip
+        # on their own: head i > 0 runs on its own stream with its own arrival counters and y1 buffer
+        use_streams = self.streams and len(self.heads) > 1
+        if use_streams and (B.get("side") is None or len(B["side"]) < len(self.heads) - 1):
+            aux = N_.lib().cdn_codenet_aux_workspace_bytes()
+            B["side"] = [torch.cuda.Stream(r.device) for _ in range(len(self.heads) - 1)]
+            B["ws_side"] = [torch.zeros(aux // 4 + 64, device=r.device) for _ in range(len(self.heads) - 1)]
+            B["y1_side"] = [torch.empty_like(B["y1"]) for _ in range(len(self.heads) - 1)]
+        forked = []
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
 
         def act_args(act):
@@ -406,7 +418,17 @@ class FusedHeads:
 
         outs = {}
         with torch.no_grad():
-            for name, mod in self.heads.items():
+            for hi, (name, mod) in enumerate(self.heads.items()):
+                y1buf = B["y1"]
+                if use_streams and hi > 0:
+                    sd, wsb, y1buf = B["side"][hi - 1], B["ws_side"][hi - 1], B["y1_side"][hi - 1]
+                    sd.wait_stream(main)
+                    forked.append(sd)
+                    stream = sd.cuda_stream
+                    ws_ptr = (wsb.data_ptr() + 255) // 256 * 256
+                    ws_bytes = (wsb.numel() * 4 - (ws_ptr - wsb.data_ptr())) // 256 * 256
+                else:
+                    stream, ws_ptr, ws_bytes = main_launch
                 layers = self._params(mod)
                 fuse = (self.fuse_tail and len(layers) == 3 and layers[0]["act"] is not None
                         and layers[1]["act"] is not None and layers[1]["ep"] is None
@@ -430,7 +452,7 @@ class FusedHeads:
                     outs[name] = B["out"][name]
                     continue
                 l1, l2, l3 = layers
-                pw(r, r_qstate, M, l1, B["y1"])
+                pw(r, r_qstate, M, l1, y1buf)
                 q1 = l1["act"]._device_state(r.device).data_ptr() if l1["act"] is not None else None
                 ep = l2["ep"] or (None, None)
                 if small:
@@ -439,7 +461,7 @@ class FusedHeads:
                     # full-resolution tensor is never stored (bit-identical to the unfused schedule)
                     rec = ops._tic("head_range", (C, 2 * Hs, 2 * Ws))
                     rc = lib.cdn_codenet_head_range_forward(
-                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]),
+                        y1buf.data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]),
                         *act_args(l2["act"]), ws_ptr, ws_bytes, stream)
                     ops._toc(rec)
                     N_.check(rc, "cdn_codenet_head_range_forward")
@@ -447,7 +469,7 @@ class FusedHeads:
                     i8 = l3["i8"]
                     rec = ops._tic("head_tail_small", (C, l3["w"].shape[0], 4 * M))
                     rc = lib.cdn_codenet_head_tail_small_forward(
-                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]),
+                        y1buf.data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]),
                         ptr(i8[1]), ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(),
                         stream)
                     ops._toc(rec)
@@ -459,7 +481,7 @@ class FusedHeads:
                     # kernel: the 64-channel full-resolution tensor is never stored
                     rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
                     rc = lib.cdn_codenet_dw3x3_nhwc_forward(
-                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
+                        y1buf.data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
                         None, None, l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes, None, stream)
                     ops._toc(rec)
                     N_.check(rc, "cdn_codenet_dw3x3_nhwc_forward")
@@ -467,7 +489,7 @@ class FusedHeads:
                     i8 = l3["i8"]
                     rec = ops._tic("head_tail", (C, l3["w"].shape[0], 4 * M))
                     rc = lib.cdn_codenet_head_tail_forward(
-                        B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2,
+                        y1buf.data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2,
                         ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(l3["w"]), ptr(l3["bias"]),
                         l3["w"].shape[0], B["out"][name].data_ptr(), stream)
                     ops._toc(rec)
@@ -476,7 +498,7 @@ class FusedHeads:
                     continue
                 rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
                 rc = lib.cdn_codenet_dw3x3_nhwc_forward(
-                    B["y1"].data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
+                    y1buf.data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
                     ptr(ep[0]), ptr(ep[1]), l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes,
                     B["y2"].data_ptr(), stream)
                 ops._toc(rec)
@@ -488,6 +510,8 @@ class FusedHeads:
                                                  o.shape[1], 2 * Hs, 2 * Ws, 0, stream)
                 N_.check(rc, "cdn_codenet_unpack_nchw")
                 outs[name] = B["out"][name]
+        for sd in forked:
+            main.wait_stream(sd)
         return outs
 
 

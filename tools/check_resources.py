@@ -19,6 +19,13 @@ BUDGET = {
     "pwi8_kernelILi64ELi128ELi2ELb1": 128,        # stages 0-1: four workgroups per CU
     "pwi8_kernelILi128ELi64ELi4ELb1": 128,        # stage 2
     "scale_nchw_kernel": 128, "scale_nhwc_kernelILb1": 128, "unpack_kernelILb1": 128,
+    "pwd3_kernelILi2": 256, "pwd3_kernelILi4": 256,   # streaming pointwise: two waves per SIMD
+}
+# codenet_layers.hip: no spills; the row-streaming kernels must leave two workgroups per CU
+BUDGET_LAYERS = {
+    "dwx_kernelILb1ELi1ELi2": 256, "dwx_kernelILb1ELi2ELi2": 256,
+    "dws_kernelILb1ELi1ELi32ELi1": 256, "dws_kernelILb1ELi1ELi64ELi1": 256, "dws_kernelILb1ELi2ELi32ELi1": 256,
+    "head_small_kernelILi0": 256, "head_small_kernelILi1ELi2": 256, "head_small_kernelILi2": 256,
 }
 
 
@@ -41,6 +48,18 @@ def kernel_resources(src="codenet_fused.hip"):
 def check():
     res = kernel_resources()
     problems = []
+    res_l = kernel_resources("codenet_layers.hip")
+    for frag, cap in BUDGET_LAYERS.items():
+        hits = [(n, r) for n, r in res_l.items() if frag in n]
+        if not hits:
+            problems.append("kernel %s not found" % frag)
+        for n, r in hits:
+            # (a few bytes of private segment for a local array are tolerated here: no VGPR spills)
+            if r["spill"] or r["sgpr_spill"]:
+                problems.append("%s spills: %s" % (n, r))
+            if r["vgpr"] > cap:
+                problems.append("%s uses %d VGPRs (budget %d)" % (n, r["vgpr"], cap))
+    res.update(res_l)
     for frag, cap in BUDGET.items():
         hits = [(n, r) for n, r in res.items() if frag in n]
         if not hits:
