@@ -1631,7 +1631,7 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 // 3 instructions instead of the ~10 of the IEEE expansion (this loop is VALU-bound next to the MFMAs).
 // ------------------------------------------------------------------------------------------
 template <int TN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2)))
 pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu,
@@ -2050,7 +2050,7 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
       // persistent: as many workgroups as stay resident (VGPRs, LDS), each walks row blocks
       const unsigned ny = (unsigned)cdn::ceil_div(Co, 32 * tn);
       static const int d3_occ = getenv("CDN_D3_OCC") ? atoi(getenv("CDN_D3_OCC")) : 0;   // tuning knob
-      long per_cu = std::min<long>(2, (long)(160 * 1024 / (lds_d3 + 512)));   // 172 / 256 VGPRs: 2 waves per SIMD
+      long per_cu = std::min<long>(tn == 2 ? 3 : 2, (long)(160 * 1024 / (lds_d3 + 512)));   // 168 / 256 VGPRs
       if (d3_occ > 0) per_cu = d3_occ;
       const long gx = std::max<long>(1, std::min<long>(cdn::ceil_div(M, 128), per_cu * cdn::kCUs / ny));
       dim3 g((unsigned)gx, ny);
