@@ -1198,6 +1198,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   __shared__ __attribute__((aligned(16))) unsigned char A1[2][BM * kI8LD];
   __shared__ __attribute__((aligned(16))) unsigned char B0[2][BN * kI8LD];
   __shared__ __attribute__((aligned(16))) unsigned char B1[2][BN * kI8LD];
+  CDN_STAMPR(2, 0);
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1356,6 +1357,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   load_tile(0);
   store_tile(0, 0);
   __syncthreads();
+  CDN_STAMPR(2, 1);
   const int nk = (C + 31) / 32;   // (Cpad >= 32 * nk: the weight rows are zero padded to 64)
   for (int t = 0; t < nk; ++t) {
     const int buf = t & 1;
@@ -1382,6 +1384,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * 32);
     __syncthreads();
   }
+  CDN_STAMPR(2, 2);
   float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -1408,9 +1411,11 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         }
       }
   }
+  CDN_STAMPR(2, 3);
   if (rmm)
     cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
+  CDN_STAMPR(2, 4);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -428,3 +428,44 @@ def test_pointwise_mixed_generations_and_output_map(seed):
     untouched[omap.long()] = False
     assert (out[:, untouched] == -7.0).all()
     assert xmin.item() == out[:, omap.long()].min().item() and xmax.item() == out[:, omap.long()].max().item()
+
+
+@pytest.mark.parametrize("M,C,Co,relu", [(1000, 1024, 256, 1), (16384, 1024, 256, 1), (333, 512, 200, 0),
+                                         (4096, 544, 256, 1), (700, 256, 128, 1), (5000, 128, 64, 1)])
+def test_int8_pointwise_exact_integer_sums(M, C, Co, relu):
+    """int8-MFMA pointwise on integer codes (one QuantAct state on the input) at the stage shapes: the integer
+    sums are exact, so the result equals a float64 evaluation of
+    sum_c L_c * qw / (s * sw) + b to fp32 rounding of the final scale."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(M + C + Co)
+    a = (torch.randn(M, C, generator=g) * 2).to(dev)
+    S = torch.zeros(8, device=dev)
+    S[2], S[3] = 17.3, -41.0
+    a = _avoid_ties(a, S[2], S[3])
+    L = torch.round(S[2] * a - S[3]) + S[3]                      # integer levels
+    cpad = (C + 63) // 64 * 64
+    q = torch.randint(-8, 8, (Co, C), generator=g)
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = q.to(torch.int8)
+    codes = codes.to(dev)
+    scale = (torch.rand(Co, generator=g) * 20 + 1).to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    wf = (q.to(dev).float() / scale[:, None]).contiguous()
+    colsum = q.sum(1).to(torch.int32).to(dev)
+    out = torch.empty(M, Co, device=dev)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    Si = S.view(torch.int32).clone()
+    rc = lib.cdn_codenet_pointwise_nhwc_forward(
+        a.data_ptr(), Si.data_ptr(), M, C, Co, 0, 0, wf.data_ptr(), codes.data_ptr(), scale.data_ptr(),
+        colsum.data_ptr(), bias.data_ptr(), None, None, relu, xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8,
+        0.99, 1, wp, wb, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "pw int8")
+    isum = L.double() @ q.to(dev).double().t()                   # exact integers in float64
+    rinv = (1.0 / (S[2] * scale)).double()                       # fp32 product, fp32 reciprocal (as the kernel)
+    ref = isum * rinv[None, :] + bias.double()
+    ref = torch.relu(ref) if relu else ref
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-6 * (ref.abs().max().item() + 1.0), err
+    assert xmin.item() == out.min().item() and xmax.item() == out.max().item()
