@@ -1181,6 +1181,9 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 constexpr int kI8LD = 48;   // bytes per LDS row: 32 k + 16 pad -> conflict-free ds_read_b128
+constexpr int kMixedMaxC = 512;   // channels of a mixed-generation input (per-channel state table in LDS)
+constexpr int kMaxSegs = 128;     // (k-tile, generation) segments of pwi8m_kernel
+constexpr int kMaxGens = 16;      // generations of one layer (2 + units)
 
 template <int BM, int BN, int WGM, bool FAST>
 __global__ void __launch_bounds__(256)
@@ -1419,6 +1422,293 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 }
 
 // ------------------------------------------------------------------------------------------
+// pwi8m: the int8 pointwise conv for a MIXED-GENERATION input: channel c of A holds
+// pre-quantisation values of generation gen[c] of a layer's running QuantAct, so there is no common integer
+// grid -- but the channels of ONE generation have one.  K is cut into SEGMENTS (32-channel k-tile, generation):
+//   y[m][co] = ( sum_g (1 / s_g) * ( sum_{c in g} L_c * qw[co][c] ) ) / sw[co] + b[co]
+// the host lists, generation by generation, the k-tiles that hold live (non-zero weight) channels of that
+// generation together with the tile's weight codes masked to the generation (zero elsewhere; a tile that
+// holds two generations appears twice, a tile of pass-through channels not at all).  A segment runs exactly
+// pwi8_kernel's k-tile step -- every channel of the tile is quantised with ITS generation's (s, z) from a
+// table in LDS; foreign channels meet zero weights -- and after the last segment of a generation the exact
+// int32 sums (+ 128 * that generation's column sums) are scaled by 1 / s_g into fp32 accumulators.
+// Against the bf16 x 3 split (pwd3): 2 instead of 6 MFMAs per 32 k, ~8 instead of ~13 VALU per element, and
+// exact integer sums per generation.  Codes too wide for the nibble split in ANY generation: the f32-MFMA
+// branch on the per-channel fake-quantised values (pwi8_kernel's rare path).
+// ------------------------------------------------------------------------------------------
+struct SegList {
+  const int *k0;            // [nseg] first channel of the k-tile (multiple of 32)
+  const int *gen;           // [nseg] generation of the segment
+  const int *flush;         // [nseg] 1: last segment of its generation
+  const signed char *codes; // [nseg][Co][32] weight codes masked to the segment's generation
+  const int *colsum;        // [ngen][Co] column sums of each generation's codes
+  int nseg, ngen;
+};
+
+template <int BM, int BN, int WGM>
+__global__ void __launch_bounds__(256)
+pwi8m_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+             const unsigned char *__restrict__ agen, SegList sg, const float *__restrict__ wscale,
+             const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ R,
+             float2 *rmm, cdn::QUpdate qu, long M, int C, int Co, int relu, int lda, int ldo,
+             const int *__restrict__ omap) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+  constexpr int AI = BM * 8 / 256;
+  constexpr int BI = (BN * 2 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char A0[2][BM * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char A1[2][BM * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char B0[2][BN * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char B1[2][BN * kI8LD];
+  __shared__ float4 qt[kMixedMaxC];        // {s, z, bit image of the code offset, -} per channel
+  __shared__ int any_wide;
+  __shared__ int cs_s[kMaxGens * BN];      // 128 * column sums [generation][column of this tile]
+  __shared__ float rg_s[kMaxGens];         // 1 / s_g
+  __shared__ int seg_s[kMaxSegs];          // k0 | gen << 16 | flush << 24 (a global load per iteration would sit
+                                           // on the k loop's critical path)
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
+  if (tid == 0) any_wide = 0;
+  __syncthreads();
+  {
+    int w_ = 0;
+    for (int c = tid; c < ((C + 31) & ~31); c += 256) {
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) {
+        const unsigned *st = aq + cdn::kQStateWords * agen[c];
+        const float s_ = __uint_as_float(st[2]), z_ = __uint_as_float(st[3]);
+        e = make_float4(s_, z_, __int_as_float((int)z_ + (2048 - 128) - 0x4B400000), 0.f);
+        w_ |= (int)st[6];
+      }
+      qt[c] = e;
+    }
+    if (w_) any_wide = 1;
+    for (int i = tid; i < sg.nseg; i += 256) seg_s[i] = sg.k0[i] | (sg.gen[i] << 16) | (sg.flush[i] << 24);
+    for (int i = tid; i < sg.ngen * BN; i += 256) {
+      const int g = i / BN, col = i - g * BN;
+      cs_s[i] = n0 + col < Co ? 128 * sg.colsum[(long)g * Co + n0 + col] : 0;
+    }
+    if (tid < sg.ngen) rg_s[tid] = __fdiv_rn(1.0f, __uint_as_float(aq[cdn::kQStateWords * tid + 2]));
+  }
+  __syncthreads();
+  float mn = INFINITY, mx = -INFINITY;
+  if (any_wide) {
+    constexpr int LDF = 17;
+    static_assert(BM * LDF * 4 <= 2 * BM * kI8LD && BN * LDF * 4 <= 2 * BN * kI8LD, "LDS reuse");
+    float *As = reinterpret_cast<float *>(&A0[0][0]);
+    float *Bs = reinterpret_cast<float *>(&B0[0][0]);
+    f32x16 accw[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) accw[i][j] = (f32x16){0};
+    for (int k0 = 0; k0 < C; k0 += 16) {
+      for (int q = tid; q < (BM + BN) * 4; q += 256) {
+        const bool isA = q < BM * 4;
+        const int row = (isA ? q : q - BM * 4) >> 2, kq = (q & 3) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (isA) {
+          const long m = min(m0 + row, M - 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + kq + e < C) {
+              const float4 t4 = qt[k0 + kq + e];
+              v[e] = fake_quant(A[m * lda + k0 + kq + e], t4.x, t4.y);
+            }
+        } else {
+          const int co = min(n0 + row, Co - 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + kq + e < C) v[e] = Wp[(long)co * C + k0 + kq + e];
+        }
+        float *dst = (isA ? As : Bs) + row * LDF + kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = v[e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = As[(wm + i * 32 + (lane & 31)) * LDF + 2 * kk + (lane >> 5)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn + j * 32 + (lane & 31)) * LDF + 2 * kk + (lane >> 5)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], accw[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + wn + j * 32 + (lane & 31);
+      const float bsv = (co < Co && bias) ? bias[co] : 0.f;
+      const int oc = (co < Co && omap) ? omap[co] : co;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M && co < Co) {
+            float v = accw[i][j][r] + bsv;
+            if (relu) v = fmaxf(v, 0.0f);
+            R[m * ldo + oc] = v;
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+          }
+        }
+    }
+    if (rmm)
+      cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                               gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A1[0][0]));
+    return;
+  }
+  i32x16 acc[TM][TN];
+  f32x16 accf[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j] = (i32x16){0};
+      accf[i][j] = (f32x16){0};
+    }
+  const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
+  const bool vec4 = (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16-byte half bh
+  float4 a[AI];
+  i32x4 b[BI];
+  const float *arow[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) arow[i] = A + min(m0 + lr + 32 * i, M - 1) * lda + lk;
+  auto load_seg = [&](int sidx) {
+    const int k0 = seg_s[sidx] & 0xFFFF, k = k0 + lk;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      if (vec4) {
+        a[i] = (k < C) ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
+        a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
+        a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
+        a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int co = min(n0 + br + 128 * i, Co - 1);
+      b[i] = *reinterpret_cast<const i32x4 *>(sg.codes + ((long)sidx * Co + co) * 32 + bh);
+    }
+  };
+  auto ucode = [&](float v, const float4 t4) -> unsigned {
+    // u = rint(s*v - z) + z - 128 + 2048 with the channel's own (s, z); 0 * anything finite for dead channels
+    const float y = __fadd_rn(__fsub_rn(__fmul_rn(t4.x, v), t4.y), 12582912.0f);
+    const int u = (int)__float_as_uint(y) + __float_as_int(t4.z);
+    return (unsigned)min(max(u, 8), 4087);
+  };
+  auto store_seg = [&](int buf, int sidx) {
+    const int kb = (seg_s[sidx] & 0xFFFF) + lk;
+    const float4 t0 = qt[kb], t1 = qt[kb + 1], t2 = qt[kb + 2], t3 = qt[kb + 3];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      // (channels >= C: the table holds s = 0, offset 0 -> u = 0x4B400000 + 0 clamps to a finite code that only
+      //  meets zero weights)
+      const unsigned u0 = ucode(a[i].x, t0), u1 = ucode(a[i].y, t1), u2 = ucode(a[i].z, t2), u3 = ucode(a[i].w, t3);
+      const unsigned p01 = u0 | (u1 << 16), p23 = u2 | (u3 << 16);
+      const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu;
+      const unsigned hi = __builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u;
+      *reinterpret_cast<unsigned *>(&A0[buf][(lr + 32 * i) * kI8LD + lk]) = lo;
+      *reinterpret_cast<unsigned *>(&A1[buf][(lr + 32 * i) * kI8LD + lk]) = hi;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      if (br + 128 * i < BN) {
+        i32x4 s16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)b[i][e] << 4) & 0xF0F0F0F0u);
+        *reinterpret_cast<i32x4 *>(&B0[buf][(br + 128 * i) * kI8LD + bh]) = b[i];
+        *reinterpret_cast<i32x4 *>(&B1[buf][(br + 128 * i) * kI8LD + bh]) = s16;
+      }
+  };
+  const int nseg = sg.nseg;
+  if (nseg > 0) {
+    load_seg(0);
+    store_seg(0, 0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nseg; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nseg) load_seg(t + 1);
+    i32x4 a0[TM], a1[TM], b0[TN], b1[TN];
+    const int fo = (lane & 31) * kI8LD + (lane >> 5) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      a0[i] = *reinterpret_cast<const i32x4 *>(&A0[buf][(wm + i * 32) * kI8LD + fo]);
+      a1[i] = *reinterpret_cast<const i32x4 *>(&A1[buf][(wm + i * 32) * kI8LD + fo]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      b0[j] = *reinterpret_cast<const i32x4 *>(&B0[buf][(wn + j * 32) * kI8LD + fo]);
+      b1[j] = *reinterpret_cast<const i32x4 *>(&B1[buf][(wn + j * 32) * kI8LD + fo]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      }
+    if (seg_s[t] >> 24) {                               // workgroup-uniform: this generation is complete
+      const int g = (seg_s[t] >> 16) & 0xFF;
+      const float rg = rg_s[g];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int t128 = cs_s[g * BN + wn + j * 32 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            accf[i][j][r] = fmaf((float)(acc[i][j][r] + t128), rg, accf[i][j][r]);
+            acc[i][j][r] = 0;
+          }
+      }
+    }
+    if (t + 1 < nseg) store_seg(buf ^ 1, t + 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    float bsv = 0.f, rinv = 0.f;
+    int oc = co;
+    if (co < Co) {
+      if (bias) bsv = bias[co];
+      rinv = __fdiv_rn(1.0f, wscale[co]);
+      if (omap) oc = omap[co];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < M && co < Co) {
+          float v = fmaf(accf[i][j][r], rinv, bsv);
+          if (relu) v = fmaxf(v, 0.0f);
+          R[m * ldo + oc] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
+      }
+  }
+  if (rmm)
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
+}
+
+// ------------------------------------------------------------------------------------------
 // pwb3: the W4 pointwise conv on FINAL (already fake-quantised, or fp32) activations -- the first 1x1 of a
 // ShuffleNetV2 unit, whose input channels carry different generations of the layer's running QuantAct and
 // so have no common integer grid.  Exact products on the bf16 matrix cores:
@@ -1433,7 +1723,6 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 // ------------------------------------------------------------------------------------------
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int kB3LD = 80;
-constexpr int kMixedMaxC = 512;   // channels of a mixed-generation input (per-channel state table in LDS)
 
 template <int BM, int BN, int WGM>
 __global__ void __launch_bounds__(256)
@@ -2259,6 +2548,53 @@ extern "C" int cdn_codenet_pointwise_nhwc_forward(
                                              w_colsum, bias, ep_scale, ep_shift, relu, nullptr, r_min, r_max,
                                              r_state, bits, momentum, running, workspace, workspace_bytes,
                                              out, stream);
+}
+
+// Mixed-generation pointwise conv on the int8 matrix cores, K cut into (k-tile, generation) segments: see
+// pwi8m_kernel.
+extern "C" int cdn_codenet_pointwise_mixed_i8_forward(
+    const float *a, const void *a_states, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
+    int64_t lda, int64_t ldo, const float *w, const int *seg_k0, const int *seg_gen, const int *seg_flush,
+    int64_t nseg, int64_t ngen, const signed char *seg_codes, const int *seg_colsum, const float *w_scale,
+    const float *bias, int relu, const int *out_map, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  CDN_REQUIRE(a && a_states && a_gen && w && seg_k0 && seg_gen && seg_flush && seg_codes && seg_colsum &&
+                  w_scale && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && nseg >= 0 && nseg <= kMaxSegs && ngen >= 1 && ngen <= kMaxGens &&
+                  C <= kMixedMaxC &&
+                  M * std::max(C, Co) < (1ll << 31),
+              CDN_ERR_ARG, "bad size (C <= %d, nseg <= %d)", kMixedMaxC, kMaxSegs);
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
+              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
+  if (lda == 0) lda = C;
+  if (ldo == 0) ldo = Co;
+  CDN_REQUIRE(lda >= C && (out_map || ldo >= Co) && M * std::max(lda, ldo) < (1ll << 31), CDN_ERR_ARG,
+              "bad row strides");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(seg_codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 3) == 0,
+              CDN_ERR_ARG, "seg_codes must be 16-byte aligned");
+  cdn::AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
+  float2 *rmm = r_state ? ws.partials : nullptr;
+  const SegList sg{seg_k0, seg_gen, seg_flush, seg_codes, seg_colsum, (int)nseg, (int)ngen};
+  const unsigned *aq = static_cast<const unsigned *>(a_states);
+  cdn::ProfScope ps(cdn::kProfPointwise, 0, st);
+  if (Co > 64) {
+    dim3 g((unsigned)cdn::ceil_div(M, 64), (unsigned)cdn::ceil_div(Co, 128));
+    CDN_REQUIRE((long)g.x * g.y <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
+    pwi8m_kernel<64, 128, 2><<<g, 256, 0, st>>>(a, aq, a_gen, sg, w_scale, w, bias, out, rmm, qu, (long)M, (int)C,
+                                                (int)Co, relu, (int)lda, (int)ldo, out_map);
+  } else {
+    dim3 g((unsigned)cdn::ceil_div(M, 128), (unsigned)cdn::ceil_div(Co, 64));
+    CDN_REQUIRE((long)g.x * g.y <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
+    pwi8m_kernel<128, 64, 4><<<g, 256, 0, st>>>(a, aq, a_gen, sg, w_scale, w, bias, out, rmm, qu, (long)M, (int)C,
+                                                (int)Co, relu, (int)lda, (int)ldo, out_map);
+  }
+  return cdn::check_launch("codenet pointwise (mixed generations, int8)");
 }
 
 extern "C" int cdn_codenet_pointwise_mixed_forward(

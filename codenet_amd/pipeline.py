@@ -9,6 +9,8 @@ independent image batches over one process per GPU; the only collective is a sta
 of parameters and buffers (weights, BN statistics, QuantAct ranges) from rank 0 over RCCL
 (SURVEY.md section 8e).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -307,7 +309,7 @@ class FusedHeads:
         # W4A8 heads with <= 4 output channels (wh, reg): range pass + depthwise -> quantise -> 1x1 conv as exact
         # integer dot products on the VALU (cdn_codenet_head_range_forward / _head_tail_small_forward)
         self.small_tail = small_tail and int8_pointwise
-        self.streams = streams
+        self.streams = streams and os.environ.get("CDN_HEAD_STREAMS", "1") != "0"          # tuning knob
         # W4A8 option: range-only depthwise pass, then depthwise + QuantAct + last 1x1 conv in ONE kernel
         # (cdn_codenet_head_tail_forward): the 268 MB depthwise output is never stored.  Parity-tested, but
         # measured slower at batch 64 (3 heads 0.75 ms vs 0.66 ms: the recompute is VALU-bound), so off.
@@ -534,13 +536,20 @@ class FusedBackbone:
         self.model = model
         self.int8 = int8_pointwise
         self.shuffle_free = shuffle_free and int8_pointwise
-        self.two_streams = two_streams
+        # mixed-generation 1x1 convs on the int8 matrix cores, K segmented by generation
+        # (cdn_codenet_pointwise_mixed_i8_forward) instead of the bf16 x 3 split: exact integer sums per
+        # generation, parity-tested, but measured no faster -- opt-in: CDN_INT8_SEGMENTS=1 for
+        # the few-row layers, =all everywhere
+        self.int8_segments = os.environ.get("CDN_INT8_SEGMENTS", "0") != "0"
+        self.int8_segments_all = os.environ.get("CDN_INT8_SEGMENTS", "0") == "all"
+        self.two_streams = two_streams and os.environ.get("CDN_TWO_STREAMS", "1") != "0"   # tuning knob
         self._bufs = None
 
-    def _l4_weights(self, q4, logical, dev):
+    def _l4_weights(self, q4, logical, dev, gens=None):
         """layer4's 1x1 weights with the input columns in the physical order of the last layer."""
         key = (q4.conv.weight.data_ptr(), q4.conv.weight._version, q4.bn.weight._version,
-               q4.bn.running_var._version, tuple(logical), dev)
+               q4.bn.running_var._version, tuple(logical), tuple(gens) if gens is not None else None,
+               self.int8_segments, dev)
         c = self.__dict__.get("_l4_cache")
         if c is None or c[0] != key:
             w, b = q4.folded()
@@ -549,8 +558,13 @@ class FusedBackbone:
             K, Co = len(logical), w.shape[0]
             cp = torch.zeros(Co, (K + 63) // 64 * 64, dtype=torch.int8, device=dev)
             cp[:, :K] = codes[:, cols]
-            self._l4_cache = (key, dict(w=w.reshape(Co, -1)[:, cols].contiguous(), codes=cp, scale=scale,
-                                        colsum=colsum, bias=b.contiguous(), Co=Co, K=K))
+            W4 = dict(w=w.reshape(Co, -1)[:, cols].contiguous(), codes=cp, scale=scale, colsum=colsum,
+                      bias=b.contiguous(), Co=Co, K=K)
+            if gens is not None and self.int8_segments:
+                sg = self._segments(cp[:, :K], [True] * K, list(gens), dev)
+                if sg is not None:
+                    W4["seg"] = sg
+            self._l4_cache = (key, W4)
         return self._l4_cache[1]
 
     @staticmethod
@@ -764,7 +778,41 @@ class FusedBackbone:
             L, d = 2 * L, d + 1
         return d
 
-    def _mixed_plan(self, nodes, in_logical, dev):
+    @staticmethod
+    def _segments(codes, live, gens, dev):
+        """(k-tile, generation) segments of a mixed-generation 1x1 conv for cdn_codenet_pointwise_mixed_i8_forward:
+        codes int8 [Co, K] in physical column order, live[c] = the column carries weights, gens[c] = its
+        generation.  Generation by generation, every 32-channel tile that holds live channels of it."""
+        Co, K = codes.shape
+        ntile = (K + 31) // 32
+        k0, sg, fl, blocks = [], [], [], []
+        ngen = max(gens) + 1
+        colsum = torch.zeros(ngen, Co, dtype=torch.int32, device=dev)
+        codes_c = codes.cpu()
+        for g in sorted(set(g_ for g_, l_ in zip(gens, live) if l_)):
+            first = len(k0)
+            for t in range(ntile):
+                idx = [c for c in range(32 * t, min(32 * t + 32, K)) if live[c] and gens[c] == g]
+                if not idx:
+                    continue
+                blk = torch.zeros(Co, 32, dtype=torch.int8)
+                loc = [c - 32 * t for c in idx]
+                blk[:, loc] = codes_c[:, idx]
+                k0.append(32 * t)
+                sg.append(g)
+                fl.append(0)
+                blocks.append(blk)
+            if len(k0) > first:
+                fl[-1] = 1
+                sel = [c for c in range(K) if live[c] and gens[c] == g]
+                colsum[g] = codes_c[:, sel].to(torch.int32).sum(1).to(dev)
+        i32 = lambda v: torch.tensor(v if v else [0], device=dev, dtype=torch.int32)   # noqa: E731
+        seg_codes = (torch.stack(blocks) if blocks else torch.zeros(1, Co, 32, dtype=torch.int8)).contiguous().to(dev)
+        if len(k0) > 128 or ngen > 16:   # kMaxSegs / kMaxGens of the kernel: the caller keeps the bf16-split form
+            return None
+        return dict(k0=i32(k0), gen=i32(sg), flush=i32(fl), nseg=len(k0), codes=seg_codes, colsum=colsum.contiguous())
+
+    def _mixed_plan(self, nodes, in_logical, dev, in_gens=None):
         """Host bookkeeping of one layer: slot assignment, generations, permuted weights (cached until a
         weight changes).  in_logical: logical index of every physical input channel (None: identity)."""
         units = [self._unit(n) for n in nodes]
@@ -773,7 +821,8 @@ class FusedBackbone:
             convs += [u[k] for k in ("c1", "c2", "c3", "c4", "c5") if k in u]
         key = (tuple((c.conv.weight.data_ptr(), c.conv.weight._version, c.bn.weight._version,
                       c.bn.running_var._version, c.bn.running_mean._version, c.bn.bias._version) for c in convs),
-               tuple(in_logical) if in_logical is not None else None, dev)
+               tuple(in_logical) if in_logical is not None else None,
+               tuple(in_gens) if in_gens is not None else None, self.int8_segments, dev)
         cache = self.__dict__.setdefault("_mixed_cache", {})
         ck = id(nodes[0])
         if ck in cache and cache[ck]["key"] == key:
@@ -785,9 +834,10 @@ class FusedBackbone:
         i32 = lambda v: torch.tensor(v, device=dev, dtype=torch.int32)   # noqa: E731
         u8 = lambda v: torch.tensor(v, device=dev, dtype=torch.uint8)    # noqa: E731
 
-        def pw_weights(convbn, cols, K):
+        def pw_weights(convbn, cols, K, gens=None):
             """1x1 weights with input columns re-ordered: column p of the result is logical column cols[p]
-            (-1: zero column).  Returns dict(w fp32 [Co,K], codes int8 [Co,Kpad], scale, colsum, bias)."""
+            (-1: zero column).  Returns dict(w fp32 [Co,K], codes int8 [Co,Kpad], scale, colsum, bias); with the
+            generation of every column (gens) also the (k-tile, generation) segments of the int8 kernel."""
             w, b = convbn.folded()
             codes, scale, colsum = convbn.folded_int8()
             Co = w.shape[0]
@@ -798,8 +848,13 @@ class FusedBackbone:
             kpad = (K + 63) // 64 * 64
             cp = torch.zeros(Co, kpad, dtype=torch.int8, device=dev)
             cp[:, :K] = codes[:, src] * live.to(torch.int8)
-            return dict(w=w2.contiguous(), codes=cp.contiguous(), scale=scale, colsum=colsum, bias=b.contiguous(),
-                        Co=Co, K=K)
+            out = dict(w=w2.contiguous(), codes=cp.contiguous(), scale=scale, colsum=colsum, bias=b.contiguous(),
+                       Co=Co, K=K)
+            if gens is not None and self.int8_segments:
+                sg = self._segments(cp[:, :K], [c >= 0 for c in cols], list(gens), dev)
+                if sg is not None:
+                    out["seg"] = sg
+            return out
 
         plan = dict(key=key, h=h, cin=cin, C=C, units=[])
         logical, gen = [0] * C, [0] * C
@@ -813,7 +868,7 @@ class FusedBackbone:
                 P["w4"] = w4.reshape(cin, 9)[lin_t].contiguous()
                 P["b4"] = b4[lin_t].contiguous()
                 P["c5"] = pw_weights(u["c5"], lin, cin)
-                P["c1"] = pw_weights(u["c1"], lin, cin)
+                P["c1"] = pw_weights(u["c1"], lin, cin, in_gens)
                 P["c3"] = pw_weights(u["c3"], list(range(h)), h)
                 P["omapA"] = i32([slot_of[2 * i] for i in range(h)])
                 P["omapB"] = i32([slot_of[2 * i + 1] for i in range(h)])
@@ -825,7 +880,8 @@ class FusedBackbone:
             else:
                 P2 = [p_ for p_ in range(C) if logical[p_] >= h]
                 P["gen_in"] = u8(gen)
-                P["c1"] = pw_weights(u["c1"], [logical[p_] - h if logical[p_] >= h else -1 for p_ in range(C)], C)
+                P["c1"] = pw_weights(u["c1"], [logical[p_] - h if logical[p_] >= h else -1 for p_ in range(C)], C,
+                                     list(gen))
                 P["c3"] = pw_weights(u["c3"], list(range(h)), h)
                 fresh = sorted(range(h), key=lambda i: (self._death(2 * i + 1, h), i))
                 omap = [0] * h
@@ -843,7 +899,7 @@ class FusedBackbone:
             P["w2"], P["b2"] = w2.reshape(h, 9).contiguous(), b2.contiguous()
             plan["units"].append(P)
         assert sorted(logical) == list(range(C))
-        plan.update(logical=list(logical), gen=u8(gen), ngen=ngen,
+        plan.update(logical=list(logical), gen=u8(gen), gen_list=list(gen), ngen=ngen,
                     states=torch.zeros(ngen * 8, dtype=torch.int32, device=dev))
         cache[ck] = plan
         return plan
@@ -875,6 +931,18 @@ class FusedBackbone:
         aa = self._act_args(act, self._dev)
         if state_ptr is not None:
             aa[2] = state_ptr
+        sg = Wt.get("seg") if a_gen is not None else None
+        # measured: the segmented int8 form wins for few rows (layer 3 units: 29-34 us vs 39-43 us for the bf16
+        # split); with many rows the extra segments (a k-tile per generation it holds) re-read A and it loses
+        # (layer 2: 40-57 vs 36 us; stride-2 units: 190 vs 74 us)
+        if sg is not None and (self.int8_segments_all or (M <= 32768 and Wt["Co"] <= 256)):
+            rc = N_.lib().cdn_codenet_pointwise_mixed_i8_forward(
+                a_ptr, a_q, a_gen, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), sg["k0"].data_ptr(),
+                sg["gen"].data_ptr(), sg["flush"].data_ptr(), sg["nseg"], sg["colsum"].shape[0], sg["codes"].data_ptr(),
+                sg["colsum"].data_ptr(), Wt["scale"].data_ptr(), Wt["bias"].data_ptr(), int(relu), out_map, *aa,
+                self._ws_ptr, self._ws_bytes, out_ptr, self._stream)
+            N_.check(rc, "cdn_codenet_pointwise_mixed_i8_forward")
+            return
         rc = N_.lib().cdn_codenet_pointwise_mixed_forward(
             a_ptr, a_q, a_gen, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), Wt["codes"].data_ptr(),
             Wt["scale"].data_ptr(), Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), None, None, int(relu),
@@ -896,7 +964,8 @@ class FusedBackbone:
         dev = x.device
         self._prepare(dev)
         mixed_in = isinstance(x_in, dict)
-        plan = self._mixed_plan(nodes, x_in["logical"] if mixed_in else None, dev)
+        plan = self._mixed_plan(nodes, x_in["logical"] if mixed_in else None, dev,
+                                x_in.get("gen_list") if mixed_in else None)
         units = [self._unit(n) for n in nodes]
         h, cin, C = plan["h"], plan["cin"], plan["C"]
         L = self._layer_bufs(nodes, h, cin, Nb, H, W, dev)
@@ -935,7 +1004,8 @@ class FusedBackbone:
                                  P["w2"], P["b2"], u["a2"], L["t2"], ldh)
                 self._pw_raw(L["t2"].data_ptr(), qptr(u["a2"]), None, Mo, ldh, P["c3"], True, sh, sp(P["genB"]),
                              P["omapB"].data_ptr(), Y.data_ptr(), C)
-        return dict(t=Y, logical=plan["logical"], gen=plan["gen"], states=S, C=C, H=L["H"], W=L["W"])
+        return dict(t=Y, logical=plan["logical"], gen=plan["gen"], gen_list=plan["gen_list"], states=S, C=C,
+                    H=L["H"], W=L["W"])
 
     @staticmethod
     def materialize(layout):
@@ -1008,7 +1078,7 @@ class FusedBackbone:
             if B.get("out") is None or B["out"].shape != (Nb, H * W, c4):
                 B["out"] = torch.empty(Nb, H * W, c4, device=dev)
             if lay is not None and q4.folded_int8() is not None and x_ld <= self._MIXED_MAX_C:
-                W4 = self._l4_weights(q4, lay["logical"], dev)
+                W4 = self._l4_weights(q4, lay["logical"], dev, lay.get("gen_list"))
                 self._pw_raw(x.data_ptr(), lay["states"].data_ptr(), lay["gen"].data_ptr(), Nb * H * W, x_ld, W4,
                              True, act4, None, None, B["out"].data_ptr(), c4)
             else:

@@ -272,6 +272,22 @@ int cdn_codenet_pointwise_mixed_forward(
     const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
     const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
     void *workspace, size_t workspace_bytes, float *out, void *stream);
+/* The mixed-generation pointwise conv on the int8 matrix cores.  The channels of ONE generation share an integer
+ * grid, so K is cut into segments (32-channel k-tile, generation), listed generation by generation:
+ *   seg_k0[s] first channel of the tile (multiple of 32), seg_gen[s] its generation, seg_flush[s] = 1 on the
+ *   last segment of a generation; seg_codes [nseg][Co][32] int8 = the tile's weight codes with zeros outside
+ *   the generation (a tile holding two generations appears twice, a tile of pass-through channels not at
+ *   all); seg_colsum [ngen][Co] int32 = column sums of each generation's codes (ngen <= 16 generations,
+ *   nseg <= 128 segments).
+ *   y[m][co] = ( sum_g (sum_{c in g} L_c qw[co][c]) / s_g ) / w_scale[co] + bias[co]   -- exact integer sums
+ * w [Co][C] fp32 (physical order, zero columns) serves the f32 branch taken when any generation's codes are
+ * too wide for int8.  C <= 512.  Other arguments as cdn_codenet_pointwise_mixed_forward. */
+int cdn_codenet_pointwise_mixed_i8_forward(
+    const float *a, const void *a_states, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
+    int64_t lda, int64_t ldo, const float *w, const int *seg_k0, const int *seg_gen, const int *seg_flush,
+    int64_t nseg, int64_t ngen, const signed char *seg_codes, const int *seg_colsum, const float *w_scale,
+    const float *bias, int relu, const int *out_map, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream);
 int cdn_codenet_dw3x3_mixed_forward(
     const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t N, int64_t C, int64_t H,
     int64_t W, int up, int stride, int64_t ld_in, int64_t ld_out, const float *w, const float *bias,
