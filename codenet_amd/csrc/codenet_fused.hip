@@ -1935,7 +1935,10 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   CDN_STAMPR(2, 0);
   const int nwin = (C + 31) >> 5, Kp = nwin * 32;
   const int ldb = Kp * 2 + 16;                               // bytes per B row: conflict-free ds_read_b128
-  float4 *qtab = reinterpret_cast<float4 *>(smem + (size_t)32 * TN * ldb);   // [Kp] {s, z, 1/s, -}
+  // quantiser table: three float arrays [Kp] (s | z | 1/s): a lane reads its 16 channels of a window as 4 + 4 + 4
+  // ds_read_b128 issued together (one {s, z, r} record per channel cost 16 reads, each waited for: 1600 cycles
+  // per half window in the ISA)
+  float *qtab = reinterpret_cast<float *>(smem + (size_t)32 * TN * ldb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.y * 32 * TN;
   const bool has_q = aq != nullptr;
@@ -1982,8 +1985,9 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     for (int u = 0; u < 2; ++u) {
       const int c = tid + 256 * u;
       if (c < Kp) {
-        if (c < C) te[u].z = __fdiv_rn(1.0f, te[u].x);
-        qtab[c] = te[u];
+        qtab[c] = te[u].x;
+        qtab[Kp + c] = te[u].y;
+        qtab[2 * Kp + c] = c < C ? __fdiv_rn(1.0f, te[u].x) : 0.0f;
       }
     }
     for (int c = tid + 512; c < Kp; c += 256) {                // (C > 512: not reached by the dispatcher)
@@ -1992,7 +1996,9 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         const float *sp = reinterpret_cast<const float *>(aq) + (agen ? cdn::kQStateWords * agen[c] : 0);
         e = make_float4(sp[2], sp[3], __fdiv_rn(1.0f, sp[2]), 0.f);
       }
-      qtab[c] = e;
+      qtab[c] = e.x;
+      qtab[Kp + c] = e.y;
+      qtab[2 * Kp + c] = e.z;
     }
   }
   const int chunks = Kp >> 4;                                // 16-code chunks per row
@@ -2048,7 +2054,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   CDN_STAMPR(2, 1);
 
   const unsigned char *bbase = smem + (size_t)(lane & 31) * ldb + 32 * (lane >> 5);
-  const float4 *qrow = qtab + 16 * (lane >> 5);
+  const float *qrow = qtab + 16 * (lane >> 5);
   float mn = INFINITY, mx = -INFINITY;
 
   for (long rb = rb_first; rb < nrb; rb += rb_stride) {
@@ -2069,18 +2075,33 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
           load_next(buf[p_]);
           unsigned hb[16], mb[16], lb[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float x = v[e];
+          for (int hh = 0; hh < 2; ++hh) {                      // 8 channels at a time: 6 table reads in flight
+            float ts[8], tz[8], tr[8];
             if (has_q) {
-              const float4 t4 = qrow[32 * w + e];               // {s, z, 1/s}: same address in a half-wave
-              const float n = __fadd_rn(rintf(__fsub_rn(__fmul_rn(t4.x, x), t4.y)), t4.y);
-              const float q0 = __fmul_rn(n, t4.z);
-              x = fmaf(fmaf(-q0, t4.x, n), t4.z, q0);
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const float4 s4 = *reinterpret_cast<const float4 *>(qrow + 32 * w + 8 * hh + 4 * i);
+                const float4 z4 = *reinterpret_cast<const float4 *>(qrow + Kp + 32 * w + 8 * hh + 4 * i);
+                const float4 r4 = *reinterpret_cast<const float4 *>(qrow + 2 * Kp + 32 * w + 8 * hh + 4 * i);
+                ts[4 * i] = s4.x; ts[4 * i + 1] = s4.y; ts[4 * i + 2] = s4.z; ts[4 * i + 3] = s4.w;
+                tz[4 * i] = z4.x; tz[4 * i + 1] = z4.y; tz[4 * i + 2] = z4.z; tz[4 * i + 3] = z4.w;
+                tr[4 * i] = r4.x; tr[4 * i + 1] = r4.y; tr[4 * i + 2] = r4.z; tr[4 * i + 3] = r4.w;
+              }
             }
-            hb[e] = __float_as_uint(x);
-            const float r1 = __fsub_rn(x, __uint_as_float(hb[e] & 0xFFFF0000u));
-            mb[e] = __float_as_uint(r1);
-            lb[e] = __float_as_uint(__fsub_rn(r1, __uint_as_float(mb[e] & 0xFFFF0000u)));
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+              const int e = 8 * hh + e8;
+              float x = v[e];
+              if (has_q) {
+                const float n = __fadd_rn(rintf(__fsub_rn(__fmul_rn(ts[e8], x), tz[e8])), tz[e8]);
+                const float q0 = __fmul_rn(n, tr[e8]);
+                x = fmaf(fmaf(-q0, ts[e8], n), tr[e8], q0);
+              }
+              hb[e] = __float_as_uint(x);
+              const float r1 = __fsub_rn(x, __uint_as_float(hb[e] & 0xFFFF0000u));
+              mb[e] = __float_as_uint(r1);
+              lb[e] = __float_as_uint(__fsub_rn(r1, __uint_as_float(mb[e] & 0xFFFF0000u)));
+            }
           }
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
