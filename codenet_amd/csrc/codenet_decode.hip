@@ -33,20 +33,23 @@ __global__ void __launch_bounds__(kKeyThreads)
 decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
                    unsigned *__restrict__ hist, float *__restrict__ heat_out, int cat, int H, int W,
                    int apply_sigmoid) {
-  extern __shared__ float plane[];              // [(H + 2)][(W + 2)] with a -inf border
+  // [(H + 2)][Wp] with a -inf border; Wp = W + 8 and the interior starts at column 4, so that every row of
+  // the interior is 16-byte aligned: a thread handles 4 consecutive pixels with 3 ds_read_b128 + 6 ds_read_b32
+  // (9 scalar reads per PIXEL, each waited for, made this phase 440 cycles per pixel and wave in the ISA)
+  extern __shared__ __attribute__((aligned(16))) float plane[];
   __shared__ unsigned lh[kBins];
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int HW = H * W, Wp = W + 2;
+  const int HW = H * W, Wp = ((W + 3) & ~3) + 8;
   const float *hp = heat + ((long)b * cat + c) * HW;
   unsigned *kp = keys + ((long)b * cat + c) * HW;
   float *op = heat_out ? heat_out + ((long)b * cat + c) * HW : nullptr;
   for (int i = tid; i < kBins; i += kKeyThreads) lh[i] = 0;
-  for (int i = tid; i < 2 * (Wp + H); i += kKeyThreads) {      // the -inf border (max_pool2d padding)
+  for (int i = tid; i < 2 * (W + 2 + H); i += kKeyThreads) {   // the -inf border (max_pool2d padding)
     int cell;
-    if (i < Wp) cell = i;
-    else if (i < 2 * Wp) cell = (H + 1) * Wp + (i - Wp);
-    else if (i < 2 * Wp + H) cell = (i - 2 * Wp + 1) * Wp;
-    else cell = (i - 2 * Wp - H + 1) * Wp + W + 1;
+    if (i < W + 2) cell = 3 + i;                                            // row -1, columns -1 .. W
+    else if (i < 2 * (W + 2)) cell = (H + 1) * Wp + 3 + (i - (W + 2));      // row H
+    else if (i < 2 * (W + 2) + H) cell = (i - 2 * (W + 2) + 1) * Wp + 3;    // column -1
+    else cell = (i - 2 * (W + 2) - H + 1) * Wp + 4 + W;                     // column W
     plane[cell] = -INFINITY;
   }
   const bool vec = (W & 3) == 0;
@@ -68,8 +71,7 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
             t.x = sigmoidf_ref(t.x); t.y = sigmoidf_ref(t.y); t.z = sigmoidf_ref(t.z); t.w = sigmoidf_ref(t.w);
           }
           const int p = q * 4, y = p / W, x = p - y * W;
-          float *d = plane + (y + 1) * Wp + (x + 1);
-          d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+          *reinterpret_cast<float4 *>(plane + (y + 1) * Wp + 4 + x) = t;
           if (op) reinterpret_cast<float4 *>(op)[q] = t;
         }
       }
@@ -78,7 +80,7 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
     for (int p = tid; p < HW; p += kKeyThreads) {
       float v = hp[p];
       if (apply_sigmoid) v = sigmoidf_ref(v);
-      plane[(p / W + 1) * Wp + (p % W + 1)] = v;
+      plane[(p / W + 1) * Wp + 4 + p % W] = v;
       if (op) op[p] = v;
     }
   }
@@ -87,14 +89,10 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
   // (16384 same-address LDS atomics per plane cost 250 us per launch)
   const unsigned zkey = cdn::f2ord(0.0f);
   unsigned zeros = 0;
-  auto key_of = [&](int p) -> unsigned {
-    const int y = p / W, x = p - y * W;
-    const float *q = plane + (y + 1) * Wp + (x + 1);
-    const float v = q[0];
-    float m = fmaxf(fmaxf(q[-Wp - 1], q[-Wp]), fmaxf(q[-Wp + 1], q[-1]));
-    m = fmaxf(m, fmaxf(fmaxf(q[1], q[Wp - 1]), fmaxf(q[Wp], q[Wp + 1])));
-    // hmax == heat  <=>  v >= every neighbour (NaN compares false, as in the reference)
-    const float s = (fmaxf(m, v) == v) ? v : v * 0.0f;
+  // v = the pixel, m9 = the maximum of its 3x3 neighbourhood INCLUDING itself:
+  // hmax == heat  <=>  fmaxf(m8, v) == v  <=>  m9 == v (NaN compares false, as in the reference)
+  auto key_from = [&](float v, float m9) -> unsigned {
+    const float s = (m9 == v) ? v : v * 0.0f;
     const unsigned k = cdn::f2ord(s + 0.0f);    // (+0.0f: -0 and +0 get the same key)
     if (k == zkey) ++zeros;
     else atomicAdd(&lh[k >> (32 - 11)], 1u);
@@ -102,12 +100,35 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
   };
   if (vec) {
     for (int q = tid; q < (HW >> 2); q += kKeyThreads) {
+      const int p = q * 4, y = p / W, x = p - y * W;
+      const float *ctr = plane + (y + 1) * Wp + 4 + x;
+      float hm[3][4];                           // horizontal 3-maxima of the three rows
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float *row = ctr + (r - 1) * Wp;
+        const float4 cv = *reinterpret_cast<const float4 *>(row);
+        const float l = row[-1], rr = row[4];
+        hm[r][0] = fmaxf(fmaxf(l, cv.x), cv.y);
+        hm[r][1] = fmaxf(fmaxf(cv.x, cv.y), cv.z);
+        hm[r][2] = fmaxf(fmaxf(cv.y, cv.z), cv.w);
+        hm[r][3] = fmaxf(fmaxf(cv.z, cv.w), rr);
+      }
+      const float4 cv = *reinterpret_cast<const float4 *>(ctr);
       uint4 k4;
-      k4.x = key_of(q * 4); k4.y = key_of(q * 4 + 1); k4.z = key_of(q * 4 + 2); k4.w = key_of(q * 4 + 3);
+      k4.x = key_from(cv.x, fmaxf(fmaxf(hm[0][0], hm[1][0]), hm[2][0]));
+      k4.y = key_from(cv.y, fmaxf(fmaxf(hm[0][1], hm[1][1]), hm[2][1]));
+      k4.z = key_from(cv.z, fmaxf(fmaxf(hm[0][2], hm[1][2]), hm[2][2]));
+      k4.w = key_from(cv.w, fmaxf(fmaxf(hm[0][3], hm[1][3]), hm[2][3]));
       reinterpret_cast<uint4 *>(kp)[q] = k4;
     }
   } else {
-    for (int p = tid; p < HW; p += kKeyThreads) kp[p] = key_of(p);
+    for (int p = tid; p < HW; p += kKeyThreads) {
+      const int y = p / W, x = p - y * W;
+      const float *q = plane + (y + 1) * Wp + 4 + x;
+      float m = fmaxf(fmaxf(q[-Wp - 1], q[-Wp]), fmaxf(q[-Wp + 1], q[-1]));
+      m = fmaxf(m, fmaxf(fmaxf(q[1], q[Wp - 1]), fmaxf(q[Wp], q[Wp + 1])));
+      kp[p] = key_from(q[0], fmaxf(m, q[0]));
+    }
   }
   if (zeros) atomicAdd(&lh[zkey >> (32 - 11)], zeros);
   __syncthreads();
@@ -181,12 +202,26 @@ decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ h
     const int sh = shifts[lvl + 1];
     const unsigned wm = (1u << widths[lvl + 1]) - 1u;
     if (vec4) {
-      for (long q = tid; q < (total >> 2); q += kSelThreads) {
-        const uint4 k4 = reinterpret_cast<const uint4 *>(kb)[q];
-        if ((k4.x & pmask) == pval) atomicAdd(&h[(k4.x >> sh) & wm], 1u);
-        if ((k4.y & pmask) == pval) atomicAdd(&h[(k4.y >> sh) & wm], 1u);
-        if ((k4.z & pmask) == pval) atomicAdd(&h[(k4.z >> sh) & wm], 1u);
-        if ((k4.w & pmask) == pval) atomicAdd(&h[(k4.w >> sh) & wm], 1u);
+      // 8 loads in flight per thread: with one load per iteration a pass over the image's keys is 80
+      // dependent round trips (one workgroup per image: nothing else hides them)
+      const long nq = total >> 2;
+      for (long q0 = tid; q0 < nq; q0 += (long)kSelThreads * 8) {
+        uint4 kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long q = q0 + (long)u * kSelThreads;
+          kk[u] = q < nq ? reinterpret_cast<const uint4 *>(kb)[q] : make_uint4(~pval, ~pval, ~pval, ~pval);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (q0 + (long)u * kSelThreads < nq) {
+            const uint4 k4 = kk[u];
+            if ((k4.x & pmask) == pval) atomicAdd(&h[(k4.x >> sh) & wm], 1u);
+            if ((k4.y & pmask) == pval) atomicAdd(&h[(k4.y >> sh) & wm], 1u);
+            if ((k4.z & pmask) == pval) atomicAdd(&h[(k4.z >> sh) & wm], 1u);
+            if ((k4.w & pmask) == pval) atomicAdd(&h[(k4.w >> sh) & wm], 1u);
+          }
+        }
       }
     } else {
       for (long i = tid; i < total; i += kSelThreads) {
@@ -206,9 +241,22 @@ decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ h
       }
     };
     if (vec4) {
-      for (long q = tid; q < (total >> 2); q += kSelThreads) {
-        const uint4 k4 = reinterpret_cast<const uint4 *>(kb)[q];
-        take(k4.x, q * 4); take(k4.y, q * 4 + 1); take(k4.z, q * 4 + 2); take(k4.w, q * 4 + 3);
+      const long nq = total >> 2;
+      for (long q0 = tid; q0 < nq; q0 += (long)kSelThreads * 8) {
+        uint4 kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long q = q0 + (long)u * kSelThreads;
+          kk[u] = q < nq ? reinterpret_cast<const uint4 *>(kb)[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long q = q0 + (long)u * kSelThreads;
+          if (q < nq) {
+            const uint4 k4 = kk[u];
+            take(k4.x, q * 4); take(k4.y, q * 4 + 1); take(k4.z, q * 4 + 2); take(k4.w, q * 4 + 3);
+          }
+        }
       }
     } else {
       for (long i = tid; i < total; i += kSelThreads) take(kb[i], i);
@@ -311,7 +359,7 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   CDN_REQUIRE(K <= 1024 && K <= cat * H * W, CDN_ERR_UNSUPPORTED, "K = %d unsupported", K);
   CDN_REQUIRE(B <= 65535 && cat <= 65535 && cat * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED,
               "shape too large");
-  CDN_REQUIRE((size_t)(H + 2) * (W + 2) * 4 <= 128 * 1024, CDN_ERR_UNSUPPORTED,
+  CDN_REQUIRE((size_t)(H + 2) * (((W + 3) & ~3) + 8) * 4 <= 128 * 1024, CDN_ERR_UNSUPPORTED,
               "heat-map plane %lldx%lld does not fit LDS", (long long)H, (long long)W);
   CDN_REQUIRE(workspace_bytes >= cdn_ctdet_decode_workspace_bytes(B, cat, H, W) &&
                   (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
@@ -322,7 +370,7 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   // the per-image histograms live in the LAST bytes: zero them once, every call leaves them zero
   unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + workspace_bytes / 256 * 256 -
                                                 r((size_t)B * kBins * 4));
-  const size_t lds = (size_t)(H + 2) * (W + 2) * sizeof(float);
+  const size_t lds = (size_t)(H + 2) * (((W + 3) & ~3) + 8) * sizeof(float);
   (void)hipFuncSetAttribute((const void *)decode_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   decode_keys_kernel<<<dim3((unsigned)cat, (unsigned)B), kKeyThreads, lds, st>>>(heat, keys, hist, heat_out,
