@@ -542,9 +542,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   float *wl = reinterpret_cast<float *>(img + (size_t)cells * LPP);
   float *sl = wl + CCH * 9;
   float *red = sl + HWl;
-  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f;
+  float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f, xr_ = 1.f;
   if (XQ) {
     xs = reinterpret_cast<const float *>(xq)[2];
+    xr_ = __fdiv_rn(1.0f, xs);   // Markstein division in fake_quant_r
     xz = reinterpret_cast<const float *>(xq)[3];
   }
   if (SQ) {
@@ -582,10 +583,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         if (q < total) {
           float4 t = v[u];
           if (XQ) {
-            t.x = fake_quant(t.x, xs, xz);
-            t.y = fake_quant(t.y, xs, xz);
-            t.z = fake_quant(t.z, xs, xz);
-            t.w = fake_quant(t.w, xs, xz);
+            t.x = cdn::fake_quant_r(t.x, xs, xz, xr_);
+            t.y = cdn::fake_quant_r(t.y, xs, xz, xr_);
+            t.z = cdn::fake_quant_r(t.z, xs, xz, xr_);
+            t.w = cdn::fake_quant_r(t.w, xs, xz, xr_);
           }
           img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] = t;
         }
@@ -616,7 +617,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int pix = j * 4 + e;
-              const float t = XQ ? fake_quant(e4[e], xs, xz) : e4[e];
+              const float t = XQ ? cdn::fake_quant_r(e4[e], xs, xz, xr_) : e4[e];
               imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = live ? t : 0.0f;
             }
           }
@@ -637,7 +638,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         for (int e = 0; e < 4; ++e) {
           const int pix = j * 4 + e;
           if (pix < HWl)
-            imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = XQ ? fake_quant(v[e], xs, xz) : v[e];
+            imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = XQ ? cdn::fake_quant_r(v[e], xs, xz, xr_) : v[e];
         }
       }
     }
