@@ -19,6 +19,7 @@
 #include "cdn_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -32,56 +33,59 @@ __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + e
 __global__ void __launch_bounds__(kKeyThreads)
 decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
                    unsigned *__restrict__ hist, float *__restrict__ heat_out, int cat, int H, int W,
-                   int apply_sigmoid) {
-  // [(H + 2)][Wp] with a -inf border; Wp = W + 8 and the interior starts at column 4, so that every row of
-  // the interior is 16-byte aligned: a thread handles 4 consecutive pixels with 3 ds_read_b128 + 6 ds_read_b32
+                   int apply_sigmoid, int RB) {
+  // One workgroup = (class plane, band of RB rows).  LDS: [(RB + 2)][Wp] with a -inf border where the image
+  // ends (band halo rows are loaded); Wp = W + 8 and the interior starts at column 4, so that every interior
+  // row is 16-byte aligned: a thread handles 4 consecutive pixels with 3 ds_read_b128 + 6 ds_read_b32
   // (9 scalar reads per PIXEL, each waited for, made this phase 440 cycles per pixel and wave in the ISA)
   extern __shared__ __attribute__((aligned(16))) float plane[];
   __shared__ unsigned lh[kBins];
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int y0 = blockIdx.z * RB, y1 = min(H, y0 + RB), nr = y1 - y0;      // own rows [y0, y1)
   const int HW = H * W, Wp = ((W + 3) & ~3) + 8;
   const float *hp = heat + ((long)b * cat + c) * HW;
   unsigned *kp = keys + ((long)b * cat + c) * HW;
   float *op = heat_out ? heat_out + ((long)b * cat + c) * HW : nullptr;
   for (int i = tid; i < kBins; i += kKeyThreads) lh[i] = 0;
-  for (int i = tid; i < 2 * (W + 2 + H); i += kKeyThreads) {   // the -inf border (max_pool2d padding)
-    int cell;
-    if (i < W + 2) cell = 3 + i;                                            // row -1, columns -1 .. W
-    else if (i < 2 * (W + 2)) cell = (H + 1) * Wp + 3 + (i - (W + 2));      // row H
-    else if (i < 2 * (W + 2) + H) cell = (i - 2 * (W + 2) + 1) * Wp + 3;    // column -1
-    else cell = (i - 2 * (W + 2) - H + 1) * Wp + 4 + W;                     // column W
-    plane[cell] = -INFINITY;
-  }
+  // LDS row r holds image row y0 - 1 + r.  -inf: columns -1 and W of every row; whole rows outside the image
+  for (int i = tid; i < 2 * (nr + 2); i += kKeyThreads)
+    plane[(i >> 1) * Wp + ((i & 1) ? 4 + W : 3)] = -INFINITY;
+  if (y0 == 0)
+    for (int i = tid; i < W; i += kKeyThreads) plane[4 + i] = -INFINITY;
+  if (y1 == H)
+    for (int i = tid; i < W; i += kKeyThreads) plane[(nr + 1) * Wp + 4 + i] = -INFINITY;
+  const int ylo = max(y0 - 1, 0), yhi = min(y1 + 1, H);                    // rows to load
   const bool vec = (W & 3) == 0;
   if (vec) {                                    // 16-byte loads, 8 in flight per thread
-    const int quads = HW >> 2;
-    for (int base = 0; base < quads; base += kKeyThreads * 8) {
+    const int q_lo = (ylo * W) >> 2, q_hi = (yhi * W) >> 2;
+    for (int base = q_lo; base < q_hi; base += kKeyThreads * 8) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int q = base + u * kKeyThreads + tid;
-        v[u] = q < quads ? reinterpret_cast<const float4 *>(hp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = q < q_hi ? reinterpret_cast<const float4 *>(hp)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int q = base + u * kKeyThreads + tid;
-        if (q < quads) {
+        if (q < q_hi) {
           float4 t = v[u];
           if (apply_sigmoid) {
             t.x = sigmoidf_ref(t.x); t.y = sigmoidf_ref(t.y); t.z = sigmoidf_ref(t.z); t.w = sigmoidf_ref(t.w);
           }
           const int p = q * 4, y = p / W, x = p - y * W;
-          *reinterpret_cast<float4 *>(plane + (y + 1) * Wp + 4 + x) = t;
-          if (op) reinterpret_cast<float4 *>(op)[q] = t;
+          *reinterpret_cast<float4 *>(plane + (y - y0 + 1) * Wp + 4 + x) = t;
+          if (op && y >= y0 && y < y1) reinterpret_cast<float4 *>(op)[q] = t;   // halo rows: their own band
         }
       }
     }
   } else {
-    for (int p = tid; p < HW; p += kKeyThreads) {
+    for (int p = ylo * W + tid; p < yhi * W; p += kKeyThreads) {
       float v = hp[p];
       if (apply_sigmoid) v = sigmoidf_ref(v);
-      plane[(p / W + 1) * Wp + 4 + p % W] = v;
-      if (op) op[p] = v;
+      const int y = p / W;
+      plane[(y - y0 + 1) * Wp + 4 + p % W] = v;
+      if (op && y >= y0 && y < y1) op[p] = v;
     }
   }
   __syncthreads();
@@ -99,9 +103,9 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
     return k;
   };
   if (vec) {
-    for (int q = tid; q < (HW >> 2); q += kKeyThreads) {
+    for (int q = ((y0 * W) >> 2) + tid; q < ((y1 * W) >> 2); q += kKeyThreads) {
       const int p = q * 4, y = p / W, x = p - y * W;
-      const float *ctr = plane + (y + 1) * Wp + 4 + x;
+      const float *ctr = plane + (y - y0 + 1) * Wp + 4 + x;
       float hm[3][4];                           // horizontal 3-maxima of the three rows
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -122,9 +126,9 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
       reinterpret_cast<uint4 *>(kp)[q] = k4;
     }
   } else {
-    for (int p = tid; p < HW; p += kKeyThreads) {
+    for (int p = y0 * W + tid; p < y1 * W; p += kKeyThreads) {
       const int y = p / W, x = p - y * W;
-      const float *q = plane + (y + 1) * Wp + 4 + x;
+      const float *q = plane + (y - y0 + 1) * Wp + 4 + x;
       float m = fmaxf(fmaxf(q[-Wp - 1], q[-Wp]), fmaxf(q[-Wp + 1], q[-1]));
       m = fmaxf(m, fmaxf(fmaxf(q[1], q[Wp - 1]), fmaxf(q[Wp], q[Wp + 1])));
       kp[p] = key_from(q[0], fmaxf(m, q[0]));
@@ -359,8 +363,9 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   CDN_REQUIRE(K <= 1024 && K <= cat * H * W, CDN_ERR_UNSUPPORTED, "K = %d unsupported", K);
   CDN_REQUIRE(B <= 65535 && cat <= 65535 && cat * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED,
               "shape too large");
-  CDN_REQUIRE((size_t)(H + 2) * (((W + 3) & ~3) + 8) * 4 <= 128 * 1024, CDN_ERR_UNSUPPORTED,
-              "heat-map plane %lldx%lld does not fit LDS", (long long)H, (long long)W);
+  const size_t wp_bytes = (size_t)(((W + 3) & ~3) + 8) * 4;
+  CDN_REQUIRE(3 * wp_bytes <= 128 * 1024, CDN_ERR_UNSUPPORTED, "heat-map row of %lld pixels does not fit LDS",
+              (long long)W);
   CDN_REQUIRE(workspace_bytes >= cdn_ctdet_decode_workspace_bytes(B, cat, H, W) &&
                   (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
               CDN_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
@@ -370,12 +375,18 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   // the per-image histograms live in the LAST bytes: zero them once, every call leaves them zero
   unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + workspace_bytes / 256 * 256 -
                                                 r((size_t)B * kBins * 4));
-  const size_t lds = (size_t)(H + 2) * (((W + 3) & ~3) + 8) * sizeof(float);
+  // row bands: ~36 KiB of plane per workgroup (3 workgroups per CU with the histogram), at least 8 rows
+  static const int kb_kib = getenv("CDN_KEYS_KIB") ? atoi(getenv("CDN_KEYS_KIB")) : 36;   // tuning knob
+  int RB = (int)std::max<long>(8, (long)((size_t)kb_kib * 1024 / wp_bytes) - 2);
+  RB = (int)std::min<long>(RB, H);
+  const int nbands = (int)cdn::ceil_div(H, RB);
+  RB = (int)cdn::ceil_div(H, nbands);                       // balanced bands
+  const size_t lds = (size_t)(RB + 2) * wp_bytes;
+  CDN_REQUIRE(lds <= 128 * 1024, CDN_ERR_UNSUPPORTED, "heat-map band does not fit LDS");
   (void)hipFuncSetAttribute((const void *)decode_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  decode_keys_kernel<<<dim3((unsigned)cat, (unsigned)B), kKeyThreads, lds, st>>>(heat, keys, hist, heat_out,
-                                                                         (int)cat, (int)H, (int)W,
-                                                                         apply_sigmoid);
+  decode_keys_kernel<<<dim3((unsigned)cat, (unsigned)B, (unsigned)nbands), kKeyThreads, lds, st>>>(
+      heat, keys, hist, heat_out, (int)cat, (int)H, (int)W, apply_sigmoid, RB);
   int rc = cdn::check_launch("ctdet decode keys");
   if (rc) return rc;
   decode_select_kernel<<<(unsigned)B, kSelThreads, 0, st>>>(keys, hist, wh, reg, dets, (int)cat, (int)H,
