@@ -27,6 +27,8 @@ _SIGNATURES = {
     "cdn_modulated_deform_conv_backward": (_i, [_vp] * 11 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),
     "cdn_codenet_scale_forward": (_i, [_vp] * 4 + [_i64] * 4 + [_f, _f, _vp]),
     "cdn_codenet_dw_forward": (_i, [_vp] * 4 + [_i64] * 4 + [_vp]),
+    "cdn_codenet_dw_backward_supported": (_i, [_i64, _i64]),
+    "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_dw_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
     "cdn_codenet_pointwise_forward": (_i, [_vp] * 6 + [_i64] * 4 + [_i, _vp]),
     "cdn_quantact_state_bytes": (ctypes.c_size_t, []),
@@ -106,11 +108,16 @@ def last_error():
 
 
 class NativeError(RuntimeError):
-    pass
+    status = 0
+
+
+CDN_ERR_UNSUPPORTED = -5
 
 
 def check(rc, what):
     """Map a cdn_status to the exception types the reference raises
     (AT_CHECK/AT_ERROR -> RuntimeError, dcn_deform_conv_cuda.cpp:61-149)."""
     if rc != 0:
-        raise NativeError("%s failed (cdn_status %d): %s" % (what, rc, last_error()))
+        err = NativeError("%s failed (cdn_status %d): %s" % (what, rc, last_error()))
+        err.status = rc
+        raise err

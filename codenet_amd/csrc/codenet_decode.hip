@@ -31,9 +31,12 @@ constexpr int kKeyThreads = 512;
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __global__ void __launch_bounds__(kKeyThreads)
-decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
-                   unsigned *__restrict__ hist, float *__restrict__ heat_out, int cat, int H, int W,
-                   int apply_sigmoid, int RB) {
+decode_keys_kernel(const float *heat, unsigned *__restrict__ keys, unsigned *__restrict__ hist,
+                   float *heat_out, int cat, int H, int W, int apply_sigmoid, int RB) {
+  // heat_out may alias heat ONLY when a workgroup owns whole planes (one band) or no sigmoid is applied
+  // (then the store rewrites the value it read); the host entry routes the other in-place case through
+  // sigmoid_store_kernel instead, because a neighbouring band's halo rows would otherwise be read after
+  // this band has overwritten them with their sigmoid (no __restrict__ on the two pointers).
   // One workgroup = (class plane, band of RB rows).  LDS: [(RB + 2)][Wp] with a -inf border where the image
   // ends (band halo rows are loaded); Wp = W + 8 and the interior starts at column 4, so that every interior
   // row is 16-byte aligned: a thread handles 4 consecutive pixels with 3 ds_read_b128 + 6 ds_read_b32
@@ -138,6 +141,21 @@ decode_keys_kernel(const float *__restrict__ heat, unsigned *__restrict__ keys,
   __syncthreads();
   for (int i = tid; i < kBins; i += kKeyThreads)
     if (lh[i]) atomicAdd(&hist[(long)b * kBins + i], lh[i]);
+}
+
+// In-place sigmoid for the banded case (heat_out aliases heat): runs AFTER decode_keys_kernel in stream
+// order, so every band has read its halo rows as logits before any of them is overwritten.
+__global__ void __launch_bounds__(256) sigmoid_store_kernel(const float *in, float *out, long n) {
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      float4 t = *reinterpret_cast<const float4 *>(in + i);
+      t.x = sigmoidf_ref(t.x); t.y = sigmoidf_ref(t.y); t.z = sigmoidf_ref(t.z); t.w = sigmoidf_ref(t.w);
+      *reinterpret_cast<float4 *>(out + i) = t;
+    } else {
+      for (long j = i; j < n; ++j) out[j] = sigmoidf_ref(in[j]);
+    }
+  }
 }
 
 // From the top bin down: the bin D with (count of bins > D) < need <= (count of bins >= D), by a block-wide
@@ -385,10 +403,23 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   CDN_REQUIRE(lds <= 128 * 1024, CDN_ERR_UNSUPPORTED, "heat-map band does not fit LDS");
   (void)hipFuncSetAttribute((const void *)decode_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
+  // heat_out overlapping heat with a sigmoid and more than one band per plane: a band's halo rows belong to
+  // its neighbours, which may already have stored their sigmoid -- keep the keys kernel read-only there and
+  // store the sigmoid from a second kernel behind it
+  const long n_heat = (long)(B * cat * H * W);
+  const bool overlap = heat_out && heat_out < heat + n_heat && heat < heat_out + n_heat;
+  const bool deferred = overlap && apply_sigmoid && nbands > 1;
+  CDN_REQUIRE(!overlap || heat_out == heat, CDN_ERR_ARG, "heat_out partially overlaps heat");
   decode_keys_kernel<<<dim3((unsigned)cat, (unsigned)B, (unsigned)nbands), kKeyThreads, lds, st>>>(
-      heat, keys, hist, heat_out, (int)cat, (int)H, (int)W, apply_sigmoid, RB);
+      heat, keys, hist, deferred ? nullptr : heat_out, (int)cat, (int)H, (int)W, apply_sigmoid, RB);
   int rc = cdn::check_launch("ctdet decode keys");
   if (rc) return rc;
+  if (deferred) {
+    const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(n_heat, 1024), 4096);
+    sigmoid_store_kernel<<<blocks, 256, 0, st>>>(heat, heat_out, n_heat);
+    rc = cdn::check_launch("ctdet decode in-place sigmoid");
+    if (rc) return rc;
+  }
   decode_select_kernel<<<(unsigned)B, kSelThreads, 0, st>>>(keys, hist, wh, reg, dets, (int)cat, (int)H,
                                                            (int)W, cat_spec_wh ? (int)(2 * cat) : 2, K);
   return cdn::check_launch("ctdet decode select");

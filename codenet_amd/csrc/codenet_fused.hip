@@ -2403,6 +2403,27 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
                   3 * r(cdn::kArriveWords * 4));
 }
 
+// LDS budget of the gather kernel decides the channel chunk (64 or 32 channels x the whole stored plane);
+// 0: the plane does not fit
+static int stage_channel_chunk(int Hl, int Wl) {
+  const size_t cells = (size_t)(Hl + 1) * (Wl + 1);   // + the zero row and zero column
+  const long lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (long)Hl * Wl * 4;   // scale plane, weights, scratch
+  if (lds_max <= 0) return 0;
+  if (cells * 64 * 4 <= (size_t)lds_max) return 64;
+  if (cells * 32 * 4 <= (size_t)lds_max) return 32;
+  return 0;
+}
+
+extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (x_up != 0 && x_up != 1)) return 0;
+  if (x_up && ((H & 1) || (W & 1))) return 0;
+  if (x_nhwc && (C & 3)) return 0;
+  if (N > 65535 || N * C * H * W >= (1ll << 31)) return 0;
+  if ((H >> x_up) > 4096 || (W >> x_up) > 4096) return 0;
+  const int cch = stage_channel_chunk((int)(H >> x_up), (int)(W >> x_up));
+  return cch != 0 && cdn::ceil_div(C, cch) * N <= kMaxPartials;
+}
+
 extern "C" int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
@@ -2451,13 +2472,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
            *rst = static_cast<unsigned *>(r_state);
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
 
-  // LDS budget of the gather kernel decides the channel chunk
-  const size_t cells = (size_t)(Hl + 1) * (Wl + 1);   // + the zero row and zero column
-  // scale plane, weights and reduction scratch share the 160 KiB
-  const size_t lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (size_t)HWl * 4;
-  int cch = 0;
-  if (cells * 64 * 4 <= lds_max) cch = 64;
-  else if (cells * 32 * 4 <= lds_max) cch = 32;
+  const int cch = (Hl <= 4096 && Wl <= 4096) ? stage_channel_chunk(Hl, Wl) : 0;
   CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
               "stored plane %dx%d too large for the LDS-resident gather (max ~1250 pixels)", Hl, Wl);
 

@@ -380,6 +380,9 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   int e = 0;
   (void)frexpf(gmax, &e);                 // gmax < 2^e
   if (!(gmax > 0.0f) || !(gmax < INFINITY)) e = 0;
+  // 2^(40-e) and 2^(e-40) must both be finite, normal floats: for gradients below ~2^-86 the scale would
+  // overflow to inf (0 * inf = NaN in the scatter); clamp -- such contributions keep >= 2^-126 resolution
+  e = max(-86, min(e, 126 + 40));
   const float scale = ldexpf(1.0f, 40 - e), inv_scale = ldexpf(1.0f, e - 40);
   {   // stage x: lane <-> channel, 4 pixels per thread, conflict-free scalar LDS stores
     const int quads = (HW + 3) >> 2;
@@ -646,6 +649,13 @@ extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, 
   pointwise_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(d, w_pw, bias, ep_scale, ep_shift, y,
                                                              (int)C, (int)Co, (int)HW, relu);
   return cdn::check_launch("codenet pointwise forward");
+}
+
+extern "C" int cdn_codenet_dw_backward_supported(int64_t H, int64_t W) {
+  if (H <= 0 || W <= 0 || H > 65535 || W > 65535) return 0;
+  const size_t cells = (size_t)(H + 1) * (W + 1);
+  if (cells * 2 * 12 + 2 * 9 * 4 + 128 <= (size_t)160 * 1024 - 512) return 1;      // lanes <-> channels kernel
+  return (150 * 1024 / 4 - 64) / (2 * (H + 2) * (W + 2) + 18) >= 1;                 // bordered-plane kernel
 }
 
 extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,

@@ -106,8 +106,35 @@ class PoseShuffleNetV2(nn.Module):
         self._fpath = self._fheads = self._fbackbone = None
         return self
 
+    def _fused_ok(self, x):
+        """The fused schedules implement the reference's default QuantAct settings and stored planes that fit
+        the LDS-resident gather (inputs up to ~544 px); anything else (--act-percentile, symmetric activations,
+        larger resolutions) keeps the module-by-module path -- decided BEFORE any kernel runs, so no QuantAct
+        state is half-updated.  Cached per (input shape, QuantAct configuration)."""
+        from . import pipeline
+        from .portable_quantizer.quant_modules import QuantAct
+        cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat)
+                    for a in self.modules() if isinstance(a, QuantAct))
+        key = (tuple(x.shape), cfg)
+        cache = self.__dict__.setdefault("_fused_ok_cache", {})
+        if key not in cache:
+            Nb, _, R, R2 = x.shape
+            stem = self.layer0[0].conv if hasattr(self.layer0[0], "conv") else self.layer0[0]
+            down = stem.stride[0] * (2 if any(isinstance(m, nn.MaxPool2d) for m in self.layer0.modules()) else 1)
+            h, w = R // (down * 8), R2 // (down * 8)
+            ok = (R % (down * 8) == 0 and R2 % (down * 8) == 0 and h > 0 and w > 0
+                  and pipeline.FusedHotPath.supported(self.deconv_layers, (Nb, self.channels[4], h, w))
+                  and pipeline.FusedHeads.supported({hd: getattr(self, hd) for hd in self.heads}))
+            if not ok:
+                import warnings
+                warnings.warn("codenet_amd: enable_fused() does not cover this model configuration / input "
+                              "shape %s; running the module-by-module path" % (tuple(x.shape),))
+            cache[key] = ok
+        return cache[key]
+
     def forward(self, x):
-        if getattr(self, "_fused", False) and x.is_cuda and not torch.is_grad_enabled():
+        if getattr(self, "_fused", False) and x.is_cuda and not torch.is_grad_enabled() \
+                and self._fused_ok(x):
             from . import pipeline
             if self._fpath is None:
                 self._fpath = pipeline.FusedHotPath(self.deconv_layers)
@@ -217,6 +244,14 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100):
 
 
 _decode_ws = {}
+_sigmoid_bufs = {}
+
+
+def _sigmoid_buffer(hm):
+    key = (hm.device, tuple(hm.shape), torch.cuda.current_stream(hm.device).cuda_stream)
+    if key not in _sigmoid_bufs:
+        _sigmoid_bufs[key] = torch.empty_like(hm)
+    return _sigmoid_bufs[key]
 
 
 def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=False,
@@ -232,9 +267,12 @@ def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigm
     B, cat, H, W = heat.shape
     lib = N_.lib()
     need = lib.cdn_ctdet_decode_workspace_bytes(B, cat, H, W)
-    key = (heat.device, need)
+    # one workspace per (device, size, stream): its histograms must be zero at entry and are left zero by
+    # every call, so concurrent calls on different streams must not share one; entries are never freed
+    # (a captured graph keeps the raw pointer)
+    stream = torch.cuda.current_stream(heat.device)
+    key = (heat.device, need, stream.cuda_stream)
     if key not in _decode_ws:
-        _decode_ws.clear()
         _decode_ws[key] = torch.zeros(need // 4 + 64, dtype=torch.int32, device=heat.device)
     ws = _decode_ws[key]
     ws_ptr = (ws.data_ptr() + 255) // 256 * 256
@@ -242,7 +280,7 @@ def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigm
     rc = lib.cdn_ctdet_decode(heat.data_ptr(), wh.data_ptr(), reg.data_ptr() if reg is not None else None,
                               B, cat, H, W, int(bool(cat_spec_wh)), K, int(bool(apply_sigmoid)),
                               heat_out.data_ptr() if heat_out is not None else None, dets.data_ptr(),
-                              ws_ptr, need, torch.cuda.current_stream(heat.device).cuda_stream)
+                              ws_ptr, need, stream.cuda_stream)
     N_.check(rc, "cdn_ctdet_decode")
     return dets
 
@@ -258,8 +296,13 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
         reg = output["reg"] if reg_offset else None
         if native_decode and not flip_test:
             hm = output["hm"]
+            # the reference's in-place hm.sigmoid_() (ctdet.py:32): the sigmoid goes to a second static buffer
+            # that replaces output["hm"] (in place it would cost a second kernel, see cdn_ctdet_decode)
+            sig = _sigmoid_buffer(hm)
             dets = ctdet_decode_native(hm, output["wh"], reg=reg, cat_spec_wh=cat_spec_wh, K=K,
-                                       apply_sigmoid=True, heat_out=hm)      # in place, like sigmoid_()
+                                       apply_sigmoid=True, heat_out=sig)
+            output = dict(output)
+            output["hm"] = sig
             return output, dets
         hm = output["hm"].sigmoid_()
         wh = output["wh"]

@@ -111,6 +111,8 @@ class _CodenetDW(Function):
         x, s, w_dw = ctx.saved_tensors
         gd = gd.contiguous()
         Nb, C, H, W = x.shape
+        if not N_.lib().cdn_codenet_dw_backward_supported(H, W):
+            return _dw_backward_generic(x, s, w_dw, gd, ctx.needs_input_grad)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gs = torch.empty_like(s) if ctx.needs_input_grad[1] else None
         gw = torch.zeros_like(w_dw) if ctx.needs_input_grad[2] else None
@@ -118,6 +120,24 @@ class _CodenetDW(Function):
                                               Nb, C, H, W, _stream(x))
         N_.check(rc, "cdn_codenet_dw_backward")
         return gx, gs, gw
+
+
+def _dw_backward_generic(x, s, w_dw, gd, needs):
+    """Planes too large for the LDS-resident backward (H*W above ~17k pixels): the same gradients through
+    the generic deform-conv entry points (cdn_deform_conv_backward_input / _parameters) with the offsets
+    the reference materialises, offset = anchor * (s - 1) (modules/dcn_deform_conv.py:319-325)."""
+    from .functions.dcn_deform_conv import deform_conv
+    C = x.shape[1]
+    anchor = torch.tensor([v for dy in (-1, 0, 1) for dx in (-1, 0, 1) for v in (dy, dx)],
+                          dtype=x.dtype, device=x.device).view(1, 18, 1, 1)
+    with torch.enable_grad():
+        xg = x.detach().requires_grad_(bool(needs[0]))
+        sg = s.detach().requires_grad_(bool(needs[1]))
+        wg = w_dw.detach().requires_grad_(bool(needs[2]))
+        d = deform_conv(xg, anchor * (sg - 1), wg, 1, 1, 1, C, 1)
+        wanted = [t for t, n in zip((xg, sg, wg), needs) if n]
+        got = iter(torch.autograd.grad(d, wanted, gd)) if wanted else iter(())
+    return tuple(next(got) if n else None for n in needs)
 
 
 codenet_dw = _CodenetDW.apply

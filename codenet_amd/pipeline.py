@@ -97,18 +97,74 @@ def broadcast_parameters(net, src=0):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    tensors = [p.data for p in net.parameters()] + [b.data for b in net.buffers()
-                                                    if b.dtype.is_floating_point]
+    tensors = list(net.parameters()) + [b for b in net.buffers() if b.dtype.is_floating_point]
     if not tensors:
         return 0
-    flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    dist.broadcast(flat, src=src)
-    off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
-        off += n
+    with torch.no_grad():
+        flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in tensors:
+            # copy into the parameter / buffer itself (not .data): the in-place write bumps the tensor's
+            # version counter, which is what the derived-weight caches (fake-quantised, folded, int8 forms,
+            # BN affines) are keyed on
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
     return flat.numel() * 4
+
+
+def gather_detections(dets, dst=None):
+    """Per-batch collection of every rank's detections [B, K, 6] (collective 2; the
+    reference's only mechanism is DataParallel's gather, lib/models/data_parallel.py:64-84,120-129).
+    all_gather over RCCL (gloo in the CPU tests); shards may differ in size by one image (shard_range),
+    so they are padded to the largest.  Returns [sum B_r, K, 6] in rank order on every rank (dst=None)
+    or only on rank dst (other ranks: None)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dets
+    world = dist.get_world_size()
+    nb = torch.tensor([dets.shape[0]], device=dets.device, dtype=torch.int64)
+    counts = [torch.zeros_like(nb) for _ in range(world)]
+    dist.all_gather(counts, nb)
+    counts = [int(c.item()) for c in counts]
+    bmax = max(counts)
+    pad = dets if dets.shape[0] == bmax else torch.cat(
+        [dets, dets.new_zeros((bmax - dets.shape[0],) + tuple(dets.shape[1:]))])
+    pad = pad.contiguous()
+    if dst is None:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)] if dist.get_rank() == dst else None
+        dist.gather(pad, parts, dst=dst)
+        if parts is None:
+            return None
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
+def act_fusable(act):
+    """The fused schedules implement the reference's default QuantAct: plain batch min/max tracking,
+    asymmetric, quantising (quant_modules.py:163-225 with percentile=False).  --act-percentile, symmetric
+    activations and full_precision_flag stay on the module path."""
+    return (act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag)
+
+
+def uniform_act_settings(acts, what):
+    """(bits, momentum, running) shared by the QuantActs of one fused C call, which takes them once."""
+    acts = [a for a in acts if a is not None]
+    if not acts:
+        return 8, 0.99, 0
+    for a in acts:
+        if not act_fusable(a):
+            raise NotImplementedError("%s: QuantAct(percentile=%s, quant_mode=%s, full_precision_flag=%s) is not "
+                                      "implemented by the fused schedule; use the module path"
+                                      % (what, a.percentile, a.quant_mode, a.full_precision_flag))
+    st = {(a.activation_bit, float(a.momentum), int(bool(a.running_stat))) for a in acts}
+    if len(st) != 1:
+        raise NotImplementedError("%s: the QuantActs of one fused call must share activation_bit / momentum / "
+                                  "running_stat (got %s)" % (what, sorted(st)))
+    return st.pop()
 
 
 def shard_range(total, rank, world):
@@ -136,6 +192,23 @@ def algorithmic_bytes(batch, input_res=512, w2=False, fused=False, act_bytes=4):
     return tot, per
 
 
+def bn_affine(cache, bn):
+    """BatchNorm (eval) as a per-channel affine, cached until one of its tensors changes (keyed on
+    data_ptr + version like the weight caches; refreshed in place so captured graphs stay valid)."""
+    from .portable_quantizer.quant_modules import refresh_in_place
+    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version, t.device) for t in src)
+    ent = cache.get(id(bn))
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            inv = torch.rsqrt(bn.running_var + bn.eps)
+            es = (bn.weight * inv).contiguous()
+            new = (es, (bn.bias - bn.running_mean * es).contiguous())
+            ent = (key, refresh_in_place(ent[1] if ent else None, new))
+        cache[id(bn)] = ent
+    return ent[1]
+
+
 class FusedHotPath:
     """Runs a ``deconv_layers`` Sequential (fp32 or W4A8, built from the modules of this package)
     as the fused per-stage kernel schedule of codenet_fused.hip: one C-ABI call per stage, then one
@@ -161,6 +234,47 @@ class FusedHotPath:
         self._affine = {}
         self.stage_hook = None        # diagnostics: called as stage_hook(stage_shape_dict) after each stage
 
+    @staticmethod
+    def supported(deconv_layers, input_shape=None):
+        """True when the fused schedule implements this Sequential (and, given the NCHW shape of its input,
+        this geometry): callers keep the module path otherwise."""
+        from . import _native as N_
+        from .portable_quantizer.quant_modules import QuantAct, QuantDeformConvWithOffsetScaleBoundPositive
+        mods = list(deconv_layers)
+        if not mods:
+            return False
+        quantized = isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive)
+        step = 3 if quantized else 4
+        if len(mods) % step:
+            return False
+        shape = tuple(input_shape) if input_shape is not None else None
+        for i in range(0, len(mods), step):
+            st = mods[i:i + step]
+            if not (isinstance(st[-1], nn.Upsample) and st[-1].scale_factor in (2, 2.0)):
+                return False
+            if quantized:
+                if not (isinstance(st[0], QuantDeformConvWithOffsetScaleBoundPositive) and len(st[1]) == 2
+                        and isinstance(st[1][1], QuantAct)):
+                    return False
+                acts = (st[0].quant_act[1], st[0].quant_identity_deform, st[1][1])
+                try:
+                    uniform_act_settings(acts, "stage")
+                except NotImplementedError:
+                    return False
+                cout = st[0].quant_conv_channel_bn.conv.out_channels
+            else:
+                if not (isinstance(st[0], DeformConvWithOffsetScaleBoundPositive)
+                        and isinstance(st[1], nn.BatchNorm2d) and hasattr(st[0], "conv_channel")):
+                    return False
+                cout = st[0].out_channels
+            if shape is not None:
+                Nb, C, H, W = shape
+                up = 0 if i == 0 else 1
+                if not N_.lib().cdn_codenet_stage_supported(Nb, C, H, W, 0 if i == 0 else 1, up):
+                    return False
+                shape = (Nb, cout, 2 * H, 2 * W)
+        return True
+
     # -- per-stage parameter views -------------------------------------------------------------
     def _stage_params(self, st):
         if self.quantized:
@@ -175,12 +289,7 @@ class FusedHotPath:
                 bias=b_pw, ep_scale=None, ep_shift=None,
                 acts=(q.quant_act[1], q.quant_identity_deform, post[1]))
         op, bn = st[0], st[1]
-        key = id(st[0])
-        if key not in self._affine:      # BN as a per-channel affine (inference: derived once)
-            inv = torch.rsqrt(bn.running_var + bn.eps)
-            es = (bn.weight * inv).contiguous()
-            self._affine[key] = (es, (bn.bias - bn.running_mean * es).contiguous())
-        es, eh = self._affine[key]
+        es, eh = bn_affine(self._affine, bn)
         return dict(w_scale=op.conv_scale.weight.reshape(-1), b_scale=op.conv_scale.bias,
                     lo=op.conv_bound.min_val, hi=op.conv_bound.max_val, w_dw=op.conv.weight,
                     w_pw=op.conv_channel.weight.reshape(op.out_channels, -1), bias=None,
@@ -251,14 +360,13 @@ class FusedHotPath:
                 p = self._stage_params(st)
                 ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
                 a = []
-                bits, mom, running = 8, 0.99, 0
+                bits, mom, running = uniform_act_settings(p["acts"], "FusedHotPath stage")
                 for act in p["acts"]:
                     if act is None:
                         a += [None, None, None]
                     else:
                         a += [act.x_min.data_ptr(), act.x_max.data_ptr(),
                               act._device_state(x.device).data_ptr()]
-                        bits, mom, running = act.activation_bit, act.momentum, int(act.running_stat)
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
                 rc = lib.cdn_codenet_stage_fused_forward(
                     cur.data_ptr(), cur_nhwc, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
@@ -318,12 +426,23 @@ class FusedHeads:
         self._affine = {}
 
     def _bn_affine(self, bn):
-        key = id(bn)
-        if key not in self._affine:
-            inv = torch.rsqrt(bn.running_var + bn.eps)
-            es = (bn.weight * inv).contiguous()
-            self._affine[key] = (es, (bn.bias - bn.running_mean * es).contiguous())
-        return self._affine[key]
+        return bn_affine(self._affine, bn)
+
+    @staticmethod
+    def supported(heads):
+        """True when every head is a form the fused schedule implements with the QuantAct settings it
+        implements (see act_fusable)."""
+        from .portable_quantizer.quant_modules import QuantDepthwiseNode
+        for mod in dict(heads).values():
+            if isinstance(mod, QuantDepthwiseNode):
+                if not (act_fusable(mod.quant_act1[1]) and act_fusable(mod.quant_act3[1])):
+                    return False
+            elif isinstance(mod, nn.Conv2d):
+                if tuple(mod.kernel_size) != (1, 1):
+                    return False
+            elif not (isinstance(mod, nn.Sequential) and len(mod) == 7):
+                return False
+        return True
 
     def _params(self, mod):
         """-> list of layer dicts in execution order."""
@@ -404,6 +523,9 @@ class FusedHeads:
         def act_args(act):
             if act is None:
                 return [None, None, None, 8, 0.99, 0]
+            if not act_fusable(act):
+                raise NotImplementedError("FusedHeads: this QuantAct configuration (percentile / symmetric / "
+                                          "full precision) is not implemented by the fused schedule")
             return [act.x_min.data_ptr(), act.x_max.data_ptr(), act._device_state(r.device).data_ptr(),
                     act.activation_bit, act.momentum, int(act.running_stat)]
 
@@ -591,6 +713,9 @@ class FusedBackbone:
                 for node in getattr(model, name):
                     ok = ok and isinstance(node, QuantBaseNode) and node.quant_act.quant_mode == "asymmetric" \
                         and node.quant_act2.quant_mode == "asymmetric"
+            if ok:      # plain min/max, asymmetric, quantising QuantActs only (--act-percentile: module path)
+                for part in (l0, model.layer1, model.layer2, model.layer3, l4):
+                    ok = ok and all(act_fusable(a) for a in part.modules() if isinstance(a, QuantAct))
             return bool(ok)
         except (AttributeError, IndexError, TypeError):
             return False

@@ -54,6 +54,23 @@ def _channel_range(w2d, percentile):
     return (torch.kthvalue(w2d, k=lo, dim=1).values, torch.kthvalue(w2d, k=hi, dim=1).values)
 
 
+def refresh_in_place(old, new):
+    """Derived tensors are cached per source version.  When a source changes, the new values are written
+    INTO the previously cached tensors wherever shape / dtype / device still match, so raw pointers held by a
+    captured HIP graph stay valid (and the graph sees the new weights); otherwise the entry is replaced."""
+    if isinstance(new, torch.Tensor):
+        if (isinstance(old, torch.Tensor) and old.shape == new.shape and old.dtype == new.dtype
+                and old.device == new.device and old.is_contiguous() and old.data_ptr() != new.data_ptr()
+                and not old.requires_grad):
+            old.copy_(new)
+            return old
+        return new
+    if isinstance(new, (tuple, list)):
+        olds = old if isinstance(old, (tuple, list)) and len(old) == len(new) else [None] * len(new)
+        return type(new)(refresh_in_place(o, n) for o, n in zip(olds, new))
+    return new
+
+
 class _WeightQuantizer:
     """Shared weight fake-quantisation of the three Quant*Conv modules + an inference cache."""
 
@@ -115,7 +132,7 @@ class _WeightQuantizer:
         cache = getattr(self, "_i8_cache", None)
         if cache is None or cache[0] != key:
             with torch.no_grad():
-                self._i8_cache = (key, compute())
+                self._i8_cache = (key, refresh_in_place(cache[1] if cache else None, compute()))
         return self._i8_cache[1]
 
     def _cached(self, key_tensors, compute):
@@ -125,8 +142,15 @@ class _WeightQuantizer:
         key = tuple((t.data_ptr(), t._version, t.device) for t in key_tensors)
         if self._wq_cache is None or self._wq_cache[0] != key:
             with torch.no_grad():
-                self._wq_cache = (key, compute())
+                old = self._wq_cache[1] if self._wq_cache else None
+                self._wq_cache = (key, refresh_in_place(old, compute()))
         return self._wq_cache[1]
+
+    def invalidate(self):
+        """Drop the derived-weight caches (needed only after writes that bypass the version counter, i.e.
+        through ``.data``)."""
+        self._wq_cache = None
+        self._i8_cache = None
 
 
 class QuantAct(Module):

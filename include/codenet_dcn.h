@@ -140,6 +140,7 @@ int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, fl
  * grad_w [C,1,3,3] is ACCUMULATED into (caller zero-fills).  Any of grad_x / grad_s / grad_w
  * may be NULL.  Requires the (H+2)x(W+2) plane to fit LDS twice (H*W up to ~17k pixels).
  * grad_s is dL/ds = sum_k (i-1)*dL/doff_y,k + (j-1)*dL/doff_x,k. */
+int cdn_codenet_dw_backward_supported(int64_t H, int64_t W);   /* 1: the plane fits; 0: use the generic path */
 int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
                             const float *grad_d, float *grad_x, float *grad_s, float *grad_w,
                             int64_t N, int64_t C, int64_t H, int64_t W, void *stream);
@@ -209,6 +210,10 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
  *             parameters are left in r_state for the consumer)
  * ---------------------------------------------------------------------------------------- */
 size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up);
+/* 1 when cdn_codenet_stage_fused_forward implements this geometry (the stored plane must fit the
+ * LDS-resident gather: ~1250 stored pixels, i.e. inputs up to ~544 px), 0 otherwise: callers then keep the
+ * module path (cdn_codenet_{scale,dw,pointwise}_forward, any plane size). */
+int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
@@ -378,8 +383,10 @@ int cdn_codenet_maxpool3x3s2_nhwc_forward(const float *a, const void *a_qstate, 
  * 8f row 2): 3x3 peak filter, top-K over all classes, reg / wh gather, boxes.
  *   heat [B][cat][H][W]  scores (after sigmoid), or logits with apply_sigmoid != 0
  *   wh   [B][2][H][W]    (cat_spec_wh != 0: [B][2*cat][H][W]);  reg [B][2][H][W] or NULL (-> +0.5)
- *   heat_out  NULL, or [B][cat][H][W] receiving the (sigmoid of the) input -- may alias heat: the
- *             in-place sigmoid_ of lib/detectors/ctdet.py:32
+ *   heat_out  NULL, or [B][cat][H][W] receiving the (sigmoid of the) input.  heat_out == heat is
+ *             allowed (the in-place sigmoid_ of lib/detectors/ctdet.py:32; with a sigmoid on planes that
+ *             are cut into row bands it is stored by a second kernel behind the key pass, because a
+ *             band's halo rows belong to its neighbours); a partial overlap is CDN_ERR_ARG
  *   dets [B][K][6] = x1, y1, x2, y2, score, class;  K <= 1024
  * Equal scores are ordered by ascending index class*H*W + y*W + x (torch.topk leaves it unspecified).
  * workspace: cdn_ctdet_decode_workspace_bytes(B,cat,H,W) bytes, 256-byte aligned; its LAST

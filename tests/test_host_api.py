@@ -238,9 +238,35 @@ def test_weight_cache_invalidated_by_in_place_update():
     qc.set_param(conv)
     with torch.no_grad():
         a = qc.quantized_weight()
+        a0, ptr = a.clone(), a.data_ptr()
         qc.weight.mul_(2.0)
         b = qc.quantized_weight()
-    assert a is not b and torch.allclose(b, 2 * a)
+    # refreshed IN PLACE: the pointer a captured HIP graph holds stays valid and sees the new values
+    assert b.data_ptr() == ptr and torch.allclose(b, 2 * a0)
+    # writes through .data bypass the version counter: invalidate() is the explicit way out
+    with torch.no_grad():
+        qc.weight.data.mul_(0.5)
+        assert torch.allclose(qc.quantized_weight(), 2 * a0)      # stale by construction
+        qc.invalidate()
+        assert torch.allclose(qc.quantized_weight(), a0)
+
+
+def test_broadcast_style_copy_bumps_versions_and_bn_affine_cache_follows():
+    """pipeline.broadcast_parameters copies into the parameters themselves (version bump), and the BN
+    affine caches of the fused schedules are keyed on versions -- loading a checkpoint after the first
+    fused call must not keep the old statistics."""
+    from codenet_amd import pipeline
+    bn = nn.BatchNorm2d(4).eval()
+    cache = {}
+    es0, eh0 = [t.clone() for t in pipeline.bn_affine(cache, bn)]
+    ptr = pipeline.bn_affine(cache, bn)[0].data_ptr()
+    with torch.no_grad():
+        bn.running_var.copy_(torch.full((4,), 4.0))
+        bn.running_mean.copy_(torch.full((4,), 1.0))
+    es1, eh1 = pipeline.bn_affine(cache, bn)
+    assert es1.data_ptr() == ptr
+    assert torch.allclose(es1, torch.full((4,), 1.0 / (4.0 + bn.eps) ** 0.5)) and not torch.allclose(es1, es0)
+    assert torch.allclose(eh1, -es1)
 
 
 @pytest.mark.reference

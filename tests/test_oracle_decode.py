@@ -110,3 +110,31 @@ def test_hip_decode_random_shapes(B, cat, H, W, K, spec, use_reg):
     o = OD.ctdet_decode(heat.numpy(), wh.numpy(), reg.numpy() if use_reg else None, spec, K)
     assert np.array_equal(d[..., 4:], o[..., 4:])
     assert np.abs(d[..., :4] - o[..., :4]).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 128, 128), (64, 128, 128), (3, 96, 130)])
+def test_hip_decode_in_place_sigmoid_banded_plane(B, H, W):
+    """heat_out == heat (the reference's hm.sigmoid_(), lib/detectors/ctdet.py:32) on planes that are cut
+    into row bands: a band's halo rows belong to its neighbours, so the sigmoid must not be stored before
+    every band has read them.  Peaks are planted on every row so that each band boundary carries some."""
+    from codenet_amd import harness
+    g = torch.Generator().manual_seed(77 + B)
+    cat, K = 20, 100
+    heat = torch.randn(B, cat, H, W, generator=g) * 0.5 - 3.0          # logits well below zero ...
+    ys = torch.arange(H)
+    for b in range(B):                                                    # ... and strong peaks on every row
+        xs = torch.randint(0, W, (H,), generator=g)
+        cs = torch.randint(0, cat, (H,), generator=g)
+        heat[b, cs, ys, xs] = 2.0 + torch.rand(H, generator=g)
+    wh, reg = torch.rand(B, 2, H, W, generator=g) * 9, torch.rand(B, 2, H, W, generator=g)
+    sg = torch.sigmoid(heat)
+    for _ in range(3):                                                    # timing dependent: repeat
+        buf = heat.cuda()
+        d = harness.ctdet_decode_native(buf, wh.cuda(), reg.cuda(), K=K, apply_sigmoid=True, heat_out=buf)
+        got = buf.cpu()
+        assert (got - sg).abs().max().item() < 1e-6                       # sigmoid applied exactly once
+        o = OD.ctdet_decode(got.numpy(), wh.numpy(), reg.numpy(), False, K)
+        d = d.cpu().numpy()
+        assert np.array_equal(d[..., 4:], o[..., 4:])                     # scores + classes: bit-exact
+        assert np.abs(d[..., :4] - o[..., :4]).max() < 1e-4
