@@ -1,20 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- images/sec of CoDeNet's deform hot path (the three up-sampling stages,
-``deconv_layers``) on MI355X.
+``deconv_layers``) on MI355X, plus the whole-network figure it is a part of.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic images whose stage-0 input is
-already resident in HBM.  Default workload = BASELINE.json configs[2]:
-CoDeNet1x config-c, 512x512, W4A8, batch 64 per GPU (weak scaling: every rank processes its own
-64 images; the only collective is the start-up RCCL broadcast of weights / BN stats / QuantAct
-ranges).  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, live HIP-event timing on
-its launch stream) and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
-workload; N = 1 only).
+N > 1: either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (the
+driver's way: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or run directly -- then this process starts
+the N ranks itself as CHILD processes before it has touched the GPU, waits for them and exits with their
+code.  The run fails (non-zero exit) unless exactly N ranks joined the RCCL process group.
+
+A "step" is one pass of the hot path over one batch of synthetic images whose stage-0 input is already
+resident in HBM: scale 1x1 -> QuantAct -> bilinear-gather depthwise 3x3 -> QuantAct -> pointwise 1x1 + folded
+BN -> ReLU -> (range of the) QuantAct, three times, handing the channels-last half-resolution tensor + its
+QuantAct state to the consumer (the native detection heads).  The NCHW / up-sampled copy a PyTorch consumer
+would need (``unpack``) is timed and reported separately (`with_unpack`), not part of the step.
+
+Default workload = BASELINE.json configs[2] ("cfg3"): CoDeNet1x config-c, 512x512, W4A8, batch 64 per GPU
+(weak scaling: every rank processes its own images; start-up RCCL broadcast of weights / BN statistics /
+QuantAct ranges; in the `e2e` leg a per-batch all_gather of the detections [B,100,6]).  --config cfg4 =
+configs[3] (CoDeNet2x, 32 images per GPU, global 256 at 8 GPUs), --config cfg2 = configs[1] (256x256 fp32,
+batch 32).
+
+Rank 0 prints ONE JSON line with
+  roofline          dominant kernel family (the gather), live HIP-event timing on its launch stream
+  cpu_baseline      the CPU oracle timed on a bounded sample of the same hot-path workload (N = 1 only)
+  e2e               whole network (native backbone + stages + heads) + native ctdet_decode as one HIP graph
+  cpu_baseline_e2e  whole model + decode on the CPU oracle path, batch 1 and 8, all cores and 1 thread
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,22 +39,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TF = 157.3
 
+PRESETS = {
+    "cfg2": dict(res=256, batch=32, w2=False, fp32=True),     # BASELINE configs[1]
+    "cfg3": dict(res=512, batch=64, w2=False, fp32=False),    # BASELINE configs[2] (the metric's config)
+    "cfg4": dict(res=512, batch=32, w2=True, fp32=False),     # BASELINE configs[3]: 256 images over 8 GPUs
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--w2", action="store_true", help="CoDeNet2x (stage-0 C = 2153)")
-    ap.add_argument("--fp32", action="store_true", help="fp32 hot path instead of W4A8")
+    ap.add_argument("--config", choices=sorted(PRESETS), default=None,
+                    help="preset of --res/--batch/--w2/--fp32 (default: cfg3 values)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--w2", action="store_true", default=None, help="CoDeNet2x (stage-0 C = 2153)")
+    ap.add_argument("--fp32", action="store_true", default=None, help="fp32 hot path instead of W4A8")
     ap.add_argument("--frozen", action="store_true",
                     help="freeze QuantAct ranges (default: reference-faithful running ranges)")
     ap.add_argument("--path", choices=["fused", "modules"], default="fused",
@@ -46,15 +68,58 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="fused path: launch eagerly instead of "
                     "replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-network leg")
     ap.add_argument("--cpu-images", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl == RCCL on ROCm; gloo only with --plumbing-only")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no kernels are launched and no rate is reported: exercises the launcher, the rendezvous, "
+                         "the start-up broadcast, the image sharding and the detections gather on CPU tensors "
+                         "(tests/test_distributed_cpu.py)")
+    a = ap.parse_args(argv)
+    base = dict(PRESETS[a.config or "cfg3"])
+    for k in ("batch", "res", "w2", "fp32"):
+        if getattr(a, k) is None:
+            setattr(a, k, base[k])
+    if a.backend == "gloo" and not a.plumbing_only:
+        ap.error("--backend gloo runs no kernels: use it with --plumbing-only")
+    return a
 
+
+# ---- launcher --------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """Start N ranks as child processes (torch.distributed.run, one rank per GPU) BEFORE this process touches
+    the GPU, and return their exit code.  Never exec: a child is spawned and waited for."""
+    import torch
+    if not args.plumbing_only:
+        have = torch.cuda.device_count()        # does not initialise the GPU runtime on this image
+        if have < args.gpus:
+            print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL needs it on this host driver)
+    return subprocess.call(cmd, env=env)
+
+
+# ---- CPU baselines (the only place bench.py touches oracle/) ------------------------------------------------
 
 def cpu_baseline(args, net_cpu):
     """The CPU oracle (oracle/ -- the reference has no CPU deform conv) timed
     on a bounded sample: `cpu_images` images of the same workload through the same three stages
     in the reference's algorithmic form (im2col gather + per-group contraction in C/OpenMP,
     torch-CPU conv2d / fake-quant around it).  kind = "port"."""
+    import torch
     import torch.nn.functional as F
     from codenet_amd import pipeline
     from oracle import dcn as O
@@ -91,7 +156,7 @@ def cpu_baseline(args, net_cpu):
         while True:
             run(x)
             reps += 1
-            if time.perf_counter() - t0 > 12.0 or reps >= 400:
+            if time.perf_counter() - t0 > 10.0 or reps >= 400:
                 break
         dt = time.perf_counter() - t0
     return {"value": n * reps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
@@ -99,17 +164,133 @@ def cpu_baseline(args, net_cpu):
                       % (reps, n, "fp32" if args.fp32 else "W4A8", args.res, args.res)}
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_e2e(args, budget_s=5.0):
+    """SURVEY.md section 8(d) CPU protocol: WHOLE-model forward + ctdet_decode (the body of
+    CtdetDetector.process, lib/detectors/ctdet.py:29-46, timed like BaseDetector.run,
+    lib/detectors/base_detector.py:93-155) on the host cores: the harness model on torch-CPU with the
+    module-level ``deform_conv`` bound to the CPU oracle (the reference has no CPU deform conv), batch 1 and 8,
+    all cores and 1 thread.  Bounded: every leg runs one warm-up forward at batch 1 and then whole batches until
+    `budget_s` seconds have passed (at least one)."""
+    import torch
+    from codenet_amd import harness
+    from codenet_amd.modules import dcn_deform_conv as M
+    from codenet_amd.portable_quantizer import quant_modules as QM
+    from oracle import dcn as O
+    O.lib()
+    saved = (M.deform_conv, QM.deform_conv)
+    M.deform_conv = QM.deform_conv = O.deform_conv
+    all_threads = torch.get_num_threads()
+    legs = {}
+    try:
+        model = harness.create_model(w2=args.w2, quantize=not args.fp32)
+        g = torch.Generator().manual_seed(0)
+        for threads in (all_threads, 1):
+            torch.set_num_threads(threads)
+            O.set_threads(threads)                   # the oracle's OpenMP loops follow the same count
+            for n in (1, 8):
+                x = torch.randn(n, 3, args.res, args.res, generator=g)
+                harness.process(model, x[:1], flip_test=False, native_decode=False)
+                t0 = time.perf_counter()
+                reps = 0
+                while True:
+                    harness.process(model, x, flip_test=False, native_decode=False)
+                    reps += 1
+                    if time.perf_counter() - t0 > budget_s:
+                        break
+                dt = time.perf_counter() - t0
+                legs["batch%d_threads%d" % (n, threads)] = {
+                    "images_per_s": round(n * reps / dt, 3), "ms_per_batch": round(dt / reps * 1e3, 1),
+                    "batches": reps}
+    finally:
+        torch.set_num_threads(all_threads)
+        O.set_threads(all_threads)
+        M.deform_conv, QM.deform_conv = saved
+    best = max(v["images_per_s"] for v in legs.values())
+    return {"value": best, "unit": "images/sec", "kind": "port", "cores": all_threads, "nproc": os.cpu_count(),
+            "cpu_model": cpu_model_name(), "legs": legs,
+            "sample": "CoDeNet%s %dx%d %s whole model + ctdet_decode on torch-CPU + the C/OpenMP oracle for the "
+                      "deform conv; per leg one warm-up image, then whole batches for >= %.0f s"
+                      % ("2x" if args.w2 else "1x", args.res, args.res, "fp32" if args.fp32 else "W4A8", budget_s)}
+
+
+# ---- plumbing-only mode (CPU, gloo): launcher + collectives, no kernels ---------------------------------------
+
+def plumbing_only(args, world, rank):
+    import torch
+    import torch.distributed as dist
+    from codenet_amd import pipeline
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    joined = dist.get_world_size() if world > 1 else 1
+    if joined != args.gpus:
+        print("bench.py: --gpus %d but %d rank(s) joined" % (args.gpus, joined), file=sys.stderr)
+        return 3
+    net = pipeline.build_hot_path(w2=args.w2, quantized=not args.fp32, seed=317 if rank == 0 else 1000 + rank)
+    nbytes = pipeline.broadcast_parameters(net, src=0)
+    digest = torch.stack([v.double().sum() for v in net.state_dict().values() if v.dtype.is_floating_point])
+    same = True
+    if world > 1:
+        parts = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(parts, digest)
+        same = all(torch.equal(parts[0], p) for p in parts)
+    lo, hi = pipeline.shard_range(world * args.batch + 1, rank, world)      # uneven on purpose
+    dets = torch.full((hi - lo, 100, 6), float(rank))
+    dets[:, 0, 0] = torch.arange(lo, hi, dtype=torch.float32)               # global image index
+    allv = pipeline.gather_detections(dets)
+    ok = (allv.shape[0] == world * args.batch + 1
+          and torch.equal(allv[:, 0, 0], torch.arange(world * args.batch + 1, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": joined, "backend": args.backend,
+                          "broadcast_bytes": nbytes, "replicas_identical": bool(same),
+                          "detections_gathered": list(allv.shape), "detections_in_rank_order": bool(ok),
+                          "value": None}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if (same and ok) else 4
+
+
+# ---- the measured run ----------------------------------------------------------------------------------------
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(launch_ranks(args))            # children do the work; nothing here has touched the GPU
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if args.plumbing_only:
+        sys.exit(plumbing_only(args, world, rank))
+
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)          # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world)   # nccl == RCCL on ROCm
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    # ranks seen by the collective itself (not the launcher's claim)
+    seen = torch.ones(1, device=dev)
+    if world > 1:
+        dist.all_reduce(seen)
+    n_seen = int(round(seen.item()))
+    if n_seen != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but %d rank(s) joined RCCL" % (args.gpus, n_seen), file=sys.stderr)
+        sys.exit(3)
 
     from codenet_amd import ops, pipeline
 
@@ -132,9 +313,12 @@ def main():
 
     def eager_step():
         if fused is not None:
-            return fused(x)
+            return fused.forward_nhwc(x)[0]
         with torch.no_grad():
             return net(x)
+
+    def eager_step_unpack():
+        return fused(x)
 
     def barrier():
         if world > 1:
@@ -148,7 +332,7 @@ def main():
     for _ in range(max(1, args.warmup // 2)):
         eager_step()
     use_graph = fused is not None and not args.no_graph
-    step = fused.capture(x) if use_graph else eager_step
+    step = fused.capture(x, unpack=False) if use_graph else eager_step
     for _ in range(args.warmup):
         step()
     barrier()
@@ -166,6 +350,19 @@ def main():
     dt = tmax.item()
     assert torch.isfinite(out).all()
 
+    # ---- the same step + the NCHW / up-sampled copy for a PyTorch consumer (reported separately) ---
+    with_unpack_ms = None
+    if fused is not None:
+        step_u = fused.capture(x, unpack=True) if use_graph else eager_step_unpack
+        for _ in range(5):
+            step_u()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_u()
+        barrier()
+        with_unpack_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
     # ---- per-kernel durations: HIP events on the launch stream (fused path: the library's own
     #      event pairs around every kernel, K eager steps right after the timed region) ------------
     durs = {}
@@ -173,7 +370,7 @@ def main():
         lib = _native.lib()
         lib.cdn_profile_enable(1)
         for _ in range(args.steps):
-            eager_step()
+            eager_step_unpack()
         torch.cuda.synchronize()
         cap = args.steps * 16
         ids = (ctypes.c_int * cap)()
@@ -187,6 +384,11 @@ def main():
     elif rank == 0:
         durs = kt.durations_ms()
 
+    # ---- whole network + native decode as one HIP graph (every rank; per-batch detections all_gather) ---
+    e2e = None
+    if not args.no_e2e and args.path == "fused":
+        e2e = e2e_leg(args, dev, rank, world, local_rank, dt / args.steps * 1e3)
+
     if rank == 0:
         per_kernel = {}
         for (name, tag), v in durs.items():
@@ -194,7 +396,8 @@ def main():
             per_kernel[name] += sum(v) / args.steps          # ms per step in this kernel
         per_launch = {"%s@%s" % (name, "x".join(str(t) for t in tag)): round(sum(v) / len(v), 5)
                       for (name, tag), v in sorted(durs.items())}
-        dominant = max(per_kernel, key=per_kernel.get)
+        in_step = {k: v for k, v in per_kernel.items() if k != "unpack"}
+        dominant = max(in_step, key=in_step.get)
         _, per_stage = pipeline.algorithmic_bytes(args.batch, args.res, args.w2)
         alg = {"scale": 0, "dw": 0, "pointwise": 0}
         for v in per_stage.values():
@@ -217,7 +420,7 @@ def main():
             ach = flops_pw / (per_kernel["pointwise"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
-                    "kernel": "pw2_kernel" if fused is not None else "pointwise_kernel"}
+                    "kernel": "pwi8_kernel/pw3_kernel" if fused is not None else "pointwise_kernel"}
         else:
             key = dominant if dominant in alg else "dw"
             nbytes = alg.get(key, 0)
@@ -232,27 +435,32 @@ def main():
                                 "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (only valid for
         # the workload they were collected on; null otherwise)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        for rnd in ("r02", "r01"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
+            except (OSError, ValueError):
+                continue
             w = pm["workload"]
             if (w["res"], w["batch"], w["w2"], w["fp32"], w["path"]) == \
-                    (args.res, args.batch, args.w2, args.fp32, args.path) and roof["bound"] == "hbm":
+                    (args.res, args.batch, args.w2, args.fp32, args.path) and roof["bound"] == "hbm" \
+                    and bool(w.get("frozen", False)) == bool(args.frozen):
                 roof["traffic"] = pm["bytes_per_step"].get(dominant)
-                roof["traffic_note"] = "bytes per step (sum over the kernel's launches), PMC FETCH_SIZE*2 + WRITE_SIZE"
+                roof["traffic_note"] = ("bytes per step (sum over the kernel's launches), PMC FETCH_SIZE*2 + "
+                                        "WRITE_SIZE, profiles/%s" % rnd)
                 roof["algorithmic_bytes_per_step"] = nbytes
-        except Exception:
-            pass
+            break
         roof["launches_per_step"] = sum(1 for (nm, _t) in durs if nm == dominant)
         roof["ms_per_step_in_kernel"] = per_kernel[dominant]
+        ms_step = dt / args.steps * 1e3
         res = {
-            "metric": "images/sec CoDeNet%s %dx%d ctdet inference (deform hot path: deconv_layers)"
+            "metric": "images/sec CoDeNet%s %dx%d ctdet inference (deform hot path: deconv_layers; whole network in `e2e`)"
                       % ("2x" if args.w2 else "1x", args.res, args.res),
             "value": world * args.batch * args.steps / dt,
             "unit": "images/sec",
-            "n_gpus": world,
+            "n_gpus": n_seen,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -261,28 +469,86 @@ def main():
             "config": {
                 "workload": "CoDeNet%s config-%s %dx%d %s, batch %d per GPU, 3 deform stages "
                             "(scale 1x1 -> QuantAct -> bilinear-gather depthwise 3x3 -> QuantAct -> "
-                            "pointwise 1x1 + folded BN -> ReLU -> QuantAct -> upsample x2), %s, %s"
-                            % ("2x" if args.w2 else "1x", "d" if args.w2 else "c", args.res, args.res,
-                               "fp32" if args.fp32 else "W4A8", args.batch,
+                            "pointwise 1x1 + folded BN -> ReLU -> QuantAct range; output channels-last at stage "
+                            "resolution for the native heads), %s, %s"
+                            % ("2x" if args.w2 else "1x", "d" if args.w2 else ("c" if quantized else "a"),
+                               args.res, args.res, "fp32" if args.fp32 else "W4A8", args.batch,
                                "frozen QuantAct ranges" if args.frozen else
                                "running QuantAct ranges (reference-faithful)",
                                ("fused per-stage schedule" + (", HIP-graph replay" if use_graph else ", eager launches"))
                                if fused is not None else "module-by-module"),
+                "preset": args.config or "cfg3",
                 "global_batch": world * args.batch,
-                "parallelism": "dp%d (independent image shards, start-up RCCL broadcast of %d bytes)"
-                               % (world, bcast_bytes),
+                "parallelism": "dp%d (independent image shards, start-up RCCL broadcast of %d bytes, per-batch "
+                               "all_gather of detections in the e2e leg)" % (world, bcast_bytes),
             },
             "roofline": roof,
+            "with_unpack": (None if with_unpack_ms is None else
+                            {"ms_per_step": with_unpack_ms, "images_per_s": world * args.batch / with_unpack_ms * 1e3,
+                             "note": "step + unpack_kernel (fake-quant + nearest x2 + NCHW copy for a PyTorch "
+                                     "consumer; the native heads do not need it)"}),
             "kernel_ms_per_step": per_kernel,
             "kernel_ms_per_launch": per_launch,
+            "e2e": e2e,
         }
         if net_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(args, net_cpu)
+            res["cpu_baseline_e2e"] = cpu_baseline_e2e(args) if e2e is not None else None
+            if e2e is not None and res["cpu_baseline_e2e"]:
+                res["e2e"]["vs_cpu_baseline_e2e"] = e2e["images_per_s"] / res["cpu_baseline_e2e"]["value"]
         else:
             res["cpu_baseline"] = None
+            res["cpu_baseline_e2e"] = None
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def e2e_leg(args, dev, rank, world, local_rank, hot_ms):
+    """Whole network (stem + 16 ShuffleNetV2 units + layer4 + three deform stages + three heads, all on the HIP
+    kernels) + native ctdet_decode, captured as ONE HIP graph per rank over a static image buffer; for N > 1
+    every batch ends with the all_gather of the ranks' detections [B,100,6]."""
+    import torch
+    import torch.distributed as dist
+    from codenet_amd import harness, pipeline
+    model = harness.create_model(w2=args.w2, quantize=not args.fp32, seed=317 if rank == 0 else 1000 + rank).to(dev)
+    pipeline.broadcast_parameters(model, src=0)
+    model.enable_fused()
+    g = torch.Generator().manual_seed(rank)
+    images = torch.randn(args.batch, 3, args.res, args.res, generator=g).to(dev)
+    if not args.fp32 and args.frozen:
+        harness.process(model, images, flip_test=False)
+        pipeline.set_running_stat(model, False)
+    replay = harness.capture_process(model, images)
+
+    def step():
+        dets = replay()[1]
+        return pipeline.gather_detections(dets) if world > 1 else dets
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+    for _ in range(5):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dets = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    assert torch.isfinite(dets).all() and dets.shape[0] == world * args.batch
+    ms = dt / args.steps * 1e3
+    return {"ms_per_batch": ms, "images_per_s": world * args.batch / ms * 1e3,
+            "hot_path_share": hot_ms / ms, "detections": list(dets.shape),
+            "what": "CoDeNet%s %dx%d %s batch %d per GPU: whole network on the HIP kernels + native ctdet_decode "
+                    "(K=100), one HIP graph per rank%s" % (
+                        "2x" if args.w2 else "1x", args.res, args.res, "fp32" if args.fp32 else "W4A8", args.batch,
+                        ", all_gather of detections per batch" if world > 1 else "")}
 
 
 if __name__ == "__main__":

@@ -385,14 +385,16 @@ class FusedHotPath:
         return cur, cur_q, B["stages"][-1]
 
     # -- HIP graph -----------------------------------------------------------------------------
-    def capture(self, x):
+    def capture(self, x, unpack=True):
         """Capture one pass over the static input buffer `x` into a HIP graph; returns a callable
-        replaying it (the output tensor is static too)."""
-        self(x)                       # allocate + warm (also derives cached weights)
+        replaying it (the output tensor is static too).  unpack=False: the three stages only, returning the
+        channels-last stage-resolution tensor ``forward_nhwc`` hands to the native heads."""
+        run = self.__call__ if unpack else (lambda t: self.forward_nhwc(t)[0])
+        run(x)                        # allocate + warm (also derives cached weights)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = self(x)
+            out = run(x)
         self._graph = g
 
         def replay():

@@ -32,6 +32,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP team size of the oracle's loops; returns the previous value."""
+    return int(lib().dcn_oracle_set_threads(int(n)))
+
+
 def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
 

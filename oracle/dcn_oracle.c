@@ -33,3 +33,15 @@
 #undef FN
 
 int dcn_oracle_abi_version(void) { return 1; }
+
+/* OpenMP team size of the loops above (bench.py's single-thread CPU baseline leg); returns the old value. */
+#ifdef _OPENMP
+#include <omp.h>
+int dcn_oracle_set_threads(int n) {
+  const int old = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return old;
+}
+#else
+int dcn_oracle_set_threads(int n) { (void)n; return 1; }
+#endif

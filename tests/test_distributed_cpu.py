@@ -61,3 +61,46 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True,
+                       text=True, timeout=600)
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(line[-1]) if line else None), p.stderr
+
+
+def test_bench_launcher_starts_its_own_ranks_world2():
+    """`python bench.py --gpus 2` run DIRECTLY (no torchrun around it) must start two ranks itself -- as child
+    processes, before touching any GPU -- and report the number of ranks the collective saw.
+    --plumbing-only --backend gloo: launcher, rendezvous, start-up broadcast, uneven image shards and the
+    per-batch detections all_gather on CPU tensors; no kernels, no rate."""
+    rc, res, err = _bench("--gpus", "2", "--plumbing-only", "--backend", "gloo", "--batch", "3")
+    assert rc == 0, err[-2000:]
+    assert res["n_gpus"] == 2 and res["replicas_identical"] and res["detections_in_rank_order"]
+    assert res["detections_gathered"] == [7, 100, 6] and res["broadcast_bytes"] > 1_000_000
+    assert res["value"] is None                                     # a plumbing run never reports a rate
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus N with a different WORLD_SIZE in the environment is an error (exit 2), not a silent 1-rank run."""
+    rc, res, err = _bench("--gpus", "2", "--plumbing-only", "--backend", "gloo",
+                          env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and res is None and "WORLD_SIZE 1" in err
+
+
+def test_bench_presets():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(["--config", "cfg4"])
+    assert (a.w2, a.batch, a.res, a.fp32) == (True, 32, 512, False)          # 32 / GPU x 8 = 256 (configs[3])
+    a = bench.parse([])
+    assert (a.w2, a.batch, a.res, a.fp32) == (False, 64, 512, False)         # configs[2]
+    a = bench.parse(["--config", "cfg2", "--batch", "8"])
+    assert (a.w2, a.batch, a.res, a.fp32) == (False, 8, 256, True)
