@@ -1026,7 +1026,11 @@ class FusedBackbone:
             P["w2"], P["b2"] = w2.reshape(h, 9).contiguous(), b2.contiguous()
             plan["units"].append(P)
         assert sorted(logical) == list(range(C))
+        inv = [0] * C                  # physical slot of every logical channel (materialize; built once: a
+        for p_, L_ in enumerate(logical):   # host-to-device copy is not allowed while a graph is captured)
+            inv[L_] = p_
         plan.update(logical=list(logical), gen=u8(gen), gen_list=list(gen), ngen=ngen,
+                    inv=torch.tensor(inv, device=dev, dtype=torch.long), gen_long=u8(gen).long(),
                     states=torch.zeros(ngen * 8, dtype=torch.int32, device=dev))
         cache[ck] = plan
         return plan
@@ -1132,18 +1136,21 @@ class FusedBackbone:
                 self._pw_raw(L["t2"].data_ptr(), qptr(u["a2"]), None, Mo, ldh, P["c3"], True, sh, sp(P["genB"]),
                              P["omapB"].data_ptr(), Y.data_ptr(), C)
         return dict(t=Y, logical=plan["logical"], gen=plan["gen"], gen_list=plan["gen_list"], states=S, C=C,
-                    H=L["H"], W=L["W"])
+                    H=L["H"], W=L["W"], inv=plan["inv"], gen_long=plan["gen_long"])
 
     @staticmethod
     def materialize(layout):
         """The layer output in the reference's (logical) channel order with every channel fake-quantised by
         its generation's state -- what the module path holds; plain torch, for tests and hand-overs."""
         t, S = layout["t"], layout["states"].view(torch.float32).view(-1, 8)
-        g = layout["gen"].long()
+        g = layout["gen_long"] if "gen_long" in layout else layout["gen"].long()
         scale, zp = S[g, 2], S[g, 3]
         q = (torch.round(scale * t - zp) + zp) / scale
-        inv = torch.empty(len(layout["logical"]), dtype=torch.long, device=t.device)
-        inv[torch.tensor(layout["logical"], device=t.device)] = torch.arange(len(layout["logical"]), device=t.device)
+        inv = layout.get("inv")
+        if inv is None:
+            inv = torch.empty(len(layout["logical"]), dtype=torch.long, device=t.device)
+            inv[torch.tensor(layout["logical"], device=t.device)] = torch.arange(len(layout["logical"]),
+                                                                                 device=t.device)
         return q[:, inv]
 
     def __call__(self, images):
