@@ -1,0 +1,238 @@
+// codenet_train.hip -- backward kernels of the two 1x1 convolutions around the gather (config e, the QAT step of
+// quant_main.py).  The reference runs them as cuDNN / cuBLAS calls under autograd:
+//   conv_scale   (modules/dcn_deform_conv.py:295,324; Quant_Conv2d quant_modules.py:314-321)   C -> 1, bias
+//   conv_channel (modules/dcn_deform_conv.py:311-312,328; QuantBnConv2d quant_modules.py:412-419)  C -> Co
+// Forward and data-gradient of conv_channel are cdn_codenet_pointwise_forward (the data gradient is the same
+// contraction with the transposed weights); here: its weight gradient on f32 MFMA, and the backward of the
+// scale prediction.  NCHW fp32, like the module path (codenet_stage.hip).
+#include "cdn_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------------------------------------
+// pw_wgrad_kernel: partial[z][co][c] = sum over the k-chunks of slice z of  gy[n][co][p] * d[n][c][p].
+// Both operands have the reduction index (pixels) contiguous, so this is an "NT" GEMM with K = N*HW:
+//   workgroup tile 64 (co) x 64 (c), 4 waves x one 32x32 accumulator, K tiles of 64 pixels of ONE image
+//   staged through LDS as [row][k] (row stride 68 floats: a quarter-wave's 16 ds_read_b128 cover the 64 banks);
+//   lane l reads 4 consecutive k (k = 4*(l>>5) + e of every 8): the two lane halves are the two k slots of
+//   v_mfma_f32_32x32x2_f32 (A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]) and e = 0..3 are four MFMAs -- a sum
+//   over k does not care which slot a k lands in, only that A and B agree.
+//   Next tile's global loads (8 x 16 B per thread) are in flight behind the 32 MFMAs of the current one.
+// Split-K over gridDim.z (few output tiles: 64 x 128 outputs at stage 2), partial tiles reduced in a fixed
+// order by wgrad_reduce_kernel: bitwise reproducible.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kWgBM = 64, kWgBN = 64, kWgBK = 64, kWgLd = kWgBK + 4;
+
+__global__ void __launch_bounds__(256)
+pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float *__restrict__ partial,
+                int C, int Co, int HW, int chunks_per_img, int nchunks, int chunks_per_slice) {
+  __shared__ __attribute__((aligned(16))) float As[kWgBM][kWgLd];
+  __shared__ __attribute__((aligned(16))) float Bs[kWgBN][kWgLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * kWgBN, m0 = blockIdx.y * kWgBM, z = blockIdx.z;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int ch_lo = z * chunks_per_slice, ch_hi = min(nchunks, ch_lo + chunks_per_slice);
+  const int lrow = tid >> 4, lk = (tid & 15) * 4;      // staging: rows lrow + 16*i, floats lk .. lk+3
+  const bool hw4 = (HW & 3) == 0;
+  f32x16 acc = {0};
+  float4 ra[4], rb[4];
+  auto load = [&](int ch) {
+    const int n = ch / chunks_per_img, p0 = (ch - n * chunks_per_img) * kWgBK;
+    const float *ga = gy + (long)n * Co * HW, *gb = d + (long)n * C * HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lrow + 16 * i, p = p0 + lk;
+      const int ma = m0 + r, cb = c0 + r;
+      if (hw4 && p + 3 < HW) {
+        ra[i] = ma < Co ? *reinterpret_cast<const float4 *>(ga + (long)ma * HW + p) : make_float4(0, 0, 0, 0);
+        rb[i] = cb < C ? *reinterpret_cast<const float4 *>(gb + (long)cb * HW + p) : make_float4(0, 0, 0, 0);
+      } else {
+        float a[4], b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = (ma < Co && p + e < HW) ? ga[(long)ma * HW + p + e] : 0.0f;
+          b[e] = (cb < C && p + e < HW) ? gb[(long)cb * HW + p + e] : 0.0f;
+        }
+        ra[i] = make_float4(a[0], a[1], a[2], a[3]);
+        rb[i] = make_float4(b[0], b[1], b[2], b[3]);
+      }
+    }
+  };
+  if (ch_lo < ch_hi) load(ch_lo);
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {
+    __syncthreads();                       // the previous tile has been consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4 *>(&As[lrow + 16 * i][lk]) = ra[i];
+      *reinterpret_cast<float4 *>(&Bs[lrow + 16 * i][lk]) = rb[i];
+    }
+    __syncthreads();
+    if (ch + 1 < ch_hi) load(ch + 1);      // in flight during the MFMAs below
+    const float *ap = &As[wm + (lane & 31)][4 * (lane >> 5)];
+    const float *bp = &Bs[wn + (lane & 31)][4 * (lane >> 5)];
+#pragma unroll
+    for (int kk = 0; kk < kWgBK; kk += 8) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(ap + kk);
+      const float4 b4 = *reinterpret_cast<const float4 *>(bp + kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+  }
+  // C/D layout: column (B row = c) = l & 31, row (A row = co) = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+  float *out = partial + (long)z * Co * C;
+  const int col = c0 + wn + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < Co && col < C) out[(long)row * C + col] = acc[r];
+  }
+}
+
+// gw[i] = sum_z partial[z][i], z ascending (fixed order)
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int nz) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int z = 0; z < nz; ++z) s += partial[(long)z * n + i];
+  gw[i] = s;
+}
+
+// gb[co] = sum_{n,p} gy[n][co][p]: one workgroup per output channel, fixed summation tree
+__global__ void __launch_bounds__(256)
+bias_grad_kernel(const float *__restrict__ gy, float *__restrict__ gb, int N, int Co, int HW) {
+  __shared__ float red[4];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  float s = 0.0f;
+  for (int n = 0; n < N; ++n) {
+    const float *g = gy + ((long)n * Co + co) * HW;
+    for (int p = tid; p < HW; p += 256) s += g[p];
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) gb[co] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// scale_bwd_kernel: backward of s_raw[n][p] = sum_c w[c] x[n][c][p] + b given g[n][p] = dL/ds_raw (the caller
+// has applied the Hardtanh mask and the straight-through QuantAct):
+//   grad_x[n][c][p] += w[c] * g[n][p]           (accumulated into the gather's grad_x)
+//   gw_part[n][c]    = sum_p x[n][c][p] g[n][p]  (summed over n by the caller in a fixed order)
+// One wave per (image, channel) row; g (N*HW floats) stays in L2.  HBM: read x, read + write grad_x.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+scale_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ w,
+                 float *__restrict__ gx, float *__restrict__ gw_part, int C, int HW) {
+  const int n = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const float wc = w[c];
+  const float *xp = x + ((long)n * C + c) * HW, *gp = g + (long)n * HW;
+  float *gxp = gx ? gx + ((long)n * C + c) * HW : nullptr;
+  float acc = 0.0f;
+  if ((HW & 3) == 0) {
+    for (int q = lane; q < (HW >> 2); q += 64) {
+      const float4 xv = reinterpret_cast<const float4 *>(xp)[q];
+      const float4 gv = reinterpret_cast<const float4 *>(gp)[q];
+      acc = fmaf(xv.x, gv.x, acc); acc = fmaf(xv.y, gv.y, acc);
+      acc = fmaf(xv.z, gv.z, acc); acc = fmaf(xv.w, gv.w, acc);
+      if (gxp) {
+        float4 o = reinterpret_cast<float4 *>(gxp)[q];
+        o.x = fmaf(wc, gv.x, o.x); o.y = fmaf(wc, gv.y, o.y);
+        o.z = fmaf(wc, gv.z, o.z); o.w = fmaf(wc, gv.w, o.w);
+        reinterpret_cast<float4 *>(gxp)[q] = o;
+      }
+    }
+  } else {
+    for (int p = lane; p < HW; p += 64) {
+      const float gv = gp[p];
+      acc = fmaf(xp[p], gv, acc);
+      if (gxp) gxp[p] = fmaf(wc, gv, gxp[p]);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0 && gw_part) gw_part[(long)n * C + c] = acc;
+}
+
+struct WgPlan {
+  int tiles_c, tiles_m, chunks_per_img, nchunks, nz, per_slice;
+};
+
+WgPlan wgrad_plan(int64_t N, int64_t C, int64_t Co, int64_t HW) {
+  WgPlan p;
+  p.tiles_c = (int)cdn::ceil_div(C, kWgBN);
+  p.tiles_m = (int)cdn::ceil_div(Co, kWgBM);
+  p.chunks_per_img = (int)cdn::ceil_div(HW, kWgBK);
+  p.nchunks = (int)(N * p.chunks_per_img);
+  // ~3 workgroups per CU in total, at least 2 K tiles per slice, at most 1024 slices
+  int nz = (int)std::max<int64_t>(1, (3 * cdn::kCUs) / ((int64_t)p.tiles_c * p.tiles_m));
+  nz = std::min(nz, std::max(1, p.nchunks / 2));
+  nz = std::min(nz, 1024);
+  p.per_slice = (int)cdn::ceil_div(p.nchunks, nz);
+  p.nz = (int)cdn::ceil_div(p.nchunks, p.per_slice);
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW) {
+  if (N <= 0 || C <= 0 || Co <= 0 || HW <= 0) return 0;
+  const WgPlan p = wgrad_plan(N, C, Co, HW);
+  return ((size_t)p.nz * (size_t)Co * (size_t)C * 4 + 255) / 256 * 256;
+}
+
+extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b,
+                                           int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+  CDN_REQUIRE(grad_y && d && grad_w && workspace, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && HW > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N * C * HW < (1ll << 31) && N * Co * HW < (1ll << 31) && C * Co < (1ll << 31),
+              CDN_ERR_UNSUPPORTED, "shape too large");
+  CDN_REQUIRE(workspace_bytes >= cdn_codenet_pointwise_wgrad_workspace_bytes(N, C, Co, HW) &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              CDN_ERR_WORKSPACE, "workspace too small or not 16-byte aligned");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(grad_y) & 15) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0,
+              CDN_ERR_ARG, "grad_y / d must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const WgPlan p = wgrad_plan(N, C, Co, HW);
+  CDN_REQUIRE(p.tiles_m <= 65535 && p.nz <= 65535, CDN_ERR_UNSUPPORTED, "too many tiles");
+  float *partial = static_cast<float *>(workspace);
+  pw_wgrad_kernel<<<dim3((unsigned)p.tiles_c, (unsigned)p.tiles_m, (unsigned)p.nz), 256, 0, st>>>(
+      grad_y, d, partial, (int)C, (int)Co, (int)HW, p.chunks_per_img, p.nchunks, p.per_slice);
+  int rc = cdn::check_launch("codenet pointwise weight gradient");
+  if (rc) return rc;
+  const long n = (long)(Co * C);
+  wgrad_reduce_kernel<<<(unsigned)cdn::ceil_div(n, 256), 256, 0, st>>>(partial, grad_w, n, p.nz);
+  rc = cdn::check_launch("codenet pointwise weight gradient reduce");
+  if (rc) return rc;
+  if (grad_b) {
+    bias_grad_kernel<<<(unsigned)Co, 256, 0, st>>>(grad_y, grad_b, (int)N, (int)Co, (int)HW);
+    rc = cdn::check_launch("codenet pointwise bias gradient");
+  }
+  return rc;
+}
+
+extern "C" int cdn_codenet_scale_backward(const float *x, const float *grad_s, const float *w_scale, float *grad_x,
+                                          float *grad_w_partial, int64_t N, int64_t C, int64_t H, int64_t W,
+                                          void *stream) {
+  CDN_REQUIRE(x && grad_s && w_scale, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  const int HW = (int)(H * W);
+  CDN_REQUIRE((HW & 3) != 0 || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                                (reinterpret_cast<uintptr_t>(grad_s) & 15) == 0 &&
+                                (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0),
+              CDN_ERR_ARG, "x / grad_s / grad_x must be 16-byte aligned");
+  dim3 grid((unsigned)cdn::ceil_div(C, 4), (unsigned)N);
+  scale_bwd_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, grad_s, w_scale, grad_x, grad_w_partial, (int)C,
+                                                             HW);
+  return cdn::check_launch("codenet scale backward");
+}

@@ -1,0 +1,153 @@
+"""The CoDeNet stage as ONE autograd function on the HIP kernels (training path, config e).
+
+The reference composes ``DeformConvWithOffsetScaleBoundPositive`` / its W4A8 counterpart from framework ops
+under autograd (modules/dcn_deform_conv.py:323-330; quant_modules.py:668-671): conv_scale -> Hardtanh
+[-> QuantAct] -> offsets -> deform_conv (native forward / backward, dcn_deform_conv_cuda.cpp:151-484)
+[-> QuantAct] -> conv_channel.  Here forward and backward of the whole chain are native:
+
+    forward   cdn_codenet_scale_forward, cdn_quantact_forward, cdn_codenet_dw_forward, cdn_quantact_forward,
+              cdn_codenet_pointwise_forward
+    backward  cdn_codenet_pointwise_forward on the transposed weights (data gradient), cdn_codenet_pointwise_wgrad
+              (weight + bias gradient, f32 MFMA), cdn_codenet_dw_backward (grad_x, grad_s, grad_w_dw),
+              cdn_codenet_scale_backward (grad_x +=, grad_w_scale)
+
+Straight-through estimators exactly as the reference's quantisers define them (quant_utils.py:202-204,
+227-229: the QuantAct backward is the identity); the Hardtanh passes gradients where lo < s_raw < hi.
+The WEIGHT transformations (per-channel fake-quantisation, BN fold) are tiny tensors and stay torch ops in the
+calling module, so their gradients (straight-through, chain rule through the fold) come from autograd.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _native as N_
+from .. import ops
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+_wgrad_ws = {}
+
+
+def _workspace(nbytes, device):
+    """Split-K scratch of the weight-gradient kernel, one per (device, stream), grown on demand."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def pointwise_wgrad(grad_y, d, want_bias):
+    """(grad_w [Co, C], grad_b [Co] or None) of y = conv1x1(d, w) + b; grad_y [N,Co,H,W], d [N,C,H,W]."""
+    Nb, Co, H, W = grad_y.shape
+    C = d.shape[1]
+    lib = N_.lib()
+    need = lib.cdn_codenet_pointwise_wgrad_workspace_bytes(Nb, C, Co, H * W)
+    ws = _workspace(need, grad_y.device)
+    gw = torch.empty(Co, C, device=grad_y.device)
+    gb = torch.empty(Co, device=grad_y.device) if want_bias else None
+    rc = lib.cdn_codenet_pointwise_wgrad(_p(grad_y), _p(d), _p(gw), _p(gb), Nb, C, Co, H * W, _p(ws),
+                                         ws.numel() * 4, ops._stream(grad_y))
+    N_.check(rc, "cdn_codenet_pointwise_wgrad")
+    return gw, gb
+
+
+class CodenetStageFunction(Function):
+    """y = conv1x1(QA_d(dw_deform(x, QA_s(hardtanh(conv1x1(x, w_scale) + b_scale)), w_dw)), w_pw) + b_pw.
+    act_s / act_d: QuantAct modules (asymmetric, plain min/max) or None; their buffers are updated in place
+    by the forward exactly as in eval mode (the reference's QuantAct does not distinguish, quant_modules.py:
+    203-219)."""
+
+    @staticmethod
+    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d):
+        ops._gpu_f32(x, w_scale, b_scale, w_dw, w_pw, b_pw)
+        x = x.contiguous()
+        s_c = ops.codenet_scale(x, w_scale, b_scale, lo, hi)            # clamped, pre-quantisation
+        s = _native_quantact(act_s, s_c) if act_s is not None else s_c
+        with torch.no_grad():
+            d = ops.codenet_dw(x, s, w_dw.contiguous())
+        d_q = _native_quantact(act_d, d) if act_d is not None else d
+        have_pw = w_pw is not None
+        y = ops.codenet_pointwise(d_q, w_pw, b_pw) if have_pw else d_q
+        ctx.lo, ctx.hi, ctx.have_pw = float(lo), float(hi), have_pw
+        ctx.has_b_scale, ctx.has_b_pw = b_scale is not None, b_pw is not None
+        ctx.save_for_backward(x, s_c, s, w_scale, w_dw, d_q if have_pw else None, w_pw)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, s_c, s, w_scale, w_dw, d_q, w_pw = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gy = gy.contiguous()
+        Nb, C, H, W = x.shape
+        lib = N_.lib()
+        g_wpw = g_bpw = None
+        if ctx.have_pw:
+            Co = w_pw.shape[0]
+            if need[4] or (need[5] and ctx.has_b_pw):
+                gw2, g_bpw = pointwise_wgrad(gy, d_q, need[5] and ctx.has_b_pw)
+                g_wpw = gw2.view_as(w_pw) if need[4] else None
+            # data gradient: the same contraction with the transposed weights
+            gd = ops.codenet_pointwise(gy, w_pw.reshape(Co, C).t().contiguous().view(C, Co, 1, 1))
+        else:
+            gd = gy
+        # gather backward (QuantAct on d: straight-through)
+        want_x, want_s, want_wdw = need[0], (need[1] or need[2] or need[0]), need[3]
+        if not lib.cdn_codenet_dw_backward_supported(H, W):
+            gx, gs, g_wdw = ops._dw_backward_generic(x, s, w_dw, gd, (want_x, want_s, want_wdw))
+            gx = gx.contiguous() if gx is not None else None
+        else:
+            gx = torch.empty_like(x) if want_x else None
+            gs = torch.empty_like(s) if want_s else None
+            g_wdw = torch.zeros_like(w_dw) if want_wdw else None
+            rc = lib.cdn_codenet_dw_backward(_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw),
+                                             Nb, C, H, W, ops._stream(x))
+            N_.check(rc, "cdn_codenet_dw_backward")
+        g_wscale = g_bscale = None
+        if want_s:
+            # QuantAct on s: straight-through; Hardtanh: gradient where lo < s_raw < hi (s_c is the clamped
+            # value: s_c == lo or hi <=> s_raw outside or on the bound, where torch's hardtanh_backward is 0 too)
+            g_raw = gs * ((s_c > ctx.lo) & (s_c < ctx.hi)).to(gs.dtype)
+            part = torch.empty(Nb, C, device=x.device) if need[1] else None
+            rc = lib.cdn_codenet_scale_backward(_p(x), _p(g_raw), _p(w_scale.contiguous().view(-1)), _p(gx),
+                                                _p(part), Nb, C, H, W, ops._stream(x))
+            N_.check(rc, "cdn_codenet_scale_backward")
+            if need[1]:
+                g_wscale = part.sum(0).view_as(w_scale)
+            if need[2] and ctx.has_b_scale:
+                g_bscale = g_raw.sum().reshape(1)
+        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None
+
+
+def _native_quantact(act, t):
+    """QuantAct.forward on the device kernel: range tracking in place + fake-quantisation (no autograd)."""
+    out, _ = ops.quantact_forward(t, act.x_min, act.x_max, act._device_state(t.device), bits=act.activation_bit,
+                                  momentum=act.momentum, running=act.running_stat)
+    return out
+
+
+def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None):
+    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d)
+
+
+class QuantActSTE(Function):
+    """QuantAct under autograd on the device kernel: forward = range tracking + fake-quantisation, backward =
+    identity (AsymmetricQuantFunction.backward, quant_utils.py:202-204)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        return _native_quantact(act, x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def native_act_ok(act):
+    """The device QuantAct implements the reference's default: asymmetric, plain batch min/max, quantising."""
+    return act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag

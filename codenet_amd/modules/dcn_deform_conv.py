@@ -323,9 +323,12 @@ class DeformConvWithOffsetScaleBoundPositive(_ScaleOffset):
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
-            s = self.conv_bound(self.conv_scale(x))
-            d = ops.codenet_dw(x, s, self.conv.weight)
-            return self.conv_channel(d) if self.in_channels != self.out_channels else d
+            # training: scale 1x1, gather and pointwise 1x1 forward AND backward on the HIP kernels
+            from ..functions.codenet_stage import codenet_stage
+            pw = self.conv_channel if self.in_channels != self.out_channels else None
+            return codenet_stage(x, self.conv_scale.weight, self.conv_scale.bias, self.conv.weight,
+                                 pw.weight if pw is not None else None, pw.bias if pw is not None else None,
+                                 self.conv_bound.min_val, self.conv_bound.max_val)
         s = ops.codenet_scale(x, self.conv_scale.weight, self.conv_scale.bias,
                               self.conv_bound.min_val, self.conv_bound.max_val)
         d = ops.codenet_dw(x, s, self.conv.weight)

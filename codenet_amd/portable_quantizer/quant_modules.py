@@ -193,6 +193,11 @@ class QuantAct(Module):
                 and not (torch.is_grad_enabled() and x.requires_grad))
 
     def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad
+                and self.quant_mode == "asymmetric" and not self.full_precision_flag and not self.percentile):
+            # training: the same device kernel, straight-through backward (quant_utils.py:202-204)
+            from ..functions.codenet_stage import QuantActSTE
+            return QuantActSTE.apply(x, self)
         if self._native_ok(x):
             bmin = bmax = None
             if self.running_stat and self.percentile:
@@ -386,6 +391,18 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
                 and tuple(cs.stride) == (1, 1) and tuple(pw.kernel_size) == (1, 1)
                 and pw.groups == 1 and self.act_quant_mode == "asymmetric")
 
+    def _train_path_ok(self, x):
+        """Forward + backward of the whole stage on the HIP kernels (functions/codenet_stage.py)."""
+        from ..functions.codenet_stage import native_act_ok
+        dc, cs, pw = self.quant_deform_conv, self.quant_conv_scale, self.quant_conv_channel_bn.conv
+        return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and torch.is_grad_enabled()
+                and tuple(dc.kernel_size) == (3, 3) and tuple(dc.stride) == (1, 1)
+                and tuple(dc.padding) == (1, 1) and tuple(dc.dilation) == (1, 1)
+                and dc.deformable_groups == 1 and dc.groups == dc.in_channels == dc.out_channels
+                and cs.out_channels == 1 and tuple(cs.kernel_size) == (1, 1) and tuple(cs.stride) == (1, 1)
+                and tuple(pw.kernel_size) == (1, 1) and pw.groups == 1 and tuple(pw.stride) == (1, 1)
+                and native_act_ok(self.quant_act[1]) and native_act_ok(self.quant_identity_deform))
+
     def forward(self, x):
         if self._fast_path_ok(x):
             bound = self.quant_act[0]
@@ -396,6 +413,15 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
             d_q = self.quant_identity_deform(d)
             w, b = self.quant_conv_channel_bn.folded()
             return ops.codenet_pointwise(d_q, w, b)
+        if self._train_path_ok(x):
+            # QAT step (config e): the stage as one native autograd function; the weight transformations
+            # (fake-quantisation with straight-through gradients, BN fold) are tiny torch ops under autograd
+            from ..functions.codenet_stage import codenet_stage
+            bound = self.quant_act[0]
+            w, b = self.quant_conv_channel_bn.folded()
+            return codenet_stage(x, self.quant_conv_scale.quantized_weight(), self.quant_conv_scale.bias,
+                                 self.quant_deform_conv.quantized_weight(), w, b, bound.min_val, bound.max_val,
+                                 self.quant_act[1], self.quant_identity_deform)
         s = self.quant_act(self.quant_conv_scale(x))
         dc = self.quant_deform_conv
         if (x.is_cuda and x.dtype == torch.float32 and s.shape[1] == 1

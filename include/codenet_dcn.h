@@ -140,6 +140,28 @@ int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, fl
  * grad_w [C,1,3,3] is ACCUMULATED into (caller zero-fills).  Any of grad_x / grad_s / grad_w
  * may be NULL.  Requires the (H+2)x(W+2) plane to fit LDS twice (H*W up to ~17k pixels).
  * grad_s is dL/ds = sum_k (i-1)*dL/doff_y,k + (j-1)*dL/doff_x,k. */
+/* ------------------------------------------------------------------------------------------
+ * Backward of the two 1x1 convolutions around the gather (config e: the QAT step of quant_main.py; the
+ * reference runs them as cuDNN calls under autograd: conv_scale modules/dcn_deform_conv.py:295,324 /
+ * Quant_Conv2d quant_modules.py:314-321, conv_channel :311-312,328 / QuantBnConv2d :412-419).  NCHW fp32.
+ *
+ * cdn_codenet_pointwise_wgrad: grad_w [Co][C] = sum_{n,p} grad_y[n][co][p] * d[n][c][p] on f32 MFMA and,
+ *   when grad_b != NULL, grad_b [Co] = sum_{n,p} grad_y[n][co][p]; both OVERWRITTEN, split-K partial tiles
+ *   reduced in a fixed order (bitwise reproducible).  workspace: ..._wgrad_workspace_bytes(N,C,Co,HW) bytes,
+ *   16-byte aligned, contents irrelevant.  (The data gradient grad_d = W^T grad_y is
+ *   cdn_codenet_pointwise_forward with the transposed weights.)
+ * cdn_codenet_scale_backward: backward of s_raw = conv1x1(x; C -> 1) + b given grad_s = dL/ds_raw [N][H*W]
+ *   (the caller has applied the Hardtanh mask lo < s_raw < hi and the straight-through QuantAct):
+ *   grad_x [N][C][H*W] += w_scale[c] * grad_s  (ACCUMULATED into, normally the gather's grad_x; may be NULL),
+ *   grad_w_partial [N][C] = sum_p x * grad_s per image (overwritten; the caller sums over n; may be NULL).
+ * ---------------------------------------------------------------------------------------- */
+size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW);
+int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b, int64_t N,
+                                int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
+                                void *stream);
+int cdn_codenet_scale_backward(const float *x, const float *grad_s, const float *w_scale, float *grad_x,
+                               float *grad_w_partial, int64_t N, int64_t C, int64_t H, int64_t W, void *stream);
+
 int cdn_codenet_dw_backward_supported(int64_t H, int64_t W);   /* 1: the plane fits; 0: use the generic path */
 int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
                             const float *grad_d, float *grad_x, float *grad_s, float *grad_w,

@@ -214,6 +214,60 @@ def make_stage_w4a8(ref_mod, ref_qm):
     return t2n(out)
 
 
+def make_stage_w4a8_grads(ref_mod, ref_qm):
+    """cfg5 (BASELINE configs[4], quant_main.py QAT step): the reference's W4A8 stage
+    [QuantDeformConvWithOffsetScaleBoundPositive, Sequential(ReLU, QuantAct), Upsample x2] in train() mode,
+    two consecutive forward + backward passes (the QuantAct ranges move between them).  Gradients flow through
+    the straight-through estimators (quant_utils.py:202-204,227-229), the Hardtanh, the BN fold
+    (quant_modules.py:365-372) and -- rebound to the oracle -- the native backward
+    (dcn_deform_conv_cuda.cpp:260-484)."""
+    g = torch.Generator().manual_seed(41)
+    N, C, Co, H, W = 2, 16, 8, 12, 12
+    out = {}
+    for pct in (False, True):
+        tag = "p" if pct else "n"
+        p = _stage_params(C, Co, g)
+        m = _ref_stage(ref_mod, C, Co, p)
+        bn = torch.nn.BatchNorm2d(Co)
+        bn.weight.data = torch.rand(Co, generator=g) + 0.5
+        bn.bias.data = torch.randn(Co, generator=g) * 0.1
+        bn.running_mean = torch.randn(Co, generator=g) * 0.1
+        bn.running_var = torch.rand(Co, generator=g) + 0.5
+        q = ref_qm.QuantDeformConvWithOffsetScaleBoundPositive(
+            4, 8, act_percentile=False, wt_quant_mode="symmetric", act_quant_mode="asymmetric",
+            per_channel=True, weight_percentile=pct)
+        q.set_param(m, bn)
+        post = torch.nn.Sequential(torch.nn.ReLU(inplace=True), ref_qm.QuantAct(8, quant_mode="asymmetric"))
+        up = torch.nn.Upsample(scale_factor=2, mode="nearest")
+        net = torch.nn.Sequential(q, post, up).train()
+        for k, v in p.items():
+            out["%s_%s" % (tag, k)] = v
+        for k in ("weight", "bias"):
+            out["%s_bn_%s" % (tag, k)] = getattr(bn, k).data.clone()
+        out["%s_bn_running_mean" % tag] = bn.running_mean.clone()
+        out["%s_bn_running_var" % tag] = bn.running_var.clone()
+        params = {"g_w_scale": q.quant_conv_scale.weight, "g_b_scale": q.quant_conv_scale.bias,
+                  "g_w_dw": q.quant_deform_conv.weight, "g_w_pw": q.quant_conv_channel_bn.conv.weight,
+                  "g_bn_weight": q.quant_conv_channel_bn.bn.weight, "g_bn_bias": q.quant_conv_channel_bn.bn.bias}
+        for it in range(2):
+            x = (torch.randn(N, C, H, W, generator=g) * (1.0 + 0.3 * it)).requires_grad_(True)
+            net.zero_grad()
+            y = net(x)
+            go = torch.randn(y.shape, generator=g)
+            y.backward(go)
+            out["%s_x%d" % (tag, it)] = x.detach()
+            out["%s_y%d" % (tag, it)] = y.detach()
+            out["%s_go%d" % (tag, it)] = go
+            out["%s_gx%d" % (tag, it)] = x.grad
+            for k, prm in params.items():
+                out["%s_%s%d" % (tag, k, it)] = prm.grad.clone()
+            out["%s_smin%d" % (tag, it)] = q.quant_act[1].x_min.clone()
+            out["%s_smax%d" % (tag, it)] = q.quant_act[1].x_max.clone()
+            out["%s_dmax%d" % (tag, it)] = q.quant_identity_deform.x_max.clone()
+            out["%s_rmax%d" % (tag, it)] = post[1].x_max.clone()
+    return t2n(out)
+
+
 def make_head_w4a8(ref_qm):
     """The reference's QuantDepthwiseNode (quant_modules.py:1013-1071) on a head-shaped nn.Sequential
     (shufflenetv2_dcn.py:244-262), 3 consecutive forwards (EMA state), plus the fp32 Sequential."""
@@ -431,14 +485,20 @@ def main():
     torch.manual_seed(317)
     torch.set_num_threads(1)
     ref_mod, ref_qm, ref_qu = import_reference()
-    np.savez_compressed(os.path.join(HERE, "quant_ref.npz"), **make_quant_ref(ref_qm, ref_qu))
-    np.savez_compressed(os.path.join(HERE, "stage_fp32.npz"), **make_stage_fp32(ref_mod))
-    np.savez_compressed(os.path.join(HERE, "stage_w4a8.npz"), **make_stage_w4a8(ref_mod, ref_qm))
-    np.savez_compressed(os.path.join(HERE, "deform_raw.npz"), **make_deform_raw())
-    np.savez_compressed(os.path.join(HERE, "model_io.npz"), **make_model_io(ref_qm))
-    np.savez_compressed(os.path.join(HERE, "head_w4a8.npz"), **make_head_w4a8(ref_qm))
-    np.savez_compressed(os.path.join(HERE, "decode_ref.npz"), **make_decode())
-    np.savez_compressed(os.path.join(HERE, "base_nodes.npz"), **make_base_nodes(ref_qm))
+    makers = {
+        "quant_ref": lambda: make_quant_ref(ref_qm, ref_qu),
+        "stage_fp32": lambda: make_stage_fp32(ref_mod),
+        "stage_w4a8": lambda: make_stage_w4a8(ref_mod, ref_qm),
+        "stage_w4a8_grads": lambda: make_stage_w4a8_grads(ref_mod, ref_qm),
+        "deform_raw": make_deform_raw,
+        "model_io": lambda: make_model_io(ref_qm),
+        "head_w4a8": lambda: make_head_w4a8(ref_qm),
+        "decode_ref": make_decode,
+        "base_nodes": lambda: make_base_nodes(ref_qm),
+    }
+    only = sys.argv[1:] or list(makers)           # `make_golden.py stage_w4a8_grads` regenerates one fixture
+    for name in only:
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **makers[name]())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

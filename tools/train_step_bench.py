@@ -1,6 +1,9 @@
-"""Config-e context (BASELINE.json configs[4]): forward + backward of the W4A8 deform stages under
-autograd (QAT step of quant_main.py restricted to the hot path): gather forward/backward on the HIP
-kernels, 1x1 convolutions and fake-quant (straight-through) on PyTorch-ROCm.  GPU only."""
+"""Config e (BASELINE.json configs[4]): forward + backward + Adam step of the W4A8 deform stages (the QAT step
+of quant_main.py restricted to the hot path).  Per stage ONE native autograd function
+(codenet_amd/functions/codenet_stage.py): scale 1x1, QuantAct, gather, QuantAct, pointwise 1x1 forward and
+backward on the HIP kernels (f32 MFMA for the 1x1 convolutions' data and weight gradients, straight-through
+quantisers); the per-channel weight fake-quantisation / BN fold (tiny tensors), ReLU, Upsample and Adam are torch
+ops.  --graph replays the whole step as one HIP graph (a QAT step is ~500 small launches).  GPU only."""
 import argparse
 import json
 import os
@@ -19,13 +22,14 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--graph", action="store_true", help="capture forward + backward + optimizer step in one HIP graph")
     a = ap.parse_args()
     net = pipeline.build_hot_path(quantized=not a.fp32).cuda().train()
     for m in net.modules():                      # BN inside QuantBnConv2d is never called; plain BN in fp32
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eval()
     x = pipeline.make_input(a.batch, a.res, device="cuda").requires_grad_(True)
-    opt = torch.optim.Adam(net.parameters(), lr=1.25e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1.25e-4, capturable=a.graph)     # lib/opts.py:93 lr
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -35,6 +39,25 @@ def main():
         opt.step()
         return loss
 
+    if a.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            y = net(x)
+            static_loss = y.square().mean()
+            static_loss.backward()
+            opt.step()
+
+        def step():   # noqa: F811
+            g.replay()
+            return static_loss
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -44,7 +67,8 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"config": "CoDeNet1x %dx%d %s QAT step over deconv_layers, batch %d" % (
-        a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch), "ms_per_step": round(dt * 1e3, 3),
+        a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch) + (", one HIP graph" if a.graph else ", eager launches"),
+        "ms_per_step": round(dt * 1e3, 3),
         "images_per_s": round(a.batch / dt, 1), "loss": float(loss)}))
 
 
