@@ -532,49 +532,65 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
 // C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
 // ------------------------------------------------------------------------------------------
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int kPwBM = 64, kPwBN = 64, kPwBK = 16;
+constexpr int kPwBM = 64, kPwBN = 64, kPwBK = 32;
 
 __global__ void __launch_bounds__(256)
 pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ ep_scale,
                  const float *__restrict__ ep_shift, float *__restrict__ Y, int C, int Co, int HW,
                  int relu) {
+  // K tiles of 32, the NEXT tile's global loads (4 x 16 B per thread) in flight behind the 16 MFMAs of the
+  // current one: with one 16-deep tile and no prefetch every tile paid a full global-load latency (50 TF at
+  // the stage-0 shape; the QAT step runs this kernel six times: forward and data gradient of three stages)
   __shared__ float As[kPwBK][kPwBM + 4];
-  __shared__ float Bs[kPwBK][kPwBN + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[kPwBK][kPwBN + 4];
   const int n = blockIdx.z;
   const int m0 = blockIdx.y * kPwBM, p0 = blockIdx.x * kPwBN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const float *Dn = D + (long)n * C * HW;
   f32x16 acc = {0};
-  // staging assignments: A tile 64(m) x 16(k): thread -> (m = tid>>2, k4 = (tid&3)*4)
-  //                      B tile 16(k) x 64(n): thread -> (k = tid>>4, n4 = (tid&15)*4)
-  const int am = tid >> 2, ak = (tid & 3) * 4;
+  // staging: A tile 64(m) x 32(k): thread -> (m = tid>>2, 8 consecutive k from (tid&3)*8)
+  //          B tile 32(k) x 64(n): thread -> (k = tid>>4 and +16, 4 pixels from (tid&15)*4)
+  const int am = tid >> 2, ak = (tid & 3) * 8;
   const int bk = tid >> 4, bn = (tid & 15) * 4;
-  const bool hw4 = (HW & 3) == 0;
-  for (int k0 = 0; k0 < C; k0 += kPwBK) {
-    float a[4], b[4];
+  const bool hw4 = (HW & 3) == 0, c4 = (C & 3) == 0;
+  float a[8], b[8];
+  auto load = [&](int k0) {
+    const int m = m0 + am;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = m0 + am, k = k0 + ak + q;
-      a[q] = (m < Co && k < C) ? Wp[(long)m * C + k] : 0.0f;
-    }
-    {
-      const int k = k0 + bk, p = p0 + bn;
-      if (k < C && hw4 && p + 3 < HW) {
-        const float4 v = *reinterpret_cast<const float4 *>(Dn + (long)k * HW + p);
-        b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + ak + 4 * h;
+      if (m < Co && c4 && k + 3 < C) {
+        const float4 v = *reinterpret_cast<const float4 *>(Wp + (long)m * C + k);
+        a[4 * h] = v.x; a[4 * h + 1] = v.y; a[4 * h + 2] = v.z; a[4 * h + 3] = v.w;
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = (k < C && p + q < HW) ? Dn[(long)k * HW + p + q] : 0.0f;
+        for (int q = 0; q < 4; ++q) a[4 * h + q] = (m < Co && k + q < C) ? Wp[(long)m * C + k + q] : 0.0f;
       }
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + bk + 16 * h, p = p0 + bn;
+      if (k < C && hw4 && p + 3 < HW) {
+        const float4 v = *reinterpret_cast<const float4 *>(Dn + (long)k * HW + p);
+        b[4 * h] = v.x; b[4 * h + 1] = v.y; b[4 * h + 2] = v.z; b[4 * h + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[4 * h + q] = (k < C && p + q < HW) ? Dn[(long)k * HW + p + q] : 0.0f;
+      }
+    }
+  };
+  load(0);
+  for (int k0 = 0; k0 < C; k0 += kPwBK) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
-    for (int q = 0; q < 4; ++q) As[ak + q][am] = a[q];
+    for (int q = 0; q < 8; ++q) As[ak + q][am] = a[q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Bs[bk][bn + q] = b[q];
+    for (int h = 0; h < 2; ++h)
+      *reinterpret_cast<float4 *>(&Bs[bk + 16 * h][bn]) = make_float4(b[4 * h], b[4 * h + 1], b[4 * h + 2], b[4 * h + 3]);
     __syncthreads();
+    if (k0 + kPwBK < C) load(k0 + kPwBK);
 #pragma unroll
     for (int kk = 0; kk < kPwBK; kk += 2) {
       const float av = As[kk + (lane >> 5)][wm + (lane & 31)];

@@ -29,7 +29,8 @@ constexpr int kWgBM = 64, kWgBN = 64, kWgBK = 64, kWgLd = kWgBK + 4;
 
 __global__ void __launch_bounds__(256)
 pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float *__restrict__ partial,
-                int C, int Co, int HW, int chunks_per_img, int nchunks, int chunks_per_slice) {
+                float *__restrict__ partial_b, int C, int Co, int HW, int chunks_per_img, int nchunks,
+                int chunks_per_slice) {
   __shared__ __attribute__((aligned(16))) float As[kWgBM][kWgLd];
   __shared__ __attribute__((aligned(16))) float Bs[kWgBN][kWgLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,6 +41,10 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
   const bool hw4 = (HW & 3) == 0;
   f32x16 acc = {0};
   float4 ra[4], rb[4];
+  // bias gradient = row sums of grad_y: taken by the workgroups of channel tile 0 from the A tiles as they pass
+  // through registers (a separate one-workgroup-per-channel kernel took 175 us per step)
+  const bool do_bias = partial_b != nullptr && blockIdx.x == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   auto load = [&](int ch) {
     const int n = ch / chunks_per_img, p0 = (ch - n * chunks_per_img) * kWgBK;
     const float *ga = gy + (long)n * Co * HW, *gb = d + (long)n * C * HW;
@@ -69,6 +74,7 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<float4 *>(&As[lrow + 16 * i][lk]) = ra[i];
       *reinterpret_cast<float4 *>(&Bs[lrow + 16 * i][lk]) = rb[i];
+      if (do_bias) bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
     }
     __syncthreads();
     if (ch + 1 < ch_hi) load(ch + 1);      // in flight during the MFMAs below
@@ -92,33 +98,40 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
     const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (row < Co && col < C) out[(long)row * C + col] = acc[r];
   }
+  if (do_bias) {       // the 16 threads that share a row: lanes 16*j .. 16*j+15 of a wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+#pragma unroll
+      for (int m = 8; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+      const int row = m0 + lrow + 16 * i;
+      if ((tid & 15) == 0 && row < Co) partial_b[(long)z * Co + row] = v;
+    }
+  }
 }
 
-// gw[i] = sum_z partial[z][i], z ascending (fixed order)
+// gw[i] = sum_z partial[z][i] in a fixed order: a workgroup owns 64 outputs, its 4 waves take z = w, w+4, ...
+// with 4 loads in flight, then the 4 wave sums are added in wave order (with few outputs -- 64 x 128 at stage 2 --
+// one thread per output walking hundreds of slices was a 36 us latency chain).
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int nz) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.0f;
-  for (int z = 0; z < nz; ++z) s += partial[(long)z * n + i];
-  gw[i] = s;
-}
-
-// gb[co] = sum_{n,p} gy[n][co][p]: one workgroup per output channel, fixed summation tree
-__global__ void __launch_bounds__(256)
-bias_grad_kernel(const float *__restrict__ gy, float *__restrict__ gb, int N, int Co, int HW) {
-  __shared__ float red[4];
-  const int co = blockIdx.x, tid = threadIdx.x;
-  float s = 0.0f;
-  for (int n = 0; n < N; ++n) {
-    const float *g = gy + ((long)n * Co + co) * HW;
-    for (int p = tid; p < HW; p += 256) s += g[p];
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int z = w;
+    for (; z + 12 < nz; z += 16) {
+      s0 += partial[(long)z * n + i];
+      s1 += partial[(long)(z + 4) * n + i];
+      s2 += partial[(long)(z + 8) * n + i];
+      s3 += partial[(long)(z + 12) * n + i];
+    }
+    for (; z < nz; z += 4) s0 += partial[(long)z * n + i];
   }
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
-  if ((tid & 63) == 0) red[tid >> 6] = s;
+  red[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (tid == 0) gb[co] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (w == 0 && i < n) gw[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -186,7 +199,7 @@ WgPlan wgrad_plan(int64_t N, int64_t C, int64_t Co, int64_t HW) {
 extern "C" size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW) {
   if (N <= 0 || C <= 0 || Co <= 0 || HW <= 0) return 0;
   const WgPlan p = wgrad_plan(N, C, Co, HW);
-  return ((size_t)p.nz * (size_t)Co * (size_t)C * 4 + 255) / 256 * 256;
+  return ((size_t)p.nz * (size_t)Co * (size_t)(C + 1) * 4 + 255) / 256 * 256;   // weight tiles + bias rows
 }
 
 extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b,
@@ -205,17 +218,18 @@ extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, 
   const WgPlan p = wgrad_plan(N, C, Co, HW);
   CDN_REQUIRE(p.tiles_m <= 65535 && p.nz <= 65535, CDN_ERR_UNSUPPORTED, "too many tiles");
   float *partial = static_cast<float *>(workspace);
+  float *partial_b = grad_b ? partial + (size_t)p.nz * Co * C : nullptr;
   pw_wgrad_kernel<<<dim3((unsigned)p.tiles_c, (unsigned)p.tiles_m, (unsigned)p.nz), 256, 0, st>>>(
-      grad_y, d, partial, (int)C, (int)Co, (int)HW, p.chunks_per_img, p.nchunks, p.per_slice);
+      grad_y, d, partial, partial_b, (int)C, (int)Co, (int)HW, p.chunks_per_img, p.nchunks, p.per_slice);
   int rc = cdn::check_launch("codenet pointwise weight gradient");
   if (rc) return rc;
   const long n = (long)(Co * C);
-  wgrad_reduce_kernel<<<(unsigned)cdn::ceil_div(n, 256), 256, 0, st>>>(partial, grad_w, n, p.nz);
+  wgrad_reduce_kernel<<<(unsigned)cdn::ceil_div(n, 64), 256, 0, st>>>(partial, grad_w, n, p.nz);
   rc = cdn::check_launch("codenet pointwise weight gradient reduce");
   if (rc) return rc;
   if (grad_b) {
-    bias_grad_kernel<<<(unsigned)Co, 256, 0, st>>>(grad_y, grad_b, (int)N, (int)Co, (int)HW);
-    rc = cdn::check_launch("codenet pointwise bias gradient");
+    wgrad_reduce_kernel<<<(unsigned)cdn::ceil_div(Co, 64), 256, 0, st>>>(partial_b, grad_b, (long)Co, p.nz);
+    rc = cdn::check_launch("codenet pointwise bias gradient reduce");
   }
   return rc;
 }
