@@ -255,6 +255,13 @@ __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2 *o
 namespace cdn {
 // per-kernel capacity of the {min,max} partial arrays; grids are clamped / checked against it
 constexpr int kMaxPartials = 16384;
+// codenet_fused.hip, shared with the frozen-range schedule (codenet_frozen.hip)
+int stage_channel_chunk(int Hl, int Wl);
+int launch_frozen_scale(const void *x, int x_kind, const unsigned *xq, const float *w_scale, const float *b_scale,
+                        float *s_raw, int64_t N, int64_t C, int64_t HWl, float lo, float hi, hipStream_t st);
+int launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
+                     const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H, int W,
+                     int up, hipStream_t st);
 // Workspace of the stand-alone layer entry points: partials first, arrival counters in the LAST bytes
 // (zeroed once by the caller); size = cdn_codenet_aux_workspace_bytes().
 struct AuxWs {

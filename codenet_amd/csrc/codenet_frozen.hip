@@ -1,0 +1,321 @@
+// codenet_frozen.hip -- the stage schedule for FROZEN QuantAct ranges with byte codes in HBM.
+//
+// In the reference `running_stat` is a plain attribute of QuantAct (portable_quantizer/quant_modules.py:172,181);
+// with running_stat = False the range update (:203-219) is skipped and every QuantAct is a fixed affine grid
+// (quant_utils.py:60-75,193-200).  The batch-global min / max that makes each QuantAct a global dependency in
+// the reference-faithful schedule (codenet_fused.hip) is gone, so:
+//   * no range epilogues, no arrival counters;
+//   * every quantised tensor crosses HBM as ONE byte per element (a = level - 128, see Code8 in
+//     codenet_fused.hip) instead of four: d (gather output) 4x smaller on both sides, the stage output r too;
+//   * the pointwise conv reads its int8 MFMA operand as it lies in memory: no fp32 -> code conversion per tile
+//     and no nibble split (stored codes are in [-128,127] by construction), half the MFMAs of pwi8_kernel.
+// Same arithmetic as the fp32 schedule wherever a rounding happens (scale sums, bilinear taps, the pointwise
+// epilogue fmaf((float)(isum + 128*colsum), 1/(sc*sw), bias), the two-rounding code expression), so as long as
+// no code saturates the results are BIT-IDENTICAL to cdn_codenet_stage_fused_forward with running = 0
+// (tests/test_gpu_frozen.py).  A saturated code (the reference does not clamp, a byte must) sets *overflow:
+// the caller recomputes that batch on the fp32 schedule.
+#include "cdn_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+
+struct Code8 {   // (same as codenet_fused.hip)
+  float qs, qz;
+  int ioff;
+};
+using BadMask = int;
+__device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad) {
+  Code8 c;
+  c.qs = reinterpret_cast<const float *>(state)[2];
+  c.qz = reinterpret_cast<const float *>(state)[3];
+  if (!(fabsf(c.qz) < 4.0e6f)) bad = 1;
+  c.ioff = (int)fminf(fmaxf(c.qz, -4.0e6f), 4.0e6f) - 128 - 0x4B400000;
+  return c;
+}
+__device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
+  const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
+  const int a = (int)__float_as_uint(y) + c.ioff;
+  const int s = min(max(a, -128), 127);
+  bad |= a ^ s;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// frozen_params_kernel: (scale, zero-point) of up to 12 frozen QuantActs from their x_min / x_max buffers
+// into state words [2], [3] -- the expressions of cdn::quantact_update_device without the range update
+// (quant_utils.py:60-75).  One launch per step for the whole schedule.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kMaxFrozen = 12;
+struct FrozenList {
+  const float *x_min[kMaxFrozen];
+  const float *x_max[kMaxFrozen];
+  unsigned *state[kMaxFrozen];
+  int n, bits;
+};
+__global__ void frozen_params_kernel(FrozenList f) {
+  const int i = threadIdx.x;
+  if (i >= f.n) return;
+  const float lo = f.x_min[i][0], hi = f.x_max[i][0];
+  const float nlev = (float)((1 << f.bits) - 1);
+  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);
+  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);          // n / tensor = reciprocal * n in torch
+  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (f.bits - 1)));
+  float *sf = reinterpret_cast<float *>(f.state[i]);
+  sf[2] = scale;
+  sf[3] = zp;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// pwq8_kernel: R8[m][co] = code_r( act( (sum_c a[m][c] * qw[co][c] + 128 * colsum[co]) / (sc_d * sw[co]) + b[co] ) )
+//   a   [M][C]      byte codes of the d quantiser (level - 128), channels-last, as the gather wrote them
+//   qw  [Co][Cpad]  4-bit weight codes as int8, zero padded to a multiple of 64
+// v_mfma_i32_32x32x32_i8: lane (r = l & 31, h = l >> 5) supplies the 16 k bytes [16h, 16h+16) of row r of a
+// 32-byte k step for both operands; C/D as f32 (column = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)).
+// Workgroup tile BM x BN, K tiles of 64 bytes: LDS rows of 64 + 16 bytes (a quarter-wave's 16 ds_read_b128 cover
+// the 64 banks), the next tile's 16-byte global loads in flight behind the MFMAs of the current one.
+// HBM-bound: A is read once (BN covers all Co up to 256), the weights stay in L2.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kQK = 64, kQLD = kQK + 16;
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
+            const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
+            const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
+            const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int C, int Cpad, int Co,
+            int relu) {
+  constexpr int WGM = BM / 32, WGN = 4 / WGM, TN = BN / (32 * WGN);
+  constexpr int AI = BM * kQK / 16 / 256;       // 16-byte loads of A per thread per k tile (1 or 2)
+  constexpr int BI = BN * kQK / 16 / 256;       // of the weights (1, 2 or 4)
+  static_assert(AI >= 1 && BI >= 1 && TN >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) unsigned char As[BM * kQLD];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * kQLD];
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * 32, wn = (wave % WGN) * TN * 32;
+  const float qs = reinterpret_cast<const float *>(aq)[2];
+  const bool a16 = (C & 15) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  i32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
+  // staging: 4 threads per 64-byte row segment
+  const int lr = tid >> 2, lk = (tid & 3) * 16;
+  i32x4 ra[AI], rb[BI];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const long m = min(m0 + lr + 64 * i, M - 1);
+      const int k = k0 + lk;
+      if (a16 && k + 15 < C) {
+        ra[i] = *reinterpret_cast<const i32x4 *>(A + m * C + k);
+      } else {            // ragged tail: bytes beyond C are paired with zero weights, any finite value will do
+        i32x4 t = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + 4 * e + 3 < C) t[e] = *reinterpret_cast<const int *>(A + m * C + k + 4 * e);
+        ra[i] = t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int co = min(n0 + lr + 64 * i, Co - 1);
+      rb[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + lk);
+    }
+  };
+  load(0);
+  const int nk = (C + kQK - 1) / kQK;          // (Cpad >= 64 * nk)
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();                            // the previous tile has been consumed
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<i32x4 *>(&As[(lr + 64 * i) * kQLD + lk]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<i32x4 *>(&Bs[(lr + 64 * i) * kQLD + lk]) = rb[i];
+    __syncthreads();
+    if (t + 1 < nk) load((t + 1) * kQK);
+    const int fo = (lane & 31) * kQLD + (lane >> 5) * 16;
+#pragma unroll
+    for (int ks = 0; ks < kQK / 32; ++ks) {
+      const i32x4 a = *reinterpret_cast<const i32x4 *>(&As[wm * kQLD + fo + ks * 32]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const i32x4 b = *reinterpret_cast<const i32x4 *>(&Bs[(wn + j * 32) * kQLD + fo + ks * 32]);
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: the expressions of pwi8_kernel, then the output quantiser's code (or fp32 for a consumer
+  // that wants pre-quantisation values)
+  BadMask bad = 0;
+  Code8 c8 = {1.f, 0.f, 0};
+  if (R8) c8 = make_code8(rq, bad);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    float bsv = 0.f, rinv = 0.f;
+    int t128 = 0;
+    if (co < Co) {
+      if (bias) bsv = bias[co];
+      rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
+      t128 = 128 * wsum[co];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < M && co < Co) {
+        float v = fmaf((float)(acc[j][r] + t128), rinv, bsv);
+        if (relu) v = fmaxf(v, 0.0f);
+        if (R8) R8[m * Co + co] = (signed char)act_code8(v, c8, bad);
+        else Rf[m * Co + co] = v;
+      }
+    }
+  }
+  if (bad) atomicOr(oflow, 1u);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// expand8_kernel: byte codes [M][C] -> the fake-quantised fp32 values level / scale, channels-last (for consumers
+// that take fp32 + a quantiser state: fake-quantising level / scale again returns the same value).
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+expand8_kernel(const signed char *__restrict__ a, const unsigned *__restrict__ aq, float *__restrict__ out, long n4) {
+  const float scale = reinterpret_cast<const float *>(aq)[2];
+  const float r = __fdiv_rn(1.0f, scale);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const unsigned u = reinterpret_cast<const unsigned *>(a)[i];
+    float4 t;
+    const float l0 = (float)((int)(signed char)(u & 0xff) + 128), l1 = (float)((int)(signed char)((u >> 8) & 0xff) + 128);
+    const float l2 = (float)((int)(signed char)((u >> 16) & 0xff) + 128), l3 = (float)((int)(signed char)(u >> 24) + 128);
+    float q0 = __fmul_rn(l0, r); t.x = fmaf(fmaf(-q0, scale, l0), r, q0);
+    q0 = __fmul_rn(l1, r); t.y = fmaf(fmaf(-q0, scale, l1), r, q0);
+    q0 = __fmul_rn(l2, r); t.z = fmaf(fmaf(-q0, scale, l2), r, q0);
+    q0 = __fmul_rn(l3, r); t.w = fmaf(fmaf(-q0, scale, l3), r, q0);
+    reinterpret_cast<float4 *>(out)[i] = t;
+  }
+}
+
+template <int BM, int BN>
+void launch_pwq8(const signed char *A, const unsigned *aq, const signed char *Wq, const float *ws, const int *wsum,
+                 const float *bias, signed char *R8, float *Rf, const unsigned *rq, unsigned *oflow, long M, int C,
+                 int Co, int relu, hipStream_t st) {
+  dim3 g((unsigned)cdn::ceil_div(M, BM), (unsigned)cdn::ceil_div(Co, BN));
+  pwq8_kernel<BM, BN><<<g, 256, 0, st>>>(A, aq, Wq, ws, wsum, bias, R8, Rf, rq, oflow, M, C, (C + 63) / 64 * 64, Co,
+                                         relu);
+}
+
+}  // namespace
+
+extern "C" int cdn_quantact_frozen_params(int n, float *const *x_min, float *const *x_max, void *const *state,
+                                          int bits, void *stream) {
+  CDN_REQUIRE(n >= 0 && n <= kMaxFrozen, CDN_ERR_ARG, "at most %d QuantActs per call", kMaxFrozen);
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
+  if (n == 0) return CDN_OK;
+  CDN_REQUIRE(x_min && x_max && state, CDN_ERR_ARG, "null pointer");
+  FrozenList f;
+  f.n = n;
+  f.bits = bits;
+  for (int i = 0; i < kMaxFrozen; ++i) {
+    const int j = i < n ? i : 0;
+    CDN_REQUIRE(x_min[j] && x_max[j] && state[j], CDN_ERR_ARG, "null pointer in entry %d", j);
+    f.x_min[i] = x_min[j];
+    f.x_max[i] = x_max[j];
+    f.state[i] = static_cast<unsigned *>(state[j]);
+  }
+  frozen_params_kernel<<<1, 64, 0, cdn::as_stream(stream)>>>(f);
+  return cdn::check_launch("frozen QuantAct parameters");
+}
+
+extern "C" size_t cdn_codenet_stage_frozen_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up) {
+  const int64_t HWl = (H >> x_up) * (W >> x_up);
+  auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
+  return (size_t)(r(N * HWl * 4) + r(N * H * W * C));        // s_raw (fp32) + d (byte codes)
+}
+
+extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void *a_state, int64_t M, int64_t C,
+                                                int64_t Co, const signed char *w_codes, const float *w_scale,
+                                                const int *w_colsum, const float *bias, int relu,
+                                                const void *r_state, signed char *r8_out, float *r_out,
+                                                unsigned *overflow, void *stream) {
+  CDN_REQUIRE(a && a_state && w_codes && w_scale && w_colsum && overflow, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE((r8_out != nullptr) != (r_out != nullptr), CDN_ERR_ARG, "exactly one of r8_out / r_out");
+  CDN_REQUIRE(r8_out == nullptr || r_state != nullptr, CDN_ERR_ARG, "byte output needs the output quantiser state");
+  CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && (C & 3) == 0, CDN_ERR_ARG, "bad size (C %% 4 == 0)");
+  CDN_REQUIRE(M * std::max(C, Co) < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 3) == 0,
+              CDN_ERR_ARG, "w_codes must be 16-byte, a 4-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const unsigned *aq = static_cast<const unsigned *>(a_state), *rq = static_cast<const unsigned *>(r_state);
+  const int bn = Co <= 64 ? 64 : (Co <= 128 ? 128 : 256);
+  const long gy = cdn::ceil_div(Co, bn);
+  const bool small_m = cdn::ceil_div(M, 128) * gy < 2L * cdn::kCUs;
+#define CDN_Q8(BM_, BN_) \
+  launch_pwq8<BM_, BN_>(a, aq, w_codes, w_scale, w_colsum, bias, r8_out, r_out, rq, overflow, (long)M, (int)C, (int)Co, relu, st)
+  if (bn == 256) CDN_Q8(64, 256);                 // (one 64-row tile holds 64 accumulator registers per lane)
+  else if (bn == 128) { if (small_m) CDN_Q8(64, 128); else CDN_Q8(128, 128); }
+  else { if (small_m) CDN_Q8(64, 64); else CDN_Q8(128, 64); }
+#undef CDN_Q8
+  return cdn::check_launch("codenet pointwise on byte codes");
+}
+
+extern "C" int cdn_codenet_stage_frozen_forward(
+    const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
+    const float *w_scale, const float *b_scale, float lo, float hi, const float *w_dw,
+    const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
+    const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
+    signed char *r8_out, unsigned *overflow, void *stream) {
+  CDN_REQUIRE(x && w_scale && w_dw && w_pw_codes && w_pw_scale && w_pw_colsum && s_state && d_state && r_state &&
+                  workspace && r8_out && overflow, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(x_kind >= 0 && x_kind <= 2 && (x_up == 0 || x_up == 1), CDN_ERR_ARG, "bad x_kind / x_up");
+  CDN_REQUIRE((x_kind == 0) == (x_state == nullptr), CDN_ERR_ARG,
+              "x_state goes with channels-last inputs (x_kind 1, 2) and only with them");
+  CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(!x_up || ((H & 1) == 0 && (W & 1) == 0), CDN_ERR_SHAPE, "x_up needs even H, W");
+  CDN_REQUIRE(x_up == 0 || x_kind != 0, CDN_ERR_UNSUPPORTED, "an up-sampled input must be channels-last");
+  CDN_REQUIRE((C & 3) == 0, CDN_ERR_UNSUPPORTED, "byte codes need C %% 4 == 0 (got %lld)", (long long)C);
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31) && N * Co * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED,
+              "shape too large");
+  CDN_REQUIRE(workspace_bytes >= cdn_codenet_stage_frozen_workspace_bytes(N, C, H, W, x_up) &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, CDN_ERR_WORKSPACE,
+              "workspace too small or not 256-byte aligned");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(r8_out) & 15) == 0,
+              CDN_ERR_ARG, "x / r8_out must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const int64_t HWl = (H >> x_up) * (W >> x_up);
+  auto r256 = [](int64_t b) { return (b + 255) / 256 * 256; };
+  float *s_raw = static_cast<float *>(workspace);
+  signed char *d8 = static_cast<signed char *>(workspace) + r256(N * HWl * 4);
+  const unsigned *xq = static_cast<const unsigned *>(x_state);
+  const int ptag = (int)(H > 0xffff ? 0xffff : H);
+  int rc;
+  {
+    cdn::ProfScope ps(cdn::kProfScale, ptag, st);
+    rc = cdn::launch_frozen_scale(x, x_kind, xq, w_scale, b_scale, s_raw, N, C, HWl, lo, hi, st);
+  }
+  if (rc) return rc;
+  {
+    cdn::ProfScope ps(cdn::kProfDw, ptag, st);
+    rc = cdn::launch_frozen_dw(x, x_kind, xq, s_raw, static_cast<const unsigned *>(s_state), w_dw, d8,
+                               static_cast<unsigned *>(const_cast<void *>(d_state)), overflow, (int)N, (int)C, (int)H,
+                               (int)W, x_up, st);
+  }
+  if (rc) return rc;
+  cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+  return cdn_codenet_pointwise_q8_forward(d8, d_state, N * H * W, C, Co, w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw,
+                                          relu, r_state, r8_out, nullptr, overflow, stream);
+}
+
+extern "C" int cdn_codenet_expand_codes(const signed char *a, const void *a_state, float *out, int64_t numel,
+                                        void *stream) {
+  CDN_REQUIRE(a && a_state && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(numel > 0 && (numel & 3) == 0, CDN_ERR_ARG, "numel must be a positive multiple of 4");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(a) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, CDN_ERR_ARG,
+              "a must be 4-byte, out 16-byte aligned");
+  const long n4 = (long)(numel >> 2);
+  const int blocks = (int)std::min<long>(cdn::ceil_div(n4, 256), (long)cdn::kCUs * 8);
+  expand8_kernel<<<blocks, 256, 0, cdn::as_stream(stream)>>>(a, static_cast<const unsigned *>(a_state), out, n4);
+  return cdn::check_launch("codenet expand codes");
+}

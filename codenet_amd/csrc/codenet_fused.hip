@@ -86,6 +86,51 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
   return a;
 }
 
+// ---- int8 activation codes in HBM (frozen-range schedule, codenet_frozen.hip) -------------------------
+// A frozen QuantAct (running_stat = False, quant_modules.py:203-219 skipped) has a fixed (scale, zp), so its
+// output can cross HBM as ONE byte per element: a = L - 128 with the level L = q + zp, q = round(scale*x - zp)
+// (quant_utils.py:33-41,60-75); the value every consumer sees is L / scale, exactly what the fp32 schedule
+// materialises.  The reference does not clamp q (quant_utils.py:193-200); a byte must: a code outside
+// [-128,127] is saturated AND reported through a device flag -- the caller then recomputes that batch on the
+// fp32 schedule.  Rounding: the 1.5*2^23 trick, as in pwi8_kernel::ucode (round-half-even of the reference's
+// two-rounding expression); values too large for the trick land far outside int8 and are flagged as well.
+struct Code8 {
+  float qs, qz;
+  int ioff;       // (int)qz - 128 - 0x4B400000
+};
+using BadMask = int;     // per-lane: non-zero when some code of this lane saturated
+__device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad) {
+  Code8 c;
+  c.qs = reinterpret_cast<const float *>(state)[2];
+  c.qz = reinterpret_cast<const float *>(state)[3];
+  if (!(fabsf(c.qz) < 4.0e6f)) bad = 1;          // degenerate range: the integer offset would overflow
+  c.ioff = (int)fminf(fmaxf(c.qz, -4.0e6f), 4.0e6f) - 128 - 0x4B400000;
+  return c;
+}
+__device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
+  const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
+  const int a = (int)__float_as_uint(y) + c.ioff;
+  const int s = min(max(a, -128), 127);
+  bad |= a ^ s;          // (non-zero iff the clamp changed the code: one xor + one or, no compare)
+  return s;
+}
+__device__ __forceinline__ unsigned pack_code8(const float4 &v, const Code8 &c, BadMask &bad) {
+  return (unsigned)(act_code8(v.x, c, bad) & 0xff) | ((unsigned)(act_code8(v.y, c, bad) & 0xff) << 8) |
+         ((unsigned)(act_code8(v.z, c, bad) & 0xff) << 16) | ((unsigned)act_code8(v.w, c, bad) << 24);
+}
+// four stored codes -> the fake-quantised values L / scale (Markstein division, bit-identical to
+// cdn::fake_quant_r of the pre-quantisation value that produced the code)
+__device__ __forceinline__ float4 unpack_code8(unsigned u, float scale, float r) {
+  float4 t;
+  const float l0 = (float)((int)(signed char)(u & 0xff) + 128), l1 = (float)((int)(signed char)((u >> 8) & 0xff) + 128);
+  const float l2 = (float)((int)(signed char)((u >> 16) & 0xff) + 128), l3 = (float)((int)(signed char)(u >> 24) + 128);
+  float q0 = __fmul_rn(l0, r); t.x = fmaf(fmaf(-q0, scale, l0), r, q0);
+  q0 = __fmul_rn(l1, r); t.y = fmaf(fmaf(-q0, scale, l1), r, q0);
+  q0 = __fmul_rn(l2, r); t.z = fmaf(fmaf(-q0, scale, l2), r, q0);
+  q0 = __fmul_rn(l3, r); t.w = fmaf(fmaf(-q0, scale, l3), r, q0);
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------
 // scale, NCHW input (stage 0 of the model: x comes from the PyTorch backbone).
 // s[n,p] = clamp(b + sum_c w[c]*x[n,c,p]); block min/max -> state.
@@ -141,7 +186,7 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
 // scale, channels-last input x[pix][C] (stored resolution), optional fake-quant on load.
 // One wave per pixel step; lane covers channels 4*lane + 256*j (float4 loads: C % 4 == 0).
 // ------------------------------------------------------------------------------------------
-template <bool XQ>
+template <bool XQ, bool X8 = false>      // X8: x is a byte tensor of codes of the quantiser xq (see Code8)
 __global__ void __launch_bounds__(256)
 scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                   const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ s,
@@ -162,9 +207,14 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     const float *xp = x + p * C;
     float acc = 0.f;
     for (int c = lane * 4; c < C; c += 256) {
-      float4 v = *reinterpret_cast<const float4 *>(xp + c);
+      float4 v;
+      if (X8)
+        v = unpack_code8(*reinterpret_cast<const unsigned *>(reinterpret_cast<const signed char *>(x) + p * C + c),
+                         qs, qr_);
+      else
+        v = *reinterpret_cast<const float4 *>(xp + c);
       const float4 ww = *reinterpret_cast<const float4 *>(w + c);
-      if (XQ) {
+      if (XQ && !X8) {
         v.x = cdn::fake_quant_r(v.x, qs, qz, qr_);
         v.y = cdn::fake_quant_r(v.y, qs, qz, qr_);
         v.z = cdn::fake_quant_r(v.z, qs, qz, qr_);
@@ -196,7 +246,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 // = 4 mod 32 banks).  Used for large planes only (see the launch site).
 // ------------------------------------------------------------------------------------------
 constexpr int kScaleTilePix = 64;
-template <bool XQ>
+template <bool XQ, bool X8 = false>
 __global__ void __launch_bounds__(256)
 scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                        const float *__restrict__ w, const float *__restrict__ b,
@@ -216,14 +266,17 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
     qr_ = __fdiv_rn(1.0f, qs);   // Markstein division in fake_quant_r
     qz = reinterpret_cast<const float *>(xq)[3];
   }
-  const float4 *xt = reinterpret_cast<const float4 *>(x + pix0 * C);
+  const float4 *xt = reinterpret_cast<const float4 *>(x + (X8 ? 0 : pix0 * C));
+  const unsigned *xt8 = reinterpret_cast<const unsigned *>(reinterpret_cast<const signed char *>(x) + pix0 * C);
   const float4 *w4 = reinterpret_cast<const float4 *>(w);
   constexpr int U = 16;               // 64 * 64 / 256: every load of a C = 256 tile in flight
   float4 v[U];
+  unsigned v8[X8 ? U : 1];
 #pragma unroll
   for (int i = 0; i < U; ++i) {
     const int q = threadIdx.x + 256 * i;
-    v[i] = q < total ? xt[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (X8) v8[X8 ? i : 0] = q < total ? xt8[q] : 0x80808080u;
+    else v[i] = q < total ? xt[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < U; ++i) {
@@ -231,8 +284,8 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
     if (q < total) {
       const int pix = q / CQ, cq = q - pix * CQ;
       const float4 ww = w4[cq];
-      float4 t = v[i];
-      if (XQ) {
+      float4 t = X8 ? unpack_code8(v8[X8 ? i : 0], qs, qr_) : v[i];
+      if (XQ && !X8) {
         t.x = cdn::fake_quant_r(t.x, qs, qz, qr_);
         t.y = cdn::fake_quant_r(t.y, qs, qz, qr_);
         t.z = cdn::fake_quant_r(t.z, qs, qz, qr_);
@@ -323,10 +376,12 @@ constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (5
 
 // The gather + depthwise of one staged plane (shared by dw2_kernel and the persistent dw2p_kernel):
 // img = [(Hl+1)*(Wl+1)][CCH] cells with the zero row / column, wl = [CCH][9] weights, sl = scale plane.
-template <int CCH, int DEEP>
+// OUT8: d is a byte tensor of codes (see Code8) instead of fp32; mn / mx are not tracked.
+template <int CCH, int DEEP, bool OUT8 = false>
 __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, const float *sl,
                                            float *__restrict__ d, int n, int c0, int C, int H, int W,
-                                           int up, int kWaves, float &mn, float &mx) {
+                                           int up, int kWaves, float &mn, float &mx,
+                                           const Code8 *c8 = nullptr, BadMask *bad = nullptr) {
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
   const int tid = threadIdx.x;
@@ -493,7 +548,11 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
 #undef CDN_TAP2
 #undef CDN_WACC
 #undef CDN_RD
-      if (p < p_end) {
+      if (OUT8) {
+        if (p < p_end && c0 + cq * 4 + 3 < C)       // (C % 4 == 0 is checked by the host)
+          reinterpret_cast<unsigned *>(reinterpret_cast<signed char *>(d) + ((long)n * HW + p) * C + c0)[cq] =
+              pack_code8(acc, *c8, *bad);
+      } else if (p < p_end) {
         float *dp = d + ((long)n * HW + p) * C + c0 + cq * 4;
         const int cbase = c0 + cq * 4;
         if (vec_store && cbase + 3 < C) {
@@ -518,12 +577,15 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
   }
 }
 
-template <int CCH, bool NHWC_IN, bool XQ, bool SQ, int MAXT>
+// X8 (with NHWC_IN and XQ): x is a byte tensor of codes of the quantiser xq.  OUT8: d is a byte tensor of codes
+// of the quantiser qu.state (frozen: no range tracking), dmm is reinterpreted as the overflow flag word.
+template <int CCH, bool NHWC_IN, bool XQ, bool SQ, int MAXT, bool X8 = false, bool OUT8 = false>
 __global__ void __launch_bounds__(MAXT)
 dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
            int C, int H, int W, int up) {
+  static_assert(!X8 || (NHWC_IN && XQ), "codes come channels-last with their quantiser state");
   // LDS: [(Hl+1)*(Wl+1)][CCH] image cells; row Hl and column Wl are ZERO and every out-of-image
   // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
   // cell address is just row offset + column offset, no bounds test and no clamp per corner.
@@ -563,7 +625,28 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   // flight per thread); a plain loop leaves ONE dependent load per thread in flight and the
   // staging then costs a full HBM round trip per iteration (measured: 21 of 58 us at stage 0).
   constexpr int kStageU = 8;
-  if (NHWC_IN) {
+  if (X8) {
+    const signed char *xg = reinterpret_cast<const signed char *>(x) + (long)n * HWl * C + c0;
+    const int total = HWl * LPP;
+    for (int base = 0; base < total; base += kDw2Threads * kStageU) {
+      unsigned v[kStageU];
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * kDw2Threads + tid;
+        const int pix = q / LPP, cq = q % LPP;
+        v[u] = 0x80808080u;                                           // level 0
+        if (q < total && c0 + cq * 4 + 3 < C) v[u] = *reinterpret_cast<const unsigned *>(xg + (long)pix * C + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * kDw2Threads + tid;
+        const int pix = q / LPP, cq = q % LPP;
+        if (q < total)
+          img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] =
+              (c0 + cq * 4 + 3 < C) ? unpack_code8(v[u], xs, xr_) : z4;
+      }
+    }
+  } else if (NHWC_IN) {
     const float *xg = x + (long)n * HWl * C + c0;
     const int total = HWl * LPP;
     for (int base = 0; base < total; base += kDw2Threads * kStageU) {
@@ -655,6 +738,13 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   __syncthreads();
   CDN_STAMP(2);
   float mn = INFINITY, mx = -INFINITY;
+  if (OUT8) {
+    BadMask bad = 0;
+    const Code8 c8 = make_code8(qu.state, bad);
+    dw2_gather<CCH, DEEP, true>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx, &c8, &bad);
+    if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
+    return;
+  }
   dw2_gather<CCH, DEEP>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx);
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
@@ -711,12 +801,13 @@ __device__ __forceinline__ int fold_axis(const AxisRaw &a, const AxisRaw &b, flo
   return cb;
 }
 
-template <int CCH, bool XQ, bool SQ>
+template <int CCH, bool XQ, bool SQ, bool X8 = false, bool OUT8 = false>   // X8 / OUT8: see dw2_kernel
 __global__ void __launch_bounds__(512)   // ~250 VGPRs: 2 waves/SIMD (168 spills and is 2.5x slower)
 dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
             int C, int H, int W) {
+  static_assert(!X8 || XQ, "codes come with their quantiser state");
   extern __shared__ float4 img[];
   CDN_STAMP(0);
   constexpr int LPP = CCH / 4;     // lanes per block (one float4 of channels each)
@@ -747,7 +838,29 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
     img[cell * LPP + (q % LPP)] = z4;
   }
-  {
+  if (X8) {
+    constexpr int kStageU = 8;
+    const signed char *xg = reinterpret_cast<const signed char *>(x) + (long)n * HWl * C + c0;
+    const int total = HWl * LPP;
+    for (int base = 0; base < total; base += nthreads * kStageU) {
+      unsigned v[kStageU];
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * nthreads + tid;
+        const int pix = q / LPP, cq4 = q % LPP;
+        v[u] = 0x80808080u;
+        if (q < total && c0 + cq4 * 4 + 3 < C) v[u] = *reinterpret_cast<const unsigned *>(xg + (long)pix * C + cq4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const int q = base + u * nthreads + tid;
+        const int pix = q / LPP, cq4 = q % LPP;
+        if (q < total)
+          img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq4] =
+              (c0 + cq4 * 4 + 3 < C) ? unpack_code8(v[u], xs, xr_) : z4;
+      }
+    }
+  } else {
     // batched: kStageU loads per thread in flight (see dw2_kernel)
     constexpr int kStageU = 8;
     const float *xg = x + (long)n * HWl * C + c0;
@@ -805,6 +918,9 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
 
   float mn = INFINITY, mx = -INFINITY;
+  BadMask bad = 0;
+  Code8 c8 = {1.f, 0.f, 0};
+  if (OUT8) c8 = make_code8(qu.state, bad);
   const bool vec_store = ((C & 3) == 0);
   // every wave owns a contiguous range of blocks (= stored pixels)
   const int bpw = (HWl + nwaves - 1) / nwaves;
@@ -932,7 +1048,12 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
           for (int px = 0; px < 2; ++px) {
             const float4 a = acc[py][px];
             float *dp = d + ((long)n * HW + (long)(2 * Y + py) * W + 2 * X + px) * C + cbase;
-            if (vec_store && cbase + 3 < C) {
+            if (OUT8) {
+              if (cbase + 3 < C)
+                *reinterpret_cast<unsigned *>(reinterpret_cast<signed char *>(d) +
+                                              ((long)n * HW + (long)(2 * Y + py) * W + 2 * X + px) * C + cbase) =
+                    pack_code8(a, c8, bad);
+            } else if (vec_store && cbase + 3 < C) {
               *reinterpret_cast<float4 *>(dp) = a;
               mn = fminf(mn, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
               mx = fmaxf(mx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
@@ -951,6 +1072,10 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     }
   }
 #undef CDN_RD
+  if (OUT8) {
+    if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
+    return;
+  }
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
@@ -2277,6 +2402,87 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
 
 }  // namespace
 
+// ---- launchers of the frozen-range schedule (codenet_frozen.hip): the same scale / gather kernels with byte
+// codes on one or both sides.  x_kind: 0 = NCHW fp32 final values, 1 = channels-last fp32 pre-quantisation
+// values + their quantiser state xq, 2 = channels-last byte codes of the quantiser xq.  The kernel choice
+// mirrors cdn_codenet_stage_fused_forward, so that every fp32 sum is formed in the same order (bit-identical
+// s_raw and d codes).
+int cdn::launch_frozen_scale(const void *x, int x_kind, const unsigned *xq, const float *w_scale,
+                             const float *b_scale, float *s_raw, int64_t N, int64_t C, int64_t HWl, float lo,
+                             float hi, hipStream_t st) {
+  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
+  const float *xf = static_cast<const float *>(x);
+  const long npix = (long)(N * HWl);
+  if (x_kind == 0) {
+    dim3 grid((unsigned)cdn::ceil_div(HWl, 64), (unsigned)N);
+    scale_nchw_kernel<<<grid, kScaleWaves * 64, 0, st>>>(xf, w_scale, b_scale, s_raw, nullptr, none, (int)C,
+                                                          (int)HWl, lo, hi);
+  } else if (C <= 256 && npix >= 32768 && cdn::ceil_div(npix, kScaleTilePix) <= cdn::kMaxPartials) {
+    const int blocks = (int)cdn::ceil_div(npix, kScaleTilePix);
+    const int CQ = (int)C >> 2, LD = ((CQ + 31) & ~31) + 4;
+    const size_t lds = ((size_t)kScaleTilePix * LD + 16) * sizeof(float);
+    if (x_kind == 2)
+      scale_nhwc_tile_kernel<true, true><<<blocks, 256, lds, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none,
+                                                                   (int)C, npix, lo, hi);
+    else
+      scale_nhwc_tile_kernel<true><<<blocks, 256, lds, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none, (int)C,
+                                                             npix, lo, hi);
+  } else {
+    const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
+    if (x_kind == 2)
+      scale_nhwc_kernel<true, true><<<blocks, 256, 0, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none, (int)C,
+                                                            npix, lo, hi);
+    else
+      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none, (int)C, npix,
+                                                      lo, hi);
+  }
+  return cdn::check_launch("codenet frozen scale");
+}
+
+namespace {
+template <int CCH>
+int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
+                       const float *wd, float *d8, unsigned *dstate, float2 *oflow, int N, int C, int H, int W,
+                       int up, hipStream_t st) {
+  const int Hl = H >> up, Wl = W >> up;
+  const size_t lds = ((size_t)(Hl + 1) * (Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl + 2 * kDw2MaxThreads / 64 + 4) *
+                     sizeof(float);
+  dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
+  const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
+  const int threads = two_per_cu ? 512 : 1024;
+  const cdn::QUpdate qu{nullptr, nullptr, dstate, nullptr, 0.f, 0.f, 8, 0};
+#define CDN_FGO(KERN, THREADS, ...)                                                                         \
+  {                                                                                                         \
+    auto kern = KERN;                                                                                       \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    kern<<<grid, THREADS, lds, st>>>(x, xq, s_raw, sq, wd, d8, oflow, qu, C, H, W, ##__VA_ARGS__);          \
+  }
+  if (x_kind != 0 && up == 1) {
+    if (x_kind == 2) CDN_FGO((dw2u_kernel<CCH, true, true, true, true>), 512)
+    else CDN_FGO((dw2u_kernel<CCH, true, true, false, true>), 512)
+  } else if (x_kind == 2) {
+    CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, true, true>), threads, up)
+  } else if (x_kind == 1) {
+    CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, false, true>), threads, up)
+  } else {
+    CDN_FGO((dw2_kernel<CCH, false, false, true, kDw2MaxThreads, false, true>), threads, up)
+  }
+#undef CDN_FGO
+  return cdn::check_launch("codenet frozen gather");
+}
+}  // namespace
+
+int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
+                          const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H,
+                          int W, int up, hipStream_t st) {
+  const int cch = cdn::stage_channel_chunk(H >> up, W >> up);
+  if (cch == 0) return cdn::fail(CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident gather");
+  if ((long)cdn::ceil_div(C, cch) * N > cdn::kMaxPartials) return cdn::fail(CDN_ERR_UNSUPPORTED, "too many workgroups");
+  auto fn = cch == 64 ? launch_frozen_dw_t<64> : launch_frozen_dw_t<32>;
+  return fn(static_cast<const float *>(x), x_kind, xq, s_raw, sq, wd, reinterpret_cast<float *>(d8), dstate,
+            reinterpret_cast<float2 *>(oflow), N, C, H, W, up, st);
+}
+
 // Pointwise (1x1) convolution on a channels-last activation A [M][C] -> R [M][Co]: int8 MFMA on codes
 // when the A quantiser state and the integer weights are given, f32 MFMA otherwise.  Shared by the
 // stage schedule and the stand-alone entry point (detection heads).
@@ -2405,7 +2611,7 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
 
 // LDS budget of the gather kernel decides the channel chunk (64 or 32 channels x the whole stored plane);
 // 0: the plane does not fit
-static int stage_channel_chunk(int Hl, int Wl) {
+int cdn::stage_channel_chunk(int Hl, int Wl) {
   const size_t cells = (size_t)(Hl + 1) * (Wl + 1);   // + the zero row and zero column
   const long lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (long)Hl * Wl * 4;   // scale plane, weights, scratch
   if (lds_max <= 0) return 0;
@@ -2420,7 +2626,7 @@ extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int6
   if (x_nhwc && (C & 3)) return 0;
   if (N > 65535 || N * C * H * W >= (1ll << 31)) return 0;
   if ((H >> x_up) > 4096 || (W >> x_up) > 4096) return 0;
-  const int cch = stage_channel_chunk((int)(H >> x_up), (int)(W >> x_up));
+  const int cch = cdn::stage_channel_chunk((int)(H >> x_up), (int)(W >> x_up));
   return cch != 0 && cdn::ceil_div(C, cch) * N <= kMaxPartials;
 }
 
@@ -2472,7 +2678,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
            *rst = static_cast<unsigned *>(r_state);
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
 
-  const int cch = (Hl <= 4096 && Wl <= 4096) ? stage_channel_chunk(Hl, Wl) : 0;
+  const int cch = (Hl <= 4096 && Wl <= 4096) ? cdn::stage_channel_chunk(Hl, Wl) : 0;
   CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
               "stored plane %dx%d too large for the LDS-resident gather (max ~1250 pixels)", Hl, Wl);
 

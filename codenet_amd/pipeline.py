@@ -403,6 +403,182 @@ class FusedHotPath:
         return replay
 
 
+class FrozenHotPath:
+    """``deconv_layers`` (W4A8) with FROZEN QuantAct ranges on byte codes: cdn_codenet_stage_frozen_forward, three
+    launches per stage, every quantised tensor crosses HBM as one byte per element.  This is the serving
+    mode (``QuantAct.running_stat = False``: a plain attribute in the reference, quant_modules.py:172,181,203-219),
+    NOT the reference's default -- ``FusedHotPath`` is.  Results are bit-identical to ``FusedHotPath`` with
+    running_stat False as long as no activation leaves its frozen 8-bit grid; the reference does not clamp codes,
+    a byte must, so a saturated code raises the sticky device flag read by ``overflowed()`` and the caller
+    recomputes that batch with ``FusedHotPath``.  Stages whose input channel count is not a multiple of 4
+    (CoDeNet2x stage 0, C = 2153) run on the fp32 frozen schedule and hand fp32 + state to the next stage."""
+
+    def __init__(self, deconv_layers):
+        from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
+        mods = list(deconv_layers)
+        if not mods or not isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive):
+            raise NotImplementedError("FrozenHotPath needs the W4A8 deconv_layers")
+        if not FusedHotPath.supported(deconv_layers):
+            raise NotImplementedError("this deconv_layers configuration is not implemented by the fused schedules")
+        self.seq = deconv_layers
+        self.stages = [mods[i:i + 3] for i in range(0, len(mods), 3)]
+        for st in self.stages:
+            if st[0].quant_conv_channel_bn.folded_int8() is None:
+                raise NotImplementedError("FrozenHotPath needs per-channel symmetric <= 4-bit pointwise weights")
+        self._fp32 = FusedHotPath(deconv_layers)        # fp32 frozen schedule for stages without byte codes
+        self._bufs = None
+
+    def _acts(self, st):
+        return (st[0].quant_act[1], st[0].quant_identity_deform, st[1][1])
+
+    def _alloc(self, shape, dev, nhwc_in):
+        import ctypes
+        from . import _native as N_
+        Nb, C, H, W = shape
+        lib = N_.lib()
+        bufs, ws_bytes, ws32_bytes = [], 0, 0
+        for i, st in enumerate(self.stages):
+            cin = st[0].quant_deform_conv.in_channels
+            cout = st[0].quant_conv_channel_bn.conv.out_channels
+            up = 0 if i == 0 else 1
+            Hs, Ws = (H, W) if i == 0 else (bufs[-1]["H"] * 2, bufs[-1]["W"] * 2)
+            codes = cin % 4 == 0 and bool(lib.cdn_codenet_stage_supported(Nb, cin, Hs, Ws, 1 if (i or nhwc_in) else 0, up))
+            if codes:
+                ws_bytes = max(ws_bytes, lib.cdn_codenet_stage_frozen_workspace_bytes(Nb, cin, Hs, Ws, up))
+            else:
+                ws32_bytes = max(ws32_bytes, lib.cdn_codenet_stage_workspace_bytes(Nb, cin, Hs, Ws, up))
+            bufs.append(dict(C=cin, Co=cout, H=Hs, W=Ws, up=up, codes=codes,
+                             r8=torch.empty(Nb, Hs * Ws, cout, dtype=torch.int8, device=dev) if codes else None,
+                             r=None if codes else torch.empty(Nb, Hs * Ws, cout, device=dev)))
+        acts = [a for st in self.stages for a in self._acts(st)]
+        n = len(acts)
+        arr = ctypes.c_void_p * n
+        last = bufs[-1]
+        self._bufs = dict(
+            key=(tuple(shape), dev, nhwc_in), stages=bufs,
+            ws=torch.empty(ws_bytes + 512, dtype=torch.uint8, device=dev),
+            ws32=torch.zeros(ws32_bytes // 4 + 64, device=dev) if ws32_bytes else None,
+            overflow=torch.zeros(1, dtype=torch.int32, device=dev),
+            expanded=torch.empty(Nb, last["H"] * last["W"], last["Co"], device=dev),
+            out=torch.empty(Nb, last["Co"], last["H"] * 2, last["W"] * 2, device=dev),
+            n_acts=n, acts=acts,      # (kept alive: the pointer arrays below refer to their buffers)
+            p_min=arr(*[a.x_min.data_ptr() for a in acts]), p_max=arr(*[a.x_max.data_ptr() for a in acts]),
+            p_state=arr(*[a._device_state(dev).data_ptr() for a in acts]))
+
+    def forward_codes(self, x, x_qstate=None, hw=None):
+        """-> (r8 [N, H*W, Co] int8 codes of the last stage's output QuantAct (or the fp32 tensor when that stage
+        had to run on the fp32 schedule), r_state pointer, the stage's shape dict).  Input as FusedHotPath.forward_nhwc."""
+        from . import _native as N_
+        nhwc_in = hw is not None
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == (3 if nhwc_in else 4)):
+            raise NotImplementedError("FrozenHotPath needs a float32 GPU tensor: NCHW, or [N, H*W, C] with hw")
+        x = x.contiguous()
+        shape = (x.shape[0], x.shape[2], hw[0], hw[1]) if nhwc_in else tuple(x.shape)
+        dev = x.device
+        if self._bufs is None or self._bufs["key"] != (shape, dev, nhwc_in):
+            self._alloc(shape, dev, nhwc_in)
+        B = self._bufs
+        lib = N_.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        Nb = shape[0]
+        for st in self.stages:
+            bits, _, _ = uniform_act_settings(self._acts(st), "FrozenHotPath stage")
+        # (scale, zero-point) of all nine frozen QuantActs from their range buffers: one launch per step
+        N_.check(lib.cdn_quantact_frozen_params(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits, stream),
+                 "cdn_quantact_frozen_params")
+        ws_ptr = (B["ws"].data_ptr() + 255) // 256 * 256
+        ws_bytes = B["ws"].numel() - (ws_ptr - B["ws"].data_ptr())
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        cur_ptr, cur_kind, cur_q = x.data_ptr(), (1 if nhwc_in else 0), (x_qstate if nhwc_in else None)
+        with torch.no_grad():
+            for st, sb in zip(self.stages, B["stages"]):
+                q = st[0]
+                a_s, a_d, a_r = self._acts(st)
+                sp = [a._device_state(dev).data_ptr() for a in (a_s, a_d, a_r)]
+                codes, scale, colsum = q.quant_conv_channel_bn.folded_int8()
+                w_pw, b_pw = q.quant_conv_channel_bn.folded()
+                w_sc = q.quant_conv_scale.quantized_weight().reshape(-1)
+                w_dw = q.quant_deform_conv.quantized_weight()
+                bound = q.quant_act[0]
+                if sb["codes"]:
+                    rc = lib.cdn_codenet_stage_frozen_forward(
+                        cur_ptr, cur_kind, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                        ptr(w_sc), ptr(q.quant_conv_scale.bias), float(bound.min_val), float(bound.max_val),
+                        ptr(w_dw), ptr(codes), ptr(scale), ptr(colsum), ptr(b_pw), 1, sp[0], sp[1], sp[2],
+                        ws_ptr, ws_bytes, sb["r8"].data_ptr(), B["overflow"].data_ptr(), stream)
+                    N_.check(rc, "cdn_codenet_stage_frozen_forward")
+                    cur_ptr, cur_kind, cur_q = sb["r8"].data_ptr(), 2, sp[2]
+                else:
+                    if cur_kind == 2:
+                        raise NotImplementedError("a byte-code stage cannot feed an fp32-schedule stage")
+                    w32 = B["ws32"]
+                    w32_ptr = (w32.data_ptr() + 255) // 256 * 256
+                    w32_bytes = (w32.numel() * 4 - (w32_ptr - w32.data_ptr())) // 256 * 256
+                    acts3 = []
+                    for a in (a_s, a_d, a_r):
+                        acts3 += [a.x_min.data_ptr(), a.x_max.data_ptr(), a._device_state(dev).data_ptr()]
+                    rc = lib.cdn_codenet_stage_fused_forward(
+                        cur_ptr, cur_kind, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                        ptr(w_sc), ptr(q.quant_conv_scale.bias), float(bound.min_val), float(bound.max_val),
+                        ptr(w_dw), ptr(w_pw.reshape(w_pw.size(0), -1)), ptr(codes), ptr(scale), ptr(colsum), ptr(b_pw),
+                        None, None, 1, *acts3, bits, float(a_r.momentum), 0, w32_ptr, w32_bytes,
+                        sb["r"].data_ptr(), stream)
+                    N_.check(rc, "cdn_codenet_stage_fused_forward")
+                    cur_ptr, cur_kind, cur_q = sb["r"].data_ptr(), 1, sp[2]
+        last = B["stages"][-1]
+        return (last["r8"] if last["codes"] else last["r"]), cur_q, last
+
+    def forward_nhwc(self, x, x_qstate=None, hw=None):
+        """What FusedHotPath.forward_nhwc returns -- (fp32 [N, H*W, Co], QuantAct state pointer, shape) -- for the
+        native heads: the byte codes expanded to the values level / scale (re-quantising them with the same state
+        returns the same values)."""
+        from . import _native as N_
+        r, rq, last = self.forward_codes(x, x_qstate, hw)
+        if r.dtype != torch.int8:
+            return r, rq, last
+        B = self._bufs
+        rc = N_.lib().cdn_codenet_expand_codes(r.data_ptr(), rq, B["expanded"].data_ptr(), r.numel(),
+                                               torch.cuda.current_stream(r.device).cuda_stream)
+        N_.check(rc, "cdn_codenet_expand_codes")
+        return B["expanded"], rq, last
+
+    def __call__(self, x):
+        """The Sequential's output tensor (NCHW, up-sampled, fake-quantised), like FusedHotPath.__call__."""
+        from . import _native as N_
+        r, rq, last = self.forward_nhwc(x)
+        B = self._bufs
+        rc = N_.lib().cdn_codenet_unpack_nchw(r.data_ptr(), rq, B["out"].data_ptr(), x.shape[0], last["Co"], last["H"],
+                                              last["W"], 1, torch.cuda.current_stream(x.device).cuda_stream)
+        N_.check(rc, "cdn_codenet_unpack_nchw")
+        return B["out"]
+
+    def overflowed(self):
+        """True when some code saturated since the last call of this method (synchronises; resets the flag): the
+        batches computed in between must be recomputed with FusedHotPath (running_stat False)."""
+        if self._bufs is None:
+            return False
+        flag = bool(self._bufs["overflow"].item())
+        if flag:
+            self._bufs["overflow"].zero_()
+        return flag
+
+    def capture(self, x, codes_only=True):
+        """One pass over the static buffer `x` as a HIP graph; returns replay() -> the static output (byte codes
+        of the last stage with codes_only, else the unpacked NCHW tensor)."""
+        run = (lambda t: self.forward_codes(t)[0]) if codes_only else self.__call__
+        run(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = run(x)
+        self._graph = g
+
+        def replay():
+            g.replay()
+            return out
+        return replay
+
+
 class FusedHeads:
     """The detection heads on the stage kernels, fed by
     ``FusedHotPath.forward_nhwc``: per head

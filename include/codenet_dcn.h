@@ -246,6 +246,49 @@ int cdn_codenet_stage_fused_forward(
     double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
     void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FROZEN-RANGE schedule with byte codes in HBM (serving mode; not the reference's default behaviour).
+ * `running_stat` is a plain attribute of the reference's QuantAct (portable_quantizer/quant_modules.py:172,181);
+ * with running_stat = False the range update (:203-219) is skipped, every QuantAct is a fixed affine grid
+ * (quant_utils.py:60-75,193-200) and stops being a batch-global dependency.  Activations then cross HBM as
+ * one byte per element: code a = level - 128, level = round(scale*x - zp) + zp, value = level / scale.
+ * The reference does not clamp codes; a byte must: a code outside [-128,127] is saturated and *overflow
+ * (a device word the caller zeroes) is set to 1 -- recompute that batch with cdn_codenet_stage_fused_forward
+ * (running = 0), to which the results are otherwise bit-identical.
+ *
+ * cdn_quantact_frozen_params   state[i] words [2],[3] = (scale, zero-point) of x_min[i] / x_max[i] for up to 12
+ *            QuantActs in ONE launch (host arrays of device pointers); call it once per step before the
+ *            stages (or whenever a range buffer changed).
+ * cdn_codenet_stage_frozen_forward   one stage: scale 1x1 -> QuantAct -> gather / depthwise -> QuantAct (bytes)
+ *            -> int8-MFMA pointwise + bias -> ReLU -> QuantAct (bytes).  3 launches.
+ *   x / x_kind   0: [N][C][H][W] fp32 final values (a PyTorch backbone), x_state NULL
+ *                1: [N][Hs*Ws][C] fp32 pre-quantisation values + their quantiser x_state
+ *                2: [N][Hs*Ws][C] byte codes of the quantiser x_state (the previous stage's r8_out)
+ *                (Hs, Ws) = (H >> x_up, W >> x_up): x_up = 1 folds the nearest x2 Upsample; C % 4 == 0
+ *   weights      as cdn_codenet_stage_fused_forward (the integer form of the pointwise weights is required)
+ *   {s,d,r}_state  QuantAct device states with current (scale, zero-point) -- see cdn_quantact_frozen_params
+ *   workspace    cdn_codenet_stage_frozen_workspace_bytes(N,C,H,W,x_up) bytes, 256-byte aligned
+ *   r8_out       [N][H*W][Co] byte codes of the r quantiser (at stage resolution, not up-sampled)
+ * cdn_codenet_pointwise_q8_forward   the pointwise step alone (detection heads): a [M][C] byte codes of a_state;
+ *            output either r8_out (byte codes of r_state) or r_out (fp32 pre-quantisation values).
+ * cdn_codenet_expand_codes     byte codes -> the fp32 values level / scale (for consumers that take fp32 + the
+ *            quantiser state; fake-quantising level / scale again returns the same value).
+ * ---------------------------------------------------------------------------------------- */
+int cdn_quantact_frozen_params(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
+                               void *stream);
+size_t cdn_codenet_stage_frozen_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up);
+int cdn_codenet_stage_frozen_forward(
+    const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
+    const float *w_scale, const float *b_scale, float lo, float hi, const float *w_dw,
+    const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
+    const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
+    signed char *r8_out, unsigned *overflow, void *stream);
+int cdn_codenet_pointwise_q8_forward(const signed char *a, const void *a_state, int64_t M, int64_t C, int64_t Co,
+                                     const signed char *w_codes, const float *w_scale, const int *w_colsum,
+                                     const float *bias, int relu, const void *r_state, signed char *r8_out,
+                                     float *r_out, unsigned *overflow, void *stream);
+int cdn_codenet_expand_codes(const signed char *a, const void *a_state, float *out, int64_t numel, void *stream);
+
 /* out_nchw[n][c][(h<<up)+dy][(w<<up)+dx] = fq(r_nhwc[n][h*W+w][c]): channels-last -> NCHW with the
  * nearest x2 up-sampling (up = 1) and, if r_qstate != NULL, the fake-quantisation applied. */
 int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw, int64_t N,

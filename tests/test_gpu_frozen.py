@@ -1,0 +1,215 @@
+"""Frozen-range schedule with byte codes in HBM (codenet_frozen.hip, pipeline.FrozenHotPath) -- the serving mode
+``QuantAct.running_stat = False`` (a plain attribute in the reference, quant_modules.py:172,181; the update
+:203-219 is skipped):
+
+  * BIT-IDENTICAL to the fp32 fused schedule (cdn_codenet_stage_fused_forward, running = 0) while no code leaves
+    its 8-bit grid -- same scale sums, same bilinear arithmetic, exact integer pointwise sums, same epilogue;
+  * a saturated code (the reference does not clamp, a byte must) raises the overflow flag;
+  * against the CPU oracle with frozen ranges at the BASELINE stage shapes: the standard W4A8 acceptance;
+  * the int8 pointwise kernel alone against an exact integer evaluation.
+"""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import quant as Q
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, c, res, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(n, c, res, res, generator=g).abs_() * (1.66 * (1.0 - 0.04 * i)) for i in range(k)]
+
+
+def _warm_and_freeze(net, xs):
+    """Ranges from running-mode passes over the first input (identical batches: the tracked range equals the
+    batch extremes), then frozen."""
+    from codenet_amd import pipeline
+    pipeline.set_running_stat(net, True)
+    warm = pipeline.FusedHotPath(net.deconv_layers)
+    for _ in range(3):
+        warm(xs[0].cuda())
+    pipeline.set_running_stat(net, False)
+
+
+@pytest.mark.parametrize("planes,res,n", [([64, 32, 16, 8], 8, 3), ([128, 64, 32, 16], 8, 2),
+                                          ([1024, 256, 128, 64], 16, 4), ([1024, 256, 128, 64], 16, 64),
+                                          ([1024, 256, 128, 64], 8, 32)])
+def test_frozen_codes_bit_identical_to_fp32_frozen_schedule(planes, res, n):
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=planes, seed=41).cuda()
+    xs = _inputs(n, planes[0], res, 3, 141)
+    _warm_and_freeze(net, xs)
+    ref = pipeline.FusedHotPath(net.deconv_layers)
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    for x in xs:                                   # later inputs are slightly smaller: inside the frozen ranges
+        xg = x.cuda()
+        a = ref(xg).clone()
+        b = frz(xg).clone()
+        assert not frz.overflowed()
+        assert torch.equal(a, b)
+        # the byte codes themselves against the fp32 schedule's pre-quantisation output + its quantiser state
+        r, rq, shape = ref.forward_nhwc(xg)
+        r8, rq8, shape8 = frz.forward_codes(xg)
+        assert rq == rq8 and r8.dtype == torch.int8 and tuple(r8.shape) == tuple(r.shape)
+        act = list(net.deconv_layers)[-2][1]
+        st = act._device_state(xg.device).view(torch.float32)
+        scale, zp = st[2], st[3]
+        want = torch.round(scale * r - zp) + zp - 128.0
+        assert torch.equal(r8.float(), want)
+    # graph replay of the byte-code schedule
+    xbuf = xs[0].cuda()
+    replay = frz.capture(xbuf)
+    for x in xs:
+        xbuf.copy_(x.cuda())
+        got = replay().clone()
+        assert torch.equal(got, frz.forward_codes(xbuf)[0])
+
+
+def test_frozen_overflow_flag_when_codes_leave_the_grid():
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[64, 32, 16, 8], seed=42).cuda()
+    xs = _inputs(2, 64, 8, 1, 142)
+    _warm_and_freeze(net, xs)
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    frz(xs[0].cuda())
+    assert not frz.overflowed()
+    frz(xs[0].cuda() * 3.0)                         # far outside the frozen ranges
+    assert frz.overflowed()
+    assert not frz.overflowed()                     # reading resets the flag
+    # each of the three quantisers of a stage on its own: shrink one range, everything else untouched
+    for which in ("quant_identity_deform", "post"):
+        net2 = copy.deepcopy(net)
+        st0 = list(net2.deconv_layers)
+        act = st0[0].quant_identity_deform if which == "quant_identity_deform" else st0[1][1]
+        with torch.no_grad():
+            mid, half = (act.x_max + act.x_min) / 2, (act.x_max - act.x_min) / 2
+            act.x_min.copy_(mid - 0.5 * half)
+            act.x_max.copy_(mid + 0.5 * half)
+        f2 = pipeline.FrozenHotPath(net2.deconv_layers)
+        f2(xs[0].cuda())
+        assert f2.overflowed(), which
+
+
+def test_frozen_nhwc_input_with_quantiser_state():
+    """Stage 0 fed by a native backbone: channels-last pre-quantisation values + their QuantAct state."""
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+    net = pipeline.build_hot_path(quantized=True, planes=[64, 32, 16, 8], seed=43).cuda()
+    xs = _inputs(3, 64, 8, 2, 143)
+    # the backbone's last QuantAct: run it once in running mode so that its state holds (scale, zp)
+    act_in = QuantAct(8, quant_mode="asymmetric").cuda()
+    xq = act_in(xs[0].cuda())                       # fake-quantised NCHW tensor: what a PyTorch backbone hands over
+    _warm_and_freeze(net, [xq.cpu()])
+    act_in.running_stat = False
+    x_nhwc = xs[0].cuda().permute(0, 2, 3, 1).reshape(3, 64, 64).contiguous()
+    qptr = act_in._device_state(x_nhwc.device).data_ptr()
+    ref = pipeline.FusedHotPath(net.deconv_layers)
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    a = ref.forward_nhwc(x_nhwc, qptr, (8, 8))[0].clone()
+    r8, rq, _ = frz.forward_codes(x_nhwc, qptr, (8, 8))
+    assert not frz.overflowed()
+    st = list(net.deconv_layers)[-2][1]._device_state(x_nhwc.device).view(torch.float32)
+    assert torch.equal(r8.float(), torch.round(st[2] * a - st[3]) + st[3] - 128.0)
+    b = frz.forward_nhwc(x_nhwc, qptr, (8, 8))[0]
+    assert torch.equal(b, (torch.round(st[2] * a - st[3]) + st[3]) / st[2])
+
+
+def test_frozen_w2_stage0_runs_on_fp32_schedule():
+    """CoDeNet2x: C = 2153 is not a multiple of 4 -> stage 0 on the fp32 frozen schedule, stages 1-2 on codes."""
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[2153, 256, 128, 64], seed=44).cuda()
+    xs = _inputs(2, 2153, 8, 2, 144)
+    _warm_and_freeze(net, xs)
+    ref = pipeline.FusedHotPath(net.deconv_layers)
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    for x in xs:
+        assert torch.equal(ref(x.cuda()), frz(x.cuda()))
+        assert not frz.overflowed()
+
+
+def test_frozen_matches_oracle_with_frozen_ranges_real_shapes():
+    """cfg3 stage shapes against the CPU oracle with running = False (oracle/quant.py::stage_w4a8)."""
+    from codenet_amd import pipeline
+    planes, res, n = [1024, 256, 128, 64], 16, 4
+    net = pipeline.build_hot_path(quantized=True, planes=planes, seed=45)
+    xs = _inputs(n, planes[0], res, 2, 145)
+    net = net.cuda()
+    _warm_and_freeze(net, xs)
+    net_cpu = copy.deepcopy(net).cpu()
+    mods = list(net_cpu.deconv_layers)
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    for x in xs:
+        cur = x
+        with torch.no_grad():
+            for i in range(0, len(mods), 3):
+                q, post = mods[i], mods[i + 1]
+                bnm = q.quant_conv_channel_bn.bn
+                bn = (bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var, bnm.eps)
+                acts = [Q.QuantActState(x_min=a.x_min.item(), x_max=a.x_max.item())
+                        for a in (q.quant_act[1], q.quant_identity_deform, post[1])]
+                r = Q.stage_w4a8(cur, q.quant_conv_scale.weight, q.quant_conv_scale.bias, q.quant_deform_conv.weight,
+                                 q.quant_conv_channel_bn.conv.weight, bn, acts[0], acts[1], running=False)
+                cur = F.interpolate(acts[2](torch.relu(r["y"]), running=False), scale_factor=2, mode="nearest")
+        y = frz(x.cuda()).cpu()
+        assert not frz.overflowed()
+        last = list(net.deconv_layers)[-2][1]
+        lsb = (last.x_max - last.x_min).item() / 255.0
+        diff = (y - cur).abs()
+        assert diff.max().item() <= 1.05 * lsb + 1e-3
+        assert (diff > 1e-3).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("M,C,Co", [(300, 64, 20), (4096, 1024, 256), (1000, 128, 64), (513, 256, 128), (77, 36, 5)])
+def test_pointwise_q8_exact_integer_sums(M, C, Co):
+    """cdn_codenet_pointwise_q8_forward against float64 arithmetic on the integer codes (the sum is exact in
+    both; the epilogue is one fmaf + the code expression): bytes equal except where the fp32 epilogue lands
+    within rounding distance of a code boundary (none expected: compared through the same fp32 expressions)."""
+    from codenet_amd import _native as N_
+    g = torch.Generator().manual_seed(M + C)
+    a = torch.randint(-128, 128, (M, C), generator=g, dtype=torch.int32).to(torch.int8).cuda()
+    qw = torch.randint(-8, 8, (Co, C), generator=g, dtype=torch.int32)
+    cpad = (C + 63) // 64 * 64
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = qw.to(torch.int8)
+    codes = codes.cuda()
+    wscale = (torch.rand(Co, generator=g) * 20 + 5).cuda()
+    colsum = qw.sum(1).to(torch.int32).cuda()
+    bias = (torch.randn(Co, generator=g) * 0.1).cuda()
+    a_state = torch.zeros(8, dtype=torch.float32).cuda()
+    r_state = torch.zeros(8, dtype=torch.float32).cuda()
+    a_state[2], a_state[3] = 37.5, 11.0
+    # output range chosen from the data so that nothing saturates
+    isum = (a.cpu().double() + 128.0) @ qw.double().t()
+    v64 = torch.relu(isum / (37.5 * wscale.cpu().double()) + bias.cpu().double())
+    r_scale = 255.0 / max(v64.max().item(), 1e-6) * 0.98
+    r_state[2], r_state[3] = r_scale, 128.0
+    out8 = torch.empty(M, Co, dtype=torch.int8).cuda()
+    outf = torch.empty(M, Co).cuda()
+    flag = torch.zeros(1, dtype=torch.int32).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    lib = N_.lib()
+    N_.check(lib.cdn_codenet_pointwise_q8_forward(a.data_ptr(), a_state.data_ptr(), M, C, Co, codes.data_ptr(),
+                                                  wscale.data_ptr(), colsum.data_ptr(), bias.data_ptr(), 1,
+                                                  r_state.data_ptr(), None, outf.data_ptr(), flag.data_ptr(), st), "q8 f")
+    N_.check(lib.cdn_codenet_pointwise_q8_forward(a.data_ptr(), a_state.data_ptr(), M, C, Co, codes.data_ptr(),
+                                                  wscale.data_ptr(), colsum.data_ptr(), bias.data_ptr(), 1,
+                                                  r_state.data_ptr(), out8.data_ptr(), None, flag.data_ptr(), st), "q8 b")
+    torch.cuda.synchronize()
+    assert flag.item() == 0
+    # fp32 epilogue: fmaf(float(isum), 1 / (qs * sw), bias) -- reproduce it in fp32 on the exact integer sum
+    rinv = 1.0 / (torch.tensor(37.5) * wscale.cpu())
+    want = torch.relu(torch.addcmul(bias.cpu(), isum.float(), rinv))
+    assert (outf.cpu() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    code = torch.round(r_state[2].cpu() * outf.cpu() - 128.0) + 128.0 - 128.0
+    assert torch.equal(out8.cpu().float(), code)
+    # saturation is reported
+    r_state[2] = r_scale * 4
+    N_.check(lib.cdn_codenet_pointwise_q8_forward(a.data_ptr(), a_state.data_ptr(), M, C, Co, codes.data_ptr(),
+                                                  wscale.data_ptr(), colsum.data_ptr(), bias.data_ptr(), 1,
+                                                  r_state.data_ptr(), out8.data_ptr(), None, flag.data_ptr(), st), "q8 s")
+    torch.cuda.synchronize()
+    assert flag.item() == 1 and out8.max().item() == 127
