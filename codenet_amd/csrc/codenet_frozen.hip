@@ -5,7 +5,7 @@
 // (quant_utils.py:60-75,193-200).  The batch-global min / max that makes each QuantAct a global dependency in
 // the reference-faithful schedule (codenet_fused.hip) is gone, so:
 //   * no range epilogues, no arrival counters;
-//   * every quantised tensor crosses HBM as ONE byte per element (a = level - 128, see Code8 in
+//   * every quantised tensor crosses HBM as ONE byte per element (the code q = round(scale*x - zp), see Code8 in
 //     codenet_fused.hip) instead of four: d (gather output) 4x smaller on both sides, the stage output r too;
 //   * the pointwise conv reads its int8 MFMA operand as it lies in memory: no fp32 -> code conversion per tile
 //     and no nibble split (stored codes are in [-128,127] by construction), half the MFMAs of pwi8_kernel.
@@ -23,9 +23,8 @@ namespace {
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 
-struct Code8 {   // (same as codenet_fused.hip)
+struct Code8 {   // (same as codenet_fused.hip: the byte is the code q = round(scale*x - zp) itself)
   float qs, qz;
-  int ioff;
 };
 using BadMask = int;
 __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad) {
@@ -33,12 +32,11 @@ __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad)
   c.qs = reinterpret_cast<const float *>(state)[2];
   c.qz = reinterpret_cast<const float *>(state)[3];
   if (!(fabsf(c.qz) < 4.0e6f)) bad = 1;
-  c.ioff = (int)fminf(fmaxf(c.qz, -4.0e6f), 4.0e6f) - 128 - 0x4B400000;
   return c;
 }
 __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
   const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
-  const int a = (int)__float_as_uint(y) + c.ioff;
+  const int a = (int)__float_as_uint(y) - 0x4B400000;      // rint(scale*v - zp)
   const int s = min(max(a, -128), 127);
   bad |= a ^ s;
   return s;
@@ -70,8 +68,9 @@ __global__ void frozen_params_kernel(FrozenList f) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// pwq8_kernel: R8[m][co] = code_r( act( (sum_c a[m][c] * qw[co][c] + 128 * colsum[co]) / (sc_d * sw[co]) + b[co] ) )
-//   a   [M][C]      byte codes of the d quantiser (level - 128), channels-last, as the gather wrote them
+// pwq8_kernel: R8[m][co] = code_r( act( (sum_c q[m][c] * qw[co][c] + zp_d * colsum[co]) / (sc_d * sw[co]) + b[co] ) )
+//   q   [M][C]      byte codes of the d quantiser, channels-last, as the gather wrote them; the sum in
+//                   brackets is sum_c level * qw, the integer pwi8_kernel forms as sum (level - 128) * qw + 128 * colsum
 //   qw  [Co][Cpad]  4-bit weight codes as int8, zero padded to a multiple of 64
 // v_mfma_i32_32x32x32_i8: lane (r = l & 31, h = l >> 5) supplies the 16 k bytes [16h, 16h+16) of row r of a
 // 32-byte k step for both operands; C/D as f32 (column = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)).
@@ -99,6 +98,7 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * 32, wn = (wave % WGN) * TN * 32;
   const float qs = reinterpret_cast<const float *>(aq)[2];
+  const float qzf = reinterpret_cast<const float *>(aq)[3];
   const bool a16 = (C & 15) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   i32x16 acc[TN];
 #pragma unroll
@@ -151,8 +151,10 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   // epilogue: the expressions of pwi8_kernel, then the output quantiser's code (or fp32 for a consumer
   // that wants pre-quantisation values)
   BadMask bad = 0;
-  Code8 c8 = {1.f, 0.f, 0};
+  Code8 c8 = {1.f, 0.f};
   if (R8) c8 = make_code8(rq, bad);
+  if (!(fabsf(qzf) < 4.0e6f)) bad = 1;
+  const int qzi = (int)fminf(fmaxf(qzf, -4.0e6f), 4.0e6f);      // zero-point of the A codes: an integer
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
@@ -161,7 +163,7 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
     if (co < Co) {
       if (bias) bsv = bias[co];
       rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
-      t128 = 128 * wsum[co];
+      t128 = qzi * wsum[co];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -178,18 +180,18 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// expand8_kernel: byte codes [M][C] -> the fake-quantised fp32 values level / scale, channels-last (for consumers
+// expand8_kernel: byte codes [M][C] -> the fake-quantised fp32 values (q + zp) / scale, channels-last (for consumers
 // that take fp32 + a quantiser state: fake-quantising level / scale again returns the same value).
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 expand8_kernel(const signed char *__restrict__ a, const unsigned *__restrict__ aq, float *__restrict__ out, long n4) {
-  const float scale = reinterpret_cast<const float *>(aq)[2];
+  const float scale = reinterpret_cast<const float *>(aq)[2], zp = reinterpret_cast<const float *>(aq)[3];
   const float r = __fdiv_rn(1.0f, scale);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const unsigned u = reinterpret_cast<const unsigned *>(a)[i];
     float4 t;
-    const float l0 = (float)((int)(signed char)(u & 0xff) + 128), l1 = (float)((int)(signed char)((u >> 8) & 0xff) + 128);
-    const float l2 = (float)((int)(signed char)((u >> 16) & 0xff) + 128), l3 = (float)((int)(signed char)(u >> 24) + 128);
+    const float l0 = __fadd_rn((float)(int)(signed char)(u & 0xff), zp), l1 = __fadd_rn((float)(int)(signed char)((u >> 8) & 0xff), zp);
+    const float l2 = __fadd_rn((float)(int)(signed char)((u >> 16) & 0xff), zp), l3 = __fadd_rn((float)(int)(signed char)(u >> 24), zp);
     float q0 = __fmul_rn(l0, r); t.x = fmaf(fmaf(-q0, scale, l0), r, q0);
     q0 = __fmul_rn(l1, r); t.y = fmaf(fmaf(-q0, scale, l1), r, q0);
     q0 = __fmul_rn(l2, r); t.z = fmaf(fmaf(-q0, scale, l2), r, q0);

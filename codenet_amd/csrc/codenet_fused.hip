@@ -88,28 +88,28 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
 
 // ---- int8 activation codes in HBM (frozen-range schedule, codenet_frozen.hip) -------------------------
 // A frozen QuantAct (running_stat = False, quant_modules.py:203-219 skipped) has a fixed (scale, zp), so its
-// output can cross HBM as ONE byte per element: a = L - 128 with the level L = q + zp, q = round(scale*x - zp)
-// (quant_utils.py:33-41,60-75); the value every consumer sees is L / scale, exactly what the fp32 schedule
-// materialises.  The reference does not clamp q (quant_utils.py:193-200); a byte must: a code outside
+// output can cross HBM as ONE byte per element: the code q = round(scale*x - zp) itself (quant_utils.py:33-41,
+// 60-75), which lies in [-128,127] for every x inside the frozen range; the value every consumer sees is
+// (q + zp) / scale, exactly what the fp32 schedule materialises (the level L = q + zp is NOT byte sized: it runs
+// from round(scale*x_min) to round(scale*x_min) + 255).  The reference does not clamp q (quant_utils.py:193-200);
+// a byte must: a code outside
 // [-128,127] is saturated AND reported through a device flag -- the caller then recomputes that batch on the
 // fp32 schedule.  Rounding: the 1.5*2^23 trick, as in pwi8_kernel::ucode (round-half-even of the reference's
 // two-rounding expression); values too large for the trick land far outside int8 and are flagged as well.
 struct Code8 {
   float qs, qz;
-  int ioff;       // (int)qz - 128 - 0x4B400000
 };
 using BadMask = int;     // per-lane: non-zero when some code of this lane saturated
 __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad) {
   Code8 c;
   c.qs = reinterpret_cast<const float *>(state)[2];
   c.qz = reinterpret_cast<const float *>(state)[3];
-  if (!(fabsf(c.qz) < 4.0e6f)) bad = 1;          // degenerate range: the integer offset would overflow
-  c.ioff = (int)fminf(fmaxf(c.qz, -4.0e6f), 4.0e6f) - 128 - 0x4B400000;
+  if (!(fabsf(c.qz) < 4.0e6f)) bad = 1;          // degenerate range (zp must stay an exactly representable integer)
   return c;
 }
 __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
   const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
-  const int a = (int)__float_as_uint(y) + c.ioff;
+  const int a = (int)__float_as_uint(y) - 0x4B400000;      // rint(scale*v - zp)
   const int s = min(max(a, -128), 127);
   bad |= a ^ s;          // (non-zero iff the clamp changed the code: one xor + one or, no compare)
   return s;
@@ -118,12 +118,12 @@ __device__ __forceinline__ unsigned pack_code8(const float4 &v, const Code8 &c, 
   return (unsigned)(act_code8(v.x, c, bad) & 0xff) | ((unsigned)(act_code8(v.y, c, bad) & 0xff) << 8) |
          ((unsigned)(act_code8(v.z, c, bad) & 0xff) << 16) | ((unsigned)act_code8(v.w, c, bad) << 24);
 }
-// four stored codes -> the fake-quantised values L / scale (Markstein division, bit-identical to
+// four stored codes -> the fake-quantised values (q + zp) / scale (Markstein division, bit-identical to
 // cdn::fake_quant_r of the pre-quantisation value that produced the code)
-__device__ __forceinline__ float4 unpack_code8(unsigned u, float scale, float r) {
+__device__ __forceinline__ float4 unpack_code8(unsigned u, float scale, float zp, float r) {
   float4 t;
-  const float l0 = (float)((int)(signed char)(u & 0xff) + 128), l1 = (float)((int)(signed char)((u >> 8) & 0xff) + 128);
-  const float l2 = (float)((int)(signed char)((u >> 16) & 0xff) + 128), l3 = (float)((int)(signed char)(u >> 24) + 128);
+  const float l0 = __fadd_rn((float)(int)(signed char)(u & 0xff), zp), l1 = __fadd_rn((float)(int)(signed char)((u >> 8) & 0xff), zp);
+  const float l2 = __fadd_rn((float)(int)(signed char)((u >> 16) & 0xff), zp), l3 = __fadd_rn((float)(int)(signed char)(u >> 24), zp);
   float q0 = __fmul_rn(l0, r); t.x = fmaf(fmaf(-q0, scale, l0), r, q0);
   q0 = __fmul_rn(l1, r); t.y = fmaf(fmaf(-q0, scale, l1), r, q0);
   q0 = __fmul_rn(l2, r); t.z = fmaf(fmaf(-q0, scale, l2), r, q0);
@@ -210,7 +210,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       float4 v;
       if (X8)
         v = unpack_code8(*reinterpret_cast<const unsigned *>(reinterpret_cast<const signed char *>(x) + p * C + c),
-                         qs, qr_);
+                         qs, qz, qr_);
       else
         v = *reinterpret_cast<const float4 *>(xp + c);
       const float4 ww = *reinterpret_cast<const float4 *>(w + c);
@@ -275,7 +275,7 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
 #pragma unroll
   for (int i = 0; i < U; ++i) {
     const int q = threadIdx.x + 256 * i;
-    if (X8) v8[X8 ? i : 0] = q < total ? xt8[q] : 0x80808080u;
+    if (X8) v8[X8 ? i : 0] = q < total ? xt8[q] : 0u;
     else v[i] = q < total ? xt[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
@@ -284,7 +284,7 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
     if (q < total) {
       const int pix = q / CQ, cq = q - pix * CQ;
       const float4 ww = w4[cq];
-      float4 t = X8 ? unpack_code8(v8[X8 ? i : 0], qs, qr_) : v[i];
+      float4 t = X8 ? unpack_code8(v8[X8 ? i : 0], qs, qz, qr_) : v[i];
       if (XQ && !X8) {
         t.x = cdn::fake_quant_r(t.x, qs, qz, qr_);
         t.y = cdn::fake_quant_r(t.y, qs, qz, qr_);
@@ -634,7 +634,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       for (int u = 0; u < kStageU; ++u) {
         const int q = base + u * kDw2Threads + tid;
         const int pix = q / LPP, cq = q % LPP;
-        v[u] = 0x80808080u;                                           // level 0
+        v[u] = 0u;
         if (q < total && c0 + cq * 4 + 3 < C) v[u] = *reinterpret_cast<const unsigned *>(xg + (long)pix * C + cq * 4);
       }
 #pragma unroll
@@ -643,7 +643,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         const int pix = q / LPP, cq = q % LPP;
         if (q < total)
           img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] =
-              (c0 + cq * 4 + 3 < C) ? unpack_code8(v[u], xs, xr_) : z4;
+              (c0 + cq * 4 + 3 < C) ? unpack_code8(v[u], xs, xz, xr_) : z4;
       }
     }
   } else if (NHWC_IN) {
@@ -848,7 +848,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       for (int u = 0; u < kStageU; ++u) {
         const int q = base + u * nthreads + tid;
         const int pix = q / LPP, cq4 = q % LPP;
-        v[u] = 0x80808080u;
+        v[u] = 0u;
         if (q < total && c0 + cq4 * 4 + 3 < C) v[u] = *reinterpret_cast<const unsigned *>(xg + (long)pix * C + cq4 * 4);
       }
 #pragma unroll
@@ -857,7 +857,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
         const int pix = q / LPP, cq4 = q % LPP;
         if (q < total)
           img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq4] =
-              (c0 + cq4 * 4 + 3 < C) ? unpack_code8(v[u], xs, xr_) : z4;
+              (c0 + cq4 * 4 + 3 < C) ? unpack_code8(v[u], xs, xz, xr_) : z4;
       }
     }
   } else {
@@ -919,7 +919,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 
   float mn = INFINITY, mx = -INFINITY;
   BadMask bad = 0;
-  Code8 c8 = {1.f, 0.f, 0};
+  Code8 c8 = {1.f, 0.f};
   if (OUT8) c8 = make_code8(qu.state, bad);
   const bool vec_store = ((C & 3) == 0);
   // every wave owns a contiguous range of blocks (= stored pixels)

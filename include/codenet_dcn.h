@@ -251,7 +251,7 @@ int cdn_codenet_stage_fused_forward(
  * `running_stat` is a plain attribute of the reference's QuantAct (portable_quantizer/quant_modules.py:172,181);
  * with running_stat = False the range update (:203-219) is skipped, every QuantAct is a fixed affine grid
  * (quant_utils.py:60-75,193-200) and stops being a batch-global dependency.  Activations then cross HBM as
- * one byte per element: code a = level - 128, level = round(scale*x - zp) + zp, value = level / scale.
+ * one byte per element: the code q = round(scale*x - zp), in [-128,127] inside the range; value = (q + zp) / scale.
  * The reference does not clamp codes; a byte must: a code outside [-128,127] is saturated and *overflow
  * (a device word the caller zeroes) is set to 1 -- recompute that batch with cdn_codenet_stage_fused_forward
  * (running = 0), to which the results are otherwise bit-identical.

@@ -58,8 +58,7 @@ def test_frozen_codes_bit_identical_to_fp32_frozen_schedule(planes, res, n):
         act = list(net.deconv_layers)[-2][1]
         st = act._device_state(xg.device).view(torch.float32)
         scale, zp = st[2], st[3]
-        want = torch.round(scale * r - zp) + zp - 128.0
-        assert torch.equal(r8.float(), want)
+        assert torch.equal(r8.float(), torch.round(scale * r - zp))
     # graph replay of the byte-code schedule
     xbuf = xs[0].cuda()
     replay = frz.capture(xbuf)
@@ -113,7 +112,7 @@ def test_frozen_nhwc_input_with_quantiser_state():
     r8, rq, _ = frz.forward_codes(x_nhwc, qptr, (8, 8))
     assert not frz.overflowed()
     st = list(net.deconv_layers)[-2][1]._device_state(x_nhwc.device).view(torch.float32)
-    assert torch.equal(r8.float(), torch.round(st[2] * a - st[3]) + st[3] - 128.0)
+    assert torch.equal(r8.float(), torch.round(st[2] * a - st[3]))
     b = frz.forward_nhwc(x_nhwc, qptr, (8, 8))[0]
     assert torch.equal(b, (torch.round(st[2] * a - st[3]) + st[3]) / st[2])
 
@@ -183,7 +182,7 @@ def test_pointwise_q8_exact_integer_sums(M, C, Co):
     r_state = torch.zeros(8, dtype=torch.float32).cuda()
     a_state[2], a_state[3] = 37.5, 11.0
     # output range chosen from the data so that nothing saturates
-    isum = (a.cpu().double() + 128.0) @ qw.double().t()
+    isum = (a.cpu().double() + 11.0) @ qw.double().t()          # levels = codes + zero-point of the A quantiser
     v64 = torch.relu(isum / (37.5 * wscale.cpu().double()) + bias.cpu().double())
     r_scale = 255.0 / max(v64.max().item(), 1e-6) * 0.98
     r_state[2], r_state[3] = r_scale, 128.0
@@ -204,8 +203,7 @@ def test_pointwise_q8_exact_integer_sums(M, C, Co):
     rinv = 1.0 / (torch.tensor(37.5) * wscale.cpu())
     want = torch.relu(torch.addcmul(bias.cpu(), isum.float(), rinv))
     assert (outf.cpu() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
-    code = torch.round(r_state[2].cpu() * outf.cpu() - 128.0) + 128.0 - 128.0
-    assert torch.equal(out8.cpu().float(), code)
+    assert torch.equal(out8.cpu().float(), torch.round(r_state[2].cpu() * outf.cpu() - r_state[3].cpu()))
     # saturation is reported
     r_state[2] = r_scale * 4
     N_.check(lib.cdn_codenet_pointwise_q8_forward(a.data_ptr(), a_state.data_ptr(), M, C, Co, codes.data_ptr(),
