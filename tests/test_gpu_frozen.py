@@ -24,7 +24,7 @@ def _inputs(n, c, res, k, seed):
     return [torch.randn(n, c, res, res, generator=g).abs_() * (1.66 * (1.0 - 0.04 * i)) for i in range(k)]
 
 
-def _warm_and_freeze(net, xs, margin=0.1):
+def _warm_and_freeze(net, xs, margin=0.5):
     """Ranges from running-mode passes over the inputs, widened by `margin` of their width on both sides (the
     gather output depends on the input through the sampling positions too, so a slightly different batch can
     exceed the extremes of the warm-up batches), then frozen."""
