@@ -151,6 +151,22 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int c = wave;
   constexpr int S = kScaleWaves;
+  // 8 loads in flight per lane; the accumulation order is that of the 4-wide loop below (a0 takes c, c + 4S, ...),
+  // so the sums are bit-identical to it
+  for (; c + 7 * S < C; c += 8 * S) {
+    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + S) * HW];
+    const float v2 = xp[(long)(c + 2 * S) * HW], v3 = xp[(long)(c + 3 * S) * HW];
+    const float v4 = xp[(long)(c + 4 * S) * HW], v5 = xp[(long)(c + 5 * S) * HW];
+    const float v6 = xp[(long)(c + 6 * S) * HW], v7 = xp[(long)(c + 7 * S) * HW];
+    a0 = fmaf(w[c], v0, a0);
+    a1 = fmaf(w[c + S], v1, a1);
+    a2 = fmaf(w[c + 2 * S], v2, a2);
+    a3 = fmaf(w[c + 3 * S], v3, a3);
+    a0 = fmaf(w[c + 4 * S], v4, a0);
+    a1 = fmaf(w[c + 5 * S], v5, a1);
+    a2 = fmaf(w[c + 6 * S], v6, a2);
+    a3 = fmaf(w[c + 7 * S], v7, a3);
+  }
   for (; c + 3 * S < C; c += 4 * S) {
     const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + S) * HW];
     const float v2 = xp[(long)(c + 2 * S) * HW], v3 = xp[(long)(c + 3 * S) * HW];
