@@ -477,7 +477,8 @@ def main():
         # the workload they were collected on; null otherwise)
         for rnd in ("r02", "r01"):
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", rnd,
+                                                 "pmc_traffic_frozen.json" if frozen_main else "pmc_traffic.json")))
             except (OSError, ValueError):
                 continue
             w = pm["workload"]

@@ -20,6 +20,23 @@ __all__ = ["DeformConvFunction", "ModulatedDeformConvFunction", "deform_conv",
            "modulated_deform_conv"]
 
 
+def conv_out_shape(x, weight, stride, padding, dilation):
+    """[N, C_out, H_out, W_out] of a (deformable) convolution -- the one formula both functions and the native
+    library use (dcn_deform_conv_cuda.cpp:187-190): out = (in + 2 p - (d (k - 1) + 1)) // s + 1 per axis."""
+    spatial = [(i + 2 * p - (d * (k - 1) + 1)) // s + 1
+               for i, k, s, p, d in zip(x.shape[2:], weight.shape[2:], stride, padding, dilation)]
+    if min(spatial) <= 0:
+        raise ValueError("convolution input is too small (output would be {})".format(
+            "x".join(str(v) for v in [x.shape[0], weight.shape[0]] + spatial)))
+    return (x.shape[0], weight.shape[0], *spatial)
+
+
+def _wh_first(weight, stride, padding, dilation):
+    """The eight geometry ints of the three deform_conv_*_cuda entry points, W before H
+    (dcn_deform_conv_cuda.cpp:151-156)."""
+    return (weight.size(3), weight.size(2), stride[1], stride[0], padding[1], padding[0], dilation[1], dilation[0])
+
+
 class DeformConvFunction(Function):
 
     @staticmethod
@@ -37,13 +54,11 @@ class DeformConvFunction(Function):
         ctx.save_for_backward(input, offset, weight)
         if not input.is_cuda:
             raise NotImplementedError  # as the reference: no CPU path
-        output = input.new_empty(
-            DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride))
+        output = input.new_empty(conv_out_shape(input, weight, ctx.stride, ctx.padding, ctx.dilation))
         empty = input.new_empty(0)
         dcn_deform_conv_cuda.deform_conv_forward_cuda(
-            input, weight, offset, output, empty, empty, weight.size(3), weight.size(2),
-            ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0], ctx.dilation[1],
-            ctx.dilation[0], ctx.groups, ctx.deformable_groups, min(im2col_step, input.shape[0]))
+            input, weight, offset, output, empty, empty, *_wh_first(weight, ctx.stride, ctx.padding, ctx.dilation),
+            ctx.groups, ctx.deformable_groups, min(im2col_step, input.shape[0]))
         return output
 
     @staticmethod
@@ -55,34 +70,17 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         empty = input.new_empty(0)
         step = min(ctx.im2col_step, input.shape[0])
+        geom = _wh_first(weight, ctx.stride, ctx.padding, ctx.dilation) + (ctx.groups, ctx.deformable_groups)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             grad_input = torch.zeros_like(input)
             grad_offset = torch.zeros_like(offset)
             dcn_deform_conv_cuda.deform_conv_backward_input_cuda(
-                input, offset, grad_output, grad_input, grad_offset, weight, empty,
-                weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1],
-                ctx.padding[0], ctx.dilation[1], ctx.dilation[0], ctx.groups,
-                ctx.deformable_groups, step)
+                input, offset, grad_output, grad_input, grad_offset, weight, empty, *geom, step)
         if ctx.needs_input_grad[2]:
-            grad_weight = torch.zeros_like(weight)
+            grad_weight = torch.zeros_like(weight)      # the native call accumulates into it (cpp:456-462)
             dcn_deform_conv_cuda.deform_conv_backward_parameters_cuda(
-                input, offset, grad_output, grad_weight, empty, empty, weight.size(3),
-                weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0],
-                ctx.dilation[1], ctx.dilation[0], ctx.groups, ctx.deformable_groups, 1, step)
+                input, offset, grad_output, grad_weight, empty, empty, *geom, 1, step)
         return grad_input, grad_offset, grad_weight, None, None, None, None, None, None
-
-    @staticmethod
-    def _output_size(input, weight, padding, dilation, stride):
-        channels = weight.size(0)
-        output_size = (input.size(0), channels)
-        for d in range(input.dim() - 2):
-            in_size = input.size(d + 2)
-            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
-            output_size += ((in_size + (2 * padding[d]) - kernel) // stride[d] + 1,)
-        if not all(map(lambda s: s > 0, output_size)):
-            raise ValueError("convolution input is too small (output would be {})".format(
-                "x".join(map(str, output_size))))
-        return output_size
 
 
 class ModulatedDeformConvFunction(Function):
@@ -103,13 +101,19 @@ class ModulatedDeformConvFunction(Function):
         if weight.requires_grad or mask.requires_grad or offset.requires_grad \
                 or input.requires_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
-        output = input.new_empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
+        # (the modulated variant takes int, not pair, stride / padding / dilation: functions/...:127-129)
+        output = input.new_empty(conv_out_shape(input, weight, _pair(stride), _pair(padding), _pair(dilation)))
         empty = input.new_empty(0)
         dcn_deform_conv_cuda.modulated_deform_conv_cuda_forward(
-            input, weight, bias, empty, offset, mask, output, empty, weight.shape[2],
-            weight.shape[3], ctx.stride, ctx.stride, ctx.padding, ctx.padding, ctx.dilation,
-            ctx.dilation, ctx.groups, ctx.deformable_groups, ctx.with_bias)
+            input, weight, bias, empty, offset, mask, output, empty, *ModulatedDeformConvFunction._hw_first(ctx, weight),
+            ctx.with_bias)
         return output
+
+    @staticmethod
+    def _hw_first(ctx, weight):
+        """Geometry ints of the two modulated entry points, H before W (dcn_deform_conv_cuda.cpp:486-492)."""
+        return (weight.shape[2], weight.shape[3], ctx.stride, ctx.stride, ctx.padding, ctx.padding, ctx.dilation,
+                ctx.dilation, ctx.groups, ctx.deformable_groups)
 
     @staticmethod
     @once_differentiable
@@ -125,23 +129,11 @@ class ModulatedDeformConvFunction(Function):
         empty = input.new_empty(0)
         dcn_deform_conv_cuda.modulated_deform_conv_cuda_backward(
             input, weight, bias, empty, offset, mask, empty, grad_input, grad_weight, grad_bias,
-            grad_offset, grad_mask, grad_output, weight.shape[2], weight.shape[3], ctx.stride,
-            ctx.stride, ctx.padding, ctx.padding, ctx.dilation, ctx.dilation, ctx.groups,
-            ctx.deformable_groups, ctx.with_bias)
+            grad_offset, grad_mask, grad_output, *ModulatedDeformConvFunction._hw_first(ctx, weight), ctx.with_bias)
         if not ctx.with_bias:
             grad_bias = None
         return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None,
                 None, None)
-
-    @staticmethod
-    def _infer_shape(ctx, input, weight):
-        n = input.size(0)
-        channels_out = weight.size(0)
-        height, width = input.shape[2:4]
-        kernel_h, kernel_w = weight.shape[2:4]
-        height_out = (height + 2 * ctx.padding - (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
-        width_out = (width + 2 * ctx.padding - (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
-        return n, channels_out, height_out, width_out
 
 
 deform_conv = DeformConvFunction.apply

@@ -28,7 +28,22 @@ HOT = tuple(FAMILY)
 
 
 def short(k):
-    return (k.split("::")[1] if "::" in k else k).split("(")[0][:52]
+    return (k.split("::")[1] if "::" in k else k).split("(")[0][:64]
+
+
+def is_frozen_variant(k):
+    """kernels of the byte-code schedule: pwq8 / expand8 / frozen_params, the gather and scale instantiations with
+    byte input and / or output (their last template flags), plus the stage-0 scale kernel both schedules share"""
+    name = k.split(" grid=")[0]
+    if any(t in name for t in ("pwq8", "expand8", "frozen_params", "scale_nchw")):
+        return True
+    if name.startswith("dw2_kernel"):
+        return name.rstrip(">").endswith("true")                  # <..., X8, OUT8>: OUT8
+    if name.startswith("dw2u_kernel"):
+        return name.rstrip(">").endswith("true")
+    if name.startswith("scale_nhwc"):
+        return name.rstrip(">").endswith("true, true")            # <XQ, X8>
+    return False
 
 
 def rows_of(path, keep=HOT):
@@ -64,9 +79,13 @@ for mode in ("running", "frozen"):
     lines = ["schedule: %s  (bench.py %s--steps 3 --no-graph; rocprofv3 --pmc in separate passes: FETCH_SIZE | "
              "WRITE_SIZE | SQ_* | MFMA; mean per dispatch)" % (mode, "--frozen " if mode == "frozen" else ""),
              "FETCH_SIZE/WRITE_SIZE are KB; gfx950 counts 1/2 of wide coalesced reads -> read MB = 2*FETCH_SIZE/1024", ""]
+    # the frozen run also executes the running schedule while it warms the ranges up: keep the schedule's own kernels
+    member = (lambda k: is_frozen_variant(k)) if mode == "frozen" else \
+        (lambda k: not is_frozen_variant(k) or "scale_nchw" in k)
+    fe = {k: v for k, v in fe.items() if member(k)}
     for k in sorted(fe):
         rd, wt = 2 * fe[k].get("FETCH_SIZE", 0) / 1024, wr.get(k, {}).get("WRITE_SIZE", 0) / 1024
-        line = "%-68s read %7.1f MB  write %7.1f MB" % (k, rd, wt)
+        line = "%-80s read %7.1f MB  write %7.1f MB" % (k, rd, wt)
         s = sq.get(k)
         if s and s.get("SQ_WAVE_CYCLES"):
             wc = s["SQ_WAVE_CYCLES"]
@@ -76,13 +95,12 @@ for mode in ("running", "frozen"):
         if k in mf:
             line += "  | " + mfma_line(mf[k])
         lines.append(line)
-    # bytes per step: a kernel launched once per step appears `nsteps` times in the pass
-    count = collections.Counter(k for k, _ in rows_of(src + "/pmc_fetch_%s/*/*counter_collection.csv" % mode))
-    nsteps = max(1, min(count.values()))
+    # bytes per step: every (kernel, grid) entry of the schedule is launched once per step (three stages with
+    # different grids; expand8 / unpack belong to the optional hand-over to an fp32 consumer)
     per_family = collections.defaultdict(float)
     for k in fe:
         fam = next(v for t, v in FAMILY.items() if t in k)
-        per_family[fam] += count[k] / nsteps * (2 * fe[k].get("FETCH_SIZE", 0) + wr.get(k, {}).get("WRITE_SIZE", 0)) * 1024
+        per_family[fam] += (2 * fe[k].get("FETCH_SIZE", 0) + wr.get(k, {}).get("WRITE_SIZE", 0)) * 1024
     tot = sum(v for f_, v in per_family.items() if f_ != "unpack")
     lines += ["", "HBM bytes per step by kernel family: " +
               ", ".join("%s %.1f MB" % (f_, v / 2 ** 20) for f_, v in sorted(per_family.items())),
