@@ -56,14 +56,9 @@ _SIGNATURES = {
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_pointwise_mixed_forward": (
         _i, [_vp] * 3 + [_i64] * 5 + [_vp] * 7 + [_i] + [_vp] * 4 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
-    "cdn_codenet_pointwise_mixed_i8_forward": (
-        _i, [_vp] * 3 + [_i64] * 5 + [_vp] * 4 + [_i64, _i64] + [_vp] * 4 + [_i] + [_vp] * 4
-        + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_dw3x3_mixed_forward": (
         _i, [_vp] * 3 + [_i64] * 4 + [_i, _i] + [_i64] * 2 + [_vp] * 4 + [_i] + [_vp] * 3
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
-    "cdn_codenet_head_tail_forward": (
-        _i, [_vp, _vp] + [_i64] * 4 + [_vp] * 8 + [_i64, _vp, _vp]),
     "cdn_codenet_head_range_forward": (
         _i, [_vp, _vp] + [_i64] * 4 + [_vp] * 5 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp]),
     "cdn_codenet_head_tail_small_forward": (

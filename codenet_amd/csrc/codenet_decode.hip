@@ -394,7 +394,7 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + workspace_bytes / 256 * 256 -
                                                 r((size_t)B * kBins * 4));
   // row bands: ~36 KiB of plane per workgroup (3 workgroups per CU with the histogram), at least 8 rows
-  static const int kb_kib = getenv("CDN_KEYS_KIB") ? atoi(getenv("CDN_KEYS_KIB")) : 36;   // tuning knob
+  constexpr int kb_kib = 36;
   int RB = (int)std::max<long>(8, (long)((size_t)kb_kib * 1024 / wp_bytes) - 2);
   RB = (int)std::min<long>(RB, H);
   const int nbands = (int)cdn::ceil_div(H, RB);

@@ -256,8 +256,6 @@ extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void
   // hide the global-load latency: the largest tile that still gives >= 4 workgroups per CU (measured at stage 0,
   // M = 16384, K = 1024, Co = 256: one 64 x 256 workgroup per CU 25.9 us).  A narrower N tile re-reads A through L2
   // (HBM reads it once: the column tiles of a row block are resident together), never through HBM.
-  static const int force_bm = getenv("CDN_Q8_BM") ? atoi(getenv("CDN_Q8_BM")) : 0;   // tuning knobs
-  static const int force_bn = getenv("CDN_Q8_BN") ? atoi(getenv("CDN_Q8_BN")) : 0;
   int bm = 128, bn = Co <= 64 ? 64 : (Co <= 128 ? 128 : 256);
   auto wgs = [&](int bm_, int bn_) { return cdn::ceil_div(M, bm_) * cdn::ceil_div(Co, bn_); };
   if (bn == 256) bm = 64;                          // (a 128 x 256 tile would need 128 accumulator registers per lane)
@@ -266,9 +264,6 @@ extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void
     else if (bn > 64) bn >>= 1;
     else break;
   }
-  if (force_bm == 64 || force_bm == 128) bm = force_bm;
-  if (force_bn == 64 || force_bn == 128 || force_bn == 256) bn = force_bn;
-  if (bm == 128 && bn == 256) bm = 64;
 #define CDN_Q8(BM_, BN_) \
   launch_pwq8<BM_, BN_>(a, aq, w_codes, w_scale, w_colsum, bias, r8_out, r_out, rq, overflow, (long)M, (int)C, (int)Co, relu, st)
   if (bn == 256) CDN_Q8(64, 256);

@@ -390,10 +390,10 @@ constexpr bool use_dpp() { return (LPP == 16 && CDN_DPP16) || (LPP == 8 && CDN_D
 
 constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (512 or 1024)
 
-// The gather + depthwise of one staged plane (shared by dw2_kernel and the persistent dw2p_kernel):
+// The gather + depthwise of one staged plane:
 // img = [(Hl+1)*(Wl+1)][CCH] cells with the zero row / column, wl = [CCH][9] weights, sl = scale plane.
 // OUT8: d is a byte tensor of codes (see Code8) instead of fp32; mn / mx are not tracked.
-template <int CCH, int DEEP, bool OUT8 = false>
+template <int CCH, bool OUT8 = false>
 __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, const float *sl,
                                            float *__restrict__ d, int n, int c0, int C, int H, int W,
                                            int up, int kWaves, float &mn, float &mx,
@@ -501,23 +501,10 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
                          r[2] + c[0], r[2] + c[1], r[3] + c[0], r[3] + c[1],      // tap 6
                          r[2] + c[4], r[3] + c[4],                                // tap 7
                          r[2] + c[2], r[2] + c[3], r[3] + c[2], r[3] + c[3]};     // tap 8
-      // DEEP 1 (<= 256 threads, up to 256 VGPRs): every read of the step is in flight before the first
-      // use.  DEEP 2: a rolling window of 13 reads (52 VGPRs): the reads of taps 5..8 are issued into
-      // the registers taps 0..3 free up.  DEEP 0: reads at their use; under the 128-VGPR cap the
-      // compiler then keeps 2-4 reads in flight and drains the queue (lgkmcnt(0)) 5 times per step:
-      // 17 waits x ~250 cycles of loaded LDS latency per step.
-      float4 v[DEEP ? 25 : 1];
-#define CDN_ISSUE(A, B)                                                       \
-  {                                                                           \
-    /* the accumulator passes through the asm: the taps before it cannot sink below the reads */ \
-    asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) :: "memory");           \
-    _Pragma("unroll") for (int i = (A); i <= (B); ++i) v[DEEP ? i : 0] = CDN_RD(o[i]); \
-    asm volatile("" ::: "memory");                                            \
-    __builtin_amdgcn_sched_barrier(0);                                        \
-  }
-      if (DEEP == 1) CDN_ISSUE(0, 24)
-      if (DEEP == 2) CDN_ISSUE(0, 12)
-#define CDN_VAL(I) (DEEP ? v[DEEP ? (I) : 0] : CDN_RD(o[I]))
+      // Reads are issued at their use: under the 128-VGPR cap of the 16-waves-per-CU launch the compiler keeps 2-4 in
+      // flight.  (Tried and removed: all 25 reads of a step in flight at <= 256 threads / 256 VGPRs, and a rolling
+      // window of 13 -- both slower in the pipeline)
+#define CDN_VAL(I) CDN_RD(o[I])
       // corner taps: cells I..I+3, axis weights (Y0,Y1) x (X0,X1)
 #define CDN_TAP4(I, Y0, Y1, X0, X1, K)                                    \
   {                                                                       \
@@ -543,13 +530,9 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
     CDN_WACC(K, tv)                                 \
   }
       CDN_TAP4(0, wt[0], wt[1], wt[4], wt[5], 0)
-      if (DEEP == 2) CDN_ISSUE(13, 16)
       CDN_TAP2(4, wt[0], wt[1], 1)
-      if (DEEP == 2) CDN_ISSUE(17, 18)
       CDN_TAP4(6, wt[0], wt[1], wt[6], wt[7], 2)
-      if (DEEP == 2) CDN_ISSUE(19, 22)
       CDN_TAP2(10, wt[4], wt[5], 3)
-      if (DEEP == 2) CDN_ISSUE(23, 24)
       {
         const float4 vc = CDN_VAL(12);
         CDN_WACC(4, vc)
@@ -558,7 +541,6 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
       CDN_TAP4(15, wt[2], wt[3], wt[4], wt[5], 6)
       CDN_TAP2(19, wt[2], wt[3], 7)
       CDN_TAP4(21, wt[2], wt[3], wt[6], wt[7], 8)
-#undef CDN_ISSUE
 #undef CDN_VAL
 #undef CDN_TAP4
 #undef CDN_TAP2
@@ -609,7 +591,6 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   extern __shared__ float4 img[];
   CDN_STAMP(0);
   constexpr int LPP = CCH / 4;     // lanes per pixel
-  constexpr int DEEP = MAXT <= 256 ? 1 : 0;
   const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
   const int Hl = H >> up, Wl = W >> up;
   const int HWl = Hl * Wl;
@@ -757,11 +738,11 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   if (OUT8) {
     BadMask bad = 0;
     const Code8 c8 = make_code8(qu.state, bad);
-    dw2_gather<CCH, DEEP, true>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx, &c8, &bad);
+    dw2_gather<CCH, true>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx, &c8, &bad);
     if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
     return;
   }
-  dw2_gather<CCH, DEEP>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx);
+  dw2_gather<CCH>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx);
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
@@ -1324,8 +1305,6 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 constexpr int kI8LD = 48;   // bytes per LDS row: 32 k + 16 pad -> conflict-free ds_read_b128
 constexpr int kMixedMaxC = 512;   // channels of a mixed-generation input (per-channel state table in LDS)
-constexpr int kMaxSegs = 128;     // (k-tile, generation) segments of pwi8m_kernel
-constexpr int kMaxGens = 16;      // generations of one layer (2 + units)
 
 template <int BM, int BN, int WGM, bool FAST>
 __global__ void __launch_bounds__(256)
@@ -1561,293 +1540,6 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
   CDN_STAMPR(2, 4);
-}
-
-// ------------------------------------------------------------------------------------------
-// pwi8m: the int8 pointwise conv for a MIXED-GENERATION input: channel c of A holds
-// pre-quantisation values of generation gen[c] of a layer's running QuantAct, so there is no common integer
-// grid -- but the channels of ONE generation have one.  K is cut into SEGMENTS (32-channel k-tile, generation):
-//   y[m][co] = ( sum_g (1 / s_g) * ( sum_{c in g} L_c * qw[co][c] ) ) / sw[co] + b[co]
-// the host lists, generation by generation, the k-tiles that hold live (non-zero weight) channels of that
-// generation together with the tile's weight codes masked to the generation (zero elsewhere; a tile that
-// holds two generations appears twice, a tile of pass-through channels not at all).  A segment runs exactly
-// pwi8_kernel's k-tile step -- every channel of the tile is quantised with ITS generation's (s, z) from a
-// table in LDS; foreign channels meet zero weights -- and after the last segment of a generation the exact
-// int32 sums (+ 128 * that generation's column sums) are scaled by 1 / s_g into fp32 accumulators.
-// Against the bf16 x 3 split (pwd3): 2 instead of 6 MFMAs per 32 k, ~8 instead of ~13 VALU per element, and
-// exact integer sums per generation.  Codes too wide for the nibble split in ANY generation: the f32-MFMA
-// branch on the per-channel fake-quantised values (pwi8_kernel's rare path).
-// ------------------------------------------------------------------------------------------
-struct SegList {
-  const int *k0;            // [nseg] first channel of the k-tile (multiple of 32)
-  const int *gen;           // [nseg] generation of the segment
-  const int *flush;         // [nseg] 1: last segment of its generation
-  const signed char *codes; // [nseg][Co][32] weight codes masked to the segment's generation
-  const int *colsum;        // [ngen][Co] column sums of each generation's codes
-  int nseg, ngen;
-};
-
-template <int BM, int BN, int WGM>
-__global__ void __launch_bounds__(256)
-pwi8m_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
-             const unsigned char *__restrict__ agen, SegList sg, const float *__restrict__ wscale,
-             const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ R,
-             float2 *rmm, cdn::QUpdate qu, long M, int C, int Co, int relu, int lda, int ldo,
-             const int *__restrict__ omap) {
-  constexpr int WGN = 4 / WGM;
-  constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
-  constexpr int AI = BM * 8 / 256;
-  constexpr int BI = (BN * 2 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned char A0[2][BM * kI8LD];
-  __shared__ __attribute__((aligned(16))) unsigned char A1[2][BM * kI8LD];
-  __shared__ __attribute__((aligned(16))) unsigned char B0[2][BN * kI8LD];
-  __shared__ __attribute__((aligned(16))) unsigned char B1[2][BN * kI8LD];
-  __shared__ float4 qt[kMixedMaxC];        // {s, z, bit image of the code offset, -} per channel
-  __shared__ int any_wide;
-  __shared__ int cs_s[kMaxGens * BN];      // 128 * column sums [generation][column of this tile]
-  __shared__ float rg_s[kMaxGens];         // 1 / s_g
-  __shared__ int seg_s[kMaxSegs];          // k0 | gen << 16 | flush << 24 (a global load per iteration would sit
-                                           // on the k loop's critical path)
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
-  if (tid == 0) any_wide = 0;
-  __syncthreads();
-  {
-    int w_ = 0;
-    for (int c = tid; c < ((C + 31) & ~31); c += 256) {
-      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C) {
-        const unsigned *st = aq + cdn::kQStateWords * agen[c];
-        const float s_ = __uint_as_float(st[2]), z_ = __uint_as_float(st[3]);
-        e = make_float4(s_, z_, __int_as_float((int)z_ + (2048 - 128) - 0x4B400000), 0.f);
-        w_ |= (int)st[6];
-      }
-      qt[c] = e;
-    }
-    if (w_) any_wide = 1;
-    for (int i = tid; i < sg.nseg; i += 256) seg_s[i] = sg.k0[i] | (sg.gen[i] << 16) | (sg.flush[i] << 24);
-    for (int i = tid; i < sg.ngen * BN; i += 256) {
-      const int g = i / BN, col = i - g * BN;
-      cs_s[i] = n0 + col < Co ? 128 * sg.colsum[(long)g * Co + n0 + col] : 0;
-    }
-    if (tid < sg.ngen) rg_s[tid] = __fdiv_rn(1.0f, __uint_as_float(aq[cdn::kQStateWords * tid + 2]));
-  }
-  __syncthreads();
-  float mn = INFINITY, mx = -INFINITY;
-  if (any_wide) {
-    constexpr int LDF = 17;
-    static_assert(BM * LDF * 4 <= 2 * BM * kI8LD && BN * LDF * 4 <= 2 * BN * kI8LD, "LDS reuse");
-    float *As = reinterpret_cast<float *>(&A0[0][0]);
-    float *Bs = reinterpret_cast<float *>(&B0[0][0]);
-    f32x16 accw[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) accw[i][j] = (f32x16){0};
-    for (int k0 = 0; k0 < C; k0 += 16) {
-      for (int q = tid; q < (BM + BN) * 4; q += 256) {
-        const bool isA = q < BM * 4;
-        const int row = (isA ? q : q - BM * 4) >> 2, kq = (q & 3) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (isA) {
-          const long m = min(m0 + row, M - 1);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k0 + kq + e < C) {
-              const float4 t4 = qt[k0 + kq + e];
-              v[e] = fake_quant(A[m * lda + k0 + kq + e], t4.x, t4.y);
-            }
-        } else {
-          const int co = min(n0 + row, Co - 1);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k0 + kq + e < C) v[e] = Wp[(long)co * C + k0 + kq + e];
-        }
-        float *dst = (isA ? As : Bs) + row * LDF + kq;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = v[e];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        float av[TM], bv[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) av[i] = As[(wm + i * 32 + (lane & 31)) * LDF + 2 * kk + (lane >> 5)];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn + j * 32 + (lane & 31)) * LDF + 2 * kk + (lane >> 5)];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], accw[i][j], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int co = n0 + wn + j * 32 + (lane & 31);
-      const float bsv = (co < Co && bias) ? bias[co] : 0.f;
-      const int oc = (co < Co && omap) ? omap[co] : co;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M && co < Co) {
-            float v = accw[i][j][r] + bsv;
-            if (relu) v = fmaxf(v, 0.0f);
-            R[m * ldo + oc] = v;
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
-          }
-        }
-    }
-    if (rmm)
-      cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
-                               gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A1[0][0]));
-    return;
-  }
-  i32x16 acc[TM][TN];
-  f32x16 accf[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      acc[i][j] = (i32x16){0};
-      accf[i][j] = (f32x16){0};
-    }
-  const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
-  const bool vec4 = (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
-  const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16-byte half bh
-  float4 a[AI];
-  i32x4 b[BI];
-  const float *arow[AI];
-#pragma unroll
-  for (int i = 0; i < AI; ++i) arow[i] = A + min(m0 + lr + 32 * i, M - 1) * lda + lk;
-  auto load_seg = [&](int sidx) {
-    const int k0 = seg_s[sidx] & 0xFFFF, k = k0 + lk;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      if (vec4) {
-        a[i] = (k < C) ? *reinterpret_cast<const float4 *>(arow[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        a[i].x = (k + 0 < C) ? arow[i][k0 + 0] : 0.0f;
-        a[i].y = (k + 1 < C) ? arow[i][k0 + 1] : 0.0f;
-        a[i].z = (k + 2 < C) ? arow[i][k0 + 2] : 0.0f;
-        a[i].w = (k + 3 < C) ? arow[i][k0 + 3] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int co = min(n0 + br + 128 * i, Co - 1);
-      b[i] = *reinterpret_cast<const i32x4 *>(sg.codes + ((long)sidx * Co + co) * 32 + bh);
-    }
-  };
-  auto ucode = [&](float v, const float4 t4) -> unsigned {
-    // u = rint(s*v - z) + z - 128 + 2048 with the channel's own (s, z); 0 * anything finite for dead channels
-    const float y = __fadd_rn(__fsub_rn(__fmul_rn(t4.x, v), t4.y), 12582912.0f);
-    const int u = (int)__float_as_uint(y) + __float_as_int(t4.z);
-    return (unsigned)min(max(u, 8), 4087);
-  };
-  auto store_seg = [&](int buf, int sidx) {
-    const int kb = (seg_s[sidx] & 0xFFFF) + lk;
-    const float4 t0 = qt[kb], t1 = qt[kb + 1], t2 = qt[kb + 2], t3 = qt[kb + 3];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      // (channels >= C: the table holds s = 0, offset 0 -> u = 0x4B400000 + 0 clamps to a finite code that only
-      //  meets zero weights)
-      const unsigned u0 = ucode(a[i].x, t0), u1 = ucode(a[i].y, t1), u2 = ucode(a[i].z, t2), u3 = ucode(a[i].w, t3);
-      const unsigned p01 = u0 | (u1 << 16), p23 = u2 | (u3 << 16);
-      const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu;
-      const unsigned hi = __builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u;
-      *reinterpret_cast<unsigned *>(&A0[buf][(lr + 32 * i) * kI8LD + lk]) = lo;
-      *reinterpret_cast<unsigned *>(&A1[buf][(lr + 32 * i) * kI8LD + lk]) = hi;
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-      if (br + 128 * i < BN) {
-        i32x4 s16;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)b[i][e] << 4) & 0xF0F0F0F0u);
-        *reinterpret_cast<i32x4 *>(&B0[buf][(br + 128 * i) * kI8LD + bh]) = b[i];
-        *reinterpret_cast<i32x4 *>(&B1[buf][(br + 128 * i) * kI8LD + bh]) = s16;
-      }
-  };
-  const int nseg = sg.nseg;
-  if (nseg > 0) {
-    load_seg(0);
-    store_seg(0, 0);
-  }
-  __syncthreads();
-  for (int t = 0; t < nseg; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nseg) load_seg(t + 1);
-    i32x4 a0[TM], a1[TM], b0[TN], b1[TN];
-    const int fo = (lane & 31) * kI8LD + (lane >> 5) * 16;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      a0[i] = *reinterpret_cast<const i32x4 *>(&A0[buf][(wm + i * 32) * kI8LD + fo]);
-      a1[i] = *reinterpret_cast<const i32x4 *>(&A1[buf][(wm + i * 32) * kI8LD + fo]);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      b0[j] = *reinterpret_cast<const i32x4 *>(&B0[buf][(wn + j * 32) * kI8LD + fo]);
-      b1[j] = *reinterpret_cast<const i32x4 *>(&B1[buf][(wn + j * 32) * kI8LD + fo]);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[i], b0[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[i], b1[j], acc[i][j], 0, 0, 0);
-      }
-    if (seg_s[t] >> 24) {                               // workgroup-uniform: this generation is complete
-      const int g = (seg_s[t] >> 16) & 0xFF;
-      const float rg = rg_s[g];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int t128 = cs_s[g * BN + wn + j * 32 + (lane & 31)];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            accf[i][j][r] = fmaf((float)(acc[i][j][r] + t128), rg, accf[i][j][r]);
-            acc[i][j][r] = 0;
-          }
-      }
-    }
-    if (t + 1 < nseg) store_seg(buf ^ 1, t + 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn + j * 32 + (lane & 31);
-    float bsv = 0.f, rinv = 0.f;
-    int oc = co;
-    if (co < Co) {
-      if (bias) bsv = bias[co];
-      rinv = __fdiv_rn(1.0f, wscale[co]);
-      if (omap) oc = omap[co];
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M && co < Co) {
-          float v = fmaf(accf[i][j][r], rinv, bsv);
-          if (relu) v = fmaxf(v, 0.0f);
-          R[m * ldo + oc] = v;
-          mn = fminf(mn, v);
-          mx = fmaxf(mx, v);
-        }
-      }
-  }
-  if (rmm)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
-                             gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2370,24 +2062,19 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
-  int threads = two_per_cu ? 512 : 1024;
-  // deep variant: two 256-thread workgroups per CU at up to 256 VGPRs, all 25 reads of a step in flight
-  // (measured at stage 0: 62 us vs 56 us for the 512-thread kernel; a persistent, double-buffered form
-  // -- next item's global loads in flight during the gather -- measured 66 us: at 2 waves/SIMD the
-  // per-step LDS latency chain is exposed.  Opt-in for experiments.)
-  static const bool want_deep = getenv("CDN_DW_DEEP") != nullptr;   // tuning knob
-  const bool deep = two_per_cu && want_deep;
-  if (deep) threads = 256;
-  if (const char *e = getenv("CDN_DW_THREADS")) threads = atoi(e);   // tuning knob
+  const int threads = two_per_cu ? 512 : 1024;
+  // (tried and removed: two 256-thread workgroups per CU at up to 256 VGPRs with all 25 reads of a step in flight,
+  // 62 us vs 56 us at stage 0; a persistent, double-buffered form -- next item's global loads in flight during
+  // the gather -- 66 us: at 2 waves/SIMD the per-step LDS latency chain is exposed.  DESIGN.md section 4.1)
 #define CDN_GO(NH, XQ_, SQ_)                                                                  \
   {                                                                                           \
-    auto kern = deep ? dw2_kernel<CCH, NH, XQ_, SQ_, 256> : dw2_kernel<CCH, NH, XQ_, SQ_, kDw2MaxThreads>; \
+    auto kern = dw2_kernel<CCH, NH, XQ_, SQ_, kDw2MaxThreads>;                                \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, deep ? std::min(threads, 256) : threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up); \
+    kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up);          \
   }
   const bool XQ = xq != nullptr, SQ = sq != nullptr;
-  const bool blocks = nhwc && up == 1 && !getenv("CDN_DW_NO_BLOCKS");
+  const bool blocks = nhwc && up == 1;
   if (blocks) {   // 2x2-block kernel for up-sampled inputs
 #define CDN_GOU(XQ_, SQ_)                                                                     \
   {                                                                                           \
@@ -2513,8 +2200,7 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   if (ldo == 0) ldo = Co;
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
   const int pw_bn = Co > 64 ? 128 : 64;
-  int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
-  if (const char *e = getenv("CDN_PW_BM")) pw_bm = (atoi(e) == 64 && Co > 64) ? 64 : 128;   // tuning knob
+  const int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
   const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
   const bool pw_fast = (C % 32) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
@@ -2531,9 +2217,8 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   const bool use_i8 = w_pw_codes != nullptr && dst != nullptr && ep_scale == nullptr && a_gen == nullptr;
   // final-valued input (no QuantAct state to derive integer codes from) with 4-bit weight codes: exact
   // bf16 x 3 split instead of f32 MFMA
-  static const bool no_b3 = getenv("CDN_NO_B3") != nullptr;   // tuning knob
   const bool use_b3 = w_pw_codes != nullptr && ep_scale == nullptr && w_pw_scale != nullptr &&
-                      (a_gen != nullptr || (!no_b3 && dst == nullptr));
+                      (a_gen != nullptr || dst == nullptr);
   CDN_REQUIRE(a_gen == nullptr || (use_b3 && dst != nullptr && C <= kMixedMaxC), CDN_ERR_UNSUPPORTED,
               "a mixed-generation input needs the states, 4-bit weight codes and C <= %d", kMixedMaxC);
   CDN_REQUIRE(out_map == nullptr || use_i8 || use_b3, CDN_ERR_UNSUPPORTED,
@@ -2559,9 +2244,7 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   } while (0)
     // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
     // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
-    static const int i8_bm = getenv("CDN_PWI_BM") ? atoi(getenv("CDN_PWI_BM")) : 0;   // tuning knob
-    if (pw_bn == 128 && i8_bm == 128) CDN_PWI(128, 128, 4);
-    else if (pw_bn == 128) CDN_PWI(64, 128, 2);
+    if (pw_bn == 128) CDN_PWI(64, 128, 2);
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI
     // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)
@@ -2578,18 +2261,15 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                                                    (int)lda, (int)ldo, a_gen, out_map);          \
   } while (0)
     // streaming form when the rows are 16-byte aligned quads and the N tile's weights fit in LDS
-    static const bool no_d3 = getenv("CDN_NO_D3") != nullptr;   // tuning knob
     const int tn = Co > 64 ? 4 : 2;
     const int Kp = (int)((C + 31) / 32 * 32);
     const size_t lds_d3 = (size_t)32 * tn * (Kp * 2 + 16) + (size_t)Kp * 16;
     const long nblk_d3 = cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 32 * tn);
-    if (!no_d3 && (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
+    if ((C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
         lds_d3 <= 150 * 1024 && nblk_d3 <= kMaxPartials) {
       // persistent: as many workgroups as stay resident (VGPRs, LDS), each walks row blocks
       const unsigned ny = (unsigned)cdn::ceil_div(Co, 32 * tn);
-      static const int d3_occ = getenv("CDN_D3_OCC") ? atoi(getenv("CDN_D3_OCC")) : 0;   // tuning knob
-      long per_cu = std::min<long>(tn == 2 ? 3 : 2, (long)(160 * 1024 / (lds_d3 + 512)));   // 168 / 256 VGPRs
-      if (d3_occ > 0) per_cu = d3_occ;
+      const long per_cu = std::min<long>(tn == 2 ? 3 : 2, (long)(160 * 1024 / (lds_d3 + 512)));   // 168 / 256 VGPRs
       const long gx = std::max<long>(1, std::min<long>(cdn::ceil_div(M, 128), per_cu * cdn::kCUs / ny));
       dim3 g((unsigned)gx, ny);
       auto kern = tn == 4 ? pwd3_kernel<4> : pwd3_kernel<2>;
@@ -2711,10 +2391,9 @@ extern "C" int cdn_codenet_stage_fused_forward(
   int n_part_s = 0;
   {
   cdn::ProfScope ps(cdn::kProfScale, ptag, st);
-  static const bool scale_old = getenv("CDN_SCALE_OLD") != nullptr;   // tuning knob
   // tiled kernel for large planes (measured: 18 vs 22 us at 65536 pixels x 128 channels; the
   // wave-per-pixel kernel is ahead at 16384 x 256: 13.7 vs 15.0 us)
-  if (x_nhwc && C <= 256 && !scale_old && N * HWl >= 32768 &&
+  if (x_nhwc && C <= 256 && N * HWl >= 32768 &&
       cdn::ceil_div(N * HWl, kScaleTilePix) <= kMaxPartials) {
     const long npix = (long)(N * HWl);
     const int blocks = (int)cdn::ceil_div(npix, kScaleTilePix);
@@ -2729,8 +2408,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
                                                               smm, qu_s, (int)C, npix, lo, hi);
   } else if (x_nhwc) {
     const long npix = (long)(N * HWl);
-    static const int bpc = getenv("CDN_SCALE_BPC") ? atoi(getenv("CDN_SCALE_BPC")) : 8;   // tuning knob
-    const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * bpc);
+    const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
     n_part_s = blocks;
     if (xq)
       scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, qu_s,
@@ -2807,53 +2485,6 @@ extern "C" int cdn_codenet_pointwise_nhwc_forward(
                                              w_colsum, bias, ep_scale, ep_shift, relu, nullptr, r_min, r_max,
                                              r_state, bits, momentum, running, workspace, workspace_bytes,
                                              out, stream);
-}
-
-// Mixed-generation pointwise conv on the int8 matrix cores, K cut into (k-tile, generation) segments: see
-// pwi8m_kernel.
-extern "C" int cdn_codenet_pointwise_mixed_i8_forward(
-    const float *a, const void *a_states, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
-    int64_t lda, int64_t ldo, const float *w, const int *seg_k0, const int *seg_gen, const int *seg_flush,
-    int64_t nseg, int64_t ngen, const signed char *seg_codes, const int *seg_colsum, const float *w_scale,
-    const float *bias, int relu, const int *out_map, float *r_min, float *r_max, void *r_state, int bits,
-    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream) {
-  CDN_REQUIRE(a && a_states && a_gen && w && seg_k0 && seg_gen && seg_flush && seg_codes && seg_colsum &&
-                  w_scale && out, CDN_ERR_ARG, "null pointer");
-  CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && nseg >= 0 && nseg <= kMaxSegs && ngen >= 1 && ngen <= kMaxGens &&
-                  C <= kMixedMaxC &&
-                  M * std::max(C, Co) < (1ll << 31),
-              CDN_ERR_ARG, "bad size (C <= %d, nseg <= %d)", kMixedMaxC, kMaxSegs);
-  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr),
-              CDN_ERR_ARG, "the output QuantAct needs x_min, x_max and state together");
-  if (lda == 0) lda = C;
-  if (ldo == 0) ldo = Co;
-  CDN_REQUIRE(lda >= C && (out_map || ldo >= Co) && M * std::max(lda, ldo) < (1ll << 31), CDN_ERR_ARG,
-              "bad row strides");
-  CDN_REQUIRE((reinterpret_cast<uintptr_t>(seg_codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 3) == 0,
-              CDN_ERR_ARG, "seg_codes must be 16-byte aligned");
-  cdn::AuxWs ws{nullptr, nullptr};
-  if (r_state)
-    CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
-                "workspace missing, too small or not 256-byte aligned");
-  hipStream_t st = cdn::as_stream(stream);
-  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive,
-                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
-  float2 *rmm = r_state ? ws.partials : nullptr;
-  const SegList sg{seg_k0, seg_gen, seg_flush, seg_codes, seg_colsum, (int)nseg, (int)ngen};
-  const unsigned *aq = static_cast<const unsigned *>(a_states);
-  cdn::ProfScope ps(cdn::kProfPointwise, 0, st);
-  if (Co > 64) {
-    dim3 g((unsigned)cdn::ceil_div(M, 64), (unsigned)cdn::ceil_div(Co, 128));
-    CDN_REQUIRE((long)g.x * g.y <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-    pwi8m_kernel<64, 128, 2><<<g, 256, 0, st>>>(a, aq, a_gen, sg, w_scale, w, bias, out, rmm, qu, (long)M, (int)C,
-                                                (int)Co, relu, (int)lda, (int)ldo, out_map);
-  } else {
-    dim3 g((unsigned)cdn::ceil_div(M, 128), (unsigned)cdn::ceil_div(Co, 64));
-    CDN_REQUIRE((long)g.x * g.y <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-    pwi8m_kernel<128, 64, 4><<<g, 256, 0, st>>>(a, aq, a_gen, sg, w_scale, w, bias, out, rmm, qu, (long)M, (int)C,
-                                                (int)Co, relu, (int)lda, (int)ldo, out_map);
-  }
-  return cdn::check_launch("codenet pointwise (mixed generations, int8)");
 }
 
 extern "C" int cdn_codenet_pointwise_mixed_forward(

@@ -5,7 +5,6 @@
 //                      (detection heads: SURVEY.md section 8f row 1; ShuffleNetV2 units: row 3)
 //   interleave_kernel  concat + channel_shuffle(2) + the shared block-output QuantAct of a unit
 //   stem_kernel        layer0: dense 3x3 conv 3 -> 24 on the NCHW image
-//   head_tail_kernel   depthwise -> QuantAct -> last 1x1 conv of a W4A8 head in one kernel (opt-in)
 // The pointwise convolutions of these layers are the stage's pointwise kernels (codenet_fused.hip,
 // cdn_codenet_pointwise_nhwc_forward).
 #include "cdn_common.h"
@@ -630,206 +629,7 @@ stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const fl
   if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu, red);
 }
 
-// ------------------------------------------------------------------------------------------
-// head_tail: the second half of a W4A8 detection head in ONE kernel (quant_modules.py:1062-1069):
-//     depthwise 3x3 on the up-sampled y1 (+ folded BN bias) -> ReLU -> QuantAct -> 1x1 conv C -> classes + bias
-// once the QuantAct range is known (a range-only pass of dw3_kernel tracks it first).  The depthwise
-// output -- 268 MB per head at batch 64, written and re-read by the unfused schedule -- never leaves the CU:
-// workgroup = (image, stored row): for each 32-channel half, stage 3 stored rows of y1 (fake-quantised on
-// load), compute the 2 x 2*Ws output pixels of the row exactly like dw3_kernel<UP>, quantise them to integer
-// codes and park the nibble-split codes in LDS as the A operand of v_mfma_i32_32x32x32_i8 (pwi8_kernel's
-// layout); B = the 4-bit weight codes of up to 32 classes; the int32 sums are scaled / biased, transposed
-// through LDS and stored as NCHW rows.  Codes too wide for the nibble split (state[6]) take an f32-MFMA
-// branch on the fake-quantised values, like pwi8_kernel.
-// ------------------------------------------------------------------------------------------
-constexpr int kHtLD = 48;      // bytes per A / B row of one 32-channel k-step (32 + 16 pad)
-constexpr int kHtLDF = 33;     // floats per row in the f32 branch
-template <int NB>    // 32-pixel row blocks per wave: 2 (Ws <= 64) or 4 (Ws <= 128)
-__global__ void __launch_bounds__(256, 2)   // <= 256 VGPRs: two workgroups per CU (LDS allows two)
-head_tail_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
-                 const float *__restrict__ wdw, const float *__restrict__ bdw,
-                 const unsigned *__restrict__ q2, const signed char *__restrict__ Wq,
-                 const float *__restrict__ wscale, const int *__restrict__ wsum,
-                 const float *__restrict__ Wp, const float *__restrict__ bias, float *__restrict__ out,
-                 int C, int Cpad, int Hs, int Ws, int classes) {
-  extern __shared__ float4 ht_lds[];
-  const int n = blockIdx.y, Y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Wc = Ws + 2, Wo = 2 * Ws, Ho = 2 * Hs, npix = 2 * Wo;           // output pixels of this row pair
-  // LDS: [3][Wc][8] float4 depthwise tile | A region | B region ; the output transpose re-uses the front
-  float4 *tile = ht_lds;
-  unsigned char *Areg = reinterpret_cast<unsigned char *>(ht_lds + 3 * Wc * 8);
-  const size_t a_bytes = (size_t)npix * (kHtLDF * 4);                        // sized for the f32 branch
-  unsigned char *Breg = Areg + a_bytes;
-  const float s1 = reinterpret_cast<const float *>(q1)[2], z1 = reinterpret_cast<const float *>(q1)[3];
-  const float s2 = reinterpret_cast<const float *>(q2)[2], z2 = reinterpret_cast<const float *>(q2)[3];
-  const bool wide = q2[6] != 0;
-  const int ioff = (int)z2 + (2048 - 128) - 0x4B400000;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int nblk = npix / 32;                       // 32-pixel row blocks of the MFMA; npix % 32 == 0
-  i32x16 acc[NB];        // the f32 branch keeps its sums in the same registers (bit casts)
-#pragma unroll
-  for (int i = 0; i < NB; ++i) acc[i] = (i32x16){0};
-  const int cq = tid & 7;                           // channel quad of the 32-channel half
-  for (int half = 0; half * 32 < C; ++half) {
-    const int c0 = half * 32;
-    // ---- stage stored rows Y-1 .. Y+1 (zero halo), fake-quantised -----------------------------------
-    for (int q = tid; q < 3 * Wc * 8; q += 256) {
-      const int cqq = q & 7, cell = q >> 3;
-      const int r = cell / Wc, col = cell - r * Wc;
-      const int y = Y - 1 + r, x = col - 1;
-      float4 v = z4;
-      if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws && c0 + cqq * 4 + 3 < C) {
-        v = *reinterpret_cast<const float4 *>(y1 + ((long)n * Hs * Ws + (long)y * Ws + x) * C + c0 + cqq * 4);
-        v.x = fake_quant(v.x, s1, z1);
-        v.y = fake_quant(v.y, s1, z1);
-        v.z = fake_quant(v.z, s1, z1);
-        v.w = fake_quant(v.w, s1, z1);
-      }
-      tile[q] = v;
-    }
-    // ---- B operand of this half: weight codes (and 16x codes), or f32 weights in the wide branch -------
-    if (!wide) {
-      for (int q = tid; q < 32 * 2; q += 256) {     // 32 class rows x two 16-byte pieces
-        const int cls = q >> 1, part = (q & 1) * 16;
-        i32x4 b = (i32x4){0, 0, 0, 0};
-        if (cls < classes) b = *reinterpret_cast<const i32x4 *>(Wq + (long)cls * Cpad + c0 + part);
-        i32x4 s16;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)b[e] << 4) & 0xF0F0F0F0u);
-        *reinterpret_cast<i32x4 *>(Breg + cls * kHtLD + part) = b;
-        *reinterpret_cast<i32x4 *>(Breg + 32 * kHtLD + cls * kHtLD + part) = s16;
-      }
-    } else {
-      float *Bf = reinterpret_cast<float *>(Breg);
-      for (int q = tid; q < 32 * 32; q += 256) {
-        const int cls = q >> 5, k = q & 31;
-        Bf[cls * kHtLDF + k] = (cls < classes && c0 + k < C) ? Wp[(long)cls * C + c0 + k] : 0.0f;
-      }
-    }
-    __syncthreads();
-    // ---- depthwise 3x3 on the up-sampled tile, ReLU, quantise, park as the A operand ------------------
-    {
-      const int cb = c0 + cq * 4;
-      float wk[9][4], bs[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool live = cb + e < C;
-        const int c = min(cb + e, C - 1);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k][e] = live ? wdw[(long)c * 9 + k] : 0.0f;
-        bs[e] = (bdw && live) ? bdw[c] : 0.0f;
-      }
-      for (int X = tid >> 3; X < Ws; X += 32) {
-        float4 V[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) V[i][j] = tile[(i * Wc + (X + j)) * 8 + cq];
-#pragma unroll
-        for (int py = 0; py < 2; ++py)
-#pragma unroll
-          for (int px = 0; px < 2; ++px) {
-            float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-              for (int dx = 0; dx < 3; ++dx) {
-                const float4 t = V[(py + dy + 1) >> 1][(px + dx + 1) >> 1];
-                a4[0] = fmaf(wk[dy * 3 + dx][0], t.x, a4[0]);
-                a4[1] = fmaf(wk[dy * 3 + dx][1], t.y, a4[1]);
-                a4[2] = fmaf(wk[dy * 3 + dx][2], t.z, a4[2]);
-                a4[3] = fmaf(wk[dy * 3 + dx][3], t.w, a4[3]);
-              }
-            const int row = py * Wo + 2 * X + px;
-            if (!wide) {
-              unsigned u[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float v = fmaxf(a4[e] + bs[e], 0.0f);
-                const float yv = __fadd_rn(__fsub_rn(__fmul_rn(s2, v), z2), 12582912.0f);
-                int uu = (int)__float_as_uint(yv) + ioff;
-                uu = min(max(uu, 8), 4087);
-                u[e] = (cb + e < C) ? (unsigned)uu : 2048u;
-              }
-              const unsigned p01 = u[0] | (u[1] << 16), p23 = u[2] | (u[3] << 16);
-              const unsigned lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu;
-              const unsigned hi = __builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u;
-              *reinterpret_cast<unsigned *>(Areg + row * kHtLD + cq * 4) = lo;
-              *reinterpret_cast<unsigned *>(Areg + (size_t)npix * kHtLD + row * kHtLD + cq * 4) = hi;
-            } else {
-              float *Af = reinterpret_cast<float *>(Areg) + row * kHtLDF + cq * 4;
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                Af[e] = (cb + e < C) ? fake_quant(fmaxf(a4[e] + bs[e], 0.0f), s2, z2) : 0.0f;
-            }
-          }
-      }
-    }
-    __syncthreads();
-    // ---- this half's k-step: wave w owns the row blocks w, w + 4, ... -----------------------------------
-    if (!wide) {
-      const int fo = (lane & 31) * kHtLD + (lane >> 5) * 16;
-      const i32x4 b0 = *reinterpret_cast<const i32x4 *>(Breg + fo);
-      const i32x4 b1 = *reinterpret_cast<const i32x4 *>(Breg + 32 * kHtLD + fo);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int blk = wave + 4 * i;
-        if (blk < nblk) {
-          const i32x4 a0 = *reinterpret_cast<const i32x4 *>(Areg + blk * 32 * kHtLD + fo);
-          const i32x4 a1 = *reinterpret_cast<const i32x4 *>(Areg + (size_t)npix * kHtLD + blk * 32 * kHtLD + fo);
-          acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[i], 0, 0, 0);
-        }
-      }
-    } else {
-      const float *Af = reinterpret_cast<const float *>(Areg), *Bf = reinterpret_cast<const float *>(Breg);
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const float bv = Bf[(lane & 31) * kHtLDF + 2 * kk + (lane >> 5)];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const int blk = wave + 4 * i;
-          if (blk < nblk) {
-            const float av = Af[(blk * 32 + (lane & 31)) * kHtLDF + 2 * kk + (lane >> 5)];
-            acc[i] = __builtin_bit_cast(i32x16, __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                                    av, bv, __builtin_bit_cast(f32x16, acc[i]), 0, 0, 0));
-          }
-        }
-      }
-    }
-    __syncthreads();                                // the next half overwrites tile / A / B
-  }
-  // ---- scale, bias, transpose through LDS ([class][pixel]), NCHW rows --------------------------------
-  float *ot = reinterpret_cast<float *>(ht_lds);    // [32][npix + 1]
-  {
-    const int cls = lane & 31;
-    float bsv = 0.f, rinv = 0.f;
-    int t128 = 0;
-    if (cls < classes) {
-      if (bias) bsv = bias[cls];
-      rinv = __fdiv_rn(1.0f, __fmul_rn(s2, wscale[cls]));
-      t128 = 128 * wsum[cls];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int blk = wave + 4 * i;
-      if (blk < nblk) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const float v = wide ? __int_as_float(acc[i][r]) + bsv : fmaf((float)(acc[i][r] + t128), rinv, bsv);
-          ot[cls * (npix + 1) + m] = v;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int q = tid; q < classes * npix; q += 256) {
-    const int cls = q / npix, m = q - cls * npix;
-    const int py = m / Wo, x = m - py * Wo;
-    out[(((long)n * classes + cls) * Ho + 2 * Y + py) * Wo + x] = ot[cls * (npix + 1) + m];
-  }
-}
+constexpr int kHtLD = 48;      // bytes per A / B row of one 32-channel int8 k-step (32 + 16 pad): head_small_kernel
 
 // ------------------------------------------------------------------------------------------
 // maxpool: MaxPool2d(3, stride 2, padding 1) of the "S2 + MaxPool" stems (shufflenetv2_dcn.py:209-214;
@@ -1216,13 +1016,13 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
   CDN_REQUIRE(N <= 65535 && N * std::max(ld_in, ld_out) * H * W * (up ? 4 : 1) < (1ll << 31),
               CDN_ERR_UNSUPPORTED, "shape too large");
   // ---- backbone form: row-streaming kernel (no up-sampling, values are written) ----------------------
-  static const bool no_dws = getenv("CDN_NO_DWS") != nullptr;   // tuning knob
+  constexpr bool no_dws = false;
   if (!up && out && !no_dws && (out == nullptr || (reinterpret_cast<uintptr_t>(out) & 15) == 0 || (ld_out & 3))) {
     const int Ho_ = Hi;
-    static const bool no_dwx = getenv("CDN_NO_DWX") != nullptr;   // tuning knob
+    constexpr bool no_dwx = false;
     // measured (fake-quantising input): x strips win at 24 and 58 channels (76 vs 124 us at 58 ch, 128 x 128,
     // stride 2), channel chunks at 116 (128-byte pieces of 464-byte pixels: 27 vs 29 us, 53 vs 60 us)
-    static const int dwx_max_c = getenv("CDN_DWX_MAXC") ? atoi(getenv("CDN_DWX_MAXC")) : 64;
+    constexpr int dwx_max_c = 64;      // measured crossover between the x-strip and the channel-chunk kernel
     if (!no_dwx && C <= dwx_max_c && C <= 128) {
       // x-strip form: all channels of a pixel in one workgroup
       const int LPP = (int)cdn::ceil_div(C, 4), XPT = 256 / LPP;
@@ -1246,7 +1046,7 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
       if (best_maxl) {
         const int XSo = best_xso, nxs = (int)cdn::ceil_div(Wo_, XSo), wc = stride * (XSo - 1) + 3;
         const size_t lds = (size_t)ring * wc * LPP * 16;
-        static const int wg_per_cu = getenv("CDN_DWS_WGS") ? atoi(getenv("CDN_DWS_WGS")) : 2;
+        constexpr int wg_per_cu = 2;
         long want = cdn::ceil_div((long)wg_per_cu * cdn::kCUs, (long)N * nxs);
         int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho_ / 8)));
         const int rps = (int)cdn::ceil_div(Ho_, nstrips);
@@ -1293,7 +1093,7 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
       const size_t lds = (size_t)ring * (Ws + 2) * cch * sizeof(float);
       const int nchunks = (int)cdn::ceil_div(C, cch);
       // strips: enough workgroups to fill the chip twice, at least 8 output rows each
-      static const int wg_per_cu = getenv("CDN_DWS_WGS") ? atoi(getenv("CDN_DWS_WGS")) : 2;   // tuning knob
+      constexpr int wg_per_cu = 2;
       long want = cdn::ceil_div((long)wg_per_cu * cdn::kCUs, (long)N * nchunks);
       int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho_ / 8)));
       const int rps = (int)cdn::ceil_div(Ho_, nstrips);
@@ -1433,8 +1233,8 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
   CDN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && N <= 65535, CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0, CDN_ERR_ARG, "y1 must be 16-byte aligned");
-  static const int hs_wgs = getenv("CDN_HS_WGS") ? atoi(getenv("CDN_HS_WGS")) : 2;     // tuning knobs
-  static const int hs_minrows = getenv("CDN_HS_MINROWS") ? atoi(getenv("CDN_HS_MINROWS")) : 8;
+  constexpr int hs_wgs = 2;
+  constexpr int hs_minrows = 8;
   hipStream_t st = cdn::as_stream(stream);
   const unsigned *q1 = static_cast<const unsigned *>(y1_qstate);
   // geometry for strips of XS stored columns
@@ -1474,7 +1274,7 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
   const unsigned *q2 = static_cast<const unsigned *>(y2_qstate);
   // matrix cores whenever the shape allows (measured at 2 classes: 64 us vs 74 us for the VALU form, which
   // remains for other widths and as the wide-code fallback)
-  static const bool hs_no_mfma = getenv("CDN_HS_NO_MFMA") != nullptr;   // tuning knob
+  constexpr bool hs_no_mfma = false;
   const bool mfma_ok = !hs_no_mfma && w_colsum && (Ws & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(out_nchw) & 15) == 0;
   if (mfma_ok) {
@@ -1527,37 +1327,6 @@ extern "C" int cdn_codenet_head_tail_small_forward(const float *y1, const void *
   return launch_head_small(1, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate, w_codes, w_scale, w_colsum, bias,
                            classes, out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0, nullptr, 0, stream);
 }
-
-// The tail of a W4A8 detection head in one kernel: see head_tail_kernel.
-extern "C" int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
-                                             int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
-                                             const void *y2_qstate, const signed char *w_codes,
-                                             const float *w_scale, const int *w_colsum, const float *w,
-                                             const float *bias, int64_t classes, float *out_nchw,
-                                             void *stream) {
-  CDN_REQUIRE(y1 && y1_qstate && w_dw && y2_qstate && w_codes && w_scale && w_colsum && w && out_nchw,
-              CDN_ERR_ARG, "null pointer");
-  CDN_REQUIRE(N > 0 && C > 0 && Hs > 0 && Ws > 0 && classes > 0, CDN_ERR_ARG, "non-positive size");
-  CDN_REQUIRE((C & 3) == 0 && classes <= 32 && (Ws & 7) == 0 && 4 * Ws <= 512 && N <= 65535 && Hs <= 65535,
-              CDN_ERR_UNSUPPORTED, "head tail needs C %% 4 == 0, <= 32 classes, Ws %% 8 == 0, Ws <= 128");
-  CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_codes) & 15) == 0,
-              CDN_ERR_ARG, "y1 / w_codes must be 16-byte aligned");
-  const int Cpad = (int)((C + 63) / 64 * 64);
-  const int npix = (int)(4 * Ws);
-  const size_t tile = (size_t)3 * (Ws + 2) * 8 * 16, a_bytes = (size_t)npix * kHtLDF * 4,
-               b_bytes = (size_t)32 * kHtLDF * 4;
-  const size_t lds = std::max(tile + a_bytes + b_bytes, (size_t)32 * (npix + 1) * 4);
-  CDN_REQUIRE(lds <= 160 * 1024, CDN_ERR_UNSUPPORTED, "row too wide for LDS");
-  hipStream_t st = cdn::as_stream(stream);
-  cdn::ProfScope ps(cdn::kProfDw, (int)Hs, st);
-  auto kern = Ws <= 64 ? head_tail_kernel<2> : head_tail_kernel<4>;
-  (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<dim3((unsigned)Hs, (unsigned)N), 256, lds, st>>>(
-      y1, static_cast<const unsigned *>(y1_qstate), w_dw, b_dw, static_cast<const unsigned *>(y2_qstate),
-      w_codes, w_scale, w_colsum, w, bias, out_nchw, (int)C, Cpad, (int)Hs, (int)Ws, (int)classes);
-  return cdn::check_launch("codenet head tail");
-}
-
 
 // out[n][oy*Wo+ox][c] = max_{3x3, stride 2, pad 1} fq(a[n][..][c]): see maxpool_kernel.
 extern "C" int cdn_codenet_maxpool3x3s2_nhwc_forward(const float *a, const void *a_qstate, int64_t N, int64_t C,

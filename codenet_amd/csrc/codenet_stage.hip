@@ -696,7 +696,7 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
       cch = c;
       break;
     }
-  if (cch != 0 && !getenv("CDN_BWD_OLD")) {
+  if (cch != 0) {
     const size_t lds = bwd_lds(cch);
     dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
 #define CDN_BWD(CCH_)                                                                          \

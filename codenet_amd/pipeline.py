@@ -589,17 +589,13 @@ class FusedHeads:
     by addressing, so the up-sampled 64-channel tensor is never built.  Same parameters and QuantAct
     buffers (updated in place) as calling the head modules on the unpacked tensor."""
 
-    def __init__(self, heads, int8_pointwise=True, fuse_tail=False, small_tail=True, streams=True):
+    def __init__(self, heads, int8_pointwise=True, small_tail=True, streams=True):
         self.heads = dict(heads)
         self.int8_pointwise = int8_pointwise
         # W4A8 heads with <= 4 output channels (wh, reg): range pass + depthwise -> quantise -> 1x1 conv as exact
         # integer dot products on the VALU (cdn_codenet_head_range_forward / _head_tail_small_forward)
         self.small_tail = small_tail and int8_pointwise
-        self.streams = streams and os.environ.get("CDN_HEAD_STREAMS", "1") != "0"          # tuning knob
-        # W4A8 option: range-only depthwise pass, then depthwise + QuantAct + last 1x1 conv in ONE kernel
-        # (cdn_codenet_head_tail_forward): the 268 MB depthwise output is never stored.  Parity-tested, but
-        # measured slower at batch 64 (3 heads 0.75 ms vs 0.66 ms: the recompute is VALU-bound), so off.
-        self.fuse_tail = fuse_tail
+        self.streams = streams
         self._bufs = None
         self._affine = {}
 
@@ -732,16 +728,12 @@ class FusedHeads:
                 else:
                     stream, ws_ptr, ws_bytes = main_launch
                 layers = self._params(mod)
-                fuse = (self.fuse_tail and len(layers) == 3 and layers[0]["act"] is not None
-                        and layers[1]["act"] is not None and layers[1]["ep"] is None
-                        and layers[2]["i8"] is not None and layers[2]["w"].shape[0] <= 32
-                        and Ws % 8 == 0 and Ws <= 128 and C % 4 == 0)
-                small = (self.small_tail and not fuse and len(layers) == 3 and layers[0]["act"] is not None
+                small = (self.small_tail and len(layers) == 3 and layers[0]["act"] is not None
                          and layers[1]["act"] is not None and layers[1]["ep"] is None and layers[1]["relu"]
                          and layers[2]["i8"] is not None and C == 64
                          and (layers[2]["w"].shape[0] <= 4 or (layers[2]["w"].shape[0] <= 32 and Ws % 16 == 0))
                          and layers[2]["act"] is None and not layers[2]["relu"])
-                if not fuse and not small and name not in B["o"]:
+                if not small and name not in B["o"]:
                     B["o"][name] = torch.empty(4 * M, self._out_channels(mod), device=r.device)
                     if B["y2"] is None and len(layers) == 3:
                         B["y2"] = torch.empty(4 * M, C, device=r.device)
@@ -776,26 +768,6 @@ class FusedHeads:
                         stream)
                     ops._toc(rec)
                     N_.check(rc, "cdn_codenet_head_tail_small_forward")
-                    outs[name] = B["out"][name]
-                    continue
-                if fuse:
-                    # W4A8: range-only depthwise pass, then depthwise -> quantise -> int8 1x1 -> NCHW in one
-                    # kernel: the 64-channel full-resolution tensor is never stored
-                    rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
-                    rc = lib.cdn_codenet_dw3x3_nhwc_forward(
-                        y1buf.data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
-                        None, None, l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes, None, stream)
-                    ops._toc(rec)
-                    N_.check(rc, "cdn_codenet_dw3x3_nhwc_forward")
-                    q2 = l2["act"]._device_state(r.device).data_ptr()
-                    i8 = l3["i8"]
-                    rec = ops._tic("head_tail", (C, l3["w"].shape[0], 4 * M))
-                    rc = lib.cdn_codenet_head_tail_forward(
-                        y1buf.data_ptr(), q1, Nb, C, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2,
-                        ptr(i8[0]), ptr(i8[1]), ptr(i8[2]), ptr(l3["w"]), ptr(l3["bias"]),
-                        l3["w"].shape[0], B["out"][name].data_ptr(), stream)
-                    ops._toc(rec)
-                    N_.check(rc, "cdn_codenet_head_tail_forward")
                     outs[name] = B["out"][name]
                     continue
                 rec = ops._tic("head_dw", (C, 2 * Hs, 2 * Ws))
@@ -836,20 +808,13 @@ class FusedBackbone:
         self.model = model
         self.int8 = int8_pointwise
         self.shuffle_free = shuffle_free and int8_pointwise
-        # mixed-generation 1x1 convs on the int8 matrix cores, K segmented by generation
-        # (cdn_codenet_pointwise_mixed_i8_forward) instead of the bf16 x 3 split: exact integer sums per
-        # generation, parity-tested, but measured no faster -- opt-in: CDN_INT8_SEGMENTS=1 for
-        # the few-row layers, =all everywhere
-        self.int8_segments = os.environ.get("CDN_INT8_SEGMENTS", "0") != "0"
-        self.int8_segments_all = os.environ.get("CDN_INT8_SEGMENTS", "0") == "all"
-        self.two_streams = two_streams and os.environ.get("CDN_TWO_STREAMS", "1") != "0"   # tuning knob
+        self.two_streams = two_streams
         self._bufs = None
 
     def _l4_weights(self, q4, logical, dev, gens=None):
         """layer4's 1x1 weights with the input columns in the physical order of the last layer."""
         key = (q4.conv.weight.data_ptr(), q4.conv.weight._version, q4.bn.weight._version,
-               q4.bn.running_var._version, tuple(logical), tuple(gens) if gens is not None else None,
-               self.int8_segments, dev)
+               q4.bn.running_var._version, tuple(logical), tuple(gens) if gens is not None else None, dev)
         c = self.__dict__.get("_l4_cache")
         if c is None or c[0] != key:
             w, b = q4.folded()
@@ -860,10 +825,6 @@ class FusedBackbone:
             cp[:, :K] = codes[:, cols]
             W4 = dict(w=w.reshape(Co, -1)[:, cols].contiguous(), codes=cp, scale=scale, colsum=colsum,
                       bias=b.contiguous(), Co=Co, K=K)
-            if gens is not None and self.int8_segments:
-                sg = self._segments(cp[:, :K], [True] * K, list(gens), dev)
-                if sg is not None:
-                    W4["seg"] = sg
             self._l4_cache = (key, W4)
         return self._l4_cache[1]
 
@@ -1081,40 +1042,6 @@ class FusedBackbone:
             L, d = 2 * L, d + 1
         return d
 
-    @staticmethod
-    def _segments(codes, live, gens, dev):
-        """(k-tile, generation) segments of a mixed-generation 1x1 conv for cdn_codenet_pointwise_mixed_i8_forward:
-        codes int8 [Co, K] in physical column order, live[c] = the column carries weights, gens[c] = its
-        generation.  Generation by generation, every 32-channel tile that holds live channels of it."""
-        Co, K = codes.shape
-        ntile = (K + 31) // 32
-        k0, sg, fl, blocks = [], [], [], []
-        ngen = max(gens) + 1
-        colsum = torch.zeros(ngen, Co, dtype=torch.int32, device=dev)
-        codes_c = codes.cpu()
-        for g in sorted(set(g_ for g_, l_ in zip(gens, live) if l_)):
-            first = len(k0)
-            for t in range(ntile):
-                idx = [c for c in range(32 * t, min(32 * t + 32, K)) if live[c] and gens[c] == g]
-                if not idx:
-                    continue
-                blk = torch.zeros(Co, 32, dtype=torch.int8)
-                loc = [c - 32 * t for c in idx]
-                blk[:, loc] = codes_c[:, idx]
-                k0.append(32 * t)
-                sg.append(g)
-                fl.append(0)
-                blocks.append(blk)
-            if len(k0) > first:
-                fl[-1] = 1
-                sel = [c for c in range(K) if live[c] and gens[c] == g]
-                colsum[g] = codes_c[:, sel].to(torch.int32).sum(1).to(dev)
-        i32 = lambda v: torch.tensor(v if v else [0], device=dev, dtype=torch.int32)   # noqa: E731
-        seg_codes = (torch.stack(blocks) if blocks else torch.zeros(1, Co, 32, dtype=torch.int8)).contiguous().to(dev)
-        if len(k0) > 128 or ngen > 16:   # kMaxSegs / kMaxGens of the kernel: the caller keeps the bf16-split form
-            return None
-        return dict(k0=i32(k0), gen=i32(sg), flush=i32(fl), nseg=len(k0), codes=seg_codes, colsum=colsum.contiguous())
-
     def _mixed_plan(self, nodes, in_logical, dev, in_gens=None):
         """Host bookkeeping of one layer: slot assignment, generations, permuted weights (cached until a
         weight changes).  in_logical: logical index of every physical input channel (None: identity)."""
@@ -1125,7 +1052,7 @@ class FusedBackbone:
         key = (tuple((c.conv.weight.data_ptr(), c.conv.weight._version, c.bn.weight._version,
                       c.bn.running_var._version, c.bn.running_mean._version, c.bn.bias._version) for c in convs),
                tuple(in_logical) if in_logical is not None else None,
-               tuple(in_gens) if in_gens is not None else None, self.int8_segments, dev)
+               tuple(in_gens) if in_gens is not None else None, dev)
         cache = self.__dict__.setdefault("_mixed_cache", {})
         ck = id(nodes[0])
         if ck in cache and cache[ck]["key"] == key:
@@ -1153,10 +1080,6 @@ class FusedBackbone:
             cp[:, :K] = codes[:, src] * live.to(torch.int8)
             out = dict(w=w2.contiguous(), codes=cp.contiguous(), scale=scale, colsum=colsum, bias=b.contiguous(),
                        Co=Co, K=K)
-            if gens is not None and self.int8_segments:
-                sg = self._segments(cp[:, :K], [c >= 0 for c in cols], list(gens), dev)
-                if sg is not None:
-                    out["seg"] = sg
             return out
 
         plan = dict(key=key, h=h, cin=cin, C=C, units=[])
@@ -1238,18 +1161,6 @@ class FusedBackbone:
         aa = self._act_args(act, self._dev)
         if state_ptr is not None:
             aa[2] = state_ptr
-        sg = Wt.get("seg") if a_gen is not None else None
-        # measured: the segmented int8 form wins for few rows (layer 3 units: 29-34 us vs 39-43 us for the bf16
-        # split); with many rows the extra segments (a k-tile per generation it holds) re-read A and it loses
-        # (layer 2: 40-57 vs 36 us; stride-2 units: 190 vs 74 us)
-        if sg is not None and (self.int8_segments_all or (M <= 32768 and Wt["Co"] <= 256)):
-            rc = N_.lib().cdn_codenet_pointwise_mixed_i8_forward(
-                a_ptr, a_q, a_gen, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), sg["k0"].data_ptr(),
-                sg["gen"].data_ptr(), sg["flush"].data_ptr(), sg["nseg"], sg["colsum"].shape[0], sg["codes"].data_ptr(),
-                sg["colsum"].data_ptr(), Wt["scale"].data_ptr(), Wt["bias"].data_ptr(), int(relu), out_map, *aa,
-                self._ws_ptr, self._ws_bytes, out_ptr, self._stream)
-            N_.check(rc, "cdn_codenet_pointwise_mixed_i8_forward")
-            return
         rc = N_.lib().cdn_codenet_pointwise_mixed_forward(
             a_ptr, a_q, a_gen, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), Wt["codes"].data_ptr(),
             Wt["scale"].data_ptr(), Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), None, None, int(relu),

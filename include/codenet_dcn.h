@@ -342,22 +342,6 @@ int cdn_codenet_pointwise_mixed_forward(
     const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
     const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
     void *workspace, size_t workspace_bytes, float *out, void *stream);
-/* The mixed-generation pointwise conv on the int8 matrix cores.  The channels of ONE generation share an integer
- * grid, so K is cut into segments (32-channel k-tile, generation), listed generation by generation:
- *   seg_k0[s] first channel of the tile (multiple of 32), seg_gen[s] its generation, seg_flush[s] = 1 on the
- *   last segment of a generation; seg_codes [nseg][Co][32] int8 = the tile's weight codes with zeros outside
- *   the generation (a tile holding two generations appears twice, a tile of pass-through channels not at
- *   all); seg_colsum [ngen][Co] int32 = column sums of each generation's codes (ngen <= 16 generations,
- *   nseg <= 128 segments).
- *   y[m][co] = ( sum_g (sum_{c in g} L_c qw[co][c]) / s_g ) / w_scale[co] + bias[co]   -- exact integer sums
- * w [Co][C] fp32 (physical order, zero columns) serves the f32 branch taken when any generation's codes are
- * too wide for int8.  C <= 512.  Other arguments as cdn_codenet_pointwise_mixed_forward. */
-int cdn_codenet_pointwise_mixed_i8_forward(
-    const float *a, const void *a_states, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
-    int64_t lda, int64_t ldo, const float *w, const int *seg_k0, const int *seg_gen, const int *seg_flush,
-    int64_t nseg, int64_t ngen, const signed char *seg_codes, const int *seg_colsum, const float *w_scale,
-    const float *bias, int relu, const int *out_map, float *r_min, float *r_max, void *r_state, int bits,
-    double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream);
 int cdn_codenet_dw3x3_mixed_forward(
     const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t N, int64_t C, int64_t H,
     int64_t W, int up, int stride, int64_t ld_in, int64_t ld_out, const float *w, const float *bias,
@@ -378,22 +362,13 @@ int cdn_codenet_dw3x3_nhwc_forward(
     const float *ep_shift, int relu, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *out, void *stream);
 
-/* The tail of a W4A8 detection head in ONE kernel (quant_modules.py:1062-1069): depthwise 3x3 on the nearest
- * x2 up-sampled y1 (+ folded-BN bias) -> ReLU -> QuantAct -> 1x1 conv C -> classes (+ bias), NCHW output.
- * The QuantAct range must be known: call cdn_codenet_dw3x3_nhwc_forward with out = NULL first (range-only
- * pass: tracks r_min / r_max / r_state without storing), then this with that state as y2_qstate.
+/* The tail of a W4A8 detection head (quant_modules.py:1062-1069): depthwise 3x3 on the nearest x2 up-sampled y1
+ * (+ folded-BN bias) -> ReLU -> QuantAct -> 1x1 conv C -> classes (+ bias), NCHW output, as ROW-STREAMING kernels
+ * (every stored row staged and fake-quantised once), and its range pass; C == 64 (head_conv of every reference
+ * configuration):
  *   y1 [N][Hs*Ws][C] pre-quantisation values + y1_qstate;  w_dw [C][9], b_dw [C] or NULL
- *   w_codes / w_scale / w_colsum: integer form of the 1x1 weights ([classes][round_up(C,64)] int8, ...) and
- *   w [classes][C] their fake-quantised fp32 form (used when the codes are too wide for int8 MFMA)
- *   out_nchw [N][classes][2Hs][2Ws];  C % 4 == 0, classes <= 32, Ws % 8 == 0, Ws <= 128. */
-int cdn_codenet_head_tail_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C, int64_t Hs,
-                                  int64_t Ws, const float *w_dw, const float *b_dw, const void *y2_qstate,
-                                  const signed char *w_codes, const float *w_scale, const int *w_colsum,
-                                  const float *w, const float *bias, int64_t classes, float *out_nchw,
-                                  void *stream);
-
-/* The same tail as ROW-STREAMING kernels (every stored row staged and fake-quantised once), and its range
- * pass; C == 64 (head_conv of every reference configuration):
+ *   w_codes / w_scale / w_colsum: integer form of the 1x1 weights ([classes][round_up(C,64)] int8, ...)
+ *   out_nchw [N][classes][2Hs][2Ws]
  *   cdn_codenet_head_range_forward       tracks the QuantAct after the depthwise conv (r_min / r_max / r_state)
  *                                        from ReLU(dw3x3(up2(fq(y1))) + b_dw) without storing it;
  *   cdn_codenet_head_tail_small_forward  recomputes those values, quantises them with y2_qstate and applies the

@@ -471,59 +471,3 @@ def test_int8_pointwise_exact_integer_sums(M, C, Co, relu):
     assert xmin.item() == out.min().item() and xmax.item() == out.max().item()
 
 
-@pytest.mark.parametrize("seed", range(10))
-def test_pointwise_mixed_generations_int8_segments(seed):
-    """Mixed-generation pointwise on the int8 matrix cores (K cut into (k-tile, generation) segments) vs a
-    float64 evaluation of sum_g (sum_{c in g} L_c qw) / s_g / sw + b: exact integer sums per generation."""
-    import random
-    from codenet_amd import _native as N_, ops, pipeline
-    lib, dev = N_.lib(), torch.device("cuda", 0)
-    ws, wp, wb = _ws(lib, dev)
-    rnd = random.Random(seed)
-    g = torch.Generator().manual_seed(300 + seed)
-    M = rnd.choice([1, 31, 129, 1000, 4100])
-    C = rnd.choice([4, 24, 58, 116, 232, 464])
-    Co = rnd.choice([1, 29, 58, 116, 130, 300])
-    lda = C + rnd.choice([0, 4, 6]) if C % 4 == 0 else C + 3
-    ldo = Co * 2 + rnd.choice([0, 1])
-    ngen = rnd.choice([1, 2, 5, 9])
-    S = _states(dev, ngen, g)
-    gens = torch.randint(0, ngen, (C,), generator=g)
-    if rnd.random() < 0.5:                                       # runs, as the slot policy produces them
-        gens, _ = torch.sort(gens)
-    gen = gens.to(torch.uint8).to(dev)
-    a = (torch.randn(M, lda, generator=g) * 2).to(dev)
-    sc, zp = S[gens.to(dev), 2].view(1, C), S[gens.to(dev), 3].view(1, C)
-    a[:, :C] = _avoid_ties(a[:, :C], sc, zp)
-    L = torch.round(sc * a[:, :C] - zp) + zp
-    q = torch.randint(-8, 8, (Co, C), generator=g)
-    livec = torch.rand(C, generator=g) >= 0.4
-    q[:, ~livec] = 0                                             # pass-through columns
-    codes = q.to(torch.int8).to(dev)
-    seg = pipeline.FusedBackbone._segments(codes, livec.tolist(), gens.tolist(), dev)
-    scale = (torch.rand(Co, generator=g) * 20 + 1).to(dev)
-    bias = torch.randn(Co, generator=g).to(dev)
-    wf = (q.to(dev).float() / scale[:, None]).contiguous()
-    omap = torch.randperm(ldo, generator=g)[:Co].to(torch.int32).to(dev)
-    out = torch.full((M, ldo), -7.0, device=dev)
-    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
-    Si = S.view(torch.int32).clone()
-    rc = lib.cdn_codenet_pointwise_mixed_i8_forward(
-        a.data_ptr(), Si.data_ptr(), gen.data_ptr(), M, C, Co, lda, ldo, wf.data_ptr(), seg["k0"].data_ptr(),
-        seg["gen"].data_ptr(), seg["flush"].data_ptr(), seg["nseg"], seg["colsum"].shape[0], seg["codes"].data_ptr(),
-        seg["colsum"].data_ptr(), scale.data_ptr(), bias.data_ptr(), 1, omap.data_ptr(), xmin.data_ptr(),
-        xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    N_.check(rc, "pw mixed i8")
-    acc = torch.zeros(M, Co, dtype=torch.float64, device=dev)
-    for gi in range(ngen):
-        sel = (gens == gi).to(dev)
-        if sel.any():
-            isum = L[:, sel].double() @ q.to(dev)[:, sel].double().t()
-            acc += isum * (1.0 / S[gi, 2]).double()
-    ref = torch.relu(acc / scale.double()[None, :] + bias.double())
-    got = out[:, omap.long()].double()
-    assert (got - ref).abs().max().item() < 3e-6 * (ref.abs().max().item() + 1.0)
-    untouched = torch.ones(ldo, dtype=torch.bool, device=dev)
-    untouched[omap.long()] = False
-    assert (out[:, untouched] == -7.0).all()
-    assert xmin.item() == out[:, omap.long()].min().item() and xmax.item() == out[:, omap.long()].max().item()

@@ -545,9 +545,9 @@ def _head_modules(C, classes, g, quantized, pct=False):
     return heads
 
 
-@pytest.mark.parametrize("quantized,fuse_tail", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("quantized", [False, True])
 @pytest.mark.parametrize("planes,res", [([24, 16, 12, 8], 6), ([64, 32, 16, 64], 4)])
-def test_fused_heads_match_modules(quantized, fuse_tail, planes, res):
+def test_fused_heads_match_modules(quantized, planes, res):
     """FusedHotPath.forward_nhwc -> FusedHeads (half-resolution 1x1, up-sampling depthwise, 1x1) vs
     the head modules applied to the unpacked tensor, over 3 forwards (QuantAct EMA state)."""
     import copy
@@ -559,7 +559,7 @@ def test_fused_heads_match_modules(quantized, fuse_tail, planes, res):
     heads_a = {k: copy.deepcopy(v).cuda() for k, v in heads.items()}
     heads_b = {k: copy.deepcopy(v).cuda() for k, v in heads.items()}
     path = pipeline.FusedHotPath(net_b.deconv_layers)
-    fheads = pipeline.FusedHeads(heads_b, fuse_tail=fuse_tail)
+    fheads = pipeline.FusedHeads(heads_b)
     for it in range(3):
         x = (torch.randn(2, planes[0], res, res, generator=g).abs() * (1.0 + 0.2 * it)).cuda()
         with torch.no_grad():

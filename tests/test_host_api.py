@@ -91,10 +91,6 @@ def test_argument_validation_of_the_layer_entry_points_without_gpu():
     rc = lib.cdn_codenet_stem_forward(one, 1, 32, 32, 16, 4, one, None, 1, None, None, None, 8, 0.99, 0,
                                       None, 0, one, None)
     assert rc != 0 and b"24" in lib.cdn_last_error()
-    # head tail: more than 32 classes
-    rc = lib.cdn_codenet_head_tail_forward(one * 4, one, 1, 64, 8, 8, one, None, one, one * 4, one, one, one,
-                                           None, 80, one, None)
-    assert rc != 0
     # decode: K larger than the map, missing workspace
     assert lib.cdn_ctdet_decode_workspace_bytes(2, 20, 128, 128) >= 2 * 20 * 128 * 128 * 4
     rc = lib.cdn_ctdet_decode(one, one, None, 1, 2, 4, 4, 0, 100, 0, None, one, one * 64, 1 << 20, None)
