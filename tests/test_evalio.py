@@ -97,3 +97,31 @@ def test_export_w4_is_bit_exact(tmp_path):
     # pack / unpack round trip on every nibble value
     allv = torch.arange(-8, 8, dtype=torch.int8).view(1, 16)
     assert torch.equal(evalio.unpack_int4(evalio.pack_int4(allv)), allv)
+
+
+def test_eval_voc_pieces_known_answers():
+    """tools/eval_voc.py: the pre-processing crop is the identity on a res x res image; the VOC07 11-point AP of
+    perfect detections is 1, of detections on the wrong images 0, and a half-recall set gives 6/11."""
+    import importlib.util
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_voc", os.path.join(root, "tools", "eval_voc.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    g = np.random.RandomState(0)
+    img = g.randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    inp, meta = ev.pre_process(img, 64)
+    want = (torch.from_numpy(img).permute(2, 0, 1).float() / 255.0 - torch.from_numpy(ev.MEAN).view(3, 1, 1)) \
+        / torch.from_numpy(ev.STD).view(3, 1, 1)
+    assert (inp[0] - want).abs().max().item() < 1e-5 and meta["s"] == 64.0 and tuple(meta["c"]) == (32.0, 32.0)
+    # a 40 x 80 image: the long side maps onto the input, the short side is centred with zero padding
+    inp, meta = ev.pre_process(g.randint(0, 256, (40, 80, 3)).astype(np.uint8), 80)
+    assert meta["s"] == 80.0 and inp.shape == (1, 3, 80, 80)
+    pad = (0.0 - torch.from_numpy(ev.MEAN)) / torch.from_numpy(ev.STD)
+    assert (inp[0, :, 5, 40] - pad).abs().max().item() < 1e-5          # above the image: padding value
+    gts = {i: (np.array([[10., 10., 50., 50.]]), np.array([False])) for i in range(10)}
+    perfect = [(i, 0.9 - 0.01 * i, 10., 10., 50., 50.) for i in range(10)]
+    assert abs(ev.voc_eval(perfect, gts) - 1.0) < 1e-9
+    assert ev.voc_eval([(i + 100, 0.9, 10., 10., 50., 50.) for i in range(10)], gts) == 0.0
+    half = perfect[:5]
+    assert abs(ev.voc_eval(half, gts) - 6.0 / 11.0) < 1e-9              # recall 0.5 reached at precision 1

@@ -1,0 +1,199 @@
+"""AP50 on PASCAL VOC2007 test through the native network, end to end -- the reference's procedure
+(README.md:87-108: ``test.py ctdet --arch shufflenetv2 ... --resume-quantize`` then ``tools/reval.py``):
+
+    image -> pre_process (lib/detectors/base_detector.py:47-77: keep-ratio affine crop to input_res, mean / std)
+          -> PoseShuffleNetV2 on the HIP kernels (harness.enable_fused) [+ W-flip averaging, ctdet.py:32-39]
+          -> ctdet_decode (K = 100) -> post_process / merge_outputs (lib/utils/post_process.py:86-103, ctdet.py:48-72)
+          -> results.json (lib/datasets/dataset/pascal.py:58-79)
+          -> VOC07 11-point AP at IoU 0.5 per class, mean = AP50
+             (tools/voc_eval_lib/datasets/voc_eval.py:31-48,95-200, pascal_voc.py:237-247)
+
+Needs what the reference needs and this container does not have: ``<data>/voc/images/*.jpg`` +
+``<data>/voc/annotations/pascal_test2007.json`` (tools/get_pascal_voc.sh) and a checkpoint
+(``exp/ctdet/pascal_shufflenetv2_config_*/model_last.pth``).  When they are absent it prints the PROXY of SURVEY 8(d)
+instead -- the whole network against tests/golden/model_io.npz (outputs of the reference's own model) -- and says so.
+cv2 is not available here: images are read with PIL and the affine crop is done by torch's bilinear grid_sample
+(cv2.INTER_LINEAR's arithmetic differs in the last bits; this is stated in the output).
+
+    python tools/eval_voc.py --data /data --load_model exp/ctdet/pascal_shufflenetv2_config_c/model_last.pth \
+        --res 512 --quantize [--w2] [--maxpool] [--flip_test] [--reference-json results_ref.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from codenet_amd import evalio, harness
+
+CLASSES = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
+           "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]   # pascal.py:32-36
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)                                           # pascal.py:15-18
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+
+
+def pre_process(img, res):
+    """BaseDetector.pre_process with fix_res (ctdet on pascal: opts.py keep_res False): c = image centre,
+    s = max(h, w); the un-rotated affine map of get_affine_transform (lib/utils/image.py:30-55) sends the square of
+    side s around c onto the res x res input.  img: uint8 [H, W, 3] RGB -> ([1,3,res,res] float32, meta)."""
+    h, w = img.shape[:2]
+    c = np.array([w / 2.0, h / 2.0], dtype=np.float32)
+    s = float(max(h, w))
+    t = torch.from_numpy(img).permute(2, 0, 1).float().unsqueeze(0)
+    # output pixel (u, v) <- source (c + ((u, v) - res/2) * s/res); grid_sample wants normalised source coordinates
+    u = (torch.arange(res, dtype=torch.float32) - res / 2.0) * (s / res)
+    xs, ys = c[0] + u, c[1] + u
+    gx = (2 * xs + 1) / w - 1           # align_corners=False: pixel centres at (i + 0.5) / size
+    gy = (2 * ys + 1) / h - 1
+    grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], dim=-1).unsqueeze(0)
+    inp = torch.nn.functional.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    inp = (inp / 255.0 - torch.from_numpy(MEAN).view(1, 3, 1, 1)) / torch.from_numpy(STD).view(1, 3, 1, 1)
+    return inp, {"c": c, "s": s, "out_height": res // 4, "out_width": res // 4}
+
+
+def voc_ap07(rec, prec):
+    """11-point interpolated AP (voc_eval.py:36-48)."""
+    ap = 0.0
+    for t in np.arange(0.0, 1.1, 0.1):
+        ap += (np.max(prec[rec >= t]) if np.sum(rec >= t) else 0.0) / 11.0
+    return ap
+
+
+def voc_eval(dets, gts, ovthresh=0.5):
+    """dets: list of (image_id, score, x1, y1, x2, y2) of one class; gts: image_id -> (boxes [n,4], difficult [n]).
+    voc_eval.py:95-200 (+1 pixel conventions kept)."""
+    npos = sum(int((~d).sum()) for _, d in gts.values())
+    seen = {k: np.zeros(len(b), dtype=bool) for k, (b, _) in gts.items()}
+    dets = sorted(dets, key=lambda r: -r[1])
+    tp, fp = np.zeros(len(dets)), np.zeros(len(dets))
+    for i, (img, _score, *bb) in enumerate(dets):
+        boxes, diff = gts.get(img, (np.zeros((0, 4)), np.zeros(0, dtype=bool)))
+        ovmax, jmax = -np.inf, -1
+        if len(boxes):
+            ixmin, iymin = np.maximum(boxes[:, 0], bb[0]), np.maximum(boxes[:, 1], bb[1])
+            ixmax, iymax = np.minimum(boxes[:, 2], bb[2]), np.minimum(boxes[:, 3], bb[3])
+            inter = np.maximum(ixmax - ixmin + 1.0, 0.0) * np.maximum(iymax - iymin + 1.0, 0.0)
+            uni = (bb[2] - bb[0] + 1.0) * (bb[3] - bb[1] + 1.0) + \
+                (boxes[:, 2] - boxes[:, 0] + 1.0) * (boxes[:, 3] - boxes[:, 1] + 1.0) - inter
+            ov = inter / uni
+            jmax = int(np.argmax(ov))
+            ovmax = ov[jmax]
+        if ovmax > ovthresh:
+            if not diff[jmax]:
+                if not seen[img][jmax]:
+                    tp[i] = 1.0
+                    seen[img][jmax] = True
+                else:
+                    fp[i] = 1.0
+        else:
+            fp[i] = 1.0
+    tp, fp = np.cumsum(tp), np.cumsum(fp)
+    rec = tp / max(npos, 1)
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    return voc_ap07(rec, prec)
+
+
+def run_voc(args):
+    from PIL import Image
+    root = os.path.join(args.data, "voc")
+    ann = json.load(open(os.path.join(root, "annotations", "pascal_test2007.json")))
+    images = {im["id"]: im for im in ann["images"]}
+    gts = {c: {} for c in range(1, 21)}
+    for a in ann["annotations"]:
+        x, y, w, h = a["bbox"]
+        g = gts[a["category_id"]].setdefault(a["image_id"], ([], []))
+        g[0].append([x, y, x + w, y + h])
+        g[1].append(bool(a.get("ignore", 0) or a.get("difficult", 0)))
+    gts = {c: {k: (np.array(b, dtype=np.float64), np.array(d, dtype=bool)) for k, (b, d) in v.items()}
+           for c, v in gts.items()}
+    model = harness.create_model(w2=args.w2, maxpool=args.maxpool, quantize=args.quantize)
+    evalio.load_model(model, args.load_model)
+    model = model.cuda().eval().enable_fused()
+    results = {}
+    ids = sorted(images)[: args.limit or None]
+    for n, img_id in enumerate(ids):
+        img = np.asarray(Image.open(os.path.join(root, "images", images[img_id]["file_name"])).convert("RGB"))
+        inp, meta = pre_process(img, args.res)
+        if args.flip_test:
+            inp = torch.cat([inp, torch.flip(inp, [3])], 0)
+        _, dets = harness.process(model, inp.cuda(), flip_test=args.flip_test)
+        per_class = evalio.post_process(dets, meta, 20)
+        results[img_id] = evalio.merge_outputs([per_class], 20)
+        if n % 500 == 0:
+            print("%d / %d images" % (n, len(ids)), file=sys.stderr)
+    os.makedirs(args.out, exist_ok=True)
+    evalio.save_results(results, ids, 20, args.out)
+    aps = []
+    for c in range(1, 21):
+        rows = [(img_id, float(r[4]), *map(float, r[:4])) for img_id in ids for r in results[img_id][c]]
+        aps.append(voc_eval(rows, gts[c]))
+        print("AP for %s = %.4f" % (CLASSES[c - 1], aps[-1]))
+    out = {"AP50": float(np.mean(aps)), "per_class": dict(zip(CLASSES, map(float, aps))), "images": len(ids),
+           "note": "VOC07 11-point, IoU 0.5; pre-processing by PIL + torch bilinear grid_sample (cv2 absent)"}
+    if args.reference_ap50 is not None:
+        out["delta_vs_reference"] = out["AP50"] - args.reference_ap50
+    print(json.dumps(out))
+
+
+def run_proxy(args):
+    """No data / checkpoint here: the SURVEY 8(d) proxy on the reference model's golden outputs."""
+    g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    z = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(g, "model_io.npz")).items()}
+    nz = {k: float(v) for k, v in np.load(os.path.join(g, "model_noise.npz")).items()}
+    gen = torch.Generator().manual_seed(int(z["image_seed"]))
+    img = torch.randn(1, 3, 256, 256, generator=gen)
+    images = torch.cat([img, torch.flip(img, [3])], 0).cuda()
+    out = {"measured": "PROXY (no VOC data / checkpoint on this box): whole network vs the reference model's golden "
+                       "outputs on a synthetic image + its flip, synthetic weights"}
+    for tag in ("fp32", "w4a8"):
+        model = harness.create_model(quantize=(tag == "w4a8")).cuda().enable_fused()
+        for _ in range(int(z[tag + "_nfwd"]) - 1):
+            with torch.no_grad():
+                model(images)
+        o, dets = harness.process(model, images)
+        worst, means = 0.0, {}
+        for k in ("hm", "wh", "reg"):
+            raw = o[k].cpu() if k != "hm" else torch.logit(o[k].cpu())
+            d = (raw[:, :, ::4, ::4] - z["%s_%s_sub" % (tag, k)]).abs()
+            worst = max(worst, d.max().item())
+            means[k] = d.mean().item()
+        ref = z[tag + "_dets"][0]
+        ours = dets.cpu()[0]
+        oc = torch.stack([(ours[:, 0] + ours[:, 2]) / 2, (ours[:, 1] + ours[:, 3]) / 2], 1)
+        rc = torch.stack([(ref[:, 0] + ref[:, 2]) / 2, (ref[:, 1] + ref[:, 3]) / 2], 1)
+        tol = (0.05, 2e-3) if tag == "fp32" else (0.5, 2e-2)
+        hit = sum(int(((ours[:, 5] == ref[i, 5]) & ((oc - rc[i]).abs().max(dim=1).values <= tol[0])
+                       & ((ours[:, 4] - ref[i, 4]).abs() <= tol[1])).any()) for i in range(ref.shape[0]))
+        out[tag] = {"max_abs_diff": worst, "mean_abs_diff": means, "top100_agreement": hit / ref.shape[0]}
+    out["reference_vs_itself_w4a8"] = {"mean_abs_diff": {k: nz["noise_mean_" + k] for k in ("hm", "wh", "reg")},
+                                       "top100_agreement": nz["self_agreement"]}
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", default="data")
+    ap.add_argument("--load_model", default="")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--quantize", action="store_true")
+    ap.add_argument("--w2", action="store_true")
+    ap.add_argument("--maxpool", action="store_true")
+    ap.add_argument("--flip_test", action="store_true")
+    ap.add_argument("--limit", type=int, default=0)
+    ap.add_argument("--out", default="gpurun_out/voc_eval")
+    ap.add_argument("--reference-ap50", type=float, default=None, help="the reference's AP50 for this config "
+                    "(README.md:14-18) to print the delta")
+    args = ap.parse_args()
+    have = (os.path.isfile(os.path.join(args.data, "voc", "annotations", "pascal_test2007.json"))
+            and os.path.isfile(args.load_model))
+    if have:
+        run_voc(args)
+    else:
+        run_proxy(args)
+
+
+if __name__ == "__main__":
+    main()
