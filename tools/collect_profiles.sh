@@ -35,6 +35,7 @@ python3 tools/heads_bench.py > "$OUT/heads_bench.json" 2>/dev/null
 python3 tools/decode_bench.py > "$OUT/decode_bench.json" 2>/dev/null
 python3 tools/backbone_bench.py > "$OUT/backbone_bench.json" 2>/dev/null
 python3 tools/e2e_native_bench.py --graph > "$OUT/e2e_native.json" 2>/dev/null
+python3 tools/generic_bench.py > "$OUT/generic_bench.json" 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/e2e_stats" -- python3 tools/e2e_native_bench.py > "$OUT/e2e_stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc $MFMA --output-format csv -d "$OUT/pmc_mfma_e2e" -- python3 tools/e2e_native_bench.py --steps 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_stats" -- python3 tools/train_step_bench.py > "$OUT/train_stats.log" 2>&1
