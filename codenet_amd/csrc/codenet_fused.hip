@@ -118,6 +118,20 @@ __device__ __forceinline__ unsigned pack_code8(const float4 &v, const Code8 &c, 
   return (unsigned)(act_code8(v.x, c, bad) & 0xff) | ((unsigned)(act_code8(v.y, c, bad) & 0xff) << 8) |
          ((unsigned)(act_code8(v.z, c, bad) & 0xff) << 16) | ((unsigned)act_code8(v.w, c, bad) << 24);
 }
+// Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own L2.  With byte
+// tensors a 32- or 64-channel chunk is 32 / 64 bytes of every 128-byte line, so the chunk workgroups of ONE image
+// must share an L2 or every line crosses the fabric once per chunk (PMC: 33 MB read for the 8 MB stage-2 input,
+// and partial-line writes of d from different XCDs).  Remap (chunk, image) so that XCD k walks the images
+// [k*N/8, (k+1)*N/8) chunk by chunk; identity when the grid is not a multiple of 8.  Scalar arithmetic only.
+__device__ __forceinline__ void xcd_remap(int &chunk, int &n) {
+  const int nch = gridDim.x, total = gridDim.x * gridDim.y;
+  if (total & 7) return;
+  const int id = blockIdx.y * nch + blockIdx.x;
+  const int item = (id & 7) * (total >> 3) + (id >> 3);
+  n = item / nch;
+  chunk = item - n * nch;
+}
+
 // four stored codes -> the fake-quantised values (q + zp) / scale (Markstein division, bit-identical to
 // cdn::fake_quant_r of the pre-quantisation value that produced the code)
 __device__ __forceinline__ float4 unpack_code8(unsigned u, float scale, float zp, float r) {
@@ -151,21 +165,20 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int c = wave;
   constexpr int S = kScaleWaves;
-  // 8 loads in flight per lane; the accumulation order is that of the 4-wide loop below (a0 takes c, c + 4S, ...),
-  // so the sums are bit-identical to it
-  for (; c + 7 * S < C; c += 8 * S) {
-    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + S) * HW];
-    const float v2 = xp[(long)(c + 2 * S) * HW], v3 = xp[(long)(c + 3 * S) * HW];
-    const float v4 = xp[(long)(c + 4 * S) * HW], v5 = xp[(long)(c + 5 * S) * HW];
-    const float v6 = xp[(long)(c + 6 * S) * HW], v7 = xp[(long)(c + 7 * S) * HW];
-    a0 = fmaf(w[c], v0, a0);
-    a1 = fmaf(w[c + S], v1, a1);
-    a2 = fmaf(w[c + 2 * S], v2, a2);
-    a3 = fmaf(w[c + 3 * S], v3, a3);
-    a0 = fmaf(w[c + 4 * S], v4, a0);
-    a1 = fmaf(w[c + 5 * S], v5, a1);
-    a2 = fmaf(w[c + 6 * S], v6, a2);
-    a3 = fmaf(w[c + 7 * S], v7, a3);
+  // 16 loads in flight per lane (one 16-wave workgroup per CU: 8 in flight left the kernel at 2.7 TB/s); the
+  // accumulation order is that of the 4-wide loop below (a0 takes c, c + 4S, ...), so the sums are bit-identical
+  // to it whatever the unroll
+  for (; c + 15 * S < C; c += 16 * S) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = xp[(long)(c + u * S) * HW];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      a0 = fmaf(w[c + u * S], v[u], a0);
+      a1 = fmaf(w[c + (u + 1) * S], v[u + 1], a1);
+      a2 = fmaf(w[c + (u + 2) * S], v[u + 2], a2);
+      a3 = fmaf(w[c + (u + 3) * S], v[u + 3], a3);
+    }
   }
   for (; c + 3 * S < C; c += 4 * S) {
     const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + S) * HW];
@@ -594,7 +607,9 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
   const int Hl = H >> up, Wl = W >> up;
   const int HWl = Hl * Wl;
-  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  int n = blockIdx.y, chunk = blockIdx.x;
+  if (X8 || OUT8) xcd_remap(chunk, n);
+  const int c0 = chunk * CCH;
   const int tid = threadIdx.x;
   const int Wc = Wl + 1;                       // cells per LDS row
   const int cells = (Hl + 1) * Wc;
@@ -812,7 +827,9 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
   const int Hl = H >> 1, Wl = W >> 1;
   const int HWl = Hl * Wl, HW = H * W;
-  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  int n = blockIdx.y, chunk = blockIdx.x;
+  if (X8 || OUT8) xcd_remap(chunk, n);
+  const int c0 = chunk * CCH;
   const int tid = threadIdx.x;
   const int Wc = Wl + 1;
   const int cells = (Hl + 1) * Wc;
