@@ -317,3 +317,49 @@ print(json.dumps({"cls": cls, "fp": k_fp, "q": k_q}))
     assert outs["ours"]["fp"] == outs["ref"]["fp"]
     assert outs["ours"]["q"] == outs["ref"]["q"]
     assert len(outs["ours"]["q"]) > 300
+
+
+def test_argument_validation_of_round2_entry_points_without_gpu():
+    """Frozen-range schedule, training kernels and capability queries validate before any HIP call."""
+    import ctypes
+    from codenet_amd import _native
+    lib = _native.lib()
+    one = 4096
+    # capability queries (pure host arithmetic)
+    assert lib.cdn_codenet_stage_supported(64, 1024, 16, 16, 0, 0) == 1          # cfg3 stage 0
+    assert lib.cdn_codenet_stage_supported(64, 128, 64, 64, 1, 1) == 1           # cfg3 stage 2 (stored 32 x 32)
+    assert lib.cdn_codenet_stage_supported(1, 128, 160, 160, 1, 1) == 0          # stored 80 x 80: not LDS resident
+    assert lib.cdn_codenet_stage_supported(1, 2153, 16, 16, 1, 0) == 0           # channels-last needs C % 4 == 0
+    assert lib.cdn_codenet_stage_supported(1, 128, 15, 16, 1, 1) == 0            # x_up needs even H
+    assert lib.cdn_codenet_dw_backward_supported(64, 64) == 1 and lib.cdn_codenet_dw_backward_supported(136, 136) == 1
+    assert lib.cdn_codenet_dw_backward_supported(400, 400) == 0
+    # frozen stage: byte codes need C % 4 == 0; x_state goes with channels-last inputs only; workspace size
+    args = lambda **kw: [kw.get("x", one * 4), kw.get("kind", 0), kw.get("up", 0), kw.get("xs", None), 2,   # noqa: E731
+                         kw.get("C", 64), 32, 8, 8, one, one, -7.0, 8.0, one, one * 4, one, one, None, 1, one, one, one,
+                         kw.get("ws", one * 64), kw.get("wsb", 1 << 30), one * 4, one, None]
+    assert lib.cdn_codenet_stage_frozen_forward(*args(C=2153)) == _native.CDN_ERR_UNSUPPORTED
+    assert b"C % 4" in lib.cdn_last_error()
+    assert lib.cdn_codenet_stage_frozen_forward(*args(kind=2)) == -1 and b"x_state" in lib.cdn_last_error()
+    assert lib.cdn_codenet_stage_frozen_forward(*args(kind=0, xs=one)) == -1
+    assert lib.cdn_codenet_stage_frozen_forward(*args(kind=0, up=1)) == _native.CDN_ERR_UNSUPPORTED
+    assert lib.cdn_codenet_stage_frozen_forward(*args(wsb=16)) == -6
+    assert lib.cdn_codenet_stage_frozen_workspace_bytes(64, 1024, 16, 16, 0) == 64 * 256 * 4 + 64 * 256 * 1024
+    # frozen parameters: at most 12 QuantActs per call
+    arr = (ctypes.c_void_p * 13)(*([one] * 13))
+    assert lib.cdn_quantact_frozen_params(13, arr, arr, arr, 8, None) == -1
+    assert lib.cdn_quantact_frozen_params(0, None, None, None, 8, None) == 0
+    # byte-code pointwise: exactly one output form; the byte form needs the output quantiser
+    assert lib.cdn_codenet_pointwise_q8_forward(one * 4, one, 64, 64, 16, one * 4, one, one, None, 1, one, one * 4,
+                                                one * 4, one, None) == -1
+    assert lib.cdn_codenet_pointwise_q8_forward(one * 4, one, 64, 64, 16, one * 4, one, one, None, 1, None, one * 4,
+                                                None, one, None) == -1
+    assert lib.cdn_codenet_pointwise_q8_forward(one * 4, one, 64, 62, 16, one * 4, one, one, None, 1, one, one * 4,
+                                                None, one, None) == -1          # C % 4
+    # weight gradient: workspace too small; scale backward: null pointers
+    need = lib.cdn_codenet_pointwise_wgrad_workspace_bytes(32, 128, 64, 4096)
+    assert need >= 64 * 128 * 4
+    assert lib.cdn_codenet_pointwise_wgrad(one * 4, one * 4, one, None, 32, 128, 64, 4096, one * 4, need - 256, None) == -6
+    assert lib.cdn_codenet_scale_backward(None, one, one, one, one, 1, 4, 8, 8, None) == -1
+    # decode: heat_out partially overlapping heat is an argument error
+    rc = lib.cdn_ctdet_decode(one * 64, one, None, 1, 2, 8, 8, 0, 10, 1, one * 64 + 64, one, one * 64, 1 << 20, None)
+    assert rc == -1 and b"overlaps" in lib.cdn_last_error()
