@@ -351,12 +351,17 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   unsigned long long *gimg = smem64;                                   // [cells][CCH] fixed point
   float *ximg = reinterpret_cast<float *>(smem64 + (size_t)cells * CCH);  // [cells][CCH]
   float *gwl = ximg + (size_t)cells * CCH;                             // [CCH][9]
-  float *red = gwl + CCH * 9;                                          // [nwaves + 1]
+  float *wls = gwl + CCH * 9;                                          // [9][CCH] the chunk's weights, tap-major
+  float *red = wls + CCH * 9;                                          // [2 * nwaves + 1]
   for (int q = tid; q < cells * CCH; q += nthreads) {
     ximg[q] = 0.0f;
     gimg[q] = 0ull;
   }
-  for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
+  for (int q = tid; q < CCH * 9; q += nthreads) {
+    gwl[q] = 0.0f;
+    const int k = q / CCH, c = q - k * CCH;      // (36 weight registers per lane with 4 channels per lane would
+    wls[q] = (c0 + c < C) ? wd[(long)(c0 + c) * 9 + k] : 0.0f;   //  spill: the taps read them from LDS instead)
+  }
   // ---- fixed-point scale of this workgroup: max |grad_d| over its slice, max |w| over its chunk --
   float gmax = 0.0f;
   {
@@ -412,19 +417,28 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   const int lane = tid & 63, wave = tid >> 6;
   const int cl = (lane % LPP) * CPL, sub = lane / LPP;       // first of the lane's CPL local channels, pixel slot
   bool ch_ok[CPL];
-  float wk[9][CPL], gwa[9][CPL];
+  float gwa[9][CPL];
 #pragma unroll
   for (int e = 0; e < CPL; ++e) {
     ch_ok[e] = c0 + cl + e < C;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      wk[k][e] = ch_ok[e] ? wd[(long)(c0 + cl + e) * 9 + k] : 0.0f;
-      gwa[k][e] = 0.0f;
-    }
+    for (int k = 0; k < 9; ++k) gwa[k][e] = 0.0f;
   }
   auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? yy : H) * Wc * CCH; };
   auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH + cl; };
   // the lane's CPL consecutive channels of one cell (CPL * 4 bytes, naturally aligned)
+  auto ldw = [&](int k, float (&v)[CPL]) {
+    const float *b = wls + k * CCH + cl;
+    if (CPL == 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(b);
+      v[0] = t.x; v[1 % CPL] = t.y; v[2 % CPL] = t.z; v[3 % CPL] = t.w;
+    } else if (CPL == 2) {
+      const float2 t = *reinterpret_cast<const float2 *>(b);
+      v[0] = t.x; v[1 % CPL] = t.y;
+    } else {
+      v[0] = b[0];
+    }
+  };
   auto ld = [&](int o, float (&v)[CPL]) {
     if (CPL == 4) {
       const float4 t = *reinterpret_cast<const float4 *>(ximg + o);
@@ -456,14 +470,15 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     auto tap = [&](const Axis &Y, const Axis &X, float ay, float ax, int k) {
       const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1);
       const int q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
-      float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
+      float v00[CPL], v01[CPL], v10[CPL], v11[CPL], wkk[CPL];
       ld(r0 + q0, v00); ld(r0 + q1, v01); ld(r1 + q0, v10); ld(r1 + q1, v11);
+      ldw(k, wkk);
       const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1, w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;
       const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
 #pragma unroll
       for (int e = 0; e < CPL; ++e) {
         const float S = (w00 * v00[e] + w01 * v01[e]) + w10 * v10[e] + w11 * v11[e];
-        const float gk = g[e] * wk[k][e];
+        const float gk = g[e] * wkk[e];
         if (gx != nullptr) {
           scatter(r0 + q0 + e, w00 * gk);
           scatter(r0 + q1 + e, w01 * gk);
@@ -479,11 +494,12 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     // edge / centre taps touch only the cells with non-zero weight
     auto tap_v = [&](const Axis &Y, float ay, int k) {     // column exact
       const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1), q0 = col_off(w);
-      float v0[CPL], v1[CPL];
+      float v0[CPL], v1[CPL], wkk[CPL];
       ld(r0 + q0, v0); ld(r1 + q0, v1);
+      ldw(k, wkk);
 #pragma unroll
       for (int e = 0; e < CPL; ++e) {
-        const float gk = g[e] * wk[k][e];
+        const float gk = g[e] * wkk[e];
         if (gx != nullptr) {
           scatter(r0 + q0 + e, Y.w0 * gk);
           scatter(r1 + q0 + e, Y.w1 * gk);
@@ -494,11 +510,12 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     };
     auto tap_h = [&](const Axis &X, float ax, int k) {     // row exact
       const int r0 = row_off(h), q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
-      float v0[CPL], v1[CPL];
+      float v0[CPL], v1[CPL], wkk[CPL];
       ld(r0 + q0, v0); ld(r0 + q1, v1);
+      ldw(k, wkk);
 #pragma unroll
       for (int e = 0; e < CPL; ++e) {
-        const float gk = g[e] * wk[k][e];
+        const float gk = g[e] * wkk[e];
         if (gx != nullptr) {
           scatter(r0 + q0 + e, X.w0 * gk);
           scatter(r0 + q1 + e, X.w1 * gk);
@@ -513,11 +530,12 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     tap_h(xa, -1.f, 3);
     {
       const int o = row_off(h) + col_off(w);
-      float vc[CPL];
+      float vc[CPL], wkk[CPL];
       ld(o, vc);
+      ldw(4, wkk);
 #pragma unroll
       for (int e = 0; e < CPL; ++e) {
-        if (gx != nullptr) scatter(o + e, g[e] * wk[4][e]);
+        if (gx != nullptr) scatter(o + e, g[e] * wkk[e]);
         gwa[4][e] = fmaf(g[e], vc[e], gwa[4][e]);
       }
     }
@@ -717,7 +735,7 @@ extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, 
 extern "C" int cdn_codenet_dw_backward_supported(int64_t H, int64_t W) {
   if (H <= 0 || W <= 0 || H > 65535 || W > 65535) return 0;
   const size_t cells = (size_t)(H + 1) * (W + 1);
-  if (cells * 2 * 12 + 2 * 9 * 4 + 128 <= (size_t)160 * 1024 - 512) return 1;      // lanes <-> channels kernel
+  if (cells * 2 * 12 + 2 * 9 * 8 + 128 <= (size_t)160 * 1024 - 512) return 1;      // lanes <-> channels kernel
   return (150 * 1024 / 4 - 64) / (2 * (H + 2) * (W + 2) + 18) >= 1;                 // bordered-plane kernel
 }
 
@@ -737,7 +755,7 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   const size_t cells = (size_t)(H + 1) * (W + 1);
   const size_t lds_max = 160 * 1024 - 512;
   int cch = 0;
-  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 128; };
+  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 8 + 128; };   // images + grad_w + weights
   for (int c : {32, 16, 8, 4, 2})
     if (bwd_lds(c) <= lds_max) {
       cch = c;
