@@ -323,26 +323,24 @@ dw_bwd_kernel(const float *__restrict__ x, const float *__restrict__ s,
 //     2^-40 of the workgroup maximum -- finer than fp32), summed exactly and converted back once:
 //     the sum is order-independent, so grad_x is bitwise reproducible (the reference's float
 //     atomics, _kernel.cu:329, are not);
-//   * grad_w accumulates in lane-private registers over all pixels (a lane owns its channels): no
-//     per-element cross-lane reduction, one LDS add per lane and channel at the end;
-//   * grad_s is reduced over the lanes of a pixel with xor shuffles, one global atomic per
-//     (pixel, channel chunk);
-//   * a lane owns CPL consecutive channels of its pixel (CPL = min(CCH, 4)).  The kernel is VALU-bound -- about
-//     1000 instructions per (pixel, channel) with one channel per lane (rocprofv3: 0.46 ms for the 64 x 64 plane
-//     = 16.8 M lane steps x 1000 / the chip's issue rate), of which the tap geometry, the corner-weight products
-//     and the cell addresses are the same for every channel of the pixel: with CPL channels per lane they are
-//     computed once per CPL channels.  Per channel the arithmetic and its order are unchanged.
+//   * grad_w accumulates in lane-private registers over all pixels (a lane IS a channel): no
+//     per-element cross-lane reduction, one LDS add per lane at the end;
+//   * grad_s is reduced over the CCH lanes of a pixel with xor shuffles, one global atomic per
+//     (pixel, channel chunk).
 // CCH is the largest of {32,16,8,4,2} whose images (4 + 8 bytes per cell and channel) fit LDS.
+// Tried in round 2 and reverted: a lane owning 2-4 consecutive channels of its pixel (tap geometry, corner
+// weights and cell addresses once per lane instead of once per channel: ~40 % fewer VALU instructions).  Slower at
+// every stage shape (64 x 64 plane 458 -> 636 us, 16 x 16 x 1024 channels 250 -> 282 us): the kernel is bound by
+// the LDS atomics' bank conflicts, not by instruction issue, and with fewer lanes per pixel one wave instruction
+// scatters to twice as many unrelated cells.
 // ------------------------------------------------------------------------------------------
-template <int CCH, int CPL>
+template <int CCH>
 __global__ void __launch_bounds__(512)
 dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
                const float *__restrict__ wd, const float *__restrict__ gd, float *__restrict__ gx,
                float *__restrict__ gs, float *__restrict__ gw, int C, int H, int W) {
   extern __shared__ unsigned long long smem64[];
-  static_assert(CCH % CPL == 0 && CPL >= 1 && CPL <= 4, "channels per lane");
-  constexpr int LPP = CCH / CPL;                 // lanes per pixel
-  constexpr int PPW = 64 / LPP;                  // pixels per wave step
+  constexpr int PPW = 64 / CCH;                  // pixels per wave step
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
   const int HW = H * W, Wc = W + 1;
   const int cells = (H + 1) * Wc;
@@ -351,17 +349,12 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   unsigned long long *gimg = smem64;                                   // [cells][CCH] fixed point
   float *ximg = reinterpret_cast<float *>(smem64 + (size_t)cells * CCH);  // [cells][CCH]
   float *gwl = ximg + (size_t)cells * CCH;                             // [CCH][9]
-  float *wls = gwl + CCH * 9;                                          // [9][CCH] the chunk's weights, tap-major
-  float *red = wls + CCH * 9;                                          // [2 * nwaves + 1]
+  float *red = gwl + CCH * 9;                                          // [nwaves + 1]
   for (int q = tid; q < cells * CCH; q += nthreads) {
     ximg[q] = 0.0f;
     gimg[q] = 0ull;
   }
-  for (int q = tid; q < CCH * 9; q += nthreads) {
-    gwl[q] = 0.0f;
-    const int k = q / CCH, c = q - k * CCH;      // (36 weight registers per lane with 4 channels per lane would
-    wls[q] = (c0 + c < C) ? wd[(long)(c0 + c) * 9 + k] : 0.0f;   //  spill: the taps read them from LDS instead)
-  }
+  for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
   // ---- fixed-point scale of this workgroup: max |grad_d| over its slice, max |w| over its chunk --
   float gmax = 0.0f;
   {
@@ -415,41 +408,16 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   float *gx_ = gx; gx = nullptr;
 #endif
   const int lane = tid & 63, wave = tid >> 6;
-  const int cl = (lane % LPP) * CPL, sub = lane / LPP;       // first of the lane's CPL local channels, pixel slot
-  bool ch_ok[CPL];
-  float gwa[9][CPL];
+  const int cl = lane % CCH, sub = lane / CCH;
+  const bool ch_ok = c0 + cl < C;
+  float wk[9], gwa[9];
 #pragma unroll
-  for (int e = 0; e < CPL; ++e) {
-    ch_ok[e] = c0 + cl + e < C;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) gwa[k][e] = 0.0f;
+  for (int k = 0; k < 9; ++k) {
+    wk[k] = ch_ok ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;
+    gwa[k] = 0.0f;
   }
   auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? yy : H) * Wc * CCH; };
   auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH + cl; };
-  // the lane's CPL consecutive channels of one cell (CPL * 4 bytes, naturally aligned)
-  auto ldw = [&](int k, float (&v)[CPL]) {
-    const float *b = wls + k * CCH + cl;
-    if (CPL == 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(b);
-      v[0] = t.x; v[1 % CPL] = t.y; v[2 % CPL] = t.z; v[3 % CPL] = t.w;
-    } else if (CPL == 2) {
-      const float2 t = *reinterpret_cast<const float2 *>(b);
-      v[0] = t.x; v[1 % CPL] = t.y;
-    } else {
-      v[0] = b[0];
-    }
-  };
-  auto ld = [&](int o, float (&v)[CPL]) {
-    if (CPL == 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(ximg + o);
-      v[0] = t.x; v[1 % CPL] = t.y; v[2 % CPL] = t.z; v[3 % CPL] = t.w;
-    } else if (CPL == 2) {
-      const float2 t = *reinterpret_cast<const float2 *>(ximg + o);
-      v[0] = t.x; v[1 % CPL] = t.y;
-    } else {
-      v[0] = ximg[o];
-    }
-  };
   auto scatter = [&](int o, float c) {
     atomicAdd(&gimg[o], (unsigned long long)__float2ll_rn(c * scale));
   };
@@ -462,67 +430,49 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     const float t = s[(long)n * HW + pp] - 1.0f;
     const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
     const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
-    float g[CPL];
-#pragma unroll
-    for (int e = 0; e < CPL; ++e)
-      g[e] = (live && ch_ok[e]) ? gd[((long)n * C + c0 + cl + e) * HW + pp] : 0.0f;
+    const float g = (live && ch_ok) ? gd[((long)n * C + c0 + cl) * HW + pp] : 0.0f;
     float gs_acc = 0.0f;
     auto tap = [&](const Axis &Y, const Axis &X, float ay, float ax, int k) {
       const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1);
       const int q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
-      float v00[CPL], v01[CPL], v10[CPL], v11[CPL], wkk[CPL];
-      ld(r0 + q0, v00); ld(r0 + q1, v01); ld(r1 + q0, v10); ld(r1 + q1, v11);
-      ldw(k, wkk);
+      const float v00 = ximg[r0 + q0], v01 = ximg[r0 + q1], v10 = ximg[r1 + q0], v11 = ximg[r1 + q1];
       const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1, w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;
-      const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) {
-        const float S = (w00 * v00[e] + w01 * v01[e]) + w10 * v10[e] + w11 * v11[e];
-        const float gk = g[e] * wkk[e];
-        if (gx != nullptr) {
-          scatter(r0 + q0 + e, w00 * gk);
-          scatter(r0 + q1 + e, w01 * gk);
-          scatter(r1 + q0 + e, w10 * gk);
-          scatter(r1 + q1 + e, w11 * gk);
-        }
-        const float dSdy = X.w0 * (v10[e] - v00[e]) + X.w1 * (v11[e] - v01[e]);
-        const float dSdx = Y.w0 * (v01[e] - v00[e]) + Y.w1 * (v11[e] - v10[e]);
-        gs_acc += okf * gk * (ay * dSdy + ax * dSdx);
-        gwa[k][e] = fmaf(g[e], S, gwa[k][e]);
+      const float S = (w00 * v00 + w01 * v01) + w10 * v10 + w11 * v11;
+      const float gk = g * wk[k];
+      if (gx != nullptr) {
+        scatter(r0 + q0, w00 * gk);
+        scatter(r0 + q1, w01 * gk);
+        scatter(r1 + q0, w10 * gk);
+        scatter(r1 + q1, w11 * gk);
       }
+      const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
+      const float dSdy = X.w0 * (v10 - v00) + X.w1 * (v11 - v01);
+      const float dSdx = Y.w0 * (v01 - v00) + Y.w1 * (v11 - v10);
+      gs_acc += okf * gk * (ay * dSdy + ax * dSdx);
+      gwa[k] = fmaf(g, S, gwa[k]);
     };
     // edge / centre taps touch only the cells with non-zero weight
     auto tap_v = [&](const Axis &Y, float ay, int k) {     // column exact
       const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1), q0 = col_off(w);
-      float v0[CPL], v1[CPL], wkk[CPL];
-      ld(r0 + q0, v0); ld(r1 + q0, v1);
-      ldw(k, wkk);
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) {
-        const float gk = g[e] * wkk[e];
-        if (gx != nullptr) {
-          scatter(r0 + q0 + e, Y.w0 * gk);
-          scatter(r1 + q0 + e, Y.w1 * gk);
-        }
-        gs_acc += (Y.ok ? 1.0f : 0.0f) * gk * ay * (v1[e] - v0[e]);
-        gwa[k][e] = fmaf(g[e], Y.w0 * v0[e] + Y.w1 * v1[e], gwa[k][e]);
+      const float v0 = ximg[r0 + q0], v1 = ximg[r1 + q0];
+      const float gk = g * wk[k];
+      if (gx != nullptr) {
+        scatter(r0 + q0, Y.w0 * gk);
+        scatter(r1 + q0, Y.w1 * gk);
       }
+      gs_acc += (Y.ok ? 1.0f : 0.0f) * gk * ay * (v1 - v0);
+      gwa[k] = fmaf(g, Y.w0 * v0 + Y.w1 * v1, gwa[k]);
     };
     auto tap_h = [&](const Axis &X, float ax, int k) {     // row exact
       const int r0 = row_off(h), q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
-      float v0[CPL], v1[CPL], wkk[CPL];
-      ld(r0 + q0, v0); ld(r0 + q1, v1);
-      ldw(k, wkk);
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) {
-        const float gk = g[e] * wkk[e];
-        if (gx != nullptr) {
-          scatter(r0 + q0 + e, X.w0 * gk);
-          scatter(r0 + q1 + e, X.w1 * gk);
-        }
-        gs_acc += (X.ok ? 1.0f : 0.0f) * gk * ax * (v1[e] - v0[e]);
-        gwa[k][e] = fmaf(g[e], X.w0 * v0[e] + X.w1 * v1[e], gwa[k][e]);
+      const float v0 = ximg[r0 + q0], v1 = ximg[r0 + q1];
+      const float gk = g * wk[k];
+      if (gx != nullptr) {
+        scatter(r0 + q0, X.w0 * gk);
+        scatter(r0 + q1, X.w1 * gk);
       }
+      gs_acc += (X.ok ? 1.0f : 0.0f) * gk * ax * (v1 - v0);
+      gwa[k] = fmaf(g, X.w0 * v0 + X.w1 * v1, gwa[k]);
     };
     tap(ya, xa, -1.f, -1.f, 0);
     tap_v(ya, -1.f, 1);
@@ -530,14 +480,8 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     tap_h(xa, -1.f, 3);
     {
       const int o = row_off(h) + col_off(w);
-      float vc[CPL], wkk[CPL];
-      ld(o, vc);
-      ldw(4, wkk);
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) {
-        if (gx != nullptr) scatter(o + e, g[e] * wkk[e]);
-        gwa[4][e] = fmaf(g[e], vc[e], gwa[4][e]);
-      }
+      if (gx != nullptr) scatter(o, g * wk[4]);
+      gwa[4] = fmaf(g, ximg[o], gwa[4]);
     }
     tap_h(xb, 1.f, 5);
     tap(yb, xa, 1.f, -1.f, 6);
@@ -545,17 +489,13 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     tap(yb, xb, 1.f, 1.f, 8);
     if (gs != nullptr) {
 #pragma unroll
-      for (int m = LPP / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
+      for (int m = CCH / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
       if (cl == 0 && live) atomicAdd(&gs[(long)n * HW + p], gs_acc);
     }
   }
-  if (gw != nullptr) {
+  if (gw != nullptr && ch_ok) {
 #pragma unroll
-    for (int e = 0; e < CPL; ++e)
-      if (ch_ok[e]) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&gwl[(cl + e) * 9 + k], gwa[k][e]);   // 9 per lane and channel, once
-      }
+    for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);   // 9 per lane, once
   }
 #if defined(CDN_DIAG) && CDN_DIAG == 3
   gx = gx_;
@@ -735,7 +675,7 @@ extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, 
 extern "C" int cdn_codenet_dw_backward_supported(int64_t H, int64_t W) {
   if (H <= 0 || W <= 0 || H > 65535 || W > 65535) return 0;
   const size_t cells = (size_t)(H + 1) * (W + 1);
-  if (cells * 2 * 12 + 2 * 9 * 8 + 128 <= (size_t)160 * 1024 - 512) return 1;      // lanes <-> channels kernel
+  if (cells * 2 * 12 + 2 * 9 * 4 + 128 <= (size_t)160 * 1024 - 512) return 1;      // lanes <-> channels kernel
   return (150 * 1024 / 4 - 64) / (2 * (H + 2) * (W + 2) + 18) >= 1;                 // bordered-plane kernel
 }
 
@@ -755,7 +695,7 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   const size_t cells = (size_t)(H + 1) * (W + 1);
   const size_t lds_max = 160 * 1024 - 512;
   int cch = 0;
-  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 8 + 128; };   // images + grad_w + weights
+  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 128; };
   for (int c : {32, 16, 8, 4, 2})
     if (bwd_lds(c) <= lds_max) {
       cch = c;
@@ -766,7 +706,7 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
     dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
 #define CDN_BWD(CCH_)                                                                          \
   {                                                                                            \
-    auto kern = dw_bwd2_kernel<CCH_, (CCH_ < 4 ? CCH_ : 4)>;                                   \
+    auto kern = dw_bwd2_kernel<CCH_>;                                                          \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                               (int)lds);                                                       \
     kern<<<grid, 512, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H,   \
