@@ -47,10 +47,10 @@ def is_frozen_variant(k):
 
 
 def rows_of(path, keep=HOT):
-    files = glob.glob(path)
+    files = sorted(glob.glob(path), key=os.path.getmtime)      # a re-collected round leaves several: newest
     if not files:
         return
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(files[-1])):
         if keep is None or any(t in r["Kernel_Name"] for t in keep):
             yield short(r["Kernel_Name"]) + " grid=" + r["Grid_Size"], r
 
