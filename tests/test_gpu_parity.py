@@ -685,3 +685,57 @@ def test_fused_heads_match_reference_golden():
             assert (act.x_max.cpu() - z["n_%smax%d" % (tag, it)]).abs().item() < 1e-4
         diff = (out - z["n_out%d" % it]).abs()
         assert diff.max().item() < 0.05 and (diff > 1e-3).float().mean().item() < 0.02
+
+
+def test_codenet_dw_backward_large_plane_uses_generic_entry_points():
+    """Planes beyond the LDS-resident backward: cdn_codenet_dw_backward_supported says no and the autograd
+    function falls back to the generic deform-conv entry points with offset = anchor * (s - 1) -- same gradients."""
+    from codenet_amd import _native as N_, ops
+    N, C, H, W = 1, 3, 150, 150
+    assert not N_.lib().cdn_codenet_dw_backward_supported(H, W)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, C, H, W, generator=g)
+    s = torch.randint(-6, 7, (N, 1, H, W), generator=g).float() + torch.empty(N, 1, H, W).uniform_(0.2, 0.8, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    go = torch.randn(N, C, H, W, generator=g)
+    off = Q.ANCHOR * (s - 1)
+    gx_ref, goff_ref = O.deform_conv_backward_input(x, off, w, go, 1, 1, 1, C, 1)
+    gw_ref = O.deform_conv_backward_params(x, off, tuple(w.shape), go, 1, 1, 1, C, 1)
+    gs_ref = (goff_ref * Q.ANCHOR).sum(dim=1, keepdim=True)
+    xg, sg, wg = (t.cuda().requires_grad_(True) for t in (x, s, w))
+    d = ops.codenet_dw(xg, sg, wg)
+    assert (d.detach().cpu() - O.deform_conv_forward(x, off, w, 1, 1, 1, C, 1)).abs().max().item() < 1e-4
+    d.backward(go.cuda())
+    assert (xg.grad.cpu() - gx_ref).abs().max().item() < 1e-3
+    assert (sg.grad.cpu() - gs_ref).abs().max().item() < 2e-3 * max(1.0, gs_ref.abs().max().item())
+    assert (wg.grad.cpu() - gw_ref).abs().max().item() < 2e-3 * max(1.0, gw_ref.abs().max().item())
+
+
+def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
+    """enable_fused() on a configuration / resolution the fused schedules do not implement (--act-percentile;
+    stored planes beyond the LDS-resident gather) must decide BEFORE any kernel runs and give the module path's
+    results (no silent difference, no exception at run time)."""
+    import copy
+    import warnings
+    from codenet_amd import harness
+    x = torch.randn(1, 3, 128, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    m = harness.create_model(quantize=True, act_percentile=True).cuda()
+    m2 = copy.deepcopy(m).enable_fused()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            a, b = m(x)[-1], m2(x)[-1]
+    assert any("module-by-module" in str(w.message) for w in wlist)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # 640 x 640: stage 2's stored plane is 40 x 40 -> not LDS resident
+    m3 = harness.create_model(quantize=False).cuda()
+    m4 = copy.deepcopy(m3).enable_fused()
+    xl = torch.randn(1, 3, 640, 640, generator=torch.Generator().manual_seed(4)).cuda()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            a, b = m3(xl)[-1], m4(xl)[-1]
+    assert any("module-by-module" in str(w.message) for w in wlist)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
