@@ -718,7 +718,9 @@ def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
     import copy
     import warnings
     from codenet_amd import harness
-    x = torch.randn(1, 3, 128, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    # (the percentile statistic needs >= 500 elements per tensor: kthvalue(k = round(n * 0.001)), k >= 1 -- the
+    # reference's own formula, quant_utils.py:18-30; the smallest tensor is the stage-0 scale plane, N * 8 * 8)
+    x = torch.randn(8, 3, 256, 256, generator=torch.Generator().manual_seed(3)).cuda()
     m = harness.create_model(quantize=True, act_percentile=True).cuda()
     m2 = copy.deepcopy(m).enable_fused()
     with warnings.catch_warnings(record=True) as wlist:
