@@ -125,3 +125,26 @@ def test_eval_voc_pieces_known_answers():
     assert ev.voc_eval([(i + 100, 0.9, 10., 10., 50., 50.) for i in range(10)], gts) == 0.0
     half = perfect[:5]
     assert abs(ev.voc_eval(half, gts) - 6.0 / 11.0) < 1e-9              # recall 0.5 reached at precision 1
+
+
+def test_pre_process_matches_affine_crop_known_answer():
+    """pre_process against a closed form: a horizontal ramp image keeps its slope s/res per output pixel and the image
+    centre lands on the output centre (get_affine_transform, lib/utils/image.py:30-55, rot = 0)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("eval_voc", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools", "eval_voc.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    h, w, res = 120, 200, 64
+    ramp = np.broadcast_to(np.arange(w, dtype=np.float32)[None, :, None], (h, w, 3)).copy()
+    img = np.clip(ramp, 0, 255).astype(np.uint8)
+    inp, meta = ev.pre_process(img, res)
+    assert inp.shape == (1, 3, res, res) and meta["s"] == 200.0 and list(meta["c"]) == [100.0, 60.0]
+    raw = (inp[0] * torch.from_numpy(ev.STD).view(3, 1, 1) + torch.from_numpy(ev.MEAN).view(3, 1, 1)) * 255.0
+    row = raw[0, res // 2]                      # a row through the image centre (inside the 120-pixel-high band)
+    step = 200.0 / res
+    want = torch.arange(res, dtype=torch.float32) * step + (100.0 - res / 2 * step)
+    inside = (want >= 0.5) & (want <= w - 1.5)
+    assert torch.allclose(row[inside], want[inside], atol=1e-2)
+    # rows outside the image band (|v - res/2| * step > h/2) are the zero padding
+    assert abs(float(raw[0, 0, res // 2])) < 1e-3

@@ -42,7 +42,7 @@ def pre_process(img, res):
     h, w = img.shape[:2]
     c = np.array([w / 2.0, h / 2.0], dtype=np.float32)
     s = float(max(h, w))
-    t = torch.from_numpy(img).permute(2, 0, 1).float().unsqueeze(0)
+    t = torch.from_numpy(np.ascontiguousarray(img).copy()).permute(2, 0, 1).float().unsqueeze(0)
     # output pixel (u, v) <- source (c + ((u, v) - res/2) * s/res); grid_sample wants normalised source coordinates
     u = (torch.arange(res, dtype=torch.float32) - res / 2.0) * (s / res)
     xs, ys = c[0] + u, c[1] + u
