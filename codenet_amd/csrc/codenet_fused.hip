@@ -132,6 +132,26 @@ __device__ __forceinline__ void xcd_remap(int &chunk, int &n) {
   chunk = item - n * nch;
 }
 
+// running extremes of a float4 of accumulators: two three-operand instructions per side.  (fminf / fmaxf make the
+// compiler quiet each operand first -- v_max_f32 x, x -- which was 16 of the 40 min/max instructions per gather step;
+// the operands here are fma results, never signalling NaNs.)
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ void track4(const float4 &a, float &mn, float &mn2, float &mx, float &mx2) {
+  mn = min3f(mn, a.x, a.y);
+  mn2 = min3f(mn2, a.z, a.w);
+  mx = max3f(mx, a.x, a.y);
+  mx2 = max3f(mx2, a.z, a.w);
+}
+
 // four stored codes -> the fake-quantised values (q + zp) / scale (Markstein division, bit-identical to
 // cdn::fake_quant_r of the pre-quantisation value that produced the code)
 __device__ __forceinline__ float4 unpack_code8(unsigned u, float scale, float zp, float r) {
@@ -571,8 +591,7 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
           if (acc.x == 1234.5f)
 #endif
           *reinterpret_cast<float4 *>(dp) = acc;
-          mn = fminf(mn, fminf(fminf(acc.x, acc.y), fminf(acc.z, acc.w)));
-          mx = fmaxf(mx, fmaxf(fmaxf(acc.x, acc.y), fmaxf(acc.z, acc.w)));
+          track4(acc, mn, mn, mx, mx);      // one pair: the kernel sits at its 128-VGPR cap
         } else {
           const float av[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
@@ -931,7 +950,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
 #define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
 
-  float mn = INFINITY, mx = -INFINITY;
+  float mn = INFINITY, mx = -INFINITY, mn2 = INFINITY, mx2 = -INFINITY;
   BadMask bad = 0;
   Code8 c8 = {1.f, 0.f};
   if (OUT8) c8 = make_code8(qu.state, bad);
@@ -1046,8 +1065,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                     pack_code8(a, c8, bad);
             } else if (vec_store && cbase + 3 < C) {
               *reinterpret_cast<float4 *>(dp) = a;
-              mn = fminf(mn, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
-              mx = fmaxf(mx, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+              track4(a, mn, mn2, mx, mx2);
             } else {
               const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -1067,6 +1085,8 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
     return;
   }
+  mn = fminf(mn, mn2);
+  mx = fmaxf(mx, mx2);
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
