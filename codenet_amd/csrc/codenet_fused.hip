@@ -839,9 +839,14 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
             int C, int H, int W) {
   static_assert(!X8 || XQ, "codes come with their quantiser state");
-  extern __shared__ float4 img[];
+  // LDS: one ZERO cell, then the image as in dw2_kernel.  Cell (r, -1) is the cell in front of row r: the zero
+  // column of row r - 1, or the leading zero cell for r = 0 -- so column -1 needs no parking and the two cells
+  // {cb, cb + 1} of a column class are ALWAYS adjacent: one offset per class, the second read is the first plus
+  // an immediate.
+  extern __shared__ float4 img_lds[];
   CDN_STAMP(0);
   constexpr int LPP = CCH / 4;     // lanes per block (one float4 of channels each)
+  float4 *img = img_lds + LPP;
   constexpr int PPW = 64 / LPP;    // blocks per wave step
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
   const int Hl = H >> 1, Wl = W >> 1;
@@ -871,6 +876,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
     img[cell * LPP + (q % LPP)] = z4;
   }
+  if (tid < LPP) img_lds[tid] = z4;                          // the leading zero cell
   if (X8) {
     constexpr int kStageU = 8;
     const signed char *xg = reinterpret_cast<const signed char *>(x) + (long)n * HWl * C + c0;
@@ -946,7 +952,10 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int rstride = Wc * LPP * 16;
   // stored-cell index -> byte offset (out-of-image cells select the zero row / column)
   auto row_off = [&](int cy) { return (((unsigned)cy < (unsigned)Hl) ? cy : Hl) * rstride; };
-  auto col_off = [&](int cx) { return (((unsigned)cx < (unsigned)Wl) ? cx : Wl) * (LPP * 16); };
+  // first cell of a column class: cb in [-1, Wl - 1] as it is (cells cb, cb + 1 lie in [-1, Wl]); outside that
+  // range every weight of the class is zero (fold_axis), any pair of cells will do
+  constexpr int kCell = LPP * 16;
+  auto col_off = [&](int cb) { return min(max(cb, -1), Wl - 1) * kCell; };
   const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
 #define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
 
@@ -960,7 +969,8 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   const int b_begin = wave * bpw, b_end = min(HWl, b_begin + bpw);
   for (int bb = b_begin; bb < b_end; bb += 64) {
     // ---- geometry phase: lane i owns block bb + i -----------------------------------------------
-    int g_o[10];      // byte offsets: rows {ya: r0,r1; yb: r0,r1; mid}, cols {xa: c0,c1; xb: c0,c1; mid}
+    int g_o[9];       // byte offsets: rows {ya: r0,r1; yb: r0,r1; mid}, cols {xa, xb: first cell; mid}; [8]: the
+                      // block's first output pixel 2Y * W + 2X
     float g_w[16];    // slot weights [class ya,yb,xa,xb][pixel a/b][slot 0/1]
     {
       const int blk = min(bb + (use_dpp<LPP>() ? owner_item<LPP>(lane) : lane), HWl - 1);
@@ -979,22 +989,23 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       g_o[0] = row_off(rya); g_o[1] = row_off(rya + 1);
       g_o[2] = row_off(ryb); g_o[3] = row_off(ryb + 1);
       g_o[4] = row_off(Y);
-      g_o[5] = col_off(cxa); g_o[6] = col_off(cxa + 1);
-      g_o[7] = col_off(cxb); g_o[8] = col_off(cxb + 1);
-      g_o[9] = col_off(X);
+      g_o[5] = col_off(cxa);
+      g_o[6] = col_off(cxb);
+      g_o[7] = X * kCell;
+      g_o[8] = h0 * W + w0;
     }
     // ---- gather phase: PPW blocks per step -----------------------------------------------------
 #pragma unroll 1
     for (int j = 0; j < 64 / PPW; ++j) {
       const int src = j * PPW + sub;
       const int blk = bb + src;
-      int o[10];
+      int o[9];
       float w[16];
       if (use_dpp<LPP>()) {
         fetch_record<LPP == 8>(j, g_o, g_w, o, w);
       } else {
 #pragma unroll
-        for (int q = 0; q < 10; ++q) o[q] = __shfl(g_o[q], src, 64);
+        for (int q = 0; q < 9; ++q) o[q] = __shfl(g_o[q], src, 64);
 #pragma unroll
         for (int q = 0; q < 16; ++q) w[q] = __shfl(g_w[q], src, 64);
       }
@@ -1007,9 +1018,10 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       // (+ 64 scalar weight products) when every tap of every pixel is mixed on its own.
       float4 acc[2][2];     // [py][px]
       auto row_taps = [&](int ro, int K0, float4 (&U)[2]) {
-        const float4 va0 = CDN_RD(ro + o[5]), va1 = CDN_RD(ro + o[6]);
-        const float4 vc = CDN_RD(ro + o[9]);
-        const float4 vb0 = CDN_RD(ro + o[7]), vb1 = CDN_RD(ro + o[8]);
+        const int oa = ro + o[5], ob = ro + o[6];
+        const float4 va0 = CDN_RD(oa), va1 = CDN_RD(oa + kCell);
+        const float4 vc = CDN_RD(ro + o[7]);
+        const float4 vb0 = CDN_RD(ob), vb1 = CDN_RD(ob + kCell);
         const float4 t = make_float4(wk[K0 + 1][0] * vc.x, wk[K0 + 1][1] * vc.y, wk[K0 + 1][2] * vc.z,
                                      wk[K0 + 1][3] * vc.w);
 #pragma unroll
@@ -1050,19 +1062,18 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
           }
       }
       if (blk < b_end) {
-        const int Y = blk / Wl, X = blk - Y * Wl;
         const int cbase = c0 + cq * 4;
+        const long e0 = ((long)n * HW + o[8]) * C + cbase;    // element index of the block's first output pixel
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
           for (int px = 0; px < 2; ++px) {
             const float4 a = acc[py][px];
-            float *dp = d + ((long)n * HW + (long)(2 * Y + py) * W + 2 * X + px) * C + cbase;
+            const long e = e0 + (long)(py * W + px) * C;
+            float *dp = d + e;
             if (OUT8) {
               if (cbase + 3 < C)
-                *reinterpret_cast<unsigned *>(reinterpret_cast<signed char *>(d) +
-                                              ((long)n * HW + (long)(2 * Y + py) * W + 2 * X + px) * C + cbase) =
-                    pack_code8(a, c8, bad);
+                *reinterpret_cast<unsigned *>(reinterpret_cast<signed char *>(d) + e) = pack_code8(a, c8, bad);
             } else if (vec_store && cbase + 3 < C) {
               *reinterpret_cast<float4 *>(dp) = a;
               track4(a, mn, mn2, mx, mx2);
@@ -2065,13 +2076,19 @@ unpack_kernel(const float *__restrict__ r, const unsigned *__restrict__ rq, floa
 
 using cdn::kMaxPartials;
 
+// dynamic LDS of dw2_kernel / dw2u_kernel: the leading zero cell (dw2u), (Hl+1) x (Wl+1) cells of CCH floats, the
+// chunk's depthwise weights, the scale plane, reduction scratch
+static size_t dw2_lds_bytes(int Hl, int Wl, int CCH) {
+  return ((size_t)CCH + (size_t)(Hl + 1) * (Wl + 1) * CCH + (size_t)CCH * 9 + (size_t)Hl * Wl +
+          2 * kDw2MaxThreads / 64 + 4) * sizeof(float);
+}
+
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
                const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
                int C, int H, int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
-  const size_t lds = ((size_t)(Hl + 1) * (Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl +
-                      2 * kDw2MaxThreads / 64 + 4) * sizeof(float);
+  const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
@@ -2162,8 +2179,7 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
                        const float *wd, float *d8, unsigned *dstate, float2 *oflow, int N, int C, int H, int W,
                        int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
-  const size_t lds = ((size_t)(Hl + 1) * (Wl + 1) * CCH + CCH * 9 + (size_t)Hl * Wl + 2 * kDw2MaxThreads / 64 + 4) *
-                     sizeof(float);
+  const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
   const int threads = two_per_cu ? 512 : 1024;
@@ -2322,7 +2338,7 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
 // LDS budget of the gather kernel decides the channel chunk (64 or 32 channels x the whole stored plane);
 // 0: the plane does not fit
 int cdn::stage_channel_chunk(int Hl, int Wl) {
-  const size_t cells = (size_t)(Hl + 1) * (Wl + 1);   // + the zero row and zero column
+  const size_t cells = (size_t)(Hl + 1) * (Wl + 1) + 1;   // + the zero row and zero column, + the leading zero cell
   const long lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (long)Hl * Wl * 4;   // scale plane, weights, scratch
   if (lds_max <= 0) return 0;
   if (cells * 64 * 4 <= (size_t)lds_max) return 64;
