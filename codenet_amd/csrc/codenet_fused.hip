@@ -426,11 +426,15 @@ constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (5
 // The gather + depthwise of one staged plane:
 // img = [(Hl+1)*(Wl+1)][CCH] cells with the zero row / column, wl = [CCH][9] weights, sl = scale plane.
 // OUT8: d is a byte tensor of codes (see Code8) instead of fp32; mn / mx are not tracked.
-template <int CCH, bool OUT8 = false>
+// The input is at the resolution of the output (up-sampled inputs go to dw2u_kernel): img has a zero cell in front
+// of it, so the corner columns i0, i0 + 1 of a tap are adjacent cells for every i0 in [-1, W - 1].
+template <int CCH, bool OUT8>
 __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, const float *sl,
                                            float *__restrict__ d, int n, int c0, int C, int H, int W,
-                                           int up, int kWaves, float &mn, float &mx,
+                                           int kWaves, float &mn, float &mx,
                                            const Code8 *c8 = nullptr, BadMask *bad = nullptr) {
+  constexpr bool ADJ = true;
+  constexpr int up = 0;
   constexpr int LPP = CCH / 4;     // lanes per pixel
   constexpr int PPW = 64 / LPP;    // pixels per wave step
   const int tid = threadIdx.x;
@@ -449,7 +453,11 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
   // byte offsets: row part + column part; out-of-image coordinates select the zero row / column
   const int rstride = Wc * LPP * 16;
   auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? (yy >> up) : Hl) * rstride; };
-  auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? (xx >> up) : Wl) * (LPP * 16); };
+  constexpr int kCell = LPP * 16;
+  auto col_off = [&](int xx) {
+    if (ADJ) return xx * kCell;                 // xx in [-1, W - 1]: as it is
+    return (((unsigned)xx < (unsigned)W) ? (xx >> up) : Wl) * kCell;
+  };
   const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
 
   const bool vec_store = ((C & 3) == 0);
@@ -475,8 +483,8 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
       g_r[0] = row_off(ya.i0); g_r[1] = row_off(ya.i0 + 1);
       g_r[2] = row_off(yb.i0); g_r[3] = row_off(yb.i0 + 1);
       g_r[4] = row_off(h);
-      g_c[0] = col_off(xa.i0); g_c[1] = col_off(xa.i0 + 1);
-      g_c[2] = col_off(xb.i0); g_c[3] = col_off(xb.i0 + 1);
+      g_c[0] = col_off(xa.i0); g_c[1] = ADJ ? 0 : col_off(xa.i0 + 1);
+      g_c[2] = col_off(xb.i0); g_c[3] = ADJ ? 0 : col_off(xb.i0 + 1);
       g_c[4] = col_off(w);
       g_w[0] = ya.w0; g_w[1] = ya.w1; g_w[2] = yb.w0; g_w[3] = yb.w1;
       g_w[4] = xa.w0; g_w[5] = xa.w1; g_w[6] = xb.w0; g_w[7] = xb.w1;
@@ -495,7 +503,13 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
       for (int q = 0; q < 8; ++q) wt[q] = g_w[q];
       (void)src;
 #else
-      if (use_dpp<LPP>()) {
+      if (use_dpp<LPP>() && ADJ) {
+        int gi[8] = {g_r[0], g_r[1], g_r[2], g_r[3], g_r[4], g_c[0], g_c[2], g_c[4]}, oi[8];
+        fetch_record<LPP == 8>(j, gi, g_w, oi, wt);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r[q] = oi[q];
+        c[0] = oi[5]; c[2] = oi[6]; c[4] = oi[7];
+      } else if (use_dpp<LPP>()) {
         int gi[10], oi[10];
 #pragma unroll
         for (int q = 0; q < 5; ++q) { gi[q] = g_r[q]; gi[5 + q] = g_c[q]; }
@@ -506,11 +520,12 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
           r[q] = __shfl(g_r[q], src, 64);
-          c[q] = __shfl(g_c[q], src, 64);
+          if (!ADJ || !(q & 1)) c[q] = __shfl(g_c[q], src, 64);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) wt[q] = __shfl(g_w[q], src, 64);
       }
+      if (ADJ) { c[1] = c[0] + kCell; c[3] = c[2] + kCell; }   // (folded into the reads' immediate offsets)
 #endif
       if (pb + j * PPW >= p_end) break;       // wave-uniform: whole step beyond this wave's range
       float4 acc = z4;
@@ -620,9 +635,13 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   // corner coordinate maps there (per-corner zeroing of the reference, _kernel.cu:97-108) -- a
   // cell address is just row offset + column offset, no bounds test and no clamp per corner.
   // Then the chunk's depthwise weights [CCH][9], the scale plane [Hl*Wl], reduction scratch.
-  extern __shared__ float4 img[];
+  // In front of the image: ONE zero cell, so that cell (r, -1) -- the cell in front of row r -- is always zero
+  // (the zero column of row r - 1, or that leading cell): with up == 0 the two corner columns i0, i0 + 1 of a tap
+  // are adjacent cells for every i0 in [-1, W - 1] and the gather fetches one column offset per tap class.
+  extern __shared__ float4 img_lds[];
   CDN_STAMP(0);
   constexpr int LPP = CCH / 4;     // lanes per pixel
+  float4 *img = img_lds + LPP;
   const int kDw2Threads = blockDim.x, kWaves = kDw2Threads / 64;
   const int Hl = H >> up, Wl = W >> up;
   const int HWl = Hl * Wl;
@@ -651,6 +670,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     const int cell = i < Wc ? Hl * Wc + i : (i - Wc) * Wc + Wl;
     img[cell * LPP + (q % LPP)] = z4;
   }
+  if (tid < LPP) img_lds[tid] = z4;                            // the leading zero cell
   // ---- stage the image -------------------------------------------------------------------
   // All of a thread's global loads of a batch are issued before the first one is used (kStageU in
   // flight per thread); a plain loop leaves ONE dependent load per thread in flight and the
@@ -772,11 +792,11 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   if (OUT8) {
     BadMask bad = 0;
     const Code8 c8 = make_code8(qu.state, bad);
-    dw2_gather<CCH, true>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx, &c8, &bad);
+    dw2_gather<CCH, true>(img, wl, sl, d, n, c0, C, H, W, kWaves, mn, mx, &c8, &bad);
     if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
     return;
   }
-  dw2_gather<CCH>(img, wl, sl, d, n, c0, C, H, W, up, kWaves, mn, mx);
+  dw2_gather<CCH, false>(img, wl, sl, d, n, c0, C, H, W, kWaves, mn, mx);
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
@@ -2350,6 +2370,7 @@ extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int6
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (x_up != 0 && x_up != 1)) return 0;
   if (x_up && ((H & 1) || (W & 1))) return 0;
   if (x_nhwc && (C & 3)) return 0;
+  if (x_up && !x_nhwc) return 0;
   if (N > 65535 || N * C * H * W >= (1ll << 31)) return 0;
   if ((H >> x_up) > 4096 || (W >> x_up) > 4096) return 0;
   const int cch = cdn::stage_channel_chunk((int)(H >> x_up), (int)(W >> x_up));
@@ -2378,6 +2399,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
               CDN_ERR_ARG, "each QuantAct needs x_min, x_max and state together");
   CDN_REQUIRE(!x_nhwc || (C & 3) == 0, CDN_ERR_UNSUPPORTED,
               "channels-last input needs C %% 4 == 0 (got %lld)", (long long)C);
+  CDN_REQUIRE(x_up == 0 || x_nhwc, CDN_ERR_UNSUPPORTED, "an up-sampled input must be channels-last");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31) && N * Co * H * W < (1ll << 31),
               CDN_ERR_UNSUPPORTED, "shape too large");
   CDN_REQUIRE(workspace_bytes >= cdn_codenet_stage_workspace_bytes(N, C, H, W, x_up),

@@ -208,7 +208,8 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
  * fake-quantisation (same fp32 expression as cdn_quantact_forward) is applied by the consumer while
  * loading, so results equal the module-by-module composition.
  *
- *   x         stage input at STORED resolution (H>>x_up) x (W>>x_up); x_nhwc ? [N][pix][C] : [N][C][pix]
+ *   x         stage input at STORED resolution (H>>x_up) x (W>>x_up); x_nhwc ? [N][pix][C] : [N][C][pix];
+ *             x_up = 1 needs a channels-last input (CDN_ERR_UNSUPPORTED otherwise)
  *   x_qstate  NULL, or the QuantAct state of the producer: x then holds PRE-quantisation values
  *             (channels-last only) and is fake-quantised on load
  *   H, W      stage (output) resolution;  C -> Co channels
