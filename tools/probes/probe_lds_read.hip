@@ -5,12 +5,15 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int MODE, int NREAD>
-__global__ void __launch_bounds__(512) k(float *out, const int *cells, int iters) {
+__global__ void __launch_bounds__(1024) k(float *out, const int *cells, int iters) {
   extern __shared__ float4 img[];
   const int ncell = 289;
   for (int i = threadIdx.x; i < ncell * 16; i += blockDim.x) img[i] = make_float4(i, 1, 2, 3);
   __syncthreads();
-  const int lane = threadIdx.x & 63, cq = lane & 15, sub = lane >> 4;
+  // MODE 2: scattered, with the pixel of a lane chosen so that each HARDWARE lane group of ds_read_b128
+  // ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32) reads ONE cell: group = parity of the lane's quad index
+  const int lane = threadIdx.x & 63, cq = lane & 15;
+  const int sub = MODE == 2 ? 2 * (lane >> 5) + (__popc((lane >> 2) & 7) & 1) : lane >> 4;
   float4 acc = make_float4(0, 0, 0, 0);
   int cell = (threadIdx.x * 7 + sub * 13) % (ncell - 32);
   const char *base = reinterpret_cast<const char *>(img) + cq * 16;
@@ -20,7 +23,7 @@ __global__ void __launch_bounds__(512) k(float *out, const int *cells, int iters
     for (int r = 0; r < NREAD; ++r) {
       int c = cell + (r * 5) % 31;
       // scattered: every 16-lane pixel group reads a different pseudo-random cell each time (2 VALU ops)
-      if (MODE == 1) c = (cell * 37 + r * 53 + it * 11 + sub * 101) & 255;
+      if (MODE >= 1) c = (cell * 37 + r * 53 + it * 11 + sub * 101) & 255;
       o[r] = c * 256;
     }
 #pragma unroll
@@ -61,6 +64,9 @@ int main() {
   };
   rep("25 reads/iter, 2 WG x 512 thr, static cells", run<0, 25>(d, cells, 2, 512, iters), 2, 512, 25);
   rep("25 reads/iter, 2 WG x 512 thr, scattered cells", run<1, 25>(d, cells, 2, 512, iters), 2, 512, 25);
+  rep("25 reads/iter, 2 WG x 512 thr, scattered, hw-group lanes", run<2, 25>(d, cells, 2, 512, iters), 2, 512, 25);
+  rep("25 reads/iter, 2 WG x 1024 thr, scattered cells", run<1, 25>(d, cells, 2, 1024, iters), 2, 1024, 25);
+  rep("25 reads/iter, 2 WG x 1024 thr, scattered, hw-group lanes", run<2, 25>(d, cells, 2, 1024, iters), 2, 1024, 25);
   rep("25 reads/iter, 1 WG x 512 thr, static cells", run<0, 25>(d, cells, 1, 512, iters), 1, 512, 25);
   rep("25 reads/iter, 1 WG x 256 thr, static cells", run<0, 25>(d, cells, 1, 256, iters), 1, 256, 25);
   rep("8 reads/iter, 2 WG x 512 thr, static cells", run<0, 8>(d, cells, 2, 512, iters), 2, 512, 8);
