@@ -416,7 +416,8 @@ __device__ __forceinline__ int owner_item(int lane) {
 #define CDN_DPP16 1      // DPP fetch when an item spans a whole 16-lane row (CCH = 64)
 #endif
 #ifndef CDN_DPP8
-#define CDN_DPP8 0       // DPP fetch for 8-lane items (CCH = 32): two movs per value
+#define CDN_DPP8 1       // DPP fetch for 8-lane items (CCH = 32): two movs per value (1.8 us per step ahead of
+                         // ds_bpermute once the tap math was factored; it made no difference before)
 #endif
 template <int LPP>
 constexpr bool use_dpp() { return (LPP == 16 && CDN_DPP16) || (LPP == 8 && CDN_DPP8); }
@@ -671,6 +672,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     img[cell * LPP + (q % LPP)] = z4;
   }
   if (tid < LPP) img_lds[tid] = z4;                            // the leading zero cell
+  // the chunk's depthwise weights and the scale plane are requested BEFORE the image (one element per thread;
+  // stored to LDS after it), so their round trips overlap the image's instead of following it
+  const float w_pre = (tid < CCH * 9 && c0 + tid / 9 < C) ? wd[(long)c0 * 9 + tid] : 0.0f;
+  const float s_pre = tid < HWl ? s_raw[(long)n * HWl + tid] : 0.0f;
   // ---- stage the image -------------------------------------------------------------------
   // All of a thread's global loads of a batch are issued before the first one is used (kStageU in
   // flight per thread); a plain loop leaves ONE dependent load per thread in flight and the
@@ -777,10 +782,12 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       }
     }
   }
-  // ---- chunk weights (coalesced) and the (fake-quantised) scale plane ------------------------
-  for (int q = tid; q < CCH * 9; q += kDw2Threads)
+  // ---- chunk weights (coalesced) and the (fake-quantised) scale plane: first element per thread prefetched ----
+  if (tid < CCH * 9) wl[tid] = w_pre;
+  for (int q = tid + kDw2Threads; q < CCH * 9; q += kDw2Threads)
     wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
-  for (int q = tid; q < HWl; q += kDw2Threads) {
+  if (tid < HWl) sl[tid] = SQ ? fake_quant(s_pre, ss, sz) : s_pre;
+  for (int q = tid + kDw2Threads; q < HWl; q += kDw2Threads) {
     float sv = s_raw[(long)n * HWl + q];
     if (SQ) sv = fake_quant(sv, ss, sz);
     sl[q] = sv;
@@ -897,6 +904,9 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     img[cell * LPP + (q % LPP)] = z4;
   }
   if (tid < LPP) img_lds[tid] = z4;                          // the leading zero cell
+  // weights and scale plane requested before the image (see dw2_kernel)
+  const float w_pre = (tid < CCH * 9 && c0 + tid / 9 < C) ? wd[(long)c0 * 9 + tid] : 0.0f;
+  const float s_pre = tid < HWl ? s_raw[(long)n * HWl + tid] : 0.0f;
   if (X8) {
     constexpr int kStageU = 8;
     const signed char *xg = reinterpret_cast<const signed char *>(x) + (long)n * HWl * C + c0;
@@ -951,9 +961,11 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
       }
     }
   }
-  for (int q = tid; q < CCH * 9; q += nthreads)
+  if (tid < CCH * 9) wl[tid] = w_pre;
+  for (int q = tid + nthreads; q < CCH * 9; q += nthreads)
     wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
-  for (int q = tid; q < HWl; q += nthreads) {
+  if (tid < HWl) sl[tid] = SQ ? fake_quant(s_pre, ss, sz) : s_pre;
+  for (int q = tid + nthreads; q < HWl; q += nthreads) {
     float sv = s_raw[(long)n * HWl + q];
     if (SQ) sv = fake_quant(sv, ss, sz);
     sl[q] = sv;
@@ -977,7 +989,11 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   constexpr int kCell = LPP * 16;
   auto col_off = [&](int cb) { return min(max(cb, -1), Wl - 1) * kCell; };
   const char *imgb = reinterpret_cast<const char *>(img) + cq * 16;
+#if defined(CDN_DIAG) && CDN_DIAG == 2   // diagnostic build: no LDS cell reads (wrong results)
+#define CDN_RD(O) make_float4(__int_as_float(O), 1.f, 2.f, 3.f)
+#else
 #define CDN_RD(O) (*reinterpret_cast<const float4 *>(imgb + (O)))
+#endif
 
   float mn = INFINITY, mx = -INFINITY, mn2 = INFINITY, mx2 = -INFINITY;
   BadMask bad = 0;
