@@ -331,6 +331,7 @@ def test_argument_validation_of_round2_entry_points_without_gpu():
     assert lib.cdn_codenet_stage_supported(1, 128, 160, 160, 1, 1) == 0          # stored 80 x 80: not LDS resident
     assert lib.cdn_codenet_stage_supported(1, 2153, 16, 16, 1, 0) == 0           # channels-last needs C % 4 == 0
     assert lib.cdn_codenet_stage_supported(1, 128, 15, 16, 1, 1) == 0            # x_up needs even H
+    assert lib.cdn_codenet_stage_supported(1, 128, 16, 16, 0, 1) == 0            # an up-sampled input must be channels-last
     assert lib.cdn_codenet_dw_backward_supported(64, 64) == 1 and lib.cdn_codenet_dw_backward_supported(136, 136) == 1
     assert lib.cdn_codenet_dw_backward_supported(400, 400) == 0
     # frozen stage: byte codes need C % 4 == 0; x_state goes with channels-last inputs only; workspace size
