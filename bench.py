@@ -505,7 +505,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.fp32 else "f32 (W4A8 fake-quant: 4-bit weight / 8-bit activation codes)",
+            "dtype": "f32" if args.fp32 else "f32+i8 (W4A8: fp32 scale / gather, int8-MFMA pointwise on 8-bit activation and 4-bit weight codes, i32 sums)",
             "data": "synthetic",
             "config": {
                 "workload": "CoDeNet%s config-%s %dx%d %s, batch %d per GPU, 3 deform stages "
