@@ -1472,6 +1472,28 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (i32x16){0};
+  // Epilogue constants of this lane's TN output columns, requested NOW (branch-free, clamped column): read after
+  // the k loop they were 2 dependent round trips per column with the workgroup idle (the ISA waited for bias /
+  // scale / colsum, then for the channel map), ~3 us at the end of every launch.
+  float e_bias[TN], e_ws[TN];
+  int e_sum[TN], e_oc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    const int cc = min(co, Co - 1);
+    e_ws[j] = wscale[cc];
+    e_sum[j] = wsum[cc];
+    e_bias[j] = 0.f;
+    e_oc[j] = co;
+  }
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) e_bias[j] = bias[min(n0 + wn + j * 32 + (lane & 31), Co - 1)];
+  }
+  if (omap) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) e_oc[j] = omap[min(n0 + wn + j * 32 + (lane & 31), Co - 1)];
+  }
   const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
   const bool vec4 = !FAST && (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16-byte half bh
@@ -1574,14 +1596,8 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
-    float bsv = 0.f, rinv = 0.f;
-    int t128 = 0, oc = co;
-    if (co < Co) {
-      if (bias) bsv = bias[co];
-      rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
-      t128 = 128 * wsum[co];
-      if (omap) oc = omap[co];
-    }
+    const float bsv = e_bias[j], rinv = __fdiv_rn(1.0f, __fmul_rn(qs, e_ws[j]));
+    const int t128 = 128 * e_sum[j], oc = e_oc[j];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1851,11 +1867,14 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     const bool live = prb < nrb;
     const long row = min(prb * 32 + (lane & 31), M - 1);
     const int k = 32 * pw_ + 16 * (lane >> 5);
-    const float *src = A + row * lda + k;
+    // unconditional loads from clamped addresses (C % 4 == 0, C >= 4), zeroed afterwards: a load under a
+    // per-lane condition is a branch + a wait of its own in the ISA
+    const float *rowp = A + row * lda;
+    float4 t4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      d[i] = (live && k + 4 * i < C) ? *reinterpret_cast<const float4 *>(src + 4 * i)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) t4[i] = *reinterpret_cast<const float4 *>(rowp + min(k + 4 * i, C - 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = (live && k + 4 * i < C) ? t4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (++pw_ == nwin) {
       pw_ = 0;
       prb += rb_stride;
@@ -1867,14 +1886,16 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // ---- quantiser table and B tile -> LDS (loads batched: the prologue is latency, not work) -----------
   if (has_q) {
     float4 te[2];
+    int gen[2] = {0, 0};
+    if (agen) {                                      // both generation bytes first, then both states: 2 round trips
+#pragma unroll
+      for (int u = 0; u < 2; ++u) gen[u] = agen[min(tid + 256 * u, C - 1)];
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int c = tid + 256 * u;
-      te[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C) {
-        const float *sp = reinterpret_cast<const float *>(aq) + (agen ? cdn::kQStateWords * agen[c] : 0);
-        te[u] = make_float4(sp[2], sp[3], 0.f, 0.f);
-      }
+      const float2 sz2 = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
+                                                           cdn::kQStateWords * gen[u] + 2);
+      te[u] = make_float4(sz2.x, sz2.y, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1933,16 +1954,31 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // epilogue constants of this lane's TN output columns
   float bsv[TN], rinv[TN];
   int oc[TN];
+  {
+    float ws_[TN];                                            // branch-free, clamped column: ONE round trip
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + j * 32 + (lane & 31);
-    bsv[j] = 0.f;
-    rinv[j] = 0.f;
-    oc[j] = -1;                                               // dead column
-    if (co < Co) {
-      if (bias) bsv[j] = bias[co];
-      rinv[j] = __fdiv_rn(1.0f, wscale[co]);
-      oc[j] = omap ? omap[co] : co;
+    for (int j = 0; j < TN; ++j) {
+      const int cc = min(n0 + j * 32 + (lane & 31), Co - 1);
+      ws_[j] = wscale[cc];
+      bsv[j] = 0.f;
+      oc[j] = cc;
+    }
+    if (bias) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bsv[j] = bias[min(n0 + j * 32 + (lane & 31), Co - 1)];
+    }
+    if (omap) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) oc[j] = omap[min(n0 + j * 32 + (lane & 31), Co - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool live = n0 + j * 32 + (lane & 31) < Co;
+      rinv[j] = live ? __fdiv_rn(1.0f, ws_[j]) : 0.f;
+      if (!live) {
+        bsv[j] = 0.f;
+        oc[j] = -1;                                           // dead column
+      }
     }
   }
   __syncthreads();
