@@ -1581,13 +1581,18 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       b0[j] = *reinterpret_cast<const i32x4 *>(&B0[buf][(wn + j * 32) * kI8LD + fo]);
       b1[j] = *reinterpret_cast<const i32x4 *>(&B1[buf][(wn + j * 32) * kI8LD + fo]);
     }
+    // (low nibbles for every accumulator, then the high parts: two MFMAs into the same accumulator back to back
+    // wait for each other; the integer sum does not depend on the order)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+      for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1[i], b1[j], acc[i][j], 0, 0, 0);
-      }
     if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * 32);
     __syncthreads();
   }
@@ -2045,13 +2050,30 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             }
             const bf16x8 fh = __builtin_bit_cast(bf16x8, ph), fm = __builtin_bit_cast(bf16x8, pm),
                          fl = __builtin_bit_cast(bf16x8, pl);
+            // lo, mid, hi terms in this order into every accumulator (the fp32 sums are those of the j-major
+            // form), but interleaved over the TN accumulators: three MFMAs into one accumulator back to back stall
+            // (TN = 2 sits at its 168-VGPR cap for three waves per SIMD: one B fragment at a time there)
+            if constexpr (TN >= 4) {
+              bf16x8 fb[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const bf16x8 fb = __builtin_bit_cast(
-                  bf16x8, *reinterpret_cast<const i32x4 *>(bbase + (size_t)j * 32 * ldb + 64 * w + 16 * ks));
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fb, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, fb, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fb, acc[j], 0, 0, 0);
+              for (int j = 0; j < TN; ++j)
+                fb[j] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const i32x4 *>(bbase + (size_t)j * 32 * ldb + 64 * w + 16 * ks));
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fb[j], acc[j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, fb[j], acc[j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fb[j], acc[j], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const bf16x8 fb = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const i32x4 *>(bbase + (size_t)j * 32 * ldb + 64 * w + 16 * ks));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fb, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, fb, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fb, acc[j], 0, 0, 0);
+              }
             }
           }
         }
