@@ -77,17 +77,11 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   return __uint_as_float(u);
 }
 // q = round(scale*x - zp) (half-even), no FMA contraction: quant_utils.py:33-41
-// (`#pragma clang fp contract(off)`: the _rn intrinsics alone do NOT keep the compiler from fusing a product into a
-// following add -- seen in the in-kernel range update, whose EMA came out 1 ulp off the reference's two-rounding
-// arithmetic in ~5 % of the updates, tools/experiments/deferred_race.py)
 __device__ __forceinline__ float quant_code(float x, float scale, float zp) {
-#pragma clang fp contract(off)
-  const float p = scale * x;
-  return rintf(p - zp);
+  return rintf(__fsub_rn(__fmul_rn(scale, x), zp));
 }
 // (q + zp) / scale, true division: quant_utils.py:44-52
 __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
-#pragma clang fp contract(off)
   return __fdiv_rn(__fadd_rn(quant_code(x, scale, zp), zp), scale);
 }
 // The same value with r = RN(1 / scale) precomputed: Markstein's division q0 = n*r, q = fma(fma(-q0, s, n), r, q0)
@@ -95,7 +89,6 @@ __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
 // of the IEEE expansion -- for loops that fake-quantise every loaded element (checked against true division
 // for 3.6e6 (n, s) pairs on the host, tools note in DESIGN.md section 7.3).
 __device__ __forceinline__ float fake_quant_r(float x, float scale, float zp, float r) {
-#pragma clang fp contract(off)
   const float n = __fadd_rn(quant_code(x, scale, zp), zp);
   const float q0 = __fmul_rn(n, r);
   return fmaf(fmaf(-q0, scale, n), r, q0);
@@ -109,54 +102,11 @@ struct QUpdate {
   unsigned *counters;    // fused schedule only: kArriveWords zero-initialised arrival counters
   float m_minus_1, one_minus_m;
   int bits, running;
-  int deferred;          // 1: deferred range commit (producer: push only; consumer: derive from `counters`)
 };
 // Arrival counters: 64 group counters + 1 top counter, one per 64-byte line (a single contended
 // word sustains only ~88 atomics/us; 2048 workgroups on one word cost ~25 us).
 constexpr int kArriveGroups = 64;
 constexpr int kArriveWords = (kArriveGroups + 1) * 16;
-
-// The arithmetic alone: new running range (lo, hi in / out), scale, zero-point and the wide flag.
-struct QParams {
-  float scale, zp;
-  unsigned wide;
-};
-__device__ __forceinline__ QParams quantact_compute(float &lo, float &hi, float bmin, float bmax, bool have_stats,
-                                                    float m_minus_1, float one_minus_m, int bits, int running) {
-#pragma clang fp contract(off)
-  if (running) {
-    // (plain operators under contract(off), every product in a variable of its own: the ocml _rn intrinsics carry
-    // their own fast-math flags into the caller and were fused with the following add in some inlining contexts)
-    if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
-      lo = lo + bmin;
-      hi = hi + bmax;
-    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219)
-      const float pl = m_minus_1 * lo, ql = one_minus_m * bmin, ph = m_minus_1 * hi, qh = one_minus_m * bmax;
-      const float sl = pl + ql, sh = ph + qh;
-      lo = lo + sl;
-      hi = hi + sh;
-    }
-  }
-  QParams q;
-  const float nlev = (float)((1 << bits) - 1);
-  const float range = fmaxf(hi - lo, 1e-10f);          // torch.clamp(min=1e-10)
-  // `n / tensor` in torch is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
-  const float rcp = __fdiv_rn(1.0f, range);
-  q.scale = rcp * nlev;
-  const float sl0 = q.scale * lo;
-  q.zp = rintf(sl0) + (float)(1 << (bits - 1));
-  // wide: 1 when some level L - 128 = round(scale*x - zp) + zp - 128 of this batch cannot be
-  // carried by the int8 kernels' nibble split (|.| > 2039) or the batch extremes are unknown --
-  // consumers then take their f32 path.  Codes are monotone in x, so the extremes decide.
-  q.wide = 1u;
-  if (have_stats && bits == 8) {
-    const float a0 = quant_code(bmin, q.scale, q.zp) + (q.zp - 128.0f);
-    const float a1 = quant_code(bmax, q.scale, q.zp) + (q.zp - 128.0f);
-    q.wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1) ||
-              !(fabsf(q.zp) < 4.0e6f)) ? 1u : 0u;   // (the int8 kernels do integer arithmetic on zp)
-  }
-  return q;
-}
 
 __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float bmin, float bmax,
                                                        bool have_stats, bool preloaded = false,
@@ -167,55 +117,35 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
     sf[4] = bmin;
     sf[5] = bmax;
   }
-  const QParams q = quantact_compute(lo, hi, bmin, bmax, have_stats, u.m_minus_1, u.one_minus_m, u.bits, u.running);
   if (u.running) {
+    if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
+      lo = __fadd_rn(lo, bmin);
+      hi = __fadd_rn(hi, bmax);
+    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219)
+      lo = __fadd_rn(lo, __fadd_rn(__fmul_rn(u.m_minus_1, lo), __fmul_rn(u.one_minus_m, bmin)));
+      hi = __fadd_rn(hi, __fadd_rn(__fmul_rn(u.m_minus_1, hi), __fmul_rn(u.one_minus_m, bmax)));
+    }
     u.x_min[0] = lo;
     u.x_max[0] = hi;
   }
-  sf[2] = q.scale;
-  sf[3] = q.zp;
-  u.state[6] = q.wide;       // state[6]: see quantact_compute
-}
-
-// ---- Deferred range commit (cdn_codenet_stage_fused_forward with `lines`): a producer only folds its workgroups'
-// extremes into the 64 group lines (block_minmax_push: two no-return atomics, no ticket -- the kernel boundary
-// orders them before every consumer), each CONSUMER wave derives range / scale / zero-point itself from the lines
-// and the not yet updated running range (derive_qparams: one 64-lane load beside the kernel's other prologue
-// loads, 12 shuffles, the arithmetic above), and ONE commit launch per step stores the updated ranges, the state
-// words for consumers outside the step, and zeroes the lines.  The producer's tail of three dependent L2 round
-// trips (ticket -> top ticket -> read 64 lines) disappears from all nine launches of a step.
-__device__ __forceinline__ void lines_extremes(const unsigned *lines, float &bmin, float &bmax) {
-  const int lane = threadIdx.x & 63;
-  // (agent-scope loads, as the last-arriver of the ticket protocol uses; untouched lines hold 0: neutral for max)
-  unsigned a = __hip_atomic_load(lines + 16 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned b = __hip_atomic_load(lines + 16 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    a = max(a, (unsigned)__shfl_xor((int)a, m, 64));
-    b = max(b, (unsigned)__shfl_xor((int)b, m, 64));
+  const float nlev = (float)((1 << u.bits) - 1);
+  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);          // torch.clamp(min=1e-10)
+  // `n / tensor` in torch is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
+  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);
+  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (u.bits - 1)));
+  sf[2] = scale;
+  sf[3] = zp;
+  // state[6]: 1 when some level L - 128 = round(scale*x - zp) + zp - 128 of this batch cannot be
+  // carried by the int8 kernels' nibble split (|.| > 2039) or the batch extremes are unknown --
+  // consumers then take their f32 path.  Codes are monotone in x, so the extremes decide.
+  unsigned wide = 1u;
+  if (have_stats && u.bits == 8) {
+    const float a0 = quant_code(bmin, scale, zp) + (zp - 128.0f);
+    const float a1 = quant_code(bmax, scale, zp) + (zp - 128.0f);
+    wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1) ||
+            !(fabsf(zp) < 4.0e6f)) ? 1u : 0u;   // (the int8 kernels do integer arithmetic on zp)
   }
-  bmin = ord2f(~a);
-  bmax = ord2f(b);
-}
-// Every lane of a FULL wave must call this (u.counters = the quantiser's lines).
-__device__ __forceinline__ QParams derive_qparams(const QUpdate &u) {
-  float lo = u.x_min[0], hi = u.x_max[0];
-  float bmin, bmax;
-  lines_extremes(u.counters, bmin, bmax);
-  return quantact_compute(lo, hi, bmin, bmax, true, u.m_minus_1, u.one_minus_m, u.bits, u.running);
-}
-// Input-side quantiser of a kernel: derived from the lines when the producer deferred its commit (in.deferred),
-// else read from the state words xq (null: scale 1, zero-point 0, not wide).
-template <bool MAY_DEFER = true>     // false: instantiations of the frozen schedule (never deferred; saves their registers)
-__device__ __forceinline__ QParams input_qparams(const unsigned *xq, const QUpdate &in) {
-  if (MAY_DEFER && in.deferred) return derive_qparams(in);
-  QParams q = {1.f, 0.f, 0u};
-  if (xq) {
-    q.scale = reinterpret_cast<const float *>(xq)[2];
-    q.zp = reinterpret_cast<const float *>(xq)[3];
-    q.wide = xq[6];
-  }
-  return q;
+  u.state[6] = wide;
 }
 
 // Epilogue of a producer kernel in the fused schedule: workgroup min/max -> the workgroup's GROUP LINE ->
@@ -294,37 +224,6 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
   }
   if (threadIdx.x == 64)
     __hip_atomic_store(&u.counters[16 * kArriveGroups], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Deferred protocol, producer side: extremes into the workgroup's group line, nothing else.
-__device__ __forceinline__ void block_minmax_push(float mn, float mx, int bid, const QUpdate &u, float *red) {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, m, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-  }
-  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();   // `red` may alias tiles other waves are still reading
-  if ((threadIdx.x & 63) == 0) {
-    red[2 * wave] = mn;
-    red[2 * wave + 1] = mx;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < nw; ++i) {
-      mn = fminf(mn, red[2 * i]);
-      mx = fmaxf(mx, red[2 * i + 1]);
-    }
-    unsigned *line = u.counters + 16 * (bid % kArriveGroups);
-    (void)__hip_atomic_fetch_max(line + 1, ~f2ord(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_fetch_max(line + 2, f2ord(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// Producer epilogue of either protocol
-__device__ __forceinline__ void block_minmax_out(float mn, float mx, float2 *partials, int bid, int nblocks,
-                                                 const QUpdate &u, float *red) {
-  if (u.deferred) block_minmax_push(mn, mx, bid, u, red);
-  else block_minmax_finish(mn, mx, partials, bid, nblocks, u, red);
 }
 
 // Workgroup-level min/max -> ONE {min,max} pair stored at out[0] (plain store, no atomics: a

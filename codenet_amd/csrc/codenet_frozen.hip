@@ -36,9 +36,7 @@ __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad)
   return c;
 }
 __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
-#pragma clang fp contract(off)
-  const float y_p = c.qs * v;      // (a variable of its own: never fused into the subtraction)
-  const float y = (y_p - c.qz) + 12582912.0f;
+  const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
   const int a = (int)__float_as_uint(y) - 0x4B400000;      // rint(scale*v - zp)
   const int s = min(max(a, -128), 127);
   bad |= a ^ s;
@@ -68,34 +66,6 @@ __global__ void frozen_params_kernel(FrozenList f) {
   float *sf = reinterpret_cast<float *>(f.state[i]);
   sf[2] = scale;
   sf[3] = zp;
-}
-
-// ------------------------------------------------------------------------------------------------------
-// commit_kernel: the ONE launch per step of the deferred range commit (cdn_common.h, block_minmax_push /
-// derive_qparams): wave i reduces the 64 group lines of QuantAct i, runs the reference's range tracking on the
-// running range (quant_modules.py:203-219), stores range, scale, zero-point, batch extremes and the wide flag for
-// consumers outside the step, and zeroes the lines for the next step.
-// ------------------------------------------------------------------------------------------------------
-struct CommitList {
-  float *x_min[kMaxFrozen];
-  float *x_max[kMaxFrozen];
-  unsigned *state[kMaxFrozen];
-  unsigned *lines[kMaxFrozen];
-  float m_minus_1, one_minus_m;
-  int n, bits, running;
-};
-__global__ void __launch_bounds__(64 * kMaxFrozen) commit_kernel(CommitList f) {
-  const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (i >= f.n) return;
-  float bmin, bmax;
-  cdn::lines_extremes(f.lines[i], bmin, bmax);
-  if (lane == 0) {
-    const cdn::QUpdate u{f.x_min[i], f.x_max[i], f.state[i], f.lines[i], f.m_minus_1, f.one_minus_m, f.bits,
-                         f.running, 1};
-    cdn::quantact_update_device(u, bmin, bmax, true);
-  }
-  f.lines[i][16 * lane + 1] = 0u;
-  f.lines[i][16 * lane + 2] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -260,30 +230,6 @@ extern "C" int cdn_quantact_frozen_params(int n, float *const *x_min, float *con
   }
   frozen_params_kernel<<<1, 64, 0, cdn::as_stream(stream)>>>(f);
   return cdn::check_launch("frozen QuantAct parameters");
-}
-
-extern "C" int cdn_quantact_commit(int n, float *const *x_min, float *const *x_max, void *const *state,
-                                   void *const *lines, int bits, double momentum, int running, void *stream) {
-  CDN_REQUIRE(n >= 0 && n <= kMaxFrozen, CDN_ERR_ARG, "at most %d QuantActs per call", kMaxFrozen);
-  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
-  if (n == 0) return CDN_OK;
-  CDN_REQUIRE(x_min && x_max && state && lines, CDN_ERR_ARG, "null pointer");
-  CommitList f;
-  f.n = n;
-  f.bits = bits;
-  f.running = running;
-  f.m_minus_1 = (float)(momentum - 1.0);       // as cdn_codenet_stage_fused_forward (quant_modules.py:217-219)
-  f.one_minus_m = (float)(1.0 - momentum);
-  for (int i = 0; i < kMaxFrozen; ++i) {
-    const int j = i < n ? i : 0;
-    CDN_REQUIRE(x_min[j] && x_max[j] && state[j] && lines[j], CDN_ERR_ARG, "null pointer in entry %d", j);
-    f.x_min[i] = x_min[j];
-    f.x_max[i] = x_max[j];
-    f.state[i] = static_cast<unsigned *>(state[j]);
-    f.lines[i] = static_cast<unsigned *>(lines[j]);
-  }
-  commit_kernel<<<1, 64 * n, 0, cdn::as_stream(stream)>>>(f);
-  return cdn::check_launch("QuantAct range commit");
 }
 
 extern "C" size_t cdn_codenet_stage_frozen_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up) {

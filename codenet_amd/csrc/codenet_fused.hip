@@ -108,9 +108,7 @@ __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad)
   return c;
 }
 __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
-#pragma clang fp contract(off)
-  const float y_p = c.qs * v;      // (a variable of its own: never fused into the subtraction)
-  const float y = (y_p - c.qz) + 12582912.0f;
+  const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
   const int a = (int)__float_as_uint(y) - 0x4B400000;      // rint(scale*v - zp)
   const int s = min(max(a, -128), 127);
   bad |= a ^ s;          // (non-zero iff the clamp changed the code: one xor + one or, no compare)
@@ -228,7 +226,7 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
   }
   CDN_STAMPR(0, 2);
   if (mm)
-    cdn::block_minmax_out(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, &red[0][0]);
   CDN_STAMPR(0, 3);
 }
@@ -239,7 +237,7 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
 // ------------------------------------------------------------------------------------------
 template <bool XQ, bool X8 = false>      // X8: x is a byte tensor of codes of the quantiser xq (see Code8)
 __global__ void __launch_bounds__(256)
-scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::QUpdate xin,
+scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                   const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ s,
                   float2 *mm, cdn::QUpdate qu, int C, long npix, float lo, float hi) {
   __shared__ float red[12];
@@ -249,10 +247,9 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, 
   const long nwaves = (long)gridDim.x * 4;
   float qs = 1.f, qz = 0.f, qr_ = 1.f;
   if (XQ) {
-    const cdn::QParams xp = cdn::input_qparams<!X8>(xq, xin);
-    qs = xp.scale;
+    qs = reinterpret_cast<const float *>(xq)[2];
     qr_ = __fdiv_rn(1.0f, qs);   // Markstein division in fake_quant_r
-    qz = xp.zp;
+    qz = reinterpret_cast<const float *>(xq)[3];
   }
   float mn = INFINITY, mx = -INFINITY;
   for (long p = wave; p < npix; p += nwaves) {
@@ -286,7 +283,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, 
     mx = fmaxf(mx, v);
   }
   CDN_STAMPR(0, 2);
-  if (mm) cdn::block_minmax_out(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
   CDN_STAMPR(0, 3);
 }
 
@@ -300,7 +297,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, 
 constexpr int kScaleTilePix = 64;
 template <bool XQ, bool X8 = false>
 __global__ void __launch_bounds__(256)
-scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::QUpdate xin,
+scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                        const float *__restrict__ w, const float *__restrict__ b,
                        float *__restrict__ s, float2 *mm, cdn::QUpdate qu, int C, long npix,
                        float lo, float hi) {
@@ -314,10 +311,9 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
   const int total = tile_pix * CQ;    // float4 items of this tile
   float qs = 1.f, qz = 0.f, qr_ = 1.f;
   if (XQ) {
-    const cdn::QParams xp = cdn::input_qparams<!X8>(xq, xin);
-    qs = xp.scale;
+    qs = reinterpret_cast<const float *>(xq)[2];
     qr_ = __fdiv_rn(1.0f, qs);   // Markstein division in fake_quant_r
-    qz = xp.zp;
+    qz = reinterpret_cast<const float *>(xq)[3];
   }
   const float4 *xt = reinterpret_cast<const float4 *>(x + (X8 ? 0 : pix0 * C));
   const unsigned *xt8 = reinterpret_cast<const unsigned *>(reinterpret_cast<const signed char *>(x) + pix0 * C);
@@ -362,7 +358,7 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
     mn = mx = r;
   }
   CDN_STAMPR(0, 2);
-  if (mm) cdn::block_minmax_out(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
   CDN_STAMPR(0, 3);
 }
 
@@ -631,8 +627,8 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
 // of the quantiser qu.state (frozen: no range tracking), dmm is reinterpreted as the overflow flag word.
 template <int CCH, bool NHWC_IN, bool XQ, bool SQ, int MAXT, bool X8 = false, bool OUT8 = false>
 __global__ void __launch_bounds__(MAXT)
-dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::QUpdate xin,
-           const float *__restrict__ s_raw, const unsigned *__restrict__ sq, cdn::QUpdate sin,
+dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+           const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
            int C, int H, int W, int up) {
   static_assert(!X8 || (NHWC_IN && XQ), "codes come channels-last with their quantiser state");
@@ -661,15 +657,13 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::QU
   float *red = sl + HWl;
   float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f, xr_ = 1.f;
   if (XQ) {
-    const cdn::QParams xp = cdn::input_qparams<!(X8 || OUT8)>(xq, xin);
-    xs = xp.scale;
+    xs = reinterpret_cast<const float *>(xq)[2];
     xr_ = __fdiv_rn(1.0f, xs);   // Markstein division in fake_quant_r
-    xz = xp.zp;
+    xz = reinterpret_cast<const float *>(xq)[3];
   }
   if (SQ) {
-    const cdn::QParams sp = cdn::input_qparams<!(X8 || OUT8)>(sq, sin);
-    ss = sp.scale;
-    sz = sp.zp;
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int q = tid; q < (Wc + Hl) * LPP; q += kDw2Threads) {   // zero row, then zero column
@@ -813,7 +807,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::QU
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
-    cdn::block_minmax_out(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red);
   CDN_STAMP(4);
 }
@@ -867,8 +861,8 @@ __device__ __forceinline__ int fold_axis(const AxisRaw &a, const AxisRaw &b, flo
 
 template <int CCH, bool XQ, bool SQ, bool X8 = false, bool OUT8 = false>   // X8 / OUT8: see dw2_kernel
 __global__ void __launch_bounds__(512)   // ~250 VGPRs: 2 waves/SIMD (168 spills and is 2.5x slower)
-dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::QUpdate xin,
-            const float *__restrict__ s_raw, const unsigned *__restrict__ sq, cdn::QUpdate sin,
+dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
+            const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
             int C, int H, int W) {
   static_assert(!X8 || XQ, "codes come with their quantiser state");
@@ -895,15 +889,13 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::Q
   float *red = sl + HWl;
   float xs = 1.f, xz = 0.f, ss = 1.f, sz = 0.f, xr_ = 1.f;
   if (XQ) {
-    const cdn::QParams xp = cdn::input_qparams<!(X8 || OUT8)>(xq, xin);
-    xs = xp.scale;
+    xs = reinterpret_cast<const float *>(xq)[2];
     xr_ = __fdiv_rn(1.0f, xs);   // Markstein division in fake_quant_r
-    xz = xp.zp;
+    xz = reinterpret_cast<const float *>(xq)[3];
   }
   if (SQ) {
-    const cdn::QParams sp = cdn::input_qparams<!(X8 || OUT8)>(sq, sin);
-    ss = sp.scale;
-    sz = sp.zp;
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int q = tid; q < (Wc + Hl) * LPP; q += nthreads) {   // zero row, then zero column
@@ -1145,7 +1137,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, cdn::Q
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
-    cdn::block_minmax_out(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red);
   CDN_STAMP(4);
 }
@@ -1352,7 +1344,7 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   }
   }   // tile loop
   if (rmm)   // (block_minmax_finish syncs before reusing As as scratch)
-    cdn::block_minmax_out(mn, mx, rmm, blockIdx.x, gridDim.x, qu, &As[0][0]);
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.x, gridDim.x, qu, &As[0][0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1377,7 +1369,7 @@ constexpr int kMixedMaxC = 512;   // channels of a mixed-generation input (per-c
 
 template <int BM, int BN, int WGM, bool FAST>
 __global__ void __launch_bounds__(256)
-pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq, cdn::QUpdate ain,
+pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const int *__restrict__ wsum, const float *__restrict__ Wp,
             const float *__restrict__ bias, float *__restrict__ R,
@@ -1396,9 +1388,9 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq, cdn::Q
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
-  const cdn::QParams ap = cdn::input_qparams(aq, ain);
-  const float qs = ap.scale, qz = ap.zp;
-  if (ap.wide) {
+  const float qs = reinterpret_cast<const float *>(aq)[2];
+  const float qz = reinterpret_cast<const float *>(aq)[3];
+  if (aq[6]) {
     // Codes too wide for the nibble split (the tracked range is far narrower than the batch: the first
     // ~100 calls of a fresh EMA): this batch runs on f32 MFMA with the fake-quantised weights, inside
     // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
@@ -1469,7 +1461,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq, cdn::Q
         }
     }
     if (rmm)
-      cdn::block_minmax_out(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+      cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                                gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A1[0][0]));
     return;
   }
@@ -1538,11 +1530,9 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq, cdn::Q
     }
   };
   auto ucode = [&](float v, bool live) -> unsigned {
-#pragma clang fp contract(off)
     // t = sc*d - zp (two roundings, as the reference); rint(t) by the 1.5*2^23 trick; then integer:
     // u = rint(t) + zp - 128 + 2048 in [8, 4087]
-    const float y_p = qs * v;      // (a variable of its own: never fused into the subtraction)
-  const float y = (y_p - qz) + 12582912.0f;
+    const float y = __fadd_rn(__fsub_rn(__fmul_rn(qs, v), qz), 12582912.0f);
     int u = (int)__float_as_uint(y) + ioff;
     u = min(max(u, 8), 4087);       // |L - 128| <= 2040: never active unless state[6] lied
     return live ? (unsigned)u : 2048u;
@@ -1629,7 +1619,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq, cdn::Q
   }
   CDN_STAMPR(2, 3);
   if (rmm)
-    cdn::block_minmax_out(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
   CDN_STAMPR(2, 4);
 }
@@ -1832,7 +1822,7 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
   }
   if (rmm)
-    cdn::block_minmax_out(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&Ah[0]));
 }
 
@@ -2039,9 +2029,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
               const int e = 8 * hh + e8;
               float x = v[e];
               if (has_q) {
-#pragma clang fp contract(off)
-                const float sx = ts[e8] * x;
-                const float n = rintf(sx - tz[e8]) + tz[e8];
+                const float n = __fadd_rn(rintf(__fsub_rn(__fmul_rn(ts[e8], x), tz[e8])), tz[e8]);
                 const float q0 = __fmul_rn(n, tr[e8]);
                 x = fmaf(fmaf(-q0, ts[e8], n), tr[e8], q0);
               }
@@ -2109,7 +2097,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   }
   CDN_STAMPR(2, 3);
   if (rmm)
-    cdn::block_minmax_out(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(smem));
   CDN_STAMPR(2, 4);
 }
@@ -2190,9 +2178,9 @@ static size_t dw2_lds_bytes(int Hl, int Wl, int CCH) {
 }
 
 template <int CCH>
-int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const cdn::QUpdate &xin, const float *s_raw,
-               const unsigned *sq, const cdn::QUpdate &sin, const float *wd, float *d, float2 *dmm,
-               cdn::QUpdate qu, int N, int C, int H, int W, int up, hipStream_t st) {
+int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
+               const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
+               int C, int H, int W, int up, hipStream_t st) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
@@ -2208,7 +2196,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const cdn::QUpdate
     auto kern = dw2_kernel<CCH, NH, XQ_, SQ_, kDw2MaxThreads>;                                \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, threads, lds, st>>>(x, xq, xin, s_raw, sq, sin, wd, d, dmm, qu, C, H, W, up); \
+    kern<<<grid, threads, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up);          \
   }
   const bool XQ = xq != nullptr, SQ = sq != nullptr;
   const bool blocks = nhwc && up == 1;
@@ -2218,7 +2206,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const cdn::QUpdate
     auto kern = dw2u_kernel<CCH, XQ_, SQ_>;                                                   \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, 512, lds, st>>>(x, xq, xin, s_raw, sq, sin, wd, d, dmm, qu, C, H, W);        \
+    kern<<<grid, 512, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W);                  \
   }
     if (XQ && SQ) CDN_GOU(true, true)
     else if (XQ) CDN_GOU(true, false)
@@ -2262,18 +2250,18 @@ int cdn::launch_frozen_scale(const void *x, int x_kind, const unsigned *xq, cons
     const int CQ = (int)C >> 2, LD = ((CQ + 31) & ~31) + 4;
     const size_t lds = ((size_t)kScaleTilePix * LD + 16) * sizeof(float);
     if (x_kind == 2)
-      scale_nhwc_tile_kernel<true, true><<<blocks, 256, lds, st>>>(xf, xq, none, w_scale, b_scale, s_raw, nullptr, none,
+      scale_nhwc_tile_kernel<true, true><<<blocks, 256, lds, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none,
                                                                    (int)C, npix, lo, hi);
     else
-      scale_nhwc_tile_kernel<true><<<blocks, 256, lds, st>>>(xf, xq, none, w_scale, b_scale, s_raw, nullptr, none, (int)C,
+      scale_nhwc_tile_kernel<true><<<blocks, 256, lds, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none, (int)C,
                                                              npix, lo, hi);
   } else {
     const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
     if (x_kind == 2)
-      scale_nhwc_kernel<true, true><<<blocks, 256, 0, st>>>(xf, xq, none, w_scale, b_scale, s_raw, nullptr, none, (int)C,
+      scale_nhwc_kernel<true, true><<<blocks, 256, 0, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none, (int)C,
                                                             npix, lo, hi);
     else
-      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(xf, xq, none, w_scale, b_scale, s_raw, nullptr, none, (int)C, npix,
+      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(xf, xq, w_scale, b_scale, s_raw, nullptr, none, (int)C, npix,
                                                       lo, hi);
   }
   return cdn::check_launch("codenet frozen scale");
@@ -2290,12 +2278,11 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
   const int threads = two_per_cu ? 512 : 1024;
   const cdn::QUpdate qu{nullptr, nullptr, dstate, nullptr, 0.f, 0.f, 8, 0};
-  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
 #define CDN_FGO(KERN, THREADS, ...)                                                                         \
   {                                                                                                         \
     auto kern = KERN;                                                                                       \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-    kern<<<grid, THREADS, lds, st>>>(x, xq, none, s_raw, sq, none, wd, d8, oflow, qu, C, H, W, ##__VA_ARGS__); \
+    kern<<<grid, THREADS, lds, st>>>(x, xq, s_raw, sq, wd, d8, oflow, qu, C, H, W, ##__VA_ARGS__);          \
   }
   if (x_kind != 0 && up == 1) {
     if (x_kind == 2) CDN_FGO((dw2u_kernel<CCH, true, true, true, true>), 512)
@@ -2332,8 +2319,7 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                             const float *ep_shift, int relu, float *r_out, float2 *rmm,
                             const cdn::QUpdate &qu_r, int ptag, hipStream_t st, int64_t lda = 0,
                             int64_t ldo = 0, const unsigned char *a_gen = nullptr,
-                            const int *out_map = nullptr, const cdn::QUpdate *a_in = nullptr) {
-  const cdn::QUpdate ain = a_in ? *a_in : cdn::QUpdate{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
+                            const int *out_map = nullptr) {
   if (lda == 0) lda = C;      // row strides of A / R in floats (views into wider channels-last tensors)
   if (ldo == 0) ldo = Co;
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
@@ -2372,11 +2358,11 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   do {                                                                                           \
     dim3 g((unsigned)cdn::ceil_div(M, BM_), (unsigned)cdn::ceil_div(Co, BN_));                   \
     if (pw_fast)                                                                                 \
-      pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, ain, w_pw_codes, w_pw_scale,   \
+      pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
                                                             qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map); \
     else                                                                                         \
-      pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, ain, w_pw_codes, w_pw_scale,  \
+      pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
                                                              w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
                                                              qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map); \
   } while (0)
@@ -2465,9 +2451,7 @@ extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int6
   return cch != 0 && cdn::ceil_div(C, cch) * N <= kMaxPartials;
 }
 
-// x_in_*: the input's QuantAct when ITS producer deferred the commit (range buffers + lines); lines: this stage's
-// three line blocks (s, d, r) -- non-null selects the deferred protocol for the stage's own QuantActs.
-static int stage_fused_impl(
+extern "C" int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
     const float *w_dw, const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
@@ -2475,7 +2459,7 @@ static int stage_fused_impl(
     int relu, float *s_min, float *s_max, void *s_state, float *d_min,
     float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
-    void *stream, float *x_in_min, float *x_in_max, unsigned *x_in_lines, unsigned *lines) {
+    void *stream) {
   CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(x_up == 0 || x_up == 1, CDN_ERR_ARG, "x_up must be 0 or 1");
@@ -2524,22 +2508,9 @@ static int stage_fused_impl(
   // cdn::block_minmax_finish: no separate update launches.  Python evaluates (momentum - 1.) and
   // (1. - momentum) in double, then the tensor op rounds the scalar to fp32 (quant_modules.py:217-219).
   const float mm1 = (float)(momentum - 1.0), omm = (float)(1.0 - momentum);
-  const int defer = lines != nullptr;
-  if (defer) {
-    CDN_REQUIRE(sst && dst && rst, CDN_ERR_ARG, "the deferred range commit needs all three QuantActs");
-    CDN_REQUIRE((reinterpret_cast<uintptr_t>(lines) & 63) == 0, CDN_ERR_ARG, "lines must be 64-byte aligned");
-    arrive = lines;
-  }
-  CDN_REQUIRE(x_in_lines == nullptr || (xq && x_in_min && x_in_max), CDN_ERR_ARG,
-              "x_in_lines goes with x_qstate, x_in_min and x_in_max");
-  const cdn::QUpdate qu_s{s_min, s_max, sst, arrive, mm1, omm, bits, running, defer};
-  const cdn::QUpdate qu_d{d_min, d_max, dst, arrive + arr_stride, mm1, omm, bits, running, defer};
-  const cdn::QUpdate qu_r{r_min, r_max, rst, arrive + 2 * arr_stride, mm1, omm, bits, running, defer};
-  // input-side views: derived from the lines when the producer deferred, else the state words are read
-  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0, 0};
-  const cdn::QUpdate xin = x_in_lines ? cdn::QUpdate{x_in_min, x_in_max, nullptr, x_in_lines, mm1, omm, bits, running, 1}
-                                      : none;
-  const cdn::QUpdate sin = defer ? qu_s : none, din = defer ? qu_d : none;
+  const cdn::QUpdate qu_s{s_min, s_max, sst, arrive, mm1, omm, bits, running};
+  const cdn::QUpdate qu_d{d_min, d_max, dst, arrive + arr_stride, mm1, omm, bits, running};
+  const cdn::QUpdate qu_r{r_min, r_max, rst, arrive + 2 * arr_stride, mm1, omm, bits, running};
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
   // 1. scale prediction at stored resolution (+ min/max of s)
   float2 *smm = sst ? part_s : nullptr;
@@ -2556,20 +2527,20 @@ static int stage_fused_impl(
     const int CQ = (int)C >> 2, LD = ((CQ + 31) & ~31) + 4;
     const size_t lds = ((size_t)kScaleTilePix * LD + 16) * sizeof(float);
     if (xq)
-      scale_nhwc_tile_kernel<true><<<blocks, 256, lds, st>>>(x, xq, xin, w_scale, b_scale, s_raw, smm,
+      scale_nhwc_tile_kernel<true><<<blocks, 256, lds, st>>>(x, xq, w_scale, b_scale, s_raw, smm,
                                                              qu_s, (int)C, npix, lo, hi);
     else
-      scale_nhwc_tile_kernel<false><<<blocks, 256, lds, st>>>(x, nullptr, none, w_scale, b_scale, s_raw,
+      scale_nhwc_tile_kernel<false><<<blocks, 256, lds, st>>>(x, nullptr, w_scale, b_scale, s_raw,
                                                               smm, qu_s, (int)C, npix, lo, hi);
   } else if (x_nhwc) {
     const long npix = (long)(N * HWl);
     const int blocks = (int)std::min<long>(cdn::ceil_div(npix, 4), (long)cdn::kCUs * 8);
     n_part_s = blocks;
     if (xq)
-      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, xin, w_scale, b_scale, s_raw, smm, qu_s,
+      scale_nhwc_kernel<true><<<blocks, 256, 0, st>>>(x, xq, w_scale, b_scale, s_raw, smm, qu_s,
                                                       (int)C, npix, lo, hi);
     else
-      scale_nhwc_kernel<false><<<blocks, 256, 0, st>>>(x, nullptr, none, w_scale, b_scale, s_raw, smm,
+      scale_nhwc_kernel<false><<<blocks, 256, 0, st>>>(x, nullptr, w_scale, b_scale, s_raw, smm,
                                                        qu_s, (int)C, npix, lo, hi);
   } else {
     CDN_REQUIRE(xq == nullptr, CDN_ERR_UNSUPPORTED, "quant-on-load needs a channels-last input");
@@ -2590,48 +2561,15 @@ static int stage_fused_impl(
   {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     if (cch == 64)
-      rc = launch_dw2<64>(x_nhwc != 0, x, xq, xin, s_raw, sst, sin, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
+      rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
     else
-      rc = launch_dw2<32>(x_nhwc != 0, x, xq, xin, s_raw, sst, sin, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
+      rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
   }
   if (rc) return rc;
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
   return launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
                           bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
-                          st, 0, 0, nullptr, nullptr, defer ? &din : nullptr);
-}
-
-extern "C" int cdn_codenet_stage_fused_forward(
-    const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
-    int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
-    const float *w_dw, const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
-    const int *w_pw_colsum, const float *bias_pw, const float *ep_scale, const float *ep_shift,
-    int relu, float *s_min, float *s_max, void *s_state, float *d_min,
-    float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
-    double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
-    void *stream) {
-  return stage_fused_impl(x, x_nhwc, x_up, x_qstate, N, C, Co, H, W, w_scale, b_scale, lo, hi, w_dw, w_pw,
-                          w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw, ep_scale, ep_shift, relu, s_min, s_max,
-                          s_state, d_min, d_max, d_state, r_min, r_max, r_state, bits, momentum, running,
-                          workspace, workspace_bytes, r_out, stream, nullptr, nullptr, nullptr, nullptr);
-}
-
-extern "C" size_t cdn_codenet_stage_lines_bytes(void) { return 3 * ((cdn::kArriveWords * 4 + 255) / 256 * 256); }
-
-extern "C" int cdn_codenet_stage_fused_forward_deferred(
-    const float *x, int x_nhwc, int x_up, const void *x_qstate, float *x_in_min, float *x_in_max,
-    void *x_in_lines, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W, const float *w_scale,
-    const float *b_scale, float lo, float hi, const float *w_dw, const float *w_pw, const signed char *w_pw_codes,
-    const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu, float *s_min, float *s_max,
-    void *s_state, float *d_min, float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
-    double momentum, int running, void *lines, void *workspace, size_t workspace_bytes, float *r_out,
-    void *stream) {
-  CDN_REQUIRE(lines, CDN_ERR_ARG, "lines is NULL");
-  return stage_fused_impl(x, x_nhwc, x_up, x_qstate, N, C, Co, H, W, w_scale, b_scale, lo, hi, w_dw, w_pw,
-                          w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw, nullptr, nullptr, relu, s_min, s_max,
-                          s_state, d_min, d_max, d_state, r_min, r_max, r_state, bits, momentum, running,
-                          workspace, workspace_bytes, r_out, stream, x_in_min, x_in_max,
-                          static_cast<unsigned *>(x_in_lines), static_cast<unsigned *>(lines));
+                          st);
 }
 
 extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw,

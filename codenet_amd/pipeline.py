@@ -218,8 +218,6 @@ class FusedHotPath:
     All device buffers are allocated once per input shape, so a call issues only kernel launches
     and can be captured into a HIP graph (``capture()``)."""
 
-    deferred = True      # deferred range commit when the configuration allows it (forward_nhwc)
-
     def __init__(self, deconv_layers, int8_pointwise=True):
         from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
         self.seq = deconv_layers
@@ -315,8 +313,7 @@ class FusedHotPath:
         last = bufs[-1]
         out = torch.empty(Nb, last["Co"], last["H"] * 2, last["W"] * 2, device=dev)
         ws = torch.zeros(ws_bytes // 4 + 64, device=dev)   # arrival counters must start at zero
-        lines = torch.zeros(len(bufs) * N_.lib().cdn_codenet_stage_lines_bytes() // 4, device=dev)   # (256-byte aligned)
-        self._bufs = dict(shape=tuple(x.shape), dev=dev, stages=bufs, ws=ws, out=out, lines=lines)
+        self._bufs = dict(shape=tuple(x.shape), dev=dev, stages=bufs, ws=ws, out=out)
 
     def __call__(self, x):
         """Stages + unpack: the Sequential's output tensor (NCHW, up-sampled, fake-quantised)."""
@@ -358,24 +355,12 @@ class FusedHotPath:
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         ws_bytes = (ws.numel() * 4 - (ws_ptr - ws.data_ptr())) // 256 * 256
         cur, cur_nhwc, cur_q = x, int(nhwc_in), (x_qstate if nhwc_in else None)
-        with torch.no_grad():      # (derived weights are cached per weight version only without autograd)
-            params = [self._stage_params(st) for st in self.stages]
-        settings = [uniform_act_settings(p["acts"], "FusedHotPath stage") for p in params]
-        # Deferred range commit (include/codenet_dcn.h): the kernels only collect extremes, consumers derive the
-        # quantisers themselves and ONE commit launch after the last stage updates ranges and states -- when every
-        # stage is W4A8 with the same QuantAct settings and nobody looks at the states between stages.
-        defer = (self.deferred and self.stage_hook is None and len(params) <= 4
-                 and all(p["acts"][0] is not None and p["acts"][1] is not None and p["acts"][2] is not None
-                         and p["ep_scale"] is None for p in params)
-                 and len(set(settings)) == 1)
-        lines_bytes = lib.cdn_codenet_stage_lines_bytes()
-        commit = []                 # (x_min, x_max, state, lines block) of every QuantAct of the step
-        x_in = (None, None, None)   # range buffers + line block of the previous stage's output QuantAct
         with torch.no_grad():
-            for i, (st, sb, p) in enumerate(zip(self.stages, B["stages"], params)):
+            for st, sb in zip(self.stages, B["stages"]):
+                p = self._stage_params(st)
                 ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
                 a = []
-                bits, mom, running = settings[i]
+                bits, mom, running = uniform_act_settings(p["acts"], "FusedHotPath stage")
                 for act in p["acts"]:
                     if act is None:
                         a += [None, None, None]
@@ -383,37 +368,20 @@ class FusedHotPath:
                         a += [act.x_min.data_ptr(), act.x_max.data_ptr(),
                               act._device_state(x.device).data_ptr()]
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
-                i8 = [ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]
-                if defer:
-                    lines = B["lines"].data_ptr() + i * lines_bytes
-                    rc = lib.cdn_codenet_stage_fused_forward_deferred(
-                        cur.data_ptr(), cur_nhwc, sb["up"], cur_q, *x_in, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
-                        ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
-                        ptr(p["w_dw"]), ptr(p["w_pw"]), *i8, ptr(p["bias"]), 1, *a, bits, mom, running,
-                        lines, ws_ptr, ws_bytes, sb["r"].data_ptr(), stream)
-                    commit += [(a[3 * k], a[3 * k + 1], a[3 * k + 2], lines + k * (lines_bytes // 3))
-                               for k in range(3)]
-                    x_in = (a[6], a[7], lines + 2 * (lines_bytes // 3))
-                else:
-                    rc = lib.cdn_codenet_stage_fused_forward(
-                        cur.data_ptr(), cur_nhwc, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
-                        ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
-                        ptr(p["w_dw"]), ptr(p["w_pw"]), *i8, ptr(p["bias"]), ptr(p["ep_scale"]),
-                        ptr(p["ep_shift"]), 1, *a, bits, mom, running, ws_ptr, ws_bytes,
-                        sb["r"].data_ptr(), stream)
+                rc = lib.cdn_codenet_stage_fused_forward(
+                    cur.data_ptr(), cur_nhwc, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                    ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
+                    ptr(p["w_dw"]), ptr(p["w_pw"]),
+                    *([ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]),
+                    ptr(p["bias"]), ptr(p["ep_scale"]),
+                    ptr(p["ep_shift"]), 1, *a, bits, mom, running, ws_ptr, ws_bytes,
+                    sb["r"].data_ptr(), stream)
                 ops._toc(rec)
                 N_.check(rc, "cdn_codenet_stage_fused_forward")
                 if self.stage_hook is not None:
                     self.stage_hook(sb)
                 cur, cur_nhwc = sb["r"], 1
                 cur_q = a[8]          # r_state of this stage (None in fp32)
-            if defer:
-                import ctypes
-                n = len(commit)
-                arr = lambda k: (ctypes.c_void_p * n)(*[c[k] for c in commit])   # noqa: E731
-                bits, mom, running = settings[0]
-                rc = lib.cdn_quantact_commit(n, arr(0), arr(1), arr(2), arr(3), bits, mom, running, stream)
-                N_.check(rc, "cdn_quantact_commit")
         return cur, cur_q, B["stages"][-1]
 
     # -- HIP graph -----------------------------------------------------------------------------

@@ -247,31 +247,6 @@ int cdn_codenet_stage_fused_forward(
     double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
     void *stream);
 
-/* Deferred range commit -- the same stage, same arithmetic and same results (outputs, x_min / x_max, states are
- * bit-identical to cdn_codenet_stage_fused_forward), with the QuantAct bookkeeping moved off the kernels' tails:
- * each producer kernel only folds its workgroups' extremes into 64 "group lines" (two no-return atomics), every
- * consumer kernel derives range / scale / zero-point itself from those lines and the not yet updated x_min / x_max,
- * and ONE cdn_quantact_commit launch per step (after the last stage, before anything else reads a state or a range
- * buffer) runs the reference's range tracking (quant_modules.py:203-219), stores the states and zeroes the lines.
- *   lines        cdn_codenet_stage_lines_bytes() bytes of device memory PER STAGE, 256-byte aligned, zeroed once by
- *                the caller: three blocks (s, d, r) of lines; block i starts at lines + i * bytes / 3
- *   x_qstate     as in cdn_codenet_stage_fused_forward; when the tensor x was produced by a deferred stage,
- *                ALSO pass x_in_min / x_in_max (that stage's r_min / r_max) and x_in_lines (its r block);
- *                NULL otherwise (the state words of x_qstate are read)
- *   no ep_scale / ep_shift in this form.
- * cdn_quantact_commit: up to 12 QuantActs per launch (host arrays of device pointers; lines[i] = the block). */
-size_t cdn_codenet_stage_lines_bytes(void);
-int cdn_codenet_stage_fused_forward_deferred(
-    const float *x, int x_nhwc, int x_up, const void *x_qstate, float *x_in_min, float *x_in_max,
-    void *x_in_lines, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W, const float *w_scale,
-    const float *b_scale, float lo, float hi, const float *w_dw, const float *w_pw, const signed char *w_pw_codes,
-    const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu, float *s_min, float *s_max,
-    void *s_state, float *d_min, float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
-    double momentum, int running, void *lines, void *workspace, size_t workspace_bytes, float *r_out,
-    void *stream);
-int cdn_quantact_commit(int n, float *const *x_min, float *const *x_max, void *const *state, void *const *lines,
-                        int bits, double momentum, int running, void *stream);
-
 /* ------------------------------------------------------------------------------------------
  * FROZEN-RANGE schedule with byte codes in HBM (serving mode; not the reference's default behaviour).
  * `running_stat` is a plain attribute of the reference's QuantAct (portable_quantizer/quant_modules.py:172,181);
