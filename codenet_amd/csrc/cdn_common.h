@@ -77,11 +77,19 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   return __uint_as_float(u);
 }
 // q = round(scale*x - zp) (half-even), no FMA contraction: quant_utils.py:33-41
+// `#pragma clang fp contract(off)` + plain operators: the ocml _rn intrinsics do NOT keep the compiler from fusing a
+// product into the following add / subtract (they bring their own fast-math flags into the caller).  Seen in the ISA:
+// pwi8_kernel formed its codes as v_fma_f32(scale, x, -zp) -- ONE rounding where the reference has two
+// (quant_utils.py:33-41) -- and the in-kernel range update's EMA came out 1 ulp off the reference arithmetic in ~5 %
+// of the updates, depending on the inlining context.
 __device__ __forceinline__ float quant_code(float x, float scale, float zp) {
-  return rintf(__fsub_rn(__fmul_rn(scale, x), zp));
+#pragma clang fp contract(off)
+  const float p = scale * x;
+  return rintf(p - zp);
 }
 // (q + zp) / scale, true division: quant_utils.py:44-52
 __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
+#pragma clang fp contract(off)
   return __fdiv_rn(__fadd_rn(quant_code(x, scale, zp), zp), scale);
 }
 // The same value with r = RN(1 / scale) precomputed: Markstein's division q0 = n*r, q = fma(fma(-q0, s, n), r, q0)
@@ -89,6 +97,7 @@ __device__ __forceinline__ float fake_quant(float x, float scale, float zp) {
 // of the IEEE expansion -- for loops that fake-quantise every loaded element (checked against true division
 // for 3.6e6 (n, s) pairs on the host, tools note in DESIGN.md section 7.3).
 __device__ __forceinline__ float fake_quant_r(float x, float scale, float zp, float r) {
+#pragma clang fp contract(off)
   const float n = __fadd_rn(quant_code(x, scale, zp), zp);
   const float q0 = __fmul_rn(n, r);
   return fmaf(fmaf(-q0, scale, n), r, q0);
@@ -111,6 +120,7 @@ constexpr int kArriveWords = (kArriveGroups + 1) * 16;
 __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float bmin, float bmax,
                                                        bool have_stats, bool preloaded = false,
                                                        float pre_lo = 0.f, float pre_hi = 0.f) {
+#pragma clang fp contract(off)
   float lo = preloaded ? pre_lo : u.x_min[0], hi = preloaded ? pre_hi : u.x_max[0];
   float *sf = reinterpret_cast<float *>(u.state);
   if (have_stats) {
@@ -119,20 +129,24 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
   }
   if (u.running) {
     if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
-      lo = __fadd_rn(lo, bmin);
-      hi = __fadd_rn(hi, bmax);
-    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219)
-      lo = __fadd_rn(lo, __fadd_rn(__fmul_rn(u.m_minus_1, lo), __fmul_rn(u.one_minus_m, bmin)));
-      hi = __fadd_rn(hi, __fadd_rn(__fmul_rn(u.m_minus_1, hi), __fmul_rn(u.one_minus_m, bmax)));
+      lo = lo + bmin;
+      hi = hi + bmax;
+    } else {  // x += (m-1)*x + (1-m)*xb  (:217-219): every product and sum rounded on its own
+      const float pl = u.m_minus_1 * lo, ql = u.one_minus_m * bmin, ph = u.m_minus_1 * hi, qh = u.one_minus_m * bmax;
+      const float sl = pl + ql, sh = ph + qh;
+      lo = lo + sl;
+      hi = hi + sh;
     }
     u.x_min[0] = lo;
     u.x_max[0] = hi;
   }
   const float nlev = (float)((1 << u.bits) - 1);
-  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);          // torch.clamp(min=1e-10)
+  const float range = fmaxf(hi - lo, 1e-10f);          // torch.clamp(min=1e-10)
   // `n / tensor` in torch is Tensor.__rtruediv__ = tensor.reciprocal() * n: two roundings
-  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);
-  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (u.bits - 1)));
+  const float rcp = __fdiv_rn(1.0f, range);
+  const float scale = rcp * nlev;
+  const float sl0 = scale * lo;
+  const float zp = rintf(sl0) + (float)(1 << (u.bits - 1));
   sf[2] = scale;
   sf[3] = zp;
   // state[6]: 1 when some level L - 128 = round(scale*x - zp) + zp - 128 of this batch cannot be

@@ -36,7 +36,9 @@ __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad)
   return c;
 }
 __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
-  const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
+#pragma clang fp contract(off)
+  const float y_p = c.qs * v;      // (plain operators under fp contract(off): two roundings, cdn_common.h)
+  const float y = (y_p - c.qz) + 12582912.0f;
   const int a = (int)__float_as_uint(y) - 0x4B400000;      // rint(scale*v - zp)
   const int s = min(max(a, -128), 127);
   bad |= a ^ s;
@@ -56,13 +58,16 @@ struct FrozenList {
   int n, bits;
 };
 __global__ void frozen_params_kernel(FrozenList f) {
+#pragma clang fp contract(off)
   const int i = threadIdx.x;
   if (i >= f.n) return;
   const float lo = f.x_min[i][0], hi = f.x_max[i][0];
   const float nlev = (float)((1 << f.bits) - 1);
-  const float range = fmaxf(__fsub_rn(hi, lo), 1e-10f);
-  const float scale = __fmul_rn(__fdiv_rn(1.0f, range), nlev);          // n / tensor = reciprocal * n in torch
-  const float zp = __fadd_rn(rintf(__fmul_rn(scale, lo)), (float)(1 << (f.bits - 1)));
+  const float range = fmaxf(hi - lo, 1e-10f);
+  const float rcp = __fdiv_rn(1.0f, range);
+  const float scale = rcp * nlev;                                        // n / tensor = reciprocal * n in torch
+  const float sl0 = scale * lo;
+  const float zp = rintf(sl0) + (float)(1 << (f.bits - 1));
   float *sf = reinterpret_cast<float *>(f.state[i]);
   sf[2] = scale;
   sf[3] = zp;

@@ -108,7 +108,9 @@ __device__ __forceinline__ Code8 make_code8(const unsigned *state, BadMask &bad)
   return c;
 }
 __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) {
-  const float y = __fadd_rn(__fsub_rn(__fmul_rn(c.qs, v), c.qz), 12582912.0f);
+#pragma clang fp contract(off)
+  const float y_p = c.qs * v;      // (plain operators under fp contract(off): two roundings, cdn_common.h)
+  const float y = (y_p - c.qz) + 12582912.0f;
   const int a = (int)__float_as_uint(y) - 0x4B400000;      // rint(scale*v - zp)
   const int s = min(max(a, -128), 127);
   bad |= a ^ s;          // (non-zero iff the clamp changed the code: one xor + one or, no compare)
@@ -1530,9 +1532,11 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     }
   };
   auto ucode = [&](float v, bool live) -> unsigned {
+#pragma clang fp contract(off)
     // t = sc*d - zp (two roundings, as the reference); rint(t) by the 1.5*2^23 trick; then integer:
     // u = rint(t) + zp - 128 + 2048 in [8, 4087]
-    const float y = __fadd_rn(__fsub_rn(__fmul_rn(qs, v), qz), 12582912.0f);
+    const float y_p = qs * v;      // (plain operators under fp contract(off): two roundings, cdn_common.h)
+  const float y = (y_p - qz) + 12582912.0f;
     int u = (int)__float_as_uint(y) + ioff;
     u = min(max(u, 8), 4087);       // |L - 128| <= 2040: never active unless state[6] lied
     return live ? (unsigned)u : 2048u;
@@ -2029,7 +2033,9 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
               const int e = 8 * hh + e8;
               float x = v[e];
               if (has_q) {
-                const float n = __fadd_rn(rintf(__fsub_rn(__fmul_rn(ts[e8], x), tz[e8])), tz[e8]);
+#pragma clang fp contract(off)
+                const float sx = ts[e8] * x;
+                const float n = rintf(sx - tz[e8]) + tz[e8];
                 const float q0 = __fmul_rn(n, tr[e8]);
                 x = fmaf(fmaf(-q0, ts[e8], n), tr[e8], q0);
               }

@@ -870,7 +870,9 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
                   unsigned uc[4];
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
-                    const float yv = __fadd_rn(__fsub_rn(__fmul_rn(s2, v4[e]), z2), 12582912.0f);
+#pragma clang fp contract(off)
+                    const float yv_p = s2 * v4[e];      // (plain operators under fp contract(off): two roundings, cdn_common.h)
+  const float yv = (yv_p - z2) + 12582912.0f;
                     int uu = (int)__float_as_uint(yv) + ioff;
                     uc[e] = (unsigned)min(max(uu, 8), 4087);
                   }

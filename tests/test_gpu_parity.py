@@ -741,3 +741,39 @@ def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
     assert any("module-by-module" in str(w.message) for w in wlist)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_fused_range_update_is_the_reference_two_rounding_ema_bit_exactly():
+    """The in-kernel range tracking of the fused schedule (cdn::quantact_update_device, run by the last workgroup of
+    the producing kernel) against numpy fp32 with every product and sum rounded on its own, as PyTorch's separate
+    elementwise kernels do (quant_modules.py:217-219): x += (m - 1) * x + (1 - m) * x_batch.  The batch extremes come
+    from the stage output tensor itself, so the comparison is EXACT.  (With the ocml _rn intrinsics the compiler fused
+    (m - 1) * x into the following add in this inlining context: 1 ulp off in ~5 % of the updates.)"""
+    import numpy as np
+    from codenet_amd import pipeline
+    dev = torch.device("cuda:0")
+    planes, res, n = [256, 64, 32, 16], 8, 2
+    net = pipeline.build_hot_path(quantized=True, planes=planes).to(dev).eval()
+    fused = pipeline.FusedHotPath(net.deconv_layers)
+    x = torch.randn(n, planes[0], res, res, device=dev).abs() * 2
+    fused.forward_nhwc(x)                                  # "+=" initialisation call
+    acts = [m for m in net.modules() if hasattr(m, "x_min") and isinstance(m.x_min, torch.Tensor)]
+    f = np.float32
+    m1, om = f(0.99 - 1.0), f(1.0 - 0.99)                  # Python doubles rounded to fp32 by the tensor op
+    checked = 0
+    for it in range(60):
+        x.mul_(1.003)
+        prev = [(f(a.x_min.item()), f(a.x_max.item())) for a in acts]
+        fused.forward_nhwc(x)
+        torch.cuda.synchronize()
+        for k in range(3):                                 # the output QuantAct of each stage: its input is r
+            a = acts[3 * k + 2]
+            assert a.momentum == 0.99
+            r = fused._bufs["stages"][k]["r"]
+            bmin, bmax = f(r.min().item()), f(r.max().item())
+            lo, hi = prev[3 * k + 2]
+            want_lo = lo + f(f(m1 * lo) + f(om * bmin))
+            want_hi = hi + f(f(m1 * hi) + f(om * bmax))
+            assert f(a.x_min.item()) == want_lo and f(a.x_max.item()) == want_hi, (it, k)
+            checked += 1
+    assert checked == 180
