@@ -13,8 +13,9 @@ inputs so that the running QuantAct ranges ("+=" initialisation, then two EMA st
 
 Acceptance (same as tests/test_gpu_parity.py::test_fused_hot_path_matches_modules_and_oracle): fp32 within
 1e-3; W4A8 outputs are 8-bit fake-quantised values -- fp32 re-association between CPU and GPU (~1e-6) can move a
-pre-quantisation value across a rounding boundary, i.e. flip a code by ONE LSB: <= 1 LSB, on < 0.2 % of the
-elements; every tracked range within 1e-5 of its magnitude (+1e-6).
+pre-quantisation value across a rounding boundary, i.e. flip a code by ONE LSB: <= 1 LSB, on < 0.02 % of the
+elements (measured 0.001-0.004 %, tools/experiments/code_mismatch_rate.py); every tracked range within 3e-6 of its
+magnitude (+1e-6; measured <= 6.3e-7).
 """
 import copy
 
@@ -79,12 +80,12 @@ def _check(y, ref, quantized, lsb, what):
         return
     assert diff.max().item() <= 1.05 * lsb + 1e-3, "%s: max |diff| %g vs LSB %g" % (what, diff.max().item(), lsb)
     frac = (diff > 1e-3).float().mean().item()
-    assert frac < 2e-3, "%s: %.3g of the outputs differ" % (what, frac)
+    assert frac < 2e-4, "%s: %.3g of the outputs differ" % (what, frac)     # measured: 1e-5 .. 4e-5
 
 
 def _check_ranges(got, want, what):
     for k, ((a0, a1), (b0, b1)) in enumerate(zip(got, want)):
-        tol = 1e-5 * max(abs(b0), abs(b1), 1.0) + 1e-6
+        tol = 3e-6 * max(abs(b0), abs(b1), 1.0) + 1e-6      # measured: <= 6.3e-7 relative
         assert abs(a0 - b0) <= tol and abs(a1 - b1) <= tol, \
             "%s: QuantAct %d range (%g, %g) vs oracle (%g, %g)" % (what, k, a0, a1, b0, b1)
 

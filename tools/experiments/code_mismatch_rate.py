@@ -12,7 +12,9 @@ import torch
 import test_gpu_real_shapes as T
 from codenet_amd import pipeline
 
-planes, res, n, forwards, seed = T.CFG3, 16, 4, 3, 11
+planes = T.CFG4 if "--cfg4" in sys.argv else T.CFG3
+n = int(sys.argv[sys.argv.index("--n") + 1]) if "--n" in sys.argv else 4
+res, forwards, seed = 16, 3, 11
 net = pipeline.build_hot_path(quantized=True, planes=planes, seed=seed)
 net_cpu = copy.deepcopy(net)
 xs = T._inputs(n, planes[0], res, forwards, seed + 100)
