@@ -206,40 +206,69 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   const int tid = threadIdx.x, cq = tid % LPP, cb = c0 + cq * 4, x_l = tid / LPP;
   const bool quad_in = cb + 3 < ld_in;       // the quad can be loaded (channels >= C are finite padding)
   float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f}, qr[4] = {1.f, 1.f, 1.f, 1.f};
+  // Prologue loads are branch-free and batched (clamped indices, values selected afterwards): a load in one arm of
+  // a conditional is a branch and a wait of its own in the ISA -- 10-13 serialised round trips here before.
   if (XQ) {
+    int gen[4] = {0, 0, 0, 0};
+    if (agen) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gen[e] = agen[min(cb + e, C - 1)];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float *sp = reinterpret_cast<const float *>(aq);
-      if (agen) sp += cdn::kQStateWords * agen[min(cb + e, C - 1)];
-      qs[e] = sp[2];
-      qz[e] = sp[3];
-      qr[e] = __fdiv_rn(1.0f, sp[2]);
+      const float2 sz = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
+                                                          cdn::kQStateWords * gen[e] + 2);
+      qs[e] = sz.x;
+      qz[e] = sz.y;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qr[e] = __fdiv_rn(1.0f, qs[e]);
   }
   float wk[9][4], bs[4], es[4], eh[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const bool live = cb + e < C;
     const int c = min(cb + e, C - 1);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
-    bs[e] = (bias && live) ? bias[c] : 0.0f;
-    es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
-    eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
+    for (int k = 0; k < 9; ++k) wk[k][e] = w[(long)c * 9 + k];
+    bs[e] = 0.0f;
+    es[e] = 1.0f;
+    eh[e] = 0.0f;
   }
+  if (bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs[e] = bias[min(cb + e, C - 1)];
+  }
+  if (ep_scale) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      es[e] = ep_scale[min(cb + e, C - 1)];
+      eh[e] = ep_shift[min(cb + e, C - 1)];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (!(cb + e < C)) {                       // channels beyond C: zero weights, identity epilogue
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wk[k][e] = 0.0f;
+      bs[e] = 0.0f;
+      es[e] = 1.0f;
+      eh[e] = 0.0f;
+    }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = tid; i < RING * 2 * LPP; i += 256) {          // the zero halo columns of every ring slot
     const int slot = i / (2 * LPP), side = (i / LPP) & 1, q = i % LPP;
     ring4[(slot * Wc + (side ? Ws + 1 : 0)) * LPP + q] = z4;
   }
   const int r_first = STRIDE * oy0 - 1;                       // first input row of the strip (may be -1)
-  const float *abase = a + (long)n * Hs * Ws * ld_in + cb;
+  const float *abase = a + (long)n * Hs * Ws * ld_in + (quad_in ? cb : 0);
   auto load_row = [&](int r, float4 (&d)[MAXL]) {
     const bool row_in = (unsigned)r < (unsigned)Hs && quad_in;
+    const long rc = min(max(r, 0), Hs - 1);
 #pragma unroll
     for (int u = 0; u < MAXL; ++u) {
       const int x = x_l + u * XPT;
-      d[u] = (row_in && x < Ws) ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * ld_in) : z4;
+      const float4 t = *reinterpret_cast<const float4 *>(abase + (rc * Ws + min(x, Ws - 1)) * ld_in);
+      d[u] = (row_in && x < Ws) ? t : z4;
     }
   };
   auto write_row = [&](int r, int slot, const float4 (&d)[MAXL]) {
@@ -377,37 +406,65 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   const int tid = threadIdx.x, cq = tid % LPP, cb = cq * 4, x_l = tid / LPP;
   const bool quad_in = cb + 3 < ld_in;
   float qs[4] = {1.f, 1.f, 1.f, 1.f}, qz[4] = {0.f, 0.f, 0.f, 0.f}, qr[4] = {1.f, 1.f, 1.f, 1.f};
+  // Prologue loads are branch-free and batched (clamped indices, values selected afterwards): a load in one arm of
+  // a conditional is a branch and a wait of its own in the ISA -- 10-13 serialised round trips here before.
   if (XQ) {
+    int gen[4] = {0, 0, 0, 0};
+    if (agen) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gen[e] = agen[min(cb + e, C - 1)];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float *sp = reinterpret_cast<const float *>(aq);
-      if (agen) sp += cdn::kQStateWords * agen[min(cb + e, C - 1)];
-      qs[e] = sp[2];
-      qz[e] = sp[3];
-      qr[e] = __fdiv_rn(1.0f, sp[2]);
+      const float2 sz = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
+                                                          cdn::kQStateWords * gen[e] + 2);
+      qs[e] = sz.x;
+      qz[e] = sz.y;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qr[e] = __fdiv_rn(1.0f, qs[e]);
   }
   float wk[9][4], bs[4], es[4], eh[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const bool live = cb + e < C;
     const int c = min(cb + e, C - 1);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
-    bs[e] = (bias && live) ? bias[c] : 0.0f;
-    es[e] = (ep_scale && live) ? ep_scale[c] : 1.0f;
-    eh[e] = (ep_scale && live) ? ep_shift[c] : 0.0f;
+    for (int k = 0; k < 9; ++k) wk[k][e] = w[(long)c * 9 + k];
+    bs[e] = 0.0f;
+    es[e] = 1.0f;
+    eh[e] = 0.0f;
   }
+  if (bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bs[e] = bias[min(cb + e, C - 1)];
+  }
+  if (ep_scale) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      es[e] = ep_scale[min(cb + e, C - 1)];
+      eh[e] = ep_shift[min(cb + e, C - 1)];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (!(cb + e < C)) {                       // channels beyond C: zero weights, identity epilogue
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wk[k][e] = 0.0f;
+      bs[e] = 0.0f;
+      es[e] = 1.0f;
+      eh[e] = 0.0f;
+    }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int r_first = STRIDE * oy0 - 1;
-  const float *abase = a + (long)n * Hs * Ws * ld_in + cb;
+  const float *abase = a + (long)n * Hs * Ws * ld_in + (quad_in ? cb : 0);
   auto load_row = [&](int r, float4 (&d)[MAXL]) {
     const bool row_in = (unsigned)r < (unsigned)Hs && quad_in;
+    const long rc = min(max(r, 0), Hs - 1);
 #pragma unroll
     for (int u = 0; u < MAXL; ++u) {
       const int col = x_l + u * XPT, x = ix0 + col;
-      d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws)
-                 ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * ld_in) : z4;
+      const float4 t = *reinterpret_cast<const float4 *>(abase + (rc * Ws + min(max(x, 0), Ws - 1)) * ld_in);
+      d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws) ? t : z4;
     }
   };
   auto write_row = [&](int r, int slot, const float4 (&d)[MAXL]) {
