@@ -149,19 +149,30 @@ def cpu_baseline(args, net_cpu):
             x = F.interpolate(y, scale_factor=2, mode="nearest")
         return x
 
+    # two thread counts on many-core hosts (torch-CPU's small ops are slower on 128 threads than on 16: the
+    # whole-model legs below show the same); `value` is the faster leg and `cores` the threads it used
+    legs = {}
     with torch.no_grad():
-        run(x[:1])                       # warm caches / thread pools
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            run(x)
-            reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 400:
-                break
-        dt = time.perf_counter() - t0
-    return {"value": n * reps / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+        for threads in ((cores, 16) if cores > 32 else (cores,)):
+            torch.set_num_threads(threads)
+            O.set_threads(threads)
+            run(x[:1])                       # warm caches / thread pools
+            t0 = time.perf_counter()
+            reps = 0
+            while True:
+                run(x)
+                reps += 1
+                if time.perf_counter() - t0 > (6.0 if cores > 32 else 10.0) or reps >= 400:
+                    break
+            dt = time.perf_counter() - t0
+            legs[threads] = (n * reps / dt, reps)
+        torch.set_num_threads(cores)
+        O.set_threads(cores)
+    best = max(legs, key=lambda t: legs[t][0])
+    return {"value": legs[best][0], "unit": "images/sec", "cores": best, "kind": "port",
+            "legs": {"threads%d" % t: round(v[0], 3) for t, v in legs.items()},
             "sample": "%d x %d images, %s hot path, %dx%d, oracle C (OpenMP) + torch CPU"
-                      % (reps, n, "fp32" if args.fp32 else "W4A8", args.res, args.res)}
+                      % (legs[best][1], n, "fp32" if args.fp32 else "W4A8", args.res, args.res)}
 
 
 def cpu_model_name():
