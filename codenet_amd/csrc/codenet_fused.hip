@@ -1533,6 +1533,9 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   };
   auto ucode = [&](float v, bool live) -> unsigned {
 #pragma clang fp contract(off)
+#if defined(CDN_DIAG) && CDN_DIAG == 7   // diagnostic build: no fp32 -> code arithmetic (wrong results)
+    return (__float_as_uint(v) & 0xfffu) | 8u;
+#endif
     // t = sc*d - zp (two roundings, as the reference); rint(t) by the 1.5*2^23 trick; then integer:
     // u = rint(t) + zp - 128 + 2048 in [8, 4087]
     const float y_p = qs * v;      // (plain operators under fp contract(off): two roundings, cdn_common.h)
