@@ -467,8 +467,8 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
   // The kernel is VALU-issue bound and the tap geometry is the bulk of the VALU work, so it is
   // computed ONCE per pixel: in the geometry phase lane i owns pixel pb+i (64 different pixels
   // per wave instruction instead of 16 lanes repeating the same pixel); in the gather phase the
-  // LPP lanes of an output pixel fetch that pixel's 18-word record from its owner lane with
-  // ds_bpermute (no LDS storage) and only add offsets, mix and accumulate.
+  // LPP lanes of an output pixel fetch that pixel's 16-word record from its owner lane with DPP row broadcasts
+  // (fetch_record; no LDS storage, no LDS pipeline) and only add offsets, mix and accumulate.
   // every wave owns a contiguous pixel range (a multiple of PPW), so all waves gather even when the
   // plane has fewer than 64 pixels per wave (stage 0: 256 pixels over 8 waves)
   const int ppw = ((HW + kWaves - 1) / kWaves + PPW - 1) / PPW * PPW;
