@@ -500,6 +500,12 @@ def main():
                 roof["traffic_note"] = ("bytes per step (sum over the kernel's launches), PMC FETCH_SIZE*2 + "
                                         "WRITE_SIZE, profiles/%s" % rnd)
                 roof["algorithmic_bytes_per_step"] = nbytes
+                # the whole step against the same peak: every kernel family's PMC bytes / the step's wall time
+                step_bytes = sum(v for k, v in pm["bytes_per_step"].items() if k != "unpack")
+                roof["step"] = {"traffic": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
+                                "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                "note": "all kernels of the step (scale + gather + pointwise): PMC bytes per step / "
+                                        "ms_per_step"}
             break
         roof["launches_per_step"] = sum(1 for (nm, _t) in durs if nm == dominant)
         roof["ms_per_step_in_kernel"] = per_kernel[dominant]
