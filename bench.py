@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=15,
+                    help="the timed K-step region (barrier + synchronize on both sides) is run this many times "
+                         "back to back; the headline ms_per_step is the MEDIAN region, min / max are reported")
     ap.add_argument("--config", choices=sorted(PRESETS), default=None,
                     help="preset of --res/--batch/--w2/--fp32 (default: cfg3 values)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
@@ -96,13 +99,35 @@ def _free_port():
     return p
 
 
+def _visible_gpus():
+    """GPU count from the KFD topology in sysfs (nodes with SIMDs), narrowed by HIP_/ROCR_VISIBLE_DEVICES;
+    None when sysfs does not say -- the ranks then fail by themselves (main() exits 3 unless N ranks joined)."""
+    import glob
+    n = 0
+    props = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not props:
+        return None
+    for f in props:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip()]))
+    return n
+
+
 def launch_ranks(args):
     """Start N ranks as child processes (torch.distributed.run, one rank per GPU) BEFORE this process touches
     the GPU, and return their exit code.  Never exec: a child is spawned and waited for."""
-    import torch
     if not args.plumbing_only:
-        have = torch.cuda.device_count()        # does not initialise the GPU runtime on this image
-        if have < args.gpus:
+        have = _visible_gpus()                  # sysfs only: the launcher parent never calls into HIP / torch.cuda
+        if have is not None and have < args.gpus:
             print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -175,6 +200,29 @@ def cpu_baseline(args, net_cpu):
                       % (legs[best][1], n, "fp32" if args.fp32 else "W4A8", args.res, args.res)}
 
 
+def gpu_clock_state(index=0):
+    """Shader / memory clock levels as sysfs shows them (read-only; None where not readable).  The in-kernel
+    clock under load can sit below pp_dpm_sclk (MI355X_MICROARCH.md, DVFS give-back) -- context, not a correction."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    base = os.path.dirname(cards[min(index, len(cards) - 1)])
+    for key, fn in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+        try:
+            lines = [l.strip() for l in open(os.path.join(base, fn)) if l.strip()]
+            cur = [l for l in lines if l.endswith("*")]
+            out[key] = (cur[0] if cur else lines[-1]).rstrip("*").strip()
+        except OSError:
+            out[key] = None
+    try:
+        out["power_cap_w"] = int(open(glob.glob(os.path.join(base, "hwmon/hwmon*/power1_cap"))[0]).read()) / 1e6
+    except (OSError, IndexError, ValueError):
+        pass
+    return out
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -238,6 +286,33 @@ def cpu_baseline_e2e(args, budget_s=4.0):
 
 # ---- plumbing-only mode (CPU, gloo): launcher + collectives, no kernels ---------------------------------------
 
+class _count_host_syncs:
+    """Counts Tensor.item() / .tolist() / .cpu() calls (the host reads of a tensor) inside the block: the per-batch
+    detections gather must make none when the shard sizes are known."""
+    def __call__(self):
+        return self
+
+    def __enter__(self):
+        import torch
+        self.n = 0
+        self._saved = {}
+        for name in ("item", "tolist", "cpu"):
+            orig = getattr(torch.Tensor, name)
+            self._saved[name] = orig
+
+            def wrap(t, *a, _o=orig, **k):
+                self.n += 1
+                return _o(t, *a, **k)
+            setattr(torch.Tensor, name, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        for name, orig in self._saved.items():
+            setattr(torch.Tensor, name, orig)
+        return False
+
+
 def plumbing_only(args, world, rank):
     import torch
     import torch.distributed as dist
@@ -259,17 +334,23 @@ def plumbing_only(args, world, rank):
     lo, hi = pipeline.shard_range(world * args.batch + 1, rank, world)      # uneven on purpose
     dets = torch.full((hi - lo, 100, 6), float(rank))
     dets[:, 0, 0] = torch.arange(lo, hi, dtype=torch.float32)               # global image index
-    allv = pipeline.gather_detections(dets)
+    counts = pipeline.exchange_shard_sizes(hi - lo)                          # once, at start-up
+    syncs = _count_host_syncs()
+    with syncs:
+        allv = pipeline.gather_detections(dets, counts=counts)               # per batch: one collective, no host read
+        even = pipeline.gather_detections(dets[:args.batch], counts=[args.batch] * world)
+    ok_even = (even.shape[0] == world * args.batch)
     ok = (allv.shape[0] == world * args.batch + 1
           and torch.equal(allv[:, 0, 0], torch.arange(world * args.batch + 1, dtype=torch.float32)))
     if rank == 0:
         print(json.dumps({"plumbing_only": True, "n_gpus": joined, "backend": args.backend,
                           "broadcast_bytes": nbytes, "replicas_identical": bool(same),
                           "detections_gathered": list(allv.shape), "detections_in_rank_order": bool(ok),
-                          "value": None}))
+                          "equal_shards_gathered": bool(ok_even), "shard_sizes": counts,
+                          "host_syncs_in_gather": syncs.n, "value": None}))
     if world > 1:
         dist.destroy_process_group()
-    return 0 if (same and ok) else 4
+    return 0 if (same and ok and ok_even and syncs.n == 0) else 4
 
 
 # ---- the measured run ----------------------------------------------------------------------------------------
@@ -358,18 +439,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # ---- timed region: exactly K steps ---------------------------------------------------------
+    # ---- timed regions: each is exactly K steps between barrier + synchronize; R of them back to back,
+    #      MAX over ranks per region, headline = the median region (one region = ms_per_step * steps) ------
     names = {"scale", "dw", "pointwise", "quantact"}
+    region_s = []
     with ops.KernelTimer(names if fused is None else set()) as kt:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        barrier()
-        dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        for _ in range(max(1, args.regions)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = step()
+            barrier()
+            region_s.append(time.perf_counter() - t0)
+    tmax = torch.tensor(region_s, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    region_s = sorted(tmax.tolist())
+    dt = region_s[len(region_s) // 2] if len(region_s) % 2 else 0.5 * (region_s[len(region_s) // 2 - 1]
+                                                                       + region_s[len(region_s) // 2])
     assert out.dtype == torch.int8 or torch.isfinite(out).all()
     if frozen_main:
         assert not frz.overflowed(), "a code left its frozen 8-bit grid: this batch needs the fp32 schedule"
@@ -519,6 +606,13 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "regions": {"n": len(region_s), "steps_each": args.steps,
+                        "ms_per_step_min": region_s[0] / args.steps * 1e3,
+                        "ms_per_step_median": ms_step,
+                        "ms_per_step_max": region_s[-1] / args.steps * 1e3,
+                        "note": "every region = exactly `steps` steps between barrier + synchronize, MAX over "
+                                "ranks; value / ms_per_step are the median region"},
+            "gpu_clock": gpu_clock_state(local_rank),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -579,10 +673,11 @@ def e2e_leg(args, dev, rank, world, local_rank, hot_ms):
         harness.process(model, images, flip_test=False)
         pipeline.set_running_stat(model, False)
     replay = harness.capture_process(model, images)
+    counts = pipeline.exchange_shard_sizes(args.batch, dev)      # once: shard sizes are static
 
     def step():
         dets = replay()[1]
-        return pipeline.gather_detections(dets) if world > 1 else dets
+        return pipeline.gather_detections(dets, counts=counts) if world > 1 else dets
 
     def barrier():
         if world > 1:

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("CDN_LIB") or os.path.join(_HERE, "lib", "libcodenet_dcn.so")
+SO_PATH = os.path.join(_HERE, "lib", "libcodenet_dcn.so")      # the product library; no environment override
 CSRC = os.path.join(_HERE, "csrc")
 
 CDN_F32, CDN_F64 = 0, 1
@@ -82,6 +82,20 @@ def build(force=False):
         cmd.append("-B")
     subprocess.check_call(cmd)
     return SO_PATH
+
+
+def use_library(path):
+    """A/B tooling only (tools/with_lib.py): load a VARIANT build of the library instead of the product one.
+    Must be called explicitly, with a path, before the first lib() -- nothing in the environment can redirect
+    the product loader (a `make diag` / `make stamps` build computes wrong or slower results on purpose)."""
+    global SO_PATH
+    if _lib is not None:
+        raise RuntimeError("codenet_amd: use_library() after the library was loaded")
+    path = os.path.abspath(path)
+    if not os.path.exists(path):
+        raise RuntimeError("codenet_amd: variant library %s does not exist" % path)
+    SO_PATH = path
+    return path
 
 
 def lib():

@@ -161,6 +161,10 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   if (R8) c8 = make_code8(rq, bad);
   if (!(fabsf(qzf) < 4.0e6f)) bad = 1;
   const int qzi = (int)fminf(fmaxf(qzf, -4.0e6f), 4.0e6f);      // zero-point of the A codes: an integer
+  // sum q*qw + zp*colsum is formed in int32: |sum q*qw| <= 128*8*Cpad and |zp*colsum| <= |zp|*8*Cpad, so a narrow
+  // frozen range far from zero (large |zp|) can leave int32 long before |zp| reaches 4e6 -- flagged, never silent
+  // (the fp32 schedule takes its wide-code f32 branch for such ranges)
+  if (((long)abs(qzi) + 128) * 8 * (long)Cpad >= (1L << 31)) bad = 1;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);

@@ -559,7 +559,10 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
   //          B tile 32(k) x 64(n): thread -> (k = tid>>4 and +16, 4 pixels from (tid&15)*4)
   const int am = tid >> 2, ak = (tid & 3) * 8;
   const int bk = tid >> 4, bn = (tid & 15) * 4;
-  const bool hw4 = (HW & 3) == 0, c4 = (C & 3) == 0;
+  // 16-byte loads only when the rows are 16-byte aligned: the public entry point puts no alignment requirement on
+  // w_pw / d (a weight view at a 4-byte offset takes the scalar path)
+  const bool hw4 = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
+  const bool c4 = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(Wp) & 15) == 0;
   float a[8], b[8];
   auto load = [&](int k0) {
     const int m = m0 + am;

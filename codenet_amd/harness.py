@@ -101,9 +101,14 @@ class PoseShuffleNetV2(nn.Module):
         (pipeline.FusedHotPath.forward_nhwc -> pipeline.FusedHeads; nothing is materialised between
         them) and, for a W4A8 model (backbone=True), layer0..layer4 on pipeline.FusedBackbone.  The
         returned tensors are static buffers, overwritten by the next call."""
+        from .portable_quantizer.quant_modules import QuantAct
         self._fused = bool(flag)
         self._fused_backbone = bool(backbone)
         self._fpath = self._fheads = self._fbackbone = None
+        # the QuantActs whose settings decide _fused_ok(): collected once (the module tree is fixed after
+        # quantize_shufflenetv2_dcn), so a forward reads 5 attributes of ~70 modules instead of walking the tree
+        self.__dict__["_fused_acts"] = [a for a in self.modules() if isinstance(a, QuantAct)]
+        self.__dict__["_fused_ok_cache"] = {}
         return self
 
     def _fused_ok(self, x):
@@ -112,9 +117,8 @@ class PoseShuffleNetV2(nn.Module):
         larger resolutions) keeps the module-by-module path -- decided BEFORE any kernel runs, so no QuantAct
         state is half-updated.  Cached per (input shape, QuantAct configuration)."""
         from . import pipeline
-        from .portable_quantizer.quant_modules import QuantAct
         cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat)
-                    for a in self.modules() if isinstance(a, QuantAct))
+                    for a in self.__dict__["_fused_acts"])
         key = (tuple(x.shape), cfg)
         cache = self.__dict__.setdefault("_fused_ok_cache", {})
         if key not in cache:
@@ -243,19 +247,47 @@ def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100):
     return torch.cat([bboxes, scores, clses], dim=2)
 
 
-_decode_ws = {}
-_sigmoid_bufs = {}
+class ProcessBuffers:
+    """Static buffers of the native post-processing -- the sigmoid copy of `hm` and the decode workspace -- keyed by
+    (device, shape / size, stream).  OWNED: one instance lives on the model (`process`) or in the replay closure of a
+    captured graph (`capture_process`, which runs on its own side stream), so the buffers die with their owner and
+    two models / graphs of the same shape never share an `hm` a caller still holds."""
+
+    def __init__(self):
+        self.sigmoid = {}
+        self.decode_ws = {}
+
+    def sigmoid_buffer(self, hm):
+        key = (hm.device, tuple(hm.shape), torch.cuda.current_stream(hm.device).cuda_stream)
+        if key not in self.sigmoid:
+            self.sigmoid[key] = torch.empty_like(hm)
+        return self.sigmoid[key]
+
+    def workspace(self, device, need, stream):
+        # its histograms must be zero at entry and are left zero by every call, so concurrent calls on
+        # different streams must not share one
+        key = (device, need, stream.cuda_stream)
+        if key not in self.decode_ws:
+            self.decode_ws[key] = torch.zeros(need // 4 + 64, dtype=torch.int32, device=device)
+        return self.decode_ws[key]
 
 
-def _sigmoid_buffer(hm):
-    key = (hm.device, tuple(hm.shape), torch.cuda.current_stream(hm.device).cuda_stream)
-    if key not in _sigmoid_bufs:
-        _sigmoid_bufs[key] = torch.empty_like(hm)
-    return _sigmoid_bufs[key]
+class _BoundedBuffers(ProcessBuffers):
+    """Owner-less calls of ctdet_decode_native: at most `cap` workspaces are kept (oldest dropped first)."""
+    cap = 4
+
+    def workspace(self, device, need, stream):
+        ws = super().workspace(device, need, stream)
+        while len(self.decode_ws) > self.cap:
+            self.decode_ws.pop(next(iter(self.decode_ws)))
+        return ws
+
+
+_default_bufs = _BoundedBuffers()
 
 
 def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigmoid=False,
-                        heat_out=None):
+                        heat_out=None, bufs=None):
     """ctdet_decode on the HIP kernels (codenet_decode.hip, cdn_ctdet_decode): same arguments and result
     as ``ctdet_decode``; apply_sigmoid=True takes logits (heat_out, if given, receives the sigmoid).
     Equal scores are ordered by ascending flat index.  GPU float32 tensors only."""
@@ -267,14 +299,10 @@ def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigm
     B, cat, H, W = heat.shape
     lib = N_.lib()
     need = lib.cdn_ctdet_decode_workspace_bytes(B, cat, H, W)
-    # one workspace per (device, size, stream): its histograms must be zero at entry and are left zero by
-    # every call, so concurrent calls on different streams must not share one; entries are never freed
-    # (a captured graph keeps the raw pointer)
+    # one workspace per (owner, device, size, stream); `bufs` = the owner's ProcessBuffers (a captured graph keeps
+    # the raw pointer, so its owner must outlive the graph: capture_process keeps it in the replay closure)
     stream = torch.cuda.current_stream(heat.device)
-    key = (heat.device, need, stream.cuda_stream)
-    if key not in _decode_ws:
-        _decode_ws[key] = torch.zeros(need // 4 + 64, dtype=torch.int32, device=heat.device)
-    ws = _decode_ws[key]
+    ws = (bufs if bufs is not None else _default_bufs).workspace(heat.device, need, stream)
     ws_ptr = (ws.data_ptr() + 255) // 256 * 256
     dets = torch.empty(B, K, 6, device=heat.device)
     rc = lib.cdn_ctdet_decode(heat.data_ptr(), wh.data_ptr(), reg.data_ptr() if reg is not None else None,
@@ -285,10 +313,13 @@ def ctdet_decode_native(heat, wh, reg=None, cat_spec_wh=False, K=100, apply_sigm
     return dets
 
 
-def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K=100, native_decode=None):
+def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K=100, native_decode=None,
+            bufs=None):
     """CtdetDetector.process (lib/detectors/ctdet.py:29-46): images [2,3,R,R] = image + its W-flip
     when flip_test.  Returns (output dict, dets [B,K,6]).  native_decode (default: on GPU tensors) runs
     the peak filter / top-K / box assembly on the HIP kernels, without flip_test fused with the sigmoid."""
+    if bufs is None and isinstance(model, nn.Module):
+        bufs = model.__dict__.setdefault("_process_bufs", ProcessBuffers())      # owned by (and freed with) the model
     with torch.no_grad():
         output = model(images)[-1]
         if native_decode is None:
@@ -298,9 +329,12 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
             hm = output["hm"]
             # the reference's in-place hm.sigmoid_() (ctdet.py:32): the sigmoid goes to a second static buffer
             # that replaces output["hm"] (in place it would cost a second kernel, see cdn_ctdet_decode)
-            sig = _sigmoid_buffer(hm)
+            # (a model on the fused path returns static buffers anyway; the module-by-module path returns fresh
+            # tensors per call, so its sigmoid is a fresh tensor too)
+            static = bufs is not None and getattr(model, "_fused", False)
+            sig = bufs.sigmoid_buffer(hm) if static else torch.empty_like(hm)
             dets = ctdet_decode_native(hm, output["wh"], reg=reg, cat_spec_wh=cat_spec_wh, K=K,
-                                       apply_sigmoid=True, heat_out=sig)
+                                       apply_sigmoid=True, heat_out=sig, bufs=bufs)
             output = dict(output)
             output["hm"] = sig
             return output, dets
@@ -310,8 +344,10 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
             hm = (hm[0:1] + torch.flip(hm[1:2], [3])) / 2
             wh = (wh[0:1] + torch.flip(wh[1:2], [3])) / 2
             reg = reg[0:1] if reg is not None else None
-        decode = ctdet_decode_native if native_decode else ctdet_decode
-        dets = decode(hm, wh, reg=reg, cat_spec_wh=cat_spec_wh, K=K)
+        if native_decode:
+            dets = ctdet_decode_native(hm, wh, reg=reg, cat_spec_wh=cat_spec_wh, K=K, bufs=bufs)
+        else:
+            dets = ctdet_decode(hm, wh, reg=reg, cat_spec_wh=cat_spec_wh, K=K)
     return output, dets
 
 
@@ -321,7 +357,8 @@ def capture_process(model, images, reg_offset=True, cat_spec_wh=False, K=100):
     launch overhead of issuing them one by one dominates).  Returns replay() -> (output dict, dets); copy
     new images into `images` before each replay.  Needs model.enable_fused() and a GPU tensor."""
     assert getattr(model, "_fused", False) and images.is_cuda
-    kw = dict(flip_test=False, reg_offset=reg_offset, cat_spec_wh=cat_spec_wh, K=K)
+    bufs = ProcessBuffers()          # owned by this capture: kept alive by replay(), released with it
+    kw = dict(flip_test=False, reg_offset=reg_offset, cat_spec_wh=cat_spec_wh, K=K, bufs=bufs)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                 # warm-up: buffers, cached weights, kernel attributes
@@ -336,6 +373,7 @@ def capture_process(model, images, reg_offset=True, cat_spec_wh=False, K=100):
     def replay():
         graph.replay()
         return result
+    replay.buffers = bufs
     return replay
 
 

@@ -114,24 +114,45 @@ def broadcast_parameters(net, src=0):
     return flat.numel() * 4
 
 
-def gather_detections(dets, dst=None):
+def exchange_shard_sizes(n_local, device=None):
+    """ONE start-up exchange of the ranks' per-batch image counts (shard sizes are static for a run): the list
+    `counts` that gather_detections() then takes, so that no batch pays a count all_gather + host sync."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [int(n_local)]
+    world = dist.get_world_size()
+    nb = torch.tensor([int(n_local)], device=device, dtype=torch.int64)
+    parts = [torch.zeros_like(nb) for _ in range(world)]
+    dist.all_gather(parts, nb)
+    return [int(c.item()) for c in parts]
+
+
+def gather_detections(dets, dst=None, counts=None):
     """Per-batch collection of every rank's detections [B, K, 6] (collective 2; the
     reference's only mechanism is DataParallel's gather, lib/models/data_parallel.py:64-84,120-129).
-    all_gather over RCCL (gloo in the CPU tests); shards may differ in size by one image (shard_range),
-    so they are padded to the largest.  Returns [sum B_r, K, 6] in rank order on every rank (dst=None)
-    or only on rank dst (other ranks: None)."""
+    all_gather over RCCL (gloo in the CPU tests).  `counts` = the ranks' shard sizes from exchange_shard_sizes()
+    (static per run): with it a batch is ONE collective and no host synchronisation -- equal shards gather
+    straight into one [world*B, K, 6] tensor; shards that differ by an image (shard_range) are padded to the
+    largest.  Without `counts` the sizes are exchanged first (one extra small all_gather + a host read per call;
+    kept for one-off calls).  Returns [sum B_r, K, 6] in rank order on every rank (dst=None) or only on rank dst
+    (other ranks: None)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return dets
     world = dist.get_world_size()
-    nb = torch.tensor([dets.shape[0]], device=dets.device, dtype=torch.int64)
-    counts = [torch.zeros_like(nb) for _ in range(world)]
-    dist.all_gather(counts, nb)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        counts = exchange_shard_sizes(dets.shape[0], dets.device)
+    if len(counts) != world or counts[dist.get_rank()] != dets.shape[0]:
+        raise ValueError("gather_detections: counts %r do not describe this rank's shard of %d images"
+                         % (counts, dets.shape[0]))
     bmax = max(counts)
     pad = dets if dets.shape[0] == bmax else torch.cat(
         [dets, dets.new_zeros((bmax - dets.shape[0],) + tuple(dets.shape[1:]))])
     pad = pad.contiguous()
+    if dst is None and min(counts) == bmax:
+        out = pad.new_empty((world * bmax,) + tuple(pad.shape[1:]))
+        dist.all_gather_into_tensor(out, pad)
+        return out
     if dst is None:
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad)
@@ -431,7 +452,7 @@ class FrozenHotPath:
     def _acts(self, st):
         return (st[0].quant_act[1], st[0].quant_identity_deform, st[1][1])
 
-    def _alloc(self, shape, dev, nhwc_in):
+    def _alloc(self, shape, dev, nhwc_in, key):
         import ctypes
         from . import _native as N_
         Nb, C, H, W = shape
@@ -455,7 +476,7 @@ class FrozenHotPath:
         arr = ctypes.c_void_p * n
         last = bufs[-1]
         self._bufs = dict(
-            key=(tuple(shape), dev, nhwc_in), stages=bufs,
+            key=key, stages=bufs,
             ws=torch.empty(ws_bytes + 512, dtype=torch.uint8, device=dev),
             ws32=torch.zeros(ws32_bytes // 4 + 64, device=dev) if ws32_bytes else None,
             overflow=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -475,14 +496,20 @@ class FrozenHotPath:
         x = x.contiguous()
         shape = (x.shape[0], x.shape[2], hw[0], hw[1]) if nhwc_in else tuple(x.shape)
         dev = x.device
-        if self._bufs is None or self._bufs["key"] != (shape, dev, nhwc_in):
-            self._alloc(shape, dev, nhwc_in)
+        # the cached pointer arrays name the QuantActs' range buffers: a re-assigned buffer (load_state_dict(assign=
+        # True), a .to() round trip) must rebuild them, so their addresses are part of the key
+        key = (shape, dev, nhwc_in) + tuple(p for st in self.stages for a in self._acts(st)
+                                            for p in (a.x_min.data_ptr(), a.x_max.data_ptr()))
+        if self._bufs is None or self._bufs["key"] != key:
+            self._alloc(shape, dev, nhwc_in, key)
         B = self._bufs
         lib = N_.lib()
         stream = torch.cuda.current_stream(dev).cuda_stream
         Nb = shape[0]
-        for st in self.stages:
-            bits, _, _ = uniform_act_settings(self._acts(st), "FrozenHotPath stage")
+        # ONE (bits, momentum, running_stat) over all nine QuantActs: cdn_quantact_frozen_params takes the bit
+        # width once for every state it derives (stages with different activation_bit would silently get the
+        # last stage's grid otherwise)
+        bits, _, _ = uniform_act_settings(B["acts"], "FrozenHotPath (all stages)")
         # (scale, zero-point) of all nine frozen QuantActs from their range buffers: one launch per step
         N_.check(lib.cdn_quantact_frozen_params(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits, stream),
                  "cdn_quantact_frozen_params")

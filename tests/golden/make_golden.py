@@ -17,6 +17,8 @@ Fixtures
                     W4A8, through CtdetDetector.process' body: sub-sampled hm/wh/reg, checksums and
                     the decoded detections [1,100,6] (weights: codenet_amd.harness.fill_state_dict_).
   model_noise.npz   the reference W4A8 model against ITSELF with 1 vs 8 CPU threads (code-flip noise floor).
+  voc_eval_ref.npz  the reference's own VOC evaluator (tools/voc_eval_lib/datasets/voc_eval.py, pure numpy) over a
+                    synthetic VOC tree: rec / prec / AP per class (difficult objects, duplicates, partial recall).
   deform_raw.npz    oracle-only regression vectors for the generic op (fwd + all grads, plain
                     and modulated); the reference cannot produce these (CUDA-only).
 
@@ -531,6 +533,90 @@ def make_model_noise(ref_qm):
     return t2n(out)
 
 
+def make_voc_eval():
+    """The reference's OWN evaluator -- tools/voc_eval_lib/datasets/voc_eval.py::voc_eval / voc_ap, pure numpy,
+    imported from /root/reference -- over a small synthetic VOC tree written to a temporary directory (XML annotations,
+    image-set file, per-class detection files in the reference's formats): partial recall, difficult objects (hit and
+    missed), duplicate detections of one box, detections on images without that class, overlaps just above / below
+    0.5, a class without detections, a class whose every detection is wrong.  Scores are distinct (the reference's
+    argsort leaves ties unspecified).  The only shim: `np.bool`, an alias numpy >= 1.24 removed (voc_eval.py:139-141).
+    Stored: the inputs (boxes, difficult flags, detections) and the reference's rec / prec / AP (VOC07 11-point and
+    area form) per class."""
+    import importlib.util
+    import tempfile
+    if not hasattr(np, "bool"):
+        np.bool = bool                       # removed alias the reference still uses
+    spec = importlib.util.spec_from_file_location(
+        "ref_voc_eval", os.path.join(REF, "tools", "voc_eval_lib", "datasets", "voc_eval.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.RandomState(2007)
+    classes = ["car", "dog", "person", "sofa", "bird"]
+    n_img = 14
+    gt = []           # rows: image, class, x1, y1, x2, y2, difficult
+    for im in range(n_img):
+        for c in range(3):                                   # sofa: one object only; bird: objects but no detections
+            for _ in range(rng.randint(0, 4)):
+                x1, y1 = rng.randint(0, 300, 2)
+                w, h = rng.randint(20, 160, 2)
+                gt.append((im, c, x1, y1, x1 + w, y1 + h, int(rng.rand() < 0.25)))
+    gt.append((3, 3, 40, 40, 200, 180, 0))
+    gt += [(5, 4, 10, 10, 90, 120, 0), (6, 4, 30, 50, 130, 160, 1)]
+    gt = np.array(gt, dtype=np.int64)
+    dets = []         # rows: image, class, score, x1, y1, x2, y2
+    score = iter(rng.permutation(4000)[:2000] / 4000.0 + 1e-4)          # distinct scores
+    for row in gt:
+        im, c, x1, y1, x2, y2, _d = row
+        if c > 2:
+            continue
+        r = rng.rand()
+        if r < 0.2:
+            continue                                           # missed object (partial recall)
+        for _ in range(1 if r < 0.7 else 2):                   # duplicates of one box
+            j = rng.uniform(-0.18, 0.18, 4) * np.array([x2 - x1, y2 - y1, x2 - x1, y2 - y1])
+            dets.append((im, c, next(score), x1 + j[0], y1 + j[1], x2 + j[2], y2 + j[3]))
+    for _ in range(25):                                        # false positives, some on images without that class
+        im, c = rng.randint(0, n_img), rng.randint(0, 3)
+        x1, y1 = rng.uniform(0, 350, 2)
+        dets.append((im, c, next(score), x1, y1, x1 + rng.uniform(15, 120), y1 + rng.uniform(15, 120)))
+    # IoU exactly around the threshold on a known box: GT 100 x 100 px (+1 convention: 101 x 101)
+    gt = np.concatenate([gt, np.array([(13, 0, 200, 200, 300, 300, 0), (13, 1, 200, 200, 300, 300, 0)])])
+    dets.append((13, 0, next(score), 200.0, 200.0, 300.0, 249.0))      # 101*50 / 101*101 = 0.495 -> FP
+    dets.append((13, 1, next(score), 200.0, 200.0, 300.0, 251.0))      # 101*52 / 101*101 = 0.515 -> TP
+    dets += [(3, 3, next(score), 300.0, 300.0, 380.0, 380.0), (7, 3, next(score), 10.0, 10.0, 50.0, 50.0)]   # sofa: all wrong
+    dets = np.array(dets, dtype=np.float64)
+    out = {"classes": np.array(classes), "n_images": np.array(n_img), "gt": gt, "dets": dets}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "Annotations"))
+        names = ["%06d" % i for i in range(n_img)]
+        with open(os.path.join(tmp, "test.txt"), "w") as f:
+            f.write("\n".join(names) + "\n")
+        for im, name in enumerate(names):
+            objs = "".join(
+                "<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>"
+                "<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                % (classes[r[1]], r[6], r[2], r[3], r[4], r[5]) for r in gt if r[0] == im)
+            with open(os.path.join(tmp, "Annotations", name + ".xml"), "w") as f:
+                f.write("<annotation><filename>%s.jpg</filename>%s</annotation>" % (name, objs))
+        for c, cname in enumerate(classes):
+            with open(os.path.join(tmp, "det_%s.txt" % cname), "w") as f:
+                for r in dets[dets[:, 1] == c]:
+                    f.write("%s %.6f %.3f %.3f %.3f %.3f\n" % (names[int(r[0])], r[2], r[3], r[4], r[5], r[6]))
+        for c, cname in enumerate(classes):
+            for tag, use07 in (("07", True), ("area", False)):
+                with np.errstate(all="ignore"):
+                    rec, prec, ap = ref.voc_eval(os.path.join(tmp, "det_{:s}.txt"),
+                                                 os.path.join(tmp, "Annotations", "{:s}.xml"),
+                                                 os.path.join(tmp, "test.txt"), cname,
+                                                 os.path.join(tmp, "cache"), ovthresh=0.5, use_07_metric=use07)
+                out["%s_ap_%s" % (cname, tag)] = np.array(ap, dtype=np.float64)
+            out["%s_rec" % cname] = np.asarray(rec, dtype=np.float64)
+            out["%s_prec" % cname] = np.asarray(prec, dtype=np.float64)
+    # the detection files round coordinates to 3 and scores to 6 decimals: store what the reference actually read
+    out["dets"] = np.concatenate([dets[:, :2], np.round(dets[:, 2:3], 6), np.round(dets[:, 3:], 3)], axis=1)
+    return out
+
+
 def main():
     assert os.path.isdir(REF), "needs the reference checkout at /root/reference"
     torch.manual_seed(317)
@@ -547,6 +633,7 @@ def main():
         "head_w4a8": lambda: make_head_w4a8(ref_qm),
         "decode_ref": make_decode,
         "base_nodes": lambda: make_base_nodes(ref_qm),
+        "voc_eval_ref": make_voc_eval,
     }
     only = sys.argv[1:] or list(makers)           # `make_golden.py stage_w4a8_grads` regenerates one fixture
     for name in only:

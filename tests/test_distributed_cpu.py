@@ -86,6 +86,10 @@ def test_bench_launcher_starts_its_own_ranks_world2():
     assert res["n_gpus"] == 2 and res["replicas_identical"] and res["detections_in_rank_order"]
     assert res["detections_gathered"] == [7, 100, 6] and res["broadcast_bytes"] > 1_000_000
     assert res["value"] is None                                     # a plumbing run never reports a rate
+    # shard sizes are exchanged ONCE at start-up; the per-batch gather is then one collective and no host read
+    # (no count all_gather + .item() per batch)
+    assert res["shard_sizes"] == [4, 3] and res["equal_shards_gathered"]
+    assert res["host_syncs_in_gather"] == 0
 
 
 def test_bench_refuses_world_size_mismatch():

@@ -127,6 +127,38 @@ def test_eval_voc_pieces_known_answers():
     assert abs(ev.voc_eval(half, gts) - 6.0 / 11.0) < 1e-9              # recall 0.5 reached at precision 1
 
 
+def test_voc_eval_reproduces_the_reference_evaluator():
+    """tools/eval_voc.py::voc_eval_curve / voc_ap07 / voc_ap_area against the reference's OWN evaluator
+    (tools/voc_eval_lib/datasets/voc_eval.py:31-209, run by tests/golden/make_golden.py::make_voc_eval over a synthetic
+    VOC tree): rec, prec and both APs per class, exactly -- difficult objects (ignored when hit, not counted in npos),
+    duplicate detections (second one a FP), partial recall, detections on images without the class, overlaps of
+    0.495 / 0.515 around the threshold, a class without detections and one whose detections are all wrong."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_voc", os.path.join(root, "tools", "eval_voc.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    z = np.load(os.path.join(root, "tests", "golden", "voc_eval_ref.npz"))
+    gt, dets = z["gt"], z["dets"]
+    seen_nontrivial = 0
+    for c, cname in enumerate(z["classes"]):
+        cname = str(cname)
+        gts = {}
+        for im in range(int(z["n_images"])):       # every image is a key, as in the reference's class_recs
+            rows = gt[(gt[:, 0] == im) & (gt[:, 1] == c)]
+            gts[im] = (rows[:, 2:6].astype(np.float64), rows[:, 6].astype(bool))
+        rows = [(int(r[0]), float(r[2]), *map(float, r[3:7])) for r in dets[dets[:, 1] == c]]
+        rec, prec = ev.voc_eval_curve(rows, gts)
+        assert rec.shape == z[cname + "_rec"].shape
+        np.testing.assert_array_equal(rec, z[cname + "_rec"])
+        np.testing.assert_array_equal(prec, z[cname + "_prec"])
+        assert ev.voc_ap07(rec, prec) == float(z[cname + "_ap_07"])
+        assert abs(ev.voc_ap_area(rec, prec) - float(z[cname + "_ap_area"])) < 1e-15
+        assert ev.voc_eval(rows, gts) == float(z[cname + "_ap_07"])
+        seen_nontrivial += 0.05 < float(z[cname + "_ap_07"]) < 0.95
+    assert seen_nontrivial >= 3                      # the fixture pins non-trivial answers, not only AP 0 / 1
+
+
 def test_pre_process_matches_affine_crop_known_answer():
     """pre_process against a closed form: a horizontal ramp image keeps its slope s/res per output pixel and the image
     centre lands on the output centre (get_affine_transform, lib/utils/image.py:30-55, rot = 0)."""

@@ -5,7 +5,7 @@ PAT="$1"; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 one() {
   rm -rf gpurun_out/abs && mkdir -p gpurun_out/abs
-  CDN_LIB="$1" rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abs -- python3 bench.py --no-cpu-baseline --no-e2e > gpurun_out/abs.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abs -- python3 tools/with_lib.py "$1" bench.py --no-cpu-baseline --no-e2e > gpurun_out/abs.log 2>&1
   f=$(find gpurun_out/abs -name "*kernel_stats.csv" | head -1)
   python3 - "$f" "$PAT" <<'PY'
 import csv, sys, re

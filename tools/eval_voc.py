@@ -62,9 +62,22 @@ def voc_ap07(rec, prec):
     return ap
 
 
-def voc_eval(dets, gts, ovthresh=0.5):
+def voc_ap_area(rec, prec):
+    """Area under the monotone precision envelope (voc_eval.py:49-62, use_07_metric=False)."""
+    mrec = np.concatenate(([0.0], rec, [1.0]))
+    mpre = np.concatenate(([0.0], prec, [0.0]))
+    for i in range(mpre.size - 1, 0, -1):
+        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    return float(np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1]))
+
+
+def voc_eval_curve(dets, gts, ovthresh=0.5):
     """dets: list of (image_id, score, x1, y1, x2, y2) of one class; gts: image_id -> (boxes [n,4], difficult [n]).
-    voc_eval.py:95-200 (+1 pixel conventions kept)."""
+    -> (rec, prec) over the detections in descending score order.  voc_eval.py:95-207 (+1 pixel conventions kept;
+    a detection on a difficult box is neither TP nor FP; a second detection of a found box is a FP; equal scores
+    keep their input order -- the reference's argsort leaves ties unspecified).  One divergence: with no
+    non-difficult ground truth the reference divides by npos = 0; here rec is all zeros."""
     npos = sum(int((~d).sum()) for _, d in gts.values())
     seen = {k: np.zeros(len(b), dtype=bool) for k, (b, _) in gts.items()}
     dets = sorted(dets, key=lambda r: -r[1])
@@ -93,7 +106,12 @@ def voc_eval(dets, gts, ovthresh=0.5):
     tp, fp = np.cumsum(tp), np.cumsum(fp)
     rec = tp / max(npos, 1)
     prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
-    return voc_ap07(rec, prec)
+    return rec, prec
+
+
+def voc_eval(dets, gts, ovthresh=0.5):
+    """VOC07 11-point AP of one class (what pascal_voc.py:237-247 asks voc_eval for)."""
+    return voc_ap07(*voc_eval_curve(dets, gts, ovthresh))
 
 
 def run_voc(args):

@@ -1,6 +1,6 @@
 """Fraction of the fused W4A8 hot path's outputs that differ from the CPU oracle (one code LSB each), and the largest
 relative deviation of the nine tracked ranges, at the cfg3 stage shapes (batch 4, three forwards).  Run with
-CDN_LIB=<variant .so> to compare library builds."""
+run under tools/with_lib.py <variant .so> to compare library builds."""
 import copy
 import os
 import sys

@@ -1,7 +1,7 @@
 """Phase timeline of every kernel of the fused hot path IN PIPELINE CONTEXT, from in-kernel stamps
 (thread 0 of each workgroup records s_memrealtime at phase boundaries; library built with
 -DCDN_STAMPS: `make -C codenet_amd/csrc stamps`).  Usage (GPU):
-    CDN_LIB=$PWD/codenet_amd/lib/libcodenet_dcn_stamps.so python tools/stamps.py [--batch 64]
+    python tools/with_lib.py codenet_amd/lib/libcodenet_dcn_stamps.so tools/stamps.py [--batch 64]
 Prints, per stage and kernel: kernel span (first start .. last end), number of workgroups, mean
 per-workgroup phase durations and the distribution of workgroup start times."""
 import argparse
