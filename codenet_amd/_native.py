@@ -32,6 +32,7 @@ _SIGNATURES = {
     "cdn_codenet_pointwise_wgrad": (_i, [_vp] * 4 + [_i64] * 4 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_codenet_scale_backward": (_i, [_vp] * 5 + [_i64] * 4 + [_vp]),
     "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
+    "cdn_codenet_set_gather_mode": (_i, [_i]),
     "cdn_codenet_dw_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
     "cdn_codenet_pointwise_forward": (_i, [_vp] * 6 + [_i64] * 4 + [_i, _vp]),
     "cdn_quantact_state_bytes": (ctypes.c_size_t, []),

@@ -162,6 +162,19 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
   u.state[6] = wide;
 }
 
+// Barrier of the range epilogue.  __syncthreads() also waits for the wave's outstanding GLOBAL stores (s_waitcnt
+// vmcnt(0)): at the end of a producer kernel that is the drain of its whole output tile, in front of the epilogue's
+// atomic round trip.  An LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier) lets the two overlap -- built and
+// measured in round 3: step 0.2503 vs 0.2508 ms, i.e. nothing (the kernel cannot end before its stores have drained
+// anyway), so the plain form stays.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(CDN_EPILOGUE_LDS_BARRIER) && CDN_EPILOGUE_LDS_BARRIER      // A/B build (measured: no difference)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+}
+
 // Epilogue of a producer kernel in the fused schedule: workgroup min/max -> the workgroup's GROUP LINE ->
 // arrival ticket; the LAST workgroup to arrive reads the 64 group lines and runs the range update, so no
 // separate update launch (~4.4 us each inside a graph) and no heavily contended atomics are needed.
@@ -184,12 +197,12 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
     mx = fmaxf(mx, __shfl_xor(mx, m, 64));
   }
   const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();   // `red` may alias tiles other waves are still reading
+  lds_barrier();      // `red` may alias tiles other waves are still reading
   if ((threadIdx.x & 63) == 0) {
     red[2 * wave] = mn;
     red[2 * wave + 1] = mx;
   }
-  __syncthreads();
+  lds_barrier();
   float pre_lo = 0.f, pre_hi = 0.f;
   if (threadIdx.x == 0) {
     pre_lo = u.x_min[0];      // in flight during the ticket round trip (only the last arriver uses them)
@@ -213,7 +226,7 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
     }
     red[2 * nw] = last ? 1.0f : 0.0f;
   }
-  __syncthreads();
+  lds_barrier();
   if (red[2 * nw] == 0.0f) return;
   // ---- last workgroup: wave 0 reads the group lines, updates ranges and parameters ---------------
   if (threadIdx.x < 64) {

@@ -815,6 +815,166 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 }
 
 // ------------------------------------------------------------------------------------------
+// dw0p: PERSISTENT form of dw2_kernel<64> for an NCHW fp32 input at output resolution (stage 0 of the model),
+// with the next item's input in flight by LDS-DMA while the current item is gathered.
+//
+// dw2_kernel runs stage 0 as two rounds of two 512-thread workgroups per CU that stage (HBM) and gather (LDS / VALU)
+// in lock-step: HBM idles during the gather and the SIMDs idle during staging (in-kernel stamps).
+// A register-staged double buffer cannot be built under the 128-VGPR cap of 16 waves per CU.  Here ONE 1024-thread
+// workgroup per CU walks over its items (image n, 64-channel chunk):
+//
+//   raw   [64][HW] floats  <- global_load_lds_dwordx4 (no VGPRs): an item's 64 channel planes are ONE contiguous
+//                             64*HW*4-byte block of the NCHW tensor; 1-KB pieces, each lane's 16 bytes = 4 pixels of a
+//                             channel, stored at slot (quad ^ (channel & 15)) of the channel's row -- the XOR is
+//                             applied to the per-lane SOURCE address (the DMA's LDS side is lane-linear), so that
+//   img   [cell][64]       <- the transposing pass (lane <-> channel: ds_read_b128 of raw, four ds_write_b32 into the
+//                             [cell][channel] image the gather wants) reads 16 different 16-byte bank groups per
+//                             hardware lane group and writes 32 consecutive banks: conflict-free both ways;
+//   wl, sl (two sets)      <- global_load_lds_dword: the chunk's depthwise weights and the image's scale plane.
+//
+//   per item:  wait for this item's DMA | barrier | raw -> img (+ fake-quant of s) | barrier |
+//              issue the NEXT item's DMA into raw / the other (wl, sl) set | gather this item (dw2_gather, unchanged).
+//
+// Same arithmetic as dw2_kernel (same staged values, same gather routine): results are bit-identical to it.
+// Needs W % 4 == 0, H*W a power of two >= 64 (whole 1-KB pieces per channel group, shifts instead of divisions in the
+// per-step DMA issue), C % 64 == 0.
+// ------------------------------------------------------------------------------------------
+// LDS-DMA as inline asm, on purpose: with __builtin_amdgcn_global_load_lds the compiler orders every later LDS
+// read of the wave behind the pending DMA (it cannot prove that the gather's image reads do not alias the raw
+// buffer being filled) and emits s_waitcnt vmcnt(0) right after the issue -- the next item's transfer was then
+// fully exposed (in-kernel stamps: 9.0 / 11.6 / 13.8 us per item with the DMA "in flight" against 4.5 us for the last
+// item without one).  The asm form is invisible to that bookkeeping; completion is waited for explicitly
+// (s_waitcnt vmcnt(0) + barrier at the top of every item).  M0 = wave-uniform LDS byte address of the piece, the
+// lane's 16 (4) bytes land at M0 + lane * 16 (4); M0 is saved and restored (compiler-reserved register).
+__device__ __forceinline__ void glds16(const void *gbase, unsigned voff, unsigned lds_dst) {
+  // gbase: wave-uniform 64-bit base (SGPR pair), voff: the lane's byte offset, lds_dst: wave-uniform LDS byte address
+  unsigned keep;
+  const unsigned long long b = (unsigned long long)gbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned long long b = (unsigned long long)gbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+// LDS byte address of a pointer into the workgroup's LDS, wave-uniform by construction (made provable for "s")
+__device__ __forceinline__ unsigned lds_addr_uniform(const void *p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p);
+}
+
+template <bool SQ, bool OUT8>
+__global__ void __launch_bounds__(1024)
+dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
+            const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
+            int C, int H, int W, int nitems) {
+  extern __shared__ float4 img_lds[];
+  CDN_STAMP(0);
+  constexpr int CCH = 64, LPP = 16, kWaves = 16;
+  const int HW = H * W, Wc = W + 1, cells = (H + 1) * Wc;
+  const int Q = HW >> 2;                      // 16-byte quads per channel plane
+  const int nchunk = C / CCH;
+  float4 *img = img_lds + LPP;
+  float *raw = reinterpret_cast<float *>(img + (size_t)cells * LPP);
+  float *wl0 = raw + CCH * HW;                // two sets of [64][9]
+  float *sl0 = wl0 + 2 * CCH * 9;             // two sets of [HW]
+  float *red = sl0 + 2 * HW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float ss = 1.f, sz = 0.f;
+  if (SQ) {
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = tid; q < (Wc + H) * LPP; q += 1024) {   // zero row, then zero column: written once
+    const int i = q / LPP;
+    const int cell = i < Wc ? H * Wc + i : (i - Wc) * Wc + W;
+    img[cell * LPP + (q % LPP)] = z4;
+  }
+  if (tid < LPP) img_lds[tid] = z4;                    // the leading zero cell
+
+  const int npiece_w = CCH * 9 / 64, npiece_s = HW / 64;
+  const unsigned raw_a = lds_addr_uniform(raw), wl_a = lds_addr_uniform(wl0), sl_a = lds_addr_uniform(sl0);
+  // DMA of one item = Q 1-KB pieces of the raw buffer (wave w: pieces w, w + 16, ...) + the small pieces (weights,
+  // scale plane).  issue_step(item, set, k): the wave's k-th raw piece, and with k == 0 its small piece.
+  const int qsh = 31 - __builtin_clz(Q);                           // Q is a power of two (host check)
+  auto issue_step = [&](int item, int set, int k) {
+    const int n = item / nchunk, chunk = item - n * nchunk;
+    const int piece = __builtin_amdgcn_readfirstlane(wave + kWaves * k);
+    if (piece < Q) {                                               // Q pieces of 1 KB = 64 * HW * 4 bytes
+      const int idx = piece * 64 + lane;                           // 16-byte slot of the raw buffer
+      const int c = idx >> qsh, slot = idx & (Q - 1);
+#if defined(CDN_DIAG) && CDN_DIAG == 8   // diagnostic build: every item reads the planes of item 0 (wrong results)
+      glds16(x, (unsigned)(((c << qsh) + (slot ^ (c & 15))) << 4), raw_a + piece * 1024);
+#else
+      glds16(x + ((long)n * C + (long)chunk * CCH) * HW, (unsigned)(((c << qsh) + (slot ^ (c & 15))) << 4),
+             raw_a + piece * 1024);
+#endif
+    }
+    if (k == 0)
+      for (int sp = wave; sp < npiece_w + npiece_s; sp += kWaves) {
+        if (sp < npiece_w)
+          glds4(wd + (long)chunk * CCH * 9 + sp * 64, lane * 4, wl_a + (set * CCH * 9 + sp * 64) * 4);
+        else
+          glds4(s_raw + (long)n * HW + (sp - npiece_w) * 64, lane * 4, sl_a + (set * HW + (sp - npiece_w) * 64) * 4);
+      }
+  };
+  const int npieces = (Q + kWaves - 1) / kWaves;                   // raw pieces per wave
+  auto issue = [&](int item, int set, int k0) {
+    for (int k = k0; k < max(npieces, 1); ++k) issue_step(item, set, k);
+  };
+  float mn = INFINITY, mx = -INFINITY;
+  BadMask bad = 0;
+  Code8 c8 = {1.f, 0.f};
+  if (OUT8) c8 = make_code8(qu.state, bad);
+  int item = blockIdx.x, set = 0;
+  if (item < nitems) issue(item, 0, 0);
+  for (; item < nitems; item += gridDim.x, set ^= 1) {
+    const int n = item / nchunk, chunk = item - n * nchunk;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the item's DMA have landed ...
+    __syncthreads();       // ... everybody's have, and everybody is done with img and the other (wl, sl) set
+    CDN_STAMP(1);
+    if (item == (int)blockIdx.x) CDN_STAMP(5);
+    // ---- raw -> img: lane <-> channel, wave w takes quads w, w + 16, ... -----------------------------------
+    float *imgf = reinterpret_cast<float *>(img);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    for (int qd = wave; qd < Q; qd += kWaves) {
+      const float4 v = *reinterpret_cast<const float4 *>(raw + (ln * Q + (qd ^ (ln & 15))) * 4);
+      const int p = qd * 4, row = p / W, col = p - row * W;         // W % 4 == 0: one row
+      float *dst = imgf + (row * Wc + col) * CCH + ln;
+      dst[0] = v.x; dst[CCH] = v.y; dst[2 * CCH] = v.z; dst[3 * CCH] = v.w;
+    }
+    float *sl = sl0 + set * HW;
+    if (SQ) for (int q = tid; q < HW; q += 1024) sl[q] = fake_quant(sl[q], ss, sz);
+    __syncthreads();
+    CDN_STAMP(2);
+    // the NEXT item's transfer: in flight during the gather below.  (Issuing one raw piece per gather step instead of
+    // the 64-KB burst was built and measured: no difference, 0.2521 vs 0.2524 ms per step, and the hook cost the
+    // byte-code instantiation 20 spilled VGPRs.)
+    const int nxt = item + gridDim.x;
+    if (nxt < nitems) issue(nxt, set ^ 1, 0);
+    if (OUT8) dw2_gather<CCH, true>(img, wl0 + set * CCH * 9, sl, d, n, chunk * CCH, C, H, W, kWaves, mn, mx, &c8, &bad);
+    else dw2_gather<CCH, false>(img, wl0 + set * CCH * 9, sl, d, n, chunk * CCH, C, H, W, kWaves, mn, mx);
+    CDN_STAMP(3);
+    if (item == (int)blockIdx.x) CDN_STAMP(6);
+    if (item == (int)(blockIdx.x + gridDim.x)) CDN_STAMP(7);
+  }
+  if (OUT8) {
+    if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
+    return;
+  }
+  if (dmm) cdn::block_minmax_finish(mn, mx, dmm, blockIdx.x, gridDim.x, qu, red);
+  CDN_STAMP(4);
+}
+
+// ------------------------------------------------------------------------------------------
 // dw2u: the gather + depthwise kernel for an UP-SAMPLED input (up = 1, channels-last, stages >= 1),
 // processing one 2x2 block of output pixels -- one stored pixel (Y,X) -- per lane group.
 //
@@ -860,6 +1020,11 @@ __device__ __forceinline__ int fold_axis(const AxisRaw &a, const AxisRaw &b, flo
   out[3] = (sb0 == 1 ? b.w0 : 0.0f) + (sb1 == 1 ? b.w1 : 0.0f);
   return cb;
 }
+
+#ifndef CDN_UNEVEN_SPLIT
+#define CDN_UNEVEN_SPLIT 1
+#endif
+constexpr bool kUnevenSplit = CDN_UNEVEN_SPLIT != 0;
 
 template <int CCH, bool XQ, bool SQ, bool X8 = false, bool OUT8 = false>   // X8 / OUT8: see dw2_kernel
 __global__ void __launch_bounds__(512)   // ~250 VGPRs: 2 waves/SIMD (168 spills and is 2.5x slower)
@@ -1002,9 +1167,27 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   Code8 c8 = {1.f, 0.f};
   if (OUT8) c8 = make_code8(qu.state, bad);
   const bool vec_store = ((C & 3) == 0);
-  // every wave owns a contiguous range of blocks (= stored pixels)
-  const int bpw = (HWl + nwaves - 1) / nwaves;
-  const int b_begin = wave * bpw, b_end = min(HWl, b_begin + bpw);
+  // every wave owns a contiguous range of blocks (= stored pixels).  The second-dispatched half of the waves
+  // (4..7) loses the oldest-first arbitration of VALU / LDS issue on every step and finishes ~30 % later than the
+  // first half on equal ranges (in-kernel per-wave stamps: 20.2 vs 26.0 us at stage 2); with >= 12 steps per wave
+  // the first half therefore takes 9/16 of the steps.  (Fixed assignment: results do not depend on it.)
+  int b_begin, b_end;
+  {
+    const int steps = (HWl + PPW - 1) / PPW, half = nwaves / 2;
+    if (kUnevenSplit && (nwaves & 1) == 0 && steps >= 12 * nwaves) {
+      const int old_each = (steps * 9 / 16 + half - 1) / half;           // steps per wave, first half
+      const int old_total = min(steps, old_each * half);
+      const int young_each = (steps - old_total + half - 1) / half;
+      const int s0 = wave < half ? wave * old_each : old_total + (wave - half) * young_each;
+      const int s1 = wave < half ? min(old_total, s0 + old_each) : s0 + young_each;
+      b_begin = min(HWl, s0 * PPW);
+      b_end = min(HWl, s1 * PPW);
+    } else {
+      const int bpw = ((HWl + nwaves - 1) / nwaves + PPW - 1) / PPW * PPW;
+      b_begin = min(HWl, wave * bpw);
+      b_end = min(HWl, b_begin + bpw);
+    }
+  }
   for (int bb = b_begin; bb < b_end; bb += 64) {
     // ---- geometry phase: lane i owns block bb + i -----------------------------------------------
     int g_o[9];       // byte offsets: rows {ya: r0,r1; yb: r0,r1; mid}, cols {xa, xb: first cell; mid}; [8]: the
@@ -2186,6 +2369,38 @@ static size_t dw2_lds_bytes(int Hl, int Wl, int CCH) {
           2 * kDw2MaxThreads / 64 + 4) * sizeof(float);
 }
 
+// gather schedule for an NCHW input: 0 = automatic (persistent LDS-DMA kernel where it applies), 1 = always the
+// per-item kernels (dw2_kernel), 2 = persistent wherever its shape conditions hold (also on small grids)
+static int g_gather_mode = 0;
+
+static size_t dw0p_lds_bytes(int H, int W) {
+  return ((size_t)64 + (size_t)(H + 1) * (W + 1) * 64 + (size_t)64 * H * W + 2 * 64 * 9 + 2 * (size_t)H * W +
+          2 * 16 + 4) * sizeof(float);
+}
+// shape conditions of dw0p_kernel (see there)
+static bool dw0p_applies(int C, int H, int W) {
+  const int HW = H * W;
+  return (W & 3) == 0 && (HW & 63) == 0 && (HW & (HW - 1)) == 0 && (C & 63) == 0 &&
+         dw0p_lds_bytes(H, W) <= 160 * 1024;
+}
+template <bool OUT8>
+static int launch_dw0p(const float *x, const float *s_raw, const unsigned *sq, const float *wd, float *d,
+                       float2 *dmm, cdn::QUpdate qu, int N, int C, int H, int W, hipStream_t st) {
+  const int nitems = N * (C / 64);
+  const int grid = std::min(nitems, cdn::kCUs);
+  const size_t lds = dw0p_lds_bytes(H, W);
+#define CDN_GOP(SQ_)                                                                                      \
+  {                                                                                                       \
+    auto kern = dw0p_kernel<SQ_, OUT8>;                                                                   \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    kern<<<grid, 1024, lds, st>>>(x, s_raw, sq, wd, d, dmm, qu, C, H, W, nitems);                         \
+  }
+  if (sq) CDN_GOP(true)
+  else CDN_GOP(false)
+#undef CDN_GOP
+  return cdn::check_launch("codenet fused dw (persistent)");
+}
+
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
                const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
@@ -2193,6 +2408,10 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
+  // NCHW input at output resolution (stage 0): the persistent LDS-DMA form once every CU gets >= 2 items to pipeline
+  if (CCH == 64 && !nhwc && up == 0 && xq == nullptr && g_gather_mode != 1 && dw0p_applies(C, H, W) &&
+      (g_gather_mode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs))
+    return launch_dw0p<false>(x, s_raw, sq, wd, d, dmm, qu, N, C, H, W, st);
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
   const bool two_per_cu = lds * 2 <= 160 * 1024 && (long)grid.x * grid.y >= 2L * cdn::kCUs;
@@ -2300,6 +2519,9 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
     CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, true, true>), threads, up)
   } else if (x_kind == 1) {
     CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, false, true>), threads, up)
+  } else if (CCH == 64 && up == 0 && g_gather_mode != 1 && dw0p_applies(C, H, W) &&
+             (g_gather_mode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs)) {
+    return launch_dw0p<true>(x, s_raw, sq, wd, d8, oflow, qu, N, C, H, W, st);
   } else {
     CDN_FGO((dw2_kernel<CCH, false, false, true, kDw2MaxThreads, false, true>), threads, up)
   }
@@ -2447,6 +2669,12 @@ int cdn::stage_channel_chunk(int Hl, int Wl) {
   if (cells * 64 * 4 <= (size_t)lds_max) return 64;
   if (cells * 32 * 4 <= (size_t)lds_max) return 32;
   return 0;
+}
+
+extern "C" int cdn_codenet_set_gather_mode(int mode) {
+  const int old = g_gather_mode;
+  if (mode >= 0 && mode <= 2) g_gather_mode = mode;
+  return old;
 }
 
 extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up) {

@@ -237,6 +237,11 @@ size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_
  * LDS-resident gather: ~1250 stored pixels, i.e. inputs up to ~544 px), 0 otherwise: callers then keep the
  * module path (cdn_codenet_{scale,dw,pointwise}_forward, any plane size). */
 int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
+/* Schedule of the gather for an NCHW input at output resolution (stage 0): 0 = automatic (default: the persistent
+ * LDS-DMA kernel when every CU gets >= 2 items, the per-item kernel otherwise), 1 = always the per-item kernel,
+ * 2 = persistent wherever its shape conditions hold.  Both compute bit-identical results (tests compare them);
+ * process-wide, returns the previous mode.  No reference counterpart (tuning knob). */
+int cdn_codenet_set_gather_mode(int mode);
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,

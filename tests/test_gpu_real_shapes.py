@@ -190,3 +190,56 @@ def test_cfg3_modules_w4a8_batch64_matches_fused():
         assert diff.max().item() <= 1.05 * lsb + 1e-3
         assert (diff > 1e-3).float().mean().item() < 2e-3
         _check_ranges(_gpu_ranges(b), _gpu_ranges(a), "modules vs fused fwd %d" % it)
+
+
+@pytest.mark.parametrize("res,n,quantized", [(16, 64, True), (16, 33, True), (8, 32, False), (8, 40, True)])
+def test_persistent_dma_gather_is_bit_identical_to_per_item_gather(res, n, quantized):
+    """Stage 0 (NCHW input): dw0p_kernel -- one persistent workgroup per CU, the next item's planes in flight by LDS-DMA
+    (global_load_lds) during the gather, XOR-swizzled raw buffer -> [cell][channel] image -- against dw2_kernel (one
+    workgroup per item, register staging).  Same staged values, same gather routine: outputs and all nine QuantAct
+    ranges must be bit-identical over three forwards, for even (4 / 2 items per workgroup) and ragged (33 x 16 = 528,
+    40 x 16 = 640 items over 256 workgroups) item counts.  Both also run against the oracle in the tests above (the
+    automatic mode picks the persistent kernel at N = 64 / 32)."""
+    from codenet_amd import _native as N_, pipeline
+    lib = N_.lib()
+    net = pipeline.build_hot_path(quantized=quantized, planes=CFG3, seed=41)
+    xs = [x.cuda() for x in _inputs(n, 1024, res, 3, 141)]
+    a, b = copy.deepcopy(net).cuda(), copy.deepcopy(net).cuda()
+    if quantized:
+        pipeline.set_running_stat(a, True)
+        pipeline.set_running_stat(b, True)
+    fa, fb = pipeline.FusedHotPath(a.deconv_layers), pipeline.FusedHotPath(b.deconv_layers)
+    old = lib.cdn_codenet_set_gather_mode(1)
+    try:
+        for x in xs:
+            lib.cdn_codenet_set_gather_mode(1)
+            ya = fa(x).clone()
+            lib.cdn_codenet_set_gather_mode(2)
+            yb = fb(x).clone()
+            assert torch.equal(ya, yb)
+            if quantized:
+                assert _gpu_ranges(a) == _gpu_ranges(b)
+    finally:
+        lib.cdn_codenet_set_gather_mode(old)
+
+
+def test_persistent_dma_gather_frozen_codes_bit_identical():
+    """The same for the frozen byte-code schedule (OUT8 instantiation of dw0p_kernel): codes and overflow flag."""
+    from codenet_amd import _native as N_, pipeline
+    lib = N_.lib()
+    net = pipeline.build_hot_path(quantized=True, planes=CFG3, seed=42).cuda()
+    xs = [x.cuda() for x in _inputs(64, 1024, 16, 2, 142)]
+    pipeline.set_running_stat(net, True)
+    fused = pipeline.FusedHotPath(net.deconv_layers)
+    for x in xs:
+        fused(x)
+    pipeline.set_running_stat(net, False)
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    old = lib.cdn_codenet_set_gather_mode(1)
+    try:
+        ca = frz.forward_codes(xs[0])[0].clone()
+        lib.cdn_codenet_set_gather_mode(2)
+        cb = frz.forward_codes(xs[0])[0].clone()
+        assert ca.dtype == torch.int8 and torch.equal(ca, cb) and not frz.overflowed()
+    finally:
+        lib.cdn_codenet_set_gather_mode(old)

@@ -69,6 +69,11 @@ def main():
                 name, start - t_first, end - start, n,
                 "  ".join("%s %5.1f" % (p, d) for p, d in zip(phases, durs)),
                 float((rr[:, lastcol] - rr[:, 0]).mean()), s0[n // 2], s0[int(n * 0.9)], s0[-1]))
+        r1 = st[1][st[1][:, 0] > 0]
+        if r1.shape[0] and (r1[:, 5] > 0).all():       # persistent gather (dw0p_kernel): first-item stamps
+            print("  dw0p: first DMA landed +%.1f us, first gather done +%.1f, second +%.1f, last item: barrier +%.1f, "
+                  "image +%.1f, gathered +%.1f, finished +%.1f (means over %d workgroups, relative to the workgroup's start)"
+                  % tuple([float((r1[:, k] - r1[:, 0]).mean()) for k in (5, 6, 7, 1, 2, 3, 4)] + [r1.shape[0]]))
         if (wv > 0).any():
             base = st[1][0, 2]
             print("  gather: per-wave end of workgroup 0 relative to its barrier: " +
