@@ -57,6 +57,27 @@ def test_deform_conv_forward_backward(case, dtype):
     assert (wg.grad.cpu() - gw).abs().max().item() < sc * _tol(dtype)
 
 
+@pytest.mark.parametrize("N,C,H,W,spread", [(2, 37, 9, 11, 2.0), (1, 70, 16, 16, 4.0), (2, 8, 33, 20, 6.0),
+                                              (3, 33, 8, 8, 12.0), (1, 4, 3, 3, 1.0)])
+def test_generic_depthwise_fast_path_matches_oracle(N, C, H, W, spread):
+    """cdn_deform_conv_forward with the CoDeNet call geometry (groups = C = Co, deformable_groups = 1, 3x3, stride 1,
+    pad 1: modules/dcn_deform_conv.py:319-325) takes the LDS-plane depthwise kernel (dwo_kernel, dcn_generic.hip)
+    instead of one thread per output.  Arbitrary 18-channel offsets (not the anchor * (s - 1) family): widths that
+    are not multiples of 4, channel counts that leave a partial chunk (37 = 32 + 5, 70 = 32 + 32 + 6), offsets far
+    outside the plane (per-sample `> -1 / < size` gate and per-corner zeroing, _kernel.cu:97-108,228), a 3x3 plane (the smallest the shape check admits)."""
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    g = torch.Generator().manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    off = torch.randn(N, 18, H, W, generator=g) * spread
+    off[:, :, 0, 0] = 0.0                     # exact integer positions too
+    off[:, 0::2, -1, -1] = -1.0               # row positions exactly on -1 .. (boundary of the gate)
+    w = torch.randn(C, 1, 3, 3, generator=g)
+    ref = O.deform_conv_forward(x, off, w, 1, 1, 1, C, 1)
+    out = deform_conv(x.cuda(), off.cuda(), w.cuda(), 1, 1, 1, C, 1)
+    assert out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("case", GENERIC_CASES[:4])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("with_bias", [False, True])
