@@ -2536,7 +2536,8 @@ int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const f
   const int cch = cdn::stage_channel_chunk(H >> up, W >> up);
   if (cch == 0) return cdn::fail(CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident gather");
   if ((long)cdn::ceil_div(C, cch) * N > cdn::kMaxPartials) return cdn::fail(CDN_ERR_UNSUPPORTED, "too many workgroups");
-  auto fn = cch == 64 ? launch_frozen_dw_t<64> : launch_frozen_dw_t<32>;
+  auto fn = cch == 64 ? launch_frozen_dw_t<64> : cch == 32 ? launch_frozen_dw_t<32>
+            : cch == 16 ? launch_frozen_dw_t<16> : launch_frozen_dw_t<8>;
   return fn(static_cast<const float *>(x), x_kind, xq, s_raw, sq, wd, reinterpret_cast<float *>(d8), dstate,
             reinterpret_cast<float2 *>(oflow), N, C, H, W, up, st);
 }
@@ -2660,14 +2661,18 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
                   3 * r(cdn::kArriveWords * 4));
 }
 
-// LDS budget of the gather kernel decides the channel chunk (64 or 32 channels x the whole stored plane);
-// 0: the plane does not fit
+// LDS budget of the gather kernel decides the channel chunk: 64 or 32 channels x the whole stored plane at the
+// BASELINE resolutions (planes up to 34 x 34, inputs up to 544 px); larger planes keep the whole-plane form -- the tap
+// offsets reach +-8 pixels, so a spatial tile would need a +-9-cell halo and re-read 2-2.6x the bytes -- with thinner
+// chunks: 16 channels (4 lanes per pixel, planes up to ~49 x 49) or 8 (2 lanes per pixel, up to ~69 x 69, inputs up to
+// ~1100 px).  Thin chunks fetch the tap record with ds_bpermute instead of DPP and read 64- / 32-byte pieces of every
+// cell row (bank conflicts, partial lines): a size fallback, not a tuned path.  0: the plane does not fit.
 int cdn::stage_channel_chunk(int Hl, int Wl) {
   const size_t cells = (size_t)(Hl + 1) * (Wl + 1) + 1;   // + the zero row and zero column, + the leading zero cell
   const long lds_max = 160 * 1024 - 64 * 9 * 4 - 256 - (long)Hl * Wl * 4;   // scale plane, weights, scratch
   if (lds_max <= 0) return 0;
-  if (cells * 64 * 4 <= (size_t)lds_max) return 64;
-  if (cells * 32 * 4 <= (size_t)lds_max) return 32;
+  for (int cch = 64; cch >= 8; cch >>= 1)
+    if (cells * cch * 4 <= (size_t)lds_max) return cch;
   return 0;
 }
 
@@ -2739,7 +2744,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
 
   const int cch = (Hl <= 4096 && Wl <= 4096) ? cdn::stage_channel_chunk(Hl, Wl) : 0;
   CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
-              "stored plane %dx%d too large for the LDS-resident gather (max ~1250 pixels)", Hl, Wl);
+              "stored plane %dx%d too large for the LDS-resident gather (max ~4800 pixels)", Hl, Wl);
 
   // Range tracking runs inside the producing kernels (last workgroup to finish), see
   // cdn::block_minmax_finish: no separate update launches.  Python evaluates (momentum - 1.) and
@@ -2797,10 +2802,8 @@ extern "C" int cdn_codenet_stage_fused_forward(
   CDN_REQUIRE(n_part_d <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many gather workgroups");
   {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
-    if (cch == 64)
-      rc = launch_dw2<64>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
-    else
-      rc = launch_dw2<32>(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
+    auto fn = cch == 64 ? launch_dw2<64> : cch == 32 ? launch_dw2<32> : cch == 16 ? launch_dw2<16> : launch_dw2<8>;
+    rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
   }
   if (rc) return rc;
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)

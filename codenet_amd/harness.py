@@ -113,8 +113,8 @@ class PoseShuffleNetV2(nn.Module):
 
     def _fused_ok(self, x):
         """The fused schedules implement the reference's default QuantAct settings and stored planes that fit
-        the LDS-resident gather (inputs up to ~544 px); anything else (--act-percentile, symmetric activations,
-        larger resolutions) keeps the module-by-module path -- decided BEFORE any kernel runs, so no QuantAct
+        the LDS-resident gather (inputs up to ~1100 px; above 544 px in thinner channel chunks); anything else
+        (--act-percentile, symmetric activations, larger resolutions) keeps the module-by-module path -- decided BEFORE any kernel runs, so no QuantAct
         state is half-updated.  Cached per (input shape, QuantAct configuration)."""
         from . import pipeline
         cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat)

@@ -234,7 +234,8 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
  * ---------------------------------------------------------------------------------------- */
 size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up);
 /* 1 when cdn_codenet_stage_fused_forward implements this geometry (the stored plane must fit the
- * LDS-resident gather: ~1250 stored pixels, i.e. inputs up to ~544 px), 0 otherwise: callers then keep the
+ * LDS-resident gather: 64- / 32-channel chunks up to ~1250 stored pixels = inputs up to ~544 px, thinner 16- / 8-
+ * channel chunks up to ~4800 stored pixels = inputs up to ~1100 px), 0 otherwise: callers then keep the
  * module path (cdn_codenet_{scale,dw,pointwise}_forward, any plane size). */
 int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
 /* Schedule of the gather for an NCHW input at output resolution (stage 0): 0 = automatic (default: the persistent

@@ -751,10 +751,10 @@ def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
     assert any("module-by-module" in str(w.message) for w in wlist)
     for k in a:
         assert torch.equal(a[k], b[k]), k
-    # 640 x 640: stage 2's stored plane is 40 x 40 -> not LDS resident
+    # 1280 x 1280: stage 2's stored plane is 80 x 80 -> not LDS resident even in 8-channel chunks
     m3 = harness.create_model(quantize=False).cuda()
     m4 = copy.deepcopy(m3).enable_fused()
-    xl = torch.randn(1, 3, 640, 640, generator=torch.Generator().manual_seed(4)).cuda()
+    xl = torch.randn(1, 3, 1280, 1280, generator=torch.Generator().manual_seed(4)).cuda()
     with warnings.catch_warnings(record=True) as wlist:
         warnings.simplefilter("always")
         with torch.no_grad():
@@ -762,6 +762,57 @@ def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
     assert any("module-by-module" in str(w.message) for w in wlist)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("res,quantize", [(640, False), (640, True), (1024, False)])
+def test_fused_schedule_on_large_inputs(res, quantize):
+    """Inputs above 544 px: the stored planes of the later stages no longer fit the LDS-resident gather in 64- / 32-
+    channel chunks (640 px: stage 2 gathers from a 40 x 40 stored plane for its 80 x 80 output; 1024 px: 64 x 64), so the
+    gather runs in 16- / 8-channel chunks (VERDICT r2 missing #3).  enable_fused() must hold (no fallback warning) and
+    the whole network must match the module-by-module path: fp32 to 1e-3; W4A8 within the evaluation-order noise
+    (model_noise yardstick, as in tests/test_harness.py)."""
+    import copy
+    import warnings
+    from codenet_amd import harness
+    m = harness.create_model(quantize=quantize).cuda()
+    m2 = copy.deepcopy(m).enable_fused()
+    x = torch.randn(2, 3, res, res, generator=torch.Generator().manual_seed(res)).cuda()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            a = {k: v.clone() for k, v in m(x)[-1].items()}
+            b = m2(x)[-1]
+    assert not any("module-by-module" in str(w.message) for w in wlist)
+    for k in a:
+        diff = (a[k] - b[k]).abs()
+        if quantize:
+            std = a[k].std().item() + 1e-6
+            assert diff.mean().item() < 0.06 * std and diff.max().item() < 1.5 * std, (k, diff.mean().item(), diff.max().item(), std)
+        else:
+            assert diff.max().item() < 1e-3 * max(1.0, a[k].abs().max().item()), (k, diff.max().item())
+
+
+@pytest.mark.parametrize("C,Hl,n", [(128, 40, 2), (64, 64, 1), (24, 48, 2)])
+def test_fused_stage_large_plane_matches_oracle(C, Hl, n):
+    """One W4A8 stage with an up-sampled channels-last input whose STORED plane is 40 x 40 / 48 x 48 / 64 x 64 (output 80^2
+    .. 128^2): dw2u_kernel in 16- / 8-channel chunks, against the CPU oracle (oracle/quant.py::stage_w4a8 over the C
+    restatement) -- same acceptance as the real-shape tests: <= 1 LSB on < 0.02 % of the outputs, ranges to 3e-6."""
+    import copy
+    from codenet_amd import pipeline
+    planes = [2 * C, C, C // 2]              # stage 0 at Hl x Hl (also a large NCHW plane), stage 1 up-sampled to 2 Hl
+    net = pipeline.build_hot_path(quantized=True, planes=planes, seed=C + Hl)
+    net_cpu = copy.deepcopy(net)
+    from tests.test_gpu_real_shapes import _check, _check_ranges, _gpu_ranges, _inputs, _oracle
+    xs = _inputs(n, 2 * C, Hl, 2, seed=Hl)
+    ref, ref_ranges = _oracle(net_cpu, xs, True)
+    net = net.cuda()
+    pipeline.set_running_stat(net, True)
+    fused = pipeline.FusedHotPath(net.deconv_layers)
+    for it, x in enumerate(xs):
+        y = fused(x.cuda())
+        last = list(net.deconv_layers)[-2][1]
+        _check_ranges(_gpu_ranges(net), ref_ranges[it], "large plane fwd %d" % it)
+        _check(y, ref[it], True, (last.x_max - last.x_min).item() / 255.0, "large plane fwd %d" % it)
 
 
 def test_fused_range_update_is_the_reference_two_rounding_ema_bit_exactly():
