@@ -1546,44 +1546,33 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 // the final fp32 scale and bias add.  Operand lane map: lane (r = l&31, h = l>>5) supplies 16
 // consecutive k bytes [16h, 16h+16) of its row's 32-byte k-step for BOTH operands (any k order works as long as A
 // and B agree; checked with exact integer data, tools/probes/probe_i8.hip); C/D map as f32.
+// Tried in round 3 and removed (source kept in tools/probes/archive/pwi8r_kernel.inc): the same kernel with the raw fp32 A / int8 B tiles fetched by
+// global_load_lds into a 3-slot LDS ring two tiles ahead (counted vmcnt, no compiler-visible load in the k loop,
+// bit-identical results) -- stage 0 (K = 1024) 39.7 vs 38.3 us, stage 1 (K = 256, only two 72-KB workgroups per CU
+// instead of four) 31.6 vs 23.6 us: the k loop is not waiting for its global loads.
 // ------------------------------------------------------------------------------------------
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 constexpr int kI8LD = 48;   // bytes per LDS row: 32 k + 16 pad -> conflict-free ds_read_b128
 constexpr int kMixedMaxC = 512;   // channels of a mixed-generation input (per-channel state table in LDS)
 
-template <int BM, int BN, int WGM, bool FAST>
-__global__ void __launch_bounds__(256)
-pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
-            const signed char *__restrict__ Wq, const float *__restrict__ wscale,
-            const int *__restrict__ wsum, const float *__restrict__ Wp,
-            const float *__restrict__ bias, float *__restrict__ R,
-            float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu, int lda,
-            int ldo, const int *__restrict__ omap) {
+// The rare branch of the int8 pointwise kernels: this batch's codes are too wide for the nibble split (state[6]), so
+// it runs on f32 MFMA with the fake-quantised weights Wp.  As / Bs: BM x 17 / BN x 17 floats of LDS, red: scratch of
+// block_minmax_finish.
+template <int BM, int BN, int WGM>
+__device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, const float *__restrict__ Wp,
+                                               const float *__restrict__ bias, float *__restrict__ R, float2 *rmm,
+                                               const cdn::QUpdate &qu, long M, int C, int Co, int relu, int lda,
+                                               int ldo, const int *__restrict__ omap, float qs, float qz,
+                                               float *As, float *Bs, float *red) {
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
-  constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
-  constexpr int BI = (BN * 2 + 255) / 256;  // 16-byte loads of W per thread per k-tile
-  __shared__ __attribute__((aligned(16))) unsigned char A0[2][BM * kI8LD];
-  __shared__ __attribute__((aligned(16))) unsigned char A1[2][BM * kI8LD];
-  __shared__ __attribute__((aligned(16))) unsigned char B0[2][BN * kI8LD];
-  __shared__ __attribute__((aligned(16))) unsigned char B1[2][BN * kI8LD];
-  CDN_STAMPR(2, 0);
+  constexpr int LDF = 17;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
-  const float qs = reinterpret_cast<const float *>(aq)[2];
-  const float qz = reinterpret_cast<const float *>(aq)[3];
-  if (aq[6]) {
-    // Codes too wide for the nibble split (the tracked range is far narrower than the batch: the first
-    // ~100 calls of a fresh EMA): this batch runs on f32 MFMA with the fake-quantised weights, inside
-    // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
-    // do).  Simple single-buffered 16-deep k-tiles in the int8 path's LDS arrays: the rare path.
-    constexpr int LDF = 17;
-    static_assert(BM * LDF * 4 <= 2 * BM * kI8LD && BN * LDF * 4 <= 2 * BN * kI8LD, "LDS reuse");
-    float *As = reinterpret_cast<float *>(&A0[0][0]);
-    float *Bs = reinterpret_cast<float *>(&B0[0][0]);
+  {
     f32x16 accf[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1647,7 +1636,42 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     }
     if (rmm)
       cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
-                               gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A1[0][0]));
+                               gridDim.x * gridDim.y, qu, red);
+  }
+}
+
+template <int BM, int BN, int WGM, bool FAST>
+__global__ void __launch_bounds__(256)
+pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
+            const signed char *__restrict__ Wq, const float *__restrict__ wscale,
+            const int *__restrict__ wsum, const float *__restrict__ Wp,
+            const float *__restrict__ bias, float *__restrict__ R,
+            float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu, int lda,
+            int ldo, const int *__restrict__ omap) {
+  constexpr int WGN = 4 / WGM;
+  constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+  constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
+  constexpr int BI = (BN * 2 + 255) / 256;  // 16-byte loads of W per thread per k-tile
+  __shared__ __attribute__((aligned(16))) unsigned char A0[2][BM * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char A1[2][BM * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char B0[2][BN * kI8LD];
+  __shared__ __attribute__((aligned(16))) unsigned char B1[2][BN * kI8LD];
+  CDN_STAMPR(2, 0);
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
+  const float qs = reinterpret_cast<const float *>(aq)[2];
+  const float qz = reinterpret_cast<const float *>(aq)[3];
+  if (aq[6]) {
+    // Codes too wide for the nibble split (the tracked range is far narrower than the batch: the first
+    // ~100 calls of a fresh EMA): this batch runs on f32 MFMA with the fake-quantised weights, inside
+    // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
+    // do).  Simple single-buffered 16-deep k-tiles in the int8 path's LDS arrays: the rare path.
+    static_assert(BM * 17 * 4 <= 2 * BM * kI8LD && BN * 17 * 4 <= 2 * BN * kI8LD, "LDS reuse");
+    pwi8_wide_path<BM, BN, WGM>(A, Wp, bias, R, rmm, qu, M, C, Co, relu, lda, ldo, omap, qs, qz,
+                                reinterpret_cast<float *>(&A0[0][0]), reinterpret_cast<float *>(&B0[0][0]),
+                                reinterpret_cast<float *>(&A1[0][0]));
     return;
   }
   // as_uint(t + 1.5*2^23) = 0x4B400000 + rint(t) for |t| < 2^22 (guaranteed when state[6] == 0)
