@@ -117,8 +117,8 @@ class PoseShuffleNetV2(nn.Module):
         (--act-percentile, symmetric activations, larger resolutions) keeps the module-by-module path -- decided BEFORE any kernel runs, so no QuantAct
         state is half-updated.  Cached per (input shape, QuantAct configuration)."""
         from . import pipeline
-        cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat)
-                    for a in self.__dict__["_fused_acts"])
+        cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat,
+                     getattr(a, "global_range", False)) for a in self.__dict__["_fused_acts"])
         key = (tuple(x.shape), cfg)
         cache = self.__dict__.setdefault("_fused_ok_cache", {})
         if key not in cache:

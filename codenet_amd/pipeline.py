@@ -164,11 +164,26 @@ def gather_detections(dets, dst=None, counts=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
+def set_global_range(model, flag=True):
+    """Multi-process parity mode of every QuantAct of `model` (collective 3): the batch extremes
+    are all-reduced (MIN / MAX, two 4-byte collectives per QuantAct call, RCCL over xGMI / gloo) before the range
+    update, so R ranks x B images track the ranges of one R*B-image run.  Such QuantActs keep the module-by-module
+    path (the fused schedules update ranges inside the producing kernels).  Returns the number of QuantActs set."""
+    from .portable_quantizer.quant_modules import QuantAct
+    n = 0
+    for m in model.modules():
+        if isinstance(m, QuantAct):
+            m.global_range = bool(flag)
+            n += 1
+    return n
+
+
 def act_fusable(act):
     """The fused schedules implement the reference's default QuantAct: plain batch min/max tracking,
     asymmetric, quantising (quant_modules.py:163-225 with percentile=False).  --act-percentile, symmetric
     activations and full_precision_flag stay on the module path."""
-    return (act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag)
+    return (act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag
+            and not (getattr(act, "global_range", False) and act.running_stat))
 
 
 def uniform_act_settings(acts, what):

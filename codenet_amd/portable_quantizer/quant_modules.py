@@ -172,6 +172,11 @@ class QuantAct(Module):
         self.register_buffer("x_max", torch.zeros(1))
         self.act_function = _quant_function(quant_mode)
         self._state = None
+        # multi-process parity mode (collective 3; not in the reference, which has one process):
+        # the batch extremes are all-reduced (MIN / MAX) over the process group before the range update, so that R
+        # ranks with B images each track exactly the ranges of ONE process running all R*B images.  Off by default
+        # (per-rank ranges = R independent reference runs); pipeline.set_global_range(model, True) turns it on.
+        self.global_range = False
 
     def __repr__(self):
         return "{0}(activation_bit={1}, full_precision_flag={2}, Act_min: {3:.2f}, " \
@@ -187,6 +192,21 @@ class QuantAct(Module):
             self._state = ops.quantact_state(device)
         return self._state
 
+    def _global_extremes(self, x):
+        """(min, max) of x over ALL ranks as 1-element tensors, or None when the mode is off / there is one rank."""
+        import torch.distributed as dist
+        if not (getattr(self, "global_range", False) and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1):
+            return None
+        if self.percentile:
+            raise NotImplementedError("QuantAct: global_range with percentile statistics is not defined "
+                                      "(a percentile of the union is not a function of the ranks' percentiles)")
+        xd = x.detach()
+        bmin, bmax = xd.min().reshape(1).contiguous(), xd.max().reshape(1).contiguous()
+        dist.all_reduce(bmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(bmax, op=dist.ReduceOp.MAX)
+        return bmin, bmax
+
     def _native_ok(self, x):
         return (x.is_cuda and x.dtype == torch.float32 and self.quant_mode == "asymmetric"
                 and not self.full_precision_flag
@@ -194,7 +214,8 @@ class QuantAct(Module):
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.requires_grad
-                and self.quant_mode == "asymmetric" and not self.full_precision_flag and not self.percentile):
+                and self.quant_mode == "asymmetric" and not self.full_precision_flag and not self.percentile
+                and not getattr(self, "global_range", False)):
             # training: the same device kernel, straight-through backward (quant_utils.py:202-204)
             from ..functions.codenet_stage import QuantActSTE
             return QuantActSTE.apply(x, self)
@@ -204,6 +225,10 @@ class QuantAct(Module):
                 bmin, bmax = get_percentile_min_max(x.detach().view(-1), 0.1, 99.9,
                                                     output_tensor=True)
                 bmin, bmax = bmin.reshape(1).contiguous(), bmax.reshape(1).contiguous()
+            if self.running_stat:
+                glob = self._global_extremes(x)
+                if glob is not None:
+                    bmin, bmax = glob
             out, _ = ops.quantact_forward(x, self.x_min, self.x_max, self._device_state(x.device),
                                           bits=self.activation_bit, momentum=self.momentum,
                                           running=self.running_stat, batch_min=bmin, batch_max=bmax)
@@ -215,6 +240,9 @@ class QuantAct(Module):
             else:
                 x_min, x_max = get_percentile_min_max(x.detach().view(-1), 0.1, 99.9,
                                                       output_tensor=True)
+            glob = self._global_extremes(x)
+            if glob is not None:
+                x_min, x_max = glob[0][0], glob[1][0]
             if self.x_min == self.x_max:     # "initialisation": += (reference :211-213)
                 self.x_min += x_min
                 self.x_max += x_max

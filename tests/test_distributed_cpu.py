@@ -52,6 +52,48 @@ def test_broadcast_and_sharding_world2(tmp_path):
     assert [r["shard"] for r in res] == [(0, 7), (7, 13)]          # contiguous, sizes differ by <= 1
 
 
+def _worker_global_range(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+    torch.manual_seed(0)
+    full = [torch.randn(6, 5, 4, 4) * (1.0 + 0.5 * i) + 0.3 * i for i in range(4)]       # the "one process" batches
+    act = QuantAct(8, quant_mode="asymmetric")
+    assert pipeline.set_global_range(act, True) == 1
+    lo, hi = pipeline.shard_range(6, rank, world)
+    outs = [act(x[lo:hi]) for x in full]
+    torch.save({"outs": outs, "x_min": act.x_min.clone(), "x_max": act.x_max.clone(), "shard": (lo, hi)}, out % rank)
+    dist.destroy_process_group()
+
+
+def test_global_range_mode_equals_one_process_world2(tmp_path):
+    """SURVEY 8(e)(3) parity mode: with QuantAct.global_range the batch extremes are all-reduced (MIN / MAX), so two
+    ranks with 3 images each track EXACTLY the ranges -- and produce exactly the outputs -- of one process running
+    all 6 images, over four forwards (the '+=' initialisation and three EMA steps)."""
+    world = 2
+    out = str(tmp_path / "g%d.pt")
+    mp.spawn(_worker_global_range, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = [torch.load(out % r) for r in range(world)]
+    sys.path.insert(0, ROOT)
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+    torch.manual_seed(0)
+    full = [torch.randn(6, 5, 4, 4) * (1.0 + 0.5 * i) + 0.3 * i for i in range(4)]
+    ref = QuantAct(8, quant_mode="asymmetric")
+    ref_outs = [ref(x) for x in full]
+    for r in res:
+        lo, hi = r["shard"]
+        assert torch.equal(r["x_min"], ref.x_min) and torch.equal(r["x_max"], ref.x_max)
+        for a, b in zip(r["outs"], ref_outs):
+            assert torch.equal(a, b[lo:hi])
+    # and without the mode the ranks' ranges differ from the one-process run (the mode is what makes them equal)
+    own = QuantAct(8, quant_mode="asymmetric")
+    for x in full:
+        own(x[:3])
+    assert not torch.equal(own.x_min, ref.x_min) or not torch.equal(own.x_max, ref.x_max)
+
+
 def test_shard_range_partitions():
     from codenet_amd.pipeline import shard_range
     for total in (1, 7, 64, 256, 257):
