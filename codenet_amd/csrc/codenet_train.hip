@@ -250,3 +250,81 @@ extern "C" int cdn_codenet_scale_backward(const float *x, const float *grad_s, c
                                                              HW);
   return cdn::check_launch("codenet scale backward");
 }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// weight_prep_kernel: the per-step WEIGHT transformation of a quantised convolution in ONE launch --
+//   [BN fold]  wf = w * sf[co];  b = (conv_bias - mean) * sf + beta              (quant_modules.py:365-372; the
+//              per-channel factor sf = gamma / sqrt(var + eps) itself comes from the caller as two framework ops:
+//              PyTorch-ROCm's sqrt is not the correctly rounded one, and sf must be the framework's bit for bit)
+//   per output channel (symmetric, per_channel=True, no percentile):
+//              mag = max(|min_k wf|, |max_k wf|); scale = n / clamp(mag, 1e-10)  (quant_utils.py:78-84)
+//              q = clamp(round(scale * wf), -n-1, n); wq = q / scale             (:33-52, 207-225)
+// The reference (and the module mirror) run this as ~15 framework ops per convolution and step, recomputed in every
+// forward; three convolutions x three stages = the ~25 % of the QAT step that were PyTorch elementwise / reduction
+// kernels (profiles/r02/train_step_kernel_stats.csv).  Every operation is rounded on its own exactly like the
+// separate framework kernels (`n / t` = reciprocal * n: two roundings; true divisions; no FMA contraction), so wq and
+// b are BIT-IDENTICAL to the torch composition (tests/test_train_step.py).  One wave per output channel.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__restrict__ sf_in,
+                   const float *__restrict__ bn_b, const float *__restrict__ bn_mean,
+                   const float *__restrict__ conv_bias, float nlev, float *__restrict__ wq,
+                   float *__restrict__ b_out) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (co >= Co) return;
+  float sf = 1.0f;
+  const bool fold = sf_in != nullptr;
+  if (fold) {
+    sf = sf_in[co];
+    if (lane == 0) {
+      const float cb = conv_bias ? conv_bias[co] : 0.0f;
+      const float t = cb - bn_mean[co];
+      const float p = t * sf;
+      b_out[co] = p + bn_b[co];
+    }
+  }
+  const float *wr = w + (long)co * K;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) {
+    const float v = fold ? wr[k] * sf : wr[k];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  }
+  const float mag = fmaxf(fabsf(mn), fabsf(mx));
+  const float rcp = __fdiv_rn(1.0f, fmaxf(mag, 1e-10f));
+  const float scale = rcp * nlev;
+  float *out = wq + (long)co * K;
+  for (int k = lane; k < K; k += 64) {
+    const float v = fold ? wr[k] * sf : wr[k];
+    const float pq = scale * v;
+    const float q = fminf(fmaxf(rintf(pq), -(nlev + 1.0f)), nlev);
+    out[k] = __fdiv_rn(q, scale);
+  }
+}
+
+}  // namespace
+
+extern "C" int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor,
+                                       const float *bn_bias, const float *bn_mean, const float *conv_bias, int bits,
+                                       float *w_q, float *bias_out, void *stream) {
+  CDN_REQUIRE(w && w_q, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(Co > 0 && K > 0 && Co * K < (1ll << 31), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(bits >= 2 && bits <= 8, CDN_ERR_ARG, "bits must be in [2, 8]");
+  const bool fold = scale_factor != nullptr;
+  CDN_REQUIRE(!fold || (bn_bias && bn_mean && bias_out), CDN_ERR_ARG,
+              "the BN fold needs scale_factor, bias, running_mean and bias_out together");
+  hipStream_t st = cdn::as_stream(stream);
+  const float nlev = (float)((1 << (bits - 1)) - 1);
+  weight_prep_kernel<<<(unsigned)cdn::ceil_div(Co, 4), 256, 0, st>>>(w, (int)Co, (int)K, scale_factor, bn_bias, bn_mean,
+                                                                     conv_bias, nlev, w_q, bias_out);
+  return cdn::check_launch("codenet weight prep");
+}

@@ -148,6 +148,80 @@ class QuantActSTE(Function):
         return g, None
 
 
+class FakeQuantWeight(Function):
+    """Per-output-channel symmetric weight fake-quantisation in one launch (cdn_codenet_weight_prep), straight-through
+    backward (SymmetricQuantFunction.backward returns grad_output.clone(), quant_utils.py:227-229).  Bit-identical to
+    the torch composition in portable_quantizer (min / max per channel, n / clamp(mag), round, clamp, true division)."""
+
+    @staticmethod
+    def forward(ctx, w, bits):
+        w = w.contiguous()
+        out = torch.empty_like(w)
+        co = w.shape[0]
+        rc = N_.lib().cdn_codenet_weight_prep(_p(w), co, w.numel() // co, None, None, None, None, int(bits),
+                                              _p(out), None, ops._stream(w))
+        N_.check(rc, "cdn_codenet_weight_prep")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone(), None
+
+
+class FoldFakeQuantWeight(Function):
+    """QuantBnConv2d's weight path in one launch: BN fold from the running statistics, then per-channel symmetric
+    fake-quantisation; returns (w_q, folded fp32 bias).  Backward = autograd of the reference's composition
+    (quant_modules.py:365-372 under a straight-through quantiser): with sf = gamma / sqrt(var + eps),
+    grad_w = g * sf, grad_gamma = (sum_k g * w + grad_b * (conv_bias - mean)) / sqrt(var + eps), grad_beta = grad_b,
+    grad_conv_bias = grad_b * sf."""
+
+    @staticmethod
+    def forward(ctx, w, conv_bias, gamma, beta, mean, var, eps, bits):
+        w = w.contiguous()
+        co = w.shape[0]
+        wq = torch.empty_like(w)
+        b = torch.empty(co, device=w.device)
+        # the per-channel factor with the framework's own sqrt / division (PyTorch-ROCm's sqrt is not the correctly
+        # rounded one; the factor must be the framework's bit for bit): two tiny ops, everything else is the kernel
+        std = torch.sqrt(var + eps)
+        sf = (gamma / std).contiguous()
+        rc = N_.lib().cdn_codenet_weight_prep(_p(w), co, w.numel() // co, _p(sf), _p(beta.contiguous()),
+                                              _p(mean.contiguous()),
+                                              _p(conv_bias.contiguous()) if conv_bias is not None else None, int(bits),
+                                              _p(wq), _p(b), ops._stream(w))
+        N_.check(rc, "cdn_codenet_weight_prep")
+        ctx.save_for_backward(w, sf, std, mean, conv_bias)
+        ctx.has_cb = conv_bias is not None
+        return wq, b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_wq, g_b):
+        w, sf, std, mean, conv_bias = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        shape = (-1,) + (1,) * (w.dim() - 1)
+        g_w = g_wq * sf.view(shape) if need[0] else None
+        g_cb = g_gamma = g_beta = None
+        if need[2]:
+            g_sf = (g_wq * w).flatten(1).sum(1)
+            cbm = (conv_bias - mean) if ctx.has_cb else -mean
+            g_sf = g_sf + g_b * cbm
+            g_gamma = g_sf / std                                # d sf / d gamma = 1 / running_std
+        if need[3]:
+            g_beta = g_b.clone()
+        if ctx.has_cb and need[1]:
+            g_cb = g_b * sf
+        return g_w, g_cb, g_gamma, g_beta, None, None, None, None
+
+
+def native_weight_prep_ok(w, quantizer):
+    """Training-time weight transformation on the device kernel: per-channel symmetric fake-quantisation with plain
+    min / max ranges (the configuration of the README's W4A8 commands without --wt-percentile)."""
+    return (w.is_cuda and w.dtype == torch.float32 and torch.is_grad_enabled() and quantizer.per_channel
+            and quantizer.quant_mode == "symmetric" and not quantizer.weight_percentile
+            and not quantizer.full_precision_flag and not quantizer.quantize_bias)
+
+
 def native_act_ok(act):
     """The device QuantAct implements the reference's default: asymmetric, plain batch min/max, quantising."""
     return act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag

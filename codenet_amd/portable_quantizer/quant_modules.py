@@ -89,6 +89,9 @@ class _WeightQuantizer:
     def _fake_quant_weight(self, w, out_channels):
         if self.full_precision_flag:
             return w
+        from ..functions import codenet_stage as CS
+        if CS.native_weight_prep_ok(w, self):      # QAT step on the GPU: one launch, bit-identical values
+            return CS.FakeQuantWeight.apply(w, self.weight_bit)
         if self.per_channel:
             if self.quantize_bias:
                 raise NotImplementedError("channel-wise quantize bias is not supported")
@@ -306,6 +309,11 @@ class QuantBnConv2d(Module, _WeightQuantizer):
     def folded(self):
         """(fake-quantised folded weight, fp32 folded bias)."""
         def compute():
+            from ..functions import codenet_stage as CS
+            if CS.native_weight_prep_ok(self.conv.weight, self):      # QAT step on the GPU: fold + quantiser fused
+                return CS.FoldFakeQuantWeight.apply(self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
+                                                    self.bn.running_mean, self.bn.running_var, self.bn.eps,
+                                                    self.weight_bit)
             running_std = torch.sqrt(self.bn.running_var + self.bn.eps)
             scale_factor = self.bn.weight / running_std
             w = self.conv.weight * scale_factor.reshape([self.conv.out_channels, 1, 1, 1])

@@ -155,6 +155,16 @@ int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, fl
  *   grad_x [N][C][H*W] += w_scale[c] * grad_s  (ACCUMULATED into, normally the gather's grad_x; may be NULL),
  *   grad_w_partial [N][C] = sum_p x * grad_s per image (overwritten; the caller sums over n; may be NULL).
  * ---------------------------------------------------------------------------------------- */
+/* cdn_codenet_weight_prep: the per-forward WEIGHT transformation of Quant_Conv2d / QuantDeformConv2d / QuantBnConv2d
+ *   (quant_modules.py:278-300 / 473-495 / 364-372 + SymmetricQuantFunction, quant_utils.py:207-225) in one launch:
+ *   optional BN fold (scale_factor != NULL: [Co] = gamma / sqrt(running_var + eps), computed by the caller;
+ *   w * scale_factor per output channel, bias_out = (conv_bias - mean) * scale_factor + beta, conv_bias may be NULL
+ *   = 0), then per-output-channel symmetric fake-quantisation to `bits` bits (plain min / max ranges:
+ *   per_channel=True, no --wt-percentile).  w [Co][K] -> w_q [Co][K].  Every operation is rounded like the
+ *   reference's separate framework kernels: bit-identical to that composition. */
+int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor, const float *bn_bias,
+                            const float *bn_mean, const float *conv_bias, int bits, float *w_q, float *bias_out,
+                            void *stream);
 size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW);
 int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b, int64_t N,
                                 int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
