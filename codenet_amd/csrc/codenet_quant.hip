@@ -11,6 +11,8 @@
 // compiler cannot contract them into FMAs: identical fp32 inputs give identical integer codes.
 #include "cdn_common.h"
 
+#include <algorithm>
+
 namespace {
 
 using cdn::f2ord;
@@ -31,6 +33,9 @@ __global__ void minmax_init_kernel(unsigned *s0, unsigned *s1, unsigned *s2) {
     }
 }
 
+// RELU: the extremes of max(x, 0) (the block ReLU -> QuantAct of the training path reads the pre-ReLU tensor once);
+// min / max commute with the monotone ReLU, so it is applied to the two reduced values
+template <bool RELU>
 __global__ void __launch_bounds__(256)
 minmax_kernel(const float *__restrict__ x, long n, unsigned *state) {
   float mn = INFINITY, mx = -INFINITY;
@@ -71,6 +76,10 @@ minmax_kernel(const float *__restrict__ x, long n, unsigned *state) {
   if (threadIdx.x == 0) {
     mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
     mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    if (RELU) {
+      mn = fmaxf(mn, 0.0f);
+      mx = fmaxf(mx, 0.0f);
+    }
     atomicMin(&state[0], f2ord(mn));
     atomicMax(&state[1], f2ord(mx));
   }
@@ -147,6 +156,63 @@ fake_quant_kernel(const float *__restrict__ x, float *__restrict__ out, int16_t 
   }
 }
 
+// Block `ReLU(inplace) -> QuantAct -> Upsample(x2, nearest)` that follows every deform stage
+// (lib/models/networks/shufflenetv2_dcn.py:303-308; quantize_model.py:79-81), training path: one pass that reads the
+// pre-ReLU tensor y [rows = planes*H][W] and writes the fake-quantised values of max(y, 0) to the 2x2 replicas
+// out [rows*2][2W] -- instead of relu (read + write), fake_quant (read + write) and upsample (read + 4 writes).
+// A thread handles two neighbouring inputs of a row: one 16-byte store per output row.
+__global__ void __launch_bounds__(256)
+relu_fq_up2_kernel(const float *__restrict__ y, float *__restrict__ out, long rows, int W,
+                   const unsigned *__restrict__ state) {
+  const float scale = reinterpret_cast<const float *>(state)[2];
+  const float zp = reinterpret_cast<const float *>(state)[3];
+  const int Wh = (W + 1) >> 1;
+  const long total = rows * Wh;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Wh;
+    const int w0 = (int)(i - r * Wh) * 2;
+    const bool two = w0 + 1 < W;
+    const float a = fmaxf(y[r * W + w0], 0.0f), b = two ? fmaxf(y[r * W + w0 + 1], 0.0f) : 0.0f;
+    const float qa = __fdiv_rn(__fadd_rn(quant_code(a, scale, zp), zp), scale);
+    const float qb = __fdiv_rn(__fadd_rn(quant_code(b, scale, zp), zp), scale);
+    float *o = out + (r * 2) * (2L * W) + 2 * w0;
+    if (two && (W & 1) == 0) {
+      const float4 v = make_float4(qa, qa, qb, qb);
+      *reinterpret_cast<float4 *>(o) = v;
+      *reinterpret_cast<float4 *>(o + 2L * W) = v;
+    } else {
+      o[0] = qa; o[1] = qa; o[2L * W] = qa; o[2L * W + 1] = qa;
+      if (two) { o[2] = qb; o[3] = qb; o[2L * W + 2] = qb; o[2L * W + 3] = qb; }
+    }
+  }
+}
+
+// backward of that block: grad_y[r][w] = (sum of the 2x2 replicas' gradients) * (y > 0)   (straight-through QuantAct,
+// quant_utils.py:202-204; threshold backward of ReLU; nearest-upsample backward = sum over the replicas, added in
+// row-major order like at::native::upsample_nearest2d_backward)
+__global__ void __launch_bounds__(256)
+up2_relu_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, float *__restrict__ gy, long rows, int W) {
+  const int Wh = (W + 1) >> 1;
+  const long total = rows * Wh;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Wh;
+    const int w0 = (int)(i - r * Wh) * 2;
+    const bool two = w0 + 1 < W;
+    const float *p = g + (r * 2) * (2L * W) + 2 * w0;
+    float sa, sb = 0.0f;
+    if (two && (W & 1) == 0) {
+      const float4 t = *reinterpret_cast<const float4 *>(p), u = *reinterpret_cast<const float4 *>(p + 2L * W);
+      sa = ((t.x + t.y) + u.x) + u.y;
+      sb = ((t.z + t.w) + u.z) + u.w;
+    } else {
+      sa = ((p[0] + p[1]) + p[2L * W]) + p[2L * W + 1];
+      if (two) sb = ((p[2] + p[3]) + p[2L * W + 2]) + p[2L * W + 3];
+    }
+    gy[r * W + w0] = y[r * W + w0] > 0.0f ? sa : 0.0f;
+    if (two) gy[r * W + w0 + 1] = y[r * W + w0 + 1] > 0.0f ? sb : 0.0f;
+  }
+}
+
 // Every workgroup ends with two atomics on the SAME two words, and one contended word sustains only ~88
 // atomics/us on MI355X: 2048 workgroups cost ~35 us per launch whatever the tensor size (measured in the QAT
 // step, 9 launches).  512 workgroups (2 per CU, 4 loads in flight per thread) keep the tail at ~6 us.
@@ -199,11 +265,45 @@ extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, 
   unsigned *stt = static_cast<unsigned *>(state);
   if (running && !batch_min) {
     cdn::launch_minmax_init(stt, nullptr, nullptr, st);
-    minmax_kernel<<<minmax_grid(numel), 256, 0, st>>>(x, (long)numel, stt);
+    minmax_kernel<false><<<minmax_grid(numel), 256, 0, st>>>(x, (long)numel, stt);
   }
   cdn::launch_quantact_update(x_min, x_max, stt, batch_min, batch_max, nullptr, 0, bits, momentum,
                               running, st);
   if (out || codes)
     fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, codes, (long)numel, stt);
   return cdn::check_launch("quantact forward");
+}
+
+extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
+                                             float *x_min, float *x_max, void *state, int bits, double momentum,
+                                             int running, void *stream) {
+  CDN_REQUIRE(y && out && x_min && x_max && state, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * H * W < (1ll << 31), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+              CDN_ERR_ARG, "tensors must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  unsigned *stt = static_cast<unsigned *>(state);
+  const long numel = (long)(planes * H * W);
+  if (running) {
+    cdn::launch_minmax_init(stt, nullptr, nullptr, st);
+    minmax_kernel<true><<<minmax_grid(numel), 256, 0, st>>>(y, numel, stt);
+  }
+  cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, nullptr, 0, bits, momentum, running, st);
+  const long rows = (long)(planes * H);
+  relu_fq_up2_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
+                       256, 0, st>>>(y, out, rows, (int)W, stt);
+  return cdn::check_launch("quantact relu up2 forward");
+}
+
+extern "C" int cdn_up2_relu_backward(const float *grad_out, const float *y, float *grad_y, int64_t planes, int64_t H,
+                                     int64_t W, void *stream) {
+  CDN_REQUIRE(grad_out && y && grad_y, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * H * W < (1ll << 29), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(grad_out) & 15) == 0, CDN_ERR_ARG, "grad_out must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const long rows = (long)(planes * H);
+  up2_relu_bwd_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
+                        256, 0, st>>>(grad_out, y, grad_y, rows, (int)W);
+  return cdn::check_launch("up2 relu backward");
 }

@@ -222,6 +222,61 @@ def native_weight_prep_ok(w, quantizer):
             and not quantizer.full_precision_flag and not quantizer.quantize_bias)
 
 
+class ReluQuantUpsample(Function):
+    """The block after every deform stage -- ReLU(inplace) -> QuantAct -> Upsample(x2, nearest)
+    (lib/models/networks/shufflenetv2_dcn.py:303-308 after quantize_model.py:79-81) -- as one autograd function on two
+    kernels: forward reads the pre-ReLU tensor once (range tracking on max(y, 0), then the fake-quantised values
+    written straight to their 2x2 replicas); backward sums the replicas' gradients where y > 0 (straight-through
+    QuantAct).  Same values as the three modules (tests/test_train_step.py)."""
+
+    @staticmethod
+    def forward(ctx, y, act):
+        ops._gpu_f32(y)
+        y = y.contiguous()
+        Nb, C, H, W = y.shape
+        out = torch.empty(Nb, C, 2 * H, 2 * W, device=y.device)
+        rc = N_.lib().cdn_quantact_relu_up2_forward(_p(y), _p(out), Nb * C, H, W, _p(act.x_min), _p(act.x_max),
+                                                    _p(act._device_state(y.device)), int(act.activation_bit),
+                                                    float(act.momentum), int(bool(act.running_stat)), ops._stream(y))
+        N_.check(rc, "cdn_quantact_relu_up2_forward")
+        ctx.save_for_backward(y)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        Nb, C, H, W = y.shape
+        gy = torch.empty_like(y)
+        rc = N_.lib().cdn_up2_relu_backward(_p(g), _p(y), _p(gy), Nb * C, H, W, ops._stream(y))
+        N_.check(rc, "cdn_up2_relu_backward")
+        return gy, None
+
+
+def forward_stage_blocks(seq, x):
+    """``seq(x)`` for a quantised ``deconv_layers`` Sequential; in the QAT step on the GPU the block
+    [ReLU, QuantAct] + Upsample(x2, nearest) behind every stage runs as ReluQuantUpsample (one forward and one
+    backward kernel instead of relu / fake-quant / upsample and their three backward kernels)."""
+    import torch.nn as nn
+    from ..portable_quantizer.quant_modules import QuantAct, QuantDeformConvWithOffsetScaleBoundPositive
+    mods = list(seq)
+
+    def block_ok(q, post, up):
+        return (isinstance(q, QuantDeformConvWithOffsetScaleBoundPositive) and isinstance(post, nn.Sequential)
+                and len(post) == 2 and isinstance(post[0], nn.ReLU) and isinstance(post[1], QuantAct)
+                and native_act_ok(post[1]) and not getattr(post[1], "global_range", False)
+                and isinstance(up, nn.Upsample) and up.mode == "nearest" and up.size is None
+                and up.scale_factor in (2, 2.0, (2, 2), (2.0, 2.0)))
+
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and len(mods) % 3 == 0 and mods
+            and all(block_ok(*mods[i:i + 3]) for i in range(0, len(mods), 3))):
+        return seq(x)
+    for i in range(0, len(mods), 3):
+        x = ReluQuantUpsample.apply(mods[i](x), mods[i + 1][1])
+    return x
+
+
 def native_act_ok(act):
     """The device QuantAct implements the reference's default: asymmetric, plain batch min/max, quantising."""
     return act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag

@@ -151,7 +151,8 @@ class PoseShuffleNetV2(nn.Module):
             x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
             return [self._fheads(*self._fpath.forward_nhwc(x))]
         x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
-        x = self.deconv_layers(x)
+        from .functions.codenet_stage import forward_stage_blocks
+        x = forward_stage_blocks(self.deconv_layers, x)      # == self.deconv_layers(x); fused blocks in the QAT step
         return [{head: getattr(self, head)(x) for head in self.heads}]
 
 

@@ -45,7 +45,8 @@ class DeconvLayers(nn.Module):
         self.deconv_layers = nn.Sequential(*layers)
 
     def forward(self, x):
-        return self.deconv_layers(x)
+        from .functions.codenet_stage import forward_stage_blocks
+        return forward_stage_blocks(self.deconv_layers, x)      # (== self.deconv_layers(x); fused blocks in the QAT step)
 
 
 def build_hot_path(w2=False, quantized=True, seed=317, scale_std=3.0, planes=None):

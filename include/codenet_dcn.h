@@ -205,6 +205,16 @@ int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t num
                          float *x_max, void *state, const float *batch_min,
                          const float *batch_max, int bits, double momentum, int running,
                          void *stream);
+/* Training-path block `ReLU(inplace) -> QuantAct -> Upsample(x2, nearest)` that follows every deform stage
+ * (lib/models/networks/shufflenetv2_dcn.py:303-308 after quantize_model.py:79-81) as ONE QuantAct call that reads the
+ * pre-ReLU tensor y [planes][H][W] once: range tracking on max(y, 0) exactly as cdn_quantact_forward would on the
+ * ReLU output (x_min / x_max updated in place when running), out [planes][2H][2W] = the fake-quantised values
+ * replicated 2x2.  cdn_up2_relu_backward: grad_y = (sum of the four replicas of grad_out) where y > 0, else 0
+ * (straight-through QuantAct, quant_utils.py:202-204). */
+int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t planes, int64_t H, int64_t W, float *x_min,
+                                  float *x_max, void *state, int bits, double momentum, int running, void *stream);
+int cdn_up2_relu_backward(const float *grad_out, const float *y, float *grad_y, int64_t planes, int64_t H, int64_t W,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One whole up-sampling stage of the head as a fused kernel schedule (codenet_fused.hip):
