@@ -507,14 +507,17 @@ class FrozenHotPath:
         had to run on the fp32 schedule), r_state pointer, the stage's shape dict).  Input as FusedHotPath.forward_nhwc."""
         from . import _native as N_
         nhwc_in = hw is not None
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == (3 if nhwc_in else 4)):
-            raise NotImplementedError("FrozenHotPath needs a float32 GPU tensor: NCHW, or [N, H*W, C] with hw")
+        codes_in = x.dtype == torch.int8       # byte codes of the QuantAct whose state is x_qstate (a frozen backbone)
+        if not (x.is_cuda and (x.dtype == torch.float32 or (codes_in and nhwc_in and x_qstate is not None))
+                and x.dim() == (3 if nhwc_in else 4)):
+            raise NotImplementedError("FrozenHotPath needs a GPU tensor: float32 NCHW, float32 [N, H*W, C] with hw "
+                                      "and its QuantAct state, or int8 codes [N, H*W, C] with hw and the state")
         x = x.contiguous()
         shape = (x.shape[0], x.shape[2], hw[0], hw[1]) if nhwc_in else tuple(x.shape)
         dev = x.device
         # the cached pointer arrays name the QuantActs' range buffers: a re-assigned buffer (load_state_dict(assign=
         # True), a .to() round trip) must rebuild them, so their addresses are part of the key
-        key = (shape, dev, nhwc_in) + tuple(p for st in self.stages for a in self._acts(st)
+        key = (shape, dev, nhwc_in, codes_in) + tuple(p for st in self.stages for a in self._acts(st)
                                             for p in (a.x_min.data_ptr(), a.x_max.data_ptr()))
         if self._bufs is None or self._bufs["key"] != key:
             self._alloc(shape, dev, nhwc_in, key)
@@ -532,7 +535,7 @@ class FrozenHotPath:
         ws_ptr = (B["ws"].data_ptr() + 255) // 256 * 256
         ws_bytes = B["ws"].numel() - (ws_ptr - B["ws"].data_ptr())
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-        cur_ptr, cur_kind, cur_q = x.data_ptr(), (1 if nhwc_in else 0), (x_qstate if nhwc_in else None)
+        cur_ptr, cur_kind, cur_q = x.data_ptr(), (2 if codes_in else 1 if nhwc_in else 0), (x_qstate if nhwc_in else None)
         with torch.no_grad():
             for st, sb in zip(self.stages, B["stages"]):
                 q = st[0]
@@ -605,10 +608,16 @@ class FrozenHotPath:
             self._bufs["overflow"].zero_()
         return flag
 
-    def capture(self, x, codes_only=True):
+    def capture(self, x, codes_only=True, x_qstate=None, hw=None):
         """One pass over the static buffer `x` as a HIP graph; returns replay() -> the static output (byte codes
-        of the last stage with codes_only, else the unpacked NCHW tensor)."""
-        run = (lambda t: self.forward_codes(t)[0]) if codes_only else self.__call__
+        of the last stage with codes_only, else the unpacked NCHW tensor).  x_qstate / hw: a channels-last input
+        (fp32 pre-quantisation values or int8 codes) as in forward_codes."""
+        if hw is not None:
+            if not codes_only:
+                raise NotImplementedError("a channels-last input is captured with codes_only")
+            run = lambda t: self.forward_codes(t, x_qstate, hw)[0]      # noqa: E731
+        else:
+            run = (lambda t: self.forward_codes(t)[0]) if codes_only else self.__call__
         run(x)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

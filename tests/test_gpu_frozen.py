@@ -126,6 +126,34 @@ def test_frozen_nhwc_input_with_quantiser_state():
     assert torch.equal(b, (torch.round(st[2] * a - st[3]) + st[3]) / st[2])
 
 
+@pytest.mark.parametrize("planes,res,n", [([64, 32, 16, 8], 8, 3), ([1024, 256, 128, 64], 16, 8)])
+def test_frozen_byte_code_input_equals_its_expanded_values(planes, res, n):
+    """Stage 0 fed with BYTE CODES of the backbone's last QuantAct (x_kind 2: what a frozen byte-code backbone hands
+    over; 1 byte per element instead of the 4-byte pre-quantisation values read twice) -- the codes of every stage
+    must equal those computed from the fp32 channels-last input holding the same values (q + zp) / scale with the same
+    state (fake-quantising them on load returns them unchanged)."""
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+    net = pipeline.build_hot_path(quantized=True, planes=planes, seed=45).cuda()
+    xs = _inputs(n, planes[0], res, 2, 145)
+    act_in = QuantAct(8, quant_mode="asymmetric").cuda()
+    xq = act_in(xs[0].cuda())
+    _warm_and_freeze(net, [xq.cpu()])
+    act_in.running_stat = False
+    st = act_in._device_state(xq.device).view(torch.float32)
+    x_nhwc = xq.permute(0, 2, 3, 1).reshape(n, res * res, planes[0]).contiguous()     # final values (q + zp) / scale
+    codes = torch.round(st[2] * x_nhwc - st[3])
+    assert codes.abs().max().item() <= 128
+    x8 = codes.clamp(-128, 127).to(torch.int8).contiguous()
+    qptr = act_in._device_state(xq.device).data_ptr()
+    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    a = frz.forward_codes(x_nhwc, qptr, (res, res))[0].clone()
+    b = frz.forward_codes(x8, qptr, (res, res))[0].clone()
+    assert not frz.overflowed() and a.dtype == torch.int8 and torch.equal(a, b)
+    replay = frz.capture(x8, x_qstate=qptr, hw=(res, res))
+    assert torch.equal(replay(), a)
+
+
 def test_frozen_w2_stage0_runs_on_fp32_schedule():
     """CoDeNet2x: C = 2153 is not a multiple of 4 -> stage 0 on the fp32 frozen schedule, stages 1-2 on codes."""
     from codenet_amd import pipeline
