@@ -543,6 +543,21 @@ def main():
                 stepc()
             barrier()
             msc = (time.perf_counter() - t0) / args.steps * 1e3
+            frzc = pipeline.FrozenHotPath(net.deconv_layers, chain_scale=True)
+            stepcc = frzc.capture(x8, x_qstate=qptr, hw=(H0, W0))
+            for _ in range(5):
+                stepcc()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                stepcc()
+            barrier()
+            mscc = (time.perf_counter() - t0) / args.steps * 1e3
+            frozen_leg["codes_in_chained_scale"] = {
+                "ms_per_step": mscc, "images_per_s": world * args.batch / mscc * 1e3, "overflow": bool(frzc.overflowed()),
+                "what": "as codes_in, with the scale prediction of stages 1-2 accumulated as exact integer sums in the "
+                        "previous stage's pointwise epilogue (7 launches instead of 9; declared non-bit-identical "
+                        "variant: the exact sum rounded once)"}
             frozen_leg["codes_in"] = {
                 "ms_per_step": msc, "images_per_s": world * args.batch / msc * 1e3, "overflow": bool(frz.overflowed()),
                 "what": "stage-0 input as int8 codes [N, H*W, C] of the backbone's last QuantAct + its state "

@@ -286,9 +286,18 @@ constexpr int kMaxPartials = 16384;
 int stage_channel_chunk(int Hl, int Wl);
 int launch_frozen_scale(const void *x, int x_kind, const unsigned *xq, const float *w_scale, const float *b_scale,
                         float *s_raw, int64_t N, int64_t C, int64_t HWl, float lo, float hi, hipStream_t st);
+// Frozen schedule, chained stages: the producer's pointwise epilogue leaves sums[m] = sum_co qw_s[co] * level_r[m][co]
+// (exact int32) and the consumer's gather forms s_raw = clamp(bias + sums / (sw * sc_r), lo, hi) itself (sc_r: scale of
+// its input quantiser).  sums == nullptr: s_raw comes from the scale kernel as usual.
+struct ScaleFromSums {
+  const int *sums;
+  const float *sw;      // device scalar: scale of the conv_scale weight codes (w = qw / sw)
+  const float *bias;    // device scalar or nullptr
+  float lo, hi;
+};
 int launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                      const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H, int W,
-                     int up, hipStream_t st);
+                     int up, hipStream_t st, ScaleFromSums si = ScaleFromSums{nullptr, nullptr, nullptr, 0.f, 0.f});
 // Workspace of the stand-alone layer entry points: partials first, arrival counters in the LAST bytes
 // (zeroed once by the caller); size = cdn_codenet_aux_workspace_bytes().
 struct AuxWs {

@@ -56,9 +56,16 @@ struct FrozenList {
   const float *x_max[kMaxFrozen];
   unsigned *state[kMaxFrozen];
   int n, bits;
+  int4 *zero;          // optional: zero_n16 16-byte words to clear (the chained schedule's integer scale sums)
+  long zero_n16;
 };
-__global__ void frozen_params_kernel(FrozenList f) {
+__global__ void __launch_bounds__(256) frozen_params_kernel(FrozenList f) {
 #pragma clang fp contract(off)
+  if (blockIdx.x > 0) {      // blocks 1.. clear the sums buffer (a separate memset node costs 4.7 us per buffer)
+    for (long q = (long)(blockIdx.x - 1) * 256 + threadIdx.x; q < f.zero_n16; q += (long)(gridDim.x - 1) * 256)
+      f.zero[q] = make_int4(0, 0, 0, 0);
+    return;
+  }
   const int i = threadIdx.x;
   if (i >= f.n) return;
   const float lo = f.x_min[i][0], hi = f.x_max[i][0];
@@ -92,7 +99,7 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
             const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
             const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int C, int Cpad, int Co,
-            int relu) {
+            int relu, const signed char *__restrict__ nsc, int *__restrict__ sacc) {
   constexpr int WGM = BM / 32, WGN = 4 / WGM, TN = BN / (32 * WGN);
   constexpr int AI = BM * kQK / 16 / 256;       // 16-byte loads of A per thread per k tile (1 or 2)
   constexpr int BI = BN * kQK / 16 / 256;       // of the weights (1, 2 or 4)
@@ -165,15 +172,25 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   // frozen range far from zero (large |zp|) can leave int32 long before |zp| reaches 4e6 -- flagged, never silent
   // (the fp32 schedule takes its wide-code f32 branch for such ranges)
   if (((long)abs(qzi) + 128) * 8 * (long)Cpad >= (1L << 31)) bad = 1;
+  // Scale prediction of the NEXT stage folded in (frozen schedule only, nsc != NULL): that stage's conv_scale is
+  // s_raw[m] = b + sum_co (qw_s[co] / sw) * ((q_r[m][co] + zp_r) / sc_r) -- a sum of integer products over a common
+  // denominator, so I[m] = sum_co qw_s[co] * (q_r + zp_r) is accumulated HERE in exact int32 (per row over this wave's
+  // columns, then one integer atomic per row: order-independent, reproducible) and the consumer's gather forms
+  // s_raw = b + I / (sw * sc_r) with one rounding -- instead of re-reading r in a separate scale launch.
+  int rowsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowsum[r] = 0;
+  const int zpr = (int)c8.qz;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
     float bsv = 0.f, rinv = 0.f;
-    int t128 = 0;
+    int t128 = 0, nq = 0;
     if (co < Co) {
       if (bias) bsv = bias[co];
       rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
       t128 = qzi * wsum[co];
+      if (nsc) nq = nsc[co];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -181,9 +198,24 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
       if (m < M && co < Co) {
         float v = fmaf((float)(acc[j][r] + t128), rinv, bsv);
         if (relu) v = fmaxf(v, 0.0f);
-        if (R8) R8[m * Co + co] = (signed char)act_code8(v, c8, bad);
-        else Rf[m * Co + co] = v;
+        if (R8) {
+          const int code = act_code8(v, c8, bad);
+          R8[m * Co + co] = (signed char)code;
+          rowsum[r] += nq * (code + zpr);
+        } else {
+          Rf[m * Co + co] = v;
+        }
       }
+    }
+  }
+  if (nsc && R8) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int v = rowsum[r];
+#pragma unroll
+      for (int msk = 16; msk > 0; msk >>= 1) v += __shfl_xor(v, msk, 64);      // over the 32 columns of this half-wave
+      const long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if ((lane & 31) == 0 && m < M) atomicAdd(&sacc[m], v);
     }
   }
   if (bad) atomicOr(oflow, 1u);
@@ -213,31 +245,49 @@ expand8_kernel(const signed char *__restrict__ a, const unsigned *__restrict__ a
 template <int BM, int BN>
 void launch_pwq8(const signed char *A, const unsigned *aq, const signed char *Wq, const float *ws, const int *wsum,
                  const float *bias, signed char *R8, float *Rf, const unsigned *rq, unsigned *oflow, long M, int C,
-                 int Co, int relu, hipStream_t st) {
+                 int Co, int relu, hipStream_t st, const signed char *nsc = nullptr, int *sacc = nullptr) {
   dim3 g((unsigned)cdn::ceil_div(M, BM), (unsigned)cdn::ceil_div(Co, BN));
   pwq8_kernel<BM, BN><<<g, 256, 0, st>>>(A, aq, Wq, ws, wsum, bias, R8, Rf, rq, oflow, M, C, (C + 63) / 64 * 64, Co,
-                                         relu);
+                                         relu, nsc, sacc);
 }
 
 }  // namespace
 
+static int frozen_params_impl(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
+                              void *zero, size_t zero_bytes, void *stream);
+
 extern "C" int cdn_quantact_frozen_params(int n, float *const *x_min, float *const *x_max, void *const *state,
                                           int bits, void *stream) {
+  return frozen_params_impl(n, x_min, x_max, state, bits, nullptr, 0, stream);
+}
+
+extern "C" int cdn_quantact_frozen_params_clear(int n, float *const *x_min, float *const *x_max, void *const *state,
+                                                int bits, void *clear, size_t clear_bytes, void *stream) {
+  CDN_REQUIRE(clear_bytes == 0 || (clear && (reinterpret_cast<uintptr_t>(clear) & 15) == 0 && (clear_bytes & 15) == 0),
+              CDN_ERR_ARG, "the buffer to clear must be 16-byte aligned and a multiple of 16 bytes");
+  return frozen_params_impl(n, x_min, x_max, state, bits, clear, clear_bytes, stream);
+}
+
+static int frozen_params_impl(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
+                              void *zero, size_t zero_bytes, void *stream) {
   CDN_REQUIRE(n >= 0 && n <= kMaxFrozen, CDN_ERR_ARG, "at most %d QuantActs per call", kMaxFrozen);
   CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
-  if (n == 0) return CDN_OK;
-  CDN_REQUIRE(x_min && x_max && state, CDN_ERR_ARG, "null pointer");
+  if (n == 0 && zero_bytes == 0) return CDN_OK;
+  CDN_REQUIRE(n == 0 || (x_min && x_max && state), CDN_ERR_ARG, "null pointer");
   FrozenList f;
   f.n = n;
   f.bits = bits;
-  for (int i = 0; i < kMaxFrozen; ++i) {
+  for (int i = 0; i < kMaxFrozen && n > 0; ++i) {
     const int j = i < n ? i : 0;
     CDN_REQUIRE(x_min[j] && x_max[j] && state[j], CDN_ERR_ARG, "null pointer in entry %d", j);
     f.x_min[i] = x_min[j];
     f.x_max[i] = x_max[j];
     f.state[i] = static_cast<unsigned *>(state[j]);
   }
-  frozen_params_kernel<<<1, 64, 0, cdn::as_stream(stream)>>>(f);
+  f.zero = static_cast<int4 *>(zero);
+  f.zero_n16 = (long)(zero_bytes / 16);
+  const int zblocks = (int)std::min<long>(cdn::ceil_div(f.zero_n16, 256 * 4), 256);
+  frozen_params_kernel<<<1 + zblocks, 256, 0, cdn::as_stream(stream)>>>(f);
   return cdn::check_launch("frozen QuantAct parameters");
 }
 
@@ -247,11 +297,11 @@ extern "C" size_t cdn_codenet_stage_frozen_workspace_bytes(int64_t N, int64_t C,
   return (size_t)(r(N * HWl * 4) + r(N * H * W * C));        // s_raw (fp32) + d (byte codes)
 }
 
-extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void *a_state, int64_t M, int64_t C,
-                                                int64_t Co, const signed char *w_codes, const float *w_scale,
-                                                const int *w_colsum, const float *bias, int relu,
-                                                const void *r_state, signed char *r8_out, float *r_out,
-                                                unsigned *overflow, void *stream) {
+static int pointwise_q8_impl(const signed char *a, const void *a_state, int64_t M, int64_t C,
+                             int64_t Co, const signed char *w_codes, const float *w_scale,
+                             const int *w_colsum, const float *bias, int relu,
+                             const void *r_state, signed char *r8_out, float *r_out,
+                             unsigned *overflow, void *stream, const signed char *nsc, int *sacc) {
   CDN_REQUIRE(a && a_state && w_codes && w_scale && w_colsum && overflow, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE((r8_out != nullptr) != (r_out != nullptr), CDN_ERR_ARG, "exactly one of r8_out / r_out");
   CDN_REQUIRE(r8_out == nullptr || r_state != nullptr, CDN_ERR_ARG, "byte output needs the output quantiser state");
@@ -274,7 +324,7 @@ extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void
     else break;
   }
 #define CDN_Q8(BM_, BN_) \
-  launch_pwq8<BM_, BN_>(a, aq, w_codes, w_scale, w_colsum, bias, r8_out, r_out, rq, overflow, (long)M, (int)C, (int)Co, relu, st)
+  launch_pwq8<BM_, BN_>(a, aq, w_codes, w_scale, w_colsum, bias, r8_out, r_out, rq, overflow, (long)M, (int)C, (int)Co, relu, st, nsc, sacc)
   if (bn == 256) CDN_Q8(64, 256);
   else if (bn == 128) { if (bm == 64) CDN_Q8(64, 128); else CDN_Q8(128, 128); }
   else { if (bm == 64) CDN_Q8(64, 64); else CDN_Q8(128, 64); }
@@ -282,13 +332,23 @@ extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void
   return cdn::check_launch("codenet pointwise on byte codes");
 }
 
-extern "C" int cdn_codenet_stage_frozen_forward(
+extern "C" int cdn_codenet_pointwise_q8_forward(const signed char *a, const void *a_state, int64_t M, int64_t C,
+                                                int64_t Co, const signed char *w_codes, const float *w_scale,
+                                                const int *w_colsum, const float *bias, int relu,
+                                                const void *r_state, signed char *r8_out, float *r_out,
+                                                unsigned *overflow, void *stream) {
+  return pointwise_q8_impl(a, a_state, M, C, Co, w_codes, w_scale, w_colsum, bias, relu, r_state, r8_out, r_out,
+                           overflow, stream, nullptr, nullptr);
+}
+
+static int stage_frozen_impl(
     const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
     const float *w_scale, const float *b_scale, float lo, float hi, const float *w_dw,
     const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
     const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
-    signed char *r8_out, unsigned *overflow, void *stream) {
-  CDN_REQUIRE(x && w_scale && w_dw && w_pw_codes && w_pw_scale && w_pw_colsum && s_state && d_state && r_state &&
+    signed char *r8_out, unsigned *overflow, void *stream, const int *s_acc_in, const float *w_scale_sw,
+    const signed char *next_scale_codes, int *s_acc_out) {
+  CDN_REQUIRE(x && (w_scale || s_acc_in) && w_dw && w_pw_codes && w_pw_scale && w_pw_colsum && s_state && d_state && r_state &&
                   workspace && r8_out && overflow, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(x_kind >= 0 && x_kind <= 2 && (x_up == 0 || x_up == 1), CDN_ERR_ARG, "bad x_kind / x_up");
   CDN_REQUIRE((x_kind == 0) == (x_state == nullptr), CDN_ERR_ARG,
@@ -311,8 +371,14 @@ extern "C" int cdn_codenet_stage_frozen_forward(
   signed char *d8 = static_cast<signed char *>(workspace) + r256(N * HWl * 4);
   const unsigned *xq = static_cast<const unsigned *>(x_state);
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
-  int rc;
-  {
+  int rc = 0;
+  cdn::ScaleFromSums si{nullptr, nullptr, nullptr, 0.f, 0.f};
+  if (s_acc_in) {
+    // the producer's pointwise epilogue left the integer sums of this stage's scale prediction: no scale launch
+    CDN_REQUIRE(x_kind == 2 && x_up == 1 && w_scale_sw, CDN_ERR_ARG,
+                "scale sums come with an up-sampled byte-code input and the conv_scale weight scale");
+    si = cdn::ScaleFromSums{s_acc_in, w_scale_sw, b_scale, lo, hi};
+  } else {
     cdn::ProfScope ps(cdn::kProfScale, ptag, st);
     rc = cdn::launch_frozen_scale(x, x_kind, xq, w_scale, b_scale, s_raw, N, C, HWl, lo, hi, st);
   }
@@ -321,12 +387,38 @@ extern "C" int cdn_codenet_stage_frozen_forward(
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     rc = cdn::launch_frozen_dw(x, x_kind, xq, s_raw, static_cast<const unsigned *>(s_state), w_dw, d8,
                                static_cast<unsigned *>(const_cast<void *>(d_state)), overflow, (int)N, (int)C, (int)H,
-                               (int)W, x_up, st);
+                               (int)W, x_up, st, si);
   }
   if (rc) return rc;
+  if (s_acc_out)      // (zero on entry: cleared by cdn_quantact_frozen_params_clear at the start of the step)
+    CDN_REQUIRE(next_scale_codes, CDN_ERR_ARG, "s_acc_out needs the next stage's conv_scale weight codes");
   cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
-  return cdn_codenet_pointwise_q8_forward(d8, d_state, N * H * W, C, Co, w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw,
-                                          relu, r_state, r8_out, nullptr, overflow, stream);
+  return pointwise_q8_impl(d8, d_state, N * H * W, C, Co, w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw, relu, r_state,
+                           r8_out, nullptr, overflow, stream, s_acc_out ? next_scale_codes : nullptr, s_acc_out);
+}
+
+extern "C" int cdn_codenet_stage_frozen_forward(
+    const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
+    const float *w_scale, const float *b_scale, float lo, float hi, const float *w_dw,
+    const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
+    const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
+    signed char *r8_out, unsigned *overflow, void *stream) {
+  return stage_frozen_impl(x, x_kind, x_up, x_state, N, C, Co, H, W, w_scale, b_scale, lo, hi, w_dw, w_pw_codes,
+                           w_pw_scale, w_pw_colsum, bias_pw, relu, s_state, d_state, r_state, workspace,
+                           workspace_bytes, r8_out, overflow, stream, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int cdn_codenet_stage_frozen_chained_forward(
+    const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
+    const float *w_scale, const float *b_scale, float lo, float hi, const float *w_dw,
+    const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
+    const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
+    signed char *r8_out, unsigned *overflow, const int *s_sums_in, const float *w_scale_sw,
+    const signed char *next_scale_codes, int *s_sums_out, void *stream) {
+  return stage_frozen_impl(x, x_kind, x_up, x_state, N, C, Co, H, W, w_scale, b_scale, lo, hi, w_dw, w_pw_codes,
+                           w_pw_scale, w_pw_colsum, bias_pw, relu, s_state, d_state, r_state, workspace,
+                           workspace_bytes, r8_out, overflow, stream, s_sums_in, w_scale_sw, next_scale_codes,
+                           s_sums_out);
 }
 
 extern "C" int cdn_codenet_expand_codes(const signed char *a, const void *a_state, float *out, int64_t numel,

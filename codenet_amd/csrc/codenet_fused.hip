@@ -1031,7 +1031,7 @@ __global__ void __launch_bounds__(512)   // ~250 VGPRs: 2 waves/SIMD (168 spills
 dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
-            int C, int H, int W) {
+            int C, int H, int W, cdn::ScaleFromSums si) {
   static_assert(!X8 || XQ, "codes come with their quantiser state");
   // LDS: one ZERO cell, then the image as in dw2_kernel.  Cell (r, -1) is the cell in front of row r: the zero
   // column of row r - 1, or the leading zero cell for r = 0 -- so column -1 needs no parking and the two cells
@@ -1073,7 +1073,18 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   if (tid < LPP) img_lds[tid] = z4;                          // the leading zero cell
   // weights and scale plane requested before the image (see dw2_kernel)
   const float w_pre = (tid < CCH * 9 && c0 + tid / 9 < C) ? wd[(long)c0 * 9 + tid] : 0.0f;
-  const float s_pre = tid < HWl ? s_raw[(long)n * HWl + tid] : 0.0f;
+  // scale plane: from the scale kernel, or (frozen chained stages) from the producer's exact integer sums --
+  // s_raw = clamp(bias + sums / (sw * sc_x)): ONE rounding of the exact sum instead of the fp32 sum of C products
+  float s_inv = 0.f, s_b = 0.f;
+  if (XQ && si.sums) {
+    s_inv = __fdiv_rn(1.0f, __fmul_rn(si.sw[0], xs));
+    s_b = si.bias ? si.bias[0] : 0.0f;
+  }
+  auto s_at = [&](int q) -> float {
+    if (XQ && si.sums) return fminf(fmaxf(fmaf((float)si.sums[(long)n * HWl + q], s_inv, s_b), si.lo), si.hi);
+    return s_raw[(long)n * HWl + q];
+  };
+  const float s_pre = tid < HWl ? s_at(tid) : 0.0f;
   if (X8) {
     constexpr int kStageU = 8;
     const signed char *xg = reinterpret_cast<const signed char *>(x) + (long)n * HWl * C + c0;
@@ -1133,7 +1144,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     wl[q] = (c0 + q / 9 < C) ? wd[(long)c0 * 9 + q] : 0.0f;
   if (tid < HWl) sl[tid] = SQ ? fake_quant(s_pre, ss, sz) : s_pre;
   for (int q = tid + nthreads; q < HWl; q += nthreads) {
-    float sv = s_raw[(long)n * HWl + q];
+    float sv = s_at(q);
     if (SQ) sv = fake_quant(sv, ss, sz);
     sl[q] = sv;
   }
@@ -2458,7 +2469,8 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
     auto kern = dw2u_kernel<CCH, XQ_, SQ_>;                                                   \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, 512, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W);                  \
+    kern<<<grid, 512, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W,                   \
+                                 cdn::ScaleFromSums{nullptr, nullptr, nullptr, 0.f, 0.f});     \
   }
     if (XQ && SQ) CDN_GOU(true, true)
     else if (XQ) CDN_GOU(true, false)
@@ -2523,7 +2535,7 @@ namespace {
 template <int CCH>
 int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                        const float *wd, float *d8, unsigned *dstate, float2 *oflow, int N, int C, int H, int W,
-                       int up, hipStream_t st) {
+                       int up, hipStream_t st, cdn::ScaleFromSums si) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
@@ -2534,11 +2546,11 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
   {                                                                                                         \
     auto kern = KERN;                                                                                       \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-    kern<<<grid, THREADS, lds, st>>>(x, xq, s_raw, sq, wd, d8, oflow, qu, C, H, W, ##__VA_ARGS__);          \
+    kern<<<grid, THREADS, lds, st>>>(x, xq, s_raw, sq, wd, d8, oflow, qu, C, H, W, __VA_ARGS__);            \
   }
   if (x_kind != 0 && up == 1) {
-    if (x_kind == 2) CDN_FGO((dw2u_kernel<CCH, true, true, true, true>), 512)
-    else CDN_FGO((dw2u_kernel<CCH, true, true, false, true>), 512)
+    if (x_kind == 2) CDN_FGO((dw2u_kernel<CCH, true, true, true, true>), 512, si)
+    else CDN_FGO((dw2u_kernel<CCH, true, true, false, true>), 512, si)
   } else if (x_kind == 2) {
     CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, true, true>), threads, up)
   } else if (x_kind == 1) {
@@ -2556,14 +2568,16 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
 
 int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                           const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H,
-                          int W, int up, hipStream_t st) {
+                          int W, int up, hipStream_t st, cdn::ScaleFromSums si) {
+  if (si.sums && !(x_kind != 0 && up == 1))
+    return cdn::fail(CDN_ERR_UNSUPPORTED, "scale sums are consumed by the up-sampled channels-last gather only");
   const int cch = cdn::stage_channel_chunk(H >> up, W >> up);
   if (cch == 0) return cdn::fail(CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident gather");
   if ((long)cdn::ceil_div(C, cch) * N > cdn::kMaxPartials) return cdn::fail(CDN_ERR_UNSUPPORTED, "too many workgroups");
   auto fn = cch == 64 ? launch_frozen_dw_t<64> : cch == 32 ? launch_frozen_dw_t<32>
             : cch == 16 ? launch_frozen_dw_t<16> : launch_frozen_dw_t<8>;
   return fn(static_cast<const float *>(x), x_kind, xq, s_raw, sq, wd, reinterpret_cast<float *>(d8), dstate,
-            reinterpret_cast<float2 *>(oflow), N, C, H, W, up, st);
+            reinterpret_cast<float2 *>(oflow), N, C, H, W, up, st, si);
 }
 
 // Pointwise (1x1) convolution on a channels-last activation A [M][C] -> R [M][Co]: int8 MFMA on codes

@@ -448,10 +448,17 @@ class FrozenHotPath:
     running_stat False as long as no activation leaves its frozen 8-bit grid; the reference does not clamp codes,
     a byte must, so a saturated code raises the sticky device flag read by ``overflowed()`` and the caller
     recomputes that batch with ``FusedHotPath``.  Stages whose input channel count is not a multiple of 4
-    (CoDeNet2x stage 0, C = 2153) run on the fp32 frozen schedule and hand fp32 + state to the next stage."""
+    (CoDeNet2x stage 0, C = 2153) run on the fp32 frozen schedule and hand fp32 + state to the next stage.
 
-    def __init__(self, deconv_layers):
+    chain_scale=True (cdn_codenet_stage_frozen_chained_forward): the scale prediction of stage k+1 is accumulated as
+    exact integer sums in stage k's pointwise epilogue and finished by stage k+1's gather -- two launches fewer and no
+    re-read of r.  A DECLARED non-bit-identical variant: s_raw is the exact sum rounded once instead of an fp32 sum
+    of C products, so single scale codes can differ from the default schedule by one LSB (checked against the oracle
+    with the same code-flip tolerance, tests/test_gpu_frozen.py)."""
+
+    def __init__(self, deconv_layers, chain_scale=False):
         from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
+        self.chain_scale = bool(chain_scale)
         mods = list(deconv_layers)
         if not mods or not isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive):
             raise NotImplementedError("FrozenHotPath needs the W4A8 deconv_layers")
@@ -486,13 +493,26 @@ class FrozenHotPath:
                 ws32_bytes = max(ws32_bytes, lib.cdn_codenet_stage_workspace_bytes(Nb, cin, Hs, Ws, up))
             bufs.append(dict(C=cin, Co=cout, H=Hs, W=Ws, up=up, codes=codes,
                              r8=torch.empty(Nb, Hs * Ws, cout, dtype=torch.int8, device=dev) if codes else None,
-                             r=None if codes else torch.empty(Nb, Hs * Ws, cout, device=dev)))
+                             r=None if codes else torch.empty(Nb, Hs * Ws, cout, device=dev),
+                             sums=None))
+        sums_all = None
+        if self.chain_scale:      # stage k's pointwise leaves the integer scale sums of stage k+1 (both on byte codes)
+            take = [i for i in range(len(bufs) - 1)
+                    if bufs[i]["codes"] and bufs[i + 1]["codes"]
+                    and self.stages[i + 1][0].quant_conv_scale.int8_form() is not None]
+            sizes = [(Nb * bufs[i]["H"] * bufs[i]["W"] + 3) // 4 * 4 for i in take]
+            if take:      # ONE buffer, cleared by the step's first launch (cdn_quantact_frozen_params_clear)
+                sums_all = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
+                off = 0
+                for i, sz in zip(take, sizes):
+                    bufs[i]["sums"] = sums_all[off:off + Nb * bufs[i]["H"] * bufs[i]["W"]]
+                    off += sz
         acts = [a for st in self.stages for a in self._acts(st)]
         n = len(acts)
         arr = ctypes.c_void_p * n
         last = bufs[-1]
         self._bufs = dict(
-            key=key, stages=bufs,
+            key=key, stages=bufs, sums_all=sums_all,
             ws=torch.empty(ws_bytes + 512, dtype=torch.uint8, device=dev),
             ws32=torch.zeros(ws32_bytes // 4 + 64, device=dev) if ws32_bytes else None,
             overflow=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -530,8 +550,11 @@ class FrozenHotPath:
         # last stage's grid otherwise)
         bits, _, _ = uniform_act_settings(B["acts"], "FrozenHotPath (all stages)")
         # (scale, zero-point) of all nine frozen QuantActs from their range buffers: one launch per step
-        N_.check(lib.cdn_quantact_frozen_params(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits, stream),
-                 "cdn_quantact_frozen_params")
+        sa = B["sums_all"]
+        N_.check(lib.cdn_quantact_frozen_params_clear(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits,
+                                                      sa.data_ptr() if sa is not None else None,
+                                                      sa.numel() * 4 if sa is not None else 0, stream),
+                 "cdn_quantact_frozen_params_clear")
         ws_ptr = (B["ws"].data_ptr() + 255) // 256 * 256
         ws_bytes = B["ws"].numel() - (ws_ptr - B["ws"].data_ptr())
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
@@ -547,12 +570,20 @@ class FrozenHotPath:
                 w_dw = q.quant_deform_conv.quantized_weight()
                 bound = q.quant_act[0]
                 if sb["codes"]:
-                    rc = lib.cdn_codenet_stage_frozen_forward(
+                    si = B["stages"].index(sb)
+                    sums_in = B["stages"][si - 1]["sums"] if si > 0 and cur_kind == 2 else None
+                    sw_ptr = nsc_ptr = None
+                    if sums_in is not None:
+                        sw_ptr = q.quant_conv_scale.int8_form()[1].data_ptr()
+                    if sb["sums"] is not None:
+                        nsc_ptr = self.stages[si + 1][0].quant_conv_scale.int8_form()[0].data_ptr()
+                    rc = lib.cdn_codenet_stage_frozen_chained_forward(
                         cur_ptr, cur_kind, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
                         ptr(w_sc), ptr(q.quant_conv_scale.bias), float(bound.min_val), float(bound.max_val),
                         ptr(w_dw), ptr(codes), ptr(scale), ptr(colsum), ptr(b_pw), 1, sp[0], sp[1], sp[2],
-                        ws_ptr, ws_bytes, sb["r8"].data_ptr(), B["overflow"].data_ptr(), stream)
-                    N_.check(rc, "cdn_codenet_stage_frozen_forward")
+                        ws_ptr, ws_bytes, sb["r8"].data_ptr(), B["overflow"].data_ptr(),
+                        ptr(sums_in), sw_ptr, nsc_ptr, ptr(sb["sums"]), stream)
+                    N_.check(rc, "cdn_codenet_stage_frozen_chained_forward")
                     cur_ptr, cur_kind, cur_q = sb["r8"].data_ptr(), 2, sp[2]
                 else:
                     if cur_kind == 2:

@@ -303,6 +303,10 @@ int cdn_codenet_stage_fused_forward(
  * ---------------------------------------------------------------------------------------- */
 int cdn_quantact_frozen_params(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
                                void *stream);
+/* The same launch also clears `clear_bytes` bytes at `clear` (16-byte aligned, multiple of 16): the integer scale sums
+ * of the chained frozen schedule, cdn_codenet_stage_frozen_chained_forward. */
+int cdn_quantact_frozen_params_clear(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
+                                     void *clear, size_t clear_bytes, void *stream);
 size_t cdn_codenet_stage_frozen_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int x_up);
 int cdn_codenet_stage_frozen_forward(
     const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
@@ -310,6 +314,24 @@ int cdn_codenet_stage_frozen_forward(
     const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
     const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
     signed char *r8_out, unsigned *overflow, void *stream);
+/* The same stage, CHAINED with its neighbours (frozen serving schedule only): the scale prediction of stage k+1 --
+ * s_raw = b + sum_co (qw_s[co] / sw) * ((q_r + zp_r) / sc_r), a sum of integer products over one denominator -- is
+ * accumulated by stage k's pointwise epilogue as exact int32 sums and finished by stage k+1's gather with ONE rounding,
+ * s_raw = clamp(b + sums / (sw * sc_r), lo, hi), instead of a scale launch that re-reads r (quant_modules.py:668-669
+ * evaluate the same sum as an fp32 convolution: this is a DECLARED non-bit-identical variant -- the exact sum rounded
+ * once -- checked against the oracle within its code-flip tolerance, tests/test_gpu_frozen.py).
+ *   s_sums_in         [N][(H/2)*(W/2)] int32 from the previous stage (needs x_kind 2, x_up 1) or NULL (scale launch);
+ *   w_scale_sw        device scalar: scale of this stage's conv_scale weight codes (w = codes / sw), with s_sums_in
+ *   next_scale_codes  [Co] int8 codes of the NEXT stage's conv_scale weights, s_sums_out [N][H*W] int32 that must be
+ *                     ZERO on entry (cdn_quantact_frozen_params_clear clears it in the step's first launch; a separate
+ *                     memset node costs 4.7 us) and holds the sums afterwards, or both NULL. */
+int cdn_codenet_stage_frozen_chained_forward(
+    const void *x, int x_kind, int x_up, const void *x_state, int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W,
+    const float *w_scale, const float *b_scale, float lo, float hi, const float *w_dw,
+    const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum, const float *bias_pw, int relu,
+    const void *s_state, const void *d_state, const void *r_state, void *workspace, size_t workspace_bytes,
+    signed char *r8_out, unsigned *overflow, const int *s_sums_in, const float *w_scale_sw,
+    const signed char *next_scale_codes, int *s_sums_out, void *stream);
 int cdn_codenet_pointwise_q8_forward(const signed char *a, const void *a_state, int64_t M, int64_t C, int64_t Co,
                                      const signed char *w_codes, const float *w_scale, const int *w_colsum,
                                      const float *bias, int relu, const void *r_state, signed char *r8_out,

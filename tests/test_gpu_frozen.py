@@ -167,8 +167,12 @@ def test_frozen_w2_stage0_runs_on_fp32_schedule():
         assert not frz.overflowed()
 
 
-def test_frozen_matches_oracle_with_frozen_ranges_real_shapes():
-    """cfg3 stage shapes against the CPU oracle with running = False (oracle/quant.py::stage_w4a8)."""
+@pytest.mark.parametrize("chain_scale", [False, True])
+def test_frozen_matches_oracle_with_frozen_ranges_real_shapes(chain_scale):
+    """cfg3 stage shapes against the CPU oracle with running = False (oracle/quant.py::stage_w4a8).  chain_scale: the
+    declared variant in which stage k's pointwise epilogue accumulates the exact integer sums of stage k+1's scale
+    prediction (one rounding of the exact sum instead of an fp32 sum of C products) -- same acceptance: a scale code
+    that lands on the other side of a rounding boundary moves that pixel's outputs, like any other code flip."""
     from codenet_amd import pipeline
     planes, res, n = [1024, 256, 128, 64], 16, 4
     net = pipeline.build_hot_path(quantized=True, planes=planes, seed=45)
@@ -177,7 +181,7 @@ def test_frozen_matches_oracle_with_frozen_ranges_real_shapes():
     _warm_and_freeze(net, xs)
     net_cpu = copy.deepcopy(net).cpu()
     mods = list(net_cpu.deconv_layers)
-    frz = pipeline.FrozenHotPath(net.deconv_layers)
+    frz = pipeline.FrozenHotPath(net.deconv_layers, chain_scale=chain_scale)
     for x in xs:
         cur = x
         with torch.no_grad():
@@ -197,6 +201,34 @@ def test_frozen_matches_oracle_with_frozen_ranges_real_shapes():
         diff = (y - cur).abs()
         assert diff.max().item() <= 1.05 * lsb + 1e-3
         assert (diff > 1e-3).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("n", [4, 64])
+def test_frozen_chained_scale_against_the_default_frozen_schedule(n):
+    """FrozenHotPath(chain_scale=True) vs the default frozen schedule at the cfg3 shapes: the scale planes of stages
+    1 and 2 come from exact integer sums left by the previous pointwise instead of a scale launch; every output code
+    equals the default schedule's except around the (rare) pixels whose 8-bit scale code rounds the other way
+    (fraction of differing outputs < 1e-3, none by more than a few LSB), no overflow, and a replayed HIP graph of the
+    chained schedule reproduces its eager result bit for bit (the integer atomics are order-independent)."""
+    from codenet_amd import pipeline
+    planes, res = [1024, 256, 128, 64], 16
+    net = pipeline.build_hot_path(quantized=True, planes=planes, seed=46).cuda()
+    xs = _inputs(n, planes[0], res, 2, 146)
+    _warm_and_freeze(net, xs)
+    base = pipeline.FrozenHotPath(net.deconv_layers)
+    chained = pipeline.FrozenHotPath(net.deconv_layers, chain_scale=True)
+    x = xs[0].cuda()
+    a = base.forward_codes(x)[0].clone()
+    b = chained.forward_codes(x)[0].clone()
+    assert not base.overflowed() and not chained.overflowed()
+    assert chained._bufs["stages"][0]["sums"] is not None and chained._bufs["stages"][1]["sums"] is not None
+    d = (a.int() - b.int()).abs()
+    frac = (d > 0).float().mean().item()
+    print("   chained scale: %.2e of the output codes differ, max %d LSB" % (frac, d.max().item()))
+    assert frac < 1e-3 and d.max().item() <= 8
+    replay = chained.capture(x)
+    for _ in range(3):
+        assert torch.equal(replay(), b)
 
 
 @pytest.mark.parametrize("M,C,Co", [(300, 64, 20), (4096, 1024, 256), (1000, 128, 64), (513, 256, 128), (77, 36, 5)])
