@@ -2307,6 +2307,20 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
     }
     if (rb == rb_first) CDN_STAMPR(2, 2);
+    // The prefetch stream alternates between the two buffers item by item, the loop above indexes them by the
+    // window's position in its pair (static register indexing).  With an ODD number of windows per block the two
+    // disagree from the second block of a wave on (window 0 of the next block sits in buf[1]): swap them.  Without
+    // this, layer4 (K = 464: 15 windows) computed every second 32-row block of a wave from swapped k windows
+    // whenever a wave walked more than one block (M > 8192 rows: batch 64 at 512 x 512 only; found by
+    // tests/test_harness.py::test_whole_network_512_batch64_fused_vs_module_path in round 3).
+    if (nwin & 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t = buf[0][i];
+        buf[0][i] = buf[1][i];
+        buf[1][i] = t;
+      }
+    }
     const long mb0 = rb * 32;
 #pragma unroll
     for (int j = 0; j < TN; ++j)

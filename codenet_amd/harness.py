@@ -96,20 +96,38 @@ class PoseShuffleNetV2(nn.Module):
                 fc = nn.Conv2d(64, classes, kernel_size=1, stride=1, padding=0, bias=True)
             setattr(self, head, fc)
 
-    def enable_fused(self, flag=True, backbone=True):
+    def enable_fused(self, flag=True, backbone=True, frozen_codes=False):
         """Inference on GPU tensors: run deconv_layers AND the heads on the fused HIP schedules
         (pipeline.FusedHotPath.forward_nhwc -> pipeline.FusedHeads; nothing is materialised between
         them) and, for a W4A8 model (backbone=True), layer0..layer4 on pipeline.FusedBackbone.  The
-        returned tensors are static buffers, overwritten by the next call."""
+        returned tensors are static buffers, overwritten by the next call.
+
+        frozen_codes (serving mode; needs every QuantAct of deconv_layers at running_stat False, e.g. after
+        pipeline.set_running_stat(model, False)): the three deform stages run on the byte-code schedule
+        (pipeline.FrozenHotPath, chained scale sums).  The reference does not clamp activation codes, a byte must:
+        check ``frozen_overflowed()`` after a batch and recompute it with frozen_codes off if it says True."""
         from .portable_quantizer.quant_modules import QuantAct
         self._fused = bool(flag)
         self._fused_backbone = bool(backbone)
-        self._fpath = self._fheads = self._fbackbone = None
+        self._frozen_codes = bool(frozen_codes)
+        self._fpath = self._fheads = self._fbackbone = self._ffrozen = None
         # the QuantActs whose settings decide _fused_ok(): collected once (the module tree is fixed after
         # quantize_shufflenetv2_dcn), so a forward reads 5 attributes of ~70 modules instead of walking the tree
         self.__dict__["_fused_acts"] = [a for a in self.modules() if isinstance(a, QuantAct)]
         self.__dict__["_fused_ok_cache"] = {}
         return self
+
+    def _stage_acts_frozen(self):
+        from .portable_quantizer.quant_modules import QuantAct
+        acts = self.__dict__.get("_stage_acts")
+        if acts is None:
+            acts = self.__dict__["_stage_acts"] = [a for a in self.deconv_layers.modules() if isinstance(a, QuantAct)]
+        return bool(acts) and not any(a.running_stat for a in acts)
+
+    def frozen_overflowed(self):
+        """True when a code of the byte-code stage schedule saturated since the last call (synchronises, resets)."""
+        f = getattr(self, "_ffrozen", None)
+        return bool(f is not None and f.overflowed())
 
     def _fused_ok(self, x):
         """The fused schedules implement the reference's default QuantAct settings and stored planes that fit
@@ -145,9 +163,14 @@ class PoseShuffleNetV2(nn.Module):
                 self._fheads = pipeline.FusedHeads({h: getattr(self, h) for h in self.heads})
                 self._fbackbone = (pipeline.FusedBackbone(self)
                                    if self._fused_backbone and pipeline.FusedBackbone.supported(self) else None)
+            stages = self._fpath
+            if getattr(self, "_frozen_codes", False) and self._stage_acts_frozen():
+                if self._ffrozen is None:
+                    self._ffrozen = pipeline.FrozenHotPath(self.deconv_layers, chain_scale=True)
+                stages = self._ffrozen
             if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
                 feat, fq, hw = self._fbackbone(x)       # hw None: an NCHW tensor (odd channel count)
-                return [self._fheads(*self._fpath.forward_nhwc(feat, fq, hw))]
+                return [self._fheads(*stages.forward_nhwc(feat, fq, hw))]
             x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
             return [self._fheads(*self._fpath.forward_nhwc(x))]
         x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))

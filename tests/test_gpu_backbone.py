@@ -278,10 +278,14 @@ def test_range_epilogue_stress_exact_extremes():
 
 @pytest.mark.parametrize("M,C,Co,lda,off,ldo,relu", [
     (4099, 58, 58, 116, 58, 60, 1), (1500, 116, 116, 232, 116, 116, 1), (700, 232, 232, 464, 232, 232, 1),
-    (300, 464, 1024, 464, 0, 1024, 1), (257, 24, 58, 24, 0, 60, 0), (130, 37, 70, 37, 0, 70, 1)])
+    (300, 464, 1024, 464, 0, 1024, 1), (257, 24, 58, 24, 0, 60, 0), (130, 37, 70, 37, 0, 70, 1),
+    (16384, 464, 1024, 464, 0, 1024, 1), (40000, 80, 58, 80, 0, 58, 1)])
 def test_pointwise_bf16_split_is_exact_product(M, C, Co, lda, off, ldo, relu):
     """Final-valued input + 4-bit weight codes runs on the bf16 x 3 split kernel: products are exact, so the
-    result matches a float64 reference to fp32 accumulation rounding (and the f32-MFMA kernel)."""
+    result matches a float64 reference to fp32 accumulation rounding (and the f32-MFMA kernel).
+    (16384 x 464 -> 1024 = layer4 at batch 64, 512 x 512, and 40000 x 80: an ODD number of 32-channel windows with
+    more than one 32-row block per wave of the persistent streaming kernel -- the prefetch buffers of pwd3_kernel
+    used to come out swapped from the second block on; round 3.)"""
     from codenet_amd import _native as N_, ops
     lib, dev = N_.lib(), torch.device("cuda", 0)
     ws, wp, wb = _ws(lib, dev)
