@@ -621,7 +621,7 @@ def main():
                                 "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (only valid for
         # the workload they were collected on; null otherwise)
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", rnd,
                                                  "pmc_traffic_frozen.json" if frozen_main else "pmc_traffic.json")))
