@@ -17,6 +17,34 @@ __all__ = [
 ]
 
 
+def _half_through_float(out_names):
+    """fp16 (the reference dispatches half too: AT_DISPATCH_FLOATING_TYPES_AND_HALF, _kernel.cu:258,352,450).  The C
+    ABI computes in fp32 / fp64: for half tensors the call runs on fp32 copies and the tensors named in `out_names`
+    (outputs and accumulated-into gradients) are written back in half -- i.e. fp32 arithmetic rounded once at the end,
+    where the reference rounds every intermediate to half."""
+    import functools
+    import inspect
+
+    def deco(fn):
+        names = list(inspect.signature(fn).parameters)
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            bound = dict(zip(names, args))
+            bound.update(kwargs)
+            if not any(isinstance(v, torch.Tensor) and v.dtype == torch.float16 for v in bound.values()):
+                return fn(*args, **kwargs)
+            conv = {k: (v.float() if isinstance(v, torch.Tensor) and v.dtype == torch.float16 else v)
+                    for k, v in bound.items()}
+            res = fn(**conv)
+            for k in out_names:
+                if isinstance(bound.get(k), torch.Tensor) and bound[k].dtype == torch.float16:
+                    bound[k].copy_(conv[k])
+            return res
+        return wrapper
+    return deco
+
+
 def _dtype_enum(t):
     if t.dtype == torch.float32:
         return N_.CDN_F32
@@ -80,6 +108,7 @@ def _check_common(input, offset, weight, kH, kW, dH, dW, padH, padW, dilH, dilW,
     return Ho, Wo
 
 
+@_half_through_float(("output",))
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW,
                              padH, dilationW, dilationH, group, deformable_group, im2col_step):
     """cpp:151-258.  `columns`, `ones`, `im2col_step` are accepted and ignored (vestigial)."""
@@ -98,6 +127,7 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
     return 1
 
 
+@_half_through_float(("gradInput", "gradOffset"))
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight,
                                     columns, kW, kH, dW, dH, padW, padH, dilationW, dilationH,
                                     group, deformable_group, im2col_step):
@@ -117,6 +147,7 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
     return 1
 
 
+@_half_through_float(("gradWeight",))
 def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW,
                                          kH, dW, dH, padW, padH, dilationW, dilationH, group,
                                          deformable_group, scale, im2col_step):
@@ -159,6 +190,7 @@ def _check_modulated(input, weight, offset, mask, kernel_h, kernel_w, stride_h, 
     return Ho, Wo
 
 
+@_half_through_float(("output",))
 def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, output, columns,
                                        kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
                                        dilation_h, dilation_w, group, deformable_group, with_bias):
@@ -179,6 +211,7 @@ def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, 
     N_.check(rc, "modulated_deform_conv_cuda_forward")
 
 
+@_half_through_float(("grad_input", "grad_weight", "grad_bias", "grad_offset", "grad_mask"))
 def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask, columns,
                                         grad_input, grad_weight, grad_bias, grad_offset, grad_mask,
                                         grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,

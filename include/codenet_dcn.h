@@ -17,7 +17,9 @@
  *   - Every function returns 0 (CDN_OK) or a negative cdn_status; cdn_last_error() gives a
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - dtype: CDN_F32 or CDN_F64 for the generic entry points; the CoDeNet fast paths are f32
- *     (activations) with int8 code paths where stated.
+ *     (activations) with int8 code paths where stated.  fp16 tensors (the reference also dispatches half,
+ *     dcn_deform_conv_cuda_kernel.cu:258,352,450) are served by the binding above this ABI: the call runs on fp32
+ *     copies and results are rounded to half once (codenet_amd/_ext/dcn/dcn_deform_conv_cuda.py).
  *   - Re-entrant, no global mutable state; safe to call concurrently from several host
  *     threads on different streams / devices (the current HIP device must be the one that
  *     owns the pointers).

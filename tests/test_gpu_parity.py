@@ -78,6 +78,28 @@ def test_generic_depthwise_fast_path_matches_oracle(N, C, H, W, spread):
     assert (out.cpu() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("case", [GENERIC_CASES[0], GENERIC_CASES[-1]])
+def test_deform_conv_half_tensors(case):
+    """fp16 tensors through the generic op (the reference dispatches half: _kernel.cu:258,352,450): forward and all
+    three gradients come back in half and equal the fp32 oracle on the same (half-rounded) inputs to half precision."""
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    x, off, w, _, cfg = _mk(case, torch.float32)
+    xh, oh, wh = x.half(), off.half(), w.half()
+    ref = O.deform_conv_forward(xh.float(), oh.float(), wh.float(), *cfg)
+    xg, og, wg = (t.cuda().requires_grad_(True) for t in (xh, oh, wh))
+    out = deform_conv(xg, og, wg, *cfg)
+    assert out.dtype == torch.float16 and out.shape == ref.shape
+    tol = 2e-3 * max(1.0, ref.abs().max().item())
+    assert (out.detach().float().cpu() - ref).abs().max().item() < tol
+    go = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1)).half()
+    out.backward(go.cuda())
+    gx, goff = O.deform_conv_backward_input(xh.float(), oh.float(), wh.float(), go.float(), *cfg)
+    gw = O.deform_conv_backward_params(xh.float(), oh.float(), tuple(w.shape), go.float(), *cfg)
+    for got, want in ((xg.grad, gx), (og.grad, goff), (wg.grad, gw)):
+        assert got.dtype == torch.float16
+        assert (got.float().cpu() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("case", GENERIC_CASES[:4])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("with_bias", [False, True])
