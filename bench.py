@@ -752,30 +752,35 @@ def e2e_leg(args, dev, rank, world, local_rank, hot_ms):
             replay()
         torch.cuda.synchronize()
         pipeline.set_running_stat(model, False)
-        # a serving deployment freezes CALIBRATED ranges with head-room; here they are this batch's exact extremes, and
-        # the chained-scale variant is not bit-identical to the schedule that tracked them: 2 % of head-room per side
-        # on the stage quantisers keeps the extreme elements inside the byte grid
-        with torch.no_grad():
-            for a in model.deconv_layers.modules():
-                if hasattr(a, "x_min") and isinstance(getattr(a, "x_min"), torch.Tensor):
-                    w = (a.x_max - a.x_min) * 0.02
-                    a.x_min.sub_(w)
-                    a.x_max.add_(w)
-        model.enable_fused(frozen_codes=True)
-        replay_f = harness.capture_process(model, images)
-        for _ in range(5):
-            replay_f()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dets_f = replay_f()[1]
-        barrier()
-        msf = (time.perf_counter() - t0) / args.steps * 1e3
+        # a serving deployment freezes CALIBRATED ranges: the EMA ranges are widened over what the frozen network
+        # feeds each QuantAct on this batch (+2 % of the span), so that every code fits the byte grid
+        model.enable_fused(False)
+        moved = pipeline.cover_frozen_ranges(model, [images], margin=0.02)
+        torch.cuda.empty_cache()
+
+        def timed(**kw):
+            model.enable_fused(frozen_codes=True, **kw)
+            replay_f = harness.capture_process(model, images)
+            for _ in range(5):
+                replay_f()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dets_f = replay_f()[1]
+            barrier()
+            return (time.perf_counter() - t0) / args.steps * 1e3, dets_f, bool(model.frozen_overflowed())
+        ms_st, dets_s, of_s = timed(frozen_backbone=False)
+        msf, dets_f, of_f = timed()
         frozen = {"ms_per_batch": msf, "images_per_s": args.batch / msf * 1e3, "per_rank": True,
-                  "overflow": bool(model.frozen_overflowed()), "finite": bool(torch.isfinite(dets_f).all()),
+                  "overflow": of_f, "finite": bool(torch.isfinite(dets_f).all()),
+                  "byte_backbone": model._fzbackbone is not None,
+                  "stages_only": {"ms_per_batch": ms_st, "overflow": of_s,
+                                  "what": "backbone on the fp32 kernels without range updates, stages on byte codes"},
+                  "ranges_widened": moved,
                   "what": "the same network with every QuantAct frozen (running_stat False: serving mode, not the "
-                          "reference's default): backbone / heads kernels without range updates, the three deform "
-                          "stages on byte codes with chained scale sums"}
+                          "reference's default) on BYTE CODES from the stem to the heads' input: backbone "
+                          "(pipeline.FrozenBackbone), the three deform stages with chained scale sums "
+                          "(pipeline.FrozenHotPath); heads on the fp32 kernels without range updates"}
     return {"ms_per_batch": ms, "images_per_s": world * args.batch / ms * 1e3, "frozen": frozen,
             "hot_path_share": hot_ms / ms, "detections": list(dets.shape),
             "what": "CoDeNet%s %dx%d %s batch %d per GPU: whole network on the HIP kernels + native ctdet_decode "

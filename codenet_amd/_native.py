@@ -53,6 +53,9 @@ _SIGNATURES = {
     "cdn_codenet_stage_frozen_chained_forward": (
         _i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 5 + [_i] + [_vp] * 4
         + [ctypes.c_size_t, _vp, _vp] + [_vp] * 4 + [_vp]),
+    "cdn_codenet_pointwise_q8_strided_forward": (_i, [_vp, _vp] + [_i64] * 5 + [_vp] * 4 + [_i] + [_vp] * 6),
+    "cdn_codenet_stem_q8_forward": (_i, [_vp] + [_i64] * 4 + [_i, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
+    "cdn_codenet_dw3x3_q8_forward": (_i, [_vp, _vp] + [_i64] * 4 + [_i] + [_i64] * 2 + [_vp, _vp, _i] + [_vp] * 4),
     "cdn_codenet_pointwise_q8_forward": (_i, [_vp, _vp] + [_i64] * 3 + [_vp] * 4 + [_i] + [_vp] * 5),
     "cdn_codenet_expand_codes": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "cdn_codenet_unpack_nchw": (_i, [_vp] * 3 + [_i64] * 4 + [_i, _vp]),

@@ -46,11 +46,11 @@ __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// frozen_params_kernel: (scale, zero-point) of up to 12 frozen QuantActs from their x_min / x_max buffers
+// frozen_params_kernel: (scale, zero-point) of up to 48 frozen QuantActs from their x_min / x_max buffers
 // into state words [2], [3] -- the expressions of cdn::quantact_update_device without the range update
 // (quant_utils.py:60-75).  One launch per step for the whole schedule.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kMaxFrozen = 12;
+constexpr int kMaxFrozen = 48;
 struct FrozenList {
   const float *x_min[kMaxFrozen];
   const float *x_max[kMaxFrozen];
@@ -99,7 +99,8 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
             const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
             const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int C, int Cpad, int Co,
-            int relu, const signed char *__restrict__ nsc, int *__restrict__ sacc) {
+            int relu, const signed char *__restrict__ nsc, int *__restrict__ sacc, int lda, int ldo,
+            const int *__restrict__ omap) {
   constexpr int WGM = BM / 32, WGN = 4 / WGM, TN = BN / (32 * WGN);
   constexpr int AI = BM * kQK / 16 / 256;       // 16-byte loads of A per thread per k tile (1 or 2)
   constexpr int BI = BN * kQK / 16 / 256;       // of the weights (1, 2 or 4)
@@ -112,7 +113,7 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   const int wm = (wave / WGN) * 32, wn = (wave % WGN) * TN * 32;
   const float qs = reinterpret_cast<const float *>(aq)[2];
   const float qzf = reinterpret_cast<const float *>(aq)[3];
-  const bool a16 = (C & 15) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const bool a16 = (lda & 15) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;   // (rows 16-byte aligned)
   i32x16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
@@ -124,13 +125,13 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
     for (int i = 0; i < AI; ++i) {
       const long m = min(m0 + lr + 64 * i, M - 1);
       const int k = k0 + lk;
-      if (a16 && k + 15 < C) {
-        ra[i] = *reinterpret_cast<const i32x4 *>(A + m * C + k);
+      if (a16 && k + 15 < lda) {       // (bytes beyond C inside the row are paired with zero weights)
+        ra[i] = *reinterpret_cast<const i32x4 *>(A + m * lda + k);
       } else {            // ragged tail: bytes beyond C are paired with zero weights, any finite value will do
         i32x4 t = {0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (k + 4 * e + 3 < C) t[e] = *reinterpret_cast<const int *>(A + m * C + k + 4 * e);
+          if (k + 4 * e + 3 < lda) t[e] = *reinterpret_cast<const int *>(A + m * lda + k + 4 * e);   // (lda % 4 == 0)
         ra[i] = t;
       }
     }
@@ -185,12 +186,13 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
     float bsv = 0.f, rinv = 0.f;
-    int t128 = 0, nq = 0;
+    int t128 = 0, nq = 0, oc = co;
     if (co < Co) {
       if (bias) bsv = bias[co];
       rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
       t128 = qzi * wsum[co];
       if (nsc) nq = nsc[co];
+      if (omap) oc = omap[co];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -200,10 +202,10 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
         if (relu) v = fmaxf(v, 0.0f);
         if (R8) {
           const int code = act_code8(v, c8, bad);
-          R8[m * Co + co] = (signed char)code;
+          R8[m * ldo + oc] = (signed char)code;
           rowsum[r] += nq * (code + zpr);
         } else {
-          Rf[m * Co + co] = v;
+          Rf[m * ldo + oc] = v;
         }
       }
     }
@@ -245,12 +247,140 @@ expand8_kernel(const signed char *__restrict__ a, const unsigned *__restrict__ a
 template <int BM, int BN>
 void launch_pwq8(const signed char *A, const unsigned *aq, const signed char *Wq, const float *ws, const int *wsum,
                  const float *bias, signed char *R8, float *Rf, const unsigned *rq, unsigned *oflow, long M, int C,
-                 int Co, int relu, hipStream_t st, const signed char *nsc = nullptr, int *sacc = nullptr) {
+                 int Co, int relu, hipStream_t st, const signed char *nsc = nullptr, int *sacc = nullptr, int lda = 0,
+                 int ldo = 0, const int *omap = nullptr) {
   dim3 g((unsigned)cdn::ceil_div(M, BM), (unsigned)cdn::ceil_div(Co, BN));
   pwq8_kernel<BM, BN><<<g, 256, 0, st>>>(A, aq, Wq, ws, wsum, bias, R8, Rf, rq, oflow, M, C, (C + 63) / 64 * 64, Co,
-                                         relu, nsc, sacc);
+                                         relu, nsc, sacc, lda ? lda : C, ldo ? ldo : Co, omap);
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Byte-code kernels for the layers AROUND the hot path in the frozen serving mode (the ShuffleNetV2
+// backbone, quant_modules.py:809-907 with every QuantAct at running_stat = False).  Same arithmetic as the fp32
+// kernels of codenet_layers.hip on the values (q + zp) / scale -- the accumulation chains below are theirs -- with one
+// byte per element in HBM on both sides.
+//
+// value of a stored code: (q + zp) / scale by Markstein's division, bit-identical to cdn::fake_quant_r of the
+// pre-quantisation value that produced the code (codenet_fused.hip::unpack_code8)
+__device__ __forceinline__ float code_value(int q, float scale, float zp, float r) {
+  const float l = __fadd_rn((float)q, zp);
+  const float q0 = __fmul_rn(l, r);
+  return fmaf(fmaf(-q0, scale, l), r, q0);
+}
+
+// stemq8: stem_kernel<24> (dense 3x3 conv 3 -> 24 + folded BN + ReLU on the NCHW image, one lane per output pixel)
+// writing the codes of its QuantAct, rows of ld_out bytes.
+__global__ void __launch_bounds__(256)
+stemq8_kernel(const float *__restrict__ img, const float *__restrict__ w, const float *__restrict__ bias,
+              signed char *__restrict__ out8, const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, int H, int W,
+              int Ho, int Wo, int stride, int relu, int ld_out) {
+  constexpr int CO = 24;
+  const int n = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  BadMask bad = 0;
+  const Code8 c8 = make_code8(rq, bad);
+  if (p < (long)Ho * Wo) {
+    const int oy = (int)(p / Wo), ox = (int)(p - (long)oy * Wo);
+    float v[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int y = oy * stride + dy - 1, x = ox * stride + dx - 1;
+          v[(c * 3 + dy) * 3 + dx] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                                         ? img[(((long)n * 3 + c) * H + y) * W + x] : 0.0f;
+        }
+    unsigned *op = reinterpret_cast<unsigned *>(out8 + ((long)n * Ho * Wo + p) * ld_out);
+#pragma unroll
+    for (int c4 = 0; c4 < CO; c4 += 4) {
+      unsigned pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = c4 + e;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
+        acc += bias ? bias[co] : 0.0f;
+        if (relu) acc = fmaxf(acc, 0.0f);
+        pk |= (unsigned)(act_code8(acc, c8, bad) & 0xff) << (8 * e);
+      }
+      op[c4 >> 2] = pk;
+    }
+  }
+  if (bad) atomicOr(oflow, 1u);
+}
+
+// dwq8: depthwise 3x3 (stride 1 / 2, zero padding 1) + folded-BN bias [+ ReLU] on byte codes, channels-last rows of
+// ld_in / ld_out bytes.  One thread = one output pixel x 4 channels: nine 4-byte loads (the 3x3 neighbourhood's code
+// quads: L1 / L2 hits after the first touch, a byte tensor is small), the dws / dwx accumulation chain
+// acc = fmaf(w[dy][dx], x, acc) from zero in (dy, dx) order, then + bias, ReLU, the output code.
+template <int STRIDE>
+__global__ void __launch_bounds__(256)
+dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq, const float *__restrict__ w,
+            const float *__restrict__ bias, signed char *__restrict__ out8, const unsigned *__restrict__ rq,
+            unsigned *__restrict__ oflow, int C, int ld_in, int ld_out, int Hs, int Ws, int Ho, int Wo, int relu,
+            long total) {
+  const float qs = reinterpret_cast<const float *>(aq)[2], qz = reinterpret_cast<const float *>(aq)[3];
+  const float qr = __fdiv_rn(1.0f, qs);
+  BadMask bad = 0;
+  const Code8 c8 = make_code8(rq, bad);
+  const int CQ = (C + 3) >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cq = (int)(i % CQ);
+    const long pix = i / CQ;
+    const int ox = (int)(pix % Wo);
+    const long t2 = pix / Wo;
+    const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
+    const int cb = cq * 4;
+    float wk[9][4], bs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = min(cb + e, C - 1);
+      const bool live = cb + e < C;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
+      bs[e] = (live && bias) ? bias[c] : 0.0f;
+    }
+    const signed char *ab = a8 + (long)n * Hs * Ws * ld_in + cb;
+    unsigned cw[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int y = STRIDE * oy + dy - 1, x = STRIDE * ox + dx - 1;
+        const bool in = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        const long off = ((long)min(max(y, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1)) * ld_in;
+        cw[dy * 3 + dx] = in ? *reinterpret_cast<const unsigned *>(ab + off) : 0u;
+      }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int y = STRIDE * oy + dy - 1, x = STRIDE * ox + dx - 1;
+        const bool in = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        const unsigned u = cw[dy * 3 + dx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = (int)(signed char)((u >> (8 * e)) & 0xff);
+          const float t = in ? code_value(q, qs, qz, qr) : 0.0f;       // the conv's zero padding is the VALUE zero
+          acc[e] = fmaf(wk[dy * 3 + dx][e], t, acc[e]);
+        }
+      }
+    unsigned pk = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[e] + bs[e];
+      if (relu) v = fmaxf(v, 0.0f);
+      pk |= (unsigned)(act_code8(v, c8, bad) & 0xff) << (8 * e);
+    }
+    *reinterpret_cast<unsigned *>(out8 + ((long)n * Ho * Wo + (long)oy * Wo + ox) * ld_out + cb) = pk;
+  }
+  if (bad) atomicOr(oflow, 1u);
+}
 }  // namespace
 
 static int frozen_params_impl(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
@@ -301,12 +431,16 @@ static int pointwise_q8_impl(const signed char *a, const void *a_state, int64_t 
                              int64_t Co, const signed char *w_codes, const float *w_scale,
                              const int *w_colsum, const float *bias, int relu,
                              const void *r_state, signed char *r8_out, float *r_out,
-                             unsigned *overflow, void *stream, const signed char *nsc, int *sacc) {
+                             unsigned *overflow, void *stream, const signed char *nsc, int *sacc,
+                             int64_t lda = 0, int64_t ldo = 0, const int *omap = nullptr) {
   CDN_REQUIRE(a && a_state && w_codes && w_scale && w_colsum && overflow, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE((r8_out != nullptr) != (r_out != nullptr), CDN_ERR_ARG, "exactly one of r8_out / r_out");
   CDN_REQUIRE(r8_out == nullptr || r_state != nullptr, CDN_ERR_ARG, "byte output needs the output quantiser state");
-  CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && (C & 3) == 0, CDN_ERR_ARG, "bad size (C %% 4 == 0)");
-  CDN_REQUIRE(M * std::max(C, Co) < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && (((lda ? lda : C) & 3) == 0), CDN_ERR_ARG,
+              "bad size (the row length -- lda, or C when dense -- must be a multiple of 4)");
+  CDN_REQUIRE((lda == 0 || (lda >= C && (lda & 3) == 0)) && (ldo == 0 || ldo >= Co), CDN_ERR_ARG,
+              "row strides must be 0 (dense) or >= the channel counts (lda a multiple of 4)");
+  CDN_REQUIRE(M * std::max(std::max(C, Co), std::max(lda, ldo)) < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(a) & 3) == 0,
               CDN_ERR_ARG, "w_codes must be 16-byte, a 4-byte aligned");
   hipStream_t st = cdn::as_stream(stream);
@@ -324,7 +458,7 @@ static int pointwise_q8_impl(const signed char *a, const void *a_state, int64_t 
     else break;
   }
 #define CDN_Q8(BM_, BN_) \
-  launch_pwq8<BM_, BN_>(a, aq, w_codes, w_scale, w_colsum, bias, r8_out, r_out, rq, overflow, (long)M, (int)C, (int)Co, relu, st, nsc, sacc)
+  launch_pwq8<BM_, BN_>(a, aq, w_codes, w_scale, w_colsum, bias, r8_out, r_out, rq, overflow, (long)M, (int)C, (int)Co, relu, st, nsc, sacc, (int)lda, (int)ldo, omap)
   if (bn == 256) CDN_Q8(64, 256);
   else if (bn == 128) { if (bm == 64) CDN_Q8(64, 128); else CDN_Q8(128, 128); }
   else { if (bm == 64) CDN_Q8(64, 64); else CDN_Q8(128, 64); }
@@ -431,4 +565,54 @@ extern "C" int cdn_codenet_expand_codes(const signed char *a, const void *a_stat
   const int blocks = (int)std::min<long>(cdn::ceil_div(n4, 256), (long)cdn::kCUs * 8);
   expand8_kernel<<<blocks, 256, 0, cdn::as_stream(stream)>>>(a, static_cast<const unsigned *>(a_state), out, n4);
   return cdn::check_launch("codenet expand codes");
+}
+
+extern "C" int cdn_codenet_pointwise_q8_strided_forward(
+    const signed char *a, const void *a_state, int64_t M, int64_t C, int64_t Co, int64_t lda, int64_t ldo,
+    const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias, int relu,
+    const int *out_map, const void *r_state, signed char *r8_out, float *r_out, unsigned *overflow, void *stream) {
+  return pointwise_q8_impl(a, a_state, M, C, Co, w_codes, w_scale, w_colsum, bias, relu, r_state, r8_out, r_out,
+                           overflow, stream, nullptr, nullptr, lda, ldo, out_map);
+}
+
+extern "C" int cdn_codenet_stem_q8_forward(const float *img, int64_t N, int64_t H, int64_t W, int64_t Co, int stride,
+                                           const float *w, const float *bias, int relu, const void *r_state,
+                                           signed char *out8, int64_t ld_out, unsigned *overflow, void *stream) {
+  CDN_REQUIRE(img && w && r_state && out8 && overflow, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && H > 0 && W > 0 && stride >= 1 && N <= 65535, CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(Co == 24, CDN_ERR_UNSUPPORTED, "stem kernel is instantiated for 24 output channels (got %lld)",
+              (long long)Co);
+  CDN_REQUIRE(ld_out >= Co && (ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(out8) & 3) == 0, CDN_ERR_ARG,
+              "ld_out must be >= Co and a multiple of 4, out8 4-byte aligned");
+  const int Ho = (int)((H + 2 - 3) / stride + 1), Wo = (int)((W + 2 - 3) / stride + 1);
+  dim3 grid((unsigned)cdn::ceil_div((long)Ho * Wo, 256), (unsigned)N);
+  stemq8_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(img, w, bias, out8, static_cast<const unsigned *>(r_state),
+                                                          overflow, (int)H, (int)W, Ho, Wo, stride, relu, (int)ld_out);
+  return cdn::check_launch("codenet stem (byte codes)");
+}
+
+extern "C" int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H,
+                                            int64_t W, int stride, int64_t ld_in, int64_t ld_out, const float *w,
+                                            const float *bias, int relu, const void *r_state, signed char *out8,
+                                            unsigned *overflow, void *stream) {
+  CDN_REQUIRE(a8 && a_state && w && r_state && out8 && overflow, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), CDN_ERR_ARG, "bad size / stride");
+  const int64_t Cq4 = (C + 3) / 4 * 4;
+  CDN_REQUIRE(ld_in >= Cq4 && ld_out >= Cq4 && (ld_in & 3) == 0 && (ld_out & 3) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a8) & 3) == 0 && (reinterpret_cast<uintptr_t>(out8) & 3) == 0,
+              CDN_ERR_ARG, "rows must hold round_up(C, 4) bytes, strides multiples of 4, pointers 4-byte aligned");
+  const int Ho = stride == 2 ? (int)((H - 1) / 2 + 1) : (int)H, Wo = stride == 2 ? (int)((W - 1) / 2 + 1) : (int)W;
+  CDN_REQUIRE(N * H * W * ld_in < (1ll << 31) && N * Ho * (int64_t)Wo * ld_out < (1ll << 31), CDN_ERR_UNSUPPORTED,
+              "shape too large");
+  const long total = (long)N * Ho * Wo * ((C + 3) / 4);
+  const int blocks = (int)std::min<long>(cdn::ceil_div(total, 256), (long)cdn::kCUs * 32);
+  hipStream_t st = cdn::as_stream(stream);
+  const unsigned *aq = static_cast<const unsigned *>(a_state), *rq = static_cast<const unsigned *>(r_state);
+  if (stride == 2)
+    dwq8_kernel<2><<<blocks, 256, 0, st>>>(a8, aq, w, bias, out8, rq, overflow, (int)C, (int)ld_in, (int)ld_out, (int)H,
+                                           (int)W, Ho, Wo, relu, total);
+  else
+    dwq8_kernel<1><<<blocks, 256, 0, st>>>(a8, aq, w, bias, out8, rq, overflow, (int)C, (int)ld_in, (int)ld_out, (int)H,
+                                           (int)W, Ho, Wo, relu, total);
+  return cdn::check_launch("codenet dw3x3 (byte codes)");
 }

@@ -96,7 +96,7 @@ class PoseShuffleNetV2(nn.Module):
                 fc = nn.Conv2d(64, classes, kernel_size=1, stride=1, padding=0, bias=True)
             setattr(self, head, fc)
 
-    def enable_fused(self, flag=True, backbone=True, frozen_codes=False):
+    def enable_fused(self, flag=True, backbone=True, frozen_codes=False, frozen_backbone=True):
         """Inference on GPU tensors: run deconv_layers AND the heads on the fused HIP schedules
         (pipeline.FusedHotPath.forward_nhwc -> pipeline.FusedHeads; nothing is materialised between
         them) and, for a W4A8 model (backbone=True), layer0..layer4 on pipeline.FusedBackbone.  The
@@ -104,13 +104,17 @@ class PoseShuffleNetV2(nn.Module):
 
         frozen_codes (serving mode; needs every QuantAct of deconv_layers at running_stat False, e.g. after
         pipeline.set_running_stat(model, False)): the three deform stages run on the byte-code schedule
-        (pipeline.FrozenHotPath, chained scale sums).  The reference does not clamp activation codes, a byte must:
-        check ``frozen_overflowed()`` after a batch and recompute it with frozen_codes off if it says True."""
+        (pipeline.FrozenHotPath, chained scale sums), and -- frozen_backbone, when the QuantActs of layer0..layer4
+        are frozen too and pipeline.FrozenBackbone.supported(model) -- the backbone on byte codes as well, so that
+        every activation between the image and the heads crosses HBM as one byte.  The reference does not clamp
+        activation codes, a byte must: check ``frozen_overflowed()`` after a batch and recompute it with frozen_codes
+        off if it says True (pipeline.cover_frozen_ranges widens EMA ranges over calibration batches beforehand)."""
         from .portable_quantizer.quant_modules import QuantAct
         self._fused = bool(flag)
         self._fused_backbone = bool(backbone)
         self._frozen_codes = bool(frozen_codes)
-        self._fpath = self._fheads = self._fbackbone = self._ffrozen = None
+        self._frozen_backbone = bool(frozen_backbone)
+        self._fpath = self._fheads = self._fbackbone = self._ffrozen = self._fzbackbone = None
         # the QuantActs whose settings decide _fused_ok(): collected once (the module tree is fixed after
         # quantize_shufflenetv2_dcn), so a forward reads 5 attributes of ~70 modules instead of walking the tree
         self.__dict__["_fused_acts"] = [a for a in self.modules() if isinstance(a, QuantAct)]
@@ -126,8 +130,11 @@ class PoseShuffleNetV2(nn.Module):
 
     def frozen_overflowed(self):
         """True when a code of the byte-code stage schedule saturated since the last call (synchronises, resets)."""
-        f = getattr(self, "_ffrozen", None)
-        return bool(f is not None and f.overflowed())
+        hit = False
+        for f in (getattr(self, "_ffrozen", None), getattr(self, "_fzbackbone", None)):
+            if f is not None and f.overflowed():
+                hit = True
+        return hit
 
     def _fused_ok(self, x):
         """The fused schedules implement the reference's default QuantAct settings and stored planes that fit
@@ -167,7 +174,13 @@ class PoseShuffleNetV2(nn.Module):
             if getattr(self, "_frozen_codes", False) and self._stage_acts_frozen():
                 if self._ffrozen is None:
                     self._ffrozen = pipeline.FrozenHotPath(self.deconv_layers, chain_scale=True)
+                    self._fzbackbone = (pipeline.FrozenBackbone(self) if self._fbackbone is not None
+                                        and self._frozen_backbone and pipeline.FrozenBackbone.supported(self) else None)
                 stages = self._ffrozen
+                # every QuantAct of the backbone frozen too: byte codes end to end
+                if self._fzbackbone is not None and self._fzbackbone.still_frozen():
+                    feat8, fq, hw = self._fzbackbone(x)
+                    return [self._fheads(*stages.forward_nhwc(feat8, fq, hw))]
             if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
                 feat, fq, hw = self._fbackbone(x)       # hw None: an NCHW tensor (odd channel count)
                 return [self._fheads(*stages.forward_nhwc(feat, fq, hw))]

@@ -92,6 +92,61 @@ def set_running_stat(net, flag):
             m.running_stat = flag
 
 
+def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
+    """Deployment step for the byte-code serving mode.  With ``running_stat = False`` the reference keeps the EMA
+    ranges it trained with (quant_modules.py:203-219 skipped) and a value outside such a range simply becomes a code
+    beyond the 8-bit grid (the fake-quantised float has no clamp, quant_utils.py:132-171).  A byte cannot hold that code
+    -- the frozen kernels flag it (``overflowed()``) and the caller goes back to the fp32 schedule -- and an EMA range
+    is routinely exceeded: a QuantAct shared by the units of a ShuffleNetV2 layer averages the extremes of four
+    different tensors.  This helper runs ``forward(batch)`` (default: ``net``) on calibration batches with every
+    QuantAct frozen, records what each one is fed, and WIDENS x_min / x_max (never narrows) to cover it with `margin` of
+    the span to spare; two passes, since moving a grid moves what the layers behind it see.  It changes the model's
+    quantisation grids -- the same widened model is what the fp32 frozen schedule is compared on.  Returns the number of
+    QuantActs whose range moved."""
+    from .portable_quantizer.quant_modules import QuantAct
+    acts = [m for m in net.modules() if isinstance(m, QuantAct)]
+    was = [a.running_stat for a in acts]
+    forward = forward if forward is not None else net
+    moved = set()
+    try:
+        for a in acts:
+            a.running_stat = False
+        for _ in range(passes):
+            seen = {}
+
+            def hook(mod, args):
+                x = args[0].detach()
+                lo, hi = x.min().float(), x.max().float()
+                if id(mod) in seen:
+                    seen[id(mod)] = (torch.minimum(seen[id(mod)][0], lo), torch.maximum(seen[id(mod)][1], hi))
+                else:
+                    seen[id(mod)] = (lo, hi)
+            handles = [a.register_forward_pre_hook(hook) for a in acts]
+            try:
+                with torch.no_grad():
+                    for b in batches:
+                        forward(b)
+            finally:
+                for h_ in handles:
+                    h_.remove()
+            with torch.no_grad():
+                for a in acts:
+                    if id(a) not in seen:
+                        continue
+                    lo, hi = seen[id(a)]
+                    span = (torch.maximum(hi, a.x_max.reshape(())) - torch.minimum(lo, a.x_min.reshape(()))) * margin
+                    new_lo = torch.minimum(a.x_min.reshape(()), lo - span)
+                    new_hi = torch.maximum(a.x_max.reshape(()), hi + span)
+                    if bool(new_lo < a.x_min.reshape(())) or bool(new_hi > a.x_max.reshape(())):
+                        moved.add(id(a))
+                    a.x_min.copy_(new_lo.reshape(a.x_min.shape))
+                    a.x_max.copy_(new_hi.reshape(a.x_max.shape))
+    finally:
+        for a, f in zip(acts, was):
+            a.running_stat = f
+    return len(moved)
+
+
 def broadcast_parameters(net, src=0):
     """Start-up broadcast of every parameter and buffer from `src` as ONE flat tensor
     (RCCL over xGMI when the process group backend is nccl; gloo in the CPU tests)."""
@@ -1399,3 +1454,169 @@ class FusedBackbone:
                 N_.check(rc, "cdn_codenet_unpack_nchw")
                 return B["out_nchw"], None, None
         return B["out"], qptr(act4), (H, W)
+
+
+class FrozenBackbone:
+    """layer0 .. layer4 of a W4A8 ``PoseShuffleNetV2`` with every QuantAct FROZEN (``running_stat = False``: the
+    serving mode, quant_modules.py:172,181,203-219 skipped) on BYTE CODES: every activation crosses HBM as one byte
+    per element (the code of its QuantAct), every 1x1 conv is the int8-MFMA kernel on the codes as they lie in memory
+    (cdn_codenet_pointwise_q8_strided_forward), the depthwise convs and the stem write codes directly
+    (cdn_codenet_dw3x3_q8_forward, cdn_codenet_stem_q8_forward); no range epilogues, no arrival counters.  With frozen
+    ranges the layer's shared block-output QuantAct is ONE fixed grid, so the "generations" of the running-range
+    schedule (FusedBackbone) collapse and a layer is one int8 tensor whose channel slots never move (same slot
+    assignment and permuted weight codes as FusedBackbone._mixed_plan).  Returns (codes [N, H*W, 1024] int8, state
+    pointer of layer4's QuantAct, (H, W)) -- what ``FrozenHotPath.forward_codes`` takes.
+
+    Arithmetic: the depthwise chains and the stem are those of the fp32 kernels on the values (q + zp) / scale
+    (bit-identical); a unit's first 1x1 conv is an EXACT integer sum here where the running-range schedule
+    accumulates exact products in fp32 (pwd3_kernel), so results agree with FusedBackbone at running_stat False up
+    to single code flips (tests/test_gpu_backbone.py).  A saturated code sets the overflow flag (``overflowed()``)."""
+
+    def __init__(self, model):
+        self.model = model
+        self._fb = FusedBackbone(model)
+        self._bufs = None
+
+    @staticmethod
+    def supported(model):
+        from .portable_quantizer.quant_modules import QuantAct
+        if not FusedBackbone.supported(model) or not hasattr(model.layer0[0], "folded"):
+            return False
+        fb = FusedBackbone(model)
+        if len(model.layer0[1]) != 2:                       # "S2 + MaxPool" stems keep the fp32 schedule
+            return False
+        for name in ("layer1", "layer2", "layer3"):
+            if not fb.mixed_supported(list(getattr(model, name))):
+                return False
+        q4 = model.layer4[0]
+        if q4.folded_int8() is None or q4.conv.out_channels % 4:
+            return False
+        acts = [a for n in ("layer0", "layer1", "layer2", "layer3", "layer4") for a in getattr(model, n).modules()
+                if isinstance(a, QuantAct)]
+        return bool(acts) and len(acts) <= 48 and all(act_fusable(a) and not a.running_stat for a in acts)
+
+    def still_frozen(self):
+        """The per-forward check (supported() walks the module tree once, when the object is built)."""
+        from .portable_quantizer.quant_modules import QuantAct
+        acts = self.__dict__.get("_acts")
+        if acts is None:
+            acts = self._acts = [a for n in ("layer0", "layer1", "layer2", "layer3", "layer4")
+                                 for a in getattr(self.model, n).modules() if isinstance(a, QuantAct)]
+        return not any(a.running_stat for a in acts)
+
+    def overflowed(self):
+        if self._bufs is None:
+            return False
+        flag = bool(self._bufs["overflow"].item())
+        if flag:
+            self._bufs["overflow"].zero_()
+        return flag
+
+    def _alloc(self, images, key):
+        import ctypes
+        from .portable_quantizer.quant_modules import QuantAct
+        m, dev = self.model, images.device
+        acts = []
+        for n in ("layer0", "layer1", "layer2", "layer3", "layer4"):
+            for a in getattr(m, n).modules():
+                if isinstance(a, QuantAct) and all(a is not b for b in acts):
+                    acts.append(a)
+        arr = ctypes.c_void_p * len(acts)
+        self._bufs = dict(
+            key=key, layers={}, overflow=torch.zeros(1, dtype=torch.int32, device=dev), acts=acts, n_acts=len(acts),
+            p_min=arr(*[a.x_min.data_ptr() for a in acts]), p_max=arr(*[a.x_max.data_ptr() for a in acts]),
+            p_state=arr(*[a._device_state(dev).data_ptr() for a in acts]))
+
+    @staticmethod
+    def _ld(c):
+        return (c + 15) // 16 * 16          # 16-byte aligned byte rows (the int8 pointwise loads 16 bytes per lane)
+
+    def _layer(self, name, nodes, x8, x_ld, x_state, in_logical, Nb, H, W):
+        from . import _native as N_
+        fb, lib, B = self._fb, N_.lib(), self._bufs
+        dev = x8.device
+        plan = fb._mixed_plan(nodes, in_logical, dev, None)
+        units = [fb._unit(n) for n in nodes]
+        h, cin, C = plan["h"], plan["cin"], plan["C"]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        Mi, Mo = Nb * H * W, Nb * Ho * Wo
+        ldh, ldc, ldi = self._ld(h), self._ld(C), self._ld(cin)
+        L = B["layers"].get(name)
+        if L is None:
+            z = lambda m_, c_: torch.zeros(m_, c_, dtype=torch.int8, device=dev)   # noqa: E731
+            L = B["layers"][name] = dict(Y=z(Mo, ldc), t4=z(Mo, ldi), t1s2=z(Mi, ldh), t1=z(Mo, ldh), t2=z(Mo, ldh))
+        of, st = B["overflow"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream
+        qp = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
+
+        def pw(a, a_state, M, K, lda, Wt, act, out, ldo, omap):
+            rc = lib.cdn_codenet_pointwise_q8_strided_forward(
+                a.data_ptr(), a_state, M, K, Wt["Co"], lda, ldo, Wt["codes"].data_ptr(), Wt["scale"].data_ptr(),
+                Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), 1, omap, qp(act), out.data_ptr(), None, of, st)
+            N_.check(rc, "cdn_codenet_pointwise_q8_strided_forward")
+
+        def dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, out, ld_out):
+            rc = lib.cdn_codenet_dw3x3_q8_forward(a.data_ptr(), a_state, Nb, Cc, Hs, Ws, stride, ld_in, ld_out,
+                                                  w.data_ptr(), b.data_ptr(), 0, qp(act), out.data_ptr(), of, st)
+            N_.check(rc, "cdn_codenet_dw3x3_q8_forward")
+
+        Y = L["Y"]
+        with torch.no_grad():
+            for k, (u, P) in enumerate(zip(units, plan["units"])):
+                sh = u["sh"]
+                if k == 0:
+                    # branch 1: dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct (slots omapA)
+                    dw(x8, x_state, cin, H, W, 2, x_ld, P["w4"], P["b4"], u["a4"], L["t4"], ldi)
+                    pw(L["t4"], qp(u["a4"]), Mo, cin, ldi, P["c5"], sh, Y, ldc, P["omapA"].data_ptr())
+                    # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct (omapB)
+                    pw(x8, x_state, Mi, cin, x_ld, P["c1"], u["a1"], L["t1s2"], ldh, None)
+                    dw(L["t1s2"], qp(u["a1"]), h, H, W, 2, ldh, P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                else:
+                    pw(Y, qp(sh), Mo, C, ldc, P["c1"], u["a1"], L["t1"], ldh, None)
+                    dw(L["t1"], qp(u["a1"]), h, Ho, Wo, 1, ldh, P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                pw(L["t2"], qp(u["a2"]), Mo, h, ldh, P["c3"], sh, Y, ldc, P["omapB"].data_ptr())
+        return Y, ldc, qp(units[0]["sh"]), plan["logical"], Ho, Wo
+
+    def __call__(self, images):
+        from . import _native as N_
+        if not (images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3):
+            raise NotImplementedError("FrozenBackbone needs a [N,3,H,W] float32 GPU tensor")
+        images = images.contiguous()
+        m, dev, lib = self.model, images.device, N_.lib()
+        Nb, _, R, R2 = images.shape
+        # (the cached pointer arrays name the QuantActs' range buffers: their addresses are part of the key)
+        stale = (self._bufs is None or self._bufs["key"][:2] != (tuple(images.shape), dev)
+                 or self._bufs["key"][2:] != tuple(a.x_min.data_ptr() for a in self._bufs["acts"]))
+        if stale:
+            self._alloc(images, None)
+            self._bufs["key"] = (tuple(images.shape), dev) + tuple(a.x_min.data_ptr() for a in self._bufs["acts"])
+        B = self._bufs
+        st = torch.cuda.current_stream(dev).cuda_stream
+        bits, _, _ = uniform_act_settings(B["acts"], "FrozenBackbone")
+        N_.check(lib.cdn_quantact_frozen_params(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits, st),
+                 "cdn_quantact_frozen_params")
+        q0, act0 = m.layer0[0], m.layer0[1][1]
+        q4, act4 = m.layer4[0], m.layer4[1][1]
+        s0 = q0.conv.stride[0]
+        H, W = (R + 2 - 3) // s0 + 1, (R2 + 2 - 3) // s0 + 1
+        with torch.no_grad():
+            w0, b0 = self._fb._folded(q0)
+            if B.get("x0") is None:
+                B["x0"] = torch.zeros(Nb, H * W, 32, dtype=torch.int8, device=dev)
+            rc = lib.cdn_codenet_stem_q8_forward(images.data_ptr(), Nb, R, R2, 24, s0, w0.reshape(24, 27).data_ptr(),
+                                                 b0.data_ptr(), 1, act0._device_state(dev).data_ptr(),
+                                                 B["x0"].data_ptr(), 32, B["overflow"].data_ptr(), st)
+            N_.check(rc, "cdn_codenet_stem_q8_forward")
+            x8, x_ld, x_state, logical = B["x0"], 32, act0._device_state(dev).data_ptr(), None
+            for name in ("layer1", "layer2", "layer3"):
+                x8, x_ld, x_state, logical, H, W = self._layer(name, list(getattr(m, name)), x8, x_ld, x_state, logical,
+                                                               Nb, H, W)
+            c4 = q4.conv.out_channels
+            if B.get("out") is None:
+                B["out"] = torch.empty(Nb, H * W, c4, dtype=torch.int8, device=dev)
+            W4 = self._fb._l4_weights(q4, logical, dev, None)
+            rc = lib.cdn_codenet_pointwise_q8_strided_forward(
+                x8.data_ptr(), x_state, Nb * H * W, W4["K"], c4, x_ld, c4, W4["codes"].data_ptr(),
+                W4["scale"].data_ptr(), W4["colsum"].data_ptr(), W4["bias"].data_ptr(), 1, None,
+                act4._device_state(dev).data_ptr(), B["out"].data_ptr(), None, B["overflow"].data_ptr(), st)
+            N_.check(rc, "cdn_codenet_pointwise_q8_strided_forward (layer4)")
+        return B["out"], act4._device_state(dev).data_ptr(), (H, W)

@@ -338,6 +338,27 @@ int cdn_codenet_pointwise_q8_forward(const signed char *a, const void *a_state, 
                                      const signed char *w_codes, const float *w_scale, const int *w_colsum,
                                      const float *bias, int relu, const void *r_state, signed char *r8_out,
                                      float *r_out, unsigned *overflow, void *stream);
+/* Byte-code counterparts of the layers around the hot path (frozen serving mode: every QuantAct at running_stat
+ * False; same arithmetic as cdn_codenet_{pointwise,dw3x3}_nhwc_forward / cdn_codenet_stem_forward on
+ * the values (q + zp) / scale, one byte per element in HBM; a saturated output code sets *overflow):
+ *   cdn_codenet_pointwise_q8_strided_forward  cdn_codenet_pointwise_q8_forward with row strides lda / ldo (bytes / elements
+ *       per row, 0 = dense, lda % 4 == 0) and an optional output channel map (out_map[co] = slot of channel co:
+ *       the shuffle-free unit layout of pipeline.FusedBackbone);
+ *   cdn_codenet_stem_q8_forward   layer0: dense 3x3 conv 3 -> 24 (stride 2 / 4, pad 1) + folded BN + ReLU on the NCHW
+ *       fp32 image -> codes of its QuantAct, channels-last rows of ld_out bytes (shufflenetv2_dcn.py:205-214);
+ *   cdn_codenet_dw3x3_q8_forward  depthwise 3x3 (stride 1 / 2, pad 1) + folded-BN bias [+ ReLU] on codes, rows of
+ *       ld_in / ld_out bytes holding round_up(C, 4) channels. */
+int cdn_codenet_pointwise_q8_strided_forward(
+    const signed char *a, const void *a_state, int64_t M, int64_t C, int64_t Co, int64_t lda, int64_t ldo,
+    const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias, int relu,
+    const int *out_map, const void *r_state, signed char *r8_out, float *r_out, unsigned *overflow, void *stream);
+int cdn_codenet_stem_q8_forward(const float *img, int64_t N, int64_t H, int64_t W, int64_t Co, int stride,
+                                const float *w, const float *bias, int relu, const void *r_state,
+                                signed char *out8, int64_t ld_out, unsigned *overflow, void *stream);
+int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H,
+                                 int64_t W, int stride, int64_t ld_in, int64_t ld_out, const float *w,
+                                 const float *bias, int relu, const void *r_state, signed char *out8,
+                                 unsigned *overflow, void *stream);
 int cdn_codenet_expand_codes(const signed char *a, const void *a_state, float *out, int64_t numel, void *stream);
 
 /* out_nchw[n][c][(h<<up)+dy][(w<<up)+dx] = fq(r_nhwc[n][h*W+w][c]): channels-last -> NCHW with the

@@ -475,3 +475,91 @@ def test_int8_pointwise_exact_integer_sums(M, C, Co, relu):
     assert xmin.item() == out.min().item() and xmax.item() == out.max().item()
 
 
+
+
+@pytest.mark.parametrize("res,batch", [(64, 2), (128, 3), (256, 2)])
+def test_frozen_backbone_on_byte_codes_matches_fp32_frozen_schedule(res, batch):
+    """pipeline.FrozenBackbone (stem, 16 units, layer4 on BYTE CODES: cdn_codenet_stem_q8 / dw3x3_q8 /
+    pointwise_q8_strided, every QuantAct frozen) against FusedBackbone on the same model with running_stat False.
+    The depthwise chains and the stem are the fp32 kernels' arithmetic on (q + zp) / scale; a unit's first 1x1 conv is an
+    exact integer sum here where the running-range schedule accumulates exact products in fp32, so single codes can
+    flip, and a flip early in this deep random-weight network moves many codes behind it.  The yardstick is the
+    difference between FusedBackbone and the MODULE path (torch ops) on the same frozen model: the byte schedule must
+    be at least that close to FusedBackbone.  The kernels themselves are pinned exactly in
+    test_dw3x3_q8_is_the_fp32_kernel_on_code_values, test_gpu_frozen.py::test_stem_q8_* and *_strided_*.  No overflow
+    (ranges covered by pipeline.cover_frozen_ranges); no range moves."""
+    import copy
+    from codenet_amd import harness, pipeline
+    model = harness.create_model(quantize=True).cuda()
+    fb = pipeline.FusedBackbone(model)
+    g = torch.Generator().manual_seed(res + batch)
+    xs = [torch.randn(batch, 3, res, res, generator=g).cuda() for i in range(3)]
+    for _ in range(20):
+        for x in xs:
+            fb(x)                                           # running ranges settle
+    pipeline.set_running_stat(model, False)
+    # the byte grid must hold every code: widen the EMA ranges over what the frozen network feeds each QuantAct
+    assert pipeline.cover_frozen_ranges(model, xs, margin=0.05) > 0
+    assert pipeline.FrozenBackbone.supported(model)
+    ranges = [(a.x_min.item(), a.x_max.item()) for a in model.modules() if hasattr(a, "x_min") and isinstance(a.x_min, torch.Tensor)]
+    fz = pipeline.FrozenBackbone(model)
+    act4 = model.layer4[1][1]
+    for x in xs:
+        feat, fq, hw = fb(x)
+        st = act4._device_state(x.device).view(torch.float32)
+        want = torch.round(st[2] * feat - st[3])            # codes of the fp32 schedule's pre-quantisation output
+        with torch.no_grad():                               # the module path (torch ops): the noise yardstick
+            r = x
+            for name in ("layer0", "layer1", "layer2", "layer3", "layer4"):
+                r = getattr(model, name)(r)
+        mod = torch.round(st[2] * r - st[3]).permute(0, 2, 3, 1).reshape(want.shape)
+        got, gq, ghw = fz(x)
+        assert got.dtype == torch.int8 and tuple(got.shape) == tuple(feat.shape) and ghw == hw and gq == fq
+        assert not fz.overflowed()
+        d, noise = (got.float() - want).abs(), (want - mod).abs()
+        print("   res %d: %.2e of the layer4 codes differ, mean %.3f max %d LSB   (fp32 schedule vs module path: "
+              "%.2e, mean %.3f max %d)" % (res, (d > 0).float().mean().item(), d.mean().item(), int(d.max().item()),
+                                           (noise > 0).float().mean().item(), noise.mean().item(), int(noise.max().item())))
+        # a flipped code early in a 50-layer random-weight network moves many codes behind it: the two schedules may
+        # differ by what two ACCEPTED implementations of the reference differ by, not more
+        assert d.mean().item() <= max(0.02, 1.25 * noise.mean().item())
+        assert d.max().item() <= max(4, 2 * noise.max().item())
+    assert ranges == [(a.x_min.item(), a.x_max.item()) for a in model.modules()
+                      if hasattr(a, "x_min") and isinstance(a.x_min, torch.Tensor)]
+
+
+@pytest.mark.parametrize("N,C,H,W,stride,ld", [(2, 58, 9, 11, 1, 64), (1, 24, 16, 16, 2, 32), (3, 116, 7, 8, 2, 128),
+                                                 (2, 232, 5, 5, 1, 240)])
+def test_dw3x3_q8_is_the_fp32_kernel_on_code_values(N, C, H, W, stride, ld):
+    """cdn_codenet_dw3x3_q8_forward (byte codes in, byte codes out) against the fp32 depthwise kernel fed with the
+    values (q + zp) / scale and the same quantiser state (frozen), its output quantised with the output state:
+    identical codes (same accumulation chain), padding channels ignored."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(C + H)
+    codes = torch.randint(-128, 128, (N, H * W, ld), generator=g, dtype=torch.int32).to(torch.int8).to(dev)
+    sa = ops.quantact_state(dev); sr = ops.quantact_state(dev)
+    sa.view(torch.float32)[2], sa.view(torch.float32)[3] = 31.7, -17.0
+    sr.view(torch.float32)[2], sr.view(torch.float32)[3] = 9.3, -101.0
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.4).to(dev)
+    b = (torch.randn(C, generator=g) * 0.2).to(dev)
+    Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if stride == 2 else (H, W)
+    out8 = torch.zeros(N, Ho * Wo, ld, dtype=torch.int8, device=dev)
+    of = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = lib.cdn_codenet_dw3x3_q8_forward(codes.data_ptr(), sa.data_ptr(), N, C, H, W, stride, ld, ld, w.data_ptr(),
+                                          b.data_ptr(), 0, sr.data_ptr(), out8.data_ptr(), of.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "dw q8")
+    # fp32 reference path: the same values through the fp32 kernel (no input quantiser: final values), then the code
+    vals = ((codes.float() + sa.view(torch.float32)[3]) / sa.view(torch.float32)[2]).contiguous()
+    out = torch.empty(N, Ho * Wo, ld, device=dev)
+    rc = lib.cdn_codenet_dw3x3_nhwc_forward(vals.data_ptr(), None, N, C, H, W, 0, stride, ld, ld, w.data_ptr(),
+                                            b.data_ptr(), None, None, 0, None, None, None, 8, 0.99, 0, wp, wb,
+                                            out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    N_.check(rc, "dw fp32")
+    s2, z2 = sr.view(torch.float32)[2], sr.view(torch.float32)[3]
+    want = torch.round(s2 * out[:, :, :C] - z2)
+    inside = (want >= -128) & (want <= 127)
+    assert torch.equal(out8[:, :, :C].float()[inside], want[inside])
+    assert bool(of.item()) == bool((~inside).any().item())

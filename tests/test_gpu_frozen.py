@@ -280,3 +280,82 @@ def test_pointwise_q8_exact_integer_sums(M, C, Co):
                                                   r_state.data_ptr(), out8.data_ptr(), None, flag.data_ptr(), st), "q8 s")
     torch.cuda.synchronize()
     assert flag.item() == 1 and out8.max().item() == 127
+
+
+@pytest.mark.parametrize("M,C,Co,lda,ldo", [(300, 58, 58, 64, 128), (1000, 24, 58, 32, 128), (513, 232, 232, 240, 464),
+                                             (77, 116, 116, 128, 240), (4096, 464, 1024, 464, 1024)])
+def test_pointwise_q8_strided_rows_and_output_map(M, C, Co, lda, ldo):
+    """cdn_codenet_pointwise_q8_strided_forward: rows of lda bytes holding C codes (the bytes behind them are junk
+    paired with zero weight codes), outputs scattered through out_map into rows of ldo bytes whose other slots stay
+    untouched -- the same bytes as the dense entry point on the compacted operands."""
+    from codenet_amd import _native as N_
+    g = torch.Generator().manual_seed(M + C + ldo)
+    a = torch.randint(-128, 128, (M, lda), generator=g, dtype=torch.int32).to(torch.int8).cuda()
+    qw = torch.randint(-8, 8, (Co, C), generator=g, dtype=torch.int32)
+    cpad = (C + 63) // 64 * 64
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = qw.to(torch.int8)
+    codes = codes.cuda()
+    wscale = (torch.rand(Co, generator=g) * 20 + 5).cuda()
+    colsum = qw.sum(1).to(torch.int32).cuda()
+    bias = (torch.randn(Co, generator=g) * 0.1).cuda()
+    a_state = torch.zeros(8, dtype=torch.float32).cuda()
+    r_state = torch.zeros(8, dtype=torch.float32).cuda()
+    a_state[2], a_state[3] = 37.5, -23.0
+    r_state[2], r_state[3] = 255.0 / (C * 0.35), 128.0
+    omap = torch.randperm(ldo, generator=g)[:Co].to(torch.int32).cuda()
+    lib, st = N_.lib(), torch.cuda.current_stream().cuda_stream
+    flag = torch.zeros(1, dtype=torch.int32).cuda()
+    dense_a = a[:, :C].contiguous() if C % 4 == 0 else None
+    out = torch.full((M, ldo), 77, dtype=torch.int8).cuda()
+    N_.check(lib.cdn_codenet_pointwise_q8_strided_forward(
+        a.data_ptr(), a_state.data_ptr(), M, C, Co, lda, ldo, codes.data_ptr(), wscale.data_ptr(), colsum.data_ptr(),
+        bias.data_ptr(), 1, omap.data_ptr(), r_state.data_ptr(), out.data_ptr(), None, flag.data_ptr(), st), "strided")
+    # expected: exact integer sum -> the fp32 epilogue expressions -> code
+    isum = (a[:, :C].cpu().double() - 23.0) @ qw.double().t()
+    rinv = 1.0 / (torch.tensor(37.5) * wscale.cpu())
+    v = torch.relu(torch.addcmul(bias.cpu(), isum.float(), rinv))
+    want = torch.round(r_state[2].cpu() * v - r_state[3].cpu()).clamp(-128, 127)
+    got = out.cpu()
+    touched = torch.zeros(ldo, dtype=torch.bool)
+    touched[omap.cpu().long()] = True
+    assert torch.equal(got[:, omap.cpu().long()].float(), want)
+    assert bool((got[:, ~touched] == 77).all())
+    if dense_a is not None:
+        dense = torch.empty(M, Co, dtype=torch.int8).cuda()
+        N_.check(lib.cdn_codenet_pointwise_q8_forward(dense_a.data_ptr(), a_state.data_ptr(), M, C, Co, codes.data_ptr(),
+                                                      wscale.data_ptr(), colsum.data_ptr(), bias.data_ptr(), 1,
+                                                      r_state.data_ptr(), dense.data_ptr(), None, flag.data_ptr(), st), "dense")
+        assert torch.equal(dense.cpu(), got[:, omap.cpu().long()])
+
+
+@pytest.mark.parametrize("N,R,stride", [(2, 64, 2), (3, 96, 4), (1, 250, 2)])
+def test_stem_q8_is_the_fp32_stem_then_the_code(N, R, stride):
+    """cdn_codenet_stem_q8_forward against cdn_codenet_stem_forward (frozen state, running = 0) followed by the code
+    expression: identical bytes, padding bytes of the 32-byte rows untouched."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(R)
+    img = torch.randn(N, 3, R, R, generator=g).to(dev)
+    w = (torch.randn(24, 27, generator=g) * 0.3).to(dev)
+    b = (torch.randn(24, generator=g) * 0.1).to(dev)
+    Ho = (R + 2 - 3) // stride + 1
+    aux = lib.cdn_codenet_aux_workspace_bytes()
+    ws = torch.zeros(aux // 4 + 64, device=dev)
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    sr = ops.quantact_state(dev)
+    sr.view(torch.float32)[2], sr.view(torch.float32)[3] = 18.0, 128.0
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(N, Ho * Ho, 24, device=dev)
+    N_.check(lib.cdn_codenet_stem_forward(img.data_ptr(), N, R, R, 24, stride, w.data_ptr(), b.data_ptr(), 1, None, None,
+                                          None, 8, 0.99, 0, wp, (ws.numel() * 4 - 256) // 256 * 256, out.data_ptr(), st),
+             "stem fp32")
+    out8 = torch.full((N, Ho * Ho, 32), 55, dtype=torch.int8, device=dev)
+    of = torch.zeros(1, dtype=torch.int32, device=dev)
+    N_.check(lib.cdn_codenet_stem_q8_forward(img.data_ptr(), N, R, R, 24, stride, w.data_ptr(), b.data_ptr(), 1,
+                                             sr.data_ptr(), out8.data_ptr(), 32, of.data_ptr(), st), "stem q8")
+    want = torch.round(18.0 * out - 128.0)
+    inside = (want >= -128) & (want <= 127)
+    assert torch.equal(out8[:, :, :24].float()[inside], want[inside])
+    assert bool((out8[:, :, 24:] == 55).all())
+    assert bool(of.item()) == bool((~inside).any().item())

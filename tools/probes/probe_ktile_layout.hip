@@ -7,7 +7,7 @@
 // Build: hipcc -O3 --offload-arch=gfx950.  Results: DESIGN.md section 8.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <int LAYOUT, int DEPTH, int BM>
+template <int LAYOUT, int DEPTH, int BM, bool BAR = true>
 __global__ void __launch_bounds__(256) k(const float *A, float *out, int M, int K) {
   constexpr int AI = BM / 32;
   const int m0 = blockIdx.x * BM, tid = threadIdx.x;
@@ -34,24 +34,24 @@ __global__ void __launch_bounds__(256) k(const float *A, float *out, int M, int 
         acc += v.x + v.y + v.z + v.w;
         if (t + DEPTH < nk) ring[d][i] = *addr(i, t + DEPTH);
       }
-      __syncthreads();
+      if (BAR) __syncthreads();
     }
   }
   out[(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid] = acc;
 }
-template <int LAYOUT, int DEPTH, int BM>
+template <int LAYOUT, int DEPTH, int BM, bool BAR = true, int NY = 2>
 void run(const float *A, float *out, float *junk, int M, int K) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float best = 1e9f;
   for (int rep = 0; rep < 4; ++rep) {
     (void)hipMemsetAsync(junk, rep, 512u << 20);          // evict A from the Infinity Cache
     (void)hipEventRecord(e0);
-    k<LAYOUT, DEPTH, BM><<<dim3(M / BM, 2), 256>>>(A, out, M, K);
+    k<LAYOUT, DEPTH, BM, BAR><<<dim3(M / BM, NY), 256>>>(A, out, M, K);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep > 0 && ms < best) best = ms;
   }
-  printf("layout %d depth %d BM %3d: %6.1f us  (%.2f TB/s of the 67 MB read once)\n", LAYOUT, DEPTH, BM, best * 1e3, 67.1 / (best * 1e3));
+  printf("layout %d depth %d BM %3d barrier %d column tiles %d: %6.1f us  (%.2f TB/s of the 67 MB read once)\n", LAYOUT, DEPTH, BM, (int)BAR, NY, best * 1e3, 67.1 / (best * 1e3));
 }
 int main() {
   const int M = 16384, K = 1024;
@@ -62,5 +62,10 @@ int main() {
   run<0, 1, 32>(A, out, junk, M, K); run<0, 2, 32>(A, out, junk, M, K); run<0, 4, 32>(A, out, junk, M, K); run<0, 8, 32>(A, out, junk, M, K);
   run<1, 1, 64>(A, out, junk, M, K); run<1, 2, 64>(A, out, junk, M, K); run<1, 4, 64>(A, out, junk, M, K); run<1, 8, 64>(A, out, junk, M, K);
   run<1, 1, 32>(A, out, junk, M, K); run<1, 2, 32>(A, out, junk, M, K); run<1, 4, 32>(A, out, junk, M, K); run<1, 8, 32>(A, out, junk, M, K);
+  // without the per-tile barrier / without the second column-tile workgroup re-reading the same pieces
+  run<0, 2, 64, false>(A, out, junk, M, K); run<1, 2, 64, false>(A, out, junk, M, K);
+  run<0, 2, 64, true, 1>(A, out, junk, M, K); run<1, 2, 64, true, 1>(A, out, junk, M, K);
+  run<0, 4, 32, false, 1>(A, out, junk, M, K); run<1, 4, 32, false, 1>(A, out, junk, M, K);
+  run<1, 8, 32, false, 1>(A, out, junk, M, K);
   return 0;
 }
