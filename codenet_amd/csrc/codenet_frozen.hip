@@ -314,27 +314,32 @@ stemq8_kernel(const float *__restrict__ img, const float *__restrict__ w, const 
 }
 
 // dwq8: depthwise 3x3 (stride 1 / 2, zero padding 1) + folded-BN bias [+ ReLU] on byte codes, channels-last rows of
-// ld_in / ld_out bytes.  One thread = one output pixel x 4 channels: nine 4-byte loads (the 3x3 neighbourhood's code
-// quads: L1 / L2 hits after the first touch, a byte tensor is small), the dws / dwx accumulation chain
+// ld_in / ld_out bytes.  One thread = 4 channels x a strip of SW output columns x YS output rows, walked top to bottom
+// with the three live input rows DECODED ONCE into registers (a rotating window, resolved at compile time by the full
+// unroll): a code is expanded to its value ((q + zp) / scale, five operations) (SW + 2) / SW times per output instead of
+// nine times, the 36 weights of the channel quad are loaded once per thread, and every load is a 4-byte quad of one
+// pixel (a wave reads whole 64-byte row segments).  The accumulation chain is the fp32 kernels' (dws / dwx):
 // acc = fmaf(w[dy][dx], x, acc) from zero in (dy, dx) order, then + bias, ReLU, the output code.
-template <int STRIDE>
+template <int STRIDE, int SW, int YS>
 __global__ void __launch_bounds__(256)
 dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq, const float *__restrict__ w,
             const float *__restrict__ bias, signed char *__restrict__ out8, const unsigned *__restrict__ rq,
             unsigned *__restrict__ oflow, int C, int ld_in, int ld_out, int Hs, int Ws, int Ho, int Wo, int relu,
-            long total) {
+            int strips, int ysegs, long total) {
+  constexpr int NC = (SW - 1) * STRIDE + 3;          // input columns under a strip
   const float qs = reinterpret_cast<const float *>(aq)[2], qz = reinterpret_cast<const float *>(aq)[3];
   const float qr = __fdiv_rn(1.0f, qs);
   BadMask bad = 0;
   const Code8 c8 = make_code8(rq, bad);
   const int CQ = (C + 3) >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < total) {
     const int cq = (int)(i % CQ);
-    const long pix = i / CQ;
-    const int ox = (int)(pix % Wo);
-    const long t2 = pix / Wo;
-    const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
-    const int cb = cq * 4;
+    long t = i / CQ;
+    const int sx = (int)(t % strips);
+    t /= strips;
+    const int ys = (int)(t % ysegs), n = (int)(t / ysegs);
+    const int cb = cq * 4, ox0 = sx * SW, oy0 = ys * YS;
     float wk[9][4], bs[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -345,39 +350,55 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
       bs[e] = (live && bias) ? bias[c] : 0.0f;
     }
     const signed char *ab = a8 + (long)n * Hs * Ws * ld_in + cb;
-    unsigned cw[9];
+    signed char *ob = out8 + (long)n * Ho * Wo * ld_out + cb;
+    const int xb = STRIDE * ox0 - 1, yb = STRIDE * oy0 - 1;      // input coordinates of window row / column 0
+    float v[3][NC][4];
+    // input row yb + j decoded into slot j % 3 (the conv's zero padding is the VALUE zero)
+#define CDN_DWQ8_ROW(j)                                                                                   \
+    {                                                                                                       \
+      const int y = yb + (j);                                                                               \
+      const bool yin = (unsigned)y < (unsigned)Hs;                                                          \
+      const signed char *rp = ab + (long)min(max(y, 0), Hs - 1) * Ws * ld_in;                               \
+      _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                      \
+        const int x = xb + c;                                                                               \
+        const bool in = yin && (unsigned)x < (unsigned)Ws;                                                  \
+        const unsigned u = in ? *reinterpret_cast<const unsigned *>(rp + (long)min(max(x, 0), Ws - 1) * ld_in) : 0u; \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                     \
+          const int q = (int)(signed char)((u >> (8 * e)) & 0xff);                                          \
+          v[(j) % 3][c][e] = in ? code_value(q, qs, qz, qr) : 0.0f;                                         \
+        }                                                                                                   \
+      }                                                                                                     \
+    }
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int j = 0; j < 3 - STRIDE; ++j) CDN_DWQ8_ROW(j)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int y = STRIDE * oy + dy - 1, x = STRIDE * ox + dx - 1;
-        const bool in = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-        const long off = ((long)min(max(y, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1)) * ld_in;
-        cw[dy * 3 + dx] = in ? *reinterpret_cast<const unsigned *>(ab + off) : 0u;
-      }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < YS; ++r) {
+      const int oy = oy0 + r;
+      if (oy < Ho) {                                 // (uniform per thread; rows below the plane need no loads)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+        for (int j = STRIDE * r + 3 - STRIDE; j < STRIDE * r + 3; ++j) CDN_DWQ8_ROW(j)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int y = STRIDE * oy + dy - 1, x = STRIDE * ox + dx - 1;
-        const bool in = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-        const unsigned u = cw[dy * 3 + dx];
+        for (int sw = 0; sw < SW; ++sw) {
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = (int)(signed char)((u >> (8 * e)) & 0xff);
-          const float t = in ? code_value(q, qs, qz, qr) : 0.0f;       // the conv's zero padding is the VALUE zero
-          acc[e] = fmaf(wk[dy * 3 + dx][e], t, acc[e]);
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[e] = fmaf(wk[dy * 3 + dx][e], v[(STRIDE * r + dy) % 3][sw * STRIDE + dx][e], acc[e]);
+          unsigned pk = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o = acc[e] + bs[e];
+            if (relu) o = fmaxf(o, 0.0f);
+            pk |= (unsigned)(act_code8(o, c8, bad) & 0xff) << (8 * e);
+          }
+          if (ox0 + sw < Wo) *reinterpret_cast<unsigned *>(ob + ((long)oy * Wo + ox0 + sw) * ld_out) = pk;
         }
       }
-    unsigned pk = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = acc[e] + bs[e];
-      if (relu) v = fmaxf(v, 0.0f);
-      pk |= (unsigned)(act_code8(v, c8, bad) & 0xff) << (8 * e);
     }
-    *reinterpret_cast<unsigned *>(out8 + ((long)n * Ho * Wo + (long)oy * Wo + ox) * ld_out + cb) = pk;
+#undef CDN_DWQ8_ROW
   }
   if (bad) atomicOr(oflow, 1u);
 }
@@ -604,15 +625,32 @@ extern "C" int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a
   const int Ho = stride == 2 ? (int)((H - 1) / 2 + 1) : (int)H, Wo = stride == 2 ? (int)((W - 1) / 2 + 1) : (int)W;
   CDN_REQUIRE(N * H * W * ld_in < (1ll << 31) && N * Ho * (int64_t)Wo * ld_out < (1ll << 31), CDN_ERR_UNSUPPORTED,
               "shape too large");
-  const long total = (long)N * Ho * Wo * ((C + 3) / 4);
-  const int blocks = (int)std::min<long>(cdn::ceil_div(total, 256), (long)cdn::kCUs * 32);
   hipStream_t st = cdn::as_stream(stream);
   const unsigned *aq = static_cast<const unsigned *>(a_state), *rq = static_cast<const unsigned *>(r_state);
-  if (stride == 2)
-    dwq8_kernel<2><<<blocks, 256, 0, st>>>(a8, aq, w, bias, out8, rq, overflow, (int)C, (int)ld_in, (int)ld_out, (int)H,
-                                           (int)W, Ho, Wo, relu, total);
-  else
-    dwq8_kernel<1><<<blocks, 256, 0, st>>>(a8, aq, w, bias, out8, rq, overflow, (int)C, (int)ld_in, (int)ld_out, (int)H,
-                                           (int)W, Ho, Wo, relu, total);
+  // rows per thread: 8 while that still gives >= 2 workgroups per CU, else 4, else 2 (more halo rows decoded twice,
+  // more threads in flight: the deep layers' planes are 16 x 16)
+  const int CQ = (int)((C + 3) / 4);
+  auto launch = [&](auto stride_c, auto sw_c, auto ys_c) {
+    constexpr int S = decltype(stride_c)::value, SW = decltype(sw_c)::value, YS = decltype(ys_c)::value;
+    const int strips = cdn::ceil_div(Wo, SW), ysegs = cdn::ceil_div(Ho, YS);
+    const long total = (long)N * ysegs * strips * CQ;
+    dwq8_kernel<S, SW, YS><<<(unsigned)cdn::ceil_div(total, 256), 256, 0, st>>>(
+        a8, aq, w, bias, out8, rq, overflow, (int)C, (int)ld_in, (int)ld_out, (int)H, (int)W, Ho, Wo, relu, strips,
+        ysegs, total);
+  };
+  auto wgs = [&](int sw, int ys) { return (long)N * cdn::ceil_div(Ho, ys) * cdn::ceil_div(Wo, sw) * CQ / 256; };
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I4 = std::integral_constant<int, 4>;
+  using I8 = std::integral_constant<int, 8>;
+  if (stride == 2) {
+    if (wgs(2, 8) >= 2L * cdn::kCUs) launch(I2{}, I2{}, I8{});
+    else if (wgs(2, 4) >= 2L * cdn::kCUs) launch(I2{}, I2{}, I4{});
+    else launch(I2{}, I2{}, I2{});
+  } else {
+    if (wgs(4, 8) >= 2L * cdn::kCUs) launch(I1{}, I4{}, I8{});
+    else if (wgs(4, 4) >= 2L * cdn::kCUs) launch(I1{}, I4{}, I4{});
+    else launch(I1{}, I4{}, I2{});
+  }
   return cdn::check_launch("codenet dw3x3 (byte codes)");
 }

@@ -1,0 +1,27 @@
+"""Profile target: the whole W4A8 network in the frozen byte-code serving mode (batch 64, 512x512), eager launches.
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_fz -- python3 tools/prof_e2e_frozen.py [stages_only]"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from codenet_amd import harness, pipeline
+
+stages_only = len(sys.argv) > 1 and sys.argv[1] == "stages_only"
+dev = torch.device("cuda", 0)
+model = harness.create_model(quantize=True).to(dev)
+model.enable_fused()
+images = torch.randn(64, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(dev)
+with torch.no_grad():
+    for _ in range(30):
+        model(images)
+    pipeline.set_running_stat(model, False)
+    model.enable_fused(False)
+    pipeline.cover_frozen_ranges(model, [images], margin=0.02)
+    model.enable_fused(frozen_codes=True, frozen_backbone=not stages_only)
+    for _ in range(3):
+        model(images)
+    torch.cuda.synchronize()
+    print("MARK begin")
+    for _ in range(20):
+        harness.process(model, images, flip_test=False)
+    torch.cuda.synchronize()
+    print("overflow", model.frozen_overflowed(), "byte backbone", model._fzbackbone is not None)
