@@ -334,20 +334,22 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
   const int CQ = (C + 3) >> 2;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < total) {
-    const int cq = (int)(i % CQ);
-    long t = i / CQ;
-    const int sx = (int)(t % strips);
-    t /= strips;
-    const int ys = (int)(t % ysegs), n = (int)(t / ysegs);
+    const unsigned iu = (unsigned)i;                    // (total < 2^31: checked by the caller)
+    const int cq = (int)(iu % (unsigned)CQ);
+    unsigned t = iu / (unsigned)CQ;
+    const int sx = (int)(t % (unsigned)strips);
+    t /= (unsigned)strips;
+    const int ys = (int)(t % (unsigned)ysegs), n = (int)(t / (unsigned)ysegs);
     const int cb = cq * 4, ox0 = sx * SW, oy0 = ys * YS;
     float wk[9][4], bs[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = min(cb + e, C - 1);
       const bool live = cb + e < C;
+      const unsigned lm = live ? 0xffffffffu : 0u;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) wk[k][e] = live ? w[(long)c * 9 + k] : 0.0f;
-      bs[e] = (live && bias) ? bias[c] : 0.0f;
+      for (int k = 0; k < 9; ++k) wk[k][e] = __uint_as_float(__float_as_uint(w[(long)c * 9 + k]) & lm);
+      bs[e] = bias ? __uint_as_float(__float_as_uint(bias[c]) & lm) : 0.0f;
     }
     const signed char *ab = a8 + (long)n * Hs * Ws * ld_in + cb;
     signed char *ob = out8 + (long)n * Ho * Wo * ld_out + cb;
@@ -359,15 +361,19 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
       const int y = yb + (j);                                                                               \
       const bool yin = (unsigned)y < (unsigned)Hs;                                                          \
       const signed char *rp = ab + (long)min(max(y, 0), Hs - 1) * Ws * ld_in;                               \
+      unsigned u[NC], msk[NC];                                                                              \
+      /* clamped addresses, always valid: unconditional loads issued back to back, then branch-free decoding   \
+         (a guarded load or a guarded decode becomes a branch with its own s_waitcnt: the loads serialise) */ \
       _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                      \
         const int x = xb + c;                                                                               \
-        const bool in = yin && (unsigned)x < (unsigned)Ws;                                                  \
-        const unsigned u = in ? *reinterpret_cast<const unsigned *>(rp + (long)min(max(x, 0), Ws - 1) * ld_in) : 0u; \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                     \
-          const int q = (int)(signed char)((u >> (8 * e)) & 0xff);                                          \
-          v[(j) % 3][c][e] = in ? code_value(q, qs, qz, qr) : 0.0f;                                         \
-        }                                                                                                   \
+        u[c] = *reinterpret_cast<const unsigned *>(rp + (long)min(max(x, 0), Ws - 1) * ld_in);              \
+        msk[c] = (yin && (unsigned)x < (unsigned)Ws) ? 0xffffffffu : 0u;                                    \
       }                                                                                                     \
+      _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                     \
+          const int q = (int)(signed char)((u[c] >> (8 * e)) & 0xff);                                       \
+          v[(j) % 3][c][e] = __uint_as_float(__float_as_uint(code_value(q, qs, qz, qr)) & msk[c]);          \
+        }                                                                                                   \
     }
 #pragma unroll
     for (int j = 0; j < 3 - STRIDE; ++j) CDN_DWQ8_ROW(j)
