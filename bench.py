@@ -774,13 +774,16 @@ def e2e_leg(args, dev, rank, world, local_rank, hot_ms):
         frozen = {"ms_per_batch": msf, "images_per_s": args.batch / msf * 1e3, "per_rank": True,
                   "overflow": of_f, "finite": bool(torch.isfinite(dets_f).all()),
                   "byte_backbone": model._fzbackbone is not None,
+                  "byte_heads": model._fzheads is not None and model._fzheads._bufs is not None
+                  and model._fzheads._bufs["key"][0][0] == "codes",
                   "stages_only": {"ms_per_batch": ms_st, "overflow": of_s,
                                   "what": "backbone on the fp32 kernels without range updates, stages on byte codes"},
                   "ranges_widened": moved,
                   "what": "the same network with every QuantAct frozen (running_stat False: serving mode, not the "
                           "reference's default) on BYTE CODES from the stem to the heads' input: backbone "
                           "(pipeline.FrozenBackbone), the three deform stages with chained scale sums "
-                          "(pipeline.FrozenHotPath); heads on the fp32 kernels without range updates"}
+                          "(pipeline.FrozenHotPath), the heads' 1x1 convs and tails (FusedHeads.forward_codes); no "
+                          "range passes anywhere"}
     return {"ms_per_batch": ms, "images_per_s": world * args.batch / ms * 1e3, "frozen": frozen,
             "hot_path_share": hot_ms / ms, "detections": list(dets.shape),
             "what": "CoDeNet%s %dx%d %s batch %d per GPU: whole network on the HIP kernels + native ctdet_decode "

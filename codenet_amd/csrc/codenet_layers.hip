@@ -10,6 +10,7 @@
 #include "cdn_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -742,8 +743,11 @@ maxpool_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, flo
 // the 16 lanes of a pixel with a 15-shuffle transpose-reduce.  Workgroup = (image, strip of 32 stored
 // columns, strip of stored rows), ring of 4 stored rows in LDS (fake-quantised once), two rows in flight.
 // C == 64: lane = (pixel x_l = tid / 16, channel quad cq = tid % 16).
+// Y8 (frozen serving mode): y1 holds the BYTE CODES of its QuantAct ([N][Hs*Ws][64] int8, written by the int8 pointwise
+// kernel on codes) instead of fp32 pre-quantisation values: a lane loads one 4-byte code quad and the ring receives
+// (q + zp) / scale -- the value fake_quant_r gives the fp32 element that produced the code, bit for bit.
 // ------------------------------------------------------------------------------------------
-template <int MODE, int NCLS>
+template <int MODE, int NCLS, bool Y8 = false>
 __global__ void __launch_bounds__(256)
 head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1, const float *__restrict__ wdw,
                   const float *__restrict__ bdw, const unsigned *__restrict__ q2,
@@ -832,13 +836,19 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float *abase = y1 + (long)n * Hs * Ws * C + cb;
+  const signed char *abase8 = reinterpret_cast<const signed char *>(y1) + (long)n * Hs * Ws * C + cb;
   auto load_row = [&](int r, float4 (&d)[MAXL]) {
     const bool row_in = (unsigned)r < (unsigned)Hs;
 #pragma unroll
     for (int u = 0; u < MAXL; ++u) {
       const int col = x_l + u * XPT, x = ix0 + col;
-      d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws)
-                 ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * C) : z4;
+      if (Y8) {      // (clamped address: an unconditional load; the mask is applied in write_row)
+        const long pix = (long)min(max(r, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1);
+        d[u].x = __uint_as_float(*reinterpret_cast<const unsigned *>(abase8 + pix * C));
+      } else {
+        d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws)
+                   ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * C) : z4;
+      }
     }
   };
   auto write_row = [&](int r, int slot, const float4 (&d)[MAXL]) {
@@ -848,7 +858,18 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
       const int col = x_l + u * XPT, x = ix0 + col;
       if (col < Wc) {
         float4 t = d[u];
-        if (row_in && (unsigned)x < (unsigned)Ws) {
+        const bool in = row_in && (unsigned)x < (unsigned)Ws;
+        if (Y8) {
+          const unsigned wd = __float_as_uint(d[u].x), mk = in ? 0xffffffffu : 0u;
+          float e4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float l = __fadd_rn((float)(int)(signed char)((wd >> (8 * e)) & 0xff), z1);
+            const float q0 = __fmul_rn(l, r1);
+            e4[e] = __uint_as_float(__float_as_uint(fmaf(fmaf(-q0, s1, l), r1, q0)) & mk);
+          }
+          t = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        } else if (in) {
           t.x = cdn::fake_quant_r(t.x, s1, z1, r1);
           t.y = cdn::fake_quant_r(t.y, s1, z1, r1);
           t.z = cdn::fake_quant_r(t.z, s1, z1, r1);
@@ -1287,7 +1308,7 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
                              const signed char *w_codes, const float *w_scale, const int *w_colsum,
                              const float *bias, int64_t classes, float *out_nchw, float *r_min, float *r_max,
                              void *r_state, int bits, double momentum, int running, void *workspace,
-                             size_t workspace_bytes, void *stream) {
+                             size_t workspace_bytes, void *stream, bool y8 = false) {
   CDN_REQUIRE(y1 && y1_qstate && w_dw, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && N <= 65535, CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
@@ -1336,37 +1357,41 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
   constexpr bool hs_no_mfma = false;
   const bool mfma_ok = !hs_no_mfma && w_colsum && (Ws & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(out_nchw) & 15) == 0;
-  if (mfma_ok) {
-  } else if (classes <= 2) {
-    head_small_kernel<1, 2><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias, out_nchw,
-                                                    nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS,
-                                                    nstrips, rps, 0);
-    return cdn::check_launch("codenet head tail (small)");
-  }
-  if (classes <= 4 && !mfma_ok) {
-    head_small_kernel<1, 4><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias, out_nchw,
-                                                    nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS,
-                                                    nstrips, rps, 0);
-    return cdn::check_launch("codenet head tail (small)");
-  }
-  // int8 matrix cores on 16-column strips; a batch whose codes are too wide for the nibble
-  // split (state[6]) is computed by the VALU kernel launched behind it (4 classes at a time)
-  CDN_REQUIRE(mfma_ok, CDN_ERR_UNSUPPORTED,
-              "more than 4 classes need w_colsum, Ws %% 16 == 0 and a 16-byte aligned output");
-  {
-    int nxs2, nstrips2, rps2;
-    size_t lds2;
-    dim3 grid2;
-    CDN_REQUIRE(geom(16, &nxs2, &nstrips2, &rps2, &lds2, &grid2), CDN_ERR_UNSUPPORTED, "too many workgroups");
-    lds2 += (size_t)2 * 2 * (4 * 16) * kHtLD + (size_t)2 * 2 * 32 * kHtLD;
-    head_small_kernel<2, 2><<<grid2, 256, lds2, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, w_colsum, bias,
-                                                      out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
-                                                      nxs2, 16, nstrips2, rps2, 0);
-  }
-  head_small_kernel<1, 4><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias, out_nchw,
-                                                  nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad, nxs, XS, nstrips,
-                                                  rps, 1);
-  return cdn::check_launch("codenet head tail (matrix cores)");
+  auto tail = [&](auto y8c) -> int {
+    constexpr bool Y8 = decltype(y8c)::value;
+    if (mfma_ok) {
+    } else if (classes <= 2) {
+      head_small_kernel<1, 2, Y8><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias,
+                                                          out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
+                                                          nxs, XS, nstrips, rps, 0);
+      return cdn::check_launch("codenet head tail (small)");
+    }
+    if (classes <= 4 && !mfma_ok) {
+      head_small_kernel<1, 4, Y8><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias,
+                                                          out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
+                                                          nxs, XS, nstrips, rps, 0);
+      return cdn::check_launch("codenet head tail (small)");
+    }
+    // int8 matrix cores on 16-column strips; a batch whose codes are too wide for the nibble
+    // split (state[6]) is computed by the VALU kernel launched behind it (4 classes at a time)
+    CDN_REQUIRE(mfma_ok, CDN_ERR_UNSUPPORTED,
+                "more than 4 classes need w_colsum, Ws %% 16 == 0 and a 16-byte aligned output");
+    {
+      int nxs2, nstrips2, rps2;
+      size_t lds2;
+      dim3 grid2;
+      CDN_REQUIRE(geom(16, &nxs2, &nstrips2, &rps2, &lds2, &grid2), CDN_ERR_UNSUPPORTED, "too many workgroups");
+      lds2 += (size_t)2 * 2 * (4 * 16) * kHtLD + (size_t)2 * 2 * 32 * kHtLD;
+      head_small_kernel<2, 2, Y8><<<grid2, 256, lds2, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, w_colsum, bias,
+                                                            out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes,
+                                                            Cpad, nxs2, 16, nstrips2, rps2, 0);
+    }
+    head_small_kernel<1, 4, Y8><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias,
+                                                        out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
+                                                        nxs, XS, nstrips, rps, 1);
+    return cdn::check_launch("codenet head tail (matrix cores)");
+  };
+  return y8 ? tail(std::true_type{}) : tail(std::false_type{});
 }
 
 extern "C" int cdn_codenet_head_range_forward(const float *y1, const void *y1_qstate, int64_t N, int64_t C,
@@ -1385,6 +1410,17 @@ extern "C" int cdn_codenet_head_tail_small_forward(const float *y1, const void *
                                                    int64_t classes, float *out_nchw, void *stream) {
   return launch_head_small(1, y1, y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate, w_codes, w_scale, w_colsum, bias,
                            classes, out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0, nullptr, 0, stream);
+}
+
+extern "C" int cdn_codenet_head_tail_small_q8_forward(const signed char *y1_codes, const void *y1_qstate, int64_t N,
+                                                      int64_t C, int64_t Hs, int64_t Ws, const float *w_dw,
+                                                      const float *b_dw, const void *y2_qstate,
+                                                      const signed char *w_codes, const float *w_scale,
+                                                      const int *w_colsum, const float *bias, int64_t classes,
+                                                      float *out_nchw, void *stream) {
+  return launch_head_small(1, reinterpret_cast<const float *>(y1_codes), y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate,
+                           w_codes, w_scale, w_colsum, bias, classes, out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0,
+                           nullptr, 0, stream, true);
 }
 
 // out[n][oy*Wo+ox][c] = max_{3x3, stride 2, pad 1} fq(a[n][..][c]): see maxpool_kernel.

@@ -114,7 +114,7 @@ class PoseShuffleNetV2(nn.Module):
         self._fused_backbone = bool(backbone)
         self._frozen_codes = bool(frozen_codes)
         self._frozen_backbone = bool(frozen_backbone)
-        self._fpath = self._fheads = self._fbackbone = self._ffrozen = self._fzbackbone = None
+        self._fpath = self._fheads = self._fbackbone = self._ffrozen = self._fzbackbone = self._fzheads = None
         # the QuantActs whose settings decide _fused_ok(): collected once (the module tree is fixed after
         # quantize_shufflenetv2_dcn), so a forward reads 5 attributes of ~70 modules instead of walking the tree
         self.__dict__["_fused_acts"] = [a for a in self.modules() if isinstance(a, QuantAct)]
@@ -180,6 +180,12 @@ class PoseShuffleNetV2(nn.Module):
                 # every QuantAct of the backbone frozen too: byte codes end to end
                 if self._fzbackbone is not None and self._fzbackbone.still_frozen():
                     feat8, fq, hw = self._fzbackbone(x)
+                    r8, rq, last = stages.forward_codes(feat8, fq, hw)
+                    if r8.dtype == torch.int8:
+                        if self._fzheads is None:
+                            self._fzheads = pipeline.FusedHeads({h: getattr(self, h) for h in self.heads})
+                        if self._fzheads.codes_supported(last):          # the heads on byte codes as well
+                            return [self._fzheads.forward_codes(r8, rq, last, stages._bufs["overflow"])]
                     return [self._fheads(*stages.forward_nhwc(feat8, fq, hw))]
             if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
                 feat, fq, hw = self._fbackbone(x)       # hw None: an NCHW tensor (odd channel count)

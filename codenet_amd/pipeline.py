@@ -927,6 +927,89 @@ class FusedHeads:
         return outs
 
 
+    # ---- frozen serving mode: the heads on the stages' byte codes --------------------------------------------
+    def codes_supported(self, shape):
+        """True when every head is a W4A8 QuantDepthwiseNode (64 channels, <= 32 outputs) with both QuantActs frozen:
+        the form ``forward_codes`` implements."""
+        from .portable_quantizer.quant_modules import QuantDepthwiseNode
+        if shape["Co"] != 64 or not self.small_tail:
+            return False
+        for mod in self.heads.values():
+            if not isinstance(mod, QuantDepthwiseNode):
+                return False
+            a1, a3 = mod.quant_act1[1], mod.quant_act3[1]
+            if not (act_fusable(a1) and act_fusable(a3)) or a1.running_stat or a3.running_stat:
+                return False
+            nc = mod.quant_conv.out_channels
+            if not (nc <= 4 or (nc <= 32 and shape["W"] % 16 == 0)) or mod.quant_conv.int8_form() is None:
+                return False
+        return True
+
+    def forward_codes(self, r8, r_qstate, shape, overflow):
+        """The heads on the BYTE CODES of the last deform stage (``FrozenHotPath.forward_codes``), every QuantAct
+        frozen: per head the int8 pointwise kernel on codes (cdn_codenet_pointwise_q8_forward: exact integer sums,
+        the codes of quant_act1 written as bytes) and the row-streaming tail reading those bytes
+        (cdn_codenet_head_tail_small_q8_forward); no range passes, no fp32 copy of the stage output or of y1.
+        Same values as ``__call__`` on the expanded codes with the same frozen states (the first 1x1 conv is the same
+        integer sum; the tail decodes a code to the value its fp32 form fake-quantises to).  `overflow`: the int32 flag
+        a saturated y1 code sets."""
+        import ctypes
+        from . import _native as N_
+        dev = r8.device
+        if self._bufs is None or self._bufs["key"] != (("codes",) + tuple(r8.shape), dev):
+            Nb = r8.shape[0]
+            M = Nb * shape["H"] * shape["W"]
+            acts = [a for m in self.heads.values() for a in (m.quant_act1[1], m.quant_act3[1])]
+            arr = ctypes.c_void_p * len(acts)
+            self._bufs = dict(
+                key=(("codes",) + tuple(r8.shape), dev), acts=acts,
+                y8=[torch.empty(M, 64, dtype=torch.int8, device=dev) for _ in self.heads],
+                side=[torch.cuda.Stream(dev) for _ in range(len(self.heads) - 1)] if self.streams else [],
+                out={name: torch.empty(Nb, self._out_channels(m), 2 * shape["H"], 2 * shape["W"], device=dev)
+                     for name, m in self.heads.items()})
+        B = self._bufs
+        acts = B["acts"]
+        ptrs = tuple(a.x_min.data_ptr() for a in acts)
+        if B.get("ptrs") != ptrs:             # (the arrays name the range buffers: rebuilt when they move)
+            arr = ctypes.c_void_p * len(acts)
+            B["p"] = (arr(*[a.x_min.data_ptr() for a in acts]), arr(*[a.x_max.data_ptr() for a in acts]),
+                      arr(*[a._device_state(dev).data_ptr() for a in acts]))
+            B["ptrs"] = ptrs
+        lib = N_.lib()
+        Nb, Hs, Ws = r8.shape[0], shape["H"], shape["W"]
+        M = Nb * Hs * Ws
+        main = torch.cuda.current_stream(dev)
+        bits, _, _ = uniform_act_settings(acts, "FusedHeads.forward_codes")
+        N_.check(lib.cdn_quantact_frozen_params(len(acts), *B["p"], bits, main.cuda_stream),
+                 "cdn_quantact_frozen_params")
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        forked = []
+        with torch.no_grad():
+            for hi, (name, mod) in enumerate(self.heads.items()):
+                st = main
+                if B["side"] and hi > 0:
+                    st = B["side"][hi - 1]
+                    st.wait_stream(main)
+                    forked.append(st)
+                l1, l2, l3 = self._params(mod)
+                q1 = l1["act"]._device_state(dev).data_ptr()
+                q2 = l2["act"]._device_state(dev).data_ptr()
+                c1, s1, k1 = l1["i8"]
+                y8 = B["y8"][hi]
+                rc = lib.cdn_codenet_pointwise_q8_forward(
+                    r8.data_ptr(), r_qstate, M, 64, 64, c1.data_ptr(), s1.data_ptr(), k1.data_ptr(), ptr(l1["bias"]),
+                    1, q1, y8.data_ptr(), None, overflow.data_ptr(), st.cuda_stream)
+                N_.check(rc, "cdn_codenet_pointwise_q8_forward")
+                i8 = l3["i8"]
+                rc = lib.cdn_codenet_head_tail_small_q8_forward(
+                    y8.data_ptr(), q1, Nb, 64, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]), ptr(i8[1]),
+                    ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), st.cuda_stream)
+                N_.check(rc, "cdn_codenet_head_tail_small_q8_forward")
+        for sd in forked:
+            main.wait_stream(sd)
+        return B["out"]
+
+
 class FusedBackbone:
     """layer0 .. layer4 of a ``PoseShuffleNetV2`` on the HIP kernels.
     W4A8: the reference's module tree after ``quantize_shufflenetv2_dcn`` (quantize_model.py:26-60) --

@@ -359,3 +359,40 @@ def test_stem_q8_is_the_fp32_stem_then_the_code(N, R, stride):
     assert torch.equal(out8[:, :, :24].float()[inside], want[inside])
     assert bool((out8[:, :, 24:] == 55).all())
     assert bool(of.item()) == bool((~inside).any().item())
+
+
+@pytest.mark.parametrize("N,Hs,Ws,classes", [(2, 16, 16, 2), (3, 8, 32, 20), (1, 12, 20, 2), (2, 16, 48, 4)])
+def test_head_tail_on_byte_codes_equals_the_fp32_form(N, Hs, Ws, classes):
+    """cdn_codenet_head_tail_small_q8_forward (y1 as the byte codes of its QuantAct) against
+    cdn_codenet_head_tail_small_forward on the pre-quantisation fp32 tensor that produced those codes: identical
+    outputs (a code decodes to the value the fp32 form's fake-quantisation gives)."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(Hs * Ws + classes)
+    y1 = (torch.rand(N, Hs * Ws, 64, generator=g) * 4.0).to(dev)
+    q1 = ops.quantact_state(dev); q2 = ops.quantact_state(dev)
+    q1.view(torch.float32)[2], q1.view(torch.float32)[3] = 255.0 / 4.2, 128.0 - 3.0
+    q2.view(torch.float32)[2], q2.view(torch.float32)[3] = 11.0, 128.0
+    s1, z1 = q1.view(torch.float32)[2], q1.view(torch.float32)[3]
+    codes = torch.round(s1 * y1 - z1)
+    assert codes.min().item() >= -128 and codes.max().item() <= 127
+    y8 = codes.to(torch.int8).contiguous()
+    w_dw = (torch.randn(64, 9, generator=g) * 0.3).to(dev)
+    b_dw = (torch.randn(64, generator=g) * 0.1).to(dev)
+    wq = torch.randint(-8, 8, (classes, 64), generator=g, dtype=torch.int32)
+    w_codes = wq.to(torch.int8).to(dev)
+    w_scale = (torch.rand(classes, generator=g) * 10 + 3).to(dev)
+    w_colsum = wq.sum(1).to(torch.int32).to(dev)
+    bias = (torch.randn(classes, generator=g) * 0.1).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(N, classes, 2 * Hs, 2 * Ws, device=dev)
+    b = torch.zeros_like(a)
+    N_.check(lib.cdn_codenet_head_tail_small_forward(y1.data_ptr(), q1.data_ptr(), N, 64, Hs, Ws, w_dw.data_ptr(),
+                                                     b_dw.data_ptr(), q2.data_ptr(), w_codes.data_ptr(),
+                                                     w_scale.data_ptr(), w_colsum.data_ptr(), bias.data_ptr(), classes,
+                                                     a.data_ptr(), st), "fp32 tail")
+    N_.check(lib.cdn_codenet_head_tail_small_q8_forward(y8.data_ptr(), q1.data_ptr(), N, 64, Hs, Ws, w_dw.data_ptr(),
+                                                        b_dw.data_ptr(), q2.data_ptr(), w_codes.data_ptr(),
+                                                        w_scale.data_ptr(), w_colsum.data_ptr(), bias.data_ptr(),
+                                                        classes, b.data_ptr(), st), "byte tail")
+    assert a.abs().max().item() > 0 and torch.equal(a, b)
