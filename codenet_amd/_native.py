@@ -75,7 +75,7 @@ _SIGNATURES = {
     "cdn_codenet_head_tail_small_forward": (
         _i, [_vp, _vp] + [_i64] * 4 + [_vp] * 7 + [_i64, _vp, _vp]),
     "cdn_codenet_head_tail_small_q8_forward": (
-        _i, [_vp, _vp] + [_i64] * 4 + [_vp] * 7 + [_i64, _vp, _vp]),
+        _i, [_vp, _vp] + [_i64] * 4 + [_vp] * 7 + [_i64, _vp, _vp, _vp]),
     "cdn_codenet_interleave_forward": (
         _i, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "cdn_codenet_maxpool3x3s2_nhwc_forward": (_i, [_vp, _vp] + [_i64] * 4 + [_vp, _vp]),

@@ -47,7 +47,7 @@ __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) 
 
 // ------------------------------------------------------------------------------------------------------
 // frozen_params_kernel: (scale, zero-point) of up to 48 frozen QuantActs from their x_min / x_max buffers
-// into state words [2], [3] -- the expressions of cdn::quantact_update_device without the range update
+// into state words [2], [3] (and [6] = 0) -- the expressions of cdn::quantact_update_device without the range update
 // (quant_utils.py:60-75).  One launch per step for the whole schedule.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kMaxFrozen = 48;
@@ -78,6 +78,10 @@ __global__ void __launch_bounds__(256) frozen_params_kernel(FrozenList f) {
   float *sf = reinterpret_cast<float *>(f.state[i]);
   sf[2] = scale;
   sf[3] = zp;
+  // word [6] ("this batch has levels too wide for the int8 kernels' nibble split", written by the running-range
+  // epilogues from the batch extremes) is stale once the range is frozen: cleared -- a frozen consumer that meets such
+  // a level (a value 8 ranges outside the frozen range) sets its overflow flag instead
+  f.state[i][6] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -754,7 +754,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
                   const signed char *__restrict__ Wq, const float *__restrict__ wscale,
                   const int *__restrict__ wsum, const float *__restrict__ bias, float *__restrict__ out,
                   float2 *mm, cdn::QUpdate qu, int Hs, int Ws, int classes, int Cpad, int nxs, int XS,
-                  int nstrips, int rps, int only_if_wide) {
+                  int nstrips, int rps, int only_if_wide, unsigned *oflow = nullptr) {
   // MODE 2 (up to 32 classes on the int8 matrix cores) handles codes that fit the nibble split; a batch with
   // wider codes (state[6], the first calls of a fresh running range) is left to the MODE 1 launch behind it
   if (MODE == 2 && q2[6]) return;
@@ -894,6 +894,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   }
   float mn = INFINITY, mx = -INFINITY;
   int cslot = 0;
+  unsigned clamped = 0;
   const int Ho = 2 * Hs, Wo = 2 * Ws;
   constexpr int NPASS = MODE == 2 ? 1 : 2;                      // MODE 2 runs on 16-column strips
   for (int Yb = Y0; Yb < Y1; Yb += DEPTH) {
@@ -952,6 +953,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
                     const float yv_p = s2 * v4[e];      // (plain operators under fp contract(off): two roundings, cdn_common.h)
   const float yv = (yv_p - z2) + 12582912.0f;
                     int uu = (int)__float_as_uint(yv) + ioff;
+                    if (Y8 && (uu < 8 || uu > 4087)) clamped = 1;   // (frozen: nobody measured this batch's extremes)
                     uc[e] = (unsigned)min(max(uu, 8), 4087);
                   }
                   const unsigned p01 = uc[0] | (uc[1] << 16), p23 = uc[2] | (uc[3] << 16);
@@ -1050,6 +1052,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
       }
     }
   }
+  if (Y8 && MODE == 2 && clamped && oflow) atomicOr(oflow, 1u);
   if (MODE == 0 && mm) {
     __syncthreads();
     cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
@@ -1308,7 +1311,8 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
                              const signed char *w_codes, const float *w_scale, const int *w_colsum,
                              const float *bias, int64_t classes, float *out_nchw, float *r_min, float *r_max,
                              void *r_state, int bits, double momentum, int running, void *workspace,
-                             size_t workspace_bytes, void *stream, bool y8 = false) {
+                             size_t workspace_bytes, void *stream, bool y8 = false,
+                             unsigned *overflow = nullptr) {
   CDN_REQUIRE(y1 && y1_qstate && w_dw, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && N <= 65535, CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
@@ -1384,7 +1388,7 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
       lds2 += (size_t)2 * 2 * (4 * 16) * kHtLD + (size_t)2 * 2 * 32 * kHtLD;
       head_small_kernel<2, 2, Y8><<<grid2, 256, lds2, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, w_colsum, bias,
                                                             out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes,
-                                                            Cpad, nxs2, 16, nstrips2, rps2, 0);
+                                                            Cpad, nxs2, 16, nstrips2, rps2, 0, overflow);
     }
     head_small_kernel<1, 4, Y8><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias,
                                                         out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
@@ -1417,10 +1421,11 @@ extern "C" int cdn_codenet_head_tail_small_q8_forward(const signed char *y1_code
                                                       const float *b_dw, const void *y2_qstate,
                                                       const signed char *w_codes, const float *w_scale,
                                                       const int *w_colsum, const float *bias, int64_t classes,
-                                                      float *out_nchw, void *stream) {
+                                                      float *out_nchw, unsigned *overflow, void *stream) {
+  CDN_REQUIRE(overflow, CDN_ERR_ARG, "null pointer");
   return launch_head_small(1, reinterpret_cast<const float *>(y1_codes), y1_qstate, N, C, Hs, Ws, w_dw, b_dw, y2_qstate,
                            w_codes, w_scale, w_colsum, bias, classes, out_nchw, nullptr, nullptr, nullptr, 8, 0.99, 0,
-                           nullptr, 0, stream, true);
+                           nullptr, 0, stream, true, overflow);
 }
 
 // out[n][oy*Wo+ox][c] = max_{3x3, stride 2, pad 1} fq(a[n][..][c]): see maxpool_kernel.

@@ -1003,7 +1003,8 @@ class FusedHeads:
                 i8 = l3["i8"]
                 rc = lib.cdn_codenet_head_tail_small_q8_forward(
                     y8.data_ptr(), q1, Nb, 64, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]), ptr(i8[1]),
-                    ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), st.cuda_stream)
+                    ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), overflow.data_ptr(),
+                    st.cuda_stream)
                 N_.check(rc, "cdn_codenet_head_tail_small_q8_forward")
         for sd in forked:
             main.wait_stream(sd)

@@ -463,12 +463,14 @@ int cdn_codenet_head_tail_small_forward(const float *y1, const void *y1_qstate, 
 /* The same tail in the frozen serving mode: y1 holds the BYTE CODES of its QuantAct ([N][Hs*Ws][64] int8, 16-byte
  * aligned; written by cdn_codenet_pointwise_q8_forward) -- a code is decoded to (q + zp) / scale, the value the fp32
  * form's fake-quantisation gives the element that produced the code, so the outputs are those of
- * cdn_codenet_head_tail_small_forward on the pre-quantisation tensor, bit for bit, at a quarter of the read traffic. */
+ * cdn_codenet_head_tail_small_forward on the pre-quantisation tensor, bit for bit, at a quarter of the read traffic.
+ * No range pass has measured this batch (y2_qstate word [6] is 0 after cdn_quantact_frozen_params): a y2 level outside
+ * the int8 kernels' nibble split (|level - 128| > 2040, a value 8 ranges outside the frozen range) sets *overflow. */
 int cdn_codenet_head_tail_small_q8_forward(const signed char *y1_codes, const void *y1_qstate, int64_t N, int64_t C,
                                            int64_t Hs, int64_t Ws, const float *w_dw, const float *b_dw,
                                            const void *y2_qstate, const signed char *w_codes, const float *w_scale,
                                            const int *w_colsum, const float *bias, int64_t classes, float *out_nchw,
-                                           void *stream);
+                                           unsigned *overflow, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * The backbone's remaining layer types (lib/models/networks/
