@@ -49,16 +49,15 @@ struct ProfScope {
 };
 
 // ---- QuantAct device state (codenet_quant.hip) --------------------------------------------------
-// 8 x 4-byte words: [0] ordered-uint batch min, [1] ordered-uint batch max, [2] scale (f32),
-// [3] zero-point (f32), [4] batch min (f32), [5] batch max (f32), [6..7] reserved.
+// 8 x 4-byte words, zero-initialised by the owner: [0] ~ordered-uint batch min and [1] ordered-uint batch max while
+// a range pass (codenet_quant.hip::minmax_kernel) is in flight, zero between calls; [2] scale (f32), [3] zero-point
+// (f32), [4] batch min (f32), [5] batch max (f32), [6] wide-code flag, [7] the range pass's arrival ticket.
 constexpr int kQStateWords = 8;
 
-// Reset the running batch min/max of up to three states (null entries skipped): 1 launch.
-void launch_minmax_init(unsigned *s0, unsigned *s1, unsigned *s2, hipStream_t st);
 // Range tracking + scale / zero-point derivation, see quantact_update_kernel.  Batch statistics
-// come from (in this order of precedence) ext_min/ext_max device scalars, `partials`
-// ([n_partials] {min,max} pairs written by producer workgroups, reduced here -- no atomics), or
-// the ordered-uint words state[0..1].
+// come from (in this order of precedence) ext_min/ext_max device scalars or `partials`
+// ([n_partials] {min,max} pairs written by producer workgroups, reduced here -- no atomics); without either only
+// frozen ranges (running == 0) are meaningful.
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                             const float *ext_max, const float2 *partials, int n_partials, int bits,
                             double momentum, int running, hipStream_t st);

@@ -94,78 +94,23 @@ __global__ void __launch_bounds__(256) frozen_params_kernel(FrozenList f) {
 // Workgroup tile BM x BN, K tiles of 64 bytes: LDS rows of 64 + 16 bytes (a quarter-wave's 16 ds_read_b128 cover
 // the 64 banks), the next tile's 16-byte global loads in flight behind the MFMAs of the current one.
 // HBM-bound: A is read once (BN covers all Co up to 256), the weights stay in L2.
+// (Round 3, measured and removed: a variant with the WHOLE K extent of both tiles in LDS -- every load of a workgroup
+// issued before the first wait -- for the backbone's K <= 512: 67-101 KB of LDS leave 1-2 workgroups per CU and nothing
+// to overlap a workgroup's load phase with; 0.97 ms against 0.73 ms over the 42 launches of the frozen network.)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kQK = 64, kQLD = kQK + 16;
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256)
-pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
-            const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
-            const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
-            const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int C, int Cpad, int Co,
-            int relu, const signed char *__restrict__ nsc, int *__restrict__ sacc, int lda, int ldo,
-            const int *__restrict__ omap) {
-  constexpr int WGM = BM / 32, WGN = 4 / WGM, TN = BN / (32 * WGN);
-  constexpr int AI = BM * kQK / 16 / 256;       // 16-byte loads of A per thread per k tile (1 or 2)
-  constexpr int BI = BN * kQK / 16 / 256;       // of the weights (1, 2 or 4)
-  static_assert(AI >= 1 && BI >= 1 && TN >= 1, "tile too small");
-  __shared__ __attribute__((aligned(16))) unsigned char As[BM * kQLD];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * kQLD];
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave / WGN) * 32, wn = (wave % WGN) * TN * 32;
+// The epilogue shared by the int8 pointwise kernels on codes: acc[j][r] is the exact integer sum of row
+// m0 + wm + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column n0 + wn + 32 j + (lane & 31).
+template <int TN>
+__device__ __forceinline__ void pwq8_epilogue(
+    i32x16 (&acc)[TN], const unsigned *__restrict__ aq, const float *__restrict__ wscale,
+    const int *__restrict__ wsum, const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
+    const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int Cpad, int Co, int relu,
+    const signed char *__restrict__ nsc, int *__restrict__ sacc, int ldo, const int *__restrict__ omap, long m0, int n0,
+    int wm, int wn, int lane) {
   const float qs = reinterpret_cast<const float *>(aq)[2];
   const float qzf = reinterpret_cast<const float *>(aq)[3];
-  const bool a16 = (lda & 15) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;   // (rows 16-byte aligned)
-  i32x16 acc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
-  // staging: 4 threads per 64-byte row segment
-  const int lr = tid >> 2, lk = (tid & 3) * 16;
-  i32x4 ra[AI], rb[BI];
-  auto load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const long m = min(m0 + lr + 64 * i, M - 1);
-      const int k = k0 + lk;
-      if (a16 && k + 15 < lda) {       // (bytes beyond C inside the row are paired with zero weights)
-        ra[i] = *reinterpret_cast<const i32x4 *>(A + m * lda + k);
-      } else {            // ragged tail: bytes beyond C are paired with zero weights, any finite value will do
-        i32x4 t = {0, 0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + 4 * e + 3 < lda) t[e] = *reinterpret_cast<const int *>(A + m * lda + k + 4 * e);   // (lda % 4 == 0)
-        ra[i] = t;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int co = min(n0 + lr + 64 * i, Co - 1);
-      rb[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + lk);
-    }
-  };
-  load(0);
-  const int nk = (C + kQK - 1) / kQK;          // (Cpad >= 64 * nk)
-  for (int t = 0; t < nk; ++t) {
-    __syncthreads();                            // the previous tile has been consumed
-#pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<i32x4 *>(&As[(lr + 64 * i) * kQLD + lk]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) *reinterpret_cast<i32x4 *>(&Bs[(lr + 64 * i) * kQLD + lk]) = rb[i];
-    __syncthreads();
-    if (t + 1 < nk) load((t + 1) * kQK);
-    const int fo = (lane & 31) * kQLD + (lane >> 5) * 16;
-#pragma unroll
-    for (int ks = 0; ks < kQK / 32; ++ks) {
-      const i32x4 a = *reinterpret_cast<const i32x4 *>(&As[wm * kQLD + fo + ks * 32]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const i32x4 b = *reinterpret_cast<const i32x4 *>(&Bs[(wn + j * 32) * kQLD + fo + ks * 32]);
-        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
-      }
-    }
-  }
   // epilogue: the expressions of pwi8_kernel, then the output quantiser's code (or fp32 for a consumer
   // that wants pre-quantisation values)
   BadMask bad = 0;
@@ -225,6 +170,77 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
     }
   }
   if (bad) atomicOr(oflow, 1u);
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
+            const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
+            const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
+            const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int C, int Cpad, int Co,
+            int relu, const signed char *__restrict__ nsc, int *__restrict__ sacc, int lda, int ldo,
+            const int *__restrict__ omap) {
+  constexpr int WGM = BM / 32, WGN = 4 / WGM, TN = BN / (32 * WGN);
+  constexpr int AI = BM * kQK / 16 / 256;       // 16-byte loads of A per thread per k tile (1 or 2)
+  constexpr int BI = BN * kQK / 16 / 256;       // of the weights (1, 2 or 4)
+  static_assert(AI >= 1 && BI >= 1 && TN >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) unsigned char As[BM * kQLD];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * kQLD];
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * 32, wn = (wave % WGN) * TN * 32;
+  const bool a16 = (lda & 15) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;   // (rows 16-byte aligned)
+  i32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
+  // staging: 4 threads per 64-byte row segment
+  const int lr = tid >> 2, lk = (tid & 3) * 16;
+  i32x4 ra[AI], rb[BI];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const long m = min(m0 + lr + 64 * i, M - 1);
+      const int k = k0 + lk;
+      if (a16 && k + 15 < lda) {       // (bytes beyond C inside the row are paired with zero weights)
+        ra[i] = *reinterpret_cast<const i32x4 *>(A + m * lda + k);
+      } else {            // ragged tail: bytes beyond C are paired with zero weights, any finite value will do
+        i32x4 t = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + 4 * e + 3 < lda) t[e] = *reinterpret_cast<const int *>(A + m * lda + k + 4 * e);   // (lda % 4 == 0)
+        ra[i] = t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int co = min(n0 + lr + 64 * i, Co - 1);
+      rb[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + lk);
+    }
+  };
+  load(0);
+  const int nk = (C + kQK - 1) / kQK;          // (Cpad >= 64 * nk)
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();                            // the previous tile has been consumed
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<i32x4 *>(&As[(lr + 64 * i) * kQLD + lk]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<i32x4 *>(&Bs[(lr + 64 * i) * kQLD + lk]) = rb[i];
+    __syncthreads();
+    if (t + 1 < nk) load((t + 1) * kQK);
+    const int fo = (lane & 31) * kQLD + (lane >> 5) * 16;
+#pragma unroll
+    for (int ks = 0; ks < kQK / 32; ++ks) {
+      const i32x4 a = *reinterpret_cast<const i32x4 *>(&As[wm * kQLD + fo + ks * 32]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const i32x4 b = *reinterpret_cast<const i32x4 *>(&Bs[(wn + j * 32) * kQLD + fo + ks * 32]);
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  pwq8_epilogue<TN>(acc, aq, wscale, wsum, bias, R8, Rf, rq, oflow, M, Cpad, Co, relu, nsc, sacc, ldo, omap, m0, n0, wm,
+                    wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -20,24 +20,22 @@ using cdn::ord2f;
 using cdn::quant_code;
 
 // state layout (device, 8 x 4 bytes):
-//   [0] ordered-uint running batch min   [1] ordered-uint running batch max
-//   [2] scale  [3] zero_point  [4] batch min (float)  [5] batch max (float)  [6..7] reserved
+//   [0] ~ordered-uint batch min, [1] ordered-uint batch max while a range pass is in flight (zero between calls)
+//   [2] scale  [3] zero_point  [4] batch min (float)  [5] batch max (float)  [6] wide-code flag
+//   [7] arrival ticket of the range pass (zero between calls)
 constexpr int kStateWords = cdn::kQStateWords;
-
-__global__ void minmax_init_kernel(unsigned *s0, unsigned *s1, unsigned *s2) {
-  unsigned *st[3] = {s0, s1, s2};
-  for (int i = 0; i < 3; ++i)
-    if (st[i]) {
-      st[i][0] = 0xffffffffu;  // +inf side for min
-      st[i][1] = 0u;           // -inf side for max
-    }
-}
 
 // RELU: the extremes of max(x, 0) (the block ReLU -> QuantAct of the training path reads the pre-ReLU tensor once);
 // min / max commute with the monotone ReLU, so it is applied to the two reduced values
+// The LAST workgroup to arrive (ticket in state word [7]) folds the batch extremes into the running range and derives
+// (scale, zero-point) -- cdn::quantact_update_device, the expressions of the separate update kernel -- and leaves words
+// [0], [1], [7] zero again for the next call: one launch instead of init + min/max + update (the QAT step has ~10
+// QuantAct calls; each launch costs ~4.5 us inside the step's graph).  Words [0] / [1] hold ~ord(min) / ord(max) under
+// atomic MAX, so a zero-initialised state is the identity.
 template <bool RELU>
 __global__ void __launch_bounds__(256)
-minmax_kernel(const float *__restrict__ x, long n, unsigned *state) {
+minmax_kernel(const float *__restrict__ x, long n, cdn::QUpdate qu) {
+  unsigned *state = qu.state;
   float mn = INFINITY, mx = -INFINITY;
   const long n4 = n >> 2;
   const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -80,8 +78,21 @@ minmax_kernel(const float *__restrict__ x, long n, unsigned *state) {
       mn = fmaxf(mn, 0.0f);
       mx = fmaxf(mx, 0.0f);
     }
-    atomicMin(&state[0], f2ord(mn));
-    atomicMax(&state[1], f2ord(mx));
+    // ordering without a fence (an agent-scope release writes L2 back: +5..10 us per launch, measured): the two
+    // extremes are RETURNING atomics whose results the ticket waits for, so they have been applied at L2 (where all
+    // three words live and are only ever touched by atomics) before the ticket is taken
+    const unsigned r0 = __hip_atomic_fetch_max(&state[0], ~f2ord(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned r1 = __hip_atomic_fetch_max(&state[1], f2ord(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(r0), "v"(r1) : "memory");
+    const unsigned t = __hip_atomic_fetch_add(&state[7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      const float bmin = ord2f(~__hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float bmax = ord2f(__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      cdn::quantact_update_device(qu, bmin, bmax, true);
+      __hip_atomic_store(&state[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&state[7], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -106,11 +117,12 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
-  const bool have_stats = ext_min || from_partials || running;
+  const bool have_stats = ext_min || from_partials;
   float bmin = 0.f, bmax = 0.f;
   if (have_stats) {
-    bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : ord2f(state[0]));
-    bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : ord2f(state[1]));
+    // (running without external extremes or partials is the fused range pass, minmax_kernel: never here)
+    bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : 0.0f);
+    bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : 0.0f);
   }
   cdn::QUpdate u{x_min, x_max, state, nullptr, m_minus_1, one_minus_m, bits, running};
   cdn::quantact_update_device(u, bmin, bmax, have_stats);
@@ -231,9 +243,6 @@ inline int stream_grid(long n) {
 }  // namespace
 
 namespace cdn {
-void launch_minmax_init(unsigned *s0, unsigned *s1, unsigned *s2, hipStream_t st) {
-  minmax_init_kernel<<<1, 1, 0, st>>>(s0, s1, s2);
-}
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                             const float *ext_max, const float2 *partials, int n_partials, int bits,
                             double momentum, int running, hipStream_t st) {
@@ -263,12 +272,13 @@ extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, 
               CDN_ERR_ARG, "tensors must be 16-byte aligned");
   hipStream_t st = cdn::as_stream(stream);
   unsigned *stt = static_cast<unsigned *>(state);
-  if (running && !batch_min) {
-    cdn::launch_minmax_init(stt, nullptr, nullptr, st);
-    minmax_kernel<false><<<minmax_grid(numel), 256, 0, st>>>(x, (long)numel, stt);
+  if (running && !batch_min) {     // range pass + update in one launch (the last workgroup updates)
+    const cdn::QUpdate qu{x_min, x_max, stt, nullptr, (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1};
+    minmax_kernel<false><<<minmax_grid(numel), 256, 0, st>>>(x, (long)numel, qu);
+  } else {
+    cdn::launch_quantact_update(x_min, x_max, stt, batch_min, batch_max, nullptr, 0, bits, momentum,
+                                running, st);
   }
-  cdn::launch_quantact_update(x_min, x_max, stt, batch_min, batch_max, nullptr, 0, bits, momentum,
-                              running, st);
   if (out || codes)
     fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, codes, (long)numel, stt);
   return cdn::check_launch("quantact forward");
@@ -286,10 +296,11 @@ extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t
   unsigned *stt = static_cast<unsigned *>(state);
   const long numel = (long)(planes * H * W);
   if (running) {
-    cdn::launch_minmax_init(stt, nullptr, nullptr, st);
-    minmax_kernel<true><<<minmax_grid(numel), 256, 0, st>>>(y, numel, stt);
+    const cdn::QUpdate qu{x_min, x_max, stt, nullptr, (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1};
+    minmax_kernel<true><<<minmax_grid(numel), 256, 0, st>>>(y, numel, qu);
+  } else {
+    cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, nullptr, 0, bits, momentum, running, st);
   }
-  cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, nullptr, 0, bits, momentum, running, st);
   const long rows = (long)(planes * H);
   relu_fq_up2_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
                        256, 0, st>>>(y, out, rows, (int)W, stt);

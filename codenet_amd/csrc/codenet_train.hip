@@ -142,18 +142,47 @@ wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, l
 // One wave per (image, channel) row; g (N*HW floats) stays in L2.  HBM: read x, read + write grad_x.
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-scale_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ w,
-                 float *__restrict__ gx, float *__restrict__ gw_part, int C, int HW) {
+scale_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, const float *__restrict__ sc, float lo,
+                 float hi, const float *__restrict__ w, float *__restrict__ gx, float *__restrict__ gw_part, int C,
+                 int HW, int ldp) {
   const int n = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
+  const float *gp = g + (long)n * HW, *sp = sc ? sc + (long)n * HW : nullptr;
+  // Hardtanh backward folded in (sc != NULL): the gradient passes where lo < s_clamped < hi
+  auto mask4 = [&](float4 gv, int q) {
+    if (sp) {
+      const float4 sv = reinterpret_cast<const float4 *>(sp)[q];
+      gv.x = (sv.x > lo && sv.x < hi) ? gv.x : 0.0f; gv.y = (sv.y > lo && sv.y < hi) ? gv.y : 0.0f;
+      gv.z = (sv.z > lo && sv.z < hi) ? gv.z : 0.0f; gv.w = (sv.w > lo && sv.w < hi) ? gv.w : 0.0f;
+    }
+    return gv;
+  };
+  auto mask1 = [&](float gv, int p) { return (sp && !(sp[p] > lo && sp[p] < hi)) ? 0.0f : gv; };
+  if (c >= C) {
+    // the extra workgroup row (ldp > C): column C of the partials = sum_p g_raw[n][p], the bias gradient's share
+    if (c == C && ldp > C && gw_part) {
+      float acc = 0.0f;
+      if ((HW & 3) == 0) {
+        for (int q = lane; q < (HW >> 2); q += 64) {
+          const float4 gv = mask4(reinterpret_cast<const float4 *>(gp)[q], q);
+          acc += (gv.x + gv.y) + (gv.z + gv.w);
+        }
+      } else {
+        for (int p = lane; p < HW; p += 64) acc += mask1(gp[p], p);
+      }
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) gw_part[(long)n * ldp + C] = acc;
+    }
+    return;
+  }
   const float wc = w[c];
-  const float *xp = x + ((long)n * C + c) * HW, *gp = g + (long)n * HW;
+  const float *xp = x + ((long)n * C + c) * HW;
   float *gxp = gx ? gx + ((long)n * C + c) * HW : nullptr;
   float acc = 0.0f;
   if ((HW & 3) == 0) {
     for (int q = lane; q < (HW >> 2); q += 64) {
       const float4 xv = reinterpret_cast<const float4 *>(xp)[q];
-      const float4 gv = reinterpret_cast<const float4 *>(gp)[q];
+      const float4 gv = mask4(reinterpret_cast<const float4 *>(gp)[q], q);
       acc = fmaf(xv.x, gv.x, acc); acc = fmaf(xv.y, gv.y, acc);
       acc = fmaf(xv.z, gv.z, acc); acc = fmaf(xv.w, gv.w, acc);
       if (gxp) {
@@ -165,14 +194,14 @@ scale_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g, const
     }
   } else {
     for (int p = lane; p < HW; p += 64) {
-      const float gv = gp[p];
+      const float gv = mask1(gp[p], p);
       acc = fmaf(xp[p], gv, acc);
       if (gxp) gxp[p] = fmaf(wc, gv, gxp[p]);
     }
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-  if (lane == 0 && gw_part) gw_part[(long)n * C + c] = acc;
+  if (lane == 0 && gw_part) gw_part[(long)n * ldp + c] = acc;
 }
 
 struct WgPlan {
@@ -234,21 +263,37 @@ extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, 
   return rc;
 }
 
-extern "C" int cdn_codenet_scale_backward(const float *x, const float *grad_s, const float *w_scale, float *grad_x,
-                                          float *grad_w_partial, int64_t N, int64_t C, int64_t H, int64_t W,
-                                          void *stream) {
+static int scale_backward_impl(const float *x, const float *grad_s, const float *s_clamped, float lo, float hi,
+                               const float *w_scale, float *grad_x, float *grad_w_partial, int with_bias, int64_t N,
+                               int64_t C, int64_t H, int64_t W, void *stream) {
   CDN_REQUIRE(x && grad_s && w_scale, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   const int HW = (int)(H * W);
   CDN_REQUIRE((HW & 3) != 0 || ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                                 (reinterpret_cast<uintptr_t>(grad_s) & 15) == 0 &&
+                                (reinterpret_cast<uintptr_t>(s_clamped) & 15) == 0 &&
                                 (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0),
-              CDN_ERR_ARG, "x / grad_s / grad_x must be 16-byte aligned");
-  dim3 grid((unsigned)cdn::ceil_div(C, 4), (unsigned)N);
-  scale_bwd_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, grad_s, w_scale, grad_x, grad_w_partial, (int)C,
-                                                             HW);
+              CDN_ERR_ARG, "x / grad_s / s_clamped / grad_x must be 16-byte aligned");
+  const int extra = (with_bias && grad_w_partial) ? 1 : 0;       // channel index C: the bias column
+  dim3 grid((unsigned)cdn::ceil_div(C + extra, 4), (unsigned)N);
+  scale_bwd_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, grad_s, s_clamped, lo, hi, w_scale, grad_x,
+                                                             grad_w_partial, (int)C, HW, (int)C + extra);
   return cdn::check_launch("codenet scale backward");
+}
+
+extern "C" int cdn_codenet_scale_backward(const float *x, const float *grad_s, const float *w_scale, float *grad_x,
+                                          float *grad_w_partial, int64_t N, int64_t C, int64_t H, int64_t W,
+                                          void *stream) {
+  return scale_backward_impl(x, grad_s, nullptr, 0.f, 0.f, w_scale, grad_x, grad_w_partial, 0, N, C, H, W, stream);
+}
+
+extern "C" int cdn_codenet_scale_backward_masked(const float *x, const float *grad_s, const float *s_clamped,
+                                                 float lo, float hi, const float *w_scale, float *grad_x,
+                                                 float *grad_wb_partial, int64_t N, int64_t C, int64_t H, int64_t W,
+                                                 void *stream) {
+  CDN_REQUIRE(s_clamped, CDN_ERR_ARG, "null pointer");
+  return scale_backward_impl(x, grad_s, s_clamped, lo, hi, w_scale, grad_x, grad_wb_partial, 1, N, C, H, W, stream);
 }
 
 namespace {
@@ -312,6 +357,53 @@ weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__re
 }
 
 }  // namespace
+
+namespace {
+// weight_prep_bwd_kernel: backward of the BN fold under a straight-through weight quantiser, one wave per output
+// channel (the composition functions/codenet_stage.py::FoldFakeQuantWeight.backward spells out in nine framework ops):
+//   grad_w[co][k] = g_wq[co][k] * sf[co]
+//   grad_gamma[co] = (sum_k g_wq[co][k] * w[co][k] + g_b[co] * (conv_bias[co] - mean[co])) / std[co]
+//   grad_beta[co] = g_b[co];   grad_conv_bias[co] = g_b[co] * sf[co]
+__global__ void __launch_bounds__(256)
+weight_prep_bwd_kernel(const float *__restrict__ g_wq, const float *__restrict__ g_b, const float *__restrict__ w,
+                       const float *__restrict__ sf, const float *__restrict__ stdv, const float *__restrict__ mean,
+                       const float *__restrict__ conv_bias, int Co, int K, float *__restrict__ g_w,
+                       float *__restrict__ g_gamma, float *__restrict__ g_beta, float *__restrict__ g_cb) {
+#pragma clang fp contract(off)
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (co >= Co) return;
+  const float f = sf[co];
+  const float *gp = g_wq + (long)co * K, *wp = w + (long)co * K;
+  float dot = 0.0f;
+  for (int k = lane; k < K; k += 64) {
+    const float g = gp[k];
+    dot += g * wp[k];
+    if (g_w) g_w[(long)co * K + k] = g * f;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) dot += __shfl_xor(dot, m, 64);
+  if (lane == 0) {
+    const float gb = g_b ? g_b[co] : 0.0f;
+    const float cbm = (conv_bias ? conv_bias[co] : 0.0f) - mean[co];
+    if (g_gamma) g_gamma[co] = __fdiv_rn(dot + gb * cbm, stdv[co]);
+    if (g_beta) g_beta[co] = gb;
+    if (g_cb) g_cb[co] = gb * f;
+  }
+}
+}  // namespace
+
+extern "C" int cdn_codenet_weight_prep_backward(const float *grad_wq, const float *grad_bias, const float *w,
+                                                const float *scale_factor, const float *bn_std, const float *bn_mean,
+                                                const float *conv_bias, int64_t Co, int64_t K, float *grad_w,
+                                                float *grad_gamma, float *grad_beta, float *grad_conv_bias,
+                                                void *stream) {
+  CDN_REQUIRE(grad_wq && w && scale_factor && bn_std && bn_mean, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(Co > 0 && K > 0 && Co * K < (1ll << 31), CDN_ERR_ARG, "bad size");
+  weight_prep_bwd_kernel<<<(unsigned)cdn::ceil_div(Co, 4), 256, 0, cdn::as_stream(stream)>>>(
+      grad_wq, grad_bias, w, scale_factor, bn_std, bn_mean, conv_bias, (int)Co, (int)K, grad_w, grad_gamma, grad_beta,
+      grad_conv_bias);
+  return cdn::check_launch("codenet weight prep backward");
+}
 
 extern "C" int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor,
                                        const float *bn_bias, const float *bn_mean, const float *conv_bias, int bits,

@@ -112,15 +112,19 @@ class CodenetStageFunction(Function):
         if want_s:
             # QuantAct on s: straight-through; Hardtanh: gradient where lo < s_raw < hi (s_c is the clamped
             # value: s_c == lo or hi <=> s_raw outside or on the bound, where torch's hardtanh_backward is 0 too)
-            g_raw = gs * ((s_c > ctx.lo) & (s_c < ctx.hi)).to(gs.dtype)
-            part = torch.empty(Nb, C, device=x.device) if need[1] else None
-            rc = lib.cdn_codenet_scale_backward(_p(x), _p(g_raw), _p(w_scale.contiguous().view(-1)), _p(gx),
-                                                _p(part), Nb, C, H, W, ops._stream(x))
-            N_.check(rc, "cdn_codenet_scale_backward")
-            if need[1]:
-                g_wscale = part.sum(0).view_as(w_scale)
-            if need[2] and ctx.has_b_scale:
-                g_bscale = g_raw.sum().reshape(1)
+            # -- folded into the kernel (cdn_codenet_scale_backward_masked); column C of the partials is the bias share
+            want_w, want_b = need[1], need[2] and ctx.has_b_scale
+            part = torch.empty(Nb, C + 1, device=x.device) if (want_w or want_b) else None
+            rc = lib.cdn_codenet_scale_backward_masked(_p(x), _p(gs), _p(s_c), ctx.lo, ctx.hi,
+                                                       _p(w_scale.contiguous().view(-1)), _p(gx), _p(part), Nb, C, H, W,
+                                                       ops._stream(x))
+            N_.check(rc, "cdn_codenet_scale_backward_masked")
+            if part is not None:
+                tot = part.sum(0)                               # over the images, one reduction for both
+                if want_w:
+                    g_wscale = tot[:C].view_as(w_scale)
+                if want_b:
+                    g_bscale = tot[C:].reshape(1)
         return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None
 
 
@@ -165,7 +169,7 @@ class FakeQuantWeight(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.clone(), None
+        return g, None          # (the reference clones; an identity backward needs no copy)
 
 
 class FoldFakeQuantWeight(Function):
@@ -199,18 +203,17 @@ class FoldFakeQuantWeight(Function):
     def backward(ctx, g_wq, g_b):
         w, sf, std, mean, conv_bias = ctx.saved_tensors
         need = ctx.needs_input_grad
-        shape = (-1,) + (1,) * (w.dim() - 1)
-        g_w = g_wq * sf.view(shape) if need[0] else None
-        g_cb = g_gamma = g_beta = None
-        if need[2]:
-            g_sf = (g_wq * w).flatten(1).sum(1)
-            cbm = (conv_bias - mean) if ctx.has_cb else -mean
-            g_sf = g_sf + g_b * cbm
-            g_gamma = g_sf / std                                # d sf / d gamma = 1 / running_std
-        if need[3]:
-            g_beta = g_b.clone()
-        if ctx.has_cb and need[1]:
-            g_cb = g_b * sf
+        co = w.shape[0]
+        new = lambda *sh: torch.empty(*sh, device=w.device)      # noqa: E731
+        g_w = torch.empty_like(w) if need[0] else None
+        g_gamma = new(co) if need[2] else None
+        g_beta = new(co) if need[3] else None
+        g_cb = new(co) if (ctx.has_cb and need[1]) else None
+        rc = N_.lib().cdn_codenet_weight_prep_backward(
+            _p(g_wq.contiguous()), _p(g_b.contiguous()) if g_b is not None else None, _p(w), _p(sf), _p(std),
+            _p(mean.contiguous()), _p(conv_bias.contiguous()) if ctx.has_cb else None, co, w.numel() // co, _p(g_w),
+            _p(g_gamma), _p(g_beta), _p(g_cb), ops._stream(w))
+        N_.check(rc, "cdn_codenet_weight_prep_backward")
         return g_w, g_cb, g_gamma, g_beta, None, None, None, None
 
 

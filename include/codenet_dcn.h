@@ -167,12 +167,28 @@ int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, fl
 int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor, const float *bn_bias,
                             const float *bn_mean, const float *conv_bias, int bits, float *w_q, float *bias_out,
                             void *stream);
+/* Backward of the BN fold of cdn_codenet_weight_prep under the straight-through weight quantiser
+ * (SymmetricQuantFunction.backward, quant_utils.py:227-229; autograd of quant_modules.py:365-372) in one launch:
+ *   grad_w = grad_wq * scale_factor,  grad_gamma = (sum_k grad_wq * w + grad_bias * (conv_bias - mean)) / bn_std,
+ *   grad_beta = grad_bias,  grad_conv_bias = grad_bias * scale_factor;  bn_std = sqrt(running_var + eps) as the caller
+ *   computed it for the forward.  grad_bias / conv_bias may be NULL (= 0); every output may be NULL (not wanted). */
+int cdn_codenet_weight_prep_backward(const float *grad_wq, const float *grad_bias, const float *w,
+                                     const float *scale_factor, const float *bn_std, const float *bn_mean,
+                                     const float *conv_bias, int64_t Co, int64_t K, float *grad_w, float *grad_gamma,
+                                     float *grad_beta, float *grad_conv_bias, void *stream);
 size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW);
 int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b, int64_t N,
                                 int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
                                 void *stream);
 int cdn_codenet_scale_backward(const float *x, const float *grad_s, const float *w_scale, float *grad_x,
                                float *grad_w_partial, int64_t N, int64_t C, int64_t H, int64_t W, void *stream);
+/* The same with the Hardtanh backward folded in (F.hardtanh_backward of dcn_v2.py's scale clamp): grad_s is the gradient
+ * with respect to the CLAMPED scale, s_clamped [N][H*W] the clamped value saved by the forward; the gradient passes
+ * where lo < s_clamped < hi.  grad_wb_partial [N][C + 1] (may be NULL): columns 0..C-1 as above, column C =
+ * sum_p of the masked gradient (the bias gradient's share of image n). */
+int cdn_codenet_scale_backward_masked(const float *x, const float *grad_s, const float *s_clamped, float lo, float hi,
+                                      const float *w_scale, float *grad_x, float *grad_wb_partial, int64_t N,
+                                      int64_t C, int64_t H, int64_t W, void *stream);
 
 int cdn_codenet_dw_backward_supported(int64_t H, int64_t W);   /* 1: the plane fits; 0: use the generic path */
 int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
@@ -198,8 +214,9 @@ int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, const float
  *   always:       scale = (2^bits-1)/clamp(x_max-x_min,1e-10), zp = round(scale*x_min)+2^(bits-1),
  *                 q = round(scale*x - zp) (round-half-even, NOT clamped),
  *                 out = (q + zp)/scale (fp32, may alias x) and/or codes = q as int16.
- * `state` is a caller-owned device scratch of cdn_quantact_state_bytes() bytes; after the call
- * it holds {.., .., scale, zp, batch_min, batch_max} as fp32 words 2..5.
+ * `state` is a caller-owned device buffer of cdn_quantact_state_bytes() bytes, ZERO-INITIALISED before its first use
+ * (words 0, 1 and 7 carry the range pass's atomics and arrival ticket and are left zero by every call); after the
+ * call it holds {.., .., scale, zp, batch_min, batch_max} as fp32 words 2..5.
  * x, out must be 16-byte aligned, codes 8-byte aligned.  out and codes may be NULL.
  * ---------------------------------------------------------------------------------------- */
 size_t cdn_quantact_state_bytes(void);

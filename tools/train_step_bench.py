@@ -24,13 +24,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--loss", action="store_true", help="surrogate loss on the stage output instead of a fixed upstream gradient")
     ap.add_argument("--graph", action="store_true", help="capture forward + backward + optimizer step in one HIP graph")
+    ap.add_argument("--foreach-adam", action="store_true",
+                    help="torch.optim.Adam's default multi-tensor form (8 launches per step) instead of fused=True (1)")
     a = ap.parse_args()
     net = pipeline.build_hot_path(quantized=not a.fp32).cuda().train()
     for m in net.modules():                      # BN inside QuantBnConv2d is never called; plain BN in fp32
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eval()
     x = pipeline.make_input(a.batch, a.res, device="cuda").requires_grad_(True)
-    opt = torch.optim.Adam(net.parameters(), lr=1.25e-4, capturable=a.graph)     # lib/opts.py:93 lr
+    # lib/opts.py:93 lr; the reference's torch.optim.Adam, in its single-kernel form unless --foreach-adam
+    opt = torch.optim.Adam(net.parameters(), lr=1.25e-4, capturable=a.graph, fused=not a.foreach_adam)
 
     # the stages' output gradient comes from the heads in the real QAT step: a fixed upstream gradient of the
     # output's shape (a loss computed on this 134 MB tensor would add ~160 us of reductions that are not part
