@@ -333,6 +333,11 @@ dw_bwd_kernel(const float *__restrict__ x, const float *__restrict__ s,
 // every stage shape (64 x 64 plane 458 -> 636 us, 16 x 16 x 1024 channels 250 -> 282 us): the kernel is bound by
 // the LDS atomics' bank conflicts, not by instruction issue, and with fewer lanes per pixel one wave instruction
 // scatters to twice as many unrelated cells.
+// Tried in round 3 and removed: lanes <-> PIXELS with the same integer atomics on [channel][cell] planes (tap geometry
+// once per lane, reused over the chunk's channels; grad_w wave-reduced).  grad_x bit-identical (the fixed-point sum is
+// order-independent), 1.4-1.6 x SLOWER at every shape (16 x 16 x 1024 ch: 210 -> 328 us, 32 x 32 x 256: 232 -> 313,
+// 64 x 64 x 128: 443 -> 648): the cells under 64 neighbouring pixels of one tap crowd into a few banks / the same
+// addresses, where the lanes of one pixel's channels hit 64 distinct consecutive words.
 // ------------------------------------------------------------------------------------------
 template <int CCH>
 __global__ void __launch_bounds__(512)
