@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(256) frozen_params_kernel(FrozenList f) {
 // HBM-bound: A is read once (BN covers all Co up to 256), the weights stay in L2.
 // (Round 3, measured and removed: a variant with the WHOLE K extent of both tiles in LDS -- every load of a workgroup
 // issued before the first wait -- for the backbone's K <= 512: 67-101 KB of LDS leave 1-2 workgroups per CU and nothing
-// to overlap a workgroup's load phase with; 0.97 ms against 0.73 ms over the 42 launches of the frozen network.)
+// to overlap a workgroup's load phase with; 0.97 ms against 0.73 ms over the 42 launches of the frozen network.  Nor
+// do 128-byte k tiles (half the round trips per workgroup, twice the loads in flight): 0.751 against 0.735 ms.  At
+// M = 16 k .. 262 k rows and K <= 464 these launches sit at 9-23 us whatever the tile pipeline does.)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kQK = 64, kQLD = kQK + 16;
 

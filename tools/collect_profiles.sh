@@ -42,6 +42,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_stats" -- py
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/bb_trace" -- python3 tools/backbone_bench.py > "$OUT/bb_trace.log" 2>&1
 f=$(find "$OUT/bb_trace" -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_order.py "$f" stem_kernel > "$OUT/backbone_kernel_order.txt"
+# frozen serving mode end to end (byte codes from the stem to the heads' outputs / stages only): steady-state kernel
+# time per batch, computed here from the trace (the traces themselves are large)
+for mode in bytes stages_only; do
+  arg=""; [ $mode = stages_only ] && arg=stages_only
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/fz_$mode" -o fz -- python3 tools/prof_e2e_frozen.py $arg > "$OUT/fz_$mode.log" 2>&1
+  f=$(find "$OUT/fz_$mode" -name "fz_kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python3 tools/steady_stats.py "$f" 23 > "$OUT/e2e_frozen_${mode}_steady.txt"
+  rm -rf "$OUT/fz_$mode"
+done
 for n in e2e_stats train_stats stats stats_frozen; do
   f=$(find "$OUT/$n" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${n}_kernel_stats.csv"

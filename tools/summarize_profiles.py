@@ -13,7 +13,8 @@ import sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = "gpurun_out/" + R, "profiles/" + R
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(src + "/*.json") + glob.glob(src + "/*kernel_stats.csv") + glob.glob(src + "/backbone_kernel_order.txt"):
+for f in (glob.glob(src + "/*.json") + glob.glob(src + "/*kernel_stats.csv") + glob.glob(src + "/backbone_kernel_order.txt")
+          + glob.glob(src + "/e2e_frozen_*_steady.txt")):
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for a, b in (("stats_kernel_stats.csv", "bench_w4a8_fused_kernel_stats.csv"),
              ("stats_frozen_kernel_stats.csv", "bench_w4a8_frozen_kernel_stats.csv"),
