@@ -36,6 +36,9 @@ _SIGNATURES = {
     "cdn_codenet_weight_prep": (_i, [_vp, _i64, _i64] + [_vp] * 4 + [_i] + [_vp] * 3),
     "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_set_gather_mode": (_i, [_i]),
+    "cdn_codenet_dwpw_q8_supported": (_i, [_i64] * 3 + [_i, _i64]),
+    "cdn_codenet_dwpw_q8_forward": (
+        _i, [_vp, _vp] + [_i64] * 4 + [_i, _i64, _vp, _vp, _i, _vp, _i64] + [_vp] * 4 + [_i, _i64] + [_vp] * 5),
     "cdn_codenet_dw_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
     "cdn_codenet_pointwise_forward": (_i, [_vp] * 6 + [_i64] * 4 + [_i, _vp]),
     "cdn_quantact_state_bytes": (ctypes.c_size_t, []),

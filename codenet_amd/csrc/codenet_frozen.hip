@@ -430,6 +430,143 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
   }
   if (bad) atomicOr(oflow, 1u);
 }
+
+// dwpwq8: a unit's depthwise 3x3 computed INTO the A tile of the 1x1 conv behind it (frozen serving mode; the
+// depthwise output never reaches HBM and one launch per unit disappears -- the byte-code backbone is bound by its ~60
+// launches of 9-23 us, not by bytes).  Workgroup = 64 consecutive output pixels of one image (TR = 64 / Wseg rows of
+// Wseg = min(Wo, 64) columns) x ALL channels:
+//   phase 1  dwq8's strip walk per (channel quad, strip of SW columns) item over the tile's TR rows -- same
+//            accumulation chain, same output code -- with the packed code quad stored to the LDS A tile [64][KP + 16];
+//   phase 2  pwq8's MFMA loop with the A operand resident and the weights streamed in 64-byte k tiles, BN = all Co
+//            (<= 256: every column tile would recompute phase 1), pwq8's epilogue.
+// Bit-identical to dwq8_kernel followed by pwq8_kernel (tests/test_gpu_frozen.py).
+template <int STRIDE, int SW, int TR, int BN>
+__global__ void __launch_bounds__(256)
+dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq, const float *__restrict__ wdw,
+              const float *__restrict__ bdw, int dw_relu, const unsigned *__restrict__ dq,
+              const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
+              const float *__restrict__ bias, signed char *__restrict__ R8, const unsigned *__restrict__ rq,
+              unsigned *__restrict__ oflow, long M, int C, int KP, int ld_in, int Hs, int Ws, int Ho, int Wo, int Co,
+              int relu, int ldo, const int *__restrict__ omap) {
+  constexpr int BM = 64, WGM = 2, WGN = 2, TN = BN / (32 * WGN), BI = BN * kQK / 16 / 256, NC = (SW - 1) * STRIDE + 3;
+  constexpr int Wseg = BM / TR;                    // columns of the tile (== Wo, or a 64-column segment of a row)
+  static_assert(TN >= 1 && BI >= 1, "tile too small");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dp[];
+  const int QA = KP + 16;
+  unsigned char *As = lds_dp, *Bs = lds_dp + (size_t)BM * QA;
+  const long m0 = (long)blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WGN) * 32, wn = (wave % WGN) * TN * 32;
+  // ---- the weights' first k tile goes out before the depthwise phase ------------------------------------------
+  const int lr = tid >> 2, lk = (tid & 3) * 16;
+  i32x4 rb[BI];
+  auto loadB = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int co = min(lr + 64 * i, Co - 1);
+      rb[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * KP + k0 + lk);
+    }
+  };
+  loadB(0);
+  // ---- phase 1: depthwise into the A tile ---------------------------------------------------------------------
+  {
+    const float qs = reinterpret_cast<const float *>(aq)[2], qz = reinterpret_cast<const float *>(aq)[3];
+    const float qr = __fdiv_rn(1.0f, qs);
+    BadMask bad = 0;
+    const Code8 c8 = make_code8(dq, bad);
+    const int CQ = (C + 3) >> 2;
+    constexpr int strips = Wseg / SW;
+    const long pix0 = m0 % ((long)Ho * Wo);          // first pixel of the tile inside its image
+    const int n = (int)(m0 / ((long)Ho * Wo));
+    const int oy0 = (int)(pix0 / Wo), oxs = (int)(pix0 - (long)oy0 * Wo);   // (oxs != 0 only when Wo > 64)
+    for (int item = tid; item < CQ * strips; item += 256) {
+      const int cq = item % CQ, sx = item / CQ;
+      const int cb = cq * 4, ox0 = oxs + sx * SW;
+      float wk[9][4], bs[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = min(cb + e, C - 1);
+        const unsigned lm = cb + e < C ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k][e] = __uint_as_float(__float_as_uint(wdw[(long)c * 9 + k]) & lm);
+        bs[e] = bdw ? __uint_as_float(__float_as_uint(bdw[c]) & lm) : 0.0f;
+      }
+      const signed char *ab = a8 + (long)n * Hs * Ws * ld_in + cb;
+      const int xb = STRIDE * ox0 - 1, yb = STRIDE * oy0 - 1;
+      float v[3][NC][4];
+#define CDN_DWPW_ROW(j)                                                                                   \
+      {                                                                                                     \
+        const int y = yb + (j);                                                                             \
+        const bool yin = (unsigned)y < (unsigned)Hs;                                                        \
+        const signed char *rp = ab + (long)min(max(y, 0), Hs - 1) * Ws * ld_in;                             \
+        unsigned u[NC], msk[NC];                                                                            \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c) {                                                    \
+          const int x = xb + c;                                                                             \
+          u[c] = *reinterpret_cast<const unsigned *>(rp + (long)min(max(x, 0), Ws - 1) * ld_in);            \
+          msk[c] = (yin && (unsigned)x < (unsigned)Ws) ? 0xffffffffu : 0u;                                  \
+        }                                                                                                   \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                      \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+            const int q = (int)(signed char)((u[c] >> (8 * e)) & 0xff);                                     \
+            v[(j) % 3][c][e] = __uint_as_float(__float_as_uint(code_value(q, qs, qz, qr)) & msk[c]);        \
+          }                                                                                                 \
+      }
+#pragma unroll
+      for (int j = 0; j < 3 - STRIDE; ++j) CDN_DWPW_ROW(j)
+#pragma unroll
+      for (int r = 0; r < TR; ++r) {
+#pragma unroll
+        for (int j = STRIDE * r + 3 - STRIDE; j < STRIDE * r + 3; ++j) CDN_DWPW_ROW(j)
+#pragma unroll
+        for (int sw = 0; sw < SW; ++sw) {
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[e] = fmaf(wk[dy * 3 + dx][e], v[(STRIDE * r + dy) % 3][sw * STRIDE + dx][e], acc[e]);
+          unsigned pk = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float o = acc[e] + bs[e];
+            if (dw_relu) o = fmaxf(o, 0.0f);
+            pk |= (unsigned)(act_code8(o, c8, bad) & 0xff) << (8 * e);
+          }
+          *reinterpret_cast<unsigned *>(&As[(r * Wseg + sx * SW + sw) * QA + cb]) = pk;
+        }
+      }
+#undef CDN_DWPW_ROW
+    }
+    if (bad) atomicOr(oflow, 1u);
+  }
+  // ---- phase 2: the 1x1 conv on the resident A tile -----------------------------------------------------------
+  i32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
+  const int nk = (C + kQK - 1) / kQK;
+  constexpr int QB = kQK + 16;
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();                                // (t == 0: also the A tile is complete)
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<i32x4 *>(&Bs[(lr + 64 * i) * QB + lk]) = rb[i];
+    __syncthreads();
+    if (t + 1 < nk) loadB((t + 1) * kQK);
+    const int foA = (lane & 31) * QA + (lane >> 5) * 16, foB = (lane & 31) * QB + (lane >> 5) * 16;
+#pragma unroll
+    for (int ks = 0; ks < kQK / 32; ++ks) {
+      const i32x4 a = *reinterpret_cast<const i32x4 *>(&As[wm * QA + foA + t * kQK + ks * 32]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const i32x4 b = *reinterpret_cast<const i32x4 *>(&Bs[(wn + j * 32) * QB + foB + ks * 32]);
+        acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  pwq8_epilogue<TN>(acc, dq, wscale, wsum, bias, R8, nullptr, rq, oflow, M, KP, Co, relu, nullptr, nullptr, ldo, omap,
+                    m0, 0, wm, wn, lane);
+}
 }  // namespace
 
 static int frozen_params_impl(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
@@ -638,6 +775,66 @@ extern "C" int cdn_codenet_stem_q8_forward(const float *img, int64_t N, int64_t 
   stemq8_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(img, w, bias, out8, static_cast<const unsigned *>(r_state),
                                                           overflow, (int)H, (int)W, Ho, Wo, stride, relu, (int)ld_out);
   return cdn::check_launch("codenet stem (byte codes)");
+}
+
+// 1 when cdn_codenet_dwpw_q8_forward implements this geometry (else: the two separate entry points)
+extern "C" int cdn_codenet_dwpw_q8_supported(int64_t C, int64_t H, int64_t W, int stride, int64_t Co) {
+  if (C <= 0 || H <= 0 || W <= 0 || Co <= 0 || Co > 256 || (stride != 1 && stride != 2)) return 0;
+  const int64_t Ho = stride == 2 ? (H - 1) / 2 + 1 : H, Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
+  const bool w_ok = Wo == 8 || Wo == 16 || Wo == 32 || (Wo >= 64 && Wo % 64 == 0);
+  return (w_ok && (Ho * Wo) % 64 == 0 && (C + 63) / 64 * 64 <= 512) ? 1 : 0;
+}
+
+extern "C" int cdn_codenet_dwpw_q8_forward(
+    const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H, int64_t W, int stride, int64_t ld_in,
+    const float *w_dw, const float *b_dw, int dw_relu, const void *d_state, int64_t Co, const signed char *w_codes,
+    const float *w_scale, const int *w_colsum, const float *bias, int relu, int64_t ldo, const int *out_map,
+    const void *r_state, signed char *r8_out, unsigned *overflow, void *stream) {
+  CDN_REQUIRE(a8 && a_state && w_dw && d_state && w_codes && w_scale && w_colsum && r_state && r8_out && overflow,
+              CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && cdn_codenet_dwpw_q8_supported(C, H, W, stride, Co), CDN_ERR_UNSUPPORTED,
+              "geometry not implemented by the fused depthwise + pointwise kernel (see cdn_codenet_dwpw_q8_supported)");
+  const int64_t Cq4 = (C + 3) / 4 * 4;
+  CDN_REQUIRE(ld_in >= Cq4 && (ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(a8) & 3) == 0 &&
+                  (ldo == 0 || ldo >= Co) && (reinterpret_cast<uintptr_t>(w_codes) & 15) == 0,
+              CDN_ERR_ARG, "rows must hold round_up(C, 4) bytes, ld_in % 4 == 0, a8 4-byte / w_codes 16-byte aligned");
+  const int Ho = stride == 2 ? (int)((H - 1) / 2 + 1) : (int)H, Wo = stride == 2 ? (int)((W - 1) / 2 + 1) : (int)W;
+  const long M = (long)N * Ho * Wo;
+  CDN_REQUIRE(N * H * W * ld_in < (1ll << 31) && M * std::max<int64_t>(Co, ldo) < (1ll << 31), CDN_ERR_UNSUPPORTED,
+              "shape too large");
+  hipStream_t st = cdn::as_stream(stream);
+  const unsigned *aq = static_cast<const unsigned *>(a_state), *dq = static_cast<const unsigned *>(d_state);
+  const unsigned *rq = static_cast<const unsigned *>(r_state);
+  const int KP = (int)((C + 63) / 64 * 64);
+  const int bn = Co <= 64 ? 64 : (Co <= 128 ? 128 : 256);
+  const size_t lds = (size_t)64 * (KP + 16) + (size_t)bn * (kQK + 16);
+  const unsigned grid = (unsigned)(M / 64);
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    kern<<<grid, 256, lds, st>>>(a8, aq, w_dw, b_dw, dw_relu, dq, w_codes, w_scale, w_colsum, bias, r8_out, rq, overflow,
+                                 M, (int)C, KP, (int)ld_in, (int)H, (int)W, Ho, Wo, (int)Co, relu,
+                                 (int)(ldo ? ldo : Co), out_map);
+  };
+#define CDN_DP_BN(S_, SW_, TR_)                                         \
+  {                                                                     \
+    if (bn == 64) go(dwpwq8_kernel<S_, SW_, TR_, 64>);                  \
+    else if (bn == 128) go(dwpwq8_kernel<S_, SW_, TR_, 128>);           \
+    else go(dwpwq8_kernel<S_, SW_, TR_, 256>);                          \
+  }
+  const int tr = Wo >= 64 ? 1 : 64 / Wo;
+  if (stride == 1) {
+    if (tr == 1) CDN_DP_BN(1, 4, 1)
+    else if (tr == 2) CDN_DP_BN(1, 4, 2)
+    else if (tr == 4) CDN_DP_BN(1, 4, 4)
+    else CDN_DP_BN(1, 4, 8)
+  } else {
+    if (tr == 1) CDN_DP_BN(2, 2, 1)
+    else if (tr == 2) CDN_DP_BN(2, 2, 2)
+    else if (tr == 4) CDN_DP_BN(2, 2, 4)
+    else CDN_DP_BN(2, 2, 8)
+  }
+#undef CDN_DP_BN
+  return cdn::check_launch("codenet depthwise + pointwise on byte codes");
 }
 
 extern "C" int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H,

@@ -1556,10 +1556,11 @@ class FrozenBackbone:
     accumulates exact products in fp32 (pwd3_kernel), so results agree with FusedBackbone at running_stat False up
     to single code flips (tests/test_gpu_backbone.py).  A saturated code sets the overflow flag (``overflowed()``)."""
 
-    def __init__(self, model):
+    def __init__(self, model, fuse_dwpw=True):
         self.model = model
         self._fb = FusedBackbone(model)
         self._bufs = None
+        self.fuse_dwpw = fuse_dwpw          # a unit's depthwise inside its second 1x1 conv (cdn_codenet_dwpw_q8_forward)
 
     @staticmethod
     def supported(model):
@@ -1643,21 +1644,36 @@ class FrozenBackbone:
                                                   w.data_ptr(), b.data_ptr(), 0, qp(act), out.data_ptr(), of, st)
             N_.check(rc, "cdn_codenet_dw3x3_q8_forward")
 
+        def dwpw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, Wt, out_act, omap):
+            """depthwise (output codes of `act`) -> 1x1 conv -> ReLU -> codes of out_act into Y's slots: one launch
+            where cdn_codenet_dwpw_q8_supported, else the two kernels through the scratch tensor"""
+            if self.fuse_dwpw and lib.cdn_codenet_dwpw_q8_supported(Cc, Hs, Ws, stride, Wt["Co"]):
+                rc = lib.cdn_codenet_dwpw_q8_forward(
+                    a.data_ptr(), a_state, Nb, Cc, Hs, Ws, stride, ld_in, w.data_ptr(), b.data_ptr(), 0, qp(act),
+                    Wt["Co"], Wt["codes"].data_ptr(), Wt["scale"].data_ptr(), Wt["colsum"].data_ptr(),
+                    Wt["bias"].data_ptr(), 1, ldc, omap, qp(out_act), Y.data_ptr(), of, st)
+                N_.check(rc, "cdn_codenet_dwpw_q8_forward")
+                return
+            tmp = L["t4"] if Cc == cin and stride == 2 and a is x8 else L["t2"]
+            ldt = ldi if tmp is L["t4"] else ldh
+            dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, tmp, ldt)
+            pw(tmp, qp(act), Mo, Cc, ldt, Wt, out_act, Y, ldc, omap)
+
         Y = L["Y"]
         with torch.no_grad():
             for k, (u, P) in enumerate(zip(units, plan["units"])):
                 sh = u["sh"]
                 if k == 0:
                     # branch 1: dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct (slots omapA)
-                    dw(x8, x_state, cin, H, W, 2, x_ld, P["w4"], P["b4"], u["a4"], L["t4"], ldi)
-                    pw(L["t4"], qp(u["a4"]), Mo, cin, ldi, P["c5"], sh, Y, ldc, P["omapA"].data_ptr())
+                    dwpw(x8, x_state, cin, H, W, 2, x_ld, P["w4"], P["b4"], u["a4"], P["c5"], sh, P["omapA"].data_ptr())
                     # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct (omapB)
                     pw(x8, x_state, Mi, cin, x_ld, P["c1"], u["a1"], L["t1s2"], ldh, None)
-                    dw(L["t1s2"], qp(u["a1"]), h, H, W, 2, ldh, P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                    dwpw(L["t1s2"], qp(u["a1"]), h, H, W, 2, ldh, P["w2"], P["b2"], u["a2"], P["c3"], sh,
+                         P["omapB"].data_ptr())
                 else:
                     pw(Y, qp(sh), Mo, C, ldc, P["c1"], u["a1"], L["t1"], ldh, None)
-                    dw(L["t1"], qp(u["a1"]), h, Ho, Wo, 1, ldh, P["w2"], P["b2"], u["a2"], L["t2"], ldh)
-                pw(L["t2"], qp(u["a2"]), Mo, h, ldh, P["c3"], sh, Y, ldc, P["omapB"].data_ptr())
+                    dwpw(L["t1"], qp(u["a1"]), h, Ho, Wo, 1, ldh, P["w2"], P["b2"], u["a2"], P["c3"], sh,
+                         P["omapB"].data_ptr())
         return Y, ldc, qp(units[0]["sh"]), plan["logical"], Ho, Wo
 
     def __call__(self, images):

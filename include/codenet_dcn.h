@@ -376,6 +376,16 @@ int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a_state, int
                                  int64_t W, int stride, int64_t ld_in, int64_t ld_out, const float *w,
                                  const float *bias, int relu, const void *r_state, signed char *out8,
                                  unsigned *overflow, void *stream);
+/* cdn_codenet_dw3x3_q8_forward followed by cdn_codenet_pointwise_q8_strided_forward in ONE launch: the depthwise output
+ * (codes of d_state) is computed into the LDS operand tile of the 1x1 conv and never stored.  Bit-identical to the two
+ * calls.  Geometry: cdn_codenet_dwpw_q8_supported (output width 8 / 16 / 32 or a multiple of 64, Ho * Wo % 64 == 0,
+ * C <= 512, Co <= 256); a8 rows of ld_in bytes, outputs rows of ldo bytes (0 = Co) through the optional out_map. */
+int cdn_codenet_dwpw_q8_supported(int64_t C, int64_t H, int64_t W, int stride, int64_t Co);
+int cdn_codenet_dwpw_q8_forward(const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H, int64_t W,
+                                int stride, int64_t ld_in, const float *w_dw, const float *b_dw, int dw_relu,
+                                const void *d_state, int64_t Co, const signed char *w_codes, const float *w_scale,
+                                const int *w_colsum, const float *bias, int relu, int64_t ldo, const int *out_map,
+                                const void *r_state, signed char *r8_out, unsigned *overflow, void *stream);
 int cdn_codenet_expand_codes(const signed char *a, const void *a_state, float *out, int64_t numel, void *stream);
 
 /* out_nchw[n][c][(h<<up)+dy][(w<<up)+dx] = fq(r_nhwc[n][h*W+w][c]): channels-last -> NCHW with the

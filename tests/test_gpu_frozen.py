@@ -404,3 +404,56 @@ def test_head_tail_on_byte_codes_equals_the_fp32_form(N, Hs, Ws, classes):
                                                             w_scale.data_ptr(), w_colsum.data_ptr(), bias.data_ptr(),
                                                             classes, b.data_ptr(), of.data_ptr(), st), "byte tail")
         assert of.item() == 1
+
+
+@pytest.mark.parametrize("N,C,H,W,stride,Co,ldo", [
+    (2, 58, 64, 64, 1, 58, 128), (2, 116, 32, 32, 1, 116, 240), (3, 232, 16, 16, 1, 232, 464), (2, 24, 128, 128, 2, 58, 128),
+    (2, 58, 128, 128, 2, 58, 128), (1, 116, 64, 64, 2, 116, 240), (2, 232, 32, 32, 2, 232, 464), (2, 36, 16, 16, 1, 20, 0),
+    (1, 58, 64, 128, 1, 58, 64)])
+def test_dwpw_q8_equals_depthwise_then_pointwise(N, C, H, W, stride, Co, ldo):
+    """cdn_codenet_dwpw_q8_forward (the depthwise computed into the LDS operand tile of the 1x1 conv) against
+    cdn_codenet_dw3x3_q8_forward + cdn_codenet_pointwise_q8_strided_forward: identical bytes, slots outside the output
+    map untouched, the overflow flag of either stage reported."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    assert lib.cdn_codenet_dwpw_q8_supported(C, H, W, stride, Co) == 1
+    g = torch.Generator().manual_seed(C + H + Co)
+    ld = (C + 15) // 16 * 16
+    a8 = torch.randint(-128, 128, (N, H * W, ld), generator=g, dtype=torch.int32).to(torch.int8).to(dev)
+    sa, sd, sr = ops.quantact_state(dev), ops.quantact_state(dev), ops.quantact_state(dev)
+    sa.view(torch.float32)[2], sa.view(torch.float32)[3] = 31.7, -17.0
+    sd.view(torch.float32)[2], sd.view(torch.float32)[3] = 6.0, 21.0
+    sr.view(torch.float32)[2], sr.view(torch.float32)[3] = 255.0 / (C * 0.9), 128.0
+    w_dw = (torch.randn(C, 9, generator=g) * 0.4).to(dev)
+    b_dw = (torch.randn(C, generator=g) * 0.2).to(dev)
+    qw = torch.randint(-8, 8, (Co, C), generator=g, dtype=torch.int32)
+    cpad = (C + 63) // 64 * 64
+    codes = torch.zeros(Co, cpad, dtype=torch.int8)
+    codes[:, :C] = qw.to(torch.int8)
+    codes = codes.to(dev)
+    wscale = (torch.rand(Co, generator=g) * 20 + 5).to(dev)
+    colsum = qw.sum(1).to(torch.int32).to(dev)
+    bias = (torch.randn(Co, generator=g) * 0.1).to(dev)
+    ldo_ = ldo if ldo else Co
+    omap = torch.randperm(ldo_, generator=g)[:Co].to(torch.int32).to(dev) if ldo else None
+    Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if stride == 2 else (H, W)
+    M = N * Ho * Wo
+    st = torch.cuda.current_stream().cuda_stream
+    of1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    of2 = torch.zeros(1, dtype=torch.int32, device=dev)
+    t2 = torch.zeros(M, ld, dtype=torch.int8, device=dev)
+    want = torch.full((M, ldo_), 77, dtype=torch.int8, device=dev)
+    got = torch.full((M, ldo_), 77, dtype=torch.int8, device=dev)
+    N_.check(lib.cdn_codenet_dw3x3_q8_forward(a8.data_ptr(), sa.data_ptr(), N, C, H, W, stride, ld, ld, w_dw.data_ptr(),
+                                              b_dw.data_ptr(), 0, sd.data_ptr(), t2.data_ptr(), of1.data_ptr(), st), "dw")
+    N_.check(lib.cdn_codenet_pointwise_q8_strided_forward(
+        t2.data_ptr(), sd.data_ptr(), M, C, Co, ld, ldo_, codes.data_ptr(), wscale.data_ptr(), colsum.data_ptr(),
+        bias.data_ptr(), 1, omap.data_ptr() if omap is not None else None, sr.data_ptr(), want.data_ptr(), None,
+        of1.data_ptr(), st), "pw")
+    N_.check(lib.cdn_codenet_dwpw_q8_forward(
+        a8.data_ptr(), sa.data_ptr(), N, C, H, W, stride, ld, w_dw.data_ptr(), b_dw.data_ptr(), 0, sd.data_ptr(), Co,
+        codes.data_ptr(), wscale.data_ptr(), colsum.data_ptr(), bias.data_ptr(), 1, ldo, omap.data_ptr() if omap is not None
+        else None, sr.data_ptr(), got.data_ptr(), of2.data_ptr(), st), "dwpw")
+    assert torch.equal(got, want)
+    assert of1.item() == of2.item()
+    assert want.float().std().item() > 1.0          # (a non-degenerate case)

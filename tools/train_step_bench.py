@@ -84,10 +84,54 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"config": "CoDeNet1x %dx%d %s QAT step over deconv_layers, batch %d" % (
+    out = {"config": "CoDeNet1x %dx%d %s QAT step over deconv_layers, batch %d" % (
         a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch) + (", one HIP graph" if a.graph else ", eager launches"),
         "ms_per_step": round(dt * 1e3, 3),
-        "images_per_s": round(a.batch / dt, 1), "probe": float(loss)}))
+        "images_per_s": round(a.batch / dt, 1), "probe": float(loss)}
+    out["roofline_dw_bwd2"] = dw_bwd2_roofline(a.batch, a.res)
+    print(json.dumps(out))
+
+
+def dw_bwd2_roofline(batch, res):
+    """The step's dominant kernel family against ITS bound: dw_bwd2_kernel is not an HBM kernel (12 B per element
+    in, 4 B out) -- each (pixel, channel) pair issues 25 64-bit LDS atomics, and tools/probes/probe_lds_atomics.hip
+    measured 9.1 lane-ops per clock and CU for ds_add_u64 on gfx950 (x 256 CUs x 2.4 GHz = 5.59e12 / s).  Timed per
+    launch with HIP events at the step's three stage shapes."""
+    from codenet_amd import _native as N_
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    peak = 9.1 * 256 * 2.4e9
+    g = torch.Generator().manual_seed(0)
+    rows, tot_pairs, tot_s = [], 0, 0.0
+    for C, H in ((1024, res // 32), (256, res // 16), (128, res // 8)):
+        x = torch.randn(batch, C, H, H, generator=g).to(dev)
+        s = (torch.rand(batch, 1, H, H, generator=g) * 2.5 + 0.5).to(dev)
+        w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(dev)
+        gd = (torch.randn(batch, C, H, H, generator=g) * 1e-3).to(dev)
+        gx, gs, gw = torch.empty_like(x), torch.empty_like(s), torch.zeros_like(w)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            N_.check(lib.cdn_codenet_dw_backward(x.data_ptr(), s.data_ptr(), w.data_ptr(), gd.data_ptr(), gx.data_ptr(),
+                                                 gs.data_ptr(), gw.data_ptr(), batch, C, H, H, st), "dw backward")
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) / 20 * 1e-3
+        pairs = batch * C * H * H
+        rows.append({"plane": "%dx%d" % (H, H), "channels": C, "us_per_launch": round(sec * 1e6, 1),
+                     "lds_atomics_per_s": 25 * pairs / sec, "frac": 25 * pairs / sec / peak,
+                     "hbm_GBps": 16 * pairs / sec / 1e9})
+        tot_pairs += pairs
+        tot_s += sec
+    return {"bound": "lds_atomic", "unit": "64-bit LDS atomics/s", "peak": peak, "achieved": 25 * tot_pairs / tot_s,
+            "frac": 25 * tot_pairs / tot_s / peak, "per_stage": rows,
+            "note": "25 ds_add_u64 per (pixel, channel) pair; peak = 9.1 lane-ops/clk/CU (probe_lds_atomics) x 256 CUs x "
+                    "2.4 GHz; the kernel also reads x and grad_d and writes grad_x: 16 B per pair of HBM traffic (hbm_GBps)"}
 
 
 if __name__ == "__main__":
