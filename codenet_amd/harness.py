@@ -186,7 +186,7 @@ class PoseShuffleNetV2(nn.Module):
                             self._fzheads = pipeline.FusedHeads({h: getattr(self, h) for h in self.heads})
                         if self._fzheads.codes_supported(last):          # the heads on byte codes as well
                             return [self._fzheads.forward_codes(r8, rq, last, stages._bufs["overflow"])]
-                    return [self._fheads(*stages.forward_nhwc(feat8, fq, hw))]
+                    return [self._fheads(*stages.expand(r8, rq, last))]
             if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
                 feat, fq, hw = self._fbackbone(x)       # hw None: an NCHW tensor (odd channel count)
                 return [self._fheads(*stages.forward_nhwc(feat, fq, hw))]

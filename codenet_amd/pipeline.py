@@ -664,8 +664,11 @@ class FrozenHotPath:
         """What FusedHotPath.forward_nhwc returns -- (fp32 [N, H*W, Co], QuantAct state pointer, shape) -- for the
         native heads: the byte codes expanded to the values level / scale (re-quantising them with the same state
         returns the same values)."""
+        return self.expand(*self.forward_codes(x, x_qstate, hw))
+
+    def expand(self, r, rq, last):
+        """forward_codes' result -> what the fp32 heads take (byte codes expanded to level / scale; fp32 passes)."""
         from . import _native as N_
-        r, rq, last = self.forward_codes(x, x_qstate, hw)
         if r.dtype != torch.int8:
             return r, rq, last
         B = self._bufs
