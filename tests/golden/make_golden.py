@@ -617,6 +617,67 @@ def make_voc_eval():
     return out
 
 
+def make_post_process():
+    """The reference's own lib/utils/image.py::transform_preds / get_affine_transform / affine_transform and
+    lib/utils/post_process.py::ctdet_post_process, imported from /root/reference, on random detections with square and
+    non-square crops.  OpenCV is not installed here; the ONE cv2 function on this path, cv2.getAffineTransform, is given by
+    its definition -- the unique affine map through three point pairs, solved in float64 (what OpenCV does) -- in a stub
+    module; everything else (the three-point construction in float32, get_dir / get_3rd_point, the per-point loop, the
+    class dictionaries) is the reference's code."""
+    import importlib.util
+    cv2 = types.ModuleType("cv2")
+
+    def get_affine_transform(src, dst):
+        src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+        a = np.concatenate([src, np.ones((3, 1))], axis=1)          # [3, 3]: rows (x, y, 1)
+        return np.linalg.solve(a, dst).T                             # [2, 3]
+    cv2.getAffineTransform = get_affine_transform
+    had = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2
+    try:
+        pkg = types.ModuleType("ref_utils")
+        pkg.__path__ = [os.path.join(REF, "lib", "utils")]
+        sys.modules["ref_utils"] = pkg
+        mods = {}
+        for name in ("image", "ddd_utils", "post_process"):
+            spec = importlib.util.spec_from_file_location("ref_utils." + name,
+                                                          os.path.join(REF, "lib", "utils", name + ".py"))
+            mods[name] = importlib.util.module_from_spec(spec)
+            sys.modules["ref_utils." + name] = mods[name]
+            spec.loader.exec_module(mods[name])
+    finally:
+        if had is not None:
+            sys.modules["cv2"] = had
+        else:
+            del sys.modules["cv2"]
+    img, pp = mods["image"], mods["post_process"]
+    rng = np.random.RandomState(11)
+    out = {}
+    cases = [((250.5, 187.0), 512.0, (128, 128)), ((320.0, 240.0), 640.0, (128, 128)),
+             ((100.0, 333.5), np.array([480.0, 480.0], np.float32), (160, 96)), ((64.0, 64.0), 128.0, (32, 32))]
+    for i, (c, sc, osz) in enumerate(cases):
+        pts = (rng.rand(40, 2) * np.array(osz)).astype(np.float64)
+        out["tp%d_pts" % i] = pts
+        out["tp%d_center" % i] = np.array(c, np.float32)
+        out["tp%d_scale" % i] = np.asarray(sc, np.float32)
+        out["tp%d_osize" % i] = np.array(osz)
+        out["tp%d_out" % i] = img.transform_preds(pts, np.array(c, np.float32), sc, osz)
+    B, K, ncls = 3, 50, 20
+    dets = np.zeros((B, K, 6), np.float32)
+    dets[:, :, :2] = rng.rand(B, K, 2) * 100
+    dets[:, :, 2:4] = dets[:, :, :2] + rng.rand(B, K, 2) * 28
+    dets[:, :, 4] = rng.rand(B, K)
+    dets[:, :, 5] = rng.randint(0, ncls, (B, K))
+    c = np.array([[256.0, 200.0], [300.5, 187.5], [111.0, 222.0]], np.float32)
+    s = np.array([512.0, 600.0, 448.0], np.float32)
+    out["pp_dets"], out["pp_c"], out["pp_s"] = dets.copy(), c, s
+    res = pp.ctdet_post_process(dets.copy(), c, s, 128, 128, ncls)
+    for b in range(B):
+        for j in range(1, ncls + 1):
+            out["pp_out_%d_%d" % (b, j)] = np.asarray(res[b][j], np.float32).reshape(-1, 5)
+    return out
+
+
 def main():
     assert os.path.isdir(REF), "needs the reference checkout at /root/reference"
     torch.manual_seed(317)
@@ -634,6 +695,7 @@ def main():
         "decode_ref": make_decode,
         "base_nodes": lambda: make_base_nodes(ref_qm),
         "voc_eval_ref": make_voc_eval,
+        "post_process_ref": make_post_process,
     }
     only = sys.argv[1:] or list(makers)           # `make_golden.py stage_w4a8_grads` regenerates one fixture
     for name in only:

@@ -180,3 +180,27 @@ def test_pre_process_matches_affine_crop_known_answer():
     assert torch.allclose(row[inside], want[inside], atol=1e-2)
     # rows outside the image band (|v - res/2| * step > h/2) are the zero padding
     assert abs(float(raw[0, 0, res // 2])) < 1e-3
+
+
+def test_transform_preds_and_ctdet_post_process_reproduce_the_reference():
+    """evalio.transform_preds / ctdet_post_process against the REFERENCE's own lib/utils/image.py and
+    lib/utils/post_process.py (tests/golden/post_process_ref.npz, make_golden.py::make_post_process: the reference's code
+    with cv2.getAffineTransform given by its definition).  The reference builds the three point pairs in float32 and
+    solves in float64; the closed form here agrees to 1e-4 px on coordinates up to 700 px."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "post_process_ref.npz"))
+    for i in range(4):
+        got = evalio.transform_preds(g["tp%d_pts" % i], g["tp%d_center" % i], g["tp%d_scale" % i].tolist()
+                                     if g["tp%d_scale" % i].ndim else float(g["tp%d_scale" % i]),
+                                     tuple(int(v) for v in g["tp%d_osize" % i]))
+        assert np.abs(got - g["tp%d_out" % i]).max() < 1e-4, i
+    res = evalio.ctdet_post_process(g["pp_dets"].copy(), g["pp_c"], g["pp_s"], 128, 128, 20)
+    total = 0
+    for b in range(3):
+        assert sorted(res[b]) == list(range(1, 21))
+        for j in range(1, 21):
+            want = g["pp_out_%d_%d" % (b, j)]
+            got = np.asarray(res[b][j], np.float32).reshape(-1, 5)
+            assert got.shape == want.shape and (got.size == 0 or np.abs(got - want).max() < 2e-4), (b, j)
+            total += want.shape[0]
+    assert total == 150
