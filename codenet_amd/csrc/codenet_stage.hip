@@ -340,7 +340,7 @@ dw_bwd_kernel(const float *__restrict__ x, const float *__restrict__ s,
 // addresses, where the lanes of one pixel's channels hit 64 distinct consecutive words.
 // ------------------------------------------------------------------------------------------
 template <int CCH>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
                const float *__restrict__ wd, const float *__restrict__ gd, float *__restrict__ gx,
                float *__restrict__ gs, float *__restrict__ gw, int C, int H, int W) {
@@ -715,12 +715,18 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   if (cch != 0) {
     const size_t lds = bwd_lds(cch);
     dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
+    // one workgroup per CU (the images of a large plane fill LDS): 16 waves instead of 8 to hide the LDS atomics' latency
+#if defined(CDN_BWD_THREADS)
+    const int bwd_threads = CDN_BWD_THREADS;
+#else
+    const int bwd_threads = bwd_lds(cch) * 2 <= lds_max ? 512 : 1024;
+#endif
 #define CDN_BWD(CCH_)                                                                          \
   {                                                                                            \
     auto kern = dw_bwd2_kernel<CCH_>;                                                          \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                               (int)lds);                                                       \
-    kern<<<grid, 512, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H,   \
+    kern<<<grid, bwd_threads, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H,   \
                                  (int)W);                                                      \
   }
     switch (cch) {
