@@ -102,7 +102,7 @@ minmax_kernel(const float *__restrict__ x, long n, cdn::QUpdate qu) {
 __global__ void __launch_bounds__(256)
 quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                        const float *ext_max, const float2 *partials, int n_partials, int bits,
-                       float m_minus_1, float one_minus_m, int running) {
+                       float m_minus_1, float one_minus_m, int running, int relu) {
   __shared__ float red[8];
   __shared__ float2 pr;
   const bool from_partials = !ext_min && partials;
@@ -123,6 +123,10 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
     // (running without external extremes or partials is the fused range pass, minmax_kernel: never here)
     bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : 0.0f);
     bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : 0.0f);
+    if (relu) {      // the extremes of max(x, 0) from those of x (ReLU is monotone)
+      bmin = fmaxf(bmin, 0.0f);
+      bmax = fmaxf(bmax, 0.0f);
+    }
   }
   cdn::QUpdate u{x_min, x_max, state, nullptr, m_minus_1, one_minus_m, bits, running};
   cdn::quantact_update_device(u, bmin, bmax, have_stats);
@@ -245,13 +249,13 @@ inline int stream_grid(long n) {
 namespace cdn {
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                             const float *ext_max, const float2 *partials, int n_partials, int bits,
-                            double momentum, int running, hipStream_t st) {
+                            double momentum, int running, hipStream_t st, int relu) {
   // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
   // the scalar to fp32 (quant_modules.py:217-219).
   const int threads = (!ext_min && partials) ? 256 : 64;
   quantact_update_kernel<<<1, threads, 0, st>>>(x_min, x_max, state, ext_min, ext_max, partials,
                                                 n_partials, bits, (float)(momentum - 1.0),
-                                                (float)(1.0 - momentum), running);
+                                                (float)(1.0 - momentum), running, relu);
 }
 }  // namespace cdn
 
@@ -284,9 +288,28 @@ extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, 
   return cdn::check_launch("quantact forward");
 }
 
-extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
-                                             float *x_min, float *x_max, void *state, int bits, double momentum,
-                                             int running, void *stream) {
+// QuantAct.forward with the batch extremes given as per-workgroup {min, max} pairs of the PRODUCING kernel
+// (cdn_codenet_{scale,dw,pointwise}_forward_range): update + fake-quantisation, no range pass over x.
+extern "C" int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, float *x_min, float *x_max,
+                                             void *state, const float *partials, int64_t n_partials, int bits,
+                                             double momentum, int running, void *stream) {
+  CDN_REQUIRE(x && out && x_min && x_max && state && partials, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(numel > 0 && n_partials > 0 && n_partials < (1ll << 31), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(partials) & 7) == 0,
+              CDN_ERR_ARG, "tensors must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  unsigned *stt = static_cast<unsigned *>(state);
+  cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, reinterpret_cast<const float2 *>(partials),
+                              (int)n_partials, bits, momentum, running, st);
+  fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, nullptr, (long)numel, stt);
+  return cdn::check_launch("quantact forward (partials)");
+}
+
+static int relu_up2_impl(const float *y, float *out, int64_t planes, int64_t H, int64_t W, float *x_min, float *x_max,
+                         void *state, const float *partials, int64_t n_partials, int bits, double momentum, int running,
+                         void *stream) {
   CDN_REQUIRE(y && out && x_min && x_max && state, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * H * W < (1ll << 31), CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
@@ -295,7 +318,10 @@ extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t
   hipStream_t st = cdn::as_stream(stream);
   unsigned *stt = static_cast<unsigned *>(state);
   const long numel = (long)(planes * H * W);
-  if (running) {
+  if (running && partials) {     // extremes of y from its producer, clamped at zero: those of max(y, 0)
+    cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, reinterpret_cast<const float2 *>(partials),
+                                (int)n_partials, bits, momentum, running, st, 1);
+  } else if (running) {
     const cdn::QUpdate qu{x_min, x_max, stt, nullptr, (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1};
     minmax_kernel<true><<<minmax_grid(numel), 256, 0, st>>>(y, numel, qu);
   } else {
@@ -305,6 +331,21 @@ extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t
   relu_fq_up2_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
                        256, 0, st>>>(y, out, rows, (int)W, stt);
   return cdn::check_launch("quantact relu up2 forward");
+}
+
+extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
+                                             float *x_min, float *x_max, void *state, int bits, double momentum,
+                                             int running, void *stream) {
+  return relu_up2_impl(y, out, planes, H, W, x_min, x_max, state, nullptr, 0, bits, momentum, running, stream);
+}
+
+extern "C" int cdn_quantact_relu_up2_forward_partials(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
+                                                      float *x_min, float *x_max, void *state, const float *partials,
+                                                      int64_t n_partials, int bits, double momentum, int running,
+                                                      void *stream) {
+  CDN_REQUIRE(partials && n_partials > 0 && n_partials < (1ll << 31), CDN_ERR_ARG, "bad partials");
+  return relu_up2_impl(y, out, planes, H, W, x_min, x_max, state, partials, n_partials, bits, momentum, running,
+                       stream);
 }
 
 extern "C" int cdn_up2_relu_backward(const float *grad_out, const float *y, float *grad_y, int64_t planes, int64_t H,

@@ -56,7 +56,7 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
 __global__ void __launch_bounds__(256)
 scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
              const float *__restrict__ b, float *__restrict__ s, int C, int HW, float lo,
-             float hi) {
+             float hi, float2 *__restrict__ mm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
   const int n = blockIdx.y;
@@ -76,11 +76,18 @@ scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
   __shared__ float red[4][64];
   red[wave][lane] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
+  float mn = INFINITY, mx = -INFINITY;
   if (wave == 0 && live) {
     float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     v += b ? b[0] : 0.0f;
     v = fminf(fmaxf(v, lo), hi);  // Hardtanh(lo, hi), modules/dcn_deform_conv.py:304-305
     s[(long)n * HW + p] = v;
+    mn = mx = v;
+  }
+  // training path: this workgroup's {min, max} of what it wrote, for the QuantAct behind it (no separate range pass)
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_store(mn, mx, &mm[blockIdx.y * gridDim.x + blockIdx.x], &red[0][0]);
   }
 }
 
@@ -94,8 +101,10 @@ constexpr int kDwThreads = 256;
 template <bool LDS>
 __global__ void __launch_bounds__(kDwThreads)
 dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
-          float *__restrict__ d, int C, int H, int W, int CC) {
+          float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm) {
   extern __shared__ float smem[];
+  __shared__ float red_mm[8];
+  float mn = INFINITY, mx = -INFINITY;
   const int HW = H * W;
   const int Wp = W + 2, Hp = H + 2;
   const int pstride = Hp * Wp;
@@ -181,8 +190,11 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
         acc = fmaf(wk[8], tap(yb, xb), acc);
       }
       d[((long)n * C + c0 + ch) * HW + p] = acc;
+      mn = fminf(mn, acc);
+      mx = fmaxf(mx, acc);
     }
   }
+  if (mm) cdn::block_minmax_store(mn, mx, &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -548,7 +560,7 @@ __global__ void __launch_bounds__(256)
 pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ ep_scale,
                  const float *__restrict__ ep_shift, float *__restrict__ Y, int C, int Co, int HW,
-                 int relu) {
+                 int relu, float2 *__restrict__ mm) {
   // K tiles of 32, the NEXT tile's global loads (4 x 16 B per thread) in flight behind the 16 MFMAs of the
   // current one: with one 16-deep tile and no prefetch every tile paid a full global-load latency (50 TF at
   // the stage-0 shape; the QAT step runs this kernel six times: forward and data gradient of three stages)
@@ -612,6 +624,7 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
     }
   }
   const int col = p0 + wn + (lane & 31);
+  float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -621,53 +634,102 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
       if (ep_scale) v = fmaf(v, ep_scale[row], ep_shift[row]);
       if (relu) v = fmaxf(v, 0.0f);
       Y[((long)n * Co + row) * HW + col] = v;
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
     }
+  }
+  if (mm) {
+    __syncthreads();      // (As is free: every wave has left the k loop)
+    cdn::block_minmax_store(mn, mx, &mm[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x], &As[0][0]);
   }
 }
 
 }  // namespace
 
-extern "C" int cdn_codenet_scale_forward(const float *x, const float *w_scale,
-                                         const float *b_scale, float *s, int64_t N, int64_t C,
-                                         int64_t H, int64_t W, float lo, float hi, void *stream) {
+// The three forward kernels of the stage optionally leave one {min, max} pair per workgroup of the tensor they wrote
+// (`partials`, *_range_partials(...) float2 entries): the training path's QuantAct behind them reduces those instead of
+// re-reading the tensor (cdn_quantact_forward_partials / cdn_quantact_relu_up2_forward_partials).
+static int scale_forward_impl(const float *x, const float *w_scale, const float *b_scale, float *s, int64_t N,
+                              int64_t C, int64_t H, int64_t W, float lo, float hi, float *partials, void *stream) {
   CDN_REQUIRE(x && w_scale && s, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   const int HW = (int)(H * W);
   dim3 grid((unsigned)cdn::ceil_div(HW, 64), (unsigned)N);
-  scale_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo,
-                                                         hi);
+  scale_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo, hi,
+                                                         reinterpret_cast<float2 *>(partials));
   return cdn::check_launch("codenet scale forward");
 }
 
-extern "C" int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, float *d,
-                                      int64_t N, int64_t C, int64_t H, int64_t W, void *stream) {
+extern "C" int cdn_codenet_scale_forward(const float *x, const float *w_scale,
+                                         const float *b_scale, float *s, int64_t N, int64_t C,
+                                         int64_t H, int64_t W, float lo, float hi, void *stream) {
+  return scale_forward_impl(x, w_scale, b_scale, s, N, C, H, W, lo, hi, nullptr, stream);
+}
+
+extern "C" int64_t cdn_codenet_scale_range_partials(int64_t N, int64_t H, int64_t W) {
+  return (N > 0 && H > 0 && W > 0) ? cdn::ceil_div(H * W, 64) * N : 0;
+}
+
+extern "C" int cdn_codenet_scale_forward_range(const float *x, const float *w_scale, const float *b_scale, float *s,
+                                               int64_t N, int64_t C, int64_t H, int64_t W, float lo, float hi,
+                                               float *partials, void *stream) {
+  CDN_REQUIRE(partials, CDN_ERR_ARG, "null partials pointer");
+  return scale_forward_impl(x, w_scale, b_scale, s, N, C, H, W, lo, hi, partials, stream);
+}
+
+static int dw_channels_per_wg(int64_t C, int64_t H, int64_t W) {
+  const int pstride = (int)((H + 2) * (W + 2));
+  const int budget = 64 * 1024 / 4;  // floats of LDS per workgroup (2 workgroups per CU)
+  int CC = (budget - 64) / (pstride + 9);
+  if (CC < 1) return -4;                                 // planes too large: global gather, 4 channels per workgroup
+  if (CC > 32) CC = 32;
+  if (CC > C) CC = (int)C;
+  return CC;
+}
+
+static int dw_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
+                           int64_t H, int64_t W, float *partials, void *stream) {
   CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   const int pstride = (int)((H + 2) * (W + 2));
-  const int budget = 64 * 1024 / 4;  // floats of LDS per workgroup (2 workgroups per CU)
-  int CC = (budget - 64) / (pstride + 9);
+  int CC = dw_channels_per_wg(C, H, W);
   hipStream_t st = cdn::as_stream(stream);
+  float2 *mm = reinterpret_cast<float2 *>(partials);
   if (CC >= 1) {
-    if (CC > 32) CC = 32;
-    if (CC > C) CC = (int)C;
     const size_t lds = (size_t)(((CC * 9 + 3) & ~3) + CC * pstride) * sizeof(float);
     dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
-    dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC);
+    dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
   } else {
     CC = 4;
     const size_t lds = (size_t)((CC * 9 + 3) & ~3) * sizeof(float);
     dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
-    dw_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC);
+    dw_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
   }
   return cdn::check_launch("codenet dw forward");
 }
 
-extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, const float *bias,
-                                             const float *ep_scale, const float *ep_shift,
-                                             float *y, int64_t N, int64_t C, int64_t Co,
-                                             int64_t HW, int relu, void *stream) {
+extern "C" int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, float *d,
+                                      int64_t N, int64_t C, int64_t H, int64_t W, void *stream) {
+  return dw_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream);
+}
+
+extern "C" int64_t cdn_codenet_dw_range_partials(int64_t N, int64_t C, int64_t H, int64_t W) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const int CC = dw_channels_per_wg(C, H, W);
+  return cdn::ceil_div(C, CC >= 1 ? CC : 4) * N;
+}
+
+extern "C" int cdn_codenet_dw_forward_range(const float *x, const float *s, const float *w_dw, float *d, int64_t N,
+                                            int64_t C, int64_t H, int64_t W, float *partials, void *stream) {
+  CDN_REQUIRE(partials, CDN_ERR_ARG, "null partials pointer");
+  return dw_forward_impl(x, s, w_dw, d, N, C, H, W, partials, stream);
+}
+
+static int pointwise_forward_impl(const float *d, const float *w_pw, const float *bias, const float *ep_scale,
+                                  const float *ep_shift, float *y, int64_t N, int64_t C, int64_t Co, int64_t HW,
+                                  int relu, float *partials, void *stream) {
   CDN_REQUIRE(d && w_pw && y, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
               "ep_scale and ep_shift must both be set or both be NULL");
@@ -676,8 +738,28 @@ extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, 
               CDN_ERR_UNSUPPORTED, "shape too large");
   dim3 grid((unsigned)cdn::ceil_div(HW, kPwBN), (unsigned)cdn::ceil_div(Co, kPwBM), (unsigned)N);
   pointwise_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(d, w_pw, bias, ep_scale, ep_shift, y,
-                                                             (int)C, (int)Co, (int)HW, relu);
+                                                             (int)C, (int)Co, (int)HW, relu,
+                                                             reinterpret_cast<float2 *>(partials));
   return cdn::check_launch("codenet pointwise forward");
+}
+
+extern "C" int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, const float *bias,
+                                             const float *ep_scale, const float *ep_shift,
+                                             float *y, int64_t N, int64_t C, int64_t Co,
+                                             int64_t HW, int relu, void *stream) {
+  return pointwise_forward_impl(d, w_pw, bias, ep_scale, ep_shift, y, N, C, Co, HW, relu, nullptr, stream);
+}
+
+extern "C" int64_t cdn_codenet_pointwise_range_partials(int64_t N, int64_t Co, int64_t HW) {
+  return (N > 0 && Co > 0 && HW > 0) ? cdn::ceil_div(HW, kPwBN) * cdn::ceil_div(Co, kPwBM) * N : 0;
+}
+
+extern "C" int cdn_codenet_pointwise_forward_range(const float *d, const float *w_pw, const float *bias,
+                                                   const float *ep_scale, const float *ep_shift, float *y, int64_t N,
+                                                   int64_t C, int64_t Co, int64_t HW, int relu, float *partials,
+                                                   void *stream) {
+  CDN_REQUIRE(partials, CDN_ERR_ARG, "null partials pointer");
+  return pointwise_forward_impl(d, w_pw, bias, ep_scale, ep_shift, y, N, C, Co, HW, relu, partials, stream);
 }
 
 extern "C" int cdn_codenet_dw_backward_supported(int64_t H, int64_t W) {

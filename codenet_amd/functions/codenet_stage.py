@@ -63,24 +63,42 @@ class CodenetStageFunction(Function):
     203-219)."""
 
     @staticmethod
-    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d):
+    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range=False):
         ops._gpu_f32(x, w_scale, b_scale, w_dw, w_pw, b_pw)
         x = x.contiguous()
-        s_c = ops.codenet_scale(x, w_scale, b_scale, lo, hi)            # clamped, pre-quantisation
-        s = _native_quantact(act_s, s_c) if act_s is not None else s_c
+        # every producer leaves the {min, max} pairs of its output for the QuantAct behind it: no range passes
+        if act_s is not None and act_s.running_stat:
+            s_c, sp = ops.codenet_scale(x, w_scale, b_scale, lo, hi, want_range=True)   # clamped, pre-quantisation
+            s = ops.quantact_forward_partials(s_c, act_s, sp)
+        else:
+            s_c = ops.codenet_scale(x, w_scale, b_scale, lo, hi)
+            s = _native_quantact(act_s, s_c) if act_s is not None else s_c
         with torch.no_grad():
-            d = ops.codenet_dw(x, s, w_dw.contiguous())
-        d_q = _native_quantact(act_d, d) if act_d is not None else d
+            if act_d is not None and act_d.running_stat:
+                d, dp = ops.codenet_dw_range(x, s, w_dw)
+                d_q = ops.quantact_forward_partials(d, act_d, dp)
+            else:
+                d = ops.codenet_dw(x, s, w_dw.contiguous())
+                d_q = _native_quantact(act_d, d) if act_d is not None else d
         have_pw = w_pw is not None
-        y = ops.codenet_pointwise(d_q, w_pw, b_pw) if have_pw else d_q
+        yp = None
+        if have_pw and want_range:
+            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True)
+        else:
+            y = ops.codenet_pointwise(d_q, w_pw, b_pw) if have_pw else d_q
         ctx.lo, ctx.hi, ctx.have_pw = float(lo), float(hi), have_pw
         ctx.has_b_scale, ctx.has_b_pw = b_scale is not None, b_pw is not None
         ctx.save_for_backward(x, s_c, s, w_scale, w_dw, d_q if have_pw else None, w_pw)
+        if want_range:
+            if yp is None:
+                yp = y.new_zeros(0, 2)
+            ctx.mark_non_differentiable(yp)
+            return y, yp
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, *unused):
         x, s_c, s, w_scale, w_dw, d_q, w_pw = ctx.saved_tensors
         need = ctx.needs_input_grad
         gy = gy.contiguous()
@@ -125,7 +143,7 @@ class CodenetStageFunction(Function):
                     g_wscale = tot[:C].view_as(w_scale)
                 if want_b:
                     g_bscale = tot[C:].reshape(1)
-        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None
+        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None, None
 
 
 def _native_quantact(act, t):
@@ -135,8 +153,10 @@ def _native_quantact(act, t):
     return out
 
 
-def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None):
-    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d)
+def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None, want_range=False):
+    """want_range: returns (y, partials) -- the per-workgroup {min, max} pairs of y ([n, 2], empty without a pointwise
+    conv) for a QuantAct behind the stage (ReluQuantUpsample)."""
+    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range)
 
 
 class QuantActSTE(Function):
@@ -233,15 +253,23 @@ class ReluQuantUpsample(Function):
     QuantAct).  Same values as the three modules (tests/test_train_step.py)."""
 
     @staticmethod
-    def forward(ctx, y, act):
+    def forward(ctx, y, act, partials=None):
         ops._gpu_f32(y)
         y = y.contiguous()
         Nb, C, H, W = y.shape
         out = torch.empty(Nb, C, 2 * H, 2 * W, device=y.device)
-        rc = N_.lib().cdn_quantact_relu_up2_forward(_p(y), _p(out), Nb * C, H, W, _p(act.x_min), _p(act.x_max),
-                                                    _p(act._device_state(y.device)), int(act.activation_bit),
-                                                    float(act.momentum), int(bool(act.running_stat)), ops._stream(y))
-        N_.check(rc, "cdn_quantact_relu_up2_forward")
+        if partials is not None and partials.shape[0] > 0 and act.running_stat:
+            # the stage's pointwise kernel left the {min, max} pairs of y: no range pass over y
+            rc = N_.lib().cdn_quantact_relu_up2_forward_partials(
+                _p(y), _p(out), Nb * C, H, W, _p(act.x_min), _p(act.x_max), _p(act._device_state(y.device)),
+                _p(partials), partials.shape[0], int(act.activation_bit), float(act.momentum), 1, ops._stream(y))
+            N_.check(rc, "cdn_quantact_relu_up2_forward_partials")
+        else:
+            rc = N_.lib().cdn_quantact_relu_up2_forward(_p(y), _p(out), Nb * C, H, W, _p(act.x_min), _p(act.x_max),
+                                                        _p(act._device_state(y.device)), int(act.activation_bit),
+                                                        float(act.momentum), int(bool(act.running_stat)),
+                                                        ops._stream(y))
+            N_.check(rc, "cdn_quantact_relu_up2_forward")
         ctx.save_for_backward(y)
         return out
 
@@ -254,7 +282,7 @@ class ReluQuantUpsample(Function):
         gy = torch.empty_like(y)
         rc = N_.lib().cdn_up2_relu_backward(_p(g), _p(y), _p(gy), Nb * C, H, W, ops._stream(y))
         N_.check(rc, "cdn_up2_relu_backward")
-        return gy, None
+        return gy, None, None
 
 
 def forward_stage_blocks(seq, x):
@@ -276,7 +304,9 @@ def forward_stage_blocks(seq, x):
             and all(block_ok(*mods[i:i + 3]) for i in range(0, len(mods), 3))):
         return seq(x)
     for i in range(0, len(mods), 3):
-        x = ReluQuantUpsample.apply(mods[i](x), mods[i + 1][1])
+        y = mods[i](x, want_range=True)                    # (y, {min, max} pairs of y) on the native training path
+        y, part = y if isinstance(y, tuple) else (y, None)
+        x = ReluQuantUpsample.apply(y, mods[i + 1][1], part)
     return x
 
 

@@ -67,8 +67,13 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def codenet_scale(x, w_scale, b_scale, lo, hi):
-    """s = Hardtanh(lo,hi)(conv1x1(x; C->1) + b): [N,C,H,W] -> [N,1,H,W]."""
+def _partials(n, like):
+    return torch.empty(int(n), 2, device=like.device, dtype=torch.float32)
+
+
+def codenet_scale(x, w_scale, b_scale, lo, hi, want_range=False):
+    """s = Hardtanh(lo,hi)(conv1x1(x; C->1) + b): [N,C,H,W] -> [N,1,H,W].  want_range: also the per-workgroup
+    {min, max} pairs of s for the QuantAct behind it (cdn_quantact_forward_partials)."""
     _gpu_f32(x, w_scale, b_scale)
     x = x.contiguous()
     Nb, C, H, W = x.shape
@@ -78,11 +83,42 @@ def codenet_scale(x, w_scale, b_scale, lo, hi):
     b = b_scale.contiguous().view(-1) if b_scale is not None else None
     s = x.new_empty(Nb, 1, H, W)
     rec = _tic("scale", (C, H, W))
+    if want_range:
+        part = _partials(N_.lib().cdn_codenet_scale_range_partials(Nb, H, W), x)
+        rc = N_.lib().cdn_codenet_scale_forward_range(_p(x), _p(w), _p(b), _p(s), Nb, C, H, W, float(lo), float(hi),
+                                                      _p(part), _stream(x))
+        _toc(rec)
+        N_.check(rc, "cdn_codenet_scale_forward_range")
+        return s, part
     rc = N_.lib().cdn_codenet_scale_forward(_p(x), _p(w), _p(b), _p(s), Nb, C, H, W, float(lo),
                                             float(hi), _stream(x))
     _toc(rec)
     N_.check(rc, "cdn_codenet_scale_forward")
     return s
+
+
+def codenet_dw_range(x, s, w_dw):
+    """The gather / depthwise forward (no autograd) + the {min, max} pairs of its output."""
+    _gpu_f32(x, s, w_dw)
+    x, s, w_dw = x.contiguous(), s.contiguous(), w_dw.contiguous()
+    Nb, C, H, W = x.shape
+    d = torch.empty_like(x)
+    part = _partials(N_.lib().cdn_codenet_dw_range_partials(Nb, C, H, W), x)
+    rc = N_.lib().cdn_codenet_dw_forward_range(_p(x), _p(s), _p(w_dw), _p(d), Nb, C, H, W, _p(part), _stream(x))
+    N_.check(rc, "cdn_codenet_dw_forward_range")
+    return d, part
+
+
+def quantact_forward_partials(x, act, partials):
+    """QuantAct.forward on the device with the batch extremes from the producer's {min, max} pairs: range update in
+    place + fake-quantisation, no pass over x for the range."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    rc = N_.lib().cdn_quantact_forward_partials(_p(x), _p(out), x.numel(), _p(act.x_min), _p(act.x_max),
+                                                _p(act._device_state(x.device)), _p(partials), partials.shape[0],
+                                                int(act.activation_bit), float(act.momentum), 1, _stream(x))
+    N_.check(rc, "cdn_quantact_forward_partials")
+    return out
 
 
 class _CodenetDW(Function):
@@ -143,8 +179,9 @@ def _dw_backward_generic(x, s, w_dw, gd, needs):
 codenet_dw = _CodenetDW.apply
 
 
-def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False):
-    """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA."""
+def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False):
+    """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA.  want_range: also the per-workgroup
+    {min, max} pairs of y."""
     _gpu_f32(d, w_pw, bias, ep_scale, ep_shift)
     d = d.contiguous()
     Nb, C, H, W = d.shape
@@ -154,11 +191,16 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
     Co = w.size(0)
     y = d.new_empty(Nb, Co, H, W)
     rec = _tic("pointwise", (C, H, W))
-    rc = N_.lib().cdn_codenet_pointwise_forward(
-        _p(d), _p(w), _p(bias.contiguous() if bias is not None else None),
-        _p(ep_scale.contiguous() if ep_scale is not None else None),
-        _p(ep_shift.contiguous() if ep_shift is not None else None), _p(y), Nb, C, Co, H * W,
-        int(bool(relu)), _stream(d))
+    args = (_p(d), _p(w), _p(bias.contiguous() if bias is not None else None),
+            _p(ep_scale.contiguous() if ep_scale is not None else None),
+            _p(ep_shift.contiguous() if ep_shift is not None else None), _p(y), Nb, C, Co, H * W, int(bool(relu)))
+    if want_range:
+        part = _partials(N_.lib().cdn_codenet_pointwise_range_partials(Nb, Co, H * W), d)
+        rc = N_.lib().cdn_codenet_pointwise_forward_range(*args, _p(part), _stream(d))
+        _toc(rec)
+        N_.check(rc, "cdn_codenet_pointwise_forward_range")
+        return y, part
+    rc = N_.lib().cdn_codenet_pointwise_forward(*args, _stream(d))
     _toc(rec)
     N_.check(rc, "cdn_codenet_pointwise_forward")
     return y

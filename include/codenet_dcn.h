@@ -167,6 +167,30 @@ int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, fl
 int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor, const float *bn_bias,
                             const float *bn_mean, const float *conv_bias, int bits, float *w_q, float *bias_out,
                             void *stream);
+/* Training path without separate range passes: the three forward kernels of the stage can leave one {min, max} pair
+ * per workgroup of the tensor they wrote (`partials`: 2 floats per pair, 8-byte aligned, *_range_partials(...) pairs),
+ * and the QuantAct behind them reduces those pairs instead of re-reading the tensor:
+ *   cdn_codenet_{scale,dw,pointwise}_forward_range  = the plain entry points + partials (same outputs);
+ *   cdn_quantact_forward_partials                   = cdn_quantact_forward with the batch extremes from the pairs;
+ *   cdn_quantact_relu_up2_forward_partials          = cdn_quantact_relu_up2_forward with the pairs of the PRE-ReLU tensor
+ *                                                     (clamped at zero: the extremes of max(y, 0)).
+ * Same range updates and values as the entry points with a range pass (min / max are exact). */
+int64_t cdn_codenet_scale_range_partials(int64_t N, int64_t H, int64_t W);
+int cdn_codenet_scale_forward_range(const float *x, const float *w_scale, const float *b_scale, float *s, int64_t N,
+                                    int64_t C, int64_t H, int64_t W, float lo, float hi, float *partials, void *stream);
+int64_t cdn_codenet_dw_range_partials(int64_t N, int64_t C, int64_t H, int64_t W);
+int cdn_codenet_dw_forward_range(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
+                                 int64_t H, int64_t W, float *partials, void *stream);
+int64_t cdn_codenet_pointwise_range_partials(int64_t N, int64_t Co, int64_t HW);
+int cdn_codenet_pointwise_forward_range(const float *d, const float *w_pw, const float *bias, const float *ep_scale,
+                                        const float *ep_shift, float *y, int64_t N, int64_t C, int64_t Co, int64_t HW,
+                                        int relu, float *partials, void *stream);
+int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, float *x_min, float *x_max, void *state,
+                                  const float *partials, int64_t n_partials, int bits, double momentum, int running,
+                                  void *stream);
+int cdn_quantact_relu_up2_forward_partials(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
+                                           float *x_min, float *x_max, void *state, const float *partials,
+                                           int64_t n_partials, int bits, double momentum, int running, void *stream);
 /* Backward of the BN fold of cdn_codenet_weight_prep under the straight-through weight quantiser
  * (SymmetricQuantFunction.backward, quant_utils.py:227-229; autograd of quant_modules.py:365-372) in one launch:
  *   grad_w = grad_wq * scale_factor,  grad_gamma = (sum_k grad_wq * w + grad_bias * (conv_bias - mean)) / bn_std,
