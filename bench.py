@@ -482,19 +482,28 @@ def main():
     durs = {}
     if fused is not None and rank == 0:
         lib = _native.lib()
-        lib.cdn_profile_enable(1)
-        for _ in range(args.steps):
-            eager_step_unpack()
-        torch.cuda.synchronize()
-        cap = args.steps * 16
-        ids = (ctypes.c_int * cap)()
-        tags = (ctypes.c_int * cap)()
-        ms = (ctypes.c_float * cap)()
-        n = lib.cdn_profile_read(cap, ids, tags, ms)
-        lib.cdn_profile_enable(0)
         kname = {0: "scale", 1: "dw", 2: "pointwise", 3: "unpack"}
-        for i in range(n):
-            durs.setdefault((kname.get(ids[i], "other"), (tags[i],)), []).append(ms[i])
+
+        def timed_eager(step_fn, keep):
+            # K eager steps with the library's event pairs around every kernel.  `step_fn` must be the TIMED step: until
+            # round 3 these steps also ran unpack_kernel (320 MB through the caches between two steps), which made the
+            # kernels behind it -- the stage-0 scale and gather above all -- 10-40 % slower than inside the timed region
+            lib.cdn_profile_enable(1)
+            for _ in range(args.steps):
+                step_fn()
+            torch.cuda.synchronize()
+            cap = args.steps * 16
+            ids = (ctypes.c_int * cap)()
+            tags = (ctypes.c_int * cap)()
+            ms = (ctypes.c_float * cap)()
+            n = lib.cdn_profile_read(cap, ids, tags, ms)
+            lib.cdn_profile_enable(0)
+            for i in range(n):
+                name = kname.get(ids[i], "other")
+                if keep(name):
+                    durs.setdefault((name, (tags[i],)), []).append(ms[i])
+        timed_eager(eager_step, lambda nm: nm != "unpack")
+        timed_eager(eager_step_unpack, lambda nm: nm == "unpack")       # (reported separately, `with_unpack`)
     elif rank == 0:
         durs = kt.durations_ms()
 
