@@ -725,6 +725,48 @@ def main():
         dist.destroy_process_group()
 
 
+def _e2e_frozen_leg(args, model, images, replay):
+    """Serving mode of the whole network on THIS rank: every QuantAct frozen, byte codes from the stem to the heads."""
+    import torch
+    from codenet_amd import harness, pipeline
+    for _ in range(300):                  # let the running (EMA) ranges settle on this input before freezing them
+        replay()
+    torch.cuda.synchronize()
+    pipeline.set_running_stat(model, False)
+    # a serving deployment freezes CALIBRATED ranges: the EMA ranges are widened over what the frozen network
+    # feeds each QuantAct on this batch (+2 % of the span), so that every code fits the byte grid
+    model.enable_fused(False)
+    moved = pipeline.cover_frozen_ranges(model, [images], margin=0.02)
+    torch.cuda.empty_cache()
+
+    def timed(**kw):
+        model.enable_fused(frozen_codes=True, **kw)
+        replay_f = harness.capture_process(model, images)
+        for _ in range(5):
+            replay_f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dets_f = replay_f()[1]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3, dets_f, bool(model.frozen_overflowed())
+    ms_st, dets_s, of_s = timed(frozen_backbone=False)
+    msf, dets_f, of_f = timed()
+    return {"ms_per_batch": msf, "images_per_s": args.batch / msf * 1e3, "per_rank": True,
+            "overflow": of_f, "finite": bool(torch.isfinite(dets_f).all()),
+            "byte_backbone": model._fzbackbone is not None,
+            "byte_heads": model._fzheads is not None and model._fzheads._bufs is not None
+            and model._fzheads._bufs["key"][0][0] == "codes",
+            "stages_only": {"ms_per_batch": ms_st, "overflow": of_s,
+                            "what": "backbone on the fp32 kernels without range updates, stages on byte codes"},
+            "ranges_widened": moved,
+            "what": "the same network with every QuantAct frozen (running_stat False: serving mode, not the "
+                    "reference's default) on BYTE CODES from the stem to the heads' input: backbone "
+                    "(pipeline.FrozenBackbone), the three deform stages with chained scale sums "
+                    "(pipeline.FrozenHotPath), the heads' 1x1 convs and tails (FusedHeads.forward_codes); no "
+                    "range passes anywhere; timed on rank 0's shard without collectives"}
+
+
 def e2e_leg(args, dev, rank, world, local_rank, hot_ms):
     """Whole network (stem + 16 ShuffleNetV2 units + layer4 + three deform stages + three heads, all on the HIP
     kernels) + native ctdet_decode, captured as ONE HIP graph per rank over a static image buffer; for N > 1
@@ -768,42 +810,11 @@ def e2e_leg(args, dev, rank, world, local_rank, hot_ms):
     # ---- serving mode: every QuantAct frozen (running_stat False), the three stages on the byte-code schedule ----
     frozen = None
     if not args.fp32 and not args.frozen:
-        for _ in range(300):                  # let the running (EMA) ranges settle on this input before freezing them
-            replay()
-        torch.cuda.synchronize()
-        pipeline.set_running_stat(model, False)
-        # a serving deployment freezes CALIBRATED ranges: the EMA ranges are widened over what the frozen network
-        # feeds each QuantAct on this batch (+2 % of the span), so that every code fits the byte grid
-        model.enable_fused(False)
-        moved = pipeline.cover_frozen_ranges(model, [images], margin=0.02)
-        torch.cuda.empty_cache()
-
-        def timed(**kw):
-            model.enable_fused(frozen_codes=True, **kw)
-            replay_f = harness.capture_process(model, images)
-            for _ in range(5):
-                replay_f()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                dets_f = replay_f()[1]
-            barrier()
-            return (time.perf_counter() - t0) / args.steps * 1e3, dets_f, bool(model.frozen_overflowed())
-        ms_st, dets_s, of_s = timed(frozen_backbone=False)
-        msf, dets_f, of_f = timed()
-        frozen = {"ms_per_batch": msf, "images_per_s": args.batch / msf * 1e3, "per_rank": True,
-                  "overflow": of_f, "finite": bool(torch.isfinite(dets_f).all()),
-                  "byte_backbone": model._fzbackbone is not None,
-                  "byte_heads": model._fzheads is not None and model._fzheads._bufs is not None
-                  and model._fzheads._bufs["key"][0][0] == "codes",
-                  "stages_only": {"ms_per_batch": ms_st, "overflow": of_s,
-                                  "what": "backbone on the fp32 kernels without range updates, stages on byte codes"},
-                  "ranges_widened": moved,
-                  "what": "the same network with every QuantAct frozen (running_stat False: serving mode, not the "
-                          "reference's default) on BYTE CODES from the stem to the heads' input: backbone "
-                          "(pipeline.FrozenBackbone), the three deform stages with chained scale sums "
-                          "(pipeline.FrozenHotPath), the heads' 1x1 convs and tails (FusedHeads.forward_codes); no "
-                          "range passes anywhere"}
+        # per-rank leg without collectives (a failure here must not hang the other ranks or lose the headline)
+        try:
+            frozen = _e2e_frozen_leg(args, model, images, replay)
+        except Exception as exc:          # noqa: BLE001 -- reported in the JSON line, the step's numbers stand
+            frozen = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return {"ms_per_batch": ms, "images_per_s": world * args.batch / ms * 1e3, "frozen": frozen,
             "hot_path_share": hot_ms / ms, "detections": list(dets.shape),
             "what": "CoDeNet%s %dx%d %s batch %d per GPU: whole network on the HIP kernels + native ctdet_decode "
