@@ -60,7 +60,8 @@ constexpr int kQStateWords = 8;
 // frozen ranges (running == 0) are meaningful.
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                             const float *ext_max, const float2 *partials, int n_partials, int bits,
-                            double momentum, int running, hipStream_t st, int relu = 0);
+                            double momentum, int running, hipStream_t st, int relu = 0,
+                            unsigned *state_copy = nullptr);
 
 }  // namespace cdn
 

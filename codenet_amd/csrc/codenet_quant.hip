@@ -102,7 +102,7 @@ minmax_kernel(const float *__restrict__ x, long n, cdn::QUpdate qu) {
 __global__ void __launch_bounds__(256)
 quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                        const float *ext_max, const float2 *partials, int n_partials, int bits,
-                       float m_minus_1, float one_minus_m, int running, int relu) {
+                       float m_minus_1, float one_minus_m, int running, int relu, unsigned *state_copy) {
   __shared__ float red[8];
   __shared__ float2 pr;
   const bool from_partials = !ext_min && partials;
@@ -130,6 +130,9 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
   }
   cdn::QUpdate u{x_min, x_max, state, nullptr, m_minus_1, one_minus_m, bits, running};
   cdn::quantact_update_device(u, bmin, bmax, have_stats);
+  if (state_copy) {      // a snapshot for consumers that outlive the next call of this QuantAct (the training backward)
+    for (int i = 0; i < kStateWords; ++i) state_copy[i] = (i >= 2 && i <= 6) ? state[i] : 0u;
+  }
 }
 
 // out = (q + zp) / scale; optionally also the integer codes (int16: codes are NOT clamped to
@@ -249,13 +252,13 @@ inline int stream_grid(long n) {
 namespace cdn {
 void launch_quantact_update(float *x_min, float *x_max, unsigned *state, const float *ext_min,
                             const float *ext_max, const float2 *partials, int n_partials, int bits,
-                            double momentum, int running, hipStream_t st, int relu) {
+                            double momentum, int running, hipStream_t st, int relu, unsigned *state_copy) {
   // Python evaluates (momentum - 1.) and (1. - momentum) in double, then the tensor op rounds
   // the scalar to fp32 (quant_modules.py:217-219).
   const int threads = (!ext_min && partials) ? 256 : 64;
   quantact_update_kernel<<<1, threads, 0, st>>>(x_min, x_max, state, ext_min, ext_max, partials,
                                                 n_partials, bits, (float)(momentum - 1.0),
-                                                (float)(1.0 - momentum), running, relu);
+                                                (float)(1.0 - momentum), running, relu, state_copy);
 }
 }  // namespace cdn
 
@@ -292,9 +295,10 @@ extern "C" int cdn_quantact_forward(const float *x, float *out, int16_t *codes, 
 // (cdn_codenet_{scale,dw,pointwise}_forward_range): update + fake-quantisation, no range pass over x.
 extern "C" int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, float *x_min, float *x_max,
                                              void *state, const float *partials, int64_t n_partials, int bits,
-                                             double momentum, int running, void *stream) {
-  CDN_REQUIRE(x && out && x_min && x_max && state && partials, CDN_ERR_ARG, "null pointer");
-  CDN_REQUIRE(numel > 0 && n_partials > 0 && n_partials < (1ll << 31), CDN_ERR_ARG, "bad size");
+                                             double momentum, int running, void *state_copy, void *stream) {
+  CDN_REQUIRE(x_min && x_max && state && partials, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE((out == nullptr || (x != nullptr && numel > 0)) && n_partials > 0 && n_partials < (1ll << 31), CDN_ERR_ARG,
+              "bad size");
   CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(partials) & 7) == 0,
@@ -302,8 +306,8 @@ extern "C" int cdn_quantact_forward_partials(const float *x, float *out, int64_t
   hipStream_t st = cdn::as_stream(stream);
   unsigned *stt = static_cast<unsigned *>(state);
   cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, reinterpret_cast<const float2 *>(partials),
-                              (int)n_partials, bits, momentum, running, st);
-  fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, nullptr, (long)numel, stt);
+                              (int)n_partials, bits, momentum, running, st, 0, static_cast<unsigned *>(state_copy));
+  if (out) fake_quant_kernel<<<stream_grid(numel), 256, 0, st>>>(x, out, nullptr, (long)numel, stt);
   return cdn::check_launch("quantact forward (partials)");
 }
 

@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(256)
 pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
                  const float *__restrict__ bias, const float *__restrict__ ep_scale,
                  const float *__restrict__ ep_shift, float *__restrict__ Y, int C, int Co, int HW,
-                 int relu, float2 *__restrict__ mm) {
+                 int relu, float2 *__restrict__ mm, const unsigned *__restrict__ dq) {
   // K tiles of 32, the NEXT tile's global loads (4 x 16 B per thread) in flight behind the 16 MFMAs of the
   // current one: with one 16-deep tile and no prefetch every tile paid a full global-load latency (50 TF at
   // the stage-0 shape; the QAT step runs this kernel six times: forward and data gradient of three stages)
@@ -581,6 +581,14 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
   const bool hw4 = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(D) & 15) == 0;
   const bool c4 = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(Wp) & 15) == 0;
   float a[8], b[8];
+  // dq != NULL (training path): D holds PRE-quantisation values and is fake-quantised with that QuantAct state while
+  // loading -- the values a separate fake-quant pass would have stored (fq(0) = 0: padding stays zero)
+  float dqs = 1.f, dqz = 0.f, dqr = 1.f;
+  if (dq) {
+    dqs = reinterpret_cast<const float *>(dq)[2];
+    dqz = reinterpret_cast<const float *>(dq)[3];
+    dqr = __fdiv_rn(1.0f, dqs);
+  }
   auto load = [&](int k0) {
     const int m = m0 + am;
 #pragma unroll
@@ -604,6 +612,10 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[4 * h + q] = (k < C && p + q < HW) ? Dn[(long)k * HW + p + q] : 0.0f;
       }
+    }
+    if (dq) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = cdn::fake_quant_r(b[q], dqs, dqz, dqr);
     }
   };
   load(0);
@@ -729,7 +741,7 @@ extern "C" int cdn_codenet_dw_forward_range(const float *x, const float *s, cons
 
 static int pointwise_forward_impl(const float *d, const float *w_pw, const float *bias, const float *ep_scale,
                                   const float *ep_shift, float *y, int64_t N, int64_t C, int64_t Co, int64_t HW,
-                                  int relu, float *partials, void *stream) {
+                                  int relu, float *partials, void *stream, const void *d_state = nullptr) {
   CDN_REQUIRE(d && w_pw && y, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,
               "ep_scale and ep_shift must both be set or both be NULL");
@@ -739,7 +751,8 @@ static int pointwise_forward_impl(const float *d, const float *w_pw, const float
   dim3 grid((unsigned)cdn::ceil_div(HW, kPwBN), (unsigned)cdn::ceil_div(Co, kPwBM), (unsigned)N);
   pointwise_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(d, w_pw, bias, ep_scale, ep_shift, y,
                                                              (int)C, (int)Co, (int)HW, relu,
-                                                             reinterpret_cast<float2 *>(partials));
+                                                             reinterpret_cast<float2 *>(partials),
+                                                             static_cast<const unsigned *>(d_state));
   return cdn::check_launch("codenet pointwise forward");
 }
 
@@ -754,12 +767,12 @@ extern "C" int64_t cdn_codenet_pointwise_range_partials(int64_t N, int64_t Co, i
   return (N > 0 && Co > 0 && HW > 0) ? cdn::ceil_div(HW, kPwBN) * cdn::ceil_div(Co, kPwBM) * N : 0;
 }
 
-extern "C" int cdn_codenet_pointwise_forward_range(const float *d, const float *w_pw, const float *bias,
-                                                   const float *ep_scale, const float *ep_shift, float *y, int64_t N,
-                                                   int64_t C, int64_t Co, int64_t HW, int relu, float *partials,
-                                                   void *stream) {
-  CDN_REQUIRE(partials, CDN_ERR_ARG, "null partials pointer");
-  return pointwise_forward_impl(d, w_pw, bias, ep_scale, ep_shift, y, N, C, Co, HW, relu, partials, stream);
+extern "C" int cdn_codenet_pointwise_forward_range(const float *d, const void *d_state, const float *w_pw,
+                                                   const float *bias, const float *ep_scale, const float *ep_shift,
+                                                   float *y, int64_t N, int64_t C, int64_t Co, int64_t HW, int relu,
+                                                   float *partials, void *stream) {
+  CDN_REQUIRE(partials || d_state, CDN_ERR_ARG, "neither partials nor d_state: use cdn_codenet_pointwise_forward");
+  return pointwise_forward_impl(d, w_pw, bias, ep_scale, ep_shift, y, N, C, Co, HW, relu, partials, stream, d_state);
 }
 
 extern "C" int cdn_codenet_dw_backward_supported(int64_t H, int64_t W) {

@@ -30,7 +30,7 @@ constexpr int kWgBM = 64, kWgBN = 64, kWgBK = 64, kWgLd = kWgBK + 4;
 __global__ void __launch_bounds__(256)
 pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float *__restrict__ partial,
                 float *__restrict__ partial_b, int C, int Co, int HW, int chunks_per_img, int nchunks,
-                int chunks_per_slice) {
+                int chunks_per_slice, const unsigned *__restrict__ dq) {
   __shared__ __attribute__((aligned(16))) float As[kWgBM][kWgLd];
   __shared__ __attribute__((aligned(16))) float Bs[kWgBN][kWgLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,6 +44,12 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
   // bias gradient = row sums of grad_y: taken by the workgroups of channel tile 0 from the A tiles as they pass
   // through registers (a separate one-workgroup-per-channel kernel took 175 us per step)
   const bool do_bias = partial_b != nullptr && blockIdx.x == 0;
+  float dqs = 1.f, dqz = 0.f, dqr = 1.f;
+  if (dq) {
+    dqs = reinterpret_cast<const float *>(dq)[2];
+    dqz = reinterpret_cast<const float *>(dq)[3];
+    dqr = __fdiv_rn(1.0f, dqs);
+  }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   auto load = [&](int ch) {
     const int n = ch / chunks_per_img, p0 = (ch - n * chunks_per_img) * kWgBK;
@@ -64,6 +70,10 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
         }
         ra[i] = make_float4(a[0], a[1], a[2], a[3]);
         rb[i] = make_float4(b[0], b[1], b[2], b[3]);
+      }
+      if (dq) {      // d holds pre-quantisation values: fake-quantised with its QuantAct state while loading
+        rb[i].x = cdn::fake_quant_r(rb[i].x, dqs, dqz, dqr); rb[i].y = cdn::fake_quant_r(rb[i].y, dqs, dqz, dqr);
+        rb[i].z = cdn::fake_quant_r(rb[i].z, dqs, dqz, dqr); rb[i].w = cdn::fake_quant_r(rb[i].w, dqs, dqz, dqr);
       }
     }
   };
@@ -231,9 +241,9 @@ extern "C" size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t
   return ((size_t)p.nz * (size_t)Co * (size_t)(C + 1) * 4 + 255) / 256 * 256;   // weight tiles + bias rows
 }
 
-extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b,
-                                           int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace,
-                                           size_t workspace_bytes, void *stream) {
+static int pointwise_wgrad_impl(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
+                                int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
+                                void *stream) {
   CDN_REQUIRE(grad_y && d && grad_w && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && HW > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N * C * HW < (1ll << 31) && N * Co * HW < (1ll << 31) && C * Co < (1ll << 31),
@@ -249,7 +259,8 @@ extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, 
   float *partial = static_cast<float *>(workspace);
   float *partial_b = grad_b ? partial + (size_t)p.nz * Co * C : nullptr;
   pw_wgrad_kernel<<<dim3((unsigned)p.tiles_c, (unsigned)p.tiles_m, (unsigned)p.nz), 256, 0, st>>>(
-      grad_y, d, partial, partial_b, (int)C, (int)Co, (int)HW, p.chunks_per_img, p.nchunks, p.per_slice);
+      grad_y, d, partial, partial_b, (int)C, (int)Co, (int)HW, p.chunks_per_img, p.nchunks, p.per_slice,
+      static_cast<const unsigned *>(d_state));
   int rc = cdn::check_launch("codenet pointwise weight gradient");
   if (rc) return rc;
   const long n = (long)(Co * C);
@@ -261,6 +272,19 @@ extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, 
     rc = cdn::check_launch("codenet pointwise bias gradient reduce");
   }
   return rc;
+}
+
+extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b,
+                                           int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+  return pointwise_wgrad_impl(grad_y, d, nullptr, grad_w, grad_b, N, C, Co, HW, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d, const void *d_state, float *grad_w,
+                                             float *grad_b, int64_t N, int64_t C, int64_t Co, int64_t HW,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+  CDN_REQUIRE(d_state, CDN_ERR_ARG, "null pointer");
+  return pointwise_wgrad_impl(grad_y, d, d_state, grad_w, grad_b, N, C, Co, HW, workspace, workspace_bytes, stream);
 }
 
 static int scale_backward_impl(const float *x, const float *grad_s, const float *s_clamped, float lo, float hi,

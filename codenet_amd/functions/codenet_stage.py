@@ -41,8 +41,9 @@ def _workspace(nbytes, device):
     return ws
 
 
-def pointwise_wgrad(grad_y, d, want_bias):
-    """(grad_w [Co, C], grad_b [Co] or None) of y = conv1x1(d, w) + b; grad_y [N,Co,H,W], d [N,C,H,W]."""
+def pointwise_wgrad(grad_y, d, want_bias, d_state=None):
+    """(grad_w [Co, C], grad_b [Co] or None) of y = conv1x1(d, w) + b; grad_y [N,Co,H,W], d [N,C,H,W].  d_state: d holds
+    pre-quantisation values, fake-quantised on load with that (snapshot of a) QuantAct state."""
     Nb, Co, H, W = grad_y.shape
     C = d.shape[1]
     lib = N_.lib()
@@ -50,10 +51,20 @@ def pointwise_wgrad(grad_y, d, want_bias):
     ws = _workspace(need, grad_y.device)
     gw = torch.empty(Co, C, device=grad_y.device)
     gb = torch.empty(Co, device=grad_y.device) if want_bias else None
+    if d_state is not None:
+        rc = lib.cdn_codenet_pointwise_wgrad_q(_p(grad_y), _p(d), _p(d_state), _p(gw), _p(gb), Nb, C, Co, H * W, _p(ws),
+                                               ws.numel() * 4, ops._stream(grad_y))
+        N_.check(rc, "cdn_codenet_pointwise_wgrad_q")
+        return gw, gb
     rc = lib.cdn_codenet_pointwise_wgrad(_p(grad_y), _p(d), _p(gw), _p(gb), Nb, C, Co, H * W, _p(ws),
                                          ws.numel() * 4, ops._stream(grad_y))
     N_.check(rc, "cdn_codenet_pointwise_wgrad")
     return gw, gb
+
+
+# A/B switch (tools/train_step_bench.py --no-fuse-dq): d fake-quantised by its consumers while loading (True) or stored
+# fake-quantised by a pass of its own (False).  Same values either way.
+FUSE_DQ_ON_LOAD = True
 
 
 class CodenetStageFunction(Function):
@@ -73,22 +84,29 @@ class CodenetStageFunction(Function):
         else:
             s_c = ops.codenet_scale(x, w_scale, b_scale, lo, hi)
             s = _native_quantact(act_s, s_c) if act_s is not None else s_c
+        have_pw = w_pw is not None
+        d_snap = None          # snapshot of act_d's state when d stays un-quantised in memory (quantised by its consumers)
         with torch.no_grad():
-            if act_d is not None and act_d.running_stat:
+            if act_d is not None and act_d.running_stat and have_pw and FUSE_DQ_ON_LOAD:
+                # the gather leaves its {min, max} pairs, the QuantAct only updates, the pointwise kernel (and, in the
+                # backward, the weight-gradient kernel) fake-quantise d while loading it: d_q is never stored
+                d, dp = ops.codenet_dw_range(x, s, w_dw)
+                d_snap = ops.quantact_forward_partials(d, act_d, dp, want_out=False, want_state_copy=True)
+                d_q = d
+            elif act_d is not None and act_d.running_stat:
                 d, dp = ops.codenet_dw_range(x, s, w_dw)
                 d_q = ops.quantact_forward_partials(d, act_d, dp)
             else:
                 d = ops.codenet_dw(x, s, w_dw.contiguous())
                 d_q = _native_quantact(act_d, d) if act_d is not None else d
-        have_pw = w_pw is not None
         yp = None
         if have_pw and want_range:
-            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True)
+            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap)
         else:
-            y = ops.codenet_pointwise(d_q, w_pw, b_pw) if have_pw else d_q
+            y = ops.codenet_pointwise(d_q, w_pw, b_pw, d_state=d_snap) if have_pw else d_q
         ctx.lo, ctx.hi, ctx.have_pw = float(lo), float(hi), have_pw
         ctx.has_b_scale, ctx.has_b_pw = b_scale is not None, b_pw is not None
-        ctx.save_for_backward(x, s_c, s, w_scale, w_dw, d_q if have_pw else None, w_pw)
+        ctx.save_for_backward(x, s_c, s, w_scale, w_dw, d_q if have_pw else None, w_pw, d_snap)
         if want_range:
             if yp is None:
                 yp = y.new_zeros(0, 2)
@@ -99,7 +117,7 @@ class CodenetStageFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, *unused):
-        x, s_c, s, w_scale, w_dw, d_q, w_pw = ctx.saved_tensors
+        x, s_c, s, w_scale, w_dw, d_q, w_pw, d_snap = ctx.saved_tensors
         need = ctx.needs_input_grad
         gy = gy.contiguous()
         Nb, C, H, W = x.shape
@@ -108,7 +126,7 @@ class CodenetStageFunction(Function):
         if ctx.have_pw:
             Co = w_pw.shape[0]
             if need[4] or (need[5] and ctx.has_b_pw):
-                gw2, g_bpw = pointwise_wgrad(gy, d_q, need[5] and ctx.has_b_pw)
+                gw2, g_bpw = pointwise_wgrad(gy, d_q, need[5] and ctx.has_b_pw, d_state=d_snap)
                 g_wpw = gw2.view_as(w_pw) if need[4] else None
             # data gradient: the same contraction with the transposed weights
             gd = ops.codenet_pointwise(gy, w_pw.reshape(Co, C).t().contiguous().view(C, Co, 1, 1))

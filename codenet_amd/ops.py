@@ -109,16 +109,21 @@ def codenet_dw_range(x, s, w_dw):
     return d, part
 
 
-def quantact_forward_partials(x, act, partials):
+def quantact_forward_partials(x, act, partials, want_out=True, want_state_copy=False):
     """QuantAct.forward on the device with the batch extremes from the producer's {min, max} pairs: range update in
-    place + fake-quantisation, no pass over x for the range."""
+    place + fake-quantisation, no pass over x for the range.  want_out=False: only the update (the consumer
+    fake-quantises while loading); want_state_copy: also a snapshot of the device state (for the backward pass).
+    Returns out / (out, state_copy) / state_copy."""
     x = x.contiguous()
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if want_out else None
+    snap = torch.zeros(8, dtype=torch.int32, device=x.device) if want_state_copy else None
     rc = N_.lib().cdn_quantact_forward_partials(_p(x), _p(out), x.numel(), _p(act.x_min), _p(act.x_max),
                                                 _p(act._device_state(x.device)), _p(partials), partials.shape[0],
-                                                int(act.activation_bit), float(act.momentum), 1, _stream(x))
+                                                int(act.activation_bit), float(act.momentum), 1, _p(snap), _stream(x))
     N_.check(rc, "cdn_quantact_forward_partials")
-    return out
+    if want_out and want_state_copy:
+        return out, snap
+    return out if want_out else snap
 
 
 class _CodenetDW(Function):
@@ -179,9 +184,10 @@ def _dw_backward_generic(x, s, w_dw, gd, needs):
 codenet_dw = _CodenetDW.apply
 
 
-def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False):
+def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False, d_state=None):
     """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA.  want_range: also the per-workgroup
-    {min, max} pairs of y."""
+    {min, max} pairs of y.  d_state (8-word QuantAct state tensor): d holds pre-quantisation values, fake-quantised
+    with that state while the kernel loads them."""
     _gpu_f32(d, w_pw, bias, ep_scale, ep_shift)
     d = d.contiguous()
     Nb, C, H, W = d.shape
@@ -191,15 +197,16 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
     Co = w.size(0)
     y = d.new_empty(Nb, Co, H, W)
     rec = _tic("pointwise", (C, H, W))
-    args = (_p(d), _p(w), _p(bias.contiguous() if bias is not None else None),
+    tail = (_p(w), _p(bias.contiguous() if bias is not None else None),
             _p(ep_scale.contiguous() if ep_scale is not None else None),
             _p(ep_shift.contiguous() if ep_shift is not None else None), _p(y), Nb, C, Co, H * W, int(bool(relu)))
-    if want_range:
-        part = _partials(N_.lib().cdn_codenet_pointwise_range_partials(Nb, Co, H * W), d)
-        rc = N_.lib().cdn_codenet_pointwise_forward_range(*args, _p(part), _stream(d))
+    if want_range or d_state is not None:
+        part = _partials(N_.lib().cdn_codenet_pointwise_range_partials(Nb, Co, H * W), d) if want_range else None
+        rc = N_.lib().cdn_codenet_pointwise_forward_range(_p(d), _p(d_state), *tail, _p(part), _stream(d))
         _toc(rec)
         N_.check(rc, "cdn_codenet_pointwise_forward_range")
-        return y, part
+        return (y, part) if want_range else y
+    args = (_p(d),) + tail
     rc = N_.lib().cdn_codenet_pointwise_forward(*args, _stream(d))
     _toc(rec)
     N_.check(rc, "cdn_codenet_pointwise_forward")

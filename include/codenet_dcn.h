@@ -182,11 +182,20 @@ int64_t cdn_codenet_dw_range_partials(int64_t N, int64_t C, int64_t H, int64_t W
 int cdn_codenet_dw_forward_range(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
                                  int64_t H, int64_t W, float *partials, void *stream);
 int64_t cdn_codenet_pointwise_range_partials(int64_t N, int64_t Co, int64_t HW);
-int cdn_codenet_pointwise_forward_range(const float *d, const float *w_pw, const float *bias, const float *ep_scale,
-                                        const float *ep_shift, float *y, int64_t N, int64_t C, int64_t Co, int64_t HW,
-                                        int relu, float *partials, void *stream);
+int cdn_codenet_pointwise_forward_range(const float *d, const void *d_state, const float *w_pw, const float *bias,
+                                        const float *ep_scale, const float *ep_shift, float *y, int64_t N, int64_t C,
+                                        int64_t Co, int64_t HW, int relu, float *partials, void *stream);
+/* (d_state != NULL: d holds PRE-quantisation values and is fake-quantised with that QuantAct state while the kernel loads
+ * it -- the values a separate cdn_quantact_forward pass would have stored; partials may then be NULL.)
+ * cdn_quantact_forward_partials: out may be NULL (range update + parameters only: the consumer quantises on load);
+ * state_copy (8 words, may be NULL) receives a snapshot of the state for consumers that outlive the QuantAct's next
+ * call -- cdn_codenet_pointwise_wgrad_q in the backward pass. */
 int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, float *x_min, float *x_max, void *state,
                                   const float *partials, int64_t n_partials, int bits, double momentum, int running,
+                                  void *state_copy, void *stream);
+/* cdn_codenet_pointwise_wgrad with d given as pre-quantisation values + the state that quantised them in the forward */
+int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
+                                  int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
                                   void *stream);
 int cdn_quantact_relu_up2_forward_partials(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
                                            float *x_min, float *x_max, void *state, const float *partials,

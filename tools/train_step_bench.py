@@ -26,7 +26,12 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture forward + backward + optimizer step in one HIP graph")
     ap.add_argument("--foreach-adam", action="store_true",
                     help="torch.optim.Adam's default multi-tensor form (8 launches per step) instead of fused=True (1)")
+    ap.add_argument("--no-fuse-dq", action="store_true", help="A/B: store the fake-quantised gather output instead of "
+                    "quantising it in the consumers' loads")
     a = ap.parse_args()
+    if a.no_fuse_dq:
+        from codenet_amd.functions import codenet_stage as _cs
+        _cs.FUSE_DQ_ON_LOAD = False
     net = pipeline.build_hot_path(quantized=not a.fp32).cuda().train()
     for m in net.modules():                      # BN inside QuantBnConv2d is never called; plain BN in fp32
         if isinstance(m, torch.nn.BatchNorm2d):
