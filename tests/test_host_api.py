@@ -364,3 +364,41 @@ def test_argument_validation_of_round2_entry_points_without_gpu():
     # decode: heat_out partially overlapping heat is an argument error
     rc = lib.cdn_ctdet_decode(one * 64, one, None, 1, 2, 8, 8, 0, 10, 1, one * 64 + 64, one, one * 64, 1 << 20, None)
     assert rc == -1 and b"overlaps" in lib.cdn_last_error()
+
+
+def test_cover_frozen_ranges_only_widens_and_restores_the_running_flags():
+    """pipeline.cover_frozen_ranges (the calibration step of the byte-code serving mode): every QuantAct range ends up
+    covering what the frozen network feeds it (+ margin), never narrower than before; running_stat flags are restored;
+    a shared QuantAct (called more than once per forward) covers the extremes of all its inputs."""
+    import torch.nn as nn
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.shared = QuantAct(8), QuantAct(8)
+
+        def forward(self, x):
+            y = self.a(x)
+            return self.shared(y * 3.0) + self.shared(y - 5.0)      # one QuantAct, two different tensors
+
+    net = Net()
+    x = torch.linspace(-1.0, 2.0, 64).reshape(1, 1, 8, 8)
+    net(x)                                                   # running update: ranges initialised from this batch
+    net.a.x_min.fill_(-0.5); net.a.x_max.fill_(1.0)          # too narrow on both sides
+    net.shared.x_min.fill_(-100.0); net.shared.x_max.fill_(0.5)   # wide below (must stay), narrow above
+    flags = [a.running_stat for a in (net.a, net.shared)]
+    moved = pipeline.cover_frozen_ranges(net, [x], margin=0.05, passes=3)
+    assert moved == 2 and [a.running_stat for a in (net.a, net.shared)] == flags
+    assert net.a.x_min.item() <= -1.0 and net.a.x_max.item() >= 2.0
+    assert net.shared.x_min.item() == -100.0                 # never narrowed
+    with torch.no_grad():
+        pipeline.set_running_stat(net, False)
+        y = net.a(x)
+        assert net.shared.x_max.item() >= (y * 3.0).max().item() and net.shared.x_min.item() <= (y - 5.0).min().item()
+    # a second call changes nothing
+    before = [t.clone() for t in (net.a.x_min, net.a.x_max, net.shared.x_min, net.shared.x_max)]
+    pipeline.set_running_stat(net, True)
+    assert pipeline.cover_frozen_ranges(net, [x], margin=0.0) == 0
+    assert all(torch.equal(p, q) for p, q in zip(before, (net.a.x_min, net.a.x_max, net.shared.x_min, net.shared.x_max)))
