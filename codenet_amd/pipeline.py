@@ -1559,11 +1559,12 @@ class FrozenBackbone:
     accumulates exact products in fp32 (pwd3_kernel), so results agree with FusedBackbone at running_stat False up
     to single code flips (tests/test_gpu_backbone.py).  A saturated code sets the overflow flag (``overflowed()``)."""
 
-    def __init__(self, model, fuse_dwpw=True):
+    def __init__(self, model, fuse_dwpw=True, two_streams=True):
         self.model = model
         self._fb = FusedBackbone(model)
         self._bufs = None
         self.fuse_dwpw = fuse_dwpw          # a unit's depthwise inside its second 1x1 conv (cdn_codenet_dwpw_q8_forward)
+        self.two_streams = two_streams      # the two branches of a stride-2 unit on two streams
 
     @staticmethod
     def supported(model):
@@ -1633,23 +1634,24 @@ class FrozenBackbone:
         if L is None:
             z = lambda m_, c_: torch.zeros(m_, c_, dtype=torch.int8, device=dev)   # noqa: E731
             L = B["layers"][name] = dict(Y=z(Mo, ldc), t4=z(Mo, ldi), t1s2=z(Mi, ldh), t1=z(Mo, ldh), t2=z(Mo, ldh))
-        of, st = B["overflow"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream
+        main = torch.cuda.current_stream(dev)
+        of, st = B["overflow"].data_ptr(), main.cuda_stream
         qp = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
 
-        def pw(a, a_state, M, K, lda, Wt, act, out, ldo, omap):
+        def pw(a, a_state, M, K, lda, Wt, act, out, ldo, omap, st=st):
             rc = lib.cdn_codenet_pointwise_q8_strided_forward(
                 a.data_ptr(), a_state, M, K, Wt["Co"], lda, ldo, Wt["codes"].data_ptr(), Wt["scale"].data_ptr(),
                 Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), 1, omap, qp(act), out.data_ptr(), None, of, st)
             N_.check(rc, "cdn_codenet_pointwise_q8_strided_forward")
 
-        def dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, out, ld_out):
+        def dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, out, ld_out, st=st):
             rc = lib.cdn_codenet_dw3x3_q8_forward(a.data_ptr(), a_state, Nb, Cc, Hs, Ws, stride, ld_in, ld_out,
                                                   w.data_ptr(), b.data_ptr(), 0, qp(act), out.data_ptr(), of, st)
             N_.check(rc, "cdn_codenet_dw3x3_q8_forward")
 
-        def dwpw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, Wt, out_act, omap):
+        def dwpw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, Wt, out_act, omap, tmp=None, st=st):
             """depthwise (output codes of `act`) -> 1x1 conv -> ReLU -> codes of out_act into Y's slots: one launch
-            where cdn_codenet_dwpw_q8_supported, else the two kernels through the scratch tensor"""
+            where cdn_codenet_dwpw_q8_supported, else the two kernels through the scratch tensor `tmp`"""
             if self.fuse_dwpw and lib.cdn_codenet_dwpw_q8_supported(Cc, Hs, Ws, stride, Wt["Co"]):
                 rc = lib.cdn_codenet_dwpw_q8_forward(
                     a.data_ptr(), a_state, Nb, Cc, Hs, Ws, stride, ld_in, w.data_ptr(), b.data_ptr(), 0, qp(act),
@@ -1657,22 +1659,33 @@ class FrozenBackbone:
                     Wt["bias"].data_ptr(), 1, ldc, omap, qp(out_act), Y.data_ptr(), of, st)
                 N_.check(rc, "cdn_codenet_dwpw_q8_forward")
                 return
-            tmp = L["t4"] if Cc == cin and stride == 2 and a is x8 else L["t2"]
-            ldt = ldi if tmp is L["t4"] else ldh
-            dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, tmp, ldt)
-            pw(tmp, qp(act), Mo, Cc, ldt, Wt, out_act, Y, ldc, omap)
+            tmp = L["t2"] if tmp is None else tmp
+            ldt = tmp.shape[1]
+            dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, tmp, ldt, st=st)
+            pw(tmp, qp(act), Mo, Cc, ldt, Wt, out_act, Y, ldc, omap, st=st)
 
         Y = L["Y"]
         with torch.no_grad():
             for k, (u, P) in enumerate(zip(units, plan["units"])):
                 sh = u["sh"]
                 if k == 0:
+                    # the two branches of a stride-2 unit read the same input and write disjoint slots of Y: branch 1
+                    # on a side stream (these launches leave most of the chip idle on their own)
+                    side = None
+                    if self.two_streams:
+                        side = B.get("side")
+                        if side is None:
+                            side = B["side"] = torch.cuda.Stream(dev)
+                        side.wait_stream(main)
                     # branch 1: dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct (slots omapA)
-                    dwpw(x8, x_state, cin, H, W, 2, x_ld, P["w4"], P["b4"], u["a4"], P["c5"], sh, P["omapA"].data_ptr())
+                    dwpw(x8, x_state, cin, H, W, 2, x_ld, P["w4"], P["b4"], u["a4"], P["c5"], sh, P["omapA"].data_ptr(),
+                         tmp=L["t4"], st=side.cuda_stream if side is not None else st)
                     # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct (omapB)
                     pw(x8, x_state, Mi, cin, x_ld, P["c1"], u["a1"], L["t1s2"], ldh, None)
                     dwpw(L["t1s2"], qp(u["a1"]), h, H, W, 2, ldh, P["w2"], P["b2"], u["a2"], P["c3"], sh,
                          P["omapB"].data_ptr())
+                    if side is not None:
+                        main.wait_stream(side)
                 else:
                     pw(Y, qp(sh), Mo, C, ldc, P["c1"], u["a1"], L["t1"], ldh, None)
                     dwpw(L["t1"], qp(u["a1"]), h, Ho, Wo, 1, ldh, P["w2"], P["b2"], u["a2"], P["c3"], sh,
