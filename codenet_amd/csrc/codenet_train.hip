@@ -336,11 +336,12 @@ namespace {
 // separate framework kernels (`n / t` = reciprocal * n: two roundings; true divisions; no FMA contraction), so wq and
 // b are BIT-IDENTICAL to the torch composition (tests/test_train_step.py).  One wave per output channel.
 // ------------------------------------------------------------------------------------------------------
+constexpr int kPctMax = 4;
 __global__ void __launch_bounds__(256)
 weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__restrict__ sf_in,
                    const float *__restrict__ bn_b, const float *__restrict__ bn_mean,
                    const float *__restrict__ conv_bias, float nlev, float *__restrict__ wq,
-                   float *__restrict__ b_out) {
+                   float *__restrict__ b_out, int k_low, int k_high, float shrink) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -358,16 +359,67 @@ weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__re
   }
   const float *wr = w + (long)co * K;
   float mn = INFINITY, mx = -INFINITY;
-  for (int k = lane; k < K; k += 64) {
-    const float v = fold ? wr[k] * sf : wr[k];
-    mn = fminf(mn, v);
-    mx = fmaxf(mx, v);
-  }
+  if (k_low <= 1 && k_high <= 1) {
+    for (int k = lane; k < K; k += 64) {
+      const float v = fold ? wr[k] * sf : wr[k];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
 #pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, m, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    for (int m = 32; m > 0; m >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, m, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    }
+  } else {
+    // --wt-percentile (quant_modules.py:287-300): the k_low-th smallest and the k_high-th largest value of the channel
+    // (torch.kthvalue counts duplicates).  k <= kPctMax: every lane keeps its kPctMax smallest / largest values sorted,
+    // then the wave pops the global extreme k times (the owner of the popped value advances to its next one).
+    float lo[kPctMax], hi[kPctMax];
+#pragma unroll
+    for (int i = 0; i < kPctMax; ++i) {
+      lo[i] = INFINITY;
+      hi[i] = -INFINITY;
+    }
+    for (int k = lane; k < K; k += 64) {
+      float v = fold ? wr[k] * sf : wr[k], u = v;
+#pragma unroll
+      for (int i = 0; i < kPctMax; ++i) {       // insertion into the ascending lo[] / descending hi[]
+        const float t = fminf(lo[i], v);
+        v = fmaxf(lo[i], v);
+        lo[i] = t;
+        const float t2 = fmaxf(hi[i], u);
+        u = fminf(hi[i], u);
+        hi[i] = t2;
+      }
+    }
+    for (int r = 0; r < k_low; ++r) {
+      float best = lo[0];
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) best = fminf(best, __shfl_xor(best, m, 64));
+      mn = best;
+      // ONE owner of this value advances (the lowest lane holding it: duplicates are separate elements)
+      const unsigned long long own = __ballot(lo[0] == best);
+      if (lane == __ffsll((long long)own) - 1) {
+#pragma unroll
+        for (int i = 0; i + 1 < kPctMax; ++i) lo[i] = lo[i + 1];
+        lo[kPctMax - 1] = INFINITY;
+      }
+    }
+    for (int r = 0; r < k_high; ++r) {
+      float best = hi[0];
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) best = fmaxf(best, __shfl_xor(best, m, 64));
+      mx = best;
+      const unsigned long long own = __ballot(hi[0] == best);
+      if (lane == __ffsll((long long)own) - 1) {
+#pragma unroll
+        for (int i = 0; i + 1 < kPctMax; ++i) hi[i] = hi[i + 1];
+        hi[kPctMax - 1] = -INFINITY;
+      }
+    }
   }
+  mn = mn * shrink;        // (0.95 for channels of < 10 weights under --wt-percentile, else 1: exact)
+  mx = mx * shrink;
   const float mag = fmaxf(fabsf(mn), fabsf(mx));
   const float rcp = __fdiv_rn(1.0f, fmaxf(mag, 1e-10f));
   const float scale = rcp * nlev;
@@ -429,18 +481,37 @@ extern "C" int cdn_codenet_weight_prep_backward(const float *grad_wq, const floa
   return cdn::check_launch("codenet weight prep backward");
 }
 
-extern "C" int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor,
-                                       const float *bn_bias, const float *bn_mean, const float *conv_bias, int bits,
-                                       float *w_q, float *bias_out, void *stream) {
+static int weight_prep_impl(const float *w, int64_t Co, int64_t K, const float *scale_factor, const float *bn_bias,
+                            const float *bn_mean, const float *conv_bias, int bits, int k_low, int k_high, float shrink,
+                            float *w_q, float *bias_out, void *stream) {
   CDN_REQUIRE(w && w_q, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(Co > 0 && K > 0 && Co * K < (1ll << 31), CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(bits >= 2 && bits <= 8, CDN_ERR_ARG, "bits must be in [2, 8]");
+  CDN_REQUIRE(k_low >= 1 && k_high >= 1 && k_low <= K && k_high <= K, CDN_ERR_ARG, "k_low / k_high must be in [1, K]");
+  CDN_REQUIRE(k_low <= kPctMax && k_high <= kPctMax, CDN_ERR_UNSUPPORTED,
+              "percentile ranks above %d are not implemented (channels of more than %d weights)", kPctMax,
+              kPctMax * 1000);
   const bool fold = scale_factor != nullptr;
   CDN_REQUIRE(!fold || (bn_bias && bn_mean && bias_out), CDN_ERR_ARG,
               "the BN fold needs scale_factor, bias, running_mean and bias_out together");
   hipStream_t st = cdn::as_stream(stream);
   const float nlev = (float)((1 << (bits - 1)) - 1);
   weight_prep_kernel<<<(unsigned)cdn::ceil_div(Co, 4), 256, 0, st>>>(w, (int)Co, (int)K, scale_factor, bn_bias, bn_mean,
-                                                                     conv_bias, nlev, w_q, bias_out);
+                                                                     conv_bias, nlev, w_q, bias_out, k_low, k_high,
+                                                                     shrink);
   return cdn::check_launch("codenet weight prep");
+}
+
+extern "C" int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor,
+                                       const float *bn_bias, const float *bn_mean, const float *conv_bias, int bits,
+                                       float *w_q, float *bias_out, void *stream) {
+  return weight_prep_impl(w, Co, K, scale_factor, bn_bias, bn_mean, conv_bias, bits, 1, 1, 1.0f, w_q, bias_out, stream);
+}
+
+extern "C" int cdn_codenet_weight_prep_ranked(const float *w, int64_t Co, int64_t K, const float *scale_factor,
+                                              const float *bn_bias, const float *bn_mean, const float *conv_bias,
+                                              int bits, int k_low, int k_high, float shrink, float *w_q,
+                                              float *bias_out, void *stream) {
+  return weight_prep_impl(w, Co, K, scale_factor, bn_bias, bn_mean, conv_bias, bits, k_low, k_high, shrink, w_q,
+                          bias_out, stream);
 }

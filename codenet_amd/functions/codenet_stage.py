@@ -196,18 +196,19 @@ class FakeQuantWeight(Function):
     the torch composition in portable_quantizer (min / max per channel, n / clamp(mag), round, clamp, true division)."""
 
     @staticmethod
-    def forward(ctx, w, bits):
+    def forward(ctx, w, bits, percentile=False):
         w = w.contiguous()
         out = torch.empty_like(w)
         co = w.shape[0]
-        rc = N_.lib().cdn_codenet_weight_prep(_p(w), co, w.numel() // co, None, None, None, None, int(bits),
-                                              _p(out), None, ops._stream(w))
-        N_.check(rc, "cdn_codenet_weight_prep")
+        k_lo, k_hi, shrink = weight_range_ranks(w.numel() // co, percentile)
+        rc = N_.lib().cdn_codenet_weight_prep_ranked(_p(w), co, w.numel() // co, None, None, None, None, int(bits),
+                                                     k_lo, k_hi, shrink, _p(out), None, ops._stream(w))
+        N_.check(rc, "cdn_codenet_weight_prep_ranked")
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, None          # (the reference clones; an identity backward needs no copy)
+        return g, None, None    # (the reference clones; an identity backward needs no copy)
 
 
 class FoldFakeQuantWeight(Function):
@@ -218,7 +219,7 @@ class FoldFakeQuantWeight(Function):
     grad_conv_bias = grad_b * sf."""
 
     @staticmethod
-    def forward(ctx, w, conv_bias, gamma, beta, mean, var, eps, bits):
+    def forward(ctx, w, conv_bias, gamma, beta, mean, var, eps, bits, percentile=False):
         w = w.contiguous()
         co = w.shape[0]
         wq = torch.empty_like(w)
@@ -227,11 +228,12 @@ class FoldFakeQuantWeight(Function):
         # rounded one; the factor must be the framework's bit for bit): two tiny ops, everything else is the kernel
         std = torch.sqrt(var + eps)
         sf = (gamma / std).contiguous()
-        rc = N_.lib().cdn_codenet_weight_prep(_p(w), co, w.numel() // co, _p(sf), _p(beta.contiguous()),
-                                              _p(mean.contiguous()),
-                                              _p(conv_bias.contiguous()) if conv_bias is not None else None, int(bits),
-                                              _p(wq), _p(b), ops._stream(w))
-        N_.check(rc, "cdn_codenet_weight_prep")
+        k_lo, k_hi, shrink = weight_range_ranks(w.numel() // co, percentile)
+        rc = N_.lib().cdn_codenet_weight_prep_ranked(
+            _p(w), co, w.numel() // co, _p(sf), _p(beta.contiguous()), _p(mean.contiguous()),
+            _p(conv_bias.contiguous()) if conv_bias is not None else None, int(bits), k_lo, k_hi, shrink, _p(wq), _p(b),
+            ops._stream(w))
+        N_.check(rc, "cdn_codenet_weight_prep_ranked")
         ctx.save_for_backward(w, sf, std, mean, conv_bias)
         ctx.has_cb = conv_bias is not None
         return wq, b
@@ -252,15 +254,32 @@ class FoldFakeQuantWeight(Function):
             _p(mean.contiguous()), _p(conv_bias.contiguous()) if ctx.has_cb else None, co, w.numel() // co, _p(g_w),
             _p(g_gamma), _p(g_beta), _p(g_cb), ops._stream(w))
         N_.check(rc, "cdn_codenet_weight_prep_backward")
-        return g_w, g_cb, g_gamma, g_beta, None, None, None, None
+        return g_w, g_cb, g_gamma, g_beta, None, None, None, None, None
+
+
+def weight_range_ranks(length, percentile):
+    """(k_low, k_high, shrink) of cdn_codenet_weight_prep_ranked for a channel of `length` weights: plain min / max, or
+    the reference's --wt-percentile rule (quant_modules.py:287-300; the expressions of portable_quantizer._channel_range)."""
+    import math
+    if not percentile:
+        return 1, 1, 1.0
+    if length < 10:
+        return 1, 1, 0.95
+    lo = math.ceil(length * 0.1 * 0.01)
+    hi = math.ceil(length * 99.9 * 0.01)
+    return lo, length - hi + 1, 1.0
 
 
 def native_weight_prep_ok(w, quantizer):
     """Training-time weight transformation on the device kernel: per-channel symmetric fake-quantisation with plain
-    min / max ranges (the configuration of the README's W4A8 commands without --wt-percentile)."""
-    return (w.is_cuda and w.dtype == torch.float32 and torch.is_grad_enabled() and quantizer.per_channel
-            and quantizer.quant_mode == "symmetric" and not quantizer.weight_percentile
-            and not quantizer.full_precision_flag and not quantizer.quantize_bias)
+    min / max ranges or the --wt-percentile ranges of the README's QAT command (ranks up to 4: channels of up to 4000
+    weights)."""
+    if not (w.is_cuda and w.dtype == torch.float32 and torch.is_grad_enabled() and quantizer.per_channel
+            and quantizer.quant_mode == "symmetric" and not quantizer.full_precision_flag
+            and not quantizer.quantize_bias):
+        return False
+    k_lo, k_hi, _ = weight_range_ranks(w.numel() // w.shape[0], quantizer.weight_percentile)
+    return k_lo <= 4 and k_hi <= 4
 
 
 class ReluQuantUpsample(Function):

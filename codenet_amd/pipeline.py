@@ -49,7 +49,7 @@ class DeconvLayers(nn.Module):
         return forward_stage_blocks(self.deconv_layers, x)      # (== self.deconv_layers(x); fused blocks in the QAT step)
 
 
-def build_hot_path(w2=False, quantized=True, seed=317, scale_std=3.0, planes=None):
+def build_hot_path(w2=False, quantized=True, seed=317, scale_std=3.0, planes=None, wt_percentile=False):
     """Seeded synthetic weights: reference initialisers, except a non-degenerate
     conv_scale (weight ~ N(0, scale_std/sqrt(C)), bias 1 => s ~ N(1, scale_std) on unit-power inputs,
     clipped to [-7, 8] with ~1 % of pixels at each clamp) and non-trivial BN running statistics."""
@@ -70,7 +70,8 @@ def build_hot_path(w2=False, quantized=True, seed=317, scale_std=3.0, planes=Non
                 m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
                 m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
     if quantized:
-        quantize_deform_stages(net, 4, 8, "symmetric", "asymmetric", True, False, False)
+        # (the README's QAT command passes --wt-percentile, its test commands do not: README.md:87-116)
+        quantize_deform_stages(net, 4, 8, "symmetric", "asymmetric", True, bool(wt_percentile), False)
     return net.eval()
 
 

@@ -91,7 +91,7 @@ class _WeightQuantizer:
             return w
         from ..functions import codenet_stage as CS
         if CS.native_weight_prep_ok(w, self):      # QAT step on the GPU: one launch, bit-identical values
-            return CS.FakeQuantWeight.apply(w, self.weight_bit)
+            return CS.FakeQuantWeight.apply(w, self.weight_bit, bool(self.weight_percentile))
         if self.per_channel:
             if self.quantize_bias:
                 raise NotImplementedError("channel-wise quantize bias is not supported")
@@ -313,7 +313,7 @@ class QuantBnConv2d(Module, _WeightQuantizer):
             if CS.native_weight_prep_ok(self.conv.weight, self):      # QAT step on the GPU: fold + quantiser fused
                 return CS.FoldFakeQuantWeight.apply(self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
                                                     self.bn.running_mean, self.bn.running_var, self.bn.eps,
-                                                    self.weight_bit)
+                                                    self.weight_bit, bool(self.weight_percentile))
             running_std = torch.sqrt(self.bn.running_var + self.bn.eps)
             scale_factor = self.bn.weight / running_std
             w = self.conv.weight * scale_factor.reshape([self.conv.out_channels, 1, 1, 1])

@@ -200,6 +200,15 @@ int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d, const voi
 int cdn_quantact_relu_up2_forward_partials(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
                                            float *x_min, float *x_max, void *state, const float *partials,
                                            int64_t n_partials, int bits, double momentum, int running, void *stream);
+/* The same with the reference's --wt-percentile ranges (quant_modules.py:287-300): per output channel the range is
+ * [k_low-th smallest, k_high-th largest] * shrink instead of [min, max] -- the caller passes
+ *   K < 10 (every depthwise 3x3):  k_low = k_high = 1, shrink = 0.95f
+ *   else:  k_low = ceil(K * 0.1 * 0.01), k_high = K - ceil(K * 99.9 * 0.01) + 1, shrink = 1   (torch.kthvalue ranks)
+ * (k_low = k_high = 1, shrink = 1: exactly cdn_codenet_weight_prep).  Ranks up to 4 (channels of up to 4000 weights);
+ * CDN_ERR_UNSUPPORTED beyond. */
+int cdn_codenet_weight_prep_ranked(const float *w, int64_t Co, int64_t K, const float *scale_factor, const float *bn_bias,
+                                   const float *bn_mean, const float *conv_bias, int bits, int k_low, int k_high,
+                                   float shrink, float *w_q, float *bias_out, void *stream);
 /* Backward of the BN fold of cdn_codenet_weight_prep under the straight-through weight quantiser
  * (SymmetricQuantFunction.backward, quant_utils.py:227-229; autograd of quant_modules.py:365-372) in one launch:
  *   grad_w = grad_wq * scale_factor,  grad_gamma = (sum_k grad_wq * w + grad_bias * (conv_bias - mean)) / bn_std,

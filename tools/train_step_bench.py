@@ -26,13 +26,21 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture forward + backward + optimizer step in one HIP graph")
     ap.add_argument("--foreach-adam", action="store_true",
                     help="torch.optim.Adam's default multi-tensor form (8 launches per step) instead of fused=True (1)")
+    ap.add_argument("--wt-percentile", action="store_true",
+                    help="weight ranges of the README's QAT command (quant_main.py --wt-percentile: 0.1 / 99.9 percentile "
+                         "k-th values per output channel, 0.95 x min / max for depthwise channels)")
+    ap.add_argument("--torch-weight-prep", action="store_true",
+                    help="A/B: the weight transformation as the torch composition (kthvalue with --wt-percentile)")
     ap.add_argument("--no-fuse-dq", action="store_true", help="A/B: store the fake-quantised gather output instead of "
                     "quantising it in the consumers' loads")
     a = ap.parse_args()
+    if a.torch_weight_prep:
+        from codenet_amd.functions import codenet_stage as _cs0
+        _cs0.native_weight_prep_ok = lambda *args, **kw: False
     if a.no_fuse_dq:
         from codenet_amd.functions import codenet_stage as _cs
         _cs.FUSE_DQ_ON_LOAD = False
-    net = pipeline.build_hot_path(quantized=not a.fp32).cuda().train()
+    net = pipeline.build_hot_path(quantized=not a.fp32, wt_percentile=a.wt_percentile).cuda().train()
     for m in net.modules():                      # BN inside QuantBnConv2d is never called; plain BN in fp32
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eval()
@@ -90,7 +98,8 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     out = {"config": "CoDeNet1x %dx%d %s QAT step over deconv_layers, batch %d" % (
-        a.res, a.res, "fp32" if a.fp32 else "W4A8", a.batch) + (", one HIP graph" if a.graph else ", eager launches"),
+        a.res, a.res, "fp32" if a.fp32 else ("W4A8 --wt-percentile" if a.wt_percentile else "W4A8"), a.batch)
+        + (", one HIP graph" if a.graph else ", eager launches"),
         "ms_per_step": round(dt * 1e3, 3),
         "images_per_s": round(a.batch / dt, 1), "probe": float(loss)}
     out["roofline_dw_bwd2"] = dw_bwd2_roofline(a.batch, a.res)
