@@ -98,6 +98,7 @@ _SIGNATURES = {
     "cdn_codenet_stem_forward": (
         _i, [_vp] + [_i64] * 4 + [_i] + [_vp, _vp, _i] + [_vp] * 3 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_ctdet_decode_workspace_bytes": (ctypes.c_size_t, [_i64] * 4),
+    "cdn_ctdet_flip_merge": (_i, [_vp, _vp] + [_i64] * 5 + [_vp, _vp, _vp]),
     "cdn_ctdet_decode": (_i, [_vp] * 3 + [_i64] * 4 + [_i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "cdn_profile_enable": (_i, [_i]),
     "cdn_profile_read": (_i, [_i, _vp, _vp, _vp]),

@@ -158,6 +158,33 @@ __global__ void __launch_bounds__(256) sigmoid_store_kernel(const float *in, flo
   }
 }
 
+// Test-time flip augmentation (lib/detectors/ctdet.py:32-38 with opt.flip_test; every test command of the reference's
+// README passes --flip_test): the network ran on [image, its W-mirror];
+//   hm.sigmoid_() in place;  hm' = (hm[0] + flip_W(hm[1])) / 2,   wh' = (wh[0] + flip_W(wh[1])) / 2,   reg' = reg[0]
+// in one launch (the reference: sigmoid_, two flips, two adds, two divisions).  P pairs: originals 0 .. P-1, mirrors
+// P .. 2P-1 (P = 1 is the reference's layout).
+__global__ void __launch_bounds__(256)
+flip_merge_kernel(float *__restrict__ hm, const float *__restrict__ wh, float *__restrict__ hm_out,
+                  float *__restrict__ wh_out, long n_hm, long n_wh, int W, long pair_hm, long pair_wh) {
+  // n_hm = P * cat * H * W output elements; pair_hm = P * cat * H * W (offset of the mirrors); same for wh
+  const long total = n_hm + n_wh;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const bool is_hm = i < n_hm;
+    const long j = is_hm ? i : i - n_hm;
+    const long row = j / W;
+    const int x = (int)(j - row * W);
+    const long jm = row * W + (W - 1 - x);
+    if (is_hm) {
+      const float a = sigmoidf_ref(hm[j]), b = sigmoidf_ref(hm[pair_hm + jm]);
+      hm[j] = a;                      // the reference's in-place hm.sigmoid_() on the whole pair (ctdet.py:32):
+      hm[pair_hm + jm] = b;           // every element is read and written by exactly one thread
+      hm_out[j] = __fdiv_rn(__fadd_rn(a, b), 2.0f);
+    } else {
+      wh_out[j] = __fdiv_rn(__fadd_rn(wh[j], wh[pair_wh + jm]), 2.0f);
+    }
+  }
+}
+
 // From the top bin down: the bin D with (count of bins > D) < need <= (count of bins >= D), by a block-wide
 // suffix scan over bin pairs (a single thread walking 2048 LDS words costs ~55 us per level).
 // Every thread of the workgroup calls it; nbins <= 2 * kSelThreads.  Results in *digit / *above (LDS).
@@ -423,4 +450,16 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   decode_select_kernel<<<(unsigned)B, kSelThreads, 0, st>>>(keys, hist, wh, reg, dets, (int)cat, (int)H,
                                                            (int)W, cat_spec_wh ? (int)(2 * cat) : 2, K);
   return cdn::check_launch("ctdet decode select");
+}
+
+extern "C" int cdn_ctdet_flip_merge(float *hm, const float *wh, int64_t P, int64_t cat, int64_t wh_ch, int64_t H,
+                                    int64_t W, float *hm_out, float *wh_out, void *stream) {
+  CDN_REQUIRE(hm && wh && hm_out && wh_out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(P > 0 && cat > 0 && wh_ch > 0 && H > 0 && W > 0 && 2 * P * std::max(cat, wh_ch) * H * W < (1ll << 31),
+              CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE(hm_out != hm && wh_out != wh, CDN_ERR_ARG, "the merge is not an in-place operation (it reads mirrored columns)");
+  const long n_hm = (long)(P * cat * H * W), n_wh = (long)(P * wh_ch * H * W);
+  const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(n_hm + n_wh, 256), (long)cdn::kCUs * 16);
+  flip_merge_kernel<<<blocks, 256, 0, cdn::as_stream(stream)>>>(hm, wh, hm_out, wh_out, n_hm, n_wh, (int)W, n_hm, n_wh);
+  return cdn::check_launch("ctdet flip merge");
 }

@@ -381,6 +381,24 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
             output = dict(output)
             output["hm"] = sig
             return output, dets
+        if native_decode and flip_test and output["hm"].shape[0] == 2 and not cat_spec_wh:
+            # the README's test commands (--flip_test): sigmoid + mirror merge in one launch into static buffers, then
+            # the native decode (capturable as a graph: capture_process(flip_test=True))
+            from . import _native as N_
+            hm2, wh2 = output["hm"].contiguous(), output["wh"].contiguous()
+            static = bufs is not None and getattr(model, "_fused", False)
+            hm = bufs.sigmoid_buffer(hm2[0:1]) if static else torch.empty_like(hm2[0:1])
+            wh = bufs.sigmoid_buffer(wh2[0:1]) if static else torch.empty_like(wh2[0:1])
+            rc = N_.lib().cdn_ctdet_flip_merge(hm2.data_ptr(), wh2.data_ptr(), 1, hm2.shape[1], wh2.shape[1], hm2.shape[2],
+                                               hm2.shape[3], hm.data_ptr(), wh.data_ptr(),
+                                               torch.cuda.current_stream(hm2.device).cuda_stream)
+            N_.check(rc, "cdn_ctdet_flip_merge")
+            dets = ctdet_decode_native(hm, wh, reg=reg[0:1] if reg is not None else None, cat_spec_wh=False, K=K,
+                                       bufs=bufs)
+            if hm2.data_ptr() != output["hm"].data_ptr():      # (contiguous() copied: hand the sigmoid back)
+                output = dict(output)
+                output["hm"] = hm2
+            return output, dets         # output["hm"] holds the sigmoid of both images, as after the reference's sigmoid_()
         hm = output["hm"].sigmoid_()
         wh = output["wh"]
         if flip_test:
@@ -394,14 +412,15 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
     return output, dets
 
 
-def capture_process(model, images, reg_offset=True, cat_spec_wh=False, K=100):
-    """Capture ``process(model, images, flip_test=False)`` -- the whole fused network + native decode -- over the
+def capture_process(model, images, reg_offset=True, cat_spec_wh=False, K=100, flip_test=False):
+    """Capture ``process(model, images, flip_test)`` -- the whole fused network + native decode (flip_test: images =
+    [image, its W-mirror] and the native sigmoid + mirror merge in between, the README's test procedure) -- over the
     static `images` buffer into one HIP graph (about 110 kernel launches; at small batches the Python /
     launch overhead of issuing them one by one dominates).  Returns replay() -> (output dict, dets); copy
     new images into `images` before each replay.  Needs model.enable_fused() and a GPU tensor."""
     assert getattr(model, "_fused", False) and images.is_cuda
     bufs = ProcessBuffers()          # owned by this capture: kept alive by replay(), released with it
-    kw = dict(flip_test=False, reg_offset=reg_offset, cat_spec_wh=cat_spec_wh, K=K, bufs=bufs)
+    kw = dict(flip_test=bool(flip_test), reg_offset=reg_offset, cat_spec_wh=cat_spec_wh, K=K, bufs=bufs)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                 # warm-up: buffers, cached weights, kernel attributes

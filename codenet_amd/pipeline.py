@@ -796,7 +796,7 @@ class FusedHeads:
         aux = N_.lib().cdn_codenet_aux_workspace_bytes()
         self._bufs = dict(
             key=(tuple(r.shape), dev), y1=torch.empty(M, C, device=dev),
-            y2=None, o={},                                    # unfused tail only: allocated on first use
+            y2={}, o={},                                      # unfused tail only: allocated on first use, PER HEAD
             ws=torch.zeros(aux // 4 + 64, device=dev),        # arrival counters start at zero
             out={name: torch.empty(Nb, self._out_channels(m), 2 * Hs, 2 * Ws, device=dev)
                  for name, m in self.heads.items()})
@@ -877,8 +877,10 @@ class FusedHeads:
                          and layers[2]["act"] is None and not layers[2]["relu"])
                 if not small and name not in B["o"]:
                     B["o"][name] = torch.empty(4 * M, self._out_channels(mod), device=r.device)
-                    if B["y2"] is None and len(layers) == 3:
-                        B["y2"] = torch.empty(4 * M, C, device=r.device)
+                if not small and len(layers) == 3 and name not in B["y2"]:
+                    # one scratch per head: the heads run concurrently on their own streams (a shared one was a race
+                    # between them -- fp32 heads only: the W4A8 tails never store this tensor)
+                    B["y2"][name] = torch.empty(4 * M, C, device=r.device)
                 if len(layers) == 1:          # head_conv == 0: one 1x1 conv, up-sampled afterwards
                     o = B["o"][name][:M]
                     pw(r, r_qstate, M, layers[0], o)
@@ -916,12 +918,12 @@ class FusedHeads:
                 rc = lib.cdn_codenet_dw3x3_nhwc_forward(
                     y1buf.data_ptr(), q1, Nb, C, Hs, Ws, 1, 1, 0, 0, ptr(l2["w"]), ptr(l2["bias"]),
                     ptr(ep[0]), ptr(ep[1]), l2["relu"], *act_args(l2["act"]), ws_ptr, ws_bytes,
-                    B["y2"].data_ptr(), stream)
+                    B["y2"][name].data_ptr(), stream)
                 ops._toc(rec)
                 N_.check(rc, "cdn_codenet_dw3x3_nhwc_forward")
                 q2 = l2["act"]._device_state(r.device).data_ptr() if l2["act"] is not None else None
                 o = B["o"][name]
-                pw(B["y2"], q2, 4 * M, l3, o)
+                pw(B["y2"][name], q2, 4 * M, l3, o)
                 rc = lib.cdn_codenet_unpack_nchw(o.data_ptr(), None, B["out"][name].data_ptr(), Nb,
                                                  o.shape[1], 2 * Hs, 2 * Ws, 0, stream)
                 N_.check(rc, "cdn_codenet_unpack_nchw")

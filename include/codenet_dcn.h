@@ -589,6 +589,14 @@ size_t cdn_ctdet_decode_workspace_bytes(int64_t B, int64_t cat, int64_t H, int64
 int cdn_ctdet_decode(const float *heat, const float *wh, const float *reg, int64_t B, int64_t cat,
                      int64_t H, int64_t W, int cat_spec_wh, int K, int apply_sigmoid, float *heat_out,
                      float *dets, void *workspace, size_t workspace_bytes, void *stream);
+/* Test-time flip augmentation in front of cdn_ctdet_decode (lib/detectors/ctdet.py:32-38, opt.flip_test: every test
+ * command of the reference's README): hm [2P][cat][H][W] logits and wh [2P][wh_ch][H][W] of P images (0 .. P-1) and
+ * their W-mirrors (P .. 2P-1; P = 1 is the reference's layout) ->
+ *   hm <- sigmoid(hm) IN PLACE (the reference's hm.sigmoid_() on the whole batch),
+ *   hm_out [P][cat][H][W] = (hm[p] + flip_W(hm[P + p])) / 2,   wh_out = (wh[p] + flip_W(wh[P + p])) / 2
+ * (decode then takes hm_out without a sigmoid and reg[0 .. P-1]).  hm_out / wh_out must not alias the inputs. */
+int cdn_ctdet_flip_merge(float *hm, const float *wh, int64_t P, int64_t cat, int64_t wh_ch, int64_t H, int64_t W,
+                         float *hm_out, float *wh_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (thread-local; off by default).
