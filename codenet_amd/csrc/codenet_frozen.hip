@@ -567,6 +567,42 @@ dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ a
   pwq8_epilogue<TN>(acc, dq, wscale, wsum, bias, R8, nullptr, rq, oflow, M, KP, Co, relu, nullptr, nullptr, ldo, omap,
                     m0, 0, wm, wn, lane);
 }
+
+// maxq8: MaxPool2d(3, stride 2, padding 1) of the "S2 + MaxPool" stems (shufflenetv2_dcn.py:209-214; README configs b and
+// e) on byte codes: the pool follows ReLU + QuantAct, fake-quantisation is monotone, so the maximum of the codes is the
+// code of the maximum -- exactly what maxpool_kernel<true> computes on values.  One thread = one output pixel x 4
+// channels; window cells outside the image do not take part (clamped address, code -128 = identity of max).
+__global__ void __launch_bounds__(256)
+maxq8_kernel(const signed char *__restrict__ a8, signed char *__restrict__ out8, int C, int ld_in, int ld_out, int Hs,
+             int Ws, int Ho, int Wo, long total) {
+  const int CQ = (C + 3) >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const unsigned iu = (unsigned)i;
+    const int cq = (int)(iu % (unsigned)CQ);
+    unsigned t = iu / (unsigned)CQ;
+    const int ox = (int)(t % (unsigned)Wo);
+    t /= (unsigned)Wo;
+    const int oy = (int)(t % (unsigned)Ho), n = (int)(t / (unsigned)Ho);
+    const signed char *ab = a8 + (long)n * Hs * Ws * ld_in + cq * 4;
+    int m[4] = {-128, -128, -128, -128};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int y = 2 * oy + dy - 1, x = 2 * ox + dx - 1;
+        const bool in = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        const unsigned u = *reinterpret_cast<const unsigned *>(ab + ((long)min(max(y, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1)) * ld_in);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = (int)(signed char)((u >> (8 * e)) & 0xff);
+          m[e] = max(m[e], in ? q : -128);
+        }
+      }
+    const unsigned pk = (unsigned)(m[0] & 0xff) | ((unsigned)(m[1] & 0xff) << 8) | ((unsigned)(m[2] & 0xff) << 16) |
+                        ((unsigned)(m[3] & 0xff) << 24);
+    *reinterpret_cast<unsigned *>(out8 + ((long)n * Ho * Wo + (long)oy * Wo + ox) * ld_out + cq * 4) = pk;
+  }
+}
 }  // namespace
 
 static int frozen_params_impl(int n, float *const *x_min, float *const *x_max, void *const *state, int bits,
@@ -835,6 +871,22 @@ extern "C" int cdn_codenet_dwpw_q8_forward(
   }
 #undef CDN_DP_BN
   return cdn::check_launch("codenet depthwise + pointwise on byte codes");
+}
+
+extern "C" int cdn_codenet_maxpool3x3s2_q8_forward(const signed char *a8, int64_t N, int64_t C, int64_t H, int64_t W,
+                                                   int64_t ld_in, int64_t ld_out, signed char *out8, void *stream) {
+  CDN_REQUIRE(a8 && out8, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "bad size");
+  const int64_t Cq4 = (C + 3) / 4 * 4;
+  CDN_REQUIRE(ld_in >= Cq4 && ld_out >= Cq4 && (ld_in & 3) == 0 && (ld_out & 3) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a8) & 3) == 0 && (reinterpret_cast<uintptr_t>(out8) & 3) == 0,
+              CDN_ERR_ARG, "rows must hold round_up(C, 4) bytes, strides multiples of 4, pointers 4-byte aligned");
+  const int Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);
+  const long total = (long)N * Ho * Wo * ((C + 3) / 4);
+  CDN_REQUIRE(N * H * W * ld_in < (1ll << 31) && total < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  maxq8_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(total, 256), (long)cdn::kCUs * 32), 256, 0, cdn::as_stream(stream)>>>(
+      a8, out8, (int)C, (int)ld_in, (int)ld_out, (int)H, (int)W, Ho, Wo, total);
+  return cdn::check_launch("codenet maxpool (byte codes)");
 }
 
 extern "C" int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H,

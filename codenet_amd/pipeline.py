@@ -1575,8 +1575,8 @@ class FrozenBackbone:
         if not FusedBackbone.supported(model) or not hasattr(model.layer0[0], "folded"):
             return False
         fb = FusedBackbone(model)
-        if len(model.layer0[1]) != 2:                       # "S2 + MaxPool" stems keep the fp32 schedule
-            return False
+        if not (len(model.layer0[1]) == 2 or (len(model.layer0[1]) == 3 and FusedBackbone._is_pool(model.layer0[1][2]))):
+            return False                                     # (stem = conv, [ReLU, QuantAct] or [ReLU, QuantAct, MaxPool])
         for name in ("layer1", "layer2", "layer3"):
             if not fb.mixed_supported(list(getattr(model, name))):
                 return False
@@ -1726,6 +1726,13 @@ class FrozenBackbone:
                                                  B["x0"].data_ptr(), 32, B["overflow"].data_ptr(), st)
             N_.check(rc, "cdn_codenet_stem_q8_forward")
             x8, x_ld, x_state, logical = B["x0"], 32, act0._device_state(dev).data_ptr(), None
+            if len(m.layer0[1]) == 3:                        # "S2 + MaxPool" stems (README configs b, e): pool the codes
+                Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                if B.get("x0p") is None:
+                    B["x0p"] = torch.zeros(Nb, Hp * Wp, 32, dtype=torch.int8, device=dev)
+                rc = lib.cdn_codenet_maxpool3x3s2_q8_forward(x8.data_ptr(), Nb, 24, H, W, 32, 32, B["x0p"].data_ptr(), st)
+                N_.check(rc, "cdn_codenet_maxpool3x3s2_q8_forward")
+                x8, H, W = B["x0p"], Hp, Wp
             for name in ("layer1", "layer2", "layer3"):
                 x8, x_ld, x_state, logical, H, W = self._layer(name, list(getattr(m, name)), x8, x_ld, x_state, logical,
                                                                Nb, H, W)

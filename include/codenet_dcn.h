@@ -415,6 +415,10 @@ int cdn_codenet_pointwise_q8_strided_forward(
 int cdn_codenet_stem_q8_forward(const float *img, int64_t N, int64_t H, int64_t W, int64_t Co, int stride,
                                 const float *w, const float *bias, int relu, const void *r_state,
                                 signed char *out8, int64_t ld_out, unsigned *overflow, void *stream);
+/* MaxPool2d(3, stride 2, padding 1) on byte codes (the "S2 + MaxPool" stems; the maximum of the codes is the code of
+ * the maximum: the pool follows the QuantAct): a8 [N][H*W] rows of ld_in bytes -> out8 [N][Ho*Wo] rows of ld_out bytes. */
+int cdn_codenet_maxpool3x3s2_q8_forward(const signed char *a8, int64_t N, int64_t C, int64_t H, int64_t W, int64_t ld_in,
+                                        int64_t ld_out, signed char *out8, void *stream);
 int cdn_codenet_dw3x3_q8_forward(const signed char *a8, const void *a_state, int64_t N, int64_t C, int64_t H,
                                  int64_t W, int stride, int64_t ld_in, int64_t ld_out, const float *w,
                                  const float *bias, int relu, const void *r_state, signed char *out8,

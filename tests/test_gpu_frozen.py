@@ -457,3 +457,23 @@ def test_dwpw_q8_equals_depthwise_then_pointwise(N, C, H, W, stride, Co, ldo):
     assert torch.equal(got, want)
     assert of1.item() == of2.item()
     assert want.float().std().item() > 1.0          # (a non-degenerate case)
+
+
+@pytest.mark.parametrize("N,C,H,W,ld", [(2, 24, 9, 11, 32), (1, 24, 64, 64, 32), (3, 58, 7, 8, 64)])
+def test_maxpool_q8_is_the_code_of_the_pooled_values(N, C, H, W, ld):
+    """cdn_codenet_maxpool3x3s2_q8_forward against F.max_pool2d(3, 2, 1) of the code tensor (the pool follows the
+    QuantAct and fake-quantisation is monotone: the maximum of the codes is the code of the maximum)."""
+    import torch.nn.functional as F
+    from codenet_amd import _native as N_
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(H * W + C)
+    a8 = torch.randint(-128, 128, (N, H * W, ld), generator=g, dtype=torch.int32).to(torch.int8).to(dev)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.full((N, Ho * Wo, ld), 55, dtype=torch.int8, device=dev)
+    N_.check(lib.cdn_codenet_maxpool3x3s2_q8_forward(a8.data_ptr(), N, C, H, W, ld, ld, out.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "maxpool q8")
+    x = a8[:, :, :C].float().reshape(N, H, W, C).permute(0, 3, 1, 2)
+    want = F.max_pool2d(x, 3, 2, 1).permute(0, 2, 3, 1).reshape(N, Ho * Wo, C)
+    cq4 = (C + 3) // 4 * 4
+    assert torch.equal(out[:, :, :C].float(), want)
+    assert bool((out[:, :, cq4:] == 55).all())
