@@ -198,6 +198,94 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
 }
 
 // ------------------------------------------------------------------------------------------
+// dw4_kernel (round 3): dw_kernel's LDS form with the planes interleaved in channel QUADS -- [CC / 4][Hp][Wp][4] -- so a
+// lane fetches the four channels of a cell with ONE ds_read_b128 where dw_kernel issues four ds_read_b32 (25 instead
+// of 100 LDS reads per pixel and quad; consecutive lanes = consecutive pixels read consecutive 16-byte cells).  Same
+// per-channel expressions in the same order: bit-identical to dw_kernel.  C % 4 == 0, CC % 4 == 0.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kDwThreads)
+dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
+           float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm) {
+  extern __shared__ float smem[];
+  __shared__ float red_mm[8];
+  float mn = INFINITY, mx = -INFINITY;
+  const int HW = H * W;
+  const int Wp = W + 2, Hp = H + 2;
+  const int pstride = Hp * Wp;
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * CC;
+  const int cc = min(CC, C - c0);                         // (a multiple of 4)
+  const float *xg = x + ((long)n * C + c0) * HW;
+  float *wl = smem;                                       // [CC][9] depthwise weights
+  float4 *planes = reinterpret_cast<float4 *>(smem + ((CC * 9 + 3) & ~3));   // [CC / 4][Hp][Wp] of channel quads
+  for (int q = threadIdx.x; q < cc * 9; q += kDwThreads) wl[q] = wd[(long)c0 * 9 + q];
+  for (int q = threadIdx.x; q < (cc >> 2) * pstride; q += kDwThreads) planes[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  for (int q = threadIdx.x; q < cc * HW; q += kDwThreads) {
+    const int ch = q / HW, r = q - ch * HW;
+    const int yy = r / W, xx = r - yy * W;
+    reinterpret_cast<float *>(planes)[(((ch >> 2) * pstride + (yy + 1) * Wp + xx + 1) << 2) + (ch & 3)] = xg[q];
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += kDwThreads) {
+    const int h = p / W, w = p - h * W;
+    const float t = s[(long)n * HW + p] - 1.0f;
+    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    const int b00 = (ya.i0 + 1) * Wp + xa.i0 + 1, b02 = (ya.i0 + 1) * Wp + xb.i0 + 1;
+    const int b20 = (yb.i0 + 1) * Wp + xa.i0 + 1, b22 = (yb.i0 + 1) * Wp + xb.i0 + 1;
+    const int b01 = (ya.i0 + 1) * Wp + w + 1, b21 = (yb.i0 + 1) * Wp + w + 1;
+    const int b10 = (h + 1) * Wp + xa.i0 + 1, b12 = (h + 1) * Wp + xb.i0 + 1;
+    const int b11 = (h + 1) * Wp + w + 1;
+    // the products of the corner weights, once per pixel (dw_kernel forms the same products per channel)
+    const float aa00 = ya.w0 * xa.w0, aa01 = ya.w0 * xa.w1, aa10 = ya.w1 * xa.w0, aa11 = ya.w1 * xa.w1;
+    const float ab00 = ya.w0 * xb.w0, ab01 = ya.w0 * xb.w1, ab10 = ya.w1 * xb.w0, ab11 = ya.w1 * xb.w1;
+    const float ba00 = yb.w0 * xa.w0, ba01 = yb.w0 * xa.w1, ba10 = yb.w1 * xa.w0, ba11 = yb.w1 * xa.w1;
+    const float bb00 = yb.w0 * xb.w0, bb01 = yb.w0 * xb.w1, bb10 = yb.w1 * xb.w0, bb11 = yb.w1 * xb.w1;
+    for (int g = 0; g < (cc >> 2); ++g) {
+      const float4 *pl = planes + g * pstride;
+      const float4 c00 = pl[b00], c01 = pl[b00 + 1], c02 = pl[b00 + Wp], c03 = pl[b00 + Wp + 1];
+      const float4 c20 = pl[b02], c21 = pl[b02 + 1], c22 = pl[b02 + Wp], c23 = pl[b02 + Wp + 1];
+      const float4 c60 = pl[b20], c61 = pl[b20 + 1], c62 = pl[b20 + Wp], c63 = pl[b20 + Wp + 1];
+      const float4 c80 = pl[b22], c81 = pl[b22 + 1], c82 = pl[b22 + Wp], c83 = pl[b22 + Wp + 1];
+      const float4 e10 = pl[b01], e11 = pl[b01 + Wp], e70 = pl[b21], e71 = pl[b21 + Wp];
+      const float4 e30 = pl[b10], e31 = pl[b10 + 1], e50 = pl[b12], e51 = pl[b12 + 1];
+      const float4 ctr = pl[b11];
+#define CDN_DW4_CH(E, OFF)                                                                             \
+      {                                                                                                  \
+        const float *wk = wl + (4 * g + OFF) * 9;                                                        \
+        const float v0 = ((aa00 * c00.E + aa01 * c01.E) + aa10 * c02.E) + aa11 * c03.E;                  \
+        const float v2 = ((ab00 * c20.E + ab01 * c21.E) + ab10 * c22.E) + ab11 * c23.E;                  \
+        const float v6 = ((ba00 * c60.E + ba01 * c61.E) + ba10 * c62.E) + ba11 * c63.E;                  \
+        const float v8 = ((bb00 * c80.E + bb01 * c81.E) + bb10 * c82.E) + bb11 * c83.E;                  \
+        const float v1 = ya.w0 * e10.E + ya.w1 * e11.E;                                                  \
+        const float v7 = yb.w0 * e70.E + yb.w1 * e71.E;                                                  \
+        const float v3 = xa.w0 * e30.E + xa.w1 * e31.E;                                                  \
+        const float v5 = xb.w0 * e50.E + xb.w1 * e51.E;                                                  \
+        float acc = wk[0] * v0;                                                                          \
+        acc = fmaf(wk[1], v1, acc);                                                                      \
+        acc = fmaf(wk[2], v2, acc);                                                                      \
+        acc = fmaf(wk[3], v3, acc);                                                                      \
+        acc = fmaf(wk[4], ctr.E, acc);                                                                   \
+        acc = fmaf(wk[5], v5, acc);                                                                      \
+        acc = fmaf(wk[6], v6, acc);                                                                      \
+        acc = fmaf(wk[7], v7, acc);                                                                      \
+        acc = fmaf(wk[8], v8, acc);                                                                      \
+        d[((long)n * C + c0 + 4 * g + OFF) * HW + p] = acc;                                              \
+        mn = fminf(mn, acc);                                                                             \
+        mx = fmaxf(mx, acc);                                                                             \
+      }
+      CDN_DW4_CH(x, 0)
+      CDN_DW4_CH(y, 1)
+      CDN_DW4_CH(z, 2)
+      CDN_DW4_CH(w, 3)
+#undef CDN_DW4_CH
+    }
+  }
+  if (mm) cdn::block_minmax_store(mn, mx, &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
+}
+
+// ------------------------------------------------------------------------------------------
 // dw_bwd_kernel: backward of dw_kernel for one (n, CC channels, plane) workgroup.
 //   grad_x : the <=25 bilinear corner contributions of every (pixel, channel) are summed
 //            with LDS float atomics into a zero-bordered LDS image of the plane (the border
@@ -692,11 +780,17 @@ extern "C" int cdn_codenet_scale_forward_range(const float *x, const float *w_sc
 
 static int dw_channels_per_wg(int64_t C, int64_t H, int64_t W) {
   const int pstride = (int)((H + 2) * (W + 2));
-  const int budget = 64 * 1024 / 4;  // floats of LDS per workgroup (2 workgroups per CU)
+  int budget = 64 * 1024 / 4;  // floats of LDS per workgroup (2 workgroups per CU)
   int CC = (budget - 64) / (pstride + 9);
+  if (CC < 4 && (C & 3) == 0) {                          // 64 x 64 planes: 76 KB hold a channel quad, still two per CU
+    budget = 76 * 1024 / 4;
+    CC = (budget - 64) / (pstride + 9);
+    if (CC < 4) CC = (64 * 1024 / 4 - 64) / (pstride + 9);
+  }
   if (CC < 1) return -4;                                 // planes too large: global gather, 4 channels per workgroup
   if (CC > 32) CC = 32;
   if (CC > C) CC = (int)C;
+  if (CC >= 4 && (C & 3) == 0) CC &= ~3;                 // whole channel quads per workgroup (dw4_kernel)
   return CC;
 }
 
@@ -712,7 +806,13 @@ static int dw_forward_impl(const float *x, const float *s, const float *w_dw, fl
   if (CC >= 1) {
     const size_t lds = (size_t)(((CC * 9 + 3) & ~3) + CC * pstride) * sizeof(float);
     dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
-    dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
+    if ((CC & 3) == 0 && (C & 3) == 0) {    // channel quads in LDS: one 16-byte read per cell and quad
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)dw4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      dw4_kernel<<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
+    }
+    else
+      dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
   } else {
     CC = 4;
     const size_t lds = (size_t)((CC * 9 + 3) & ~3) * sizeof(float);
