@@ -726,45 +726,51 @@ def main():
 
 
 def _e2e_frozen_leg(args, model, images, replay):
-    """Serving mode of the whole network on THIS rank: every QuantAct frozen, byte codes from the stem to the heads."""
+    """Serving mode of the whole network on THIS rank: every QuantAct frozen, byte codes from the stem to the heads.
+    Ranges are calibrated on the schedule that serves (pipeline.prepare_serving -> calibrate_serving: the byte network
+    itself names the QuantActs whose codes saturate).  A leg whose timed batches still overflowed is reported
+    "valid": false with the time INCLUDING the recompute on the fp32 frozen schedule (the serving contract,
+    INTEGRATION.md)."""
     import torch
     from codenet_amd import harness, pipeline
-    for _ in range(300):                  # let the running (EMA) ranges settle on this input before freezing them
-        replay()
-    torch.cuda.synchronize()
-    pipeline.set_running_stat(model, False)
-    # a serving deployment freezes CALIBRATED ranges: the EMA ranges are widened over what the frozen network
-    # feeds each QuantAct on this batch (+2 % of the span), so that every code fits the byte grid
-    model.enable_fused(False)
-    moved = pipeline.cover_frozen_ranges(model, [images], margin=0.02)
+    report = pipeline.prepare_serving(model, images, settle=300, margin=0.02, replay=replay)
     torch.cuda.empty_cache()
 
     def timed(**kw):
-        model.enable_fused(frozen_codes=True, **kw)
+        model.enable_fused(**kw)
         replay_f = harness.capture_process(model, images)
         for _ in range(5):
             replay_f()
         torch.cuda.synchronize()
+        model.frozen_overflowed()          # (reset: only the timed batches count)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             dets_f = replay_f()[1]
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps * 1e3, dets_f, bool(model.frozen_overflowed())
-    ms_st, dets_s, of_s = timed(frozen_backbone=False)
-    msf, dets_f, of_f = timed()
-    return {"ms_per_batch": msf, "images_per_s": args.batch / msf * 1e3, "per_rank": True,
-            "overflow": of_f, "finite": bool(torch.isfinite(dets_f).all()),
-            "byte_backbone": model._fzbackbone is not None,
-            "byte_heads": model._fzheads is not None and model._fzheads._bufs is not None
-            and model._fzheads._bufs["key"][0][0] == "codes",
-            "stages_only": {"ms_per_batch": ms_st, "overflow": of_s,
+    ms_st, dets_s, of_s = timed(frozen_codes=True, frozen_backbone=False)
+    msf, dets_f, of_f = timed(frozen_codes=True)
+    byte_backbone = model._fzbackbone is not None
+    byte_heads = (model._fzheads is not None and model._fzheads._bufs is not None
+                  and model._fzheads._bufs["key"][0][0] == "codes")
+    recompute_ms = None
+    if of_f:                                # the contract: an overflowed batch is recomputed on the fp32 frozen schedule
+        recompute_ms, _, _ = timed(frozen_codes=False)
+    total = msf + (recompute_ms or 0.0)
+    return {"ms_per_batch": total, "images_per_s": args.batch / total * 1e3, "per_rank": True,
+            "valid": not of_f, "overflow": of_f, "byte_schedule_ms": msf, "fp32_recompute_ms": recompute_ms,
+            "finite": bool(torch.isfinite(dets_f).all()),
+            "byte_backbone": byte_backbone, "byte_heads": byte_heads,
+            "stages_only": {"ms_per_batch": ms_st, "overflow": of_s, "valid": not of_s,
                             "what": "backbone on the fp32 kernels without range updates, stages on byte codes"},
-            "ranges_widened": moved,
+            "calibration": report,
             "what": "the same network with every QuantAct frozen (running_stat False: serving mode, not the "
                     "reference's default) on BYTE CODES from the stem to the heads' input: backbone "
                     "(pipeline.FrozenBackbone), the three deform stages with chained scale sums "
                     "(pipeline.FrozenHotPath), the heads' 1x1 convs and tails (FusedHeads.forward_codes); no "
-                    "range passes anywhere; timed on rank 0's shard without collectives"}
+                    "range passes anywhere; ranges calibrated on the byte schedule itself "
+                    "(pipeline.calibrate_serving); timed on rank 0's shard without collectives; ms_per_batch "
+                    "includes the fp32 recompute when a timed batch overflowed (valid: false)"}
 
 
 def e2e_leg(args, dev, rank, world, local_rank, hot_ms):

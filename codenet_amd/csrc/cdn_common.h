@@ -297,7 +297,8 @@ struct ScaleFromSums {
 };
 int launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                      const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H, int W,
-                     int up, hipStream_t st, ScaleFromSums si = ScaleFromSums{nullptr, nullptr, nullptr, 0.f, 0.f});
+                     int up, hipStream_t st, ScaleFromSums si = ScaleFromSums{nullptr, nullptr, nullptr, 0.f, 0.f},
+                     int gmode = 0);
 // Workspace of the stand-alone layer entry points: partials first, arrival counters in the LAST bytes
 // (zeroed once by the caller); size = cdn_codenet_aux_workspace_bytes().
 struct AuxWs {

@@ -459,6 +459,16 @@ extern "C" int cdn_ctdet_flip_merge(float *hm, const float *wh, int64_t P, int64
               CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(hm_out != hm && wh_out != wh, CDN_ERR_ARG, "the merge is not an in-place operation (it reads mirrored columns)");
   const long n_hm = (long)(P * cat * H * W), n_wh = (long)(P * wh_ch * H * W);
+  {
+    // the four ranges {hm (2P images, written in place), wh (read), hm_out, wh_out} must be pairwise disjoint except
+    // hm / wh among themselves never are the same tensor anyway: a shared hm_out == wh_out buffer (two heads of equal
+    // shape keyed by shape alone) used to be written by both halves of the launch
+    auto disjoint = [](const float *a, long na, const float *b, long nb) { return a + na <= b || b + nb <= a; };
+    CDN_REQUIRE(disjoint(hm_out, n_hm, wh_out, n_wh) && disjoint(hm_out, n_hm, hm, 2 * n_hm) &&
+                    disjoint(hm_out, n_hm, wh, 2 * n_wh) && disjoint(wh_out, n_wh, hm, 2 * n_hm) &&
+                    disjoint(wh_out, n_wh, wh, 2 * n_wh),
+                CDN_ERR_ARG, "hm_out / wh_out overlap each other or the inputs");
+  }
   const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(n_hm + n_wh, 256), (long)cdn::kCUs * 16);
   flip_merge_kernel<<<blocks, 256, 0, cdn::as_stream(stream)>>>(hm, wh, hm_out, wh_out, n_hm, n_wh, (int)W, n_hm, n_wh);
   return cdn::check_launch("ctdet flip merge");

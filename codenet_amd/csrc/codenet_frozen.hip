@@ -706,6 +706,10 @@ static int stage_frozen_impl(
     const signed char *next_scale_codes, int *s_acc_out) {
   CDN_REQUIRE(x && (w_scale || s_acc_in) && w_dw && w_pw_codes && w_pw_scale && w_pw_colsum && s_state && d_state && r_state &&
                   workspace && r8_out && overflow, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE((x_kind & ~(3 | CDN_X_GATHER_MASK)) == 0 && ((x_kind & CDN_X_GATHER_MASK) >> 8) <= 2, CDN_ERR_ARG,
+              "x_kind: 0 / 1 / 2, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT");
+  const int gmode = (x_kind & CDN_X_GATHER_MASK) >> 8;      // per-call schedule choice (tests); no library state
+  x_kind &= 3;
   CDN_REQUIRE(x_kind >= 0 && x_kind <= 2 && (x_up == 0 || x_up == 1), CDN_ERR_ARG, "bad x_kind / x_up");
   CDN_REQUIRE((x_kind == 0) == (x_state == nullptr), CDN_ERR_ARG,
               "x_state goes with channels-last inputs (x_kind 1, 2) and only with them");
@@ -743,7 +747,7 @@ static int stage_frozen_impl(
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     rc = cdn::launch_frozen_dw(x, x_kind, xq, s_raw, static_cast<const unsigned *>(s_state), w_dw, d8,
                                static_cast<unsigned *>(const_cast<void *>(d_state)), overflow, (int)N, (int)C, (int)H,
-                               (int)W, x_up, st, si);
+                               (int)W, x_up, st, si, gmode);
   }
   if (rc) return rc;
   if (s_acc_out)      // (zero on entry: cleared by cdn_quantact_frozen_params_clear at the start of the step)

@@ -2419,9 +2419,10 @@ static size_t dw2_lds_bytes(int Hl, int Wl, int CCH) {
           2 * kDw2MaxThreads / 64 + 4) * sizeof(float);
 }
 
-// gather schedule for an NCHW input: 0 = automatic (persistent LDS-DMA kernel where it applies), 1 = always the
-// per-item kernels (dw2_kernel), 2 = persistent wherever its shape conditions hold (also on small grids)
-static int g_gather_mode = 0;
+// gather schedule for an NCHW input (`gmode`, a PER-CALL argument: bits 8-9 of the stage entry points' layout
+// argument, CDN_X_GATHER_* in codenet_dcn.h; the library keeps no process-wide setting): 0 = automatic (persistent
+// LDS-DMA kernel where it applies), 1 = always the per-item kernels (dw2_kernel), 2 = persistent wherever its shape
+// conditions hold (also on small grids)
 
 static size_t dw0p_lds_bytes(int H, int W) {
   return ((size_t)64 + (size_t)(H + 1) * (W + 1) * 64 + (size_t)64 * H * W + 2 * 64 * 9 + 2 * (size_t)H * W +
@@ -2454,13 +2455,13 @@ static int launch_dw0p(const float *x, const float *s_raw, const unsigned *sq, c
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
                const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
-               int C, int H, int W, int up, hipStream_t st) {
+               int C, int H, int W, int up, hipStream_t st, int gmode) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
   // NCHW input at output resolution (stage 0): the persistent LDS-DMA form once every CU gets >= 2 items to pipeline
-  if (CCH == 64 && !nhwc && up == 0 && xq == nullptr && g_gather_mode != 1 && dw0p_applies(C, H, W) &&
-      (g_gather_mode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs))
+  if (CCH == 64 && !nhwc && up == 0 && xq == nullptr && gmode != 1 && dw0p_applies(C, H, W) &&
+      (gmode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs))
     return launch_dw0p<false>(x, s_raw, sq, wd, d, dmm, qu, N, C, H, W, st);
   // two 512-thread workgroups per CU when LDS allows and the grid is large enough to fill them
   // (staging of one overlaps compute of the other); otherwise one 1024-thread workgroup per CU.
@@ -2550,7 +2551,7 @@ namespace {
 template <int CCH>
 int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                        const float *wd, float *d8, unsigned *dstate, float2 *oflow, int N, int C, int H, int W,
-                       int up, hipStream_t st, cdn::ScaleFromSums si) {
+                       int up, hipStream_t st, cdn::ScaleFromSums si, int gmode) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
@@ -2570,8 +2571,8 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
     CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, true, true>), threads, up)
   } else if (x_kind == 1) {
     CDN_FGO((dw2_kernel<CCH, true, true, true, kDw2MaxThreads, false, true>), threads, up)
-  } else if (CCH == 64 && up == 0 && g_gather_mode != 1 && dw0p_applies(C, H, W) &&
-             (g_gather_mode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs)) {
+  } else if (CCH == 64 && up == 0 && gmode != 1 && dw0p_applies(C, H, W) &&
+             (gmode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs)) {
     return launch_dw0p<true>(x, s_raw, sq, wd, d8, oflow, qu, N, C, H, W, st);
   } else {
     CDN_FGO((dw2_kernel<CCH, false, false, true, kDw2MaxThreads, false, true>), threads, up)
@@ -2583,7 +2584,7 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
 
 int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                           const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H,
-                          int W, int up, hipStream_t st, cdn::ScaleFromSums si) {
+                          int W, int up, hipStream_t st, cdn::ScaleFromSums si, int gmode) {
   if (si.sums && !(x_kind != 0 && up == 1))
     return cdn::fail(CDN_ERR_UNSUPPORTED, "scale sums are consumed by the up-sampled channels-last gather only");
   const int cch = cdn::stage_channel_chunk(H >> up, W >> up);
@@ -2592,7 +2593,7 @@ int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const f
   auto fn = cch == 64 ? launch_frozen_dw_t<64> : cch == 32 ? launch_frozen_dw_t<32>
             : cch == 16 ? launch_frozen_dw_t<16> : launch_frozen_dw_t<8>;
   return fn(static_cast<const float *>(x), x_kind, xq, s_raw, sq, wd, reinterpret_cast<float *>(d8), dstate,
-            reinterpret_cast<float2 *>(oflow), N, C, H, W, up, st, si);
+            reinterpret_cast<float2 *>(oflow), N, C, H, W, up, st, si, gmode);
 }
 
 // Pointwise (1x1) convolution on a channels-last activation A [M][C] -> R [M][Co]: int8 MFMA on codes
@@ -2729,12 +2730,6 @@ int cdn::stage_channel_chunk(int Hl, int Wl) {
   return 0;
 }
 
-extern "C" int cdn_codenet_set_gather_mode(int mode) {
-  const int old = g_gather_mode;
-  if (mode >= 0 && mode <= 2) g_gather_mode = mode;
-  return old;
-}
-
 extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up) {
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (x_up != 0 && x_up != 1)) return 0;
   if (x_up && ((H & 1) || (W & 1))) return 0;
@@ -2757,6 +2752,10 @@ extern "C" int cdn_codenet_stage_fused_forward(
     void *stream) {
   CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK)) == 0 && ((x_nhwc & CDN_X_GATHER_MASK) >> 8) <= 2, CDN_ERR_ARG,
+              "x_nhwc: 0 / 1, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT");
+  const int gmode = (x_nhwc & CDN_X_GATHER_MASK) >> 8;      // per-call schedule choice (tests); no library state
+  x_nhwc &= 1;
   CDN_REQUIRE(x_up == 0 || x_up == 1, CDN_ERR_ARG, "x_up must be 0 or 1");
   CDN_REQUIRE(!x_up || ((H & 1) == 0 && (W & 1) == 0), CDN_ERR_SHAPE,
               "x_up needs even H, W (got %lld x %lld)", (long long)H, (long long)W);
@@ -2856,7 +2855,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
   {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     auto fn = cch == 64 ? launch_dw2<64> : cch == 32 ? launch_dw2<32> : cch == 16 ? launch_dw2<16> : launch_dw2<8>;
-    rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
+    rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st, gmode);
   }
   if (rc) return rc;
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)

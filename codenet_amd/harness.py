@@ -119,6 +119,8 @@ class PoseShuffleNetV2(nn.Module):
         # quantize_shufflenetv2_dcn), so a forward reads 5 attributes of ~70 modules instead of walking the tree
         self.__dict__["_fused_acts"] = [a for a in self.modules() if isinstance(a, QuantAct)]
         self.__dict__["_fused_ok_cache"] = {}
+        self.__dict__.pop("_stage_acts", None)           # re-collected after a re-quantisation
+        self.__dict__["_fzbackbone_tried"] = None
         return self
 
     def _stage_acts_frozen(self):
@@ -174,8 +176,13 @@ class PoseShuffleNetV2(nn.Module):
             if getattr(self, "_frozen_codes", False) and self._stage_acts_frozen():
                 if self._ffrozen is None:
                     self._ffrozen = pipeline.FrozenHotPath(self.deconv_layers, chain_scale=True)
-                    self._fzbackbone = (pipeline.FrozenBackbone(self) if self._fbackbone is not None
-                                        and self._frozen_backbone and pipeline.FrozenBackbone.supported(self) else None)
+                if self._fzbackbone is None and self._fbackbone is not None and self._frozen_backbone:
+                    # decided per QuantAct configuration, not once: the backbone may be frozen after the stages
+                    cfg = tuple(a.running_stat for a in self.__dict__["_fused_acts"])
+                    if self.__dict__.get("_fzbackbone_tried") != cfg:
+                        self.__dict__["_fzbackbone_tried"] = cfg
+                        if pipeline.FrozenBackbone.supported(self):
+                            self._fzbackbone = pipeline.FrozenBackbone(self)
                 stages = self._ffrozen
                 # every QuantAct of the backbone frozen too: byte codes end to end
                 if self._fzbackbone is not None and self._fzbackbone.still_frozen():
@@ -185,7 +192,7 @@ class PoseShuffleNetV2(nn.Module):
                         if self._fzheads is None:
                             self._fzheads = pipeline.FusedHeads({h: getattr(self, h) for h in self.heads})
                         if self._fzheads.codes_supported(last):          # the heads on byte codes as well
-                            return [self._fzheads.forward_codes(r8, rq, last, stages._bufs["overflow"])]
+                            return [self._fzheads.forward_codes(r8, rq, last, stages.head_flags())]
                     return [self._fheads(*stages.expand(r8, rq, last))]
             if self._fbackbone is not None:       # W4A8: the whole network on the HIP kernels
                 feat, fq, hw = self._fbackbone(x)       # hw None: an NCHW tensor (odd channel count)
@@ -300,8 +307,9 @@ class ProcessBuffers:
         self.sigmoid = {}
         self.decode_ws = {}
 
-    def sigmoid_buffer(self, hm):
-        key = (hm.device, tuple(hm.shape), torch.cuda.current_stream(hm.device).cuda_stream)
+    def sigmoid_buffer(self, hm, tag="hm"):
+        # `tag` keeps the merged hm and wh of a flip test apart: a 2-class model gives both the shape [1,2,H,W]
+        key = (tag, hm.device, tuple(hm.shape), torch.cuda.current_stream(hm.device).cuda_stream)
         if key not in self.sigmoid:
             self.sigmoid[key] = torch.empty_like(hm)
         return self.sigmoid[key]
@@ -316,10 +324,15 @@ class ProcessBuffers:
 
 
 class _BoundedBuffers(ProcessBuffers):
-    """Owner-less calls of ctdet_decode_native: at most `cap` workspaces are kept (oldest dropped first)."""
+    """Owner-less calls of ctdet_decode_native: at most `cap` workspaces are kept (oldest dropped first).  A captured
+    graph keeps the raw workspace pointer, so an owner-less call under stream capture is refused: capture with an
+    owner (`bufs=ProcessBuffers()` kept alive next to the graph; capture_process does that)."""
     cap = 4
 
     def workspace(self, device, need, stream):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ctdet_decode_native under graph capture needs bufs=ProcessBuffers() owned by the "
+                               "capture (the graph keeps the workspace pointer; the shared default cache evicts)")
         ws = super().workspace(device, need, stream)
         while len(self.decode_ws) > self.cap:
             self.decode_ws.pop(next(iter(self.decode_ws)))
@@ -387,8 +400,8 @@ def process(model, images, flip_test=True, reg_offset=True, cat_spec_wh=False, K
             from . import _native as N_
             hm2, wh2 = output["hm"].contiguous(), output["wh"].contiguous()
             static = bufs is not None and getattr(model, "_fused", False)
-            hm = bufs.sigmoid_buffer(hm2[0:1]) if static else torch.empty_like(hm2[0:1])
-            wh = bufs.sigmoid_buffer(wh2[0:1]) if static else torch.empty_like(wh2[0:1])
+            hm = bufs.sigmoid_buffer(hm2[0:1], "hm") if static else torch.empty_like(hm2[0:1])
+            wh = bufs.sigmoid_buffer(wh2[0:1], "wh") if static else torch.empty_like(wh2[0:1])
             rc = N_.lib().cdn_ctdet_flip_merge(hm2.data_ptr(), wh2.data_ptr(), 1, hm2.shape[1], wh2.shape[1], hm2.shape[2],
                                                hm2.shape[3], hm.data_ptr(), wh.data_ptr(),
                                                torch.cuda.current_stream(hm2.device).cuda_stream)

@@ -130,6 +130,10 @@ def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
             finally:
                 for h_ in handles:
                     h_.remove()
+            if acts and not seen:
+                raise RuntimeError("cover_frozen_ranges: no QuantAct was called by forward() -- the model runs a fused "
+                                   "schedule (enable_fused()), which never calls the modules; calibrate on the module "
+                                   "path (model.enable_fused(False)) or use pipeline.calibrate_serving(model, batches)")
             with torch.no_grad():
                 for a in acts:
                     if id(a) not in seen:
@@ -146,6 +150,154 @@ def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
         for a, f in zip(acts, was):
             a.running_stat = f
     return len(moved)
+
+
+# per-call gather schedule choice for an NCHW stage-0 input (include/codenet_dcn.h: CDN_X_GATHER_*), set as
+# `path.gather_flag` on a FusedHotPath / FrozenHotPath by the tests that compare the two schedules bit for bit
+GATHER_PER_ITEM, GATHER_PERSISTENT = 0x100, 0x200
+
+
+class OverflowFlags:
+    """The sticky saturation flags of a byte-code schedule: one int32 word PER LAUNCH GROUP (the kernels only
+    ``atomicOr(flag, 1)``, so a distinct word per launch attributes a saturated code to the QuantAct(s) whose codes
+    that launch writes).  ``any()`` is the old single-flag question; ``acts()`` names the QuantActs to widen
+    (calibrate_serving)."""
+
+    def __init__(self, n, dev):
+        self.words = torch.zeros(max(1, n), dtype=torch.int32, device=dev)
+        self.who = [[] for _ in range(max(1, n))]
+        self.off = 0
+
+    def ptr(self, i=0):
+        return self.words.data_ptr() + 4 * (self.off + i)
+
+    def data_ptr(self):
+        return self.ptr(0)
+
+    def count(self):
+        return len(self.who) - self.off
+
+    def slice(self, lo):
+        """a view of the words from `lo` on, sharing words and names (for a consumer that numbers its own launches from 0)"""
+        v = OverflowFlags.__new__(OverflowFlags)
+        v.words, v.who, v.off = self.words, self.who, self.off + lo
+        return v
+
+    def name(self, i, acts):
+        self.who[self.off + i] = list(acts)
+
+    def any(self, reset=True):
+        """True when some code saturated since the last reset (synchronises)."""
+        hit = bool(self.words.any().item())
+        if hit and reset:
+            self.words.zero_()
+        return hit
+
+    def acts(self, reset=True):
+        """The QuantActs of the launches that saturated since the last reset (synchronises)."""
+        w = self.words.tolist()
+        out = []
+        for i, v in enumerate(w):
+            if v:
+                for a in self.who[i]:
+                    if all(a is not b for b in out):
+                        out.append(a)
+        if reset and any(w):
+            self.words.zero_()
+        return out
+
+
+def _widen(act, frac, low_too):
+    with torch.no_grad():
+        lo, hi = act.x_min.reshape(()), act.x_max.reshape(())
+        span = (hi - lo).clamp_min(1e-6) * frac
+        act.x_max.copy_((hi + span).reshape(act.x_max.shape))
+        if low_too:
+            act.x_min.copy_((lo - span).reshape(act.x_min.shape))
+
+
+def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40):
+    """Calibration of the byte-code serving mode ON THE SCHEDULE THAT SERVES.
+
+    cover_frozen_ranges() records what the MODULE path feeds every QuantAct; the byte network's exact-integer first
+    convolutions flip single codes against that path and a deep network amplifies them, so ranges that cover the module
+    path with 2 % to spare can still saturate a byte on the serving schedule.  Here: (1) cover_frozen_ranges on the
+    module path without margin (a starting point), (2) the byte network itself (``model.enable_fused(frozen_codes=True)``)
+    runs the calibration batches; every launch that saturated a code names its QuantAct(s) through its own flag word
+    (OverflowFlags) and exactly those ranges are widened by `grow` of their span -- repeated until a whole pass is
+    clean; (3) every range gets `margin` of its span to spare and the pass is repeated until clean again.  Only widens.
+    Leaves the model frozen (running_stat False) and on the byte schedule.  Returns a dict (iterations, widened, clean)."""
+    from .portable_quantizer.quant_modules import QuantAct
+    acts = [m for m in model.modules() if isinstance(m, QuantAct)]
+    set_running_stat(model, False)
+    model.enable_fused(False)
+    covered = cover_frozen_ranges(model, batches, margin=0.0)
+    model.enable_fused(frozen_codes=True)
+    # attribution needs one launch per QuantAct: the depthwise-into-pointwise fusion of the byte backbone writes two
+    # QuantActs' codes from one launch (bit-identical to the two kernels), so it is off while calibrating
+    hits, widened, iters = {}, set(), 0
+
+    def one_pass():
+        with torch.no_grad():
+            for b in batches:
+                model(b)
+        fz = getattr(model, "_fzbackbone", None)
+        bad = []
+        for f in (getattr(model, "_ffrozen", None), fz):
+            if f is not None and f._bufs is not None:
+                for a in f._bufs["overflow"].acts():
+                    if all(a is not b_ for b_ in bad):
+                        bad.append(a)
+        return bad
+
+    def until_clean():
+        nonlocal iters
+        while iters < max_iter:
+            iters += 1
+            fz = getattr(model, "_fzbackbone", None)
+            if fz is not None:
+                fz.fuse_dwpw = False
+            bad = one_pass()
+            if not bad:
+                return True
+            for a in bad:
+                hits[id(a)] = hits.get(id(a), 0) + 1
+                _widen(a, grow, bool(a.x_min.reshape(()) < 0) or hits[id(a)] >= 3)
+                widened.add(id(a))
+        return False
+    with torch.no_grad():
+        model(batches[0])                   # builds the byte-code objects
+    clean = until_clean()
+    if clean and margin > 0:
+        for a in acts:
+            _widen(a, margin, bool(a.x_min.reshape(()) < 0))
+        clean = until_clean()
+    fz = getattr(model, "_fzbackbone", None)
+    if fz is not None:
+        fz.fuse_dwpw = True
+        with torch.no_grad():
+            for b in batches:               # the serving configuration itself (fused depthwise) must be clean too
+                model(b)
+        clean = clean and not model.frozen_overflowed()
+    return {"iterations": iters, "covered_on_module_path": covered, "widened_on_byte_schedule": len(widened),
+            "clean": bool(clean), "byte_backbone": fz is not None}
+
+
+def prepare_serving(model, images, settle=300, margin=0.02, replay=None):
+    """The serving recipe bench.py's `e2e.frozen` leg times and tests/test_harness.py checks on three seeds: let the
+    running (EMA) ranges settle over `settle` forwards of `images` (replay: an already captured graph of the running
+    network), freeze every QuantAct, calibrate ON THE BYTE SCHEDULE (calibrate_serving).  Leaves the model on
+    enable_fused(frozen_codes=True); returns calibrate_serving's report."""
+    if replay is None:
+        model.enable_fused()
+        with torch.no_grad():
+            for _ in range(settle):
+                model(images)
+    else:
+        for _ in range(settle):
+            replay()
+    torch.cuda.synchronize()
+    return calibrate_serving(model, [images], margin=margin)
 
 
 def broadcast_parameters(net, src=0):
@@ -462,7 +614,8 @@ class FusedHotPath:
                               act._device_state(x.device).data_ptr()]
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
                 rc = lib.cdn_codenet_stage_fused_forward(
-                    cur.data_ptr(), cur_nhwc, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                    cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0), sb["up"], cur_q, Nb, sb["C"], sb["Co"],
+                    sb["H"], sb["W"],
                     ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
                     ptr(p["w_dw"]), ptr(p["w_pw"]),
                     *([ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]),
@@ -571,12 +724,18 @@ class FrozenHotPath:
             key=key, stages=bufs, sums_all=sums_all,
             ws=torch.empty(ws_bytes + 512, dtype=torch.uint8, device=dev),
             ws32=torch.zeros(ws32_bytes // 4 + 64, device=dev) if ws32_bytes else None,
-            overflow=torch.zeros(1, dtype=torch.int32, device=dev),
+            overflow=OverflowFlags(len(bufs) + 16, dev),      # word i: stage i; words n .. n+15: the byte-code heads
             expanded=torch.empty(Nb, last["H"] * last["W"], last["Co"], device=dev),
             out=torch.empty(Nb, last["Co"], last["H"] * 2, last["W"] * 2, device=dev),
             n_acts=n, acts=acts,      # (kept alive: the pointer arrays below refer to their buffers)
             p_min=arr(*[a.x_min.data_ptr() for a in acts]), p_max=arr(*[a.x_max.data_ptr() for a in acts]),
             p_state=arr(*[a._device_state(dev).data_ptr() for a in acts]))
+        for i, st in enumerate(self.stages):
+            self._bufs["overflow"].name(i, self._acts(st))
+
+    def head_flags(self):
+        """the flag words the byte-code heads number from 0 (FusedHeads.forward_codes)"""
+        return self._bufs["overflow"].slice(len(self.stages))
 
     def forward_codes(self, x, x_qstate=None, hw=None):
         """-> (r8 [N, H*W, Co] int8 codes of the last stage's output QuantAct (or the fp32 tensor when that stage
@@ -634,10 +793,11 @@ class FrozenHotPath:
                     if sb["sums"] is not None:
                         nsc_ptr = self.stages[si + 1][0].quant_conv_scale.int8_form()[0].data_ptr()
                     rc = lib.cdn_codenet_stage_frozen_chained_forward(
-                        cur_ptr, cur_kind, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                        cur_ptr, cur_kind | getattr(self, "gather_flag", 0), sb["up"], cur_q, Nb, sb["C"], sb["Co"],
+                        sb["H"], sb["W"],
                         ptr(w_sc), ptr(q.quant_conv_scale.bias), float(bound.min_val), float(bound.max_val),
                         ptr(w_dw), ptr(codes), ptr(scale), ptr(colsum), ptr(b_pw), 1, sp[0], sp[1], sp[2],
-                        ws_ptr, ws_bytes, sb["r8"].data_ptr(), B["overflow"].data_ptr(),
+                        ws_ptr, ws_bytes, sb["r8"].data_ptr(), B["overflow"].ptr(si),
                         ptr(sums_in), sw_ptr, nsc_ptr, ptr(sb["sums"]), stream)
                     N_.check(rc, "cdn_codenet_stage_frozen_chained_forward")
                     cur_ptr, cur_kind, cur_q = sb["r8"].data_ptr(), 2, sp[2]
@@ -693,10 +853,7 @@ class FrozenHotPath:
         batches computed in between must be recomputed with FusedHotPath (running_stat False)."""
         if self._bufs is None:
             return False
-        flag = bool(self._bufs["overflow"].item())
-        if flag:
-            self._bufs["overflow"].zero_()
-        return flag
+        return self._bufs["overflow"].any()
 
     def capture(self, x, codes_only=True, x_qstate=None, hw=None):
         """One pass over the static buffer `x` as a HIP graph; returns replay() -> the static output (byte codes
@@ -957,8 +1114,8 @@ class FusedHeads:
         the codes of quant_act1 written as bytes) and the row-streaming tail reading those bytes
         (cdn_codenet_head_tail_small_q8_forward); no range passes, no fp32 copy of the stage output or of y1.
         Same values as ``__call__`` on the expanded codes with the same frozen states (the first 1x1 conv is the same
-        integer sum; the tail decodes a code to the value its fp32 form fake-quantises to).  `overflow`: the int32 flag
-        a saturated y1 code sets."""
+        integer sum; the tail decodes a code to the value its fp32 form fake-quantises to).  `overflow`: an OverflowFlags
+        (word 2i: head i's y1 codes, word 2i + 1: its tail) or an int32 tensor (one word for everything)."""
         import ctypes
         from . import _native as N_
         dev = r8.device
@@ -1002,14 +1159,20 @@ class FusedHeads:
                 q2 = l2["act"]._device_state(dev).data_ptr()
                 c1, s1, k1 = l1["i8"]
                 y8 = B["y8"][hi]
+                if isinstance(overflow, OverflowFlags) and 2 * hi + 1 < overflow.count():
+                    of1, of2 = overflow.ptr(2 * hi), overflow.ptr(2 * hi + 1)
+                    overflow.name(2 * hi, [l1["act"]])
+                    overflow.name(2 * hi + 1, [l2["act"]])
+                else:
+                    of1 = of2 = overflow.data_ptr()
                 rc = lib.cdn_codenet_pointwise_q8_forward(
                     r8.data_ptr(), r_qstate, M, 64, 64, c1.data_ptr(), s1.data_ptr(), k1.data_ptr(), ptr(l1["bias"]),
-                    1, q1, y8.data_ptr(), None, overflow.data_ptr(), st.cuda_stream)
+                    1, q1, y8.data_ptr(), None, of1, st.cuda_stream)
                 N_.check(rc, "cdn_codenet_pointwise_q8_forward")
                 i8 = l3["i8"]
                 rc = lib.cdn_codenet_head_tail_small_q8_forward(
                     y8.data_ptr(), q1, Nb, 64, Hs, Ws, ptr(l2["w"]), ptr(l2["bias"]), q2, ptr(i8[0]), ptr(i8[1]),
-                    ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), overflow.data_ptr(),
+                    ptr(i8[2]), ptr(l3["bias"]), l3["w"].shape[0], B["out"][name].data_ptr(), of2,
                     st.cuda_stream)
                 N_.check(rc, "cdn_codenet_head_tail_small_q8_forward")
         for sd in forked:
@@ -1599,10 +1762,7 @@ class FrozenBackbone:
     def overflowed(self):
         if self._bufs is None:
             return False
-        flag = bool(self._bufs["overflow"].item())
-        if flag:
-            self._bufs["overflow"].zero_()
-        return flag
+        return self._bufs["overflow"].any()
 
     def _alloc(self, images, key):
         import ctypes
@@ -1615,9 +1775,21 @@ class FrozenBackbone:
                     acts.append(a)
         arr = ctypes.c_void_p * len(acts)
         self._bufs = dict(
-            key=key, layers={}, overflow=torch.zeros(1, dtype=torch.int32, device=dev), acts=acts, n_acts=len(acts),
+            key=key, layers={}, overflow=OverflowFlags(len(acts), dev), acts=acts, n_acts=len(acts),
             p_min=arr(*[a.x_min.data_ptr() for a in acts]), p_max=arr(*[a.x_max.data_ptr() for a in acts]),
             p_state=arr(*[a._device_state(dev).data_ptr() for a in acts]))
+        for i, a in enumerate(acts):            # word i: the launches that write act i's codes
+            self._bufs["overflow"].name(i, [a])
+
+    def _of(self, *acts):
+        """the flag word of the launch writing `acts[0]`'s codes (a fused launch writing two QuantActs' codes is
+        attributed to both)"""
+        B = self._bufs
+        i = next(k for k, a in enumerate(B["acts"]) if a is acts[0])
+        for extra in acts[1:]:
+            if all(extra is not b for b in B["overflow"].who[i]):
+                B["overflow"].who[i].append(extra)      # (the backbone's flags are never sliced: word i == who[i])
+        return B["overflow"].ptr(i)
 
     @staticmethod
     def _ld(c):
@@ -1638,18 +1810,18 @@ class FrozenBackbone:
             z = lambda m_, c_: torch.zeros(m_, c_, dtype=torch.int8, device=dev)   # noqa: E731
             L = B["layers"][name] = dict(Y=z(Mo, ldc), t4=z(Mo, ldi), t1s2=z(Mi, ldh), t1=z(Mo, ldh), t2=z(Mo, ldh))
         main = torch.cuda.current_stream(dev)
-        of, st = B["overflow"].data_ptr(), main.cuda_stream
+        st = main.cuda_stream
         qp = lambda act: act._device_state(dev).data_ptr()   # noqa: E731
 
         def pw(a, a_state, M, K, lda, Wt, act, out, ldo, omap, st=st):
             rc = lib.cdn_codenet_pointwise_q8_strided_forward(
                 a.data_ptr(), a_state, M, K, Wt["Co"], lda, ldo, Wt["codes"].data_ptr(), Wt["scale"].data_ptr(),
-                Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), 1, omap, qp(act), out.data_ptr(), None, of, st)
+                Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), 1, omap, qp(act), out.data_ptr(), None, self._of(act), st)
             N_.check(rc, "cdn_codenet_pointwise_q8_strided_forward")
 
         def dw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, out, ld_out, st=st):
             rc = lib.cdn_codenet_dw3x3_q8_forward(a.data_ptr(), a_state, Nb, Cc, Hs, Ws, stride, ld_in, ld_out,
-                                                  w.data_ptr(), b.data_ptr(), 0, qp(act), out.data_ptr(), of, st)
+                                                  w.data_ptr(), b.data_ptr(), 0, qp(act), out.data_ptr(), self._of(act), st)
             N_.check(rc, "cdn_codenet_dw3x3_q8_forward")
 
         def dwpw(a, a_state, Cc, Hs, Ws, stride, ld_in, w, b, act, Wt, out_act, omap, tmp=None, st=st):
@@ -1659,7 +1831,7 @@ class FrozenBackbone:
                 rc = lib.cdn_codenet_dwpw_q8_forward(
                     a.data_ptr(), a_state, Nb, Cc, Hs, Ws, stride, ld_in, w.data_ptr(), b.data_ptr(), 0, qp(act),
                     Wt["Co"], Wt["codes"].data_ptr(), Wt["scale"].data_ptr(), Wt["colsum"].data_ptr(),
-                    Wt["bias"].data_ptr(), 1, ldc, omap, qp(out_act), Y.data_ptr(), of, st)
+                    Wt["bias"].data_ptr(), 1, ldc, omap, qp(out_act), Y.data_ptr(), self._of(out_act, act), st)
                 N_.check(rc, "cdn_codenet_dwpw_q8_forward")
                 return
             tmp = L["t2"] if tmp is None else tmp
@@ -1723,7 +1895,7 @@ class FrozenBackbone:
                 B["x0"] = torch.zeros(Nb, H * W, 32, dtype=torch.int8, device=dev)
             rc = lib.cdn_codenet_stem_q8_forward(images.data_ptr(), Nb, R, R2, 24, s0, w0.reshape(24, 27).data_ptr(),
                                                  b0.data_ptr(), 1, act0._device_state(dev).data_ptr(),
-                                                 B["x0"].data_ptr(), 32, B["overflow"].data_ptr(), st)
+                                                 B["x0"].data_ptr(), 32, self._of(act0), st)
             N_.check(rc, "cdn_codenet_stem_q8_forward")
             x8, x_ld, x_state, logical = B["x0"], 32, act0._device_state(dev).data_ptr(), None
             if len(m.layer0[1]) == 3:                        # "S2 + MaxPool" stems (README configs b, e): pool the codes
@@ -1743,6 +1915,6 @@ class FrozenBackbone:
             rc = lib.cdn_codenet_pointwise_q8_strided_forward(
                 x8.data_ptr(), x_state, Nb * H * W, W4["K"], c4, x_ld, c4, W4["codes"].data_ptr(),
                 W4["scale"].data_ptr(), W4["colsum"].data_ptr(), W4["bias"].data_ptr(), 1, None,
-                act4._device_state(dev).data_ptr(), B["out"].data_ptr(), None, B["overflow"].data_ptr(), st)
+                act4._device_state(dev).data_ptr(), B["out"].data_ptr(), None, self._of(act4), st)
             N_.check(rc, "cdn_codenet_pointwise_q8_strided_forward (layer4)")
         return B["out"], act4._device_state(dev).data_ptr(), (H, W)

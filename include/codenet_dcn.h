@@ -20,9 +20,11 @@
  *     (activations) with int8 code paths where stated.  fp16 tensors (the reference also dispatches half,
  *     dcn_deform_conv_cuda_kernel.cu:258,352,450) are served by the binding above this ABI: the call runs on fp32
  *     copies and results are rounded to half once (codenet_amd/_ext/dcn/dcn_deform_conv_cuda.py).
- *   - Re-entrant, no global mutable state; safe to call concurrently from several host
+ *   - Re-entrant, no global mutable state (the only per-thread state: the cdn_last_error() message and the
+ *     optional cdn_profile_* event list, both thread-local); safe to call concurrently from several host
  *     threads on different streams / devices (the current HIP device must be the one that
- *     owns the pointers).
+ *     owns the pointers).  tests/test_gpu_parity.py::test_stage_entry_points_from_two_threads drives two
+ *     streams from two threads concurrently against the serial result.
  */
 #ifndef CODENET_DCN_H_
 #define CODENET_DCN_H_
@@ -319,11 +321,16 @@ size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_
  * channel chunks up to ~4800 stored pixels = inputs up to ~1100 px), 0 otherwise: callers then keep the
  * module path (cdn_codenet_{scale,dw,pointwise}_forward, any plane size). */
 int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
-/* Schedule of the gather for an NCHW input at output resolution (stage 0): 0 = automatic (default: the persistent
- * LDS-DMA kernel when every CU gets >= 2 items, the per-item kernel otherwise), 1 = always the per-item kernel,
- * 2 = persistent wherever its shape conditions hold.  Both compute bit-identical results (tests compare them);
- * process-wide, returns the previous mode.  No reference counterpart (tuning knob). */
-int cdn_codenet_set_gather_mode(int mode);
+/* Schedule of the gather for an NCHW input at output resolution (stage 0) -- a PER-CALL choice OR-ed into the layout
+ * argument of the stage entry points (`x_nhwc` of cdn_codenet_stage_fused_forward, `x_kind` of
+ * cdn_codenet_stage_frozen[_chained]_forward); the library keeps no setting of its own (round 4: this replaces the
+ * process-wide cdn_codenet_set_gather_mode, which contradicted "no global mutable state" above).  Nothing OR-ed in =
+ * automatic (the persistent LDS-DMA kernel when every CU gets >= 2 items, the per-item kernel otherwise);
+ * CDN_X_GATHER_PER_ITEM = always the per-item kernel; CDN_X_GATHER_PERSISTENT = persistent wherever its shape
+ * conditions hold.  All compute bit-identical results (tests compare them).  No reference counterpart. */
+#define CDN_X_GATHER_PER_ITEM 0x100
+#define CDN_X_GATHER_PERSISTENT 0x200
+#define CDN_X_GATHER_MASK 0x300
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
@@ -598,7 +605,8 @@ int cdn_ctdet_decode(const float *heat, const float *wh, const float *reg, int64
  * their W-mirrors (P .. 2P-1; P = 1 is the reference's layout) ->
  *   hm <- sigmoid(hm) IN PLACE (the reference's hm.sigmoid_() on the whole batch),
  *   hm_out [P][cat][H][W] = (hm[p] + flip_W(hm[P + p])) / 2,   wh_out = (wh[p] + flip_W(wh[P + p])) / 2
- * (decode then takes hm_out without a sigmoid and reg[0 .. P-1]).  hm_out / wh_out must not alias the inputs. */
+ * (decode then takes hm_out without a sigmoid and reg[0 .. P-1]).  hm_out / wh_out must not overlap the inputs nor each
+ * other (CDN_ERR_ARG). */
 int cdn_ctdet_flip_merge(float *hm, const float *wh, int64_t P, int64_t cat, int64_t wh_ch, int64_t H, int64_t W,
                          float *hm_out, float *wh_out, void *stream);
 

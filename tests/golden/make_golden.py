@@ -16,6 +16,7 @@ Fixtures
   model_io.npz      F5: the reference's whole PoseShuffleNetV2 at 256x256 (image + flip), fp32 and
                     W4A8, through CtdetDetector.process' body: sub-sampled hm/wh/reg, checksums and
                     the decoded detections [1,100,6] (weights: codenet_amd.harness.fill_state_dict_).
+  model_io_512.npz / model_noise_512.npz   the same two at the BASELINE resolution 512x512 (seed 52).
   model_noise.npz   the reference W4A8 model against ITSELF with 1 vs 8 CPU threads (code-flip noise floor).
   voc_eval_ref.npz  the reference's own VOC evaluator (tools/voc_eval_lib/datasets/voc_eval.py, pure numpy) over a
                     synthetic VOC tree: rec / prec / AP per class (difficult objects, duplicates, partial recall).
@@ -445,19 +446,20 @@ def make_deform_raw():
     return t2n(out)
 
 
-def make_model_io(ref_qm):
+def make_model_io(ref_qm, res=256, seed=51):
     """F5: the reference's whole PoseShuffleNetV2 (256x256, image + W-flip, seed-filled weights) in
-    fp32 and W4A8 through the body of CtdetDetector.process; native deform_conv -> oracle."""
+    fp32 and W4A8 through the body of CtdetDetector.process; native deform_conv -> oracle.
+    res=512 (model_io_512.npz): the same at the BASELINE resolution (VERDICT r3 "next" #5)."""
     import models.networks.shufflenetv2_dcn as ref_net
     from models.decode import ctdet_decode as ref_decode
     from models.utils import flip_tensor
     from portable_quantizer import quantize_shufflenetv2_dcn as ref_quantize
     from codenet_amd.harness import fill_state_dict_
     heads = {"hm": 20, "wh": 2, "reg": 2}
-    g = torch.Generator().manual_seed(51)
-    img = torch.randn(1, 3, 256, 256, generator=g)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(1, 3, res, res, generator=g)
     images = torch.cat([img, torch.flip(img, [3])], dim=0)
-    out = {"image_seed": np.array(51)}          # images are re-generated from the seed by the tests
+    out = {"image_seed": np.array(seed), "res": np.array(res)}     # images are re-generated from the seed by the tests
     for tag, quant in (("fp32", False), ("w4a8", True)):
         net = ref_net.PoseShuffleNetV2(heads, 64)
         fill_state_dict_(net, 317)
@@ -483,7 +485,7 @@ def make_model_io(ref_qm):
     return t2n(out)
 
 
-def make_model_noise(ref_qm):
+def make_model_noise(ref_qm, res=256, seed=51):
     """The REFERENCE against itself: its W4A8 PoseShuffleNetV2 (same weights / images as model_io.npz) run with
     1 and with 8 CPU threads.  Only the summation order inside torch's CPU convolutions changes, yet 8-bit codes
     flip where a value sits on a rounding boundary and ~70 re-quantising layers amplify the flips.  These
@@ -496,8 +498,8 @@ def make_model_noise(ref_qm):
     from portable_quantizer import quantize_shufflenetv2_dcn as ref_quantize
     from codenet_amd.harness import fill_state_dict_
     heads = {"hm": 20, "wh": 2, "reg": 2}
-    g = torch.Generator().manual_seed(51)
-    img = torch.randn(1, 3, 256, 256, generator=g)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(1, 3, res, res, generator=g)
     images = torch.cat([img, torch.flip(img, [3])], dim=0)
     net = ref_net.PoseShuffleNetV2(heads, 64)
     fill_state_dict_(net, 317)
@@ -691,6 +693,8 @@ def main():
         "deform_raw": make_deform_raw,
         "model_io": lambda: make_model_io(ref_qm),
         "model_noise": lambda: make_model_noise(ref_qm),
+        "model_io_512": lambda: make_model_io(ref_qm, res=512, seed=52),
+        "model_noise_512": lambda: make_model_noise(ref_qm, res=512, seed=52),
         "head_w4a8": lambda: make_head_w4a8(ref_qm),
         "decode_ref": make_decode,
         "base_nodes": lambda: make_base_nodes(ref_qm),

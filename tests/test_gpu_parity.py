@@ -871,3 +871,53 @@ def test_fused_range_update_is_the_reference_two_rounding_ema_bit_exactly():
             assert f(a.x_min.item()) == want_lo and f(a.x_max.item()) == want_hi, (it, k)
             checked += 1
     assert checked == 180
+
+
+def test_stage_entry_points_from_two_threads():
+    """include/codenet_dcn.h: "Re-entrant, no global mutable state; safe to call concurrently from several host threads
+    on different streams" (the reference is called from DataParallel threads, lib/models/data_parallel.py:64-84; its
+    extension has no global state, dcn_deform_conv_cuda.cpp:681-695).  Round 3 still had a process-wide gather-mode
+    setter; it is a per-call argument now.  Two threads, each with its own stream, its own copy of the W4A8 stages and
+    a different gather schedule flag, run the fused stage entry points concurrently; outputs and all QuantAct ranges
+    equal the serial runs bit for bit."""
+    import copy
+    import threading
+    from codenet_amd import pipeline
+    CFG = [(1024, 256, 16), (256, 128, 32), (128, 64, 64)]
+    net = pipeline.build_hot_path(quantized=True, planes=CFG, seed=77)
+    pipeline.set_running_stat(net, True)
+    g = torch.Generator().manual_seed(78)
+    xs = [(torch.randn(32, 1024, 16, 16, generator=g).abs_() * 1.66).cuda() for _ in range(4)]
+    flags = [pipeline.GATHER_PER_ITEM, pipeline.GATHER_PERSISTENT]
+
+    def run(flag, stream, out, barrier=None):
+        m = copy.deepcopy(net).cuda()
+        f = pipeline.FusedHotPath(m.deconv_layers)
+        f.gather_flag = flag
+        with torch.cuda.stream(stream):
+            ys = []
+            for it in range(6):
+                if barrier is not None:
+                    barrier.wait()
+                ys.append(f(xs[it % len(xs)]).clone())
+            stream.synchronize()
+        out.append((ys, {n: b.clone() for n, b in m.named_buffers() if n.endswith(("x_min", "x_max"))}))
+
+    serial = []
+    for fl in flags:
+        run(fl, torch.cuda.Stream(), serial)
+    par = [[], []]
+    bar = threading.Barrier(2)
+    ts = [threading.Thread(target=run, args=(flags[i], torch.cuda.Stream(), par[i], bar)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        assert par[i], "thread %d failed" % i
+        ys, rng = par[i][0]
+        ys0, rng0 = serial[i]
+        assert all(torch.equal(a, b) for a, b in zip(ys, ys0))
+        assert all(torch.equal(rng[k], rng0[k]) for k in rng0)
+    # and the two schedules agree with each other (bit-identical kernels)
+    assert all(torch.equal(a, b) for a, b in zip(serial[0][0], serial[1][0]))

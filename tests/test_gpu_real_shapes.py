@@ -209,18 +209,13 @@ def test_persistent_dma_gather_is_bit_identical_to_per_item_gather(res, n, quant
         pipeline.set_running_stat(a, True)
         pipeline.set_running_stat(b, True)
     fa, fb = pipeline.FusedHotPath(a.deconv_layers), pipeline.FusedHotPath(b.deconv_layers)
-    old = lib.cdn_codenet_set_gather_mode(1)
-    try:
-        for x in xs:
-            lib.cdn_codenet_set_gather_mode(1)
-            ya = fa(x).clone()
-            lib.cdn_codenet_set_gather_mode(2)
-            yb = fb(x).clone()
-            assert torch.equal(ya, yb)
-            if quantized:
-                assert _gpu_ranges(a) == _gpu_ranges(b)
-    finally:
-        lib.cdn_codenet_set_gather_mode(old)
+    fa.gather_flag, fb.gather_flag = pipeline.GATHER_PER_ITEM, pipeline.GATHER_PERSISTENT     # a per-call argument
+    for x in xs:
+        ya = fa(x).clone()
+        yb = fb(x).clone()
+        assert torch.equal(ya, yb)
+        if quantized:
+            assert _gpu_ranges(a) == _gpu_ranges(b)
 
 
 def test_persistent_dma_gather_frozen_codes_bit_identical():
@@ -235,11 +230,8 @@ def test_persistent_dma_gather_frozen_codes_bit_identical():
         fused(x)
     pipeline.set_running_stat(net, False)
     frz = pipeline.FrozenHotPath(net.deconv_layers)
-    old = lib.cdn_codenet_set_gather_mode(1)
-    try:
-        ca = frz.forward_codes(xs[0])[0].clone()
-        lib.cdn_codenet_set_gather_mode(2)
-        cb = frz.forward_codes(xs[0])[0].clone()
-        assert ca.dtype == torch.int8 and torch.equal(ca, cb) and not frz.overflowed()
-    finally:
-        lib.cdn_codenet_set_gather_mode(old)
+    frz.gather_flag = pipeline.GATHER_PER_ITEM
+    ca = frz.forward_codes(xs[0])[0].clone()
+    frz.gather_flag = pipeline.GATHER_PERSISTENT
+    cb = frz.forward_codes(xs[0])[0].clone()
+    assert ca.dtype == torch.int8 and torch.equal(ca, cb) and not frz.overflowed()

@@ -10,12 +10,8 @@ dev = torch.device("cuda", 0)
 model = harness.create_model(quantize=True).to(dev)
 model.enable_fused()
 images = torch.randn(64, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(dev)
+print("calibration", pipeline.prepare_serving(model, images, settle=30, margin=0.02))
 with torch.no_grad():
-    for _ in range(30):
-        model(images)
-    pipeline.set_running_stat(model, False)
-    model.enable_fused(False)
-    pipeline.cover_frozen_ranges(model, [images], margin=0.02)
     model.enable_fused(frozen_codes=True, frozen_backbone=not stages_only)
     for _ in range(3):
         model(images)
