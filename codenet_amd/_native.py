@@ -56,6 +56,12 @@ _SIGNATURES = {
     "cdn_quantact_forward": (_i, [_vp] * 3 + [_i64] + [_vp] * 5 + [_i, _d, _i, _vp]),
     "cdn_quantact_relu_up2_forward": (_i, [_vp, _vp] + [_i64] * 3 + [_vp] * 3 + [_i, _d, _i, _vp]),
     "cdn_up2_relu_backward": (_i, [_vp] * 3 + [_i64] * 3 + [_vp]),
+    "cdn_quantact_relu_forward": (_i, [_vp, _vp, _i64] + [_vp] * 4 + [_i64, _i, _d, _i, _vp]),
+    "cdn_relu_backward": (_i, [_vp] * 3 + [_i64, _vp]),
+    "cdn_codenet_dw_up2_supported": (_i, [_i64] * 4),
+    "cdn_codenet_dw_up2_range_partials": (_i64, [_i64] * 4),
+    "cdn_codenet_dw_up2_forward": (_i, [_vp] * 4 + [_i64] * 4 + [_vp, _vp]),
+    "cdn_codenet_dw_up2_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
     "cdn_codenet_stage_workspace_bytes": (ctypes.c_size_t, [_i64] * 4 + [_i]),
     "cdn_codenet_stage_fused_forward": (
         _i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 8 + [_i] + [_vp] * 9

@@ -191,7 +191,9 @@ relu_fq_up2_kernel(const float *__restrict__ y, float *__restrict__ out, long ro
     const long r = i / Wh;
     const int w0 = (int)(i - r * Wh) * 2;
     const bool two = w0 + 1 < W;
-    const float a = fmaxf(y[r * W + w0], 0.0f), b = two ? fmaxf(y[r * W + w0 + 1], 0.0f) : 0.0f;
+    // (ReLU that propagates NaN like torch's threshold, so that a diverged step is not hidden: ADVICE r3)
+    const float ya = y[r * W + w0], yb = two ? y[r * W + w0 + 1] : 0.0f;
+    const float a = ya > 0.0f ? ya : (ya != ya ? ya : 0.0f), b = yb > 0.0f ? yb : (yb != yb ? yb : 0.0f);
     const float qa = __fdiv_rn(__fadd_rn(quant_code(a, scale, zp), zp), scale);
     const float qb = __fdiv_rn(__fadd_rn(quant_code(b, scale, zp), zp), scale);
     float *o = out + (r * 2) * (2L * W) + 2 * w0;
@@ -204,6 +206,36 @@ relu_fq_up2_kernel(const float *__restrict__ y, float *__restrict__ out, long ro
       if (two) { o[2] = qb; o[3] = qb; o[2L * W + 2] = qb; o[2L * W + 3] = qb; }
     }
   }
+}
+
+// The same block WITHOUT the up-sampling (round 4: stages 1-2 of the QAT step read their input at stored resolution,
+// cdn_codenet_dw_up2_*): out[i] = fake_quant(max(y[i], 0)), and its backward grad_y = grad_out where y > 0.
+__global__ void __launch_bounds__(256)
+relu_fq_kernel(const float *__restrict__ y, float *__restrict__ out, long n, const unsigned *__restrict__ state) {
+  const float scale = reinterpret_cast<const float *>(state)[2];
+  const float zp = reinterpret_cast<const float *>(state)[3];
+  const long n4 = n >> 2;
+  auto fq = [&](float v) {
+    const float a = v > 0.0f ? v : (v != v ? v : 0.0f);         // ReLU that propagates NaN like torch's
+    return __fdiv_rn(__fadd_rn(quant_code(a, scale, zp), zp), scale);
+  };
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4 *>(y)[i];
+    reinterpret_cast<float4 *>(out)[i] = make_float4(fq(v.x), fq(v.y), fq(v.z), fq(v.w));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = fq(y[i]);
+}
+__global__ void __launch_bounds__(256)
+relu_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, float *__restrict__ gy, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4 *>(y)[i], a = reinterpret_cast<const float4 *>(g)[i];
+    reinterpret_cast<float4 *>(gy)[i] = make_float4(v.x > 0.f ? a.x : 0.f, v.y > 0.f ? a.y : 0.f, v.z > 0.f ? a.z : 0.f,
+                                                    v.w > 0.f ? a.w : 0.f);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    gy[i] = y[i] > 0.f ? g[i] : 0.f;
 }
 
 // backward of that block: grad_y[r][w] = (sum of the 2x2 replicas' gradients) * (y > 0)   (straight-through QuantAct,
@@ -313,7 +345,7 @@ extern "C" int cdn_quantact_forward_partials(const float *x, float *out, int64_t
 
 static int relu_up2_impl(const float *y, float *out, int64_t planes, int64_t H, int64_t W, float *x_min, float *x_max,
                          void *state, const float *partials, int64_t n_partials, int bits, double momentum, int running,
-                         void *stream) {
+                         void *stream, int up = 1) {
   CDN_REQUIRE(y && out && x_min && x_max && state, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * H * W < (1ll << 31), CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
@@ -332,9 +364,28 @@ static int relu_up2_impl(const float *y, float *out, int64_t planes, int64_t H, 
     cdn::launch_quantact_update(x_min, x_max, stt, nullptr, nullptr, nullptr, 0, bits, momentum, running, st);
   }
   const long rows = (long)(planes * H);
-  relu_fq_up2_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
-                       256, 0, st>>>(y, out, rows, (int)W, stt);
-  return cdn::check_launch("quantact relu up2 forward");
+  if (up)
+    relu_fq_up2_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
+                         256, 0, st>>>(y, out, rows, (int)W, stt);
+  else
+    relu_fq_kernel<<<stream_grid(numel), 256, 0, st>>>(y, out, numel, stt);
+  return cdn::check_launch("quantact relu [up2] forward");
+}
+
+extern "C" int cdn_quantact_relu_forward(const float *y, float *out, int64_t numel, float *x_min, float *x_max,
+                                         void *state, const float *partials, int64_t n_partials, int bits,
+                                         double momentum, int running, void *stream) {
+  CDN_REQUIRE(partials == nullptr || (n_partials > 0 && n_partials < (1ll << 31)), CDN_ERR_ARG, "bad partials");
+  return relu_up2_impl(y, out, numel, 1, 1, x_min, x_max, state, partials, n_partials, bits, momentum, running, stream,
+                       0);
+}
+
+extern "C" int cdn_relu_backward(const float *grad_out, const float *y, float *grad_y, int64_t numel, void *stream) {
+  CDN_REQUIRE(grad_out && y && grad_y && numel > 0 && numel < (1ll << 31), CDN_ERR_ARG, "null pointer / bad size");
+  CDN_REQUIRE(((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(y) |
+                reinterpret_cast<uintptr_t>(grad_y)) & 15) == 0, CDN_ERR_ARG, "tensors must be 16-byte aligned");
+  relu_bwd_kernel<<<stream_grid(numel), 256, 0, cdn::as_stream(stream)>>>(grad_out, y, grad_y, (long)numel);
+  return cdn::check_launch("relu backward");
 }
 
 extern "C" int cdn_quantact_relu_up2_forward(const float *y, float *out, int64_t planes, int64_t H, int64_t W,

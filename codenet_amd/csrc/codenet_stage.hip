@@ -203,6 +203,12 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
 // of 100 LDS reads per pixel and quad; consecutive lanes = consecutive pixels read consecutive 16-byte cells).  Same
 // per-channel expressions in the same order: bit-identical to dw_kernel.  C % 4 == 0, CC % 4 == 0.
 // ------------------------------------------------------------------------------------------
+// UP (round 4, stages 1-2 of the QAT step): x and s are given at STORED resolution -- x [N][C][H/2][W/2] is the tensor
+// whose nearest x2 up-sampling the stage reads, s [N][H/2][W/2] is constant over each 2x2 block (a 1x1 conv of a
+// replicated tensor) -- and the planes in LDS are the stored ones: the full-resolution corner (yy, xx) is the stored
+// cell (yy >> 1, xx >> 1).  Same per-pixel expressions on the same values: d is bit-identical to the kernel run on the
+// materialised up-sampled tensor, which is never written or read (4x less staging, 4x less LDS per channel).
+template <bool UP>
 __global__ void __launch_bounds__(kDwThreads)
 dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
            float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm) {
@@ -210,33 +216,41 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
   __shared__ float red_mm[8];
   float mn = INFINITY, mx = -INFINITY;
   const int HW = H * W;
-  const int Wp = W + 2, Hp = H + 2;
+  const int Hl = UP ? H >> 1 : H, Wl = UP ? W >> 1 : W;   // resolution of the planes in LDS
+  const int HWl = Hl * Wl;
+  const int Wp = Wl + 2, Hp = Hl + 2;
   const int pstride = Hp * Wp;
   const int n = blockIdx.y;
   const int c0 = blockIdx.x * CC;
   const int cc = min(CC, C - c0);                         // (a multiple of 4)
-  const float *xg = x + ((long)n * C + c0) * HW;
+  const float *xg = x + ((long)n * C + c0) * HWl;
   float *wl = smem;                                       // [CC][9] depthwise weights
   float4 *planes = reinterpret_cast<float4 *>(smem + ((CC * 9 + 3) & ~3));   // [CC / 4][Hp][Wp] of channel quads
   for (int q = threadIdx.x; q < cc * 9; q += kDwThreads) wl[q] = wd[(long)c0 * 9 + q];
   for (int q = threadIdx.x; q < (cc >> 2) * pstride; q += kDwThreads) planes[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  for (int q = threadIdx.x; q < cc * HW; q += kDwThreads) {
-    const int ch = q / HW, r = q - ch * HW;
-    const int yy = r / W, xx = r - yy * W;
+  for (int q = threadIdx.x; q < cc * HWl; q += kDwThreads) {
+    const int ch = q / HWl, r = q - ch * HWl;
+    const int yy = r / Wl, xx = r - yy * Wl;
     reinterpret_cast<float *>(planes)[(((ch >> 2) * pstride + (yy + 1) * Wp + xx + 1) << 2) + (ch & 3)] = xg[q];
   }
   __syncthreads();
   for (int p = threadIdx.x; p < HW; p += kDwThreads) {
     const int h = p / W, w = p - h * W;
-    const float t = s[(long)n * HW + p] - 1.0f;
+    const float t = (UP ? s[(long)n * HWl + (h >> 1) * Wl + (w >> 1)] : s[(long)n * HW + p]) - 1.0f;
     const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
     const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
-    const int b00 = (ya.i0 + 1) * Wp + xa.i0 + 1, b02 = (ya.i0 + 1) * Wp + xb.i0 + 1;
-    const int b20 = (yb.i0 + 1) * Wp + xa.i0 + 1, b22 = (yb.i0 + 1) * Wp + xb.i0 + 1;
-    const int b01 = (ya.i0 + 1) * Wp + w + 1, b21 = (yb.i0 + 1) * Wp + w + 1;
-    const int b10 = (h + 1) * Wp + xa.i0 + 1, b12 = (h + 1) * Wp + xb.i0 + 1;
-    const int b11 = (h + 1) * Wp + w + 1;
+    // row / column of a full-resolution index in the bordered LDS plane, and the step to the next corner
+    auto cell = [&](int i) { return (UP ? (i >> 1) : i) + 1; };
+    auto step = [&](int i) { return UP ? ((i + 1) >> 1) - (i >> 1) : 1; };
+    const int rya = cell(ya.i0) * Wp, ryb = cell(yb.i0) * Wp, rh = cell(h) * Wp;
+    const int cxa = cell(xa.i0), cxb = cell(xb.i0), cw = cell(w);
+    const int dya = step(ya.i0) * Wp, dyb = step(yb.i0) * Wp, dxa = step(xa.i0), dxb = step(xb.i0);
+    const int b00 = rya + cxa, b02 = rya + cxb;
+    const int b20 = ryb + cxa, b22 = ryb + cxb;
+    const int b01 = rya + cw, b21 = ryb + cw;
+    const int b10 = rh + cxa, b12 = rh + cxb;
+    const int b11 = rh + cw;
     // the products of the corner weights, once per pixel (dw_kernel forms the same products per channel)
     const float aa00 = ya.w0 * xa.w0, aa01 = ya.w0 * xa.w1, aa10 = ya.w1 * xa.w0, aa11 = ya.w1 * xa.w1;
     const float ab00 = ya.w0 * xb.w0, ab01 = ya.w0 * xb.w1, ab10 = ya.w1 * xb.w0, ab11 = ya.w1 * xb.w1;
@@ -244,12 +258,12 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
     const float bb00 = yb.w0 * xb.w0, bb01 = yb.w0 * xb.w1, bb10 = yb.w1 * xb.w0, bb11 = yb.w1 * xb.w1;
     for (int g = 0; g < (cc >> 2); ++g) {
       const float4 *pl = planes + g * pstride;
-      const float4 c00 = pl[b00], c01 = pl[b00 + 1], c02 = pl[b00 + Wp], c03 = pl[b00 + Wp + 1];
-      const float4 c20 = pl[b02], c21 = pl[b02 + 1], c22 = pl[b02 + Wp], c23 = pl[b02 + Wp + 1];
-      const float4 c60 = pl[b20], c61 = pl[b20 + 1], c62 = pl[b20 + Wp], c63 = pl[b20 + Wp + 1];
-      const float4 c80 = pl[b22], c81 = pl[b22 + 1], c82 = pl[b22 + Wp], c83 = pl[b22 + Wp + 1];
-      const float4 e10 = pl[b01], e11 = pl[b01 + Wp], e70 = pl[b21], e71 = pl[b21 + Wp];
-      const float4 e30 = pl[b10], e31 = pl[b10 + 1], e50 = pl[b12], e51 = pl[b12 + 1];
+      const float4 c00 = pl[b00], c01 = pl[b00 + dxa], c02 = pl[b00 + dya], c03 = pl[b00 + dya + dxa];
+      const float4 c20 = pl[b02], c21 = pl[b02 + dxb], c22 = pl[b02 + dya], c23 = pl[b02 + dya + dxb];
+      const float4 c60 = pl[b20], c61 = pl[b20 + dxa], c62 = pl[b20 + dyb], c63 = pl[b20 + dyb + dxa];
+      const float4 c80 = pl[b22], c81 = pl[b22 + dxb], c82 = pl[b22 + dyb], c83 = pl[b22 + dyb + dxb];
+      const float4 e10 = pl[b01], e11 = pl[b01 + dya], e70 = pl[b21], e71 = pl[b21 + dyb];
+      const float4 e30 = pl[b10], e31 = pl[b10 + dxa], e50 = pl[b12], e51 = pl[b12 + dxb];
       const float4 ctr = pl[b11];
 #define CDN_DW4_CH(E, OFF)                                                                             \
       {                                                                                                  \
@@ -634,6 +648,294 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
 }
 
 // ------------------------------------------------------------------------------------------
+// dw_bwd2u_kernel (round 4; VERDICT r3 "next" #3): the backward of the gather for a stage whose input is the nearest x2
+// up-sampling of a STORED tensor x [N][C][H/2][W/2] with a scale plane s [N][H/2][W/2] that is constant over each 2x2
+// block of output pixels (stages 1-2 of the QAT step: the stage input is the replicated output of ReLU -> QuantAct ->
+// Upsample and s is a 1x1 conv of it).  dw_bwd2_kernel's structure -- lanes <-> channels, x and the 64-bit fixed-point
+// grad_x accumulator as [cell][CCH] LDS images -- at STORED resolution, one 2x2 block of output pixels per lane step:
+//   * the four pixels share s, so along an axis their 2 + 2 bilinear corners fall onto at most two consecutive stored
+//     cells (make_fold): a corner tap scatters 2 x 2 stored cells for the whole block instead of 16 full-resolution
+//     ones, an edge tap 2 instead of 8, the centre 1 instead of 4 -- 25 LDS atomics (and 25 LDS reads) per block and
+//     channel instead of 100, on images a quarter of the size (4x the channels per workgroup);
+//   * the gradient is accumulated with respect to the STORED tensor directly (the 2x2 sum of the up-sampling backward
+//     happens in registers / in the accumulator), grad_s with respect to the stored scale plane;
+//   * every pixel keeps its own fp32 corner weights (positions are those of the full-resolution kernel, bit for bit);
+//     the four pixels' contributions to a stored cell are added in fp32 before the fixed-point conversion (the
+//     full-resolution kernel converts each one), so grad_x agrees with it to fp32 rounding, not bit for bit.
+// A pair of pixels whose floor indices differ by 2 (pos0 just below an integer, pos1 rounded up to the next one: the
+// second pixel sits exactly on a grid line) does not fold onto two cells for its one-sided derivative; such a block
+// (about one in 10^7 axis evaluations) is processed pixel by pixel in four passes of the same code.
+// ------------------------------------------------------------------------------------------
+struct Fold {
+  int k;            // stored index of window slot 0 (-1 .. size/2 - 1); slot 1 = k + 1
+  float r[2][2];    // r[p][slot]: weight of pixel p on the window slot (0 where p is out of range)
+  float dd[2];      // 1 when pixel p's two corners ARE the two window slots (dS/dpos = V[1] - V[0]) and p is in range
+  bool good;
+};
+
+__device__ __forceinline__ Fold make_fold(const Axis &a0, const Axis &a1) {
+  Fold f;
+  const int k = (a0.ok ? a0.i0 : a1.i0) >> 1;     // (both parked at 0 with zero weights when neither is in range)
+  f.k = k;
+  f.good = true;
+  const Axis *ax[2] = {&a0, &a1};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const Axis &a = *ax[p];
+    const int s0 = (a.i0 >> 1) - k, s1 = ((a.i0 + 1) >> 1) - k;
+    f.r[p][0] = (s0 == 0 ? a.w0 : 0.0f) + (s1 == 0 ? a.w1 : 0.0f);
+    f.r[p][1] = (s0 == 1 ? a.w0 : 0.0f) + (s1 == 1 ? a.w1 : 0.0f);
+    f.dd[p] = (a.ok && s1 != s0) ? 1.0f : 0.0f;
+    if (a.ok && (s0 < 0 || s1 > 1)) f.good = false;
+  }
+  return f;
+}
+
+template <int CCH, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
+                const float *__restrict__ gd, float *__restrict__ gx, float *__restrict__ gs,
+                float *__restrict__ gw, int C, int H, int W) {
+  extern __shared__ unsigned long long smem64[];
+  constexpr int PPW = 64 / CCH;                  // 2x2 blocks per wave step
+  const int nthreads = blockDim.x, nwaves = nthreads / 64;
+  const int Hs = H >> 1, Ws = W >> 1, HWs = Hs * Ws, HW = H * W;
+  const int Wc = Ws + 1;
+  const int cells = (Hs + 1) * Wc;
+  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  const int tid = threadIdx.x;
+  unsigned long long *gimg = smem64;                                      // [cells][CCH] fixed point
+  float *ximg = reinterpret_cast<float *>(smem64 + (size_t)cells * CCH);  // [cells][CCH]
+  float *gwl = ximg + (size_t)cells * CCH;                                // [CCH][9]
+  float *red = gwl + CCH * 9;                                             // [2 * nwaves]
+  for (int q = tid; q < cells * CCH; q += nthreads) {
+    ximg[q] = 0.0f;
+    gimg[q] = 0ull;
+  }
+  for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
+  float gmax = 0.0f;
+  {
+    const int cc = min(CCH, C - c0);
+    const float *gp = gd + ((long)n * C + c0) * HW;
+    for (int q = tid; q < cc * HW; q += nthreads) gmax = fmaxf(gmax, fabsf(gp[q]));
+    float wmax = 0.0f;
+    for (int q = tid; q < cc * 9; q += nthreads) wmax = fmaxf(wmax, fabsf(wd[(long)c0 * 9 + q]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
+      wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64));
+    }
+    __syncthreads();   // (also orders the zero fill above)
+    if ((tid & 63) == 0) {
+      red[2 * (tid >> 6)] = gmax;
+      red[2 * (tid >> 6) + 1] = wmax;
+    }
+    __syncthreads();
+    gmax = 0.0f;
+    wmax = 0.0f;
+    for (int i = 0; i < nwaves; ++i) {
+      gmax = fmaxf(gmax, red[2 * i]);
+      wmax = fmaxf(wmax, red[2 * i + 1]);
+    }
+    gmax *= 4.0f * wmax;      // bound of one scattered value: four pixels' |bilinear weight * g * w| folded onto a cell
+  }
+  int e = 0;
+  (void)frexpf(gmax, &e);
+  if (!(gmax > 0.0f) || !(gmax < INFINITY)) e = 0;
+  e = max(-86, min(e, 126 + 40));
+  const float scale = ldexpf(1.0f, 40 - e), inv_scale = ldexpf(1.0f, e - 40);
+  {   // stage the stored planes: lane <-> channel, 4 stored pixels per thread
+    const int quads = (HWs + 3) >> 2;
+    for (int q = tid; q < quads * CCH; q += nthreads) {
+      const int cl = q % CCH, j = q / CCH;
+      if (c0 + cl < C) {
+        const float *xp = x + ((long)n * C + c0 + cl) * HWs + j * 4;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int pix = j * 4 + e4;
+          if (pix < HWs) ximg[((pix / Ws) * Wc + (pix % Ws)) * CCH + cl] = xp[e4];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int cl = lane % CCH, sub = lane / CCH;
+  const bool ch_ok = c0 + cl < C;
+  float wk[9], gwa[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    wk[k] = ch_ok ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;
+    gwa[k] = 0.0f;
+  }
+  // stored row / column index -> LDS offset; every index outside the stored plane is the zero row / zero column
+  auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)Hs) ? yy : Hs) * Wc * CCH; };
+  auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)Ws) ? xx : Ws) * CCH + cl; };
+  auto scatter = [&](int o, float c) {
+    atomicAdd(&gimg[o], (unsigned long long)__float2ll_rn(c * scale));
+  };
+
+  for (int b0 = wave * PPW; b0 < HWs; b0 += nwaves * PPW) {
+    const int b = b0 + sub;
+    const bool live = b < HWs;
+    const int bb = live ? b : 0;
+    const int hs = bb / Ws, ws = bb - hs * Ws;
+    const int h = 2 * hs, w = 2 * ws;
+    const float t = s[(long)n * HWs + bb] - 1.0f;
+    float gfull[2][2];
+    {
+      const float *gp = gd + ((long)n * C + c0 + cl) * HW + (long)h * W + w;
+      const bool on = live && ch_ok;
+      const float2 g0 = on ? *reinterpret_cast<const float2 *>(gp) : make_float2(0.f, 0.f);
+      const float2 g1 = on ? *reinterpret_cast<const float2 *>(gp + W) : make_float2(0.f, 0.f);
+      gfull[0][0] = g0.x; gfull[0][1] = g0.y; gfull[1][0] = g1.x; gfull[1][1] = g1.y;
+    }
+    float gs_acc = 0.0f;
+    int npass = 1;                               // pass 0: the whole block; passes 1..4 (rare, see the header): one pixel each
+    for (int ps = 0; ps < npass; ++ps) {
+      const int only = ps - 1, opy = only >> 1, opx = only & 1;
+      Fold fya, fyb, fxa, fxb;
+      float g[2][2];
+      float oky[2][2], okx[2][2];                // [a / b][pixel]: in-range flags of the pass' pixels
+      {
+        Axis ay_[2], by_[2], ax_[2], bx_[2];     // (temporaries of this pass: nothing of them stays live over the taps)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          ay_[p] = make_axis(h + p - 1, -t, H);
+          by_[p] = make_axis(h + p + 1, t, H);
+          ax_[p] = make_axis(w + p - 1, -t, W);
+          bx_[p] = make_axis(w + p + 1, t, W);
+          if (only >= 0 && p != opy) {
+            ay_[p].ok = false; ay_[p].i0 = 0; ay_[p].w0 = 0.f; ay_[p].w1 = 0.f;
+            by_[p].ok = false; by_[p].i0 = 0; by_[p].w0 = 0.f; by_[p].w1 = 0.f;
+          }
+          if (only >= 0 && p != opx) {
+            ax_[p].ok = false; ax_[p].i0 = 0; ax_[p].w0 = 0.f; ax_[p].w1 = 0.f;
+            bx_[p].ok = false; bx_[p].i0 = 0; bx_[p].w0 = 0.f; bx_[p].w1 = 0.f;
+          }
+          oky[0][p] = ay_[p].ok ? 1.f : 0.f; oky[1][p] = by_[p].ok ? 1.f : 0.f;
+          okx[0][p] = ax_[p].ok ? 1.f : 0.f; okx[1][p] = bx_[p].ok ? 1.f : 0.f;
+        }
+        fya = make_fold(ay_[0], ay_[1]); fyb = make_fold(by_[0], by_[1]);
+        fxa = make_fold(ax_[0], ax_[1]); fxb = make_fold(bx_[0], bx_[1]);
+      }
+      if (ps == 0 && !(fya.good && fyb.good && fxa.good && fxb.good)) {
+        npass = 5;
+        continue;
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        g[p][0] = (only < 0 || (p == opy && opx == 0)) ? gfull[p][0] : 0.f;
+        g[p][1] = (only < 0 || (p == opy && opx == 1)) ? gfull[p][1] : 0.f;
+      }
+      // ---- corner tap: rows folded by FY, columns by FX
+      auto tap = [&](const Fold &FY, const Fold &FX, const float (&OY)[2], const float (&OX)[2], float ay, float ax,
+                     int k) {
+        const int r0 = row_off(FY.k), r1 = row_off(FY.k + 1);
+        const int q0 = col_off(FX.k), q1 = col_off(FX.k + 1);
+        const float v00 = ximg[r0 + q0], v01 = ximg[r0 + q1], v10 = ximg[r1 + q0], v11 = ximg[r1 + q1];
+        // G[r][c] = sum_py sum_px FY.r[py][r] * FX.r[px][c] * g[py][px]
+        const float t00 = FX.r[0][0] * g[0][0] + FX.r[1][0] * g[0][1], t01 = FX.r[0][1] * g[0][0] + FX.r[1][1] * g[0][1];
+        const float t10 = FX.r[0][0] * g[1][0] + FX.r[1][0] * g[1][1], t11 = FX.r[0][1] * g[1][0] + FX.r[1][1] * g[1][1];
+        const float G00 = FY.r[0][0] * t00 + FY.r[1][0] * t10, G01 = FY.r[0][0] * t01 + FY.r[1][0] * t11;
+        const float G10 = FY.r[0][1] * t00 + FY.r[1][1] * t10, G11 = FY.r[0][1] * t01 + FY.r[1][1] * t11;
+        if (gx != nullptr) {
+          scatter(r0 + q0, G00 * wk[k]);
+          scatter(r0 + q1, G01 * wk[k]);
+          scatter(r1 + q0, G10 * wk[k]);
+          scatter(r1 + q1, G11 * wk[k]);
+        }
+        gwa[k] += (G00 * v00 + G01 * v01) + (G10 * v10 + G11 * v11);
+        // dS/dy of pixel (py, px) = FY.dd[py] * sum_c FX.r[px][c] * (V[1][c] - V[0][c]); dS/dx likewise
+        const float dv0 = v10 - v00, dv1 = v11 - v01, dh0 = v01 - v00, dh1 = v11 - v10;
+        const float dy0 = FX.r[0][0] * dv0 + FX.r[0][1] * dv1, dy1 = FX.r[1][0] * dv0 + FX.r[1][1] * dv1;   // by px
+        const float dx0 = FY.r[0][0] * dh0 + FY.r[0][1] * dh1, dx1 = FY.r[1][0] * dh0 + FY.r[1][1] * dh1;   // by py
+        float acc = 0.0f;
+        acc += OY[0] * OX[0] * g[0][0] * (ay * FY.dd[0] * dy0 + ax * FX.dd[0] * dx0);
+        acc += OY[0] * OX[1] * g[0][1] * (ay * FY.dd[0] * dy1 + ax * FX.dd[1] * dx0);
+        acc += OY[1] * OX[0] * g[1][0] * (ay * FY.dd[1] * dy0 + ax * FX.dd[0] * dx1);
+        acc += OY[1] * OX[1] * g[1][1] * (ay * FY.dd[1] * dy1 + ax * FX.dd[1] * dx1);
+        gs_acc += acc * wk[k];
+      };
+      // ---- edge taps: one axis exact (the pixel's own row / column = the block's stored row / column)
+      auto tap_v = [&](const Fold &FY, const float (&OY)[2], float ay, int k) {     // column exact
+        const int r0 = row_off(FY.k), r1 = row_off(FY.k + 1), q0 = col_off(ws);
+        const float v0 = ximg[r0 + q0], v1 = ximg[r1 + q0];
+        const float s0 = g[0][0] + g[0][1], s1 = g[1][0] + g[1][1];               // over px
+        const float G0 = FY.r[0][0] * s0 + FY.r[1][0] * s1, G1 = FY.r[0][1] * s0 + FY.r[1][1] * s1;
+        if (gx != nullptr) {
+          scatter(r0 + q0, G0 * wk[k]);
+          scatter(r1 + q0, G1 * wk[k]);
+        }
+        gwa[k] += G0 * v0 + G1 * v1;
+        gs_acc += wk[k] * ay * (v1 - v0) * (OY[0] * FY.dd[0] * s0 + OY[1] * FY.dd[1] * s1);
+      };
+      auto tap_h = [&](const Fold &FX, const float (&OX)[2], float ax, int k) {     // row exact
+        const int r0 = row_off(hs), q0 = col_off(FX.k), q1 = col_off(FX.k + 1);
+        const float v0 = ximg[r0 + q0], v1 = ximg[r0 + q1];
+        const float s0 = g[0][0] + g[1][0], s1 = g[0][1] + g[1][1];               // over py
+        const float G0 = FX.r[0][0] * s0 + FX.r[1][0] * s1, G1 = FX.r[0][1] * s0 + FX.r[1][1] * s1;
+        if (gx != nullptr) {
+          scatter(r0 + q0, G0 * wk[k]);
+          scatter(r0 + q1, G1 * wk[k]);
+        }
+        gwa[k] += G0 * v0 + G1 * v1;
+        gs_acc += wk[k] * ax * (v1 - v0) * (OX[0] * FX.dd[0] * s0 + OX[1] * FX.dd[1] * s1);
+      };
+      tap(fya, fxa, oky[0], okx[0], -1.f, -1.f, 0);
+      tap_v(fya, oky[0], -1.f, 1);
+      tap(fya, fxb, oky[0], okx[1], -1.f, 1.f, 2);
+      tap_h(fxa, okx[0], -1.f, 3);
+      {
+        const int o = row_off(hs) + col_off(ws);
+        const float sg = (g[0][0] + g[0][1]) + (g[1][0] + g[1][1]);
+        if (gx != nullptr) scatter(o, sg * wk[4]);
+        gwa[4] = fmaf(sg, ximg[o], gwa[4]);
+      }
+      tap_h(fxb, okx[1], 1.f, 5);
+      tap(fyb, fxa, oky[1], okx[0], 1.f, -1.f, 6);
+      tap_v(fyb, oky[1], 1.f, 7);
+      tap(fyb, fxb, oky[1], okx[1], 1.f, 1.f, 8);
+    }
+    if (gs != nullptr) {
+#pragma unroll
+      for (int m = CCH / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
+      if (cl == 0 && live) atomicAdd(&gs[(long)n * HWs + b], gs_acc);
+    }
+  }
+  if (gw != nullptr && ch_ok) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);
+  }
+  __syncthreads();
+  if (gx != nullptr) {
+    const int quads = (HWs + 3) >> 2;
+    const bool vec = (HWs & 3) == 0;
+    for (int q = tid; q < quads * CCH; q += nthreads) {
+      const int c = q % CCH, j = q / CCH;
+      if (c0 + c >= C) continue;
+      float v[4];
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int pix = min(j * 4 + e4, HWs - 1);
+        v[e4] = __ll2float_rn((long long)gimg[((pix / Ws) * Wc + (pix % Ws)) * CCH + c]) * inv_scale;
+      }
+      float *gp = gx + ((long)n * C + c0 + c) * HWs + j * 4;
+      if (vec) {
+        *reinterpret_cast<float4 *>(gp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4)
+          if (j * 4 + e4 < HWs) gp[e4] = v[e4];
+      }
+    }
+  }
+  if (gw != nullptr)
+    for (int q = tid; q < CCH * 9; q += nthreads)
+      if (c0 + q / 9 < C) atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+}
+
+// ------------------------------------------------------------------------------------------
 // pointwise_kernel: Y[n] (Co x HW) = Wp (Co x C) . D[n] (C x HW) on v_mfma_f32_32x32x2_f32.
 // Workgroup tile 64 (co) x 64 (pixels), 4 waves, each owning one 32x32 accumulator tile;
 // K tiles of 16 staged through LDS as As[k][m] / Bs[k][n] so both operand reads are
@@ -794,6 +1096,114 @@ static int dw_channels_per_wg(int64_t C, int64_t H, int64_t W) {
   return CC;
 }
 
+// channels per workgroup of the up-sampled form (planes in LDS at stored resolution): enough workgroups to fill the
+// chip twice, whole channel quads, at most 32 KB of planes (4+ workgroups per CU)
+static int dw_up2_channels_per_wg(int64_t N, int64_t C, int64_t H, int64_t W) {
+  if ((C & 3) || (H & 1) || (W & 1)) return 0;
+  const int pstride = (int)((H / 2 + 2) * (W / 2 + 2));
+  int CC = (32 * 1024 / 4 - 64) / (pstride + 9) & ~3;
+  if (CC < 4) CC = (76 * 1024 / 4 - 64) / (pstride + 9) >= 4 ? 4 : 0;
+  if (CC > 16) CC = 16;
+  while (CC > 4 && cdn::ceil_div(C, CC) * N < 2L * cdn::kCUs) CC -= 4;
+  if (CC > C) CC = (int)C;
+  return CC;
+}
+
+static int dw_up2_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
+                               int64_t H, int64_t W, float *partials, void *stream) {
+  CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  const int CC = dw_up2_channels_per_wg(N, C, H, W);
+  CDN_REQUIRE(CC >= 4, CDN_ERR_UNSUPPORTED, "up-sampled gather needs C %% 4 == 0, even H, W and a stored plane that fits LDS");
+  const int pstride = (int)((H / 2 + 2) * (W / 2 + 2));
+  const size_t lds = (size_t)(((CC * 9 + 3) & ~3) + CC * pstride) * sizeof(float);
+  hipStream_t st = cdn::as_stream(stream);
+  dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void *)dw4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dw4_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC,
+                                                  reinterpret_cast<float2 *>(partials));
+  return cdn::check_launch("codenet dw forward (up-sampled input)");
+}
+
+extern "C" int cdn_codenet_dw_up2_supported(int64_t N, int64_t C, int64_t H, int64_t W) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return 0;
+  if (dw_up2_channels_per_wg(N, C, H, W) < 4) return 0;
+  const size_t cells = (size_t)(H / 2 + 1) * (W / 2 + 1);
+  return cells * 2 * 12 + 2 * 9 * 4 + 256 <= (size_t)160 * 1024 - 512;
+}
+
+extern "C" int64_t cdn_codenet_dw_up2_range_partials(int64_t N, int64_t C, int64_t H, int64_t W) {
+  const int CC = (N > 0 && C > 0 && H > 0 && W > 0) ? dw_up2_channels_per_wg(N, C, H, W) : 0;
+  return CC >= 4 ? cdn::ceil_div(C, CC) * N : 0;
+}
+
+extern "C" int cdn_codenet_dw_up2_forward(const float *x_stored, const float *s_stored, const float *w_dw, float *d,
+                                          int64_t N, int64_t C, int64_t H, int64_t W, float *partials, void *stream) {
+  return dw_up2_forward_impl(x_stored, s_stored, w_dw, d, N, C, H, W, partials, stream);
+}
+
+extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s_stored, const float *w_dw,
+                                           const float *grad_d, float *grad_x, float *grad_s, float *grad_w, int64_t N,
+                                           int64_t C, int64_t H, int64_t W, void *stream) {
+  CDN_REQUIRE(x_stored && s_stored && w_dw && grad_d, CDN_ERR_ARG, "null tensor pointer");
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0, CDN_ERR_ARG, "bad size (even H, W)");
+  CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(grad_d) & 7) == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15) == 0,
+              CDN_ERR_ARG, "grad_d must be 8-byte, grad_x 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const int64_t Hs = H / 2, Ws = W / 2;
+  if (grad_s) {
+    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)(N * Hs * Ws), st);
+    if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
+  }
+  const size_t cells = (size_t)(Hs + 1) * (Ws + 1);
+  const size_t lds_max = 160 * 1024 - 512;
+  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 256; };
+  int cch = 0;
+  for (int c : {32, 16, 8, 4, 2})
+    if (bwd_lds(c) <= lds_max) {
+      cch = c;
+      break;
+    }
+  CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident backward");
+#if defined(CDN_BWDU_CCH)
+  cch = CDN_BWDU_CCH;
+#else
+  // two workgroups per CU when the halved chunk allows it (more waves hide the LDS atomics' latency), and enough
+  // workgroups to fill the chip
+  if (cch >= 16 && bwd_lds(cch / 2) * 2 <= lds_max) cch /= 2;
+  while (cch > 4 && cdn::ceil_div(C, cch) * N < (long)cdn::kCUs) cch /= 2;
+#endif
+  const size_t lds = bwd_lds(cch);
+  dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
+  // 512-thread workgroups: the kernel wants ~170 VGPRs (capped at 128 for 1024 threads it spills 40+ of them)
+#if !defined(CDN_BWDU_MAXT)
+#define CDN_BWDU_MAXT 512
+#endif
+#if defined(CDN_BWDU_THREADS)
+  const int threads = CDN_BWDU_THREADS;
+#else
+  const int threads = 512;
+#endif
+#define CDN_BWDU(CCH_)                                                                                      \
+  {                                                                                                         \
+    auto kern = dw_bwd2u_kernel<CCH_, CDN_BWDU_MAXT>;                                                                    \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    kern<<<grid, threads, lds, st>>>(x_stored, s_stored, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H, (int)W); \
+  }
+  switch (cch) {
+    case 32: CDN_BWDU(32) break;
+    case 16: CDN_BWDU(16) break;
+    case 8: CDN_BWDU(8) break;
+    case 4: CDN_BWDU(4) break;
+    default: CDN_BWDU(2) break;
+  }
+#undef CDN_BWDU
+  return cdn::check_launch("codenet dw backward (up-sampled input)");
+}
+
 static int dw_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
                            int64_t H, int64_t W, float *partials, void *stream) {
   CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
@@ -808,8 +1218,8 @@ static int dw_forward_impl(const float *x, const float *s, const float *w_dw, fl
     dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
     if ((CC & 3) == 0 && (C & 3) == 0) {    // channel quads in LDS: one 16-byte read per cell and quad
       if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)dw4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      dw4_kernel<<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
+        (void)hipFuncSetAttribute((const void *)dw4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      dw4_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
     }
     else
       dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);

@@ -74,9 +74,16 @@ class CodenetStageFunction(Function):
     203-219)."""
 
     @staticmethod
-    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range=False):
+    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range=False, x_up=False):
+        """x_up (round 4): x is the STORED tensor [N,C,H/2,W/2] whose nearest x2 up-sampling is the stage's input (stages
+        1-2: shufflenetv2_dcn.py:303-308).  The scale is predicted at stored resolution (a 1x1 conv of a replicated tensor
+        is the replicated conv; min / max and hence the QuantAct range are those of the replicated plane), the gather reads
+        the stored planes through the up-sampling (same values, bit-identical d), and the backward accumulates the
+        gradient with respect to the stored tensor directly (cdn_codenet_dw_up2_backward: the four pixels of a block
+        share their bilinear cells) -- the up-sampled tensor and its gradient are never written."""
         ops._gpu_f32(x, w_scale, b_scale, w_dw, w_pw, b_pw)
         x = x.contiguous()
+        ctx.x_up = bool(x_up)
         # every producer leaves the {min, max} pairs of its output for the QuantAct behind it: no range passes
         if act_s is not None and act_s.running_stat:
             s_c, sp = ops.codenet_scale(x, w_scale, b_scale, lo, hi, want_range=True)   # clamped, pre-quantisation
@@ -90,14 +97,14 @@ class CodenetStageFunction(Function):
             if act_d is not None and act_d.running_stat and have_pw and FUSE_DQ_ON_LOAD:
                 # the gather leaves its {min, max} pairs, the QuantAct only updates, the pointwise kernel (and, in the
                 # backward, the weight-gradient kernel) fake-quantise d while loading it: d_q is never stored
-                d, dp = ops.codenet_dw_range(x, s, w_dw)
+                d, dp = ops.codenet_dw_up2(x, s, w_dw) if x_up else ops.codenet_dw_range(x, s, w_dw)
                 d_snap = ops.quantact_forward_partials(d, act_d, dp, want_out=False, want_state_copy=True)
                 d_q = d
             elif act_d is not None and act_d.running_stat:
-                d, dp = ops.codenet_dw_range(x, s, w_dw)
+                d, dp = ops.codenet_dw_up2(x, s, w_dw) if x_up else ops.codenet_dw_range(x, s, w_dw)
                 d_q = ops.quantact_forward_partials(d, act_d, dp)
             else:
-                d = ops.codenet_dw(x, s, w_dw.contiguous())
+                d = ops.codenet_dw_up2(x, s, w_dw, want_range=False) if x_up else ops.codenet_dw(x, s, w_dw.contiguous())
                 d_q = _native_quantact(act_d, d) if act_d is not None else d
         yp = None
         if have_pw and want_range:
@@ -120,7 +127,7 @@ class CodenetStageFunction(Function):
         x, s_c, s, w_scale, w_dw, d_q, w_pw, d_snap = ctx.saved_tensors
         need = ctx.needs_input_grad
         gy = gy.contiguous()
-        Nb, C, H, W = x.shape
+        Nb, C, H, W = x.shape            # (x_up: the STORED resolution; the stage runs at 2H x 2W)
         lib = N_.lib()
         g_wpw = g_bpw = None
         if ctx.have_pw:
@@ -134,7 +141,14 @@ class CodenetStageFunction(Function):
             gd = gy
         # gather backward (QuantAct on d: straight-through)
         want_x, want_s, want_wdw = need[0], (need[1] or need[2] or need[0]), need[3]
-        if not lib.cdn_codenet_dw_backward_supported(H, W):
+        if ctx.x_up:
+            gx = torch.empty_like(x) if want_x else None
+            gs = torch.empty_like(s) if want_s else None
+            g_wdw = torch.zeros_like(w_dw) if want_wdw else None
+            rc = lib.cdn_codenet_dw_up2_backward(_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw),
+                                                 Nb, C, 2 * H, 2 * W, ops._stream(x))
+            N_.check(rc, "cdn_codenet_dw_up2_backward")
+        elif not lib.cdn_codenet_dw_backward_supported(H, W):
             gx, gs, g_wdw = ops._dw_backward_generic(x, s, w_dw, gd, (want_x, want_s, want_wdw))
             gx = gx.contiguous() if gx is not None else None
         else:
@@ -161,7 +175,7 @@ class CodenetStageFunction(Function):
                     g_wscale = tot[:C].view_as(w_scale)
                 if want_b:
                     g_bscale = tot[C:].reshape(1)
-        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None, None
+        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None, None, None
 
 
 def _native_quantact(act, t):
@@ -171,10 +185,10 @@ def _native_quantact(act, t):
     return out
 
 
-def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None, want_range=False):
+def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None, want_range=False, x_up=False):
     """want_range: returns (y, partials) -- the per-workgroup {min, max} pairs of y ([n, 2], empty without a pointwise
-    conv) for a QuantAct behind the stage (ReluQuantUpsample)."""
-    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range)
+    conv) for a QuantAct behind the stage (ReluQuantUpsample).  x_up: see CodenetStageFunction.forward."""
+    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range, x_up)
 
 
 class QuantActSTE(Function):
@@ -322,6 +336,42 @@ class ReluQuantUpsample(Function):
         return gy, None, None
 
 
+class ReluQuant(Function):
+    """ReLU(inplace) -> QuantAct of the block behind a stage WITHOUT materialising the Upsample that follows (round 4):
+    the next stage reads this stored tensor through the up-sampling (CodenetStageFunction x_up).  Same range tracking and
+    fake-quantised values as ReluQuantUpsample; backward = grad where y > 0 (the 2x2 sum of the up-sampling backward is
+    part of the next stage's gather backward)."""
+
+    @staticmethod
+    def forward(ctx, y, act, partials=None):
+        ops._gpu_f32(y)
+        y = y.contiguous()
+        out = torch.empty_like(y)
+        use_p = partials is not None and partials.shape[0] > 0 and act.running_stat
+        rc = N_.lib().cdn_quantact_relu_forward(
+            _p(y), _p(out), y.numel(), _p(act.x_min), _p(act.x_max), _p(act._device_state(y.device)),
+            _p(partials) if use_p else None, partials.shape[0] if use_p else 0, int(act.activation_bit),
+            float(act.momentum), int(bool(act.running_stat)), ops._stream(y))
+        N_.check(rc, "cdn_quantact_relu_forward")
+        ctx.save_for_backward(y)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        gy = torch.empty_like(y)
+        rc = N_.lib().cdn_relu_backward(_p(g), _p(y), _p(gy), y.numel(), ops._stream(y))
+        N_.check(rc, "cdn_relu_backward")
+        return gy, None, None
+
+
+# A/B switch (tools/train_step_bench.py --no-stored-res): stages 1-2 of the QAT step on the stored tensors (True) or on
+# the materialised up-sampled ones (False: round 3's path).
+STORED_RES_STAGES = True
+
+
 def forward_stage_blocks(seq, x):
     """``seq(x)`` for a quantised ``deconv_layers`` Sequential; in the QAT step on the GPU the block
     [ReLU, QuantAct] + Upsample(x2, nearest) behind every stage runs as ReluQuantUpsample (one forward and one
@@ -340,10 +390,25 @@ def forward_stage_blocks(seq, x):
     if not (torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and len(mods) % 3 == 0 and mods
             and all(block_ok(*mods[i:i + 3]) for i in range(0, len(mods), 3))):
         return seq(x)
+    # hooks on the inner modules must fire: the fused blocks bypass their __call__
     for i in range(0, len(mods), 3):
-        y = mods[i](x, want_range=True)                    # (y, {min, max} pairs of y) on the native training path
+        for m in (mods[i + 1], mods[i + 1][0], mods[i + 1][1], mods[i + 2]):
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
+                return seq(x)
+    lib = N_.lib()
+    x_up = False
+    for i in range(0, len(mods), 3):
+        y = mods[i](x, want_range=True, x_up=x_up)         # (y, {min, max} pairs of y) on the native training path
         y, part = y if isinstance(y, tuple) else (y, None)
-        x = ReluQuantUpsample.apply(y, mods[i + 1][1], part)
+        nxt = mods[i + 3] if i + 3 < len(mods) else None
+        # the next stage reads its input through the up-sampling (stored tensor, never materialised) where its gather
+        # kernels support the shape
+        x_up = bool(STORED_RES_STAGES and nxt is not None and nxt._train_path_ok(y)
+                    and lib.cdn_codenet_dw_up2_supported(y.shape[0], y.shape[1], 2 * y.shape[2], 2 * y.shape[3]))
+        if x_up:
+            x = ReluQuant.apply(y, mods[i + 1][1], part)
+        else:
+            x = ReluQuantUpsample.apply(y, mods[i + 1][1], part)
     return x
 
 

@@ -109,6 +109,21 @@ def codenet_dw_range(x, s, w_dw):
     return d, part
 
 
+def codenet_dw_up2(xs, ss, w_dw, want_range=True):
+    """The gather / depthwise forward (no autograd) of a stage whose input is the nearest x2 up-sampling of the stored
+    tensor xs [N,C,H/2,W/2] with the stored scale plane ss [N,1,H/2,W/2]: d [N,C,H,W] (+ its {min, max} pairs),
+    bit-identical to codenet_dw_range on the materialised up-sampled tensors (cdn_codenet_dw_up2_forward)."""
+    _gpu_f32(xs, ss, w_dw)
+    xs, ss, w_dw = xs.contiguous(), ss.contiguous(), w_dw.contiguous()
+    Nb, C, Hs, Ws = xs.shape
+    H, W = 2 * Hs, 2 * Ws
+    d = xs.new_empty(Nb, C, H, W)
+    part = _partials(N_.lib().cdn_codenet_dw_up2_range_partials(Nb, C, H, W), xs) if want_range else None
+    rc = N_.lib().cdn_codenet_dw_up2_forward(_p(xs), _p(ss), _p(w_dw), _p(d), Nb, C, H, W, _p(part), _stream(xs))
+    N_.check(rc, "cdn_codenet_dw_up2_forward")
+    return (d, part) if want_range else d
+
+
 def quantact_forward_partials(x, act, partials, want_out=True, want_state_copy=False):
     """QuantAct.forward on the device with the batch extremes from the producer's {min, max} pairs: range update in
     place + fake-quantisation, no pass over x for the range.  want_out=False: only the update (the consumer

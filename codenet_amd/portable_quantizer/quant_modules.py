@@ -439,9 +439,12 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
                 and tuple(pw.kernel_size) == (1, 1) and pw.groups == 1 and tuple(pw.stride) == (1, 1)
                 and native_act_ok(self.quant_act[1]) and native_act_ok(self.quant_identity_deform))
 
-    def forward(self, x, want_range=False):
+    def forward(self, x, want_range=False, x_up=False):
         """want_range (functions/codenet_stage.forward_stage_blocks only): on the native training path return
-        (y, per-workgroup {min, max} pairs of y) for the QuantAct of the block behind the stage."""
+        (y, per-workgroup {min, max} pairs of y) for the QuantAct of the block behind the stage.  x_up (the same caller,
+        training path only): x is the STORED tensor whose nearest x2 up-sampling is the stage's input."""
+        if x_up and not self._train_path_ok(x):
+            raise NotImplementedError("x_up is a training-path argument of forward_stage_blocks")
         if self._fast_path_ok(x):
             bound = self.quant_act[0]
             s_raw = ops.codenet_scale(x, self.quant_conv_scale.quantized_weight(),
@@ -459,7 +462,7 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
             w, b = self.quant_conv_channel_bn.folded()
             return codenet_stage(x, self.quant_conv_scale.quantized_weight(), self.quant_conv_scale.bias,
                                  self.quant_deform_conv.quantized_weight(), w, b, bound.min_val, bound.max_val,
-                                 self.quant_act[1], self.quant_identity_deform, want_range)
+                                 self.quant_act[1], self.quant_identity_deform, want_range, x_up)
         s = self.quant_act(self.quant_conv_scale(x))
         dc = self.quant_deform_conv
         if (x.is_cuda and x.dtype == torch.float32 and s.shape[1] == 1

@@ -883,7 +883,7 @@ def test_stage_entry_points_from_two_threads():
     import copy
     import threading
     from codenet_amd import pipeline
-    CFG = [(1024, 256, 16), (256, 128, 32), (128, 64, 64)]
+    CFG = [1024, 256, 128, 64]
     net = pipeline.build_hot_path(quantized=True, planes=CFG, seed=77)
     pipeline.set_running_stat(net, True)
     g = torch.Generator().manual_seed(78)

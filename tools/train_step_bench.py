@@ -33,7 +33,12 @@ def main():
                     help="A/B: the weight transformation as the torch composition (kthvalue with --wt-percentile)")
     ap.add_argument("--no-fuse-dq", action="store_true", help="A/B: store the fake-quantised gather output instead of "
                     "quantising it in the consumers' loads")
+    ap.add_argument("--no-stored-res", action="store_true", help="A/B: stages 1-2 on the materialised up-sampled tensors "
+                    "(round 3's path) instead of on the stored ones (dw4_kernel<UP>, dw_bwd2u_kernel)")
     a = ap.parse_args()
+    if a.no_stored_res:
+        from codenet_amd.functions import codenet_stage as _cs1
+        _cs1.STORED_RES_STAGES = False
     if a.torch_weight_prep:
         from codenet_amd.functions import codenet_stage as _cs0
         _cs0.native_weight_prep_ok = lambda *args, **kw: False
@@ -102,31 +107,38 @@ def main():
         + (", one HIP graph" if a.graph else ", eager launches"),
         "ms_per_step": round(dt * 1e3, 3),
         "images_per_s": round(a.batch / dt, 1), "probe": float(loss)}
-    out["roofline_dw_bwd2"] = dw_bwd2_roofline(a.batch, a.res)
+    out["stored_res_stages"] = not a.no_stored_res
+    out["roofline_dw_bwd2"] = dw_bwd2_roofline(a.batch, a.res, stored=not a.no_stored_res)
     print(json.dumps(out))
 
 
-def dw_bwd2_roofline(batch, res):
+def dw_bwd2_roofline(batch, res, stored=True):
     """The step's dominant kernel family against ITS bound: dw_bwd2_kernel is not an HBM kernel (12 B per element
     in, 4 B out) -- each (pixel, channel) pair issues 25 64-bit LDS atomics, and tools/probes/probe_lds_atomics.hip
     measured 9.1 lane-ops per clock and CU for ds_add_u64 on gfx950 (x 256 CUs x 2.4 GHz = 5.59e12 / s).  Timed per
-    launch with HIP events at the step's three stage shapes."""
+    launch with HIP events at the step's three stage shapes.  stored (round 4): stages 1-2 run dw_bwd2u_kernel on the
+    stored tensors -- 25 atomics per 2x2 BLOCK and channel, i.e. a quarter of the atomics for the same gradient; the
+    `frac` of those rows is priced on the atomics actually issued, `equiv_frac` on the 25 per pixel the
+    full-resolution kernel needs for the same result."""
     from codenet_amd import _native as N_
     lib, dev = N_.lib(), torch.device("cuda", 0)
     peak = 9.1 * 256 * 2.4e9
     g = torch.Generator().manual_seed(0)
     rows, tot_pairs, tot_s = [], 0, 0.0
     for C, H in ((1024, res // 32), (256, res // 16), (128, res // 8)):
-        x = torch.randn(batch, C, H, H, generator=g).to(dev)
-        s = (torch.rand(batch, 1, H, H, generator=g) * 2.5 + 0.5).to(dev)
+        up = stored and C != 1024 and bool(lib.cdn_codenet_dw_up2_supported(batch, C, H, H))
+        Hx = H // 2 if up else H
+        x = torch.randn(batch, C, Hx, Hx, generator=g).to(dev)
+        s = (torch.rand(batch, 1, Hx, Hx, generator=g) * 2.5 + 0.5).to(dev)
         w = (torch.randn(C, 1, 3, 3, generator=g) * 0.3).to(dev)
         gd = (torch.randn(batch, C, H, H, generator=g) * 1e-3).to(dev)
         gx, gs, gw = torch.empty_like(x), torch.empty_like(s), torch.zeros_like(w)
         st = torch.cuda.current_stream().cuda_stream
+        fn = lib.cdn_codenet_dw_up2_backward if up else lib.cdn_codenet_dw_backward
 
         def run():
-            N_.check(lib.cdn_codenet_dw_backward(x.data_ptr(), s.data_ptr(), w.data_ptr(), gd.data_ptr(), gx.data_ptr(),
-                                                 gs.data_ptr(), gw.data_ptr(), batch, C, H, H, st), "dw backward")
+            N_.check(fn(x.data_ptr(), s.data_ptr(), w.data_ptr(), gd.data_ptr(), gx.data_ptr(),
+                        gs.data_ptr(), gw.data_ptr(), batch, C, H, H, st), "dw backward")
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -137,10 +149,13 @@ def dw_bwd2_roofline(batch, res):
         torch.cuda.synchronize()
         sec = e0.elapsed_time(e1) / 20 * 1e-3
         pairs = batch * C * H * H
-        rows.append({"plane": "%dx%d" % (H, H), "channels": C, "us_per_launch": round(sec * 1e6, 1),
-                     "lds_atomics_per_s": 25 * pairs / sec, "frac": 25 * pairs / sec / peak,
-                     "hbm_GBps": 16 * pairs / sec / 1e9})
-        tot_pairs += pairs
+        issued = pairs // 4 if up else pairs
+        rows.append({"plane": "%dx%d" % (H, H), "channels": C, "kernel": "dw_bwd2u" if up else "dw_bwd2",
+                     "us_per_launch": round(sec * 1e6, 1),
+                     "lds_atomics_per_s": 25 * issued / sec, "frac": 25 * issued / sec / peak,
+                     "equiv_frac": 25 * pairs / sec / peak,
+                     "hbm_GBps": (4 * pairs + (8 * pairs // 4 if up else 12 * pairs)) / sec / 1e9})
+        tot_pairs += issued
         tot_s += sec
     return {"bound": "lds_atomic", "unit": "64-bit LDS atomics/s", "peak": peak, "achieved": 25 * tot_pairs / tot_s,
             "frac": 25 * tot_pairs / tot_s / peak, "per_stage": rows,
