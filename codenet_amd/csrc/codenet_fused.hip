@@ -872,7 +872,12 @@ template <bool SQ, bool OUT8>
 __global__ void __launch_bounds__(1024)
 dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const unsigned *__restrict__ sq,
             const float *__restrict__ wd, float *__restrict__ d, float2 *dmm, cdn::QUpdate qu,
-            int C, int H, int W, int nitems) {
+            int C, int H, int W, int nitems, int Cx) {
+  // Cx = channels of x / wd; C = row length of d, a multiple of 64 >= Cx.  Cx < C (round 4: CoDeNet2x, 2153 = 33 * 64 +
+  // 41): the last chunk is RAGGED -- its missing planes and weights are fetched from the chunk's LAST REAL channel
+  // (clamped source addresses: no read outside the tensors, no predicated DMA), so the pad channels of d are exact
+  // duplicates of channel Cx - 1: the {min, max} of d are unchanged and the pointwise kernel multiplies them by its
+  // zero-padded weight codes.
   extern __shared__ float4 img_lds[];
   CDN_STAMP(0);
   constexpr int CCH = 64, LPP = 16, kWaves = 16;
@@ -910,17 +915,22 @@ dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const 
     if (piece < Q) {                                               // Q pieces of 1 KB = 64 * HW * 4 bytes
       const int idx = piece * 64 + lane;                           // 16-byte slot of the raw buffer
       const int c = idx >> qsh, slot = idx & (Q - 1);
+      const int cs = min(c, Cx - 1 - chunk * CCH);                 // ragged last chunk: the last real channel again
 #if defined(CDN_DIAG) && CDN_DIAG == 8   // diagnostic build: every item reads the planes of item 0 (wrong results)
-      glds16(x, (unsigned)(((c << qsh) + (slot ^ (c & 15))) << 4), raw_a + piece * 1024);
+      glds16(x, (unsigned)(((cs << qsh) + (slot ^ (c & 15))) << 4), raw_a + piece * 1024);
 #else
-      glds16(x + ((long)n * C + (long)chunk * CCH) * HW, (unsigned)(((c << qsh) + (slot ^ (c & 15))) << 4),
+      glds16(x + ((long)n * Cx + (long)chunk * CCH) * HW, (unsigned)(((cs << qsh) + (slot ^ (c & 15))) << 4),
              raw_a + piece * 1024);
 #endif
     }
     if (k == 0)
       for (int sp = wave; sp < npiece_w + npiece_s; sp += kWaves) {
-        if (sp < npiece_w)
-          glds4(wd + (long)chunk * CCH * 9 + sp * 64, lane * 4, wl_a + (set * CCH * 9 + sp * 64) * 4);
+        if (sp < npiece_w) {
+          // (ragged last chunk: weight 9 c + k of a pad channel c comes from the last real channel)
+          const int wi = sp * 64 + lane, wc = wi / 9, wlast = Cx - 1 - chunk * CCH;
+          const int wsrc = wc <= wlast ? wi : wlast * 9 + (wi - wc * 9);
+          glds4(wd + (long)chunk * CCH * 9, (unsigned)wsrc * 4, wl_a + (set * CCH * 9 + sp * 64) * 4);
+        }
         else
           glds4(s_raw + (long)n * HW + (sp - npiece_w) * 64, lane * 4, sl_a + (set * HW + (sp - npiece_w) * 64) * 4);
       }
@@ -1659,7 +1669,9 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const int *__restrict__ wsum, const float *__restrict__ Wp,
             const float *__restrict__ bias, float *__restrict__ R,
             float2 *rmm, cdn::QUpdate qu, long M, int C, int Cpad, int Co, int relu, int lda,
-            int ldo, const int *__restrict__ omap) {
+            int ldo, const int *__restrict__ omap, int Cw) {
+  // C: the K extent of the int8 path (the channels of A, or its padded row length when the pad repeats a real channel
+  // against zero weight codes); Cw: the logical channel count = row length of the f32 weights Wp (wide-code branch)
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int AI = BM * 8 / 256;        // float4 loads of A per thread per k-tile
@@ -1681,7 +1693,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
     // do).  Simple single-buffered 16-deep k-tiles in the int8 path's LDS arrays: the rare path.
     static_assert(BM * 17 * 4 <= 2 * BM * kI8LD && BN * 17 * 4 <= 2 * BN * kI8LD, "LDS reuse");
-    pwi8_wide_path<BM, BN, WGM>(A, Wp, bias, R, rmm, qu, M, C, Co, relu, lda, ldo, omap, qs, qz,
+    pwi8_wide_path<BM, BN, WGM>(A, Wp, bias, R, rmm, qu, M, Cw, Co, relu, lda, ldo, omap, qs, qz,
                                 reinterpret_cast<float *>(&A0[0][0]), reinterpret_cast<float *>(&B0[0][0]),
                                 reinterpret_cast<float *>(&A1[0][0]));
     return;
@@ -2429,14 +2441,15 @@ static size_t dw0p_lds_bytes(int H, int W) {
           2 * 16 + 4) * sizeof(float);
 }
 // shape conditions of dw0p_kernel (see there)
-static bool dw0p_applies(int C, int H, int W) {
+static bool dw0p_applies(int C, int H, int W) {      // C: the row length of d (a multiple of 64 >= the channels of x)
   const int HW = H * W;
   return (W & 3) == 0 && (HW & 63) == 0 && (HW & (HW - 1)) == 0 && (C & 63) == 0 &&
          dw0p_lds_bytes(H, W) <= 160 * 1024;
 }
 template <bool OUT8>
 static int launch_dw0p(const float *x, const float *s_raw, const unsigned *sq, const float *wd, float *d,
-                       float2 *dmm, cdn::QUpdate qu, int N, int C, int H, int W, hipStream_t st) {
+                       float2 *dmm, cdn::QUpdate qu, int N, int C, int H, int W, hipStream_t st, int Cx = 0) {
+  if (Cx == 0) Cx = C;
   const int nitems = N * (C / 64);
   const int grid = std::min(nitems, cdn::kCUs);
   const size_t lds = dw0p_lds_bytes(H, W);
@@ -2444,7 +2457,7 @@ static int launch_dw0p(const float *x, const float *s_raw, const unsigned *sq, c
   {                                                                                                       \
     auto kern = dw0p_kernel<SQ_, OUT8>;                                                                   \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-    kern<<<grid, 1024, lds, st>>>(x, s_raw, sq, wd, d, dmm, qu, C, H, W, nitems);                         \
+    kern<<<grid, 1024, lds, st>>>(x, s_raw, sq, wd, d, dmm, qu, C, H, W, nitems, Cx);                     \
   }
   if (sq) CDN_GOP(true)
   else CDN_GOP(false)
@@ -2455,10 +2468,12 @@ static int launch_dw0p(const float *x, const float *s_raw, const unsigned *sq, c
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
                const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
-               int C, int H, int W, int up, hipStream_t st, int gmode) {
+               int C, int H, int W, int up, hipStream_t st, int gmode, int ldd = 0) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
+  // d with rows padded to a multiple of 64 channels (stage_fused_forward decides; a ragged channel count, CoDeNet2x)
+  if (ldd > C) return launch_dw0p<false>(x, s_raw, sq, wd, d, dmm, qu, N, ldd, H, W, st, C);
   // NCHW input at output resolution (stage 0): the persistent LDS-DMA form once every CU gets >= 2 items to pipeline
   if (CCH == 64 && !nhwc && up == 0 && xq == nullptr && gmode != 1 && dw0p_applies(C, H, W) &&
       (gmode == 2 || (long)grid.x * grid.y >= 2L * cdn::kCUs))
@@ -2605,7 +2620,9 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                             const float *ep_shift, int relu, float *r_out, float2 *rmm,
                             const cdn::QUpdate &qu_r, int ptag, hipStream_t st, int64_t lda = 0,
                             int64_t ldo = 0, const unsigned char *a_gen = nullptr,
-                            const int *out_map = nullptr) {
+                            const int *out_map = nullptr, bool a_padded = false) {
+  // a_padded: the rows of A hold lda = round_up(C, 64) valid floats (the pad repeats channel C - 1) and the weight
+  // codes are zero beyond C: the int8 path runs its whole-tile form over K = lda; the f32 branch for wide codes keeps C
   if (lda == 0) lda = C;      // row strides of A / R in floats (views into wider channels-last tensors)
   if (ldo == 0) ldo = Co;
   // tile choice: keep >= 2 workgroups per CU when M is small (stage 0), wide N tiles otherwise
@@ -2613,7 +2630,8 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   const int pw_bm = (Co > 64 && cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 128) <= cdn::kCUs) ? 64 : 128;
   const int n_part_r = (int)(cdn::ceil_div(M, pw_bm) * cdn::ceil_div(Co, pw_bn));
   CDN_REQUIRE(n_part_r <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many pointwise workgroups");
-  const bool pw_fast = (C % 32) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
+  const int64_t Kt = a_padded ? lda : C;
+  const bool pw_fast = (Kt % 32) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
 #define CDN_PW1(BM_, BN_, WGM_, AQ_, FAST_)                                                      \
   pw3_kernel<BM_, BN_, WGM_, AQ_, FAST_><<<(unsigned)std::min<long>(                             \
       cdn::ceil_div(M, BM_) * cdn::ceil_div(Co, BN_), only_if_wide ? 2L * cdn::kCUs : (1L << 30)), 256, 0, st>>>( \
@@ -2639,6 +2657,7 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     CDN_REQUIRE((reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG,
                 "w_pw_codes must be 16-byte aligned");
     const int Cpad = (int)((C + 63) / 64 * 64);
+    CDN_REQUIRE(!a_padded || lda == Cpad, CDN_ERR_ARG, "a padded A has round_up(C, 64) floats per row");
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
 #define CDN_PWI(BM_, BN_, WGM_)                                                                  \
   do {                                                                                           \
@@ -2646,11 +2665,11 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     if (pw_fast)                                                                                 \
       pwi8_kernel<BM_, BN_, WGM_, true><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,        \
                                                             w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                            qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map); \
+                                                            qu_r, M, (int)Kt, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map, (int)C); \
     else                                                                                         \
       pwi8_kernel<BM_, BN_, WGM_, false><<<g, 256, 0, st>>>(d, dst, w_pw_codes, w_pw_scale,       \
                                                              w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
-                                                             qu_r, M, (int)C, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map); \
+                                                             qu_r, M, (int)Kt, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map, (int)C); \
   } while (0)
     // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
     // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
@@ -2711,7 +2730,8 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
   // s_raw [N*HWl] + d [N*H*W*C] + 3 regions of per-workgroup {min,max} partials, each rounded
   // up to 256 bytes
   auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
-  return (size_t)(r(N * HWl * 4) + r(N * H * W * C * 4) + 3 * r(kMaxPartials * 8) +
+  const int64_t Cd = (C + 63) / 64 * 64;        // (rows of d may be padded to whole 64-channel chunks)
+  return (size_t)(r(N * HWl * 4) + r(N * H * W * Cd * 4) + 3 * r(kMaxPartials * 8) +
                   3 * r(cdn::kArriveWords * 4));
 }
 
@@ -2783,7 +2803,17 @@ extern "C" int cdn_codenet_stage_fused_forward(
   char *wsp = static_cast<char *>(workspace);
   float *s_raw = reinterpret_cast<float *>(wsp);
   float *d = reinterpret_cast<float *>(wsp + r256(N * HWl * 4));
-  float2 *part_s = reinterpret_cast<float2 *>(wsp + r256(N * HWl * 4) + r256(N * H * W * C * 4));
+  // Rows of d: C floats, or -- NCHW input with a ragged channel count feeding the int8 pointwise (CoDeNet2x stage 0,
+  // C = 2153; round 4) -- padded to the next multiple of 64 so that the persistent LDS-DMA gather (whole 64-channel
+  // chunks, 16-byte stores) and the int8 pointwise's 16-byte row loads apply; the pad channels duplicate channel
+  // C - 1 and meet zero weight codes (see dw0p_kernel).  Same values as the unpadded schedule, bit for bit.
+  const int64_t Cd = (C + 63) / 64 * 64;
+  const bool pad_d = !x_nhwc && x_up == 0 && Cd != C && gmode != 1 && w_pw_codes != nullptr && d_state != nullptr &&
+                     ep_scale == nullptr && w_pw_scale != nullptr && w_pw_colsum != nullptr &&
+                     cdn::stage_channel_chunk(Hl, Wl) == 64 && dw0p_applies((int)Cd, (int)H, (int)W) &&
+                     N * Cd * H * W < (1ll << 31);
+  const int64_t ldd = pad_d ? Cd : C;
+  float2 *part_s = reinterpret_cast<float2 *>(wsp + r256(N * HWl * 4) + r256(N * H * W * Cd * 4));
   float2 *part_d = part_s + kMaxPartials;
   float2 *part_r = part_d + kMaxPartials;
   // arrival counters: the LAST bytes of the workspace (the caller zeroes them once)
@@ -2855,13 +2885,14 @@ extern "C" int cdn_codenet_stage_fused_forward(
   {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     auto fn = cch == 64 ? launch_dw2<64> : cch == 32 ? launch_dw2<32> : cch == 16 ? launch_dw2<16> : launch_dw2<8>;
-    rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st, gmode);
+    rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st, gmode,
+            (int)ldd);
   }
   if (rc) return rc;
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
   return launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
                           bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
-                          st);
+                          st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d);
 }
 
 extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw,

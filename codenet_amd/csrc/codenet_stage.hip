@@ -1178,14 +1178,18 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
 #endif
   const size_t lds = bwd_lds(cch);
   dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
-  // 512-thread workgroups: the kernel wants ~170 VGPRs (capped at 128 for 1024 threads it spills 40+ of them)
+  // The kernel wants ~170 VGPRs: three waves per SIMD = 12 waves per CU (capped at 128 VGPRs for 1024-thread workgroups
+  // it spills 40+ of them: 131 / 220 us against 99 / 165 us at the two stage shapes, batch 32).  The 12 waves go to as
+  // many workgroups as LDS admits: 768 threads when one fits, 384 when two do, 256 for three or more
+  // (measured: 512 threads 105 / 184 us, 768: 99 / 165, 256: 95 / 281, 1024: 131 / 220).
 #if !defined(CDN_BWDU_MAXT)
-#define CDN_BWDU_MAXT 512
+#define CDN_BWDU_MAXT 768
 #endif
 #if defined(CDN_BWDU_THREADS)
   const int threads = CDN_BWDU_THREADS;
 #else
-  const int threads = 512;
+  const int wgs_per_cu = (int)std::min<size_t>(3, lds_max / lds);
+  const int threads = wgs_per_cu <= 1 ? 768 : wgs_per_cu == 2 ? 384 : 256;
 #endif
 #define CDN_BWDU(CCH_)                                                                                      \
   {                                                                                                         \
