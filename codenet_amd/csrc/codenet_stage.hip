@@ -1179,17 +1179,17 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
   const size_t lds = bwd_lds(cch);
   dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
   // The kernel wants ~170 VGPRs: three waves per SIMD = 12 waves per CU (capped at 128 VGPRs for 1024-thread workgroups
-  // it spills 40+ of them: 131 / 220 us against 99 / 165 us at the two stage shapes, batch 32).  The 12 waves go to as
-  // many workgroups as LDS admits: 768 threads when one fits, 384 when two do, 256 for three or more
-  // (measured: 512 threads 105 / 184 us, 768: 99 / 165, 256: 95 / 281, 1024: 131 / 220).
+  // it spills 40+ of them: 131 / 220 us against 99 / 165 us at the two stage shapes, batch 32).  768 threads when only
+  // one workgroup fits a CU (64 x 64 stage), 256 when several do (32 x 32 stage: two of 55 KB)
+  // (measured at the 32 x 32 / 64 x 64 stage: 256 threads 95 / 281 us, 384 (uneven over the four SIMDs) 122 / -,
+  // 512: 105 / 184, 768: 99 / 165, 1024: 131 / 220).
 #if !defined(CDN_BWDU_MAXT)
 #define CDN_BWDU_MAXT 768
 #endif
 #if defined(CDN_BWDU_THREADS)
   const int threads = CDN_BWDU_THREADS;
 #else
-  const int wgs_per_cu = (int)std::min<size_t>(3, lds_max / lds);
-  const int threads = wgs_per_cu <= 1 ? 768 : wgs_per_cu == 2 ? 384 : 256;
+  const int threads = lds_max / lds <= 1 ? 768 : 256;
 #endif
 #define CDN_BWDU(CCH_)                                                                                      \
   {                                                                                                         \

@@ -73,9 +73,24 @@ def test_generic_depthwise_fast_path_matches_oracle(N, C, H, W, spread):
     off[:, 0::2, -1, -1] = -1.0               # row positions exactly on -1 .. (boundary of the gate)
     w = torch.randn(C, 1, 3, 3, generator=g)
     ref = O.deform_conv_forward(x, off, w, 1, 1, 1, C, 1)
-    out = deform_conv(x.cuda(), off.cuda(), w.cuda(), 1, 1, 1, C, 1)
+    xg, og, wg = (t.cuda().requires_grad_(True) for t in (x, off, w))
+    out = deform_conv(xg, og, wg, 1, 1, 1, C, 1)
     assert out.shape == ref.shape
-    assert (out.cpu() - ref).abs().max().item() < 1e-4
+    assert (out.detach().cpu() - ref).abs().max().item() < 1e-4
+    # round 4: the three backward roles take the LDS-image depthwise kernel for this geometry too (dwo_bwd_kernel:
+    # 64-bit fixed-point LDS atomics for grad_input, the 18-channel grad_offset reduced over the chunk's lanes,
+    # lane-private grad_weight sums) -- against the oracle's restatement of _kernel.cu:278-435 / cpp:373-484
+    go = torch.randn(ref.shape, generator=g)
+    out.backward(go.cuda())
+    gx, goff = O.deform_conv_backward_input(x, off, w, go, 1, 1, 1, C, 1)
+    gw = O.deform_conv_backward_params(x, off, tuple(w.shape), go, 1, 1, 1, C, 1)
+    for name, got, want in (("grad_input", xg.grad, gx), ("grad_offset", og.grad, goff), ("grad_weight", wg.grad, gw)):
+        err = (got.cpu() - want).abs().max().item()
+        assert err < 2e-4 * max(1.0, want.abs().max().item()), "%s: %g" % (name, err)
+    # grad_input is a fixed-point sum: bitwise reproducible from call to call (the reference's float atomics are not)
+    xg2, og2, wg2 = (t.cuda().requires_grad_(True) for t in (x, off, w))
+    deform_conv(xg2, og2, wg2, 1, 1, 1, C, 1).backward(go.cuda())
+    assert torch.equal(xg.grad, xg2.grad)
 
 
 @pytest.mark.parametrize("case", [GENERIC_CASES[0], GENERIC_CASES[-1]])

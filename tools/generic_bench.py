@@ -1,6 +1,8 @@
 """The NARROWEST drop-in: the reference's own Python composition -- 18-channel offset
 tensor + generic ``deform_conv`` -- on cdn_deform_conv_forward (dcn_generic.hip), next to the CoDeNet fast path
-(cdn_codenet_dw_forward) on the same stage shapes.  Forward only, batch 64, 512x512 stage shapes.  GPU only."""
+(cdn_codenet_dw_forward) on the same stage shapes, batch 64 (argv[1]), 512x512 stage shapes; round 4: also the backward
+(cdn_deform_conv_backward_input + _parameters: grad_input, 18-channel grad_offset, grad_weight) next to the module
+kernel's (cdn_codenet_dw_backward: grad_x, grad_s, grad_w).  GPU only."""
 import json
 import os
 import sys
@@ -38,10 +40,25 @@ def main():
             t_gen = timed(lambda: deform_conv(x, anchor * (s - 1), w, 1, 1, 1, C, 1))
             t_fast = timed(lambda: ops.codenet_dw(x, s, w))
             err = (deform_conv(x, anchor * (s - 1), w, 1, 1, 1, C, 1) - ops.codenet_dw(x, s, w)).abs().max().item()
+        # backward: autograd through the generic Function (two C calls) vs the module op's backward (one)
+        go = torch.randn(batch, C, H, H, generator=g).cuda()
+
+        def bwd(fn, leaves):
+            for t in leaves:
+                t.grad = None
+            fn().backward(go)
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        og = (anchor * (s - 1)).detach().requires_grad_(True)
+        sg = s.clone().requires_grad_(True)
+        t_gen_fb = timed(lambda: bwd(lambda: deform_conv(xg, og, wg, 1, 1, 1, C, 1), (xg, og, wg)), iters=10)
+        t_fast_fb = timed(lambda: bwd(lambda: ops.codenet_dw(xg, sg, wg), (xg, sg, wg)), iters=10)
         out["%dx%dx%d" % (C, H, H)] = {"generic_ms": round(t_gen, 4), "codenet_dw_ms": round(t_fast, 4),
-                                       "max_abs_diff": err}
-    print(json.dumps({"what": "gather/depthwise forward, batch %d: generic deform_conv (offset tensor, one thread per "
-                              "output, dcn_generic.hip) vs the CoDeNet module kernel (LDS planes, codenet_stage.hip)" % batch,
+                                       "max_abs_diff": err,
+                                       "generic_bwd_ms": round(t_gen_fb - t_gen, 4),
+                                       "codenet_dw_bwd_ms": round(t_fast_fb - t_fast, 4)}
+    print(json.dumps({"what": "gather/depthwise, batch %d: generic deform_conv (18-channel offset tensor, "
+                              "dcn_generic.hip) vs the CoDeNet module kernel (one scale plane, codenet_stage.hip); "
+                              "*_bwd_ms = (forward + backward) - forward, eager launches" % batch,
                       "stages": out}))
 
 
