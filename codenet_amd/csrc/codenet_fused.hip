@@ -1650,7 +1650,7 @@ __device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, cons
           if (m < M && co < Co) {
             float v = accf[i][j][r] + bsv;
             if (relu) v = fmaxf(v, 0.0f);
-            R[m * ldo + oc] = v;
+            if (R) R[m * ldo + oc] = v;
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
           }
@@ -1849,7 +1849,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         if (m < M && co < Co) {
           float v = fmaf((float)(acc[i][j][r] + t128), rinv, bsv);
           if (relu) v = fmaxf(v, 0.0f);
-          R[m * ldo + oc] = v;
+          if (R) R[m * ldo + oc] = v;                          // (R == NULL: range-only pass)
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
         }
@@ -2942,7 +2942,11 @@ extern "C" int cdn_codenet_pointwise_mixed_forward(
     const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
     const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
     void *workspace, size_t workspace_bytes, float *out, void *stream) {
-  CDN_REQUIRE(a && w && out, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(a && w, CDN_ERR_ARG, "null pointer");
+  // out == NULL: RANGE-ONLY pass (round 4) -- the kernel computes everything and stores nothing; only the int8 kernel
+  // on one input state implements it
+  CDN_REQUIRE(out || (r_state && a_qstate && !a_gen && w_codes && !ep_scale), CDN_ERR_ARG,
+              "a range-only pass (out == NULL) needs the output QuantAct and the int8 form");
   CDN_REQUIRE(a_gen == nullptr || a_qstate != nullptr, CDN_ERR_ARG, "a_gen needs the states in a_qstate");
   CDN_REQUIRE(M > 0 && C > 0 && Co > 0 && M * std::max(C, Co) < (1ll << 31), CDN_ERR_ARG, "bad size");
   CDN_REQUIRE((ep_scale == nullptr) == (ep_shift == nullptr), CDN_ERR_ARG,

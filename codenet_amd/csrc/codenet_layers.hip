@@ -575,6 +575,244 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
 }
 
 // ------------------------------------------------------------------------------------------
+// pwdwx (round 4; VERDICT r3 "next" #1b): the first 1x1 conv of a stride-2 ShuffleNetV2 unit RECOMPUTED inside its
+// depthwise 3x3 (stride 2) instead of stored.  In layer 1 that tensor -- 58 channels at 128 x 128, fp32 because the
+// range of the QuantAct behind it is only known once the whole batch has been computed -- is 243 MB at batch 64,
+// written once and read once (pwi8_kernel 108 us + dwx_kernel 108 us).  The conv itself is tiny (K = 24): a range-only
+// pass of the int8 pointwise kernel (no store) fixes the QuantAct, then this kernel -- dwx_kernel's structure: workgroup =
+// (image, strip of output columns, strip of output rows), a ring of 3 + 2 input rows in LDS, all channels of a pixel in
+// one workgroup -- PRODUCES its ring rows from the 24-channel input:
+//   input row -> levels L = rint(s x - z) + z of the input QuantAct, a = L - 128 split into nibbles a = 16 a1 + a0
+//   (both int8; pwi8_kernel's split), four channels packed per dword in LDS;
+//   ring[col][quad] = fake_quant_a1( relu( fma( float(16 dot(a1, qw) + dot(a0, qw) + 128 colsum), 1 / (s sw), bias) ) )
+//   with v_dot4c_i32_i8 -- the same exact integer sum and the same epilogue expression as pwi8_kernel, so the values in
+//   the ring are bit for bit those dwx_kernel would load and fake-quantise from the stored tensor;
+//   then dwx_kernel's nine-tap loop, epilogue and range tracking, unchanged.
+// A batch whose input codes are too wide for the nibble split (state word [6]; a range that lags the batch by more than
+// 8x) takes an fp32 branch: sum_c fq(x_c) * w'_c accumulated in channel order -- another valid evaluation of the
+// reference's fp32 conv, not the integer one (pwi8_kernel's own wide branch is an f32-MFMA evaluation, also not).
+// Cin <= 32 (a multiple of 4), C <= 128, stride 2.
+// ------------------------------------------------------------------------------------------
+template <int MAXL>
+__global__ void __launch_bounds__(256)
+pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const signed char *__restrict__ Wq,
+             const float *__restrict__ wscale, const int *__restrict__ wsum, const float *__restrict__ Wf,
+             const float *__restrict__ pbias, const unsigned *__restrict__ mq, const float *__restrict__ w,
+             const float *__restrict__ bias, float *__restrict__ out, float2 *mm, cdn::QUpdate qu, int Cin, int Cpad,
+             int C, int ld_x, int ld_out, int Hs, int Ws, int nxs, int XSo, int nstrips, int rps, int LPP, int XPT) {
+  extern __shared__ float4 ring4[];         // [RING][Wc][LPP], then the code rows [2][Wc][16] dwords
+  constexpr int STRIDE = 2, RING = 3 + STRIDE, DEPTH = 3;
+  const int xs = blockIdx.x % nxs, strip = blockIdx.x / nxs, n = blockIdx.y;
+  const int Ho = (Hs - 1) / 2 + 1, Wo = (Ws - 1) / 2 + 1;
+  const int oy0 = strip * rps, oy1 = min(oy0 + rps, Ho);
+  const int ox0 = xs * XSo, nxo = min(XSo, Wo - ox0);
+  const int Wc = STRIDE * (XSo - 1) + 3;
+  const int ix0 = STRIDE * ox0 - 1;
+  const int tid = threadIdx.x, cq = tid % LPP, cb = cq * 4, x_l = tid / LPP;
+  const int nthreads = blockDim.x;
+  unsigned *codes = reinterpret_cast<unsigned *>(ring4 + (size_t)RING * Wc * LPP);   // [2][Wc][16]: a0 quads 0..7, a1 8..15
+  const int Q4 = Cin >> 2;                                    // input channel quads per pixel (<= 8)
+  // ---- constants: input quantiser, the mid QuantAct (known: the range pass ran before), weights of this quad ----
+  const float xs_ = reinterpret_cast<const float *>(xq)[2], xz_ = reinterpret_cast<const float *>(xq)[3];
+  const bool wide = xq[6] != 0u;
+  const float ms_ = reinterpret_cast<const float *>(mq)[2], mz_ = reinterpret_cast<const float *>(mq)[3];
+  const float mr_ = __fdiv_rn(1.0f, ms_);
+  int wq[4][8];
+  float rinv[4], pb[4], wk[9][4], bs[4];
+  int t128[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = min(cb + e, C - 1);
+    const bool on = cb + e < C;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      wq[e][q] = (on && q < Q4) ? *reinterpret_cast<const int *>(Wq + (long)c * Cpad + 4 * q) : 0;
+    rinv[e] = __fdiv_rn(1.0f, __fmul_rn(xs_, wscale[c]));
+    t128[e] = 128 * wsum[c];
+    pb[e] = pbias ? pbias[c] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k][e] = on ? w[(long)c * 9 + k] : 0.0f;
+    bs[e] = (on && bias) ? bias[c] : 0.0f;
+  }
+  const int ioff = (int)xz_ + (2048 - 128) - 0x4B400000;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int r_first = STRIDE * oy0 - 1;
+  const int nitems = Wc * Q4;                                  // float4 items of one input row of this strip
+  // ---- stage A: this thread's items of an input row (raw fp32, prefetched into registers) --------------------
+  constexpr int MAXI = 2;                                      // items per thread and row (Wc * Q4 <= 512)
+  auto load_row = [&](int r, float4 (&d)[MAXI]) {
+    const long rc = min(max(r, 0), Hs - 1);
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+      const int it = min(tid + u * nthreads, nitems - 1);
+      const int col = it / Q4, q4 = it - col * Q4;
+      const int xg = min(max(ix0 + col, 0), Ws - 1);
+      d[u] = *reinterpret_cast<const float4 *>(x + ((long)n * Hs * Ws + rc * Ws + xg) * ld_x + 4 * q4);
+    }
+  };
+  // ---- stage B: levels -> nibble-split codes of the row, four channels per dword, into code buffer `cbuf` ------
+  auto write_codes = [&](int cbuf, const float4 (&d)[MAXI]) {
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+      const int it = tid + u * nthreads;
+      if (it < nitems) {
+        const int col = it / Q4, q4 = it - col * Q4;
+        const float v[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+        unsigned lo = 0u, hi = 0u;
+        if (!wide) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma clang fp contract(off)
+            const float y_p = xs_ * v[e];
+            const float y = (y_p - xz_) + 12582912.0f;           // rint by the 1.5 * 2^23 trick (pwi8_kernel's ucode)
+            int uu = (int)__float_as_uint(y) + ioff;
+            uu = min(max(uu, 8), 4087);
+            lo |= (unsigned)(uu & 15) << (8 * e);
+            hi |= (unsigned)(((uu >> 4) - 128) & 255) << (8 * e);
+          }
+          codes[(cbuf * Wc + col) * 16 + q4] = lo;
+          codes[(cbuf * Wc + col) * 16 + 8 + q4] = hi;
+        } else {            // wide batch: the fake-quantised fp32 values themselves (two dwords hold two floats each way)
+          float *cf = reinterpret_cast<float *>(codes + (size_t)2 * Wc * 16) + ((size_t)cbuf * Wc + col) * 32 + 4 * q4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cf[e] = cdn::fake_quant_r(v[e], xs_, xz_, __fdiv_rn(1.0f, xs_));
+        }
+      }
+    }
+  };
+  // ---- stage C: the 1x1 conv + ReLU + fake-quantisation of this thread's (column, quad) items -> ring row `slot` ----
+  auto produce_row = [&](int r, int slot, int cbuf) {
+    const bool row_in = (unsigned)r < (unsigned)Hs;
+#pragma unroll
+    for (int u = 0; u < MAXL; ++u) {
+      const int col = x_l + u * XPT, xg = ix0 + col;
+      if (col < Wc) {
+        float4 t = z4;                                           // outside the image: the depthwise conv's zero padding
+        if (row_in && (unsigned)xg < (unsigned)Ws && cb < C) {
+          float y[4];
+          if (!wide) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(codes + (cbuf * Wc + col) * 16);
+            const uint4 l0 = cp[0], l1 = cp[1], h0 = cp[2], h1 = cp[3];
+            const int a0[8] = {(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+            const int a1[8] = {(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              int s0 = 0, s1 = 0;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                s0 = __builtin_amdgcn_sdot4(a0[q], wq[e][q], s0, false);
+                s1 = __builtin_amdgcn_sdot4(a1[q], wq[e][q], s1, false);
+              }
+              y[e] = fmaf((float)(16 * s1 + s0 + t128[e]), rinv[e], pb[e]);
+            }
+          } else {
+            const float *cf = reinterpret_cast<const float *>(codes + (size_t)2 * Wc * 16) + ((size_t)cbuf * Wc + col) * 32;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = min(cb + e, C - 1);
+              float acc = 0.0f;
+              for (int k = 0; k < Cin; ++k) acc = fmaf(cf[k], Wf[(long)c * Cin + k], acc);
+              y[e] = acc + pb[e];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = cdn::fake_quant_r(fmaxf(y[e], 0.0f), ms_, mz_, mr_);
+          t = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        ring4[(slot * Wc + col) * LPP + cq] = t;
+      }
+    }
+  };
+  float4 pre[DEPTH][STRIDE][MAXI];
+  int wslot = 0;
+  const int r_step0 = r_first + (3 - STRIDE);
+  if (oy0 < oy1) {
+    load_row(r_first, pre[0][0]);                                 // the one row in front of the first output row
+    write_codes(0, pre[0][0]);
+    __syncthreads();
+    produce_row(r_first, wslot, 0);
+    wslot = 1;
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_)
+      if (oy0 + d_ < oy1) {
+#pragma unroll
+        for (int s_ = 0; s_ < STRIDE; ++s_) load_row(r_step0 + STRIDE * d_ + s_, pre[d_][s_]);
+      }
+    __syncthreads();                                              // code row 0 is read: the loop may overwrite it
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  int cslot = 0;
+  for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_) {
+      const int oy = oyb + d_;
+      if (oy < oy1) {                                         // workgroup-uniform
+        const int base_r = r_step0 + STRIDE * (oy - oy0);
+        // (no barrier needed here: the code rows were last read before the previous row's barrier, and the two ring
+        // slots produced below are not among the three the previous row's taps read)
+        write_codes(0, pre[d_][0]);
+        write_codes(1, pre[d_][1]);
+        __syncthreads();
+        if (oy + DEPTH < oy1) {
+#pragma unroll
+          for (int s_ = 0; s_ < STRIDE; ++s_) load_row(base_r + STRIDE * DEPTH + s_, pre[d_][s_]);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < STRIDE; ++s_) {
+          produce_row(base_r + s_, wslot, s_);
+          wslot = wslot + 1 == RING ? 0 : wslot + 1;
+        }
+        __syncthreads();
+        int rs[3];
+        rs[0] = cslot;
+        rs[1] = cslot + 1 >= RING ? cslot + 1 - RING : cslot + 1;
+        rs[2] = cslot + 2 >= RING ? cslot + 2 - RING : cslot + 2;
+        cslot = cslot + STRIDE >= RING ? cslot + STRIDE - RING : cslot + STRIDE;
+#pragma unroll
+        for (int u = 0; u < MAXL; ++u) {
+          const int oxl = x_l + u * XPT;
+          if (oxl < nxo && cb < C) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx) {
+                const float4 t = ring4[(rs[dy] * Wc + STRIDE * oxl + dx) * LPP + cq];
+                acc[0] = fmaf(wk[dy * 3 + dx][0], t.x, acc[0]);
+                acc[1] = fmaf(wk[dy * 3 + dx][1], t.y, acc[1]);
+                acc[2] = fmaf(wk[dy * 3 + dx][2], t.z, acc[2]);
+                acc[3] = fmaf(wk[dy * 3 + dx][3], t.w, acc[3]);
+              }
+            float r4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r4[e] = acc[e] + bs[e];
+            float *op = out + ((long)n * Ho * Wo + (long)oy * Wo + ox0 + oxl) * ld_out + cb;
+            if (cb + 3 < ld_out && (ld_out & 3) == 0) {
+              *reinterpret_cast<float4 *>(op) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (cb + e < C) op[e] = r4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (cb + e < C) {
+                mn = fminf(mn, r4[e]);
+                mx = fmaxf(mx, r4[e]);
+              }
+          }
+        }
+      }
+    }
+  }
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+                             reinterpret_cast<float *>(ring4));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // interleave: the concat + channel_shuffle(groups = 2) that ends a ShuffleNetV2 unit
 // (shufflenetv2_dcn.py:43-49; quant_modules.py:905-907), with the block-output QuantAct applied:
 //     dst[m][2 i + 0] = fq_A(srcA[m][i])      dst[m][2 i + 1] = fq_B(srcB[m][i])        i < h
@@ -1445,4 +1683,89 @@ extern "C" int cdn_codenet_maxpool3x3s2_nhwc_forward(const float *a, const void 
   else
     maxpool_kernel<false><<<blocks, 256, 0, st>>>(a, nullptr, out, (int)C, (int)H, (int)W, Ho, Wo, total);
   return cdn::check_launch("codenet maxpool");
+}
+
+// First 1x1 conv (+ ReLU + QuantAct) of a stride-2 unit recomputed inside its depthwise 3x3 (pwdwx_kernel): a range-only
+// pass of the int8 pointwise kernel updates the mid QuantAct, then the fused kernel writes the depthwise output and
+// tracks the range of the QuantAct behind it.  See include/codenet_dcn.h.
+extern "C" int cdn_codenet_pwdw_s2_supported(int64_t N, int64_t Cin, int64_t C, int64_t H, int64_t W) {
+  if (N <= 0 || N > 65535 || Cin < 4 || Cin > 32 || (Cin & 3) || C < 4 || C > 128 || H < 2 || W < 2) return 0;
+  const int LPP = (int)cdn::ceil_div(C, 4), XPT = 256 / LPP;
+  const int Wo = (int)((W - 1) / 2 + 1);
+  for (int maxl = 4; maxl >= 1; --maxl) {
+    int xso = (maxl * XPT - 1) / 2;
+    if (xso < 1) continue;
+    xso = std::min(xso, Wo);
+    xso = (int)cdn::ceil_div(Wo, cdn::ceil_div(Wo, xso));
+    const int wc = 2 * (xso - 1) + 3;
+    if ((size_t)5 * wc * LPP * 16 + (size_t)wc * 384 <= 56 * 1024 && cdn::ceil_div(wc, XPT) <= maxl &&
+        wc * (Cin / 4) <= 2 * XPT * LPP)
+      return 1;
+  }
+  return 0;
+}
+
+extern "C" int cdn_codenet_pwdw_s2_forward(
+    const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
+    const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum,
+    const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
+    int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream) {
+  CDN_REQUIRE(x && x_qstate && w_pw && w_pw_codes && w_pw_scale && w_pw_colsum && m_min && m_max && m_state && w_dw && out,
+              CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE((r_state == nullptr) == (r_min == nullptr) && (r_state == nullptr) == (r_max == nullptr), CDN_ERR_ARG,
+              "the output QuantAct needs x_min, x_max and state together");
+  CDN_REQUIRE(cdn_codenet_pwdw_s2_supported(N, Cin, C, H, W), CDN_ERR_UNSUPPORTED, "shape outside the fused pw -> dw kernel");
+  CDN_REQUIRE(ld_x >= Cin && (ld_x & 3) == 0 && ld_out >= C && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(w_pw_codes) & 3) == 0, CDN_ERR_ARG, "bad row stride / alignment");
+  // 1. the 1x1 conv as a RANGE-ONLY pass (out = NULL): batch extremes of relu(conv) -> the mid QuantAct
+  const int64_t M = N * H * W;
+  int rc = cdn_codenet_pointwise_mixed_forward(x, x_qstate, nullptr, M, Cin, C, ld_x, 0, w_pw, w_pw_codes, w_pw_scale,
+                                               w_pw_colsum, bias_pw, nullptr, nullptr, 1, nullptr, m_min, m_max, m_state,
+                                               bits, momentum, running, workspace, workspace_bytes, nullptr, stream);
+  if (rc) return rc;
+  // 2. conv recomputed into the ring rows of the stride-2 depthwise
+  const int Hs = (int)H, Ws = (int)W, Ho = (Hs - 1) / 2 + 1, Wo = (Ws - 1) / 2 + 1;
+  const int LPP = (int)cdn::ceil_div(C, 4), XPT = 256 / LPP;
+  int best_maxl = 0, XSo = 0;
+  for (int maxl = 4; maxl >= 1; --maxl) {
+    int xso = (maxl * XPT - 1) / 2;
+    if (xso < 1) continue;
+    xso = std::min(xso, Wo);
+    xso = (int)cdn::ceil_div(Wo, cdn::ceil_div(Wo, xso));
+    const int wc = 2 * (xso - 1) + 3;
+    if ((size_t)5 * wc * LPP * 16 + (size_t)wc * 384 <= 56 * 1024 && cdn::ceil_div(wc, XPT) <= maxl &&
+        wc * (Cin / 4) <= 2 * XPT * LPP) {
+      best_maxl = (int)cdn::ceil_div(wc, XPT);
+      XSo = xso;
+      break;
+    }
+  }
+  const int nxs = (int)cdn::ceil_div(Wo, XSo), wc = 2 * (XSo - 1) + 3;
+  const size_t lds = (size_t)5 * wc * LPP * 16 + (size_t)wc * 384;
+  long want = cdn::ceil_div(3L * cdn::kCUs, (long)N * nxs);
+  int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho / 8)));
+  const int rps = (int)cdn::ceil_div(Ho, nstrips);
+  nstrips = (int)cdn::ceil_div(Ho, rps);
+  CDN_REQUIRE((long)nstrips * nxs * N <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many workgroups");
+  cdn::AuxWs ws{nullptr, nullptr};
+  if (r_state)
+    CDN_REQUIRE(cdn::aux_workspace(workspace, workspace_bytes, &ws), CDN_ERR_WORKSPACE,
+                "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  const cdn::QUpdate qu{r_min, r_max, static_cast<unsigned *>(r_state), ws.arrive, (float)(momentum - 1.0),
+                        (float)(1.0 - momentum), bits, running};
+  float2 *mm = r_state ? ws.partials : nullptr;
+  const int Cpad = (int)((Cin + 63) / 64 * 64);
+  dim3 grid((unsigned)(nstrips * nxs), (unsigned)N);
+#define CDN_GOPD(ML_)                                                                                          \
+  pwdwx_kernel<ML_><<<grid, XPT * LPP, lds, st>>>(x, static_cast<const unsigned *>(x_qstate), w_pw_codes, w_pw_scale, \
+      w_pw_colsum, w_pw, bias_pw, static_cast<const unsigned *>(m_state), w_dw, bias_dw, out, mm, qu, (int)Cin, Cpad, \
+      (int)C, (int)ld_x, (int)ld_out, Hs, Ws, nxs, XSo, nstrips, rps, LPP, XPT)
+  if (best_maxl == 1) CDN_GOPD(1);
+  else if (best_maxl == 2) CDN_GOPD(2);
+  else if (best_maxl == 3) CDN_GOPD(3);
+  else CDN_GOPD(4);
+#undef CDN_GOPD
+  return cdn::check_launch("codenet pw -> dw (stride 2, conv recomputed)");
 }

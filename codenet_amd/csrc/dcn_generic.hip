@@ -334,7 +334,7 @@ dwo_kernel(const float *__restrict__ x, const float *__restrict__ offset, const 
 // dwo4_kernel (round 3): dwo_kernel with the planes interleaved in channel QUADS ([CC / 4][cell][4]): one ds_read_b128
 // per cell and quad instead of four ds_read_b32 (36 instead of 144 LDS reads per pixel and quad).  Same per-channel
 // expressions in the same order.  C % 4 == 0, CC % 4 == 0.
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(kDwoThreads)
 dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const float *__restrict__ weight,
             float *__restrict__ out, int C, int H, int W, int CC) {
   extern __shared__ float dwo_smem[];
@@ -347,16 +347,16 @@ dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const
   const float *xg = x + ((long)n * C + c0) * HW;
   float *wl = dwo_smem;                                                        // [CC][9]
   float4 *planes = reinterpret_cast<float4 *>(dwo_smem + ((CC * 9 + 3) & ~3));  // [CC / 4][Hp][Wp] channel quads
-  for (int q = threadIdx.x; q < cc * 9; q += (int)blockDim.x) wl[q] = weight[(long)c0 * 9 + q];
-  for (int q = threadIdx.x; q < (cc >> 2) * pstride; q += (int)blockDim.x) planes[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = threadIdx.x; q < cc * 9; q += kDwoThreads) wl[q] = weight[(long)c0 * 9 + q];
+  for (int q = threadIdx.x; q < (cc >> 2) * pstride; q += kDwoThreads) planes[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  for (int q = threadIdx.x; q < cc * HW; q += (int)blockDim.x) {
+  for (int q = threadIdx.x; q < cc * HW; q += kDwoThreads) {
     const int ch = q / HW, r = q - ch * HW;
     const int yy = r / W, xx = r - yy * W;
     reinterpret_cast<float *>(planes)[(((ch >> 2) * pstride + (yy + 1) * Wp + xx + 1) << 2) + (ch & 3)] = xg[q];
   }
   __syncthreads();
-  for (int p = threadIdx.x; p < HW; p += (int)blockDim.x) {
+  for (int p = threadIdx.x; p < HW; p += kDwoThreads) {
     const int h = p / W, w = p - h * W;
     const float *op = offset + (long)n * 18 * HW + p;
     int base[9];
@@ -637,11 +637,9 @@ static int dwo_channels(const Geom &g) {
   const int pstride = (g.H + 2) * (g.W + 2);
   int CC = (64 * 1024 / 4 - 64) / (pstride + 9);
   if (CC < 4 && (g.C & 3) == 0 && (76 * 1024 / 4 - 64) / (pstride + 9) >= 4) CC = 4;   // 64 x 64 planes: a 76-KB quad
-#if !defined(CDN_DWO_NO8)
-  // ... or eight channels in ONE 512-thread workgroup per CU: the nine (cell, weights) records of a pixel -- half of
-  // the kernel's VALU work -- and its 18 offsets are then shared by twice the channels (round 4)
-  if (CC == 4 && (g.C & 7) == 0 && (150 * 1024 / 4 - 64) / (pstride + 9) >= 8) CC = 8;
-#endif
+  // (round 4, measured and removed: eight channels in ONE 512-thread workgroup per CU at 64 x 64 planes -- the nine
+  // (cell, weights) records of a pixel and its 18 offsets shared by twice the channels -- 0.3425 vs 0.3462 ms per
+  // launch at batch 64: nothing; and the 512-thread launch bound cost the smaller planes 20 % (0.081 -> 0.100 ms))
   if (CC > 32) CC = 32;
   if (CC > g.C) CC = g.C;
   if (CC >= 4 && (g.C & 3) == 0) CC &= ~3;          // whole channel quads per workgroup (dwo4_kernel)
@@ -663,9 +661,8 @@ int run_forward(const void *x, const void *w, const void *b, const void *off, co
     if ((CC & 3) == 0 && (g.C & 3) == 0) {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)dwo4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      const int threads = lds > 80 * 1024 ? 512 : kDwoThreads;      // one workgroup per CU: more waves in it
-      dwo4_kernel<<<grid, threads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
-                                              g.C, g.H, g.W, CC);
+      dwo4_kernel<<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
+                                                  g.C, g.H, g.W, CC);
     } else {
       dwo_kernel<<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
                                                  g.C, g.H, g.W, CC);

@@ -1345,9 +1345,17 @@ class FusedBackbone:
             cache[key] = dict(
                 cin=cin, C=oup, h=h, ldh=pad4(h), Hin=H, Win=W, H=Ho, W=Wo,
                 t4=z(Mo, pad4(cin)) if s == 2 else None, t5=z(Mo, pad4(h)) if s == 2 else None,
-                t1s2=z(Mi, pad4(h)) if s == 2 else None,       # pw1 of the stride-2 unit: input resolution
+                t1s2=None,       # pw1 of the stride-2 unit at input resolution: allocated on demand (_t1s2; the
+                                 # layer-1 unit recomputes it inside its depthwise instead, cdn_codenet_pwdw_s2_forward)
+                Mi=Mi, dev=dev,
                 t1=z(Mo, pad4(h)), t2=z(Mo, pad4(h)), t3=z(Mo, pad4(h)), ya=z(Mo, oup), yb=z(Mo, oup))
         return cache[key]
+
+    @staticmethod
+    def _t1s2(L):
+        if L["t1s2"] is None:
+            L["t1s2"] = torch.zeros(L["Mi"], L["ldh"], device=L["dev"])
+        return L["t1s2"]
 
     def _prepare(self, dev):
         from . import _native as N_
@@ -1383,7 +1391,7 @@ class FusedBackbone:
                              L["t5"], ldh)
                     self._il(L["t5"].data_ptr(), ldh, qptr(sh), None, 0, None, Mo, h, y, C)
                     # branch 2: pw -> ReLU -> QuantAct -> dw s2 -> QuantAct -> pw -> ReLU -> shared QuantAct
-                    self._pw(x.data_ptr(), x_q, Mi, x_ld, u["c1"], True, u["a1"], L["t1s2"], ldh)
+                    self._pw(x.data_ptr(), x_q, Mi, x_ld, u["c1"], True, u["a1"], self._t1s2(L), ldh)
                     self._dw(L["t1s2"], qptr(u["a1"]), Nb, h, L["Hin"], L["Win"], 2, ldh, u["c2"], u["a2"],
                              L["t2"], ldh)
                     self._pw(L["t2"].data_ptr(), qptr(u["a2"]), Mo, ldh, u["c3"], True, sh, L["t3"], ldh)
@@ -1558,6 +1566,23 @@ class FusedBackbone:
             out_map, *aa, self._ws_ptr, self._ws_bytes, out_ptr, self._stream)
         N_.check(rc, "cdn_codenet_pointwise_mixed_forward")
 
+    recompute_pw1 = True      # A/B switch (tools/e2e_native_bench.py --no-recompute)
+
+    @staticmethod
+    def _lib():
+        from . import _native as N_
+        return N_.lib()
+
+    def _pwdw_raw(self, x_ptr, x_q, N, cin, H, W, ld_x, Wt, act_mid, C, w, b, act_out, out, ld_out):
+        """1x1 conv (range-only pass -> act_mid) recomputed inside the stride-2 depthwise (-> out, range of act_out)."""
+        from . import _native as N_
+        am, ao = self._act_args(act_mid, self._dev), self._act_args(act_out, out.device)
+        rc = N_.lib().cdn_codenet_pwdw_s2_forward(
+            x_ptr, x_q, N, cin, H, W, ld_x, Wt["w"].data_ptr(), Wt["codes"].data_ptr(), Wt["scale"].data_ptr(),
+            Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), am[0], am[1], am[2], C, w.data_ptr(), b.data_ptr(), ld_out,
+            ao[0], ao[1], ao[2], ao[3], ao[4], ao[5], self._ws_ptr, self._ws_bytes, out.data_ptr(), self._stream)
+        N_.check(rc, "cdn_codenet_pwdw_s2_forward")
+
     def _dw_raw(self, a_ptr, a_q, a_gen, N, C, H, W, stride, ld_in, w, b, act, out, ld_out):
         from . import _native as N_
         rc = N_.lib().cdn_codenet_dw3x3_mixed_forward(
@@ -1600,10 +1625,17 @@ class FusedBackbone:
                                  sp(P["genA"]), P["omapA"].data_ptr(), Y.data_ptr(), C)
                     if ev is not None:
                         ev = self._leave_side(dev)
-                    self._pw_raw(x.data_ptr(), a_q, a_gen, Mi, x_ld, P["c1"], True, u["a1"], None, None,
-                                 L["t1s2"].data_ptr(), ldh)
-                    self._dw_raw(L["t1s2"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["Hin"], L["Win"], 2, ldh,
-                                 P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                    if (self.recompute_pw1 and not mixed_in and a_q is not None and u["a1"] is not None
+                            and self._lib().cdn_codenet_pwdw_s2_supported(Nb, cin, h, L["Hin"], L["Win"])):
+                        # layer 1: the 1x1 conv (K = 24) recomputed inside the stride-2 depthwise -- its 58-channel
+                        # fp32 output at input resolution (243 MB at batch 64, 512 x 512) is never stored
+                        self._pwdw_raw(x.data_ptr(), a_q, Nb, cin, L["Hin"], L["Win"], x_ld, P["c1"], u["a1"], h,
+                                       P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                    else:
+                        self._pw_raw(x.data_ptr(), a_q, a_gen, Mi, x_ld, P["c1"], True, u["a1"], None, None,
+                                     self._t1s2(L).data_ptr(), ldh)
+                        self._dw_raw(L["t1s2"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["Hin"], L["Win"], 2, ldh,
+                                     P["w2"], P["b2"], u["a2"], L["t2"], ldh)
                     if ev is not None:
                         torch.cuda.current_stream(dev).wait_event(ev)
                 else:

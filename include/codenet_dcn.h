@@ -503,6 +503,24 @@ int cdn_codenet_pointwise_nhwc_forward(
     int bits, double momentum, int running, void *workspace, size_t workspace_bytes, float *out,
     void *stream);
 
+/* The first 1x1 conv (+ folded BN + ReLU + QuantAct) of a stride-2 ShuffleNetV2 unit RECOMPUTED inside its depthwise
+ * 3x3, stride 2 (QuantBaseNode branch 2, portable_quantizer/quant_modules.py:809-907: quant_convbn1 -> ReLU -> quant_act1
+ * -> quant_convbn2 -> quant_act2), round 4: in layer 1 the conv's output at input resolution (58 channels, fp32 because
+ * the batch-global range of quant_act1 must be known before it can be quantised) is 243 MB at batch 64, 512 x 512.  Two
+ * launches: a RANGE-ONLY pass of the int8 pointwise kernel (computes the conv, stores nothing, updates m_min / m_max /
+ * m_state exactly as cdn_codenet_pointwise_mixed_forward would), then the depthwise kernel producing its input rows from
+ * x with the same exact integer sums and epilogue expression -- bit-identical to the two stored-tensor calls.
+ *   x [N][H*W][ld_x] pre-quantisation values of the input QuantAct x_qstate (one state), Cin <= 32 channels (% 4);
+ *   w_pw / codes / scale / colsum / bias_pw as in cdn_codenet_pointwise_mixed_forward (C outputs, C <= 128);
+ *   w_dw [C][9], bias_dw [C] or NULL; out [N][Ho*Wo][ld_out] pre-quantisation values of the output QuantAct
+ *   (r_min / r_max / r_state, may be NULL), Ho = (H - 1) / 2 + 1; workspace as the other layer entry points. */
+int cdn_codenet_pwdw_s2_supported(int64_t N, int64_t Cin, int64_t C, int64_t H, int64_t W);
+int cdn_codenet_pwdw_s2_forward(
+    const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
+    const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum,
+    const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
+    int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream);
 /* Mixed-generation variants (ShuffleNetV2 layers WITHOUT a physical channel shuffle):
  * the activation tensor of a layer keeps every channel in a fixed physical slot, pre-quantisation values,
  * and channel c was produced under generation a_gen[c] of the layer's running block-output QuantAct
