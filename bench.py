@@ -72,6 +72,9 @@ def parse(argv=None):
                     "replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-network leg")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs of the same "
+                         "workload, N = 1 only); the committed profiles/ numbers are used instead")
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl == RCCL on ROCm; gloo only with --plumbing-only")
@@ -135,6 +138,69 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL needs it on this host driver)
     return subprocess.call(cmd, env=env)
+
+
+
+# ---- live HBM traffic of the step (roofline.traffic measured IN THIS RUN) -------------------------
+
+FAMILY_OF = (("dw0p_kernel", "dw"), ("dw2u_kernel", "dw"), ("dw2_kernel", "dw"), ("pwi8_kernel", "pointwise"),
+             ("pw3_kernel", "pointwise"), ("pwq8_kernel", "pointwise"), ("pwb3_kernel", "pointwise"),
+             ("pwd3_kernel", "pointwise"), ("scale_n", "scale"), ("unpack_kernel", "unpack"), ("expand8", "unpack"))
+
+
+def _family_bytes(per_kernel_bytes):
+    fam = {}
+    for name, b in per_kernel_bytes.items():
+        for tag, f in FAMILY_OF:
+            if tag in name:
+                fam[f] = fam.get(f, 0) + int(b)
+                break
+    return fam
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per step by kernel family, measured now: this process (which has NOT touched the GPU yet) starts two
+    short child runs of the same workload under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    (separate passes, no trace domain beyond the kernel trace; eager launches, 3 steps) and reads the steady-state
+    iterations with tools/pmc_steady.py's rules (read bytes = 2 x FETCH_SIZE on gfx950, MI355X_MICROARCH.md).  Returns
+    None -- and the committed profiles/ numbers are used -- when rocprofv3 is missing, this process is itself being
+    profiled, or anything fails; never raises."""
+    import shutil
+    import tempfile
+    try:
+        exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+        if exe is None or args.path != "fused" or not os.path.exists("/dev/kfd"):
+            return None
+        if any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+            return None                              # already under a profiler: no nested profiling
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_steady
+        base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-graph",
+                "--no-cpu-baseline", "--no-e2e", "--no-live-pmc", "--regions", "1", "--batch", str(args.batch),
+                "--res", str(args.res)] + (["--w2"] if args.w2 else []) + (["--fp32"] if args.fp32 else []) + \
+               (["--frozen"] if args.frozen else [])
+        per = {}
+        with tempfile.TemporaryDirectory(prefix="cdn_pmc_", dir="/tmp") as tmp:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for key, counter, mul in (("read", "FETCH_SIZE", 2048.0), ("write", "WRITE_SIZE", 1024.0)):
+                d = os.path.join(tmp, key)
+                rc = subprocess.call([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"]
+                                     + base, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                     timeout=240)
+                if rc != 0:
+                    return None
+                rows, spans = pmc_steady.iterations(pmc_steady.load(d, counter),
+                                                    "frozen_params_kernel" if args.frozen and not args.fp32 else "scale_n",
+                                                    1 if (args.frozen and not args.fp32) else 3, 2,
+                                                    ["__amd_rocclr", "at::native"])
+                for lo, hi in spans:
+                    for name, v in rows[lo:hi]:
+                        k = pmc_steady.short(name)
+                        per[k] = per.get(k, 0.0) + v * mul / len(spans)
+        fam = _family_bytes(per)
+        return fam if fam.get("dw") and fam.get("pointwise") else None
+    except Exception:      # noqa: BLE001 -- a measurement aid must never take the benchmark down
+        return None
 
 
 # ---- CPU baselines (the only place bench.py touches oracle/) ------------------------------------------------
@@ -369,6 +435,11 @@ def main():
         sys.exit(2)
     if args.plumbing_only:
         sys.exit(plumbing_only(args, world, rank))
+    # roofline.traffic measured in THIS run (N = 1): two short profiled child runs, started before this process
+    # touches the GPU
+    live_traffic = None
+    if world == 1 and rank == 0 and not args.no_live_pmc and not args.no_graph:
+        live_traffic = live_pmc_traffic(args)
 
     import torch
     import torch.distributed as dist
@@ -632,29 +703,35 @@ def main():
                                if fused is not None else
                                {"dw": "dw_kernel", "scale": "scale_kernel",
                                 "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (only valid for
-        # the workload they were collected on; null otherwise)
-        for rnd in ("r03", "r02", "r01"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", rnd,
-                                                 "pmc_traffic_frozen.json" if frozen_main else "pmc_traffic.json")))
-            except (OSError, ValueError):
-                continue
-            w = pm["workload"]
-            if (w["res"], w["batch"], w["w2"], w["fp32"], w["path"]) == \
-                    (args.res, args.batch, args.w2, args.fp32, args.path) and roof["bound"] == "hbm" \
-                    and bool(w.get("frozen", False)) == bool(args.frozen):
-                roof["traffic"] = pm["bytes_per_step"].get(dominant)
-                roof["traffic_note"] = ("bytes per step (sum over the kernel's launches), PMC FETCH_SIZE*2 + "
-                                        "WRITE_SIZE, profiles/%s" % rnd)
-                roof["algorithmic_bytes_per_step"] = nbytes
-                # the whole step against the same peak: every kernel family's PMC bytes / the step's wall time
-                step_bytes = sum(v for k, v in pm["bytes_per_step"].items() if k != "unpack")
-                roof["step"] = {"traffic": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
-                                "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-                                "note": "all kernels of the step (scale + gather + pointwise): PMC bytes per step / "
-                                        "ms_per_step"}
-            break
+        # HBM traffic of the step: measured live in this run (live_pmc_traffic), else from the committed rocprofv3 PMC
+        # passes of the same workload (profiles/<round>/; null when none matches)
+        def _set_traffic(bytes_per_step, source):
+            roof["traffic"] = bytes_per_step.get(dominant)
+            roof["traffic_source"] = source
+            roof["traffic_note"] = "bytes per step (sum over the kernel family's launches), PMC FETCH_SIZE*2 + WRITE_SIZE"
+            roof["algorithmic_bytes_per_step"] = nbytes
+            step_bytes = sum(v for k, v in bytes_per_step.items() if k != "unpack")
+            roof["step"] = {"traffic": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
+                            "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                            "traffic_by_family": {k: int(v) for k, v in bytes_per_step.items()},
+                            "note": "all kernels of the step (scale + gather + pointwise): PMC bytes per step / "
+                                    "ms_per_step"}
+        if live_traffic and roof["bound"] == "hbm":
+            _set_traffic(live_traffic, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this bench.py "
+                                       "invocation (eager launches, 3 steps)")
+        elif roof["bound"] == "hbm":
+            for rnd in ("r04", "r03", "r02", "r01"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", rnd,
+                                                     "pmc_traffic_frozen.json" if frozen_main else "pmc_traffic.json")))
+                except (OSError, ValueError):
+                    continue
+                w = pm["workload"]
+                if (w["res"], w["batch"], w["w2"], w["fp32"], w["path"]) == \
+                        (args.res, args.batch, args.w2, args.fp32, args.path) \
+                        and bool(w.get("frozen", False)) == bool(args.frozen):
+                    _set_traffic(pm["bytes_per_step"], "committed: profiles/%s" % rnd)
+                break
         if fused is not None:
             # every family of the step against the same HBM peak (the dominant one flips between the gather and the
             # pointwise family from box to box: they take 103-110 us each)

@@ -2673,6 +2673,13 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   } while (0)
     // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
     // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
+    // round 4: when 64-row tiles leave the chip with at most ONE workgroup per CU (CoDeNet2x stage 0 at 32 images:
+    // M = 8192, K = 2176 -- a chain of 68 dependent k tiles per workgroup and nothing beside it), 32-row tiles give
+    // every CU two chains to interleave
+#if !defined(CDN_NO_PWI32)
+    if (pw_bn == 128 && cdn::ceil_div(M, 64) * cdn::ceil_div(Co, 128) <= cdn::kCUs && Kt >= 1024) CDN_PWI(32, 128, 1);
+    else
+#endif
     if (pw_bn == 128) CDN_PWI(64, 128, 2);
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI

@@ -593,7 +593,7 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
 // reference's fp32 conv, not the integer one (pwi8_kernel's own wide branch is an f32-MFMA evaluation, also not).
 // Cin <= 32 (a multiple of 4), C <= 128, stride 2.
 // ------------------------------------------------------------------------------------------
-template <int MAXL>
+template <int MAXL, int Q4T>      // Q4T: input channel quads per pixel the dot products run over (6: Cin <= 24, else 8)
 __global__ void __launch_bounds__(256)
 pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const signed char *__restrict__ Wq,
              const float *__restrict__ wscale, const int *__restrict__ wsum, const float *__restrict__ Wf,
@@ -617,7 +617,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   const bool wide = xq[6] != 0u;
   const float ms_ = reinterpret_cast<const float *>(mq)[2], mz_ = reinterpret_cast<const float *>(mq)[3];
   const float mr_ = __fdiv_rn(1.0f, ms_);
-  int wq[4][8];
+  int wq[4][Q4T];
   float rinv[4], pb[4], wk[9][4], bs[4];
   int t128[4];
 #pragma unroll
@@ -625,7 +625,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
     const int c = min(cb + e, C - 1);
     const bool on = cb + e < C;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < Q4T; ++q)
       wq[e][q] = (on && q < Q4) ? *reinterpret_cast<const int *>(Wq + (long)c * Cpad + 4 * q) : 0;
     rinv[e] = __fdiv_rn(1.0f, __fmul_rn(xs_, wscale[c]));
     t128[e] = 128 * wsum[c];
@@ -699,7 +699,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
             for (int e = 0; e < 4; ++e) {
               int s0 = 0, s1 = 0;
 #pragma unroll
-              for (int q = 0; q < 8; ++q) {
+              for (int q = 0; q < Q4T; ++q) {
                 s0 = __builtin_amdgcn_sdot4(a0[q], wq[e][q], s0, false);
                 s1 = __builtin_amdgcn_sdot4(a1[q], wq[e][q], s1, false);
               }
@@ -1758,14 +1758,20 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
   float2 *mm = r_state ? ws.partials : nullptr;
   const int Cpad = (int)((Cin + 63) / 64 * 64);
   dim3 grid((unsigned)(nstrips * nxs), (unsigned)N);
-#define CDN_GOPD(ML_)                                                                                          \
-  pwdwx_kernel<ML_><<<grid, XPT * LPP, lds, st>>>(x, static_cast<const unsigned *>(x_qstate), w_pw_codes, w_pw_scale, \
+#define CDN_GOPD1(ML_, Q_)                                                                                     \
+  pwdwx_kernel<ML_, Q_><<<grid, XPT * LPP, lds, st>>>(x, static_cast<const unsigned *>(x_qstate), w_pw_codes, w_pw_scale, \
       w_pw_colsum, w_pw, bias_pw, static_cast<const unsigned *>(m_state), w_dw, bias_dw, out, mm, qu, (int)Cin, Cpad, \
       (int)C, (int)ld_x, (int)ld_out, Hs, Ws, nxs, XSo, nstrips, rps, LPP, XPT)
+#define CDN_GOPD(ML_)                  \
+  do {                                 \
+    if (Cin <= 24) CDN_GOPD1(ML_, 6);  \
+    else CDN_GOPD1(ML_, 8);            \
+  } while (0)
   if (best_maxl == 1) CDN_GOPD(1);
   else if (best_maxl == 2) CDN_GOPD(2);
   else if (best_maxl == 3) CDN_GOPD(3);
   else CDN_GOPD(4);
 #undef CDN_GOPD
+#undef CDN_GOPD1
   return cdn::check_launch("codenet pw -> dw (stride 2, conv recomputed)");
 }
