@@ -13,9 +13,9 @@ run() {   # name, marker, per-iter, command...
   local name=$1 marker=$2 per=$3; shift 3
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pv_${name}_f" -- "$@" > "$OUT/pv_${name}.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pv_${name}_w" -- "$@" >> "$OUT/pv_${name}.log" 2>&1
-  python3 tools/pmc_steady.py "$OUT/pv_${name}_f" "$OUT/pv_${name}_w" "$marker" --per-iter "$per" > "$OUT/pmc_traffic_${name}.json" 2>> "$OUT/pv_${name}.log"
+  python3 tools/pmc_steady.py "$OUT/pv_${name}_f" "$OUT/pv_${name}_w" "$marker" --per-iter "$per" > "$OUT/pmc_steady_${name}.json" 2>> "$OUT/pv_${name}.log"
   rm -rf "$OUT/pv_${name}_f" "$OUT/pv_${name}_w"
-  echo "$name: $(cut -c1-300 "$OUT/pmc_traffic_${name}.json")"
+  echo "$name: $(cut -c1-300 "$OUT/pmc_steady_${name}.json")"
 }
 run cfg3 scale_nchw_kernel 1 python3 bench.py $P
 run cfg4 scale_nchw_kernel 1 python3 bench.py --config cfg4 $P

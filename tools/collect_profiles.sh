@@ -3,7 +3,7 @@
 # (separate passes, no trace domains combined with --pmc), all into gpurun_out/<round>/.
 # Afterwards: python tools/summarize_profiles.py <round>   (in the build container) -> profiles/<round>/
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
