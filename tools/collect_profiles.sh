@@ -48,7 +48,8 @@ for mode in bytes stages_only; do
   arg=""; [ $mode = stages_only ] && arg=stages_only
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/fz_$mode" -o fz -- python3 tools/prof_e2e_frozen.py $arg > "$OUT/fz_$mode.log" 2>&1
   f=$(find "$OUT/fz_$mode" -name "fz_kernel_trace.csv" | head -1)
-  [ -n "$f" ] && python3 tools/steady_stats.py "$f" 23 > "$OUT/e2e_frozen_${mode}_steady.txt"
+  m=stemq8_kernel; [ $mode = stages_only ] && m="stem_kernel<"
+  [ -n "$f" ] && python3 tools/steady_stats.py "$f" "marker:$m" erfinv > "$OUT/e2e_frozen_${mode}_steady.txt"
   rm -rf "$OUT/fz_$mode"
 done
 for n in e2e_stats train_stats stats stats_frozen; do

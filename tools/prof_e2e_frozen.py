@@ -16,6 +16,7 @@ with torch.no_grad():
     for _ in range(3):
         model(images)
     torch.cuda.synchronize()
+    torch.full((4,), 0.5, device=dev).erfinv_()      # a kernel that occurs nowhere else: tools/steady_stats.py's setup marker
     print("MARK begin")
     for _ in range(20):
         harness.process(model, images, flip_test=False)
