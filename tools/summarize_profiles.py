@@ -38,8 +38,8 @@ def is_frozen_variant(k):
     name = k.split(" grid=")[0]
     if any(t in name for t in ("pwq8", "expand8", "frozen_params", "scale_nchw")):
         return True
-    if name.startswith("dw2_kernel"):
-        return name.rstrip(">").endswith("true")                  # <..., X8, OUT8>: OUT8
+    if name.startswith("dw2_kernel") or name.startswith("dw0p_kernel"):
+        return name.rstrip(">").endswith("true")                  # <..., X8, OUT8> / <SQ, OUT8>: OUT8
     if name.startswith("dw2u_kernel"):
         return name.rstrip(">").endswith("true")
     if name.startswith("scale_nhwc"):
