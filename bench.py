@@ -180,13 +180,19 @@ def live_pmc_traffic(args):
                 "--res", str(args.res)] + (["--w2"] if args.w2 else []) + (["--fp32"] if args.fp32 else []) + \
                (["--frozen"] if args.frozen else [])
         per = {}
+        t_start = time.perf_counter()
         with tempfile.TemporaryDirectory(prefix="cdn_pmc_", dir="/tmp") as tmp:
             env = dict(os.environ, TMPDIR="/tmp")
             for key, counter, mul in (("read", "FETCH_SIZE", 2048.0), ("write", "WRITE_SIZE", 1024.0)):
+                # bounded: the two passes together get ~4 minutes (the first python start on a fresh box pages the
+                # framework in for 1-2 minutes); a slow first pass cancels the second -> committed numbers instead
+                left = 240.0 - (time.perf_counter() - t_start)
+                if left < 60.0:
+                    return None
                 d = os.path.join(tmp, key)
                 rc = subprocess.call([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"]
                                      + base, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                     timeout=240)
+                                     timeout=min(left, 170.0))
                 if rc != 0:
                     return None
                 rows, spans = pmc_steady.iterations(pmc_steady.load(d, counter),

@@ -402,3 +402,54 @@ def test_cover_frozen_ranges_only_widens_and_restores_the_running_flags():
     pipeline.set_running_stat(net, True)
     assert pipeline.cover_frozen_ranges(net, [x], margin=0.0) == 0
     assert all(torch.equal(p, q) for p, q in zip(before, (net.a.x_min, net.a.x_max, net.shared.x_min, net.shared.x_max)))
+
+
+def test_overflow_flags_name_the_quantacts_of_the_launch_that_saturated():
+    """pipeline.OverflowFlags (round 4: the byte-code schedules give every launch its own overflow word so that a
+    saturated code names the QuantAct to widen): words, views for a consumer numbering its launches from 0, reset."""
+    from codenet_amd import pipeline
+    f = pipeline.OverflowFlags(6, torch.device("cpu"))
+    a, b, c = object(), object(), object()
+    f.name(0, [a])
+    f.name(1, [a, b])
+    heads = f.slice(4)
+    heads.name(1, [c])                                   # word 5 of the parent
+    assert heads.count() == 2 and heads.ptr(1) == f.ptr(5) and f.who[5] == [c]
+    assert not f.any() and f.acts() == []
+    f.words[1] = 1
+    f.words[5] = 1
+    got = f.acts(reset=False)
+    assert got == [a, b, c] and f.any(reset=False)
+    assert f.acts() == [a, b, c] and not f.any() and int(f.words.sum()) == 0
+
+
+def test_cover_frozen_ranges_refuses_a_model_whose_quantacts_are_never_called():
+    """on a model that runs a fused schedule the QuantAct modules are never called, the hooks never fire and
+    nothing was widened -- silently.  Now it raises (calibrate on the module path, or use calibrate_serving)."""
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[8, 4])
+    x = torch.randn(1, 8, 4, 4)
+    with pytest.raises(RuntimeError, match="no QuantAct was called"):
+        pipeline.cover_frozen_ranges(net, [x], forward=lambda b: None)
+
+
+def test_pmc_steady_reads_the_steady_state_iterations(tmp_path):
+    """tools/pmc_steady.py (bench.py's live roofline.traffic and profiles/<round>/pmc_steady_*.json): iterations are
+    delimited by the marker kernel, the tail after the last marker is cut, FETCH_SIZE counts double."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pmc_steady
+    d = tmp_path / "run" / "x"
+    d.mkdir(parents=True)
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    names = ["setup", "void (anonymous namespace)::scale_nchw_kernel(float)", "dw0p_kernel<true, false>(x)",
+             "pwi8_kernel<64, 128, 2, true>(y)"]
+    seq = [0] + [1, 2, 3] * 4 + [1, 2]                     # four whole iterations, then a cut one
+    for i, k in enumerate(seq):
+        rows.append('%d,"%s",FETCH_SIZE,%g' % (i + 1, names[k], {0: 5.0, 1: 10.0, 2: 20.0, 3: 40.0}[k]))
+    (d / "1_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    data = pmc_steady.load(str(tmp_path / "run"), "FETCH_SIZE")
+    rows2, spans = pmc_steady.iterations(data, "scale_nchw", 1, 2, ["setup"])
+    assert len(spans) == 2 and all(hi - lo == 3 for lo, hi in spans)
+    per_iter = sum(v for lo, hi in spans for _, v in rows2[lo:hi]) / len(spans)
+    assert per_iter == 70.0
