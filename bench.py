@@ -190,9 +190,21 @@ def live_pmc_traffic(args):
                 if left < 60.0:
                     return None
                 d = os.path.join(tmp, key)
-                rc = subprocess.call([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"]
-                                     + base, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                     timeout=min(left, 170.0))
+                # own process group: on a timeout the profiler AND the bench under it are ended (a survivor would run
+                # beside the timed region) -- by exact group id, never by pattern
+                proc = subprocess.Popen([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"]
+                                        + base, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                                        stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    rc = proc.wait(timeout=min(left, 170.0))
+                except subprocess.TimeoutExpired:
+                    import signal
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    proc.wait()
+                    return None
                 if rc != 0:
                     return None
                 rows, spans = pmc_steady.iterations(pmc_steady.load(d, counter),
