@@ -2105,10 +2105,19 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   constexpr int PF = 2;
   float4 buf[PF][4];
   long prb = rb_first;         // block and window of the NEXT prefetch
-  int pw_ = 0;
+  // Round 4: only the 32-channel windows in which THIS column tile has a non-zero weight code are streamed.  In the
+  // shuffle-free layout the pass-through half of a unit's input row meets zero weight columns (FusedBackbone.
+  // _mixed_plan); its slots form a few runs, so 1-7 of the 4 / 8 / 15 windows of a layer-1 / 2 / 3 row hold nothing
+  // but zeros: x * 0 adds an exact zero to every accumulator, skipping the window is bit-identical, and the A stream
+  // (and the chain of dependent window loads) shrinks by that share.  wmask is built while the B tile is staged.
+  __shared__ unsigned s_wmask;
+  if (tid == 0) s_wmask = 0u;
+  __syncthreads();                    // (before the other waves OR their bits in)
+  unsigned wmask = 0u, prem = 0u;     // the tile's window set; windows of the current block not yet prefetched
   auto load_next = [&](float4 (&d)[4]) {
     const bool live = prb < nrb;
     const long row = min(prb * 32 + (lane & 31), M - 1);
+    const int pw_ = __builtin_ctz(prem);
     const int k = 32 * pw_ + 16 * (lane >> 5);
     // unconditional loads from clamped addresses (C % 4 == 0, C >= 4), zeroed afterwards: a load under a
     // per-lane condition is a branch + a wait of its own in the ISA
@@ -2118,13 +2127,12 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     for (int i = 0; i < 4; ++i) t4[i] = *reinterpret_cast<const float4 *>(rowp + min(k + 4 * i, C - 4));
 #pragma unroll
     for (int i = 0; i < 4; ++i) d[i] = (live && k + 4 * i < C) ? t4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (++pw_ == nwin) {
-      pw_ = 0;
+    prem &= prem - 1;
+    if (prem == 0u) {
+      prem = wmask;
       prb += rb_stride;
     }
   };
-#pragma unroll
-  for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
 
   // ---- quantiser table and B tile -> LDS (loads batched: the prologue is latency, not work) -----------
   if (has_q) {
@@ -2171,6 +2179,12 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       cw[u] = (i32x4){0, 0, 0, 0};
       if (q < nitems && n0 + r_ < Co)
         cw[u] = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {       // (16 codes = half a window)
+      const int q = q0 + 256 * u;
+      if (q < nitems && (cw[u][0] | cw[u][1] | cw[u][2] | cw[u][3]) != 0)
+        atomicOr(&s_wmask, 1u << ((q % chunks) >> 1));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -2226,6 +2240,15 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   }
   __syncthreads();
   CDN_STAMPR(2, 1);
+  wmask = __builtin_amdgcn_readfirstlane(s_wmask);
+  if (wmask == 0u) wmask = 1u;          // an all-zero tile still walks one window (its products are zeros)
+#if defined(CDN_NO_WSKIP)               // A/B build: every window, as in round 3
+  wmask = nwin >= 32 ? 0xffffffffu : ((1u << nwin) - 1u);
+#endif
+  prem = wmask;
+  const int nlist = __builtin_popcount(wmask);
+#pragma unroll
+  for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
 
   const unsigned char *bbase = smem + (size_t)(lane & 31) * ldb + 32 * (lane >> 5);
   const float *qrow = qtab + 16 * (lane >> 5);
@@ -2235,11 +2258,13 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     f32x16 acc[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[j] = (f32x16){0};
-    for (int w0 = 0; w0 < nwin; w0 += PF) {
+    unsigned crem = wmask;                                      // windows of this block not yet computed
+    for (int w0 = 0; w0 < nlist; w0 += PF) {
 #pragma unroll
       for (int p_ = 0; p_ < PF; ++p_) {
-        const int w = w0 + p_;
-        if (w < nwin) {                                         // wave-uniform
+        if (w0 + p_ < nlist) {                                  // wave-uniform
+          const int w = __builtin_ctz(crem);
+          crem &= crem - 1;
           float v[16];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -2326,7 +2351,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     // this, layer4 (K = 464: 15 windows) computed every second 32-row block of a wave from swapped k windows
     // whenever a wave walked more than one block (M > 8192 rows: batch 64 at 512 x 512 only; found by
     // tests/test_harness.py::test_whole_network_512_batch64_fused_vs_module_path in round 3).
-    if (nwin & 1) {
+    if (nlist & 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float4 t = buf[0][i];
