@@ -2078,8 +2078,10 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 // sequence q0 = n*r, q = fma(fma(-q0, s, n), r, q0) with r = RN(1/s): the correctly rounded quotient in
 // 3 instructions instead of the ~10 of the IEEE expansion (this loop is VALU-bound next to the MFMAs).
 // ------------------------------------------------------------------------------------------
+// (blockDim.x = 256, or 512 where the B tile leaves room for only ONE workgroup per CU -- layer4: 125 KB -- so that the CU
+// still runs two waves per SIMD behind one staged tile: round 4)
 template <int TN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2)))
 pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu,
@@ -2094,6 +2096,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // per half window in the ISA)
   float *qtab = reinterpret_cast<float *>(smem + (size_t)32 * TN * ldb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = (int)blockDim.x, nwv = nthr >> 6;
   const int n0 = blockIdx.y * 32 * TN;
   const bool has_q = aq != nullptr;
   auto pack_hi = [](unsigned a_, unsigned b_) -> unsigned { return __builtin_amdgcn_perm(a_, b_, 0x07060302u); };
@@ -2101,7 +2104,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // ---- A stream: a wave walks the 32-row blocks rb = first, first + stride, ...; its windows (rb, w) form
   // one sequence that is prefetched PF windows ahead across block boundaries -------------------------
   const long nrb = (M + 31) >> 5;
-  const long rb_first = (long)blockIdx.x * 4 + wave, rb_stride = (long)gridDim.x * 4;
+  const long rb_first = (long)blockIdx.x * nwv + wave, rb_stride = (long)gridDim.x * nwv;
   constexpr int PF = 2;
   float4 buf[PF][4];
   long prb = rb_first;         // block and window of the NEXT prefetch
@@ -2136,45 +2139,38 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 
   // ---- quantiser table and B tile -> LDS (loads batched: the prologue is latency, not work) -----------
   if (has_q) {
-    float4 te[2];
-    int gen[2] = {0, 0};
-    if (agen) {                                      // both generation bytes first, then both states: 2 round trips
+    // (a table entry per channel; both generation bytes first, then both states: 2 round trips per pass)
+    for (int c0_ = 0; c0_ < Kp; c0_ += 2 * nthr) {
+      float4 te[2];
+      int gen[2] = {0, 0};
+      if (agen) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) gen[u] = agen[min(tid + 256 * u, C - 1)];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float2 sz2 = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
-                                                           cdn::kQStateWords * gen[u] + 2);
-      te[u] = make_float4(sz2.x, sz2.y, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int c = tid + 256 * u;
-      if (c < Kp) {
-        qtab[c] = te[u].x;
-        qtab[Kp + c] = te[u].y;
-        qtab[2 * Kp + c] = c < C ? __fdiv_rn(1.0f, te[u].x) : 0.0f;
+        for (int u = 0; u < 2; ++u) gen[u] = agen[min(c0_ + tid + nthr * u, C - 1)];
       }
-    }
-    for (int c = tid + 512; c < Kp; c += 256) {                // (C > 512: not reached by the dispatcher)
-      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C) {
-        const float *sp = reinterpret_cast<const float *>(aq) + (agen ? cdn::kQStateWords * agen[c] : 0);
-        e = make_float4(sp[2], sp[3], __fdiv_rn(1.0f, sp[2]), 0.f);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float2 sz2 = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
+                                                             cdn::kQStateWords * gen[u] + 2);
+        te[u] = make_float4(sz2.x, sz2.y, 0.f, 0.f);
       }
-      qtab[c] = e.x;
-      qtab[Kp + c] = e.y;
-      qtab[2 * Kp + c] = e.z;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = c0_ + tid + nthr * u;
+        if (c < Kp) {
+          qtab[c] = te[u].x;
+          qtab[Kp + c] = te[u].y;
+          qtab[2 * Kp + c] = c < C ? __fdiv_rn(1.0f, te[u].x) : 0.0f;
+        }
+      }
     }
   }
   const int chunks = Kp >> 4;                                // 16-code chunks per row
   const int nitems = 32 * TN * chunks;
-  for (int q0 = tid; q0 < nitems; q0 += 256 * 4) {
+  for (int q0 = tid; q0 < nitems; q0 += nthr * 4) {
     i32x4 cw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int q = q0 + 256 * u;
+      const int q = q0 + nthr * u;
       const int r_ = q / chunks, ch = q - r_ * chunks;
       cw[u] = (i32x4){0, 0, 0, 0};
       if (q < nitems && n0 + r_ < Co)
@@ -2182,13 +2178,13 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {       // (16 codes = half a window)
-      const int q = q0 + 256 * u;
+      const int q = q0 + nthr * u;
       if (q < nitems && (cw[u][0] | cw[u][1] | cw[u][2] | cw[u][3]) != 0)
         atomicOr(&s_wmask, 1u << ((q % chunks) >> 1));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int q = q0 + 256 * u;
+      const int q = q0 + nthr * u;
       if (q < nitems) {
         const int r_ = q / chunks, ch = q - r_ * chunks;
         unsigned w8[8];
@@ -2735,8 +2731,16 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
       dim3 g((unsigned)gx, ny);
       auto kern = tn == 4 ? pwd3_kernel<4> : pwd3_kernel<2>;
       (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d3);
-      kern<<<g, 256, lds_d3, st>>>(d, dst, w_pw_codes, w_pw_scale, bias_pw, r_out, rmm, qu_r, M, (int)C, Cpad,
-                                   (int)Co, relu, (int)lda, (int)ldo, a_gen, out_map);
+      // one workgroup per CU (a B tile above 80 KB: layer4): 8 waves behind the one staged tile instead of 4
+#if defined(CDN_PWD3_256)
+      const int d3_threads = 256;
+#else
+      const int d3_threads = per_cu == 1 ? 512 : 256;
+#endif
+      const long gx2 = std::max<long>(1, std::min<long>(cdn::ceil_div(M, d3_threads / 2), per_cu * cdn::kCUs / ny));
+      g = dim3((unsigned)gx2, ny);
+      kern<<<g, d3_threads, lds_d3, st>>>(d, dst, w_pw_codes, w_pw_scale, bias_pw, r_out, rmm, qu_r, M, (int)C, Cpad,
+                                          (int)Co, relu, (int)lda, (int)ldo, a_gen, out_map);
     } else if (pw_bn == 128 && pw_bm == 64) CDN_PWB(64, 128, 2);
     else if (pw_bn == 128) CDN_PWB(128, 128, 4);
     else CDN_PWB(128, 64, 4);
