@@ -1999,7 +1999,7 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   load_tile(0);
   if (mixed) {
     for (int c = tid; c < C; c += 256) {
-      const float *sp = reinterpret_cast<const float *>(aq) + cdn::kQStateWords * agen[c];
+      const float *sp = reinterpret_cast<const float *>(aq) + cdn::kQStateWords * (agen[c] == 255 ? 0 : agen[c]);   // (255: unused channel)
       qt[c] = make_float2(sp[2], sp[3]);
     }
     __syncthreads();
@@ -2112,7 +2112,8 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // shuffle-free layout the pass-through half of a unit's input row meets zero weight columns (FusedBackbone.
   // _mixed_plan); its slots form a few runs, so 1-7 of the 4 / 8 / 15 windows of a layer-1 / 2 / 3 row hold nothing
   // but zeros: x * 0 adds an exact zero to every accumulator, skipping the window is bit-identical, and the A stream
-  // (and the chain of dependent window loads) shrinks by that share.  wmask is built while the B tile is staged.
+  // (and the chain of dependent window loads) shrinks by that share.  The host marks such columns with generation 255 in
+  // the per-unit a_gen array (FusedBackbone._mixed_plan); the mask is built from those bytes in the table staging.
   __shared__ unsigned s_wmask;
   if (tid == 0) s_wmask = 0u;
   __syncthreads();                    // (before the other waves OR their bits in)
@@ -2146,6 +2147,12 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       if (agen) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) gen[u] = agen[min(c0_ + tid + nthr * u, C - 1)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {         // generation 255 = "this column meets only zero weight codes" (host)
+          const int c = c0_ + tid + nthr * u;
+          if (c < C && gen[u] != 255) atomicOr(&s_wmask, 1u << (c >> 5));
+          if (gen[u] == 255) gen[u] = 0;
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -2164,6 +2171,18 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
     }
   }
+  // the window set is known after ONE round trip (the generation bytes): the A stream starts here, beside the staging of
+  // the B tile below
+  __syncthreads();
+  wmask = (has_q && agen) ? __builtin_amdgcn_readfirstlane(s_wmask) : 0u;
+  if (wmask == 0u) wmask = nwin >= 32 ? 0xffffffffu : ((1u << nwin) - 1u);      // no mask given: every window
+#if defined(CDN_NO_WSKIP)               // A/B build: every window, as in round 3
+  wmask = nwin >= 32 ? 0xffffffffu : ((1u << nwin) - 1u);
+#endif
+  prem = wmask;
+  const int nlist = __builtin_popcount(wmask);
+#pragma unroll
+  for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
   const int chunks = Kp >> 4;                                // 16-code chunks per row
   const int nitems = 32 * TN * chunks;
   for (int q0 = tid; q0 < nitems; q0 += nthr * 4) {
@@ -2176,12 +2195,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       if (q < nitems && n0 + r_ < Co)
         cw[u] = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {       // (16 codes = half a window)
-      const int q = q0 + nthr * u;
-      if (q < nitems && (cw[u][0] | cw[u][1] | cw[u][2] | cw[u][3]) != 0)
-        atomicOr(&s_wmask, 1u << ((q % chunks) >> 1));
-    }
+
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = q0 + nthr * u;
@@ -2236,15 +2250,6 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   }
   __syncthreads();
   CDN_STAMPR(2, 1);
-  wmask = __builtin_amdgcn_readfirstlane(s_wmask);
-  if (wmask == 0u) wmask = 1u;          // an all-zero tile still walks one window (its products are zeros)
-#if defined(CDN_NO_WSKIP)               // A/B build: every window, as in round 3
-  wmask = nwin >= 32 ? 0xffffffffu : ((1u << nwin) - 1u);
-#endif
-  prem = wmask;
-  const int nlist = __builtin_popcount(wmask);
-#pragma unroll
-  for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
 
   const unsigned char *bbase = smem + (size_t)(lane & 31) * ldb + 32 * (lane >> 5);
   const float *qrow = qtab + 16 * (lane >> 5);
@@ -2735,7 +2740,8 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
 #if defined(CDN_PWD3_256)
       const int d3_threads = 256;
 #else
-      const int d3_threads = per_cu == 1 ? 512 : 256;
+      // (only where 256-row workgroups still fill the chip: layer 3's units have 64 x 2 of them and keep 256 threads)
+      const int d3_threads = (per_cu == 1 && cdn::ceil_div(M, 256) * ny >= cdn::kCUs) ? 512 : 256;
 #endif
       const long gx2 = std::max<long>(1, std::min<long>(cdn::ceil_div(M, d3_threads / 2), per_cu * cdn::kCUs / ny));
       g = dim3((unsigned)gx2, ny);

@@ -1504,7 +1504,9 @@ class FusedBackbone:
                 ngen += 2
             else:
                 P2 = [p_ for p_ in range(C) if logical[p_] >= h]
-                P["gen_in"] = u8(gen)
+                # generation 255 = "this physical column meets only zero weight codes in this unit's first 1x1 conv" (the
+                # pass-through half): pwd3_kernel skips the 32-channel windows that hold nothing else (round 4)
+                P["gen_in"] = u8([gen[p_] if logical[p_] >= h else 255 for p_ in range(C)])
                 P["c1"] = pw_weights(u["c1"], [logical[p_] - h if logical[p_] >= h else -1 for p_ in range(C)], C,
                                      list(gen))
                 P["c3"] = pw_weights(u["c3"], list(range(h)), h)

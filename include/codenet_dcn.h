@@ -530,6 +530,8 @@ int cdn_codenet_pwdw_s2_forward(
  * bookkeeping on the host: weight columns are permuted to the physical order (zero columns for the
  * pass-through half of a unit) and out_map[co] names the slot output channel co is written to (NULL:
  * slot co).  a_gen == NULL: exactly cdn_codenet_pointwise_nhwc_forward / cdn_codenet_dw3x3_nhwc_forward.
+ * Pointwise only (round 4): a_gen[c] == 255 marks a column whose weight codes are all zero (the pass-through half of a
+ * shuffle-free unit row); the kernel may skip whole 32-channel windows of such columns (x * 0 adds an exact zero).
  * The pointwise form needs the 4-bit weight codes (bf16 split kernel) and C <= 512. */
 int cdn_codenet_pointwise_mixed_forward(
     const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t M, int64_t C, int64_t Co,
