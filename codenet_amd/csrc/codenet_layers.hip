@@ -1367,7 +1367,10 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
       if (best_maxl) {
         const int XSo = best_xso, nxs = (int)cdn::ceil_div(Wo_, XSo), wc = stride * (XSo - 1) + 3;
         const size_t lds = (size_t)ring * wc * LPP * 16;
-        constexpr int wg_per_cu = 2;
+#if !defined(CDN_DWX_WGPCU)
+#define CDN_DWX_WGPCU 2
+#endif
+        constexpr int wg_per_cu = CDN_DWX_WGPCU;
         long want = cdn::ceil_div((long)wg_per_cu * cdn::kCUs, (long)N * nxs);
         int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho_ / 8)));
         const int rps = (int)cdn::ceil_div(Ho_, nstrips);
@@ -1414,7 +1417,10 @@ extern "C" int cdn_codenet_dw3x3_mixed_forward(
       const size_t lds = (size_t)ring * (Ws + 2) * cch * sizeof(float);
       const int nchunks = (int)cdn::ceil_div(C, cch);
       // strips: enough workgroups to fill the chip twice, at least 8 output rows each
-      constexpr int wg_per_cu = 2;
+#if !defined(CDN_DWS_WGPCU)
+#define CDN_DWS_WGPCU 2
+#endif
+      constexpr int wg_per_cu = CDN_DWS_WGPCU;
       long want = cdn::ceil_div((long)wg_per_cu * cdn::kCUs, (long)N * nchunks);
       int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho_ / 8)));
       const int rps = (int)cdn::ceil_div(Ho_, nstrips);

@@ -17,12 +17,14 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--one-stream", action="store_true", help="A/B: the three heads back to back on one stream")
+    ap.add_argument("--graph", action="store_true", help="time a captured graph of the heads (as inside the e2e graph)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = harness.create_model(quantize=not a.fp32).to(dev)
     feat = pipeline.make_input(a.batch, a.res, device=dev)
     path = pipeline.FusedHotPath(model.deconv_layers)
-    heads = pipeline.FusedHeads({h: getattr(model, h) for h in model.heads})
+    heads = pipeline.FusedHeads({h: getattr(model, h) for h in model.heads}, streams=not a.one_stream)
     for _ in range(5):
         heads(*path.forward_nhwc(feat))
     torch.cuda.synchronize()
@@ -34,6 +36,24 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     total = e0.elapsed_time(e1) / a.steps
+    if a.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            heads(r, rq, shape)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            heads(r, rq, shape)
+        for _ in range(3):
+            g.replay()
+        e0.record()
+        for _ in range(a.steps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        total = e0.elapsed_time(e1) / a.steps
     with ops.KernelTimer({"head_pw", "head_dw", "head_range", "head_tail_small", "head_tail"}) as kt:
         for _ in range(a.steps):
             heads(r, rq, shape)
