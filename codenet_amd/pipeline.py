@@ -265,16 +265,20 @@ def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40):
                 _widen(a, grow, bool(a.x_min.reshape(()) < 0) or hits[id(a)] >= 3)
                 widened.add(id(a))
         return False
-    with torch.no_grad():
-        model(batches[0])                   # builds the byte-code objects
-    clean = until_clean()
-    if clean and margin > 0:
-        for a in acts:
-            _widen(a, margin, bool(a.x_min.reshape(()) < 0))
+    clean = False
+    try:
+        with torch.no_grad():
+            model(batches[0])                   # builds the byte-code objects
         clean = until_clean()
-    fz = getattr(model, "_fzbackbone", None)
+        if clean and margin > 0:
+            for a in acts:
+                _widen(a, margin, bool(a.x_min.reshape(()) < 0))
+            clean = until_clean()
+    finally:
+        fz = getattr(model, "_fzbackbone", None)
+        if fz is not None:
+            fz.fuse_dwpw = True                 # (also when a calibration pass raised)
     if fz is not None:
-        fz.fuse_dwpw = True
         with torch.no_grad():
             for b in batches:               # the serving configuration itself (fused depthwise) must be clean too
                 model(b)
