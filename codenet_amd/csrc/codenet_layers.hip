@@ -624,15 +624,22 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   for (int e = 0; e < 4; ++e) {
     const int c = min(cb + e, C - 1);
     const bool on = cb + e < C;
+    // (unconditional loads from the clamped channel, selected afterwards: no branch / wait per load)
 #pragma unroll
-    for (int q = 0; q < Q4T; ++q)
-      wq[e][q] = (on && q < Q4) ? *reinterpret_cast<const int *>(Wq + (long)c * Cpad + 4 * q) : 0;
+    for (int q = 0; q < Q4T; ++q) {
+      const int t = *reinterpret_cast<const int *>(Wq + (long)c * Cpad + 4 * min(q, Q4 - 1));
+      wq[e][q] = (on && q < Q4) ? t : 0;
+    }
     rinv[e] = __fdiv_rn(1.0f, __fmul_rn(xs_, wscale[c]));
     t128[e] = 128 * wsum[c];
     pb[e] = pbias ? pbias[c] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k][e] = on ? w[(long)c * 9 + k] : 0.0f;
-    bs[e] = (on && bias) ? bias[c] : 0.0f;
+    for (int k = 0; k < 9; ++k) {
+      const float t = w[(long)c * 9 + k];
+      wk[k][e] = on ? t : 0.0f;
+    }
+    bs[e] = bias ? bias[c] : 0.0f;
+    if (!on) bs[e] = 0.0f;
   }
   const int ioff = (int)xz_ + (2048 - 128) - 0x4B400000;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -898,6 +905,9 @@ stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const fl
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
+          // (round 4, measured and reverted: unconditional loads from clamped addresses, masked afterwards -- the remedy that
+          // took dwq8_kernel's guarded loads from 80 to 14-23 us -- make THIS kernel slower: 78-90 us against 61-62 us
+          // alone on the GPU, three interleaved pairs; the guarded form stays)
           const int y = oy * stride + dy - 1, x = ox * stride + dx - 1;
           v[(c * 3 + dy) * 3 + dx] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
                                          ? img[(((long)n * 3 + c) * H + y) * W + x] : 0.0f;
