@@ -600,7 +600,8 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
              const float *__restrict__ pbias, const unsigned *__restrict__ mq, const float *__restrict__ w,
              const float *__restrict__ bias, float *__restrict__ out, float2 *mm, cdn::QUpdate qu, int Cin, int Cpad,
              int C, int ld_x, int ld_out, int Hs, int Ws, int nxs, int XSo, int nstrips, int rps, int LPP, int XPT) {
-  extern __shared__ float4 ring4[];         // [RING][Wc][LPP], then the code rows [2][Wc][16] dwords
+  extern __shared__ float4 ring4[];         // [RING][Wc][LPP], then the code rows [2][Wc][24] dwords
+  __shared__ unsigned s_wide_row[2];        // some code of the rows in flight does not fit int8 (-> nibble-split sums)
   constexpr int STRIDE = 2, RING = 3 + STRIDE, DEPTH = 3;
   const int xs = blockIdx.x % nxs, strip = blockIdx.x / nxs, n = blockIdx.y;
   const int Ho = (Hs - 1) / 2 + 1, Wo = (Ws - 1) / 2 + 1;
@@ -610,7 +611,11 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   const int ix0 = STRIDE * ox0 - 1;
   const int tid = threadIdx.x, cq = tid % LPP, cb = cq * 4, x_l = tid / LPP;
   const int nthreads = blockDim.x;
-  unsigned *codes = reinterpret_cast<unsigned *>(ring4 + (size_t)RING * Wc * LPP);   // [2][Wc][16]: a0 quads 0..7, a1 8..15
+  // [2][Wc][24] dwords: nibble planes a0 (0..7) and a1 (8..15) of a = L - 128 = 16 a1 + a0, and the whole code a as a
+  // byte (16..23) -- valid when every code of the two rows fits int8 (the usual case: levels inside the tracked range),
+  // then ONE v_dot4c chain per channel instead of two
+  unsigned *codes = reinterpret_cast<unsigned *>(ring4 + (size_t)RING * Wc * LPP);
+  constexpr int CS = 24;
   const int Q4 = Cin >> 2;                                    // input channel quads per pixel (<= 8)
   // ---- constants: input quantiser, the mid QuantAct (known: the range pass ran before), weights of this quad ----
   const float xs_ = reinterpret_cast<const float *>(xq)[2], xz_ = reinterpret_cast<const float *>(xq)[3];
@@ -658,14 +663,15 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
     }
   };
   // ---- stage B: levels -> nibble-split codes of the row, four channels per dword, into code buffer `cbuf` ------
-  auto write_codes = [&](int cbuf, const float4 (&d)[MAXI]) {
+  auto write_codes = [&](int cbuf, const float4 (&d)[MAXI], int par) {
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
       const int it = tid + u * nthreads;
       if (it < nitems) {
         const int col = it / Q4, q4 = it - col * Q4;
         const float v[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
-        unsigned lo = 0u, hi = 0u;
+        unsigned lo = 0u, hi = 0u, full = 0u;
+        bool fit = true;
         if (!wide) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -676,11 +682,15 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
             uu = min(max(uu, 8), 4087);
             lo |= (unsigned)(uu & 15) << (8 * e);
             hi |= (unsigned)(((uu >> 4) - 128) & 255) << (8 * e);
+            full |= (unsigned)((uu - 2048) & 255) << (8 * e);
+            fit = fit && (unsigned)(uu - (2048 - 128)) < 256u;
           }
-          codes[(cbuf * Wc + col) * 16 + q4] = lo;
-          codes[(cbuf * Wc + col) * 16 + 8 + q4] = hi;
+          codes[(cbuf * Wc + col) * CS + q4] = lo;
+          codes[(cbuf * Wc + col) * CS + 8 + q4] = hi;
+          codes[(cbuf * Wc + col) * CS + 16 + q4] = full;
+          if (!fit) atomicOr(&s_wide_row[par], 1u);
         } else {            // wide batch: the fake-quantised fp32 values themselves (two dwords hold two floats each way)
-          float *cf = reinterpret_cast<float *>(codes + (size_t)2 * Wc * 16) + ((size_t)cbuf * Wc + col) * 32 + 4 * q4;
+          float *cf = reinterpret_cast<float *>(codes + (size_t)2 * Wc * CS) + ((size_t)cbuf * Wc + col) * 32 + 4 * q4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) cf[e] = cdn::fake_quant_r(v[e], xs_, xz_, __fdiv_rn(1.0f, xs_));
         }
@@ -688,8 +698,9 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
     }
   };
   // ---- stage C: the 1x1 conv + ReLU + fake-quantisation of this thread's (column, quad) items -> ring row `slot` ----
-  auto produce_row = [&](int r, int slot, int cbuf) {
+  auto produce_row = [&](int r, int slot, int cbuf, int par) {
     const bool row_in = (unsigned)r < (unsigned)Hs;
+    const bool fits8 = s_wide_row[par] == 0u;             // workgroup-uniform
 #pragma unroll
     for (int u = 0; u < MAXL; ++u) {
       const int col = x_l + u * XPT, xg = ix0 + col;
@@ -697,8 +708,19 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
         float4 t = z4;                                           // outside the image: the depthwise conv's zero padding
         if (row_in && (unsigned)xg < (unsigned)Ws && cb < C) {
           float y[4];
-          if (!wide) {
-            const uint4 *cp = reinterpret_cast<const uint4 *>(codes + (cbuf * Wc + col) * 16);
+          if (!wide && fits8) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(codes + (cbuf * Wc + col) * CS + 16);
+            const uint4 f0 = cp[0], f1 = cp[1];
+            const int af[8] = {(int)f0.x, (int)f0.y, (int)f0.z, (int)f0.w, (int)f1.x, (int)f1.y, (int)f1.z, (int)f1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              int sa = 0;
+#pragma unroll
+              for (int q = 0; q < Q4T; ++q) sa = __builtin_amdgcn_sdot4(af[q], wq[e][q], sa, false);
+              y[e] = fmaf((float)(sa + t128[e]), rinv[e], pb[e]);      // the same integer: sum_c a_c qw_c
+            }
+          } else if (!wide) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(codes + (cbuf * Wc + col) * CS);
             const uint4 l0 = cp[0], l1 = cp[1], h0 = cp[2], h1 = cp[3];
             const int a0[8] = {(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
             const int a1[8] = {(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
@@ -713,7 +735,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
               y[e] = fmaf((float)(16 * s1 + s0 + t128[e]), rinv[e], pb[e]);
             }
           } else {
-            const float *cf = reinterpret_cast<const float *>(codes + (size_t)2 * Wc * 16) + ((size_t)cbuf * Wc + col) * 32;
+            const float *cf = reinterpret_cast<const float *>(codes + (size_t)2 * Wc * CS) + ((size_t)cbuf * Wc + col) * 32;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int c = min(cb + e, C - 1);
@@ -734,10 +756,12 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   int wslot = 0;
   const int r_step0 = r_first + (3 - STRIDE);
   if (oy0 < oy1) {
-    load_row(r_first, pre[0][0]);                                 // the one row in front of the first output row
-    write_codes(0, pre[0][0]);
+    if (tid < 2) s_wide_row[tid] = 0u;
     __syncthreads();
-    produce_row(r_first, wslot, 0);
+    load_row(r_first, pre[0][0]);                                 // the one row in front of the first output row
+    write_codes(0, pre[0][0], 0);
+    __syncthreads();
+    produce_row(r_first, wslot, 0, 0);
     wslot = 1;
 #pragma unroll
     for (int d_ = 0; d_ < DEPTH; ++d_)
@@ -748,7 +772,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
     __syncthreads();                                              // code row 0 is read: the loop may overwrite it
   }
   float mn = INFINITY, mx = -INFINITY;
-  int cslot = 0;
+  int cslot = 0, par = 1;                        // flag word of the rows in flight (the prologue row used word 0)
   for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
 #pragma unroll
     for (int d_ = 0; d_ < DEPTH; ++d_) {
@@ -757,18 +781,21 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
         const int base_r = r_step0 + STRIDE * (oy - oy0);
         // (no barrier needed here: the code rows were last read before the previous row's barrier, and the two ring
         // slots produced below are not among the three the previous row's taps read)
-        write_codes(0, pre[d_][0]);
-        write_codes(1, pre[d_][1]);
+        write_codes(0, pre[d_][0], par);
+        write_codes(1, pre[d_][1], par);
         __syncthreads();
+        if (tid == 0) s_wide_row[par ^ 1] = 0u;           // last read before the previous row's barrier, next written
+                                                          // after this row's
         if (oy + DEPTH < oy1) {
 #pragma unroll
           for (int s_ = 0; s_ < STRIDE; ++s_) load_row(base_r + STRIDE * DEPTH + s_, pre[d_][s_]);
         }
 #pragma unroll
         for (int s_ = 0; s_ < STRIDE; ++s_) {
-          produce_row(base_r + s_, wslot, s_);
+          produce_row(base_r + s_, wslot, s_, par);
           wslot = wslot + 1 == RING ? 0 : wslot + 1;
         }
+        par ^= 1;
         __syncthreads();
         int rs[3];
         rs[0] = cslot;
@@ -1714,7 +1741,7 @@ extern "C" int cdn_codenet_pwdw_s2_supported(int64_t N, int64_t Cin, int64_t C, 
     xso = std::min(xso, Wo);
     xso = (int)cdn::ceil_div(Wo, cdn::ceil_div(Wo, xso));
     const int wc = 2 * (xso - 1) + 3;
-    if ((size_t)5 * wc * LPP * 16 + (size_t)wc * 384 <= 56 * 1024 && cdn::ceil_div(wc, XPT) <= maxl &&
+    if ((size_t)5 * wc * LPP * 16 + (size_t)wc * 448 <= 56 * 1024 && cdn::ceil_div(wc, XPT) <= maxl &&
         wc * (Cin / 4) <= 2 * XPT * LPP)
       return 1;
   }
@@ -1750,7 +1777,7 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
     xso = std::min(xso, Wo);
     xso = (int)cdn::ceil_div(Wo, cdn::ceil_div(Wo, xso));
     const int wc = 2 * (xso - 1) + 3;
-    if ((size_t)5 * wc * LPP * 16 + (size_t)wc * 384 <= 56 * 1024 && cdn::ceil_div(wc, XPT) <= maxl &&
+    if ((size_t)5 * wc * LPP * 16 + (size_t)wc * 448 <= 56 * 1024 && cdn::ceil_div(wc, XPT) <= maxl &&
         wc * (Cin / 4) <= 2 * XPT * LPP) {
       best_maxl = (int)cdn::ceil_div(wc, XPT);
       XSo = xso;
@@ -1758,7 +1785,7 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
     }
   }
   const int nxs = (int)cdn::ceil_div(Wo, XSo), wc = 2 * (XSo - 1) + 3;
-  const size_t lds = (size_t)5 * wc * LPP * 16 + (size_t)wc * 384;
+  const size_t lds = (size_t)5 * wc * LPP * 16 + (size_t)wc * 448;
   long want = cdn::ceil_div(3L * cdn::kCUs, (long)N * nxs);
   int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho / 8)));
   const int rps = (int)cdn::ceil_div(Ho, nstrips);
