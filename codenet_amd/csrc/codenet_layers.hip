@@ -1786,7 +1786,11 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
   }
   const int nxs = (int)cdn::ceil_div(Wo, XSo), wc = 2 * (XSo - 1) + 3;
   const size_t lds = (size_t)5 * wc * LPP * 16 + (size_t)wc * 448;
-  long want = cdn::ceil_div(3L * cdn::kCUs, (long)N * nxs);
+#ifndef CDN_PWDWX_WGPCU
+#define CDN_PWDWX_WGPCU 2     /* 223-250 VGPRs: two workgroups per CU, so whole rounds of 2 x 256 (3 x 256 workgroups ran as
+                                 one and a half rounds: 173 -> 160 us for the range pass + this kernel, same box) */
+#endif
+  long want = cdn::ceil_div((long)CDN_PWDWX_WGPCU * cdn::kCUs, (long)N * nxs);
   int nstrips = (int)std::max<long>(1, std::min<long>(want, std::max(1, Ho / 8)));
   const int rps = (int)cdn::ceil_div(Ho, nstrips);
   nstrips = (int)cdn::ceil_div(Ho, rps);
