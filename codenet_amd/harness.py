@@ -56,8 +56,6 @@ class PoseShuffleNetV2(nn.Module):
 
     def __init__(self, heads, head_conv, w2=None, deform=False, maxpool=False):
         super().__init__()
-        if deform:
-            raise NotImplementedError("deform backbone is dead code in the reference")
         self.w2 = w2
         self.deform_backbone = deform
         self.heads = heads
@@ -69,9 +67,11 @@ class PoseShuffleNetV2(nn.Module):
         if maxpool:
             stem.append(nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
         self.layer0 = nn.Sequential(*stem)
+        # deform=True (reference :216-230; its factory never passes it): the units' 3x3 convs are CoDeNet operators
+        kern = dcn_deform_conv.DeformConvWithOffsetScaleBoundPositive if deform else nn.Conv2d
         for idx, reps in enumerate([3, 7, 3]):
-            nodes = [BaseNode(c[idx], c[idx + 1], 2)]
-            nodes += [BaseNode(c[idx], c[idx + 1], 1) for _ in range(reps)]
+            nodes = [BaseNode(c[idx], c[idx + 1], 2, nn.BatchNorm2d, kern)]
+            nodes += [BaseNode(c[idx], c[idx + 1], 1, nn.BatchNorm2d, kern) for _ in range(reps)]
             setattr(self, "layer%d" % (idx + 1), nn.Sequential(*nodes))
         self.layer4 = nn.Sequential(nn.Conv2d(c[3], c[4], 1, 1, 0, bias=False),
                                     nn.BatchNorm2d(c[4], momentum=BN_MOMENTUM), nn.ReLU(inplace=True))

@@ -4,6 +4,9 @@ the reference's portable_quantizer/quant_modules.py:
 
     QuantAct :163-225          Quant_Conv2d :228-321        QuantBnConv2d :324-419
     QuantDeformConv2d :422-517 QuantDeformConvWithOffsetScaleBoundPositive :621-671
+    and, for the class surface (`from portable_quantizer.quant_modules import ...`; none of them is reached by the
+    shufflenetv2 configs): QuantLinear :23-160, QuantBnDeformConv2d :520-617,
+    QuantDeformConvWithOffsetScaleBoundPositiveBn :674-720, QuantSflUnit :723-806, QuantBaseNodeDeform :910-1010
 
 MI355X specifics
   * QuantAct on a GPU tensor is one C-ABI call (batch min/max reduction, range tracking with
@@ -29,7 +32,8 @@ from .quantization_utils.quant_utils import (AsymmetricQuantFunction, SymmetricQ
 
 __all__ = ["QuantAct", "Quant_Conv2d", "QuantBnConv2d", "QuantDeformConv2d",
            "QuantDeformConvWithOffsetScaleBoundPositive", "QuantBaseNode", "QuantDepthwiseNode",
-           "channel_shuffle"]
+           "channel_shuffle", "QuantLinear", "QuantBnDeformConv2d",
+           "QuantDeformConvWithOffsetScaleBoundPositiveBn", "QuantSflUnit", "QuantBaseNodeDeform"]
 
 
 def _quant_function(mode):
@@ -567,3 +571,276 @@ class QuantDepthwiseNode(_CompoundQuant):
         x = self.quant_act1(self.quant_convbn1(x))
         x = self.quant_act3(self.quant_convbn2(x))
         return self.quant_conv(x)
+
+
+# ---- the rest of the reference's class surface ---------------------------------------------------
+# Not reached by any shufflenetv2 configuration; kept so that code written against the
+# reference's module imports and runs.  Compositions of the modules above; the deformable ones use the
+# LDS gather kernel when the geometry is CoDeNet's.
+
+def _codenet_geometry(conv):
+    return (tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.deformable_groups == 1
+            and conv.groups == conv.in_channels == conv.out_channels)
+
+
+class QuantBnDeformConv2d(Module, _WeightQuantizer):
+    """DeformConv + BatchNorm folded from the running statistics, weights fake-quantised after the fold,
+    folded bias added in fp32; forward(x, offset) (reference :520-617; its per-tensor --wt-percentile branch
+    reads two undefined names, here it uses the 0.1 / 99.9 percentiles of every sibling class)."""
+
+    def __init__(self, weight_bit, bias_bit=None, full_precision_flag=False, running_stat=True,
+                 quant_mode="symmetric", per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.running_stat = running_stat
+        self._init_weight_quant(weight_bit, bias_bit, full_precision_flag, quant_mode, per_channel,
+                                weight_percentile)
+
+    def set_param(self, conv, bn):
+        self.conv = conv
+        self.bn = bn
+
+    def folded(self):
+        """(fake-quantised folded weight, fp32 folded bias)."""
+        def compute():
+            running_std = torch.sqrt(self.bn.running_var + self.bn.eps)
+            scale_factor = self.bn.weight / running_std
+            w = self.conv.weight * scale_factor.reshape([self.conv.out_channels, 1, 1, 1])
+            b = getattr(self.conv, "bias", None)
+            b = b if b is not None else torch.zeros_like(self.bn.running_mean)
+            b = (b - self.bn.running_mean) * scale_factor + self.bn.bias
+            return self._fake_quant_weight(w, self.conv.out_channels), b
+        keys = [self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        if getattr(self.conv, "bias", None) is not None:
+            keys.append(self.conv.bias)
+        return self._cached(tuple(keys), compute)
+
+    def forward(self, x, offset):
+        w, b = self.folded()
+        c = self.conv
+        out = deform_conv(x, offset, w, c.stride, c.padding, c.dilation, c.groups, c.deformable_groups)
+        return out + b.view(1, -1, 1, 1)
+
+    def forward_scaled(self, x, s):
+        """The same operator given the per-pixel scale instead of offset = anchor * (s - 1)."""
+        w, b = self.folded()
+        return ops.codenet_dw(x, s, w) + b.view(1, -1, 1, 1)
+
+
+class QuantDeformConvWithOffsetScaleBoundPositiveBn(Module):
+    """The CoDeNet operator with the BatchNorm folded into the DEFORMABLE conv (a dense deformable conv, no
+    pointwise stage behind it): scale 1x1 -> bound -> QuantAct -> folded deformable conv (reference :674-720)."""
+
+    def __init__(self, weight_bit, act_bit, full_precision_flag=False, bias_bit=None,
+                 act_percentile=False, wt_quant_mode="symmetric", act_quant_mode="symmetric",
+                 per_channel=False, weight_percentile=False):
+        super().__init__()
+        self.act_bit = act_bit
+        self.weight_bit = weight_bit
+        self.bias_bit = bias_bit
+        self.quantize_bias = bias_bit is not None
+        self.wt_quant_mode = wt_quant_mode
+        self.act_quant_mode = act_quant_mode
+        self.full_precision_flag = full_precision_flag
+        self.act_percentile = act_percentile
+        self.per_channel = per_channel
+        self.weight_percentile = weight_percentile
+
+    def set_param(self, deform_conv, bn):
+        wkw = dict(quant_mode=self.wt_quant_mode, per_channel=self.per_channel,
+                   weight_percentile=self.weight_percentile)
+        self.quant_conv_scale = Quant_Conv2d(self.weight_bit, **wkw)
+        self.quant_conv_scale.set_param(deform_conv.conv_scale)
+        self.quant_act = nn.Sequential(deform_conv.conv_bound,
+                                       QuantAct(self.act_bit, quant_mode="asymmetric",
+                                                percentile=self.act_percentile))
+        self.quant_deform_conv_bn = QuantBnDeformConv2d(self.weight_bit, **wkw)
+        self.quant_deform_conv_bn.set_param(deform_conv.conv, bn)
+        self.anchor_offset = deform_conv.anchor_offset.clone()
+
+    def forward(self, x):
+        s = self.quant_act(self.quant_conv_scale(x))
+        dc = self.quant_deform_conv_bn
+        if x.is_cuda and x.dtype == torch.float32 and s.shape[1] == 1 and _codenet_geometry(dc.conv):
+            return dc.forward_scaled(x, s)
+        return dc(x, self.anchor_offset.to(x.device) * (s - 1))
+
+
+class QuantSflUnit(_CompoundQuant):
+    """W4A8 form of pytorchcv's ShuffleUnit (duck-typed: compress_conv1 / compress_bn1, dw_conv2 / dw_bn2,
+    expand_conv3 / expand_bn3 and, with `downsample`, dw_conv4 / dw_bn4, expand_conv5 / expand_bn5); the unit-output
+    QuantAct is shared through set_act (reference :723-806; like the reference, `use_se` / `use_residual` are recorded
+    and not applied, and the two depthwise convs never use --wt-percentile)."""
+
+    def __init__(self, weight_bit, act_bit, full_precision_flag=False, bias_bit=None, act_percentile=False,
+                 wt_quant_mode="symmetric", act_quant_mode="symmetric", per_channel=False):
+        super().__init__(weight_bit, act_bit, full_precision_flag, bias_bit, act_percentile, wt_quant_mode,
+                         act_quant_mode, per_channel, False)
+
+    def _unit_convbn(self, conv, bn):
+        m = QuantBnConv2d(weight_bit=self.weight_bit, bias_bit=self.bias_bit, quant_mode=self.wt_quant_mode,
+                          per_channel=self.per_channel)
+        m.set_param(conv, bn)
+        return m
+
+    def _unit_act(self, mode):
+        return QuantAct(self.act_bit, quant_mode=mode, full_precision_flag=self.full_precision_flag,
+                        percentile=self.act_percentile)
+
+    def set_param(self, sfl_unit):
+        self.downsample = sfl_unit.downsample
+        self.use_se = sfl_unit.use_se
+        self.use_residual = sfl_unit.use_residual
+        self.quant_compr_convbn1 = self._unit_convbn(sfl_unit.compress_conv1, sfl_unit.compress_bn1)
+        self.quant_act1 = nn.Sequential(nn.ReLU(inplace=True), self._unit_act("asymmetric"))
+        self.quant_dw_convbn2 = self._unit_convbn(sfl_unit.dw_conv2, sfl_unit.dw_bn2)
+        self.quant_act2 = self._unit_act(self.act_quant_mode)
+        self.quant_exp_convbn3 = self._unit_convbn(sfl_unit.expand_conv3, sfl_unit.expand_bn3)
+        if self.downsample:
+            self.quant_dw_convbn4 = self._unit_convbn(sfl_unit.dw_conv4, sfl_unit.dw_bn4)
+            self.quant_act4 = self._unit_act(self.act_quant_mode)
+            self.quant_exp_convbn5 = self._unit_convbn(sfl_unit.expand_conv5, sfl_unit.expand_bn5)
+
+    def set_act(self, share_quant_act):
+        self.quant_act = share_quant_act
+
+    def forward(self, x):
+        if self.downsample:
+            y1 = self.quant_act4(self.quant_dw_convbn4(x))
+            y1 = self.quant_act(self.quant_exp_convbn5(y1))
+            x2 = x
+        else:
+            y1, x2 = torch.chunk(x, chunks=2, dim=1)
+        y2 = self.quant_act1(self.quant_compr_convbn1(x2))
+        y2 = self.quant_act2(self.quant_dw_convbn2(y2))
+        y2 = self.quant_act(self.quant_exp_convbn3(y2))
+        return channel_shuffle(torch.cat((y1, y2), dim=1), 2)
+
+
+class QuantBaseNodeDeform(_CompoundQuant):
+    """W4A8 BaseNode whose 3x3 convs are CoDeNet operators (`PoseShuffleNetV2(deform=True)`, shufflenetv2_dcn.py:
+    216-230): b2 = [conv, bn, relu, deform, bn, conv, bn, relu], b1 (stride 2) = [deform, bn, conv, bn, relu]
+    (reference :910-1010).  The reference class cannot run -- its set_param reads an undefined name (:950) and its
+    forward imports a module that does not exist (:984) -- so this follows its text with those two repaired."""
+
+    def _deform(self, op, bn):
+        m = QuantDeformConvWithOffsetScaleBoundPositiveBn(
+            self.weight_bit, self.act_bit, act_percentile=self.act_percentile, wt_quant_mode=self.wt_quant_mode,
+            act_quant_mode=self.act_quant_mode, per_channel=self.per_channel,
+            weight_percentile=self.weight_percentile)
+        m.set_param(op, bn)
+        return m
+
+    def set_param(self, base_node):
+        self.stride = base_node.stride
+        b2 = base_node.b2
+        self.quant_convbn1 = self._convbn(b2[0], b2[1])
+        self.quant_act1 = self._act("asymmetric")
+        self.quant_convbn2 = self._deform(b2[3], b2[4])
+        self.quant_act2 = self._act()
+        self.quant_convbn3 = self._convbn(b2[5], b2[6])
+        if base_node.stride == 2:
+            b1 = base_node.b1
+            self.quant_convbn4 = self._deform(b1[0], b1[1])
+            self.quant_act4 = self._act()
+            self.quant_convbn5 = self._convbn(b1[2], b1[3])
+
+    def set_act(self, share_quant_act):
+        self.quant_act = share_quant_act
+
+    def forward(self, x):
+        if self.stride == 1:
+            half = x.shape[1] // 2
+            x1, x2 = x[:, :half], x[:, half:]
+        else:
+            x1 = self.quant_act4(self.quant_convbn4(x))
+            x1 = self.quant_act(F.relu(self.quant_convbn5(x1)))
+            x2 = x
+        x2 = self.quant_act1(F.relu(self.quant_convbn1(x2)))
+        x2 = self.quant_act2(self.quant_convbn2(x2))
+        x2 = self.quant_act(F.relu(self.quant_convbn3(x2)))
+        return channel_shuffle(torch.cat((x1, x2), dim=1), 2)
+
+
+class QuantLinear(nn.Linear):
+    """Linear layer with fake-quantised weights and an EMA of the weight range in the buffers x_min / x_max
+    (reference :23-160: constructor arguments, buffers, `reset_bits` / `reset_alpha`, range statistics per INPUT
+    feature when per_channel, groups of input features with group_quantization, `alpha` blending).  The reference's
+    forward fails for every configuration (its quantiser reshapes per-channel statistics for 4-D conv weights and
+    hands F.linear a 4-D weight; the percentile branches index out of range) -- tests/golden/make_golden.py
+    `probe_quant_linear` records that -- so there is no reference output to pin; this class applies the same
+    statistics and the same quantiser expressions along the input-feature axis of the 2-D weight."""
+
+    def __init__(self, weight_bit, input_size, output_size, full_precision_flag=False, quant_mode="symmetric",
+                 alpha=None, per_channel=True, group_quantization=False, group_number=60,
+                 weight_percentile=False):
+        super().__init__(input_size, output_size)
+        if quant_mode not in ("symmetric", "asymmetric"):
+            raise ValueError("unknown quant mode: {}".format(quant_mode))
+        self.full_precision_flag = full_precision_flag
+        self.weight_bit = weight_bit
+        self.alpha = alpha
+        self.quant_mode = quant_mode
+        self.input_size = input_size
+        self.output_size = output_size
+        self.momentum = 0.99
+        self.register_buffer("x_min", torch.zeros(1))
+        self.register_buffer("x_max", torch.zeros(1))
+        self.per_channel = per_channel
+        self.weight_percentile = weight_percentile
+        self.group_quantization = group_quantization
+        self.group_number = group_number
+
+    def reset_bits(self, weight_bit=8):
+        self.full_precision_flag = False
+        self.weight_bit = weight_bit
+
+    def reset_alpha(self, alpha):
+        assert 0.0 <= alpha <= 1.0
+        self.alpha = alpha
+
+    def extra_repr(self):
+        return super().extra_repr() + ", weight_bit={}, full_precision_flag={}".format(
+            self.weight_bit, self.full_precision_flag)
+
+    def _range(self):
+        w = self.weight.data
+        if not self.per_channel:
+            if self.weight_percentile:
+                return get_percentile_min_max(w.reshape(-1), 0.1, 99.9, output_tensor=True)
+            return w.min().expand(1), w.max().expand(1)
+        cols = w.transpose(0, 1).contiguous()                 # one row per input feature
+        if self.weight_percentile and not self.group_quantization:
+            return _channel_range(cols, True)
+        w_min, w_max = cols.min(dim=1).values, cols.max(dim=1).values
+        if self.group_quantization:
+            glen = w_min.numel() // self.group_number
+            for i in range(self.group_number):
+                sl = slice(i * glen, (i + 1) * glen)
+                if self.weight_percentile:
+                    lo, hi = get_percentile_min_max(cols[sl].reshape(-1), 0.1, 99.9, output_tensor=True)
+                else:
+                    lo, hi = w_min[sl].min(), w_max[sl].max()
+                w_min[sl], w_max[sl] = lo, hi
+        return w_min, w_max
+
+    def _fake_quant(self):
+        """The conv modules' quantiser (quant_utils.py:172-229) with the input features as its channel axis."""
+        fn = _quant_function(self.quant_mode)
+        w4 = self.weight.transpose(0, 1).reshape(self.in_features, self.out_features, 1, 1)
+        q = fn(w4, self.weight_bit, self.x_min, self.x_max, self.per_channel, self.weight_percentile)
+        return q.reshape(self.in_features, self.out_features).transpose(0, 1)
+
+    def forward(self, x):
+        w_min, w_max = self._range()
+        if self.x_min.numel() == 1 and bool(self.x_min == self.x_max):        # first call: take the statistics
+            self.x_min, self.x_max = w_min.clone(), w_max.clone()
+        self.x_min = self.momentum * self.x_min + (1.0 - self.momentum) * w_min
+        self.x_max = self.momentum * self.x_max + (1.0 - self.momentum) * w_max
+        if self.full_precision_flag:
+            assert self.alpha is None
+            return F.linear(x, self.weight, self.bias)
+        w = self._fake_quant()
+        if self.alpha is not None:
+            w = self.alpha * w + (1 - self.alpha) * self.weight
+        return F.linear(x, w, self.bias)

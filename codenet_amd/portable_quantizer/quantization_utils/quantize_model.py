@@ -3,7 +3,7 @@ argument list and resulting module tree (checkpoint keys) as the reference's
 portable_quantizer/quantization_utils/quantize_model.py:7-82."""
 import torch.nn as nn
 
-from ..quant_modules import (QuantAct, QuantBaseNode, QuantBnConv2d, QuantDepthwiseNode,
+from ..quant_modules import (QuantAct, QuantBaseNode, QuantBaseNodeDeform, QuantBnConv2d, QuantDepthwiseNode,
                              QuantDeformConvWithOffsetScaleBoundPositive)
 
 __all__ = ["quantize_shufflenetv2_dcn", "quantize_deform_stages"]
@@ -39,9 +39,8 @@ def quantize_shufflenetv2_dcn(model, quant_conv, quant_bn, quant_act, wt_quant_m
     """quant_conv / quant_act: weight / activation bit widths (layer0 always uses 8-bit weights,
     reference :28); quant_bn, w2 are accepted for signature parity and unused, as in the
     reference."""
-    if deform_backbone:
-        raise NotImplementedError("deform_backbone=True is dead code in the reference "
-                                  "(QuantBaseNodeDeform imports a missing module)")
+    # (deform_backbone=True cannot run in the reference -- QuantBaseNodeDeform raises in set_param -- and its model
+    # factory never builds such a backbone; here it maps the nodes of PoseShuffleNetV2(deform=True) as the text says)
     wkw = dict(quant_mode=wt_quant_mode, per_channel=wt_per_channel, weight_percentile=wt_percentile)
     ckw = dict(act_percentile=act_percentile, wt_quant_mode=wt_quant_mode,
                act_quant_mode=act_quant_mode, per_channel=wt_per_channel,
@@ -58,7 +57,7 @@ def quantize_shufflenetv2_dcn(model, quant_conv, quant_bn, quant_act, wt_quant_m
         shared = QuantAct(quant_act, quant_mode="asymmetric", percentile=act_percentile)
         nodes = []
         for node in layer.children():
-            qn = QuantBaseNode(quant_conv, quant_act, **ckw)
+            qn = (QuantBaseNodeDeform if deform_backbone else QuantBaseNode)(quant_conv, quant_act, **ckw)
             qn.set_param(node)
             qn.set_act(shared)
             nodes.append(qn)

@@ -17,9 +17,16 @@ Fixtures
                     W4A8, through CtdetDetector.process' body: sub-sampled hm/wh/reg, checksums and
                     the decoded detections [1,100,6] (weights: codenet_amd.harness.fill_state_dict_).
   model_io_512.npz / model_noise_512.npz   the same two at the BASELINE resolution 512x512 (seed 52).
+  model_deform_backbone.npz   the reference's PoseShuffleNetV2(deform=True), fp32, 128x128, one image.
   model_noise.npz   the reference W4A8 model against ITSELF with 1 vs 8 CPU threads (code-flip noise floor).
   voc_eval_ref.npz  the reference's own VOC evaluator (tools/voc_eval_lib/datasets/voc_eval.py, pure numpy) over a
                     synthetic VOC tree: rec / prec / AP per class (difficult objects, duplicates, partial recall).
+  quant_extra.npz   the rest of the reference's quantiser class surface, from the reference classes themselves:
+                    QuantBnDeformConv2d (with / without --wt-percentile), QuantDeformConvWithOffsetScaleBoundPositiveBn
+                    (2 forwards, native call -> oracle), QuantSflUnit (down-sampling + plain unit chained, 2 forwards;
+                    pytorchcv's ChannelShuffle / ShuffleUnit are not installed: the unit is a plain container with
+                    the attribute names QuantSflUnit reads, the shuffle is the published view / transpose / view),
+                    and `linear_errors`: the exception every QuantLinear configuration raises in the reference.
   deform_raw.npz    oracle-only regression vectors for the generic op (fwd + all grads, plain
                     and modulated); the reference cannot produce these (CUDA-only).
 
@@ -396,6 +403,124 @@ def make_base_nodes(ref_qm):
     return t2n(out)
 
 
+def make_quant_extra(ref_mod, ref_qm):
+    nn = torch.nn
+    g = torch.Generator().manual_seed(91)
+    out = {}
+
+    def bn(c):
+        b = nn.BatchNorm2d(c)
+        b.weight.data = torch.rand(c, generator=g) + 0.5
+        b.bias.data = torch.randn(c, generator=g) * 0.1
+        b.running_mean = torch.randn(c, generator=g) * 0.1
+        b.running_var = torch.rand(c, generator=g) + 0.5
+        return b
+
+    def bn_arr(b):
+        return torch.stack([b.weight.data, b.bias.data, b.running_mean, b.running_var])
+
+    def conv(i, o, k=1, s=1, groups=1):
+        c = nn.Conv2d(i, o, k, s, k // 2, groups=groups, bias=False)
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * (1.5 / (i // groups * k * k)) ** 0.5
+        return c
+
+    # ---- QuantBnDeformConv2d: dense (groups = 1) and depthwise, arbitrary offsets, with / without --wt-percentile
+    for tag, (C, Co, groups, pct) in {"dense": (6, 8, 1, False), "dw": (8, 8, 8, False), "densep": (6, 8, 1, True)}.items():
+        dc = ref_mod.DeformConv(C, Co, 3, 1, 1, 1, groups, 1, bias=False)
+        dc.weight.data = torch.randn(dc.weight.shape, generator=g) * 0.3
+        dc.bias = None          # the reference class reads conv.bias (:566), which its own DeformConv does not have
+        b = bn(Co)
+        q = ref_qm.QuantBnDeformConv2d(4, quant_mode="symmetric", per_channel=True, weight_percentile=pct)
+        q.set_param(dc, b)
+        x = torch.randn(2, C, 9, 7, generator=g)
+        off = torch.randn(2, 18, 9, 7, generator=g) * 1.5
+        with torch.no_grad():
+            y = q(x, off)
+        out.update({"bd_%s_w" % tag: dc.weight.data, "bd_%s_bn" % tag: bn_arr(b), "bd_%s_x" % tag: x,
+                    "bd_%s_off" % tag: off, "bd_%s_y" % tag: y})
+
+    # ---- QuantDeformConvWithOffsetScaleBoundPositiveBn: the CoDeNet operator, BN folded into the deformable conv
+    C = 16
+    p = _stage_params(C, C, g)
+    m = ref_mod.DeformConvWithOffsetScaleBoundPositive(C, C, 3, 1, 1, groups=C)     # in == out: no pointwise conv
+    with torch.no_grad():
+        m.conv_scale.weight.copy_(p["w_scale"])
+        m.conv_scale.bias.copy_(p["b_scale"])
+        m.conv.weight.copy_(p["w_dw"])
+    m.conv.bias = None
+    b = bn(C)
+    q = ref_qm.QuantDeformConvWithOffsetScaleBoundPositiveBn(4, 8, wt_quant_mode="symmetric", act_quant_mode="asymmetric",
+                                                             per_channel=True)
+    q.set_param(m, b)
+    q.eval()
+    out.update({"pb_w_scale": p["w_scale"], "pb_b_scale": p["b_scale"], "pb_w_dw": p["w_dw"], "pb_bn": bn_arr(b)})
+    for it in range(2):
+        x = torch.randn(2, C, 12, 12, generator=g) * (1.0 + 0.4 * it)
+        with torch.no_grad():
+            y = q(x)
+        out["pb_x%d" % it], out["pb_y%d" % it] = x, y
+        out["pb_smin%d" % it], out["pb_smax%d" % it] = q.quant_act[1].x_min.clone(), q.quant_act[1].x_max.clone()
+
+    # ---- QuantSflUnit: pytorchcv's unit as a plain container; ChannelShuffle = view / transpose / view
+    class Shuffle(nn.Module):
+        def __init__(self, channels, groups):
+            super().__init__()
+            self.groups = groups
+
+        def forward(self, x):
+            n, c, h, w = x.shape
+            return x.view(n, self.groups, c // self.groups, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+    ref_qm.ChannelShuffle = Shuffle
+
+    class Unit:
+        def __init__(self, inp, oup, downsample):
+            self.downsample, self.use_se, self.use_residual = downsample, False, False
+            mid = oup // 2
+            cin = inp if downsample else mid
+            self.compress_conv1, self.compress_bn1 = conv(cin, mid), bn(mid)
+            self.dw_conv2, self.dw_bn2 = conv(mid, mid, 3, 2 if downsample else 1, mid), bn(mid)
+            self.expand_conv3, self.expand_bn3 = conv(mid, mid), bn(mid)
+            if downsample:
+                self.dw_conv4, self.dw_bn4 = conv(inp, inp, 3, 2, inp), bn(inp)
+                self.expand_conv5, self.expand_bn5 = conv(inp, mid), bn(mid)
+    units = [Unit(8, 20, True), Unit(20, 20, False)]
+    names = ["compress_conv1", "dw_conv2", "expand_conv3", "dw_conv4", "expand_conv5"]
+    for u, un in enumerate(units):
+        for k in names:
+            if hasattr(un, k):
+                out["sfl%d_%s" % (u, k)] = getattr(un, k).weight.data
+                kb = k.replace("conv", "bn")
+                out["sfl%d_%s" % (u, kb)] = bn_arr(getattr(un, kb))
+    shared = ref_qm.QuantAct(8, quant_mode="asymmetric")
+    qs = []
+    for un in units:
+        q = ref_qm.QuantSflUnit(4, 8, wt_quant_mode="symmetric", act_quant_mode="asymmetric", per_channel=True)
+        q.set_param(un)
+        q.set_act(shared)
+        qs.append(q.eval())
+    for it in range(2):
+        x = torch.randn(2, 8, 10, 12, generator=g).abs() * (1.0 + 0.3 * it)
+        with torch.no_grad():
+            y0 = qs[0](x.clone())
+            y1 = qs[1](y0.clone())
+        out["sfl_x%d" % it], out["sfl_y0_%d" % it], out["sfl_y1_%d" % it] = x, y0, y1
+        out["sfl_shared%d" % it] = torch.cat([shared.x_min, shared.x_max])
+
+    # ---- QuantLinear: what the reference does with each configuration
+    errs = []
+    for kw in (dict(per_channel=True), dict(per_channel=False), dict(per_channel=True, weight_percentile=True),
+               dict(per_channel=False, weight_percentile=True), dict(per_channel=True, group_quantization=True, group_number=4),
+               dict(per_channel=True, quant_mode="asymmetric")):
+        for io in ((16, 16), (16, 8), (64, 32)):
+            try:
+                ref_qm.QuantLinear(4, io[0], io[1], **kw)(torch.randn(3, io[0], generator=g))
+                errs.append("ok")
+            except Exception as e:      # noqa: BLE001
+                errs.append(type(e).__name__)
+    out["linear_errors"] = np.array(errs)
+    return t2n(out)
+
+
 def make_decode():
     """The reference's ctdet_decode (lib/models/decode.py:474-505) on random score maps; the selected
     scores are distinct floats, so torch.topk's unspecified tie order does not matter."""
@@ -482,6 +607,25 @@ def make_model_io(ref_qm, res=256, seed=51):
             out["%s_%s_abs" % (tag, k)] = t.double().abs().sum()
         out["%s_dets" % tag] = dets
         out["%s_nfwd" % tag] = np.array(n_fwd)
+    return t2n(out)
+
+
+def make_model_deform_backbone(res=128, seed=53):
+    """The reference's PoseShuffleNetV2(deform=True) -- CoDeNet operators as the 3x3 convs of every backbone unit
+    (shufflenetv2_dcn.py:216-230; stride-2 operators included) -- in fp32, one image; native deform_conv -> oracle.
+    (Its W4A8 form cannot be produced: QuantBaseNodeDeform raises in set_param.)"""
+    import models.networks.shufflenetv2_dcn as ref_net
+    from codenet_amd.harness import fill_state_dict_
+    heads = {"hm": 20, "wh": 2, "reg": 2}
+    net = ref_net.PoseShuffleNetV2(heads, 64, deform=True)
+    fill_state_dict_(net, 317)
+    net.eval()
+    img = torch.randn(1, 3, res, res, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        o = net(img)[-1]
+    out = {"image_seed": np.array(seed), "res": np.array(res)}
+    for k in ("hm", "wh", "reg"):
+        out[k] = o[k]
     return t2n(out)
 
 
@@ -695,9 +839,11 @@ def main():
         "model_noise": lambda: make_model_noise(ref_qm),
         "model_io_512": lambda: make_model_io(ref_qm, res=512, seed=52),
         "model_noise_512": lambda: make_model_noise(ref_qm, res=512, seed=52),
+        "model_deform_backbone": make_model_deform_backbone,
         "head_w4a8": lambda: make_head_w4a8(ref_qm),
         "decode_ref": make_decode,
         "base_nodes": lambda: make_base_nodes(ref_qm),
+        "quant_extra": lambda: make_quant_extra(ref_mod, ref_qm),
         "voc_eval_ref": make_voc_eval,
         "post_process_ref": make_post_process,
     }
