@@ -8,12 +8,20 @@
 //     dets[b][k] = [xs - w/2, ys - h/2, xs + w/2, ys + h/2, score, class]
 // as ~25 framework launches incl. two sorts.  The two-level top-K equals the global top-K of the
 // masked map (the global top K can hold at most K entries of one class), so here:
-//   decode_keys_kernel   one workgroup per (image, class) plane: plane -> LDS, (sigmoid,) 3x3 peak test,
-//                        32-bit order-preserving key of the masked score for every pixel + per-image
-//                        histogram of the keys' top 12 bits
-//   decode_select_kernel one workgroup per image: radix refinement of the K-th key (12 + 12 + 8 bits,
+//   decode_keys_kernel   one workgroup per (image, class, row band): band -> LDS, (sigmoid,) 3x3 peak test,
+//                        32-bit order-preserving key of the masked score of every pixel -> per-image histogram
+//                        of the keys' top 11 bits, and (round 4) the CANDIDATES -- pixels whose masked score is
+//                        above zero, i.e. the peaks -- appended as (key, inverted index) pairs to a per-image
+//                        list (count, ONE global atomic per workgroup to reserve a range, write): ~11 % of the
+//                        pixels of a heat map instead of a 4-byte key for every pixel (84 MB at batch 64)
+//   decode_select_kernel one workgroup per image: radix refinement of the K-th key (11 + 11 + 10 bits,
 //                        re-histogramming only the threshold group), one collect pass, bitonic sort of
-//                        the <= 4096 collected (key, index) pairs in LDS, gather of reg / wh, boxes.
+//                        the <= 4096 collected (key, index) pairs in LDS, gather of reg / wh, boxes -- over the
+//                        candidate list when it holds at least K entries (then the K-th key is above zero and
+//                        nothing outside the list can be selected).  Otherwise (fewer than K peaks: zeros fill
+//                        up by ascending index; a list that overflowed; more equal keys at the threshold than
+//                        the LDS list holds) the same algorithm runs over keys recomputed from the heat map
+//                        pixel by pixel: exact for every input, slow, and not met by a detector's heat maps.
 // Ties (equal scores) are ordered by ascending flat index class*H*W + y*W + x; torch.topk leaves that
 // order unspecified (lib/models/decode.py:114,120), the oracle states the same rule.
 #include "cdn_common.h"
@@ -30,9 +38,52 @@ constexpr int kKeyThreads = 512;
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Words per image in the histogram region: kBins histogram bins + the candidate counter (+ padding).
+// Words per image in the histogram region: kBins histogram bins + the candidate counter (+ padding).
+constexpr int kHistStride = kBins + 16;
+
+__device__ __forceinline__ unsigned masked_key(float v, float m9) {
+  // v = the pixel, m9 = the maximum of its 3x3 neighbourhood INCLUDING itself:
+  // hmax == heat  <=>  fmaxf(m8, v) == v  <=>  m9 == v (NaN compares false, as in the reference)
+  const float s = (m9 == v) ? v : v * 0.0f;
+  return cdn::f2ord(s + 0.0f);                  // (+0.0f: -0 and +0 get the same key)
+}
+
+// Masked keys of pixel quad q (4 consecutive pixels of a row; W % 4 == 0) of the band held in `plane`
+// ([(rows + 2)][Wp], interior from column 4, row 0 = image row y0 - 1).
+__device__ __forceinline__ uint4 quad_keys(const float *plane, int Wp, int y0, int W, int q) {
+  const int p = q * 4, y = p / W, x = p - y * W;
+  const float *ctr = plane + (y - y0 + 1) * Wp + 4 + x;
+  float hm[3][4];                           // horizontal 3-maxima of the three rows
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float *row = ctr + (r - 1) * Wp;
+    const float4 cv = *reinterpret_cast<const float4 *>(row);
+    const float l = row[-1], rr = row[4];
+    hm[r][0] = fmaxf(fmaxf(l, cv.x), cv.y);
+    hm[r][1] = fmaxf(fmaxf(cv.x, cv.y), cv.z);
+    hm[r][2] = fmaxf(fmaxf(cv.y, cv.z), cv.w);
+    hm[r][3] = fmaxf(fmaxf(cv.z, cv.w), rr);
+  }
+  const float4 cv = *reinterpret_cast<const float4 *>(ctr);
+  uint4 k4;
+  k4.x = masked_key(cv.x, fmaxf(fmaxf(hm[0][0], hm[1][0]), hm[2][0]));
+  k4.y = masked_key(cv.y, fmaxf(fmaxf(hm[0][1], hm[1][1]), hm[2][1]));
+  k4.z = masked_key(cv.z, fmaxf(fmaxf(hm[0][2], hm[1][2]), hm[2][2]));
+  k4.w = masked_key(cv.w, fmaxf(fmaxf(hm[0][3], hm[1][3]), hm[2][3]));
+  return k4;
+}
+__device__ __forceinline__ unsigned pixel_key(const float *plane, int Wp, int y0, int W, int p) {
+  const int y = p / W, x = p - y * W;
+  const float *q = plane + (y - y0 + 1) * Wp + 4 + x;
+  float m = fmaxf(fmaxf(q[-Wp - 1], q[-Wp]), fmaxf(q[-Wp + 1], q[-1]));
+  m = fmaxf(m, fmaxf(fmaxf(q[1], q[Wp - 1]), fmaxf(q[Wp], q[Wp + 1])));
+  return masked_key(q[0], fmaxf(m, q[0]));
+}
+
 __global__ void __launch_bounds__(kKeyThreads)
-decode_keys_kernel(const float *heat, unsigned *__restrict__ keys, unsigned *__restrict__ hist,
-                   float *heat_out, int cat, int H, int W, int apply_sigmoid, int RB) {
+decode_keys_kernel(const float *heat, unsigned long long *__restrict__ cand, unsigned *__restrict__ hist,
+                   float *heat_out, int cat, int H, int W, int apply_sigmoid, int RB, unsigned cap) {
   // heat_out may alias heat ONLY when a workgroup owns whole planes (one band) or no sigmoid is applied
   // (then the store rewrites the value it read); the host entry routes the other in-place case through
   // sigmoid_store_kernel instead, because a neighbouring band's halo rows would otherwise be read after
@@ -47,7 +98,6 @@ decode_keys_kernel(const float *heat, unsigned *__restrict__ keys, unsigned *__r
   const int y0 = blockIdx.z * RB, y1 = min(H, y0 + RB), nr = y1 - y0;      // own rows [y0, y1)
   const int HW = H * W, Wp = ((W + 3) & ~3) + 8;
   const float *hp = heat + ((long)b * cat + c) * HW;
-  unsigned *kp = keys + ((long)b * cat + c) * HW;
   float *op = heat_out ? heat_out + ((long)b * cat + c) * HW : nullptr;
   for (int i = tid; i < kBins; i += kKeyThreads) lh[i] = 0;
   // LDS row r holds image row y0 - 1 + r.  -inf: columns -1 and W of every row; whole rows outside the image
@@ -93,54 +143,91 @@ decode_keys_kernel(const float *heat, unsigned *__restrict__ keys, unsigned *__r
   }
   __syncthreads();
   // non-peaks all carry the key of 0.0: counted per thread, ONE histogram atomic per thread at the end
-  // (16384 same-address LDS atomics per plane cost 250 us per launch)
+  // (16384 same-address LDS atomics per plane cost 250 us per launch).  Plain locals and straight-line code:
+  // counters captured by reference in closures ended up in scratch memory (a round trip per increment, 20 us).
   const unsigned zkey = cdn::f2ord(0.0f);
-  unsigned zeros = 0;
-  // v = the pixel, m9 = the maximum of its 3x3 neighbourhood INCLUDING itself:
-  // hmax == heat  <=>  fmaxf(m8, v) == v  <=>  m9 == v (NaN compares false, as in the reference)
-  auto key_from = [&](float v, float m9) -> unsigned {
-    const float s = (m9 == v) ? v : v * 0.0f;
-    const unsigned k = cdn::f2ord(s + 0.0f);    // (+0.0f: -0 and +0 get the same key)
-    if (k == zkey) ++zeros;
-    else atomicAdd(&lh[k >> (32 - 11)], 1u);
-    return k;
-  };
-  if (vec) {
-    for (int q = ((y0 * W) >> 2) + tid; q < ((y1 * W) >> 2); q += kKeyThreads) {
-      const int p = q * 4, y = p / W, x = p - y * W;
-      const float *ctr = plane + (y - y0 + 1) * Wp + 4 + x;
-      float hm[3][4];                           // horizontal 3-maxima of the three rows
+  unsigned zeros = 0, mine = 0;
+#define CDN_TALLY(k_)                                   \
+  do {                                                  \
+    const unsigned kk_ = (k_);                          \
+    if (kk_ == zkey) {                                  \
+      ++zeros;                                          \
+    } else {                                            \
+      atomicAdd(&lh[kk_ >> (32 - 11)], 1u);             \
+      mine += kk_ > zkey ? 1u : 0u;                     \
+    }                                                   \
+  } while (0)
+  // Usual shape (the band's pixel quads fit kKeepQ per thread): the keys stay in registers between the counting
+  // and the writing pass; otherwise they are recomputed from the LDS plane.
+  constexpr int kKeepQ = 4;
+  const int q_first = (y0 * W) >> 2, q_end = (y1 * W) >> 2;
+  const bool keep = vec && (q_end - q_first) <= kKeepQ * kKeyThreads;
+  uint4 kept[kKeepQ];
+  if (keep) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float *row = ctr + (r - 1) * Wp;
-        const float4 cv = *reinterpret_cast<const float4 *>(row);
-        const float l = row[-1], rr = row[4];
-        hm[r][0] = fmaxf(fmaxf(l, cv.x), cv.y);
-        hm[r][1] = fmaxf(fmaxf(cv.x, cv.y), cv.z);
-        hm[r][2] = fmaxf(fmaxf(cv.y, cv.z), cv.w);
-        hm[r][3] = fmaxf(fmaxf(cv.z, cv.w), rr);
+    for (int u = 0; u < kKeepQ; ++u) {
+      const int q = q_first + tid + u * kKeyThreads;
+      kept[u] = make_uint4(zkey, zkey, zkey, zkey);
+      if (q < q_end) {
+        const uint4 k4 = quad_keys(plane, Wp, y0, W, q);
+        CDN_TALLY(k4.x); CDN_TALLY(k4.y); CDN_TALLY(k4.z); CDN_TALLY(k4.w);
+        kept[u] = k4;
       }
-      const float4 cv = *reinterpret_cast<const float4 *>(ctr);
-      uint4 k4;
-      k4.x = key_from(cv.x, fmaxf(fmaxf(hm[0][0], hm[1][0]), hm[2][0]));
-      k4.y = key_from(cv.y, fmaxf(fmaxf(hm[0][1], hm[1][1]), hm[2][1]));
-      k4.z = key_from(cv.z, fmaxf(fmaxf(hm[0][2], hm[1][2]), hm[2][2]));
-      k4.w = key_from(cv.w, fmaxf(fmaxf(hm[0][3], hm[1][3]), hm[2][3]));
-      reinterpret_cast<uint4 *>(kp)[q] = k4;
+    }
+  } else if (vec) {
+    for (int q = q_first + tid; q < q_end; q += kKeyThreads) {
+      const uint4 k4 = quad_keys(plane, Wp, y0, W, q);
+      CDN_TALLY(k4.x); CDN_TALLY(k4.y); CDN_TALLY(k4.z); CDN_TALLY(k4.w);
     }
   } else {
-    for (int p = y0 * W + tid; p < y1 * W; p += kKeyThreads) {
-      const int y = p / W, x = p - y * W;
-      const float *q = plane + (y - y0 + 1) * Wp + 4 + x;
-      float m = fmaxf(fmaxf(q[-Wp - 1], q[-Wp]), fmaxf(q[-Wp + 1], q[-1]));
-      m = fmaxf(m, fmaxf(fmaxf(q[1], q[Wp - 1]), fmaxf(q[Wp], q[Wp + 1])));
-      kp[p] = key_from(q[0], fmaxf(m, q[0]));
-    }
+    for (int p = y0 * W + tid; p < y1 * W; p += kKeyThreads) CDN_TALLY(pixel_key(plane, Wp, y0, W, p));
   }
+#undef CDN_TALLY
   if (zeros) atomicAdd(&lh[zkey >> (32 - 11)], zeros);
+  // Every WAVE reserves a range of the image's list for its candidates: prefix sum of the lanes' counts, one global
+  // atomic by the last lane, no barrier and no LDS atomic (512 same-address LDS atomics with a return value per
+  // workgroup cost 13 us per launch, a workgroup-wide reservation behind a barrier 20 us; the other waves of the CU
+  // cover a wave's round trip).  Order inside the list does not matter.
+  unsigned incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(incl, d, 64);
+    if ((tid & 63) >= d) incl += t;
+  }
+  unsigned *gh = hist + (long)b * kHistStride;
+  unsigned wbase = 0u;
+  if ((tid & 63) == 63 && incl) wbase = atomicAdd(&gh[kBins], incl);
+  wbase = __shfl(wbase, 63, 64);
+  unsigned long long *lp = cand + (size_t)b * cap;
+  const unsigned pix0 = (unsigned)c * (unsigned)HW;
+  unsigned slot = wbase + incl - mine;
+#define CDN_PUT(k_, p_)                                                                                         \
+  do {                                                                                                          \
+    const unsigned kk_ = (k_);                                                                                  \
+    if (kk_ > zkey) {                                                                                           \
+      if (slot < cap)                                                                                           \
+        lp[slot] = ((unsigned long long)kk_ << 32) | (unsigned long long)(0xFFFFFFFFu - (pix0 + (unsigned)(p_))); \
+      ++slot;                                                                                                   \
+    }                                                                                                           \
+  } while (0)
+  if (keep) {
+#pragma unroll
+    for (int u = 0; u < kKeepQ; ++u) {
+      const int p = (q_first + tid + u * kKeyThreads) * 4;        // (quads past the band hold zkey: skipped)
+      CDN_PUT(kept[u].x, p); CDN_PUT(kept[u].y, p + 1); CDN_PUT(kept[u].z, p + 2); CDN_PUT(kept[u].w, p + 3);
+    }
+  } else if (vec) {                                               // recomputing sweep: same pixels, same order
+    for (int q = q_first + tid; q < q_end; q += kKeyThreads) {
+      const uint4 k4 = quad_keys(plane, Wp, y0, W, q);
+      CDN_PUT(k4.x, q * 4); CDN_PUT(k4.y, q * 4 + 1); CDN_PUT(k4.z, q * 4 + 2); CDN_PUT(k4.w, q * 4 + 3);
+    }
+  } else {
+    for (int p = y0 * W + tid; p < y1 * W; p += kKeyThreads) CDN_PUT(pixel_key(plane, Wp, y0, W, p), p);
+  }
+#undef CDN_PUT
   __syncthreads();
   for (int i = tid; i < kBins; i += kKeyThreads)
-    if (lh[i]) atomicAdd(&hist[(long)b * kBins + i], lh[i]);
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
 }
 
 // In-place sigmoid for the banded case (heat_out aliases heat): runs AFTER decode_keys_kernel in stream
@@ -214,9 +301,9 @@ __device__ void find_digit(const unsigned *h, int nbins, unsigned need, unsigned
 }
 
 __global__ void __launch_bounds__(kSelThreads)
-decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ hist,
-                     const float *__restrict__ wh, const float *__restrict__ reg,
-                     float *__restrict__ dets, int cat, int H, int W, int wh_ch, int K) {
+decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__restrict__ hist, unsigned cap,
+                     const float *__restrict__ src, int need_sigmoid, const float *__restrict__ wh,
+                     const float *__restrict__ reg, float *__restrict__ dets, int cat, int H, int W, int wh_ch, int K) {
   __shared__ unsigned h[2048];
   __shared__ unsigned long long list[kCap];
   __shared__ unsigned scan[kSelThreads];
@@ -225,98 +312,125 @@ decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ h
   const int b = blockIdx.x, tid = threadIdx.x;
   const int HW = H * W;
   const long total = (long)cat * HW;
-  const unsigned *kb = keys + (long)b * total;
-  const bool vec4 = (total & 3) == 0;            // (the key planes of an image are then 16-byte aligned)
-  unsigned *gh = hist + (long)b * kBins;
-  for (int i = tid; i < kBins; i += kSelThreads) {
-    h[i] = gh[i];
-    gh[i] = 0;                                   // leave the global histogram zero for the next call
-  }
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  unsigned need = (unsigned)K, pmask = 0, pval = 0;
-  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
-  bool exhausted = false;
-  for (int lvl = 0;; ++lvl) {
-    find_digit(h, 1 << widths[lvl], need, scan, &s_digit, &s_above);
-    const unsigned digit = (unsigned)s_digit, group = h[digit];
-    need -= s_above;
-    pmask |= ((1u << widths[lvl]) - 1u) << shifts[lvl];
-    pval |= digit << shifts[lvl];
-    __syncthreads();
-    if (group + (unsigned)K <= (unsigned)kCap) break;      // the threshold group fits the list
-    if (lvl == 2) { exhausted = true; break; }             // a huge group of IDENTICAL keys
-    for (int i = tid; i < 2048; i += kSelThreads) h[i] = 0;
-    __syncthreads();
-    const int sh = shifts[lvl + 1];
-    const unsigned wm = (1u << widths[lvl + 1]) - 1u;
-    if (vec4) {
-      // 8 loads in flight per thread: with one load per iteration a pass over the image's keys is 80
-      // dependent round trips (one workgroup per image: nothing else hides them)
-      const long nq = total >> 2;
-      for (long q0 = tid; q0 < nq; q0 += (long)kSelThreads * 8) {
-        uint4 kk[8];
+  unsigned *gh = hist + (long)b * kHistStride;
+  const unsigned ncand = gh[kBins];              // candidates the keys kernel counted (above cap: not all were stored)
+  const unsigned long long *lp = cand + (size_t)b * cap;
+  const float *sp = src + (long)b * total;
+  const unsigned zkey = cdn::f2ord(0.0f);
+  // The masked key of flat index i recomputed from the heat map (slow path only): the keys kernel's expression.
+  auto key_at = [&](long i) __attribute__((always_inline)) -> unsigned {
+    const int cls = (int)(i / HW), pix = (int)(i - (long)cls * HW), y = pix / W, x = pix - y * W;
+    const float *pl = sp + (long)cls * HW;
+    float m9 = -INFINITY, v = 0.0f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+          float t = pl[yy * W + xx];
+          if (need_sigmoid) t = sigmoidf_ref(t);
+          if (dy == 0 && dx == 0) v = t;
+          m9 = fmaxf(m9, t);
+        }
+      }
+    return masked_key(v, m9);
+  };
+  // fast: the K-th key is above zero and every key at or above it is in the list.  Workgroup-uniform.
+  bool slow = !(ncand >= (unsigned)K && ncand <= cap);
+  // One pass over the keys of the image: fn(key, flat index) -- over the candidate list (two 8-byte entries per
+  // load, 8 loads in flight per thread: one workgroup per image, nothing else hides the round trips) or, on the
+  // slow path, over every pixel.
+  auto for_each_key = [&](auto &&fn) __attribute__((always_inline)) {
+    if (!slow) {
+      const unsigned npair = (ncand + 1) >> 1;
+      for (unsigned q0 = tid; q0 < npair; q0 += kSelThreads * 8) {
+        ulonglong2 e[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const long q = q0 + (long)u * kSelThreads;
-          kk[u] = q < nq ? reinterpret_cast<const uint4 *>(kb)[q] : make_uint4(~pval, ~pval, ~pval, ~pval);
+          const unsigned q = q0 + u * kSelThreads;
+          e[u] = q < npair ? reinterpret_cast<const ulonglong2 *>(lp)[q] : make_ulonglong2(0ull, 0ull);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          if (q0 + (long)u * kSelThreads < nq) {
-            const uint4 k4 = kk[u];
-            if ((k4.x & pmask) == pval) atomicAdd(&h[(k4.x >> sh) & wm], 1u);
-            if ((k4.y & pmask) == pval) atomicAdd(&h[(k4.y >> sh) & wm], 1u);
-            if ((k4.z & pmask) == pval) atomicAdd(&h[(k4.z >> sh) & wm], 1u);
-            if ((k4.w & pmask) == pval) atomicAdd(&h[(k4.w >> sh) & wm], 1u);
+          const unsigned q = q0 + u * kSelThreads;
+          if (q < npair) {
+            fn((unsigned)(e[u].x >> 32), (long)(0xFFFFFFFFu - (unsigned)(e[u].x & 0xFFFFFFFFull)));
+            if (2 * q + 1 < ncand)
+              fn((unsigned)(e[u].y >> 32), (long)(0xFFFFFFFFu - (unsigned)(e[u].y & 0xFFFFFFFFull)));
           }
         }
       }
     } else {
-      for (long i = tid; i < total; i += kSelThreads) {
-        const unsigned k = kb[i];
+      for (long i = tid; i < total; i += kSelThreads) fn(key_at(i), i);
+    }
+  };
+  for (int i = tid; i < kBins; i += kSelThreads) {
+    h[i] = gh[i];
+    gh[i] = 0;                                   // leave the global histogram zero for the next call
+  }
+  if (tid == 0) {
+    gh[kBins] = 0;                               // ... and the candidate counter
+    s_n = 0;
+  }
+  __syncthreads();
+  unsigned need, pmask, pval;
+  bool exhausted;
+  for (;;) {                                     // at most two rounds: the list, then (rarely) the heat map itself
+    need = (unsigned)K, pmask = 0, pval = 0;
+    exhausted = false;
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int lvl = 0;; ++lvl) {
+      find_digit(h, 1 << widths[lvl], need, scan, &s_digit, &s_above);
+      const unsigned digit = (unsigned)s_digit, group = h[digit];
+      need -= s_above;
+      pmask |= ((1u << widths[lvl]) - 1u) << shifts[lvl];
+      pval |= digit << shifts[lvl];
+      __syncthreads();
+      if (group + (unsigned)K <= (unsigned)kCap) break;      // the threshold group fits the list
+      if (lvl == 2) { exhausted = true; break; }             // a huge group of IDENTICAL keys
+      for (int i = tid; i < 2048; i += kSelThreads) h[i] = 0;
+      __syncthreads();
+      const int sh = shifts[lvl + 1];
+      const unsigned wm = (1u << widths[lvl + 1]) - 1u;
+      for_each_key([&](unsigned k, long) {
         if ((k & pmask) == pval) atomicAdd(&h[(k >> sh) & wm], 1u);
+      });
+      __syncthreads();
+    }
+    if (!exhausted || slow) break;
+    // equal keys at the threshold that do not fit the LDS list must be taken by ascending index, which the
+    // unordered candidate list cannot give: start over on the pixels (level-0 histogram rebuilt from them)
+    slow = true;
+    for (int i = tid; i < 2048; i += kSelThreads) h[i] = 0;
+    __syncthreads();
+    {
+      unsigned zeros = 0;
+      for (long i = tid; i < total; i += kSelThreads) {
+        const unsigned k = key_at(i);
+        if (k == zkey) ++zeros;
+        else atomicAdd(&h[k >> 21], 1u);
       }
+      if (zeros) atomicAdd(&h[zkey >> 21], zeros);
     }
     __syncthreads();
   }
   // ---- collect: everything above the threshold group, and the group (or its first `need` by index)
   if (!exhausted) {
-    auto take = [&](unsigned k, long i) {
+    for_each_key([&](unsigned k, long i) {
       if ((k & pmask) >= pval) {
         const unsigned slot = atomicAdd(&s_n, 1u);
         if (slot < (unsigned)kCap)
           list[slot] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
       }
-    };
-    if (vec4) {
-      const long nq = total >> 2;
-      for (long q0 = tid; q0 < nq; q0 += (long)kSelThreads * 8) {
-        uint4 kk[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const long q = q0 + (long)u * kSelThreads;
-          kk[u] = q < nq ? reinterpret_cast<const uint4 *>(kb)[q] : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const long q = q0 + (long)u * kSelThreads;
-          if (q < nq) {
-            const uint4 k4 = kk[u];
-            take(k4.x, q * 4); take(k4.y, q * 4 + 1); take(k4.z, q * 4 + 2); take(k4.w, q * 4 + 3);
-          }
-        }
-      }
-    } else {
-      for (long i = tid; i < total; i += kSelThreads) take(kb[i], i);
-    }
+    });
   } else {
-    // every thread owns a contiguous index range, so a block scan gives each group member its rank
+    // (slow path) every thread owns a contiguous index range, so a block scan gives each group member its rank
     const long chunk = (total + kSelThreads - 1) / kSelThreads;
     const long i0 = (long)tid * chunk, i1 = min(total, i0 + chunk);
     unsigned cnt = 0;
     for (long i = i0; i < i1; ++i) {
-      const unsigned k = kb[i];
+      const unsigned k = key_at(i);
       if (k > pval) {
         const unsigned slot = atomicAdd(&s_n, 1u);
         if (slot < (unsigned)kCap)
@@ -335,7 +449,7 @@ decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ h
     }
     unsigned rank = scan[tid] - cnt;                      // exclusive
     for (long i = i0; i < i1 && rank < need; ++i)
-      if (kb[i] == pval) {
+      if (key_at(i) == pval) {
         const unsigned slot = atomicAdd(&s_n, 1u);
         if (slot < (unsigned)kCap)
           list[slot] = ((unsigned long long)pval << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
@@ -394,9 +508,20 @@ decode_select_kernel(const unsigned *__restrict__ keys, unsigned *__restrict__ h
 
 }  // namespace
 
+// Row bands of the keys kernel: ~36 KiB of plane per workgroup (3 workgroups per CU with the histogram), at least
+// 8 rows, balanced.
+static int band_rows(int64_t H, int64_t W) {
+  const size_t wp_bytes = (size_t)(((W + 3) & ~3) + 8) * 4;
+  constexpr int kb_kib = 36;
+  int RB = (int)std::max<long>(8, (long)((size_t)kb_kib * 1024 / wp_bytes) - 2);
+  RB = (int)std::min<long>(RB, H);
+  const int nbands = (int)cdn::ceil_div(H, RB);
+  return (int)cdn::ceil_div(H, nbands);
+}
+
 extern "C" size_t cdn_ctdet_decode_workspace_bytes(int64_t B, int64_t cat, int64_t H, int64_t W) {
   auto r = [](size_t b) { return (b + 255) / 256 * 256; };
-  return r((size_t)(B * cat * H * W) * 4) + r((size_t)B * kBins * 4);
+  return r((size_t)(B * cat * H * W) * 4) + r((size_t)B * kHistStride * 4);
 }
 
 extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float *reg, int64_t B,
@@ -416,16 +541,14 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
               CDN_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
   hipStream_t st = cdn::as_stream(stream);
   auto r = [](size_t b) { return (b + 255) / 256 * 256; };
-  unsigned *keys = static_cast<unsigned *>(workspace);
-  // the per-image histograms live in the LAST bytes: zero them once, every call leaves them zero
-  unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + workspace_bytes / 256 * 256 -
-                                                r((size_t)B * kBins * 4));
-  // row bands: ~36 KiB of plane per workgroup (3 workgroups per CU with the histogram), at least 8 rows
-  constexpr int kb_kib = 36;
-  int RB = (int)std::max<long>(8, (long)((size_t)kb_kib * 1024 / wp_bytes) - 2);
-  RB = (int)std::min<long>(RB, H);
+  // candidate lists: cat * H * W * 4 bytes per image = room for half the pixels as 8-byte entries
+  unsigned long long *cand = static_cast<unsigned long long *>(workspace);
+  const unsigned cap = (unsigned)((cat * H * W) / 2) & ~1u;
+  const int RB = band_rows(H, W);
   const int nbands = (int)cdn::ceil_div(H, RB);
-  RB = (int)cdn::ceil_div(H, nbands);                       // balanced bands
+  // the per-image histograms (+ candidate counters) live in the LAST bytes: zero them once, every call leaves them zero
+  unsigned *hist = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + workspace_bytes / 256 * 256 -
+                                                r((size_t)B * kHistStride * 4));
   const size_t lds = (size_t)(RB + 2) * wp_bytes;
   CDN_REQUIRE(lds <= 128 * 1024, CDN_ERR_UNSUPPORTED, "heat-map band does not fit LDS");
   (void)hipFuncSetAttribute((const void *)decode_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -438,7 +561,7 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
   const bool deferred = overlap && apply_sigmoid && nbands > 1;
   CDN_REQUIRE(!overlap || heat_out == heat, CDN_ERR_ARG, "heat_out partially overlaps heat");
   decode_keys_kernel<<<dim3((unsigned)cat, (unsigned)B, (unsigned)nbands), kKeyThreads, lds, st>>>(
-      heat, keys, hist, deferred ? nullptr : heat_out, (int)cat, (int)H, (int)W, apply_sigmoid, RB);
+      heat, cand, hist, deferred ? nullptr : heat_out, (int)cat, (int)H, (int)W, apply_sigmoid, RB, cap);
   int rc = cdn::check_launch("ctdet decode keys");
   if (rc) return rc;
   if (deferred) {
@@ -447,8 +570,11 @@ extern "C" int cdn_ctdet_decode(const float *heat, const float *wh, const float 
     rc = cdn::check_launch("ctdet decode in-place sigmoid");
     if (rc) return rc;
   }
-  decode_select_kernel<<<(unsigned)B, kSelThreads, 0, st>>>(keys, hist, wh, reg, dets, (int)cat, (int)H,
-                                                           (int)W, cat_spec_wh ? (int)(2 * cat) : 2, K);
+  // the slow path of the select kernel recomputes keys from the scores: the stored sigmoid if there is one
+  const float *src = heat_out ? heat_out : heat;
+  const int need_sigmoid = (apply_sigmoid && !heat_out) ? 1 : 0;
+  decode_select_kernel<<<(unsigned)B, kSelThreads, 0, st>>>(cand, hist, cap, src, need_sigmoid, wh, reg, dets, (int)cat,
+                                                           (int)H, (int)W, cat_spec_wh ? (int)(2 * cat) : 2, K);
   return cdn::check_launch("ctdet decode select");
 }
 

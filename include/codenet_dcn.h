@@ -638,7 +638,7 @@ int cdn_codenet_maxpool3x3s2_nhwc_forward(const float *a, const void *a_qstate, 
  *   dets [B][K][6] = x1, y1, x2, y2, score, class;  K <= 1024
  * Equal scores are ordered by ascending index class*H*W + y*W + x (torch.topk leaves it unspecified).
  * workspace: cdn_ctdet_decode_workspace_bytes(B,cat,H,W) bytes, 256-byte aligned; its LAST
- * round_up(B*8192, 256) bytes are histograms: zero them once, every call leaves them zero.
+ * round_up(B*8256, 256) bytes are per-image histograms and list counters: zero them once, every call leaves them zero.
  * ---------------------------------------------------------------------------------------- */
 size_t cdn_ctdet_decode_workspace_bytes(int64_t B, int64_t cat, int64_t H, int64_t W);
 int cdn_ctdet_decode(const float *heat, const float *wh, const float *reg, int64_t B, int64_t cat,

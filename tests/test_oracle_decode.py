@@ -58,8 +58,14 @@ def test_hip_decode_matches_oracle_and_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["full", "ties", "plateau", "few_peaks", "sigmoid"])
+@pytest.mark.parametrize("case", ["full", "ties", "plateau", "few_peaks", "sigmoid", "few_peaks_logits", "negative",
+                                  "mostly_negative", "exactly_k", "equal_peaks_retry"])
 def test_hip_decode_edge_cases(case):
+    """The select kernel works on the list of positive peaks when that list decides the result and on keys recomputed
+    from the heat map otherwise: fewer than K positive peaks (zeros fill up by index: few_peaks, few_peaks_logits --
+    the latter recomputing the sigmoid too --, mostly_negative: negative peaks rank below the zeros), a list that
+    overflowed (plateau), more equal keys at the threshold than the LDS list holds (equal_peaks_retry: starts on the
+    list, starts over on the heat map)."""
     from codenet_amd import harness
     g = torch.Generator().manual_seed(12)
     B, cat, H, W, K = 3, 20, 128, 128, 100
@@ -73,9 +79,35 @@ def test_hip_decode_edge_cases(case):
         heat = torch.zeros(B, cat, H, W)
         heat[:, 3, 5::40, 7::40] = torch.rand(B, 4, 4, generator=g) + 0.1
         B, cat, H, W, K = 3, 20, 128, 128, 50
+    elif case == "few_peaks_logits":         # logits: sigmoid(-200) == 0 exactly; 16 peaks per image
+        heat = torch.full((B, cat, H, W), -200.0)
+        heat[:, 3, 5::40, 7::40] = torch.rand(B, 4, 4, generator=g) + 0.1
+        K = 50
+    elif case == "negative":                 # raw scores of both signs, no sigmoid
+        heat = torch.randn(B, cat, H, W, generator=g)
+    elif case == "mostly_negative":          # 12 positive peaks, zeros, and negative peaks that must come last
+        heat = -torch.rand(B, cat, H, W, generator=g)
+        heat[:, :, ::2, :] = 0.0
+        heat[:, 7, 9::50, 11::40] = torch.rand(B, 3, 3, generator=g) + 0.5
+        K = 40
+    elif case == "exactly_k":                # as many positive peaks as K
+        heat = torch.zeros(B, cat, H, W)
+        heat[:, 2, 4::12, 6::13][:, :10, :10] = torch.rand(B, 10, 10, generator=g) + 0.1
+        K = 100
+    elif case == "equal_peaks_retry":        # 8192 isolated peaks of one value: more than the LDS list, fewer than the list
+        heat = torch.zeros(B, cat, H, W)
+        heat[:, 4:6, ::2, ::2] = 0.5
+        heat[:, 9, 3::32, 5::32] = 0.75
     else:
         heat = torch.randn(B, cat, H, W, generator=g) * 2
     wh, reg = torch.rand(B, 2, H, W, generator=g) * 9, torch.rand(B, 2, H, W, generator=g)
+    if case == "few_peaks_logits":
+        d = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda(), K=K, apply_sigmoid=True).cpu().numpy()
+        sg = torch.sigmoid(heat)
+        assert sg.min().item() == 0.0
+        o = OD.ctdet_decode(sg.numpy(), wh.numpy(), reg.numpy(), False, K)
+        assert np.array_equal(d[..., 5], o[..., 5]) and np.abs(d[..., :5] - o[..., :5]).max() < 1e-4
+        return
     if case == "sigmoid":
         out = torch.empty_like(heat).cuda()
         d = harness.ctdet_decode_native(heat.cuda(), wh.cuda(), reg.cuda(), K=K, apply_sigmoid=True,
