@@ -1121,8 +1121,15 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
         const long pix = (long)min(max(r, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1);
         d[u].x = __uint_as_float(*reinterpret_cast<const unsigned *>(abase8 + pix * C));
       } else {
+#ifdef CDN_HS_GUARDED
         d[u] = (row_in && col < Wc && (unsigned)x < (unsigned)Ws)
                    ? *reinterpret_cast<const float4 *>(abase + ((long)r * Ws + x) * C) : z4;
+#else
+        // (clamped address, masked in write_row: `cond ? *p : zero` compiles to a FLAT load whose address is selected
+        // between global memory and a zero constant parked in scratch memory)
+        const long pix = (long)min(max(r, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1);
+        d[u] = *reinterpret_cast<const float4 *>(abase + pix * C);
+#endif
       }
     }
   };
@@ -1149,6 +1156,8 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
           t.y = cdn::fake_quant_r(t.y, s1, z1, r1);
           t.z = cdn::fake_quant_r(t.z, s1, z1, r1);
           t.w = cdn::fake_quant_r(t.w, s1, z1, r1);
+        } else {
+          t = z4;                              // the depthwise conv's zero padding
         }
         ring4[(slot * Wc + col) * LPP + cq] = t;
       }
@@ -1598,7 +1607,13 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
   CDN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && N <= 65535, CDN_ERR_ARG, "bad size");
   CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0, CDN_ERR_ARG, "y1 must be 16-byte aligned");
-  constexpr int hs_wgs = 2;
+#ifndef CDN_HS_WGS_RANGE
+#define CDN_HS_WGS_RANGE 2
+#endif
+#ifndef CDN_HS_WGS_TAIL
+#define CDN_HS_WGS_TAIL 2
+#endif
+  const int hs_wgs = mode == 0 ? CDN_HS_WGS_RANGE : CDN_HS_WGS_TAIL;      // row strips: workgroups per CU
   constexpr int hs_minrows = 8;
   hipStream_t st = cdn::as_stream(stream);
   const unsigned *q1 = static_cast<const unsigned *>(y1_qstate);
