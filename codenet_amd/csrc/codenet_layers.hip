@@ -1608,10 +1608,10 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
   CDN_REQUIRE(C == 64, CDN_ERR_UNSUPPORTED, "head_small is instantiated for 64 channels (got %lld)", (long long)C);
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(y1) & 15) == 0, CDN_ERR_ARG, "y1 must be 16-byte aligned");
 #ifndef CDN_HS_WGS_RANGE
-#define CDN_HS_WGS_RANGE 2
+#define CDN_HS_WGS_RANGE 4      /* 120 VGPRs, 35 KB of LDS: four workgroups per CU */
 #endif
 #ifndef CDN_HS_WGS_TAIL
-#define CDN_HS_WGS_TAIL 2
+#define CDN_HS_WGS_TAIL 3       /* 144-152 VGPRs: three (three heads, one box: 0.359-0.369 ms at 2 / 2, 0.352-0.355 at 4 / 3) */
 #endif
   const int hs_wgs = mode == 0 ? CDN_HS_WGS_RANGE : CDN_HS_WGS_TAIL;      // row strips: workgroups per CU
   constexpr int hs_minrows = 8;
