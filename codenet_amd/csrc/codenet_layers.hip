@@ -294,18 +294,23 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   // step k (output row oy0 + k) consumes input rows r_first + (3 - STRIDE) + STRIDE * k + s, s < STRIDE
   const int r_step0 = r_first + (3 - STRIDE);
   if (oy0 < oy1) {
+    // every load of the prologue goes out before the first row is consumed: load -> write -> load -> write cost the
+    // workgroup 3 - STRIDE + 1 dependent memory round trips before its first output row (all workgroups of these
+    // one-round launches start together, so the launch was that much longer)
+    float4 pro[3 - STRIDE][MAXL];
 #pragma unroll
-    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) {
-      load_row(r_first + p_, pre[0][0]);
-      write_row(r_first + p_, wslot, pre[0][0]);
-      wslot = wslot + 1 == RING ? 0 : wslot + 1;
-    }
+    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) load_row(r_first + p_, pro[p_]);
 #pragma unroll
     for (int d_ = 0; d_ < DEPTH; ++d_)
       if (oy0 + d_ < oy1) {
 #pragma unroll
         for (int s_ = 0; s_ < STRIDE; ++s_) load_row(r_step0 + STRIDE * d_ + s_, pre[d_][s_]);
       }
+#pragma unroll
+    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) {
+      write_row(r_first + p_, wslot, pro[p_]);
+      wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    }
   }
   float mn = INFINITY, mx = -INFINITY;
   int cslot = 0;                                              // ring slot of the first row of the 3x3 window
@@ -489,18 +494,23 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   int wslot = 0;
   const int r_step0 = r_first + (3 - STRIDE);
   if (oy0 < oy1) {
+    // every load of the prologue goes out before the first row is consumed: load -> write -> load -> write cost the
+    // workgroup 3 - STRIDE + 1 dependent memory round trips before its first output row (all workgroups of these
+    // one-round launches start together, so the launch was that much longer)
+    float4 pro[3 - STRIDE][MAXL];
 #pragma unroll
-    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) {
-      load_row(r_first + p_, pre[0][0]);
-      write_row(r_first + p_, wslot, pre[0][0]);
-      wslot = wslot + 1 == RING ? 0 : wslot + 1;
-    }
+    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) load_row(r_first + p_, pro[p_]);
 #pragma unroll
     for (int d_ = 0; d_ < DEPTH; ++d_)
       if (oy0 + d_ < oy1) {
 #pragma unroll
         for (int s_ = 0; s_ < STRIDE; ++s_) load_row(r_step0 + STRIDE * d_ + s_, pre[d_][s_]);
       }
+#pragma unroll
+    for (int p_ = 0; p_ < 3 - STRIDE; ++p_) {
+      write_row(r_first + p_, wslot, pro[p_]);
+      wslot = wslot + 1 == RING ? 0 : wslot + 1;
+    }
   }
   float mn = INFINITY, mx = -INFINITY;
   int cslot = 0;
@@ -629,11 +639,15 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   for (int e = 0; e < 4; ++e) {
     const int c = min(cb + e, C - 1);
     const bool on = cb + e < C;
-    // (unconditional loads from the clamped channel, selected afterwards: no branch / wait per load)
+    // the channel's code row as two vector loads (rows are zero-padded to Cpad >= 64 bytes, so the quads past Cin
+    // read zeros): one dword load per quad, each behind its own branch and `s_waitcnt vmcnt(0)` -- what the compiler
+    // made of `(on && q < Q4) ? load : 0` -- cost the workgroup 24 dependent L2 round trips before its first row
+    {
+      const i32x4 lo = *reinterpret_cast<const i32x4 *>(Wq + (long)c * Cpad);
+      const i32x4 hi = *reinterpret_cast<const i32x4 *>(Wq + (long)c * Cpad + 16);
+      const int msk = on ? -1 : 0;
 #pragma unroll
-    for (int q = 0; q < Q4T; ++q) {
-      const int t = *reinterpret_cast<const int *>(Wq + (long)c * Cpad + 4 * min(q, Q4 - 1));
-      wq[e][q] = (on && q < Q4) ? t : 0;
+      for (int q = 0; q < Q4T; ++q) wq[e][q] = (q < 4 ? lo[q] : hi[q - 4]) & msk;
     }
     rinv[e] = __fdiv_rn(1.0f, __fmul_rn(xs_, wscale[c]));
     t128[e] = 128 * wsum[c];
@@ -758,17 +772,18 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   if (oy0 < oy1) {
     if (tid < 2) s_wide_row[tid] = 0u;
     __syncthreads();
-    load_row(r_first, pre[0][0]);                                 // the one row in front of the first output row
-    write_codes(0, pre[0][0], 0);
-    __syncthreads();
-    produce_row(r_first, wslot, 0, 0);
-    wslot = 1;
+    float4 pro[MAXI];
+    load_row(r_first, pro);                                       // the one row in front of the first output row
 #pragma unroll
-    for (int d_ = 0; d_ < DEPTH; ++d_)
+    for (int d_ = 0; d_ < DEPTH; ++d_)                            // (and every prefetch row: one round trip, not two)
       if (oy0 + d_ < oy1) {
 #pragma unroll
         for (int s_ = 0; s_ < STRIDE; ++s_) load_row(r_step0 + STRIDE * d_ + s_, pre[d_][s_]);
       }
+    write_codes(0, pro, 0);
+    __syncthreads();
+    produce_row(r_first, wslot, 0, 0);
+    wslot = 1;
     __syncthreads();                                              // code row 0 is read: the loop may overwrite it
   }
   float mn = INFINITY, mx = -INFINITY;
@@ -1166,15 +1181,17 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   float4 pre[DEPTH][MAXL];
   int wslot = 0;
   if (Y0 < Y1) {
+    float4 pro[2][MAXL];                      // stored rows Y0 - 1, Y0: all prologue loads in flight together
 #pragma unroll
-    for (int p_ = 0; p_ < 2; ++p_) {          // stored rows Y0 - 1, Y0
-      load_row(Y0 - 1 + p_, pre[0]);
-      write_row(Y0 - 1 + p_, wslot, pre[0]);
-      wslot = (wslot + 1) & 3;
-    }
+    for (int p_ = 0; p_ < 2; ++p_) load_row(Y0 - 1 + p_, pro[p_]);
 #pragma unroll
     for (int d_ = 0; d_ < DEPTH; ++d_)
       if (Y0 + d_ < Y1) load_row(Y0 + 1 + d_, pre[d_]);
+#pragma unroll
+    for (int p_ = 0; p_ < 2; ++p_) {
+      write_row(Y0 - 1 + p_, wslot, pro[p_]);
+      wslot = (wslot + 1) & 3;
+    }
   }
   float mn = INFINITY, mx = -INFINITY;
   int cslot = 0;
@@ -1775,7 +1792,7 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
               "the output QuantAct needs x_min, x_max and state together");
   CDN_REQUIRE(cdn_codenet_pwdw_s2_supported(N, Cin, C, H, W), CDN_ERR_UNSUPPORTED, "shape outside the fused pw -> dw kernel");
   CDN_REQUIRE(ld_x >= Cin && (ld_x & 3) == 0 && ld_out >= C && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(w_pw_codes) & 3) == 0, CDN_ERR_ARG, "bad row stride / alignment");
+                  (reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG, "bad row stride / alignment");
   // 1. the 1x1 conv as a RANGE-ONLY pass (out = NULL): batch extremes of relu(conv) -> the mid QuantAct
   const int64_t M = N * H * W;
   int rc = cdn_codenet_pointwise_mixed_forward(x, x_qstate, nullptr, M, Cin, C, ld_x, 0, w_pw, w_pw_codes, w_pw_scale,
