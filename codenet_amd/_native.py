@@ -53,6 +53,8 @@ _SIGNATURES = {
     "cdn_codenet_dw_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
     "cdn_codenet_pointwise_forward": (_i, [_vp] * 6 + [_i64] * 4 + [_i, _vp]),
     "cdn_quantact_state_bytes": (ctypes.c_size_t, []),
+    "cdn_kth_values_workspace_bytes": (ctypes.c_size_t, []),
+    "cdn_kth_values": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "cdn_quantact_forward": (_i, [_vp] * 3 + [_i64] + [_vp] * 5 + [_i, _d, _i, _vp]),
     "cdn_quantact_relu_up2_forward": (_i, [_vp, _vp] + [_i64] * 3 + [_vp] * 3 + [_i, _d, _i, _vp]),
     "cdn_up2_relu_backward": (_i, [_vp] * 3 + [_i64] * 3 + [_vp]),

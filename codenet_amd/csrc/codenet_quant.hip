@@ -279,6 +279,102 @@ inline int stream_grid(long n) {
   return (int)(b < cap ? b : cap);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// kth_values: the k_lo-th and k_hi-th smallest elements of a tensor -- torch.kthvalue on the flattened tensor, which is
+// what --act-percentile / --wt-percentile compute per QuantAct call (quant_utils.py:18-30: the 0.1 % and 99.9 %
+// order statistics as the activation range; a full sort per call in the reference).  Radix select on the
+// order-preserving 32-bit keys (cdn::f2ord): three passes over the tensor (11 + 11 + 10 bits), each a histogram of the
+// elements that still match a rank's prefix, each followed by a one-workgroup scan that picks the digit.  Exact: the
+// result is an element of x (NaNs order above +inf, as in torch; -0.0 orders below +0.0, numerically the same value).
+// ------------------------------------------------------------------------------------------
+constexpr int kKthBins = 2048, kKthThreads = 512;
+struct KthState {            // device-side, in the workspace behind the two histograms
+  unsigned prefix[2], mask[2], rank[2];
+};
+
+__global__ void __launch_bounds__(kKthThreads)
+kth_hist_kernel(const float *__restrict__ x, long n, int shift, int width, const KthState *__restrict__ st,
+                unsigned *__restrict__ hist) {
+  __shared__ unsigned lh[2][kKthBins];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * kKthBins; i += kKthThreads) (&lh[0][0])[i] = 0u;
+  const unsigned p0 = st->prefix[0], p1 = st->prefix[1], m0 = st->mask[0], m1 = st->mask[1];
+  const bool same = p0 == p1 && m0 == m1;        // both ranks still in one group (always at the first level)
+  const unsigned wm = (1u << width) - 1u;
+  __syncthreads();
+  auto tally = [&](float v) __attribute__((always_inline)) {
+    const unsigned k = cdn::f2ord(v);
+    if ((k & m0) == p0) atomicAdd(&lh[0][(k >> shift) & wm], 1u);
+    else if (!same && (k & m1) == p1) atomicAdd(&lh[1][(k >> shift) & wm], 1u);
+  };
+  const long nq = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n >> 2 : 0;
+  for (long q = (long)blockIdx.x * kKthThreads + tid; q < nq; q += (long)gridDim.x * kKthThreads) {
+    const float4 v = reinterpret_cast<const float4 *>(x)[q];
+    tally(v.x); tally(v.y); tally(v.z); tally(v.w);
+  }
+  for (long i = nq * 4 + (long)blockIdx.x * kKthThreads + tid; i < n; i += (long)gridDim.x * kKthThreads) tally(x[i]);
+  __syncthreads();
+  for (int i = tid; i < 2 * kKthBins; i += kKthThreads) {
+    const unsigned c = (&lh[0][0])[i];
+    if (c) atomicAdd(&hist[i], c);
+  }
+}
+
+// One workgroup: for both ranks, the digit whose bin holds the rank-th smallest element of the group; extends the
+// prefix, rebases the rank, zeroes the histograms for the next level; after the last level writes the values.
+__global__ void __launch_bounds__(1024)
+kth_pick_kernel(unsigned *__restrict__ hist, KthState *__restrict__ st, int shift, int width, int last,
+                float *__restrict__ out_lo, float *__restrict__ out_hi) {
+  __shared__ unsigned scan[1024];
+  __shared__ unsigned s_digit[2], s_below[2];
+  const int tid = threadIdx.x;
+  const bool same = st->prefix[0] == st->prefix[1] && st->mask[0] == st->mask[1];
+  for (int j = 0; j < 2; ++j) {
+    const unsigned *h = hist + ((j == 1 && !same) ? kKthBins : 0);
+    const unsigned need = st->rank[j];                       // 1-based rank inside the group
+    const unsigned lo = h[2 * tid], hi = h[2 * tid + 1];
+    scan[tid] = lo + hi;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {               // inclusive prefix sums over bin pairs
+      const unsigned v = tid >= off ? scan[tid - off] : 0u;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    const unsigned incl = scan[tid], excl = incl - (lo + hi);
+    if (excl < need && need <= incl) {                       // exactly one pair crosses the rank
+      if (need <= excl + lo) {
+        s_digit[j] = 2 * tid;
+        s_below[j] = excl;
+      } else {
+        s_digit[j] = 2 * tid + 1;
+        s_below[j] = excl + lo;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 2 * kKthBins; i += 1024) hist[i] = 0u;
+  __syncthreads();
+  if (tid < 2) {
+    const unsigned wm = (1u << width) - 1u;
+    const unsigned prefix = st->prefix[tid] | (s_digit[tid] << shift), mask = st->mask[tid] | (wm << shift);
+    st->prefix[tid] = prefix;
+    st->mask[tid] = mask;
+    st->rank[tid] -= s_below[tid];
+    if (last) *(tid == 0 ? out_lo : out_hi) = cdn::ord2f(prefix);
+  }
+}
+
+__global__ void kth_init_kernel(unsigned *hist, KthState *st, unsigned k_lo, unsigned k_hi) {
+  for (int i = threadIdx.x; i < 2 * kKthBins; i += blockDim.x) hist[i] = 0u;
+  if (threadIdx.x < 2) {
+    st->prefix[threadIdx.x] = 0u;
+    st->mask[threadIdx.x] = 0u;
+    st->rank[threadIdx.x] = threadIdx.x == 0 ? k_lo : k_hi;
+  }
+}
+
 }  // namespace
 
 namespace cdn {
@@ -413,4 +509,29 @@ extern "C" int cdn_up2_relu_backward(const float *grad_out, const float *y, floa
   up2_relu_bwd_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
                         256, 0, st>>>(grad_out, y, grad_y, rows, (int)W);
   return cdn::check_launch("up2 relu backward");
+}
+
+
+extern "C" size_t cdn_kth_values_workspace_bytes(void) { return 2 * kKthBins * sizeof(unsigned) + 256; }
+
+extern "C" int cdn_kth_values(const float *x, int64_t numel, int64_t k_lo, int64_t k_hi, float *out_lo, float *out_hi,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+  CDN_REQUIRE(x && out_lo && out_hi && workspace, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(numel > 0 && numel < (1ll << 32), CDN_ERR_UNSUPPORTED, "1 <= numel < 2^32");
+  CDN_REQUIRE(k_lo >= 1 && k_lo <= numel && k_hi >= 1 && k_hi <= numel, CDN_ERR_ARG,
+              "kthvalue(): selected number k out of range (k_lo %lld, k_hi %lld, numel %lld)", (long long)k_lo,
+              (long long)k_hi, (long long)numel);
+  CDN_REQUIRE(workspace_bytes >= cdn_kth_values_workspace_bytes() && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+              CDN_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  unsigned *hist = static_cast<unsigned *>(workspace);
+  KthState *state = reinterpret_cast<KthState *>(hist + 2 * kKthBins);
+  kth_init_kernel<<<1, 256, 0, st>>>(hist, state, (unsigned)k_lo, (unsigned)k_hi);
+  const unsigned blocks = (unsigned)std::max<long>(1, std::min<long>(cdn::ceil_div((long)numel, 4L * kKthThreads * 4), 4L * cdn::kCUs));
+  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    kth_hist_kernel<<<blocks, kKthThreads, 0, st>>>(x, (long)numel, shifts[lvl], widths[lvl], state, hist);
+    kth_pick_kernel<<<1, 1024, 0, st>>>(hist, state, shifts[lvl], widths[lvl], lvl == 2, out_lo, out_hi);
+  }
+  return cdn::check_launch("kth values");
 }

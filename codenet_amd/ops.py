@@ -234,6 +234,23 @@ def quantact_state(device):
     return torch.zeros(nbytes // 4, dtype=torch.int32, device=device)
 
 
+def kth_values(x, k_lo, k_hi):
+    """(k_lo-th, k_hi-th) smallest elements of the GPU float32 tensor x, flattened -- torch.kthvalue's values for both
+    ranks from three histogram passes (cdn_kth_values); tensors of shape [1].  The ranks are the reference's
+    round(n * pct / 100) (quant_utils.py:18-30)."""
+    _gpu_f32(x)
+    x = x.contiguous()
+    lib = N_.lib()
+    need = lib.cdn_kth_values_workspace_bytes()
+    ws = torch.empty(need // 4 + 64, dtype=torch.int32, device=x.device)
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    out = torch.empty(2, device=x.device)
+    rc = lib.cdn_kth_values(_p(x), x.numel(), int(k_lo), int(k_hi), out.data_ptr(), out.data_ptr() + 4, wp, need,
+                            _stream(x))
+    N_.check(rc, "cdn_kth_values")
+    return out[0:1], out[1:2]
+
+
 def quantact_forward(x, x_min, x_max, state, bits=8, momentum=0.99, running=True,
                      batch_min=None, batch_max=None, want_codes=False, want_out=True):
     """On-device QuantAct (quant_modules.py:202-225).  Updates x_min / x_max IN PLACE when

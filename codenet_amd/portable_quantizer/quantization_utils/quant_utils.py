@@ -19,8 +19,16 @@ def clamp(input, min, max, inplace=False):
 def get_percentile_min_max(input, lower_percentile, upper_percentile, output_tensor=False):
     """k-th value bounds of a flat tensor (reference :18-30; k = round(n * pct / 100))."""
     n = input.shape[0]
-    lo = torch.kthvalue(input, k=round(n * lower_percentile * 0.01)).values
-    hi = torch.kthvalue(input, k=round(n * upper_percentile * 0.01)).values
+    k_lo, k_hi = round(n * lower_percentile * 0.01), round(n * upper_percentile * 0.01)
+    if (input.is_cuda and input.dtype == torch.float32 and 1 <= k_lo <= n and 1 <= k_hi <= n and n < 2 ** 32
+            and not (torch.is_grad_enabled() and input.requires_grad)):
+        # GPU: both order statistics from three histogram passes (exact radix select) instead of two sorts
+        from ... import ops
+        lo, hi = ops.kth_values(input, k_lo, k_hi)
+        lo, hi = lo.reshape(()), hi.reshape(())
+    else:
+        lo = torch.kthvalue(input, k=k_lo).values
+        hi = torch.kthvalue(input, k=k_hi).values
     return (lo, hi) if output_tensor else (lo.item(), hi.item())
 
 

@@ -280,6 +280,15 @@ int cdn_codenet_pointwise_forward(const float *d, const float *w_pw, const float
  * x, out must be 16-byte aligned, codes 8-byte aligned.  out and codes may be NULL.
  * ---------------------------------------------------------------------------------------- */
 size_t cdn_quantact_state_bytes(void);
+
+/* The k_lo-th and k_hi-th smallest elements (1-based, torch.kthvalue's k) of x[numel]: the order statistics that
+ * --act-percentile / --wt-percentile use as the quantisation range (portable_quantizer/quantization_utils/
+ * quant_utils.py:18-30, called per QuantAct forward at quant_modules.py:203-210).  Exact (the results are elements of
+ * x); three histogram passes over x.  workspace: cdn_kth_values_workspace_bytes() bytes, 256-byte aligned, no
+ * initialisation required.  numel < 2^32. */
+size_t cdn_kth_values_workspace_bytes(void);
+int cdn_kth_values(const float *x, int64_t numel, int64_t k_lo, int64_t k_hi, float *out_lo, float *out_hi,
+                   void *workspace, size_t workspace_bytes, void *stream);
 int cdn_quantact_forward(const float *x, float *out, int16_t *codes, int64_t numel, float *x_min,
                          float *x_max, void *state, const float *batch_min,
                          const float *batch_max, int bits, double momentum, int running,
