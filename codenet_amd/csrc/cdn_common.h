@@ -117,15 +117,18 @@ struct QUpdate {
 constexpr int kArriveGroups = 64;
 constexpr int kArriveWords = (kArriveGroups + 1) * 16;
 
+// have_wide (--act-percentile): bmin / bmax are the 0.1 % / 99.9 % order statistics the RANGE follows, wmin / wmax
+// the batch's true extremes, which still decide how wide the codes get (the reference does not clamp them).
 __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float bmin, float bmax,
                                                        bool have_stats, bool preloaded = false,
-                                                       float pre_lo = 0.f, float pre_hi = 0.f) {
+                                                       float pre_lo = 0.f, float pre_hi = 0.f, bool have_wide = false,
+                                                       float wmin = 0.f, float wmax = 0.f) {
 #pragma clang fp contract(off)
   float lo = preloaded ? pre_lo : u.x_min[0], hi = preloaded ? pre_hi : u.x_max[0];
   float *sf = reinterpret_cast<float *>(u.state);
   if (have_stats) {
-    sf[4] = bmin;
-    sf[5] = bmax;
+    sf[4] = have_wide ? wmin : bmin;
+    sf[5] = have_wide ? wmax : bmax;
   }
   if (u.running) {
     if (lo == hi) {  // "Initialization" branch: += (quant_modules.py:211-213)
@@ -154,8 +157,8 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
   // consumers then take their f32 path.  Codes are monotone in x, so the extremes decide.
   unsigned wide = 1u;
   if (have_stats && u.bits == 8) {
-    const float a0 = quant_code(bmin, scale, zp) + (zp - 128.0f);
-    const float a1 = quant_code(bmax, scale, zp) + (zp - 128.0f);
+    const float a0 = quant_code(have_wide ? wmin : bmin, scale, zp) + (zp - 128.0f);
+    const float a1 = quant_code(have_wide ? wmax : bmax, scale, zp) + (zp - 128.0f);
     wide = (fabsf(a0) > 2039.0f || fabsf(a1) > 2039.0f || !(a0 == a0) || !(a1 == a1) ||
             !(fabsf(zp) < 4.0e6f)) ? 1u : 0u;   // (the int8 kernels do integer arithmetic on zp)
   }

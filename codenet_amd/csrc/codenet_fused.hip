@@ -2766,6 +2766,19 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
   return cdn::check_launch("codenet fused pointwise");
 }
 
+// --act-percentile (CDN_X_ACT_PERCENTILE): the radix select's histograms + the two order statistics it returns
+constexpr int64_t kPctBytes = 32 * 1024;
+
+// Range commit of a percentile QuantAct: the producer (launched with running = 0) left the batch's TRUE extremes in
+// state words [4], [5]; the range follows the order statistics `pct` (quant_modules.py:203-219), the code-width flag
+// the extremes.
+__global__ void quantact_commit_percentile_kernel(cdn::QUpdate u, const float *__restrict__ pct) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float *sf = reinterpret_cast<const float *>(u.state);
+    cdn::quantact_update_device(u, pct[0], pct[1], true, false, 0.f, 0.f, true, sf[4], sf[5]);
+  }
+}
+
 extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W,
                                                     int x_up) {
   const int64_t HWl = (H >> x_up) * (W >> x_up);
@@ -2773,7 +2786,7 @@ extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_
   // up to 256 bytes
   auto r = [](int64_t b) { return (b + 255) / 256 * 256; };
   const int64_t Cd = (C + 63) / 64 * 64;        // (rows of d may be padded to whole 64-channel chunks)
-  return (size_t)(r(N * HWl * 4) + r(N * H * W * Cd * 4) + 3 * r(kMaxPartials * 8) +
+  return (size_t)(r(N * HWl * 4) + r(N * H * W * Cd * 4) + r(kPctBytes) + 3 * r(kMaxPartials * 8) +
                   3 * r(cdn::kArriveWords * 4));
 }
 
@@ -2814,10 +2827,15 @@ extern "C" int cdn_codenet_stage_fused_forward(
     void *stream) {
   CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
-  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK)) == 0 && ((x_nhwc & CDN_X_GATHER_MASK) >> 8) <= 2, CDN_ERR_ARG,
-              "x_nhwc: 0 / 1, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT");
+  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK | CDN_X_ACT_PERCENTILE)) == 0 &&
+                  ((x_nhwc & CDN_X_GATHER_MASK) >> 8) <= 2, CDN_ERR_ARG,
+              "x_nhwc: 0 / 1, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT, | CDN_X_ACT_PERCENTILE");
   const int gmode = (x_nhwc & CDN_X_GATHER_MASK) >> 8;      // per-call schedule choice (tests); no library state
+  // --act-percentile: the three QuantActs follow the 0.1 % / 99.9 % order statistics of their input instead of its
+  // extremes (only while the ranges are tracked)
+  const bool pct = (x_nhwc & CDN_X_ACT_PERCENTILE) != 0 && running != 0;
   x_nhwc &= 1;
+  CDN_REQUIRE(!pct || (s_state && d_state && r_state), CDN_ERR_ARG, "CDN_X_ACT_PERCENTILE needs the three QuantActs");
   CDN_REQUIRE(x_up == 0 || x_up == 1, CDN_ERR_ARG, "x_up must be 0 or 1");
   CDN_REQUIRE(!x_up || ((H & 1) == 0 && (W & 1) == 0), CDN_ERR_SHAPE,
               "x_up needs even H, W (got %lld x %lld)", (long long)H, (long long)W);
@@ -2850,12 +2868,14 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // chunks, 16-byte stores) and the int8 pointwise's 16-byte row loads apply; the pad channels duplicate channel
   // C - 1 and meet zero weight codes (see dw0p_kernel).  Same values as the unpadded schedule, bit for bit.
   const int64_t Cd = (C + 63) / 64 * 64;
-  const bool pad_d = !x_nhwc && x_up == 0 && Cd != C && gmode != 1 && w_pw_codes != nullptr && d_state != nullptr &&
+  const bool pad_d = !pct && !x_nhwc && x_up == 0 && Cd != C && gmode != 1 && w_pw_codes != nullptr && d_state != nullptr &&
                      ep_scale == nullptr && w_pw_scale != nullptr && w_pw_colsum != nullptr &&
                      cdn::stage_channel_chunk(Hl, Wl) == 64 && dw0p_applies((int)Cd, (int)H, (int)W) &&
                      N * Cd * H * W < (1ll << 31);
   const int64_t ldd = pad_d ? Cd : C;
-  float2 *part_s = reinterpret_cast<float2 *>(wsp + r256(N * HWl * 4) + r256(N * H * W * Cd * 4));
+  char *pct_ws = wsp + r256(N * HWl * 4) + r256(N * H * W * Cd * 4);
+  float *pct_out = reinterpret_cast<float *>(pct_ws + kPctBytes - 256);
+  float2 *part_s = reinterpret_cast<float2 *>(pct_ws + r256(kPctBytes));
   float2 *part_d = part_s + kMaxPartials;
   float2 *part_r = part_d + kMaxPartials;
   // arrival counters: the LAST bytes of the workspace (the caller zeroes them once)
@@ -2874,9 +2894,31 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // cdn::block_minmax_finish: no separate update launches.  Python evaluates (momentum - 1.) and
   // (1. - momentum) in double, then the tensor op rounds the scalar to fp32 (quant_modules.py:217-219).
   const float mm1 = (float)(momentum - 1.0), omm = (float)(1.0 - momentum);
-  const cdn::QUpdate qu_s{s_min, s_max, sst, arrive, mm1, omm, bits, running};
-  const cdn::QUpdate qu_d{d_min, d_max, dst, arrive + arr_stride, mm1, omm, bits, running};
-  const cdn::QUpdate qu_r{r_min, r_max, rst, arrive + 2 * arr_stride, mm1, omm, bits, running};
+  // (percentile: the producers only measure -- running = 0 leaves the range alone and parks the extremes in the
+  // state --, the commit follows each of them)
+  const int prun = pct ? 0 : running;
+  const cdn::QUpdate qu_s{s_min, s_max, sst, arrive, mm1, omm, bits, prun};
+  const cdn::QUpdate qu_d{d_min, d_max, dst, arrive + arr_stride, mm1, omm, bits, prun};
+  const cdn::QUpdate qu_r{r_min, r_max, rst, arrive + 2 * arr_stride, mm1, omm, bits, prun};
+  // t holds n / rep elements, each standing for `rep` equal elements of the tensor the reference ranks (rep = 4: the
+  // scale plane of an up-sampled input is computed at stored resolution; nearest x2 replicates every value four times)
+  auto commit_percentile = [&](const float *t, int64_t n, int rep, const cdn::QUpdate &qu) -> int {
+    // the reference's ranks: round(n * 0.1 * 0.01), round(n * 99.9 * 0.01), Python's round (half to even)
+    int64_t k_lo = (int64_t)std::nearbyint(((double)n * 0.1) * 0.01);
+    int64_t k_hi = (int64_t)std::nearbyint(((double)n * 99.9) * 0.01);
+    CDN_REQUIRE(k_lo >= 1 && k_hi <= n, CDN_ERR_UNSUPPORTED,
+                "kthvalue(): selected number k out of range (a tensor of %lld elements has no 0.1 %% order statistic)",
+                (long long)n);
+    k_lo = (k_lo + rep - 1) / rep;             // the k-th smallest of the replicated multiset
+    k_hi = (k_hi + rep - 1) / rep;
+    n /= rep;
+    int rc2 = cdn_kth_values(t, n, k_lo, k_hi, pct_out, pct_out + 1, pct_ws, (size_t)(kPctBytes - 256), stream);
+    if (rc2) return rc2;
+    cdn::QUpdate q2 = qu;
+    q2.running = running;
+    quantact_commit_percentile_kernel<<<1, 64, 0, st>>>(q2, pct_out);
+    return cdn::check_launch("codenet fused percentile commit");
+  };
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
   // 1. scale prediction at stored resolution (+ min/max of s)
   float2 *smm = sst ? part_s : nullptr;
@@ -2920,6 +2962,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
   int rc = cdn::check_launch("codenet fused scale");
   if (rc) return rc;
   (void)n_part_s;
+  if (pct && (rc = commit_percentile(s_raw, N * H * W, x_up ? 4 : 1, qu_s))) return rc;
   // 2. gather + depthwise (+ min/max of d)
   float2 *dmm = dst ? part_d : nullptr;   // always: the batch extremes also gate the int8 path
   const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
@@ -2931,10 +2974,14 @@ extern "C" int cdn_codenet_stage_fused_forward(
             (int)ldd);
   }
   if (rc) return rc;
+  if (pct && (rc = commit_percentile(d, N * H * W * C, 1, qu_d))) return rc;
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
-  return launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
-                          bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
-                          st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d);
+  rc = launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
+                        bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
+                        st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d);
+  if (rc) return rc;
+  if (pct) rc = commit_percentile(r_out, N * H * W * Co, 1, qu_r);
+  return rc;
 }
 
 extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw,

@@ -159,7 +159,8 @@ class PoseShuffleNetV2(nn.Module):
             if not ok:
                 import warnings
                 warnings.warn("codenet_amd: enable_fused() does not cover this model configuration / input "
-                              "shape %s; running the module-by-module path" % (tuple(x.shape),))
+                              "shape %s; running the module-by-module path (the deform stages alone stay on the "
+                              "fused schedule where it implements them, e.g. --act-percentile)" % (tuple(x.shape),))
             cache[key] = ok
         return cache[key]
 
@@ -200,9 +201,27 @@ class PoseShuffleNetV2(nn.Module):
             x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
             return [self._fheads(*self._fpath.forward_nhwc(x))]
         x = self.layer4(self.layer3(self.layer2(self.layer1(self.layer0(x)))))
+        if getattr(self, "_fused", False) and x.is_cuda and not torch.is_grad_enabled() and self._stages_fused_ok(x):
+            # enable_fused() on a configuration the fused heads / backbone do not implement (--act-percentile): the three
+            # deform stages still run on the fused schedule (one C call per stage + unpack), the rest module by module
+            from . import pipeline
+            if self._fpath is None:
+                self._fpath = pipeline.FusedHotPath(self.deconv_layers)
+            x = self._fpath(x)
+            return [{head: getattr(self, head)(x) for head in self.heads}]
         from .functions.codenet_stage import forward_stage_blocks
         x = forward_stage_blocks(self.deconv_layers, x)      # == self.deconv_layers(x); fused blocks in the QAT step
         return [{head: getattr(self, head)(x) for head in self.heads}]
+
+    def _stages_fused_ok(self, feat):
+        from . import pipeline
+        cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat,
+                     getattr(a, "global_range", False)) for a in self.__dict__.get("_fused_acts", ()))
+        key = ("stages", tuple(feat.shape), cfg)
+        cache = self.__dict__.setdefault("_fused_ok_cache", {})
+        if key not in cache:
+            cache[key] = bool(pipeline.FusedHotPath.supported(self.deconv_layers, tuple(feat.shape)))
+        return cache[key]
 
 
 def fill_state_dict_(model, seed=317):

@@ -391,21 +391,30 @@ def set_global_range(model, flag=True):
     return n
 
 
-def act_fusable(act):
+ACT_PERCENTILE = 0x400      # CDN_X_ACT_PERCENTILE (include/codenet_dcn.h)
+
+
+def act_fusable(act, allow_percentile=False):
     """The fused schedules implement the reference's default QuantAct: plain batch min/max tracking,
-    asymmetric, quantising (quant_modules.py:163-225 with percentile=False).  --act-percentile, symmetric
-    activations and full_precision_flag stay on the module path."""
-    return (act.quant_mode == "asymmetric" and not act.percentile and not act.full_precision_flag
+    asymmetric, quantising (quant_modules.py:163-225 with percentile=False).  Symmetric activations and
+    full_precision_flag stay on the module path; --act-percentile too, except in the three deform stages
+    (allow_percentile: FusedHotPath, round 4 -- the stage entry point follows the order statistics with
+    cdn_kth_values between its kernels)."""
+    return (act.quant_mode == "asymmetric" and (allow_percentile or not act.percentile)
+            and not act.full_precision_flag
             and not (getattr(act, "global_range", False) and act.running_stat))
 
 
-def uniform_act_settings(acts, what):
-    """(bits, momentum, running) shared by the QuantActs of one fused C call, which takes them once."""
+def uniform_act_settings(acts, what, allow_percentile=False):
+    """(bits, momentum, running) shared by the QuantActs of one fused C call, which takes them once.
+    allow_percentile: the call's QuantActs may all be percentile ones (never a mixture)."""
     acts = [a for a in acts if a is not None]
     if not acts:
         return 8, 0.99, 0
+    if allow_percentile and len({bool(a.percentile) for a in acts}) != 1:
+        raise NotImplementedError("%s: the QuantActs of one fused call must all or none use percentile ranges" % what)
     for a in acts:
-        if not act_fusable(a):
+        if not act_fusable(a, allow_percentile):
             raise NotImplementedError("%s: QuantAct(percentile=%s, quant_mode=%s, full_precision_flag=%s) is not "
                                       "implemented by the fused schedule; use the module path"
                                       % (what, a.percentile, a.quant_mode, a.full_precision_flag))
@@ -507,7 +516,7 @@ class FusedHotPath:
                     return False
                 acts = (st[0].quant_act[1], st[0].quant_identity_deform, st[1][1])
                 try:
-                    uniform_act_settings(acts, "stage")
+                    uniform_act_settings(acts, "stage", allow_percentile=True)
                 except NotImplementedError:
                     return False
                 cout = st[0].quant_conv_channel_bn.conv.out_channels
@@ -609,7 +618,8 @@ class FusedHotPath:
                 p = self._stage_params(st)
                 ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
                 a = []
-                bits, mom, running = uniform_act_settings(p["acts"], "FusedHotPath stage")
+                bits, mom, running = uniform_act_settings(p["acts"], "FusedHotPath stage", allow_percentile=True)
+                pct = ACT_PERCENTILE if (p["acts"][0] is not None and p["acts"][0].percentile) else 0
                 for act in p["acts"]:
                     if act is None:
                         a += [None, None, None]
@@ -618,8 +628,8 @@ class FusedHotPath:
                               act._device_state(x.device).data_ptr()]
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
                 rc = lib.cdn_codenet_stage_fused_forward(
-                    cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0), sb["up"], cur_q, Nb, sb["C"], sb["Co"],
-                    sb["H"], sb["W"],
+                    cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0) | pct, sb["up"], cur_q, Nb, sb["C"],
+                    sb["Co"], sb["H"], sb["W"],
                     ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
                     ptr(p["w_dw"]), ptr(p["w_pw"]),
                     *([ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]),

@@ -364,6 +364,10 @@ int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int 
 #define CDN_X_GATHER_PER_ITEM 0x100
 #define CDN_X_GATHER_PERSISTENT 0x200
 #define CDN_X_GATHER_MASK 0x300
+/* | CDN_X_ACT_PERCENTILE (--act-percentile, quant_modules.py:203-210): while the ranges are tracked (running != 0) the three
+ * QuantActs of the stage follow the 0.1 % / 99.9 % order statistics of their inputs (cdn_kth_values) instead of the
+ * batch extremes; needs the three QuantActs. */
+#define CDN_X_ACT_PERCENTILE 0x400
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
