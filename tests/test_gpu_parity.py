@@ -770,9 +770,9 @@ def test_codenet_dw_backward_large_plane_uses_generic_entry_points():
 
 
 def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
-    """enable_fused() on a configuration / resolution the fused schedules do not implement (--act-percentile;
-    stored planes beyond the LDS-resident gather) must decide BEFORE any kernel runs and give the module path's
-    results (no silent difference, no exception at run time)."""
+    """enable_fused() on a configuration / resolution the fused schedules do not implement (--act-percentile in the
+    backbone / heads; stored planes beyond the LDS-resident gather) must decide BEFORE any kernel runs and give the
+    module path's results (no silent difference, no exception at run time)."""
     import copy
     import warnings
     from codenet_amd import harness
@@ -786,8 +786,13 @@ def test_harness_keeps_module_path_when_fused_schedule_does_not_apply():
         with torch.no_grad():
             a, b = m(x)[-1], m2(x)[-1]
     assert any("module-by-module" in str(w.message) for w in wlist)
+    # round 4: backbone and heads module by module, the three deform stages on the fused schedule with percentile
+    # ranges (CDN_X_ACT_PERCENTILE; pinned against the module path in tests/test_kth_values.py): the same network up
+    # to the code flips between two evaluation orders
+    assert m2._fheads is None and m2._fbackbone is None and m2._fpath is not None
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        std = a[k].std().item() + 1e-6
+        assert (a[k] - b[k]).abs().mean().item() < 0.12 * std, k
     # 1280 x 1280: stage 2's stored plane is 80 x 80 -> not LDS resident even in 8-channel chunks
     m3 = harness.create_model(quantize=False).cuda()
     m4 = copy.deepcopy(m3).enable_fused()
