@@ -979,8 +979,21 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
     dqz = reinterpret_cast<const float *>(dq)[3];
     dqr = __fdiv_rn(1.0f, dqs);
   }
+  // fast: whole tiles, 16-byte aligned rows (every stage shape of the QAT step) -- four unconditional 16-byte loads
+  // per thread and k tile, no bounds tests: the general form below compiles to a branch and a wait per piece
+  const bool fast = hw4 && c4 && (C % kPwBK) == 0 && (HW % kPwBN) == 0 && (Co % kPwBM) == 0;
   auto load = [&](int k0) {
     const int m = m0 + am;
+    if (fast) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 v = *reinterpret_cast<const float4 *>(Wp + (long)m * C + k0 + ak + 4 * h);
+        a[4 * h] = v.x; a[4 * h + 1] = v.y; a[4 * h + 2] = v.z; a[4 * h + 3] = v.w;
+        const float4 u = *reinterpret_cast<const float4 *>(Dn + (long)(k0 + bk + 16 * h) * HW + p0 + bn);
+        b[4 * h] = u.x; b[4 * h + 1] = u.y; b[4 * h + 2] = u.z; b[4 * h + 3] = u.w;
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = k0 + ak + 4 * h;
@@ -1003,14 +1016,17 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
         for (int q = 0; q < 4; ++q) b[4 * h + q] = (k < C && p + q < HW) ? Dn[(long)k * HW + p + q] : 0.0f;
       }
     }
-    if (dq) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) b[q] = cdn::fake_quant_r(b[q], dqs, dqz, dqr);
-    }
   };
   load(0);
   for (int k0 = 0; k0 < C; k0 += kPwBK) {
     __syncthreads();  // previous tile fully consumed
+    // (the fake-quantisation of the training path is applied HERE, when the tile is parked: inside load() it consumed
+    // the prefetched values at once, so the loads of the next tile were waited for in front of the MFMAs they were meant
+    // to hide behind)
+    if (dq) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = cdn::fake_quant_r(b[q], dqs, dqz, dqr);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) As[ak + q][am] = a[q];
 #pragma unroll
