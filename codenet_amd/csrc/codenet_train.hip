@@ -51,9 +51,21 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
     dqr = __fdiv_rn(1.0f, dqs);
   }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  // fast: whole tiles and 16-byte aligned rows (the stage shapes of the QAT step): eight unconditional 16-byte loads
+  const bool fast = hw4 && (HW % kWgBK) == 0 && (Co % kWgBM) == 0 && (C % kWgBN) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
   auto load = [&](int ch) {
     const int n = ch / chunks_per_img, p0 = (ch - n * chunks_per_img) * kWgBK;
     const float *ga = gy + (long)n * Co * HW, *gb = d + (long)n * C * HW;
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = lrow + 16 * i, p = p0 + lk;
+        ra[i] = *reinterpret_cast<const float4 *>(ga + (long)(m0 + r) * HW + p);
+        rb[i] = *reinterpret_cast<const float4 *>(gb + (long)(c0 + r) * HW + p);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = lrow + 16 * i, p = p0 + lk;
@@ -71,10 +83,6 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
         ra[i] = make_float4(a[0], a[1], a[2], a[3]);
         rb[i] = make_float4(b[0], b[1], b[2], b[3]);
       }
-      if (dq) {      // d holds pre-quantisation values: fake-quantised with its QuantAct state while loading
-        rb[i].x = cdn::fake_quant_r(rb[i].x, dqs, dqz, dqr); rb[i].y = cdn::fake_quant_r(rb[i].y, dqs, dqz, dqr);
-        rb[i].z = cdn::fake_quant_r(rb[i].z, dqs, dqz, dqr); rb[i].w = cdn::fake_quant_r(rb[i].w, dqs, dqz, dqr);
-      }
     }
   };
   if (ch_lo < ch_hi) load(ch_lo);
@@ -82,6 +90,11 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
     __syncthreads();                       // the previous tile has been consumed
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (dq) {      // d holds pre-quantisation values: fake-quantised with its QuantAct state when the tile is parked
+                     // (inside load() it consumed the prefetch in front of the MFMAs it was meant to hide behind)
+        rb[i].x = cdn::fake_quant_r(rb[i].x, dqs, dqz, dqr); rb[i].y = cdn::fake_quant_r(rb[i].y, dqs, dqz, dqr);
+        rb[i].z = cdn::fake_quant_r(rb[i].z, dqs, dqz, dqr); rb[i].w = cdn::fake_quant_r(rb[i].w, dqs, dqz, dqr);
+      }
       *reinterpret_cast<float4 *>(&As[lrow + 16 * i][lk]) = ra[i];
       *reinterpret_cast<float4 *>(&Bs[lrow + 16 * i][lk]) = rb[i];
       if (do_bias) bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
