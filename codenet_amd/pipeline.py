@@ -1028,12 +1028,17 @@ class FusedHeads:
             N_.check(rc, "cdn_codenet_pointwise_nhwc_forward")
 
         outs = {}
+        if use_streams:
+            # fork EVERY side stream before head 0 puts its kernels on the main stream: forked inside the loop, a side
+            # stream waited for everything the main stream held by then -- head 0's whole chain -- and the heads ran as
+            # "head 0, then the others" (seen in the kernel trace of round 4: 121 us of head 0 alone on the GPU)
+            for sd in B["side"][:len(self.heads) - 1]:
+                sd.wait_stream(main)
         with torch.no_grad():
             for hi, (name, mod) in enumerate(self.heads.items()):
                 y1buf = B["y1"]
                 if use_streams and hi > 0:
                     sd, wsb, y1buf = B["side"][hi - 1], B["ws_side"][hi - 1], B["y1_side"][hi - 1]
-                    sd.wait_stream(main)
                     forked.append(sd)
                     stream = sd.cuda_stream
                     ws_ptr = (wsb.data_ptr() + 255) // 256 * 256
@@ -1161,12 +1166,13 @@ class FusedHeads:
                  "cdn_quantact_frozen_params")
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         forked = []
+        for sd in B["side"][:max(0, len(self.heads) - 1)]:      # (fork before head 0's kernels are on the main stream)
+            sd.wait_stream(main)
         with torch.no_grad():
             for hi, (name, mod) in enumerate(self.heads.items()):
                 st = main
                 if B["side"] and hi > 0:
                     st = B["side"][hi - 1]
-                    st.wait_stream(main)
                     forked.append(st)
                 l1, l2, l3 = self._params(mod)
                 q1 = l1["act"]._device_state(dev).data_ptr()
