@@ -461,7 +461,10 @@ def capture_process(model, images, reg_offset=True, cat_spec_wh=False, K=100, fl
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    # capture ON the warm-up stream: the static buffers are keyed by stream, so a capture stream of its own allocated
+    # them again INSIDE the capture -- and the zero fill of the 84-MB decode workspace became a graph node, replayed
+    # with every batch (12 us + a boundary in the kernel trace of round 4)
+    with torch.cuda.graph(graph, stream=side):
         result = process(model, images, **kw)
 
     def replay():
