@@ -64,6 +64,9 @@ _SIGNATURES = {
     "cdn_codenet_pwdw_s2_forward": (
         _i, [_vp, _vp] + [_i64] * 5 + [_vp] * 8 + [_i64, _vp, _vp, _i64] + [_vp] * 3 + [_i, _d, _i, _vp,
                                                                                     ctypes.c_size_t, _vp, _vp]),
+    "cdn_codenet_pwdw_s2_apply": (
+        _i, [_vp, _vp] + [_i64] * 5 + [_vp] * 8 + [_i64, _vp, _vp, _i64] + [_vp] * 3 + [_i, _d, _i, _vp,
+                                                                                    ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_dw_up2_supported": (_i, [_i64] * 4),
     "cdn_codenet_dw_up2_range_partials": (_i64, [_i64] * 4),
     "cdn_codenet_dw_up2_forward": (_i, [_vp] * 4 + [_i64] * 4 + [_vp, _vp]),

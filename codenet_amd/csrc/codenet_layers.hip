@@ -1780,8 +1780,8 @@ extern "C" int cdn_codenet_pwdw_s2_supported(int64_t N, int64_t Cin, int64_t C, 
   return 0;
 }
 
-extern "C" int cdn_codenet_pwdw_s2_forward(
-    const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
+static int pwdw_s2_impl(
+    bool range_pass, const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
     const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum,
     const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
     int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
@@ -1795,9 +1795,11 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
                   (reinterpret_cast<uintptr_t>(w_pw_codes) & 15) == 0, CDN_ERR_ARG, "bad row stride / alignment");
   // 1. the 1x1 conv as a RANGE-ONLY pass (out = NULL): batch extremes of relu(conv) -> the mid QuantAct
   const int64_t M = N * H * W;
-  int rc = cdn_codenet_pointwise_mixed_forward(x, x_qstate, nullptr, M, Cin, C, ld_x, 0, w_pw, w_pw_codes, w_pw_scale,
-                                               w_pw_colsum, bias_pw, nullptr, nullptr, 1, nullptr, m_min, m_max, m_state,
-                                               bits, momentum, running, workspace, workspace_bytes, nullptr, stream);
+  int rc = 0;
+  if (range_pass)
+    rc = cdn_codenet_pointwise_mixed_forward(x, x_qstate, nullptr, M, Cin, C, ld_x, 0, w_pw, w_pw_codes, w_pw_scale,
+                                             w_pw_colsum, bias_pw, nullptr, nullptr, 1, nullptr, m_min, m_max, m_state,
+                                             bits, momentum, running, workspace, workspace_bytes, nullptr, stream);
   if (rc) return rc;
   // 2. conv recomputed into the ring rows of the stride-2 depthwise
   const int Hs = (int)H, Ws = (int)W, Ho = (Hs - 1) / 2 + 1, Wo = (Ws - 1) / 2 + 1;
@@ -1853,4 +1855,28 @@ extern "C" int cdn_codenet_pwdw_s2_forward(
 #undef CDN_GOPD
 #undef CDN_GOPD1
   return cdn::check_launch("codenet pw -> dw (stride 2, conv recomputed)");
+}
+
+extern "C" int cdn_codenet_pwdw_s2_forward(
+    const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
+    const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum,
+    const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
+    int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream) {
+  return pwdw_s2_impl(true, x, x_qstate, N, Cin, H, W, ld_x, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw, m_min, m_max,
+                      m_state, C, w_dw, bias_dw, ld_out, r_min, r_max, r_state, bits, momentum, running, workspace,
+                      workspace_bytes, out, stream);
+}
+
+// The second half alone: the caller has run the range-only pass itself (cdn_codenet_pointwise_mixed_forward with
+// out = NULL on the same arguments), e.g. to start other work between the two.
+extern "C" int cdn_codenet_pwdw_s2_apply(
+    const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
+    const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum,
+    const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
+    int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream) {
+  return pwdw_s2_impl(false, x, x_qstate, N, Cin, H, W, ld_x, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw, m_min,
+                      m_max, m_state, C, w_dw, bias_dw, ld_out, r_min, r_max, r_state, bits, momentum, running, workspace,
+                      workspace_bytes, out, stream);
 }

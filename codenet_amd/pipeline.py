@@ -1589,17 +1589,20 @@ class FusedBackbone:
         N_.check(rc, "cdn_codenet_pointwise_mixed_forward")
 
     recompute_pw1 = True      # A/B switch (tools/e2e_native_bench.py --no-recompute)
+    range_first = True        # A/B switch: the recomputed conv's range pass before branch 1 is forked
 
     @staticmethod
     def _lib():
         from . import _native as N_
         return N_.lib()
 
-    def _pwdw_raw(self, x_ptr, x_q, N, cin, H, W, ld_x, Wt, act_mid, C, w, b, act_out, out, ld_out):
-        """1x1 conv (range-only pass -> act_mid) recomputed inside the stride-2 depthwise (-> out, range of act_out)."""
+    def _pwdw_raw(self, x_ptr, x_q, N, cin, H, W, ld_x, Wt, act_mid, C, w, b, act_out, out, ld_out, apply_only=False):
+        """1x1 conv (range-only pass -> act_mid) recomputed inside the stride-2 depthwise (-> out, range of act_out).
+        apply_only: the range-only pass has been issued by the caller (`_pw_raw` with out_ptr None)."""
         from . import _native as N_
         am, ao = self._act_args(act_mid, self._dev), self._act_args(act_out, out.device)
-        rc = N_.lib().cdn_codenet_pwdw_s2_forward(
+        fn = N_.lib().cdn_codenet_pwdw_s2_apply if apply_only else N_.lib().cdn_codenet_pwdw_s2_forward
+        rc = fn(
             x_ptr, x_q, N, cin, H, W, ld_x, Wt["w"].data_ptr(), Wt["codes"].data_ptr(), Wt["scale"].data_ptr(),
             Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), am[0], am[1], am[2], C, w.data_ptr(), b.data_ptr(), ld_out,
             ao[0], ao[1], ao[2], ao[3], ao[4], ao[5], self._ws_ptr, self._ws_bytes, out.data_ptr(), self._stream)
@@ -1640,6 +1643,13 @@ class FusedBackbone:
                     # (reference order: first) runs on a side stream with its own arrival counters, and branch
                     # 2's last conv -- the second call of the shared QuantAct -- waits for it
                     t4 = L["t4"]
+                    recompute = (self.recompute_pw1 and not mixed_in and a_q is not None and u["a1"] is not None
+                                 and self._lib().cdn_codenet_pwdw_s2_supported(Nb, cin, h, L["Hin"], L["Win"]))
+                    if recompute and self.two_streams and self.range_first:
+                        # the range-only pass of the recomputed conv BEFORE the fork: beside branch 1 it took 106 us of
+                        # the critical path (both stream the stem's output), alone 55; branch 1 (memory-bound) then runs
+                        # beside the VALU-bound recomputing kernel, which used to have the GPU to itself
+                        self._pw_raw(x.data_ptr(), a_q, None, Mi, x_ld, P["c1"], True, u["a1"], None, None, None, 0)
                     ev = self._fork_side(dev) if self.two_streams else None
                     self._dw_raw(x.data_ptr(), a_q, a_gen, Nb, cin, L["Hin"], L["Win"], 2, x_ld, P["w4"], P["b4"],
                                  u["a4"], t4, t4.shape[1])
@@ -1647,12 +1657,12 @@ class FusedBackbone:
                                  sp(P["genA"]), P["omapA"].data_ptr(), Y.data_ptr(), C)
                     if ev is not None:
                         ev = self._leave_side(dev)
-                    if (self.recompute_pw1 and not mixed_in and a_q is not None and u["a1"] is not None
-                            and self._lib().cdn_codenet_pwdw_s2_supported(Nb, cin, h, L["Hin"], L["Win"])):
+                    if recompute:
                         # layer 1: the 1x1 conv (K = 24) recomputed inside the stride-2 depthwise -- its 58-channel
                         # fp32 output at input resolution (243 MB at batch 64, 512 x 512) is never stored
                         self._pwdw_raw(x.data_ptr(), a_q, Nb, cin, L["Hin"], L["Win"], x_ld, P["c1"], u["a1"], h,
-                                       P["w2"], P["b2"], u["a2"], L["t2"], ldh)
+                                       P["w2"], P["b2"], u["a2"], L["t2"], ldh,
+                                       apply_only=self.two_streams and self.range_first)
                     else:
                         self._pw_raw(x.data_ptr(), a_q, a_gen, Mi, x_ld, P["c1"], True, u["a1"], None, None,
                                      self._t1s2(L).data_ptr(), ldh)

@@ -534,6 +534,15 @@ int cdn_codenet_pwdw_s2_forward(
     const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
     int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
     size_t workspace_bytes, float *out, void *stream);
+/* The second half of cdn_codenet_pwdw_s2_forward alone (same arguments): the caller has already run the range-only pass
+ * of the 1x1 conv itself -- cdn_codenet_pointwise_mixed_forward(x, x_qstate, NULL, N*H*W, Cin, C, ld_x, 0, w_pw, ...,
+ * relu = 1, NULL, m_min, m_max, m_state, ..., out = NULL) -- e.g. to fork other work between the two. */
+int cdn_codenet_pwdw_s2_apply(
+    const float *x, const void *x_qstate, int64_t N, int64_t Cin, int64_t H, int64_t W, int64_t ld_x,
+    const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale, const int *w_pw_colsum,
+    const float *bias_pw, float *m_min, float *m_max, void *m_state, int64_t C, const float *w_dw, const float *bias_dw,
+    int64_t ld_out, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running, void *workspace,
+    size_t workspace_bytes, float *out, void *stream);
 /* Mixed-generation variants (ShuffleNetV2 layers WITHOUT a physical channel shuffle):
  * the activation tensor of a layer keeps every channel in a fixed physical slot, pre-quantisation values,
  * and channel c was produced under generation a_gen[c] of the layer's running block-output QuantAct

@@ -19,12 +19,17 @@ def main():
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one HIP graph")
+    ap.add_argument("--no-range-first", action="store_true", help="A/B: the recomputed conv's range pass beside branch 1 "
+                    "(before round 4's reordering) instead of in front of the fork")
     ap.add_argument("--no-recompute", action="store_true", help="A/B: layer 1's first 1x1 conv stored (round 3) instead "
                     "of recomputed inside its depthwise")
     a = ap.parse_args()
     if a.no_recompute:
         from codenet_amd import pipeline
         pipeline.FusedBackbone.recompute_pw1 = False
+    if a.no_range_first:
+        from codenet_amd import pipeline
+        pipeline.FusedBackbone.range_first = False
     dev = torch.device("cuda", 0)
     model = harness.create_model(quantize=not a.fp32).to(dev).enable_fused()
     x = torch.randn(a.batch, 3, a.res, a.res, device=dev)
