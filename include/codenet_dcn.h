@@ -354,6 +354,10 @@ size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_
  * channel chunks up to ~4800 stored pixels = inputs up to ~1100 px), 0 otherwise: callers then keep the
  * module path (cdn_codenet_{scale,dw,pointwise}_forward, any plane size). */
 int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
+/* What cdn_codenet_stage_fused_forward itself accepts: the above, or a stored plane too large for LDS, which it gathers
+ * straight from global memory / L2 (round 4: inputs above ~1100 px; a size fallback with the module path's per-channel
+ * expressions).  The byte-code entry points (cdn_codenet_stage_frozen*) keep the LDS-resident limit above. */
+int cdn_codenet_stage_fused_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
 /* Schedule of the gather for an NCHW input at output resolution (stage 0) -- a PER-CALL choice OR-ed into the layout
  * argument of the stage entry points (`x_nhwc` of cdn_codenet_stage_fused_forward, `x_kind` of
  * cdn_codenet_stage_frozen[_chained]_forward); the library keeps no setting of its own (round 4: this replaces the
