@@ -139,10 +139,11 @@ class PoseShuffleNetV2(nn.Module):
         return hit
 
     def _fused_ok(self, x):
-        """The fused schedules implement the reference's default QuantAct settings and stored planes that fit
-        the LDS-resident gather (inputs up to ~1100 px; above 544 px in thinner channel chunks); anything else
-        (--act-percentile, symmetric activations, larger resolutions) keeps the module-by-module path -- decided BEFORE any kernel runs, so no QuantAct
-        state is half-updated.  Cached per (input shape, QuantAct configuration)."""
+        """The fused schedules implement the reference's default QuantAct settings (stored planes beyond the
+        LDS-resident gather -- inputs above ~1100 px -- are gathered from global memory); anything else
+        (--act-percentile in backbone / heads, symmetric activations) keeps the module-by-module path -- decided
+        BEFORE any kernel runs, so no QuantAct state is half-updated.  Cached per (input shape, QuantAct
+        configuration)."""
         from . import pipeline
         cfg = tuple((a.percentile, a.quant_mode, a.full_precision_flag, a.activation_bit, a.running_stat,
                      getattr(a, "global_range", False)) for a in self.__dict__["_fused_acts"])
