@@ -1028,6 +1028,15 @@ class FusedHeads:
             N_.check(rc, "cdn_codenet_pointwise_nhwc_forward")
 
         outs = {}
+        # every head's derived parameters (folded / fake-quantised weights, int8 codes: torch ops on the MAIN stream when
+        # they are not cached yet) BEFORE the side streams fork: derived inside the loop they raced with the side-stream
+        # kernels that read them -- the first call of a fresh FusedHeads returned garbage for a head about once in a
+        # thousand runs (tools/stress_heads.py; both failures seen were first calls)
+        params = {name: self._params(mod) for name, mod in self.heads.items()}
+        for layers_ in params.values():          # (and the QuantActs' device states: created by a fill on the main stream)
+            for l_ in layers_:
+                if l_["act"] is not None:
+                    l_["act"]._device_state(r.device)
         if use_streams:
             # fork EVERY side stream before head 0 puts its kernels on the main stream: forked inside the loop, a side
             # stream waited for everything the main stream held by then -- head 0's whole chain -- and the heads ran as
@@ -1045,7 +1054,7 @@ class FusedHeads:
                     ws_bytes = (wsb.numel() * 4 - (ws_ptr - wsb.data_ptr())) // 256 * 256
                 else:
                     stream, ws_ptr, ws_bytes = main_launch
-                layers = self._params(mod)
+                layers = params[name]
                 small = (self.small_tail and len(layers) == 3 and layers[0]["act"] is not None
                          and layers[1]["act"] is not None and layers[1]["ep"] is None and layers[1]["relu"]
                          and layers[2]["i8"] is not None and C == 64
@@ -1166,6 +1175,11 @@ class FusedHeads:
                  "cdn_quantact_frozen_params")
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         forked = []
+        params = {name: self._params(mod) for name, mod in self.heads.items()}   # (derived on the main stream: before the fork)
+        for layers_ in params.values():
+            for l_ in layers_:
+                if l_["act"] is not None:
+                    l_["act"]._device_state(dev)
         for sd in B["side"][:max(0, len(self.heads) - 1)]:      # (fork before head 0's kernels are on the main stream)
             sd.wait_stream(main)
         with torch.no_grad():
@@ -1174,7 +1188,7 @@ class FusedHeads:
                 if B["side"] and hi > 0:
                     st = B["side"][hi - 1]
                     forked.append(st)
-                l1, l2, l3 = self._params(mod)
+                l1, l2, l3 = params[name]
                 q1 = l1["act"]._device_state(dev).data_ptr()
                 q2 = l2["act"]._device_state(dev).data_ptr()
                 c1, s1, k1 = l1["i8"]
@@ -1394,6 +1408,10 @@ class FusedBackbone:
         dev = x.device
         self._prepare(dev)
         units = [self._unit(n) for n in nodes]
+        for u_ in units:          # the QuantActs' device states exist before branch 1 forks to the side stream (a state is
+            for k_ in ("a1", "a2", "a4", "sh"):     # created by a fill on the CURRENT stream: see FusedHeads.forward)
+                if u_.get(k_) is not None:
+                    u_[k_]._device_state(dev)
         cin = units[0]["cin"] if nodes[0].stride == 2 else x_ld
         L = self._layer_bufs(nodes, units[0]["h"], cin, Nb, H, W, dev)
         h, ldh, C = L["h"], L["ldh"], L["C"]
@@ -1465,6 +1483,10 @@ class FusedBackbone:
         """Host bookkeeping of one layer: slot assignment, generations, permuted weights (cached until a
         weight changes).  in_logical: logical index of every physical input channel (None: identity)."""
         units = [self._unit(n) for n in nodes]
+        for u_ in units:          # the QuantActs' device states exist before branch 1 forks to the side stream (a state is
+            for k_ in ("a1", "a2", "a4", "sh"):     # created by a fill on the CURRENT stream: see FusedHeads.forward)
+                if u_.get(k_) is not None:
+                    u_[k_]._device_state(dev)
         convs = []
         for u in units:
             convs += [u[k] for k in ("c1", "c2", "c3", "c4", "c5") if k in u]
@@ -1626,6 +1648,10 @@ class FusedBackbone:
         plan = self._mixed_plan(nodes, x_in["logical"] if mixed_in else None, dev,
                                 x_in.get("gen_list") if mixed_in else None)
         units = [self._unit(n) for n in nodes]
+        for u_ in units:          # the QuantActs' device states exist before branch 1 forks to the side stream (a state is
+            for k_ in ("a1", "a2", "a4", "sh"):     # created by a fill on the CURRENT stream: see FusedHeads.forward)
+                if u_.get(k_) is not None:
+                    u_[k_]._device_state(dev)
         h, cin, C = plan["h"], plan["cin"], plan["C"]
         L = self._layer_bufs(nodes, h, cin, Nb, H, W, dev)
         ldh = L["ldh"]
