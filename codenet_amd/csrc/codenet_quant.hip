@@ -286,7 +286,7 @@ inline int stream_grid(long n) {
 // order statistics as the activation range; a full sort per call in the reference).  Radix select on the
 // order-preserving 32-bit keys (cdn::f2ord): three passes over the tensor (11 + 11 + 10 bits), each a histogram of the
 // elements that still match a rank's prefix, each followed by a one-workgroup scan that picks the digit.  Exact: the
-// result is an element of x (NaNs order above +inf, as in torch; -0.0 orders below +0.0, numerically the same value).
+// result is an element of x (NaNs order last, as in torch; -0.0 orders below +0.0, numerically the same value).
 // ------------------------------------------------------------------------------------------
 constexpr int kKthBins = 2048, kKthThreads = 512;
 struct KthState {            // device-side, in the workspace behind the two histograms
@@ -304,7 +304,7 @@ kth_hist_kernel(const float *__restrict__ x, long n, int shift, int width, const
   const unsigned wm = (1u << width) - 1u;
   __syncthreads();
   auto tally = [&](float v) __attribute__((always_inline)) {
-    const unsigned k = cdn::f2ord(v);
+    const unsigned k = v != v ? 0xFFFFFFFFu : cdn::f2ord(v);      // every NaN orders last, whatever its sign bit (torch)
     if ((k & m0) == p0) atomicAdd(&lh[0][(k >> shift) & wm], 1u);
     else if (!same && (k & m1) == p1) atomicAdd(&lh[1][(k >> shift) & wm], 1u);
   };

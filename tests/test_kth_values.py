@@ -45,6 +45,13 @@ def test_kth_values_equal_torch_kthvalue(n, kind):
             assert lo.item() == ref_lo.item() and hi.item() == ref_hi.item(), (n, kind, k_lo, k_hi)
     with pytest.raises(RuntimeError):
         ops.kth_values(xd, 0, 1)
+    if kind == "mixed":                    # NaNs of either sign order last, as in torch.kthvalue
+        xn = x.clone()
+        xn[3::5003] = float("nan")
+        xn[4::7001] = -float("nan")
+        n_nan = int(torch.isnan(xn).sum())
+        lo, hi = ops.kth_values(xn.cuda(), n - n_nan, n)
+        assert lo.item() == torch.kthvalue(xn, n - n_nan).values.item() and torch.isnan(hi).item()
 
 
 @pytest.mark.gpu
