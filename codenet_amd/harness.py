@@ -175,7 +175,7 @@ class PoseShuffleNetV2(nn.Module):
                 self._fbackbone = (pipeline.FusedBackbone(self)
                                    if self._fused_backbone and pipeline.FusedBackbone.supported(self) else None)
             stages = self._fpath
-            if getattr(self, "_frozen_codes", False) and self._stage_acts_frozen():
+            if getattr(self, "_frozen_codes", False) and self._stage_acts_frozen() and self._frozen_planes_fit(x):
                 if self._ffrozen is None:
                     self._ffrozen = pipeline.FrozenHotPath(self.deconv_layers, chain_scale=True)
                 if self._fzbackbone is None and self._fbackbone is not None and self._frozen_backbone:
@@ -213,6 +213,20 @@ class PoseShuffleNetV2(nn.Module):
         from .functions.codenet_stage import forward_stage_blocks
         x = forward_stage_blocks(self.deconv_layers, x)      # == self.deconv_layers(x); fused blocks in the QAT step
         return [{head: getattr(self, head)(x) for head in self.heads}]
+
+    def _frozen_planes_fit(self, x):
+        """The byte-code schedules need every stage's stored plane in LDS; larger inputs keep the fp32 fused schedule
+        (frozen ranges included).  Cached per input shape."""
+        from . import pipeline
+        key = ("fzfit", tuple(x.shape))
+        cache = self.__dict__.setdefault("_fused_ok_cache", {})
+        if key not in cache:
+            Nb, _, R, R2 = x.shape
+            stem = self.layer0[0].conv if hasattr(self.layer0[0], "conv") else self.layer0[0]
+            down = stem.stride[0] * (2 if any(isinstance(m, nn.MaxPool2d) for m in self.layer0.modules()) else 1) * 8
+            cache[key] = bool(pipeline.FrozenHotPath.planes_fit(self.deconv_layers,
+                                                                (Nb, self.channels[4], R // down, R2 // down)))
+        return cache[key]
 
     def _stages_fused_ok(self, feat):
         from . import pipeline

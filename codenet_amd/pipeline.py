@@ -695,6 +695,22 @@ class FrozenHotPath:
         self._fp32 = FusedHotPath(deconv_layers)        # fp32 frozen schedule for stages without byte codes
         self._bufs = None
 
+    @staticmethod
+    def planes_fit(deconv_layers, input_shape):
+        """True when every stage's stored plane fits the LDS-resident gather -- the byte-code entry points' own limit
+        (cdn_codenet_stage_supported).  Above it (inputs beyond ~1100 px) the fp32 fused schedule, which honours frozen
+        ranges too and gathers large planes from global memory, is the one to use: a byte-code stage cannot hand its
+        codes to an fp32-schedule stage."""
+        from . import _native as N_
+        mods = list(deconv_layers)
+        Nb, C, H, W = input_shape
+        for i in range(0, len(mods), 3):
+            up = 0 if i == 0 else 1
+            if not N_.lib().cdn_codenet_stage_supported(Nb, C, H, W, 1, up):
+                return False
+            C, H, W = mods[i].quant_conv_channel_bn.conv.out_channels, 2 * H, 2 * W
+        return True
+
     def _acts(self, st):
         return (st[0].quant_act[1], st[0].quant_identity_deform, st[1][1])
 

@@ -830,6 +830,30 @@ def test_fused_schedule_on_large_inputs(res, quantize):
             assert diff.max().item() < 1e-3 * max(1.0, a[k].abs().max().item()), (k, diff.max().item())
 
 
+def test_serving_mode_above_the_byte_code_plane_limit_keeps_the_fp32_fused_schedule():
+    """enable_fused(frozen_codes=True) at 1280 x 1280: stage 2's stored plane (80 x 80) is beyond the LDS-resident gather
+    the byte-code entry points need, and a byte-code stage cannot hand its codes to an fp32-schedule stage -- the model
+    must take the fp32 fused schedule with the frozen ranges (bit-equal to frozen_codes=False), not fail at run time."""
+    from codenet_amd import harness, pipeline
+    m = harness.create_model(quantize=True).cuda().enable_fused()
+    x = torch.randn(1, 3, 1280, 1280, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        for _ in range(2):
+            m(x)
+        pipeline.set_running_stat(m, False)
+        ref = {k: v.clone() for k, v in m(x)[-1].items()}
+        m.enable_fused(frozen_codes=True)
+        out = m(x)[-1]
+    assert m._ffrozen is None and not m.frozen_overflowed()
+    for k in ref:
+        assert torch.equal(ref[k], out[k]), k
+    # and at the benchmark resolution the byte-code route is taken
+    x2 = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        m(x2)
+    assert m._ffrozen is not None
+
+
 @pytest.mark.parametrize("C,Hl,n", [(128, 40, 2), (64, 64, 1), (24, 48, 2), (16, 80, 1), (12, 96, 2)])
 def test_fused_stage_large_plane_matches_oracle(C, Hl, n):
     """One W4A8 stage with an up-sampled channels-last input whose STORED plane is 40 x 40 / 48 x 48 / 64 x 64 (output 80^2
