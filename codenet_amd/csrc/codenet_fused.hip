@@ -2833,6 +2833,13 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     else
 #endif
     if (pw_bn == 128) CDN_PWI(64, 128, 2);
+    // Co <= 64 (layer 1's units, the heads' first conv, stage 2): 64 x 64 tiles on the large-M launches (round 4).  Alone
+    // on the GPU the 128 x 64 tiles are as fast (33.1 vs 31.6 us at 262 144 x 58 -> 58, 38.4 vs 39.9 at K = 128), inside
+    // the network -- beside the other branch / the other heads -- the smaller tiles are worth 38 us per batch (whole
+    // network 2.594-2.599 -> 2.552-2.561 ms, three interleaved pairs on one box; the deform step itself: unchanged)
+#if !defined(CDN_PWI_NO_64X64)
+    else if (M >= 65536) CDN_PWI(64, 64, 2);
+#endif
     else CDN_PWI(128, 64, 4);
 #undef CDN_PWI
     // (wide codes, state[6] != 0, are handled by the f32 branch inside pwi8_kernel)

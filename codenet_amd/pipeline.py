@@ -1048,7 +1048,8 @@ class FusedHeads:
         # they are not cached yet) BEFORE the side streams fork: derived inside the loop they raced with the side-stream
         # kernels that read them -- the first call of a fresh FusedHeads returned garbage for a head about once in a
         # thousand runs (tools/stress_heads.py; both failures seen were first calls)
-        params = {name: self._params(mod) for name, mod in self.heads.items()}
+        with torch.no_grad():                    # (derived tensors are cached per weight version only without autograd)
+            params = {name: self._params(mod) for name, mod in self.heads.items()}
         for layers_ in params.values():          # (and the QuantActs' device states: created by a fill on the main stream)
             for l_ in layers_:
                 if l_["act"] is not None:
@@ -1191,7 +1192,8 @@ class FusedHeads:
                  "cdn_quantact_frozen_params")
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         forked = []
-        params = {name: self._params(mod) for name, mod in self.heads.items()}   # (derived on the main stream: before the fork)
+        with torch.no_grad():
+            params = {name: self._params(mod) for name, mod in self.heads.items()}   # (derived on the main stream: before the fork)
         for layers_ in params.values():
             for l_ in layers_:
                 if l_["act"] is not None:
