@@ -2832,6 +2832,13 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     if (pw_bn == 128 && cdn::ceil_div(M, 64) * cdn::ceil_div(Co, 128) <= cdn::kCUs && Kt >= 1024) CDN_PWI(32, 128, 1);
     else
 #endif
+    // ... and 32-row tiles for the K < 256 launches of layers 2-3 (unit exits, the stride-2 units' branch convs; round 4):
+    // whole network 2.564 / 2.603 -> 2.544 / 2.533 ms on one box.  NOT for K = 256 (stage 1 of the deform path: 0.2442 ->
+    // 0.2500 ms per step with them) and not at K >= 512, where nothing moved.
+#if !defined(CDN_PWI_NO_32ROWS)
+    if (pw_bn == 128 && Kt < 256) CDN_PWI(32, 128, 1);
+    else
+#endif
     if (pw_bn == 128) CDN_PWI(64, 128, 2);
     // Co <= 64 (layer 1's units, the heads' first conv, stage 2): 64 x 64 tiles on the large-M launches (round 4).  Alone
     // on the GPU the 128 x 64 tiles are as fast (33.1 vs 31.6 us at 262 144 x 58 -> 58, 38.4 vs 39.9 at K = 128), inside
