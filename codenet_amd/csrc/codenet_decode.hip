@@ -512,7 +512,10 @@ decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__re
 // 8 rows, balanced.
 static int band_rows(int64_t H, int64_t W) {
   const size_t wp_bytes = (size_t)(((W + 3) & ~3) + 8) * 4;
-  constexpr int kb_kib = 36;
+#ifndef CDN_DECODE_BAND_KIB
+#define CDN_DECODE_BAND_KIB 36
+#endif
+  constexpr int kb_kib = CDN_DECODE_BAND_KIB;
   int RB = (int)std::max<long>(8, (long)((size_t)kb_kib * 1024 / wp_bytes) - 2);
   RB = (int)std::min<long>(RB, H);
   const int nbands = (int)cdn::ceil_div(H, RB);
