@@ -674,7 +674,14 @@ static int pointwise_q8_impl(const signed char *a, const void *a_state, int64_t 
   int bm = 128, bn = Co <= 64 ? 64 : (Co <= 128 ? 128 : 256);
   auto wgs = [&](int bm_, int bn_) { return cdn::ceil_div(M, bm_) * cdn::ceil_div(Co, bn_); };
   if (bn == 256) bm = 64;                          // (a 128 x 256 tile would need 128 accumulator registers per lane)
-  while (wgs(bm, bn) < 4L * cdn::kCUs) {
+  // (round 4: "several" = 64 per CU, i.e. in practice the smallest tile.  Chosen with the launch alone on the GPU the
+  // threshold was 4; inside the serving network -- 42 of these launches in chains of 9-23 us kernels -- smaller tiles
+  // are worth 40 us per batch: 1.465-1.478 -> 1.427-1.437 ms at 64, 1.437-1.445 at 16, no change at 8; the deform
+  // step's frozen legs: unchanged)
+#ifndef CDN_Q8_WGS
+#define CDN_Q8_WGS 64
+#endif
+  while (wgs(bm, bn) < (long)CDN_Q8_WGS * cdn::kCUs) {
     if (bm == 128) bm = 64;
     else if (bn > 64) bn >>= 1;
     else break;
