@@ -1703,9 +1703,13 @@ static int launch_head_small(int mode, const float *y1, const void *y1_qstate, i
                                                             out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes,
                                                             Cpad, nxs2, 16, nstrips2, rps2, 0, overflow);
     }
-    head_small_kernel<1, 4, Y8><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias,
-                                                        out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
-                                                        nxs, XS, nstrips, rps, 1);
+    // the wide-code fallback behind it -- never on byte-code input: frozen ranges have no wide batches (state[6] is 0 by
+    // construction, a saturating code raises the overflow flag instead), and the early-exit launch still cost 14 us per
+    // head in the serving network's kernel trace
+    if (!Y8)
+      head_small_kernel<1, 4, Y8><<<grid, 256, lds, st>>>(y1, q1, w_dw, b_dw, q2, w_codes, w_scale, nullptr, bias,
+                                                          out_nchw, nullptr, none, (int)Hs, (int)Ws, (int)classes, Cpad,
+                                                          nxs, XS, nstrips, rps, 1);
     return cdn::check_launch("codenet head tail (matrix cores)");
   };
   return y8 ? tail(std::true_type{}) : tail(std::false_type{});
