@@ -217,7 +217,7 @@ def live_pmc_traffic(args):
                         per[k] = per.get(k, 0.0) + v * mul / len(spans)
         fam = _family_bytes(per)
         return fam if fam.get("dw") and fam.get("pointwise") else None
-    except Exception:      # noqa: BLE001 -- a measurement aid must never take the benchmark down
+    except (Exception, SystemExit):      # noqa: BLE001 -- a measurement aid must never take the benchmark down
         return None
 
 

@@ -308,12 +308,17 @@ decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__re
   __shared__ unsigned long long list[kCap];
   __shared__ unsigned scan[kSelThreads];
   __shared__ int s_digit;
-  __shared__ unsigned s_above, s_n;
+  __shared__ unsigned s_above, s_n, s_ncand;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int HW = H * W;
   const long total = (long)cat * HW;
   unsigned *gh = hist + (long)b * kHistStride;
-  const unsigned ncand = gh[kBins];              // candidates the keys kernel counted (above cap: not all were stored)
+  // candidates the keys kernel counted (above cap: not all were stored).  ONE thread reads the counter and the
+  // workgroup takes it from LDS behind a barrier: thread 0 resets the word below, and a wave that started late
+  // would otherwise read 0 and disagree with the others about the workgroup-uniform `slow`.
+  if (tid == 0) s_ncand = gh[kBins];
+  __syncthreads();
+  const unsigned ncand = s_ncand;
   const unsigned long long *lp = cand + (size_t)b * cap;
   const float *sp = src + (long)b * total;
   const unsigned zkey = cdn::f2ord(0.0f);

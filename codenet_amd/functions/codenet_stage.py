@@ -403,7 +403,8 @@ def forward_stage_blocks(seq, x):
         nxt = mods[i + 3] if i + 3 < len(mods) else None
         # the next stage reads its input through the up-sampling (stored tensor, never materialised) where its gather
         # kernels support the shape
-        x_up = bool(STORED_RES_STAGES and nxt is not None and nxt._train_path_ok(y)
+        # (a stage with nothing to differentiate takes the inference kernels, which want the materialised tensor)
+        x_up = bool(STORED_RES_STAGES and nxt is not None and nxt._train_path_ok(y) and not nxt._fast_path_ok(y)
                     and lib.cdn_codenet_dw_up2_supported(y.shape[0], y.shape[1], 2 * y.shape[2], 2 * y.shape[3]))
         if x_up:
             x = ReluQuant.apply(y, mods[i + 1][1], part)

@@ -1886,6 +1886,7 @@ class FrozenBackbone:
             key=key, layers={}, overflow=OverflowFlags(len(acts), dev), acts=acts, n_acts=len(acts),
             p_min=arr(*[a.x_min.data_ptr() for a in acts]), p_max=arr(*[a.x_max.data_ptr() for a in acts]),
             p_state=arr(*[a._device_state(dev).data_ptr() for a in acts]))
+        self._bufs["act_index"] = {id(a): i for i, a in enumerate(acts)}
         for i, a in enumerate(acts):            # word i: the launches that write act i's codes
             self._bufs["overflow"].name(i, [a])
 
@@ -1893,9 +1894,10 @@ class FrozenBackbone:
         """the flag word of the launch writing `acts[0]`'s codes (a fused launch writing two QuantActs' codes is
         attributed to both)"""
         B = self._bufs
-        i = next(k for k, a in enumerate(B["acts"]) if a is acts[0])
-        for extra in acts[1:]:
-            if all(extra is not b for b in B["overflow"].who[i]):
+        i = B["act_index"][id(acts[0])]                 # (the acts list keeps the modules alive: ids are stable)
+        for extra in acts[1:]:                          # (fused depthwise -> pointwise launches; recorded once)
+            if (i, id(extra)) not in B.setdefault("attributed", set()):
+                B["attributed"].add((i, id(extra)))
                 B["overflow"].who[i].append(extra)      # (the backbone's flags are never sliced: word i == who[i])
         return B["overflow"].ptr(i)
 

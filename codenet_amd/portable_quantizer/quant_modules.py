@@ -449,7 +449,7 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
         training path only): x is the STORED tensor whose nearest x2 up-sampling is the stage's input."""
         if x_up and not self._train_path_ok(x):
             raise NotImplementedError("x_up is a training-path argument of forward_stage_blocks")
-        if self._fast_path_ok(x):
+        if not x_up and self._fast_path_ok(x):      # (x_up: x is a stored tensor, only the training path reads through the up-sampling)
             bound = self.quant_act[0]
             s_raw = ops.codenet_scale(x, self.quant_conv_scale.quantized_weight(),
                                       self.quant_conv_scale.bias, bound.min_val, bound.max_val)

@@ -23,7 +23,7 @@ def short(k):
 def load(d, counter):
     files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not files:
-        raise SystemExit("no counter_collection.csv under %s" % d)
+        raise RuntimeError("no counter_collection.csv under %s" % d)
     rows = {}
     for r in csv.DictReader(open(files[-1])):
         if r["Counter_Name"] != counter:
@@ -38,7 +38,7 @@ def iterations(rows, marker, per_iter, last, skip):
     rows = [r for r in rows if not any(s in r[0] for s in skip)]
     starts = [i for i, r in enumerate(rows) if marker in r[0]][::per_iter]
     if len(starts) < 3:
-        raise SystemExit("marker %r found %d times" % (marker, len(starts)))
+        raise RuntimeError("marker %r found %d times" % (marker, len(starts)))
     spans = list(zip(starts[:-1], starts[1:]))[-last:]    # complete iterations only (the tail after the last start is cut)
     return rows, spans
 
@@ -74,4 +74,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except RuntimeError as exc:        # (library functions raise; only the command line turns that into an exit)
+        raise SystemExit(str(exc))
