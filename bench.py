@@ -72,6 +72,9 @@ def parse(argv=None):
                     "replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-network leg")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the `configs` block (the other BASELINE configs -- cfg2, cfg4 per rank, the cfg5 QAT step -- "
+                         "timed in the default single-GPU run)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child runs of the same "
                          "workload, N = 1 only); the committed profiles/ numbers are used instead")
@@ -176,7 +179,7 @@ def live_pmc_traffic(args):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pmc_steady
         base = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-graph",
-                "--no-cpu-baseline", "--no-e2e", "--no-live-pmc", "--regions", "1", "--batch", str(args.batch),
+                "--no-cpu-baseline", "--no-e2e", "--no-config-legs", "--no-live-pmc", "--regions", "1", "--batch", str(args.batch),
                 "--res", str(args.res)] + (["--w2"] if args.w2 else []) + (["--fp32"] if args.fp32 else []) + \
                (["--frozen"] if args.frozen else [])
         per = {}
@@ -221,6 +224,151 @@ def live_pmc_traffic(args):
         return None
 
 
+
+def fused_algorithmic_bytes(shapes, batch, frozen=False):
+    """ALGORITHMIC bytes per step of the fused schedule by kernel family: stages >= 1 read
+    their input at stored (half) resolution, the up-sampling is folded into addressing; the frozen schedule moves byte
+    codes everywhere except the stage-0 input and the scale planes."""
+    alg = {"scale": 0, "dw": 0, "pointwise": 0, "unpack": 0}
+    for i, (C, Co, H, W) in enumerate(shapes):
+        HWs = H * W // (1 if i == 0 else 4)
+        if frozen:
+            xb = 4 if i == 0 else 1
+            alg["scale"] += (C * xb + 4) * HWs * batch
+            alg["dw"] += (C * HWs * xb + HWs * 4 + C * H * W) * batch
+            alg["pointwise"] += (C + Co) * H * W * batch
+            continue
+        alg["scale"] += (C + 1) * HWs * 4 * batch
+        alg["dw"] += (C * HWs + HWs + C * H * W) * 4 * batch
+        alg["pointwise"] += (C + Co) * H * W * 4 * batch
+    C, Co, H, W = shapes[-1]
+    alg["unpack"] = (Co * H * W + 4 * Co * H * W) * 4 * batch
+    return alg
+
+
+def kernel_event_durations(step_fn, steps, keep, durs):
+    """`steps` eager steps with the library's HIP-event pairs around every kernel (recorded on the launch stream);
+    fills durs[(family, (tag,))] -> [ms per launch]."""
+    import ctypes
+    import torch
+    from codenet_amd import _native
+    lib = _native.lib()
+    kname = {0: "scale", 1: "dw", 2: "pointwise", 3: "unpack"}
+    lib.cdn_profile_enable(1)
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    cap = steps * 16
+    ids = (ctypes.c_int * cap)()
+    tags = (ctypes.c_int * cap)()
+    ms = (ctypes.c_float * cap)()
+    n = lib.cdn_profile_read(cap, ids, tags, ms)
+    lib.cdn_profile_enable(0)
+    for i in range(n):
+        name = kname.get(ids[i], "other")
+        if keep(name):
+            durs.setdefault((name, (tags[i],)), []).append(ms[i])
+
+
+def committed_step_traffic(preset):
+    """HBM bytes per step of a preset's fused running-range step from the newest committed PMC collection
+    (profiles/rNN/pmc_steady_<preset>.json: steady-state iterations of `bench.py --config <preset> --no-graph` under
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled; the hand-over kernels unpack / expand8 excluded)."""
+    for rnd in ("r05", "r04"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_steady_%s.json" % preset)))
+        except (OSError, ValueError):
+            continue
+        mb = sum(v["read"] + v["write"] for k, v in pm["per_kernel_MB"].items()
+                 if "unpack" not in k and "expand8" not in k)
+        return int(mb * 2 ** 20), "committed: profiles/%s/pmc_steady_%s.json" % (rnd, preset)
+    return None, None
+
+
+def hot_path_config_leg(preset, dev, steps, warmup, regions=5):
+    """One more BASELINE config through the SAME measurement as the headline (VERDICT r4 "next" #1a): the preset's
+    fused running-range step as a replayed HIP graph, `regions` regions of `steps` steps between synchronisations
+    (median), per-kernel HIP events on the launch stream, algorithmic bytes of the fused definition and the
+    committed PMC traffic of the same command."""
+    import torch
+    from codenet_amd import pipeline
+    p = PRESETS[preset]
+    quantized = not p["fp32"]
+    net = pipeline.build_hot_path(w2=p["w2"], quantized=quantized, seed=317).to(dev)
+    if quantized:
+        pipeline.set_running_stat(net, True)
+    x = pipeline.make_input(p["batch"], p["res"], p["w2"], seed=0, device=dev)
+    fused = pipeline.FusedHotPath(net.deconv_layers)
+    for _ in range(max(1, warmup // 2)):
+        fused.forward_nhwc(x)
+    step = fused.capture(x, unpack=False)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    region_s = []
+    for _ in range(regions):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        region_s.append(time.perf_counter() - t0)
+    region_s.sort()
+    ms = region_s[len(region_s) // 2] / steps * 1e3
+    assert torch.isfinite(out).all()
+    durs = {}
+    kernel_event_durations(lambda: fused.forward_nhwc(x), steps, lambda nm: nm != "unpack", durs)
+    per_kernel = {}
+    for (name, _tag), v in durs.items():
+        per_kernel[name] = per_kernel.get(name, 0.0) + sum(v) / steps
+    shapes = pipeline.stage_shapes(p["res"], p["w2"])
+    alg = fused_algorithmic_bytes(shapes, p["batch"])
+    alg_step = alg["scale"] + alg["dw"] + alg["pointwise"]
+    dominant = max(per_kernel, key=per_kernel.get)
+    traffic, source = committed_step_traffic(preset)
+    fam = {k: {"algorithmic_bytes_per_step": alg[k], "ms_per_step_in_kernel": per_kernel[k],
+               "achieved": alg[k] / (per_kernel[k] * 1e-3) / 1e9,
+               "frac": alg[k] / (per_kernel[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+           for k in ("dw", "pointwise", "scale") if per_kernel.get(k)}
+    roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel_family": dominant,
+            "achieved": fam[dominant]["achieved"], "frac": fam[dominant]["frac"],
+            "algorithmic_bytes_per_step": alg[dominant], "ms_per_step_in_kernel": per_kernel[dominant],
+            "families": fam,
+            "step": {"algorithmic_bytes": alg_step, "achieved": alg_step / ms / 1e6,
+                     "frac": alg_step / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+                     "traffic_frac": (traffic / ms / 1e6 / HBM_PEAK_GBS) if traffic else None}}
+    if p["fp32"]:
+        # SURVEY 8(d): the fp32 stage-0 pointwise (K = 1024) sits on the f32-MFMA roofline, not on HBM
+        C, Co, H, W = shapes[0]
+        pw0 = [sum(v) / len(v) for (nm, tag), v in durs.items() if nm == "pointwise" and tag == (H,)]
+        if pw0:
+            tf = 2.0 * C * Co * H * W * p["batch"] / (pw0[0] * 1e-3) / 1e12
+            roof["stage0_pointwise_mfma"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
+                                             "achieved": tf, "frac": tf / F32_MFMA_PEAK_TF, "us_per_launch": pw0[0] * 1e3}
+    del step, fused, net, x
+    torch.cuda.empty_cache()
+    return {"workload": "CoDeNet%s %dx%d %s, batch %d per GPU, the three deform stages (the headline's step), fused "
+                        "schedule, HIP-graph replay" % ("2x" if p["w2"] else "1x", p["res"], p["res"],
+                                                        "fp32" if p["fp32"] else "W4A8 (running QuantAct ranges)",
+                                                        p["batch"]),
+            "ms_per_step": ms, "images_per_s": p["batch"] / ms * 1e3,
+            "regions": {"n": regions, "steps_each": steps, "ms_per_step_min": region_s[0] / steps * 1e3,
+                        "ms_per_step_max": region_s[-1] / steps * 1e3},
+            "roofline": roof,
+            "kernel_ms_per_launch": {"%s@%d" % (nm, tag[0]): round(sum(v) / len(v), 5)
+                                     for (nm, tag), v in sorted(durs.items())}}
+
+
+def qat_step_leg(dev, steps=20):
+    """BASELINE configs[4] ("cfg5"): the W4A8 quant-aware training step of quant_main.py restricted to the hot path --
+    forward + backward + Adam over the three deform stages, batch 32 (lib/opts.py:91), 512x512, one HIP graph
+    (tools/train_step_bench.py's step) -- with its algorithmic bytes and the gather backward against the LDS-atomic
+    rate that bounds it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_step_bench as T
+    return T.measure(batch=32, res=512, steps=steps, graph=True)
+
+
 # ---- CPU baselines (the only place bench.py touches oracle/) ------------------------------------------------
 
 def cpu_baseline(args, net_cpu):
@@ -258,11 +406,13 @@ def cpu_baseline(args, net_cpu):
             x = F.interpolate(y, scale_factor=2, mode="nearest")
         return x
 
-    # two thread counts on many-core hosts (torch-CPU's small ops are slower on 128 threads than on 16: the
-    # whole-model legs below show the same); `value` is the faster leg and `cores` the threads it used
+    # on many-core hosts a 16-thread pool (torch-CPU's small ops are slower on 128 threads than on 16);
+    # `cores` is the thread count the reported leg used
     legs = {}
     with torch.no_grad():
-        for threads in ((cores, 16) if cores > 32 else (cores,)):
+        # (round 5: the all-cores leg on a >= 64-core host is oversubscribed noise -- 12 against 102 images/s on 128
+        # threads in the driver's round-4 run -- and is no longer run; `cores` is what was used)
+        for threads in ((16,) if cores > 32 else (cores,)):
             torch.set_num_threads(threads)
             O.set_threads(threads)
             run(x[:1])                       # warm caches / thread pools
@@ -271,7 +421,7 @@ def cpu_baseline(args, net_cpu):
             while True:
                 run(x)
                 reps += 1
-                if time.perf_counter() - t0 > (6.0 if cores > 32 else 10.0) or reps >= 400:
+                if time.perf_counter() - t0 > 10.0 or reps >= 400:
                     break
             dt = time.perf_counter() - t0
             legs[threads] = (n * reps / dt, reps)
@@ -337,9 +487,9 @@ def cpu_baseline_e2e(args, budget_s=4.0):
     try:
         model = harness.create_model(w2=args.w2, quantize=not args.fp32)
         g = torch.Generator().manual_seed(0)
-        # (16: with >= 64 host cores torch-CPU's small ops are slower on all cores than on one -- the
-        # extra leg shows a sensibly sized pool next to the two the protocol asks for)
-        for threads in ((all_threads, 16, 1) if all_threads > 32 else (all_threads, 1)):
+        # (>= 64 host cores: a 16-thread pool stands in for "all cores" -- torch-CPU's small ops are slower on 128
+        # threads than on one; the driver's round-4 run: 7.9 against 31.9 images/s)
+        for threads in ((16, 1) if all_threads > 32 else (all_threads, 1)):
             torch.set_num_threads(threads)
             O.set_threads(threads)                   # the oracle's OpenMP loops follow the same count
             for n in (1, 8):
@@ -361,7 +511,8 @@ def cpu_baseline_e2e(args, budget_s=4.0):
         O.set_threads(all_threads)
         M.deform_conv, QM.deform_conv = saved
     best = max(v["images_per_s"] for v in legs.values())
-    return {"value": best, "unit": "images/sec", "kind": "port", "cores": all_threads, "nproc": os.cpu_count(),
+    return {"value": best, "unit": "images/sec", "kind": "port", "cores": (16 if all_threads > 32 else all_threads),
+            "nproc": os.cpu_count(),
             "cpu_model": cpu_model_name(), "legs": legs,
             "sample": "CoDeNet%s %dx%d %s whole model + ctdet_decode on torch-CPU + the C/OpenMP oracle for the "
                       "deform conv; per leg one warm-up image, then whole batches for >= %.0f s"
@@ -570,29 +721,10 @@ def main():
     #      event pairs around every kernel, K eager steps right after the timed region) ------------
     durs = {}
     if fused is not None and rank == 0:
-        lib = _native.lib()
-        kname = {0: "scale", 1: "dw", 2: "pointwise", 3: "unpack"}
-
-        def timed_eager(step_fn, keep):
-            # K eager steps with the library's event pairs around every kernel.  `step_fn` must be the TIMED step: until
-            # round 3 these steps also ran unpack_kernel (320 MB through the caches between two steps), which made the
-            # kernels behind it -- the stage-0 scale and gather above all -- 10-40 % slower than inside the timed region
-            lib.cdn_profile_enable(1)
-            for _ in range(args.steps):
-                step_fn()
-            torch.cuda.synchronize()
-            cap = args.steps * 16
-            ids = (ctypes.c_int * cap)()
-            tags = (ctypes.c_int * cap)()
-            ms = (ctypes.c_float * cap)()
-            n = lib.cdn_profile_read(cap, ids, tags, ms)
-            lib.cdn_profile_enable(0)
-            for i in range(n):
-                name = kname.get(ids[i], "other")
-                if keep(name):
-                    durs.setdefault((name, (tags[i],)), []).append(ms[i])
-        timed_eager(eager_step, lambda nm: nm != "unpack")
-        timed_eager(eager_step_unpack, lambda nm: nm == "unpack")       # (reported separately, `with_unpack`)
+        # `eager_step` is the TIMED step: until round 3 these steps also ran unpack_kernel (320 MB through the caches
+        # between two steps), which made the kernels behind it 10-40 % slower than inside the timed region
+        kernel_event_durations(eager_step, args.steps, lambda nm: nm != "unpack", durs)
+        kernel_event_durations(eager_step_unpack, args.steps, lambda nm: nm == "unpack", durs)   # (`with_unpack`)
     elif rank == 0:
         durs = kt.durations_ms()
 
@@ -667,6 +799,20 @@ def main():
     if not args.no_e2e and args.path == "fused":
         e2e = e2e_leg(args, dev, rank, world, local_rank, dt / args.steps * 1e3)
 
+    # ---- the other BASELINE configs, timed by the same run (N = 1, default workload only): VERDICT r4 "next" #1a ----
+    configs = None
+    if rank == 0 and world == 1 and args.config is None and not args.no_config_legs and args.path == "fused" \
+            and (args.res, args.batch, args.w2, args.fp32, args.frozen) == (512, 64, False, False, False):
+        configs = {}
+        for key, fn in (("cfg2", lambda: hot_path_config_leg("cfg2", dev, args.steps, args.warmup)),
+                        ("cfg4_rank", lambda: hot_path_config_leg("cfg4", dev, args.steps, args.warmup)),
+                        ("cfg5_qat", lambda: qat_step_leg(dev))):
+            try:
+                configs[key] = fn()
+            except Exception as exc:          # noqa: BLE001 -- reported in the JSON line, the headline stands
+                configs[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         per_kernel = {}
         for (name, tag), v in durs.items():
@@ -683,21 +829,7 @@ def main():
                 alg[k] += v[k]
         shapes = pipeline.stage_shapes(args.res, args.w2)
         if fused is not None:
-            # fused schedule: stages >= 1 read their input at half resolution (up-sampling folded)
-            alg = {"scale": 0, "dw": 0, "pointwise": 0, "unpack": 0}
-            for i, (C, Co, H, W) in enumerate(shapes):
-                HWs = H * W // (1 if i == 0 else 4)
-                if frozen_main:      # byte codes everywhere except the stage-0 input and the scale planes
-                    xb = 4 if i == 0 else 1
-                    alg["scale"] += (C * xb + 4) * HWs * args.batch
-                    alg["dw"] += (C * HWs * xb + HWs * 4 + C * H * W) * args.batch
-                    alg["pointwise"] += (C + Co) * H * W * args.batch
-                    continue
-                alg["scale"] += (C + 1) * HWs * 4 * args.batch
-                alg["dw"] += (C * HWs + HWs + C * H * W) * 4 * args.batch
-                alg["pointwise"] += (C + Co) * H * W * 4 * args.batch
-            C, Co, H, W = shapes[-1]
-            alg["unpack"] = (Co * H * W + 4 * Co * H * W) * 4 * args.batch
+            alg = fused_algorithmic_bytes(shapes, args.batch, frozen_main)
         flops_pw = sum(2.0 * C * Co * H * W * args.batch
                        for (C, Co, H, W) in pipeline.stage_shapes(args.res, args.w2))
         # The fused schedules' pointwise kernels (int8 MFMA on codes / the bf16 split) keep the matrix cores 6-12 % busy
@@ -806,6 +938,7 @@ def main():
             "kernel_ms_per_launch": per_launch,
             "frozen_int8": frozen_leg,
             "e2e": e2e,
+            "configs": configs,
         }
         if net_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(args, net_cpu)

@@ -2969,6 +2969,30 @@ extern "C" int cdn_codenet_stage_fused_supported(int64_t N, int64_t C, int64_t H
   return cdn::stage_channel_chunk((int)(H >> x_up), (int)(W >> x_up)) == 0;      // (too many chunk workgroups: no)
 }
 
+// Rows of d padded to whole 64-channel chunks?  (NCHW input with a ragged channel count feeding the int8 pointwise.)
+static bool stage_pads_d(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up, int gmode, bool int8_pw) {
+  const int64_t Cd = (C + 63) / 64 * 64;
+  return !x_nhwc && x_up == 0 && Cd != C && gmode != 1 && int8_pw && cdn::stage_channel_chunk((int)H, (int)W) == 64 &&
+         dw0p_applies((int)Cd, (int)H, (int)W) && N * Cd * H * W < (1ll << 31);
+}
+
+// Diagnostics / tests: where cdn_codenet_stage_fused_forward leaves its two intermediates in the workspace -- the
+// clamped scale plane s (pre-quantisation, [N][stored pixels]) at byte offset 0 and the gather output d
+// (pre-quantisation, channels-last rows of *d_row_floats floats, of which the first C are the channels) at
+// *d_offset_bytes.  int8_pointwise: the call passes the integer form of the pointwise weights and a d quantiser
+// (W4A8 without --act-percentile).  Both stay valid until the next call that uses the workspace.
+extern "C" int cdn_codenet_stage_fused_intermediates(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up,
+                                                     int int8_pointwise, int64_t *d_offset_bytes,
+                                                     int64_t *d_row_floats) {
+  CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && d_offset_bytes && d_row_floats, CDN_ERR_ARG, "bad argument");
+  const int gmode = (x_nhwc & CDN_X_GATHER_MASK) >> 8;
+  const int64_t HWl = (H >> x_up) * (W >> x_up);
+  *d_offset_bytes = (N * HWl * 4 + 255) / 256 * 256;
+  *d_row_floats = stage_pads_d(N, C, H, W, x_nhwc & 1, x_up, gmode, int8_pointwise != 0 && !(x_nhwc & CDN_X_ACT_PERCENTILE))
+                      ? (C + 63) / 64 * 64 : C;
+  return CDN_OK;
+}
+
 extern "C" int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
@@ -3021,10 +3045,9 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // chunks, 16-byte stores) and the int8 pointwise's 16-byte row loads apply; the pad channels duplicate channel
   // C - 1 and meet zero weight codes (see dw0p_kernel).  Same values as the unpadded schedule, bit for bit.
   const int64_t Cd = (C + 63) / 64 * 64;
-  const bool pad_d = !pct && !x_nhwc && x_up == 0 && Cd != C && gmode != 1 && w_pw_codes != nullptr && d_state != nullptr &&
-                     ep_scale == nullptr && w_pw_scale != nullptr && w_pw_colsum != nullptr &&
-                     cdn::stage_channel_chunk(Hl, Wl) == 64 && dw0p_applies((int)Cd, (int)H, (int)W) &&
-                     N * Cd * H * W < (1ll << 31);
+  const bool pad_d = !pct && stage_pads_d(N, C, H, W, x_nhwc, x_up, gmode,
+                                          w_pw_codes != nullptr && d_state != nullptr && ep_scale == nullptr &&
+                                              w_pw_scale != nullptr && w_pw_colsum != nullptr);
   const int64_t ldd = pad_d ? Cd : C;
   char *pct_ws = wsp + r256(N * HWl * 4) + r256(N * H * W * Cd * 4);
   float *pct_out = reinterpret_cast<float *>(pct_ws + kPctBytes - 256);

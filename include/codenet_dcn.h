@@ -354,6 +354,14 @@ size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_
  * channel chunks up to ~4800 stored pixels = inputs up to ~1100 px), 0 otherwise: callers then keep the
  * module path (cdn_codenet_{scale,dw,pointwise}_forward, any plane size). */
 int cdn_codenet_stage_supported(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up);
+/* Diagnostics / parity tests: where cdn_codenet_stage_fused_forward leaves its intermediates in the workspace after a
+ * call with these arguments (x_nhwc as passed, flags included): the clamped scale plane s BEFORE its QuantAct
+ * ([N][stored pixels] floats) at byte offset 0, the gather output d BEFORE its QuantAct at *d_offset_bytes as
+ * channels-last rows of *d_row_floats floats (the first C are the channels; CoDeNet2x stage 0 pads its rows).
+ * int8_pointwise: the call passes w_pw_codes / scale / colsum and a d quantiser.  These are the tensors the
+ * reference materialises between conv_scale / deform_conv / conv_channel (quant_modules.py:668-671). */
+int cdn_codenet_stage_fused_intermediates(int64_t N, int64_t C, int64_t H, int64_t W, int x_nhwc, int x_up,
+                                          int int8_pointwise, int64_t *d_offset_bytes, int64_t *d_row_floats);
 /* What cdn_codenet_stage_fused_forward itself accepts: the above, or a stored plane too large for LDS, which it gathers
  * straight from global memory / L2 (round 4: inputs above ~1100 px; a size fallback with the module path's per-channel
  * expressions).  The byte-code entry points (cdn_codenet_stage_frozen*) keep the LDS-resident limit above. */

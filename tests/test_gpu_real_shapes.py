@@ -16,6 +16,13 @@ Acceptance (same as tests/test_gpu_parity.py::test_fused_hot_path_matches_module
 pre-quantisation value across a rounding boundary, i.e. flip a code by ONE LSB: <= 1 LSB, on < 0.02 % of the
 elements (measured 0.001-0.004 %, tools/experiments/code_mismatch_rate.py); every tracked range within 3e-6 of its
 magnitude (+1e-6; measured <= 6.3e-7).
+
+That the summation ORDER is the only cause of those flips -- not a tie rule, an edge weight or a quantiser expression --
+is demonstrated in tests/test_gpu_exact_codes.py (round 5): on inputs where every order gives the same fp32 value the
+same kernels match the oracle with torch.equal (s, d, relu(y), all ranges, output codes; running and frozen ranges,
+graph replay, byte-code schedule), and on THESE random inputs the oracle's QuantAct applied to the GPU's own
+pre-quantisation tensors reproduces every device range bit for bit and every consumer's output to a tenth of one
+flipped code's effect.
 """
 import copy
 

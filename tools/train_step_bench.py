@@ -45,6 +45,54 @@ def main():
     if a.no_fuse_dq:
         from codenet_amd.functions import codenet_stage as _cs
         _cs.FUSE_DQ_ON_LOAD = False
+    out = measure(batch=a.batch, res=a.res, steps=a.steps, graph=a.graph, fp32=a.fp32, loss=a.loss,
+                  foreach_adam=a.foreach_adam, wt_percentile=a.wt_percentile, stored=not a.no_stored_res)
+    print(json.dumps(out))
+
+
+def qat_algorithmic_bytes(batch, res, stored=True):
+    """ALGORITHMIC HBM bytes of one QAT step over the three stages (fp32 tensors, every kernel reading its inputs and
+    writing its outputs once; weights and their gradients -- <= 1.4 MB -- excluded as in SURVEY 8(d)).  Per stage with
+    P = N*H*W output pixels and Ps = stored input pixels (P/4 for stages 1-2 when they read through the up-sampling):
+      forward   scale (C+1)*Ps . gather C*Ps + Ps + C*P . pointwise (C + Co)*P . ReLU/QuantAct[/Upsample] block (1 + up)*Co*P
+                (up = 1 when the next stage takes the stored tensor, 4 when the x2 up-sampling is materialised)
+      backward  block (up + 2)*Co*P (gradient in, pre-ReLU tensor in, gradient out) . pointwise data grad (Co + C)*P
+                . weight grad (C + Co)*P . gather backward: read x C*Ps, grad_d C*P, s Ps; write grad_x C*Ps, grad_s Ps
+                . scale backward: read grad_s Ps, add into grad_x (read + write) 2*C*Ps
+    SURVEY 8(d): "backward ~ 3 x forward bytes"."""
+    from codenet_amd import pipeline as P_
+    tot_f = tot_b = 0
+    shapes = P_.stage_shapes(res, False)
+    for i, (C, Co, H, W) in enumerate(shapes):
+        P = batch * H * W
+        Ps = P // 4 if (stored and i > 0) else P
+        up = 1 if (stored and i + 1 < len(shapes)) else 4      # the block's output: stored hand-over or materialised x2
+        tot_f += ((C + 1) * Ps + (C * Ps + Ps + C * P) + (C + Co) * P + (Co * P + up * Co * P)) * 4
+        tot_b += ((up * Co * P + 2 * Co * P) + (Co + C) * P + (C + Co) * P + (2 * C * Ps + C * P + 2 * Ps)
+                  + (Ps + 2 * C * Ps)) * 4
+    return {"forward": tot_f, "backward": tot_b, "step": tot_f + tot_b}
+
+
+def committed_traffic():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rnd in ("r05", "r04"):
+        try:
+            pm = json.load(open(os.path.join(root, "profiles", rnd, "pmc_steady_train_step.json")))
+            return int(pm["bytes_per_iteration"]), "committed: profiles/%s/pmc_steady_train_step.json" % rnd
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def measure(batch=32, res=512, steps=10, graph=True, fp32=False, loss=False, foreach_adam=False, wt_percentile=False,
+            stored=True):
+    """One QAT step (forward + backward + Adam) of the hot path; returns the bench record (bench.py's `configs.cfg5_qat`
+    leg and this tool's output)."""
+    class A:
+        pass
+    a = A()
+    a.batch, a.res, a.steps, a.graph, a.fp32, a.loss = batch, res, steps, graph, fp32, loss
+    a.foreach_adam, a.wt_percentile, a.no_stored_res = foreach_adam, wt_percentile, not stored
     net = pipeline.build_hot_path(quantized=not a.fp32, wt_percentile=a.wt_percentile).cuda().train()
     for m in net.modules():                      # BN inside QuantBnConv2d is never called; plain BN in fp32
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -109,7 +157,17 @@ def main():
         "images_per_s": round(a.batch / dt, 1), "probe": float(loss)}
     out["stored_res_stages"] = not a.no_stored_res
     out["roofline_dw_bwd2"] = dw_bwd2_roofline(a.batch, a.res, stored=not a.no_stored_res)
-    print(json.dumps(out))
+    alg = qat_algorithmic_bytes(a.batch, a.res, stored=not a.no_stored_res)
+    traffic, source = committed_traffic() if (a.batch, a.res, a.fp32) == (32, 512, False) else (None, None)
+    out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes_per_step": alg["step"],
+                       "algorithmic_bytes": alg, "achieved": alg["step"] / dt / 1e9, "frac": alg["step"] / dt / 1e9 / 8000.0,
+                       "traffic": traffic, "traffic_source": source,
+                       "traffic_frac": (traffic / dt / 1e9 / 8000.0) if traffic else None,
+                       "note": "whole step against HBM; its dominant kernel family (the gather backward) is bound by the "
+                               "64-bit LDS atomics, see roofline_dw_bwd2"}
+    del net, opt, x, go
+    torch.cuda.empty_cache()
+    return out
 
 
 def dw_bwd2_roofline(batch, res, stored=True):
