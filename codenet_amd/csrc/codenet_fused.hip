@@ -1555,6 +1555,211 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 }
 
 // ------------------------------------------------------------------------------------------
+// pws: the f32 pointwise conv for launches with FEW output tiles (round 5; cfg2's stage 0: M = 2048 rows, K = 1024,
+// Co = 256 -- pw3_kernel's 64 x 128 tiles are 64 workgroups on 256 CUs, each a chain of 32 dependent k tiles with 32
+// MFMAs of 64 cycles per wave and tile: 27 us of matrix time on a quarter of the SIMDs, 47 us measured).
+// Every WAVE owns one 32 (m) x 32*TN (co) output tile over a k range and runs its own pipeline -- no workgroup barrier
+// in the k loop: 32-k windows of both operands (32 + 32 TN rows x 128 B) are fetched by LDS-DMA
+// (global_load_lds_dwordx4: 8 lanes per row = whole 128-byte lines, no VGPRs) into a wave-private LDS ring R - 1
+// windows ahead, read back in MFMA layout (lane (i = l & 31, h = l >> 5) takes the 16 consecutive k values
+// [16 h, 16 h + 16) of row i as four ds_read_b128; a sum over k does not care which of the two k slots of
+// v_mfma_f32_32x32x2_f32 a k lands in, only that A and B agree) and multiplied.  The DMA's LDS side is lane-linear
+// (rows of exactly 128 B), so the 16-byte chunks of a row are stored XOR-swizzled -- chunk c of row r at position
+// c ^ ((r >> 1) & 7), applied to the per-lane SOURCE address -- which makes the fragment reads conflict-free.
+// (First form of this kernel, measured: lanes loading their 64-byte operand pieces straight from global memory -- every
+// load instruction touched 32 lines for 16 bytes each; 15.3 us at cfg2's stage 0 and SLOWER, 18.3 us, with three windows
+// in flight instead of one: bound by the texture path's line touches, not by latency or matrix time.)
+// The four waves of a workgroup are
+//   KS = 4: the four quarters of K of ONE tile (wave w: [w K/4, (w+1) K/4)); the partial tiles are added through LDS in
+//           a FIXED order ((w0 + w1) + (w2 + w3)) -- for launches whose tiles alone would not give every SIMD a wave;
+//   KS = 1: four consecutive m tiles, the whole K each; accumulators go straight to the epilogue.
+// The launcher picks the widest tile and the least splitting that still gives >= 4 waves per CU.  Reproducible bit for
+// bit from call to call; against pw3_kernel the k order differs (fp32 re-association; the fp32 path's parity bound is
+// 1e-3 against the oracle).  Workgroups that share A rows (the co tiles of one m block) get ids 8 apart = the same XCD
+// under round-robin dispatch, so an A block is fetched into one L2.
+// Needs K % (32 KS) == 0 and 16-byte aligned rows; plain f32 operands (no quantise-on-load).
+// ------------------------------------------------------------------------------------------
+constexpr int kPwsLD = 72;      // floats per LDS row of a partial tile: the two lane halves (rows 4 apart) hit disjoint banks
+template <int TN> struct PwsGeom {
+  static constexpr int R = TN == 2 ? 3 : 4;                 // ring slots per wave
+  static constexpr int kSlot = (32 + 32 * TN) * 128;        // bytes per window: A rows, then B rows, 128 B each
+  static constexpr int kRing = R * kSlot;
+  static constexpr int kLds = 4 * kRing;                    // 144 KB (TN = 2) / 128 KB (TN = 1)
+};
+
+template <int TN, int KS>
+__global__ void __launch_bounds__(256)
+pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const float *__restrict__ bias,
+           const float *__restrict__ ep_scale, const float *__restrict__ ep_shift, float *__restrict__ R, float2 *rmm,
+           cdn::QUpdate qu, long M, int K, int Co, int relu, int lda, int ldo) {
+  using G = PwsGeom<TN>;
+  constexpr int BN = 32 * TN;
+  constexpr int BM = KS == 4 ? 32 : 128;          // rows of A per workgroup
+  constexpr int NL = 4 + 4 * TN;                  // DMA instructions per window and wave
+  static_assert(BN <= 64 && (KS == 1 || KS == 4) && 32 * kPwsLD * 4 <= G::kRing, "partial tile aliases the ring");
+  extern __shared__ float4 pws_lds[];
+  char *lds = reinterpret_cast<char *>(pws_lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int ntm = (int)((M + BM - 1) / BM), ntn = (Co + BN - 1) / BN;
+  // (m block, n tile) of this workgroup: within the part of the m range that is a multiple of 8 blocks, the n tiles of
+  // one m block are 8 ids apart (same XCD); the remainder is mapped plainly.  A bijection on the grid.
+  int mt, nt;
+  {
+    const int b = blockIdx.x, full_m = ntm & ~7, full = full_m * ntn;
+    if (b < full) {
+      mt = (b & 7) + 8 * (b / (8 * ntn));
+      nt = (b >> 3) % ntn;
+    } else {
+      const int rem = ntm - full_m, q = b - full;
+      mt = full_m + q % rem;
+      nt = q / rem;
+    }
+  }
+  const long m0 = (long)mt * BM + (KS == 4 ? 0 : 32 * w);      // first row of this WAVE's tile (wave-uniform)
+  const int n0 = nt * BN;
+  const int Kw = KS == 4 ? K >> 2 : K, kbase = KS == 4 ? w * Kw : 0;
+  // ---- DMA side: lane <-> (row 8 u + (l >> 3), 16-byte chunk l & 7) of instruction u; rows beyond M / Co are clamped
+  const float *abase = A + (m0 < M ? m0 : M - 1) * lda + kbase;          // wave-uniform bases, 32-bit lane offsets
+  const float *bbase = Wp + (long)n0 * K + kbase;
+  const int dr = lane >> 3, dc = lane & 7;
+  unsigned aoff[4], boff[TN][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int row = 8 * u + dr;
+    const long rmax = M - 1 - m0;                                         // last valid row of this tile (may be < 0)
+    const int rl = (int)(rmax < 0 ? 0 : (row < rmax ? row : rmax));
+    aoff[u] = (unsigned)rl * (unsigned)lda * 4u + (unsigned)((dc ^ ((row >> 1) & 7)) * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cmax = Co - 1 - n0 - 32 * j;
+      const int cl = cmax < 0 ? -32 * j : (row < cmax ? row : cmax);      // (cmax < 0: the whole co tile is padding)
+      boff[j][u] = (unsigned)(32 * j + cl) * (unsigned)K * 4u + (unsigned)((dc ^ ((row >> 1) & 7)) * 16);
+    }
+  }
+  const unsigned ring = lds_addr_uniform(lds) + (unsigned)w * G::kRing;
+  auto issue = [&](int t) {
+    const unsigned dst = ring + (unsigned)(t % G::R) * G::kSlot, koff = (unsigned)t * 128u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) glds16(abase, aoff[u] + koff, dst + u * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) glds16(bbase, boff[j][u] + koff, dst + 4096 + j * 4096 + u * 1024);
+  };
+  // ---- MFMA side
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = (f32x16){0};
+  const char *wring = lds + w * G::kRing;
+  const int frow = i * 128, fsw = (i >> 1) & 7;
+  const int nit = Kw >> 5;
+  int issued = 0;
+  for (; issued < G::R - 1 && issued < nit; ++issued) issue(issued);
+  for (int t = 0; t < nit; ++t) {
+    if (issued < nit) issue(issued++);
+    // windows t .. issued - 1 are in flight (NL DMAs each, completing in order): wait for window t
+    switch (issued - 1 - t) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: if (NL == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 2: if (NL == 12) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;      // (TN = 1, three windows behind this one)
+    }
+    const char *slot = wring + (t % G::R) * G::kSlot;
+    float4 fa[4], fb[TN][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pos = ((4 * h + q) ^ fsw) * 16;
+      fa[q] = *reinterpret_cast<const float4 *>(slot + frow + pos);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j][q] = *reinterpret_cast<const float4 *>(slot + 4096 + j * 4096 + frow + pos);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float ae[4] = {fa[q].x, fa[q].y, fa[q].z, fa[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float be = e == 0 ? fb[j][q].x : e == 1 ? fb[j][q].y : e == 2 ? fb[j][q].z : fb[j][q].w;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[e], be, acc[j], 0, 0, 0);
+        }
+    }
+  }
+  float mn = INFINITY, mx = -INFINITY;
+  if (KS == 4) {
+    // ---- the four k slices of the tile through LDS (each wave's partial tile over its own, drained ring), added in a
+    //      fixed order
+    float *Pw = reinterpret_cast<float *>(lds + w * G::kRing);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Pw[((r & 3) + 8 * (r >> 2) + 4 * h) * kPwsLD + j * 32 + i] = acc[j][r];
+    __syncthreads();
+    constexpr int RPT = 32 * BN / 256;            // rows per thread: thread <-> one column, RPT consecutive rows
+    const int col = tid % BN, r0 = (tid / BN) * RPT;
+    const int co = n0 + col;
+    float bsv = 0.f, es = 1.f, eh = 0.f;
+    if (co < Co) {
+      if (bias) bsv = bias[co];
+      if (ep_scale) {
+        es = ep_scale[co];
+        eh = ep_shift[co];
+      }
+    }
+    const float *P0 = reinterpret_cast<const float *>(lds), *P1 = reinterpret_cast<const float *>(lds + G::kRing),
+                *P2 = reinterpret_cast<const float *>(lds + 2 * G::kRing),
+                *P3 = reinterpret_cast<const float *>(lds + 3 * G::kRing);
+    float v[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+      const int o = (r0 + rr) * kPwsLD + col;
+      v[rr] = ((P0[o] + P1[o]) + (P2[o] + P3[o])) + bsv;
+      if (ep_scale) v[rr] = fmaf(v[rr], es, eh);
+      if (relu) v[rr] = fmaxf(v[rr], 0.0f);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr)
+      if (m0 + r0 + rr < M && co < Co) {
+        R[(m0 + r0 + rr) * ldo + co] = v[rr];
+        mn = fminf(mn, v[rr]);
+        mx = fmaxf(mx, v[rr]);
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = n0 + j * 32 + i;
+      float bsv = 0.f, es = 1.f, eh = 0.f;
+      if (co < Co) {
+        if (bias) bsv = bias[co];
+        if (ep_scale) {
+          es = ep_scale[co];
+          eh = ep_shift[co];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[j][r] + bsv;
+        if (ep_scale) v = fmaf(v, es, eh);
+        if (relu) v = fmaxf(v, 0.0f);
+        if (m < M && co < Co) {
+          R[m * ldo + co] = v;
+          mn = fminf(mn, v);
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+  }
+  if (rmm) {
+    __syncthreads();      // (the scratch of block_minmax_finish aliases wave 0's ring / partial tile)
+    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.x, gridDim.x, qu, reinterpret_cast<float *>(lds));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // pwi8: the W4A8 pointwise conv on INTEGER CODES with v_mfma_i32_32x32x32_i8.
 //   levels   L = q + zp,  q = round(sc*d - zp)  (QuantAct codes, NOT clamped by the reference)
 //   weights  qw in [-8, 7], W' = qw / sw[co]     (per-channel symmetric 4 bit)
@@ -2766,6 +2971,19 @@ int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const f
 // Pointwise (1x1) convolution on a channels-last activation A [M][C] -> R [M][Co]: int8 MFMA on codes
 // when the A quantiser state and the integer weights are given, f32 MFMA otherwise.  Shared by the
 // stage schedule and the stand-alone entry point (detection heads).
+// pws_kernel instead of pw3_kernel: plain f32 operands, K a multiple of 32 with 16-byte aligned rows, and a launch
+// whose pw3 tiling (64- or 128-row tiles x 128 / 64 columns) would leave the chip with at most one workgroup per CU
+// -- the latency-chain regime (cfg2: all three stages).  CDN_PWS_MAX_TILES: A/B switch.
+#ifndef CDN_PWS_MAX_TILES
+#define CDN_PWS_MAX_TILES (cdn::kCUs)
+#endif
+static bool pws_applies(long M, int64_t K, int64_t Co, int64_t lda, const float *a, const float *w) {
+  if (K < 32 || (K & 31) || (lda & 3) || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(w)) & 15))
+    return false;
+  const long tiles = cdn::ceil_div(M, Co > 64 ? 64 : 128) * cdn::ceil_div(Co, Co > 64 ? 128 : 64);
+  return tiles <= (long)CDN_PWS_MAX_TILES && cdn::ceil_div(M, 32) * cdn::ceil_div(Co, 32) <= (1L << 20);
+}
+
 static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, int64_t Co,
                             const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
                             const int *w_pw_colsum, const float *bias_pw, const float *ep_scale,
@@ -2891,6 +3109,25 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     else if (pw_bn == 128) CDN_PWB(128, 128, 4);
     else CDN_PWB(128, 64, 4);
 #undef CDN_PWB
+  } else if (!dst && a_gen == nullptr && out_map == nullptr && !a_padded && pws_applies(M, C, Co, lda, d, w_pw)) {
+    // few output tiles: streaming waves (pws_kernel) -- the widest tile and the least K splitting that give >= 4 waves
+    // per CU: (64 columns, whole K), (32, whole K), (64, K / 4), (32, K / 4)
+    cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
+    const long want = 4L * cdn::kCUs, mt32 = cdn::ceil_div(M, 32);
+    const long w21 = mt32 * cdn::ceil_div(Co, 64), w11 = mt32 * cdn::ceil_div(Co, 32);
+    const bool can_split = (C & 127) == 0;
+#define CDN_PWS(TN_, KS_)                                                                                         \
+  do {                                                                                                            \
+    auto kern = pws_kernel<TN_, KS_>;                                                                             \
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PwsGeom<TN_>::kLds); \
+    kern<<<(unsigned)(cdn::ceil_div(M, KS_ == 4 ? 32 : 128) * cdn::ceil_div(Co, 32 * TN_)), 256, PwsGeom<TN_>::kLds, st>>>( \
+        d, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, (int)lda, (int)ldo);     \
+  } while (0)
+    if (w21 >= want || (!can_split && Co > 32)) CDN_PWS(2, 1);
+    else if (w11 >= want || !can_split) CDN_PWS(1, 1);
+    else if (4 * w21 >= want) CDN_PWS(2, 4);
+    else CDN_PWS(1, 4);
+#undef CDN_PWS
   } else {
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {

@@ -68,6 +68,53 @@ def test_pointwise_row_strides_and_interleave():
     assert (out - exp).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("M,K,Co,affine,lda,ldo", [
+    (2048, 1024, 256, True, 0, 0),       # cfg2 stage 0 (32 images at 8 x 8): 256 workgroups x 4 k slices of 256
+    (8192, 256, 128, True, 0, 0),        # cfg2 stage 1
+    (32768, 128, 64, False, 0, 0),       # cfg2 stage 2: one 32-k window per wave
+    (2001, 512, 200, True, 520, 208),    # ragged m / co tiles (clamped loads, masked stores), row strides
+    (77, 384, 40, False, 0, 0),          # fewer than 8 m tiles: the plain part of the tile map; odd window count
+])
+def test_pointwise_f32_wave_split_k(M, K, Co, affine, lda, ldo):
+    """pws_kernel (round 5): the f32 pointwise for launches with few output tiles -- the four waves of a workgroup split K
+    and stream their MFMA operands from global memory, partial tiles added in a fixed order -- against float64
+    arithmetic, incl. bias, BN affine, ReLU, the range epilogue, and bitwise reproducibility from call to call."""
+    from codenet_amd import _native as N_, ops
+    lib, dev = N_.lib(), torch.device("cuda", 0)
+    ws, wp, wb = _ws(lib, dev)
+    g = torch.Generator().manual_seed(M + K)
+    lda, ldo = lda or K, ldo or Co
+    a = torch.randn(M, lda, generator=g).to(dev)
+    w = (torch.randn(Co, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    es = (torch.rand(Co, generator=g) + 0.5).to(dev) if affine else None
+    eh = torch.randn(Co, generator=g).to(dev) if affine else None
+    ref = a[:, :K].double() @ w.double().t() + b.double()
+    if affine:
+        ref = ref * es.double() + eh.double()
+    ref = torch.relu(ref)
+    xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, ldo), -7.0, device=dev)
+        xmin.zero_()
+        xmax.zero_()
+        rc = lib.cdn_codenet_pointwise_nhwc_forward(
+            a.data_ptr(), None, M, K, Co, lda, ldo, w.data_ptr(), None, None, None, b.data_ptr(),
+            es.data_ptr() if affine else None, eh.data_ptr() if affine else None, 1,
+            xmin.data_ptr(), xmax.data_ptr(), st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+        N_.check(rc, "pw")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0][:, :Co].double()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 2e-6 * scale + 1e-6
+    if ldo > Co:
+        assert (outs[0][:, Co:] == -7.0).all()
+    assert xmin.item() == got.min().item() and xmax.item() == got.max().item()      # "+=" initialisation from (0, 0)
+
+
 @pytest.mark.parametrize("stride,R", [(4, 64), (2, 50), (4, 37)])
 def test_stem_conv(stride, R):
     from codenet_amd import _native as N_, ops
