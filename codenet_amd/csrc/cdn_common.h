@@ -76,6 +76,61 @@ __device__ __forceinline__ float ord2f(unsigned o) {
   const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
   return __uint_as_float(u);
 }
+// Cross-lane fetch of a tap-geometry record WITHOUT the LDS pipeline: v_mov_b32 dpp row_newbcast:J
+// copies the value held by lane J of each 16-lane row to every lane of that row (VALU only; the
+// compiler folds single-use movs into the consuming instruction's DPP operand).  ds_bpermute costs
+// ~8 LDS-pipeline cycles per instruction: with 18 (dw2) / 26 (dw2u) of them next to 25 ds_read_b128
+// (4 cycles each) per step the gather was LDS-issue bound on the bpermutes (in-kernel stamps,
+// tools/probes/probe_dw.hip).  The DPP control is an immediate, so the step index is dispatched
+// through a (wave-uniform) switch; HALVES: the two 8-lane halves of a row fetch different lanes
+// (J and 8 + J) with complementary bank masks.
+template <int J, bool HALVES>
+__device__ __forceinline__ int row_fetch(int v) {
+  // (mov_dpp: no defined "old" value, so no zero-initialising v_mov per fetch)
+  if (HALVES) {
+    const int a = __builtin_amdgcn_mov_dpp(v, 0x150 + J, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(a, v, 0x150 + 8 + J, 0xf, 0xc, false);
+  }
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + J, 0xf, 0xf, false);
+}
+template <bool HALVES, int NI, int NF>
+__device__ __forceinline__ void fetch_record(int j, const int (&gi)[NI], const float (&gf)[NF],
+                                             int (&oi)[NI], float (&of)[NF]) {
+#define CDN_CASE(J)                                                                          \
+  case J: {                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NI; ++q) oi[q] = row_fetch<J, HALVES>(gi[q]);       \
+    _Pragma("unroll") for (int q = 0; q < NF; ++q)                                           \
+        of[q] = __int_as_float(row_fetch<J, HALVES>(__float_as_int(gf[q])));                 \
+  } break;
+  if (HALVES) {
+    switch (j) { CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) CDN_CASE(4) CDN_CASE(5) CDN_CASE(6) CDN_CASE(7) }
+  } else {
+    switch (j) {
+      CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) CDN_CASE(4) CDN_CASE(5) CDN_CASE(6) CDN_CASE(7)
+      CDN_CASE(8) CDN_CASE(9) CDN_CASE(10) CDN_CASE(11) CDN_CASE(12) CDN_CASE(13) CDN_CASE(14) CDN_CASE(15)
+    }
+  }
+#undef CDN_CASE
+}
+// lane -> owned item of a 64-item batch such that the record of (step j, group g) sits in the DPP row
+// of the lanes that consume it: row lane j (16 lanes per item) or half-row lane j (8 lanes per item)
+template <int LPP>
+__device__ __forceinline__ int owner_item(int lane) {
+  return LPP == 16 ? (lane & 15) * 4 + (lane >> 4)
+                   : (lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1));
+}
+// rint(x) as a 64-bit integer for |x| < 2^51, three instructions (v_cvt_f64_f32, v_add_f64, one add on the high word):
+// x + 1.5 * 2^52 in double rounds to the nearest integer, ties to even, and its bit pattern is that of the constant
+// plus the integer.  __float2ll_rn compiles to ~13 VALU instructions (no 64-bit convert on gfx950); the gather
+// backward converts 25 contributions per (pixel, channel) and was VALU-bound on them (profiles/r05/dwbwd_pmc.txt).
+// Identical values to __float2ll_rn for finite x in range; NaN / Inf are the caller's business.
+__device__ __forceinline__ unsigned long long fixed_rn(float x) {
+  const double r = (double)x + 6755399441055744.0;
+  return (unsigned long long)(__double_as_longlong(r) - 0x4338000000000000LL);
+}
+// |v| as an unsigned integer image whose order is that of |v| with NaN above Inf: an integer max over these images
+// PROPAGATES a NaN (fmaxf drops it)
+__device__ __forceinline__ unsigned absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 // q = round(scale*x - zp) (half-even), no FMA contraction: quant_utils.py:33-41
 // `#pragma clang fp contract(off)` + plain operators: the ocml _rn intrinsics do NOT keep the compiler from fusing a
 // product into the following add / subtract (they bring their own fast-math flags into the caller).  Seen in the ISA:

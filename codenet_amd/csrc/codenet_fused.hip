@@ -371,49 +371,9 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
 //   s_raw    [n][Hl*Wl]  (scale at stored resolution; up-sampling replicates it)
 //   d        [n][H*W][C] channels-last output at stage resolution
 // ------------------------------------------------------------------------------------------
-// Cross-lane fetch of a tap-geometry record WITHOUT the LDS pipeline: v_mov_b32 dpp row_newbcast:J
-// copies the value held by lane J of each 16-lane row to every lane of that row (VALU only; the
-// compiler folds single-use movs into the consuming instruction's DPP operand).  ds_bpermute costs
-// ~8 LDS-pipeline cycles per instruction: with 18 (dw2) / 26 (dw2u) of them next to 25 ds_read_b128
-// (4 cycles each) per step the gather was LDS-issue bound on the bpermutes (in-kernel stamps,
-// tools/probes/probe_dw.hip).  The DPP control is an immediate, so the step index is dispatched
-// through a (wave-uniform) switch; HALVES: the two 8-lane halves of a row fetch different lanes
-// (J and 8 + J) with complementary bank masks.
-template <int J, bool HALVES>
-__device__ __forceinline__ int row_fetch(int v) {
-  // (mov_dpp: no defined "old" value, so no zero-initialising v_mov per fetch)
-  if (HALVES) {
-    const int a = __builtin_amdgcn_mov_dpp(v, 0x150 + J, 0xf, 0x3, false);
-    return __builtin_amdgcn_update_dpp(a, v, 0x150 + 8 + J, 0xf, 0xc, false);
-  }
-  return __builtin_amdgcn_mov_dpp(v, 0x150 + J, 0xf, 0xf, false);
-}
-template <bool HALVES, int NI, int NF>
-__device__ __forceinline__ void fetch_record(int j, const int (&gi)[NI], const float (&gf)[NF],
-                                             int (&oi)[NI], float (&of)[NF]) {
-#define CDN_CASE(J)                                                                          \
-  case J: {                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < NI; ++q) oi[q] = row_fetch<J, HALVES>(gi[q]);       \
-    _Pragma("unroll") for (int q = 0; q < NF; ++q)                                           \
-        of[q] = __int_as_float(row_fetch<J, HALVES>(__float_as_int(gf[q])));                 \
-  } break;
-  if (HALVES) {
-    switch (j) { CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) CDN_CASE(4) CDN_CASE(5) CDN_CASE(6) CDN_CASE(7) }
-  } else {
-    switch (j) {
-      CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) CDN_CASE(4) CDN_CASE(5) CDN_CASE(6) CDN_CASE(7)
-      CDN_CASE(8) CDN_CASE(9) CDN_CASE(10) CDN_CASE(11) CDN_CASE(12) CDN_CASE(13) CDN_CASE(14) CDN_CASE(15)
-    }
-  }
-#undef CDN_CASE
-}
-// lane -> owned item of a 64-item batch such that the record of (step j, group g) sits in the DPP row
-// of the lanes that consume it: row lane j (16 lanes per item) or half-row lane j (8 lanes per item)
-template <int LPP>
-__device__ __forceinline__ int owner_item(int lane) {
-  return LPP == 16 ? (lane & 15) * 4 + (lane >> 4)
-                   : (lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1));
-}
+// (row_fetch / fetch_record / owner_item: the DPP record fetch lives in cdn_common.h, shared with the gather backward)
+using cdn::fetch_record;
+using cdn::owner_item;
 #ifndef CDN_DPP16
 #define CDN_DPP16 1      // DPP fetch when an item spans a whole 16-lane row (CCH = 64)
 #endif

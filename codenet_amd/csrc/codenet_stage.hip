@@ -475,35 +475,37 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   }
   for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
   // ---- fixed-point scale of this workgroup: max |grad_d| over its slice, max |w| over its chunk --
+  // (integer maxima of the |.| bit images: a NaN in grad_d or the weights PROPAGATES -- fmaxf would drop it -- and the
+  // chunk's grad_x then comes out NaN like the reference's float atomics, not as a finite fixed-point sum)
   float gmax = 0.0f;
   {
     const int cc = min(CCH, C - c0);
     const float *gp = gd + ((long)n * C + c0) * HW;
-    for (int q = tid; q < cc * HW; q += nthreads) gmax = fmaxf(gmax, fabsf(gp[q]));
-    float wmax = 0.0f;
-    for (int q = tid; q < cc * 9; q += nthreads) wmax = fmaxf(wmax, fabsf(wd[(long)c0 * 9 + q]));
+    unsigned gb = 0u, wb = 0u;
+    for (int q = tid; q < cc * HW; q += nthreads) gb = max(gb, cdn::absbits(gp[q]));
+    for (int q = tid; q < cc * 9; q += nthreads) wb = max(wb, cdn::absbits(wd[(long)c0 * 9 + q]));
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
-      gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
-      wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64));
+      gb = max(gb, (unsigned)__shfl_xor((int)gb, m, 64));
+      wb = max(wb, (unsigned)__shfl_xor((int)wb, m, 64));
     }
     __syncthreads();   // (also orders the zero fill above)
     if ((tid & 63) == 0) {
-      red[2 * (tid >> 6)] = gmax;
-      red[2 * (tid >> 6) + 1] = wmax;
+      red[2 * (tid >> 6)] = __uint_as_float(gb);
+      red[2 * (tid >> 6) + 1] = __uint_as_float(wb);
     }
     __syncthreads();
-    gmax = 0.0f;
-    wmax = 0.0f;
+    gb = wb = 0u;
     for (int i = 0; i < nwaves; ++i) {
-      gmax = fmaxf(gmax, red[2 * i]);
-      wmax = fmaxf(wmax, red[2 * i + 1]);
+      gb = max(gb, __float_as_uint(red[2 * i]));
+      wb = max(wb, __float_as_uint(red[2 * i + 1]));
     }
-    gmax *= wmax;      // bound of |bilinear weight * g * w|
+    gmax = __uint_as_float(gb) * __uint_as_float(wb);      // bound of |bilinear weight * g * w|; NaN / Inf when either holds one
   }
+  const bool poisoned = !(gmax < INFINITY);                 // workgroup-uniform
   int e = 0;
   (void)frexpf(gmax, &e);                 // gmax < 2^e
-  if (!(gmax > 0.0f) || !(gmax < INFINITY)) e = 0;
+  if (!(gmax > 0.0f) || poisoned) e = 0;
   // 2^(40-e) and 2^(e-40) must both be finite, normal floats: for gradients below ~2^-86 the scale would
   // overflow to inf (0 * inf = NaN in the scatter); clamp -- such contributions keep >= 2^-126 resolution
   e = max(-86, min(e, 126 + 40));
@@ -535,82 +537,130 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     wk[k] = ch_ok ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;
     gwa[k] = 0.0f;
   }
-  auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? yy : H) * Wc * CCH; };
-  auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH + cl; };
-  auto scatter = [&](int o, float c) {
-    atomicAdd(&gimg[o], (unsigned long long)__float2ll_rn(c * scale));
+  // (24-bit multiply: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter of it; offsets are far below 2^24)
+  auto row_off = [&](int yy) { return (int)__umul24((unsigned)(((unsigned)yy < (unsigned)H) ? yy : H), (unsigned)(Wc * CCH)); };
+  auto col_off0 = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH; };     // (+ the lane's channel)
+  auto scatter_s = [&](int o, float cs) {      // cs: the contribution already times the fixed-point scale
+    atomicAdd(&gimg[o], cdn::fixed_rn(cs));
   };
 
-  for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) {
-    const int p = p0 + sub;
+  // One step = PPW pixels x CCH channels.  rec: what a step needs of its pixel -- everything that does not depend on the
+  // channel: five row offsets (ya.i0, ya.i0 + 1, yb.i0, yb.i0 + 1, h), five column offsets (xa.i0, xa.i0 + 1, xb.i0,
+  // xb.i0 + 1, w; without the lane's channel), the pixel index (-1: beyond the plane), eight axis weights and the four
+  // in-range flags as 0 / 1 floats.
+  struct Rec {
+    int r[5], c[5], p;
+    float w[8], ok[4];
+  };
+  auto geometry = [&](int p) {       // the reference's sampling geometry of pixel p (_kernel.cu:220-232)
+    Rec g;
     const bool live = p < HW;
     const int pp = live ? p : 0;
     const int h = pp / W, w = pp - h * W;
     const float t = s[(long)n * HW + pp] - 1.0f;
     const Axis ya = make_axis(h - 1, -t, H), yb = make_axis(h + 1, t, H);
     const Axis xa = make_axis(w - 1, -t, W), xb = make_axis(w + 1, t, W);
+    g.r[0] = row_off(ya.i0); g.r[1] = row_off(ya.i0 + 1); g.r[2] = row_off(yb.i0); g.r[3] = row_off(yb.i0 + 1);
+    g.r[4] = row_off(h);
+    g.c[0] = col_off0(xa.i0); g.c[1] = col_off0(xa.i0 + 1); g.c[2] = col_off0(xb.i0); g.c[3] = col_off0(xb.i0 + 1);
+    g.c[4] = col_off0(w);
+    g.p = live ? p : -1;
+    g.w[0] = ya.w0; g.w[1] = ya.w1; g.w[2] = yb.w0; g.w[3] = yb.w1;
+    g.w[4] = xa.w0; g.w[5] = xa.w1; g.w[6] = xb.w0; g.w[7] = xb.w1;
+    g.ok[0] = ya.ok ? 1.0f : 0.0f; g.ok[1] = yb.ok ? 1.0f : 0.0f;
+    g.ok[2] = xa.ok ? 1.0f : 0.0f; g.ok[3] = xb.ok ? 1.0f : 0.0f;
+    return g;
+  };
+  auto step = [&](const Rec &R) {
+    const bool live = R.p >= 0;
+    const int pp = live ? R.p : 0;
     const float g = (live && ch_ok) ? gd[((long)n * C + c0 + cl) * HW + pp] : 0.0f;
+    const float gsc = g * scale;            // (power-of-two scale: commutes with the roundings of the products below)
     float gs_acc = 0.0f;
-    auto tap = [&](const Axis &Y, const Axis &X, float ay, float ax, int k) {
-      const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1);
-      const int q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
-      const float v00 = ximg[r0 + q0], v01 = ximg[r0 + q1], v10 = ximg[r1 + q0], v11 = ximg[r1 + q1];
-      const float w00 = Y.w0 * X.w0, w01 = Y.w0 * X.w1, w10 = Y.w1 * X.w0, w11 = Y.w1 * X.w1;
+    int c[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) c[q] = R.c[q] + cl;
+    // corner tap: rows (ra, ra + 1 -> offsets r0, r1), columns (q0, q1), axis weights (y0, y1) x (x0, x1)
+    auto tap = [&](int r0, int r1, int q0, int q1, float y0, float y1, float x0, float x1, float okf, float ay,
+                   float ax, int k) {
+      const int o00 = r0 + q0, o01 = r0 + q1, o10 = r1 + q0, o11 = r1 + q1;
+      const float v00 = ximg[o00], v01 = ximg[o01], v10 = ximg[o10], v11 = ximg[o11];
+      const float w00 = y0 * x0, w01 = y0 * x1, w10 = y1 * x0, w11 = y1 * x1;
       const float S = (w00 * v00 + w01 * v01) + w10 * v10 + w11 * v11;
       const float gk = g * wk[k];
       if (gx != nullptr) {
-        scatter(r0 + q0, w00 * gk);
-        scatter(r0 + q1, w01 * gk);
-        scatter(r1 + q0, w10 * gk);
-        scatter(r1 + q1, w11 * gk);
+        const float gks = gsc * wk[k];
+        scatter_s(o00, w00 * gks);
+        scatter_s(o01, w01 * gks);
+        scatter_s(o10, w10 * gks);
+        scatter_s(o11, w11 * gks);
       }
-      const float okf = (Y.ok && X.ok) ? 1.0f : 0.0f;
-      const float dSdy = X.w0 * (v10 - v00) + X.w1 * (v11 - v01);
-      const float dSdx = Y.w0 * (v01 - v00) + Y.w1 * (v11 - v10);
+      const float dSdy = x0 * (v10 - v00) + x1 * (v11 - v01);
+      const float dSdx = y0 * (v01 - v00) + y1 * (v11 - v10);
       gs_acc += okf * gk * (ay * dSdy + ax * dSdx);
       gwa[k] = fmaf(g, S, gwa[k]);
     };
-    // edge / centre taps touch only the cells with non-zero weight
-    auto tap_v = [&](const Axis &Y, float ay, int k) {     // column exact
-      const int r0 = row_off(Y.i0), r1 = row_off(Y.i0 + 1), q0 = col_off(w);
-      const float v0 = ximg[r0 + q0], v1 = ximg[r1 + q0];
+    // edge taps touch only the two cells with non-zero weight: (o0, o1) with weights (a0, a1)
+    auto tap2 = [&](int o0, int o1, float a0, float a1, float okf, float sign, int k) {
+      const float v0 = ximg[o0], v1 = ximg[o1];
       const float gk = g * wk[k];
       if (gx != nullptr) {
-        scatter(r0 + q0, Y.w0 * gk);
-        scatter(r1 + q0, Y.w1 * gk);
+        const float gks = gsc * wk[k];
+        scatter_s(o0, a0 * gks);
+        scatter_s(o1, a1 * gks);
       }
-      gs_acc += (Y.ok ? 1.0f : 0.0f) * gk * ay * (v1 - v0);
-      gwa[k] = fmaf(g, Y.w0 * v0 + Y.w1 * v1, gwa[k]);
+      gs_acc += okf * gk * sign * (v1 - v0);
+      gwa[k] = fmaf(g, a0 * v0 + a1 * v1, gwa[k]);
     };
-    auto tap_h = [&](const Axis &X, float ax, int k) {     // row exact
-      const int r0 = row_off(h), q0 = col_off(X.i0), q1 = col_off(X.i0 + 1);
-      const float v0 = ximg[r0 + q0], v1 = ximg[r0 + q1];
-      const float gk = g * wk[k];
-      if (gx != nullptr) {
-        scatter(r0 + q0, X.w0 * gk);
-        scatter(r0 + q1, X.w1 * gk);
-      }
-      gs_acc += (X.ok ? 1.0f : 0.0f) * gk * ax * (v1 - v0);
-      gwa[k] = fmaf(g, X.w0 * v0 + X.w1 * v1, gwa[k]);
-    };
-    tap(ya, xa, -1.f, -1.f, 0);
-    tap_v(ya, -1.f, 1);
-    tap(ya, xb, -1.f, 1.f, 2);
-    tap_h(xa, -1.f, 3);
+    const float *w8 = R.w;
+    tap(R.r[0], R.r[1], c[0], c[1], w8[0], w8[1], w8[4], w8[5], R.ok[0] * R.ok[2], -1.f, -1.f, 0);
+    tap2(R.r[0] + c[4], R.r[1] + c[4], w8[0], w8[1], R.ok[0], -1.f, 1);
+    tap(R.r[0], R.r[1], c[2], c[3], w8[0], w8[1], w8[6], w8[7], R.ok[0] * R.ok[3], -1.f, 1.f, 2);
+    tap2(R.r[4] + c[0], R.r[4] + c[1], w8[4], w8[5], R.ok[2], -1.f, 3);
     {
-      const int o = row_off(h) + col_off(w);
-      if (gx != nullptr) scatter(o, g * wk[4]);
+      const int o = R.r[4] + c[4];
+      if (gx != nullptr) scatter_s(o, gsc * wk[4]);
       gwa[4] = fmaf(g, ximg[o], gwa[4]);
     }
-    tap_h(xb, 1.f, 5);
-    tap(yb, xa, 1.f, -1.f, 6);
-    tap_v(yb, 1.f, 7);
-    tap(yb, xb, 1.f, 1.f, 8);
+    tap2(R.r[4] + c[2], R.r[4] + c[3], w8[6], w8[7], R.ok[3], 1.f, 5);
+    tap(R.r[2], R.r[3], c[0], c[1], w8[2], w8[3], w8[4], w8[5], R.ok[1] * R.ok[2], 1.f, -1.f, 6);
+    tap2(R.r[2] + c[4], R.r[3] + c[4], w8[2], w8[3], R.ok[1], 1.f, 7);
+    tap(R.r[2], R.r[3], c[2], c[3], w8[2], w8[3], w8[6], w8[7], R.ok[1] * R.ok[3], 1.f, 1.f, 8);
     if (gs != nullptr) {
 #pragma unroll
       for (int m = CCH / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
-      if (cl == 0 && live) atomicAdd(&gs[(long)n * HW + p], gs_acc);
+      if (cl == 0 && live) atomicAdd(&gs[(long)n * HW + R.p], gs_acc);
     }
+  };
+  if (CCH == 16 || CCH == 8) {
+    // The kernel is VALU-bound (profiles/r05/dwbwd_pmc.txt: VALU busy 0.80 of the kernel's cycles, LDS 0.2) and a
+    // third of its VALU work was the tap geometry, which every one of a pixel's CCH lanes repeated.  Geometry phase:
+    // lane <-> pixel, one record per lane for a batch of 64 pixels = 64 / PPW steps; in step j the lanes of a pixel fetch
+    // its record from the owner lane with DPP row broadcasts (cdn::fetch_record: VALU moves, no LDS).
+    constexpr int LPP = CCH, SPB = 64 / PPW;      // lanes per pixel; steps per batch
+    const int nsteps = (HW + nwaves * PPW - 1) / (nwaves * PPW);
+    for (int sb = 0; sb < nsteps; sb += SPB) {
+      const int own = cdn::owner_item<LPP>(lane);                  // = j * PPW + group
+      const Rec G = geometry((wave + (sb + own / PPW) * nwaves) * PPW + own % PPW);
+#pragma unroll 1
+      for (int j = 0; j < SPB && sb + j < nsteps; ++j) {
+        int gi[11] = {G.r[0], G.r[1], G.r[2], G.r[3], G.r[4], G.c[0], G.c[1], G.c[2], G.c[3], G.c[4], G.p}, oi[11];
+        float gf[12] = {G.w[0], G.w[1], G.w[2], G.w[3], G.w[4], G.w[5], G.w[6], G.w[7], G.ok[0], G.ok[1], G.ok[2],
+                        G.ok[3]}, of[12];
+        cdn::fetch_record<LPP == 8>(j, gi, gf, oi, of);
+        Rec R;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { R.r[q] = oi[q]; R.c[q] = oi[5 + q]; }
+        R.p = oi[10];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) R.w[q] = of[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R.ok[q] = of[8 + q];
+        step(R);
+      }
+    }
+  } else {
+    for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) step(geometry(p0 + sub));
   }
   if (gw != nullptr && ch_ok) {
 #pragma unroll
@@ -630,7 +680,8 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const int pix = min(j * 4 + e4, HW - 1);
-        v[e4] = __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
+        v[e4] = poisoned ? __uint_as_float(0x7fc00000u)
+                         : __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
       }
       float *gp = gx + ((long)n * C + c0 + c) * HW + j * 4;
       if (vec) {
@@ -713,35 +764,36 @@ dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const 
     gimg[q] = 0ull;
   }
   for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
-  float gmax = 0.0f;
+  float gmax = 0.0f;      // (NaN-propagating integer maxima, as in dw_bwd2_kernel)
   {
     const int cc = min(CCH, C - c0);
     const float *gp = gd + ((long)n * C + c0) * HW;
-    for (int q = tid; q < cc * HW; q += nthreads) gmax = fmaxf(gmax, fabsf(gp[q]));
-    float wmax = 0.0f;
-    for (int q = tid; q < cc * 9; q += nthreads) wmax = fmaxf(wmax, fabsf(wd[(long)c0 * 9 + q]));
+    unsigned gb = 0u, wb = 0u;
+    for (int q = tid; q < cc * HW; q += nthreads) gb = max(gb, cdn::absbits(gp[q]));
+    for (int q = tid; q < cc * 9; q += nthreads) wb = max(wb, cdn::absbits(wd[(long)c0 * 9 + q]));
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
-      gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
-      wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64));
+      gb = max(gb, (unsigned)__shfl_xor((int)gb, m, 64));
+      wb = max(wb, (unsigned)__shfl_xor((int)wb, m, 64));
     }
     __syncthreads();   // (also orders the zero fill above)
     if ((tid & 63) == 0) {
-      red[2 * (tid >> 6)] = gmax;
-      red[2 * (tid >> 6) + 1] = wmax;
+      red[2 * (tid >> 6)] = __uint_as_float(gb);
+      red[2 * (tid >> 6) + 1] = __uint_as_float(wb);
     }
     __syncthreads();
-    gmax = 0.0f;
-    wmax = 0.0f;
+    gb = wb = 0u;
     for (int i = 0; i < nwaves; ++i) {
-      gmax = fmaxf(gmax, red[2 * i]);
-      wmax = fmaxf(wmax, red[2 * i + 1]);
+      gb = max(gb, __float_as_uint(red[2 * i]));
+      wb = max(wb, __float_as_uint(red[2 * i + 1]));
     }
-    gmax *= 4.0f * wmax;      // bound of one scattered value: four pixels' |bilinear weight * g * w| folded onto a cell
+    // bound of one scattered value: four pixels' |bilinear weight * g * w| folded onto a cell
+    gmax = __uint_as_float(gb) * (4.0f * __uint_as_float(wb));
   }
+  const bool poisoned = !(gmax < INFINITY);
   int e = 0;
   (void)frexpf(gmax, &e);
-  if (!(gmax > 0.0f) || !(gmax < INFINITY)) e = 0;
+  if (!(gmax > 0.0f) || poisoned) e = 0;
   e = max(-86, min(e, 126 + 40));
   const float scale = ldexpf(1.0f, 40 - e), inv_scale = ldexpf(1.0f, e - 40);
   {   // stage the stored planes: lane <-> channel, 4 stored pixels per thread
@@ -769,10 +821,11 @@ dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const 
     gwa[k] = 0.0f;
   }
   // stored row / column index -> LDS offset; every index outside the stored plane is the zero row / zero column
-  auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)Hs) ? yy : Hs) * Wc * CCH; };
+  // (24-bit multiply: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter of it; offsets are far below 2^24)
+  auto row_off = [&](int yy) { return (int)__umul24((unsigned)(((unsigned)yy < (unsigned)Hs) ? yy : Hs), (unsigned)(Wc * CCH)); };
   auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)Ws) ? xx : Ws) * CCH + cl; };
   auto scatter = [&](int o, float c) {
-    atomicAdd(&gimg[o], (unsigned long long)__float2ll_rn(c * scale));
+    atomicAdd(&gimg[o], cdn::fixed_rn(c * scale));
   };
 
   for (int b0 = wave * PPW; b0 < HWs; b0 += nwaves * PPW) {
@@ -918,7 +971,8 @@ dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const 
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const int pix = min(j * 4 + e4, HWs - 1);
-        v[e4] = __ll2float_rn((long long)gimg[((pix / Ws) * Wc + (pix % Ws)) * CCH + c]) * inv_scale;
+        v[e4] = poisoned ? __uint_as_float(0x7fc00000u)
+                         : __ll2float_rn((long long)gimg[((pix / Ws) * Wc + (pix % Ws)) * CCH + c]) * inv_scale;
       }
       float *gp = gx + ((long)n * C + c0 + c) * HWs + j * 4;
       if (vec) {

@@ -451,33 +451,36 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
   }
   for (int q = tid; q < CCH * 9; q += nthreads) gwl[q] = 0.0f;
   float scale = 1.0f, inv_scale = 1.0f;
+  bool poisoned = false;      // workgroup-uniform: grad_output or the weights of this chunk hold a NaN / Inf
   if (WANT_GX) {      // fixed-point scale of this workgroup: largest contribution ~ 2^40
-    float gmax = 0.0f, wmax = 0.0f;
+    // (integer maxima of the |.| bit images: a NaN in grad_output / weight propagates -- fmaxf drops it -- and this
+    // chunk's grad_input comes out NaN like the reference's float atomics, _kernel.cu:329)
     const int cc = min(CCH, C - c0);
     const float *gp = gd + ((long)n * C + c0) * HW;
-    for (int q = tid; q < cc * HW; q += nthreads) gmax = fmaxf(gmax, fabsf(gp[q]));
-    for (int q = tid; q < cc * 9; q += nthreads) wmax = fmaxf(wmax, fabsf(wd[(long)c0 * 9 + q]));
+    unsigned gb = 0u, wb = 0u;
+    for (int q = tid; q < cc * HW; q += nthreads) gb = max(gb, cdn::absbits(gp[q]));
+    for (int q = tid; q < cc * 9; q += nthreads) wb = max(wb, cdn::absbits(wd[(long)c0 * 9 + q]));
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
-      gmax = fmaxf(gmax, __shfl_xor(gmax, m, 64));
-      wmax = fmaxf(wmax, __shfl_xor(wmax, m, 64));
+      gb = max(gb, (unsigned)__shfl_xor((int)gb, m, 64));
+      wb = max(wb, (unsigned)__shfl_xor((int)wb, m, 64));
     }
     __syncthreads();
     if ((tid & 63) == 0) {
-      red[2 * (tid >> 6)] = gmax;
-      red[2 * (tid >> 6) + 1] = wmax;
+      red[2 * (tid >> 6)] = __uint_as_float(gb);
+      red[2 * (tid >> 6) + 1] = __uint_as_float(wb);
     }
     __syncthreads();
-    gmax = 0.0f;
-    wmax = 0.0f;
+    gb = wb = 0u;
     for (int i = 0; i < nwaves; ++i) {
-      gmax = fmaxf(gmax, red[2 * i]);
-      wmax = fmaxf(wmax, red[2 * i + 1]);
+      gb = max(gb, __float_as_uint(red[2 * i]));
+      wb = max(wb, __float_as_uint(red[2 * i + 1]));
     }
-    gmax *= wmax;
+    const float gmax = __uint_as_float(gb) * __uint_as_float(wb);
+    poisoned = !(gmax < INFINITY);
     int e = 0;
     (void)frexpf(gmax, &e);
-    if (!(gmax > 0.0f) || !(gmax < INFINITY)) e = 0;
+    if (!(gmax > 0.0f) || poisoned) e = 0;
     e = max(-86, min(e, 126 + 40));
     scale = ldexpf(1.0f, 40 - e);
     inv_scale = ldexpf(1.0f, e - 40);
@@ -508,7 +511,8 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
     wk[k] = (WANT_GX && ch_ok) ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;     // (the _parameters call has no weights)
     gwa[k] = 0.0f;
   }
-  auto row_off = [&](int yy) { return (((unsigned)yy < (unsigned)H) ? yy : H) * Wc * CCH; };
+  // (24-bit multiply: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter of it; offsets are far below 2^24)
+  auto row_off = [&](int yy) { return (int)__umul24((unsigned)(((unsigned)yy < (unsigned)H) ? yy : H), (unsigned)(Wc * CCH)); };
   auto col_off = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH + cl; };
   for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) {
     const int p = p0 + sub;
@@ -531,10 +535,10 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
       const float gk = g * wk[k];
       if (WANT_GX) {
         if (gx != nullptr) {
-          atomicAdd(&gimg[r0 + q0], (unsigned long long)__float2ll_rn(w00 * gk * scale));
-          atomicAdd(&gimg[r0 + q1], (unsigned long long)__float2ll_rn(w01 * gk * scale));
-          atomicAdd(&gimg[r1 + q0], (unsigned long long)__float2ll_rn(w10 * gk * scale));
-          atomicAdd(&gimg[r1 + q1], (unsigned long long)__float2ll_rn(w11 * gk * scale));
+          atomicAdd(&gimg[r0 + q0], cdn::fixed_rn(w00 * gk * scale));
+          atomicAdd(&gimg[r0 + q1], cdn::fixed_rn(w01 * gk * scale));
+          atomicAdd(&gimg[r1 + q0], cdn::fixed_rn(w10 * gk * scale));
+          atomicAdd(&gimg[r1 + q1], cdn::fixed_rn(w11 * gk * scale));
         }
         if (goff != nullptr) {
           // d(sample)/dh and d(sample)/dw (get_coordinate_weight, _kernel.cu:144-187); zero weights when outside
@@ -571,7 +575,8 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const int pix = min(j * 4 + e4, HW - 1);
-        v[e4] = __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
+        v[e4] = poisoned ? __uint_as_float(0x7fc00000u)
+                         : __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
       }
       float *gp = gx + ((long)n * C + c0 + c) * HW + j * 4;
       if (vec) {
