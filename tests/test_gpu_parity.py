@@ -570,6 +570,41 @@ def test_codenet_dw_backward_grad_x_is_bitwise_reproducible():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_codenet_dw_backward_propagates_a_nan_in_grad_output():
+    """grad_x is a fixed-point sum; a NaN (a diverged QAT step) in grad_output must not come out finite.  The
+    workgroup's scale search propagates it (integer maxima of the |.| bit images) and the poisoned (image, channel chunk)
+    gets a NaN grad_x like the reference's float atomics (_kernel.cu:329) would give its touched cells; every other chunk
+    keeps its values bit for bit; grad_s / grad_w carry the NaN through their float sums.  Full-resolution and
+    stored-resolution kernels, and the generic deform_conv backward's depthwise path."""
+    from codenet_amd import ops
+    from codenet_amd.functions.dcn_deform_conv import deform_conv
+    N, C, H, W = 2, 64, 16, 16
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    s = torch.empty(N, 1, H, W).uniform_(-2, 3, generator=g).cuda()
+    w = (torch.randn(C, 1, 3, 3, generator=g) / 3).cuda()
+    go = torch.randn(N, C, H, W, generator=g).cuda()
+    bad = go.clone()
+    bad[1, 37, 5, 6] = float("nan")
+
+    def grads(gout):
+        xg, sg = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        ops.codenet_dw(xg, sg, w).backward(gout)
+        return xg.grad, sg.grad
+    gx0, _ = grads(go)
+    gx1, gs1 = grads(bad)
+    assert torch.isnan(gx1[1, 37]).all(), "the poisoned channel's grad_x must be NaN"
+    assert torch.equal(gx1[0], gx0[0]) and torch.isfinite(gx1[0]).all()
+    clean = torch.isfinite(gx1[1]).all(dim=(1, 2))                       # channels of image 1 outside the poisoned chunk
+    assert clean.sum().item() >= C - 32 and torch.equal(gx1[1][clean], gx0[1][clean])
+    assert torch.isnan(gs1[1]).any() and torch.isfinite(gs1[0]).all()
+    # generic entry points with the CoDeNet call geometry (dwo_bwd_kernel)
+    off = (Q.ANCHOR.cuda() * (s - 1)).contiguous()
+    xg = x.clone().requires_grad_(True)
+    deform_conv(xg, off, w, 1, 1, 1, C, 1).backward(bad)
+    assert torch.isnan(xg.grad[1, 37]).all() and torch.isfinite(xg.grad[0]).all()
+
+
 # ---- detection heads on the stage kernels (SURVEY.md section 8f row 1) ---------------------------
 
 def _head_modules(C, classes, g, quantized, pct=False):

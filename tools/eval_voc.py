@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--flip_test", action="store_true")
     ap.add_argument("--limit", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/voc_eval")
+    ap.add_argument("--proxy-images", type=int, default=0, help="without data / checkpoint: also run the detection-"
+                    "agreement proxy on this many synthetic images (tests/proxy_agreement.py; SURVEY 8(d) asks for >= 256)")
+    ap.add_argument("--proxy-out", default="", help="JSON file for the at-size proxy")
     ap.add_argument("--reference-ap50", type=float, default=None, help="the reference's AP50 for this config "
                     "(README.md:14-18) to print the delta")
     args = ap.parse_args()
@@ -223,6 +226,14 @@ def main():
         run_voc(args)
     else:
         run_proxy(args)
+        if args.proxy_images > 0:
+            # the proxy at size (>= 256 images): the GPU build against the CPU oracle path.  The comparison
+            # uses oracle/, which only tests/ may import: it lives in tests/proxy_agreement.py and runs as a child process
+            import subprocess
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            cmd = [sys.executable, os.path.join(root, "tests", "proxy_agreement.py"), "--images", str(args.proxy_images),
+                   "--res", str(args.res)] + (["--out", args.proxy_out] if args.proxy_out else [])
+            sys.exit(subprocess.call(cmd))
 
 
 if __name__ == "__main__":
