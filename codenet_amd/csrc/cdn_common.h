@@ -131,6 +131,46 @@ __device__ __forceinline__ unsigned long long fixed_rn(float x) {
 // |v| as an unsigned integer image whose order is that of |v| with NaN above Inf: an integer max over these images
 // PROPAGATES a NaN (fmaxf drops it)
 __device__ __forceinline__ unsigned absbits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+// ---- NaN-propagating range reductions.  The reference's batch statistics are x.min() / x.max()
+// (quant_modules.py:203-219), which return NaN when the tensor holds one -- the tracked range is NaN from then on and a
+// diverged QAT step is loud.  fminf / fmaxf (v_min_f32 / v_max_f32, v_min3 / v_max3) DROP a NaN, so: every producer keeps
+// a per-thread flag next to its running extremes (`has_nan |= v != v`: a compare whose result lives in a scalar mask),
+// poisons its pair before the workgroup reduction -- nan_lo / nan_hi: the canonical -NaN / +NaN -- and every reduction
+// above a thread runs on the ORDERED-UINT KEYS (key_lo = ~f2ord(min), key_hi = f2ord(max); larger key = more extreme),
+// where -NaN / +NaN are the largest keys of their slot: an integer max propagates them at the cost of the float one.
+// ReLU / Hardtanh as torch computes them: a NaN stays a NaN (fmaxf / fminf would return the bound)
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.0f ? 0.0f : v; }
+__device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float nan_lo(float mn, bool poisoned) { return poisoned ? __uint_as_float(0xffc00000u) : mn; }
+__device__ __forceinline__ float nan_hi(float mx, bool poisoned) { return poisoned ? __uint_as_float(0x7fc00000u) : mx; }
+__device__ __forceinline__ unsigned key_lo(float mn) { return ~f2ord(mn); }
+__device__ __forceinline__ unsigned key_hi(float mx) { return f2ord(mx); }
+__device__ __forceinline__ float unkey_lo(unsigned k) { return ord2f(~k); }
+__device__ __forceinline__ float unkey_hi(unsigned k) { return ord2f(k); }
+// the two keys over the 64 lanes of a wave
+__device__ __forceinline__ void wave_key_max(unsigned &klo, unsigned &khi) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    klo = max(klo, (unsigned)__shfl_xor((int)klo, m, 64));
+    khi = max(khi, (unsigned)__shfl_xor((int)khi, m, 64));
+  }
+}
+// A tensor that is NaN throughout -- the state of everything behind a poisoned range: scale and zero-point are NaN, so
+// every fake-quantised value is -- never moves a producer's extremes: its reduction ends on the EMPTY pair (+inf, -inf),
+// which no real tensor produces.  The final stage of every reduction reads it as NaN (free; this is what lets the
+// VALU-bound kernels go without a per-element flag).
+__device__ __forceinline__ void empty_pair_is_nan(unsigned &klo, unsigned &khi) {
+  if (klo == key_lo(INFINITY) && khi == key_hi(-INFINITY)) {
+    klo = key_lo(__uint_as_float(0xffc00000u));
+    khi = key_hi(__uint_as_float(0x7fc00000u));
+  }
+}
+// a {min, max} pair some producer stored (possibly poisoned) folded into running extremes + flag
+__device__ __forceinline__ void fold_pair(float2 v, float &mn, float &mx, bool &has_nan) {
+  mn = fminf(mn, v.x);
+  mx = fmaxf(mx, v.y);
+  has_nan |= (v.x != v.x) | (v.y != v.y);
+}
 // q = round(scale*x - zp) (half-even), no FMA contraction: quant_utils.py:33-41
 // `#pragma clang fp contract(off)` + plain operators: the ocml _rn intrinsics do NOT keep the compiler from fusing a
 // product into the following add / subtract (they bring their own fast-math flags into the caller).  Seen in the ISA:
@@ -249,16 +289,15 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *partials, int bid,
                                                     int nblocks, const QUpdate &u, float *red) {
   (void)partials;
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, m, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-  }
+  // (keys: see "NaN-propagating range reductions" above; mn / mx may be the poisoned pair of nan_lo / nan_hi)
+  unsigned klo = key_lo(mn), khi = key_hi(mx);
+  wave_key_max(klo, khi);
+  unsigned *redu = reinterpret_cast<unsigned *>(red);
   const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   lds_barrier();      // `red` may alias tiles other waves are still reading
   if ((threadIdx.x & 63) == 0) {
-    red[2 * wave] = mn;
-    red[2 * wave + 1] = mx;
+    redu[2 * wave] = klo;
+    redu[2 * wave + 1] = khi;
   }
   lds_barrier();
   float pre_lo = 0.f, pre_hi = 0.f;
@@ -266,16 +305,16 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
     pre_lo = u.x_min[0];      // in flight during the ticket round trip (only the last arriver uses them)
     pre_hi = u.x_max[0];
     for (int i = 1; i < nw; ++i) {
-      mn = fminf(mn, red[2 * i]);
-      mx = fmaxf(mx, red[2 * i + 1]);
+      klo = max(klo, redu[2 * i]);
+      khi = max(khi, redu[2 * i + 1]);
     }
     const int ngroups = nblocks < kArriveGroups ? nblocks : kArriveGroups;
     const int g = bid % kArriveGroups;
     const unsigned gsize = (unsigned)((nblocks - g + kArriveGroups - 1) / kArriveGroups);
     unsigned *line = u.counters + 16 * g;
     bool last = false;
-    (void)__hip_atomic_fetch_max(line + 1, ~f2ord(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_fetch_max(line + 2, f2ord(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(line + 1, klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_max(line + 2, khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned t1 = __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t1 == gsize - 1) {
       const unsigned t2 = __hip_atomic_fetch_add(&u.counters[16 * kArriveGroups], 1u,
@@ -289,19 +328,16 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
   // ---- last workgroup: wave 0 reads the group lines, updates ranges and parameters ---------------
   if (threadIdx.x < 64) {
     const int ngroups = nblocks < kArriveGroups ? nblocks : kArriveGroups;
-    mn = INFINITY;
-    mx = -INFINITY;
+    klo = key_lo(INFINITY);
+    khi = key_hi(-INFINITY);
     if ((int)threadIdx.x < ngroups) {
       unsigned *line = u.counters + 16 * threadIdx.x;
-      mn = ord2f(~__hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      mx = ord2f(__hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      klo = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      khi = __hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-      mn = fminf(mn, __shfl_xor(mn, m, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-    }
-    if (threadIdx.x == 0) quantact_update_device(u, mn, mx, true, true, pre_lo, pre_hi);
+    wave_key_max(klo, khi);
+    empty_pair_is_nan(klo, khi);
+    if (threadIdx.x == 0) quantact_update_device(u, unkey_lo(klo), unkey_hi(khi), true, true, pre_lo, pre_hi);
     // everybody has arrived: leave the lines zero again
     __hip_atomic_store(&u.counters[16 * threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&u.counters[16 * threadIdx.x + 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -315,23 +351,21 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
 // single contended word sustains only ~88 atomics/us on MI355X).  Every thread of the workgroup
 // must call it; `red` is >= 2*nwaves floats of LDS that nobody else is using.
 __device__ __forceinline__ void block_minmax_store(float mn, float mx, float2 *out, float *red) {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, m, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-  }
+  unsigned klo = key_lo(mn), khi = key_hi(mx);       // (NaN-propagating: see above)
+  wave_key_max(klo, khi);
+  unsigned *redu = reinterpret_cast<unsigned *>(red);
   const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   if ((threadIdx.x & 63) == 0) {
-    red[2 * wave] = mn;
-    red[2 * wave + 1] = mx;
+    redu[2 * wave] = klo;
+    redu[2 * wave + 1] = khi;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < nw; ++i) {
-      mn = fminf(mn, red[2 * i]);
-      mx = fmaxf(mx, red[2 * i + 1]);
+      klo = max(klo, redu[2 * i]);
+      khi = max(khi, redu[2 * i + 1]);
     }
-    *out = make_float2(mn, mx);
+    *out = make_float2(unkey_lo(klo), unkey_hi(khi));
   }
 }
 }  // namespace cdn

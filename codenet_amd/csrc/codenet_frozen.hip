@@ -150,7 +150,7 @@ __device__ __forceinline__ void pwq8_epilogue(
       const long m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m < M && co < Co) {
         float v = fmaf((float)(acc[j][r] + t128), rinv, bsv);
-        if (relu) v = fmaxf(v, 0.0f);
+        if (relu) v = cdn::relu_keep_nan(v);
         if (R8) {
           const int code = act_code8(v, c8, bad);
           R8[m * ldo + oc] = (signed char)code;
@@ -326,7 +326,7 @@ stemq8_kernel(const float *__restrict__ img, const float *__restrict__ w, const 
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
         acc += bias ? bias[co] : 0.0f;
-        if (relu) acc = fmaxf(acc, 0.0f);
+        if (relu) acc = cdn::relu_keep_nan(acc);
         pk |= (unsigned)(act_code8(acc, c8, bad) & 0xff) << (8 * e);
       }
       op[c4 >> 2] = pk;
@@ -419,7 +419,7 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float o = acc[e] + bs[e];
-            if (relu) o = fmaxf(o, 0.0f);
+            if (relu) o = cdn::relu_keep_nan(o);
             pk |= (unsigned)(act_code8(o, c8, bad) & 0xff) << (8 * e);
           }
           if (ox0 + sw < Wo) *reinterpret_cast<unsigned *>(ob + ((long)oy * Wo + ox0 + sw) * ld_out) = pk;
@@ -531,7 +531,7 @@ dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ a
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float o = acc[e] + bs[e];
-            if (dw_relu) o = fmaxf(o, 0.0f);
+            if (dw_relu) o = cdn::relu_keep_nan(o);
             pk |= (unsigned)(act_code8(o, c8, bad) & 0xff) << (8 * e);
           }
           *reinterpret_cast<unsigned *>(&As[(r * Wseg + sx * SW + sw) * QA + cb]) = pk;

@@ -147,6 +147,10 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// (No NaN flag here: the gather kernels are VALU-bound and a compare per output pair cost 15 % of them -- measured.  A NaN
+// of d comes from a NaN of x, the weights or s: the gather kernels test what they STAGE instead -- memory-bound phases --
+// and a tensor that is NaN throughout, the usual state behind a poisoned range, reduces to the empty pair (+inf, -inf),
+// which the range update reads as NaN: cdn_common.h.)
 __device__ __forceinline__ void track4(const float4 &a, float &mn, float &mn2, float &mx, float &mx2) {
   mn = min3f(mn, a.x, a.y);
   mn2 = min3f(mn2, a.z, a.w);
@@ -215,20 +219,22 @@ scale_nchw_kernel(const float *__restrict__ x, const float *__restrict__ w,
   red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (wave == 0) {
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < kScaleWaves; ++i) v += red[i][lane];
     v += b ? b[0] : 0.0f;
-    v = fminf(fmaxf(v, lo), hi);
+    v = cdn::clamp_keep_nan(v, lo, hi);
     if (live) {
       s[(long)n * HW + p] = v;
       mn = mx = v;
+      has_nan = (v != v);
     }
   }
   CDN_STAMPR(0, 2);
   if (mm)
-    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, &red[0][0]);
   CDN_STAMPR(0, 3);
 }
@@ -254,6 +260,7 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     qz = reinterpret_cast<const float *>(xq)[3];
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   for (long p = wave; p < npix; p += nwaves) {
     const float *xp = x + p * C;
     float acc = 0.f;
@@ -279,13 +286,14 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
     float v = acc + (b ? b[0] : 0.0f);
-    v = fminf(fmaxf(v, lo), hi);
+    v = cdn::clamp_keep_nan(v, lo, hi);
     if (lane == 0) s[p] = v;
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
+    has_nan |= (v != v);
   }
   CDN_STAMPR(0, 2);
-  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  if (mm) cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.x, gridDim.x, qu, red);
   CDN_STAMPR(0, 3);
 }
 
@@ -353,14 +361,16 @@ scale_nhwc_tile_kernel(const float *__restrict__ x, const unsigned *__restrict__
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (pix < tile_pix) {
     float r = acc + (b ? b[0] : 0.0f);
-    r = fminf(fmaxf(r, lo), hi);
+    r = cdn::clamp_keep_nan(r, lo, hi);
     if (k == 0) s[pix0 + pix] = r;
     mn = mx = r;
+    has_nan = (r != r);
   }
   CDN_STAMPR(0, 2);
-  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  if (mm) cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.x, gridDim.x, qu, red);
   CDN_STAMPR(0, 3);
 }
 
@@ -394,7 +404,7 @@ constexpr int kDw2MaxThreads = 1024;   // workgroup size is chosen per launch (5
 template <int CCH, bool OUT8>
 __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, const float *sl,
                                            float *__restrict__ d, int n, int c0, int C, int H, int W,
-                                           int kWaves, float &mn, float &mx,
+                                           int kWaves, float &mn, float &mx, bool &has_nan,
                                            const Code8 *c8 = nullptr, BadMask *bad = nullptr) {
   constexpr bool ADJ = true;
   constexpr int up = 0;
@@ -578,6 +588,7 @@ __device__ __forceinline__ void dw2_gather(const float4 *img, const float *wl, c
               dp[e] = av[e];
               mn = fminf(mn, av[e]);
               mx = fmaxf(mx, av[e]);
+              has_nan |= (av[e] != av[e]);
             }
         }
       }
@@ -643,6 +654,8 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   // flight per thread); a plain loop leaves ONE dependent load per thread in flight and the
   // staging then costs a full HBM round trip per iteration (measured: 21 of 58 us at stage 0).
   constexpr int kStageU = 8;
+  // a NaN of d comes from a NaN of what is staged here (x, the weights): tested in this memory-bound phase, not per output
+  bool has_nan = (w_pre != w_pre);
   if (X8) {
     const signed char *xg = reinterpret_cast<const signed char *>(x) + (long)n * HWl * C + c0;
     const int total = HWl * LPP;
@@ -689,6 +702,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             t.z = cdn::fake_quant_r(t.z, xs, xz, xr_);
             t.w = cdn::fake_quant_r(t.w, xs, xz, xr_);
           }
+          has_nan |= __builtin_isunordered(t.x, t.y) | __builtin_isunordered(t.z, t.w);
           img[((pix / Wl) * Wc + (pix % Wl)) * LPP + cq] = t;
         }
       }
@@ -719,6 +733,7 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
             for (int e = 0; e < 4; ++e) {
               const int pix = j * 4 + e;
               const float t = XQ ? cdn::fake_quant_r(e4[e], xs, xz, xr_) : e4[e];
+              has_nan |= live && (t != t);
               imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = live ? t : 0.0f;
             }
           }
@@ -738,8 +753,11 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int pix = j * 4 + e;
-          if (pix < HWl)
-            imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = XQ ? cdn::fake_quant_r(v[e], xs, xz, xr_) : v[e];
+          if (pix < HWl) {
+            const float t = XQ ? cdn::fake_quant_r(v[e], xs, xz, xr_) : v[e];
+            has_nan |= (t != t);
+            imgf[((pix / Wl) * Wc + (pix % Wl)) * CCH + cl] = t;
+          }
         }
       }
     }
@@ -761,15 +779,15 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   if (OUT8) {
     BadMask bad = 0;
     const Code8 c8 = make_code8(qu.state, bad);
-    dw2_gather<CCH, true>(img, wl, sl, d, n, c0, C, H, W, kWaves, mn, mx, &c8, &bad);
+    dw2_gather<CCH, true>(img, wl, sl, d, n, c0, C, H, W, kWaves, mn, mx, has_nan, &c8, &bad);
     if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
     return;
   }
-  dw2_gather<CCH, false>(img, wl, sl, d, n, c0, C, H, W, kWaves, mn, mx);
+  dw2_gather<CCH, false>(img, wl, sl, d, n, c0, C, H, W, kWaves, mn, mx, has_nan);
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
-    cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), dmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red);
   CDN_STAMP(4);
 }
@@ -900,6 +918,7 @@ dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const 
     for (int k = k0; k < max(npieces, 1); ++k) issue_step(item, set, k);
   };
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   BadMask bad = 0;
   Code8 c8 = {1.f, 0.f};
   if (OUT8) c8 = make_code8(qu.state, bad);
@@ -921,6 +940,7 @@ dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const 
       const int p = qd * 4, row = p / W, col = p - row * W;         // W % 4 == 0: one row
       float *dst = imgf + (row * Wc + col) * CCH + ln;
       dst[0] = v.x; dst[CCH] = v.y; dst[2 * CCH] = v.z; dst[3 * CCH] = v.w;
+      has_nan |= __builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w);   // (see track4: x is tested where it is staged)
     }
     float *sl = sl0 + set * HW;
     if (SQ) for (int q = tid; q < HW; q += 1024) sl[q] = fake_quant(sl[q], ss, sz);
@@ -931,8 +951,8 @@ dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const 
     // byte-code instantiation 20 spilled VGPRs.)
     const int nxt = item + gridDim.x;
     if (nxt < nitems) issue(nxt, set ^ 1, 0);
-    if (OUT8) dw2_gather<CCH, true>(img, wl0 + set * CCH * 9, sl, d, n, chunk * CCH, C, H, W, kWaves, mn, mx, &c8, &bad);
-    else dw2_gather<CCH, false>(img, wl0 + set * CCH * 9, sl, d, n, chunk * CCH, C, H, W, kWaves, mn, mx);
+    if (OUT8) dw2_gather<CCH, true>(img, wl0 + set * CCH * 9, sl, d, n, chunk * CCH, C, H, W, kWaves, mn, mx, has_nan, &c8, &bad);
+    else dw2_gather<CCH, false>(img, wl0 + set * CCH * 9, sl, d, n, chunk * CCH, C, H, W, kWaves, mn, mx, has_nan);
     CDN_STAMP(3);
     if (item == (int)blockIdx.x) CDN_STAMP(6);
     if (item == (int)(blockIdx.x + gridDim.x)) CDN_STAMP(7);
@@ -941,7 +961,7 @@ dw0p_kernel(const float *__restrict__ x, const float *__restrict__ s_raw, const 
     if (bad) atomicOr(reinterpret_cast<unsigned *>(dmm), 1u);
     return;
   }
-  if (dmm) cdn::block_minmax_finish(mn, mx, dmm, blockIdx.x, gridDim.x, qu, red);
+  if (dmm) cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), dmm, blockIdx.x, gridDim.x, qu, red);
   CDN_STAMP(4);
 }
 
@@ -1145,6 +1165,8 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 #endif
 
   float mn = INFINITY, mx = -INFINITY, mn2 = INFINITY, mx2 = -INFINITY;
+
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   BadMask bad = 0;
   Code8 c8 = {1.f, 0.f};
   if (OUT8) c8 = make_code8(qu.state, bad);
@@ -1288,6 +1310,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
                   dp[e] = av[e];
                   mn = fminf(mn, av[e]);
                   mx = fmaxf(mx, av[e]);
+                  has_nan |= (av[e] != av[e]);
                 }
             }
           }
@@ -1304,7 +1327,7 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   CDN_STAMP_WAVE();
   CDN_STAMP(3);
   if (dmm)
-    cdn::block_minmax_finish(mn, mx, dmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), dmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red);
   CDN_STAMP(4);
 }
@@ -1354,6 +1377,7 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // 4.3 us of workgroup dispatch inside the graph)
   const long ntm = (M + BM - 1) / BM, ntiles = ntm * ((Co + BN - 1) / BN);
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const long m0 = (tile % ntm) * BM;
   const int n0 = (int)(tile / ntm) * BN;
@@ -1502,16 +1526,17 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         if (m < M && co < Co) {
           float v = acc[i][j][r] + bsv;
           if (ep_scale) v = fmaf(v, es, eh);
-          if (relu) v = fmaxf(v, 0.0f);
+          if (relu) v = cdn::relu_keep_nan(v);
           R[m * ldo + co] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
+          has_nan |= (v != v);
         }
       }
   }
   }   // tile loop
   if (rmm)   // (block_minmax_finish syncs before reusing As as scratch)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.x, gridDim.x, qu, &As[0][0]);
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.x, gridDim.x, qu, &As[0][0]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1648,6 +1673,7 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
     }
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (KS == 4) {
     // ---- the four k slices of the tile through LDS (each wave's partial tile over its own, drained ring), added in a
     //      fixed order
@@ -1678,7 +1704,7 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
       const int o = (r0 + rr) * kPwsLD + col;
       v[rr] = ((P0[o] + P1[o]) + (P2[o] + P3[o])) + bsv;
       if (ep_scale) v[rr] = fmaf(v[rr], es, eh);
-      if (relu) v[rr] = fmaxf(v[rr], 0.0f);
+      if (relu) v[rr] = cdn::relu_keep_nan(v[rr]);
     }
 #pragma unroll
     for (int rr = 0; rr < RPT; ++rr)
@@ -1686,6 +1712,7 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
         R[(m0 + r0 + rr) * ldo + co] = v[rr];
         mn = fminf(mn, v[rr]);
         mx = fmaxf(mx, v[rr]);
+        has_nan |= (v[rr] != v[rr]);
       }
   } else {
 #pragma unroll
@@ -1704,18 +1731,19 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
         const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = acc[j][r] + bsv;
         if (ep_scale) v = fmaf(v, es, eh);
-        if (relu) v = fmaxf(v, 0.0f);
+        if (relu) v = cdn::relu_keep_nan(v);
         if (m < M && co < Co) {
           R[m * ldo + co] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
+          has_nan |= (v != v);
         }
       }
     }
   }
   if (rmm) {
     __syncthreads();      // (the scratch of block_minmax_finish aliases wave 0's ring / partial tile)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.x, gridDim.x, qu, reinterpret_cast<float *>(lds));
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.x, gridDim.x, qu, reinterpret_cast<float *>(lds));
   }
 }
 
@@ -1802,6 +1830,7 @@ __device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, cons
       __syncthreads();
     }
     float mn = INFINITY, mx = -INFINITY;
+    bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int co = n0 + wn + j * 32 + (lane & 31);
@@ -1814,15 +1843,16 @@ __device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, cons
           const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (m < M && co < Co) {
             float v = accf[i][j][r] + bsv;
-            if (relu) v = fmaxf(v, 0.0f);
+            if (relu) v = cdn::relu_keep_nan(v);
             if (R) R[m * ldo + oc] = v;
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
+            has_nan |= (v != v);
           }
         }
     }
     if (rmm)
-      cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+      cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.y * gridDim.x + blockIdx.x,
                                gridDim.x * gridDim.y, qu, red);
   }
 }
@@ -2001,6 +2031,7 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   }
   CDN_STAMPR(2, 2);
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
@@ -2013,16 +2044,17 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < M && co < Co) {
           float v = fmaf((float)(acc[i][j][r] + t128), rinv, bsv);
-          if (relu) v = fmaxf(v, 0.0f);
+          if (relu) v = cdn::relu_keep_nan(v);
           if (R) R[m * ldo + oc] = v;                          // (R == NULL: range-only pass)
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
+          has_nan |= (v != v);
         }
       }
   }
   CDN_STAMPR(2, 3);
   if (rmm)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&A0[0][0]));
   CDN_STAMPR(2, 4);
 }
@@ -2200,6 +2232,7 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     }
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn + j * 32 + (lane & 31);
@@ -2217,15 +2250,16 @@ pwb3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         const long m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < M && co < Co) {
           float v = fmaf(acc[i][j][r], rinv, bsv);
-          if (relu) v = fmaxf(v, 0.0f);
+          if (relu) v = cdn::relu_keep_nan(v);
           R[m * ldo + oc] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
+          has_nan |= (v != v);
         }
       }
   }
   if (rmm)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(&Ah[0]));
 }
 
@@ -2419,6 +2453,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   const unsigned char *bbase = smem + (size_t)(lane & 31) * ldb + 32 * (lane >> 5);
   const float *qrow = qtab + 16 * (lane >> 5);
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
 
   for (long rb = rb_first; rb < nrb; rb += rb_stride) {
     f32x16 acc[TN];
@@ -2533,16 +2568,17 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
         const long m = mb0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < M && oc[j] >= 0) {
           float v = fmaf(acc[j][r], rinv[j], bsv[j]);
-          if (relu) v = fmaxf(v, 0.0f);
+          if (relu) v = cdn::relu_keep_nan(v);
           R[m * ldo + oc[j]] = v;
           mn = fminf(mn, v);
           mx = fmaxf(mx, v);
+          has_nan |= (v != v);
         }
       }
   }
   CDN_STAMPR(2, 3);
   if (rmm)
-    cdn::block_minmax_finish(mn, mx, rmm, blockIdx.y * gridDim.x + blockIdx.x,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(smem));
   CDN_STAMPR(2, 4);
 }
@@ -2682,6 +2718,7 @@ dwg_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const f
     sz = reinterpret_cast<const float *>(sq)[3];
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
     const int cq = (int)(q % CQ);
     const long pn = q / CQ;
@@ -2758,9 +2795,10 @@ dwg_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const f
     for (int e = 0; e < nc; ++e) {
       mn = fminf(mn, acc[e]);
       mx = fmaxf(mx, acc[e]);
+      has_nan |= (acc[e] != acc[e]);
     }
   }
-  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.x, gridDim.x, qu, red);
+  if (mm) cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.x, gridDim.x, qu, red);
 }
 
 int launch_dwg(bool nhwc, const float *x, const unsigned *xq, const float *s_raw, const unsigned *sq, const float *wd,

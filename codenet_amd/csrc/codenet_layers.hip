@@ -102,6 +102,7 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
   const int Hi = STRIDE == 2 ? (Hs - 1) / 2 + 1 : Hs, Wi = STRIDE == 2 ? (Ws - 1) / 2 + 1 : Ws;
   const int Ho = Hi << UP, Wo = Wi << UP;
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   const int work = BAND * Wi * LPP;
   // 256 threads = 256 / LPP pixels x LPP channel quads per pass: a thread keeps ONE channel quad, so its weights
   // are loaded once (not per item: 45 global loads per 9 LDS reads otherwise)
@@ -153,7 +154,7 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
         for (int e = 0; e < 4; ++e) {
           float v = acc[e] + bs[e];
           if (ep_scale) v = fmaf(v, es[e], eh[e]);
-          if (relu) v = fmaxf(v, 0.0f);
+          if (relu) v = cdn::relu_keep_nan(v);
           r4[e] = v;
         }
         if (out == nullptr) {
@@ -170,12 +171,13 @@ dw3_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const f
           if (cb + e < C) {          // padding channels do not take part in the range
             mn = fminf(mn, r4[e]);
             mx = fmaxf(mx, r4[e]);
+            has_nan |= (r4[e] != r4[e]);
           }
       }
   }
   if (mm) {
     __syncthreads();
-    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
                              reinterpret_cast<float *>(band4));
   }
 }
@@ -313,6 +315,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
     }
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   int cslot = 0;                                              // ring slot of the first row of the 3x3 window
   for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
 #pragma unroll
@@ -355,7 +358,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
             for (int e = 0; e < 4; ++e) {
               float v = acc[e] + bs[e];
               if (ep_scale) v = fmaf(v, es[e], eh[e]);
-              if (relu) v = fmaxf(v, 0.0f);
+              if (relu) v = cdn::relu_keep_nan(v);
               r4[e] = v;
             }
             float *op = out + ((long)n * Ho * Wo + (long)oy * Wo + ox) * ld_out + cb;
@@ -371,6 +374,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
               if (cb + e < C) {
                 mn = fminf(mn, r4[e]);
                 mx = fmaxf(mx, r4[e]);
+                has_nan |= (r4[e] != r4[e]);
               }
           }
         }
@@ -379,7 +383,7 @@ dws_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   }
   if (mm) {
     __syncthreads();
-    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
                              reinterpret_cast<float *>(ring4));
   }
 }
@@ -513,6 +517,7 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
     }
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   int cslot = 0;
   for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
 #pragma unroll
@@ -555,7 +560,7 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
             for (int e = 0; e < 4; ++e) {
               float v = acc[e] + bs[e];
               if (ep_scale) v = fmaf(v, es[e], eh[e]);
-              if (relu) v = fmaxf(v, 0.0f);
+              if (relu) v = cdn::relu_keep_nan(v);
               r4[e] = v;
             }
             float *op = out + ((long)n * Ho * Wo + (long)oy * Wo + ox0 + oxl) * ld_out + cb;
@@ -571,6 +576,7 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
               if (cb + e < C) {
                 mn = fminf(mn, r4[e]);
                 mx = fmaxf(mx, r4[e]);
+                has_nan |= (r4[e] != r4[e]);
               }
           }
         }
@@ -579,7 +585,7 @@ dwx_kernel(const float *__restrict__ a, const unsigned *__restrict__ aq, const u
   }
   if (mm) {
     __syncthreads();
-    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
                              reinterpret_cast<float *>(ring4));
   }
 }
@@ -787,6 +793,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
     __syncthreads();                                              // code row 0 is read: the loop may overwrite it
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   int cslot = 0, par = 1;                        // flag word of the rows in flight (the prologue row used word 0)
   for (int oyb = oy0; oyb < oy1; oyb += DEPTH) {
 #pragma unroll
@@ -848,6 +855,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
               if (cb + e < C) {
                 mn = fminf(mn, r4[e]);
                 mx = fmaxf(mx, r4[e]);
+                has_nan |= (r4[e] != r4[e]);
               }
           }
         }
@@ -856,7 +864,7 @@ pwdwx_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq, const
   }
   if (mm) {
     __syncthreads();
-    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
                              reinterpret_cast<float *>(ring4));
   }
 }
@@ -938,6 +946,7 @@ stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const fl
   const int n = blockIdx.y;
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (p < (long)Ho * Wo) {
     const int oy = (int)(p / Wo), ox = (int)(p - (long)oy * Wo);
     float v[27];
@@ -966,15 +975,16 @@ stem_kernel(const float *__restrict__ img, const float *__restrict__ w, const fl
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc = fmaf(w[co * 27 + k], v[k], acc);
         acc += bias ? bias[co] : 0.0f;
-        if (relu) acc = fmaxf(acc, 0.0f);
+        if (relu) acc = cdn::relu_keep_nan(acc);
         r4[e] = acc;
         mn = fminf(mn, acc);
         mx = fmaxf(mx, acc);
+        has_nan |= (acc != acc);
       }
       *reinterpret_cast<float4 *>(op + c4) = make_float4(r4[0], r4[1], r4[2], r4[3]);   // 96-byte pixel rows
     }
   }
-  if (mm) cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu, red);
+  if (mm) cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu, red);
 }
 
 constexpr int kHtLD = 48;      // bytes per A / B row of one 32-channel int8 k-step (32 + 16 pad): head_small_kernel
@@ -1194,6 +1204,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
     }
   }
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   int cslot = 0;
   unsigned clamped = 0;
   const int Ho = 2 * Hs, Wo = 2 * Ws;
@@ -1242,6 +1253,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
                 if (MODE == 0) {
                   mn = fminf(mn, fminf(fminf(v4[0], v4[1]), fminf(v4[2], v4[3])));
                   mx = fmaxf(mx, fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3])));
+                  has_nan |= __builtin_isunordered(v4[0], v4[1]) | __builtin_isunordered(v4[2], v4[3]);
                 } else if (MODE == 1) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) Lv[py * 2 + px][e] = __fadd_rn(cdn::quant_code(v4[e], s2, z2), z2);
@@ -1356,7 +1368,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   if (Y8 && MODE == 2 && clamped && oflow) atomicOr(oflow, 1u);
   if (MODE == 0 && mm) {
     __syncthreads();
-    cdn::block_minmax_finish(mn, mx, mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, qu,
                              reinterpret_cast<float *>(ring4));
   }
 }

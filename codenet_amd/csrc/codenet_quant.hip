@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(256)
 minmax_kernel(const float *__restrict__ x, long n, cdn::QUpdate qu) {
   unsigned *state = qu.state;
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   const long n4 = n >> 2;
   const float4 *x4 = reinterpret_cast<const float4 *>(x);
   const long stride = (long)gridDim.x * blockDim.x;
@@ -48,46 +49,52 @@ minmax_kernel(const float *__restrict__ x, long n, cdn::QUpdate qu) {
     mn = fminf(fminf(fminf(mn, v2.x), fminf(v2.y, fminf(v2.z, v2.w))), fminf(fminf(v3.x, v3.y), fminf(v3.z, v3.w)));
     mx = fmaxf(fmaxf(fmaxf(mx, v0.x), fmaxf(v0.y, fmaxf(v0.z, v0.w))), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
     mx = fmaxf(fmaxf(fmaxf(mx, v2.x), fmaxf(v2.y, fmaxf(v2.z, v2.w))), fmaxf(fmaxf(v3.x, v3.y), fmaxf(v3.z, v3.w)));
+    // (v_cmp_u_f32 tests two values at once; the flag is a scalar mask)
+    has_nan |= __builtin_isunordered(v0.x, v0.y) | __builtin_isunordered(v0.z, v0.w) | __builtin_isunordered(v1.x, v1.y) |
+            __builtin_isunordered(v1.z, v1.w) | __builtin_isunordered(v2.x, v2.y) | __builtin_isunordered(v2.z, v2.w) |
+            __builtin_isunordered(v3.x, v3.y) | __builtin_isunordered(v3.z, v3.w);
   }
   for (; i < n4; i += stride) {
     const float4 v = x4[i];
     mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
     mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    has_nan |= __builtin_isunordered(v.x, v.y) | __builtin_isunordered(v.z, v.w);
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long)gridDim.x * blockDim.x) {
     mn = fminf(mn, x[i]);
     mx = fmaxf(mx, x[i]);
+    has_nan |= (x[i] != x[i]);
   }
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, m, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+  if (RELU) {      // the extremes of max(x, 0); a NaN stays one (the flag), as torch.relu keeps it
+    mn = fmaxf(mn, 0.0f);
+    mx = fmaxf(mx, 0.0f);
   }
-  __shared__ float smn[4], smx[4];
+  // NaN-propagating from here on: ordered-uint keys, integer maxima (cdn_common.h)
+  unsigned klo = cdn::key_lo(cdn::nan_lo(mn, has_nan)), khi = cdn::key_hi(cdn::nan_hi(mx, has_nan));
+  cdn::wave_key_max(klo, khi);
+  __shared__ unsigned smn[4], smx[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
-    smn[wave] = mn;
-    smx[wave] = mx;
+    smn[wave] = klo;
+    smx[wave] = khi;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
-    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-    if (RELU) {
-      mn = fmaxf(mn, 0.0f);
-      mx = fmaxf(mx, 0.0f);
-    }
+    klo = max(max(smn[0], smn[1]), max(smn[2], smn[3]));
+    khi = max(max(smx[0], smx[1]), max(smx[2], smx[3]));
     // ordering without a fence (an agent-scope release writes L2 back: +5..10 us per launch, measured): the two
     // extremes are RETURNING atomics whose results the ticket waits for, so they have been applied at L2 (where all
     // three words live and are only ever touched by atomics) before the ticket is taken
-    const unsigned r0 = __hip_atomic_fetch_max(&state[0], ~f2ord(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned r1 = __hip_atomic_fetch_max(&state[1], f2ord(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned r0 = __hip_atomic_fetch_max(&state[0], klo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned r1 = __hip_atomic_fetch_max(&state[1], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(r0), "v"(r1) : "memory");
     const unsigned t = __hip_atomic_fetch_add(&state[7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {
-      const float bmin = ord2f(~__hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const float bmax = ord2f(__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      unsigned k0 = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned k1 = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!RELU) cdn::empty_pair_is_nan(k0, k1);      // (an all-NaN tensor; with RELU the per-thread clamp already gave (inf, 0))
+      const float bmin = cdn::unkey_lo(k0), bmax = cdn::unkey_hi(k1);
       cdn::quantact_update_device(qu, bmin, bmax, true);
       __hip_atomic_store(&state[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -108,12 +115,9 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
   const bool from_partials = !ext_min && partials;
   if (from_partials) {   // reduce the producers' per-workgroup {min,max}
     float mn = INFINITY, mx = -INFINITY;
-    for (int i = threadIdx.x; i < n_partials; i += blockDim.x) {
-      const float2 v = partials[i];
-      mn = fminf(mn, v.x);
-      mx = fmaxf(mx, v.y);
-    }
-    cdn::block_minmax_store(mn, mx, &pr, red);
+    bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
+    for (int i = threadIdx.x; i < n_partials; i += blockDim.x) cdn::fold_pair(partials[i], mn, mx, has_nan);
+    cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &pr, red);
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
@@ -123,9 +127,11 @@ quantact_update_kernel(float *x_min, float *x_max, unsigned *state, const float 
     // (running without external extremes or partials is the fused range pass, minmax_kernel: never here)
     bmin = ext_min ? ext_min[0] : (from_partials ? pr.x : 0.0f);
     bmax = ext_max ? ext_max[0] : (from_partials ? pr.y : 0.0f);
+    if (from_partials && bmin == INFINITY && bmax == -INFINITY)      // every producer's pair is empty: an all-NaN tensor
+      bmin = bmax = __uint_as_float(0x7fc00000u);
     if (relu) {      // the extremes of max(x, 0) from those of x (ReLU is monotone)
-      bmin = fmaxf(bmin, 0.0f);
-      bmax = fmaxf(bmax, 0.0f);
+      bmin = (bmin != bmin) ? bmin : fmaxf(bmin, 0.0f);      // (a poisoned pair stays NaN)
+      bmax = (bmax != bmax) ? bmax : fmaxf(bmax, 0.0f);
     }
   }
   cdn::QUpdate u{x_min, x_max, state, nullptr, m_minus_1, one_minus_m, bits, running};

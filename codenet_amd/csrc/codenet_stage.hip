@@ -77,17 +77,19 @@ scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
   red[wave][lane] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (wave == 0 && live) {
     float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     v += b ? b[0] : 0.0f;
-    v = fminf(fmaxf(v, lo), hi);  // Hardtanh(lo, hi), modules/dcn_deform_conv.py:304-305
+    v = cdn::clamp_keep_nan(v, lo, hi);  // Hardtanh(lo, hi), modules/dcn_deform_conv.py:304-305
     s[(long)n * HW + p] = v;
     mn = mx = v;
+    has_nan = (v != v);
   }
   // training path: this workgroup's {min, max} of what it wrote, for the QuantAct behind it (no separate range pass)
   if (mm) {
     __syncthreads();
-    cdn::block_minmax_store(mn, mx, &mm[blockIdx.y * gridDim.x + blockIdx.x], &red[0][0]);
+    cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], &red[0][0]);
   }
 }
 
@@ -105,6 +107,7 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
   extern __shared__ float smem[];
   __shared__ float red_mm[8];
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   const int HW = H * W;
   const int Wp = W + 2, Hp = H + 2;
   const int pstride = Hp * Wp;
@@ -192,9 +195,10 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
       d[((long)n * C + c0 + ch) * HW + p] = acc;
       mn = fminf(mn, acc);
       mx = fmaxf(mx, acc);
+      has_nan |= (acc != acc);
     }
   }
-  if (mm) cdn::block_minmax_store(mn, mx, &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
+  if (mm) cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -215,6 +219,7 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
   extern __shared__ float smem[];
   __shared__ float red_mm[8];
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   const int HW = H * W;
   const int Hl = UP ? H >> 1 : H, Wl = UP ? W >> 1 : W;   // resolution of the planes in LDS
   const int HWl = Hl * Wl;
@@ -288,6 +293,7 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
         d[((long)n * C + c0 + 4 * g + OFF) * HW + p] = acc;                                              \
         mn = fminf(mn, acc);                                                                             \
         mx = fmaxf(mx, acc);                                                                             \
+        has_nan |= (acc != acc); \
       }
       CDN_DW4_CH(x, 0)
       CDN_DW4_CH(y, 1)
@@ -296,7 +302,7 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
 #undef CDN_DW4_CH
     }
   }
-  if (mm) cdn::block_minmax_store(mn, mx, &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
+  if (mm) cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1097,6 +1103,7 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
   }
   const int col = p0 + wn + (lane & 31);
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1104,15 +1111,16 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
       float v = acc[r];
       if (bias) v += bias[row];
       if (ep_scale) v = fmaf(v, ep_scale[row], ep_shift[row]);
-      if (relu) v = fmaxf(v, 0.0f);
+      if (relu) v = cdn::relu_keep_nan(v);
       Y[((long)n * Co + row) * HW + col] = v;
       mn = fminf(mn, v);
       mx = fmaxf(mx, v);
+      has_nan |= (v != v);
     }
   }
   if (mm) {
     __syncthreads();      // (As is free: every wave has left the k loop)
-    cdn::block_minmax_store(mn, mx, &mm[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x], &As[0][0]);
+    cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x], &As[0][0]);
   }
 }
 

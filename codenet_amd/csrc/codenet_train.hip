@@ -372,17 +372,20 @@ weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__re
   }
   const float *wr = w + (long)co * K;
   float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (k_low <= 1 && k_high <= 1) {
     for (int k = lane; k < K; k += 64) {
       const float v = fold ? wr[k] * sf : wr[k];
       mn = fminf(mn, v);
       mx = fmaxf(mx, v);
+      has_nan |= (v != v);
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
       mn = fminf(mn, __shfl_xor(mn, m, 64));
       mx = fmaxf(mx, __shfl_xor(mx, m, 64));
     }
+    if (__any(has_nan)) mn = mx = __uint_as_float(0x7fc00000u);      // (torch's min() / max() of a row with a NaN)
   } else {
     // --wt-percentile (quant_modules.py:287-300): the k_low-th smallest and the k_high-th largest value of the channel
     // (torch.kthvalue counts duplicates).  k <= kPctMax: every lane keeps its kPctMax smallest / largest values sorted,

@@ -605,6 +605,46 @@ def test_codenet_dw_backward_propagates_a_nan_in_grad_output():
     assert torch.isnan(xg.grad[1, 37]).all() and torch.isfinite(xg.grad[0]).all()
 
 
+@pytest.mark.parametrize("path", ["module", "fused", "train"])
+def test_a_nan_in_the_batch_poisons_the_tracked_ranges(path):
+    """the reference's batch statistics are x.min() / x.max() (quant_modules.py:203-219), which are
+    NaN when the batch holds one -- the tracked range is NaN from then on and a diverged QAT step is loud.  fminf / fmaxf
+    and v_min3 / v_max3 drop a NaN; the range reductions here carry a per-thread flag and reduce ordered-uint keys
+    (cdn_common.h), the Hardtanh / ReLU epilogues keep a NaN like torch's.  One poisoned element of the stage input:
+    the stand-alone QuantAct, the fused schedule (in-kernel range epilogues) and the training path (per-workgroup
+    partials) must all end with NaN ranges, as the oracle's QuantAct does."""
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(4, 64, 16, 16, generator=g).abs_() * 1.5)
+    clean = x.clone()
+    x[2, 17, 5, 9] = float("nan")
+    ref = Q.QuantActState()
+    ref(x)
+    assert torch.isnan(ref.x_min).all() and torch.isnan(ref.x_max).all()        # what the reference's tracker does
+    if path == "module":
+        act = QuantAct(8, quant_mode="asymmetric").cuda()
+        y = act(x.cuda())
+        assert torch.isnan(act.x_min).all() and torch.isnan(act.x_max).all()
+        assert torch.isnan(y).all()                                              # scale is NaN: every value is
+        return
+    net = pipeline.build_hot_path(quantized=True, planes=[64, 32, 16], seed=5).cuda()
+    pipeline.set_running_stat(net, True)
+    acts = [m for m in net.modules() if isinstance(m, QuantAct)]
+    if path == "fused":
+        fused = pipeline.FusedHotPath(net.deconv_layers)
+        fused(clean.cuda())                                                      # a clean forward first: finite ranges
+        assert all(torch.isfinite(a.x_min).all() and torch.isfinite(a.x_max).all() for a in acts)
+        fused(x.cuda())
+    else:
+        net.train()
+        net(clean.cuda().requires_grad_(True))
+        assert all(torch.isfinite(a.x_min).all() and torch.isfinite(a.x_max).all() for a in acts)
+        net(x.cuda().requires_grad_(True))
+    bad = [i for i, a in enumerate(acts) if not (torch.isnan(a.x_min).all() and torch.isnan(a.x_max).all())]
+    assert not bad, "QuantActs %r kept a finite range over a poisoned batch" % bad
+
+
 # ---- detection heads on the stage kernels (SURVEY.md section 8f row 1) ---------------------------
 
 def _head_modules(C, classes, g, quantized, pct=False):

@@ -23,7 +23,7 @@ BUDGET = {
     "pwd3_kernelILi2": 256, "pwd3_kernelILi4": 256,   # streaming pointwise: two waves per SIMD
 }
 # SGPR spills go to VGPR lanes (v_writelane / v_readlane, no memory): tolerated up to this many where listed
-SGPR_SPILLS_OK = {"pwd3_kernelILi4": 4}     # round 4: the window cursors of the unit-entry conv (228 VGPRs, 2 spilled SGPRs)
+SGPR_SPILLS_OK = {"pwd3_kernelILi4": 6}     # round 4: the window cursors of the unit-entry conv (228 VGPRs); round 5: + the NaN flag's mask
 # codenet_layers.hip: no spills; the row-streaming kernels must leave two workgroups per CU
 BUDGET_LAYERS = {
     "dwx_kernelILb1ELi1ELi2": 256, "dwx_kernelILb1ELi2ELi2": 256,
