@@ -119,6 +119,29 @@ __device__ __forceinline__ int owner_item(int lane) {
   return LPP == 16 ? (lane & 15) * 4 + (lane >> 4)
                    : (lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1));
 }
+// LDS-DMA (global_load_lds) as inline asm: see the note in front of dw0p_kernel (codenet_fused.hip) for why not the builtin.
+__device__ __forceinline__ void glds16(const void *gbase, unsigned voff, unsigned lds_dst) {
+  // gbase: wave-uniform 64-bit base (SGPR pair), voff: the lane's byte offset, lds_dst: wave-uniform LDS byte address
+  unsigned keep;
+  const unsigned long long b = (unsigned long long)gbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned long long b = (unsigned long long)gbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+// LDS byte address of a pointer into the workgroup's LDS, wave-uniform by construction (made provable for "s")
+__device__ __forceinline__ unsigned lds_addr_uniform(const void *p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p);
+}
+
 // rint(x) as a 64-bit integer for |x| < 2^51, three instructions (v_cvt_f64_f32, v_add_f64, one add on the high word):
 // x + 1.5 * 2^52 in double rounds to the nearest integer, ties to even, and its bit pattern is that of the constant
 // plus the integer.  __float2ll_rn compiles to ~13 VALU instructions (no 64-bit convert on gfx950); the gather

@@ -824,27 +824,10 @@ dw2_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
 // item without one).  The asm form is invisible to that bookkeeping; completion is waited for explicitly
 // (s_waitcnt vmcnt(0) + barrier at the top of every item).  M0 = wave-uniform LDS byte address of the piece, the
 // lane's 16 (4) bytes land at M0 + lane * 16 (4); M0 is saved and restored (compiler-reserved register).
-__device__ __forceinline__ void glds16(const void *gbase, unsigned voff, unsigned lds_dst) {
-  // gbase: wave-uniform 64-bit base (SGPR pair), voff: the lane's byte offset, lds_dst: wave-uniform LDS byte address
-  unsigned keep;
-  const unsigned long long b = (unsigned long long)gbase;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-  const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
-}
-__device__ __forceinline__ void glds4(const void *gbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  const unsigned long long b = (unsigned long long)gbase;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-  const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(bu), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
-}
-// LDS byte address of a pointer into the workgroup's LDS, wave-uniform by construction (made provable for "s")
-__device__ __forceinline__ unsigned lds_addr_uniform(const void *p) {
-  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p);
-}
+// (glds16 / glds4 / lds_addr_uniform: cdn_common.h, shared with the training path's pointwise kernel)
+using cdn::glds16;
+using cdn::glds4;
+using cdn::lds_addr_uniform;
 
 template <bool SQ, bool OUT8>
 __global__ void __launch_bounds__(1024)

@@ -1124,6 +1124,11 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
   }
 }
 
+// (Round 5, built and measured: a streaming form of this kernel -- pws_kernel's structure, every wave a 32 x 64 tile over
+// the whole K fed by a wave-private LDS-DMA ring, persistent over pixel tiles -- bit-reproducible and correct, 57 / 34 / 39
+// / 63 / 38 / 46 us at the QAT step's six launches against 71 / 32 / 42 / 62 / 36 / 44 us for this kernel and no change of
+// the step (1.389-1.398 vs 1.385-1.387 ms, three interleaved pairs): at 32 x 64 outputs per wave the operands cross
+// L2 -> LDS three times as often per MAC as with this kernel's shared 64 x 64 tiles.  Removed.)
 }  // namespace
 
 // The three forward kernels of the stage optionally leave one {min, max} pair per workgroup of the tensor they wrote
