@@ -147,7 +147,7 @@ def launch_ranks(args):
 # ---- live HBM traffic of the step (roofline.traffic measured IN THIS RUN) -------------------------
 
 FAMILY_OF = (("dw0p_kernel", "dw"), ("dw2u_kernel", "dw"), ("dw2_kernel", "dw"), ("pwi8_kernel", "pointwise"),
-             ("pw3_kernel", "pointwise"), ("pwq8_kernel", "pointwise"), ("pwb3_kernel", "pointwise"),
+             ("pw3_kernel", "pointwise"), ("pws_kernel", "pointwise"), ("pwq8_kernel", "pointwise"), ("pwb3_kernel", "pointwise"),
              ("pwd3_kernel", "pointwise"), ("scale_n", "scale"), ("unpack_kernel", "unpack"), ("expand8", "unpack"))
 
 
@@ -870,7 +870,7 @@ def main():
             _set_traffic(live_traffic, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this bench.py "
                                        "invocation (eager launches, 3 steps)")
         elif roof["bound"] == "hbm":
-            for rnd in ("r04", "r03", "r02", "r01"):
+            for rnd in ("r05", "r04", "r03", "r02", "r01"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", rnd,
                                                      "pmc_traffic_frozen.json" if frozen_main else "pmc_traffic.json")))

@@ -1,10 +1,12 @@
-"""The caller side of the hot path, kept on
-PyTorch-ROCm: a ``PoseShuffleNetV2`` with the reference's module tree / state-dict keys
-(lib/models/networks/shufflenetv2_dcn.py:57-114,189-330) whose ``deconv_layers`` are this
-package's deform modules, ``ctdet_decode`` (lib/models/decode.py:10-16,110-127,474-505) and the
-body of ``CtdetDetector.process`` (lib/detectors/ctdet.py:29-46).  The three deform stages run on the
-hand-written kernels; with ``enable_fused()`` so do the detection heads;
-the backbone and the decode are stock torch ops (rows 2-3, not built yet).
+"""The caller side of the hot path: a ``PoseShuffleNetV2`` with the
+reference's module tree / state-dict keys (lib/models/networks/shufflenetv2_dcn.py:57-114,189-330) whose
+``deconv_layers`` are this package's deform modules, ``ctdet_decode`` (lib/models/decode.py:10-16,110-127,474-505; a torch
+restatement for CPU tensors and ``ctdet_decode_native`` on the HIP kernels) and the body of ``CtdetDetector.process``
+(lib/detectors/ctdet.py:29-46).  Module by module every operator of the three deform stages runs on the hand-written
+kernels; ``enable_fused()`` runs the WHOLE network on them -- backbone (pipeline.FusedBackbone), stages
+(pipeline.FusedHotPath), heads (pipeline.FusedHeads) -- and ``enable_fused(frozen_codes=True)`` the byte-code serving
+schedule (pipeline.FrozenBackbone / FrozenHotPath / FusedHeads.forward_codes); ``capture_process`` records network +
+decode as one HIP graph.
 """
 import hashlib
 

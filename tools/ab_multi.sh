@@ -7,7 +7,7 @@ R=2
 [ "$1" = "-r" ] && { R=$2; shift 2; }
 for i in $(seq $R); do
   for V in "$@"; do
-    python3 tools/with_lib.py "$V" bench.py --no-cpu-baseline --no-e2e 2>/dev/null | python3 -c "
+    python3 tools/with_lib.py "$V" bench.py --no-cpu-baseline --no-e2e --no-config-legs 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernel_ms_per_launch']

@@ -4,11 +4,11 @@
 # the byte-code schedule with byte-code input + chained scale, the whole network in serving mode (e2e.frozen), the QAT
 # step.  Output: gpurun_out/<round>/pmc_traffic_<variant>.json (tools/pmc_steady.py: bytes per steady-state iteration).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-P="--steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-e2e"
+P="--steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-e2e --no-config-legs"
 run() {   # name, marker, per-iter, command...
   local name=$1 marker=$2 per=$3; shift 3
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pv_${name}_f" -- "$@" > "$OUT/pv_${name}.log" 2>&1

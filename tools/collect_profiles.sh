@@ -3,7 +3,7 @@
 # (separate passes, no trace domains combined with --pmc), all into gpurun_out/<round>/.
 # Afterwards: python tools/summarize_profiles.py <round>   (in the build container) -> profiles/<round>/
 set -u
-R=${1:-r04}
+R=${1:-r05}
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -16,7 +16,7 @@ $B --config cfg2 --no-cpu-baseline > "$OUT/bench_cfg2.json" 2>/dev/null
 $B --path modules --no-cpu-baseline > "$OUT/bench_modules.json" 2>/dev/null
 python3 tools/train_step_bench.py > "$OUT/train_step_w4a8_eager.json" 2>/dev/null
 python3 tools/train_step_bench.py --graph > "$OUT/train_step_w4a8.json" 2>/dev/null
-Q="--no-cpu-baseline --no-e2e"
+Q="--no-cpu-baseline --no-e2e --no-config-legs"
 # kernel stats: running (reference-faithful) schedule with its frozen leg, and the frozen schedule as the step
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $B $Q > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_frozen" -- $B --frozen $Q > "$OUT/stats_frozen.log" 2>&1

@@ -2,7 +2,7 @@
 # On the GPU box: rocprofv3 kernel stats of the default bench (no CPU / whole-network legs); prints the top kernels.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/qs && mkdir -p gpurun_out/qs
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qs -- python3 bench.py --no-cpu-baseline --no-e2e "$@" > gpurun_out/qs.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qs -- python3 bench.py --no-cpu-baseline --no-e2e --no-config-legs "$@" > gpurun_out/qs.log 2>&1
 f=$(find gpurun_out/qs -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, re

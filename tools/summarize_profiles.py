@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = "gpurun_out/" + R, "profiles/" + R
 os.makedirs(dst, exist_ok=True)
 for f in (glob.glob(src + "/*.json") + glob.glob(src + "/*kernel_stats.csv") + glob.glob(src + "/backbone_kernel_order.txt")
@@ -23,7 +23,7 @@ for a, b in (("stats_kernel_stats.csv", "bench_w4a8_fused_kernel_stats.csv"),
     if os.path.exists(os.path.join(dst, a)):
         os.replace(os.path.join(dst, a), os.path.join(dst, b))
 
-FAMILY = {"dw2": "dw", "dw0p": "dw", "pwi8": "pointwise", "pw3": "pointwise", "pwq8": "pointwise", "scale_n": "scale",
+FAMILY = {"dw2": "dw", "dw0p": "dw", "pwi8": "pointwise", "pw3": "pointwise", "pws_": "pointwise", "pwq8": "pointwise", "scale_n": "scale",
           "unpack": "unpack", "expand8": "unpack", "frozen_params": "other"}
 HOT = tuple(FAMILY)
 

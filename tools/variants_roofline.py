@@ -7,7 +7,7 @@ import json
 import os
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 D = os.path.join("profiles", R)
 PEAK = 8000.0
 
