@@ -48,6 +48,8 @@ _SIGNATURES = {
     "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_stage_fused_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_stage_fused_intermediates": (_i, [_i64] * 4 + [_i, _i, _i, _vp, _vp]),
+    "cdn_codenet_wcodes_kb_columns": (_i64, [_i64, _i64]),
+    "cdn_codenet_wcodes_kb_offset": (_i64, [_i64, _i64]),
     "cdn_codenet_maxpool3x3s2_q8_forward": (_i, [_vp] + [_i64] * 6 + [_vp, _vp]),
     "cdn_codenet_dwpw_q8_supported": (_i, [_i64] * 3 + [_i, _i64]),
     "cdn_codenet_dwpw_q8_forward": (

@@ -22,6 +22,7 @@
 #include "cdn_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 // In-kernel phase stamps for tools/probes/probe_dw.hip (which includes this file with
@@ -1762,15 +1763,20 @@ __device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, cons
                                                const float *__restrict__ bias, float *__restrict__ R, float2 *rmm,
                                                const cdn::QUpdate &qu, long M, int C, int Co, int relu, int lda,
                                                int ldo, const int *__restrict__ omap, float qs, float qz,
-                                               float *As, float *Bs, float *red) {
+                                               float *As, float *Bs, float *red, long m0, int n_first, int nrep, int pidx,
+                                               int npart) {
+  // the workgroup's tile: rows [m0, m0 + BM), nrep column tiles of BN from n_first on, walked one after the other
+  // (pwi8s_kernel: all its columns); Co: one past the last column it may touch; pidx / npart: its range partial
   constexpr int WGN = 4 / WGM;
   constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
   constexpr int LDF = 17;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
-  {
+  float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int n0 = n_first + rep * BN;
+    if (rep) __syncthreads();
     f32x16 accf[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1812,8 +1818,6 @@ __device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, cons
       }
       __syncthreads();
     }
-    float mn = INFINITY, mx = -INFINITY;
-    bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int co = n0 + wn + j * 32 + (lane & 31);
@@ -1834,10 +1838,9 @@ __device__ __forceinline__ void pwi8_wide_path(const float *__restrict__ A, cons
           }
         }
     }
-    if (rmm)
-      cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.y * gridDim.x + blockIdx.x,
-                               gridDim.x * gridDim.y, qu, red);
   }
+  if (rmm)
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, pidx, npart, qu, red);
 }
 
 template <int BM, int BN, int WGM, bool FAST>
@@ -1873,7 +1876,8 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     static_assert(BM * 17 * 4 <= 2 * BM * kI8LD && BN * 17 * 4 <= 2 * BN * kI8LD, "LDS reuse");
     pwi8_wide_path<BM, BN, WGM>(A, Wp, bias, R, rmm, qu, M, Cw, Co, relu, lda, ldo, omap, qs, qz,
                                 reinterpret_cast<float *>(&A0[0][0]), reinterpret_cast<float *>(&B0[0][0]),
-                                reinterpret_cast<float *>(&A1[0][0]));
+                                reinterpret_cast<float *>(&A1[0][0]), m0, n0, 1, blockIdx.y * gridDim.x + blockIdx.x,
+                                gridDim.x * gridDim.y);
     return;
   }
   // as_uint(t + 1.5*2^23) = 0x4B400000 + rint(t) for |t| < 2^22 (guaranteed when state[6] == 0)
@@ -2042,6 +2046,248 @@ pwi8_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   CDN_STAMPR(2, 4);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// pwi8s_kernel (round 5): pwi8_kernel's arithmetic as a STREAMING kernel for long-K launches (stage 0: K = 1024) --
+// pws_kernel's structure.  tools/probes/probe_rowstream.hip: the stage-0 pointwise's 67-MB A operand can be read in
+// 12-15 us (4.3-5.4 TB/s) whatever the ring depth; pwi8_kernel takes 36 us there because each of its 32 dependent k
+// tiles is the serial sum of a global round trip, the fp32 -> code conversion, LDS writes, a barrier, LDS reads and the
+// MFMAs, with two workgroups per CU to overlap (DESIGN_HISTORY section 4.1).  Here a workgroup owns a 32-row block x
+// 32 TN columns, its four WAVES are the four quarters of K and each runs its own pipeline without workgroup barriers:
+//   A   32 rows x 32 k of fp32 d per window by LDS-DMA into a wave-private ring RR - 1 windows ahead (whole 128-byte
+//       lines, XOR-swizzled source chunks: pws_kernel); the fragment -- lane (i, h): k in [16 h, 16 h + 16) of row i --
+//       is read as four ds_read_b128 and converted IN REGISTERS to the two nibble operands (pwi8_kernel's ucode / perm
+//       expressions: every element is converted once per workgroup);
+//   B   the weight codes from a K-BLOCKED copy [window][column][32 B] (behind the row-major codes, made by the host:
+//       CDN_X_WCODES_KB): the operand of a 32-column tile is one fully coalesced 1-KB load per window, straight into
+//       registers, one window ahead; 16 * qw by a byte shift.
+// The int32 partial sums of the four k quarters are added through LDS (exact: order-independent).  Same integer sums
+// and the same epilogue expression as pwi8_kernel: bit-identical outputs and ranges (tests/test_gpu_parity.py).
+// ncg = 2 (Co = 256): two workgroups per row block, 128 columns each, 8 ids apart -- the same XCD, dispatched
+// together, so the second reading of the A rows is an L2 hit; 1024 three-per-CU workgroups instead of 512 two-per-CU
+// ones, which is what lets prologues (4 us: cold instruction fetch + the first DMA round trip) and epilogues (7 us)
+// of some workgroups overlap the k loops of others -- with one round of workgroups the launch was the plain sum.
+// Wide codes (state[6]): pwi8_wide_path.
+// vmcnt discipline: the weight loads are inline asm as well.  A compiler-visible load in this loop is waited for
+// with a count the compiler derives WITHOUT the DMAs it cannot see, and in-order completion then makes every such
+// wait a wait for the newest DMA (first version: 33 us).  Their destination registers are released by an empty asm
+// that names them right behind the explicit s_waitcnt, and loaded UNCONDITIONALLY inside the loop (the last steps are
+// peeled) -- a conditional load makes the register a phi, and the copy the compiler then inserts reads it before the
+// wait (second version: wrong sums); tools/check_asm_loads.py scans the ISA for exactly that.
+// ------------------------------------------------------------------------------------------
+// the int8 part of pwi8s_kernel (a function of its own so that the kernel is a plain if / else of the two paths: with
+// the wide branch written as an early return in front of it the compiler saw that branch's pending stores on a path
+// into the prologue below and put an s_waitcnt vmcnt(0) between the first weight loads -- i.e. behind the first DMAs)
+template <int TN, int RR>
+__device__ __forceinline__ void pwi8s_body(const float *__restrict__ A, const signed char *__restrict__ Wkb,
+                                           const float *__restrict__ wscale, const int *__restrict__ wsum,
+                                           const float *__restrict__ bias, float *__restrict__ R, float2 *rmm,
+                                           const cdn::QUpdate &qu, long M, int K, int Co, int relu, int lda, int ldo,
+                                           const int *__restrict__ omap, int ncg, long m0, int cb, float qs, float qz,
+                                           char *lds) {
+  constexpr int kRing = RR * 4096;
+  // Nothing is in flight here, and the compiler is told so with a REAL s_waitcnt vmcnt(0) (the builtin, which its
+  // wait-count bookkeeping sees): the structurised control flow has an edge from the end of the wide branch to this
+  // block, and for the stores pending on that edge it otherwise puts its own vmcnt(0) in front of the first asm load
+  // that overwrites one of their registers -- in the middle of the prologue, behind the first DMAs.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int Cot = 32 * TN * ncg;                     // columns per window of the k-blocked codes (zero rows behind Co)
+  const int ioff = (int)qz + (2048 - 128) - 0x4B400000;
+  // k windows (32 channels) of this wave: whole PAIRS of windows, the first (K / 64) % 4 waves one pair more -- every
+  // wave runs an even number of steps (the two weight-register sets alternate without a copy)
+  const int pairs = K >> 6;
+  const int nit = 2 * ((pairs >> 2) + (w < (pairs & 3) ? 1 : 0));
+  const int win0 = 2 * (w * (pairs >> 2) + min(w, pairs & 3)), kbase = 32 * win0;
+  // ---- A: DMA side --------------------------------------------------------------------------------------------------
+  const float *abase = A + m0 * lda + kbase;
+  unsigned aoff[4];
+  {
+    const int dr = lane >> 3, dc = lane & 7;
+    const long rmax = M - 1 - m0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = 8 * u + dr;
+      const int rl = (int)(row < rmax ? row : rmax);
+      aoff[u] = (unsigned)rl * (unsigned)lda * 4u + (unsigned)((dc ^ ((row >> 1) & 7)) * 16);
+    }
+  }
+  const unsigned ring = cdn::lds_addr_uniform(lds) + (unsigned)w * kRing;
+  auto issue = [&](int t) {
+    const unsigned dst = ring + (unsigned)(t % RR) * 4096;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cdn::glds16(abase, aoff[u] + (unsigned)t * 128u, dst + u * 1024);
+  };
+  // ---- B: one coalesced 16-byte load per lane, tile and window (inline asm: see the header) -----------------------------
+  const unsigned long long wb = (unsigned long long)(Wkb + ((long)win0 * Cot + cb) * 32);
+  const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wb), whi = __builtin_amdgcn_readfirstlane((unsigned)(wb >> 32));
+  const unsigned long long wbu = ((unsigned long long)whi << 32) | wlo;
+  const unsigned bo0 = (unsigned)(i * 32 + 16 * h), wstep = (unsigned)Cot * 32u;
+  i32x4 bA[TN], bB[TN];
+  auto loadB = [&](i32x4 (&b)[TN], int t) {
+    static_assert(TN <= 4, "one offset register: the tiles of a window within the 13-bit immediate");
+    const unsigned v0 = bo0 + (unsigned)t * wstep;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(b[j]) : "v"(v0), "s"(wbu), "n"(1024 * j) : "memory");
+  };
+  auto release = [&](i32x4 (&b)[TN]) {      // names the registers a wait has made valid: no use moves above this point
+    if constexpr (TN == 4)
+      asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3 % TN]));
+    else
+      asm volatile("" : "+v"(b[0]), "+v"(b[1]));
+  };
+  auto ucode = [&](float v) -> unsigned {
+#pragma clang fp contract(off)
+    const float y_p = qs * v;      // (two roundings, as the reference: see pwi8_kernel)
+    const float y = (y_p - qz) + 12582912.0f;
+    int u = (int)__float_as_uint(y) + ioff;
+    u = min(max(u, 8), 4087);
+    return (unsigned)u;
+  };
+  i32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
+  const char *wring = lds + w * kRing;
+  const int frow = i * 128, fsw = (i >> 1) & 7;
+  // issue order (vmcnt counts DMAs and loads alike, completing in order):
+  //   A(0) .. A(RR-3), B(0), A(RR-2) | step t: B(t+1), A(t+RR-1), wait, compute(t)
+  // so that behind B(t) -- and A(t), older still -- there are A(t+RR-2), B(t+1), A(t+RR-1): TN + 8 in the loop
+  CDN_STAMPR(2, 1);      // (in front of the first DMA: a store here would be one more count behind every wait)
+#pragma unroll
+  for (int t = 0; t < RR - 2; ++t) issue(t);
+  loadB(bA, 0);
+  issue(RR - 2);
+  auto step = [&](int t, i32x4 (&bcur)[TN], i32x4 (&bnxt)[TN], auto more_b, auto more_a, auto prev_a) {
+    // behind B(t) there are: A(t+RR-2) if the step before (or the prologue) issued it, B(t+1), A(t+RR-1)
+    constexpr int MB = decltype(more_b)::value, MA = decltype(more_a)::value, PA = decltype(prev_a)::value;
+    if constexpr (MB) loadB(bnxt, t + 1);
+    if constexpr (MA) issue(t + RR - 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TN * MB + 4 * MA + 4 * PA) : "memory");
+    release(bcur);
+    const char *slot = wring + (t % RR) * 4096;
+    i32x4 a0, a1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(slot + frow + ((4 * h + q) ^ fsw) * 16);
+      const unsigned u0 = ucode(v.x), u1 = ucode(v.y), u2 = ucode(v.z), u3 = ucode(v.w);
+      const unsigned p01 = u0 | (u1 << 16), p23 = u2 | (u3 << 16);
+      a0[q] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu);
+      a1[q] = (int)(__builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bcur[j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      i32x4 s16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s16[e] = (int)(((unsigned)bcur[j][e] << 4) & 0xF0F0F0F0u);
+      acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, s16, acc[j], 0, 0, 0);
+    }
+  };
+  // nit is even and >= RR: every step of the loop fetches the A window RR - 1 ahead and the weights one ahead; the last
+  // steps are peeled with their own (static) counts -- no branch and no register copy anywhere near a wait
+  static_assert(RR == 3, "the peeled tail is written for a ring of three windows");
+  {
+    const std::true_type y;
+    const std::false_type n;
+    int t = 0;
+    for (; t + 2 < nit; t += 2) {
+      step(t, bA, bB, y, y, y);
+      step(t + 1, bB, bA, y, y, y);
+    }
+    step(t, bA, bB, y, n, y);
+    step(t + 1, bB, bA, n, n, n);
+  }
+  CDN_STAMPR(2, 2);
+  // ---- epilogue: the four k quarters' int32 partial tiles through LDS (exact), two 32-column tiles per round ----------
+  // P[wave][column][row], rows contiguous: a lane's four consecutive accumulator registers are four consecutive rows
+  float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
+  {
+    int *P = reinterpret_cast<int *>(lds);
+    constexpr int PLD = 36;                           // ints per column: 32 rows + 4 (16-byte aligned, bank-staggered)
+    const int col = tid & 63, r0 = (tid >> 6) * 8;
+    for (int j0 = 0; j0 < TN; j0 += 2) {
+      __syncthreads();                                // (rings drained / the previous round's sums read)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const i32x16 &c = acc[j0 + jj];
+          *reinterpret_cast<i32x4 *>(&P[((w * 64) + jj * 32 + i) * PLD + 8 * g + 4 * h]) =
+              (i32x4){c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+        }
+      __syncthreads();
+      const int co = cb + j0 * 32 + col;
+      if (co < Co) {
+        const float bsv = bias ? bias[co] : 0.0f;
+        const float rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
+        const int t128 = 128 * wsum[co], oc = omap ? omap[co] : co;
+        i32x4 s[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const i32x4 p0 = *reinterpret_cast<const i32x4 *>(&P[(0 * 64 + col) * PLD + r0 + 4 * hh]);
+          const i32x4 p1 = *reinterpret_cast<const i32x4 *>(&P[(1 * 64 + col) * PLD + r0 + 4 * hh]);
+          const i32x4 p2 = *reinterpret_cast<const i32x4 *>(&P[(2 * 64 + col) * PLD + r0 + 4 * hh]);
+          const i32x4 p3 = *reinterpret_cast<const i32x4 *>(&P[(3 * 64 + col) * PLD + r0 + 4 * hh]);
+          s[hh] = (p0 + p1) + (p2 + p3);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = r0 + rr;
+          if (m0 + row < M) {
+            float v = fmaf((float)(s[rr >> 2][rr & 3] + t128), rinv, bsv);
+            if (relu) v = cdn::relu_keep_nan(v);
+            if (R) R[(m0 + row) * ldo + oc] = v;
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+            has_nan |= (v != v);
+          }
+        }
+      }
+    }
+  }
+  CDN_STAMPR(2, 3);
+  if (rmm) {
+    __syncthreads();
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), rmm, blockIdx.x, gridDim.x, qu,
+                             reinterpret_cast<float *>(lds));
+  }
+  CDN_STAMPR(2, 4);
+}
+
+template <int TN, int RR>
+__global__ void __launch_bounds__(256)
+pwi8s_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq, const signed char *__restrict__ Wkb,
+             const float *__restrict__ wscale, const int *__restrict__ wsum, const float *__restrict__ Wp,
+             const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu, long M, int K,
+             int Co, int relu, int lda, int ldo, const int *__restrict__ omap, int Cw, int ncg) {
+  extern __shared__ float4 p8_lds[];
+  char *lds = reinterpret_cast<char *>(p8_lds);
+  CDN_STAMPR(2, 0);
+  // workgroup -> (row block, column group): the ncg workgroups of a row block are 8 ids apart (one XCD)
+  int rb = blockIdx.x, cg = 0;
+  if (ncg == 2) {
+    const int nrb8 = (int)((gridDim.x >> 1) & ~7u), b = blockIdx.x;
+    if (b < 2 * nrb8) { rb = ((b >> 4) << 3) | (b & 7); cg = (b >> 3) & 1; }
+    else { rb = nrb8 + ((b - 2 * nrb8) >> 1); cg = b & 1; }
+  }
+  const long m0 = (long)rb * 32;
+  const int cb = cg * 32 * TN;                       // first column of this workgroup
+  const float qs = reinterpret_cast<const float *>(aq)[2];
+  const float qz = reinterpret_cast<const float *>(aq)[3];
+  if (aq[6] == 0) {
+    pwi8s_body<TN, RR>(A, Wkb, wscale, wsum, bias, R, rmm, qu, M, K, Co, relu, lda, ldo, omap, ncg, m0, cb, qs, qz, lds);
+  } else {      // codes too wide for the nibble split: this batch on f32 MFMA (the rare path, as in pwi8_kernel)
+    float *fl = reinterpret_cast<float *>(lds);
+    const int cend = min(Co, cb + 32 * TN);
+    pwi8_wide_path<32, 128, 1>(A, Wp, bias, R, rmm, qu, M, Cw, cend, relu, lda, ldo, omap, qs, qz, fl, fl + 32 * 17,
+                               fl + (32 + 128) * 17, m0, cb, (32 * TN + 127) / 128, (int)blockIdx.x, (int)gridDim.x);
+  }
+}
 // ------------------------------------------------------------------------------------------
 // pwb3: the W4 pointwise conv on FINAL (already fake-quantised, or fp32) activations -- the first 1x1 of a
 // ShuffleNetV2 unit, whose input channels carry different generations of the layer's running QuantAct and
@@ -2965,13 +3211,37 @@ static bool pws_applies(long M, int64_t K, int64_t Co, int64_t lda, const float 
   return tiles <= (long)CDN_PWS_MAX_TILES && cdn::ceil_div(M, 32) * cdn::ceil_div(Co, 32) <= (1L << 20);
 }
 
+// pwi8s_kernel instead of pwi8_kernel: K >= 512 whole 64-channel blocks (every wave an even number of >= 2 windows),
+// Co <= 256, the k-blocked copy of the codes given (CDN_X_WCODES_KB).  Measured (round 5, one box, interleaved):
+// CoDeNet1x stage 0 (16384 x 1024 -> 256) 37.5 -> 31 us, CoDeNet2x stage 0 (8192 x 2176 -> 256) 47.6 -> 25.9 us.
+// CDN_NO_PWI8S: A/B switch.
+static int64_t wcodes_kb_columns(int64_t Kpad, int64_t Co) {
+#if defined(CDN_NO_PWI8S)
+  return 0;
+#endif
+  if (Kpad < 512 || (Kpad & 63) || Co > 256 || Co < 1) return 0;
+  return Co <= 64 ? 64 : Co <= 128 ? 128 : 256;
+}
+static bool pwi8s_applies(long M, int64_t Kt, int Cpad, int64_t Co, bool pw_fast, const signed char *w_kb) {
+  return w_kb != nullptr && pw_fast && Kt == Cpad && wcodes_kb_columns(Kt, Co) != 0 && M >= 1 &&
+         2 * cdn::ceil_div(M, 32) <= (long)kMaxPartials;
+}
+extern "C" int64_t cdn_codenet_wcodes_kb_columns(int64_t C, int64_t Co) {
+  return C > 0 ? wcodes_kb_columns((C + 63) / 64 * 64, Co) : 0;
+}
+extern "C" int64_t cdn_codenet_wcodes_kb_offset(int64_t C, int64_t Co) {
+  return C > 0 && Co > 0 ? (Co * ((C + 63) / 64 * 64) + 255) / 256 * 256 : 0;
+}
+
 static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, int64_t Co,
                             const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
                             const int *w_pw_colsum, const float *bias_pw, const float *ep_scale,
                             const float *ep_shift, int relu, float *r_out, float2 *rmm,
                             const cdn::QUpdate &qu_r, int ptag, hipStream_t st, int64_t lda = 0,
                             int64_t ldo = 0, const unsigned char *a_gen = nullptr,
-                            const int *out_map = nullptr, bool a_padded = false) {
+                            const int *out_map = nullptr, bool a_padded = false,
+                            const signed char *w_kb = nullptr) {
+  // w_kb: the k-blocked copy of w_pw_codes (include/codenet_dcn.h, CDN_X_WCODES_KB) or NULL
   // a_padded: the rows of A hold lda = round_up(C, 64) valid floats (the pad repeats channel C - 1) and the weight
   // codes are zero beyond C: the int8 path runs its whole-tile form over K = lda; the f32 branch for wide codes keeps C
   if (lda == 0) lda = C;      // row strides of A / R in floats (views into wider channels-last tensors)
@@ -3022,6 +3292,17 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                                                              w_pw_colsum, w_pw, bias_pw, r_out, rmm, \
                                                              qu_r, M, (int)Kt, Cpad, (int)Co, relu, (int)lda, (int)ldo, out_map, (int)C); \
   } while (0)
+    // long-K launches with the k-blocked copy of the codes at hand (the fused stage, stage 0): the streaming kernel
+    if (pwi8s_applies(M, Kt, Cpad, Co, pw_fast, w_kb)) {
+      const long nrb = cdn::ceil_div(M, 32);
+      const int ncg = Co > 128 ? 2 : 1;
+      const unsigned grid = (unsigned)(nrb * ncg);
+      constexpr int kLds = 4 * 3 * 4096;
+      auto kern = Co <= 64 ? pwi8s_kernel<2, 3> : pwi8s_kernel<4, 3>;
+      kern<<<grid, 256, kLds, st>>>(d, dst, w_kb, w_pw_scale, w_pw_colsum, w_pw, bias_pw, r_out, rmm, qu_r, M, (int)Kt,
+                                    (int)Co, relu, (int)lda, (int)ldo, out_map, (int)C, ncg);
+      return cdn::check_launch("codenet int8 pointwise (streaming)");
+    }
     // Co > 64: 64-row tiles (36 KiB LDS, 112 VGPRs: four workgroups per CU; measured at stage 1
     // 26.3 us vs 30.6 us with 128-row tiles; 32-row tiles change nothing at stage 0: 40.2 vs 40.7 us)
     // round 4: when 64-row tiles leave the chip with at most ONE workgroup per CU (CoDeNet2x stage 0 at 32 images:
@@ -3222,10 +3503,16 @@ extern "C" int cdn_codenet_stage_fused_forward(
     void *stream) {
   CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
-  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK | CDN_X_ACT_PERCENTILE)) == 0 &&
+  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK | CDN_X_ACT_PERCENTILE | CDN_X_WCODES_KB)) == 0 &&
                   ((x_nhwc & CDN_X_GATHER_MASK) >> 8) <= 2, CDN_ERR_ARG,
-              "x_nhwc: 0 / 1, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT, | CDN_X_ACT_PERCENTILE");
+              "x_nhwc: 0 / 1, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT, | CDN_X_ACT_PERCENTILE, "
+              "| CDN_X_WCODES_KB");
   const int gmode = (x_nhwc & CDN_X_GATHER_MASK) >> 8;      // per-call schedule choice (tests); no library state
+  // the k-blocked copy of the weight codes behind the row-major ones (the streaming int8 pointwise kernel)
+  CDN_REQUIRE(!(x_nhwc & CDN_X_WCODES_KB) || (w_pw_codes && cdn_codenet_wcodes_kb_columns(C, Co) != 0), CDN_ERR_ARG,
+              "CDN_X_WCODES_KB: no k-blocked form for C = %lld, Co = %lld (cdn_codenet_wcodes_kb_columns)",
+              (long long)C, (long long)Co);
+  const signed char *w_kb = (x_nhwc & CDN_X_WCODES_KB) ? w_pw_codes + cdn_codenet_wcodes_kb_offset(C, Co) : nullptr;
   // --act-percentile: the three QuantActs follow the 0.1 % / 99.9 % order statistics of their input instead of its
   // extremes (only while the ranges are tracked)
   const bool pct = (x_nhwc & CDN_X_ACT_PERCENTILE) != 0 && running != 0;
@@ -3375,7 +3662,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
   rc = launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
                         bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
-                        st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d);
+                        st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d, w_kb);
   if (rc) return rc;
   if (pct) rc = commit_percentile(r_out, N * H * W * Co, 1, qu_r);
   return rc;

@@ -392,6 +392,21 @@ def set_global_range(model, flag=True):
 
 
 ACT_PERCENTILE = 0x400      # CDN_X_ACT_PERCENTILE (include/codenet_dcn.h)
+WCODES_KB = 0x800           # CDN_X_WCODES_KB
+
+
+def stage_int8_codes(convbn, kblocked=True):
+    """(i8 triple or None, flag) for the pointwise conv of a fused stage: the int8 form of the folded weights, with the
+    k-blocked copy behind the codes -- and CDN_X_WCODES_KB to OR into the stage call's layout argument -- where the
+    library has a use for it (long-K stages: cdn_codenet_wcodes_kb_columns)."""
+    from . import _native as N_
+    lib = N_.lib()
+    conv = convbn.conv
+    cols = lib.cdn_codenet_wcodes_kb_columns(conv.in_channels, conv.out_channels) if kblocked else 0
+    if cols:
+        i8 = convbn.folded_int8_kblocked(cols, lib.cdn_codenet_wcodes_kb_offset(conv.in_channels, conv.out_channels))
+        return i8, (WCODES_KB if i8 is not None else 0)
+    return convbn.folded_int8(), 0
 
 
 def act_fusable(act, allow_percentile=False):
@@ -476,10 +491,11 @@ class FusedHotPath:
     All device buffers are allocated once per input shape, so a call issues only kernel launches
     and can be captured into a HIP graph (``capture()``)."""
 
-    def __init__(self, deconv_layers, int8_pointwise=True):
+    def __init__(self, deconv_layers, int8_pointwise=True, kblocked_codes=True):
         from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
         self.seq = deconv_layers
         self.int8_pointwise = int8_pointwise
+        self.kblocked_codes = kblocked_codes      # (False: tests compare the two int8 pointwise kernels)
         mods = list(deconv_layers)
         self.quantized = isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive)
         step = 3 if self.quantized else 4
@@ -538,9 +554,10 @@ class FusedHotPath:
         if self.quantized:
             q, post = st[0], st[1]
             w_pw, b_pw = q.quant_conv_channel_bn.folded()
-            i8 = q.quant_conv_channel_bn.folded_int8() if self.int8_pointwise else None
+            i8, kb_flag = (stage_int8_codes(q.quant_conv_channel_bn, self.kblocked_codes) if self.int8_pointwise
+                           else (None, 0))
             return dict(
-                i8=i8,
+                i8=i8, kb_flag=kb_flag,
                 w_scale=q.quant_conv_scale.quantized_weight().reshape(-1),
                 b_scale=q.quant_conv_scale.bias, lo=q.quant_act[0].min_val, hi=q.quant_act[0].max_val,
                 w_dw=q.quant_deform_conv.quantized_weight(), w_pw=w_pw.reshape(w_pw.size(0), -1),
@@ -551,7 +568,7 @@ class FusedHotPath:
         return dict(w_scale=op.conv_scale.weight.reshape(-1), b_scale=op.conv_scale.bias,
                     lo=op.conv_bound.min_val, hi=op.conv_bound.max_val, w_dw=op.conv.weight,
                     w_pw=op.conv_channel.weight.reshape(op.out_channels, -1), bias=None,
-                    ep_scale=es, ep_shift=eh, acts=(None, None, None), i8=None)
+                    ep_scale=es, ep_shift=eh, acts=(None, None, None), i8=None, kb_flag=0)
 
     def _alloc(self, x):
         from . import _native as N_
@@ -628,7 +645,8 @@ class FusedHotPath:
                               act._device_state(x.device).data_ptr()]
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
                 rc = lib.cdn_codenet_stage_fused_forward(
-                    cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0) | pct, sb["up"], cur_q, Nb, sb["C"],
+                    cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0) | pct | p["kb_flag"], sb["up"], cur_q, Nb,
+                    sb["C"],
                     sb["Co"], sb["H"], sb["W"],
                     ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
                     ptr(p["w_dw"]), ptr(p["w_pw"]),
@@ -809,7 +827,10 @@ class FrozenHotPath:
                 q = st[0]
                 a_s, a_d, a_r = self._acts(st)
                 sp = [a._device_state(dev).data_ptr() for a in (a_s, a_d, a_r)]
-                codes, scale, colsum = q.quant_conv_channel_bn.folded_int8()
+                if sb["codes"]:
+                    (codes, scale, colsum), kb_flag = q.quant_conv_channel_bn.folded_int8(), 0
+                else:
+                    (codes, scale, colsum), kb_flag = stage_int8_codes(q.quant_conv_channel_bn)
                 w_pw, b_pw = q.quant_conv_channel_bn.folded()
                 w_sc = q.quant_conv_scale.quantized_weight().reshape(-1)
                 w_dw = q.quant_deform_conv.quantized_weight()
@@ -841,7 +862,7 @@ class FrozenHotPath:
                     for a in (a_s, a_d, a_r):
                         acts3 += [a.x_min.data_ptr(), a.x_max.data_ptr(), a._device_state(dev).data_ptr()]
                     rc = lib.cdn_codenet_stage_fused_forward(
-                        cur_ptr, cur_kind, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
+                        cur_ptr, cur_kind | kb_flag, sb["up"], cur_q, Nb, sb["C"], sb["Co"], sb["H"], sb["W"],
                         ptr(w_sc), ptr(q.quant_conv_scale.bias), float(bound.min_val), float(bound.max_val),
                         ptr(w_dw), ptr(w_pw.reshape(w_pw.size(0), -1)), ptr(codes), ptr(scale), ptr(colsum), ptr(b_pw),
                         None, None, 1, *acts3, bits, float(a_r.momentum), 0, w32_ptr, w32_bytes,

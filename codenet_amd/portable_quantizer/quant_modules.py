@@ -344,6 +344,29 @@ class QuantBnConv2d(Module, _WeightQuantizer):
             return self._int8_codes(w)
         return self._cached_i8((self.conv.weight, self.bn.weight, self.bn.running_var), compute)
 
+    def folded_int8_kblocked(self, columns, offset):
+        """(codes + k-blocked copy, scale, column sums): folded_int8() with the codes followed -- at byte `offset` of the
+        same int8 buffer -- by the copy [Cpad / 32][columns][32] the streaming int8 pointwise kernel reads
+        (include/codenet_dcn.h, CDN_X_WCODES_KB; columns / offset from cdn_codenet_wcodes_kb_columns / _offset).  Cached
+        with the codes; the buffer is rewritten in place when the weights change (HIP graphs keep its address)."""
+        i8 = self.folded_int8()
+        if i8 is None:
+            return None
+        codes, scale, colsum = i8
+        key = (codes.data_ptr(), codes._version, int(columns), int(offset))
+        cache = getattr(self, "_kb_cache", None)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                co, cpad = codes.shape
+                full = torch.zeros(int(columns), cpad, dtype=torch.int8, device=codes.device)
+                full[:co] = codes
+                kb = full.view(int(columns), cpad // 32, 32).permute(1, 0, 2).contiguous()
+                buf = torch.zeros(int(offset) + kb.numel(), dtype=torch.int8, device=codes.device)
+                buf[:co * cpad] = codes.reshape(-1)
+                buf[int(offset):] = kb.reshape(-1)
+                self._kb_cache = (key, refresh_in_place(cache[1] if cache else None, buf))
+        return self._kb_cache[1], scale, colsum
+
     def forward(self, x):
         w, b = self.folded()
         return F.conv2d(x, w, b, self.conv.stride, self.conv.padding, self.conv.dilation,

@@ -380,6 +380,18 @@ int cdn_codenet_stage_fused_supported(int64_t N, int64_t C, int64_t H, int64_t W
  * QuantActs of the stage follow the 0.1 % / 99.9 % order statistics of their inputs (cdn_kth_values) instead of the
  * batch extremes; needs the three QuantActs. */
 #define CDN_X_ACT_PERCENTILE 0x400
+/* | CDN_X_WCODES_KB (round 5): w_pw_codes holds, behind the row-major codes [Co][Cpad] (Cpad = round_up(C, 64)), at byte
+ * offset cdn_codenet_wcodes_kb_offset(C, Co) = round_up(Co * Cpad, 256), a K-BLOCKED copy of the same codes
+ *   kb[window][column][32]   window < Cpad / 32, column < cdn_codenet_wcodes_kb_columns(C, Co), 32 consecutive channels;
+ *                            zero rows for column >= Co
+ * which lets the int8 pointwise kernel of a long-K stage (C >= 512: stage 0) stream the weights with one coalesced
+ * kilobyte per 32-column tile and window (pwi8s_kernel).  cdn_codenet_wcodes_kb_columns returns 0
+ * where the library has no use for the copy (the flag is then an argument error).  Host-side weight preparation only; no
+ * reference counterpart (the reference's conv_channel is a cuDNN 1x1 convolution on fake-quantised fp32 weights,
+ * quant_modules.py:441-447).  Results are bit-identical with and without the copy. */
+#define CDN_X_WCODES_KB 0x800
+int64_t cdn_codenet_wcodes_kb_columns(int64_t C, int64_t Co);
+int64_t cdn_codenet_wcodes_kb_offset(int64_t C, int64_t Co);
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,

@@ -1038,3 +1038,42 @@ def test_stage_entry_points_from_two_threads():
         assert all(torch.equal(rng[k], rng0[k]) for k in rng0)
     # and the two schedules agree with each other (bit-identical kernels)
     assert all(torch.equal(a, b) for a, b in zip(serial[0][0], serial[1][0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("planes,hw,nb", [([1024, 256, 128], 16, 5), ([2153, 256, 128], 8, 4), ([512, 100, 64], 12, 3),
+                                           ([576, 64, 32], 10, 3)])
+def test_streaming_int8_pointwise_is_bit_identical_to_the_tile_kernel(planes, hw, nb):
+    """pwi8s_kernel (k-blocked weight codes, CDN_X_WCODES_KB: four waves split K, wave-private LDS-DMA rings, inline-asm
+    weight loads) against pwi8_kernel on the same stages: the integer sums are order-independent and the epilogue
+    expression is the same, so the stage outputs, all tracked ranges and the final tensor are EQUAL -- over several
+    batches with running ranges (the first ones take the wide-code f32 branch of both kernels, later ones the int8
+    path), CoDeNet1x / 2x stage-0 shapes (K = 1024, 2176 = 17 windows per wave pair), ragged columns (Co = 100: zero rows
+    of the k-blocked copy) and a row count that is no multiple of 32."""
+    from codenet_amd import pipeline
+    import copy
+    net_a = pipeline.build_hot_path(quantized=True, planes=planes, seed=planes[0] + hw).cuda()
+    net_b = copy.deepcopy(net_a)
+    for n in (net_a, net_b):
+        pipeline.set_running_stat(n, True)
+    fa = pipeline.FusedHotPath(net_a.deconv_layers, kblocked_codes=True)
+    fb = pipeline.FusedHotPath(net_b.deconv_layers, kblocked_codes=False)
+    used = []
+    fa.stage_hook = lambda sb: used.append(fa._stage_params(fa.stages[0])["kb_flag"])
+    g = torch.Generator().manual_seed(hw)
+    for it in range(nb):
+        x = (torch.randn(3, planes[0], hw, hw, generator=g) * (1.0 + 0.3 * it)).cuda()
+        ya, yb = fa(x).clone(), fb(x).clone()
+        assert torch.equal(ya, yb), "batch %d: outputs differ (max %g)" % (it, (ya - yb).abs().max().item())
+        for ba, bb in zip(fa._bufs["stages"], fb._bufs["stages"]):
+            assert torch.equal(ba["r"], bb["r"]), "batch %d: stage output %dx%d differs" % (it, ba["H"], ba["W"])
+        ra = {k: v for k, v in net_a.state_dict().items() if k.endswith(("x_min", "x_max"))}
+        rb = net_b.state_dict()
+        for k, v in ra.items():
+            assert torch.equal(v, rb[k]), "batch %d: range %s differs" % (it, k)
+    assert used and used[0] == pipeline.WCODES_KB       # the k-blocked form was in use for stage 0
+    # a NaN in the pointwise input reaches output and range through both kernels alike
+    x = torch.randn(3, planes[0], hw, hw, generator=g).cuda()
+    x[1, 3, 2, 2] = float("nan")
+    ya, yb = fa(x), fb(x)
+    assert torch.equal(torch.isnan(ya), torch.isnan(yb))

@@ -453,3 +453,97 @@ def test_pmc_steady_reads_the_steady_state_iterations(tmp_path):
     assert len(spans) == 2 and all(hi - lo == 3 for lo, hi in spans)
     per_iter = sum(v for lo, hi in spans for _, v in rows2[lo:hi]) / len(spans)
     assert per_iter == 70.0
+
+
+def test_kblocked_weight_codes_layout_and_flag_validation():
+    """CDN_X_WCODES_KB (include/codenet_dcn.h): the library names the column count / byte offset of the k-blocked copy,
+    folded_int8_kblocked builds exactly that layout behind the row-major codes, and the flag is refused where the
+    library has no such form."""
+    from codenet_amd import _native, pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantBnConv2d
+    lib = _native.lib()
+    assert lib.cdn_codenet_wcodes_kb_columns(1024, 256) == 256 and lib.cdn_codenet_wcodes_kb_columns(2153, 256) == 256
+    assert lib.cdn_codenet_wcodes_kb_columns(512, 100) == 128 and lib.cdn_codenet_wcodes_kb_columns(512, 64) == 64
+    assert lib.cdn_codenet_wcodes_kb_columns(256, 128) == 0          # short K: the tile kernel keeps it
+    assert lib.cdn_codenet_wcodes_kb_columns(1024, 257) == 0
+    assert lib.cdn_codenet_wcodes_kb_offset(2153, 256) == 256 * 2176
+    assert lib.cdn_codenet_wcodes_kb_offset(515, 3) == (3 * 576 + 255) // 256 * 256
+    torch.manual_seed(0)
+    conv, bn = nn.Conv2d(520, 70, 1, bias=False), nn.BatchNorm2d(70)
+    q = QuantBnConv2d(weight_bit=4, quant_mode="symmetric", per_channel=True)
+    q.set_param(conv, bn)
+    q.eval()
+    with torch.no_grad():
+        codes, scale, colsum = q.folded_int8()
+        cols, off = lib.cdn_codenet_wcodes_kb_columns(520, 70), lib.cdn_codenet_wcodes_kb_offset(520, 70)
+        assert cols == 128 and codes.shape == (70, 576)
+        buf, scale2, colsum2 = q.folded_int8_kblocked(cols, off)
+        assert scale2 is scale and colsum2 is colsum
+        assert buf.dtype == torch.int8 and buf.numel() == off + 576 * cols
+        assert torch.equal(buf[:70 * 576].view(70, 576), codes)
+        kb = buf[off:].view(576 // 32, cols, 32)
+        for co in (0, 13, 69):
+            assert torch.equal(kb[:, co, :].reshape(-1), codes[co])
+        assert int(kb[:, 70:, :].abs().sum()) == 0
+        # cached: same buffer until the weights change, then rewritten IN PLACE (captured graphs keep the address)
+        again = q.folded_int8_kblocked(cols, off)[0]
+        assert again.data_ptr() == buf.data_ptr()
+        conv.weight.mul_(-1.0)
+        new = q.folded_int8_kblocked(cols, off)[0]
+        assert new.data_ptr() == buf.data_ptr()
+        codes_n = q.folded_int8()[0]
+        assert torch.equal(new[off:].view(576 // 32, cols, 32)[:, 5, :].reshape(-1), codes_n[5])
+        i8, flag = pipeline.stage_int8_codes(q)
+        assert flag == pipeline.WCODES_KB and i8[0].data_ptr() == buf.data_ptr()
+    # the flag where no k-blocked form exists: an argument error before any HIP call
+    one = 4096
+    rc = lib.cdn_codenet_stage_fused_forward(one, 1 | pipeline.WCODES_KB, 0, None, 1, 256, 128, 8, 8, one, None, -7.0, 8.0,
+                                             one, one, one, one, one, None, None, None, 1, *([None] * 9), 8, 0.99, 0,
+                                             one, 1 << 20, one, None)
+    assert rc == -1 and b"CDN_X_WCODES_KB" in lib.cdn_last_error()
+
+
+_ASM_OK = """
+_Z4demoILi1EEvPf: ; @demo
+\ts_load_dwordx2 s[4:5], s[0:1], 0x0
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[2:5], v1, s[4:5] offset:0
+\t;;#ASMEND
+\t;;#ASMSTART
+\tglobal_load_lds_dwordx4 v9, s[6:7]
+\t;;#ASMEND
+\ts_cbranch_scc1 .LBB0_2
+\tv_add_u32_e32 v7, 1, v7
+.LBB0_2:
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(1)
+\t;;#ASMEND
+\tv_mov_b32_e32 v6, v2
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def test_asm_load_checker_finds_a_read_before_the_wait(tmp_path):
+    """tools/check_asm_loads.py (the guard of pwi8s_kernel's inline-asm loads): clean on a correct sequence, and it
+    reports a copy placed between the load and the wait, a wait whose count does not cover the load, and a hazard that
+    exists on one branch only; the shipped library's own assembly is checked when the build left it behind."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_asm_loads as C
+    ok = tmp_path / "ok.s"
+    ok.write_text(_ASM_OK)
+    assert C.check(str(ok), "demo", verbose=False) == (0, 1)
+    bad = tmp_path / "copy.s"
+    bad.write_text(_ASM_OK.replace("\ts_cbranch_scc1 .LBB0_2\n", "\tv_mov_b64_e32 v[10:11], v[4:5]\n\ts_cbranch_scc1 .LBB0_2\n"))
+    assert C.check(str(bad), "demo", verbose=False)[0] == 1
+    lenient = tmp_path / "lenient.s"
+    lenient.write_text(_ASM_OK.replace("vmcnt(1)", "vmcnt(2)"))
+    assert C.check(str(lenient), "demo", verbose=False)[0] == 1
+    branch = tmp_path / "branch.s"          # the DMA on the fall-through path only: behind the branch the count is short
+    dma = "\t;;#ASMSTART\n\tglobal_load_lds_dwordx4 v9, s[6:7]\n\t;;#ASMEND\n"
+    branch.write_text(_ASM_OK.replace(dma, "").replace("\tv_add_u32_e32 v7, 1, v7\n", dma))
+    assert C.check(str(branch), "demo", verbose=False)[0] == 1
+    shipped = os.path.join(ROOT, "build", "csrc", "codenet_fused-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if os.path.exists(shipped):
+        nbad, nloads = C.check(shipped, "pwi8s_kernel", verbose=False)
+        assert nbad == 0 and nloads >= 12

@@ -18,6 +18,7 @@ BUDGET = {
     "dw2u_kernelILi32ELb1ELb1": 256,              # stage 2
     "pwi8_kernelILi64ELi128ELi2ELb1": 128,        # stages 0-1: four workgroups per CU
     "pwi8_kernelILi128ELi64ELi4ELb1": 128,        # stage 2 (small M)
+    "pwi8s_kernelILi4ELi3": 168,                  # stage 0 (round 5): three workgroups per CU (512 / 3 registers)
     "pwi8_kernelILi64ELi64ELi2ELb1": 128,         # Co <= 64 at large M: stage 2, layer 1, heads
     "scale_nchw_kernel": 128, "scale_nhwc_kernelILb1": 128, "unpack_kernelILb1": 128,
     "pwd3_kernelILi2": 256, "pwd3_kernelILi4": 256,   # streaming pointwise: two waves per SIMD
