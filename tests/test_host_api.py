@@ -543,7 +543,7 @@ def test_asm_load_checker_finds_a_read_before_the_wait(tmp_path):
     dma = "\t;;#ASMSTART\n\tglobal_load_lds_dwordx4 v9, s[6:7]\n\t;;#ASMEND\n"
     branch.write_text(_ASM_OK.replace(dma, "").replace("\tv_add_u32_e32 v7, 1, v7\n", dma))
     assert C.check(str(branch), "demo", verbose=False)[0] == 1
-    shipped = os.path.join(ROOT, "build", "csrc", "codenet_fused-hip-amdgcn-amd-amdhsa-gfx950.s")
+    shipped = os.path.join(ROOT, "build", "asm", "codenet_fused-hip-amdgcn-amd-amdhsa-gfx950.s")
     if os.path.exists(shipped):
         nbad, nloads = C.check(shipped, "pwi8s_kernel", verbose=False)
         assert nbad == 0 and nloads >= 12
