@@ -146,7 +146,7 @@ def launch_ranks(args):
 
 # ---- live HBM traffic of the step (roofline.traffic measured IN THIS RUN) -------------------------
 
-FAMILY_OF = (("dw0p_kernel", "dw"), ("dw2u_kernel", "dw"), ("dw2_kernel", "dw"), ("pwi8_kernel", "pointwise"),
+FAMILY_OF = (("dw0p_kernel", "dw"), ("dw2u_kernel", "dw"), ("dw2_kernel", "dw"), ("pwi8_kernel", "pointwise"), ("pwi8s_kernel", "pointwise"),
              ("pw3_kernel", "pointwise"), ("pws_kernel", "pointwise"), ("pwq8_kernel", "pointwise"), ("pwb3_kernel", "pointwise"),
              ("pwd3_kernel", "pointwise"), ("scale_n", "scale"), ("unpack_kernel", "unpack"), ("expand8", "unpack"))
 
@@ -839,7 +839,7 @@ def main():
             ach = flops_pw / (per_kernel["pointwise"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
-                    "kernel": "pwi8_kernel/pw3_kernel" if fused is not None else "pointwise_kernel"}
+                    "kernel": "pwi8s_kernel/pwi8_kernel/pw3_kernel" if fused is not None else "pointwise_kernel"}
         else:
             key = dominant if dominant in alg else "dw"
             nbytes = alg.get(key, 0)
@@ -849,7 +849,7 @@ def main():
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "kernel": ({"dw": "dw0p_kernel+dw2_kernel+dw2u_kernel", "scale": "scale_*_kernel",
-                                "unpack": "unpack_kernel", "pointwise": "pwi8_kernel/pw3_kernel/pwq8_kernel"}
+                                "unpack": "unpack_kernel", "pointwise": "pwi8s_kernel/pwi8_kernel/pw3_kernel/pwq8_kernel"}
                                if fused is not None else
                                {"dw": "dw_kernel", "scale": "scale_kernel",
                                 "quantact": "minmax_kernel+fake_quant_kernel"}).get(dominant, dominant)}

@@ -531,3 +531,315 @@ extern "C" int cdn_codenet_weight_prep_ranked(const float *w, int64_t Co, int64_
   return weight_prep_impl(w, Co, K, scale_factor, bn_bias, bn_mean, conv_bias, bits, k_low, k_high, shrink, w_q,
                           bias_out, stream);
 }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// pwi8n_kernel (round 5): the FORWARD conv_channel of the QAT step on the int8 matrix cores.
+// In the QAT step both operands of y = conv1x1(QA_d(d), fq_w(w)) are integers in disguise: the activation is
+// (L + zp) / scale with L the 8-bit code of the running QuantAct (quant_modules.py:203-225), the weight is q / ws with q
+// the 4-bit per-channel symmetric code (quant_utils.py:207-225).  pointwise_kernel multiplies the two fp32 disguises on
+// v_mfma_f32_32x32x2_f32 -- the fp32 VECTOR rate, 71 / 32 / 41 us at the step's three stages (4.3 GFLOP at 157 TFLOP/s
+// is 27 us at stage 0 before anything else) -- where the inference schedule (pwi8_kernel, codenet_fused.hip) sums the
+// integers exactly:  y = (sum_k (L_k + zp) q_k) / (scale ws) + b, one rounding instead of K.  This is that kernel for
+// the training path's NCHW layout, where the MFMA operand layouts need no staging at all:
+//   A  (rows = output channels)  the weight codes from a k-blocked copy [window][column][32 B] made by
+//      pwn_wcodes_kernel below from the fake-quantised fp32 weights the autograd graph holds (codes = rint(w ws));
+//   B  (columns = 32 consecutive pixels)  lane (j, h) loads d[c][p0 + j] for the 16 channels c = 32 t + 16 h + e of
+//      window t -- sixteen dword loads, each a pair of full 128-byte lines per wave -- converts them to codes and packs
+//      the two nibble operands in registers (pwi8_kernel's expressions); no LDS, no barrier in the k loop;
+//   C  lane (j, h) holds pixel j of 4 x 4 output channels per tile: the stores are 128-byte lines of y[co][p].
+// KS = 4: the four waves of a workgroup are the four quarters of K of one pixel block, int32 partial tiles added
+// through LDS (exact); KS = 1: four pixel blocks.  Codes too wide for the nibble split (state[6]: the first steps of a
+// fresh EMA) take the f32-MFMA form of the same loop on the fake-quantised values -- pointwise_kernel's arithmetic.
+// ------------------------------------------------------------------------------------------------------
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+
+__global__ void __launch_bounds__(256)
+pwn_wcodes_kernel(const float *__restrict__ wq, int Co, int C, int Cot, signed char *__restrict__ kb,
+                  float *__restrict__ wscale, int *__restrict__ wsum) {
+  // one wave per output column (Cot >= Co of them: the columns behind Co are zero).  The row holds q / ws with
+  // |q| <= 8 and its largest magnitude is 7 / ws (the channel's own extreme maps to +-7) or 8 / ws (--wt-percentile
+  // clamps): ws is recovered as 7 / max or 8 / max, whichever makes every w ws an integer.
+  const int lane = threadIdx.x & 63;
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (co >= Cot) return;
+  const float *row = wq + (long)co * C;
+  float mag = 0.0f;
+  if (co < Co)
+    for (int k = lane; k < C; k += 64) mag = fmaxf(mag, fabsf(row[k]));
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) mag = fmaxf(mag, __shfl_xor(mag, m, 64));
+  float ws = mag > 0.0f ? __fdiv_rn(7.0f, mag) : 1.0f;
+  if (co < Co) {
+    bool ok = true;
+    for (int k = lane; k < C; k += 64) {
+      const float t = row[k] * ws;
+      ok &= fabsf(t - rintf(t)) < 0.02f;
+    }
+    if (!__all(ok)) ws = __fdiv_rn(8.0f, mag);
+  }
+  int sum = 0;
+  for (int k = lane; k < C; k += 64) {
+    int q = 0;
+    if (co < Co) q = min(max((int)rintf(row[k] * ws), -8), 7);
+    kb[((long)(k >> 5) * Cot + co) * 32 + (k & 31)] = (signed char)q;
+    sum += q;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, 64);
+  if (lane == 0) {
+    wscale[co] = ws;
+    wsum[co] = sum;
+  }
+}
+
+template <int TN, int KS>
+__global__ void __launch_bounds__(256)
+pwi8n_kernel(const float *__restrict__ D, const unsigned *__restrict__ dq, const signed char *__restrict__ Wkb,
+             const float *__restrict__ wscale, const int *__restrict__ wsum, const float *__restrict__ Wq,
+             const float *__restrict__ bias, float *__restrict__ Y, float2 *__restrict__ mm, int C, int Co, int HW,
+             int ncg) {
+  extern __shared__ float4 pwn_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int cg = blockIdx.x % ncg, pbg = blockIdx.x / ncg;
+  const int pb = KS == 4 ? pbg : pbg * 4 + w;                 // this wave's 32-pixel block
+  const int npb = HW >> 5;
+  const bool live = pb < npb;                                  // (KS = 1: the last workgroup of an image may be short)
+  const int p0 = 32 * (live ? pb : 0);
+  const int cb = cg * 32 * TN, Cot = 32 * TN * ncg;
+  const int nwin = C >> 5;
+  const int t0 = KS == 4 ? w * (nwin >> 2) + min(w, nwin & 3) : 0;
+  const int nit = KS == 4 ? (nwin >> 2) + (w < (nwin & 3) ? 1 : 0) : nwin;
+  const float qs = reinterpret_cast<const float *>(dq)[2], qz = reinterpret_cast<const float *>(dq)[3];
+  const bool wide = dq[6] != 0;
+  const float *Dn = D + ((long)n * C + 32 * t0) * HW + p0 + j;
+  float mn = INFINITY, mx = -INFINITY;
+  bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
+  // epilogue of one output: value from the reduced sum (int path: exact integer; wide path: fp32 sum), store, range
+  auto finish = [&](float v, int co, int p) {
+    Y[((long)n * Co + co) * HW + p] = v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+    has_nan |= (v != v);
+  };
+  if (!wide) {
+    const int ioff = (int)qz + (2048 - 128) - 0x4B400000;
+    auto ucode = [&](float v) -> unsigned {
+#pragma clang fp contract(off)
+      const float y_p = qs * v;      // (two roundings, as the reference: quant_utils.py:33-41; see pwi8_kernel)
+      const float y = (y_p - qz) + 12582912.0f;
+      int u = (int)__float_as_uint(y) + ioff;
+      u = min(max(u, 8), 4087);
+      return (unsigned)u;
+    };
+    i32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = (i32x16){0};
+    const signed char *wp = Wkb + (((long)t0 * Cot + cb + j) * 32 + 16 * h);
+    float v[16], vn[16];
+    i32x4 a[TN], an[TN];
+    auto load = [&](float (&x)[16], i32x4 (&aw)[TN], int t) {
+      const float *src = Dn + (long)(32 * t + 16 * h) * HW;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) x[e] = src[(long)e * HW];
+#pragma unroll
+      for (int q = 0; q < TN; ++q) aw[q] = *reinterpret_cast<const i32x4 *>(wp + ((long)t * Cot + 32 * q) * 32);
+    };
+    if (nit > 0) load(v, a, 0);
+    for (int t = 0; t < nit; ++t) {
+      if (t + 1 < nit) load(vn, an, t + 1);
+      i32x4 blo, bhi;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned u0 = ucode(v[4 * q]), u1 = ucode(v[4 * q + 1]), u2 = ucode(v[4 * q + 2]), u3 = ucode(v[4 * q + 3]);
+        const unsigned p01 = u0 | (u1 << 16), p23 = u2 | (u3 << 16);
+        blo[q] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) & 0x0F0F0F0Fu);
+        bhi[q] = (int)(__builtin_amdgcn_perm(p23 >> 4, p01 >> 4, 0x06040200u) ^ 0x80808080u);
+      }
+#pragma unroll
+      for (int q = 0; q < TN; ++q) acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[q], blo, acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        i32x4 a16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a16[e] = (int)(((unsigned)a[q][e] << 4) & 0xF0F0F0F0u);
+        acc[q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a16, bhi, acc[q], 0, 0, 0);
+      }
+      if (t + 1 < nit) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = vn[e];
+#pragma unroll
+        for (int q = 0; q < TN; ++q) a[q] = an[q];
+      }
+    }
+    if (KS == 1) {
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < TN; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cb + 32 * q + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < Co) {
+              const float rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
+              finish(fmaf((float)(acc[q][r] + 128 * wsum[co]), rinv, bias ? bias[co] : 0.0f), co, p0 + j);
+            }
+          }
+      }
+    } else {
+      // P[wave][tile][row quad 2g + h][pixel] of int4: a lane's four consecutive accumulator registers are four
+      // consecutive output channels of its pixel
+      i32x4 *P = reinterpret_cast<i32x4 *>(pwn_lds);
+#pragma unroll
+      for (int q = 0; q < TN; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          P[((w * TN + q) * 8 + 2 * g + h) * 32 + j] = (i32x4){acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+      __syncthreads();
+      const int px = tid & 31, qd = tid >> 5;
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        const i32x4 s = (P[((0 * TN + q) * 8 + qd) * 32 + px] + P[((1 * TN + q) * 8 + qd) * 32 + px]) +
+                        (P[((2 * TN + q) * 8 + qd) * 32 + px] + P[((3 * TN + q) * 8 + qd) * 32 + px]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = cb + 32 * q + 4 * qd + e;
+          if (co < Co) {
+            const float rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
+            finish(fmaf((float)(s[e] + 128 * wsum[co]), rinv, bias ? bias[co] : 0.0f), co, p0 + px);
+          }
+        }
+      }
+    }
+  } else {
+    // wide codes: f32 MFMA on the fake-quantised values (A[i = co][k = h], B[k = h][j = pixel] of 32x32x2)
+    const float qr = __fdiv_rn(1.0f, qs);
+    f32x16 accf[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) accf[t] = (f32x16){0};
+    for (int k = 0; k < 32 * nit; k += 2) {
+      const float bv = cdn::fake_quant_r(Dn[(long)(k + h) * HW], qs, qz, qr);
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        const int co = min(cb + 32 * q + j, Co - 1);
+        accf[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wq[(long)co * C + 32 * t0 + k + h], bv, accf[q], 0, 0, 0);
+      }
+    }
+    if (KS == 1) {
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < TN; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cb + 32 * q + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co < Co) finish(accf[q][r] + (bias ? bias[co] : 0.0f), co, p0 + j);
+          }
+      }
+    } else {
+      float4 *P = reinterpret_cast<float4 *>(pwn_lds);
+#pragma unroll
+      for (int q = 0; q < TN; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          P[((w * TN + q) * 8 + 2 * g + h) * 32 + j] = make_float4(accf[q][4 * g], accf[q][4 * g + 1], accf[q][4 * g + 2], accf[q][4 * g + 3]);
+      __syncthreads();
+      const int px = tid & 31, qd = tid >> 5;
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        const float4 s0 = P[((0 * TN + q) * 8 + qd) * 32 + px], s1 = P[((1 * TN + q) * 8 + qd) * 32 + px];
+        const float4 s2 = P[((2 * TN + q) * 8 + qd) * 32 + px], s3 = P[((3 * TN + q) * 8 + qd) * 32 + px];
+        const float sv[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                             (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = cb + 32 * q + 4 * qd + e;
+          if (co < Co) finish(sv[e] + (bias ? bias[co] : 0.0f), co, p0 + px);
+        }
+      }
+    }
+  }
+  if (mm) {
+    __syncthreads();
+    cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x],
+                            reinterpret_cast<float *>(pwn_lds));
+  }
+}
+
+struct PwnPlan {
+  int tn, ncg, ks, cot;
+  unsigned grid_x;
+  size_t lds, off_scale, off_sum, bytes;
+};
+static bool pwn_plan(int64_t N, int64_t C, int64_t Co, int64_t HW, PwnPlan *p) {
+  if (N <= 0 || N > 65535 || C < 32 || (C & 31) || HW < 32 || (HW & 31) || Co < 1 || Co > 512 || C * HW >= (1ll << 31) ||
+      Co * HW >= (1ll << 31))
+    return false;
+  p->tn = Co <= 64 ? 2 : 4;
+  p->ncg = (int)cdn::ceil_div(Co, 32 * p->tn);
+  p->cot = 32 * p->tn * p->ncg;
+  const long npb = HW >> 5;
+  // K split over the four waves of a workgroup while whole-K waves would leave the chip short of waves (stage 0:
+  // 256 pixel blocks x 2 column groups at batch 32)
+  p->ks = (N * npb * p->ncg < 4096 && (C >> 5) >= 8) ? 4 : 1;
+  p->grid_x = (unsigned)((p->ks == 4 ? npb : cdn::ceil_div(npb, 4)) * p->ncg);
+  p->lds = p->ks == 4 ? (size_t)4 * p->tn * 8 * 32 * 16 : 256;
+  const size_t codes = ((size_t)C * p->cot + 255) / 256 * 256;
+  p->off_scale = codes;
+  p->off_sum = codes + ((size_t)p->cot * 4 + 255) / 256 * 256;
+  p->bytes = p->off_sum + ((size_t)p->cot * 4 + 255) / 256 * 256;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int cdn_codenet_pointwise_i8_supported(int64_t N, int64_t C, int64_t Co, int64_t HW) {
+  PwnPlan p;
+  return pwn_plan(N, C, Co, HW, &p) ? 1 : 0;
+}
+extern "C" size_t cdn_codenet_pointwise_i8_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW) {
+  PwnPlan p;
+  return pwn_plan(N, C, Co, HW, &p) ? p.bytes : 0;
+}
+extern "C" int64_t cdn_codenet_pointwise_i8_range_partials(int64_t N, int64_t C, int64_t Co, int64_t HW) {
+  PwnPlan p;
+  return pwn_plan(N, C, Co, HW, &p) ? (int64_t)p.grid_x * N : 0;
+}
+
+extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void *d_state, const float *w_q,
+                                                      const float *bias, float *y, int64_t N, int64_t C, int64_t Co,
+                                                      int64_t HW, float *partials, void *workspace,
+                                                      size_t workspace_bytes, void *stream) {
+  CDN_REQUIRE(d && d_state && w_q && y && workspace, CDN_ERR_ARG, "null pointer");
+  PwnPlan p;
+  CDN_REQUIRE(pwn_plan(N, C, Co, HW, &p), CDN_ERR_UNSUPPORTED,
+              "int8 forward needs C %% 32 == 0, HW %% 32 == 0, Co <= 512 (cdn_codenet_pointwise_i8_supported)");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && workspace_bytes >= p.bytes, CDN_ERR_WORKSPACE,
+              "workspace missing, too small or not 256-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  signed char *kb = static_cast<signed char *>(workspace);
+  float *wscale = reinterpret_cast<float *>(kb + p.off_scale);
+  int *wsum = reinterpret_cast<int *>(kb + p.off_sum);
+  pwn_wcodes_kernel<<<(unsigned)cdn::ceil_div(p.cot, 4), 256, 0, st>>>(w_q, (int)Co, (int)C, p.cot, kb, wscale, wsum);
+  int rc = cdn::check_launch("codenet weight codes");
+  if (rc) return rc;
+  dim3 grid(p.grid_x, (unsigned)N);
+  float2 *mm = reinterpret_cast<float2 *>(partials);
+  const unsigned *dq = static_cast<const unsigned *>(d_state);
+#define CDN_PWN(TN_, KS_)                                                                                           \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void *)pwi8n_kernel<TN_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              (int)p.lds);                                                                          \
+    pwi8n_kernel<TN_, KS_><<<grid, 256, p.lds, st>>>(d, dq, kb, wscale, wsum, w_q, bias, y, mm, (int)C, (int)Co,    \
+                                                     (int)HW, p.ncg);                                               \
+  } while (0)
+  if (p.tn == 4 && p.ks == 4) CDN_PWN(4, 4);
+  else if (p.tn == 4) CDN_PWN(4, 1);
+  else if (p.ks == 4) CDN_PWN(2, 4);
+  else CDN_PWN(2, 1);
+#undef CDN_PWN
+  return cdn::check_launch("codenet int8 pointwise forward (NCHW)");
+}

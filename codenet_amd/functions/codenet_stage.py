@@ -74,7 +74,8 @@ class CodenetStageFunction(Function):
     203-219)."""
 
     @staticmethod
-    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range=False, x_up=False):
+    def forward(ctx, x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range=False, x_up=False,
+                pw_int8=False):
         """x_up (round 4): x is the STORED tensor [N,C,H/2,W/2] whose nearest x2 up-sampling is the stage's input (stages
         1-2: shufflenetv2_dcn.py:303-308).  The scale is predicted at stored resolution (a 1x1 conv of a replicated tensor
         is the replicated conv; min / max and hence the QuantAct range are those of the replicated plane), the gather reads
@@ -108,9 +109,9 @@ class CodenetStageFunction(Function):
                 d_q = _native_quantact(act_d, d) if act_d is not None else d
         yp = None
         if have_pw and want_range:
-            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap)
+            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap, int8_weights=pw_int8)
         else:
-            y = ops.codenet_pointwise(d_q, w_pw, b_pw, d_state=d_snap) if have_pw else d_q
+            y = ops.codenet_pointwise(d_q, w_pw, b_pw, d_state=d_snap, int8_weights=pw_int8) if have_pw else d_q
         ctx.lo, ctx.hi, ctx.have_pw = float(lo), float(hi), have_pw
         ctx.has_b_scale, ctx.has_b_pw = b_scale is not None, b_pw is not None
         ctx.save_for_backward(x, s_c, s, w_scale, w_dw, d_q if have_pw else None, w_pw, d_snap)
@@ -175,7 +176,7 @@ class CodenetStageFunction(Function):
                     g_wscale = tot[:C].view_as(w_scale)
                 if want_b:
                     g_bscale = tot[C:].reshape(1)
-        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None, None, None
+        return gx, g_wscale, g_bscale, g_wdw, g_wpw, g_bpw, None, None, None, None, None, None, None
 
 
 def _native_quantact(act, t):
@@ -185,10 +186,13 @@ def _native_quantact(act, t):
     return out
 
 
-def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None, want_range=False, x_up=False):
+def codenet_stage(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s=None, act_d=None, want_range=False, x_up=False,
+                  pw_int8=False):
     """want_range: returns (y, partials) -- the per-workgroup {min, max} pairs of y ([n, 2], empty without a pointwise
-    conv) for a QuantAct behind the stage (ReluQuantUpsample).  x_up: see CodenetStageFunction.forward."""
-    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range, x_up)
+    conv) for a QuantAct behind the stage (ReluQuantUpsample).  x_up: see CodenetStageFunction.forward.  pw_int8: w_pw is
+    a per-channel symmetric <= 4-bit fake-quantised weight (the forward conv_channel may sum integer codes)."""
+    return CodenetStageFunction.apply(x, w_scale, b_scale, w_dw, w_pw, b_pw, lo, hi, act_s, act_d, want_range, x_up,
+                                      pw_int8)
 
 
 class QuantActSTE(Function):

@@ -199,10 +199,17 @@ def _dw_backward_generic(x, s, w_dw, gd, needs):
 codenet_dw = _CodenetDW.apply
 
 
-def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False, d_state=None):
+# A/B switch (tools/train_step_bench.py --no-int8-forward): the QAT step's forward conv_channel on the int8 matrix cores
+# (cdn_codenet_pointwise_i8_forward_range) where the caller vouches for <= 4-bit per-channel symmetric weights.
+INT8_FORWARD = True
+
+
+def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False, d_state=None,
+                      int8_weights=False):
     """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA.  want_range: also the per-workgroup
     {min, max} pairs of y.  d_state (8-word QuantAct state tensor): d holds pre-quantisation values, fake-quantised
-    with that state while the kernel loads them."""
+    with that state while the kernel loads them.  int8_weights (with d_state): w_pw is a per-channel symmetric <= 4-bit
+    fake-quantised weight (q / ws) -- the exact integer form on int8 MFMA (cdn_codenet_pointwise_i8_forward_range)."""
     _gpu_f32(d, w_pw, bias, ep_scale, ep_shift)
     d = d.contiguous()
     Nb, C, H, W = d.shape
@@ -212,6 +219,19 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
     Co = w.size(0)
     y = d.new_empty(Nb, Co, H, W)
     rec = _tic("pointwise", (C, H, W))
+    lib = N_.lib()
+    if (int8_weights and INT8_FORWARD and d_state is not None and ep_scale is None and not relu
+            and lib.cdn_codenet_pointwise_i8_supported(Nb, C, Co, H * W)):
+        part = _partials(lib.cdn_codenet_pointwise_i8_range_partials(Nb, C, Co, H * W), d) if want_range else None
+        need = lib.cdn_codenet_pointwise_i8_workspace_bytes(Nb, C, Co, H * W)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=d.device)
+        wp = (ws.data_ptr() + 255) // 256 * 256
+        rc = lib.cdn_codenet_pointwise_i8_forward_range(_p(d), _p(d_state), _p(w), _p(bias.contiguous() if bias is not None
+                                                                                      else None), _p(y), Nb, C, Co, H * W,
+                                                        _p(part), wp, need, _stream(d))
+        _toc(rec)
+        N_.check(rc, "cdn_codenet_pointwise_i8_forward_range")
+        return (y, part) if want_range else y
     tail = (_p(w), _p(bias.contiguous() if bias is not None else None),
             _p(ep_scale.contiguous() if ep_scale is not None else None),
             _p(ep_shift.contiguous() if ep_shift is not None else None), _p(y), Nb, C, Co, H * W, int(bool(relu)))

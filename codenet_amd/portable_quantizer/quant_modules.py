@@ -486,10 +486,12 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
             # (fake-quantisation with straight-through gradients, BN fold) are tiny torch ops under autograd
             from ..functions.codenet_stage import codenet_stage
             bound = self.quant_act[0]
-            w, b = self.quant_conv_channel_bn.folded()
+            cb = self.quant_conv_channel_bn
+            w, b = cb.folded()
             return codenet_stage(x, self.quant_conv_scale.quantized_weight(), self.quant_conv_scale.bias,
                                  self.quant_deform_conv.quantized_weight(), w, b, bound.min_val, bound.max_val,
-                                 self.quant_act[1], self.quant_identity_deform, want_range, x_up)
+                                 self.quant_act[1], self.quant_identity_deform, want_range, x_up,
+                                 cb._int8_ok(cb.conv.kernel_size, cb.conv.groups))
         s = self.quant_act(self.quant_conv_scale(x))
         dc = self.quant_deform_conv
         if (x.is_cuda and x.dtype == torch.float32 and s.shape[1] == 1

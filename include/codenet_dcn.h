@@ -195,6 +195,23 @@ int cdn_codenet_pointwise_forward_range(const float *d, const void *d_state, con
 int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, float *x_min, float *x_max, void *state,
                                   const float *partials, int64_t n_partials, int bits, double momentum, int running,
                                   void *state_copy, void *stream);
+/* The forward conv_channel of the QAT step on the int8 matrix cores (round 5; pwi8n_kernel, codenet_train.hip): same
+ * arguments as cdn_codenet_pointwise_forward_range with d_state != NULL, for weights that are per-channel symmetric
+ * <= 4-bit fake-quantised (w_q [Co][C] = q / ws, |q| <= 8: what cdn_codenet_weight_prep produces at bits <= 4) -- the
+ * integer codes of both operands are summed exactly, y = (sum_c (L_c + zp) q_c) / (scale ws) + bias, as the inference
+ * schedule does, instead of multiplying their fp32 forms on f32 MFMA (one rounding instead of C; agrees with
+ * cdn_codenet_pointwise_forward_range to fp32 summation noise, equal on exact-arithmetic inputs).  A batch whose codes are
+ * too wide for the kernel's nibble split (state word 6) runs on f32 MFMA inside the same launch.
+ *   ..._supported: C % 32 == 0, HW % 32 == 0, Co <= 512;  workspace: ..._workspace_bytes, 256-byte aligned, contents
+ *   irrelevant (the k-blocked weight codes are rebuilt by every call: the weights change every step);
+ *   partials: ..._range_partials pairs, or NULL.
+ * Reference: conv_channel under autograd, quant_modules.py:412-419 (F.conv2d on the fake-quantised operands). */
+int cdn_codenet_pointwise_i8_supported(int64_t N, int64_t C, int64_t Co, int64_t HW);
+size_t cdn_codenet_pointwise_i8_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW);
+int64_t cdn_codenet_pointwise_i8_range_partials(int64_t N, int64_t C, int64_t Co, int64_t HW);
+int cdn_codenet_pointwise_i8_forward_range(const float *d, const void *d_state, const float *w_q, const float *bias,
+                                           float *y, int64_t N, int64_t C, int64_t Co, int64_t HW, float *partials,
+                                           void *workspace, size_t workspace_bytes, void *stream);
 /* cdn_codenet_pointwise_wgrad with d given as pre-quantisation values + the state that quantised them in the forward */
 int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
                                   int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,

@@ -35,7 +35,12 @@ def main():
                     "quantising it in the consumers' loads")
     ap.add_argument("--no-stored-res", action="store_true", help="A/B: stages 1-2 on the materialised up-sampled tensors "
                     "(round 3's path) instead of on the stored ones (dw4_kernel<UP>, dw_bwd2u_kernel)")
+    ap.add_argument("--no-int8-forward", action="store_true", help="A/B: the forward conv_channel on f32 MFMA "
+                    "(pointwise_kernel) instead of the exact integer form on int8 MFMA (pwi8n_kernel)")
     a = ap.parse_args()
+    if a.no_int8_forward:
+        from codenet_amd import ops as _ops
+        _ops.INT8_FORWARD = False
     if a.no_stored_res:
         from codenet_amd.functions import codenet_stage as _cs1
         _cs1.STORED_RES_STAGES = False
