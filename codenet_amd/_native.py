@@ -50,6 +50,8 @@ _SIGNATURES = {
     "cdn_codenet_stage_fused_intermediates": (_i, [_i64] * 4 + [_i, _i, _i, _vp, _vp]),
     "cdn_codenet_wcodes_kb_columns": (_i64, [_i64, _i64]),
     "cdn_codenet_pointwise_i8_supported": (_i, [_i64] * 4),
+    "cdn_codenet_pointwise_dgrad_q4_supported": (_i, [_i64] * 4),
+    "cdn_codenet_pointwise_dgrad_q4": (_i, [_vp] * 3 + [_i64] * 4 + [_vp]),
     "cdn_codenet_pointwise_i8_workspace_bytes": (ctypes.c_size_t, [_i64] * 4),
     "cdn_codenet_pointwise_i8_range_partials": (_i64, [_i64] * 4),
     "cdn_codenet_pointwise_i8_forward_range": (_i, [_vp] * 5 + [_i64] * 4 + [_vp, _vp, ctypes.c_size_t, _vp]),

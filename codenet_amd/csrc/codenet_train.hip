@@ -556,15 +556,18 @@ namespace {
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 
-__global__ void __launch_bounds__(256)
-pwn_wcodes_kernel(const float *__restrict__ wq, int Co, int C, int Cot, signed char *__restrict__ kb,
-                  float *__restrict__ wscale, int *__restrict__ wsum) {
-  // one wave per output column (Cot >= Co of them: the columns behind Co are zero).  The row holds q / ws with
-  // |q| <= 8 and its largest magnitude is 7 / ws (the channel's own extreme maps to +-7) or 8 / ws (--wt-percentile
-  // clamps): ws is recovered as 7 / max or 8 / max, whichever makes every w ws an integer.
-  const int lane = threadIdx.x & 63;
-  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (co >= Cot) return;
+__global__ void __launch_bounds__(1024)
+pwn_prep_kernel(const float *__restrict__ wq, int Co, int C, int Cot, int Ct, signed char *__restrict__ kb,
+                float *__restrict__ wscale, int *__restrict__ wsum, unsigned short *__restrict__ wt,
+                float *__restrict__ rws) {
+  // Both integer forms of the weights in one launch: workgroup = sixteen output channels (one wave each).
+  //   kb [window][column][32]  int8, k-blocked: the A operand of pwi8n_kernel (forward); zero columns behind Co;
+  //   wt [co / 16][c][16]      bf16, transposed: the A operand of pwb3n_kernel (data gradient); zero rows behind C.
+  // A row holds q / ws with |q| <= 8 and its largest magnitude is 7 / ws (the channel's own extreme maps to +-7) or
+  // 8 / ws (--wt-percentile clamps): ws is recovered as 7 / max or 8 / max, whichever makes every w ws an integer.
+  extern __shared__ signed char prep_codes[];      // [16][C]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int co = blockIdx.x * 16 + w;
   const float *row = wq + (long)co * C;
   float mag = 0.0f;
   if (co < Co)
@@ -584,14 +587,32 @@ pwn_wcodes_kernel(const float *__restrict__ wq, int Co, int C, int Cot, signed c
   for (int k = lane; k < C; k += 64) {
     int q = 0;
     if (co < Co) q = min(max((int)rintf(row[k] * ws), -8), 7);
-    kb[((long)(k >> 5) * Cot + co) * 32 + (k & 31)] = (signed char)q;
+    if (co < Cot) kb[((long)(k >> 5) * Cot + co) * 32 + (k & 31)] = (signed char)q;
+    prep_codes[w * C + k] = (signed char)q;
     sum += q;
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, 64);
   if (lane == 0) {
-    wscale[co] = ws;
-    wsum[co] = sum;
+    if (co < Cot) {
+      wscale[co] = ws;
+      wsum[co] = sum;
+    }
+    rws[co] = co < Co ? __fdiv_rn(1.0f, ws) : 0.0f;
+  }
+  __syncthreads();
+  if (blockIdx.x * 16 < ((Co + 15) & ~15)) {
+    for (int c = threadIdx.x; c < Ct; c += 1024) {
+      unsigned wpk[8];
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float f0 = c < C ? (float)prep_codes[e * C + c] : 0.0f, f1 = c < C ? (float)prep_codes[(e + 1) * C + c] : 0.0f;
+        wpk[e >> 1] = (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xFFFF0000u);      // small integers: exact in bf16
+      }
+      uint4 *dst = reinterpret_cast<uint4 *>(wt + ((long)blockIdx.x * Ct + c) * 16);
+      dst[0] = make_uint4(wpk[0], wpk[1], wpk[2], wpk[3]);
+      dst[1] = make_uint4(wpk[4], wpk[5], wpk[6], wpk[7]);
+    }
   }
 }
 
@@ -769,10 +790,104 @@ pwi8n_kernel(const float *__restrict__ D, const unsigned *__restrict__ dq, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// pwb3n_kernel (round 5): the DATA GRADIENT of conv_channel in the QAT step,
+//   grad_d[n][c][p] = sum_co w_q[co][c] grad_y[n][co][p],   w_q = q / ws (4-bit codes),
+// on the bf16 matrix cores with EXACT products (pwb3_kernel's split, codenet_fused.hip): g' = grad_y / ws[co] is cut
+// into three bf16 terms by truncation (8 + 8 + 8 significant bits: hi + mid + lo == g' exactly), the codes are exact in
+// bf16, every product is exact in fp32 and the accumulation is fp32 -- 3 v_mfma_f32_32x32x16_bf16 per 16 k where
+// pointwise_kernel issues 8 v_mfma_f32_32x32x2_f32 (39 / 33 / 57 us at the step's three stages, matrix-core bound).
+// NCHW needs no staging: A (rows = input channels c) from a transposed bf16 copy of the codes [co / 16][c][16]
+// (pwn_prep_kernel, made with the forward's codes), B (columns = 32 pixels) as eight dword loads of grad_y per lane and 16-k step, split in registers;
+// a wave owns 32 pixels x 32 TN channels over the whole K = Co; lanes run along pixels in loads and stores.
+// Differs from the f32 kernel by rounding noise only (g' is rounded once, the f32 kernel rounds q / ws and the product).
+// ------------------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+template <int TN>
+__global__ void __launch_bounds__(256)
+pwb3n_kernel(const float *__restrict__ GY, const unsigned short *__restrict__ WT, const float *__restrict__ rws,
+             float *__restrict__ GD, int C, int Co, int HW, int Ct, int ncg) {
+  __shared__ float rw[512];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n = blockIdx.y;
+  const int S = (Co + 15) >> 4;
+  for (int q = tid; q < 16 * S; q += 256) rw[q] = rws[q];
+  __syncthreads();
+  // workgroup = 4 waves: consecutive (pixel block, channel group) pairs, channel group fastest (they share grad_y lines)
+  const int item = blockIdx.x * 4 + w;
+  const int cg = item % ncg, pb = item / ncg;
+  if (pb >= (HW >> 5)) return;
+  const int p0 = 32 * pb, cb = cg * 32 * TN;
+  const float *gyp = GY + (long)n * Co * HW + p0 + j;
+  const unsigned short *wtp = WT + ((long)cb + j) * 16 + 8 * h;
+  auto pack_hi = [](unsigned a_, unsigned b_) -> unsigned { return __builtin_amdgcn_perm(a_, b_, 0x07060302u); };
+  f32x16 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) acc[t] = (f32x16){0};
+  float g[8], gn[8];
+  i32x4 a[TN], an[TN];
+  auto load = [&](float (&x)[8], i32x4 (&aw)[TN], int s16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int co = 16 * s16 + 8 * h + e;
+      x[e] = gyp[(long)min(co, Co - 1) * HW];            // (co >= Co: multiplied by rw = 0 below)
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+      aw[t] = *reinterpret_cast<const i32x4 *>(wtp + ((long)s16 * Ct + 32 * t) * 16);
+  };
+  load(g, a, 0);
+  for (int s16 = 0; s16 < S; ++s16) {
+    if (s16 + 1 < S) load(gn, an, s16 + 1);
+    unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = __fmul_rn(g[e], rw[16 * s16 + 8 * h + e]);
+      hb[e] = __float_as_uint(x);
+      const float r1 = __fsub_rn(x, __uint_as_float(hb[e] & 0xFFFF0000u));
+      mb[e] = __float_as_uint(r1);
+      lb[e] = __float_as_uint(__fsub_rn(r1, __uint_as_float(mb[e] & 0xFFFF0000u)));
+    }
+    i32x4 ph, pm, pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ph[e] = (int)pack_hi(hb[2 * e + 1], hb[2 * e]);
+      pm[e] = (int)pack_hi(mb[2 * e + 1], mb[2 * e]);
+      pl[e] = (int)pack_hi(lb[2 * e + 1], lb[2 * e]);
+    }
+    const bf16x8 fh = __builtin_bit_cast(bf16x8, ph), fm = __builtin_bit_cast(bf16x8, pm), fl = __builtin_bit_cast(bf16x8, pl);
+    // lo, mid, hi into every accumulator, interleaved over the tiles (three MFMAs into one accumulator back to back stall)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), fl, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), fm, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), fh, acc[t], 0, 0, 0);
+    if (s16 + 1 < S) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = gn[e];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) a[t] = an[t];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = cb + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (c < C) GD[((long)n * C + c) * HW + p0 + j] = acc[t][r];
+    }
+}
+
 struct PwnPlan {
   int tn, ncg, ks, cot;
   unsigned grid_x;
   size_t lds, off_scale, off_sum, bytes;
+  int dtn, dncg, ct;               // data gradient (pwb3n_kernel): channel tiles per wave, channel groups, padded C
+  size_t off_wt, off_rws;
 };
 static bool pwn_plan(int64_t N, int64_t C, int64_t Co, int64_t HW, PwnPlan *p) {
   if (N <= 0 || N > 65535 || C < 32 || (C & 31) || HW < 32 || (HW & 31) || Co < 1 || Co > 512 || C * HW >= (1ll << 31) ||
@@ -790,7 +905,13 @@ static bool pwn_plan(int64_t N, int64_t C, int64_t Co, int64_t HW, PwnPlan *p) {
   const size_t codes = ((size_t)C * p->cot + 255) / 256 * 256;
   p->off_scale = codes;
   p->off_sum = codes + ((size_t)p->cot * 4 + 255) / 256 * 256;
-  p->bytes = p->off_sum + ((size_t)p->cot * 4 + 255) / 256 * 256;
+  p->dtn = C <= 128 ? 4 : 8;
+  p->dncg = (int)cdn::ceil_div(C, 32 * p->dtn);
+  p->ct = 32 * p->dtn * p->dncg;
+  const size_t S = (size_t)(std::max<int64_t>(Co, p->cot) + 15) / 16;      // (the prep kernel's workgroups: 16 columns each)
+  p->off_wt = p->off_sum + ((size_t)p->cot * 4 + 255) / 256 * 256;
+  p->off_rws = p->off_wt + (S * p->ct * 32 + 255) / 256 * 256;
+  p->bytes = p->off_rws + (S * 16 * 4 + 255) / 256 * 256;
   return true;
 }
 
@@ -823,7 +944,13 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
   signed char *kb = static_cast<signed char *>(workspace);
   float *wscale = reinterpret_cast<float *>(kb + p.off_scale);
   int *wsum = reinterpret_cast<int *>(kb + p.off_sum);
-  pwn_wcodes_kernel<<<(unsigned)cdn::ceil_div(p.cot, 4), 256, 0, st>>>(w_q, (int)Co, (int)C, p.cot, kb, wscale, wsum);
+  unsigned short *wt = reinterpret_cast<unsigned short *>(kb + p.off_wt);
+  float *rws = reinterpret_cast<float *>(kb + p.off_rws);
+  CDN_REQUIRE(C <= 4096, CDN_ERR_UNSUPPORTED, "C <= 4096 (sixteen code rows in LDS)");
+  if (16 * C > 48 * 1024)
+    (void)hipFuncSetAttribute((const void *)pwn_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * C));
+  pwn_prep_kernel<<<(unsigned)(p.cot / 16), 1024, (size_t)16 * C, st>>>(w_q, (int)Co, (int)C, p.cot, p.ct, kb, wscale, wsum,
+                                                                        wt, rws);
   int rc = cdn::check_launch("codenet weight codes");
   if (rc) return rc;
   dim3 grid(p.grid_x, (unsigned)N);
@@ -842,4 +969,26 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
   else CDN_PWN(2, 1);
 #undef CDN_PWN
   return cdn::check_launch("codenet int8 pointwise forward (NCHW)");
+}
+
+// ---- data gradient of conv_channel on bf16 MFMA (pwb3n_kernel) ----------------------------------------------------------
+extern "C" int cdn_codenet_pointwise_dgrad_q4_supported(int64_t N, int64_t C, int64_t Co, int64_t HW) {
+  PwnPlan p;
+  return pwn_plan(N, C, Co, HW, &p) && C <= 4096 ? 1 : 0;
+}
+extern "C" int cdn_codenet_pointwise_dgrad_q4(const float *grad_y, const void *fwd_workspace, float *grad_d, int64_t N,
+                                              int64_t C, int64_t Co, int64_t HW, void *stream) {
+  CDN_REQUIRE(grad_y && fwd_workspace && grad_d, CDN_ERR_ARG, "null pointer");
+  PwnPlan p;
+  CDN_REQUIRE(pwn_plan(N, C, Co, HW, &p) && C <= 4096, CDN_ERR_UNSUPPORTED,
+              "fwd_workspace is that of cdn_codenet_pointwise_i8_forward_range: the shape must be supported there");
+  hipStream_t st = cdn::as_stream(stream);
+  const char *base = static_cast<const char *>(fwd_workspace);
+  const unsigned short *wt = reinterpret_cast<const unsigned short *>(base + p.off_wt);
+  const float *rws = reinterpret_cast<const float *>(base + p.off_rws);
+  const long items = (HW >> 5) * p.dncg;
+  dim3 grid((unsigned)cdn::ceil_div(items, 4), (unsigned)N);
+  if (p.dtn == 8) pwb3n_kernel<8><<<grid, 256, 0, st>>>(grad_y, wt, rws, grad_d, (int)C, (int)Co, (int)HW, p.ct, p.dncg);
+  else pwb3n_kernel<4><<<grid, 256, 0, st>>>(grad_y, wt, rws, grad_d, (int)C, (int)Co, (int)HW, p.ct, p.dncg);
+  return cdn::check_launch("codenet pointwise data gradient (bf16 x 3)");
 }

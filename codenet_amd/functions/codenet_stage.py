@@ -108,10 +108,12 @@ class CodenetStageFunction(Function):
                 d = ops.codenet_dw_up2(x, s, w_dw, want_range=False) if x_up else ops.codenet_dw(x, s, w_dw.contiguous())
                 d_q = _native_quantact(act_d, d) if act_d is not None else d
         yp = None
+        keep = {}
         if have_pw and want_range:
-            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap, int8_weights=pw_int8)
+            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap, int8_weights=pw_int8, keep=keep)
         else:
-            y = ops.codenet_pointwise(d_q, w_pw, b_pw, d_state=d_snap, int8_weights=pw_int8) if have_pw else d_q
+            y = ops.codenet_pointwise(d_q, w_pw, b_pw, d_state=d_snap, int8_weights=pw_int8, keep=keep) if have_pw else d_q
+        ctx.pw_fwd_ws = keep.get("fwd_ws")      # (the int8 forward's weight scales: the data gradient reads them)
         ctx.lo, ctx.hi, ctx.have_pw = float(lo), float(hi), have_pw
         ctx.has_b_scale, ctx.has_b_pw = b_scale is not None, b_pw is not None
         ctx.save_for_backward(x, s_c, s, w_scale, w_dw, d_q if have_pw else None, w_pw, d_snap)
@@ -136,8 +138,11 @@ class CodenetStageFunction(Function):
             if need[4] or (need[5] and ctx.has_b_pw):
                 gw2, g_bpw = pointwise_wgrad(gy, d_q, need[5] and ctx.has_b_pw, d_state=d_snap)
                 g_wpw = gw2.view_as(w_pw) if need[4] else None
-            # data gradient: the same contraction with the transposed weights
-            gd = ops.codenet_pointwise(gy, w_pw.reshape(Co, C).t().contiguous().view(C, Co, 1, 1))
+            # data gradient: exact products on bf16 MFMA where the forward ran on the weight codes, else the same
+            # contraction as the forward with the transposed weights on f32 MFMA
+            gd = ops.codenet_pointwise_dgrad_q4(gy, w_pw, ctx.pw_fwd_ws) if ctx.pw_fwd_ws is not None else None
+            if gd is None:
+                gd = ops.codenet_pointwise(gy, w_pw.reshape(Co, C).t().contiguous().view(C, Co, 1, 1))
         else:
             gd = gy
         # gather backward (QuantAct on d: straight-through)

@@ -205,11 +205,13 @@ INT8_FORWARD = True
 
 
 def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False, d_state=None,
-                      int8_weights=False):
+                      int8_weights=False, keep=None):
     """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA.  want_range: also the per-workgroup
     {min, max} pairs of y.  d_state (8-word QuantAct state tensor): d holds pre-quantisation values, fake-quantised
     with that state while the kernel loads them.  int8_weights (with d_state): w_pw is a per-channel symmetric <= 4-bit
-    fake-quantised weight (q / ws) -- the exact integer form on int8 MFMA (cdn_codenet_pointwise_i8_forward_range)."""
+    fake-quantised weight (q / ws) -- the exact integer form on int8 MFMA (cdn_codenet_pointwise_i8_forward_range);
+    keep (a dict): receives "fwd_ws" = (tensor, aligned pointer) of that call's workspace -- the per-channel weight
+    scales codenet_pointwise_dgrad_q4 reads in the backward pass."""
     _gpu_f32(d, w_pw, bias, ep_scale, ep_shift)
     d = d.contiguous()
     Nb, C, H, W = d.shape
@@ -231,6 +233,8 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
                                                         _p(part), wp, need, _stream(d))
         _toc(rec)
         N_.check(rc, "cdn_codenet_pointwise_i8_forward_range")
+        if keep is not None:
+            keep["fwd_ws"] = (ws, wp)
         return (y, part) if want_range else y
     tail = (_p(w), _p(bias.contiguous() if bias is not None else None),
             _p(ep_scale.contiguous() if ep_scale is not None else None),
@@ -246,6 +250,29 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
     _toc(rec)
     N_.check(rc, "cdn_codenet_pointwise_forward")
     return y
+
+
+def codenet_pointwise_dgrad_q4(gy, w_pw, fwd_ws):
+    """grad_d = conv1x1(grad_y, w_pw^T) for a 4-bit fake-quantised w_pw [Co,C,1,1] with exact products on bf16 MFMA
+    (cdn_codenet_pointwise_dgrad_q4); fwd_ws: what codenet_pointwise(..., int8_weights=True, keep=...) kept.  None when the
+    shape is not supported (the caller takes the f32 path)."""
+    lib = N_.lib()
+    gy = gy.contiguous()
+    Nb, Co, H, W = gy.shape
+    w = w_pw.contiguous().view(Co, -1)
+    C = w.size(1)
+    if not (DGRAD_BF16X3 and lib.cdn_codenet_pointwise_dgrad_q4_supported(Nb, C, Co, H * W)):
+        return None
+    gd = gy.new_empty(Nb, C, H, W)
+    rec = _tic("pointwise", (Co, H, W))
+    rc = lib.cdn_codenet_pointwise_dgrad_q4(_p(gy), fwd_ws[1], _p(gd), Nb, C, Co, H * W, _stream(gy))
+    _toc(rec)
+    N_.check(rc, "cdn_codenet_pointwise_dgrad_q4")
+    return gd
+
+
+# A/B switch (tools/train_step_bench.py --no-bf16-dgrad)
+DGRAD_BF16X3 = True
 
 
 def quantact_state(device):

@@ -212,6 +212,15 @@ int64_t cdn_codenet_pointwise_i8_range_partials(int64_t N, int64_t C, int64_t Co
 int cdn_codenet_pointwise_i8_forward_range(const float *d, const void *d_state, const float *w_q, const float *bias,
                                            float *y, int64_t N, int64_t C, int64_t Co, int64_t HW, float *partials,
                                            void *workspace, size_t workspace_bytes, void *stream);
+/* The data gradient of the same conv, grad_d[n][c][p] = sum_co w_q[co][c] grad_y[n][co][p], with exact products on the bf16
+ * matrix cores (round 5; pwb3n_kernel): grad_y / ws[co] split into three bf16 terms (exact), the 4-bit codes exact in
+ * bf16, fp32 accumulation -- 3 bf16 MFMAs per 16 k instead of 8 f32 MFMAs.  fwd_workspace: the workspace the forward
+ * call (cdn_codenet_pointwise_i8_forward_range, same N, C, Co, HW and weights) left behind: it holds the transposed bf16
+ * codes and the reciprocal weight scales.  Agrees with cdn_codenet_pointwise_forward on the transposed weights to fp32
+ * rounding noise.  Reference: autograd of conv_channel, quant_modules.py:412-419. */
+int cdn_codenet_pointwise_dgrad_q4_supported(int64_t N, int64_t C, int64_t Co, int64_t HW);
+int cdn_codenet_pointwise_dgrad_q4(const float *grad_y, const void *fwd_workspace, float *grad_d, int64_t N, int64_t C,
+                                   int64_t Co, int64_t HW, void *stream);
 /* cdn_codenet_pointwise_wgrad with d given as pre-quantisation values + the state that quantised them in the forward */
 int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
                                   int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,

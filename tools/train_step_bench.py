@@ -37,7 +37,12 @@ def main():
                     "(round 3's path) instead of on the stored ones (dw4_kernel<UP>, dw_bwd2u_kernel)")
     ap.add_argument("--no-int8-forward", action="store_true", help="A/B: the forward conv_channel on f32 MFMA "
                     "(pointwise_kernel) instead of the exact integer form on int8 MFMA (pwi8n_kernel)")
+    ap.add_argument("--no-bf16-dgrad", action="store_true", help="A/B: the data gradient of conv_channel on f32 MFMA "
+                    "instead of the exact bf16 x 3 split (pwb3n_kernel)")
     a = ap.parse_args()
+    if a.no_bf16_dgrad:
+        from codenet_amd import ops as _ops2
+        _ops2.DGRAD_BF16X3 = False
     if a.no_int8_forward:
         from codenet_amd import ops as _ops
         _ops.INT8_FORWARD = False
