@@ -569,27 +569,53 @@ pwn_prep_kernel(const float *__restrict__ wq, int Co, int C, int Cot, int Ct, si
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int co = blockIdx.x * 16 + w;
   const float *row = wq + (long)co * C;
+  // the row in registers when it fits (C <= 1024: sixteen values per lane): one pass over memory instead of three
+  const bool cached = C <= 1024;
+  float rv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) rv[u] = (cached && co < Co && lane + 64 * u < C) ? row[lane + 64 * u] : 0.0f;
   float mag = 0.0f;
-  if (co < Co)
-    for (int k = lane; k < C; k += 64) mag = fmaxf(mag, fabsf(row[k]));
+  if (co < Co) {
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) mag = fmaxf(mag, fabsf(rv[u]));
+    } else {
+      for (int k = lane; k < C; k += 64) mag = fmaxf(mag, fabsf(row[k]));
+    }
+  }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) mag = fmaxf(mag, __shfl_xor(mag, m, 64));
   float ws = mag > 0.0f ? __fdiv_rn(7.0f, mag) : 1.0f;
   if (co < Co) {
     bool ok = true;
-    for (int k = lane; k < C; k += 64) {
-      const float t = row[k] * ws;
-      ok &= fabsf(t - rintf(t)) < 0.02f;
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float t = rv[u] * ws;
+        ok &= fabsf(t - rintf(t)) < 0.02f;
+      }
+    } else {
+      for (int k = lane; k < C; k += 64) {
+        const float t = row[k] * ws;
+        ok &= fabsf(t - rintf(t)) < 0.02f;
+      }
     }
     if (!__all(ok)) ws = __fdiv_rn(8.0f, mag);
   }
   int sum = 0;
-  for (int k = lane; k < C; k += 64) {
+  auto emit = [&](int k, float v) {
     int q = 0;
-    if (co < Co) q = min(max((int)rintf(row[k] * ws), -8), 7);
+    if (co < Co) q = min(max((int)rintf(v * ws), -8), 7);
     if (co < Cot) kb[((long)(k >> 5) * Cot + co) * 32 + (k & 31)] = (signed char)q;
     prep_codes[w * C + k] = (signed char)q;
     sum += q;
+  };
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (lane + 64 * u < C) emit(lane + 64 * u, rv[u]);
+  } else {
+    for (int k = lane; k < C; k += 64) emit(k, co < Co ? row[k] : 0.0f);
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, 64);
