@@ -724,7 +724,10 @@ class FrozenHotPath:
         Nb, C, H, W = input_shape
         for i in range(0, len(mods), 3):
             up = 0 if i == 0 else 1
-            if not N_.lib().cdn_codenet_stage_supported(Nb, C, H, W, 1, up):
+            if C % 4:      # no byte-code form (CoDeNet2x stage 0): that stage runs on the fp32 frozen schedule, NCHW input
+                if up or not N_.lib().cdn_codenet_stage_fused_supported(Nb, C, H, W, 0, 0):
+                    return False
+            elif not N_.lib().cdn_codenet_stage_supported(Nb, C, H, W, 1, up):
                 return False
             C, H, W = mods[i].quant_conv_channel_bn.conv.out_channels, 2 * H, 2 * W
         return True
@@ -796,6 +799,20 @@ class FrozenHotPath:
             raise NotImplementedError("FrozenHotPath needs a GPU tensor: float32 NCHW, float32 [N, H*W, C] with hw "
                                       "and its QuantAct state, or int8 codes [N, H*W, C] with hw and the state")
         x = x.contiguous()
+        c0 = self.stages[0][0].quant_deform_conv.in_channels
+        if codes_in and (c0 % 4 or x.shape[2] != c0):
+            # CoDeNet2x (C = 2153, round 5): stage 0 runs on the fp32 frozen schedule (no byte-code form for C % 4 != 0), so
+            # the backbone's codes -- rows padded to a multiple of 16 bytes -- are expanded to the values level / scale
+            # first (re-quantising them with the same state returns the same codes)
+            xf = self.__dict__.get("_xin")
+            if xf is None or xf.shape != x.shape or xf.device != x.device:
+                xf = self._xin = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            N_.check(N_.lib().cdn_codenet_expand_codes(x.data_ptr(), x_qstate, xf.data_ptr(), x.numel(),
+                                                        torch.cuda.current_stream(x.device).cuda_stream),
+                     "cdn_codenet_expand_codes")
+            # (an odd channel count has no channels-last form in the fused schedule either: NCHW, final values)
+            x = xf.view(x.shape[0], hw[0], hw[1], x.shape[2])[..., :c0].permute(0, 3, 1, 2).contiguous()
+            codes_in, nhwc_in, x_qstate, hw = False, False, None, None
         shape = (x.shape[0], x.shape[2], hw[0], hw[1]) if nhwc_in else tuple(x.shape)
         dev = x.device
         # the cached pointer arrays name the QuantActs' range buffers: a re-assigned buffer (load_state_dict(assign=
@@ -1496,14 +1513,18 @@ class FusedBackbone:
     # materialised at that call.  No interleave kernel, no copy of the pass-through half.
     _MIXED_MAX_C = 512
 
-    def mixed_supported(self, nodes):
+    def mixed_supported(self, nodes, max_c=None):
+        """max_c: the widest layer (2h, cin) the caller's kernels take -- the running-range schedule's per-channel state
+        table in LDS (kMixedMaxC = 512) by default; the byte-code schedule (FrozenBackbone: one frozen grid per layer, no
+        table) passes its own."""
+        max_c = self._MIXED_MAX_C if max_c is None else max_c
         if not self.int8 or not all(hasattr(n, "quant_convbn1") for n in nodes) or nodes[0].stride != 2:
             return False
         if any(n.stride != 1 for n in nodes[1:]):
             return False
         h = nodes[0].quant_convbn3.conv.out_channels
         cin = nodes[0].quant_convbn1.conv.in_channels
-        if (2 * h) % 4 or 2 * h > self._MIXED_MAX_C or cin > self._MIXED_MAX_C or len(nodes) + 1 > 250:
+        if (2 * h) % 4 or 2 * h > max_c or cin > max_c or len(nodes) + 1 > 250:
             return False
         convs = [n.quant_convbn1 for n in nodes] + [n.quant_convbn3 for n in nodes] + [nodes[0].quant_convbn5]
         return all(c.folded_int8() is not None for c in convs)
@@ -1854,6 +1875,8 @@ class FrozenBackbone:
     accumulates exact products in fp32 (pwd3_kernel), so results agree with FusedBackbone at running_stat False up
     to single code flips (tests/test_gpu_backbone.py).  A saturated code sets the overflow flag (``overflowed()``)."""
 
+    _MAX_C = 1024      # widest layer of the byte-code schedule (no per-channel table: int8 rows of up to 1024 codes)
+
     def __init__(self, model, fuse_dwpw=True, two_streams=True):
         self.model = model
         self._fb = FusedBackbone(model)
@@ -1869,11 +1892,11 @@ class FrozenBackbone:
         fb = FusedBackbone(model)
         if not (len(model.layer0[1]) == 2 or (len(model.layer0[1]) == 3 and FusedBackbone._is_pool(model.layer0[1][2]))):
             return False                                     # (stem = conv, [ReLU, QuantAct] or [ReLU, QuantAct, MaxPool])
-        for name in ("layer1", "layer2", "layer3"):
-            if not fb.mixed_supported(list(getattr(model, name))):
+        for name in ("layer1", "layer2", "layer3"):      # (CoDeNet2x: layer3 is 976 channels wide; round 5)
+            if not fb.mixed_supported(list(getattr(model, name)), max_c=FrozenBackbone._MAX_C):
                 return False
         q4 = model.layer4[0]
-        if q4.folded_int8() is None or q4.conv.out_channels % 4:
+        if q4.folded_int8() is None:
             return False
         acts = [a for n in ("layer0", "layer1", "layer2", "layer3", "layer4") for a in getattr(model, n).modules()
                 if isinstance(a, QuantAct)]
@@ -2040,11 +2063,12 @@ class FrozenBackbone:
                 x8, x_ld, x_state, logical, H, W = self._layer(name, list(getattr(m, name)), x8, x_ld, x_state, logical,
                                                                Nb, H, W)
             c4 = q4.conv.out_channels
+            ld4 = c4 if c4 % 4 == 0 else self._ld(c4)      # (CoDeNet2x: 2153 codes in rows of 2160 bytes, the pad stays 0)
             if B.get("out") is None:
-                B["out"] = torch.empty(Nb, H * W, c4, dtype=torch.int8, device=dev)
+                B["out"] = torch.zeros(Nb, H * W, ld4, dtype=torch.int8, device=dev)
             W4 = self._fb._l4_weights(q4, logical, dev, None)
             rc = lib.cdn_codenet_pointwise_q8_strided_forward(
-                x8.data_ptr(), x_state, Nb * H * W, W4["K"], c4, x_ld, c4, W4["codes"].data_ptr(),
+                x8.data_ptr(), x_state, Nb * H * W, W4["K"], c4, x_ld, ld4, W4["codes"].data_ptr(),
                 W4["scale"].data_ptr(), W4["colsum"].data_ptr(), W4["bias"].data_ptr(), 1, None,
                 act4._device_state(dev).data_ptr(), B["out"].data_ptr(), None, self._of(act4), st)
             N_.check(rc, "cdn_codenet_pointwise_q8_strided_forward (layer4)")

@@ -19,9 +19,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--stages-only", action="store_true", help="backbone on the fp32 kernels, stages on byte codes")
+    ap.add_argument("--w2", action="store_true", help="CoDeNet2x (BASELINE cfg4's model; batch 32 per GPU there): stage 0 on "
+                    "the fp32 frozen schedule, everything else on byte codes")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    model = harness.create_model(quantize=True).to(dev)
+    model = harness.create_model(quantize=True, w2=a.w2).to(dev)
     model.enable_fused()
     images = torch.randn(a.batch, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(dev)
     report = pipeline.prepare_serving(model, images, settle=30, margin=0.02)
@@ -40,7 +42,8 @@ def main():
             torch.cuda.synchronize()
             res.append((time.perf_counter() - t0) / a.steps * 1e3)
     print(json.dumps({"ms_per_batch": [round(r, 4) for r in res], "overflow": bool(model.frozen_overflowed()),
-                      "byte_backbone": model._fzbackbone is not None, "calibration_clean": report.get("clean")}))
+                      "byte_backbone": model._fzbackbone is not None, "calibration_clean": report.get("clean"),
+                      "model": "CoDeNet2x" if a.w2 else "CoDeNet1x", "batch": a.batch}))
 
 
 if __name__ == "__main__":
