@@ -1238,7 +1238,9 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
   hipStream_t st = cdn::as_stream(stream);
   const int64_t Hs = H / 2, Ws = W / 2;
   if (grad_s) {
-    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)(N * Hs * Ws), st);
+    // (grad_w directly behind grad_s: one fill for both -- a QAT step is made of launches this small)
+    const size_t ns = (size_t)(N * Hs * Ws), extra = (grad_w == grad_s + ns) ? (size_t)C * 9 : 0;
+    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (ns + extra), st);
     if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
   }
   const size_t cells = (size_t)(Hs + 1) * (Ws + 1);
@@ -1388,7 +1390,9 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   hipStream_t st = cdn::as_stream(stream);
   if (grad_s) {
-    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)(N * H * W), st);
+    // (grad_w directly behind grad_s: one fill for both -- a QAT step is made of launches this small)
+    const size_t ns = (size_t)(N * H * W), extra = (grad_w == grad_s + ns) ? (size_t)C * 9 : 0;
+    hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (ns + extra), st);
     if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
   }
   // lanes <-> channels kernel: the largest channel chunk whose two LDS images fit

@@ -85,6 +85,7 @@ class CodenetStageFunction(Function):
         ops._gpu_f32(x, w_scale, b_scale, w_dw, w_pw, b_pw)
         x = x.contiguous()
         ctx.x_up = bool(x_up)
+        ctx.set_materialize_grads(False)      # (no zero tensor for the non-differentiable partials output: a launch per stage)
         # every producer leaves the {min, max} pairs of its output for the QuantAct behind it: no range passes
         if act_s is not None and act_s.running_stat:
             s_c, sp = ops.codenet_scale(x, w_scale, b_scale, lo, hi, want_range=True)   # clamped, pre-quantisation
@@ -129,6 +130,8 @@ class CodenetStageFunction(Function):
     def backward(ctx, gy, *unused):
         x, s_c, s, w_scale, w_dw, d_q, w_pw, d_snap = ctx.saved_tensors
         need = ctx.needs_input_grad
+        if gy is None:                   # (set_materialize_grads(False): y took no part in the loss)
+            return (None,) * 13
         gy = gy.contiguous()
         Nb, C, H, W = x.shape            # (x_up: the STORED resolution; the stage runs at 2H x 2W)
         lib = N_.lib()
@@ -147,10 +150,16 @@ class CodenetStageFunction(Function):
             gd = gy
         # gather backward (QuantAct on d: straight-through)
         want_x, want_s, want_wdw = need[0], (need[1] or need[2] or need[0]), need[3]
+        def gs_and_gw():
+            # grad_s and grad_w_dw in one buffer: the library's fill of grad_s covers a grad_w that lies right behind it
+            if want_s and want_wdw:
+                buf = torch.empty(s.numel() + w_dw.numel(), device=x.device)
+                return buf[:s.numel()].view_as(s), buf[s.numel():].view_as(w_dw)
+            return (torch.empty_like(s) if want_s else None), (torch.zeros_like(w_dw) if want_wdw else None)
+
         if ctx.x_up:
             gx = torch.empty_like(x) if want_x else None
-            gs = torch.empty_like(s) if want_s else None
-            g_wdw = torch.zeros_like(w_dw) if want_wdw else None
+            gs, g_wdw = gs_and_gw()
             rc = lib.cdn_codenet_dw_up2_backward(_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw),
                                                  Nb, C, 2 * H, 2 * W, ops._stream(x))
             N_.check(rc, "cdn_codenet_dw_up2_backward")
@@ -159,8 +168,7 @@ class CodenetStageFunction(Function):
             gx = gx.contiguous() if gx is not None else None
         else:
             gx = torch.empty_like(x) if want_x else None
-            gs = torch.empty_like(s) if want_s else None
-            g_wdw = torch.zeros_like(w_dw) if want_wdw else None
+            gs, g_wdw = gs_and_gw()
             rc = lib.cdn_codenet_dw_backward(_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw),
                                              Nb, C, H, W, ops._stream(x))
             N_.check(rc, "cdn_codenet_dw_backward")

@@ -131,7 +131,7 @@ def quantact_forward_partials(x, act, partials, want_out=True, want_state_copy=F
     Returns out / (out, state_copy) / state_copy."""
     x = x.contiguous()
     out = torch.empty_like(x) if want_out else None
-    snap = torch.zeros(8, dtype=torch.int32, device=x.device) if want_state_copy else None
+    snap = torch.empty(8, dtype=torch.int32, device=x.device) if want_state_copy else None      # (all 8 words written)
     rc = N_.lib().cdn_quantact_forward_partials(_p(x), _p(out), x.numel(), _p(act.x_min), _p(act.x_max),
                                                 _p(act._device_state(x.device)), _p(partials), partials.shape[0],
                                                 int(act.activation_bit), float(act.momentum), 1, _p(snap), _stream(x))

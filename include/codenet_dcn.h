@@ -141,7 +141,8 @@ int cdn_codenet_dw_forward(const float *x, const float *s, const float *w_dw, fl
 /* Backward of cdn_codenet_dw_forward.  grad_x [N,C,H,W] and grad_s [N,1,H,W] are fully
  * overwritten (grad_x is summed in LDS and stored once -- no global atomics; grad_s is
  * zeroed on `stream` and summed with one global float atomic per pixel and channel chunk);
- * grad_w [C,1,3,3] is ACCUMULATED into (caller zero-fills).  Any of grad_x / grad_s / grad_w
+ * grad_w [C,1,3,3] is ACCUMULATED into (caller zero-fills -- except when it lies directly behind grad_s in memory,
+ * grad_w == grad_s + N*H*W (stored resolution for the _up2 form): the fill of grad_s then covers it).  Any of grad_x / grad_s / grad_w
  * may be NULL.  Requires the (H+2)x(W+2) plane to fit LDS twice (H*W up to ~17k pixels).
  * grad_s is dL/ds = sum_k (i-1)*dL/doff_y,k + (j-1)*dL/doff_x,k. */
 /* ------------------------------------------------------------------------------------------
