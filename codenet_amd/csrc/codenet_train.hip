@@ -137,24 +137,31 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
 // with 4 loads in flight, then the 4 wave sums are added in wave order (with few outputs -- 64 x 128 at stage 2 --
 // one thread per output walking hundreds of slices was a 36 us latency chain).
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int nz) {
+wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int nz,
+                    const float *__restrict__ partial_b, float *__restrict__ gb, long nb) {
+  // (the bias rows ride along: the workgroups behind the weight outputs reduce partial_b [nz][nb] -- one launch)
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + lane;
+  const long wblocks = (n + 63) / 64;
+  const bool bias = (long)blockIdx.x >= wblocks;
+  const float *src = bias ? partial_b : partial;
+  float *dst = bias ? gb : gw;
+  const long len = bias ? nb : n;
+  const long i = ((long)blockIdx.x - (bias ? wblocks : 0)) * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < n) {
+  if (i < len) {
     int z = w;
     for (; z + 12 < nz; z += 16) {
-      s0 += partial[(long)z * n + i];
-      s1 += partial[(long)(z + 4) * n + i];
-      s2 += partial[(long)(z + 8) * n + i];
-      s3 += partial[(long)(z + 12) * n + i];
+      s0 += src[(long)z * len + i];
+      s1 += src[(long)(z + 4) * len + i];
+      s2 += src[(long)(z + 8) * len + i];
+      s3 += src[(long)(z + 12) * len + i];
     }
-    for (; z < nz; z += 4) s0 += partial[(long)z * n + i];
+    for (; z < nz; z += 4) s0 += src[(long)z * len + i];
   }
   red[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (w == 0 && i < n) gw[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (w == 0 && i < len) dst[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -277,14 +284,9 @@ static int pointwise_wgrad_impl(const float *grad_y, const float *d, const void 
   int rc = cdn::check_launch("codenet pointwise weight gradient");
   if (rc) return rc;
   const long n = (long)(Co * C);
-  wgrad_reduce_kernel<<<(unsigned)cdn::ceil_div(n, 64), 256, 0, st>>>(partial, grad_w, n, p.nz);
-  rc = cdn::check_launch("codenet pointwise weight gradient reduce");
-  if (rc) return rc;
-  if (grad_b) {
-    wgrad_reduce_kernel<<<(unsigned)cdn::ceil_div(Co, 64), 256, 0, st>>>(partial_b, grad_b, (long)Co, p.nz);
-    rc = cdn::check_launch("codenet pointwise bias gradient reduce");
-  }
-  return rc;
+  const long blocks = cdn::ceil_div(n, 64) + (grad_b ? cdn::ceil_div(Co, 64) : 0);
+  wgrad_reduce_kernel<<<(unsigned)blocks, 256, 0, st>>>(partial, grad_w, n, p.nz, partial_b, grad_b, (long)Co);
+  return cdn::check_launch("codenet pointwise weight / bias gradient reduce");
 }
 
 extern "C" int cdn_codenet_pointwise_wgrad(const float *grad_y, const float *d, float *grad_w, float *grad_b,
