@@ -262,28 +262,29 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
   }
   float mn = INFINITY, mx = -INFINITY;
   bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
-  for (long p = wave; p < npix; p += nwaves) {
-    const float *xp = x + p * C;
-    float acc = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      float4 v;
-      if (X8)
-        v = unpack_code8(*reinterpret_cast<const unsigned *>(reinterpret_cast<const signed char *>(x) + p * C + c),
-                         qs, qz, qr_);
-      else
-        v = *reinterpret_cast<const float4 *>(xp + c);
-      const float4 ww = *reinterpret_cast<const float4 *>(w + c);
-      if (XQ && !X8) {
-        v.x = cdn::fake_quant_r(v.x, qs, qz, qr_);
-        v.y = cdn::fake_quant_r(v.y, qs, qz, qr_);
-        v.z = cdn::fake_quant_r(v.z, qs, qz, qr_);
-        v.w = cdn::fake_quant_r(v.w, qs, qz, qr_);
-      }
-      acc = fmaf(ww.x, v.x, acc);
-      acc = fmaf(ww.y, v.y, acc);
-      acc = fmaf(ww.z, v.z, acc);
-      acc = fmaf(ww.w, v.w, acc);
+  // one pixel's dot product (a wave: 64 lanes x 4 channels per round); `take` loads, `dot` consumes -- two pixels'
+  // loads are issued before either is consumed (round 5: at stage 1 every wave has exactly two pixels, and the
+  // second load used to wait behind the first one's reduction: one memory latency instead of two per launch)
+  auto take = [&](long p, int c) -> float4 {
+    if (X8)
+      return unpack_code8(*reinterpret_cast<const unsigned *>(reinterpret_cast<const signed char *>(x) + p * C + c), qs, qz,
+                          qr_);
+    return *reinterpret_cast<const float4 *>(x + p * C + c);
+  };
+  auto dot = [&](float4 v, int c, float acc) -> float {
+    const float4 ww = *reinterpret_cast<const float4 *>(w + c);
+    if (XQ && !X8) {
+      v.x = cdn::fake_quant_r(v.x, qs, qz, qr_);
+      v.y = cdn::fake_quant_r(v.y, qs, qz, qr_);
+      v.z = cdn::fake_quant_r(v.z, qs, qz, qr_);
+      v.w = cdn::fake_quant_r(v.w, qs, qz, qr_);
     }
+    acc = fmaf(ww.x, v.x, acc);
+    acc = fmaf(ww.y, v.y, acc);
+    acc = fmaf(ww.z, v.z, acc);
+    return fmaf(ww.w, v.w, acc);
+  };
+  auto finish = [&](float acc, long p) {
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
     float v = acc + (b ? b[0] : 0.0f);
@@ -292,6 +293,23 @@ scale_nhwc_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     mn = fminf(mn, v);
     mx = fmaxf(mx, v);
     has_nan |= (v != v);
+  };
+  long p = wave;
+  for (; p + nwaves < npix; p += 2 * nwaves) {
+    const long p2 = p + nwaves;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const float4 v0 = take(p, c), v1 = take(p2, c);
+      a0 = dot(v0, c, a0);
+      a1 = dot(v1, c, a1);
+    }
+    finish(a0, p);
+    finish(a1, p2);
+  }
+  if (p < npix) {
+    float acc = 0.f;
+    for (int c = lane * 4; c < C; c += 256) acc = dot(take(p, c), c, acc);
+    finish(acc, p);
   }
   CDN_STAMPR(0, 2);
   if (mm) cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), mm, blockIdx.x, gridDim.x, qu, red);
