@@ -39,6 +39,7 @@ _SIGNATURES = {
     "cdn_codenet_pointwise_forward_range": (_i, [_vp] * 7 + [_i64] * 4 + [_i, _vp, _vp]),
     "cdn_quantact_forward_partials": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp]),
     "cdn_codenet_pointwise_wgrad_q": (_i, [_vp] * 5 + [_i64] * 4 + [_vp, ctypes.c_size_t, _vp]),
+    "cdn_codenet_pointwise_wgrad_q_f32": (_i, [_vp] * 5 + [_i64] * 4 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_quantact_relu_up2_forward_partials": (
         _i, [_vp, _vp] + [_i64] * 3 + [_vp] * 4 + [_i64, _i, _d, _i, _vp]),
     "cdn_codenet_scale_backward_masked": (_i, [_vp] * 3 + [_f, _f] + [_vp] * 3 + [_i64] * 4 + [_vp]),

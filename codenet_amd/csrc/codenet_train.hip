@@ -133,6 +133,176 @@ pw_wgrad_kernel(const float *__restrict__ gy, const float *__restrict__ d, float
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// pw_wgrad_q3_kernel (round 5): the same partial tiles on the bf16 matrix cores with EXACT products, for d given as
+// pre-quantisation values + the QuantAct state that quantises them (the QAT step).  d' = (q' + 128) / scale with the
+// integer q' = rint(scale x - zp) + zp - 128 (|q'| <= 2040 unless the state's wide flag is set: two bf16 terms hold 16
+// bits), grad_y = hi + mid + lo in three bf16 terms by truncation (exact):
+//   partial[z][co][c] = sum_k grad_y[co][k] q'[c][k]        6 v_mfma_f32_32x32x16_bf16 per 16 k, every product exact
+//   grad_w = (sum_z partial + 128 grad_b[co]) / scale       (wgrad_reduce_q_kernel; grad_b = row sums of grad_y)
+// against 8 v_mfma_f32_32x32x2_f32 per 16 k in pw_wgrad_kernel (41 / 37 / 56 us at the step's three stages, matrix-core
+// bound).  Workgroup tile 64 (co) x 128 (c): both operands cross L2 less often than with 64 x 64 tiles; waves 2 x 2, each
+// a 32 x 64 tile; K tiles of 64 pixels of one image staged through LDS as bf16 rows of 64 k + 16 bytes of padding
+// (five planes: 64.5 KB, two workgroups per CU); the next tile's global loads in flight behind the MFMAs.
+// Whole tiles only (Co % 64, C % 128, HW % 64, 16-byte aligned rows): everything else stays on pw_wgrad_kernel.
+// ------------------------------------------------------------------------------------------------------
+using bf16x8w = __attribute__((ext_vector_type(8))) __bf16;
+using i32x4w = __attribute__((ext_vector_type(4))) int;
+constexpr int kQ3BM = 64, kQ3BN = 128, kQ3BK = 64, kQ3LD = 144;      // bytes per LDS row: 64 bf16 + 16
+
+__global__ void __launch_bounds__(256)
+pw_wgrad_q3_kernel(const float *__restrict__ gy, const float *__restrict__ d, float *__restrict__ partial,
+                   float *__restrict__ partial_b, int C, int Co, int HW, int chunks_per_img, int nchunks,
+                   int chunks_per_slice, const unsigned *__restrict__ dq) {
+  extern __shared__ float4 q3_lds[];
+  unsigned char *lds = reinterpret_cast<unsigned char *>(q3_lds);
+  unsigned char *Ah = lds, *Am = Ah + kQ3BM * kQ3LD, *Al = Am + kQ3BM * kQ3LD;
+  unsigned char *Bh = Al + kQ3BM * kQ3LD, *Bl = Bh + kQ3BN * kQ3LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * kQ3BN, m0 = blockIdx.y * kQ3BM, z = blockIdx.z;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+  const int ch_lo = z * chunks_per_slice, ch_hi = min(nchunks, ch_lo + chunks_per_slice);
+  const int lrow = tid >> 4, lk = (tid & 15) * 4;      // staging: rows lrow + 16*i, floats lk .. lk+3
+  const float qs = reinterpret_cast<const float *>(dq)[2], qz = reinterpret_cast<const float *>(dq)[3];
+  const float qoff = qz - 128.0f;                      // (integers: exact)
+  f32x16 acc[2];
+  acc[0] = (f32x16){0};
+  acc[1] = (f32x16){0};
+  float4 ra[4], rb[8];
+  const bool do_bias = blockIdx.x == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int ch) {
+    const int n = ch / chunks_per_img, p0 = (ch - n * chunks_per_img) * kQ3BK;
+    const float *ga = gy + (long)n * Co * HW + p0 + lk, *gb = d + (long)n * C * HW + p0 + lk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4 *>(ga + (long)(m0 + lrow + 16 * i) * HW);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const float4 *>(gb + (long)(c0 + lrow + 16 * i) * HW);
+  };
+  auto pack_hi = [](unsigned a_, unsigned b_) -> unsigned { return __builtin_amdgcn_perm(a_, b_, 0x07060302u); };
+  if (ch_lo < ch_hi) load(ch_lo);
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {
+    __syncthreads();                       // the previous tile has been consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hb[e] = __float_as_uint(v[e]);
+        const float r1 = __fsub_rn(v[e], __uint_as_float(hb[e] & 0xFFFF0000u));
+        mb[e] = __float_as_uint(r1);
+        lb[e] = __float_as_uint(__fsub_rn(r1, __uint_as_float(mb[e] & 0xFFFF0000u)));
+      }
+      const int o = (lrow + 16 * i) * kQ3LD + lk * 2;
+      *reinterpret_cast<uint2 *>(Ah + o) = make_uint2(pack_hi(hb[1], hb[0]), pack_hi(hb[3], hb[2]));
+      *reinterpret_cast<uint2 *>(Am + o) = make_uint2(pack_hi(mb[1], mb[0]), pack_hi(mb[3], mb[2]));
+      *reinterpret_cast<uint2 *>(Al + o) = make_uint2(pack_hi(lb[1], lb[0]), pack_hi(lb[3], lb[2]));
+      if (do_bias) bsum[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+      unsigned hb[4], lb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float q = cdn::quant_code(v[e], qs, qz) + qoff;      // q' (an integer-valued float)
+        hb[e] = __float_as_uint(q);
+        lb[e] = __float_as_uint(__fsub_rn(q, __uint_as_float(hb[e] & 0xFFFF0000u)));
+      }
+      const int o = (lrow + 16 * i) * kQ3LD + lk * 2;
+      *reinterpret_cast<uint2 *>(Bh + o) = make_uint2(pack_hi(hb[1], hb[0]), pack_hi(hb[3], hb[2]));
+      *reinterpret_cast<uint2 *>(Bl + o) = make_uint2(pack_hi(lb[1], lb[0]), pack_hi(lb[3], lb[2]));
+    }
+    __syncthreads();
+    if (ch + 1 < ch_hi) load(ch + 1);      // in flight during the MFMAs below
+    const int fo = (lane & 31) * kQ3LD + (lane >> 5) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ao = (wm)*kQ3LD + fo + ks * 32;
+      const bf16x8w fh = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const i32x4w *>(Ah + ao));
+      const bf16x8w fm = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const i32x4w *>(Am + ao));
+      const bf16x8w fl = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const i32x4w *>(Al + ao));
+      bf16x8w bh[2], bl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int bo = (wn + 32 * j) * kQ3LD + fo + ks * 32;
+        bh[j] = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const i32x4w *>(Bh + bo));
+        bl[j] = __builtin_bit_cast(bf16x8w, *reinterpret_cast<const i32x4w *>(Bl + bo));
+      }
+      // smallest terms first, the two accumulators interleaved (back-to-back MFMAs into one accumulator stall)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bh[j], acc[j], 0, 0, 0);
+    }
+  }
+  float *out = partial + (long)z * Co * C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = c0 + wn + 32 * j + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      out[(long)row * C + col] = acc[j][r];
+    }
+  }
+  if (do_bias) {       // the 16 threads that share a row: lanes 16*j .. 16*j+15 of a wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+#pragma unroll
+      for (int m = 8; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+      if ((tid & 15) == 0) partial_b[(long)z * Co + m0 + lrow + 16 * i] = v;
+    }
+  }
+}
+
+// grad_w = (sum_z partial + 128 grad_b[co]) / scale and grad_b = sum_z partial_b, fixed orders, one launch: a workgroup
+// owns 64 consecutive outputs of ONE row (C % 64 == 0) and first reduces that row's bias sum.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_q_kernel(const float *__restrict__ partial, float *__restrict__ gw, int C, int Co, int nz,
+                      const float *__restrict__ partial_b, float *__restrict__ gb, const unsigned *__restrict__ dq) {
+  __shared__ float red[4][64];
+  __shared__ float rb[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long n = (long)Co * C;
+  const long i = (long)blockIdx.x * 64 + lane;
+  const int co = (int)(((long)blockIdx.x * 64) / C);
+  // the row's bias sum: wave w takes z = w, w + 4, ... lane-strided, then a fixed-order tree
+  float b = 0.f;
+  for (int zz = w * 64 + lane; zz < nz; zz += 256) b += partial_b[(long)zz * Co + co];
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) b += __shfl_xor(b, m, 64);
+  if (lane == 0) rb[w] = b;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int zi = w;
+  for (; zi + 12 < nz; zi += 16) {
+    s0 += partial[(long)zi * n + i];
+    s1 += partial[(long)(zi + 4) * n + i];
+    s2 += partial[(long)(zi + 8) * n + i];
+    s3 += partial[(long)(zi + 12) * n + i];
+  }
+  for (; zi < nz; zi += 4) s0 += partial[(long)zi * n + i];
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0) {
+    const float gbv = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+    const float S = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const float sc = reinterpret_cast<const float *>(dq)[2];
+    gw[i] = __fdiv_rn(fmaf(128.0f, gbv, S), sc);
+    if (gb != nullptr && lane == 0 && ((long)blockIdx.x * 64) % C == 0) gb[co] = gbv;
+  }
+}
+
 // gw[i] = sum_z partial[z][i] in a fixed order: a workgroup owns 64 outputs, its 4 waves take z = w, w+4, ...
 // with 4 loads in flight, then the 4 wave sums are added in wave order (with few outputs -- 64 x 128 at stage 2 --
 // one thread per output walking hundreds of slices was a 36 us latency chain).
@@ -263,7 +433,7 @@ extern "C" size_t cdn_codenet_pointwise_wgrad_workspace_bytes(int64_t N, int64_t
 
 static int pointwise_wgrad_impl(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
                                 int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+                                void *stream, bool f32_only = false) {
   CDN_REQUIRE(grad_y && d && grad_w && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && HW > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N * C * HW < (1ll << 31) && N * Co * HW < (1ll << 31) && C * Co < (1ll << 31),
@@ -274,6 +444,31 @@ static int pointwise_wgrad_impl(const float *grad_y, const float *d, const void 
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(grad_y) & 15) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0,
               CDN_ERR_ARG, "grad_y / d must be 16-byte aligned");
   hipStream_t st = cdn::as_stream(stream);
+#if !defined(CDN_NO_WGRAD_Q3)
+  if (d_state && !f32_only && (Co % kQ3BM) == 0 && (C % kQ3BN) == 0 && (HW % kQ3BK) == 0) {
+    // exact bf16 products on the integer form of d (pw_wgrad_q3_kernel): whole 64 x 128 tiles
+    const int tiles_c = (int)(C / kQ3BN), tiles_m = (int)(Co / kQ3BM);
+    const int chunks_per_img = (int)(HW / kQ3BK), nchunks = (int)(N * chunks_per_img);
+    int nz = (int)std::max<int64_t>(1, (2 * cdn::kCUs) / ((int64_t)tiles_c * tiles_m));
+    nz = std::min(nz, std::max(1, nchunks / 2));
+    const WgPlan pl = wgrad_plan(N, C, Co, HW);
+    nz = std::min(nz, pl.nz);                    // (the workspace is sized for the f32 kernel's slice count)
+    const int per_slice = (int)cdn::ceil_div(nchunks, nz);
+    nz = (int)cdn::ceil_div(nchunks, per_slice);
+    float *part = static_cast<float *>(workspace);
+    float *part_b = part + (size_t)nz * Co * C;
+    constexpr int kLds = (3 * kQ3BM + 2 * kQ3BN) * kQ3LD;
+    (void)hipFuncSetAttribute((const void *)pw_wgrad_q3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    pw_wgrad_q3_kernel<<<dim3((unsigned)tiles_c, (unsigned)tiles_m, (unsigned)nz), 256, kLds, st>>>(
+        grad_y, d, part, part_b, (int)C, (int)Co, (int)HW, chunks_per_img, nchunks, per_slice,
+        static_cast<const unsigned *>(d_state));
+    int rc = cdn::check_launch("codenet pointwise weight gradient (bf16 x 3)");
+    if (rc) return rc;
+    wgrad_reduce_q_kernel<<<(unsigned)((long)Co * C / 64), 256, 0, st>>>(part, grad_w, (int)C, (int)Co, nz, part_b, grad_b,
+                                                                        static_cast<const unsigned *>(d_state));
+    return cdn::check_launch("codenet pointwise weight / bias gradient reduce");
+  }
+#endif
   const WgPlan p = wgrad_plan(N, C, Co, HW);
   CDN_REQUIRE(p.tiles_m <= 65535 && p.nz <= 65535, CDN_ERR_UNSUPPORTED, "too many tiles");
   float *partial = static_cast<float *>(workspace);
@@ -300,6 +495,12 @@ extern "C" int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d
                                              void *workspace, size_t workspace_bytes, void *stream) {
   CDN_REQUIRE(d_state, CDN_ERR_ARG, "null pointer");
   return pointwise_wgrad_impl(grad_y, d, d_state, grad_w, grad_b, N, C, Co, HW, workspace, workspace_bytes, stream);
+}
+extern "C" int cdn_codenet_pointwise_wgrad_q_f32(const float *grad_y, const float *d, const void *d_state, float *grad_w,
+                                                 float *grad_b, int64_t N, int64_t C, int64_t Co, int64_t HW,
+                                                 void *workspace, size_t workspace_bytes, void *stream) {
+  CDN_REQUIRE(d_state, CDN_ERR_ARG, "null pointer");
+  return pointwise_wgrad_impl(grad_y, d, d_state, grad_w, grad_b, N, C, Co, HW, workspace, workspace_bytes, stream, true);
 }
 
 static int scale_backward_impl(const float *x, const float *grad_s, const float *s_clamped, float lo, float hi,

@@ -41,6 +41,11 @@ def _workspace(nbytes, device):
     return ws
 
 
+# A/B switch (tools/train_step_bench.py --no-bf16-wgrad): exact bf16 products on the integer form of d
+# (pw_wgrad_q3_kernel) where the tiles are whole, or the f32-MFMA kernel everywhere
+WGRAD_BF16X3 = True
+
+
 def pointwise_wgrad(grad_y, d, want_bias, d_state=None):
     """(grad_w [Co, C], grad_b [Co] or None) of y = conv1x1(d, w) + b; grad_y [N,Co,H,W], d [N,C,H,W].  d_state: d holds
     pre-quantisation values, fake-quantised on load with that (snapshot of a) QuantAct state."""
@@ -52,8 +57,9 @@ def pointwise_wgrad(grad_y, d, want_bias, d_state=None):
     gw = torch.empty(Co, C, device=grad_y.device)
     gb = torch.empty(Co, device=grad_y.device) if want_bias else None
     if d_state is not None:
-        rc = lib.cdn_codenet_pointwise_wgrad_q(_p(grad_y), _p(d), _p(d_state), _p(gw), _p(gb), Nb, C, Co, H * W, _p(ws),
-                                               ws.numel() * 4, ops._stream(grad_y))
+        fn = lib.cdn_codenet_pointwise_wgrad_q if WGRAD_BF16X3 else lib.cdn_codenet_pointwise_wgrad_q_f32
+        rc = fn(_p(grad_y), _p(d), _p(d_state), _p(gw), _p(gb), Nb, C, Co, H * W, _p(ws), ws.numel() * 4,
+                ops._stream(grad_y))
         N_.check(rc, "cdn_codenet_pointwise_wgrad_q")
         return gw, gb
     rc = lib.cdn_codenet_pointwise_wgrad(_p(grad_y), _p(d), _p(gw), _p(gb), Nb, C, Co, H * W, _p(ws),

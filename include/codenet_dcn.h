@@ -222,10 +222,17 @@ int cdn_codenet_pointwise_i8_forward_range(const float *d, const void *d_state, 
 int cdn_codenet_pointwise_dgrad_q4_supported(int64_t N, int64_t C, int64_t Co, int64_t HW);
 int cdn_codenet_pointwise_dgrad_q4(const float *grad_y, const void *fwd_workspace, float *grad_d, int64_t N, int64_t C,
                                    int64_t Co, int64_t HW, void *stream);
-/* cdn_codenet_pointwise_wgrad with d given as pre-quantisation values + the state that quantised them in the forward */
+/* cdn_codenet_pointwise_wgrad with d given as pre-quantisation values + the state that quantised them in the forward:
+ * round 5: with whole 64 x 128 tiles (Co % 64 == 0, C % 128 == 0, HW % 64 == 0) the products are formed EXACTLY on the bf16
+ * matrix cores -- d as the integer q' = round(scale d - zp) + zp - 128 in two bf16 terms, grad_y in three -- and
+ * grad_w = (sum grad_y q' + 128 grad_b) / scale (pw_wgrad_q3_kernel; rounding noise against the f32-MFMA form, bitwise
+ * reproducible like it); cdn_codenet_pointwise_wgrad_q_f32 keeps the f32-MFMA kernel (A/B, tests). */
 int cdn_codenet_pointwise_wgrad_q(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
                                   int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace, size_t workspace_bytes,
                                   void *stream);
+int cdn_codenet_pointwise_wgrad_q_f32(const float *grad_y, const float *d, const void *d_state, float *grad_w, float *grad_b,
+                                      int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 int cdn_quantact_relu_up2_forward_partials(const float *y, float *out, int64_t planes, int64_t H, int64_t W,
                                            float *x_min, float *x_max, void *state, const float *partials,
                                            int64_t n_partials, int bits, double momentum, int running, void *stream);

@@ -39,7 +39,11 @@ def main():
                     "(pointwise_kernel) instead of the exact integer form on int8 MFMA (pwi8n_kernel)")
     ap.add_argument("--no-bf16-dgrad", action="store_true", help="A/B: the data gradient of conv_channel on f32 MFMA "
                     "instead of the exact bf16 x 3 split (pwb3n_kernel)")
+    ap.add_argument("--no-bf16-wgrad", action="store_true", help="A/B: the weight gradient of conv_channel on f32 MFMA")
     a = ap.parse_args()
+    if a.no_bf16_wgrad:
+        from codenet_amd.functions import codenet_stage as _cs3
+        _cs3.WGRAD_BF16X3 = False
     if a.no_bf16_dgrad:
         from codenet_amd import ops as _ops2
         _ops2.DGRAD_BF16X3 = False
