@@ -49,11 +49,25 @@ __device__ __forceinline__ Axis make_axis(int base, float off, int size) {
   return a;
 }
 
+// Bilinear sums with ONE spelled-out association (round 5).  Written with plain operators, `a*b + c*d + ...` is contracted
+// into fused multiply-adds at the compiler's discretion, and the choice differed between the two instantiations of
+// dw4_kernel: the stored-resolution form and the form on the materialised up-sampled tensor -- documented as
+// bit-identical -- were 1 ulp apart on 4 % of the outputs (seen when a changed summation order in scale_kernel moved
+// the data: a single flipped code behind them failed test_stored_resolution_stages_equal_the_upsampled_path).
+__device__ __forceinline__ float bil4(float w00, float v00, float w01, float v01, float w10, float v10, float w11,
+                                      float v11) {
+  return fmaf(w11, v11, fmaf(w10, v10, fmaf(w01, v01, w00 * v00)));
+}
+__device__ __forceinline__ float lin2(float w0, float v0, float w1, float v1) { return fmaf(w1, v1, w0 * v0); }
+
 // ------------------------------------------------------------------------------------------
 // scale_kernel: s[n,p] = clamp(b + sum_c w[c] * x[n,c,p], lo, hi)
-// grid = (ceil(HW/64), N), block = 256 (4 waves); wave v reduces channels v, v+4, ...
+// grid = (ceil(HW/64), N), block = kSclWaves waves of 64 pixels; wave v reduces channels v, v + kSclWaves, ... with 16
+// loads in flight per lane when the channel count allows (round 5: the fused schedule's scale_nchw_kernel structure --
+// four waves with four loads each left the C -> 1 reduction of the QAT step's stage 0 at 1.3 TB/s, 25 us for 33.5 MB).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kSclWaves = 16;
+__global__ void __launch_bounds__(kSclWaves * 64)
 scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
              const float *__restrict__ b, float *__restrict__ s, int C, int HW, float lo,
              float hi, float2 *__restrict__ mm) {
@@ -62,24 +76,39 @@ scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
   const int n = blockIdx.y;
   const bool live = p < HW;
   const float *xp = x + (long)n * C * HW + (live ? p : 0);
+  constexpr int S = kSclWaves;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   int c = wave;
-  for (; c + 12 < C; c += 16) {
-    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + 4) * HW];
-    const float v2 = xp[(long)(c + 8) * HW], v3 = xp[(long)(c + 12) * HW];
-    acc0 = fmaf(w[c], v0, acc0);
-    acc1 = fmaf(w[c + 4], v1, acc1);
-    acc2 = fmaf(w[c + 8], v2, acc2);
-    acc3 = fmaf(w[c + 12], v3, acc3);
+  for (; c + 15 * S < C; c += 16 * S) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = xp[(long)(c + u * S) * HW];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      acc0 = fmaf(w[c + u * S], v[u], acc0);
+      acc1 = fmaf(w[c + (u + 1) * S], v[u + 1], acc1);
+      acc2 = fmaf(w[c + (u + 2) * S], v[u + 2], acc2);
+      acc3 = fmaf(w[c + (u + 3) * S], v[u + 3], acc3);
+    }
   }
-  for (; c < C; c += 4) acc0 = fmaf(w[c], xp[(long)c * HW], acc0);
-  __shared__ float red[4][64];
+  for (; c + 3 * S < C; c += 4 * S) {
+    const float v0 = xp[(long)c * HW], v1 = xp[(long)(c + S) * HW];
+    const float v2 = xp[(long)(c + 2 * S) * HW], v3 = xp[(long)(c + 3 * S) * HW];
+    acc0 = fmaf(w[c], v0, acc0);
+    acc1 = fmaf(w[c + S], v1, acc1);
+    acc2 = fmaf(w[c + 2 * S], v2, acc2);
+    acc3 = fmaf(w[c + 3 * S], v3, acc3);
+  }
+  for (; c < C; c += S) acc0 = fmaf(w[c], xp[(long)c * HW], acc0);
+  __shared__ float red[kSclWaves][64];
   red[wave][lane] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
   float mn = INFINITY, mx = -INFINITY;
   bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   if (wave == 0 && live) {
-    float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSclWaves; ++i) v += red[i][lane];
     v += b ? b[0] : 0.0f;
     v = cdn::clamp_keep_nan(v, lo, hi);  // Hardtanh(lo, hi), modules/dcn_deform_conv.py:304-305
     s[(long)n * HW + p] = v;
@@ -147,18 +176,17 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
       float acc;
       if (LDS) {
         const float *pl = planes + ch * pstride;
-#define CDN_CORNER(B, Y, X)                                                        \
-  (((Y.w0 * X.w0) * pl[B] + (Y.w0 * X.w1) * pl[B + 1]) + (Y.w1 * X.w0) * pl[B + Wp] + \
-   (Y.w1 * X.w1) * pl[B + Wp + 1])
+#define CDN_CORNER(B, Y, X)                                                                   \
+  bil4(Y.w0 * X.w0, pl[B], Y.w0 * X.w1, pl[B + 1], Y.w1 * X.w0, pl[B + Wp], Y.w1 * X.w1, pl[B + Wp + 1])
         const float v0 = CDN_CORNER(b00, ya, xa);
         const float v2 = CDN_CORNER(b02, ya, xb);
         const float v6 = CDN_CORNER(b20, yb, xa);
         const float v8 = CDN_CORNER(b22, yb, xb);
 #undef CDN_CORNER
-        const float v1 = ya.w0 * pl[b01] + ya.w1 * pl[b01 + Wp];
-        const float v7 = yb.w0 * pl[b21] + yb.w1 * pl[b21 + Wp];
-        const float v3 = xa.w0 * pl[b10] + xa.w1 * pl[b10 + 1];
-        const float v5 = xb.w0 * pl[b12] + xb.w1 * pl[b12 + 1];
+        const float v1 = lin2(ya.w0, pl[b01], ya.w1, pl[b01 + Wp]);
+        const float v7 = lin2(yb.w0, pl[b21], yb.w1, pl[b21 + Wp]);
+        const float v3 = lin2(xa.w0, pl[b10], xa.w1, pl[b10 + 1]);
+        const float v5 = lin2(xb.w0, pl[b12], xb.w1, pl[b12 + 1]);
         const float v4 = pl[b11];
         acc = wk[0] * v0;
         acc = fmaf(wk[1], v1, acc);
@@ -176,20 +204,19 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
           return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? pl[yy * W + xx] : 0.0f;
         };
         auto tap = [&](const Axis &Y, const Axis &X) -> float {
-          return ((Y.w0 * X.w0) * rd(Y.i0, X.i0) + (Y.w0 * X.w1) * rd(Y.i0, X.i0 + 1)) +
-                 (Y.w1 * X.w0) * rd(Y.i0 + 1, X.i0) + (Y.w1 * X.w1) * rd(Y.i0 + 1, X.i0 + 1);
+          return bil4(Y.w0 * X.w0, rd(Y.i0, X.i0), Y.w0 * X.w1, rd(Y.i0, X.i0 + 1), Y.w1 * X.w0, rd(Y.i0 + 1, X.i0),
+                      Y.w1 * X.w1, rd(Y.i0 + 1, X.i0 + 1));
         };
-        Axis ym, xm;
-        ym.i0 = h; ym.w0 = 1.0f; ym.w1 = 0.0f; ym.ok = true;
-        xm.i0 = w; xm.w0 = 1.0f; xm.w1 = 0.0f; xm.ok = true;
+        auto tap_v = [&](const Axis &Y) -> float { return lin2(Y.w0, rd(Y.i0, w), Y.w1, rd(Y.i0 + 1, w)); };
+        auto tap_h = [&](const Axis &X) -> float { return lin2(X.w0, rd(h, X.i0), X.w1, rd(h, X.i0 + 1)); };
         acc = wk[0] * tap(ya, xa);
-        acc = fmaf(wk[1], tap(ya, xm), acc);
+        acc = fmaf(wk[1], tap_v(ya), acc);
         acc = fmaf(wk[2], tap(ya, xb), acc);
-        acc = fmaf(wk[3], tap(ym, xa), acc);
+        acc = fmaf(wk[3], tap_h(xa), acc);
         acc = fmaf(wk[4], pl[p], acc);
-        acc = fmaf(wk[5], tap(ym, xb), acc);
+        acc = fmaf(wk[5], tap_h(xb), acc);
         acc = fmaf(wk[6], tap(yb, xa), acc);
-        acc = fmaf(wk[7], tap(yb, xm), acc);
+        acc = fmaf(wk[7], tap_v(yb), acc);
         acc = fmaf(wk[8], tap(yb, xb), acc);
       }
       d[((long)n * C + c0 + ch) * HW + p] = acc;
@@ -273,14 +300,14 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
 #define CDN_DW4_CH(E, OFF)                                                                             \
       {                                                                                                  \
         const float *wk = wl + (4 * g + OFF) * 9;                                                        \
-        const float v0 = ((aa00 * c00.E + aa01 * c01.E) + aa10 * c02.E) + aa11 * c03.E;                  \
-        const float v2 = ((ab00 * c20.E + ab01 * c21.E) + ab10 * c22.E) + ab11 * c23.E;                  \
-        const float v6 = ((ba00 * c60.E + ba01 * c61.E) + ba10 * c62.E) + ba11 * c63.E;                  \
-        const float v8 = ((bb00 * c80.E + bb01 * c81.E) + bb10 * c82.E) + bb11 * c83.E;                  \
-        const float v1 = ya.w0 * e10.E + ya.w1 * e11.E;                                                  \
-        const float v7 = yb.w0 * e70.E + yb.w1 * e71.E;                                                  \
-        const float v3 = xa.w0 * e30.E + xa.w1 * e31.E;                                                  \
-        const float v5 = xb.w0 * e50.E + xb.w1 * e51.E;                                                  \
+        const float v0 = bil4(aa00, c00.E, aa01, c01.E, aa10, c02.E, aa11, c03.E);                       \
+        const float v2 = bil4(ab00, c20.E, ab01, c21.E, ab10, c22.E, ab11, c23.E);                       \
+        const float v6 = bil4(ba00, c60.E, ba01, c61.E, ba10, c62.E, ba11, c63.E);                       \
+        const float v8 = bil4(bb00, c80.E, bb01, c81.E, bb10, c82.E, bb11, c83.E);                       \
+        const float v1 = lin2(ya.w0, e10.E, ya.w1, e11.E);                                               \
+        const float v7 = lin2(yb.w0, e70.E, yb.w1, e71.E);                                               \
+        const float v3 = lin2(xa.w0, e30.E, xa.w1, e31.E);                                               \
+        const float v5 = lin2(xb.w0, e50.E, xb.w1, e51.E);                                               \
         float acc = wk[0] * v0;                                                                          \
         acc = fmaf(wk[1], v1, acc);                                                                      \
         acc = fmaf(wk[2], v2, acc);                                                                      \
@@ -1141,7 +1168,7 @@ static int scale_forward_impl(const float *x, const float *w_scale, const float 
   CDN_REQUIRE(N <= 65535 && C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   const int HW = (int)(H * W);
   dim3 grid((unsigned)cdn::ceil_div(HW, 64), (unsigned)N);
-  scale_kernel<<<grid, 256, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo, hi,
+  scale_kernel<<<grid, kSclWaves * 64, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo, hi,
                                                          reinterpret_cast<float2 *>(partials));
   return cdn::check_launch("codenet scale forward");
 }
