@@ -553,14 +553,13 @@ namespace {
 // b are BIT-IDENTICAL to the torch composition (tests/test_train_step.py).  One wave per output channel.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kPctMax = 4;
-__global__ void __launch_bounds__(256)
-weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__restrict__ sf_in,
+__device__ __forceinline__ void weight_prep_rows(int block, const float *__restrict__ w, int Co, int K, const float *__restrict__ sf_in,
                    const float *__restrict__ bn_b, const float *__restrict__ bn_mean,
                    const float *__restrict__ conv_bias, float nlev, float *__restrict__ wq,
                    float *__restrict__ b_out, int k_low, int k_high, float shrink) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
-  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int co = block * 4 + (threadIdx.x >> 6);      // block: this workgroup's index within the tensor
   if (co >= Co) return;
   float sf = 1.0f;
   const bool fold = sf_in != nullptr;
@@ -651,6 +650,33 @@ weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__re
   }
 }
 
+__global__ void __launch_bounds__(256)
+weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__restrict__ sf_in,
+                   const float *__restrict__ bn_b, const float *__restrict__ bn_mean,
+                   const float *__restrict__ conv_bias, float nlev, float *__restrict__ wq,
+                   float *__restrict__ b_out, int k_low, int k_high, float shrink) {
+  weight_prep_rows((int)blockIdx.x, w, Co, K, sf_in, bn_b, bn_mean, conv_bias, nlev, wq, b_out, k_low, k_high, shrink);
+}
+
+// Several plain (no BN fold) weight tensors in ONE launch (round 5: the conv_scale and depthwise weights of all three
+// stages of a QAT step -- six launches of ~4.4 us, each at its launch floor): the workgroups are dealt out tensor by
+// tensor, every row is prepared exactly as by weight_prep_kernel.
+constexpr int kPrepMulti = 8;
+struct PrepMulti {
+  const float *w[kPrepMulti];
+  float *wq[kPrepMulti];
+  int Co[kPrepMulti], K[kPrepMulti], k_low[kPrepMulti], k_high[kPrepMulti], first_block[kPrepMulti + 1];
+  float nlev[kPrepMulti], shrink[kPrepMulti];
+  int n;
+};
+__global__ void __launch_bounds__(256)
+weight_prep_multi_kernel(PrepMulti d) {
+  int t = 0;
+  while (t + 1 < d.n && (int)blockIdx.x >= d.first_block[t + 1]) ++t;
+  weight_prep_rows((int)blockIdx.x - d.first_block[t], d.w[t], d.Co[t], d.K[t], nullptr, nullptr, nullptr, nullptr,
+                   d.nlev[t], d.wq[t], nullptr, d.k_low[t], d.k_high[t], d.shrink[t]);
+}
+
 }  // namespace
 
 namespace {
@@ -719,6 +745,36 @@ static int weight_prep_impl(const float *w, int64_t Co, int64_t K, const float *
                                                                      conv_bias, nlev, w_q, bias_out, k_low, k_high,
                                                                      shrink);
   return cdn::check_launch("codenet weight prep");
+}
+
+extern "C" int cdn_codenet_weight_prep_multi(int n, const float *const *w, const int64_t *Co, const int64_t *K,
+                                             const int *bits, const int *k_low, const int *k_high, const float *shrink,
+                                             float *const *w_q, void *stream) {
+  CDN_REQUIRE(n >= 1 && n <= kPrepMulti, CDN_ERR_ARG, "1 .. %d tensors per call", kPrepMulti);
+  CDN_REQUIRE(w && Co && K && bits && k_low && k_high && shrink && w_q, CDN_ERR_ARG, "null pointer");
+  PrepMulti d;
+  d.n = n;
+  int blocks = 0;
+  for (int t = 0; t < n; ++t) {
+    CDN_REQUIRE(w[t] && w_q[t] && Co[t] > 0 && K[t] > 0 && Co[t] * K[t] < (1ll << 31), CDN_ERR_ARG, "bad tensor %d", t);
+    CDN_REQUIRE(bits[t] >= 2 && bits[t] <= 8, CDN_ERR_ARG, "bits must be in [2, 8]");
+    CDN_REQUIRE(k_low[t] <= K[t] && k_high[t] <= K[t], CDN_ERR_ARG, "k_low / k_high must be in [1, K]");
+    CDN_REQUIRE(k_low[t] >= 1 && k_high[t] >= 1 && k_low[t] <= kPctMax && k_high[t] <= kPctMax, CDN_ERR_UNSUPPORTED,
+                "ranks of 1 .. %d", kPctMax);
+    d.w[t] = w[t];
+    d.wq[t] = w_q[t];
+    d.Co[t] = (int)Co[t];
+    d.K[t] = (int)K[t];
+    d.k_low[t] = k_low[t];
+    d.k_high[t] = k_high[t];
+    d.shrink[t] = shrink[t];
+    d.nlev[t] = (float)((1 << (bits[t] - 1)) - 1);
+    d.first_block[t] = blocks;
+    blocks += (int)cdn::ceil_div(Co[t], 4);
+  }
+  d.first_block[n] = blocks;
+  weight_prep_multi_kernel<<<(unsigned)blocks, 256, 0, cdn::as_stream(stream)>>>(d);
+  return cdn::check_launch("codenet weight prep (multi)");
 }
 
 extern "C" int cdn_codenet_weight_prep(const float *w, int64_t Co, int64_t K, const float *scale_factor,

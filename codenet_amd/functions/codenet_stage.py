@@ -248,6 +248,52 @@ class FakeQuantWeight(Function):
         return g, None, None    # (the reference clones; an identity backward needs no copy)
 
 
+class MultiFakeQuantWeight(Function):
+    """FakeQuantWeight for several weight tensors in ONE launch (cdn_codenet_weight_prep_multi): meta is a tuple of
+    (bits, percentile) per tensor; returns the fake-quantised tensors (bit-identical to FakeQuantWeight on each);
+    straight-through backward."""
+
+    @staticmethod
+    def forward(ctx, meta, *ws):
+        import ctypes
+        n = len(ws)
+        ws = [w.contiguous() for w in ws]
+        outs = [torch.empty_like(w) for w in ws]
+        co = [w.shape[0] for w in ws]
+        kk = [w.numel() // w.shape[0] for w in ws]
+        ranks = [weight_range_ranks(k, bool(m[1])) for k, m in zip(kk, meta)]
+        P, I64, I, F = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n, ctypes.c_float * n
+        rc = N_.lib().cdn_codenet_weight_prep_multi(
+            n, P(*[w.data_ptr() for w in ws]), I64(*co), I64(*kk), I(*[int(m[0]) for m in meta]),
+            I(*[r[0] for r in ranks]), I(*[r[1] for r in ranks]), F(*[r[2] for r in ranks]),
+            P(*[o.data_ptr() for o in outs]), ops._stream(ws[0]))
+        N_.check(rc, "cdn_codenet_weight_prep_multi")
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return (None,) + tuple(gs)
+
+
+# A/B switch (tools/train_step_bench.py --no-multi-prep)
+MULTI_WEIGHT_PREP = True
+
+
+def small_weights_of_stages(stages):
+    """The fake-quantised conv_scale and depthwise weights of all `stages` from one launch: a list of (w_scale_q, w_dw_q)
+    per stage, or None where a quantiser is not on the device weight-prep path (the modules then prepare their own)."""
+    qs = []
+    for q in stages:
+        for m in (q.quant_conv_scale, q.quant_deform_conv):
+            if m.full_precision_flag or not native_weight_prep_ok(m.weight, m):
+                return None
+            qs.append(m)
+    if not MULTI_WEIGHT_PREP or not qs or len(qs) > 8:
+        return None
+    outs = MultiFakeQuantWeight.apply(tuple((m.weight_bit, m.weight_percentile) for m in qs), *[m.weight for m in qs])
+    return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(stages))]
+
+
 class FoldFakeQuantWeight(Function):
     """QuantBnConv2d's weight path in one launch: BN fold from the running statistics, then per-channel symmetric
     fake-quantisation; returns (w_q, folded fp32 bias).  Backward = autograd of the reference's composition
@@ -420,8 +466,11 @@ def forward_stage_blocks(seq, x):
                 return seq(x)
     lib = N_.lib()
     x_up = False
+    pre = small_weights_of_stages([mods[i] for i in range(0, len(mods), 3)]) if all(
+        mods[i]._train_path_ok(x) for i in range(0, len(mods), 3)) else None
     for i in range(0, len(mods), 3):
-        y = mods[i](x, want_range=True, x_up=x_up)         # (y, {min, max} pairs of y) on the native training path
+        # (y, {min, max} pairs of y) on the native training path; the small weights of all stages from one launch
+        y = mods[i](x, want_range=True, x_up=x_up, pre_w=pre[i // 3] if pre is not None else None)
         y, part = y if isinstance(y, tuple) else (y, None)
         nxt = mods[i + 3] if i + 3 < len(mods) else None
         # the next stage reads its input through the up-sampling (stored tensor, never materialised) where its gather

@@ -466,8 +466,10 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
                 and tuple(pw.kernel_size) == (1, 1) and pw.groups == 1 and tuple(pw.stride) == (1, 1)
                 and native_act_ok(self.quant_act[1]) and native_act_ok(self.quant_identity_deform))
 
-    def forward(self, x, want_range=False, x_up=False):
-        """want_range (functions/codenet_stage.forward_stage_blocks only): on the native training path return
+    def forward(self, x, want_range=False, x_up=False, pre_w=None):
+        """pre_w (forward_stage_blocks only): (w_scale_q, w_dw_q) already fake-quantised -- with the other stages' in
+        one launch -- for the native training path.
+        want_range (functions/codenet_stage.forward_stage_blocks only): on the native training path return
         (y, per-workgroup {min, max} pairs of y) for the QuantAct of the block behind the stage.  x_up (the same caller,
         training path only): x is the STORED tensor whose nearest x2 up-sampling is the stage's input."""
         if x_up and not self._train_path_ok(x):
@@ -488,8 +490,9 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
             bound = self.quant_act[0]
             cb = self.quant_conv_channel_bn
             w, b = cb.folded()
-            return codenet_stage(x, self.quant_conv_scale.quantized_weight(), self.quant_conv_scale.bias,
-                                 self.quant_deform_conv.quantized_weight(), w, b, bound.min_val, bound.max_val,
+            w_sc, w_dw = pre_w if pre_w is not None else (self.quant_conv_scale.quantized_weight(),
+                                                          self.quant_deform_conv.quantized_weight())
+            return codenet_stage(x, w_sc, self.quant_conv_scale.bias, w_dw, w, b, bound.min_val, bound.max_val,
                                  self.quant_act[1], self.quant_identity_deform, want_range, x_up,
                                  cb._int8_ok(cb.conv.kernel_size, cb.conv.groups))
         s = self.quant_act(self.quant_conv_scale(x))

@@ -40,7 +40,11 @@ def main():
     ap.add_argument("--no-bf16-dgrad", action="store_true", help="A/B: the data gradient of conv_channel on f32 MFMA "
                     "instead of the exact bf16 x 3 split (pwb3n_kernel)")
     ap.add_argument("--no-bf16-wgrad", action="store_true", help="A/B: the weight gradient of conv_channel on f32 MFMA")
+    ap.add_argument("--no-multi-prep", action="store_true", help="A/B: one weight-prep launch per small weight tensor")
     a = ap.parse_args()
+    if a.no_multi_prep:
+        from codenet_amd.functions import codenet_stage as _cs4
+        _cs4.MULTI_WEIGHT_PREP = False
     if a.no_bf16_wgrad:
         from codenet_amd.functions import codenet_stage as _cs3
         _cs3.WGRAD_BF16X3 = False
