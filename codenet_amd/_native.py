@@ -45,7 +45,7 @@ _SIGNATURES = {
     "cdn_codenet_scale_backward_masked": (_i, [_vp] * 3 + [_f, _f] + [_vp] * 3 + [_i64] * 4 + [_vp]),
     "cdn_codenet_weight_prep_backward": (_i, [_vp] * 7 + [_i64, _i64] + [_vp] * 5),
     "cdn_codenet_weight_prep": (_i, [_vp, _i64, _i64] + [_vp] * 4 + [_i] + [_vp] * 3),
-    "cdn_codenet_weight_prep_multi": (_i, [_i] + [_vp] * 9),
+    "cdn_codenet_weight_prep_multi": (_i, [_i] + [_vp] * 14),
     "cdn_codenet_weight_prep_ranked": (_i, [_vp, _i64, _i64] + [_vp] * 4 + [_i, _i, _i, _f] + [_vp] * 3),
     "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_stage_fused_supported": (_i, [_i64] * 4 + [_i, _i]),

@@ -658,13 +658,14 @@ weight_prep_kernel(const float *__restrict__ w, int Co, int K, const float *__re
   weight_prep_rows((int)blockIdx.x, w, Co, K, sf_in, bn_b, bn_mean, conv_bias, nlev, wq, b_out, k_low, k_high, shrink);
 }
 
-// Several plain (no BN fold) weight tensors in ONE launch (round 5: the conv_scale and depthwise weights of all three
-// stages of a QAT step -- six launches of ~4.4 us, each at its launch floor): the workgroups are dealt out tensor by
-// tensor, every row is prepared exactly as by weight_prep_kernel.
+// Several weight tensors in ONE launch (round 5: the conv_scale and depthwise weights of all three stages of a QAT step,
+// and their three BN-folded pointwise weights -- launches of ~4.4 us, each at its launch floor): the workgroups are dealt
+// out tensor by tensor, every row is prepared exactly as by weight_prep_kernel.
 constexpr int kPrepMulti = 8;
 struct PrepMulti {
   const float *w[kPrepMulti];
-  float *wq[kPrepMulti];
+  const float *sf[kPrepMulti], *bn_b[kPrepMulti], *bn_mean[kPrepMulti], *conv_bias[kPrepMulti];      // BN fold (sf NULL: none)
+  float *wq[kPrepMulti], *b_out[kPrepMulti];
   int Co[kPrepMulti], K[kPrepMulti], k_low[kPrepMulti], k_high[kPrepMulti], first_block[kPrepMulti + 1];
   float nlev[kPrepMulti], shrink[kPrepMulti];
   int n;
@@ -673,8 +674,8 @@ __global__ void __launch_bounds__(256)
 weight_prep_multi_kernel(PrepMulti d) {
   int t = 0;
   while (t + 1 < d.n && (int)blockIdx.x >= d.first_block[t + 1]) ++t;
-  weight_prep_rows((int)blockIdx.x - d.first_block[t], d.w[t], d.Co[t], d.K[t], nullptr, nullptr, nullptr, nullptr,
-                   d.nlev[t], d.wq[t], nullptr, d.k_low[t], d.k_high[t], d.shrink[t]);
+  weight_prep_rows((int)blockIdx.x - d.first_block[t], d.w[t], d.Co[t], d.K[t], d.sf[t], d.bn_b[t], d.bn_mean[t],
+                   d.conv_bias[t], d.nlev[t], d.wq[t], d.b_out[t], d.k_low[t], d.k_high[t], d.shrink[t]);
 }
 
 }  // namespace
@@ -748,8 +749,10 @@ static int weight_prep_impl(const float *w, int64_t Co, int64_t K, const float *
 }
 
 extern "C" int cdn_codenet_weight_prep_multi(int n, const float *const *w, const int64_t *Co, const int64_t *K,
-                                             const int *bits, const int *k_low, const int *k_high, const float *shrink,
-                                             float *const *w_q, void *stream) {
+                                             const float *const *scale_factor, const float *const *bn_bias,
+                                             const float *const *bn_mean, const float *const *conv_bias, const int *bits,
+                                             const int *k_low, const int *k_high, const float *shrink,
+                                             float *const *w_q, float *const *bias_out, void *stream) {
   CDN_REQUIRE(n >= 1 && n <= kPrepMulti, CDN_ERR_ARG, "1 .. %d tensors per call", kPrepMulti);
   CDN_REQUIRE(w && Co && K && bits && k_low && k_high && shrink && w_q, CDN_ERR_ARG, "null pointer");
   PrepMulti d;
@@ -761,6 +764,13 @@ extern "C" int cdn_codenet_weight_prep_multi(int n, const float *const *w, const
     CDN_REQUIRE(k_low[t] <= K[t] && k_high[t] <= K[t], CDN_ERR_ARG, "k_low / k_high must be in [1, K]");
     CDN_REQUIRE(k_low[t] >= 1 && k_high[t] >= 1 && k_low[t] <= kPctMax && k_high[t] <= kPctMax, CDN_ERR_UNSUPPORTED,
                 "ranks of 1 .. %d", kPctMax);
+    d.sf[t] = scale_factor ? scale_factor[t] : nullptr;
+    d.bn_b[t] = (d.sf[t] && bn_bias) ? bn_bias[t] : nullptr;
+    d.bn_mean[t] = (d.sf[t] && bn_mean) ? bn_mean[t] : nullptr;
+    d.conv_bias[t] = (d.sf[t] && conv_bias) ? conv_bias[t] : nullptr;
+    d.b_out[t] = (d.sf[t] && bias_out) ? bias_out[t] : nullptr;
+    CDN_REQUIRE(!d.sf[t] || (d.bn_b[t] && d.bn_mean[t] && d.b_out[t]), CDN_ERR_ARG,
+                "the BN fold needs scale_factor, bias, running_mean and bias_out together (tensor %d)", t);
     d.w[t] = w[t];
     d.wq[t] = w_q[t];
     d.Co[t] = (int)Co[t];

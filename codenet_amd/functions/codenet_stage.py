@@ -264,15 +264,107 @@ class MultiFakeQuantWeight(Function):
         ranks = [weight_range_ranks(k, bool(m[1])) for k, m in zip(kk, meta)]
         P, I64, I, F = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n, ctypes.c_float * n
         rc = N_.lib().cdn_codenet_weight_prep_multi(
-            n, P(*[w.data_ptr() for w in ws]), I64(*co), I64(*kk), I(*[int(m[0]) for m in meta]),
+            n, P(*[w.data_ptr() for w in ws]), I64(*co), I64(*kk), None, None, None, None, I(*[int(m[0]) for m in meta]),
             I(*[r[0] for r in ranks]), I(*[r[1] for r in ranks]), F(*[r[2] for r in ranks]),
-            P(*[o.data_ptr() for o in outs]), ops._stream(ws[0]))
+            P(*[o.data_ptr() for o in outs]), None, ops._stream(ws[0]))
         N_.check(rc, "cdn_codenet_weight_prep_multi")
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gs):
         return (None,) + tuple(gs)
+
+
+class MultiFoldFakeQuantWeight(Function):
+    """FoldFakeQuantWeight for several QuantBnConv2d weights in ONE launch: flat = (w, conv_bias or None, gamma, beta,
+    running_mean, running_var) per tensor, meta = (bits, percentile, eps) per tensor; returns (w_q_0, b_0, w_q_1, b_1, ...).
+    The per-channel factors come from the framework's own add / sqrt / div (their foreach forms: one launch each for all
+    tensors); backward per tensor as FoldFakeQuantWeight's."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        import ctypes
+        n = len(meta)
+        ws = [flat[6 * t].contiguous() for t in range(n)]
+        cbs = [flat[6 * t + 1] for t in range(n)]
+        gam = [flat[6 * t + 2] for t in range(n)]
+        bet = [flat[6 * t + 3].contiguous() for t in range(n)]
+        mea = [flat[6 * t + 4].contiguous() for t in range(n)]
+        var = [flat[6 * t + 5] for t in range(n)]
+        stds = torch._foreach_sqrt(torch._foreach_add(var, [float(m[2]) for m in meta]))
+        sfs = [t_.contiguous() for t_ in torch._foreach_div(gam, stds)]
+        outs = [torch.empty_like(w) for w in ws]
+        bs = [torch.empty(w.shape[0], device=w.device) for w in ws]
+        co = [w.shape[0] for w in ws]
+        kk = [w.numel() // w.shape[0] for w in ws]
+        ranks = [weight_range_ranks(k, bool(m[1])) for k, m in zip(kk, meta)]
+        P, I64, I, F = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n, ctypes.c_float * n
+        cbp = [c.contiguous() if c is not None else None for c in cbs]
+        rc = N_.lib().cdn_codenet_weight_prep_multi(
+            n, P(*[w.data_ptr() for w in ws]), I64(*co), I64(*kk), P(*[t_.data_ptr() for t_ in sfs]),
+            P(*[t_.data_ptr() for t_ in bet]), P(*[t_.data_ptr() for t_ in mea]),
+            P(*[c.data_ptr() if c is not None else None for c in cbp]), I(*[int(m[0]) for m in meta]),
+            I(*[r[0] for r in ranks]), I(*[r[1] for r in ranks]), F(*[r[2] for r in ranks]),
+            P(*[o.data_ptr() for o in outs]), P(*[b.data_ptr() for b in bs]), ops._stream(ws[0]))
+        N_.check(rc, "cdn_codenet_weight_prep_multi")
+        ctx.n = n
+        ctx.has_cb = [c is not None for c in cbs]
+        saved = []
+        for t in range(n):
+            saved += [ws[t], sfs[t], stds[t], mea[t]] + ([cbp[t]] if cbp[t] is not None else [])
+        ctx.save_for_backward(*saved)
+        res = []
+        for t in range(n):
+            res += [outs[t], bs[t]]
+        return tuple(res)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        saved = list(ctx.saved_tensors)
+        need = ctx.needs_input_grad
+        grads = [None]
+        for t in range(ctx.n):
+            w, sf, std, mean = saved[:4]
+            saved = saved[4:]
+            cb = None
+            if ctx.has_cb[t]:
+                cb, saved = saved[0], saved[1:]
+            g_wq, g_b = gs[2 * t], gs[2 * t + 1]
+            nd = need[1 + 6 * t: 7 + 6 * t]
+            co = w.shape[0]
+            if g_wq is None and g_b is None:
+                grads += [None] * 6
+                continue
+            if g_wq is None:
+                g_wq = torch.zeros_like(w)
+            new = lambda *sh: torch.empty(*sh, device=w.device)      # noqa: E731
+            g_w = torch.empty_like(w) if nd[0] else None
+            g_gamma = new(co) if nd[2] else None
+            g_beta = new(co) if nd[3] else None
+            g_cb = new(co) if (cb is not None and nd[1]) else None
+            rc = N_.lib().cdn_codenet_weight_prep_backward(
+                _p(g_wq.contiguous()), _p(g_b.contiguous()) if g_b is not None else None, _p(w), _p(sf), _p(std), _p(mean),
+                _p(cb), co, w.numel() // co, _p(g_w), _p(g_gamma), _p(g_beta), _p(g_cb), ops._stream(w))
+            N_.check(rc, "cdn_codenet_weight_prep_backward")
+            grads += [g_w, g_cb, g_gamma, g_beta, None, None]
+        return tuple(grads)
+
+
+def folded_weights_of_stages(stages):
+    """(w_q, folded bias) of every stage's conv_channel + BN from one launch (plus three foreach launches for the
+    per-channel factors), or None where a layer is not on the device weight-prep path."""
+    cbs = [q.quant_conv_channel_bn for q in stages]
+    if not MULTI_WEIGHT_PREP or not cbs or len(cbs) > 8:
+        return None
+    for cb in cbs:
+        if cb.full_precision_flag or not native_weight_prep_ok(cb.conv.weight, cb):
+            return None
+    flat = []
+    for cb in cbs:
+        flat += [cb.conv.weight, cb.conv.bias, cb.bn.weight, cb.bn.bias, cb.bn.running_mean, cb.bn.running_var]
+    outs = MultiFoldFakeQuantWeight.apply(tuple((cb.weight_bit, cb.weight_percentile, cb.bn.eps) for cb in cbs), *flat)
+    return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(cbs))]
 
 
 # A/B switch (tools/train_step_bench.py --no-multi-prep)
@@ -466,11 +558,14 @@ def forward_stage_blocks(seq, x):
                 return seq(x)
     lib = N_.lib()
     x_up = False
-    pre = small_weights_of_stages([mods[i] for i in range(0, len(mods), 3)]) if all(
-        mods[i]._train_path_ok(x) for i in range(0, len(mods), 3)) else None
+    pre = pre_pw = None
+    if all(mods[i]._train_path_ok(x) for i in range(0, len(mods), 3)):
+        stages = [mods[i] for i in range(0, len(mods), 3)]
+        pre, pre_pw = small_weights_of_stages(stages), folded_weights_of_stages(stages)
     for i in range(0, len(mods), 3):
-        # (y, {min, max} pairs of y) on the native training path; the small weights of all stages from one launch
-        y = mods[i](x, want_range=True, x_up=x_up, pre_w=pre[i // 3] if pre is not None else None)
+        # (y, {min, max} pairs of y) on the native training path; the weights of all stages from two launches
+        pw = (pre[i // 3] if pre is not None else (None, None)) + (pre_pw[i // 3] if pre_pw is not None else (None, None))
+        y = mods[i](x, want_range=True, x_up=x_up, pre_w=pw)
         y, part = y if isinstance(y, tuple) else (y, None)
         nxt = mods[i + 3] if i + 3 < len(mods) else None
         # the next stage reads its input through the up-sampling (stored tensor, never materialised) where its gather

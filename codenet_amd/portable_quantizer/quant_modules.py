@@ -467,8 +467,8 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
                 and native_act_ok(self.quant_act[1]) and native_act_ok(self.quant_identity_deform))
 
     def forward(self, x, want_range=False, x_up=False, pre_w=None):
-        """pre_w (forward_stage_blocks only): (w_scale_q, w_dw_q) already fake-quantised -- with the other stages' in
-        one launch -- for the native training path.
+        """pre_w (forward_stage_blocks only): (w_scale_q, w_dw_q, w_pw_q, b_pw) already prepared -- with the other stages'
+        in one launch each -- for the native training path; None entries are prepared here.
         want_range (functions/codenet_stage.forward_stage_blocks only): on the native training path return
         (y, per-workgroup {min, max} pairs of y) for the QuantAct of the block behind the stage.  x_up (the same caller,
         training path only): x is the STORED tensor whose nearest x2 up-sampling is the stage's input."""
@@ -489,9 +489,10 @@ class QuantDeformConvWithOffsetScaleBoundPositive(Module):
             from ..functions.codenet_stage import codenet_stage
             bound = self.quant_act[0]
             cb = self.quant_conv_channel_bn
-            w, b = cb.folded()
-            w_sc, w_dw = pre_w if pre_w is not None else (self.quant_conv_scale.quantized_weight(),
-                                                          self.quant_deform_conv.quantized_weight())
+            pre_w = pre_w if pre_w is not None else (None, None, None, None)
+            w, b = (pre_w[2], pre_w[3]) if pre_w[2] is not None else cb.folded()
+            w_sc = pre_w[0] if pre_w[0] is not None else self.quant_conv_scale.quantized_weight()
+            w_dw = pre_w[1] if pre_w[1] is not None else self.quant_deform_conv.quantized_weight()
             return codenet_stage(x, w_sc, self.quant_conv_scale.bias, w_dw, w, b, bound.min_val, bound.max_val,
                                  self.quant_act[1], self.quant_identity_deform, want_range, x_up,
                                  cb._int8_ok(cb.conv.kernel_size, cb.conv.groups))

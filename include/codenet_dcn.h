@@ -245,12 +245,16 @@ int cdn_quantact_relu_up2_forward_partials(const float *y, float *out, int64_t p
 int cdn_codenet_weight_prep_ranked(const float *w, int64_t Co, int64_t K, const float *scale_factor, const float *bn_bias,
                                    const float *bn_mean, const float *conv_bias, int bits, int k_low, int k_high,
                                    float shrink, float *w_q, float *bias_out, void *stream);
-/* cdn_codenet_weight_prep_ranked (no BN fold) for up to 8 tensors in ONE launch (round 5: the conv_scale and depthwise
- * weights of the three stages of a QAT step -- six launches at their launch floor): host arrays of n entries, every row
- * prepared exactly as by the single-tensor call (bit-identical). */
-int cdn_codenet_weight_prep_multi(int n, const float *const *w, const int64_t *Co, const int64_t *K, const int *bits,
+/* cdn_codenet_weight_prep_ranked for up to 8 tensors in ONE launch (round 5: the conv_scale and depthwise weights of the
+ * three stages of a QAT step, and their three BN-folded pointwise weights -- launches at their launch floor): host
+ * arrays of n entries; scale_factor / bn_bias / bn_mean / conv_bias / bias_out are arrays of pointers (or NULL arrays),
+ * entry t of scale_factor NULL = no BN fold for tensor t.  Every row is prepared exactly as by the single-tensor call
+ * (bit-identical). */
+int cdn_codenet_weight_prep_multi(int n, const float *const *w, const int64_t *Co, const int64_t *K,
+                                  const float *const *scale_factor, const float *const *bn_bias,
+                                  const float *const *bn_mean, const float *const *conv_bias, const int *bits,
                                   const int *k_low, const int *k_high, const float *shrink, float *const *w_q,
-                                  void *stream);
+                                  float *const *bias_out, void *stream);
 /* Backward of the BN fold of cdn_codenet_weight_prep under the straight-through weight quantiser
  * (SymmetricQuantFunction.backward, quant_utils.py:227-229; autograd of quant_modules.py:365-372) in one launch:
  *   grad_w = grad_wq * scale_factor,  grad_gamma = (sum_k grad_wq * w + grad_bias * (conv_bias - mean)) / bn_std,
