@@ -547,3 +547,43 @@ def test_asm_load_checker_finds_a_read_before_the_wait(tmp_path):
     if os.path.exists(shipped):
         nbad, nloads = C.check(shipped, "pwi8s_kernel", verbose=False)
         assert nbad == 0 and nloads >= 12
+
+
+def test_argument_validation_of_the_round5_training_entry_points_without_gpu():
+    """The integer-form 1x1-convolution entry points of the QAT step and the multi-tensor weight prep validate before any
+    HIP call; the plan functions are pure host arithmetic."""
+    import ctypes
+    from codenet_amd import _native
+    lib = _native.lib()
+    one = 4096
+    # shapes: C % 32 == 0, HW % 32 == 0, Co <= 512
+    assert lib.cdn_codenet_pointwise_i8_supported(32, 1024, 256, 256) == 1
+    assert lib.cdn_codenet_pointwise_i8_supported(32, 1000, 256, 256) == 0
+    assert lib.cdn_codenet_pointwise_i8_supported(32, 1024, 256, 100) == 0
+    assert lib.cdn_codenet_pointwise_i8_supported(32, 1024, 600, 256) == 0
+    need = lib.cdn_codenet_pointwise_i8_workspace_bytes(32, 1024, 256, 256)
+    # k-blocked int8 codes + scales + sums + the transposed bf16 codes + reciprocal scales, each 256-byte aligned
+    assert need >= 1024 * 256 + 2 * 256 * 4 + 16 * 1024 * 32 + 256 * 4 and need % 256 == 0
+    assert lib.cdn_codenet_pointwise_i8_workspace_bytes(32, 1000, 256, 256) == 0
+    # stage 0 splits K over the four waves of a workgroup (one workgroup per pixel block and column group), stage 2 not
+    assert lib.cdn_codenet_pointwise_i8_range_partials(32, 1024, 256, 256) == 32 * (256 // 32) * 2
+    assert lib.cdn_codenet_pointwise_i8_range_partials(32, 128, 64, 4096) == 32 * (4096 // 32 // 4)
+    rc = lib.cdn_codenet_pointwise_i8_forward_range(one, None, one, None, one, 32, 1024, 256, 256, None, one, need, None)
+    assert rc == -1                                              # no QuantAct state
+    rc = lib.cdn_codenet_pointwise_i8_forward_range(one, one, one, None, one, 32, 1000, 256, 256, None, 4096, need, None)
+    assert rc != 0 and b"C % 32" in lib.cdn_last_error()
+    rc = lib.cdn_codenet_pointwise_i8_forward_range(one, one, one, None, one, 32, 1024, 256, 256, None, 4096, 16, None)
+    assert rc != 0 and b"workspace" in lib.cdn_last_error()
+    assert lib.cdn_codenet_pointwise_dgrad_q4_supported(32, 1024, 256, 256) == 1
+    assert lib.cdn_codenet_pointwise_dgrad_q4(one, None, one, 32, 1024, 256, 256, None) == -1
+    # multi-tensor weight prep: 1 .. 8 tensors, a BN fold needs its four companions
+    P, I64, I, F = ctypes.c_void_p * 1, ctypes.c_int64 * 1, ctypes.c_int * 1, ctypes.c_float * 1
+    args = (P(one), I64(8), I64(16))
+    tail = (I(4), I(1), I(1), F(1.0), P(one))
+    assert lib.cdn_codenet_weight_prep_multi(0, *args, None, None, None, None, *tail, None, None) == -1
+    assert lib.cdn_codenet_weight_prep_multi(9, *args, None, None, None, None, *tail, None, None) == -1
+    rc = lib.cdn_codenet_weight_prep_multi(1, *args, P(one), None, None, None, *tail, None, None)
+    assert rc == -1 and b"BN fold" in lib.cdn_last_error()
+    rc = lib.cdn_codenet_weight_prep_multi(1, P(one), I64(8), I64(16), None, None, None, None, I(9), I(1), I(1), F(1.0), P(one),
+                                           None, None)
+    assert rc == -1 and b"bits" in lib.cdn_last_error()
