@@ -620,6 +620,10 @@ class FusedHotPath:
         x = x.contiguous()
         if nhwc_in:
             x = x.view(x.shape[0], hw[0], hw[1], x.shape[2]).permute(0, 3, 1, 2)   # logical NCHW view
+        op0 = self.stages[0][0]
+        c0 = op0.quant_deform_conv.in_channels if self.quantized else op0.in_channels
+        if x.shape[1] != c0:      # (the kernels take the channel count from the modules: a mismatch would read out of bounds)
+            raise RuntimeError("FusedHotPath: the input has %d channels, stage 0 expects %d" % (x.shape[1], c0))
         if self._bufs is None or self._bufs["shape"] != tuple(x.shape) or self._bufs["dev"] != x.device:
             self._alloc(x)
         B = self._bufs
@@ -814,6 +818,8 @@ class FrozenHotPath:
             x = xf.view(x.shape[0], hw[0], hw[1], x.shape[2])[..., :c0].permute(0, 3, 1, 2).contiguous()
             codes_in, nhwc_in, x_qstate, hw = False, False, None, None
         shape = (x.shape[0], x.shape[2], hw[0], hw[1]) if nhwc_in else tuple(x.shape)
+        if shape[1] != c0:        # (the kernels take the channel count from the modules: a mismatch would read out of bounds)
+            raise RuntimeError("FrozenHotPath: the input has %d channels, stage 0 expects %d" % (shape[1], c0))
         dev = x.device
         # the cached pointer arrays name the QuantActs' range buffers: a re-assigned buffer (load_state_dict(assign=
         # True), a .to() round trip) must rebuild them, so their addresses are part of the key

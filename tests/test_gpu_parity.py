@@ -1077,3 +1077,20 @@ def test_streaming_int8_pointwise_is_bit_identical_to_the_tile_kernel(planes, hw
     x[1, 3, 2, 2] = float("nan")
     ya, yb = fa(x), fb(x)
     assert torch.equal(torch.isnan(ya), torch.isnan(yb))
+
+
+@pytest.mark.gpu
+def test_fused_hot_path_refuses_an_input_with_the_wrong_channel_count():
+    """The fused schedules take the channel count from the modules; an input of another width must raise instead of
+    letting the kernels read out of bounds (found by a soak script that fed CoDeNet1x inputs to CoDeNet2x stages: a GPU
+    memory fault)."""
+    from codenet_amd import pipeline
+    net = pipeline.build_hot_path(quantized=True, planes=[96, 32, 16]).cuda().eval()
+    fused = pipeline.FusedHotPath(net.deconv_layers)
+    with pytest.raises(RuntimeError, match="channels"):
+        fused(torch.randn(2, 64, 8, 8).cuda())
+    pipeline.set_running_stat(net, False)
+    frozen = pipeline.FrozenHotPath(net.deconv_layers)
+    with pytest.raises(RuntimeError, match="channels"):
+        frozen.forward_codes(torch.randn(2, 64, 8, 8).cuda())
+    assert fused(torch.randn(2, 96, 8, 8).cuda()).shape == (2, 16, 32, 32)
