@@ -63,6 +63,9 @@ _SIGNATURES = {
     "cdn_codenet_dwpw_q8_forward": (
         _i, [_vp, _vp] + [_i64] * 4 + [_i, _i64, _vp, _vp, _i, _vp, _i64] + [_vp] * 4 + [_i, _i64] + [_vp] * 5),
     "cdn_codenet_dw_backward": (_i, [_vp] * 7 + [_i64] * 4 + [_vp]),
+    "cdn_codenet_dw_backward_workspace_bytes": (ctypes.c_size_t, [_i64] * 4 + [_i]),
+    "cdn_codenet_dw_backward_r": (_i, [_vp] * 7 + [_i64] * 4 + [_vp, _vp]),
+    "cdn_codenet_dw_up2_backward_r": (_i, [_vp] * 7 + [_i64] * 4 + [_vp, _vp]),
     "cdn_codenet_pointwise_forward": (_i, [_vp] * 6 + [_i64] * 4 + [_i, _vp]),
     "cdn_quantact_state_bytes": (ctypes.c_size_t, []),
     "cdn_kth_values_workspace_bytes": (ctypes.c_size_t, []),

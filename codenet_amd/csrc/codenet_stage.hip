@@ -490,7 +490,7 @@ template <int CCH>
 __global__ void __launch_bounds__(1024)
 dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
                const float *__restrict__ wd, const float *__restrict__ gd, float *__restrict__ gx,
-               float *__restrict__ gs, float *__restrict__ gw, int C, int H, int W) {
+               float *__restrict__ gs, float *__restrict__ gw, int C, int H, int W, long gs_chunk_stride) {
   extern __shared__ unsigned long long smem64[];
   constexpr int PPW = 64 / CCH;                  // pixels per wave step
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
@@ -662,7 +662,10 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
     if (gs != nullptr) {
 #pragma unroll
       for (int m = CCH / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
-      if (cl == 0 && live) atomicAdd(&gs[(long)n * HW + R.p], gs_acc);
+      if (cl == 0 && live) {
+        if (gs_chunk_stride) gs[(long)blockIdx.x * gs_chunk_stride + (long)n * HW + R.p] = gs_acc;
+        else atomicAdd(&gs[(long)n * HW + R.p], gs_acc);
+      }
     }
   };
   if (CCH == 16 || CCH == 8) {
@@ -695,7 +698,23 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   } else {
     for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) step(geometry(p0 + sub));
   }
-  if (gw != nullptr && ch_ok) {
+  if (gw != nullptr && gs_chunk_stride) {
+    // reproducible: lanes of one channel by a shuffle tree, waves in wave order (gww: LDS the host adds for this form)
+    float *gww = red + 32;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float v = ch_ok ? gwa[k] : 0.0f;
+#pragma unroll
+      for (int m = CCH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (lane < CCH) gww[(wave * CCH + cl) * 9 + k] = v;
+    }
+    __syncthreads();
+    for (int q = tid; q < CCH * 9; q += nthreads) {
+      float v = 0.0f;
+      for (int wv = 0; wv < nwaves; ++wv) v += gww[wv * CCH * 9 + q];
+      gwl[q] = v;
+    }
+  } else if (gw != nullptr && ch_ok) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);   // 9 per lane, once
   }
@@ -728,7 +747,10 @@ dw_bwd2_kernel(const float *__restrict__ x, const float *__restrict__ s,
   }
   if (gw != nullptr)
     for (int q = tid; q < CCH * 9; q += nthreads)
-      if (c0 + q / 9 < C) atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+      if (c0 + q / 9 < C) {
+        if (gs_chunk_stride) gw[(long)n * C * 9 + (long)c0 * 9 + q] = gwl[q];
+        else atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+      }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -779,7 +801,11 @@ template <int CCH, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
                 const float *__restrict__ gd, float *__restrict__ gx, float *__restrict__ gs,
-                float *__restrict__ gw, int C, int H, int W) {
+                float *__restrict__ gw, int C, int H, int W, long gs_chunk_stride) {
+  // gs_chunk_stride != 0 (round 5, the REPRODUCIBLE form): grad_s and grad_w leave the kernel as per-workgroup partials --
+  // gs[chunk * stride + n * HWs + p] and gw[n * C * 9 + ...], plain stores, every element exactly once -- and a
+  // fixed-order reduction follows (dw_bwd_reduce_kernel); the per-channel sums over a workgroup's lanes and waves are a
+  // shuffle tree and a wave-ordered loop instead of float atomics.  0: float atomics into zero-filled gs / gw.
   extern __shared__ unsigned long long smem64[];
   constexpr int PPW = 64 / CCH;                  // 2x2 blocks per wave step
   const int nthreads = blockDim.x, nwaves = nthreads / 64;
@@ -986,10 +1012,29 @@ dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const 
     if (gs != nullptr) {
 #pragma unroll
       for (int m = CCH / 2; m > 0; m >>= 1) gs_acc += __shfl_xor(gs_acc, m, 64);
-      if (cl == 0 && live) atomicAdd(&gs[(long)n * HWs + b], gs_acc);
+      if (cl == 0 && live) {
+        if (gs_chunk_stride) gs[(long)blockIdx.x * gs_chunk_stride + (long)n * HWs + b] = gs_acc;
+        else atomicAdd(&gs[(long)n * HWs + b], gs_acc);
+      }
     }
   }
-  if (gw != nullptr && ch_ok) {
+  if (gw != nullptr && gs_chunk_stride) {
+    // reproducible: lanes of one channel by a shuffle tree, waves in wave order (gww: LDS the host adds for this form)
+    float *gww = red + 32;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float v = ch_ok ? gwa[k] : 0.0f;
+#pragma unroll
+      for (int m = CCH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (lane < CCH) gww[(wave * CCH + cl) * 9 + k] = v;
+    }
+    __syncthreads();
+    for (int q = tid; q < CCH * 9; q += nthreads) {
+      float v = 0.0f;
+      for (int wv = 0; wv < nwaves; ++wv) v += gww[wv * CCH * 9 + q];
+      gwl[q] = v;
+    }
+  } else if (gw != nullptr && ch_ok) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);
   }
@@ -1019,7 +1064,10 @@ dw_bwd2u_kernel(const float *__restrict__ x, const float *__restrict__ s, const 
   }
   if (gw != nullptr)
     for (int q = tid; q < CCH * 9; q += nthreads)
-      if (c0 + q / 9 < C) atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+      if (c0 + q / 9 < C) {
+        if (gs_chunk_stride) gw[(long)n * C * 9 + (long)c0 * 9 + q] = gwl[q];
+        else atomicAdd(&gw[(long)c0 * 9 + q], gwl[q]);
+      }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1254,9 +1302,73 @@ extern "C" int cdn_codenet_dw_up2_forward(const float *x_stored, const float *s_
   return dw_up2_forward_impl(x_stored, s_stored, w_dw, d, N, C, H, W, partials, stream);
 }
 
-extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s_stored, const float *w_dw,
-                                           const float *grad_d, float *grad_x, float *grad_s, float *grad_w, int64_t N,
-                                           int64_t C, int64_t H, int64_t W, void *stream) {
+// fixed-order sums of the reproducible backward's partials: grad_s[n][p] over the channel chunks, grad_w[c][k] over the
+// images (four sums in flight, combined in one order)
+__global__ void __launch_bounds__(256)
+dw_bwd_reduce_kernel(const float *__restrict__ gs_part, float *__restrict__ gs, long ns, int chunks,
+                     const float *__restrict__ gw_part, float *__restrict__ gw, long nw, int N) {
+  const long sblocks = gs ? (ns + 255) / 256 : 0;
+  const bool second = (long)blockIdx.x >= sblocks;
+  const float *src = second ? gw_part : gs_part;
+  float *dst = second ? gw : gs;
+  const long len = second ? nw : ns;
+  const int terms = second ? N : chunks;
+  const long i = ((long)blockIdx.x - (second ? sblocks : 0)) * 256 + threadIdx.x;
+  if (i >= len) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = 0;
+  for (; z + 3 < terms; z += 4) {
+    s0 += src[(long)z * len + i];
+    s1 += src[(long)(z + 1) * len + i];
+    s2 += src[(long)(z + 2) * len + i];
+    s3 += src[(long)(z + 3) * len + i];
+  }
+  for (; z < terms; ++z) s0 += src[(long)z * len + i];
+  dst[i] = (s0 + s1) + (s2 + s3);
+}
+
+// channel chunk of the lanes <-> channels backward kernels (shared by the launchers and the workspace query)
+// (det: the reproducible form's per-wave weight-gradient sums, at most 16 waves x c x 9 floats more)
+static int bwd2u_cch(int64_t N, int64_t C, int64_t Hs, int64_t Ws, bool det) {
+  const size_t cells = (size_t)(Hs + 1) * (Ws + 1);
+  const size_t lds_max = 160 * 1024 - 512;
+  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 256 + (det ? (size_t)c * 16 * 36 : 0); };
+  int cch = 0;
+  for (int c : {32, 16, 8, 4, 2})
+    if (bwd_lds(c) <= lds_max) {
+      cch = c;
+      break;
+    }
+  if (cch == 0) return 0;
+#if defined(CDN_BWDU_CCH)
+  cch = CDN_BWDU_CCH;
+#else
+  if (cch >= 16 && bwd_lds(cch / 2) * 2 <= lds_max) cch /= 2;
+  while (cch > 4 && cdn::ceil_div(C, cch) * N < (long)cdn::kCUs) cch /= 2;
+#endif
+  return cch;
+}
+static int bwd2_cch(int64_t H, int64_t W, bool det) {
+  const size_t cells = (size_t)(H + 1) * (W + 1);
+  const size_t lds_max = 160 * 1024 - 512;
+  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 128 + (det ? (size_t)c * 16 * 36 : 0); };
+  int cch = 0;
+  for (int c : {32, 16, 8, 4, 2})
+    if (bwd_lds(c) <= lds_max) {
+      cch = c;
+      break;
+    }
+  if (cch >= 16 && bwd_lds(cch / 2) * 2 <= lds_max) cch /= 2;
+  return cch;
+}
+// workspace of the reproducible form: grad_s partials [chunks][N][plane] + grad_w partials [N][C][9]
+static size_t bwd_r_bytes(int64_t N, int64_t C, int64_t plane, int cch) {
+  return ((size_t)cdn::ceil_div(C, cch) * N * plane + (size_t)N * C * 9) * sizeof(float);
+}
+
+static int dw_up2_backward_impl(const float *x_stored, const float *s_stored, const float *w_dw,
+                                const float *grad_d, float *grad_x, float *grad_s, float *grad_w, int64_t N,
+                                int64_t C, int64_t H, int64_t W, void *stream, float *part) {
   CDN_REQUIRE(x_stored && s_stored && w_dw && grad_d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0, CDN_ERR_ARG, "bad size (even H, W)");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
@@ -1264,7 +1376,7 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
               CDN_ERR_ARG, "grad_d must be 8-byte, grad_x 16-byte aligned");
   hipStream_t st = cdn::as_stream(stream);
   const int64_t Hs = H / 2, Ws = W / 2;
-  if (grad_s) {
+  if (grad_s && !part) {
     // (grad_w directly behind grad_s: one fill for both -- a QAT step is made of launches this small)
     const size_t ns = (size_t)(N * Hs * Ws), extra = (grad_w == grad_s + ns) ? (size_t)C * 9 : 0;
     hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (ns + extra), st);
@@ -1273,22 +1385,11 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
   const size_t cells = (size_t)(Hs + 1) * (Ws + 1);
   const size_t lds_max = 160 * 1024 - 512;
   auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 256; };
-  int cch = 0;
-  for (int c : {32, 16, 8, 4, 2})
-    if (bwd_lds(c) <= lds_max) {
-      cch = c;
-      break;
-    }
-  CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident backward");
-#if defined(CDN_BWDU_CCH)
-  cch = CDN_BWDU_CCH;
-#else
   // two workgroups per CU when the halved chunk allows it (more waves hide the LDS atomics' latency), and enough
-  // workgroups to fill the chip
-  if (cch >= 16 && bwd_lds(cch / 2) * 2 <= lds_max) cch /= 2;
-  while (cch > 4 && cdn::ceil_div(C, cch) * N < (long)cdn::kCUs) cch /= 2;
-#endif
-  const size_t lds = bwd_lds(cch);
+  // workgroups to fill the chip (bwd2u_cch)
+  const int cch = bwd2u_cch(N, C, Hs, Ws, part != nullptr);
+  CDN_REQUIRE(cch != 0, CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident backward");
+  size_t lds = bwd_lds(cch);
   dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
   // The kernel wants ~170 VGPRs: three waves per SIMD = 12 waves per CU (capped at 128 VGPRs for 1024-thread workgroups
   // it spills 40+ of them: 131 / 220 us against 99 / 165 us at the two stage shapes, batch 32).  768 threads when only
@@ -1301,13 +1402,18 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
 #if defined(CDN_BWDU_THREADS)
   const int threads = CDN_BWDU_THREADS;
 #else
-  const int threads = lds_max / lds <= 1 ? 768 : 256;
+  const int threads = lds_max / (lds + (part ? (size_t)cch * 16 * 36 : 0)) <= 1 ? 768 : 256;
 #endif
+  // reproducible form: partials into the workspace, LDS for the per-wave weight-gradient sums
+  const long plane = (long)(Hs * Ws), stride = part ? (long)N * plane : 0;
+  float *gs_part = part, *gw_part = part ? part + (size_t)cdn::ceil_div(C, cch) * N * plane : nullptr;
+  if (part) lds += (size_t)(threads / 64) * cch * 9 * 4;
 #define CDN_BWDU(CCH_)                                                                                      \
   {                                                                                                         \
     auto kern = dw_bwd2u_kernel<CCH_, CDN_BWDU_MAXT>;                                                                    \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-    kern<<<grid, threads, lds, st>>>(x_stored, s_stored, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H, (int)W); \
+    kern<<<grid, threads, lds, st>>>(x_stored, s_stored, w_dw, grad_d, grad_x, part ? gs_part : grad_s,       \
+                                     part ? gw_part : grad_w, (int)C, (int)H, (int)W, stride);                \
   }
   switch (cch) {
     case 32: CDN_BWDU(32) break;
@@ -1317,7 +1423,19 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
     default: CDN_BWDU(2) break;
   }
 #undef CDN_BWDU
-  return cdn::check_launch("codenet dw backward (up-sampled input)");
+  int rc = cdn::check_launch("codenet dw backward (up-sampled input)");
+  if (rc || !part) return rc;
+  const long ns = grad_s ? (long)N * plane : 0, nw = grad_w ? (long)C * 9 : 0;
+  if (ns + nw == 0) return 0;
+  dw_bwd_reduce_kernel<<<(unsigned)(cdn::ceil_div(ns, 256) + cdn::ceil_div(nw, 256)), 256, 0, st>>>(
+      gs_part, grad_s, ns, (int)cdn::ceil_div(C, cch), gw_part, grad_w, nw, (int)N);
+  return cdn::check_launch("codenet dw backward reduce");
+}
+
+extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s_stored, const float *w_dw,
+                                           const float *grad_d, float *grad_x, float *grad_s, float *grad_w, int64_t N,
+                                           int64_t C, int64_t H, int64_t W, void *stream) {
+  return dw_up2_backward_impl(x_stored, s_stored, w_dw, grad_d, grad_x, grad_s, grad_w, N, C, H, W, stream, nullptr);
 }
 
 static int dw_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
@@ -1408,49 +1526,47 @@ extern "C" int cdn_codenet_dw_backward_supported(int64_t H, int64_t W) {
   return (150 * 1024 / 4 - 64) / (2 * (H + 2) * (W + 2) + 18) >= 1;                 // bordered-plane kernel
 }
 
-extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
-                                       const float *grad_d, float *grad_x, float *grad_s,
-                                       float *grad_w, int64_t N, int64_t C, int64_t H, int64_t W,
-                                       void *stream) {
+static int dw_backward_impl(const float *x, const float *s, const float *w_dw, const float *grad_d, float *grad_x,
+                            float *grad_s, float *grad_w, int64_t N, int64_t C, int64_t H, int64_t W, void *stream,
+                            float *part) {
   CDN_REQUIRE(x && s && w_dw && grad_d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   hipStream_t st = cdn::as_stream(stream);
-  if (grad_s) {
+  if (grad_s && !part) {
     // (grad_w directly behind grad_s: one fill for both -- a QAT step is made of launches this small)
     const size_t ns = (size_t)(N * H * W), extra = (grad_w == grad_s + ns) ? (size_t)C * 9 : 0;
     hipError_t e = hipMemsetAsync(grad_s, 0, sizeof(float) * (ns + extra), st);
     if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_s: %s", hipGetErrorString(e));
   }
-  // lanes <-> channels kernel: the largest channel chunk whose two LDS images fit
+  // lanes <-> channels kernel: the largest channel chunk whose two LDS images fit; half the chunk when that lets TWO
+  // 512-thread workgroups share a CU (16 x 16 planes: 16 channels, 55 KB each): 16 instead of 8 waves per CU hide more
+  // of the LDS-atomic latency (QAT step 2.397 -> 2.351 ms) (bwd2_cch)
   const size_t cells = (size_t)(H + 1) * (W + 1);
   const size_t lds_max = 160 * 1024 - 512;
-  int cch = 0;
-  auto bwd_lds = [&](int c) { return cells * c * 12 + (size_t)c * 9 * 4 + 128; };
-  for (int c : {32, 16, 8, 4, 2})
-    if (bwd_lds(c) <= lds_max) {
-      cch = c;
-      break;
-    }
-  // half the chunk when that lets TWO 512-thread workgroups share a CU (16 x 16 planes: 16 channels, 55 KB each):
-  // 16 instead of 8 waves per CU hide more of the LDS-atomic latency (QAT step 2.397 -> 2.351 ms)
-  if (cch >= 16 && bwd_lds(cch / 2) * 2 <= lds_max) cch /= 2;
+  const int cch = bwd2_cch(H, W, part != nullptr);
+  CDN_REQUIRE(cch != 0 || !part, CDN_ERR_UNSUPPORTED, "plane too large for the reproducible backward");
   if (cch != 0) {
-    const size_t lds = bwd_lds(cch);
+    const size_t det_lds = part ? (size_t)cch * 16 * 36 : 0;
+    const size_t lds0 = cells * cch * 12 + (size_t)cch * 9 * 4 + 128;
     dim3 grid((unsigned)cdn::ceil_div(C, cch), (unsigned)N);
     // one workgroup per CU (the images of a large plane fill LDS): 16 waves instead of 8 to hide the LDS atomics' latency
 #if defined(CDN_BWD_THREADS)
     const int bwd_threads = CDN_BWD_THREADS;
 #else
-    const int bwd_threads = bwd_lds(cch) * 2 <= lds_max ? 512 : 1024;
+    const int bwd_threads = (lds0 + det_lds) * 2 <= lds_max ? 512 : 1024;
 #endif
+    const size_t lds = lds0 + (part ? (size_t)(bwd_threads / 64) * cch * 36 : 0);
+    // reproducible form: partials into the workspace
+    const long plane = (long)(H * W), stride = part ? (long)N * plane : 0;
+    float *gs_part = part, *gw_part = part ? part + (size_t)cdn::ceil_div(C, cch) * N * plane : nullptr;
 #define CDN_BWD(CCH_)                                                                          \
   {                                                                                            \
     auto kern = dw_bwd2_kernel<CCH_>;                                                          \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                               (int)lds);                                                       \
-    kern<<<grid, bwd_threads, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C, (int)H,   \
-                                 (int)W);                                                      \
+    kern<<<grid, bwd_threads, lds, st>>>(x, s, w_dw, grad_d, grad_x, part ? gs_part : grad_s,  \
+                                         part ? gw_part : grad_w, (int)C, (int)H, (int)W, stride); \
   }
     switch (cch) {
       case 32: CDN_BWD(32) break;
@@ -1460,7 +1576,13 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
       default: CDN_BWD(2) break;
     }
 #undef CDN_BWD
-    return cdn::check_launch("codenet dw backward");
+    int rc = cdn::check_launch("codenet dw backward");
+    if (rc || !part) return rc;
+    const long ns = grad_s ? (long)N * plane : 0, nw = grad_w ? (long)C * 9 : 0;
+    if (ns + nw == 0) return 0;
+    dw_bwd_reduce_kernel<<<(unsigned)(cdn::ceil_div(ns, 256) + cdn::ceil_div(nw, 256)), 256, 0, st>>>(
+        gs_part, grad_s, ns, (int)cdn::ceil_div(C, cch), gw_part, grad_w, nw, (int)N);
+    return cdn::check_launch("codenet dw backward reduce");
   }
   // fallback for very large planes: lanes <-> pixels kernel with bordered planes
   const int pstride = (int)((H + 2) * (W + 2));
@@ -1478,4 +1600,43 @@ extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const flo
   dw_bwd_kernel<<<grid, kDwThreads, lds, st>>>(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, (int)C,
                                                (int)H, (int)W, CC);
   return cdn::check_launch("codenet dw backward");
+}
+
+extern "C" int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
+                                       const float *grad_d, float *grad_x, float *grad_s,
+                                       float *grad_w, int64_t N, int64_t C, int64_t H, int64_t W,
+                                       void *stream) {
+  return dw_backward_impl(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, N, C, H, W, stream, nullptr);
+}
+
+// ---- the REPRODUCIBLE gather backward (round 5) ----------------------------------------------------------------------
+// grad_s and grad_w_dw of the two entry points above are float atomics over the channel chunks / the images: equal inputs
+// give sums that differ in the last bits from run to run, and with them every parameter of a QAT run after a few steps.
+// The _r forms write per-workgroup partials into a caller workspace (every element exactly once, nothing to pre-zero)
+// and reduce them in a fixed order: bit-identical results for identical inputs.  grad_x is the 64-bit fixed-point LDS
+// sum in both forms (always reproducible).
+extern "C" size_t cdn_codenet_dw_backward_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int up2) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return 0;
+  if (up2) {
+    if ((H & 1) || (W & 1)) return 0;
+    const int cch = bwd2u_cch(N, C, H / 2, W / 2, true);
+    return cch ? bwd_r_bytes(N, C, (H / 2) * (W / 2), cch) : 0;
+  }
+  const int cch = bwd2_cch(H, W, true);
+  return cch ? bwd_r_bytes(N, C, H * W, cch) : 0;
+}
+
+extern "C" int cdn_codenet_dw_backward_r(const float *x, const float *s, const float *w_dw, const float *grad_d,
+                                         float *grad_x, float *grad_s, float *grad_w, int64_t N, int64_t C, int64_t H,
+                                         int64_t W, float *workspace, void *stream) {
+  CDN_REQUIRE(workspace, CDN_ERR_ARG, "null workspace (cdn_codenet_dw_backward_workspace_bytes)");
+  return dw_backward_impl(x, s, w_dw, grad_d, grad_x, grad_s, grad_w, N, C, H, W, stream, workspace);
+}
+
+extern "C" int cdn_codenet_dw_up2_backward_r(const float *x_stored, const float *s_stored, const float *w_dw,
+                                             const float *grad_d, float *grad_x, float *grad_s, float *grad_w,
+                                             int64_t N, int64_t C, int64_t H, int64_t W, float *workspace,
+                                             void *stream) {
+  CDN_REQUIRE(workspace, CDN_ERR_ARG, "null workspace (cdn_codenet_dw_backward_workspace_bytes)");
+  return dw_up2_backward_impl(x_stored, s_stored, w_dw, grad_d, grad_x, grad_s, grad_w, N, C, H, W, stream, workspace);
 }

@@ -68,6 +68,23 @@ def pointwise_wgrad(grad_y, d, want_bias, d_state=None):
     return gw, gb
 
 
+# Reproducible gather backward (round 5; tools/train_step_bench.py --atomic-dw-bwd for the A/B): grad_s / grad_w_dw as
+# per-workgroup partials reduced in a fixed order (cdn_codenet_dw_backward_r) instead of float atomics -- two identical
+# runs of a QAT step then give bit-identical parameters.
+REPRODUCIBLE_DW_BWD = True
+
+_dwbwd_ws = {}
+
+
+def _dw_bwd_workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _dwbwd_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
+        _dwbwd_ws[key] = ws
+    return ws
+
+
 # A/B switch (tools/train_step_bench.py --no-fuse-dq): d fake-quantised by its consumers while loading (True) or stored
 # fake-quantised by a pass of its own (False).  Same values either way.
 FUSE_DQ_ON_LOAD = True
@@ -163,21 +180,27 @@ class CodenetStageFunction(Function):
                 return buf[:s.numel()].view_as(s), buf[s.numel():].view_as(w_dw)
             return (torch.empty_like(s) if want_s else None), (torch.zeros_like(w_dw) if want_wdw else None)
 
-        if ctx.x_up:
+        def run(up2, Hf, Wf):
             gx = torch.empty_like(x) if want_x else None
             gs, g_wdw = gs_and_gw()
-            rc = lib.cdn_codenet_dw_up2_backward(_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw),
-                                                 Nb, C, 2 * H, 2 * W, ops._stream(x))
-            N_.check(rc, "cdn_codenet_dw_up2_backward")
+            args = (_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw), Nb, C, Hf, Wf)
+            nws = lib.cdn_codenet_dw_backward_workspace_bytes(Nb, C, Hf, Wf, int(up2)) if REPRODUCIBLE_DW_BWD else 0
+            if nws:        # (0: no reproducible form for a plane beyond LDS -- the atomic one below)
+                ws = _dw_bwd_workspace(nws, x.device)
+                fn = lib.cdn_codenet_dw_up2_backward_r if up2 else lib.cdn_codenet_dw_backward_r
+                N_.check(fn(*args, _p(ws), ops._stream(x)), "cdn_codenet_dw_backward_r")
+            else:
+                fn = lib.cdn_codenet_dw_up2_backward if up2 else lib.cdn_codenet_dw_backward
+                N_.check(fn(*args, ops._stream(x)), "cdn_codenet_dw_backward")
+            return gx, gs, g_wdw
+
+        if ctx.x_up:
+            gx, gs, g_wdw = run(True, 2 * H, 2 * W)
         elif not lib.cdn_codenet_dw_backward_supported(H, W):
             gx, gs, g_wdw = ops._dw_backward_generic(x, s, w_dw, gd, (want_x, want_s, want_wdw))
             gx = gx.contiguous() if gx is not None else None
         else:
-            gx = torch.empty_like(x) if want_x else None
-            gs, g_wdw = gs_and_gw()
-            rc = lib.cdn_codenet_dw_backward(_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw),
-                                             Nb, C, H, W, ops._stream(x))
-            N_.check(rc, "cdn_codenet_dw_backward")
+            gx, gs, g_wdw = run(False, H, W)
         g_wscale = g_bscale = None
         if want_s:
             # QuantAct on s: straight-through; Hardtanh: gradient where lo < s_raw < hi (s_c is the clamped

@@ -298,6 +298,19 @@ int cdn_codenet_dw_backward_supported(int64_t H, int64_t W);   /* 1: the plane f
 int cdn_codenet_dw_backward(const float *x, const float *s, const float *w_dw,
                             const float *grad_d, float *grad_x, float *grad_s, float *grad_w,
                             int64_t N, int64_t C, int64_t H, int64_t W, void *stream);
+/* The REPRODUCIBLE forms of the two gather backwards (round 5).  grad_s and grad_w of the entry points above are float
+ * atomics over the channel chunks / the images -- as in the reference, whose _kernel.cu:278-435 accumulates with
+ * atomicAdd -- so identical inputs give sums that differ in the last bits between runs.  These write per-workgroup
+ * partials into a caller workspace and reduce them in a fixed order: bit-identical outputs for identical inputs; grad_s
+ * and grad_w are OVERWRITTEN (not accumulated), grad_x as above.  _workspace_bytes: up2 != 0 for the up-sampled form
+ * (H, W the stage's resolution there too); 0 = this form does not exist for the shape (plane beyond LDS). */
+size_t cdn_codenet_dw_backward_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int up2);
+int cdn_codenet_dw_backward_r(const float *x, const float *s, const float *w_dw, const float *grad_d, float *grad_x,
+                              float *grad_s, float *grad_w, int64_t N, int64_t C, int64_t H, int64_t W,
+                              float *workspace, void *stream);
+int cdn_codenet_dw_up2_backward_r(const float *x_stored, const float *s_stored, const float *w_dw, const float *grad_d,
+                                  float *grad_x, float *grad_s, float *grad_w, int64_t N, int64_t C, int64_t H,
+                                  int64_t W, float *workspace, void *stream);
 
 /* y[N,Co,HW] = sum_c w_pw[co,c] * d[n,c,p] (+ bias[co]) on f32 MFMA (exact f32 products,
  * f32 accumulate).  Optional epilogue: per-channel affine y*ep_scale[co] + ep_shift[co]

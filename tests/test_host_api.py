@@ -587,3 +587,13 @@ def test_argument_validation_of_the_round5_training_entry_points_without_gpu():
     rc = lib.cdn_codenet_weight_prep_multi(1, P(one), I64(8), I64(16), None, None, None, None, I(9), I(1), I(1), F(1.0), P(one),
                                            None, None)
     assert rc == -1 and b"bits" in lib.cdn_last_error()
+    # reproducible gather backward: workspace = grad_s partials [chunks][N][plane] + grad_w partials [N][C][9]
+    need = lib.cdn_codenet_dw_backward_workspace_bytes(32, 256, 32, 32, 1)          # stored plane 16 x 16
+    assert need >= (32 * 256 + 32 * 256 * 9) * 4 and (need - 32 * 256 * 9 * 4) % (32 * 256 * 4) == 0
+    need = lib.cdn_codenet_dw_backward_workspace_bytes(32, 1024, 16, 16, 0)
+    assert need >= (32 * 256 + 32 * 1024 * 9) * 4
+    assert lib.cdn_codenet_dw_backward_workspace_bytes(32, 256, 33, 32, 1) == 0     # odd size: no stored form
+    assert lib.cdn_codenet_dw_backward_workspace_bytes(2, 8, 512, 512, 0) == 0      # plane beyond LDS
+    assert lib.cdn_codenet_dw_backward_r(one, one, one, one, one, one, one, 2, 8, 16, 16, None, None) == -1
+    assert b"workspace" in lib.cdn_last_error()
+    assert lib.cdn_codenet_dw_up2_backward_r(one, one, one, one, one, one, one, 2, 8, 16, 16, None, None) == -1

@@ -41,7 +41,11 @@ def main():
                     "instead of the exact bf16 x 3 split (pwb3n_kernel)")
     ap.add_argument("--no-bf16-wgrad", action="store_true", help="A/B: the weight gradient of conv_channel on f32 MFMA")
     ap.add_argument("--no-multi-prep", action="store_true", help="A/B: one weight-prep launch per small weight tensor")
+    ap.add_argument("--atomic-dw-bwd", action="store_true", help="A/B: float atomics for grad_s / grad_w_dw (not reproducible)")
     a = ap.parse_args()
+    if a.atomic_dw_bwd:
+        from codenet_amd.functions import codenet_stage as _cs5
+        _cs5.REPRODUCIBLE_DW_BWD = False
     if a.no_multi_prep:
         from codenet_amd.functions import codenet_stage as _cs4
         _cs4.MULTI_WEIGHT_PREP = False
