@@ -214,11 +214,20 @@ def dw_bwd2_roofline(batch, res, stored=True):
         gd = (torch.randn(batch, C, H, H, generator=g) * 1e-3).to(dev)
         gx, gs, gw = torch.empty_like(x), torch.empty_like(s), torch.zeros_like(w)
         st = torch.cuda.current_stream().cuda_stream
-        fn = lib.cdn_codenet_dw_up2_backward if up else lib.cdn_codenet_dw_backward
+        # the form the step runs: fixed-order grad_s / grad_w (its reduce launch included in the time) unless --atomic-dw-bwd
+        from codenet_amd.functions import codenet_stage as CS
+        nws = lib.cdn_codenet_dw_backward_workspace_bytes(batch, C, H, H, int(up)) if CS.REPRODUCIBLE_DW_BWD else 0
+        ws = torch.empty(max(nws // 4, 1), device=dev)
+        if nws:
+            fn = lib.cdn_codenet_dw_up2_backward_r if up else lib.cdn_codenet_dw_backward_r
+            tail = (ws.data_ptr(), st)
+        else:
+            fn = lib.cdn_codenet_dw_up2_backward if up else lib.cdn_codenet_dw_backward
+            tail = (st,)
 
         def run():
             N_.check(fn(x.data_ptr(), s.data_ptr(), w.data_ptr(), gd.data_ptr(), gx.data_ptr(),
-                        gs.data_ptr(), gw.data_ptr(), batch, C, H, H, st), "dw backward")
+                        gs.data_ptr(), gw.data_ptr(), batch, C, H, H, *tail), "dw backward")
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -231,6 +240,7 @@ def dw_bwd2_roofline(batch, res, stored=True):
         pairs = batch * C * H * H
         issued = pairs // 4 if up else pairs
         rows.append({"plane": "%dx%d" % (H, H), "channels": C, "kernel": "dw_bwd2u" if up else "dw_bwd2",
+                     "form": "fixed-order partials + reduce" if nws else "float atomics",
                      "us_per_launch": round(sec * 1e6, 1),
                      "lds_atomics_per_s": 25 * issued / sec, "frac": 25 * issued / sec / peak,
                      "equiv_frac": 25 * pairs / sec / peak,
