@@ -597,7 +597,20 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
 static int dwo_bwd_chunk(const Geom &g, bool want_gx, size_t *lds_out) {
   const size_t cells = (size_t)(g.H + 1) * (g.W + 1);
   const size_t per = want_gx ? 12 : 4;
+  // Largest chunk tried.  The input / offset kernel (WANT_GX) computes the nine taps' geometry in every lane of a pixel:
+  // 4 lanes per pixel instead of 16 / 8 quarter that redundancy and the 14-KB images let many workgroups share a CU
+  // (round 5, rocprofv3 at batch 64: 16 x 16 x 1024 621 -> 483 us, 32 x 32 x 256 594 -> 483 us; chunks of 8: 547).  The
+  // parameters kernel reads only (no atomics) and is bound by LDS bank conflicts of the [cell][chunk] image: chunks of
+  // 4 / 2 measured 431 / 564 us against 274 for 16.
+#ifndef CDN_DWOB_PARAMS_CCH
+#define CDN_DWOB_PARAMS_CCH 32
+#endif
+#ifndef CDN_DWOB_INPUT_CCH
+#define CDN_DWOB_INPUT_CCH 4
+#endif
+  const int cmax = want_gx ? CDN_DWOB_INPUT_CCH : CDN_DWOB_PARAMS_CCH;
   for (int c : {32, 16, 8, 4, 2}) {
+    if (c > cmax) continue;
     const size_t lds = cells * c * per + (size_t)c * 9 * 4 + 256;
     if (lds <= (size_t)160 * 1024 - 512) {
       // half the chunk when two workgroups then share a CU (more waves hide the LDS atomics' latency)
