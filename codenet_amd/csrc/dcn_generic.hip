@@ -560,9 +560,24 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
       }
     }
   }
-  if (!WANT_GX && gw != nullptr && ch_ok) {
+  if (!WANT_GX && gw != nullptr) {
+    // lanes of one channel by a shuffle tree, waves in wave order through LDS (gww: behind `red`, the host adds it) --
+    // ds_add_f32 sustains 0.33 lane-ops per clock and CU, and 9 of them per thread were a 6-12 us tail per workgroup
+    float *gww = red + 32;
+    const int lane_ = tid & 63, wave_ = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) atomicAdd(&gwl[cl * 9 + k], gwa[k]);
+    for (int k = 0; k < 9; ++k) {
+      float v = ch_ok ? gwa[k] : 0.0f;
+#pragma unroll
+      for (int m = CCH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (lane_ < CCH) gww[(wave_ * CCH + cl) * 9 + k] = v;
+    }
+    __syncthreads();
+    for (int q = tid; q < CCH * 9; q += nthreads) {
+      float v = 0.0f;
+      for (int wv = 0; wv < nwaves; ++wv) v += gww[wv * CCH * 9 + q];
+      gwl[q] = v;
+    }
   }
   __syncthreads();
   if (WANT_GX && gx != nullptr) {
@@ -593,6 +608,128 @@ dwo_bwd_kernel(const float *__restrict__ x, const float *__restrict__ offset, co
       if (c0 + q / 9 < C) atomicAdd(&gw[(long)c0 * 9 + q], gw_scale * gwl[q]);
 }
 
+// ---------------------------------------------------------------------------------------
+// dwo_wgrad_kernel (round 5): the _parameters call of the CoDeNet geometry with the tap geometry computed ONCE per pixel.
+// dwo_bwd_kernel<CCH, false> computed the nine taps' positions, gates and corner weights in every one of a pixel's
+// CCH lanes (~360 of its ~500 VALU instructions per (pixel, channel) step).  Here, as in dw_bwd2_kernel
+// (codenet_stage.hip): a geometry phase with lane <-> pixel leaves one record per lane for a batch of 64 pixels --
+// per tap the cell index of the upper-left corner and the four corner weights (zero when the sample is outside) --
+// and in step j the lanes of a pixel fetch its record from the owner lane with DPP row broadcasts (cdn::fetch_record:
+// 45 moves).  The x image is BORDERED ([H + 2][W + 2][CCH], zero frame) so that the four corners of every admitted
+// sample are base, base + 1, base + row, base + row + 1 (the zero-row / zero-column form of dwo_bwd_kernel needs four
+// independent offsets per tap).  Same per-sample expressions as dwo_bwd_kernel / bwd_weight_kernel; lane-private sums
+// over the pixels, lanes of a channel by a shuffle tree, waves in wave order, one float atomic per (workgroup, c, k).
+// CCH = 16 or 8 (the DPP row forms); other chunk sizes keep dwo_bwd_kernel.
+// ---------------------------------------------------------------------------------------
+template <int CCH>
+__global__ void __launch_bounds__(1024)
+dwo_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ offset, const float *__restrict__ gd,
+                 float *__restrict__ gw, float gw_scale, int C, int H, int W) {
+  extern __shared__ float dwo_wg_smem[];
+  constexpr int PPW = 64 / CCH, LPP = CCH, SPB = 64 / PPW;
+  const int nthreads = blockDim.x, nwaves = nthreads / 64;
+  const int HW = H * W, Wp = W + 2;
+  const int cells = (H + 2) * Wp;
+  const int n = blockIdx.y, c0 = blockIdx.x * CCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *ximg = dwo_wg_smem;                          // [cells][CCH], zero frame
+  float *gwl = ximg + (size_t)cells * CCH;            // [CCH][9]
+  float *gww = gwl + CCH * 9;                         // [nwaves][CCH][9]
+  for (int q = tid; q < cells * CCH; q += nthreads) ximg[q] = 0.0f;
+  __syncthreads();
+  {
+    const int quads = (HW + 3) >> 2;
+    for (int q = tid; q < quads * CCH; q += nthreads) {
+      const int cl = q % CCH, j = q / CCH;
+      if (c0 + cl < C) {
+        const float *xp = x + ((long)n * C + c0 + cl) * HW + j * 4;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int pix = j * 4 + e4;
+          if (pix < HW) ximg[((pix / W + 1) * Wp + (pix % W) + 1) * CCH + cl] = xp[e4];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int cl = lane % CCH, sub = lane / CCH;
+  const bool ch_ok = c0 + cl < C;
+  float gwa[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gwa[k] = 0.0f;
+  const float *gbase = gd + ((long)n * C + c0 + cl) * HW;
+  const int nsteps = (HW + nwaves * PPW - 1) / (nwaves * PPW);
+  for (int sb = 0; sb < nsteps; sb += SPB) {
+    // geometry phase: this lane's pixel of the batch
+    const int own = cdn::owner_item<LPP>(lane);
+    const int gp = (wave + (sb + own / PPW) * nwaves) * PPW + own % PPW;
+    int gi[9];
+    float gf[36];
+    {
+      const bool live = gp < HW;
+      const int pp = live ? gp : 0;
+      const int h = pp / W, w = pp - h * W;
+      const float *op = offset + (long)n * 18 * HW + pp;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int i = k / 3, j = k - 3 * i;
+        const float hi = (float)(h - 1 + i) + op[(long)(2 * k) * HW];
+        const float wi = (float)(w - 1 + j) + op[(long)(2 * k + 1) * HW];
+        const bool ok = live && inside(hi, wi, H, W);
+        const DAxis Y = daxis(hi, ok), X = daxis(wi, ok);
+        gi[k] = ((Y.i0 + 1) * Wp + X.i0 + 1) * CCH;          // (outside: i0 = 0, weights 0)
+        gf[4 * k + 0] = Y.w0 * X.w0;
+        gf[4 * k + 1] = Y.w0 * X.w1;
+        gf[4 * k + 2] = Y.w1 * X.w0;
+        gf[4 * k + 3] = Y.w1 * X.w1;
+      }
+    }
+#pragma unroll 1
+    for (int j = 0; j < SPB && sb + j < nsteps; ++j) {
+      int oi[9];
+      float of[36];
+      cdn::fetch_record<LPP == 8>(j, gi, gf, oi, of);
+      const int p = (wave + (sb + j) * nwaves) * PPW + sub;
+      const float g = (p < HW && ch_ok) ? gbase[p] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float *q = ximg + oi[k] + cl;
+        const float v00 = q[0], v01 = q[CCH], v10 = q[Wp * CCH], v11 = q[Wp * CCH + CCH];
+        const float S = ((of[4 * k] * v00 + of[4 * k + 1] * v01) + of[4 * k + 2] * v10) + of[4 * k + 3] * v11;
+        gwa[k] = fmaf(g, S, gwa[k]);
+      }
+    }
+  }
+  if (gw == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float v = ch_ok ? gwa[k] : 0.0f;
+#pragma unroll
+    for (int m = CCH; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (lane < CCH) gww[(wave * CCH + cl) * 9 + k] = v;
+  }
+  __syncthreads();
+  for (int q = tid; q < CCH * 9; q += nthreads) {
+    float v = 0.0f;
+    for (int wv = 0; wv < nwaves; ++wv) v += gww[wv * CCH * 9 + q];
+    if (c0 + q / 9 < C) atomicAdd(&gw[(long)c0 * 9 + q], gw_scale * v);
+  }
+}
+
+// chunk of dwo_wgrad_kernel: 16 channels, or 8 when 16 do not fit / when two workgroups of 8 then share a CU; 0: neither
+static int dwo_wgrad_chunk(const Geom &g, size_t *lds_out, int *threads_out) {
+  const size_t cells = (size_t)(g.H + 2) * (g.W + 2);
+  const size_t lim = (size_t)160 * 1024 - 512;
+  auto need = [&](int c, int waves) { return cells * c * 4 + (size_t)c * 9 * 4 + (size_t)waves * c * 9 * 4; };
+  int c = need(16, 16) <= lim ? 16 : need(8, 16) <= lim ? 8 : 0;
+  if (c == 0) return 0;
+  if (c == 16 && need(8, 8) * 2 <= lim && cdn::ceil_div(g.C, 16) * g.N < 2 * (long)cdn::kCUs) c = 8;
+  const int threads = need(c, 8) * 2 <= lim ? 512 : 1024;
+  *threads_out = threads;
+  *lds_out = need(c, threads / 64);
+  return c;
+}
+
 // the largest channel chunk whose LDS images fit (0: the plane is too large -- generic kernels)
 static int dwo_bwd_chunk(const Geom &g, bool want_gx, size_t *lds_out) {
   const size_t cells = (size_t)(g.H + 1) * (g.W + 1);
@@ -611,10 +748,11 @@ static int dwo_bwd_chunk(const Geom &g, bool want_gx, size_t *lds_out) {
   const int cmax = want_gx ? CDN_DWOB_INPUT_CCH : CDN_DWOB_PARAMS_CCH;
   for (int c : {32, 16, 8, 4, 2}) {
     if (c > cmax) continue;
+    const size_t gww = want_gx ? 0 : (size_t)c * 16 * 36;      // (the parameters kernel's per-wave sums, at most 16 waves)
     const size_t lds = cells * c * per + (size_t)c * 9 * 4 + 256;
-    if (lds <= (size_t)160 * 1024 - 512) {
+    if (lds + gww <= (size_t)160 * 1024 - 512) {
       // half the chunk when two workgroups then share a CU (more waves hide the LDS atomics' latency)
-      if (c >= 16 && (cells * (c / 2) * per + (size_t)(c / 2) * 9 * 4 + 256) * 2 <= (size_t)160 * 1024 - 512) c /= 2;
+      if (c >= 16 && (cells * (c / 2) * per + (size_t)(c / 2) * 9 * 4 + 256 + gww / 2) * 2 <= (size_t)160 * 1024 - 512) c /= 2;
       *lds_out = cells * c * per + (size_t)c * 9 * 4 + 256;
       return c;
     }
@@ -633,6 +771,7 @@ static int launch_dwo_bwd(const float *x, const float *off, const float *w, cons
   if (cch == 0) return -1;                                   // caller falls back
   dim3 grid((unsigned)cdn::ceil_div(g.C, cch), (unsigned)g.N);
   const int threads = lds * 2 <= (size_t)160 * 1024 - 512 ? 512 : 1024;
+  if (!WANT_GX) lds += (size_t)(threads / 64) * cch * 9 * 4;      // per-wave weight-gradient sums (gww)
 #define CDN_DWOB(CCH_)                                                                                     \
   {                                                                                                        \
     auto kern = dwo_bwd_kernel<CCH_, WANT_GX>;                                                             \
@@ -737,6 +876,20 @@ int run_backward_weight(const void *x, const void *off, const void *m, const voi
   const int blocks = g.Co * Cg * K;
   if (std::is_same<T, float>::value && !m && !gb && dwo_bwd_applies(g)) {
     size_t lds = 0;
+    int threads = 0;
+#ifndef CDN_NO_DWO_WGRAD
+    const int wc = dwo_wgrad_chunk(g, &lds, &threads);
+#else
+    const int wc = 0;
+#endif
+    if (wc != 0) {
+      dim3 grid((unsigned)cdn::ceil_div(g.C, wc), (unsigned)g.N);
+      auto kern = wc == 16 ? dwo_wgrad_kernel<16> : dwo_wgrad_kernel<8>;
+      (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      kern<<<grid, threads, lds, st>>>((const float *)x, (const float *)off, (const float *)go, (float *)gw, (float)scale,
+                                       g.C, g.H, g.W);
+      return cdn::check_launch("deform_conv backward_parameters (depthwise)");
+    }
     if (dwo_bwd_chunk(g, false, &lds) != 0) {
       (void)launch_dwo_bwd<false>((const float *)x, (const float *)off, nullptr, (const float *)go, nullptr, nullptr,
                                   (float *)gw, (float)scale, g, st);
