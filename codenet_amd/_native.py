@@ -90,6 +90,7 @@ _SIGNATURES = {
     "cdn_codenet_stage_fused_forward": (
         _i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 8 + [_i] + [_vp] * 9
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
+    "cdn_quantact_commit_range": (_i, [_vp, _vp, _vp, _vp, _i, _d, _i, _vp]),
     "cdn_quantact_frozen_params": (_i, [_i, _vp, _vp, _vp, _i, _vp]),
     "cdn_quantact_frozen_params_clear": (_i, [_i, _vp, _vp, _vp, _i, _vp, ctypes.c_size_t, _vp]),
     "cdn_codenet_stage_frozen_workspace_bytes": (ctypes.c_size_t, [_i64] * 4 + [_i]),

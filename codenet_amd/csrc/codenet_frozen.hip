@@ -448,7 +448,7 @@ dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ a
               const float *__restrict__ bias, signed char *__restrict__ R8, const unsigned *__restrict__ rq,
               unsigned *__restrict__ oflow, long M, int C, int KP, int ld_in, int Hs, int Ws, int Ho, int Wo, int Co,
               int relu, int ldo, const int *__restrict__ omap) {
-  constexpr int BM = 64, WGM = 2, WGN = 2, TN = BN / (32 * WGN), BI = BN * kQK / 16 / 256, NC = (SW - 1) * STRIDE + 3;
+  constexpr int BM = 64, WGN = 2, TN = BN / (32 * WGN), BI = BN * kQK / 16 / 256, NC = (SW - 1) * STRIDE + 3;      // (2 x 2 waves)
   constexpr int Wseg = BM / TR;                    // columns of the tile (== Wo, or a 64-column segment of a row)
   static_assert(TN >= 1 && BI >= 1, "tile too small");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dp[];

@@ -3436,6 +3436,16 @@ __global__ void quantact_commit_percentile_kernel(cdn::QUpdate u, const float *_
   }
 }
 
+extern "C" int cdn_quantact_commit_range(float *x_min, float *x_max, void *state, const float *range, int bits,
+                                         double momentum, int running, void *stream) {
+  CDN_REQUIRE(x_min && x_max && state && range, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits out of range");
+  const cdn::QUpdate u{x_min, x_max, static_cast<unsigned *>(state), nullptr, (float)(momentum - 1.0),
+                       (float)(1.0 - momentum), bits, running};
+  quantact_commit_percentile_kernel<<<1, 64, 0, cdn::as_stream(stream)>>>(u, range);
+  return cdn::check_launch("quantact commit range");
+}
+
 extern "C" size_t cdn_codenet_stage_workspace_bytes(int64_t N, int64_t C, int64_t H, int64_t W,
                                                     int x_up) {
   const int64_t HWl = (H >> x_up) * (W >> x_up);
@@ -3521,10 +3531,16 @@ extern "C" int cdn_codenet_stage_fused_forward(
     void *stream) {
   CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
-  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK | CDN_X_ACT_PERCENTILE | CDN_X_WCODES_KB)) == 0 &&
+  CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK | CDN_X_ACT_PERCENTILE | CDN_X_WCODES_KB | CDN_X_DEFER_RANGE |
+                          CDN_X_PHASE_MASK)) == 0 &&
                   ((x_nhwc & CDN_X_GATHER_MASK) >> 8) <= 2, CDN_ERR_ARG,
               "x_nhwc: 0 / 1, optionally | CDN_X_GATHER_PER_ITEM or CDN_X_GATHER_PERSISTENT, | CDN_X_ACT_PERCENTILE, "
-              "| CDN_X_WCODES_KB");
+              "| CDN_X_WCODES_KB, | CDN_X_DEFER_RANGE, | CDN_X_PHASE_*");
+  // split call (multi-process global ranges): which steps run, and whether the producers only measure
+  const int phases = (x_nhwc & CDN_X_PHASE_MASK) ? (x_nhwc & CDN_X_PHASE_MASK) : CDN_X_PHASE_MASK;
+  const bool defer = (x_nhwc & CDN_X_DEFER_RANGE) != 0;
+  CDN_REQUIRE(!defer || (running != 0 && s_state && d_state && r_state && !(x_nhwc & CDN_X_ACT_PERCENTILE)), CDN_ERR_ARG,
+              "CDN_X_DEFER_RANGE needs running != 0 and the three QuantActs, and excludes CDN_X_ACT_PERCENTILE");
   const int gmode = (x_nhwc & CDN_X_GATHER_MASK) >> 8;      // per-call schedule choice (tests); no library state
   // the k-blocked copy of the weight codes behind the row-major ones (the streaming int8 pointwise kernel)
   CDN_REQUIRE(!(x_nhwc & CDN_X_WCODES_KB) || (w_pw_codes && cdn_codenet_wcodes_kb_columns(C, Co) != 0), CDN_ERR_ARG,
@@ -3595,7 +3611,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
   const float mm1 = (float)(momentum - 1.0), omm = (float)(1.0 - momentum);
   // (percentile: the producers only measure -- running = 0 leaves the range alone and parks the extremes in the
   // state --, the commit follows each of them)
-  const int prun = pct ? 0 : running;
+  const int prun = (pct || defer) ? 0 : running;
   const cdn::QUpdate qu_s{s_min, s_max, sst, arrive, mm1, omm, bits, prun};
   const cdn::QUpdate qu_d{d_min, d_max, dst, arrive + arr_stride, mm1, omm, bits, prun};
   const cdn::QUpdate qu_r{r_min, r_max, rst, arrive + 2 * arr_stride, mm1, omm, bits, prun};
@@ -3619,9 +3635,11 @@ extern "C" int cdn_codenet_stage_fused_forward(
     return cdn::check_launch("codenet fused percentile commit");
   };
   const int ptag = (int)(H > 0xffff ? 0xffff : H);
+  int rc = 0;
   // 1. scale prediction at stored resolution (+ min/max of s)
   float2 *smm = sst ? part_s : nullptr;
   int n_part_s = 0;
+  if (phases & CDN_X_PHASE_SCALE) {
   {
   cdn::ProfScope ps(cdn::kProfScale, ptag, st);
   // tiled kernel for large planes (measured: 18 vs 22 us at 65536 pixels x 128 channels; the
@@ -3658,13 +3676,15 @@ extern "C" int cdn_codenet_stage_fused_forward(
                                                           (int)C, (int)HWl, lo, hi);
   }
   }
-  int rc = cdn::check_launch("codenet fused scale");
+  rc = cdn::check_launch("codenet fused scale");
   if (rc) return rc;
   (void)n_part_s;
   if (pct && (rc = commit_percentile(s_raw, N * H * W, x_up ? 4 : 1, qu_s))) return rc;
+  }
   // 2. gather + depthwise (+ min/max of d)
   float2 *dmm = dst ? part_d : nullptr;   // always: the batch extremes also gate the int8 path
-  if (cch == 0) {
+  if (!(phases & CDN_X_PHASE_GATHER)) {
+  } else if (cch == 0) {
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     rc = launch_dwg(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
   } else {
@@ -3676,7 +3696,8 @@ extern "C" int cdn_codenet_stage_fused_forward(
             (int)ldd);
   }
   if (rc) return rc;
-  if (pct && (rc = commit_percentile(d, N * H * W * C, 1, qu_d))) return rc;
+  if (pct && (phases & CDN_X_PHASE_GATHER) && (rc = commit_percentile(d, N * H * W * C, 1, qu_d))) return rc;
+  if (!(phases & CDN_X_PHASE_POINTWISE)) return CDN_OK;
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
   rc = launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
                         bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,

@@ -1139,6 +1139,7 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
   const signed char *abase8 = reinterpret_cast<const signed char *>(y1) + (long)n * Hs * Ws * C + cb;
   auto load_row = [&](int r, float4 (&d)[MAXL]) {
     const bool row_in = (unsigned)r < (unsigned)Hs;
+    (void)row_in;                              // (only the CDN_HS_GUARDED form reads it)
 #pragma unroll
     for (int u = 0; u < MAXL; ++u) {
       const int col = x_l + u * XPT, x = ix0 + col;

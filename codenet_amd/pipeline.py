@@ -380,8 +380,10 @@ def gather_detections(dets, dst=None, counts=None):
 def set_global_range(model, flag=True):
     """Multi-process parity mode of every QuantAct of `model` (collective 3): the batch extremes
     are all-reduced (MIN / MAX, two 4-byte collectives per QuantAct call, RCCL over xGMI / gloo) before the range
-    update, so R ranks x B images track the ranges of one R*B-image run.  Such QuantActs keep the module-by-module
-    path (the fused schedules update ranges inside the producing kernels).  Returns the number of QuantActs set."""
+    update, so R ranks x B images track the ranges of one R*B-image run.  The three deform stages stay on the fused
+    schedule (round 5: the stage call is split at its QuantActs, FusedHotPath._global_commit); backbone and heads keep
+    the module-by-module path in this mode (their fused schedules update ranges inside the producing kernels).  Returns
+    the number of QuantActs set."""
     from .portable_quantizer.quant_modules import QuantAct
     n = 0
     for m in model.modules():
@@ -393,6 +395,8 @@ def set_global_range(model, flag=True):
 
 ACT_PERCENTILE = 0x400      # CDN_X_ACT_PERCENTILE (include/codenet_dcn.h)
 WCODES_KB = 0x800           # CDN_X_WCODES_KB
+DEFER_RANGE = 0x1000        # CDN_X_DEFER_RANGE
+PHASE_SCALE, PHASE_GATHER, PHASE_POINTWISE = 0x2000, 0x4000, 0x8000      # CDN_X_PHASE_*
 
 
 def stage_int8_codes(convbn, kblocked=True):
@@ -409,18 +413,32 @@ def stage_int8_codes(convbn, kblocked=True):
     return convbn.folded_int8(), 0
 
 
-def act_fusable(act, allow_percentile=False):
+def act_fusable(act, allow_percentile=False, allow_global=False):
     """The fused schedules implement the reference's default QuantAct: plain batch min/max tracking,
     asymmetric, quantising (quant_modules.py:163-225 with percentile=False).  Symmetric activations and
     full_precision_flag stay on the module path; --act-percentile too, except in the three deform stages
     (allow_percentile: FusedHotPath, round 4 -- the stage entry point follows the order statistics with
-    cdn_kth_values between its kernels)."""
+    cdn_kth_values between its kernels); the multi-process global-range mode too, except in the three deform stages
+    (allow_global: FusedHotPath, round 5 -- the stage call is split at its QuantActs, `_global_commit`)."""
+    glob = getattr(act, "global_range", False) and act.running_stat
     return (act.quant_mode == "asymmetric" and (allow_percentile or not act.percentile)
             and not act.full_precision_flag
-            and not (getattr(act, "global_range", False) and act.running_stat))
+            and (not glob or (allow_global and not act.percentile)))
 
 
-def uniform_act_settings(acts, what, allow_percentile=False):
+def global_range_active(acts):
+    """True when the QuantActs of a fused stage call must see batch extremes reduced over the ranks: the mode is on, the
+    ranges are tracked and there is more than one rank (one rank: the plain call computes the same thing)."""
+    import torch.distributed as dist
+    acts = [a for a in acts if a is not None]
+    if not any(getattr(a, "global_range", False) and a.running_stat for a in acts):
+        return False
+    if not all(getattr(a, "global_range", False) for a in acts):
+        raise NotImplementedError("the QuantActs of one fused stage must all or none be in global-range mode")
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def uniform_act_settings(acts, what, allow_percentile=False, allow_global=False):
     """(bits, momentum, running) shared by the QuantActs of one fused C call, which takes them once.
     allow_percentile: the call's QuantActs may all be percentile ones (never a mixture)."""
     acts = [a for a in acts if a is not None]
@@ -429,7 +447,7 @@ def uniform_act_settings(acts, what, allow_percentile=False):
     if allow_percentile and len({bool(a.percentile) for a in acts}) != 1:
         raise NotImplementedError("%s: the QuantActs of one fused call must all or none use percentile ranges" % what)
     for a in acts:
-        if not act_fusable(a, allow_percentile):
+        if not act_fusable(a, allow_percentile, allow_global):
             raise NotImplementedError("%s: QuantAct(percentile=%s, quant_mode=%s, full_precision_flag=%s) is not "
                                       "implemented by the fused schedule; use the module path"
                                       % (what, a.percentile, a.quant_mode, a.full_precision_flag))
@@ -532,7 +550,8 @@ class FusedHotPath:
                     return False
                 acts = (st[0].quant_act[1], st[0].quant_identity_deform, st[1][1])
                 try:
-                    uniform_act_settings(acts, "stage", allow_percentile=True)
+                    uniform_act_settings(acts, "stage", allow_percentile=True, allow_global=True)
+                    global_range_active(acts)              # (raises on a mixture)
                 except NotImplementedError:
                     return False
                 cout = st[0].quant_conv_channel_bn.conv.out_channels
@@ -639,7 +658,8 @@ class FusedHotPath:
                 p = self._stage_params(st)
                 ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
                 a = []
-                bits, mom, running = uniform_act_settings(p["acts"], "FusedHotPath stage", allow_percentile=True)
+                bits, mom, running = uniform_act_settings(p["acts"], "FusedHotPath stage", allow_percentile=True,
+                                                          allow_global=True)
                 pct = ACT_PERCENTILE if (p["acts"][0] is not None and p["acts"][0].percentile) else 0
                 for act in p["acts"]:
                     if act is None:
@@ -648,29 +668,64 @@ class FusedHotPath:
                         a += [act.x_min.data_ptr(), act.x_max.data_ptr(),
                               act._device_state(x.device).data_ptr()]
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
-                rc = lib.cdn_codenet_stage_fused_forward(
-                    cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0) | pct | p["kb_flag"], sb["up"], cur_q, Nb,
-                    sb["C"],
-                    sb["Co"], sb["H"], sb["W"],
-                    ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
-                    ptr(p["w_dw"]), ptr(p["w_pw"]),
-                    *([ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]),
-                    ptr(p["bias"]), ptr(p["ep_scale"]),
-                    ptr(p["ep_shift"]), 1, *a, bits, mom, running, ws_ptr, ws_bytes,
-                    sb["r"].data_ptr(), stream)
+
+                def stage_call(extra):
+                    rc = lib.cdn_codenet_stage_fused_forward(
+                        cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0) | pct | p["kb_flag"] | extra, sb["up"],
+                        cur_q, Nb, sb["C"],
+                        sb["Co"], sb["H"], sb["W"],
+                        ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
+                        ptr(p["w_dw"]), ptr(p["w_pw"]),
+                        *([ptr(t) for t in p["i8"]] if p["i8"] is not None else [None, None, None]),
+                        ptr(p["bias"]), ptr(p["ep_scale"]),
+                        ptr(p["ep_shift"]), 1, *a, bits, mom, running, ws_ptr, ws_bytes,
+                        sb["r"].data_ptr(), stream)
+                    N_.check(rc, "cdn_codenet_stage_fused_forward")
+
+                if global_range_active(p["acts"]):
+                    # multi-process parity mode (collective 3): the stage call split at its three
+                    # QuantActs -- each producer only measures, the batch extremes are reduced over the ranks (one
+                    # 8-byte MAX all-reduce of {-min, max}), the commit applies the reference's update with them
+                    for phase, act in zip((PHASE_SCALE, PHASE_GATHER, PHASE_POINTWISE), p["acts"]):
+                        stage_call(DEFER_RANGE | phase)
+                        self._global_commit(act, x.device, bits, mom, stream)
+                else:
+                    stage_call(0)
                 ops._toc(rec)
-                N_.check(rc, "cdn_codenet_stage_fused_forward")
                 if self.stage_hook is not None:
                     self.stage_hook(sb)
                 cur, cur_nhwc = sb["r"], 1
                 cur_q = a[8]          # r_state of this stage (None in fp32)
         return cur, cur_q, B["stages"][-1]
 
+    @staticmethod
+    def _global_commit(act, dev, bits, mom, stream):
+        """Range update of one QuantAct from the extremes of ALL ranks: the producer (CDN_X_DEFER_RANGE) left this rank's
+        batch {min, max} in words [4], [5] of the device state."""
+        import torch.distributed as dist
+        from . import _native as N_
+        st = act._device_state(dev)
+        f = st.view(torch.float32)
+        t = torch.stack((-f[4], f[5]))                   # one MAX all-reduce for both ends
+        if dist.get_backend() == "gloo":                 # (tests on one GPU: gloo reduces on the host)
+            th = t.cpu()
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            t.copy_(th)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)     # RCCL over xGMI, 8 bytes, on the current stream
+        t[0].neg_()
+        rc = N_.lib().cdn_quantact_commit_range(act.x_min.data_ptr(), act.x_max.data_ptr(), st.data_ptr(), t.data_ptr(),
+                                                bits, mom, 1, stream)
+        N_.check(rc, "cdn_quantact_commit_range")
+
     # -- HIP graph -----------------------------------------------------------------------------
     def capture(self, x, unpack=True):
         """Capture one pass over the static input buffer `x` into a HIP graph; returns a callable
         replaying it (the output tensor is static too).  unpack=False: the three stages only, returning the
         channels-last stage-resolution tensor ``forward_nhwc`` hands to the native heads."""
+        if self.quantized and any(global_range_active(self._stage_params(st)["acts"]) for st in self.stages):
+            raise NotImplementedError("FusedHotPath.capture: the global-range mode runs collectives between the kernels; "
+                                      "launch it eagerly")
         run = self.__call__ if unpack else (lambda t: self.forward_nhwc(t)[0])
         run(x)                        # allocate + warm (also derives cached weights)
         torch.cuda.synchronize()

@@ -449,6 +449,26 @@ int cdn_codenet_stage_fused_supported(int64_t N, int64_t C, int64_t H, int64_t W
 #define CDN_X_WCODES_KB 0x800
 int64_t cdn_codenet_wcodes_kb_columns(int64_t C, int64_t Co);
 int64_t cdn_codenet_wcodes_kb_offset(int64_t C, int64_t Co);
+/* | CDN_X_DEFER_RANGE and the phase bits (round 5; SURVEY.md section 8e, collective 3 -- the multi-process parity mode in
+ * which R ranks x B images track the ranges of ONE R*B-image run; the reference's only multi-GPU mechanism,
+ * lib/models/data_parallel.py:64-84, scatters one batch and so has batch-global ranges by construction): the stage call
+ * is split at its three QuantActs so that the caller can all-reduce the batch extremes between the kernels.
+ *   CDN_X_PHASE_SCALE / _GATHER / _POINTWISE  run only the named steps (none named = all three); the intermediates stay
+ *                       in the workspace, so the calls of one stage must pass the same workspace and arguments;
+ *   CDN_X_DEFER_RANGE   the producers only MEASURE (needs running != 0 and the three QuantActs; not with
+ *                       CDN_X_ACT_PERCENTILE): each leaves its batch {min, max} in state words [4], [5] (as floats) and
+ *                       does not touch the range; the caller reduces them over the ranks and commits with
+ *                       cdn_quantact_commit_range before the next phase reads the state.
+ * cdn_quantact_commit_range: the QuantAct update (quant_modules.py:203-219: initialisation or momentum step, then scale /
+ * zero point) from `range` = {min, max} on the device; the code-width flag (state word [6]) follows THIS rank's extremes
+ * in words [4], [5]. */
+#define CDN_X_DEFER_RANGE 0x1000
+#define CDN_X_PHASE_SCALE 0x2000
+#define CDN_X_PHASE_GATHER 0x4000
+#define CDN_X_PHASE_POINTWISE 0x8000
+#define CDN_X_PHASE_MASK 0xE000
+int cdn_quantact_commit_range(float *x_min, float *x_max, void *state, const float *range, int bits, double momentum,
+                              int running, void *stream);
 int cdn_codenet_stage_fused_forward(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,

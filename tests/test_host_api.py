@@ -597,3 +597,25 @@ def test_argument_validation_of_the_round5_training_entry_points_without_gpu():
     assert lib.cdn_codenet_dw_backward_r(one, one, one, one, one, one, one, 2, 8, 16, 16, None, None) == -1
     assert b"workspace" in lib.cdn_last_error()
     assert lib.cdn_codenet_dw_up2_backward_r(one, one, one, one, one, one, one, 2, 8, 16, 16, None, None) == -1
+
+
+def test_split_stage_call_flags_are_validated_without_gpu():
+    """CDN_X_DEFER_RANGE / CDN_X_PHASE_* (round 5, global-range mode on the fused stages) and
+    cdn_quantact_commit_range validate before any HIP call."""
+    from codenet_amd import _native, pipeline
+    lib = _native.lib()
+    one = 4096
+    assert (pipeline.DEFER_RANGE, pipeline.PHASE_SCALE, pipeline.PHASE_GATHER, pipeline.PHASE_POINTWISE) == \
+        (0x1000, 0x2000, 0x4000, 0x8000)
+    assert lib.cdn_quantact_commit_range(None, one, one, one, 8, 0.99, 1, None) == -1
+    assert lib.cdn_quantact_commit_range(one, one, one, one, 1, 0.99, 1, None) == -1 and b"bits" in lib.cdn_last_error()
+
+    def call(flags, running, with_acts=True):
+        a = [one] * 9 if with_acts else [None] * 9
+        return lib.cdn_codenet_stage_fused_forward(
+            one, flags, 0, None, 2, 8, 8, 8, 8, one, None, -7.0, 8.0, one, one, None, None, None, None, None, None, 1,
+            *a, 8, 0.99, running, one, 1 << 30, one, None)
+    assert call(pipeline.DEFER_RANGE | pipeline.PHASE_SCALE, 0) == -1 and b"CDN_X_DEFER_RANGE" in lib.cdn_last_error()
+    assert call(pipeline.DEFER_RANGE, 1, with_acts=False) == -1 and b"CDN_X_DEFER_RANGE" in lib.cdn_last_error()
+    assert call(pipeline.DEFER_RANGE | pipeline.ACT_PERCENTILE, 1) == -1
+    assert call(0x10000, 1) == -1 and b"x_nhwc" in lib.cdn_last_error()
