@@ -124,3 +124,41 @@ def test_global_range_model_keeps_its_stages_on_the_fused_schedule():
         std = a[k].std().item() + 1e-6
         d = (a[k] - b[k]).abs()
         assert d.mean().item() < 0.12 * std, (k, d.mean().item(), std)
+
+
+def _rccl_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)       # nccl == RCCL on ROCm
+    from codenet_amd import pipeline
+    seen = torch.ones(1, device="cuda")
+    dist.all_reduce(seen)
+    net = pipeline.build_hot_path(quantized=True).cuda()
+    nbytes = pipeline.broadcast_parameters(net, src=0)
+    t = torch.tensor([-1.5, 2.5], device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                            # the collective of FusedHotPath._global_commit
+    dets = torch.arange(2 * 100 * 6, dtype=torch.float32, device="cuda").view(2, 100, 6)
+    allg = pipeline.gather_detections(dets)
+    # (the package's helpers return early on one rank: the same collectives called directly)
+    flat = torch.randn(330_000, device="cuda")
+    keep = flat.clone()
+    dist.broadcast(flat, src=0)
+    got = torch.empty(world * dets.numel(), device="cuda")
+    dist.all_gather_into_tensor(got, dets.reshape(-1).contiguous())
+    assert torch.equal(flat, keep) and torch.equal(got, dets.reshape(-1))
+    torch.cuda.synchronize()
+    torch.save({"seen": seen.item(), "nbytes": nbytes, "t": t.cpu(), "gathered": tuple(allg.shape)}, out % rank)
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_paths_collectives_on_one_rank(tmp_path):
+    """The collectives of the multi-GPU path (start-up broadcast, detection all-gather, the global-range MAX all-reduce)
+    on the RCCL backend itself, one rank on the box's one GPU: the backend loads, binds to the device and runs them on
+    GPU tensors (gpurun gives one GPU; more ranks are the driver's round-end run)."""
+    out = str(tmp_path / "n%d.pt")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out % 0)
+    assert r["seen"] == 1.0 and r["nbytes"] > 1_000_000
+    assert r["t"].tolist() == [-1.5, 2.5] and r["gathered"] == (2, 100, 6)
