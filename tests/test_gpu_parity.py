@@ -58,7 +58,10 @@ def test_deform_conv_forward_backward(case, dtype):
 
 
 @pytest.mark.parametrize("N,C,H,W,spread", [(2, 37, 9, 11, 2.0), (1, 70, 16, 16, 4.0), (2, 8, 33, 20, 6.0),
-                                              (3, 33, 8, 8, 12.0), (1, 4, 3, 3, 1.0)])
+                                              (3, 33, 8, 8, 12.0), (1, 4, 3, 3, 1.0),
+                                              # planes beyond dwo_wgrad_kernel's 8-channel chunk: the _parameters call on
+                                              # dwo_bwd_kernel<2 / 4, false>, the _input call on 2-channel chunks
+                                              (1, 6, 80, 72, 3.0), (2, 5, 100, 96, 2.0)])
 def test_generic_depthwise_fast_path_matches_oracle(N, C, H, W, spread):
     """cdn_deform_conv_forward with the CoDeNet call geometry (groups = C = Co, deformable_groups = 1, 3x3, stride 1,
     pad 1: modules/dcn_deform_conv.py:319-325) takes the LDS-plane depthwise kernel (dwo_kernel, dcn_generic.hip)
@@ -87,10 +90,13 @@ def test_generic_depthwise_fast_path_matches_oracle(N, C, H, W, spread):
     for name, got, want in (("grad_input", xg.grad, gx), ("grad_offset", og.grad, goff), ("grad_weight", wg.grad, gw)):
         err = (got.cpu() - want).abs().max().item()
         assert err < 2e-4 * max(1.0, want.abs().max().item()), "%s: %g" % (name, err)
-    # grad_input is a fixed-point sum: bitwise reproducible from call to call (the reference's float atomics are not)
-    xg2, og2, wg2 = (t.cuda().requires_grad_(True) for t in (x, off, w))
-    deform_conv(xg2, og2, wg2, 1, 1, 1, C, 1).backward(go.cuda())
-    assert torch.equal(xg.grad, xg2.grad)
+    # grad_input is a fixed-point sum: bitwise reproducible from call to call (the reference's float atomics are not) --
+    # wherever the plane fits the LDS-image kernel in 2-channel chunks (beyond: the generic float-atomic kernels, as the
+    # reference; the 100 x 96 case)
+    if (H + 1) * (W + 1) * 2 * 12 + 2 * 36 + 256 <= 160 * 1024 - 512:
+        xg2, og2, wg2 = (t.cuda().requires_grad_(True) for t in (x, off, w))
+        deform_conv(xg2, og2, wg2, 1, 1, 1, C, 1).backward(go.cuda())
+        assert torch.equal(xg.grad, xg2.grad)
 
 
 @pytest.mark.parametrize("case", [GENERIC_CASES[0], GENERIC_CASES[-1]])
