@@ -33,11 +33,18 @@ BUDGET_LAYERS = {
 }
 
 
-def kernel_resources(src="codenet_fused.hip"):
+# codenet_stage.hip is built WITHOUT the SLP vectoriser (csrc/Makefile): with it the QAT forward
+# gather needs 152 VGPRs (three waves per SIMD) instead of 99-106; dcn_generic.hip: the seam's parameter-gradient kernel
+# holds a 45-value record per lane under the 128-VGPR cap of its 1024-thread workgroups
+BUDGET_STAGE = {"dw4_kernelILb1E": 128, "dw4_kernelILb0E": 128}
+BUDGET_GENERIC = {"dwo_wgrad_kernelILi16E": 128, "dwo_wgrad_kernelILi8E": 128}
+
+
+def kernel_resources(src="codenet_fused.hip", extra=()):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
-                        "-munsafe-fp-atomics", "-S", "--cuda-device-only", "-o", out, src],
+                        "-munsafe-fp-atomics", *extra, "-S", "--cuda-device-only", "-o", out, src],
                        cwd=CSRC, check=True, stderr=subprocess.DEVNULL)
         txt = open(out).read()
     res = {}
@@ -64,6 +71,18 @@ def check():
             if r["vgpr"] > cap:
                 problems.append("%s uses %d VGPRs (budget %d)" % (n, r["vgpr"], cap))
     res.update(res_l)
+    for src, extra, budget in (("codenet_stage.hip", ("-fno-slp-vectorize",), BUDGET_STAGE), ("dcn_generic.hip", (), BUDGET_GENERIC)):
+        res_x = kernel_resources(src, extra)
+        for frag, cap in budget.items():
+            hits = [(n, r) for n, r in res_x.items() if frag in n]
+            if not hits:
+                problems.append("kernel %s not found" % frag)
+            for n, r in hits:
+                if r["spill"] or r["scratch"] or r["sgpr_spill"]:
+                    problems.append("%s spills: %s" % (n, r))
+                if r["vgpr"] > cap:
+                    problems.append("%s uses %d VGPRs (budget %d)" % (n, r["vgpr"], cap))
+        res.update(res_x)
     for frag, cap in BUDGET.items():
         hits = [(n, r) for n, r in res.items() if frag in n]
         if not hits:
@@ -78,7 +97,7 @@ def check():
 
 if __name__ == "__main__":
     res, problems = check()
-    for frag in BUDGET:
+    for frag in list(BUDGET) + list(BUDGET_STAGE) + list(BUDGET_GENERIC):
         for n, r in res.items():
             if frag in n:
                 print("%-70s %s" % (n[18:88], r))
