@@ -476,9 +476,11 @@ class GraphedTrainStep:
     (tests/test_train_step.py::test_graphed_train_step_replays_the_eager_step_bit_for_bit).  The whole W4A8 network
     (backbone and heads under autograd are PyTorch-ROCm ops) captures too and, run on its own, reproduces an eager run's
     losses to the last digit at 2.2 x the eager speed (9.3 vs 20.6 ms, batch 8 at 256 x 256) -- but PyTorch's own
-    backbone backward is not run-to-run deterministic, and with a SECOND model training eagerly in the same process
-    between the replays the replayed losses were wrong in one experiment (round 5, not understood): use one model per
-    process with it until that is.  `warmup` eager steps run first on a side stream (they DO train: allocator and
+    backbone backward is not run-to-run deterministic (two eager runs part ways at the fifth step), so there is no
+    bit-level check for it.  One open observation (round 5): a second whole-network model that was constructed BEFORE the
+    capture and took its FIRST eager steps after it made the next two replays return wrong losses (with the second model
+    constructed after the capture, on the same or another stream, every replay was right): construct and warm up other
+    models before capturing, or keep one model per process.  `warmup` eager steps run first on a side stream (they DO train: allocator and
     lazily derived tensors settle before capture)."""
 
     def __init__(self, net, optimizer, loss_fn, example_inputs, warmup=3):
