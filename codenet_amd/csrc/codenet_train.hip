@@ -832,8 +832,7 @@ pwn_prep_kernel(const float *__restrict__ wq, int Co, int C, int Cot, int Ct, si
   // Both integer forms of the weights in one launch: workgroup = sixteen output channels (one wave each).
   //   kb [window][column][32]  int8, k-blocked: the A operand of pwi8n_kernel (forward); zero columns behind Co;
   //   wt [co / 16][c][16]      bf16, transposed: the A operand of pwb3n_kernel (data gradient); zero rows behind C.
-  // A row holds q / ws with |q| <= 8 and its largest magnitude is 7 / ws (the channel's own extreme maps to +-7) or
-  // 8 / ws (--wt-percentile clamps): ws is recovered as 7 / max or 8 / max, whichever makes every w ws an integer.
+  // A row holds q / ws with |q| <= 8 (weight_bit <= 4); ws is recovered from the row itself, see below.
   extern __shared__ signed char prep_codes[];      // [16][C]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int co = blockIdx.x * 16 + w;
@@ -854,22 +853,31 @@ pwn_prep_kernel(const float *__restrict__ wq, int Co, int C, int Cot, int Ct, si
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) mag = fmaxf(mag, __shfl_xor(mag, m, 64));
-  float ws = mag > 0.0f ? __fdiv_rn(7.0f, mag) : 1.0f;
-  if (co < Co) {
-    bool ok = true;
-    if (cached) {
+  // ws = m / max|w_q| with m the row's largest code magnitude: n = 2^(bits-1) - 1 (the channel's own extreme maps to +-n),
+  // n + 1 when --wt-percentile clamps, so m is 1 ... 8 for the <= 4-bit weights this path admits.  The SMALLEST m that
+  // makes every w ws an integer is taken: it is the true one divided by the codes' common factor -- the same real
+  // values q / ws (a wrong m < the true one leaves a fractional part of a multiple of 1 / 8 or more: never accepted).
+  // No m fits (the row is not a <= 4-bit grid): ws = NaN, the outputs of that channel are NaN -- loud, never wrong codes.
+  float ws = 1.0f;
+  if (co < Co && mag > 0.0f) {
+    ws = __builtin_nanf("");
+    for (int m = 8; m >= 1; --m) {
+      const float cand = __fdiv_rn((float)m, mag);
+      bool ok = true;
+      if (cached) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float t = rv[u] * ws;
-        ok &= fabsf(t - rintf(t)) < 0.02f;
+        for (int u = 0; u < 16; ++u) {
+          const float t = rv[u] * cand;
+          ok &= fabsf(t - rintf(t)) < 0.02f;
+        }
+      } else {
+        for (int k = lane; k < C; k += 64) {
+          const float t = row[k] * cand;
+          ok &= fabsf(t - rintf(t)) < 0.02f;
+        }
       }
-    } else {
-      for (int k = lane; k < C; k += 64) {
-        const float t = row[k] * ws;
-        ok &= fabsf(t - rintf(t)) < 0.02f;
-      }
+      if (__all(ok)) ws = cand;
     }
-    if (!__all(ok)) ws = __fdiv_rn(8.0f, mag);
   }
   int sum = 0;
   auto emit = [&](int k, float v) {
@@ -1185,8 +1193,9 @@ struct PwnPlan {
   size_t off_wt, off_rws;
 };
 static bool pwn_plan(int64_t N, int64_t C, int64_t Co, int64_t HW, PwnPlan *p) {
-  if (N <= 0 || N > 65535 || C < 32 || (C & 31) || HW < 32 || (HW & 31) || Co < 1 || Co > 512 || C * HW >= (1ll << 31) ||
-      Co * HW >= (1ll << 31))
+  // C <= 4096: pwn_prep_kernel keeps sixteen code rows of C bytes in LDS (64 KB)
+  if (N <= 0 || N > 65535 || C < 32 || (C & 31) || C > 4096 || HW < 32 || (HW & 31) || Co < 1 || Co > 512 ||
+      C * HW >= (1ll << 31) || Co * HW >= (1ll << 31))
     return false;
   p->tn = Co <= 64 ? 2 : 4;
   p->ncg = (int)cdn::ceil_div(Co, 32 * p->tn);
@@ -1232,7 +1241,7 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
   CDN_REQUIRE(d && d_state && w_q && y && workspace, CDN_ERR_ARG, "null pointer");
   PwnPlan p;
   CDN_REQUIRE(pwn_plan(N, C, Co, HW, &p), CDN_ERR_UNSUPPORTED,
-              "int8 forward needs C %% 32 == 0, HW %% 32 == 0, Co <= 512 (cdn_codenet_pointwise_i8_supported)");
+              "int8 forward needs C %% 32 == 0, C <= 4096, HW %% 32 == 0, Co <= 512 (cdn_codenet_pointwise_i8_supported)");
   CDN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && workspace_bytes >= p.bytes, CDN_ERR_WORKSPACE,
               "workspace missing, too small or not 256-byte aligned");
   hipStream_t st = cdn::as_stream(stream);
@@ -1241,7 +1250,6 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
   int *wsum = reinterpret_cast<int *>(kb + p.off_sum);
   unsigned short *wt = reinterpret_cast<unsigned short *>(kb + p.off_wt);
   float *rws = reinterpret_cast<float *>(kb + p.off_rws);
-  CDN_REQUIRE(C <= 4096, CDN_ERR_UNSUPPORTED, "C <= 4096 (sixteen code rows in LDS)");
   if (16 * C > 48 * 1024)
     (void)hipFuncSetAttribute((const void *)pwn_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * C));
   pwn_prep_kernel<<<(unsigned)(p.cot / 16), 1024, (size_t)16 * C, st>>>(w_q, (int)Co, (int)C, p.cot, p.ct, kb, wscale, wsum,
@@ -1269,13 +1277,13 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
 // ---- data gradient of conv_channel on bf16 MFMA (pwb3n_kernel) ----------------------------------------------------------
 extern "C" int cdn_codenet_pointwise_dgrad_q4_supported(int64_t N, int64_t C, int64_t Co, int64_t HW) {
   PwnPlan p;
-  return pwn_plan(N, C, Co, HW, &p) && C <= 4096 ? 1 : 0;
+  return pwn_plan(N, C, Co, HW, &p) ? 1 : 0;
 }
 extern "C" int cdn_codenet_pointwise_dgrad_q4(const float *grad_y, const void *fwd_workspace, float *grad_d, int64_t N,
                                               int64_t C, int64_t Co, int64_t HW, void *stream) {
   CDN_REQUIRE(grad_y && fwd_workspace && grad_d, CDN_ERR_ARG, "null pointer");
   PwnPlan p;
-  CDN_REQUIRE(pwn_plan(N, C, Co, HW, &p) && C <= 4096, CDN_ERR_UNSUPPORTED,
+  CDN_REQUIRE(pwn_plan(N, C, Co, HW, &p), CDN_ERR_UNSUPPORTED,
               "fwd_workspace is that of cdn_codenet_pointwise_i8_forward_range: the shape must be supported there");
   hipStream_t st = cdn::as_stream(stream);
   const char *base = static_cast<const char *>(fwd_workspace);

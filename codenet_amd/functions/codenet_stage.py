@@ -28,17 +28,14 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-_wgrad_ws = {}
-
-
 def _workspace(nbytes, device):
-    """Split-K scratch of the weight-gradient kernel, one per (device, stream), grown on demand."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
-        _wgrad_ws[key] = ws
-    return ws
+    """Scratch of one native call (split-K partials, per-workgroup partial sums), owned by that call: a fresh tensor from
+    the caching allocator -- under stream capture from the capturing graph's private pool, so a graph owns every address
+    it recorded.  (Rounds 4-5 kept one buffer per (device, stream) in a module-global dict, grown by re-allocation: entries
+    leaked with every side stream, a recycled stream handle found a stale buffer, and two captures on the shared capture
+    stream shared one buffer that lived in the first graph's pool -- ADVICE r5.)  An allocation from the cache costs
+    about a microsecond of host time; stream-ordered reuse by the allocator gives the same memory back every step."""
+    return torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
 
 
 # A/B switch (tools/train_step_bench.py --no-bf16-wgrad): exact bf16 products on the integer form of d
@@ -72,18 +69,6 @@ def pointwise_wgrad(grad_y, d, want_bias, d_state=None):
 # per-workgroup partials reduced in a fixed order (cdn_codenet_dw_backward_r) instead of float atomics -- two identical
 # runs of a QAT step then give bit-identical parameters.
 REPRODUCIBLE_DW_BWD = True
-
-_dwbwd_ws = {}
-
-
-def _dw_bwd_workspace(nbytes, device):
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _dwbwd_ws.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=device)
-        _dwbwd_ws[key] = ws
-    return ws
-
 
 # A/B switch (tools/train_step_bench.py --no-fuse-dq): d fake-quantised by its consumers while loading (True) or stored
 # fake-quantised by a pass of its own (False).  Same values either way.
@@ -186,7 +171,7 @@ class CodenetStageFunction(Function):
             args = (_p(x), _p(s), _p(w_dw.contiguous()), _p(gd), _p(gx), _p(gs), _p(g_wdw), Nb, C, Hf, Wf)
             nws = lib.cdn_codenet_dw_backward_workspace_bytes(Nb, C, Hf, Wf, int(up2)) if REPRODUCIBLE_DW_BWD else 0
             if nws:        # (0: no reproducible form for a plane beyond LDS -- the atomic one below)
-                ws = _dw_bwd_workspace(nws, x.device)
+                ws = _workspace(nws, x.device)
                 fn = lib.cdn_codenet_dw_up2_backward_r if up2 else lib.cdn_codenet_dw_backward_r
                 N_.check(fn(*args, _p(ws), ops._stream(x)), "cdn_codenet_dw_backward_r")
             else:

@@ -633,6 +633,7 @@ class FusedHotPath:
         return True
 
     # -- per-stage parameter views -------------------------------------------------------------
+    @torch.no_grad()      # inference schedule: derived weights come from the modules' caches, never an autograd graph
     def _stage_params(self, st):
         if self.quantized:
             q, post = st[0], st[1]
@@ -770,14 +771,8 @@ class FusedHotPath:
         from . import _native as N_
         st = act._device_state(dev)
         f = st.view(torch.float32)
-        t = torch.stack((-f[4], f[5]))                   # one MAX all-reduce for both ends
-        if dist.get_backend() == "gloo":                 # (tests on one GPU: gloo reduces on the host)
-            th = t.cpu()
-            dist.all_reduce(th, op=dist.ReduceOp.MAX)
-            t.copy_(th)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)     # RCCL over xGMI, 8 bytes, on the current stream
-        t[0].neg_()
+        from .portable_quantizer.quant_modules import allreduce_extremes
+        t = allreduce_extremes(f[4:5], f[5:6])           # one MAX all-reduce for both ends + the NaN flag
         rc = N_.lib().cdn_quantact_commit_range(act.x_min.data_ptr(), act.x_max.data_ptr(), st.data_ptr(), t.data_ptr(),
                                                 bits, mom, 1, stream)
         N_.check(rc, "cdn_quantact_commit_range")

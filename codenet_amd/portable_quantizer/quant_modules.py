@@ -160,6 +160,26 @@ class _WeightQuantizer:
         self._i8_cache = None
 
 
+def allreduce_extremes(bmin, bmax):
+    """{min, max} over all ranks as a 2-element tensor, from ONE MAX all-reduce of {-min, max, nan flag}.  A NaN on any
+    rank makes both ends NaN on every rank, as x.min() / x.max() of the union would be (quant_modules.py:203-219 of the
+    reference on the whole batch) -- the backends' MAX does not propagate it by itself (gloo drops it).  gloo reduces on
+    the host (the tests on one GPU)."""
+    import torch.distributed as dist
+    t = torch.cat((-bmin.reshape(1), bmax.reshape(1), bmin.new_zeros(1)))
+    bad = torch.isnan(t[:2]).any()
+    t = torch.where(torch.isnan(t), torch.full_like(t, float("-inf")), t)
+    t[2] = bad.to(t.dtype)
+    if t.is_cuda and dist.get_backend() == "gloo":
+        th = t.cpu()
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        t.copy_(th)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)         # RCCL over xGMI: 12 bytes on the current stream
+    out = torch.stack((-t[0], t[1]))
+    return torch.where(t[2] > 0, torch.full_like(out, float("nan")), out)
+
+
 class QuantAct(Module):
     """Activation fake-quantiser with tracked range (reference :163-225).  `running_stat` stays
     True in eval() exactly as in the reference (nothing ever clears it); set it to False for
@@ -209,10 +229,8 @@ class QuantAct(Module):
             raise NotImplementedError("QuantAct: global_range with percentile statistics is not defined "
                                       "(a percentile of the union is not a function of the ranks' percentiles)")
         xd = x.detach()
-        bmin, bmax = xd.min().reshape(1).contiguous(), xd.max().reshape(1).contiguous()
-        dist.all_reduce(bmin, op=dist.ReduceOp.MIN)
-        dist.all_reduce(bmax, op=dist.ReduceOp.MAX)
-        return bmin, bmax
+        t = allreduce_extremes(xd.min().reshape(1), xd.max().reshape(1))
+        return t[0:1].contiguous(), t[1:2].contiguous()
 
     def _native_ok(self, x):
         return (x.is_cuda and x.dtype == torch.float32 and self.quant_mode == "asymmetric"
@@ -353,8 +371,11 @@ class QuantBnConv2d(Module, _WeightQuantizer):
         if i8 is None:
             return None
         codes, scale, colsum = i8
-        key = (codes.data_ptr(), codes._version, int(columns), int(offset))
-        cache = getattr(self, "_kb_cache", None)
+        # keyed on the SOURCE tensors, as _cached_i8 is (with grad enabled folded_int8() returns a fresh
+        # temporary per call, whose recycled address + version 0 could hit a stale buffer): under grad nothing is cached
+        src = (self.conv.weight, self.bn.weight, self.bn.running_var)
+        key = tuple((t.data_ptr(), t._version, t.device) for t in src) + (int(columns), int(offset))
+        cache = None if torch.is_grad_enabled() else getattr(self, "_kb_cache", None)
         if cache is None or cache[0] != key:
             with torch.no_grad():
                 co, cpad = codes.shape
@@ -364,6 +385,8 @@ class QuantBnConv2d(Module, _WeightQuantizer):
                 buf = torch.zeros(int(offset) + kb.numel(), dtype=torch.int8, device=codes.device)
                 buf[:co * cpad] = codes.reshape(-1)
                 buf[int(offset):] = kb.reshape(-1)
+                if torch.is_grad_enabled():
+                    return buf, scale, colsum
                 self._kb_cache = (key, refresh_in_place(cache[1] if cache else None, buf))
         return self._kb_cache[1], scale, colsum
 

@@ -202,8 +202,10 @@ int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, flo
  * integer codes of both operands are summed exactly, y = (sum_c (L_c + zp) q_c) / (scale ws) + bias, as the inference
  * schedule does, instead of multiplying their fp32 forms on f32 MFMA (one rounding instead of C; agrees with
  * cdn_codenet_pointwise_forward_range to fp32 summation noise, equal on exact-arithmetic inputs).  A batch whose codes are
- * too wide for the kernel's nibble split (state word 6) runs on f32 MFMA inside the same launch.
- *   ..._supported: C % 32 == 0, HW % 32 == 0, Co <= 512;  workspace: ..._workspace_bytes, 256-byte aligned, contents
+ * too wide for the kernel's nibble split (state word 6) runs on f32 MFMA inside the same launch.  The per-channel weight
+ * scale is recovered from each row as m / max|w_q| with the smallest m in 1 ... 8 that puts the whole row on integers (any
+ * weight_bit <= 4, --wt-percentile clamping included); a row that is on no such grid yields NaN outputs for its channel.
+ *   ..._supported: C % 32 == 0, C <= 4096, HW % 32 == 0, Co <= 512;  workspace: ..._workspace_bytes, 256-byte aligned, contents
  *   irrelevant (the k-blocked weight codes are rebuilt by every call: the weights change every step);
  *   partials: ..._range_partials pairs, or NULL.
  * Reference: conv_channel under autograd, quant_modules.py:412-419 (F.conv2d on the fake-quantised operands). */

@@ -87,6 +87,39 @@ def _set_ranges(dst, src):
     return len(sd)
 
 
+def prepare_pair(mode, res, batch, seed, dev, edit=None, margin=0.05):
+    """(cpu model, gpu model, info) for one mode of the proxies: one synthetic-weight network (seed 317) on both sides;
+    edit(model): applied to the common base before the copies (tests/proxy_ap.py gives the wh head well-formed boxes).
+    w4a8_frozen / w4a8_frozen_bytes: ONE common set of ranges -- the GPU network's running ranges settled on calibration
+    batches, (bytes: widened by the serving calibration until no code saturates,) copied into the CPU model; both frozen."""
+    from codenet_amd import harness, pipeline
+    quant = mode != "fp32"
+    base = harness.create_model(quantize=quant, seed=317)
+    if edit is not None:
+        edit(base)
+    cpu, gpu = copy.deepcopy(base), copy.deepcopy(base).to(dev)
+    info = {}
+    if mode in ("w4a8_frozen", "w4a8_frozen_bytes"):
+        cal = torch.randn(batch, 3, res, res, generator=torch.Generator().manual_seed(seed + 999)).to(dev)
+        gpu.enable_fused()
+        with torch.no_grad():
+            for _ in range(60):
+                gpu(cal)
+        pipeline.set_running_stat(gpu, False)
+        if mode == "w4a8_frozen_bytes":
+            # serving calibration on the byte schedule itself over several batches of the image distribution (a
+            # byte cannot hold what the reference's unclamped codes can: pipeline.calibrate_serving only widens)
+            gc = torch.Generator().manual_seed(seed + 1999)
+            cals = [cal] + [torch.randn(batch, 3, res, res, generator=gc).to(dev) for _ in range(7)]
+            info["calibration"] = pipeline.calibrate_serving(gpu, cals, margin=margin)
+        info["ranges_copied"] = _set_ranges(cpu, gpu)
+        pipeline.set_running_stat(cpu, False)
+        gpu.enable_fused(frozen_codes=(mode == "w4a8_frozen_bytes"))
+    else:
+        gpu.enable_fused()
+    return cpu, gpu, info
+
+
 def compare(images=256, res=512, batch=8, seed=0, modes=("fp32", "w4a8_frozen", "w4a8_frozen_bytes", "w4a8_running"),
             threads=None, log=None, yard_images=16):
     from codenet_amd import harness, pipeline
@@ -109,30 +142,8 @@ def compare(images=256, res=512, batch=8, seed=0, modes=("fp32", "w4a8_frozen", 
         for mode in modes:
             t0 = time.perf_counter()
             quant = mode != "fp32"
-            base = harness.create_model(quantize=quant, seed=317)
-            cpu, gpu = copy.deepcopy(base), copy.deepcopy(base).to(dev)
+            cpu, gpu, info = prepare_pair(mode, res, batch, seed, dev)
             g = torch.Generator().manual_seed(seed)
-            info = {}
-            if mode in ("w4a8_frozen", "w4a8_frozen_bytes"):
-                # ONE common set of ranges: the GPU network's running ranges settled on calibration batches, (bytes: widened
-                # by the serving calibration until no code saturates,) copied into the CPU model; both frozen
-                cal = torch.randn(batch, 3, res, res, generator=torch.Generator().manual_seed(seed + 999)).to(dev)
-                gpu.enable_fused()
-                with torch.no_grad():
-                    for _ in range(60):
-                        gpu(cal)
-                pipeline.set_running_stat(gpu, False)
-                if mode == "w4a8_frozen_bytes":
-                    # serving calibration on the byte schedule itself over several batches of the image distribution (a
-                    # byte cannot hold what the reference's unclamped codes can: pipeline.calibrate_serving only widens)
-                    gc = torch.Generator().manual_seed(seed + 1999)
-                    cals = [cal] + [torch.randn(batch, 3, res, res, generator=gc).to(dev) for _ in range(7)]
-                    info["calibration"] = pipeline.calibrate_serving(gpu, cals, margin=0.05)
-                info["ranges_copied"] = _set_ranges(cpu, gpu)
-                pipeline.set_running_stat(cpu, False)
-                gpu.enable_fused(frozen_codes=(mode == "w4a8_frozen_bytes"))
-            else:
-                gpu.enable_fused()
             worst_sig, agree, n_img, overflow = 0.0, [], 0, 0
             sites, yard, yard_sites, cpu_before = [], [], [], None
             means = {"hm": 0.0, "wh": 0.0, "reg": 0.0}

@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.nn as nn
 
@@ -204,3 +205,38 @@ def test_transform_preds_and_ctdet_post_process_reproduce_the_reference():
             assert got.shape == want.shape and (got.size == 0 or np.abs(got - want).max() < 2e-4), (b, j)
             total += want.shape[0]
     assert total == 150
+
+
+def test_proxy_ap_bookkeeping_on_synthetic_detections():
+    """tests/proxy_ap.py's host side (no GPU, no network): detections -> evaluator rows through the pipeline's own
+    post-processing, the pseudo-ground-truth threshold, AP50 = 1 for a run against its own top detections, a lower AP for a
+    run that lost half of them, 0 for boxes moved off their ground truth."""
+    from tests import proxy_ap as A
+    ev = A._eval_voc()
+    g = torch.Generator().manual_seed(5)
+    n, K = 6, 40
+    cx, cy = torch.rand(n, K, generator=g) * 100 + 10, torch.rand(n, K, generator=g) * 100 + 10
+    score = torch.rand(n, K, generator=g).sort(dim=1, descending=True).values
+    cls = torch.randint(0, 20, (n, K), generator=g).float()
+    dets = torch.stack([cx - 3, cy - 3, cx + 3, cy + 3, score, cls], 2)
+    rows = A.Rows(512)
+    rows.add(dets[:3], 0)
+    rows.add(dets[3:], 3)
+    assert rows.images == 6 and sum(len(v) for v in rows.rows.values()) == n * K
+    x1 = [r for v in rows.rows.values() for r in v if r[0] == 0][0]
+    assert 0 <= x1[2] < x1[4] <= 512 and abs((x1[4] - x1[2]) - 24.0) < 1e-3            # output pixels x 4
+    gts, thr, count = A.ground_truth(rows, 8)
+    assert count == 48 and thr == sorted(score.flatten().tolist(), reverse=True)[47]
+    ap, ncls = A.ap50(ev, rows, gts)
+    assert ap == pytest.approx(1.0) and ncls == sum(1 for c in gts if gts[c])
+    half = A.Rows(512)
+    half.add(dets[:, ::2], 0)
+    ap_half, _ = A.ap50(ev, half, gts)
+    assert 0.2 < ap_half < 0.9
+    moved = A.Rows(512)
+    far = dets.clone()
+    far[:, :, :4] += 20.0
+    moved.add(far, 0)
+    assert A.ap50(ev, moved, gts)[0] == 0.0
+    sub = rows.subset(2)
+    assert sub.images == 2 and all(r[0] < 2 for v in sub.rows.values() for r in v)

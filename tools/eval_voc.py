@@ -217,6 +217,10 @@ def main():
     ap.add_argument("--proxy-images", type=int, default=0, help="without data / checkpoint: also run the detection-"
                     "agreement proxy on this many synthetic images (tests/proxy_agreement.py; SURVEY 8(d) asks for >= 256)")
     ap.add_argument("--proxy-out", default="", help="JSON file for the at-size proxy")
+    ap.add_argument("--proxy-ap", type=int, default=0, help="without data / checkpoint: the AP50-DELTA proxy on this many "
+                    "synthetic images -- pseudo ground truth from the fp32 CPU-oracle path, CPU-W4A8 and GPU-W4A8 detections "
+                    "(running / frozen / byte serving) scored by this file's voc_eval (tests/proxy_ap.py)")
+    ap.add_argument("--proxy-ap-out", default="", help="JSON file for the AP50-delta proxy")
     ap.add_argument("--reference-ap50", type=float, default=None, help="the reference's AP50 for this config "
                     "(README.md:14-18) to print the delta")
     args = ap.parse_args()
@@ -233,6 +237,15 @@ def main():
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             cmd = [sys.executable, os.path.join(root, "tests", "proxy_agreement.py"), "--images", str(args.proxy_images),
                    "--res", str(args.res)] + (["--out", args.proxy_out] if args.proxy_out else [])
+            rc = subprocess.call(cmd)
+            if rc:
+                sys.exit(rc)
+        if args.proxy_ap > 0:
+            # the AP50-delta proxy through voc_eval (VERDICT r5 missing #1); uses oracle/ too: a child process of tests/
+            import subprocess
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            cmd = [sys.executable, os.path.join(root, "tests", "proxy_ap.py"), "--images", str(args.proxy_ap),
+                   "--res", str(args.res)] + (["--out", args.proxy_ap_out] if args.proxy_ap_out else [])
             sys.exit(subprocess.call(cmd))
 
 
