@@ -93,7 +93,7 @@ def set_running_stat(net, flag):
             m.running_stat = flag
 
 
-def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
+def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2, spread=None):
     """Deployment step for the byte-code serving mode.  With ``running_stat = False`` the reference keeps the EMA
     ranges it trained with (quant_modules.py:203-219 skipped) and a value outside such a range simply becomes a code
     beyond the 8-bit grid (the fake-quantised float has no clamp, quant_utils.py:132-171).  A byte cannot hold that code
@@ -103,7 +103,9 @@ def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
     QuantAct frozen, records what each one is fed, and WIDENS x_min / x_max (never narrows) to cover it with `margin` of
     the span to spare; two passes, since moving a grid moves what the layers behind it see.  It changes the model's
     quantisation grids -- the same widened model is what the fp32 frozen schedule is compared on.  Returns the number of
-    QuantActs whose range moved."""
+    QuantActs whose range moved.  spread (a dict, round 6): receives id(act) -> (sigma_lo, sigma_hi), the standard
+    deviations of the per-BATCH extremes over the calibration batches of the last pass (what calibrate_serving's
+    `sigmas` policy prices the tail of unseen batches with); needs >= 2 batches."""
     from .portable_quantizer.quant_modules import QuantAct
     acts = [m for m in net.modules() if isinstance(m, QuantAct)]
     was = [a.running_stat for a in acts]
@@ -113,7 +115,7 @@ def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
         for a in acts:
             a.running_stat = False
         for _ in range(passes):
-            seen = {}
+            seen, per_batch, cur = {}, {}, [0]
 
             def hook(mod, args):
                 x = args[0].detach()
@@ -122,10 +124,16 @@ def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
                     seen[id(mod)] = (torch.minimum(seen[id(mod)][0], lo), torch.maximum(seen[id(mod)][1], hi))
                 else:
                     seen[id(mod)] = (lo, hi)
+                pb = per_batch.setdefault(id(mod), {})      # (a QuantAct shared by several call sites: one pair per batch)
+                if cur[0] in pb:
+                    pb[cur[0]] = (torch.minimum(pb[cur[0]][0], lo), torch.maximum(pb[cur[0]][1], hi))
+                else:
+                    pb[cur[0]] = (lo, hi)
             handles = [a.register_forward_pre_hook(hook) for a in acts]
             try:
                 with torch.no_grad():
-                    for b in batches:
+                    for bi, b in enumerate(batches):
+                        cur[0] = bi
                         forward(b)
             finally:
                 for h_ in handles:
@@ -146,6 +154,13 @@ def cover_frozen_ranges(net, batches, forward=None, margin=0.02, passes=2):
                         moved.add(id(a))
                     a.x_min.copy_(new_lo.reshape(a.x_min.shape))
                     a.x_max.copy_(new_hi.reshape(a.x_max.shape))
+            if spread is not None:
+                for a in acts:
+                    pb = per_batch.get(id(a))
+                    if pb and len(pb) >= 2:
+                        los = torch.stack([v[0] for v in pb.values()]).double()
+                        his = torch.stack([v[1] for v in pb.values()]).double()
+                        spread[id(a)] = (float(los.std()), float(his.std()))
     finally:
         for a, f in zip(acts, was):
             a.running_stat = f
@@ -216,7 +231,7 @@ def _widen(act, frac, low_too):
             act.x_min.copy_((lo - span).reshape(act.x_min.shape))
 
 
-def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40):
+def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40, sigmas=0.0):
     """Calibration of the byte-code serving mode ON THE SCHEDULE THAT SERVES.
 
     cover_frozen_ranges() records what the MODULE path feeds every QuantAct; the byte network's exact-integer first
@@ -226,12 +241,24 @@ def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40):
     runs the calibration batches; every launch that saturated a code names its QuantAct(s) through its own flag word
     (OverflowFlags) and exactly those ranges are widened by `grow` of their span -- repeated until a whole pass is
     clean; (3) every range gets `margin` of its span to spare and the pass is repeated until clean again.  Only widens.
-    Leaves the model frozen (running_stat False) and on the byte schedule.  Returns a dict (iterations, widened, clean)."""
+    Leaves the model frozen (running_stat False) and on the byte schedule.  Returns a dict (iterations, widened, clean).
+
+    sigmas > 0 (round 6, VERDICT r5 weak #5: ranges that are clean on the calibration batches with 2 % to spare saturated a
+    byte in 8 of 32 UNSEEN batches): the margin of step (3) is priced per QuantAct from the spread of its per-batch
+    extremes over the calibration batches (>= 4 of them) -- each live end moves out by a further `sigmas` standard
+    deviations of that end's batch extreme.  Batch extremes are maxima of ~10^6 values: Gumbel-like with scale
+    beta = 0.78 sigma; the largest of m calibration batches sits ~ beta ln m above the location, a fresh batch exceeds
+    location + t beta with probability e^-t, and with ~140 QuantActs a batch-level recompute rate below 2 % asks for
+    t ~ 9, i.e. ~ 5-6 sigma beyond the calibration extreme at m = 8.  The price is resolution: every grid gets coarser by the
+    widening (reported as `mean_widening`).  The alternative is the saturating policy: serve what the byte schedule
+    produced and do not recompute."""
     from .portable_quantizer.quant_modules import QuantAct
     acts = [m for m in model.modules() if isinstance(m, QuantAct)]
     set_running_stat(model, False)
     model.enable_fused(False)
-    covered = cover_frozen_ranges(model, batches, margin=0.0)
+    spread = {} if (sigmas > 0 and len(batches) >= 4) else None
+    covered = cover_frozen_ranges(model, batches, margin=0.0, spread=spread)
+    span0 = {id(a): float(a.x_max.reshape(()) - a.x_min.reshape(())) for a in acts}
     model.enable_fused(frozen_codes=True)
     # attribution needs one launch per QuantAct: the depthwise-into-pointwise fusion of the byte backbone writes two
     # QuantActs' codes from one launch (bit-identical to the two kernels), so it is off while calibrating
@@ -270,9 +297,16 @@ def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40):
         with torch.no_grad():
             model(batches[0])                   # builds the byte-code objects
         clean = until_clean()
-        if clean and margin > 0:
-            for a in acts:
-                _widen(a, margin, bool(a.x_min.reshape(()) < 0))
+        if clean and (margin > 0 or spread):
+            with torch.no_grad():
+                for a in acts:
+                    low_live = bool(a.x_min.reshape(()) < 0)
+                    if margin > 0:
+                        _widen(a, margin, low_live)
+                    s_lo, s_hi = (spread or {}).get(id(a), (0.0, 0.0))
+                    a.x_max.add_(sigmas * s_hi)
+                    if low_live:
+                        a.x_min.sub_(sigmas * s_lo)
             clean = until_clean()
     finally:
         fz = getattr(model, "_fzbackbone", None)
@@ -283,15 +317,20 @@ def calibrate_serving(model, batches, margin=0.02, grow=0.04, max_iter=40):
             for b in batches:               # the serving configuration itself (fused depthwise) must be clean too
                 model(b)
         clean = clean and not model.frozen_overflowed()
+    widening = [float(a.x_max.reshape(()) - a.x_min.reshape(())) / max(span0[id(a)], 1e-12) for a in acts if span0[id(a)] > 0]
     return {"iterations": iters, "covered_on_module_path": covered, "widened_on_byte_schedule": len(widened),
-            "clean": bool(clean), "byte_backbone": fz is not None}
+            "clean": bool(clean), "byte_backbone": fz is not None, "calibration_batches": len(batches),
+            "sigmas": float(sigmas) if spread is not None else 0.0, "margin": float(margin),
+            "mean_widening": (sum(widening) / len(widening)) if widening else 1.0,
+            "max_widening": max(widening) if widening else 1.0}
 
 
-def prepare_serving(model, images, settle=300, margin=0.02, replay=None):
+def prepare_serving(model, images, settle=300, margin=0.02, replay=None, more_batches=(), sigmas=0.0):
     """The serving recipe bench.py's `e2e.frozen` leg times and tests/test_harness.py checks on three seeds: let the
     running (EMA) ranges settle over `settle` forwards of `images` (replay: an already captured graph of the running
-    network), freeze every QuantAct, calibrate ON THE BYTE SCHEDULE (calibrate_serving).  Leaves the model on
-    enable_fused(frozen_codes=True); returns calibrate_serving's report."""
+    network), freeze every QuantAct, calibrate ON THE BYTE SCHEDULE (calibrate_serving) over `images` + `more_batches`
+    (sigmas: its tail policy for unseen batches).  Leaves the model on enable_fused(frozen_codes=True); returns
+    calibrate_serving's report."""
     if replay is None:
         model.enable_fused()
         with torch.no_grad():
@@ -301,7 +340,7 @@ def prepare_serving(model, images, settle=300, margin=0.02, replay=None):
         for _ in range(settle):
             replay()
     torch.cuda.synchronize()
-    return calibrate_serving(model, [images], margin=margin)
+    return calibrate_serving(model, [images] + list(more_batches), margin=margin, sigmas=sigmas)
 
 
 def broadcast_parameters(net, src=0):
@@ -466,24 +505,40 @@ class GraphedTrainStep:
     1.05 ms of GPU work).  Captured once, the step replays without the host in the loop.  Every
     sum of the step has a fixed order (section 4.3), so a replayed step is bit-identical to the eager one.
 
-        opt = torch.optim.Adam(net.parameters(), lr=1.25e-4, capturable=True)      # optimizers must be capturable
+        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(1.25e-4, device=dev), capturable=True)
         step = GraphedTrainStep(net, opt, loss_fn, example_inputs)                  # loss_fn(net, *inputs) -> scalar
         for batch in loader:
             loss = step(*batch)           # copies the batch into the static buffers, replays; loss: a static tensor
+            step.set_lr(schedule(it))     # (a learning rate held as a Python float is a constant of the graph)
 
     Shapes are fixed at capture; QuantAct running ranges, BatchNorm buffers and the optimizer state advance in place
-    exactly as in the eager loop.  Validated bit for bit on the deform-stage stack
-    (tests/test_train_step.py::test_graphed_train_step_replays_the_eager_step_bit_for_bit).  The whole W4A8 network
-    (backbone and heads under autograd are PyTorch-ROCm ops) captures too and, run on its own, reproduces an eager run's
-    losses to the last digit at 2.2 x the eager speed (9.3 vs 20.6 ms, batch 8 at 256 x 256) -- but PyTorch's own
-    backbone backward is not run-to-run deterministic (two eager runs part ways at the fifth step), so there is no
-    bit-level check for it.  One open observation (round 5): a second whole-network model that was constructed BEFORE the
-    capture and took its FIRST eager steps after it made the next two replays return wrong losses (with the second model
-    constructed after the capture, on the same or another stream, every replay was right): construct and warm up other
-    models before capturing, or keep one model per process.  `warmup` eager steps run first on a side stream (they DO train: allocator and
-    lazily derived tensors settle before capture)."""
+    exactly as in the eager loop.  `warmup` eager steps run first on a side stream (they DO train: allocator and lazily
+    derived tensors settle before capture); the capture records on that same stream.
 
-    def __init__(self, net, optimizer, loss_fn, example_inputs, warmup=3):
+    SCOPE (round 6).  Validated -- and accepted without `unvalidated=True` -- is the stack of deform stages
+    (``pipeline.build_hot_path`` / a quantised ``deconv_layers``): every kernel of that step is this library's, every sum
+    has one order, and tests/test_train_step.py::test_graphed_train_step_* show replays bit-identical to the eager step and
+    bit-identical from a restored state whatever else the process does in between (a second model built before the capture
+    taking its first eager steps, another framework model training, the allocator's free memory filled with NaN).
+    A network that also runs PyTorch-ROCm operators under autograd (the whole CoDeNet: backbone and heads) needs
+    `unvalidated=True`; what was measured for it (tools/experiments/gts_probe*.py):
+      * parameters and gradients of a replay agree with any other replay FROM THE SAME STATE to ~1e-6 of their magnitude --
+        with or without other work in between.  That residue is the framework's own backward (atomics), present in two
+        eager runs too; after a quantiser amplifies it the loss trajectories of two runs part ways in the fifth digit by
+        the second step.  This -- not memory corruption -- is what round 5 recorded as "wrong losses after a second model's
+        first steps": poisoning every free byte of the allocator with NaN between replays changes nothing;
+      * the scalar LOSS a replay returns can be stale in one situation: loss_fn reduces a large tensor with one
+        ``mean()`` / ``sum()`` (ATen's multi-block reduction: a semaphore word zeroed by a memset node), and another model
+        takes its FIRST eager step between two replays -- that replay's reduction leaves its output unwritten while the
+        gradients and parameters of the same replay are right (the backward of a mean does not read its value).  A
+        two-level reduction (``v.square().reshape(-1, 64).sum(1).sum() / v.numel()``: no semaphore) does not show it."""
+
+    def __init__(self, net, optimizer, loss_fn, example_inputs, warmup=3, unvalidated=False):
+        if not unvalidated and not self.is_stage_stack(net):
+            raise NotImplementedError(
+                "GraphedTrainStep is validated (bit-identical replays) for a stack of quantised deform stages only; `net` "
+                "holds other modules, whose PyTorch-ROCm kernels under autograd are not run-to-run deterministic. Pass "
+                "unvalidated=True to capture it anyway (see the class docstring for what was measured).")
         self.static = [t.detach().clone() for t in example_inputs]
         for t, src in zip(self.static, example_inputs):
             t.requires_grad_(src.requires_grad)
@@ -497,10 +552,44 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # capture ON the warm-up stream: the autograd nodes of the parameters were created there, and a capture stream of
+        # its own makes every gradient accumulation a cross-stream branch of the graph (the framework warns about it)
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = loss_fn(net, *self.static)
             self.loss.backward()
             optimizer.step()
+
+    @staticmethod
+    def is_stage_stack(net):
+        """True for a (container of one) Sequential of [quantised deform stage, Sequential(ReLU, QuantAct), Upsample]
+        blocks -- what functions/codenet_stage.forward_stage_blocks runs natively and the bit-level tests cover."""
+        from .portable_quantizer.quant_modules import QuantAct, QuantDeformConvWithOffsetScaleBoundPositive
+        seq = getattr(net, "deconv_layers", net)
+        if not isinstance(seq, nn.Sequential) or len(seq) == 0 or len(seq) % 3:
+            return False
+        if seq is not net and [m for m in net.children()] != [seq]:
+            return False
+        mods = list(seq)
+        for i in range(0, len(mods), 3):
+            q, post, up = mods[i:i + 3]
+            if not (isinstance(q, QuantDeformConvWithOffsetScaleBoundPositive) and isinstance(post, nn.Sequential)
+                    and len(post) == 2 and isinstance(post[0], nn.ReLU) and isinstance(post[1], QuantAct)
+                    and isinstance(up, nn.Upsample)):
+                return False
+        return True
+
+    def set_lr(self, value, group=None):
+        """Write a new learning rate where the captured step reads it: the param group's lr must be a device TENSOR
+        (torch.optim with capturable=True accepts one).  A Python float was baked into the graph at capture -- a scheduler
+        that assigns ``group['lr'] = float`` changes nothing on replay -- so that case raises instead of silently ignoring."""
+        groups = self._opt.param_groups if group is None else [self._opt.param_groups[group]]
+        for g in groups:
+            if not torch.is_tensor(g["lr"]):
+                raise RuntimeError("GraphedTrainStep.set_lr: this optimizer holds its learning rate as a Python float, which "
+                                   "the captured graph holds as a constant; construct the optimizer with "
+                                   "lr=torch.tensor(value, device=...) (capturable=True) before the capture")
+            with torch.no_grad():
+                g["lr"].fill_(float(value))
 
     def eager_step(self):
         """The same step with eager launches (what the capture records), on the static buffers."""

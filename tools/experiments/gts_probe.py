@@ -43,8 +43,11 @@ def main():
                                     torch.nn.Conv2d(24, 58, 3, 2, 1, groups=1), torch.nn.BatchNorm2d(58), torch.nn.ReLU(),
                                     torch.nn.Conv2d(58, 58, 3, 1, 1, groups=58), torch.nn.Conv2d(58, 116, 1)).cuda().train()
         opt_b = torch.optim.Adam(net_b.parameters(), lr=1e-4, capturable=True)
+    if mode.startswith("det_"):
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        mode = mode if mode == "det_alone" else mode[4:]
     net_a, opt_a = build()
-    step = pipeline.GraphedTrainStep(net_a, opt_a, loss_fn, (x,), warmup=3)
+    step = pipeline.GraphedTrainStep(net_a, opt_a, loss_fn, (x,), warmup=3, unvalidated=True)
     if mode == "b_after":
         net_b, opt_b = build()
 
@@ -77,14 +80,36 @@ def main():
             torch.cuda.synchronize()
             del blocks
 
+    import json
+    tiny = torch.nn.Parameter(torch.zeros(4, device="cuda"))
+    opt_t = torch.optim.Adam([tiny], lr=1e-3, capturable=True)
+    sums = []
     out = []
     for it in range(steps):
-        if mode != "alone":
+        if mode == "b_adam_tiny":
+            tiny.grad = torch.ones_like(tiny)
+            opt_t.step()
+        elif mode == "b_sgd_tiny":
+            tiny.data.add_(1.0)
+        elif mode == "sleep":
+            import time
+            time.sleep(0.5)
+        elif mode not in ("alone", "det_alone"):
             b_step()
         l = step(x)
         torch.cuda.synchronize()
         out.append("%.6f" % l.item())
+        rec = {}
+        for n, p_ in net_a.named_parameters():
+            rec["p:" + n] = p_.detach().double().sum().item()
+            if p_.grad is not None:
+                rec["g:" + n] = p_.grad.detach().double().sum().item()
+        for n, b_ in net_a.named_buffers():
+            rec["b:" + n] = b_.detach().double().sum().item()
+        sums.append(rec)
     print("GTS", mode, " ".join(out), flush=True)
+    os.makedirs("gpurun_out/r6/gts", exist_ok=True)
+    json.dump(sums, open("gpurun_out/r6/gts/%s.json" % mode, "w"))
 
 
 main()
