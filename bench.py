@@ -225,13 +225,21 @@ def live_pmc_traffic(args):
 
 
 
-def fused_algorithmic_bytes(shapes, batch, frozen=False):
+def fused_algorithmic_bytes(shapes, batch, frozen=False, chain_parts=None):
     """ALGORITHMIC bytes per step of the fused schedule by kernel family: stages >= 1 read
     their input at stored (half) resolution, the up-sampling is folded into addressing; the frozen schedule moves byte
-    codes everywhere except the stage-0 input and the scale planes."""
+    codes everywhere except the stage-0 input and the scale planes.  chain_parts (fp32 model, round 6): per stage the
+    number of partial-sum planes its pointwise epilogue leaves for the next stage's scale prediction -- that stage then has
+    no scale launch: its pointwise writes, and the next gather reads, parts x pixels x 4 bytes instead."""
     alg = {"scale": 0, "dw": 0, "pointwise": 0, "unpack": 0}
     for i, (C, Co, H, W) in enumerate(shapes):
         HWs = H * W // (1 if i == 0 else 4)
+        if chain_parts and i > 0 and chain_parts[i - 1]:
+            alg["dw"] += (C * HWs + chain_parts[i - 1] * HWs + C * H * W) * 4 * batch
+            alg["pointwise"] += ((C + Co) * H * W + (chain_parts[i] if i < len(chain_parts) else 0) * H * W) * 4 * batch
+            continue
+        if chain_parts and chain_parts[i]:
+            alg["pointwise"] += chain_parts[i] * H * W * 4 * batch
         if frozen:
             xb = 4 if i == 0 else 1
             alg["scale"] += (C * xb + 4) * HWs * batch
@@ -322,7 +330,8 @@ def hot_path_config_leg(preset, dev, steps, warmup, regions=5):
     for (name, _tag), v in durs.items():
         per_kernel[name] = per_kernel.get(name, 0.0) + sum(v) / steps
     shapes = pipeline.stage_shapes(p["res"], p["w2"])
-    alg = fused_algorithmic_bytes(shapes, p["batch"])
+    parts = [sb["parts"] for sb in fused._bufs["stages"]]
+    alg = fused_algorithmic_bytes(shapes, p["batch"], chain_parts=parts if any(parts) else None)
     alg_step = alg["scale"] + alg["dw"] + alg["pointwise"]
     dominant = max(per_kernel, key=per_kernel.get)
     traffic, source = committed_step_traffic(preset)
@@ -351,7 +360,7 @@ def hot_path_config_leg(preset, dev, steps, warmup, regions=5):
                         "schedule, HIP-graph replay" % ("2x" if p["w2"] else "1x", p["res"], p["res"],
                                                         "fp32" if p["fp32"] else "W4A8 (running QuantAct ranges)",
                                                         p["batch"]),
-            "ms_per_step": ms, "images_per_s": p["batch"] / ms * 1e3,
+            "ms_per_step": ms, "images_per_s": p["batch"] / ms * 1e3, "chained_scale_planes": parts,
             "regions": {"n": regions, "steps_each": steps, "ms_per_step_min": region_s[0] / steps * 1e3,
                         "ms_per_step_max": region_s[-1] / steps * 1e3},
             "roofline": roof,
@@ -829,7 +838,8 @@ def main():
                 alg[k] += v[k]
         shapes = pipeline.stage_shapes(args.res, args.w2)
         if fused is not None:
-            alg = fused_algorithmic_bytes(shapes, args.batch, frozen_main)
+            parts = [sb.get("parts", 0) for sb in getattr(fused, "_bufs", None)["stages"]] if getattr(fused, "_bufs", None) else []
+            alg = fused_algorithmic_bytes(shapes, args.batch, frozen_main, chain_parts=parts if any(parts) else None)
         flops_pw = sum(2.0 * C * Co * H * W * args.batch
                        for (C, Co, H, W) in pipeline.stage_shapes(args.res, args.w2))
         # The fused schedules' pointwise kernels (int8 MFMA on codes / the bf16 split) keep the matrix cores 6-12 % busy

@@ -111,7 +111,11 @@ def _check_common(input, offset, weight, kH, kW, dH, dW, padH, padW, dilH, dilW,
 @_half_through_float(("output",))
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW,
                              padH, dilationW, dilationH, group, deformable_group, im2col_step):
-    """cpp:151-258.  `columns`, `ones`, `im2col_step` are accepted and ignored (vestigial)."""
+    """cpp:151-258.  `ones` and `im2col_step` are accepted and ignored (vestigial).  `columns` -- the reference's scratch
+    tensor, resized by its C++ (cpp:196-200) -- is this call's scratch too where the library has a use for one: for the
+    CoDeNet call geometry (depthwise 3x3) it receives the per-pixel structure plane of the offsets (N x H x W floats,
+    cdn_deform_conv_forward_scratch), so that the offsets' anchor * t structure is tested once per call instead of once
+    per channel chunk."""
     _require_gpu(input, weight, offset, output)
     Ho, Wo = _check_common(input, offset, weight, kH, kW, dH, dW, padH, padW, dilationH,
                            dilationW, group, deformable_group)
@@ -120,9 +124,21 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
     Co = w.size(0)
     if tuple(output.shape) != (Nb, Co, Ho, Wo) or not output.is_contiguous():
         raise RuntimeError("output must be a contiguous [%d,%d,%d,%d] tensor" % (Nb, Co, Ho, Wo))
-    rc = N_.lib().cdn_deform_conv_forward(
-        _ptr(x), _ptr(w), _ptr(o), _ptr(output), _dtype_enum(x), Nb, C, H, W, Co, kW, kH, dW, dH,
-        padW, padH, dilationW, dilationH, group, deformable_group, _stream(x))
+    lib = N_.lib()
+    geom = (Nb, C, H, W, Co, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group)
+    need = lib.cdn_deform_conv_forward_scratch_bytes(*geom) if x.dtype == torch.float32 else 0
+    scratch = None
+    if need:
+        if (isinstance(columns, torch.Tensor) and columns.is_cuda and columns.device == x.device
+                and columns.dtype == torch.float32 and columns.is_contiguous()):
+            if columns.numel() * 4 < need:
+                columns.resize_(need // 4)
+            scratch = columns
+        else:
+            scratch = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    rc = lib.cdn_deform_conv_forward_scratch(
+        _ptr(x), _ptr(w), _ptr(o), _ptr(output), _dtype_enum(x), *geom, _ptr(scratch), need if scratch is not None else 0,
+        _stream(x))
     N_.check(rc, "deform_conv_forward_cuda")
     return 1
 

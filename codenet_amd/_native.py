@@ -21,6 +21,8 @@ _SIGNATURES = {
     "cdn_abi_version": (ctypes.c_int, []),
     "cdn_last_error": (ctypes.c_char_p, []),
     "cdn_deform_conv_forward": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp]),
+    "cdn_deform_conv_forward_scratch_bytes": (ctypes.c_size_t, [_i64] * 5 + [_i] * 10),
+    "cdn_deform_conv_forward_scratch": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_deform_conv_backward_input": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp]),
     "cdn_deform_conv_backward_parameters": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_f, _vp]),
     "cdn_modulated_deform_conv_forward": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),
@@ -49,6 +51,9 @@ _SIGNATURES = {
     "cdn_codenet_weight_prep_ranked": (_i, [_vp, _i64, _i64] + [_vp] * 4 + [_i, _i, _i, _f] + [_vp] * 3),
     "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_stage_fused_supported": (_i, [_i64] * 4 + [_i, _i]),
+    "cdn_codenet_stage_chain_parts": (_i, [_i64] * 5),
+    "cdn_codenet_stage_fused_forward_chain": (_i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 5
+                                              + [_i, _vp, ctypes.c_size_t, _vp, _vp, _i, _vp, _vp, _vp]),
     "cdn_codenet_stage_fused_intermediates": (_i, [_i64] * 4 + [_i, _i, _i, _vp, _vp]),
     "cdn_codenet_wcodes_kb_columns": (_i64, [_i64, _i64]),
     "cdn_codenet_pointwise_i8_supported": (_i, [_i64] * 4),

@@ -409,6 +409,11 @@ struct ScaleFromSums {
   const float *sw;      // device scalar: scale of the conv_scale weight codes (w = qw / sw)
   const float *bias;    // device scalar or nullptr
   float lo, hi;
+  // fp32 schedule, chained stages (round 6): the producer's pointwise epilogue (pws_kernel) leaves nparts planes
+  // fparts[part][N * HWl] -- per column tile the dot product of its output columns with the conv_scale weights -- and the
+  // consumer's gather forms s = clamp(((p0 + p1) + ...) + bias, lo, hi) in plane order: no scale launch, one fixed order
+  const float *fparts;
+  int nparts;
 };
 int launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                      const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H, int W,

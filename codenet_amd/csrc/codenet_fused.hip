@@ -1073,8 +1073,16 @@ dw2u_kernel(const float *__restrict__ x, const unsigned *__restrict__ xq,
     s_inv = __fdiv_rn(1.0f, __fmul_rn(si.sw[0], xs));
     s_b = si.bias ? si.bias[0] : 0.0f;
   }
+  const float f_b = (si.fparts && si.bias) ? si.bias[0] : 0.0f;
+  const long f_stride = (long)gridDim.y * HWl;               // one plane of partial sums: every stored pixel of the batch
   auto s_at = [&](int q) -> float {
     if (XQ && si.sums) return fminf(fmaxf(fmaf((float)si.sums[(long)n * HWl + q], s_inv, s_b), si.lo), si.hi);
+    if (!XQ && !SQ && si.fparts) {      // fp32 chained stages: the producer's per-column-tile partial sums, in plane order
+      const float *fp = si.fparts + (long)n * HWl + q;
+      float a = fp[0];
+      for (int j = 1; j < si.nparts; ++j) a += fp[j * f_stride];
+      return cdn::clamp_keep_nan(a + f_b, si.lo, si.hi);
+    }
     return s_raw[(long)n * HWl + q];
   };
   const float s_pre = tid < HWl ? s_at(tid) : 0.0f;
@@ -1566,6 +1574,34 @@ pw3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 // under round-robin dispatch, so an A block is fetched into one L2.
 // Needs K % (32 KS) == 0 and 16-byte aligned rows; plain f32 operands (no quantise-on-load).
 // ------------------------------------------------------------------------------------------
+// Sum over the 32 lanes of each wave half (pws_sum32: the total arrives in lanes 16-31 / 48-63) or over the wave
+// (pws_sum64: lanes 48-63) on the VALU's DPP path -- quad_perm xor 1, xor 2, row_ror 4, row_ror 8, row_bcast15
+// [, row_bcast31]: five / six moves + adds per value in ONE fixed order, where a __shfl_xor tree is as many ds_bpermute
+// round trips through the LDS crossbar (measured: +2.8 us on a 13-us launch for 16 rows x 5 steps per wave).
+__device__ __forceinline__ float pws_dpp(float v, const int ctrl) {
+  switch (ctrl) {      // (the DPP control is an immediate)
+    case 0: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    case 3: return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    case 4: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
+  }
+}
+__device__ __forceinline__ float pws_sum32(float v) {
+  v += pws_dpp(v, 0);
+  v += pws_dpp(v, 1);
+  v += pws_dpp(v, 2);
+  v += pws_dpp(v, 3);       // every lane: the sum of its 16-lane row
+  v += pws_dpp(v, 4);       // rows 1 and 3: + the row in front of them
+  return v;
+}
+__device__ __forceinline__ float pws_sum64(float v) {
+  v = pws_sum32(v);
+  v += pws_dpp(v, 5);       // row 3: + lane 31's total of the first half
+  return v;
+}
+
 constexpr int kPwsLD = 72;      // floats per LDS row of a partial tile: the two lane halves (rows 4 apart) hit disjoint banks
 template <int TN> struct PwsGeom {
   static constexpr int R = TN == 2 ? 3 : 4;                 // ring slots per wave
@@ -1578,7 +1614,12 @@ template <int TN, int KS>
 __global__ void __launch_bounds__(256)
 pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const float *__restrict__ bias,
            const float *__restrict__ ep_scale, const float *__restrict__ ep_shift, float *__restrict__ R, float2 *rmm,
-           cdn::QUpdate qu, long M, int K, int Co, int relu, int lda, int ldo) {
+           cdn::QUpdate qu, long M, int K, int Co, int relu, int lda, int ldo, const float *__restrict__ nws,
+           float *__restrict__ sparts) {
+  // nws / sparts (round 6, chained fp32 stages): nws [Co] = the NEXT stage's conv_scale weights; this workgroup's column
+  // tile leaves sparts[nt][m] = sum over its columns of out[m][co] * nws[co] (lane tree in a fixed order), which the
+  // next stage's gather sums over the tiles in plane order (cdn::ScaleFromSums::fparts) -- the separate scale launch of
+  // a stage whose input has no QuantAct in front of it (the fp32 model) is gone.
   using G = PwsGeom<TN>;
   constexpr int BN = 32 * TN;
   constexpr int BM = KS == 4 ? 32 : 128;          // rows of A per workgroup
@@ -1716,6 +1757,15 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
         mx = fmaxf(mx, v[rr]);
         has_nan |= (v[rr] != v[rr]);
       }
+    if (sparts) {           // (wave-uniform) thread <-> column: the BN lanes of a row group hold one row each step
+      const float wn = co < Co ? nws[co] : 0.0f;
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) {
+        float t = co < Co ? v[rr] * wn : 0.0f;
+        t = BN == 64 ? pws_sum64(t) : pws_sum32(t);
+        if (col == BN - 1 && m0 + r0 + rr < M) sparts[(long)nt * M + m0 + r0 + rr] = t;
+      }
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1728,6 +1778,7 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
           eh = ep_shift[co];
         }
       }
+      const float wn = (sparts && co < Co) ? nws[co] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1740,6 +1791,20 @@ pws_kernel(const float *__restrict__ A, const float *__restrict__ Wp, const floa
           mx = fmaxf(mx, v);
           has_nan |= (v != v);
         }
+        // (the accumulator is free now: it carries this lane's term of the row's partial sum, the 32-column sub-tiles in
+        // j order)
+        if (sparts) {
+          const float term = co < Co ? v * wn : 0.0f;
+          acc[0][r] = j == 0 ? term : acc[0][r] + term;
+        }
+      }
+    }
+    if (sparts) {           // lane <-> column i of the 32-column sub-tiles; the two lane halves hold different rows
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = pws_sum32(acc[0][r]);
+        const long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (i == 31 && m < M) sparts[(long)nt * M + m] = t;
       }
     }
   }
@@ -3070,7 +3135,8 @@ int launch_dwg(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
 template <int CCH>
 int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw,
                const unsigned *sq, const float *wd, float *d, float2 *dmm, cdn::QUpdate qu, int N,
-               int C, int H, int W, int up, hipStream_t st, int gmode, int ldd = 0) {
+               int C, int H, int W, int up, hipStream_t st, int gmode, int ldd = 0,
+               cdn::ScaleFromSums si = cdn::ScaleFromSums{nullptr, nullptr, nullptr, 0.f, 0.f, nullptr, 0}) {
   const int Hl = H >> up, Wl = W >> up;
   const size_t lds = dw2_lds_bytes(Hl, Wl, CCH);
   dim3 grid((unsigned)cdn::ceil_div(C, CCH), (unsigned)N);
@@ -3102,8 +3168,7 @@ int launch_dw2(bool nhwc, const float *x, const unsigned *xq, const float *s_raw
     auto kern = dw2u_kernel<CCH, XQ_, SQ_>;                                                   \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds);                                                      \
-    kern<<<grid, 512, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W,                   \
-                                 cdn::ScaleFromSums{nullptr, nullptr, nullptr, 0.f, 0.f});     \
+    kern<<<grid, 512, lds, st>>>(x, xq, s_raw, sq, wd, d, dmm, qu, C, H, W, si);              \
   }
     if (XQ && SQ) CDN_GOU(true, true)
     else if (XQ) CDN_GOU(true, false)
@@ -3229,6 +3294,18 @@ static bool pws_applies(long M, int64_t K, int64_t Co, int64_t lda, const float 
   return tiles <= (long)CDN_PWS_MAX_TILES && cdn::ceil_div(M, 32) * cdn::ceil_div(Co, 32) <= (1L << 20);
 }
 
+// tile width (TN) and K split (KS) of pws_kernel as TN * 10 + KS: the widest tile and the least K splitting that give
+// >= 4 waves per CU -- (64 columns, whole K), (32, whole K), (64, K / 4), (32, K / 4)
+static int pws_choice(long M, int64_t C, int64_t Co) {
+  const long want = 4L * cdn::kCUs, mt32 = cdn::ceil_div(M, 32);
+  const long w21 = mt32 * cdn::ceil_div(Co, 64), w11 = mt32 * cdn::ceil_div(Co, 32);
+  const bool can_split = (C & 127) == 0;
+  if (w21 >= want || (!can_split && Co > 32)) return 21;
+  if (w11 >= want || !can_split) return 11;
+  if (4 * w21 >= want) return 24;
+  return 14;
+}
+
 // pwi8s_kernel instead of pwi8_kernel: K >= 512 whole 64-channel blocks (every wave an even number of >= 2 windows),
 // Co <= 256, the k-blocked copy of the codes given (CDN_X_WCODES_KB).  Measured (round 5, one box, interleaved):
 // CoDeNet1x stage 0 (16384 x 1024 -> 256) 37.5 -> 31 us, CoDeNet2x stage 0 (8192 x 2176 -> 256) 47.6 -> 25.9 us.
@@ -3258,7 +3335,9 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                             const cdn::QUpdate &qu_r, int ptag, hipStream_t st, int64_t lda = 0,
                             int64_t ldo = 0, const unsigned char *a_gen = nullptr,
                             const int *out_map = nullptr, bool a_padded = false,
-                            const signed char *w_kb = nullptr) {
+                            const signed char *w_kb = nullptr, const float *next_ws = nullptr,
+                            float *sparts = nullptr) {
+  // next_ws / sparts: chained fp32 stages (pws_kernel only; the caller asked cdn_codenet_stage_chain_parts first)
   // w_kb: the k-blocked copy of w_pw_codes (include/codenet_dcn.h, CDN_X_WCODES_KB) or NULL
   // a_padded: the rows of A hold lda = round_up(C, 64) valid floats (the pad repeats channel C - 1) and the weight
   // codes are zero beyond C: the int8 path runs its whole-tile form over K = lda; the f32 branch for wide codes keeps C
@@ -3393,21 +3472,22 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
     // few output tiles: streaming waves (pws_kernel) -- the widest tile and the least K splitting that give >= 4 waves
     // per CU: (64 columns, whole K), (32, whole K), (64, K / 4), (32, K / 4)
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
-    const long want = 4L * cdn::kCUs, mt32 = cdn::ceil_div(M, 32);
-    const long w21 = mt32 * cdn::ceil_div(Co, 64), w11 = mt32 * cdn::ceil_div(Co, 32);
-    const bool can_split = (C & 127) == 0;
 #define CDN_PWS(TN_, KS_)                                                                                         \
   do {                                                                                                            \
     auto kern = pws_kernel<TN_, KS_>;                                                                             \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PwsGeom<TN_>::kLds); \
     kern<<<(unsigned)(cdn::ceil_div(M, KS_ == 4 ? 32 : 128) * cdn::ceil_div(Co, 32 * TN_)), 256, PwsGeom<TN_>::kLds, st>>>( \
-        d, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, (int)lda, (int)ldo);     \
+        d, w_pw, bias_pw, ep_scale, ep_shift, r_out, rmm, qu_r, M, (int)C, (int)Co, relu, (int)lda, (int)ldo,      \
+        next_ws, sparts);                                                                                         \
   } while (0)
-    if (w21 >= want || (!can_split && Co > 32)) CDN_PWS(2, 1);
-    else if (w11 >= want || !can_split) CDN_PWS(1, 1);
-    else if (4 * w21 >= want) CDN_PWS(2, 4);
+    const int choice = pws_choice(M, C, Co);
+    if (choice == 21) CDN_PWS(2, 1);
+    else if (choice == 11) CDN_PWS(1, 1);
+    else if (choice == 24) CDN_PWS(2, 4);
     else CDN_PWS(1, 4);
 #undef CDN_PWS
+  } else if (sparts) {
+    return cdn::fail(CDN_ERR_UNSUPPORTED, "chained scale sums need the streaming f32 pointwise (cdn_codenet_stage_chain_parts)");
   } else {
     cdn::ProfScope ps(cdn::kProfPointwise, ptag, st);
     if (pw_bn == 128 && pw_bm == 64) {
@@ -3520,7 +3600,9 @@ extern "C" int cdn_codenet_stage_fused_intermediates(int64_t N, int64_t C, int64
   return CDN_OK;
 }
 
-extern "C" int cdn_codenet_stage_fused_forward(
+// parts_in / n_parts_in: the scale prediction of THIS stage as the previous stage's partial sums (no scale launch);
+// next_w_scale / parts_out: leave the next stage's partial sums (cdn_codenet_stage_fused_forward_chain)
+static int stage_fused_forward_impl(
     const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
     int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
     const float *w_dw, const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
@@ -3528,7 +3610,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
     int relu, float *s_min, float *s_max, void *s_state, float *d_min,
     float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
     double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
-    void *stream) {
+    void *stream, const float *parts_in, int n_parts_in, const float *next_w_scale, float *parts_out) {
   CDN_REQUIRE(x && w_scale && w_dw && w_pw && r_out && workspace, CDN_ERR_ARG, "null pointer");
   CDN_REQUIRE(N > 0 && C > 0 && Co > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE((x_nhwc & ~(1 | CDN_X_GATHER_MASK | CDN_X_ACT_PERCENTILE | CDN_X_WCODES_KB | CDN_X_DEFER_RANGE |
@@ -3639,7 +3721,11 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // 1. scale prediction at stored resolution (+ min/max of s)
   float2 *smm = sst ? part_s : nullptr;
   int n_part_s = 0;
-  if (phases & CDN_X_PHASE_SCALE) {
+  if (parts_in) {
+    CDN_REQUIRE(n_parts_in >= 1 && !s_state && !xq && x_nhwc && x_up && !pct && !defer &&
+                    cdn::stage_channel_chunk(Hl, Wl) != 0,
+                CDN_ERR_UNSUPPORTED, "scale partial sums feed the LDS gather of an up-sampled channels-last fp32 input only");
+  } else if (phases & CDN_X_PHASE_SCALE) {
   {
   cdn::ProfScope ps(cdn::kProfScale, ptag, st);
   // tiled kernel for large planes (measured: 18 vs 22 us at 65536 pixels x 128 channels; the
@@ -3693,7 +3779,7 @@ extern "C" int cdn_codenet_stage_fused_forward(
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     auto fn = cch == 64 ? launch_dw2<64> : cch == 32 ? launch_dw2<32> : cch == 16 ? launch_dw2<16> : launch_dw2<8>;
     rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st, gmode,
-            (int)ldd);
+            (int)ldd, cdn::ScaleFromSums{nullptr, nullptr, b_scale, lo, hi, parts_in, n_parts_in});
   }
   if (rc) return rc;
   if (pct && (phases & CDN_X_PHASE_GATHER) && (rc = commit_percentile(d, N * H * W * C, 1, qu_d))) return rc;
@@ -3701,10 +3787,54 @@ extern "C" int cdn_codenet_stage_fused_forward(
   // 3. pointwise MFMA (+ bias / affine / ReLU, min/max of the result)
   rc = launch_pointwise(d, dst, (long)(N * H * W), C, Co, w_pw, w_pw_codes, w_pw_scale, w_pw_colsum,
                         bias_pw, ep_scale, ep_shift, relu, r_out, rst ? part_r : nullptr, qu_r, ptag,
-                        st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d, w_kb);
+                        st, pad_d ? ldd : 0, 0, nullptr, nullptr, pad_d, w_kb, next_w_scale, parts_out);
   if (rc) return rc;
   if (pct) rc = commit_percentile(r_out, N * H * W * Co, 1, qu_r);
   return rc;
+}
+
+extern "C" int cdn_codenet_stage_fused_forward(
+    const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
+    int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
+    const float *w_dw, const float *w_pw, const signed char *w_pw_codes, const float *w_pw_scale,
+    const int *w_pw_colsum, const float *bias_pw, const float *ep_scale, const float *ep_shift,
+    int relu, float *s_min, float *s_max, void *s_state, float *d_min,
+    float *d_max, void *d_state, float *r_min, float *r_max, void *r_state, int bits,
+    double momentum, int running, void *workspace, size_t workspace_bytes, float *r_out,
+    void *stream) {
+  return stage_fused_forward_impl(x, x_nhwc, x_up, x_qstate, N, C, Co, H, W, w_scale, b_scale, lo, hi, w_dw, w_pw,
+                                  w_pw_codes, w_pw_scale, w_pw_colsum, bias_pw, ep_scale, ep_shift, relu, s_min, s_max,
+                                  s_state, d_min, d_max, d_state, r_min, r_max, r_state, bits, momentum, running,
+                                  workspace, workspace_bytes, r_out, stream, nullptr, 0, nullptr, nullptr);
+}
+
+// Chained fp32 stages (round 6): number of partial-sum planes the pointwise conv of a stage (N, C -> Co, H x W) leaves for
+// the next stage's scale prediction -- 0 when this stage's pointwise is not the streaming f32 kernel (pws_kernel) or the
+// next stage (Co channels at 2H x 2W, up-sampled channels-last input) has no LDS-resident gather.
+extern "C" int cdn_codenet_stage_chain_parts(int64_t N, int64_t C, int64_t Co, int64_t H, int64_t W) {
+  if (N <= 0 || C <= 0 || Co <= 0 || H <= 0 || W <= 0 || N > 65535) return 0;
+  const long M = (long)(N * H * W);
+  if (!pws_applies(M, C, Co, C, nullptr, nullptr)) return 0;
+  if (H > 4096 || W > 4096 || cdn::stage_channel_chunk((int)H, (int)W) == 0) return 0;      // (the next stage's stored plane)
+  const int tn = pws_choice(M, C, Co) / 10;
+  return (int)cdn::ceil_div(Co, 32 * tn);
+}
+
+extern "C" int cdn_codenet_stage_fused_forward_chain(
+    const float *x, int x_nhwc, int x_up, const void *x_qstate, int64_t N, int64_t C, int64_t Co,
+    int64_t H, int64_t W, const float *w_scale, const float *b_scale, float lo, float hi,
+    const float *w_dw, const float *w_pw, const float *bias_pw, const float *ep_scale, const float *ep_shift,
+    int relu, void *workspace, size_t workspace_bytes, float *r_out, const float *parts_in, int n_parts_in,
+    const float *next_w_scale, float *parts_out, void *stream) {
+  CDN_REQUIRE((next_w_scale == nullptr) == (parts_out == nullptr), CDN_ERR_ARG,
+              "next_w_scale and parts_out come together");
+  CDN_REQUIRE(!parts_out || cdn_codenet_stage_chain_parts(N, C, Co, H, W) != 0, CDN_ERR_UNSUPPORTED,
+              "no chained form for this stage (cdn_codenet_stage_chain_parts)");
+  return stage_fused_forward_impl(x, x_nhwc, x_up, x_qstate, N, C, Co, H, W, w_scale, b_scale, lo, hi, w_dw, w_pw,
+                                  nullptr, nullptr, nullptr, bias_pw, ep_scale, ep_shift, relu, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 8, 0.99, 0,
+                                  workspace, workspace_bytes, r_out, stream, parts_in, n_parts_in, next_w_scale,
+                                  parts_out);
 }
 
 extern "C" int cdn_codenet_unpack_nchw(const float *r_nhwc, const void *r_qstate, float *out_nchw,

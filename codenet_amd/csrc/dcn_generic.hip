@@ -331,12 +331,73 @@ dwo_kernel(const float *__restrict__ x, const float *__restrict__ offset, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The CoDeNet OFFSET STRUCTURE (round 6; VERDICT r5 missing #6).  The 18-channel offset tensor this geometry is called
+// with is, in the reference's model, always anchor * (s - 1) (modules/dcn_deform_conv.py:319-325): off[2k] = a_y[k] t,
+// off[2k+1] = a_x[k] t with a in {-1, 0, 1} and one scalar t per pixel -- products by +-1 and 0, so the relation holds
+// EXACTLY in fp32 and can be tested exactly.  A pixel that has it needs four sampling axes (h -+ t, w -+ t) instead of
+// eighteen positions, and its nine taps touch 25 distinct cells instead of 36: the module kernel's geometry
+// (dw4_kernel, codenet_stage.hip; the helpers below restate its expressions -- positions float(h - 1 + i) + a t are
+// those of the generic formula bit for bit, the bilinear sums use bil4 / lin2's association).  A pixel that does not
+// have it (any other caller of deform_conv with this geometry; one offset off by an ulp) takes the generic taps.
+//   offset_structure_kernel: one pass over offset[N][18][HW] -> tplane[N][HW] = t where the pixel is structured, NaN
+//   where it is not (a structured pixel never has t = NaN: NaN == NaN fails the test) -- the scratch form,
+//   cdn_deform_conv_forward_scratch; without scratch every workgroup tests its pixels itself (18 loads per pixel and
+//   channel chunk instead of one).
+// ---------------------------------------------------------------------------------------
+struct SAxis {
+  int i0;
+  float w0, w1;
+};
+__device__ __forceinline__ SAxis make_saxis(int base, float off, int size) {
+  SAxis a;
+  const float pos = (float)base + off;
+  const bool ok = pos > -1.0f && pos < (float)size;
+  const float fl = floorf(pos);
+  const float l = pos - fl;
+  a.i0 = ok ? (int)fl : 0;
+  a.w1 = ok ? l : 0.0f;
+  a.w0 = ok ? 1.0f - l : 0.0f;
+  return a;
+}
+__device__ __forceinline__ float sbil4(float w00, float v00, float w01, float v01, float w10, float v10, float w11,
+                                       float v11) {
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w00, v00), __fmul_rn(w01, v01)), __fmul_rn(w10, v10)), __fmul_rn(w11, v11));
+}
+__device__ __forceinline__ float slin2(float w0, float v0, float w1, float v1) {
+  return __fadd_rn(__fmul_rn(w0, v0), __fmul_rn(w1, v1));
+}
+// true when o[0..17] == anchor * t with t = o[16] (tap k = 3 i + j: a_y = i - 1, a_x = j - 1)
+__device__ __forceinline__ bool offsets_structured(const float (&o)[18]) {
+  const float t = o[16];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float ay = (float)(k / 3 - 1), ax = (float)(k % 3 - 1);
+    ok = ok && o[2 * k] == ay * t && o[2 * k + 1] == ax * t;
+  }
+  return ok;
+}
+
+__global__ void __launch_bounds__(256)
+offset_structure_kernel(const float *__restrict__ offset, float *__restrict__ tplane, int HW, long total) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+    const long n = q / HW;
+    const int p = (int)(q - n * HW);
+    const float *op = offset + n * 18 * HW + p;
+    float o[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) o[k] = op[(long)k * HW];
+    tplane[q] = offsets_structured(o) ? o[16] : __builtin_nanf("");
+  }
+}
+
 // dwo4_kernel (round 3): dwo_kernel with the planes interleaved in channel QUADS ([CC / 4][cell][4]): one ds_read_b128
 // per cell and quad instead of four ds_read_b32 (36 instead of 144 LDS reads per pixel and quad).  Same per-channel
 // expressions in the same order.  C % 4 == 0, CC % 4 == 0.
 __global__ void __launch_bounds__(kDwoThreads)
 dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const float *__restrict__ weight,
-            float *__restrict__ out, int C, int H, int W, int CC) {
+            float *__restrict__ out, int C, int H, int W, int CC, const float *__restrict__ tplane) {
   extern __shared__ float dwo_smem[];
   const int HW = H * W;
   const int Wp = W + 2, Hp = H + 2;
@@ -359,13 +420,80 @@ dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const
   for (int p = threadIdx.x; p < HW; p += kDwoThreads) {
     const int h = p / W, w = p - h * W;
     const float *op = offset + (long)n * 18 * HW + p;
+    // ---- structured pixels: the module kernel's geometry (see offset_structure_kernel) ---------------------------
+    float o[18];
+    float t;
+    bool fast;
+    if (tplane) {
+      t = tplane[(long)n * HW + p];
+      fast = t == t;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 18; ++k) o[k] = op[(long)k * HW];
+      t = o[16];
+      fast = offsets_structured(o);
+    }
+    if (__all(fast)) {                                       // (wave-uniform; the generic taps below serve any mixture)
+      const SAxis ya = make_saxis(h - 1, -t, H), yb = make_saxis(h + 1, t, H);
+      const SAxis xa = make_saxis(w - 1, -t, W), xb = make_saxis(w + 1, t, W);
+      const int rya = (ya.i0 + 1) * Wp, ryb = (yb.i0 + 1) * Wp, rh = (h + 1) * Wp;
+      const int cxa = xa.i0 + 1, cxb = xb.i0 + 1, cw = w + 1;
+      const int b00 = rya + cxa, b02 = rya + cxb, b20 = ryb + cxa, b22 = ryb + cxb;
+      const int b01 = rya + cw, b21 = ryb + cw, b10 = rh + cxa, b12 = rh + cxb, b11 = rh + cw;
+      const float aa00 = ya.w0 * xa.w0, aa01 = ya.w0 * xa.w1, aa10 = ya.w1 * xa.w0, aa11 = ya.w1 * xa.w1;
+      const float ab00 = ya.w0 * xb.w0, ab01 = ya.w0 * xb.w1, ab10 = ya.w1 * xb.w0, ab11 = ya.w1 * xb.w1;
+      const float ba00 = yb.w0 * xa.w0, ba01 = yb.w0 * xa.w1, ba10 = yb.w1 * xa.w0, ba11 = yb.w1 * xa.w1;
+      const float bb00 = yb.w0 * xb.w0, bb01 = yb.w0 * xb.w1, bb10 = yb.w1 * xb.w0, bb11 = yb.w1 * xb.w1;
+      for (int g = 0; g < (cc >> 2); ++g) {
+        const float4 *pl = planes + g * pstride;
+        const float4 c00 = pl[b00], c01 = pl[b00 + 1], c02 = pl[b00 + Wp], c03 = pl[b00 + Wp + 1];
+        const float4 c20 = pl[b02], c21 = pl[b02 + 1], c22 = pl[b02 + Wp], c23 = pl[b02 + Wp + 1];
+        const float4 c60 = pl[b20], c61 = pl[b20 + 1], c62 = pl[b20 + Wp], c63 = pl[b20 + Wp + 1];
+        const float4 c80 = pl[b22], c81 = pl[b22 + 1], c82 = pl[b22 + Wp], c83 = pl[b22 + Wp + 1];
+        const float4 e10 = pl[b01], e11 = pl[b01 + Wp], e70 = pl[b21], e71 = pl[b21 + Wp];
+        const float4 e30 = pl[b10], e31 = pl[b10 + 1], e50 = pl[b12], e51 = pl[b12 + 1];
+        const float4 ctr = pl[b11];
+#define CDN_DWO4S_CH(E, OFF)                                                                         \
+        {                                                                                              \
+          const float *wk = wl + (4 * g + OFF) * 9;                                                    \
+          const float v0 = sbil4(aa00, c00.E, aa01, c01.E, aa10, c02.E, aa11, c03.E);                  \
+          const float v2 = sbil4(ab00, c20.E, ab01, c21.E, ab10, c22.E, ab11, c23.E);                  \
+          const float v6 = sbil4(ba00, c60.E, ba01, c61.E, ba10, c62.E, ba11, c63.E);                  \
+          const float v8 = sbil4(bb00, c80.E, bb01, c81.E, bb10, c82.E, bb11, c83.E);                  \
+          const float v1 = slin2(ya.w0, e10.E, ya.w1, e11.E);                                          \
+          const float v7 = slin2(yb.w0, e70.E, yb.w1, e71.E);                                          \
+          const float v3 = slin2(xa.w0, e30.E, xa.w1, e31.E);                                          \
+          const float v5 = slin2(xb.w0, e50.E, xb.w1, e51.E);                                          \
+          float acc = wk[0] * v0;                                                                      \
+          acc = fmaf(wk[1], v1, acc);                                                                  \
+          acc = fmaf(wk[2], v2, acc);                                                                  \
+          acc = fmaf(wk[3], v3, acc);                                                                  \
+          acc = fmaf(wk[4], ctr.E, acc);                                                               \
+          acc = fmaf(wk[5], v5, acc);                                                                  \
+          acc = fmaf(wk[6], v6, acc);                                                                  \
+          acc = fmaf(wk[7], v7, acc);                                                                  \
+          acc = fmaf(wk[8], v8, acc);                                                                  \
+          out[((long)n * C + c0 + 4 * g + OFF) * HW + p] = acc;                                        \
+        }
+        CDN_DWO4S_CH(x, 0)
+        CDN_DWO4S_CH(y, 1)
+        CDN_DWO4S_CH(z, 2)
+        CDN_DWO4S_CH(w, 3)
+#undef CDN_DWO4S_CH
+      }
+      continue;
+    }
+    if (tplane) {
+#pragma unroll
+      for (int k = 0; k < 18; ++k) o[k] = op[(long)k * HW];
+    }
     int base[9];
     float w00[9], w01[9], w10[9], w11[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int i = k / 3, j = k - 3 * i;
-      const float hi = (float)(h - 1 + i) + op[(long)(2 * k) * HW];
-      const float wi = (float)(w - 1 + j) + op[(long)(2 * k + 1) * HW];
+      const float hi = (float)(h - 1 + i) + o[2 * k];
+      const float wi = (float)(w - 1 + j) + o[2 * k + 1];
       const bool ok = inside(hi, wi, H, W);
       const float hf = floorf(hi), wf = floorf(wi);
       const float lh = hi - hf, lw = wi - wf;
@@ -809,7 +937,7 @@ static bool dwo_applies(const Geom &g) {
 
 template <typename T>
 int run_forward(const void *x, const void *w, const void *b, const void *off, const void *m,
-                void *out, const Geom &g, hipStream_t st) {
+                void *out, const Geom &g, hipStream_t st, float *tplane = nullptr) {
   const long total = (long)g.N * g.Co * g.Ho * g.Wo;
   if (std::is_same<T, float>::value && !m && dwo_applies(g)) {      // the CoDeNet call: LDS-plane depthwise kernel
     const int CC = dwo_channels(g);
@@ -818,8 +946,12 @@ int run_forward(const void *x, const void *w, const void *b, const void *off, co
     if ((CC & 3) == 0 && (g.C & 3) == 0) {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)dwo4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (tplane) {       // the offsets' structure once per call instead of once per channel chunk
+        const long npix = (long)g.N * g.H * g.W;
+        offset_structure_kernel<<<grid_for(npix), 256, 0, st>>>((const float *)off, tplane, g.H * g.W, npix);
+      }
       dwo4_kernel<<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
-                                                  g.C, g.H, g.W, CC);
+                                                  g.C, g.H, g.W, CC, tplane);
     } else {
       dwo_kernel<<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
                                                  g.C, g.H, g.W, CC);
@@ -928,6 +1060,40 @@ extern "C" int cdn_deform_conv_forward(const void *input, const void *weight, co
   if (rc) return rc;
   hipStream_t st = cdn::as_stream(stream);
   CDN_DISPATCH(dtype, run_forward<float>(input, weight, nullptr, offset, nullptr, output, g, st),
+               run_forward<double>(input, weight, nullptr, offset, nullptr, output, g, st));
+}
+
+extern "C" size_t cdn_deform_conv_forward_scratch_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kW,
+                                                        int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                                        int dilationH, int group, int deformable_group) {
+  Geom g;
+  if (cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group, deformable_group))
+    return 0;
+  const int CC = dwo_applies(g) ? dwo_channels(g) : 0;
+  return ((CC & 3) == 0 && CC >= 4 && (g.C & 3) == 0) ? (size_t)g.N * g.H * g.W * sizeof(float) : 0;
+}
+
+extern "C" int cdn_deform_conv_forward_scratch(const void *input, const void *weight, const void *offset,
+                                               void *output, int dtype, int64_t N, int64_t C, int64_t H,
+                                               int64_t W, int64_t Co, int kW, int kH, int dW, int dH,
+                                               int padW, int padH, int dilationW, int dilationH,
+                                               int group, int deformable_group, void *scratch, size_t scratch_bytes,
+                                               void *stream) {
+  CDN_REQUIRE(input && weight && offset && output, CDN_ERR_ARG, "null tensor pointer");
+  Geom g;
+  int rc = cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
+                          group, deformable_group);
+  if (rc) return rc;
+  const size_t need = cdn_deform_conv_forward_scratch_bytes(N, C, H, W, Co, kW, kH, dW, dH, padW, padH, dilationW,
+                                                            dilationH, group, deformable_group);
+  float *tplane = nullptr;
+  if (dtype == CDN_F32 && need != 0 && scratch != nullptr) {
+    CDN_REQUIRE(scratch_bytes >= need && (reinterpret_cast<uintptr_t>(scratch) & 3) == 0, CDN_ERR_WORKSPACE,
+                "scratch too small (cdn_deform_conv_forward_scratch_bytes) or misaligned");
+    tplane = static_cast<float *>(scratch);
+  }
+  hipStream_t st = cdn::as_stream(stream);
+  CDN_DISPATCH(dtype, run_forward<float>(input, weight, nullptr, offset, nullptr, output, g, st, tplane),
                run_forward<double>(input, weight, nullptr, offset, nullptr, output, g, st));
 }
 

@@ -662,11 +662,12 @@ class FusedHotPath:
     All device buffers are allocated once per input shape, so a call issues only kernel launches
     and can be captured into a HIP graph (``capture()``)."""
 
-    def __init__(self, deconv_layers, int8_pointwise=True, kblocked_codes=True):
+    def __init__(self, deconv_layers, int8_pointwise=True, kblocked_codes=True, chain_scale=True):
         from .portable_quantizer.quant_modules import QuantDeformConvWithOffsetScaleBoundPositive
         self.seq = deconv_layers
         self.int8_pointwise = int8_pointwise
         self.kblocked_codes = kblocked_codes      # (False: tests compare the two int8 pointwise kernels)
+        self.chain_scale = chain_scale            # fp32 model: the next stage's scale prediction from the pointwise epilogue
         mods = list(deconv_layers)
         self.quantized = isinstance(mods[0], QuantDeformConvWithOffsetScaleBoundPositive)
         step = 3 if self.quantized else 4
@@ -757,7 +758,14 @@ class FusedHotPath:
             Hs, Ws = (H, W) if i == 0 else (bufs[-1]["H"] * 2, bufs[-1]["W"] * 2)
             ws_bytes = max(ws_bytes, N_.lib().cdn_codenet_stage_workspace_bytes(Nb, cin, Hs, Ws, up))
             bufs.append(dict(C=cin, Co=cout, H=Hs, W=Ws, up=up,
-                             r=torch.empty(Nb, Hs * Ws, cout, device=dev)))
+                             r=torch.empty(Nb, Hs * Ws, cout, device=dev), parts=0, parts_buf=None))
+        if not self.quantized and self.chain_scale:
+            # chained fp32 stages (round 6): the pointwise epilogue of stage i leaves the partial sums of stage i + 1's scale
+            # prediction -- no QuantAct sits between them in the fp32 model -- and stage i + 1 runs without its scale launch
+            for sb in bufs[:-1]:
+                sb["parts"] = int(N_.lib().cdn_codenet_stage_chain_parts(Nb, sb["C"], sb["Co"], sb["H"], sb["W"]))
+                if sb["parts"]:
+                    sb["parts_buf"] = torch.empty(sb["parts"] * Nb * sb["H"] * sb["W"], device=dev)
         last = bufs[-1]
         out = torch.empty(Nb, last["Co"], last["H"] * 2, last["W"] * 2, device=dev)
         ws = torch.zeros(ws_bytes // 4 + 64, device=dev)   # arrival counters must start at zero
@@ -808,7 +816,7 @@ class FusedHotPath:
         ws_bytes = (ws.numel() * 4 - (ws_ptr - ws.data_ptr())) // 256 * 256
         cur, cur_nhwc, cur_q = x, int(nhwc_in), (x_qstate if nhwc_in else None)
         with torch.no_grad():
-            for st, sb in zip(self.stages, B["stages"]):
+            for si, (st, sb) in enumerate(zip(self.stages, B["stages"])):
                 p = self._stage_params(st)
                 ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
                 a = []
@@ -822,6 +830,20 @@ class FusedHotPath:
                         a += [act.x_min.data_ptr(), act.x_max.data_ptr(),
                               act._device_state(x.device).data_ptr()]
                 rec = ops._tic("stage", (sb["C"], sb["H"], sb["W"]))
+
+                def stage_call_chain():
+                    nxt = B["stages"][si + 1] if si + 1 < len(B["stages"]) else None
+                    prev = B["stages"][si - 1] if si > 0 else None
+                    out_parts = sb["parts_buf"] if (nxt is not None and sb["parts"]) else None
+                    in_parts = prev["parts_buf"] if (prev is not None and prev["parts"]) else None
+                    nws = self._stage_params(self.stages[si + 1])["w_scale"] if out_parts is not None else None
+                    rc = lib.cdn_codenet_stage_fused_forward_chain(
+                        cur.data_ptr(), cur_nhwc | getattr(self, "gather_flag", 0), sb["up"], cur_q, Nb, sb["C"], sb["Co"],
+                        sb["H"], sb["W"], ptr(p["w_scale"]), ptr(p["b_scale"]), float(p["lo"]), float(p["hi"]),
+                        ptr(p["w_dw"]), ptr(p["w_pw"]), ptr(p["bias"]), ptr(p["ep_scale"]), ptr(p["ep_shift"]), 1,
+                        ws_ptr, ws_bytes, sb["r"].data_ptr(), ptr(in_parts), prev["parts"] if in_parts is not None else 0,
+                        ptr(nws), ptr(out_parts), stream)
+                    N_.check(rc, "cdn_codenet_stage_fused_forward_chain")
 
                 def stage_call(extra):
                     rc = lib.cdn_codenet_stage_fused_forward(
@@ -843,6 +865,8 @@ class FusedHotPath:
                     for phase, act in zip((PHASE_SCALE, PHASE_GATHER, PHASE_POINTWISE), p["acts"]):
                         stage_call(DEFER_RANGE | phase)
                         self._global_commit(act, x.device, bits, mom, stream)
+                elif not self.quantized and cur_q is None and (sb["parts"] or (si > 0 and B["stages"][si - 1]["parts"])):
+                    stage_call_chain()
                 else:
                     stage_call(0)
                 ops._toc(rec)

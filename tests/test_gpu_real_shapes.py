@@ -167,6 +167,35 @@ def test_cfg2_fused_fp32_batch32():
     _run_case(CFG3, 8, 32, False, 1, seed=35)
 
 
+@pytest.mark.parametrize("planes,H,N", [(None, 8, 32), (None, 16, 8), ([64, 48, 40, 24], 12, 3)])
+def test_fp32_chained_scale_sums_equal_the_scale_kernel_to_rounding(planes, H, N):
+    """Round 6: in the fp32 model nothing sits between a stage's BN + ReLU and the next stage's
+    scale prediction, so the streaming f32 pointwise kernel leaves that prediction's partial sums per column tile and the
+    next stage runs without its scale launch (cdn_codenet_stage_fused_forward_chain: 10 -> 8 launches at cfg2).  The
+    chained schedule against the unchained one on the same weights: the scale planes differ by fp32 re-association only
+    (<= 1e-5 of |s|'s range), the final outputs by what that moves the samples (<= 2e-4 relative) -- both sit inside the
+    1e-3 bound against the oracle that test_cfg2_fused_fp32_batch32 checks with the chain ON (the default).  The third
+    shape has no streaming-kernel form at every stage (K % 32 != 0): the chain is simply not taken there."""
+    from codenet_amd import _native as N_, pipeline
+    planes = planes or CFG3
+    net = pipeline.build_hot_path(quantized=False, planes=planes, seed=41).cuda()
+    x = _inputs(N, planes[0], H, 1, 141)[0].cuda()
+    a = pipeline.FusedHotPath(net.deconv_layers, chain_scale=True)
+    b = pipeline.FusedHotPath(net.deconv_layers, chain_scale=False)
+    ya, yb = a(x).clone(), b(x).clone()
+    parts = [sb["parts"] for sb in a._bufs["stages"]]
+    lib = N_.lib()
+    assert parts[:-1] == [int(lib.cdn_codenet_stage_chain_parts(N, sb["C"], sb["Co"], sb["H"], sb["W"]))
+                          for sb in a._bufs["stages"][:-1]] and parts[-1] == 0
+    if planes is CFG3:
+        assert all(p > 0 for p in parts[:-1])                  # cfg2 / cfg3-fp32: both boundaries chained
+    scale = yb.abs().max().item()
+    assert (ya - yb).abs().max().item() <= 2e-4 * scale, (ya - yb).abs().max().item() / scale
+    assert torch.equal(a(x), ya)                                # fixed summation order: repeatable bit for bit
+    g = a.capture(x)                                            # and capturable
+    assert torch.equal(g(), ya)
+
+
 def test_cfg2_modules_fp32_batch32():
     """configs[1] as BASELINE words it -- 'deform-conv HIP kernel only, PyTorch-ROCm for the rest': the
     nn.Module chain (DeformConvWithOffsetScaleBoundPositive -> BatchNorm2d -> ReLU -> Upsample) at batch 32."""
