@@ -17,40 +17,20 @@ __all__ = [
 ]
 
 
-def _half_through_float(out_names):
-    """fp16 (the reference dispatches half too: AT_DISPATCH_FLOATING_TYPES_AND_HALF, _kernel.cu:258,352,450).  The C
-    ABI computes in fp32 / fp64: for half tensors the call runs on fp32 copies and the tensors named in `out_names`
-    (outputs and accumulated-into gradients) are written back in half -- i.e. fp32 arithmetic rounded once at the end,
-    where the reference rounds every intermediate to half."""
-    import functools
-    import inspect
-
-    def deco(fn):
-        names = list(inspect.signature(fn).parameters)
-
-        @functools.wraps(fn)
-        def wrapper(*args, **kwargs):
-            bound = dict(zip(names, args))
-            bound.update(kwargs)
-            if not any(isinstance(v, torch.Tensor) and v.dtype == torch.float16 for v in bound.values()):
-                return fn(*args, **kwargs)
-            conv = {k: (v.float() if isinstance(v, torch.Tensor) and v.dtype == torch.float16 else v)
-                    for k, v in bound.items()}
-            res = fn(**conv)
-            for k in out_names:
-                if isinstance(bound.get(k), torch.Tensor) and bound[k].dtype == torch.float16:
-                    bound[k].copy_(conv[k])
-            return res
-        return wrapper
-    return deco
-
-
-def _dtype_enum(t):
+def _dtype_enum(t, *others):
+    """fp16 (the reference dispatches half too: AT_DISPATCH_FLOATING_TYPES_AND_HALF, _kernel.cu:258,352,450) is native in
+    the library since round 6 (CDN_F16: half in memory, fp32 arithmetic, one rounding per stored element); every tensor of
+    a call has one dtype, as in the reference."""
+    for o in others:
+        if o is not None and o.dtype != t.dtype:
+            raise RuntimeError("codenet_amd: all tensors of a call must share one dtype (got %s and %s)" % (t.dtype, o.dtype))
     if t.dtype == torch.float32:
         return N_.CDN_F32
     if t.dtype == torch.float64:
         return N_.CDN_F64
-    raise RuntimeError("codenet_amd: unsupported dtype %s (float32 / float64 only)" % t.dtype)
+    if t.dtype == torch.float16:
+        return N_.CDN_F16
+    raise RuntimeError("codenet_amd: unsupported dtype %s (float16 / float32 / float64)" % t.dtype)
 
 
 def _require_gpu(*tensors):
@@ -108,7 +88,6 @@ def _check_common(input, offset, weight, kH, kW, dH, dW, padH, padW, dilH, dilW,
     return Ho, Wo
 
 
-@_half_through_float(("output",))
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW,
                              padH, dilationW, dilationH, group, deformable_group, im2col_step):
     """cpp:151-258.  `ones` and `im2col_step` are accepted and ignored (vestigial).  `columns` -- the reference's scratch
@@ -137,13 +116,12 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
         else:
             scratch = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     rc = lib.cdn_deform_conv_forward_scratch(
-        _ptr(x), _ptr(w), _ptr(o), _ptr(output), _dtype_enum(x), *geom, _ptr(scratch), need if scratch is not None else 0,
+        _ptr(x), _ptr(w), _ptr(o), _ptr(output), _dtype_enum(x, w, o, output), *geom, _ptr(scratch), need if scratch is not None else 0,
         _stream(x))
     N_.check(rc, "deform_conv_forward_cuda")
     return 1
 
 
-@_half_through_float(("gradInput", "gradOffset"))
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight,
                                     columns, kW, kH, dW, dH, padW, padH, dilationW, dilationH,
                                     group, deformable_group, im2col_step):
@@ -156,14 +134,14 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
         raise RuntimeError("gradInput / gradOffset must be contiguous")
     Nb, C, H, W = x.shape
     rc = N_.lib().cdn_deform_conv_backward_input(
-        _ptr(x), _ptr(o), _ptr(go), _ptr(gradInput), _ptr(gradOffset), _ptr(w), _dtype_enum(x),
+        _ptr(x), _ptr(o), _ptr(go), _ptr(gradInput), _ptr(gradOffset), _ptr(w),
+        _dtype_enum(x, o, go, gradInput, gradOffset, w),
         Nb, C, H, W, w.size(0), kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
         deformable_group, _stream(x))
     N_.check(rc, "deform_conv_backward_input_cuda")
     return 1
 
 
-@_half_through_float(("gradWeight",))
 def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, columns, ones, kW,
                                          kH, dW, dH, padW, padH, dilationW, dilationH, group,
                                          deformable_group, scale, im2col_step):
@@ -176,7 +154,7 @@ def deform_conv_backward_parameters_cuda(input, offset, gradOutput, gradWeight, 
         raise RuntimeError("gradWeight must be contiguous")
     Nb, C, H, W = x.shape
     rc = N_.lib().cdn_deform_conv_backward_parameters(
-        _ptr(x), _ptr(o), _ptr(go), _ptr(gradWeight), _dtype_enum(x), Nb, C, H, W,
+        _ptr(x), _ptr(o), _ptr(go), _ptr(gradWeight), _dtype_enum(x, o, go, gradWeight), Nb, C, H, W,
         gradWeight.size(0), kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
         deformable_group, float(scale), _stream(x))
     N_.check(rc, "deform_conv_backward_parameters_cuda")
@@ -206,7 +184,6 @@ def _check_modulated(input, weight, offset, mask, kernel_h, kernel_w, stride_h, 
     return Ho, Wo
 
 
-@_half_through_float(("output",))
 def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, output, columns,
                                        kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
                                        dilation_h, dilation_w, group, deformable_group, with_bias):
@@ -227,7 +204,6 @@ def modulated_deform_conv_cuda_forward(input, weight, bias, ones, offset, mask, 
     N_.check(rc, "modulated_deform_conv_cuda_forward")
 
 
-@_half_through_float(("grad_input", "grad_weight", "grad_bias", "grad_offset", "grad_mask"))
 def modulated_deform_conv_cuda_backward(input, weight, bias, ones, offset, mask, columns,
                                         grad_input, grad_weight, grad_bias, grad_offset, grad_mask,
                                         grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,

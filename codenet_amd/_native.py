@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libcodenet_dcn.so")      # the product library; no environment override
 CSRC = os.path.join(_HERE, "csrc")
 
-CDN_F32, CDN_F64 = 0, 1
+CDN_F32, CDN_F64, CDN_F16 = 0, 1, 2
 _lib = None
 
 _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double

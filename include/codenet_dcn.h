@@ -16,10 +16,9 @@
  *     enqueued asynchronously on it; no entry point synchronises the device or the host.
  *   - Every function returns 0 (CDN_OK) or a negative cdn_status; cdn_last_error() gives a
  *     thread-local human-readable message for the last failure on the calling thread.
- *   - dtype: CDN_F32 or CDN_F64 for the generic entry points; the CoDeNet fast paths are f32
- *     (activations) with int8 code paths where stated.  fp16 tensors (the reference also dispatches half,
- *     dcn_deform_conv_cuda_kernel.cu:258,352,450) are served by the binding above this ABI: the call runs on fp32
- *     copies and results are rounded to half once (codenet_amd/_ext/dcn/dcn_deform_conv_cuda.py).
+ *   - dtype: CDN_F32, CDN_F64 or CDN_F16 (round 6: IEEE half in memory, fp32 arithmetic, one rounding per stored
+ *     element; the reference dispatches half too, dcn_deform_conv_cuda_kernel.cu:258,352,450) for the generic entry
+ *     points; the CoDeNet fast paths are f32 (activations) with int8 code paths where stated.
  *   - Re-entrant, no global mutable state (the only per-thread state: the cdn_last_error() message and the
  *     optional cdn_profile_* event list, both thread-local); safe to call concurrently from several host
  *     threads on different streams / devices (the current HIP device must be the one that
@@ -38,7 +37,7 @@ extern "C" {
 
 #define CDN_ABI_VERSION 1
 
-enum cdn_dtype { CDN_F32 = 0, CDN_F64 = 1 };
+enum cdn_dtype { CDN_F32 = 0, CDN_F64 = 1, CDN_F16 = 2 };
 
 enum cdn_status {
   CDN_OK = 0,

@@ -84,7 +84,7 @@ def test_split_stage_call_equals_the_plain_call_on_one_rank():
     pipeline.set_global_range(net_b, True)
     fa, fb = pipeline.FusedHotPath(net_a.deconv_layers), pipeline.FusedHotPath(net_b.deconv_layers)
     # (global_range_active() asks torch.distributed for the world size: stand in for "two ranks whose extremes agree")
-    saved = (pipeline.global_range_active, pipeline.FusedHotPath._global_commit)
+    saved = (pipeline.hotpath.global_range_active, pipeline.FusedHotPath._global_commit)      # (the name FusedHotPath's module resolves)
 
     def commit_local(act, dev, bits, mom, stream):
         st = act._device_state(dev)
@@ -93,7 +93,7 @@ def test_split_stage_call_equals_the_plain_call_on_one_rank():
         N_.check(N_.lib().cdn_quantact_commit_range(act.x_min.data_ptr(), act.x_max.data_ptr(), st.data_ptr(),
                                                     t.data_ptr(), bits, mom, 1, stream), "commit")
     try:
-        pipeline.global_range_active = lambda acts: any(getattr(a, "global_range", False) for a in acts if a is not None)
+        pipeline.hotpath.global_range_active = lambda acts: any(getattr(a, "global_range", False) for a in acts if a is not None)
         pipeline.FusedHotPath._global_commit = staticmethod(commit_local)
         for x in _batches(4, 3):
             ya, yb = fa(x.cuda()).clone(), fb(x.cuda()).clone()
@@ -101,7 +101,7 @@ def test_split_stage_call_equals_the_plain_call_on_one_rank():
         for (a_lo, a_hi), (b_lo, b_hi) in zip(_ranges(net_a), _ranges(net_b)):
             assert torch.equal(a_lo, b_lo) and torch.equal(a_hi, b_hi)
     finally:
-        pipeline.global_range_active, pipeline.FusedHotPath._global_commit = saved
+        pipeline.hotpath.global_range_active, pipeline.FusedHotPath._global_commit = saved
 
 
 def test_global_range_model_keeps_its_stages_on_the_fused_schedule():

@@ -33,7 +33,9 @@ def test_ap50_delta_proxy_32_images():
     reference" -- in every mode; fp32 on the GPU reproduces the ground truth it is scored against."""
     from tests import proxy_ap as A
     r = A.run(images=32, res=512, batch=8, seed=3, yard_images=32)
-    assert r["ground_truth"]["boxes"] >= 200 and r["ground_truth"]["classes_with_boxes"] >= 10, r["ground_truth"]
+    # (a random-weight hm head ranks a few classes above the rest: the top-100 detections of an image -- and with them the
+    # pseudo ground truth -- live in 2-3 of the 20 classes)
+    assert r["ground_truth"]["boxes"] >= 200 and r["ground_truth"]["classes_with_boxes"] >= 2, r["ground_truth"]
     assert r["fp32"]["ap50_cpu"] == pytest.approx(1.0) and r["fp32"]["ap50_gpu"] >= 0.99, r["fp32"]
     for mode in ("w4a8_running", "w4a8_frozen", "w4a8_frozen_bytes"):
         m = r[mode]
