@@ -282,7 +282,7 @@ def committed_step_traffic(preset):
     """HBM bytes per step of a preset's fused running-range step from the newest committed PMC collection
     (profiles/rNN/pmc_steady_<preset>.json: steady-state iterations of `bench.py --config <preset> --no-graph` under
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled; the hand-over kernels unpack / expand8 excluded)."""
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_steady_%s.json" % preset)))
         except (OSError, ValueError):

@@ -57,6 +57,14 @@ _SIGNATURES = {
     "cdn_codenet_stage_fused_intermediates": (_i, [_i64] * 4 + [_i, _i, _i, _vp, _vp]),
     "cdn_codenet_wcodes_kb_columns": (_i64, [_i64, _i64]),
     "cdn_codenet_pointwise_i8_supported": (_i, [_i64] * 4),
+    "cdn_quantact_arrive_words": (_i, []),
+    "cdn_codenet_scale_forward_update": (_i, [_vp] * 4 + [_i64] * 4 + [_f, _f] + [_vp] * 4 + [_i, _d, _vp, _vp]),
+    "cdn_codenet_dw_forward_update_supported": (_i, [_i64] * 4 + [_i]),
+    "cdn_codenet_dw_forward_update": (_i, [_vp] * 4 + [_i64] * 4 + [_i] + [_vp] * 4 + [_i, _d, _vp, _vp]),
+    "cdn_codenet_pointwise_i8_forward_update": (_i, [_vp] * 5 + [_i64] * 4 + [_vp, ctypes.c_size_t, _i] + [_vp] * 4
+                                                + [_i, _d, _vp]),
+    "cdn_quantact_apply": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "cdn_quantact_relu_apply": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _vp, _vp]),
     "cdn_codenet_pointwise_dgrad_q4_supported": (_i, [_i64] * 4),
     "cdn_codenet_pointwise_dgrad_q4": (_i, [_vp] * 3 + [_i64] * 4 + [_vp]),
     "cdn_codenet_pointwise_i8_workspace_bytes": (ctypes.c_size_t, [_i64] * 4),

@@ -229,6 +229,8 @@ struct QUpdate {
   unsigned *counters;    // fused schedule only: kArriveWords zero-initialised arrival counters
   float m_minus_1, one_minus_m;
   int bits, running;
+  unsigned *state_copy;  // optional (may be NULL): receives the 8 state words after the update -- the snapshot a backward
+                         // pass reads (round 6: the training path's producers update their QuantAct themselves)
 };
 // Arrival counters: 64 group counters + 1 top counter, one per 64-byte line (a single contended
 // word sustains only ~88 atomics/us; 2048 workgroups on one word cost ~25 us).
@@ -281,6 +283,10 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
             !(fabsf(zp) < 4.0e6f)) ? 1u : 0u;   // (the int8 kernels do integer arithmetic on zp)
   }
   u.state[6] = wide;
+  if (u.state_copy) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u.state_copy[i] = u.state[i];
+  }
 }
 
 // Barrier of the range epilogue.  __syncthreads() also waits for the wave's outstanding GLOBAL stores (s_waitcnt

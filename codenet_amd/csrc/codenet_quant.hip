@@ -445,6 +445,33 @@ extern "C" int cdn_quantact_forward_partials(const float *x, float *out, int64_t
   return cdn::check_launch("quantact forward (partials)");
 }
 
+// ---- apply-only forms (round 6): the producer has already updated the QuantAct (cdn_codenet_*_forward_update) --------
+extern "C" int cdn_quantact_apply(const float *x, float *out, int64_t numel, const void *state, void *stream) {
+  CDN_REQUIRE(x && out && state && numel > 0 && numel < (1ll << 31), CDN_ERR_ARG, "null pointer or bad size");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, CDN_ERR_ARG,
+              "tensors must be 16-byte aligned");
+  fake_quant_kernel<<<stream_grid(numel), 256, 0, cdn::as_stream(stream)>>>(
+      x, out, nullptr, (long)numel, static_cast<unsigned *>(const_cast<void *>(state)));
+  return cdn::check_launch("quantact apply");
+}
+
+extern "C" int cdn_quantact_relu_apply(const float *y, float *out, int64_t planes, int64_t H, int64_t W, int up,
+                                       const void *state, void *stream) {
+  CDN_REQUIRE(y && out && state, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(planes > 0 && H > 0 && W > 0 && planes * H * W < (1ll << 31), CDN_ERR_ARG, "bad size");
+  CDN_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+              CDN_ERR_ARG, "tensors must be 16-byte aligned");
+  hipStream_t st = cdn::as_stream(stream);
+  unsigned *stt = static_cast<unsigned *>(const_cast<void *>(state));
+  const long numel = (long)(planes * H * W), rows = (long)(planes * H);
+  if (up)
+    relu_fq_up2_kernel<<<(unsigned)std::min<long>(cdn::ceil_div(rows * cdn::ceil_div(W, 2), 256), (long)cdn::kCUs * 16),
+                         256, 0, st>>>(y, out, rows, (int)W, stt);
+  else
+    relu_fq_kernel<<<stream_grid(numel), 256, 0, st>>>(y, out, numel, stt);
+  return cdn::check_launch("quantact relu [up2] apply");
+}
+
 static int relu_up2_impl(const float *y, float *out, int64_t planes, int64_t H, int64_t W, float *x_min, float *x_max,
                          void *state, const float *partials, int64_t n_partials, int bits, double momentum, int running,
                          void *stream, int up = 1) {

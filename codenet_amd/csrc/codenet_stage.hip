@@ -70,7 +70,7 @@ constexpr int kSclWaves = 16;
 __global__ void __launch_bounds__(kSclWaves * 64)
 scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
              const float *__restrict__ b, float *__restrict__ s, int C, int HW, float lo,
-             float hi, float2 *__restrict__ mm) {
+             float hi, float2 *__restrict__ mm, cdn::QUpdate qu) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
   const int n = blockIdx.y;
@@ -116,7 +116,13 @@ scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
     has_nan = (v != v);
   }
   // training path: this workgroup's {min, max} of what it wrote, for the QuantAct behind it (no separate range pass)
-  if (mm) {
+  // (round 6: qu.counters != NULL -- the LAST workgroup to arrive runs the QuantAct's range update itself, as the fused
+  // inference schedule does: no update launch behind this kernel)
+  if (qu.counters) {
+    __syncthreads();
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), nullptr, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, &red[0][0]);
+  } else if (mm) {
     __syncthreads();
     cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], &red[0][0]);
   }
@@ -242,9 +248,9 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
 template <bool UP>
 __global__ void __launch_bounds__(kDwThreads)
 dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
-           float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm) {
+           float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm, cdn::QUpdate qu) {
   extern __shared__ float smem[];
-  __shared__ float red_mm[8];
+  __shared__ float red_mm[16];
   float mn = INFINITY, mx = -INFINITY;
   bool has_nan = false;      // a NaN among the tracked values: fminf / fmaxf drop it, the reference's min() / max() do not
   const int HW = H * W;
@@ -329,7 +335,10 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
 #undef CDN_DW4_CH
     }
   }
-  if (mm) cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
+  if (qu.counters)
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), nullptr, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, red_mm);
+  else if (mm) cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1209,15 +1218,19 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
 // The three forward kernels of the stage optionally leave one {min, max} pair per workgroup of the tensor they wrote
 // (`partials`, *_range_partials(...) float2 entries): the training path's QuantAct behind them reduces those instead of
 // re-reading the tensor (cdn_quantact_forward_partials / cdn_quantact_relu_up2_forward_partials).
+static const cdn::QUpdate kNoUpdate{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0, nullptr};
+
+// qu (round 6): the QuantAct behind the kernel, updated by its last workgroup (cdn_codenet_*_forward_update)
 static int scale_forward_impl(const float *x, const float *w_scale, const float *b_scale, float *s, int64_t N,
-                              int64_t C, int64_t H, int64_t W, float lo, float hi, float *partials, void *stream) {
+                              int64_t C, int64_t H, int64_t W, float lo, float hi, float *partials, void *stream,
+                              const cdn::QUpdate *qu = nullptr) {
   CDN_REQUIRE(x && w_scale && s, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   const int HW = (int)(H * W);
   dim3 grid((unsigned)cdn::ceil_div(HW, 64), (unsigned)N);
   scale_kernel<<<grid, kSclWaves * 64, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo, hi,
-                                                         reinterpret_cast<float2 *>(partials));
+                                                         reinterpret_cast<float2 *>(partials), qu ? *qu : kNoUpdate);
   return cdn::check_launch("codenet scale forward");
 }
 
@@ -1268,7 +1281,7 @@ static int dw_up2_channels_per_wg(int64_t N, int64_t C, int64_t H, int64_t W) {
 }
 
 static int dw_up2_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
-                               int64_t H, int64_t W, float *partials, void *stream) {
+                               int64_t H, int64_t W, float *partials, void *stream, const cdn::QUpdate *qu = nullptr) {
   CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
@@ -1281,7 +1294,7 @@ static int dw_up2_forward_impl(const float *x, const float *s, const float *w_dw
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void *)dw4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dw4_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC,
-                                                  reinterpret_cast<float2 *>(partials));
+                                                  reinterpret_cast<float2 *>(partials), qu ? *qu : kNoUpdate);
   return cdn::check_launch("codenet dw forward (up-sampled input)");
 }
 
@@ -1439,7 +1452,7 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
 }
 
 static int dw_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
-                           int64_t H, int64_t W, float *partials, void *stream) {
+                           int64_t H, int64_t W, float *partials, void *stream, const cdn::QUpdate *qu = nullptr) {
   CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
@@ -1453,11 +1466,15 @@ static int dw_forward_impl(const float *x, const float *s, const float *w_dw, fl
     if ((CC & 3) == 0 && (C & 3) == 0) {    // channel quads in LDS: one 16-byte read per cell and quad
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)dw4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      dw4_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
+      dw4_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm,
+                                                       qu ? *qu : kNoUpdate);
     }
-    else
+    else {
+      CDN_REQUIRE(!qu, CDN_ERR_UNSUPPORTED, "the in-kernel range update needs the channel-quad gather (C %% 4 == 0)");
       dw_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm);
+    }
   } else {
+    CDN_REQUIRE(!qu, CDN_ERR_UNSUPPORTED, "the in-kernel range update needs an LDS-resident plane");
     CC = 4;
     const size_t lds = (size_t)((CC * 9 + 3) & ~3) * sizeof(float);
     dim3 grid((unsigned)cdn::ceil_div(C, CC), (unsigned)N);
@@ -1481,6 +1498,48 @@ extern "C" int cdn_codenet_dw_forward_range(const float *x, const float *s, cons
                                             int64_t C, int64_t H, int64_t W, float *partials, void *stream) {
   CDN_REQUIRE(partials, CDN_ERR_ARG, "null partials pointer");
   return dw_forward_impl(x, s, w_dw, d, N, C, H, W, partials, stream);
+}
+
+// ---- round 6: the QAT step's producers update the QuantAct behind them in their LAST workgroup (cdn::block_minmax_finish,
+// the fused inference schedule's protocol) -- no cdn_quantact_forward_partials update launch, no state-copy launch.
+// counters: cdn_quantact_arrive_words() zero-initialised 32-bit words per QuantAct (left zero by every call);
+// state_copy (8 words, may be NULL): the state after the update, for the backward pass.
+static cdn::QUpdate make_update(float *x_min, float *x_max, void *state, void *counters, int bits, double momentum,
+                                void *state_copy) {
+  return cdn::QUpdate{x_min, x_max, static_cast<unsigned *>(state), static_cast<unsigned *>(counters),
+                      (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1, static_cast<unsigned *>(state_copy)};
+}
+#define CDN_REQUIRE_UPDATE()                                                                                          \
+  CDN_REQUIRE(x_min && x_max && state && counters, CDN_ERR_ARG, "null QuantAct pointer");                             \
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits)
+
+extern "C" int cdn_quantact_arrive_words(void) { return cdn::kArriveWords; }
+
+extern "C" int cdn_codenet_scale_forward_update(const float *x, const float *w_scale, const float *b_scale, float *s,
+                                                int64_t N, int64_t C, int64_t H, int64_t W, float lo, float hi,
+                                                float *x_min, float *x_max, void *state, void *counters, int bits,
+                                                double momentum, void *state_copy, void *stream) {
+  CDN_REQUIRE_UPDATE();
+  const cdn::QUpdate qu = make_update(x_min, x_max, state, counters, bits, momentum, state_copy);
+  return scale_forward_impl(x, w_scale, b_scale, s, N, C, H, W, lo, hi, nullptr, stream, &qu);
+}
+
+extern "C" int cdn_codenet_dw_forward_update_supported(int64_t N, int64_t C, int64_t H, int64_t W, int up2) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (C & 3)) return 0;
+  if (up2) return dw_up2_channels_per_wg(N, C, H, W) >= 4 ? 1 : 0;
+  const int CC = dw_channels_per_wg(C, H, W);
+  return (CC >= 4 && (CC & 3) == 0) ? 1 : 0;
+}
+
+extern "C" int cdn_codenet_dw_forward_update(const float *x, const float *s, const float *w_dw, float *d, int64_t N,
+                                             int64_t C, int64_t H, int64_t W, int up2, float *x_min, float *x_max,
+                                             void *state, void *counters, int bits, double momentum, void *state_copy,
+                                             void *stream) {
+  CDN_REQUIRE_UPDATE();
+  const cdn::QUpdate qu = make_update(x_min, x_max, state, counters, bits, momentum, state_copy);
+  // (up2: x, s are the STORED tensors, H x W the up-sampled resolution -- cdn_codenet_dw_up2_forward's convention)
+  if (up2) return dw_up2_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream, &qu);
+  return dw_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream, &qu);
 }
 
 static int pointwise_forward_impl(const float *d, const float *w_pw, const float *bias, const float *ep_scale,

@@ -924,7 +924,7 @@ __global__ void __launch_bounds__(256)
 pwi8n_kernel(const float *__restrict__ D, const unsigned *__restrict__ dq, const signed char *__restrict__ Wkb,
              const float *__restrict__ wscale, const int *__restrict__ wsum, const float *__restrict__ Wq,
              const float *__restrict__ bias, float *__restrict__ Y, float2 *__restrict__ mm, int C, int Co, int HW,
-             int ncg) {
+             int ncg, cdn::QUpdate qu, int relu_range) {
   extern __shared__ float4 pwn_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1086,7 +1086,17 @@ pwi8n_kernel(const float *__restrict__ D, const unsigned *__restrict__ dq, const
       }
     }
   }
-  if (mm) {
+  if (qu.counters) {
+    // round 6: the QuantAct behind y updated by the last workgroup; relu_range: it sits behind a ReLU (the block after a
+    // stage) and tracks the extremes of max(y, 0)
+    if (relu_range) {
+      mn = cdn::relu_keep_nan(mn);
+      mx = cdn::relu_keep_nan(mx);
+    }
+    __syncthreads();
+    cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), nullptr, blockIdx.y * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y, qu, reinterpret_cast<float *>(pwn_lds));
+  } else if (mm) {
     __syncthreads();
     cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x],
                             reinterpret_cast<float *>(pwn_lds));
@@ -1234,10 +1244,37 @@ extern "C" int64_t cdn_codenet_pointwise_i8_range_partials(int64_t N, int64_t C,
   return pwn_plan(N, C, Co, HW, &p) ? (int64_t)p.grid_x * N : 0;
 }
 
+static int pointwise_i8_forward_impl(const float *d, const void *d_state, const float *w_q, const float *bias, float *y,
+                                     int64_t N, int64_t C, int64_t Co, int64_t HW, float *partials, void *workspace,
+                                     size_t workspace_bytes, void *stream, const cdn::QUpdate &qu, int relu_range);
+
 extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void *d_state, const float *w_q,
                                                       const float *bias, float *y, int64_t N, int64_t C, int64_t Co,
                                                       int64_t HW, float *partials, void *workspace,
                                                       size_t workspace_bytes, void *stream) {
+  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0, nullptr};
+  return pointwise_i8_forward_impl(d, d_state, w_q, bias, y, N, C, Co, HW, partials, workspace, workspace_bytes, stream,
+                                   none, 0);
+}
+
+// The same launch with the QuantAct BEHIND y updated by its last workgroup (round 6; see cdn_codenet_scale_forward_update):
+// relu_range != 0: that QuantAct sits behind a ReLU and tracks the extremes of max(y, 0) (the block after a stage).
+extern "C" int cdn_codenet_pointwise_i8_forward_update(const float *d, const void *d_state, const float *w_q,
+                                                       const float *bias, float *y, int64_t N, int64_t C, int64_t Co,
+                                                       int64_t HW, void *workspace, size_t workspace_bytes,
+                                                       int relu_range, float *x_min, float *x_max, void *state,
+                                                       void *counters, int bits, double momentum, void *stream) {
+  CDN_REQUIRE(x_min && x_max && state && counters, CDN_ERR_ARG, "null QuantAct pointer");
+  CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
+  const cdn::QUpdate qu{x_min, x_max, static_cast<unsigned *>(state), static_cast<unsigned *>(counters),
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1, nullptr};
+  return pointwise_i8_forward_impl(d, d_state, w_q, bias, y, N, C, Co, HW, nullptr, workspace, workspace_bytes, stream,
+                                   qu, relu_range);
+}
+
+static int pointwise_i8_forward_impl(const float *d, const void *d_state, const float *w_q, const float *bias, float *y,
+                                     int64_t N, int64_t C, int64_t Co, int64_t HW, float *partials, void *workspace,
+                                     size_t workspace_bytes, void *stream, const cdn::QUpdate &qu, int relu_range) {
   CDN_REQUIRE(d && d_state && w_q && y && workspace, CDN_ERR_ARG, "null pointer");
   PwnPlan p;
   CDN_REQUIRE(pwn_plan(N, C, Co, HW, &p), CDN_ERR_UNSUPPORTED,
@@ -1264,7 +1301,7 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
     (void)hipFuncSetAttribute((const void *)pwi8n_kernel<TN_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                               (int)p.lds);                                                                          \
     pwi8n_kernel<TN_, KS_><<<grid, 256, p.lds, st>>>(d, dq, kb, wscale, wsum, w_q, bias, y, mm, (int)C, (int)Co,    \
-                                                     (int)HW, p.ncg);                                               \
+                                                     (int)HW, p.ncg, qu, relu_range);                               \
   } while (0)
   if (p.tn == 4 && p.ks == 4) CDN_PWN(4, 4);
   else if (p.tn == 4) CDN_PWN(4, 1);

@@ -95,7 +95,13 @@ class CodenetStageFunction(Function):
         ctx.x_up = bool(x_up)
         ctx.set_materialize_grads(False)      # (no zero tensor for the non-differentiable partials output: a launch per stage)
         # every producer leaves the {min, max} pairs of its output for the QuantAct behind it: no range passes
-        if act_s is not None and act_s.running_stat:
+        post_act = want_range if (want_range is not None and not isinstance(want_range, bool)) else None
+        want_range = bool(want_range) or post_act is not None
+        if act_s is not None and act_s.running_stat and ops.FUSE_RANGE_UPDATE:
+            # round 6: the producer's last workgroup updates the QuantAct (no update launch); one apply launch for the plane
+            s_c = ops.codenet_scale_update(x, w_scale, b_scale, lo, hi, act_s)
+            s = ops.quantact_apply(s_c, act_s)
+        elif act_s is not None and act_s.running_stat:
             s_c, sp = ops.codenet_scale(x, w_scale, b_scale, lo, hi, want_range=True)   # clamped, pre-quantisation
             s = ops.quantact_forward_partials(s_c, act_s, sp)
         else:
@@ -104,7 +110,12 @@ class CodenetStageFunction(Function):
         have_pw = w_pw is not None
         d_snap = None          # snapshot of act_d's state when d stays un-quantised in memory (quantised by its consumers)
         with torch.no_grad():
-            if act_d is not None and act_d.running_stat and have_pw and FUSE_DQ_ON_LOAD:
+            if (act_d is not None and act_d.running_stat and have_pw and FUSE_DQ_ON_LOAD
+                    and ops.codenet_dw_update_supported(x, x_up)):
+                # round 6: the gather's last workgroup updates the QuantAct and leaves the state snapshot itself
+                d, d_snap = ops.codenet_dw_update(x, s, w_dw, act_d, up2=x_up)
+                d_q = d
+            elif act_d is not None and act_d.running_stat and have_pw and FUSE_DQ_ON_LOAD:
                 # the gather leaves its {min, max} pairs, the QuantAct only updates, the pointwise kernel (and, in the
                 # backward, the weight-gradient kernel) fake-quantise d while loading it: d_q is never stored
                 d, dp = ops.codenet_dw_up2(x, s, w_dw) if x_up else ops.codenet_dw_range(x, s, w_dw)
@@ -119,7 +130,12 @@ class CodenetStageFunction(Function):
         yp = None
         keep = {}
         if have_pw and want_range:
-            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap, int8_weights=pw_int8, keep=keep)
+            upd = ((post_act, True) if (post_act is not None and post_act.running_stat and native_act_ok(post_act)
+                                        and not getattr(post_act, "global_range", False)) else None)
+            y, yp = ops.codenet_pointwise(d_q, w_pw, b_pw, want_range=True, d_state=d_snap, int8_weights=pw_int8, keep=keep,
+                                          update_act=upd)
+            if keep.get("range_committed"):
+                post_act._range_committed = True      # (ReluQuant / ReluQuantUpsample behind the stage: apply only)
         else:
             y = ops.codenet_pointwise(d_q, w_pw, b_pw, d_state=d_snap, int8_weights=pw_int8, keep=keep) if have_pw else d_q
         ctx.pw_fwd_ws = keep.get("fwd_ws")      # (the int8 forward's weight scales: the data gradient reads them)
@@ -478,7 +494,13 @@ class ReluQuantUpsample(Function):
         y = y.contiguous()
         Nb, C, H, W = y.shape
         out = torch.empty(Nb, C, 2 * H, 2 * W, device=y.device)
-        if partials is not None and partials.shape[0] > 0 and act.running_stat:
+        if getattr(act, "_range_committed", False):
+            # round 6: the stage's pointwise kernel has already updated this QuantAct (its last workgroup): apply only
+            act._range_committed = False
+            rc = N_.lib().cdn_quantact_relu_apply(_p(y), _p(out), Nb * C, H, W, 1, _p(act._device_state(y.device)),
+                                                  ops._stream(y))
+            N_.check(rc, "cdn_quantact_relu_apply")
+        elif partials is not None and partials.shape[0] > 0 and act.running_stat:
             # the stage's pointwise kernel left the {min, max} pairs of y: no range pass over y
             rc = N_.lib().cdn_quantact_relu_up2_forward_partials(
                 _p(y), _p(out), Nb * C, H, W, _p(act.x_min), _p(act.x_max), _p(act._device_state(y.device)),
@@ -516,6 +538,14 @@ class ReluQuant(Function):
         ops._gpu_f32(y)
         y = y.contiguous()
         out = torch.empty_like(y)
+        if getattr(act, "_range_committed", False):      # (see ReluQuantUpsample.forward)
+            act._range_committed = False
+            Nb, C, H, W = y.shape
+            rc = N_.lib().cdn_quantact_relu_apply(_p(y), _p(out), Nb * C, H, W, 0, _p(act._device_state(y.device)),
+                                                  ops._stream(y))
+            N_.check(rc, "cdn_quantact_relu_apply")
+            ctx.save_for_backward(y)
+            return out
         use_p = partials is not None and partials.shape[0] > 0 and act.running_stat
         rc = N_.lib().cdn_quantact_relu_forward(
             _p(y), _p(out), y.numel(), _p(act.x_min), _p(act.x_max), _p(act._device_state(y.device)),
@@ -573,7 +603,7 @@ def forward_stage_blocks(seq, x):
     for i in range(0, len(mods), 3):
         # (y, {min, max} pairs of y) on the native training path; the weights of all stages from two launches
         pw = (pre[i // 3] if pre is not None else (None, None)) + (pre_pw[i // 3] if pre_pw is not None else (None, None))
-        y = mods[i](x, want_range=True, x_up=x_up, pre_w=pw)
+        y = mods[i](x, want_range=mods[i + 1][1], x_up=x_up, pre_w=pw)      # (the QuantAct behind the stage: see forward)
         y, part = y if isinstance(y, tuple) else (y, None)
         nxt = mods[i + 3] if i + 3 < len(mods) else None
         # the next stage reads its input through the up-sampling (stored tensor, never materialised) where its gather

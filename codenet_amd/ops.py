@@ -97,6 +97,73 @@ def codenet_scale(x, w_scale, b_scale, lo, hi, want_range=False):
     return s
 
 
+# A/B switch (tools/train_step_bench.py --no-fused-update): the QAT step's producers update the QuantAct behind them in their
+# last workgroup (round 6) instead of leaving {min, max} partials for an update launch
+FUSE_RANGE_UPDATE = True
+
+
+def _arrive(act, device):
+    """The QuantAct's arrival counters for the in-kernel range update (zero between launches)."""
+    buf = getattr(act, "_arrive_buf", None)
+    if buf is None or buf.device != device:
+        buf = act._arrive_buf = torch.zeros(N_.lib().cdn_quantact_arrive_words(), dtype=torch.int32, device=device)
+    return buf
+
+
+def _update_args(act, device, snap=None):
+    return (_p(act.x_min), _p(act.x_max), _p(act._device_state(device)), _p(_arrive(act, device)),
+            int(act.activation_bit), float(act.momentum)) + ((_p(snap),) if snap is not False else ())
+
+
+def codenet_scale_update(x, w_scale, b_scale, lo, hi, act):
+    """codenet_scale + the range update of the QuantAct behind it by the launch's last workgroup
+    (cdn_codenet_scale_forward_update): returns the clamped, PRE-quantisation s; act's range / state are updated."""
+    _gpu_f32(x, w_scale, b_scale)
+    x = x.contiguous()
+    Nb, C, H, W = x.shape
+    w = w_scale.contiguous().view(-1)
+    if w.numel() != C:
+        raise RuntimeError("conv_scale weight must have %d elements, got %d" % (C, w.numel()))
+    b = b_scale.contiguous().view(-1) if b_scale is not None else None
+    s = x.new_empty(Nb, 1, H, W)
+    rec = _tic("scale", (C, H, W))
+    rc = N_.lib().cdn_codenet_scale_forward_update(_p(x), _p(w), _p(b), _p(s), Nb, C, H, W, float(lo), float(hi),
+                                                   *_update_args(act, x.device, None), _stream(x))
+    _toc(rec)
+    N_.check(rc, "cdn_codenet_scale_forward_update")
+    return s
+
+
+def quantact_apply(x, act):
+    """Fake-quantisation of x with the QuantAct's state as its producer left it (cdn_quantact_apply)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    rc = N_.lib().cdn_quantact_apply(_p(x), _p(out), x.numel(), _p(act._device_state(x.device)), _stream(x))
+    N_.check(rc, "cdn_quantact_apply")
+    return out
+
+
+def codenet_dw_update_supported(x, up2):
+    Nb, C, H, W = x.shape
+    return bool(FUSE_RANGE_UPDATE and N_.lib().cdn_codenet_dw_forward_update_supported(
+        Nb, C, (2 * H) if up2 else H, (2 * W) if up2 else W, int(bool(up2))))
+
+
+def codenet_dw_update(x, s, w_dw, act, up2=False):
+    """The gather forward + the update of the QuantAct behind d by the launch's last workgroup: (d, state snapshot).
+    up2: x, s are the stored tensors (codenet_dw_up2's convention)."""
+    _gpu_f32(x, s, w_dw)
+    x, s, w_dw = x.contiguous(), s.contiguous(), w_dw.contiguous()
+    Nb, C, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
+    d = x.new_empty(Nb, C, H, W)
+    snap = torch.empty(8, dtype=torch.int32, device=x.device)
+    rc = N_.lib().cdn_codenet_dw_forward_update(_p(x), _p(s), _p(w_dw), _p(d), Nb, C, H, W, int(bool(up2)),
+                                                *_update_args(act, x.device, snap), _stream(x))
+    N_.check(rc, "cdn_codenet_dw_forward_update")
+    return d, snap
+
+
 def codenet_dw_range(x, s, w_dw):
     """The gather / depthwise forward (no autograd) + the {min, max} pairs of its output."""
     _gpu_f32(x, s, w_dw)
@@ -213,7 +280,7 @@ INT8_FORWARD = True
 
 
 def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=False, want_range=False, d_state=None,
-                      int8_weights=False, keep=None):
+                      int8_weights=False, keep=None, update_act=None):
     """y = conv1x1(d; C->Co) (+bias) (*ep_scale + ep_shift) (ReLU) on f32 MFMA.  want_range: also the per-workgroup
     {min, max} pairs of y.  d_state (8-word QuantAct state tensor): d holds pre-quantisation values, fake-quantised
     with that state while the kernel loads them.  int8_weights (with d_state): w_pw is a per-channel symmetric <= 4-bit
@@ -232,12 +299,24 @@ def codenet_pointwise(d, w_pw, bias=None, ep_scale=None, ep_shift=None, relu=Fal
     lib = N_.lib()
     if (int8_weights and INT8_FORWARD and d_state is not None and ep_scale is None and not relu
             and lib.cdn_codenet_pointwise_i8_supported(Nb, C, Co, H * W)):
-        part = _partials(lib.cdn_codenet_pointwise_i8_range_partials(Nb, C, Co, H * W), d) if want_range else None
         need = lib.cdn_codenet_pointwise_i8_workspace_bytes(Nb, C, Co, H * W)
         ws = torch.empty(need + 256, dtype=torch.uint8, device=d.device)
         wp = (ws.data_ptr() + 255) // 256 * 256
-        rc = lib.cdn_codenet_pointwise_i8_forward_range(_p(d), _p(d_state), _p(w), _p(bias.contiguous() if bias is not None
-                                                                                      else None), _p(y), Nb, C, Co, H * W,
+        bp = _p(bias.contiguous() if bias is not None else None)
+        if update_act is not None and FUSE_RANGE_UPDATE:
+            # update_act = (QuantAct behind y, relu_range): updated by the launch's last workgroup; no partials
+            act, relu_range = update_act
+            rc = lib.cdn_codenet_pointwise_i8_forward_update(_p(d), _p(d_state), _p(w), bp, _p(y), Nb, C, Co, H * W, wp, need,
+                                                             int(bool(relu_range)), *_update_args(act, d.device, False),
+                                                             _stream(d))
+            _toc(rec)
+            N_.check(rc, "cdn_codenet_pointwise_i8_forward_update")
+            if keep is not None:
+                keep["fwd_ws"] = (ws, wp)
+                keep["range_committed"] = True
+            return (y, None) if want_range else y
+        part = _partials(lib.cdn_codenet_pointwise_i8_range_partials(Nb, C, Co, H * W), d) if want_range else None
+        rc = lib.cdn_codenet_pointwise_i8_forward_range(_p(d), _p(d_state), _p(w), bp, _p(y), Nb, C, Co, H * W,
                                                         _p(part), wp, need, _stream(d))
         _toc(rec)
         N_.check(rc, "cdn_codenet_pointwise_i8_forward_range")

@@ -226,6 +226,33 @@ int cdn_quantact_forward_partials(const float *x, float *out, int64_t numel, flo
  *   partials: ..._range_partials pairs, or NULL.
  * Reference: conv_channel under autograd, quant_modules.py:412-419 (F.conv2d on the fake-quantised operands). */
 int cdn_codenet_pointwise_i8_supported(int64_t N, int64_t C, int64_t Co, int64_t HW);
+/* Round 6: the QAT step's three producers -- scale prediction, gather, int8 pointwise -- with the QuantAct BEHIND them
+ * updated by the launch's last workgroup (the fused inference schedule's arrival protocol, cdn::block_minmax_finish)
+ * instead of per-workgroup {min, max} partials + a cdn_quantact_forward_partials update launch: same update arithmetic
+ * (quant_modules.py:203-219: `+=` initialisation / two-rounding EMA), same extremes, nine launches fewer per step.
+ *   counters: cdn_quantact_arrive_words() 32-bit words per QuantAct, zero before the first call, left zero by every call;
+ *   state_copy (8 words, may be NULL): the state after the update -- what cdn_quantact_forward_partials' state_copy gave;
+ *   ..._dw_forward_update: up2 != 0 = cdn_codenet_dw_up2_forward's convention (x, s stored, H x W up-sampled);
+ *   ..._pointwise_i8_forward_update: relu_range != 0 = the QuantAct sits behind a ReLU (tracks max(y, 0));
+ *   cdn_quantact_apply / cdn_quantact_relu_apply: the fake-quantisation [ReLU first; up != 0: + nearest x2] with the state
+ *   as the producer left it -- the second half of cdn_quantact_forward_partials / cdn_quantact_relu[_up2]_forward_partials.
+ * Reference: QuantAct.forward, quant_modules.py:203-225. */
+int cdn_quantact_arrive_words(void);
+int cdn_codenet_scale_forward_update(const float *x, const float *w_scale, const float *b_scale, float *s, int64_t N,
+                                     int64_t C, int64_t H, int64_t W, float lo, float hi, float *x_min, float *x_max,
+                                     void *state, void *counters, int bits, double momentum, void *state_copy,
+                                     void *stream);
+int cdn_codenet_dw_forward_update_supported(int64_t N, int64_t C, int64_t H, int64_t W, int up2);
+int cdn_codenet_dw_forward_update(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
+                                  int64_t H, int64_t W, int up2, float *x_min, float *x_max, void *state, void *counters,
+                                  int bits, double momentum, void *state_copy, void *stream);
+int cdn_codenet_pointwise_i8_forward_update(const float *d, const void *d_state, const float *w_q, const float *bias,
+                                            float *y, int64_t N, int64_t C, int64_t Co, int64_t HW, void *workspace,
+                                            size_t workspace_bytes, int relu_range, float *x_min, float *x_max,
+                                            void *state, void *counters, int bits, double momentum, void *stream);
+int cdn_quantact_apply(const float *x, float *out, int64_t numel, const void *state, void *stream);
+int cdn_quantact_relu_apply(const float *y, float *out, int64_t planes, int64_t H, int64_t W, int up, const void *state,
+                            void *stream);
 size_t cdn_codenet_pointwise_i8_workspace_bytes(int64_t N, int64_t C, int64_t Co, int64_t HW);
 int64_t cdn_codenet_pointwise_i8_range_partials(int64_t N, int64_t C, int64_t Co, int64_t HW);
 int cdn_codenet_pointwise_i8_forward_range(const float *d, const void *d_state, const float *w_q, const float *bias,

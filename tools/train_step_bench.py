@@ -42,7 +42,12 @@ def main():
     ap.add_argument("--no-bf16-wgrad", action="store_true", help="A/B: the weight gradient of conv_channel on f32 MFMA")
     ap.add_argument("--no-multi-prep", action="store_true", help="A/B: one weight-prep launch per small weight tensor")
     ap.add_argument("--atomic-dw-bwd", action="store_true", help="A/B: float atomics for grad_s / grad_w_dw (not reproducible)")
+    ap.add_argument("--no-fused-update", action="store_true", help="A/B: QuantAct updates as launches of their own behind "
+                    "the producers (round 5) instead of in the producers' last workgroup")
     a = ap.parse_args()
+    if a.no_fused_update:
+        from codenet_amd import ops as _ops3
+        _ops3.FUSE_RANGE_UPDATE = False
     if a.atomic_dw_bwd:
         from codenet_amd.functions import codenet_stage as _cs5
         _cs5.REPRODUCIBLE_DW_BWD = False
