@@ -229,8 +229,6 @@ struct QUpdate {
   unsigned *counters;    // fused schedule only: kArriveWords zero-initialised arrival counters
   float m_minus_1, one_minus_m;
   int bits, running;
-  unsigned *state_copy;  // optional (may be NULL): receives the 8 state words after the update -- the snapshot a backward
-                         // pass reads (round 6: the training path's producers update their QuantAct themselves)
 };
 // Arrival counters: 64 group counters + 1 top counter, one per 64-byte line (a single contended
 // word sustains only ~88 atomics/us; 2048 workgroups on one word cost ~25 us).
@@ -283,10 +281,6 @@ __device__ __forceinline__ void quantact_update_device(const QUpdate &u, float b
             !(fabsf(zp) < 4.0e6f)) ? 1u : 0u;   // (the int8 kernels do integer arithmetic on zp)
   }
   u.state[6] = wide;
-  if (u.state_copy) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u.state_copy[i] = u.state[i];
-  }
 }
 
 // Barrier of the range epilogue.  __syncthreads() also waits for the wave's outstanding GLOBAL stores (s_waitcnt
@@ -374,6 +368,16 @@ __device__ __forceinline__ void block_minmax_finish(float mn, float mx, float2 *
   }
   if (threadIdx.x == 64)
     __hip_atomic_store(&u.counters[16 * kArriveGroups], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// After block_minmax_finish in a kernel of the training path (round 6): the LAST workgroup (its flag is still in
+// red[2 * nwaves]) leaves the snapshot of the updated state a backward pass reads.  Thread 0 wrote the state itself.
+__device__ __forceinline__ void last_block_state_copy(const QUpdate &u, unsigned *state_copy, const float *red) {
+  const int nw = (blockDim.x + 63) >> 6;
+  if (state_copy && threadIdx.x == 0 && red[2 * nw] != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) state_copy[i] = u.state[i];
+  }
 }
 
 // Workgroup-level min/max -> ONE {min,max} pair stored at out[0] (plain store, no atomics: a

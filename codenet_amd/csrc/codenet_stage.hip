@@ -70,7 +70,7 @@ constexpr int kSclWaves = 16;
 __global__ void __launch_bounds__(kSclWaves * 64)
 scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
              const float *__restrict__ b, float *__restrict__ s, int C, int HW, float lo,
-             float hi, float2 *__restrict__ mm, cdn::QUpdate qu) {
+             float hi, float2 *__restrict__ mm, cdn::QUpdate qu, unsigned *__restrict__ state_copy) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
   const int n = blockIdx.y;
@@ -122,6 +122,7 @@ scale_kernel(const float *__restrict__ x, const float *__restrict__ w,
     __syncthreads();
     cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), nullptr, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, &red[0][0]);
+    cdn::last_block_state_copy(qu, state_copy, &red[0][0]);
   } else if (mm) {
     __syncthreads();
     cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], &red[0][0]);
@@ -248,7 +249,8 @@ dw_kernel(const float *__restrict__ x, const float *__restrict__ s, const float 
 template <bool UP>
 __global__ void __launch_bounds__(kDwThreads)
 dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float *__restrict__ wd,
-           float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm, cdn::QUpdate qu) {
+           float *__restrict__ d, int C, int H, int W, int CC, float2 *__restrict__ mm, cdn::QUpdate qu,
+           unsigned *__restrict__ state_copy) {
   extern __shared__ float smem[];
   __shared__ float red_mm[16];
   float mn = INFINITY, mx = -INFINITY;
@@ -335,10 +337,11 @@ dw4_kernel(const float *__restrict__ x, const float *__restrict__ s, const float
 #undef CDN_DW4_CH
     }
   }
-  if (qu.counters)
+  if (qu.counters) {
     cdn::block_minmax_finish(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), nullptr, blockIdx.y * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y, qu, red_mm);
-  else if (mm) cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
+    cdn::last_block_state_copy(qu, state_copy, red_mm);
+  } else if (mm) cdn::block_minmax_store(cdn::nan_lo(mn, has_nan), cdn::nan_hi(mx, has_nan), &mm[blockIdx.y * gridDim.x + blockIdx.x], red_mm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1218,19 +1221,19 @@ pointwise_kernel(const float *__restrict__ D, const float *__restrict__ Wp,
 // The three forward kernels of the stage optionally leave one {min, max} pair per workgroup of the tensor they wrote
 // (`partials`, *_range_partials(...) float2 entries): the training path's QuantAct behind them reduces those instead of
 // re-reading the tensor (cdn_quantact_forward_partials / cdn_quantact_relu_up2_forward_partials).
-static const cdn::QUpdate kNoUpdate{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0, nullptr};
+static const cdn::QUpdate kNoUpdate{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
 
 // qu (round 6): the QuantAct behind the kernel, updated by its last workgroup (cdn_codenet_*_forward_update)
 static int scale_forward_impl(const float *x, const float *w_scale, const float *b_scale, float *s, int64_t N,
                               int64_t C, int64_t H, int64_t W, float lo, float hi, float *partials, void *stream,
-                              const cdn::QUpdate *qu = nullptr) {
+                              const cdn::QUpdate *qu = nullptr, unsigned *qu_copy = nullptr) {
   CDN_REQUIRE(x && w_scale && s, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
   const int HW = (int)(H * W);
   dim3 grid((unsigned)cdn::ceil_div(HW, 64), (unsigned)N);
   scale_kernel<<<grid, kSclWaves * 64, 0, cdn::as_stream(stream)>>>(x, w_scale, b_scale, s, (int)C, HW, lo, hi,
-                                                         reinterpret_cast<float2 *>(partials), qu ? *qu : kNoUpdate);
+                                                         reinterpret_cast<float2 *>(partials), qu ? *qu : kNoUpdate, qu_copy);
   return cdn::check_launch("codenet scale forward");
 }
 
@@ -1281,7 +1284,8 @@ static int dw_up2_channels_per_wg(int64_t N, int64_t C, int64_t H, int64_t W) {
 }
 
 static int dw_up2_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
-                               int64_t H, int64_t W, float *partials, void *stream, const cdn::QUpdate *qu = nullptr) {
+                               int64_t H, int64_t W, float *partials, void *stream, const cdn::QUpdate *qu = nullptr,
+                               unsigned *qu_copy = nullptr) {
   CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
@@ -1294,7 +1298,7 @@ static int dw_up2_forward_impl(const float *x, const float *s, const float *w_dw
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void *)dw4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dw4_kernel<true><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC,
-                                                  reinterpret_cast<float2 *>(partials), qu ? *qu : kNoUpdate);
+                                                  reinterpret_cast<float2 *>(partials), qu ? *qu : kNoUpdate, qu_copy);
   return cdn::check_launch("codenet dw forward (up-sampled input)");
 }
 
@@ -1452,7 +1456,8 @@ extern "C" int cdn_codenet_dw_up2_backward(const float *x_stored, const float *s
 }
 
 static int dw_forward_impl(const float *x, const float *s, const float *w_dw, float *d, int64_t N, int64_t C,
-                           int64_t H, int64_t W, float *partials, void *stream, const cdn::QUpdate *qu = nullptr) {
+                           int64_t H, int64_t W, float *partials, void *stream, const cdn::QUpdate *qu = nullptr,
+                               unsigned *qu_copy = nullptr) {
   CDN_REQUIRE(x && s && w_dw && d, CDN_ERR_ARG, "null tensor pointer");
   CDN_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, CDN_ERR_ARG, "non-positive size");
   CDN_REQUIRE(N <= 65535 && N * C * H * W < (1ll << 31), CDN_ERR_UNSUPPORTED, "shape too large");
@@ -1467,7 +1472,7 @@ static int dw_forward_impl(const float *x, const float *s, const float *w_dw, fl
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)dw4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       dw4_kernel<false><<<grid, kDwThreads, lds, st>>>(x, s, w_dw, d, (int)C, (int)H, (int)W, CC, mm,
-                                                       qu ? *qu : kNoUpdate);
+                                                       qu ? *qu : kNoUpdate, qu_copy);
     }
     else {
       CDN_REQUIRE(!qu, CDN_ERR_UNSUPPORTED, "the in-kernel range update needs the channel-quad gather (C %% 4 == 0)");
@@ -1504,10 +1509,9 @@ extern "C" int cdn_codenet_dw_forward_range(const float *x, const float *s, cons
 // the fused inference schedule's protocol) -- no cdn_quantact_forward_partials update launch, no state-copy launch.
 // counters: cdn_quantact_arrive_words() zero-initialised 32-bit words per QuantAct (left zero by every call);
 // state_copy (8 words, may be NULL): the state after the update, for the backward pass.
-static cdn::QUpdate make_update(float *x_min, float *x_max, void *state, void *counters, int bits, double momentum,
-                                void *state_copy) {
+static cdn::QUpdate make_update(float *x_min, float *x_max, void *state, void *counters, int bits, double momentum) {
   return cdn::QUpdate{x_min, x_max, static_cast<unsigned *>(state), static_cast<unsigned *>(counters),
-                      (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1, static_cast<unsigned *>(state_copy)};
+                      (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1};
 }
 #define CDN_REQUIRE_UPDATE()                                                                                          \
   CDN_REQUIRE(x_min && x_max && state && counters, CDN_ERR_ARG, "null QuantAct pointer");                             \
@@ -1520,8 +1524,9 @@ extern "C" int cdn_codenet_scale_forward_update(const float *x, const float *w_s
                                                 float *x_min, float *x_max, void *state, void *counters, int bits,
                                                 double momentum, void *state_copy, void *stream) {
   CDN_REQUIRE_UPDATE();
-  const cdn::QUpdate qu = make_update(x_min, x_max, state, counters, bits, momentum, state_copy);
-  return scale_forward_impl(x, w_scale, b_scale, s, N, C, H, W, lo, hi, nullptr, stream, &qu);
+  const cdn::QUpdate qu = make_update(x_min, x_max, state, counters, bits, momentum);
+  return scale_forward_impl(x, w_scale, b_scale, s, N, C, H, W, lo, hi, nullptr, stream, &qu,
+                            static_cast<unsigned *>(state_copy));
 }
 
 extern "C" int cdn_codenet_dw_forward_update_supported(int64_t N, int64_t C, int64_t H, int64_t W, int up2) {
@@ -1536,10 +1541,11 @@ extern "C" int cdn_codenet_dw_forward_update(const float *x, const float *s, con
                                              void *state, void *counters, int bits, double momentum, void *state_copy,
                                              void *stream) {
   CDN_REQUIRE_UPDATE();
-  const cdn::QUpdate qu = make_update(x_min, x_max, state, counters, bits, momentum, state_copy);
+  const cdn::QUpdate qu = make_update(x_min, x_max, state, counters, bits, momentum);
+  unsigned *copy = static_cast<unsigned *>(state_copy);
   // (up2: x, s are the STORED tensors, H x W the up-sampled resolution -- cdn_codenet_dw_up2_forward's convention)
-  if (up2) return dw_up2_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream, &qu);
-  return dw_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream, &qu);
+  if (up2) return dw_up2_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream, &qu, copy);
+  return dw_forward_impl(x, s, w_dw, d, N, C, H, W, nullptr, stream, &qu, copy);
 }
 
 static int pointwise_forward_impl(const float *d, const float *w_pw, const float *bias, const float *ep_scale,

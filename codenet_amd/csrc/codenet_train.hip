@@ -930,7 +930,21 @@ pwi8n_kernel(const float *__restrict__ D, const unsigned *__restrict__ dq, const
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int n = blockIdx.y;
-  const int cg = blockIdx.x % ncg, pbg = blockIdx.x / ncg;
+  // (pixel-block group, column group) of this workgroup.  The column groups of one pixel block read the same rows of d:
+  // 8 ids apart they land on one XCD under round-robin dispatch and the second reading is an L2 hit (round 6: adjacent
+  // ids -- two XCDs -- made stage 0 read d twice from HBM: 97.7 MB per step for a 33.5-MB tensor, profiles/r05 PMC)
+  int cg, pbg;
+  {
+    const int grp = 8 * ncg, b = blockIdx.x, full = ((int)gridDim.x / grp) * grp;
+    if (b < full) {
+      const int lid = b % grp;
+      cg = lid >> 3;
+      pbg = (b - lid) / ncg + (lid & 7);
+    } else {
+      cg = b % ncg;
+      pbg = b / ncg;
+    }
+  }
   const int pb = KS == 4 ? pbg : pbg * 4 + w;                 // this wave's 32-pixel block
   const int npb = HW >> 5;
   const bool live = pb < npb;                                  // (KS = 1: the last workgroup of an image may be short)
@@ -1252,7 +1266,7 @@ extern "C" int cdn_codenet_pointwise_i8_forward_range(const float *d, const void
                                                       const float *bias, float *y, int64_t N, int64_t C, int64_t Co,
                                                       int64_t HW, float *partials, void *workspace,
                                                       size_t workspace_bytes, void *stream) {
-  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0, nullptr};
+  const cdn::QUpdate none{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 8, 0};
   return pointwise_i8_forward_impl(d, d_state, w_q, bias, y, N, C, Co, HW, partials, workspace, workspace_bytes, stream,
                                    none, 0);
 }
@@ -1267,7 +1281,7 @@ extern "C" int cdn_codenet_pointwise_i8_forward_update(const float *d, const voi
   CDN_REQUIRE(x_min && x_max && state && counters, CDN_ERR_ARG, "null QuantAct pointer");
   CDN_REQUIRE(bits >= 2 && bits <= 16, CDN_ERR_ARG, "bits must be in [2,16], got %d", bits);
   const cdn::QUpdate qu{x_min, x_max, static_cast<unsigned *>(state), static_cast<unsigned *>(counters),
-                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1, nullptr};
+                        (float)(momentum - 1.0), (float)(1.0 - momentum), bits, 1};
   return pointwise_i8_forward_impl(d, d_state, w_q, bias, y, N, C, Co, HW, nullptr, workspace, workspace_bytes, stream,
                                    qu, relu_range);
 }
