@@ -52,6 +52,9 @@ _SIGNATURES = {
     "cdn_codenet_stage_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_stage_fused_supported": (_i, [_i64] * 4 + [_i, _i]),
     "cdn_codenet_stage_chain_parts": (_i, [_i64] * 5),
+    "cdn_codenet_heads_pointwise_supported": (_i, [_i64, _i64, _i]),
+    "cdn_codenet_heads_pointwise_forward": (_i, [_vp, _vp, _i64, _i64, _i] + [_vp] * 5 + [_i] + [_vp] * 3 + [_i, _d, _i]
+                                            + [_vp, ctypes.c_size_t, _vp, _vp, _i64, _vp]),
     "cdn_codenet_stage_fused_forward_chain": (_i, [_vp, _i, _i, _vp] + [_i64] * 5 + [_vp, _vp, _f, _f] + [_vp] * 5
                                               + [_i, _vp, ctypes.c_size_t, _vp, _vp, _i, _vp, _vp, _vp]),
     "cdn_codenet_stage_fused_intermediates": (_i, [_i64] * 4 + [_i, _i, _i, _vp, _vp]),

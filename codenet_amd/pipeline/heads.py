@@ -20,9 +20,19 @@ class FusedHeads:
     by addressing, so the up-sampled 64-channel tensor is never built.  Same parameters and QuantAct
     buffers (updated in place) as calling the head modules on the unpacked tensor."""
 
-    def __init__(self, heads, int8_pointwise=True, small_tail=True, streams=True):
+    def __init__(self, heads, int8_pointwise=True, small_tail=True, streams=True, fuse_first=None):
         self.heads = dict(heads)
         self.int8_pointwise = int8_pointwise
+        # round 6: the heads' first 1x1 convs (64 -> 64 each, one shared input) as ONE launch (cdn_codenet_heads_pointwise_
+        # forward): the input is read from HBM once instead of once per head; bit-identical to the per-head launches.
+        # NOT the default: measured on one box, three interleaved pairs -- the heads alone 0.360 -> 0.337 ms (-6 %), but
+        # the whole network 2.548 -> 2.570 ms (+0.9 %): inside the network the stage output the heads read was written a
+        # moment ago and still sits in the 256-MB Infinity Cache, and three launches on three streams overlap each head's
+        # range pass / tail with the other heads' first convs.  CDN_HEADS_FUSE_FIRST=1 (or fuse_first=True) turns it on.
+        if fuse_first is None:
+            fuse_first = os.environ.get("CDN_HEADS_FUSE_FIRST", "0") == "1"
+        self.fuse_first = bool(fuse_first)
+        self._first = None            # (cache key, concatenated int8 forms of the first convs)
         # W4A8 heads with <= 4 output channels (wh, reg): range pass + depthwise -> quantise -> 1x1 conv as exact
         # integer dot products on the VALU (cdn_codenet_head_range_forward / _head_tail_small_forward)
         self.small_tail = small_tail and int8_pointwise
@@ -75,6 +85,33 @@ class FusedHeads:
                  ep=self._bn_affine(bn2), relu=1, act=None),
             dict(kind="pw", w=conv3.weight.reshape(conv3.out_channels, -1), bias=conv3.bias, ep=None,
                  relu=0, i8=None, act=None)]
+
+    def _first_convs(self, params, dev):
+        """The heads' first convs concatenated along the output rows (cached per weight version): dict of tensors, or None
+        when the heads do not have the common form (64 -> 64 int8 pointwise + ReLU + plain QuantAct each)."""
+        firsts = [layers[0] for layers in params.values()]
+        if not (2 <= len(firsts) <= 4) or any(len(layers) != 3 for layers in params.values()):
+            return None
+        C = firsts[0]["w"].shape[1]
+        for l_ in firsts:
+            if (l_["i8"] is None or l_["ep"] is not None or not l_["relu"] or l_["act"] is None
+                    or tuple(l_["w"].shape) != (64, C) or not act_fusable(l_["act"]) or l_["i8"][0].shape[0] != 64):
+                return None
+        key = tuple((t.data_ptr(), t._version) for l_ in firsts for t in (l_["w"], l_["i8"][0]))
+        if self._first is None or self._first[0] != key:
+            nh = len(firsts)
+            cat = dict(
+                w=torch.cat([l_["w"] for l_ in firsts], 0).contiguous(),
+                codes=torch.cat([l_["i8"][0] for l_ in firsts], 0).contiguous(),
+                scale=torch.cat([l_["i8"][1].reshape(-1) for l_ in firsts], 0).contiguous(),
+                colsum=torch.cat([l_["i8"][2].reshape(-1) for l_ in firsts], 0).contiguous(),
+                bias=(torch.cat([l_["bias"].reshape(-1) for l_ in firsts], 0).contiguous()
+                      if all(l_["bias"] is not None for l_ in firsts) else None),
+                omap=(torch.arange(64 * nh, dtype=torch.int32, device=dev) % 64).contiguous())
+            if cat["bias"] is None and any(l_["bias"] is not None for l_ in firsts):
+                return None
+            self._first = (key, cat)
+        return self._first[1]
 
     def _alloc(self, r, shape):
         from .. import _native as N_
@@ -156,6 +193,36 @@ class FusedHeads:
             for l_ in layers_:
                 if l_["act"] is not None:
                     l_["act"]._device_state(r.device)
+        # round 6: the three first convs as one launch on the main stream, in front of the fork (the side streams then wait
+        # for it: each head's range pass + tail follow on its own stream)
+        fused_first = False
+        first = (self._first_convs(params, r.device)
+                 if (self.fuse_first and use_streams and B.get("y1_side") is not None
+                     and len(B["y1_side"]) >= len(self.heads) - 1) else None)
+        if first is not None:
+            acts = [layers_[0]["act"] for layers_ in params.values()]
+            try:
+                bits, mom, running = uniform_act_settings(acts, "FusedHeads first convs")
+            except NotImplementedError:
+                first = None
+        if first is not None and lib.cdn_codenet_heads_pointwise_supported(M, C, len(self.heads)):
+            import ctypes
+            nh = len(self.heads)
+            if B.get("y1_all") is None:
+                B["y1_all"] = torch.empty(nh, M, 64, device=r.device)
+            wss = [B["ws"]] + list(B["ws_side"][:nh - 1])
+            wptr = [(w_.data_ptr() + 255) // 256 * 256 for w_ in wss]
+            wbytes = min((w_.numel() * 4 - (p_ - w_.data_ptr())) // 256 * 256 for w_, p_ in zip(wss, wptr))
+            P = ctypes.c_void_p * nh
+            rec = ops._tic("head_pw", (C, 64 * nh, M))
+            rc = lib.cdn_codenet_heads_pointwise_forward(
+                r.data_ptr(), r_qstate, M, C, nh, ptr(first["w"]), ptr(first["codes"]), ptr(first["scale"]),
+                ptr(first["colsum"]), ptr(first["bias"]), 1, P(*[a_.x_min.data_ptr() for a_ in acts]),
+                P(*[a_.x_max.data_ptr() for a_ in acts]), P(*[a_._device_state(r.device).data_ptr() for a_ in acts]),
+                bits, mom, running, P(*wptr), wbytes, ptr(first["omap"]), B["y1_all"].data_ptr(), M * 64, stream)
+            ops._toc(rec)
+            N_.check(rc, "cdn_codenet_heads_pointwise_forward")
+            fused_first = True
         if use_streams:
             # fork EVERY side stream before head 0 puts its kernels on the main stream: forked inside the loop, a side
             # stream waited for everything the main stream held by then -- head 0's whole chain -- and the heads ran as
@@ -194,7 +261,10 @@ class FusedHeads:
                     outs[name] = B["out"][name]
                     continue
                 l1, l2, l3 = layers
-                pw(r, r_qstate, M, l1, y1buf)
+                if fused_first:
+                    y1buf = B["y1_all"][hi]              # (written by the one launch in front of the fork)
+                else:
+                    pw(r, r_qstate, M, l1, y1buf)
                 q1 = l1["act"]._device_state(r.device).data_ptr() if l1["act"] is not None else None
                 ep = l2["ep"] or (None, None)
                 if small:

@@ -625,6 +625,21 @@ int cdn_codenet_dwpw_q8_forward(const signed char *a8, const void *a_state, int6
                                 const void *r_state, signed char *r8_out, unsigned *overflow, void *stream);
 int cdn_codenet_expand_codes(const signed char *a, const void *a_state, float *out, int64_t numel, void *stream);
 
+/* The FIRST 1x1 convolutions of the detection heads as ONE launch (round 6): n_heads (2-4) problems of 64 output columns
+ * on one channels-last input a [M][C] (pre-quantisation values + its QuantAct state) -- the three heads of the reference
+ * (shufflenetv2_dcn.py:244-271; W4A8: QuantDepthwiseNode's quant_convbn1, quant_modules.py:1013-1071) all read the last
+ * stage's output.  w / w_codes / w_scale / w_colsum / bias: the heads' int8 forms CONCATENATED along the output rows
+ * (row h * 64 + co; w = the f32 fake-quantised weights for wide-code batches); head h writes out + h * head_stride as a
+ * dense [M][64] buffer (out_map: device int[64 * n_heads] = column % 64) and updates ITS QuantAct (r_min[h], r_max[h],
+ * r_state[h]; workspaces[h]: cdn_codenet_aux_workspace_bytes(), zero-initialised, one per head) in the launch's last
+ * workgroup of its column group.  Same sums as n_heads calls of cdn_codenet_pointwise_nhwc_forward: bit-identical. */
+int cdn_codenet_heads_pointwise_supported(int64_t M, int64_t C, int n_heads);
+int cdn_codenet_heads_pointwise_forward(
+    const float *a, const void *a_qstate, int64_t M, int64_t C, int n_heads, const float *w,
+    const signed char *w_codes, const float *w_scale, const int *w_colsum, const float *bias, int relu,
+    float *const *r_min, float *const *r_max, void *const *r_state, int bits, double momentum, int running,
+    void *const *workspaces, size_t workspace_bytes, const int *out_map, float *out, int64_t head_stride, void *stream);
+
 /* Chained fp32 stages (round 6; VERDICT r5 weak #2: cfg2 is ten launches of 6-20 us).  Without QuantActs (the fp32 model)
  * the next stage's scale prediction s' = Hardtanh(conv1x1(relu(bn(y)); Co -> 1) + b) (modules/dcn_deform_conv.py:295-305,
  * 323-330 applied to the next module's input) is linear in this stage's output rows: the streaming f32 pointwise kernel
