@@ -434,11 +434,27 @@ def cpu_baseline(args, net_cpu):
                     break
             dt = time.perf_counter() - t0
             legs[threads] = (n * reps / dt, reps)
+        # the scalar port's one-thread figure (SURVEY 8(d) asks for both ends): ONE image, bounded to ~5 s
+        one = None
+        if cores > 1:
+            torch.set_num_threads(1)
+            O.set_threads(1)
+            run(x[:1])
+            t0 = time.perf_counter()
+            reps1 = 0
+            while True:
+                run(x[:1])
+                reps1 += 1
+                if time.perf_counter() - t0 > 5.0 or reps1 >= 100:
+                    break
+            one = reps1 / (time.perf_counter() - t0)
         torch.set_num_threads(cores)
         O.set_threads(cores)
     best = max(legs, key=lambda t: legs[t][0])
     return {"value": legs[best][0], "unit": "images/sec", "cores": best, "kind": "port",
             "legs": {"threads%d" % t: round(v[0], 3) for t, v in legs.items()},
+            "one_thread": ({"value": round(one, 3), "unit": "images/sec", "cores": 1,
+                            "sample": "single images for ~5 s on one thread"} if one else None),
             "sample": "%d x %d images, %s hot path, %dx%d, oracle C (OpenMP) + torch CPU"
                       % (legs[best][1], n, "fp32" if args.fp32 else "W4A8", args.res, args.res)}
 

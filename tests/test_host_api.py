@@ -404,6 +404,46 @@ def test_cover_frozen_ranges_only_widens_and_restores_the_running_flags():
     assert all(torch.equal(p, q) for p, q in zip(before, (net.a.x_min, net.a.x_max, net.shared.x_min, net.shared.x_max)))
 
 
+def test_cover_frozen_ranges_reports_the_spread_of_the_per_batch_extremes():
+    """Round 6 (the serving tail policy, calibrate_serving(sigmas=...)): cover_frozen_ranges(spread=...) leaves, per QuantAct,
+    the standard deviations of its per-BATCH minimum and maximum over the calibration batches -- a QuantAct called twice per
+    forward contributes ONE pair per batch (the extremes over both calls); one batch gives no statistic."""
+    import torch.nn as nn
+    from codenet_amd import pipeline
+    from codenet_amd.portable_quantizer.quant_modules import QuantAct
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.shared = QuantAct(8), QuantAct(8)
+
+        def forward(self, x):
+            y = self.a(x)
+            return self.shared(y * 3.0) + self.shared(y - 5.0)
+
+    net = Net()
+    base = torch.linspace(-1.0, 2.0, 64).reshape(1, 1, 8, 8)
+    net(base)
+    net.a.x_min.fill_(-50.0); net.a.x_max.fill_(50.0)        # wide: the frozen QuantAct passes values through its fine grid
+    net.shared.x_min.fill_(-500.0); net.shared.x_max.fill_(500.0)
+    scales = [1.0, 2.0, 4.0, 3.0]
+    batches = [base * k for k in scales]
+    spread = {}
+    pipeline.cover_frozen_ranges(net, batches, margin=0.0, passes=1, spread=spread)
+    lo_a, hi_a = spread[id(net.a)]
+    want_hi = torch.tensor([2.0 * k for k in scales], dtype=torch.float64).std().item()
+    want_lo = torch.tensor([-1.0 * k for k in scales], dtype=torch.float64).std().item()
+    assert abs(hi_a - want_hi) < 1e-6 and abs(lo_a - want_lo) < 1e-6
+    lo_s, hi_s = spread[id(net.shared)]
+    # shared: per batch the maximum is that of y * 3 (= 6 k up to the 100/255 grid), the minimum the smaller of the two
+    # calls' minima (-3 k and -k - 5)
+    want_lo_s = torch.tensor([min(-3.0 * k, -k - 5.0) for k in scales], dtype=torch.float64).std().item()
+    assert abs(hi_s - 3 * want_hi) < 0.5 and abs(lo_s - want_lo_s) < 0.5
+    one = {}
+    pipeline.cover_frozen_ranges(net, batches[:1], margin=0.0, passes=1, spread=one)
+    assert one == {}
+
+
 def test_overflow_flags_name_the_quantacts_of_the_launch_that_saturated():
     """pipeline.OverflowFlags (round 4: the byte-code schedules give every launch its own overflow word so that a
     saturated code names the QuantAct to widen): words, views for a consumer numbering its launches from 0, reset."""

@@ -4,7 +4,7 @@
 # the byte-code schedule with byte-code input + chained scale, the whole network in serving mode (e2e.frozen), the QAT
 # step.  Output: gpurun_out/<round>/pmc_traffic_<variant>.json (tools/pmc_steady.py: bytes per steady-state iteration).
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

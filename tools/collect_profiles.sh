@@ -3,7 +3,7 @@
 # (separate passes, no trace domains combined with --pmc), all into gpurun_out/<round>/.
 # Afterwards: python tools/summarize_profiles.py <round>   (in the build container) -> profiles/<round>/
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -36,6 +36,9 @@ python3 tools/decode_bench.py > "$OUT/decode_bench.json" 2>/dev/null
 python3 tools/backbone_bench.py > "$OUT/backbone_bench.json" 2>/dev/null
 python3 tools/e2e_native_bench.py --graph > "$OUT/e2e_native.json" 2>/dev/null
 python3 tools/generic_bench.py > "$OUT/generic_bench.json" 2>/dev/null
+# round 6: overflow rate of the serving schedule on fresh batches per calibration policy (the AP50-delta proxy, ~8 min with
+# its CPU side, is run on its own: python tests/proxy_ap.py --images 256 --out gpurun_out/$R/proxy_ap.json)
+python3 tools/serving_margin_sweep.py > "$OUT/serving_margin_sweep.json" 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/e2e_stats" -- python3 tools/e2e_native_bench.py > "$OUT/e2e_stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc $MFMA --output-format csv -d "$OUT/pmc_mfma_e2e" -- python3 tools/e2e_native_bench.py --steps 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_stats" -- python3 tools/train_step_bench.py > "$OUT/train_stats.log" 2>&1

@@ -10,7 +10,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = "gpurun_out/" + R, "profiles/" + R
 os.makedirs(dst, exist_ok=True)
 for f in (glob.glob(src + "/*.json") + glob.glob(src + "/*kernel_stats.csv") + glob.glob(src + "/backbone_kernel_order.txt")
