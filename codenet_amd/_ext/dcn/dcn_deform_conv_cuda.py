@@ -6,6 +6,8 @@ The module is importable where the reference expects it (``_ext.dcn.dcn_deform_c
 functions/dcn_deform_conv.py:8); only marshalling happens here: contiguity, shape checks that
 need the tensors (cpp:61-149), pointer/stream extraction.  All arithmetic is in the HIP library.
 """
+import os
+
 import torch
 
 from ... import _native as N_
@@ -106,6 +108,8 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
     lib = N_.lib()
     geom = (Nb, C, H, W, Co, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group)
     need = lib.cdn_deform_conv_forward_scratch_bytes(*geom) if x.dtype == torch.float32 else 0
+    if need and os.environ.get("CDN_SEAM_NO_SCRATCH") == "1":      # A/B: every workgroup tests its pixels itself
+        need = 0
     scratch = None
     if need:
         if (isinstance(columns, torch.Tensor) and columns.is_cuda and columns.device == x.device
