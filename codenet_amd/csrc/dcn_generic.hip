@@ -418,11 +418,9 @@ __device__ __forceinline__ SAxis make_saxis(int base, float off, int size) {
 }
 __device__ __forceinline__ float sbil4(float w00, float v00, float w01, float v01, float w10, float v10, float w11,
                                        float v11) {
-  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w00, v00), __fmul_rn(w01, v01)), __fmul_rn(w10, v10)), __fmul_rn(w11, v11));
+  return fmaf(w11, v11, fmaf(w10, v10, fmaf(w01, v01, w00 * v00)));      // == bil4 (codenet_stage.hip)
 }
-__device__ __forceinline__ float slin2(float w0, float v0, float w1, float v1) {
-  return __fadd_rn(__fmul_rn(w0, v0), __fmul_rn(w1, v1));
-}
+__device__ __forceinline__ float slin2(float w0, float v0, float w1, float v1) { return fmaf(w1, v1, w0 * v0); }      // == lin2
 // true when o[0..17] == anchor * t with t = o[16] (tap k = 3 i + j: a_y = i - 1, a_x = j - 1)
 __device__ __forceinline__ bool offsets_structured(const float (&o)[18]) {
   const float t = o[16];
@@ -450,7 +448,10 @@ offset_structure_kernel(const float *__restrict__ offset, float *__restrict__ tp
 
 // dwo4_kernel (round 3): dwo_kernel with the planes interleaved in channel QUADS ([CC / 4][cell][4]): one ds_read_b128
 // per cell and quad instead of four ds_read_b32 (36 instead of 144 LDS reads per pixel and quad).  Same per-channel
-// expressions in the same order.  C % 4 == 0, CC % 4 == 0.
+// expressions in the same order.  C % 4 == 0, CC % 4 == 0.  HAS_T (a structure plane was computed, tplane) is a
+// TEMPLATE parameter, not a test of the pointer: with the run-time test the offsets' registers stayed live across the
+// structured path and the kernel needed 170 VGPRs (two waves per SIMD); either instantiation needs 104 (four).
+template <bool HAS_T>
 __global__ void __launch_bounds__(kDwoThreads)
 dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const float *__restrict__ weight,
             float *__restrict__ out, int C, int H, int W, int CC, const float *__restrict__ tplane) {
@@ -480,7 +481,7 @@ dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const
     float o[18];
     float t;
     bool fast;
-    if (tplane) {
+    if (HAS_T) {
       t = tplane[(long)n * HW + p];
       fast = t == t;
     } else {
@@ -539,7 +540,7 @@ dwo4_kernel(const float *__restrict__ x, const float *__restrict__ offset, const
       }
       continue;
     }
-    if (tplane) {
+    if (HAS_T) {
 #pragma unroll
       for (int k = 0; k < 18; ++k) o[k] = op[(long)k * HW];
     }
@@ -1000,14 +1001,20 @@ int run_forward(const void *x, const void *w, const void *b, const void *off, co
     const size_t lds = (size_t)(((CC * 9 + 3) & ~3) + CC * (g.H + 2) * (g.W + 2)) * sizeof(float);
     dim3 grid((unsigned)cdn::ceil_div(g.C, CC), (unsigned)g.N);
     if ((CC & 3) == 0 && (g.C & 3) == 0) {
-      if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)dwo4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)dwo4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)dwo4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      }
       if (tplane) {       // the offsets' structure once per call instead of once per channel chunk
         const long npix = (long)g.N * g.H * g.W;
         offset_structure_kernel<<<grid_for(npix), 256, 0, st>>>((const float *)off, tplane, g.H * g.W, npix);
       }
-      dwo4_kernel<<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
-                                                  g.C, g.H, g.W, CC, tplane);
+      if (tplane)
+        dwo4_kernel<true><<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w,
+                                                          (float *)out, g.C, g.H, g.W, CC, tplane);
+      else
+        dwo4_kernel<false><<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w,
+                                                           (float *)out, g.C, g.H, g.W, CC, tplane);
     } else {
       dwo_kernel<<<grid, kDwoThreads, lds, st>>>((const float *)x, (const float *)off, (const float *)w, (float *)out,
                                                  g.C, g.H, g.W, CC);
