@@ -90,6 +90,17 @@ def _check_common(input, offset, weight, kH, kW, dH, dW, padH, padW, dilH, dilW,
     return Ho, Wo
 
 
+def _scratch_from(columns, need, like):
+    """`need` bytes of f32 scratch on `like`'s device: the caller's `columns` tensor when it can serve (resized, as the
+    reference's C++ resizes it), a fresh allocation otherwise."""
+    if (isinstance(columns, torch.Tensor) and columns.is_cuda and columns.device == like.device
+            and columns.dtype == torch.float32 and columns.is_contiguous()):
+        if columns.numel() * 4 < need:
+            columns.resize_((need + 3) // 4)
+        return columns
+    return torch.empty((need + 3) // 4, dtype=torch.float32, device=like.device)
+
+
 def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW,
                              padH, dilationW, dilationH, group, deformable_group, im2col_step):
     """cpp:151-258.  `ones` and `im2col_step` are accepted and ignored (vestigial).  `columns` -- the reference's scratch
@@ -110,15 +121,7 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
     need = lib.cdn_deform_conv_forward_scratch_bytes(*geom) if x.dtype == torch.float32 else 0
     if need and os.environ.get("CDN_SEAM_NO_SCRATCH") == "1":      # A/B: every workgroup tests its pixels itself
         need = 0
-    scratch = None
-    if need:
-        if (isinstance(columns, torch.Tensor) and columns.is_cuda and columns.device == x.device
-                and columns.dtype == torch.float32 and columns.is_contiguous()):
-            if columns.numel() * 4 < need:
-                columns.resize_(need // 4)
-            scratch = columns
-        else:
-            scratch = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    scratch = _scratch_from(columns, need, x) if need else None
     rc = lib.cdn_deform_conv_forward_scratch(
         _ptr(x), _ptr(w), _ptr(o), _ptr(output), _dtype_enum(x, w, o, output), *geom, _ptr(scratch), need if scratch is not None else 0,
         _stream(x))
@@ -129,7 +132,9 @@ def deform_conv_forward_cuda(input, weight, offset, output, columns, ones, kW, k
 def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOffset, weight,
                                     columns, kW, kH, dW, dH, padW, padH, dilationW, dilationH,
                                     group, deformable_group, im2col_step):
-    """cpp:260-371.  gradInput is accumulated into (zero-filled by the caller)."""
+    """cpp:260-371.  gradInput is accumulated into (zero-filled by the caller).  `columns` (the reference's scratch
+    tensor) receives the offsets' structure plane for the CoDeNet call geometry, as in deform_conv_forward_cuda:
+    cdn_deform_conv_backward_input_scratch runs the module backward's geometry when every pixel has it."""
     _require_gpu(input, offset, gradOutput, gradInput, gradOffset, weight)
     _check_common(input, offset, weight, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group,
                   deformable_group, gradOutput)
@@ -137,11 +142,16 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
     if not (gradInput.is_contiguous() and gradOffset.is_contiguous()):
         raise RuntimeError("gradInput / gradOffset must be contiguous")
     Nb, C, H, W = x.shape
-    rc = N_.lib().cdn_deform_conv_backward_input(
+    lib = N_.lib()
+    geom = (Nb, C, H, W, w.size(0), kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group)
+    need = lib.cdn_deform_conv_backward_input_scratch_bytes(*geom) if x.dtype == torch.float32 else 0
+    if need and os.environ.get("CDN_SEAM_NO_SCRATCH") == "1":      # A/B: the generic nine-tap backward
+        need = 0
+    scratch = _scratch_from(columns, need, x) if need else None
+    rc = lib.cdn_deform_conv_backward_input_scratch(
         _ptr(x), _ptr(o), _ptr(go), _ptr(gradInput), _ptr(gradOffset), _ptr(w),
-        _dtype_enum(x, o, go, gradInput, gradOffset, w),
-        Nb, C, H, W, w.size(0), kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
-        deformable_group, _stream(x))
+        _dtype_enum(x, o, go, gradInput, gradOffset, w), *geom, _ptr(scratch), need if scratch is not None else 0,
+        _stream(x))
     N_.check(rc, "deform_conv_backward_input_cuda")
     return 1
 

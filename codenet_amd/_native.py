@@ -24,6 +24,8 @@ _SIGNATURES = {
     "cdn_deform_conv_forward_scratch_bytes": (ctypes.c_size_t, [_i64] * 5 + [_i] * 10),
     "cdn_deform_conv_forward_scratch": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_deform_conv_backward_input": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp]),
+    "cdn_deform_conv_backward_input_scratch_bytes": (ctypes.c_size_t, [_i64] * 5 + [_i] * 10),
+    "cdn_deform_conv_backward_input_scratch": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_deform_conv_backward_parameters": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_f, _vp]),
     "cdn_modulated_deform_conv_forward": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),
     "cdn_modulated_deform_conv_backward": (_i, [_vp] * 11 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),

@@ -98,6 +98,25 @@ int cdn_deform_conv_backward_input(const void *input, const void *offset, const 
                                    int dilationW, int dilationH, int group, int deformable_group,
                                    void *stream);
 
+/* The same call with the reference's scratch argument put to use (round 6): `columns` of
+ * deform_conv_backward_input_cuda (cpp:260-265) -> `scratch`.  For the CoDeNet call geometry (f32, depthwise 3x3,
+ * stride 1, pad 1, dilation 1, deformable_group 1, plane images in LDS: ..._scratch_bytes != 0) the offsets are tested
+ * for the anchor * t structure (as in cdn_deform_conv_forward_scratch; scratch = the [N][H][W] plane + a count of
+ * pixels without it).  Every pixel structured: the module backward's geometry (four axes per pixel; 25 fixed-point
+ * atomics per pixel and channel instead of 36; gradInput BIT-IDENTICAL to cdn_deform_conv_backward_input's, gradOffset
+ * equal up to fp32 summation order over the channels).  Any pixel not: exactly cdn_deform_conv_backward_input.  The
+ * choice is made on the device (both kernels are launched, one returns at once): no sync, capturable.
+ * scratch == NULL or any other geometry / dtype: cdn_deform_conv_backward_input. */
+size_t cdn_deform_conv_backward_input_scratch_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kW,
+                                                    int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                                    int dilationH, int group, int deformable_group);
+int cdn_deform_conv_backward_input_scratch(const void *input, const void *offset, const void *gradOutput,
+                                           void *gradInput, void *gradOffset, const void *weight,
+                                           int dtype, int64_t N, int64_t C, int64_t H, int64_t W,
+                                           int64_t Co, int kW, int kH, int dW, int dH, int padW, int padH,
+                                           int dilationW, int dilationH, int group, int deformable_group,
+                                           void *scratch, size_t scratch_bytes, void *stream);
+
 /* Replaces deform_conv_backward_parameters_cuda (cpp:373-484).
  * gradWeight += scale * dL/dW  (accumulated, cpp:456-462; caller zero-fills). */
 int cdn_deform_conv_backward_parameters(const void *input, const void *offset,
