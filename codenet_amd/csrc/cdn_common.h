@@ -117,7 +117,21 @@ __device__ __forceinline__ void fetch_record(int j, const int (&gi)[NI], const f
 template <int LPP>
 __device__ __forceinline__ int owner_item(int lane) {
   return LPP == 16 ? (lane & 15) * 4 + (lane >> 4)
-                   : (lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1));
+         : LPP == 8 ? (lane & 7) * 8 + ((lane >> 4) * 2 + ((lane >> 3) & 1))
+                    : (lane & 3) * 16 + (lane >> 2);      // 4 lanes per item: quad lane j (fetch_record_quad)
+}
+// the 4-lanes-per-item form: lane j of every quad to the quad's four lanes (quad_perm [j, j, j, j])
+template <int NI, int NF>
+__device__ __forceinline__ void fetch_record_quad(int j, const int (&gi)[NI], const float (&gf)[NF],
+                                                  int (&oi)[NI], float (&of)[NF]) {
+#define CDN_CASE(J)                                                                                                \
+  case J: {                                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NI; ++q) oi[q] = __builtin_amdgcn_mov_dpp(gi[q], J * 0x55, 0xf, 0xf, false); \
+    _Pragma("unroll") for (int q = 0; q < NF; ++q)                                                                 \
+        of[q] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(gf[q]), J * 0x55, 0xf, 0xf, false));        \
+  } break;
+  switch (j) { CDN_CASE(0) CDN_CASE(1) CDN_CASE(2) CDN_CASE(3) }
+#undef CDN_CASE
 }
 // LDS-DMA (global_load_lds) as inline asm: see the note in front of dw0p_kernel (codenet_fused.hip) for why not the builtin.
 __device__ __forceinline__ void glds16(const void *gbase, unsigned voff, unsigned lds_dst) {

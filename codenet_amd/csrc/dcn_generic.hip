@@ -872,7 +872,12 @@ __device__ __forceinline__ float reduce_scatter(const float (&a)[16], int cl) {
   return reduce_scatter(b, cl);
 }
 
-template <int CCH>
+// MODE 0: grad_input and grad_offset in one pass (both images: 12 bytes per cell and channel); the SPLIT forms for planes
+// where that leaves room for two channels only (64 x 64): MODE 1 = grad_input only -- the scatter needs the geometry
+// and g * w, not x: no x image, 8 bytes per cell and channel, four channels per workgroup with quad-broadcast records;
+// MODE 2 = grad_offset only: no accumulator image, no fixed-point scale, 4 bytes per cell and channel -- eight channels
+// per workgroup, so a quarter of the global float atomics, which were 580 of the one-pass kernel's 1250 us there.
+template <int CCH, int MODE>
 __global__ void __launch_bounds__(1024)
 dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
                 const unsigned *__restrict__ n_unstructured, const float *__restrict__ wd,
@@ -886,9 +891,10 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
   const int cells = (H + 1) * Wc;
   const int n = blockIdx.y;
   const int tid = threadIdx.x;
-  unsigned long long *gimg = dwo_smem64;                                        // [cells][CCH] fixed point
-  float *ximg = reinterpret_cast<float *>(dwo_smem64 + (size_t)cells * CCH);    // [cells][CCH]
-  float *red = ximg + (size_t)cells * CCH;                                      // [32]
+  constexpr bool WANT_GX = MODE != 2, WANT_GOFF = MODE != 1;
+  unsigned long long *gimg = dwo_smem64;                                        // [cells][CCH] fixed point (WANT_GX)
+  float *ximg = reinterpret_cast<float *>(dwo_smem64 + (WANT_GX ? (size_t)cells * CCH : 0));   // [cells][CCH] (WANT_GOFF)
+  float *red = ximg + (WANT_GOFF ? (size_t)cells * CCH : 0);                    // [32]
   // G > 1: this workgroup does G consecutive channel chunks one after the other and sums their grad_offset terms in LDS
   // (gpart [18][HW]; an element is owned by ONE lane -- the pixel -> (wave, step, lane group) map does not depend on the
   // chunk -- so plain adds), then adds gpart to grad_offset: G times fewer global float atomics.  They are device-scope
@@ -896,20 +902,20 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
   // axis, chunk) was 70 of this kernel's 350 us at 16 x 16 x 1024 channels and 580 of 1250 at 64 x 64 x 128, where a
   // chunk is two channels and gpart (288 KB) does not fit.
   float *gpart = red + 32;
-  if (G > 1)
+  if (WANT_GOFF && G > 1)
     for (int q = tid; q < 18 * HW; q += nthreads) gpart[q] = 0.0f;
   for (int ci = 0; ci < G; ++ci) {
   const int c0 = (blockIdx.x * G + ci) * CCH;
   if (c0 >= C) break;
   if (ci) __syncthreads();      // (the previous chunk's drain reads gimg)
   for (int q = tid; q < cells * CCH; q += nthreads) {
-    ximg[q] = 0.0f;
-    gimg[q] = 0ull;
+    if (WANT_GOFF) ximg[q] = 0.0f;
+    if (WANT_GX) gimg[q] = 0ull;
   }
   // fixed-point scale of this workgroup (dwo_bwd_kernel's: NaN-propagating integer maxima, largest contribution ~ 2^40)
-  float scale, inv_scale;
-  bool poisoned;
-  {
+  float scale = 1.0f, inv_scale = 1.0f;
+  bool poisoned = false;
+  if (WANT_GX) {
     const int cc = min(CCH, C - c0);
     const float *gp = gd + ((long)n * C + c0) * HW;
     unsigned gb = 0u, wb = 0u;
@@ -940,7 +946,7 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
     scale = ldexpf(1.0f, 40 - e);
     inv_scale = ldexpf(1.0f, e - 40);
   }
-  {
+  if (WANT_GOFF) {
     const int quads = (HW + 3) >> 2;
     for (int q = tid; q < quads * CCH; q += nthreads) {
       const int cl = q % CCH, j = q / CCH;
@@ -1012,17 +1018,19 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
     auto tap = [&](int r0, int r1, int q0, int q1, float y0, float y1, float x0, float x1, float okf, int k, bool YI,
                    bool XI) {
       const int o00 = r0 + q0, o01 = r0 + q1, o10 = r1 + q0, o11 = r1 + q1;
-      const float v00 = ximg[o00], v01 = ximg[o01], v10 = ximg[o10], v11 = ximg[o11];
-      const float gk = g * wk[k];
-      if (gx != nullptr) {
+      if (WANT_GX) {
         const float gks = gsc * wk[k];
         scatter(o00, (y0 * x0) * gks);
         if (!XI) scatter(o01, (y0 * x1) * gks);
         if (!YI) scatter(o10, (y1 * x0) * gks);
         if (!XI && !YI) scatter(o11, (y1 * x1) * gks);
       }
-      go[2 * k] = okf * gk * (x0 * (v10 - v00) + x1 * (v11 - v01));
-      go[2 * k + 1] = okf * gk * (y0 * (v01 - v00) + y1 * (v11 - v10));
+      if (WANT_GOFF) {
+        const float v00 = ximg[o00], v01 = ximg[o01], v10 = ximg[o10], v11 = ximg[o11];
+        const float gk = g * wk[k];
+        go[2 * k] = okf * gk * (x0 * (v10 - v00) + x1 * (v11 - v01));
+        go[2 * k + 1] = okf * gk * (y0 * (v01 - v00) + y1 * (v11 - v10));
+      }
     };
     const float *w8 = R.w;
     tap(R.r[0], R.r[1], c[0], c[1], w8[0], w8[1], w8[4], w8[5], R.ok[0] * R.ok[2], 0, false, false);
@@ -1034,7 +1042,7 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
     tap(R.r[2], R.r[3], c[0], c[1], w8[2], w8[3], w8[4], w8[5], R.ok[1] * R.ok[2], 6, false, false);
     tap(R.r[2], R.r[3], c[4], c[5], w8[2], w8[3], 1.0f, 0.0f, R.ok[1], 7, false, true);
     tap(R.r[2], R.r[3], c[2], c[3], w8[2], w8[3], w8[6], w8[7], R.ok[1] * R.ok[3], 8, false, false);
-    if (goff != nullptr) {
+    if (WANT_GOFF) {
       float *gb = goff + (long)n * 18 * HW + pp;
 #pragma unroll
       for (int base = 0; base < 18; base += CCH) {
@@ -1062,7 +1070,7 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
       }
     }
   };
-  if (CCH == 16 || CCH == 8) {
+  if (CCH == 16 || CCH == 8 || CCH == 4) {
     constexpr int LPP = CCH, SPB = 64 / PPW;
     const int nsteps = (HW + nwaves * PPW - 1) / (nwaves * PPW);
     for (int sb = 0; sb < nsteps; sb += SPB) {
@@ -1074,7 +1082,8 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
                       G.p}, oi[13];
         float gf[12] = {G.w[0], G.w[1], G.w[2], G.w[3], G.w[4], G.w[5], G.w[6], G.w[7], G.ok[0], G.ok[1], G.ok[2],
                         G.ok[3]}, of[12];
-        cdn::fetch_record<LPP == 8>(j, gi, gf, oi, of);
+        if (LPP == 4) cdn::fetch_record_quad(j, gi, gf, oi, of);
+        else cdn::fetch_record<LPP == 8>(j, gi, gf, oi, of);
         Rec R;
 #pragma unroll
         for (int q = 0; q < 6; ++q) { R.r[q] = oi[q]; R.c[q] = oi[6 + q]; }
@@ -1090,7 +1099,7 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
     for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) step(geometry(p0 + sub));
   }
   __syncthreads();
-  if (gx != nullptr) {
+  if (WANT_GX) {
     const int quads = (HW + 3) >> 2;
     const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
     for (int q = tid; q < quads * CCH; q += nthreads) {
@@ -1114,26 +1123,31 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
     }
   }
   }      // chunks of this workgroup
-  if (G > 1 && goff != nullptr) {
+  if (WANT_GOFF && G > 1) {
     __syncthreads();
     for (int q = tid; q < 18 * HW; q += nthreads) atomicAdd(&goff[(long)n * 18 * HW + q], gpart[q]);
   }
 }
 
-// chunk of dwos_bwd_kernel: the largest of 16 / 8 / 4 / 2 channels whose two images fit (the module backward's choices,
-// bwd2_cch in codenet_stage.hip: 16 at 16 x 16 planes with two workgroups per CU, 8 at 32 x 32, 2 at 64 x 64)
-static int dwos_bwd_chunk(const Geom &g, size_t *lds_out, int *group_out = nullptr) {
+// chunk of dwos_bwd_kernel<., MODE>: the largest of 16 / 8 / 4 / 2 channels whose images fit (12 / 8 / 4 bytes per cell
+// and channel for MODE 0 / 1 / 2; MODE 0 makes the module backward's choices, bwd2_cch in codenet_stage.hip: 16 at 16 x 16
+// planes with two workgroups per CU, 8 at 32 x 32, 2 at 64 x 64)
+static int dwos_bwd_chunk(const Geom &g, int mode, size_t *lds_out, int *group_out = nullptr) {
   const size_t cells = (size_t)(g.H + 1) * (g.W + 1);
   const size_t lim = (size_t)160 * 1024 - 512;
-  auto need = [&](int c) { return cells * c * 12 + 256; };
+  const size_t per = mode == 0 ? 12 : mode == 1 ? 8 : 4;
+  auto need = [&](int c) { return cells * c * per + 256; };
+#ifndef CDN_DWOS_M2_MAX
+#define CDN_DWOS_M2_MAX 16
+#endif
   for (int c : {16, 8, 4, 2})
-    if (need(c) <= lim) {
+    if (need(c) <= lim && (mode != 2 || c <= CDN_DWOS_M2_MAX)) {
       // chunks per workgroup (the kernel's G): 4 or 2 when the [18][HW] grad_offset partial fits without costing the
       // second workgroup of a CU and the grid still holds two workgroups per CU
       const size_t part = (size_t)18 * g.H * g.W * 4;
       const bool two = need(c) * 2 <= lim;
       int G = 1;
-      if (need(c) + part <= lim && (!two || (need(c) + part) * 2 <= lim))
+      if (mode != 1 && need(c) + part <= lim && (!two || (need(c) + part) * 2 <= lim))
         for (int t : {4, 2})
           if (cdn::ceil_div(cdn::ceil_div(g.C, c), t) * g.N >= 2 * (long)cdn::kCUs) {
             G = t;
@@ -1145,17 +1159,26 @@ static int dwos_bwd_chunk(const Geom &g, size_t *lds_out, int *group_out = nullp
     }
   return 0;
 }
-static int launch_dwos_bwd(const float *x, const float *tplane, const unsigned *n_unstructured, const float *w,
-                           const float *go, float *gx, float *goff, const Geom &g, hipStream_t st) {
+// one pass (MODE 0) where it has the record path (chunks of 8 or more); otherwise the grad_input and the grad_offset pass
+static bool dwos_bwd_split(const Geom &g) {
+#if defined(CDN_DWOS_SPLIT)
+  return CDN_DWOS_SPLIT != 0;
+#else
+  size_t lds = 0;
+  return dwos_bwd_chunk(g, 0, &lds) < 8;
+#endif
+}
+template <int MODE>
+static void launch_dwos_mode(const float *x, const float *tplane, const unsigned *n_unstructured, const float *w,
+                             const float *go, float *gx, float *goff, const Geom &g, hipStream_t st) {
   size_t lds = 0;
   int G = 1;
-  const int cch = dwos_bwd_chunk(g, &lds, &G);
-  if (cch == 0) return -1;
+  const int cch = dwos_bwd_chunk(g, MODE, &lds, &G);
   dim3 grid((unsigned)cdn::ceil_div(cdn::ceil_div(g.C, cch), G), (unsigned)g.N);
   const int threads = lds * 2 <= (size_t)160 * 1024 - 512 ? 512 : 1024;
 #define CDN_DWOS(CCH_)                                                                                     \
   {                                                                                                        \
-    auto kern = dwos_bwd_kernel<CCH_>;                                                                     \
+    auto kern = dwos_bwd_kernel<CCH_, MODE>;                                                               \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
     kern<<<grid, threads, lds, st>>>(x, tplane, n_unstructured, w, go, gx, goff, g.C, g.H, g.W, G);        \
   }
@@ -1166,7 +1189,19 @@ static int launch_dwos_bwd(const float *x, const float *tplane, const unsigned *
     default: CDN_DWOS(2) break;
   }
 #undef CDN_DWOS
-  return 0;
+}
+static bool dwos_bwd_applies(const Geom &g) {
+  size_t lds = 0;
+  return dwos_bwd_chunk(g, 0, &lds) != 0;
+}
+static void launch_dwos_bwd(const float *x, const float *tplane, const unsigned *n_unstructured, const float *w,
+                            const float *go, float *gx, float *goff, const Geom &g, hipStream_t st) {
+  if (dwos_bwd_split(g)) {
+    launch_dwos_mode<1>(x, tplane, n_unstructured, w, go, gx, goff, g, st);
+    launch_dwos_mode<2>(x, tplane, n_unstructured, w, go, gx, goff, g, st);
+  } else {
+    launch_dwos_mode<0>(x, tplane, n_unstructured, w, go, gx, goff, g, st);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1422,7 +1457,7 @@ int run_backward_input(const void *x, const void *off, const void *m, const void
       hipError_t e = hipMemsetAsync(goff, 0, sizeof(float) * (size_t)g.N * 18 * P, st);
       if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset grad_offset: %s", hipGetErrorString(e));
       const unsigned *flag = nullptr;
-      if (scratch != nullptr && dwos_bwd_chunk(g, &lds) != 0) {
+      if (scratch != nullptr && dwos_bwd_applies(g)) {
         // scratch = [N][H][W] structure plane + the count of pixels without the structure: the structured kernel runs
         // when the count is zero, the generic one behind it when it is not (both launched; one returns at once)
         const long npix = (long)g.N * P;
@@ -1591,7 +1626,7 @@ extern "C" size_t cdn_deform_conv_backward_input_scratch_bytes(int64_t N, int64_
   if (cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group, deformable_group))
     return 0;
   size_t lds = 0;
-  if (!dwo_bwd_applies(g) || dwo_bwd_chunk(g, true, &lds) == 0 || dwos_bwd_chunk(g, &lds) == 0) return 0;
+  if (!dwo_bwd_applies(g) || dwo_bwd_chunk(g, true, &lds) == 0 || !dwos_bwd_applies(g)) return 0;
   return ((size_t)g.N * g.H * g.W + 4) * sizeof(float);
 }
 
