@@ -147,6 +147,8 @@ def deform_conv_backward_input_cuda(input, offset, gradOutput, gradInput, gradOf
     need = lib.cdn_deform_conv_backward_input_scratch_bytes(*geom) if x.dtype == torch.float32 else 0
     if need and os.environ.get("CDN_SEAM_NO_SCRATCH") == "1":      # A/B: the generic nine-tap backward
         need = 0
+    elif need and os.environ.get("CDN_SEAM_MIN_SCRATCH") == "1":   # A/B: structured kernels with float atomics
+        need = lib.cdn_deform_conv_backward_input_scratch_min_bytes(*geom)
     scratch = _scratch_from(columns, need, x) if need else None
     rc = lib.cdn_deform_conv_backward_input_scratch(
         _ptr(x), _ptr(o), _ptr(go), _ptr(gradInput), _ptr(gradOffset), _ptr(w),

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "cdn_deform_conv_forward_scratch": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_deform_conv_backward_input": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp]),
     "cdn_deform_conv_backward_input_scratch_bytes": (ctypes.c_size_t, [_i64] * 5 + [_i] * 10),
+    "cdn_deform_conv_backward_input_scratch_min_bytes": (ctypes.c_size_t, [_i64] * 5 + [_i] * 10),
     "cdn_deform_conv_backward_input_scratch": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 10 + [_vp, ctypes.c_size_t, _vp]),
     "cdn_deform_conv_backward_parameters": (_i, [_vp] * 4 + [_i] + [_i64] * 5 + [_i] * 10 + [_f, _vp]),
     "cdn_modulated_deform_conv_forward": (_i, [_vp] * 6 + [_i] + [_i64] * 5 + [_i] * 11 + [_vp]),

@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(1024)
 dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
                 const unsigned *__restrict__ n_unstructured, const float *__restrict__ wd,
                 const float *__restrict__ gd, float *__restrict__ gx, float *__restrict__ goff, int C, int H, int W,
-                int G) {
+                int G, float *__restrict__ part) {
   if (*n_unstructured != 0u) return;
   extern __shared__ unsigned long long dwo_smem64[];
   constexpr int PPW = 64 / CCH;
@@ -900,7 +900,9 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
   // chunk -- so plain adds), then adds gpart to grad_offset: G times fewer global float atomics.  They are device-scope
   // read-modify-writes at the memory side (the XCDs' L2s are not coherent) and sustain ~2 TB/s: one per (pixel, tap,
   // axis, chunk) was 70 of this kernel's 350 us at 16 x 16 x 1024 channels and 580 of 1250 at 64 x 64 x 128, where a
-  // chunk is two channels and gpart (288 KB) does not fit.
+  // chunk is two channels and gpart (288 KB) does not fit.  G == 1 and part != nullptr (the caller's scratch is large
+  // enough): the chunk STORES its terms in its own plane of part [chunks][N][18][HW] (plain stores overlap the compute)
+  // and goff_reduce_kernel sums the planes: no atomics at all.
   float *gpart = red + 32;
   if (WANT_GOFF && G > 1)
     for (int q = tid; q < 18 * HW; q += nthreads) gpart[q] = 0.0f;
@@ -1064,6 +1066,8 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
 #else
         if (live && base + cl < 18) {
           if (G > 1) gpart[(base + cl) * HW + pp] += mine;
+          else if (part != nullptr)      // this chunk's plane of partial sums: every element is written exactly once
+            part[(((long)blockIdx.x * gridDim.y + n) * 18 + base + cl) * HW + pp] = mine;
           else atomicAdd(gb + (long)(base + cl) * HW, mine);
         }
 #endif
@@ -1129,6 +1133,22 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
   }
 }
 
+// grad_offset = sum over the chunks' planes (part [chunks][total]); nothing when the structured route did not run
+__global__ void __launch_bounds__(256)
+goff_reduce_kernel(const float *__restrict__ part, float *__restrict__ goff, int chunks, long total4,
+                   const unsigned *__restrict__ n_unstructured) {
+  if (*n_unstructured != 0u) return;
+  const float4 *p4 = reinterpret_cast<const float4 *>(part);
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total4; q += (long)gridDim.x * 256) {
+    float4 a = p4[q];
+    for (int c = 1; c < chunks; ++c) {
+      const float4 b = p4[(long)c * total4 + q];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4 *>(goff)[q] = a;
+  }
+}
+
 // chunk of dwos_bwd_kernel<., MODE>: the largest of 16 / 8 / 4 / 2 channels whose images fit (12 / 8 / 4 bytes per cell
 // and channel for MODE 0 / 1 / 2; MODE 0 makes the module backward's choices, bwd2_cch in codenet_stage.hip: 16 at 16 x 16
 // planes with two workgroups per CU, 8 at 32 x 32, 2 at 64 x 64)
@@ -1168,9 +1188,24 @@ static bool dwos_bwd_split(const Geom &g) {
   return dwos_bwd_chunk(g, 0, &lds) < 8;
 #endif
 }
+// floats of per-chunk grad_offset planes the structured route can use: the split form's grad_offset pass only (0: one
+// pass / the planes are not 16-byte multiples).  Measured at batch 64: 64 x 64 x 128, 16 chunks, 302 MB of planes: the
+// _input call 905 -> 830 us; the one-pass kernel at 32 x 32 x 256 (32 chunks, 151 MB) 373 -> 387 us -- its atomics overlap
+// the scatter better than the stores and the reduce pass cost.
+static size_t dwos_part_floats(const Geom &g, int *chunks_out = nullptr) {
+  size_t lds = 0;
+  int G = 1;
+  if (!dwos_bwd_split(g)) return 0;
+  const int cch = dwos_bwd_chunk(g, 2, &lds, &G);
+  const size_t plane = (size_t)g.N * 18 * g.H * g.W;
+  if (cch == 0 || G > 1 || (plane & 3)) return 0;
+  const int chunks = cdn::ceil_div(g.C, cch);
+  if (chunks_out) *chunks_out = chunks;
+  return chunks < 2 ? 0 : (size_t)chunks * plane;
+}
 template <int MODE>
 static void launch_dwos_mode(const float *x, const float *tplane, const unsigned *n_unstructured, const float *w,
-                             const float *go, float *gx, float *goff, const Geom &g, hipStream_t st) {
+                             const float *go, float *gx, float *goff, const Geom &g, hipStream_t st, float *part) {
   size_t lds = 0;
   int G = 1;
   const int cch = dwos_bwd_chunk(g, MODE, &lds, &G);
@@ -1180,7 +1215,7 @@ static void launch_dwos_mode(const float *x, const float *tplane, const unsigned
   {                                                                                                        \
     auto kern = dwos_bwd_kernel<CCH_, MODE>;                                                               \
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-    kern<<<grid, threads, lds, st>>>(x, tplane, n_unstructured, w, go, gx, goff, g.C, g.H, g.W, G);        \
+    kern<<<grid, threads, lds, st>>>(x, tplane, n_unstructured, w, go, gx, goff, g.C, g.H, g.W, G, part);  \
   }
   switch (cch) {
     case 16: CDN_DWOS(16) break;
@@ -1195,12 +1230,18 @@ static bool dwos_bwd_applies(const Geom &g) {
   return dwos_bwd_chunk(g, 0, &lds) != 0;
 }
 static void launch_dwos_bwd(const float *x, const float *tplane, const unsigned *n_unstructured, const float *w,
-                            const float *go, float *gx, float *goff, const Geom &g, hipStream_t st) {
+                            const float *go, float *gx, float *goff, const Geom &g, hipStream_t st, float *part) {
   if (dwos_bwd_split(g)) {
-    launch_dwos_mode<1>(x, tplane, n_unstructured, w, go, gx, goff, g, st);
-    launch_dwos_mode<2>(x, tplane, n_unstructured, w, go, gx, goff, g, st);
+    launch_dwos_mode<1>(x, tplane, n_unstructured, w, go, gx, goff, g, st, nullptr);
+    launch_dwos_mode<2>(x, tplane, n_unstructured, w, go, gx, goff, g, st, part);
   } else {
-    launch_dwos_mode<0>(x, tplane, n_unstructured, w, go, gx, goff, g, st);
+    launch_dwos_mode<0>(x, tplane, n_unstructured, w, go, gx, goff, g, st, part);
+  }
+  if (part != nullptr) {
+    int chunks = 0;
+    (void)dwos_part_floats(g, &chunks);
+    const long total4 = (long)g.N * 18 * g.H * g.W / 4;
+    goff_reduce_kernel<<<grid_for(total4), 256, 0, st>>>(part, goff, chunks, total4, n_unstructured);
   }
 }
 
@@ -1446,7 +1487,7 @@ int run_forward(const void *x, const void *w, const void *b, const void *off, co
 template <typename S>
 int run_backward_input(const void *x, const void *off, const void *m, const void *w,
                        const void *go, void *gx, void *goff, void *gm, const Geom &g,
-                       hipStream_t st, float *scratch = nullptr) {
+                       hipStream_t st, float *scratch = nullptr, size_t scratch_floats = 0) {
   const int K = g.kH * g.kW;
   const long P = (long)g.Ho * g.Wo;
   const long t1 = (long)g.N * g.DG * K * P;
@@ -1465,8 +1506,13 @@ int run_backward_input(const void *x, const void *off, const void *m, const void
         e = hipMemsetAsync(count, 0, sizeof(unsigned), st);
         if (e != hipSuccess) return cdn::fail(CDN_ERR_HIP, "memset structure count: %s", hipGetErrorString(e));
         offset_structure_kernel<<<grid_for(npix), 256, 0, st>>>((const float *)off, scratch, (int)P, npix, count);
-        (void)launch_dwos_bwd((const float *)x, scratch, count, (const float *)w, (const float *)go, (float *)gx,
-                              (float *)goff, g, st);
+        // behind them, when the scratch has room: the chunks' grad_offset planes (16-byte aligned)
+        const size_t head = ((size_t)npix + 4 + 3) & ~(size_t)3, pf = dwos_part_floats(g);
+        float *part = (pf != 0 && scratch_floats >= head + pf &&
+                       ((reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(goff)) & 15) == 0)
+                          ? scratch + head : nullptr;
+        launch_dwos_bwd((const float *)x, scratch, count, (const float *)w, (const float *)go, (float *)gx,
+                        (float *)goff, g, st, part);
         flag = count;
       }
       (void)launch_dwo_bwd<true>((const float *)x, (const float *)off, (const float *)w, (const float *)go, (float *)gx,
@@ -1627,6 +1673,19 @@ extern "C" size_t cdn_deform_conv_backward_input_scratch_bytes(int64_t N, int64_
     return 0;
   size_t lds = 0;
   if (!dwo_bwd_applies(g) || dwo_bwd_chunk(g, true, &lds) == 0 || !dwos_bwd_applies(g)) return 0;
+  const size_t head = ((size_t)g.N * g.H * g.W + 4 + 3) & ~(size_t)3;
+  return (head + dwos_part_floats(g)) * sizeof(float);
+}
+
+extern "C" size_t cdn_deform_conv_backward_input_scratch_min_bytes(int64_t N, int64_t C, int64_t H, int64_t W,
+                                                                   int64_t Co, int kW, int kH, int dW, int dH, int padW,
+                                                                   int padH, int dilationW, int dilationH, int group,
+                                                                   int deformable_group) {
+  Geom g;
+  if (cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW, group, deformable_group))
+    return 0;
+  size_t lds = 0;
+  if (!dwo_bwd_applies(g) || dwo_bwd_chunk(g, true, &lds) == 0 || !dwos_bwd_applies(g)) return 0;
   return ((size_t)g.N * g.H * g.W + 4) * sizeof(float);
 }
 
@@ -1644,18 +1703,18 @@ extern "C" int cdn_deform_conv_backward_input_scratch(const void *input, const v
   int rc = cdn::make_geom(&g, N, C, H, W, Co, kH, kW, dH, dW, padH, padW, dilationH, dilationW,
                           group, deformable_group);
   if (rc) return rc;
-  const size_t need = cdn_deform_conv_backward_input_scratch_bytes(N, C, H, W, Co, kW, kH, dW, dH, padW, padH,
-                                                                   dilationW, dilationH, group, deformable_group);
+  const size_t need = cdn_deform_conv_backward_input_scratch_min_bytes(N, C, H, W, Co, kW, kH, dW, dH, padW, padH,
+                                                                       dilationW, dilationH, group, deformable_group);
   float *sc = nullptr;
   if (dtype == CDN_F32 && need != 0 && scratch != nullptr) {
     CDN_REQUIRE(scratch_bytes >= need && (reinterpret_cast<uintptr_t>(scratch) & 3) == 0, CDN_ERR_WORKSPACE,
-                "scratch too small (cdn_deform_conv_backward_input_scratch_bytes) or misaligned");
+                "scratch too small (cdn_deform_conv_backward_input_scratch_min_bytes) or misaligned");
     sc = static_cast<float *>(scratch);
   }
   hipStream_t st = cdn::as_stream(stream);
   CDN_DISPATCH3(dtype,
                 run_backward_input<float>(input, offset, nullptr, weight, gradOutput, gradInput,
-                                          gradOffset, nullptr, g, st, sc),
+                                          gradOffset, nullptr, g, st, sc, scratch_bytes / sizeof(float)),
                 run_backward_input<double>(input, offset, nullptr, weight, gradOutput, gradInput,
                                            gradOffset, nullptr, g, st),
                 run_backward_input<__half>(input, offset, nullptr, weight, gradOutput, gradInput,

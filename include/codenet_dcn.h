@@ -106,10 +106,20 @@ int cdn_deform_conv_backward_input(const void *input, const void *offset, const 
  * atomics per pixel and channel instead of 36; gradInput BIT-IDENTICAL to cdn_deform_conv_backward_input's, gradOffset
  * equal up to fp32 summation order over the channels).  Any pixel not: exactly cdn_deform_conv_backward_input.  The
  * choice is made on the device (both kernels are launched, one returns at once): no sync, capturable.
- * scratch == NULL or any other geometry / dtype: cdn_deform_conv_backward_input. */
+ * scratch == NULL or any other geometry / dtype: cdn_deform_conv_backward_input.
+ * Two sizes: ..._scratch_min_bytes = the plane and the count ((N H W + 4) floats; less is CDN_ERR_WORKSPACE);
+ * ..._scratch_bytes = what the call can USE: behind them one [N][18][H][W] plane of grad_offset terms per channel chunk
+ * where grad_offset has a pass of its own (planes whose two LDS images leave room for fewer than eight channels: 64 x 64;
+ * 302 MB for the 128 x 64 x 64 stage at batch 64 -- a quarter of what the reference's own `columns` takes there,
+ * cpp:196-200) -- the chunks then STORE their terms and one pass sums the planes, instead of float atomics at the memory
+ * side (~1.4 TB/s on MI355X).
+ * Anything between the two sizes is valid and uses the atomics. */
 size_t cdn_deform_conv_backward_input_scratch_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kW,
                                                     int kH, int dW, int dH, int padW, int padH, int dilationW,
                                                     int dilationH, int group, int deformable_group);
+size_t cdn_deform_conv_backward_input_scratch_min_bytes(int64_t N, int64_t C, int64_t H, int64_t W, int64_t Co, int kW,
+                                                        int kH, int dW, int dH, int padW, int padH, int dilationW,
+                                                        int dilationH, int group, int deformable_group);
 int cdn_deform_conv_backward_input_scratch(const void *input, const void *offset, const void *gradOutput,
                                            void *gradInput, void *gradOffset, const void *weight,
                                            int dtype, int64_t N, int64_t C, int64_t H, int64_t W,
