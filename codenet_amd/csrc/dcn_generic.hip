@@ -907,225 +907,229 @@ dwos_bwd_kernel(const float *__restrict__ x, const float *__restrict__ tplane,
   if (WANT_GOFF && G > 1)
     for (int q = tid; q < 18 * HW; q += nthreads) gpart[q] = 0.0f;
   for (int ci = 0; ci < G; ++ci) {
-  const int c0 = (blockIdx.x * G + ci) * CCH;
-  if (c0 >= C) break;
-  if (ci) __syncthreads();      // (the previous chunk's drain reads gimg)
-  for (int q = tid; q < cells * CCH; q += nthreads) {
-    if (WANT_GOFF) ximg[q] = 0.0f;
-    if (WANT_GX) gimg[q] = 0ull;
-  }
-  // fixed-point scale of this workgroup (dwo_bwd_kernel's: NaN-propagating integer maxima, largest contribution ~ 2^40)
-  float scale = 1.0f, inv_scale = 1.0f;
-  bool poisoned = false;
-  if (WANT_GX) {
-    const int cc = min(CCH, C - c0);
-    const float *gp = gd + ((long)n * C + c0) * HW;
-    unsigned gb = 0u, wb = 0u;
-    for (int q = tid; q < cc * HW; q += nthreads) gb = max(gb, cdn::absbits(gp[q]));
-    for (int q = tid; q < cc * 9; q += nthreads) wb = max(wb, cdn::absbits(wd[(long)c0 * 9 + q]));
+    const int c0 = (blockIdx.x * G + ci) * CCH;
+    if (c0 >= C) break;
+    if (ci) __syncthreads();      // (the previous chunk's drain reads gimg)
+    for (int q = tid; q < cells * CCH; q += nthreads) {
+      if (WANT_GOFF) ximg[q] = 0.0f;
+      if (WANT_GX) gimg[q] = 0ull;
+    }
+    // fixed-point scale of this workgroup (dwo_bwd_kernel's: NaN-propagating integer maxima, largest contribution ~ 2^40)
+    float scale = 1.0f, inv_scale = 1.0f;
+    bool poisoned = false;
+    if (WANT_GX) {
+      const int cc = min(CCH, C - c0);
+      const float *gp = gd + ((long)n * C + c0) * HW;
+      unsigned gb = 0u, wb = 0u;
+      for (int q = tid; q < cc * HW; q += nthreads) gb = max(gb, cdn::absbits(gp[q]));
+      for (int q = tid; q < cc * 9; q += nthreads) wb = max(wb, cdn::absbits(wd[(long)c0 * 9 + q]));
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-      gb = max(gb, (unsigned)__shfl_xor((int)gb, m, 64));
-      wb = max(wb, (unsigned)__shfl_xor((int)wb, m, 64));
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) {
-      red[2 * (tid >> 6)] = __uint_as_float(gb);
-      red[2 * (tid >> 6) + 1] = __uint_as_float(wb);
-    }
-    __syncthreads();
-    gb = wb = 0u;
-    for (int i = 0; i < nwaves; ++i) {
-      gb = max(gb, __float_as_uint(red[2 * i]));
-      wb = max(wb, __float_as_uint(red[2 * i + 1]));
-    }
-    const float gmax = __uint_as_float(gb) * __uint_as_float(wb);
-    poisoned = !(gmax < INFINITY);
-    int e = 0;
-    (void)frexpf(gmax, &e);
-    if (!(gmax > 0.0f) || poisoned) e = 0;
-    e = max(-86, min(e, 126 + 40));
-    scale = ldexpf(1.0f, 40 - e);
-    inv_scale = ldexpf(1.0f, e - 40);
-  }
-  if (WANT_GOFF) {
-    const int quads = (HW + 3) >> 2;
-    for (int q = tid; q < quads * CCH; q += nthreads) {
-      const int cl = q % CCH, j = q / CCH;
-      if (c0 + cl < C) {
-        const float *xp = x + ((long)n * C + c0 + cl) * HW + j * 4;
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          const int pix = j * 4 + e4;
-          if (pix < HW) ximg[((pix / W) * Wc + (pix % W)) * CCH + cl] = xp[e4];
-        }
+      for (int m = 32; m > 0; m >>= 1) {
+        gb = max(gb, (unsigned)__shfl_xor((int)gb, m, 64));
+        wb = max(wb, (unsigned)__shfl_xor((int)wb, m, 64));
       }
+      __syncthreads();
+      if ((tid & 63) == 0) {
+        red[2 * (tid >> 6)] = __uint_as_float(gb);
+        red[2 * (tid >> 6) + 1] = __uint_as_float(wb);
+      }
+      __syncthreads();
+      gb = wb = 0u;
+      for (int i = 0; i < nwaves; ++i) {
+        gb = max(gb, __float_as_uint(red[2 * i]));
+        wb = max(wb, __float_as_uint(red[2 * i + 1]));
+      }
+      const float gmax = __uint_as_float(gb) * __uint_as_float(wb);
+      poisoned = !(gmax < INFINITY);
+      int e = 0;
+      (void)frexpf(gmax, &e);
+      if (!(gmax > 0.0f) || poisoned) e = 0;
+      e = max(-86, min(e, 126 + 40));
+      scale = ldexpf(1.0f, 40 - e);
+      inv_scale = ldexpf(1.0f, e - 40);
+    } else {
+      __syncthreads();      // (the zero fill above before the staging below: another thread's cells)
     }
-  }
-  __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int cl = lane % CCH, sub = lane / CCH;
-  const bool ch_ok = c0 + cl < C;
-  float wk[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) wk[k] = ch_ok ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;
-  auto row_off = [&](int yy) { return (int)__umul24((unsigned)(((unsigned)yy < (unsigned)H) ? yy : H), (unsigned)(Wc * CCH)); };
-  auto col_off0 = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH; };     // (+ the lane's channel)
-#if defined(CDN_DWOS_DIAG) && CDN_DWOS_DIAG == 3      // timing only: no LDS atomics
-  auto scatter = [&](int o, float cs) { if (cs == 12345.678f) atomicAdd(&gimg[o], cdn::fixed_rn(cs)); };
-#else
-  auto scatter = [&](int o, float cs) { atomicAdd(&gimg[o], cdn::fixed_rn(cs)); };
-#endif
-
-  // per-pixel record: rows (ya.i0, ya.i0 + 1, yb.i0, yb.i0 + 1, h, h + 1), columns likewise (without the lane's
-  // channel), the pixel (-1: beyond the plane), the eight axis weights, the four in-range flags as 0 / 1 floats
-  struct Rec {
-    int r[6], c[6], p;
-    float w[8], ok[4];
-  };
-  auto axis_ok = [](int base, float off, int size) {
-    const float pos = (float)base + off;
-    return (pos > -1.0f && pos < (float)size) ? 1.0f : 0.0f;
-  };
-  auto geometry = [&](int p) {
-    Rec g;
-    const bool live = p < HW;
-    const int pp = live ? p : 0;
-    const int h = pp / W, w = pp - h * W;
-    const float t = tplane[(long)n * HW + pp];
-    const SAxis ya = make_saxis(h - 1, -t, H), yb = make_saxis(h + 1, t, H);
-    const SAxis xa = make_saxis(w - 1, -t, W), xb = make_saxis(w + 1, t, W);
-    g.r[0] = row_off(ya.i0); g.r[1] = row_off(ya.i0 + 1); g.r[2] = row_off(yb.i0); g.r[3] = row_off(yb.i0 + 1);
-    g.r[4] = row_off(h); g.r[5] = row_off(h + 1);
-    g.c[0] = col_off0(xa.i0); g.c[1] = col_off0(xa.i0 + 1); g.c[2] = col_off0(xb.i0); g.c[3] = col_off0(xb.i0 + 1);
-    g.c[4] = col_off0(w); g.c[5] = col_off0(w + 1);
-    g.p = live ? p : -1;
-    g.w[0] = ya.w0; g.w[1] = ya.w1; g.w[2] = yb.w0; g.w[3] = yb.w1;
-    g.w[4] = xa.w0; g.w[5] = xa.w1; g.w[6] = xb.w0; g.w[7] = xb.w1;
-    g.ok[0] = axis_ok(h - 1, -t, H); g.ok[1] = axis_ok(h + 1, t, H);
-    g.ok[2] = axis_ok(w - 1, -t, W); g.ok[3] = axis_ok(w + 1, t, W);
-    return g;
-  };
-  auto step = [&](const Rec &R) {
-    const bool live = R.p >= 0;
-    const int pp = live ? R.p : 0;
-    const float g = (live && ch_ok) ? gd[((long)n * C + c0 + cl) * HW + pp] : 0.0f;
-    const float gsc = g * scale;            // (power-of-two scale: commutes with the roundings of the products below)
-    float go[18];                           // this lane's terms of grad_offset[2 k] (d/dh), [2 k + 1] (d/dw)
-    int c[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) c[q] = R.c[q] + cl;
-    // a tap on axes Y = (rows r0, r1; weights y0, y1), X = (columns q0, q1; weights x0, x1); YI / XI: the axis is the
-    // integer one (weights 1, 0: no atomics on its second cell); okf: in-range flag of the tap (1 on integer axes)
-    auto tap = [&](int r0, int r1, int q0, int q1, float y0, float y1, float x0, float x1, float okf, int k, bool YI,
-                   bool XI) {
-      const int o00 = r0 + q0, o01 = r0 + q1, o10 = r1 + q0, o11 = r1 + q1;
-      if (WANT_GX) {
-        const float gks = gsc * wk[k];
-        scatter(o00, (y0 * x0) * gks);
-        if (!XI) scatter(o01, (y0 * x1) * gks);
-        if (!YI) scatter(o10, (y1 * x0) * gks);
-        if (!XI && !YI) scatter(o11, (y1 * x1) * gks);
-      }
-      if (WANT_GOFF) {
-        const float v00 = ximg[o00], v01 = ximg[o01], v10 = ximg[o10], v11 = ximg[o11];
-        const float gk = g * wk[k];
-        go[2 * k] = okf * gk * (x0 * (v10 - v00) + x1 * (v11 - v01));
-        go[2 * k + 1] = okf * gk * (y0 * (v01 - v00) + y1 * (v11 - v10));
-      }
-    };
-    const float *w8 = R.w;
-    tap(R.r[0], R.r[1], c[0], c[1], w8[0], w8[1], w8[4], w8[5], R.ok[0] * R.ok[2], 0, false, false);
-    tap(R.r[0], R.r[1], c[4], c[5], w8[0], w8[1], 1.0f, 0.0f, R.ok[0], 1, false, true);
-    tap(R.r[0], R.r[1], c[2], c[3], w8[0], w8[1], w8[6], w8[7], R.ok[0] * R.ok[3], 2, false, false);
-    tap(R.r[4], R.r[5], c[0], c[1], 1.0f, 0.0f, w8[4], w8[5], R.ok[2], 3, true, false);
-    tap(R.r[4], R.r[5], c[4], c[5], 1.0f, 0.0f, 1.0f, 0.0f, 1.0f, 4, true, true);
-    tap(R.r[4], R.r[5], c[2], c[3], 1.0f, 0.0f, w8[6], w8[7], R.ok[3], 5, true, false);
-    tap(R.r[2], R.r[3], c[0], c[1], w8[2], w8[3], w8[4], w8[5], R.ok[1] * R.ok[2], 6, false, false);
-    tap(R.r[2], R.r[3], c[4], c[5], w8[2], w8[3], 1.0f, 0.0f, R.ok[1], 7, false, true);
-    tap(R.r[2], R.r[3], c[2], c[3], w8[2], w8[3], w8[6], w8[7], R.ok[1] * R.ok[3], 8, false, false);
     if (WANT_GOFF) {
-      float *gb = goff + (long)n * 18 * HW + pp;
+      const int quads = (HW + 3) >> 2;
+      for (int q = tid; q < quads * CCH; q += nthreads) {
+        const int cl = q % CCH, j = q / CCH;
+        if (c0 + cl < C) {
+          const float *xp = x + ((long)n * C + c0 + cl) * HW + j * 4;
 #pragma unroll
-      for (int base = 0; base < 18; base += CCH) {
-        float mine = 0.0f;
-        if (base + CCH <= 18) {                 // a whole block of CCH sums: sum base + r to lane r of the pixel
-          float blk[CCH];
-#pragma unroll
-          for (int q = 0; q < CCH; ++q) blk[q] = go[base + q];
-          mine = reduce_scatter(blk, cl);
-        } else {                                // the last two (18 = 16 + 2 = 2 * 8 + 2 = 4 * 4 + 2)
-#pragma unroll
-          for (int q = 0; base + q < 18; ++q) {
-            const float sum = group_sum<CCH>(go[base + q]);      // (every lane: a DPP add must not sit under a lane test)
-            mine = (cl == q) ? sum : mine;
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int pix = j * 4 + e4;
+            if (pix < HW) ximg[((pix / W) * Wc + (pix % W)) * CCH + cl] = xp[e4];
           }
         }
-#if defined(CDN_DWOS_DIAG) && CDN_DWOS_DIAG == 1      // timing only: no global atomics
-        if (live && base + cl < 18 && mine == 12345.678f) atomicAdd(gb + (long)(base + cl) * HW, mine);
+      }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cl = lane % CCH, sub = lane / CCH;
+    const bool ch_ok = c0 + cl < C;
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = ch_ok ? wd[(long)(c0 + cl) * 9 + k] : 0.0f;
+    auto row_off = [&](int yy) {
+      return (int)__umul24((unsigned)(((unsigned)yy < (unsigned)H) ? yy : H), (unsigned)(Wc * CCH));
+    };
+    auto col_off0 = [&](int xx) { return (((unsigned)xx < (unsigned)W) ? xx : W) * CCH; };     // (+ the lane's channel)
+#if defined(CDN_DWOS_DIAG) && CDN_DWOS_DIAG == 3      // timing only: no LDS atomics
+    auto scatter = [&](int o, float cs) { if (cs == 12345.678f) atomicAdd(&gimg[o], cdn::fixed_rn(cs)); };
 #else
-        if (live && base + cl < 18) {
-          if (G > 1) gpart[(base + cl) * HW + pp] += mine;
-          else if (part != nullptr)      // this chunk's plane of partial sums: every element is written exactly once
-            part[(((long)blockIdx.x * gridDim.y + n) * 18 + base + cl) * HW + pp] = mine;
-          else atomicAdd(gb + (long)(base + cl) * HW, mine);
-        }
+    auto scatter = [&](int o, float cs) { atomicAdd(&gimg[o], cdn::fixed_rn(cs)); };
 #endif
+
+    // per-pixel record: rows (ya.i0, ya.i0 + 1, yb.i0, yb.i0 + 1, h, h + 1), columns likewise (without the lane's
+    // channel), the pixel (-1: beyond the plane), the eight axis weights, the four in-range flags as 0 / 1 floats
+    struct Rec {
+      int r[6], c[6], p;
+      float w[8], ok[4];
+    };
+    auto axis_ok = [](int base, float off, int size) {
+      const float pos = (float)base + off;
+      return (pos > -1.0f && pos < (float)size) ? 1.0f : 0.0f;
+    };
+    auto geometry = [&](int p) {
+      Rec g;
+      const bool live = p < HW;
+      const int pp = live ? p : 0;
+      const int h = pp / W, w = pp - h * W;
+      const float t = tplane[(long)n * HW + pp];
+      const SAxis ya = make_saxis(h - 1, -t, H), yb = make_saxis(h + 1, t, H);
+      const SAxis xa = make_saxis(w - 1, -t, W), xb = make_saxis(w + 1, t, W);
+      g.r[0] = row_off(ya.i0); g.r[1] = row_off(ya.i0 + 1); g.r[2] = row_off(yb.i0); g.r[3] = row_off(yb.i0 + 1);
+      g.r[4] = row_off(h); g.r[5] = row_off(h + 1);
+      g.c[0] = col_off0(xa.i0); g.c[1] = col_off0(xa.i0 + 1); g.c[2] = col_off0(xb.i0); g.c[3] = col_off0(xb.i0 + 1);
+      g.c[4] = col_off0(w); g.c[5] = col_off0(w + 1);
+      g.p = live ? p : -1;
+      g.w[0] = ya.w0; g.w[1] = ya.w1; g.w[2] = yb.w0; g.w[3] = yb.w1;
+      g.w[4] = xa.w0; g.w[5] = xa.w1; g.w[6] = xb.w0; g.w[7] = xb.w1;
+      g.ok[0] = axis_ok(h - 1, -t, H); g.ok[1] = axis_ok(h + 1, t, H);
+      g.ok[2] = axis_ok(w - 1, -t, W); g.ok[3] = axis_ok(w + 1, t, W);
+      return g;
+    };
+    auto step = [&](const Rec &R) {
+      const bool live = R.p >= 0;
+      const int pp = live ? R.p : 0;
+      const float g = (live && ch_ok) ? gd[((long)n * C + c0 + cl) * HW + pp] : 0.0f;
+      const float gsc = g * scale;            // (power-of-two scale: commutes with the roundings of the products below)
+      float go[18];                           // this lane's terms of grad_offset[2 k] (d/dh), [2 k + 1] (d/dw)
+      int c[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) c[q] = R.c[q] + cl;
+      // a tap on axes Y = (rows r0, r1; weights y0, y1), X = (columns q0, q1; weights x0, x1); YI / XI: the axis is the
+      // integer one (weights 1, 0: no atomics on its second cell); okf: in-range flag of the tap (1 on integer axes)
+      auto tap = [&](int r0, int r1, int q0, int q1, float y0, float y1, float x0, float x1, float okf, int k, bool YI,
+                     bool XI) {
+        const int o00 = r0 + q0, o01 = r0 + q1, o10 = r1 + q0, o11 = r1 + q1;
+        if (WANT_GX) {
+          const float gks = gsc * wk[k];
+          scatter(o00, (y0 * x0) * gks);
+          if (!XI) scatter(o01, (y0 * x1) * gks);
+          if (!YI) scatter(o10, (y1 * x0) * gks);
+          if (!XI && !YI) scatter(o11, (y1 * x1) * gks);
+        }
+        if (WANT_GOFF) {
+          const float v00 = ximg[o00], v01 = ximg[o01], v10 = ximg[o10], v11 = ximg[o11];
+          const float gk = g * wk[k];
+          go[2 * k] = okf * gk * (x0 * (v10 - v00) + x1 * (v11 - v01));
+          go[2 * k + 1] = okf * gk * (y0 * (v01 - v00) + y1 * (v11 - v10));
+        }
+      };
+      const float *w8 = R.w;
+      tap(R.r[0], R.r[1], c[0], c[1], w8[0], w8[1], w8[4], w8[5], R.ok[0] * R.ok[2], 0, false, false);
+      tap(R.r[0], R.r[1], c[4], c[5], w8[0], w8[1], 1.0f, 0.0f, R.ok[0], 1, false, true);
+      tap(R.r[0], R.r[1], c[2], c[3], w8[0], w8[1], w8[6], w8[7], R.ok[0] * R.ok[3], 2, false, false);
+      tap(R.r[4], R.r[5], c[0], c[1], 1.0f, 0.0f, w8[4], w8[5], R.ok[2], 3, true, false);
+      tap(R.r[4], R.r[5], c[4], c[5], 1.0f, 0.0f, 1.0f, 0.0f, 1.0f, 4, true, true);
+      tap(R.r[4], R.r[5], c[2], c[3], 1.0f, 0.0f, w8[6], w8[7], R.ok[3], 5, true, false);
+      tap(R.r[2], R.r[3], c[0], c[1], w8[2], w8[3], w8[4], w8[5], R.ok[1] * R.ok[2], 6, false, false);
+      tap(R.r[2], R.r[3], c[4], c[5], w8[2], w8[3], 1.0f, 0.0f, R.ok[1], 7, false, true);
+      tap(R.r[2], R.r[3], c[2], c[3], w8[2], w8[3], w8[6], w8[7], R.ok[1] * R.ok[3], 8, false, false);
+      if (WANT_GOFF) {
+        float *gb = goff + (long)n * 18 * HW + pp;
+#pragma unroll
+        for (int base = 0; base < 18; base += CCH) {
+          float mine = 0.0f;
+          if (base + CCH <= 18) {                 // a whole block of CCH sums: sum base + r to lane r of the pixel
+            float blk[CCH];
+#pragma unroll
+            for (int q = 0; q < CCH; ++q) blk[q] = go[base + q];
+            mine = reduce_scatter(blk, cl);
+          } else {                                // the last two (18 = 16 + 2 = 2 * 8 + 2 = 4 * 4 + 2)
+#pragma unroll
+            for (int q = 0; base + q < 18; ++q) {
+              const float sum = group_sum<CCH>(go[base + q]);      // (every lane: no DPP add under a lane test)
+              mine = (cl == q) ? sum : mine;
+            }
+          }
+#if defined(CDN_DWOS_DIAG) && CDN_DWOS_DIAG == 1      // timing only: no global atomics
+          if (live && base + cl < 18 && mine == 12345.678f) atomicAdd(gb + (long)(base + cl) * HW, mine);
+#else
+          if (live && base + cl < 18) {
+            if (G > 1) gpart[(base + cl) * HW + pp] += mine;
+            else if (part != nullptr)      // this chunk's plane of partial sums: every element is written exactly once
+              part[(((long)blockIdx.x * gridDim.y + n) * 18 + base + cl) * HW + pp] = mine;
+            else atomicAdd(gb + (long)(base + cl) * HW, mine);
+          }
+#endif
+        }
       }
-    }
-  };
-  if (CCH == 16 || CCH == 8 || CCH == 4) {
-    constexpr int LPP = CCH, SPB = 64 / PPW;
-    const int nsteps = (HW + nwaves * PPW - 1) / (nwaves * PPW);
-    for (int sb = 0; sb < nsteps; sb += SPB) {
-      const int own = cdn::owner_item<LPP>(lane);
-      const Rec G = geometry((wave + (sb + own / PPW) * nwaves) * PPW + own % PPW);
+    };
+    if (CCH == 16 || CCH == 8 || CCH == 4) {
+      constexpr int LPP = CCH, SPB = 64 / PPW;
+      const int nsteps = (HW + nwaves * PPW - 1) / (nwaves * PPW);
+      for (int sb = 0; sb < nsteps; sb += SPB) {
+        const int own = cdn::owner_item<LPP>(lane);
+        const Rec G = geometry((wave + (sb + own / PPW) * nwaves) * PPW + own % PPW);
 #pragma unroll 1
-      for (int j = 0; j < SPB && sb + j < nsteps; ++j) {
-        int gi[13] = {G.r[0], G.r[1], G.r[2], G.r[3], G.r[4], G.r[5], G.c[0], G.c[1], G.c[2], G.c[3], G.c[4], G.c[5],
-                      G.p}, oi[13];
-        float gf[12] = {G.w[0], G.w[1], G.w[2], G.w[3], G.w[4], G.w[5], G.w[6], G.w[7], G.ok[0], G.ok[1], G.ok[2],
-                        G.ok[3]}, of[12];
-        if (LPP == 4) cdn::fetch_record_quad(j, gi, gf, oi, of);
-        else cdn::fetch_record<LPP == 8>(j, gi, gf, oi, of);
-        Rec R;
+        for (int j = 0; j < SPB && sb + j < nsteps; ++j) {
+          int gi[13] = {G.r[0], G.r[1], G.r[2], G.r[3], G.r[4], G.r[5], G.c[0], G.c[1], G.c[2], G.c[3], G.c[4], G.c[5],
+                        G.p}, oi[13];
+          float gf[12] = {G.w[0], G.w[1], G.w[2], G.w[3], G.w[4], G.w[5], G.w[6], G.w[7], G.ok[0], G.ok[1], G.ok[2],
+                          G.ok[3]}, of[12];
+          if (LPP == 4) cdn::fetch_record_quad(j, gi, gf, oi, of);
+          else cdn::fetch_record<LPP == 8>(j, gi, gf, oi, of);
+          Rec R;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { R.r[q] = oi[q]; R.c[q] = oi[6 + q]; }
-        R.p = oi[12];
+          for (int q = 0; q < 6; ++q) { R.r[q] = oi[q]; R.c[q] = oi[6 + q]; }
+          R.p = oi[12];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) R.w[q] = of[q];
+          for (int q = 0; q < 8; ++q) R.w[q] = of[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) R.ok[q] = of[8 + q];
-        step(R);
+          for (int q = 0; q < 4; ++q) R.ok[q] = of[8 + q];
+          step(R);
+        }
+      }
+    } else {
+      for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) step(geometry(p0 + sub));
+    }
+    __syncthreads();
+    if (WANT_GX) {
+      const int quads = (HW + 3) >> 2;
+      const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
+      for (int q = tid; q < quads * CCH; q += nthreads) {
+        const int c = q % CCH, j = q / CCH;
+        if (c0 + c >= C) continue;
+        float v[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int pix = min(j * 4 + e4, HW - 1);
+          v[e4] = poisoned ? __uint_as_float(0x7fc00000u)
+                           : __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
+        }
+        float *gp = gx + ((long)n * C + c0 + c) * HW + j * 4;
+        if (vec) {
+          *reinterpret_cast<float4 *>(gp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4)
+            if (j * 4 + e4 < HW) gp[e4] = v[e4];
+        }
       }
     }
-  } else {
-    for (int p0 = wave * PPW; p0 < HW; p0 += nwaves * PPW) step(geometry(p0 + sub));
-  }
-  __syncthreads();
-  if (WANT_GX) {
-    const int quads = (HW + 3) >> 2;
-    const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0;
-    for (int q = tid; q < quads * CCH; q += nthreads) {
-      const int c = q % CCH, j = q / CCH;
-      if (c0 + c >= C) continue;
-      float v[4];
-#pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        const int pix = min(j * 4 + e4, HW - 1);
-        v[e4] = poisoned ? __uint_as_float(0x7fc00000u)
-                         : __ll2float_rn((long long)gimg[((pix / W) * Wc + (pix % W)) * CCH + c]) * inv_scale;
-      }
-      float *gp = gx + ((long)n * C + c0 + c) * HW + j * 4;
-      if (vec) {
-        *reinterpret_cast<float4 *>(gp) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4)
-          if (j * 4 + e4 < HW) gp[e4] = v[e4];
-      }
-    }
-  }
   }      // chunks of this workgroup
   if (WANT_GOFF && G > 1) {
     __syncthreads();
