@@ -2670,6 +2670,29 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   // the per-unit a_gen array (FusedBackbone._mixed_plan); the mask is built from those bytes in the table staging.
   __shared__ unsigned s_wmask;
   if (tid == 0) s_wmask = 0u;
+  // Round 6: everything of the prologue that depends on nothing is ISSUED here -- the first pass of the B tile's weight
+  // codes and the epilogue's per-column constants -- so that their round trip runs under the generation bytes' and the
+  // quantiser states' (two dependent trips) instead of after them: the prologue was three to four round trips of
+  // ~2 us each with every workgroup of the launch (one resident set) waiting at the same time.
+  const int chunks = Kp >> 4;                                // 16-code chunks per row
+  const int nitems = 32 * TN * chunks;
+  i32x4 cw0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q = tid + nthr * u;
+    const int r_ = q / chunks, ch = q - r_ * chunks;
+    cw0[u] = (i32x4){0, 0, 0, 0};
+    if (q < nitems && n0 + r_ < Co) cw0[u] = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
+  }
+  float bsv[TN], rinv[TN], ws_[TN];
+  int oc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {                             // branch-free, clamped column
+    const int cc = min(n0 + j * 32 + (lane & 31), Co - 1);
+    ws_[j] = wscale[cc];
+    bsv[j] = bias ? bias[cc] : 0.f;
+    oc[j] = omap ? omap[cc] : cc;
+  }
   __syncthreads();                    // (before the other waves OR their bits in)
   unsigned wmask = 0u, prem = 0u;     // the tile's window set; windows of the current block not yet prefetched
   auto load_next = [&](float4 (&d)[4]) {
@@ -2704,7 +2727,12 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
 #pragma unroll
         for (int u = 0; u < 2; ++u) {         // generation 255 = "this column meets only zero weight codes" (host)
           const int c = c0_ + tid + nthr * u;
-          if (c < C && gen[u] != 255) atomicOr(&s_wmask, 1u << (c >> 5));
+          // a wave's 64 channels are two windows: one LDS atomic per wave (one per channel was ~1000 atomics on one word)
+          const bool live = c < C && gen[u] != 255;
+          const unsigned long long lv = __ballot(live);
+          const int w0 = (c0_ + (tid & ~63) + nthr * u) >> 5;
+          const unsigned bits = ((lv & 0xffffffffull) ? 1u << w0 : 0u) | ((lv >> 32) ? 2u << w0 : 0u);
+          if (lane == 0 && bits) atomicOr(&s_wmask, bits);
           if (gen[u] == 255) gen[u] = 0;
         }
       }
@@ -2737,17 +2765,18 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
   const int nlist = __builtin_popcount(wmask);
 #pragma unroll
   for (int p_ = 0; p_ < PF; ++p_) load_next(buf[p_]);
-  const int chunks = Kp >> 4;                                // 16-code chunks per row
-  const int nitems = 32 * TN * chunks;
   for (int q0 = tid; q0 < nitems; q0 += nthr * 4) {
     i32x4 cw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int q = q0 + nthr * u;
       const int r_ = q / chunks, ch = q - r_ * chunks;
-      cw[u] = (i32x4){0, 0, 0, 0};
-      if (q < nitems && n0 + r_ < Co)
-        cw[u] = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
+      cw[u] = cw0[u];                                          // (first pass: loaded at the top of the kernel)
+      if (q0 != tid) {
+        cw[u] = (i32x4){0, 0, 0, 0};
+        if (q < nitems && n0 + r_ < Co)
+          cw[u] = *reinterpret_cast<const i32x4 *>(Wq + (long)(n0 + r_) * Cpad + ch * 16);
+      }
     }
 
 #pragma unroll
@@ -2772,34 +2801,14 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
     }
   }
-  // epilogue constants of this lane's TN output columns
-  float bsv[TN], rinv[TN];
-  int oc[TN];
-  {
-    float ws_[TN];                                            // branch-free, clamped column: ONE round trip
+  // epilogue constants of this lane's TN output columns (loaded at the top of the kernel)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int cc = min(n0 + j * 32 + (lane & 31), Co - 1);
-      ws_[j] = wscale[cc];
+  for (int j = 0; j < TN; ++j) {
+    const bool live = n0 + j * 32 + (lane & 31) < Co;
+    rinv[j] = live ? __fdiv_rn(1.0f, ws_[j]) : 0.f;
+    if (!live) {
       bsv[j] = 0.f;
-      oc[j] = cc;
-    }
-    if (bias) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bsv[j] = bias[min(n0 + j * 32 + (lane & 31), Co - 1)];
-    }
-    if (omap) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) oc[j] = omap[min(n0 + j * 32 + (lane & 31), Co - 1)];
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const bool live = n0 + j * 32 + (lane & 31) < Co;
-      rinv[j] = live ? __fdiv_rn(1.0f, ws_[j]) : 0.f;
-      if (!live) {
-        bsv[j] = 0.f;
-        oc[j] = -1;                                           // dead column
-      }
+      oc[j] = -1;                                             // dead column
     }
   }
   __syncthreads();
