@@ -133,6 +133,8 @@ _SIGNATURES = {
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_pointwise_mixed_forward": (
         _i, [_vp] * 3 + [_i64] * 5 + [_vp] * 7 + [_i] + [_vp] * 4 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
+    "cdn_codenet_pointwise_mixed_forward_n": (
+        _i, [_vp] * 3 + [_i] + [_i64] * 5 + [_vp] * 7 + [_i] + [_vp] * 4 + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "cdn_codenet_dw3x3_mixed_forward": (
         _i, [_vp] * 3 + [_i64] * 4 + [_i, _i] + [_i64] * 2 + [_vp] * 4 + [_i] + [_vp] * 3
         + [_i, _d, _i, _vp, ctypes.c_size_t, _vp, _vp]),

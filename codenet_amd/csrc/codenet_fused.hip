@@ -2640,7 +2640,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale,
             const float *__restrict__ bias, float *__restrict__ R, float2 *rmm, cdn::QUpdate qu,
             long M, int C, int Cpad, int Co, int relu, int lda, int ldo,
-            const unsigned char *__restrict__ agen, const int *__restrict__ omap) {
+            const unsigned char *__restrict__ agen, const int *__restrict__ omap, int ngen) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   CDN_STAMPR(2, 0);
   const int nwin = (C + 31) >> 5, Kp = nwin * 32;
@@ -2693,6 +2693,19 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
     bsv[j] = bias ? bias[cc] : 0.f;
     oc[j] = omap ? omap[cc] : cc;
   }
+  // ngen in 1 .. 16 (the caller says how many generations a_qstate holds): ALL their states and the first pass of
+  // generation bytes go out in the same round trip and the table is filled from LDS -- without it the states are loaded
+  // at addresses the generation bytes give: a second, dependent trip
+  __shared__ float2 s_states[16];
+  const bool pre_states = has_q && agen != nullptr && ngen >= 1 && ngen <= 16;
+  int gen0[2] = {0, 0};
+  if (pre_states) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) gen0[u] = agen[min(tid + nthr * u, C - 1)];
+    if (tid < 16)
+      s_states[tid] = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
+                                                        cdn::kQStateWords * min(tid, ngen - 1) + 2);
+  }
   __syncthreads();                    // (before the other waves OR their bits in)
   unsigned wmask = 0u, prem = 0u;     // the tile's window set; windows of the current block not yet prefetched
   auto load_next = [&](float4 (&d)[4]) {
@@ -2723,7 +2736,7 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       int gen[2] = {0, 0};
       if (agen) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) gen[u] = agen[min(c0_ + tid + nthr * u, C - 1)];
+        for (int u = 0; u < 2; ++u) gen[u] = (pre_states && c0_ == 0) ? gen0[u] : agen[min(c0_ + tid + nthr * u, C - 1)];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {         // generation 255 = "this column meets only zero weight codes" (host)
           const int c = c0_ + tid + nthr * u;
@@ -2738,8 +2751,9 @@ pwd3_kernel(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const float2 sz2 = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
-                                                             cdn::kQStateWords * gen[u] + 2);
+        const float2 sz2 = pre_states ? s_states[min(gen[u], 15)]
+                                      : *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(aq) +
+                                                                          cdn::kQStateWords * gen[u] + 2);
         te[u] = make_float4(sz2.x, sz2.y, 0.f, 0.f);
       }
 #pragma unroll
@@ -3388,7 +3402,8 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                             int64_t ldo = 0, const unsigned char *a_gen = nullptr,
                             const int *out_map = nullptr, bool a_padded = false,
                             const signed char *w_kb = nullptr, const float *next_ws = nullptr,
-                            float *sparts = nullptr) {
+                            float *sparts = nullptr, int n_gens = 0) {
+  // n_gens: how many states a_gen can name (0: unknown) -- pwd3_kernel then loads them all at once
   // next_ws / sparts: chained fp32 stages (pws_kernel only; the caller asked cdn_codenet_stage_chain_parts first)
   // w_kb: the k-blocked copy of w_pw_codes (include/codenet_dcn.h, CDN_X_WCODES_KB) or NULL
   // a_padded: the rows of A hold lda = round_up(C, 64) valid floats (the pad repeats channel C - 1) and the weight
@@ -3515,7 +3530,7 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
       const long gx2 = std::max<long>(1, std::min<long>(cdn::ceil_div(M, d3_threads / 2), per_cu * cdn::kCUs / ny));
       g = dim3((unsigned)gx2, ny);
       kern<<<g, d3_threads, lds_d3, st>>>(d, dst, w_pw_codes, w_pw_scale, bias_pw, r_out, rmm, qu_r, M, (int)C, Cpad,
-                                          (int)Co, relu, (int)lda, (int)ldo, a_gen, out_map);
+                                          (int)Co, relu, (int)lda, (int)ldo, a_gen, out_map, n_gens);
     } else if (pw_bn == 128 && pw_bm == 64) CDN_PWB(64, 128, 2);
     else if (pw_bn == 128) CDN_PWB(128, 128, 4);
     else CDN_PWB(128, 64, 4);
@@ -3936,7 +3951,19 @@ extern "C" int cdn_codenet_pointwise_mixed_forward(
     const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
     const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
     void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  return cdn_codenet_pointwise_mixed_forward_n(a, a_qstate, a_gen, 0, M, C, Co, lda, ldo, w, w_codes, w_scale, w_colsum,
+                                               bias, ep_scale, ep_shift, relu, out_map, r_min, r_max, r_state, bits,
+                                               momentum, running, workspace, workspace_bytes, out, stream);
+}
+
+extern "C" int cdn_codenet_pointwise_mixed_forward_n(
+    const float *a, const void *a_qstate, const unsigned char *a_gen, int n_gens, int64_t M, int64_t C, int64_t Co,
+    int64_t lda, int64_t ldo, const float *w, const signed char *w_codes, const float *w_scale,
+    const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
+    const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
+    void *workspace, size_t workspace_bytes, float *out, void *stream) {
   CDN_REQUIRE(a && w, CDN_ERR_ARG, "null pointer");
+  CDN_REQUIRE(n_gens >= 0, CDN_ERR_ARG, "n_gens must be >= 0 (0: unknown)");
   // out == NULL: RANGE-ONLY pass (round 4) -- the kernel computes everything and stores nothing; only the int8 kernel
   // on one input state implements it
   CDN_REQUIRE(out || (r_state && a_qstate && !a_gen && w_codes && !ep_scale), CDN_ERR_ARG,
@@ -3961,7 +3988,8 @@ extern "C" int cdn_codenet_pointwise_mixed_forward(
                         (float)(momentum - 1.0), (float)(1.0 - momentum), bits, running};
   return launch_pointwise(a, static_cast<unsigned *>(const_cast<void *>(a_qstate)), (long)M, C, Co, w,
                           w_codes, w_scale, w_colsum, bias, ep_scale, ep_shift, relu, out,
-                          r_state ? ws.partials : nullptr, qu, 0, st, lda, ldo, a_gen, out_map);
+                          r_state ? ws.partials : nullptr, qu, 0, st, lda, ldo, a_gen, out_map, false, nullptr, nullptr,
+                          nullptr, n_gens);
 }
 
 // The first 1x1 convs of NH detection heads (64 -> 64 each, one shared input) as ONE launch: pwi8h_kernel.

@@ -399,18 +399,21 @@ class FusedBackbone:
         self._stream, self._ws_ptr, self._ws_bytes = self._main_launch
         return ev
 
-    def _pw_raw(self, a_ptr, a_q, a_gen, M, lda, Wt, relu, act, state_ptr, out_map, out_ptr, ldo):
+    def _pw_raw(self, a_ptr, a_q, a_gen, M, lda, Wt, relu, act, state_ptr, out_map, out_ptr, ldo, n_gens=0):
+        """n_gens: the number of QuantAct states behind a_q when a_gen names them (0: unknown) -- the streaming kernel then
+        loads them all in the round trip of the generation bytes (cdn_codenet_pointwise_mixed_forward_n)."""
         from .. import _native as N_
         aa = self._act_args(act, self._dev)
         if state_ptr is not None:
             aa[2] = state_ptr
-        rc = N_.lib().cdn_codenet_pointwise_mixed_forward(
-            a_ptr, a_q, a_gen, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), Wt["codes"].data_ptr(),
+        rc = N_.lib().cdn_codenet_pointwise_mixed_forward_n(
+            a_ptr, a_q, a_gen, n_gens if (a_gen and self.preload_states) else 0, M, Wt["K"], Wt["Co"], lda, ldo, Wt["w"].data_ptr(), Wt["codes"].data_ptr(),
             Wt["scale"].data_ptr(), Wt["colsum"].data_ptr(), Wt["bias"].data_ptr(), None, None, int(relu),
             out_map, *aa, self._ws_ptr, self._ws_bytes, out_ptr, self._stream)
         N_.check(rc, "cdn_codenet_pointwise_mixed_forward")
 
     recompute_pw1 = True      # A/B switch (tools/e2e_native_bench.py --no-recompute)
+    preload_states = True     # A/B switch (--no-preload-states): n_gens handed to the mixed-generation pointwise
     range_first = True        # A/B switch: the recomputed conv's range pass before branch 1 is forked
 
     @staticmethod
@@ -491,14 +494,14 @@ class FusedBackbone:
                                        apply_only=self.two_streams and self.range_first)
                     else:
                         self._pw_raw(x.data_ptr(), a_q, a_gen, Mi, x_ld, P["c1"], True, u["a1"], None, None,
-                                     self._t1s2(L).data_ptr(), ldh)
+                                     self._t1s2(L).data_ptr(), ldh, n_gens=x_in["states"].numel() // 8 if mixed_in else 0)
                         self._dw_raw(L["t1s2"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["Hin"], L["Win"], 2, ldh,
                                      P["w2"], P["b2"], u["a2"], L["t2"], ldh)
                     if ev is not None:
                         torch.cuda.current_stream(dev).wait_event(ev)
                 else:
                     self._pw_raw(Y.data_ptr(), S.data_ptr(), P["gen_in"].data_ptr(), Mo, C, P["c1"], True,
-                                 u["a1"], None, None, L["t1"].data_ptr(), ldh)
+                                 u["a1"], None, None, L["t1"].data_ptr(), ldh, n_gens=plan["ngen"])
                     self._dw_raw(L["t1"].data_ptr(), qptr(u["a1"]), None, Nb, h, L["H"], L["W"], 1, ldh,
                                  P["w2"], P["b2"], u["a2"], L["t2"], ldh)
                 self._pw_raw(L["t2"].data_ptr(), qptr(u["a2"]), None, Mo, ldh, P["c3"], True, sh, sp(P["genB"]),
@@ -582,7 +585,7 @@ class FusedBackbone:
             if lay is not None and q4.folded_int8() is not None and x_ld <= self._MIXED_MAX_C:
                 W4 = self._l4_weights(q4, lay["logical"], dev, lay.get("gen_list"))
                 self._pw_raw(x.data_ptr(), lay["states"].data_ptr(), lay["gen"].data_ptr(), Nb * H * W, x_ld, W4,
-                             True, act4, None, None, B["out"].data_ptr(), c4)
+                             True, act4, None, None, B["out"].data_ptr(), c4, n_gens=lay["states"].numel() // 8)
             else:
                 if lay is not None:
                     x = self.materialize(lay).contiguous()

@@ -769,6 +769,16 @@ int cdn_codenet_pointwise_mixed_forward(
     const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
     const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
     void *workspace, size_t workspace_bytes, float *out, void *stream);
+/* The same call with the NUMBER of states a_qstate holds (round 6; 0: unknown = the call above): with 1 <= n_gens <= 16
+ * the streaming kernel loads all of them together with the generation bytes -- one memory round trip of the prologue
+ * instead of two dependent ones (a state's address otherwise waits for its generation byte).  Every a_gen[c] other than
+ * 255 must be < n_gens. */
+int cdn_codenet_pointwise_mixed_forward_n(
+    const float *a, const void *a_qstate, const unsigned char *a_gen, int n_gens, int64_t M, int64_t C, int64_t Co,
+    int64_t lda, int64_t ldo, const float *w, const signed char *w_codes, const float *w_scale,
+    const int *w_colsum, const float *bias, const float *ep_scale, const float *ep_shift, int relu,
+    const int *out_map, float *r_min, float *r_max, void *r_state, int bits, double momentum, int running,
+    void *workspace, size_t workspace_bytes, float *out, void *stream);
 int cdn_codenet_dw3x3_mixed_forward(
     const float *a, const void *a_qstate, const unsigned char *a_gen, int64_t N, int64_t C, int64_t H,
     int64_t W, int up, int stride, int64_t ld_in, int64_t ld_out, const float *w, const float *bias,

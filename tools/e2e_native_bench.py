@@ -23,7 +23,12 @@ def main():
                     "(before round 4's reordering) instead of in front of the fork")
     ap.add_argument("--no-recompute", action="store_true", help="A/B: layer 1's first 1x1 conv stored (round 3) instead "
                     "of recomputed inside its depthwise")
+    ap.add_argument("--no-preload-states", action="store_true", help="A/B: the mixed-generation pointwise without n_gens "
+                    "(states loaded at addresses the generation bytes give: a second round trip of its prologue)")
     a = ap.parse_args()
+    if a.no_preload_states:
+        from codenet_amd import pipeline
+        pipeline.FusedBackbone.preload_states = False
     if a.no_recompute:
         from codenet_amd import pipeline
         pipeline.FusedBackbone.recompute_pw1 = False

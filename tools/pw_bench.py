@@ -67,12 +67,14 @@ def main():
     xmin, xmax, st = torch.zeros(1, device=dev), torch.zeros(1, device=dev), ops.quantact_state(dev)
     stream = torch.cuda.current_stream().cuda_stream
     res = {}
-    for name, aq, ag, om, ld_o in (("final", None, None, None, ldo), ("single", states.data_ptr(), None, None, ldo),
-                                   ("mixed", states.data_ptr(), gen.data_ptr(), None, ldo),
-                                   ("mixed_mapped", states.data_ptr(), gen.data_ptr(), omap.data_ptr(), 2 * Co)):
+    for name, aq, ag, om, ld_o, ng in (("final", None, None, None, ldo, 0), ("single", states.data_ptr(), None, None, ldo, 0),
+                                       ("mixed", states.data_ptr(), gen.data_ptr(), None, ldo, 0),
+                                       ("mixed_n", states.data_ptr(), gen.data_ptr(), None, ldo, 8),
+                                       ("mixed_mapped", states.data_ptr(), gen.data_ptr(), omap.data_ptr(), 2 * Co, 0),
+                                       ("mixed_mapped_n", states.data_ptr(), gen.data_ptr(), omap.data_ptr(), 2 * Co, 8)):
         def run():
-            rc = lib.cdn_codenet_pointwise_mixed_forward(
-                a.data_ptr(), aq, ag, M, C, Co, lda, ld_o, w.data_ptr(), codes.data_ptr(), scale.data_ptr(),
+            rc = lib.cdn_codenet_pointwise_mixed_forward_n(
+                a.data_ptr(), aq, ag, ng, M, C, Co, lda, ld_o, w.data_ptr(), codes.data_ptr(), scale.data_ptr(),
                 colsum.data_ptr(), bias.data_ptr(), None, None, 1, om, xmin.data_ptr(), xmax.data_ptr(),
                 st.data_ptr(), 8, 0.99, 1, wp, wb, out.data_ptr(), stream)
             N_.check(rc, "pw")
