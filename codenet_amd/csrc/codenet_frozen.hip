@@ -104,20 +104,56 @@ constexpr int kQK = 64, kQLD = kQK + 16;
 
 // The epilogue shared by the int8 pointwise kernels on codes: acc[j][r] is the exact integer sum of row
 // m0 + wm + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column n0 + wn + 32 j + (lane & 31).
+// What the epilogue needs from memory -- the two quantisers' parameters and this lane's per-column constants.  LOADED
+// BEFORE THE K LOOP (round 6): read inside the epilogue they were one more memory round trip per workgroup, behind
+// the barriers of the k loop where the compiler cannot hoist them, in kernels whose workgroups live for two to four k
+// tiles.  Branch-free (clamped column); dead columns are masked where the values are used.
+template <int TN>
+struct PwqConsts {
+  float qs, qzf, rqs, rqz;
+  float bsv[TN], wsc[TN];
+  int wsm[TN], nq[TN], oc[TN];
+};
+template <int TN>
+__device__ __forceinline__ PwqConsts<TN> pwq8_consts(const unsigned *__restrict__ aq, const float *__restrict__ wscale,
+                                                     const int *__restrict__ wsum, const float *__restrict__ bias,
+                                                     const unsigned *__restrict__ rq, int Co,
+                                                     const signed char *__restrict__ nsc, const int *__restrict__ omap,
+                                                     int n0, int wn, int lane) {
+  PwqConsts<TN> k;
+  k.qs = reinterpret_cast<const float *>(aq)[2];
+  k.qzf = reinterpret_cast<const float *>(aq)[3];
+  k.rqs = rq ? reinterpret_cast<const float *>(rq)[2] : 1.f;
+  k.rqz = rq ? reinterpret_cast<const float *>(rq)[3] : 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cc = min(n0 + wn + j * 32 + (lane & 31), Co - 1);
+    k.wsc[j] = wscale[cc];
+    k.wsm[j] = wsum[cc];
+    k.bsv[j] = bias ? bias[cc] : 0.f;
+    k.nq[j] = nsc ? (int)nsc[cc] : 0;
+    k.oc[j] = omap ? omap[cc] : cc;
+  }
+  return k;
+}
+
 template <int TN>
 __device__ __forceinline__ void pwq8_epilogue(
-    i32x16 (&acc)[TN], const unsigned *__restrict__ aq, const float *__restrict__ wscale,
-    const int *__restrict__ wsum, const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
-    const unsigned *__restrict__ rq, unsigned *__restrict__ oflow, long M, int Cpad, int Co, int relu,
-    const signed char *__restrict__ nsc, int *__restrict__ sacc, int ldo, const int *__restrict__ omap, long m0, int n0,
+    i32x16 (&acc)[TN], const PwqConsts<TN> &kc, signed char *__restrict__ R8, float *__restrict__ Rf,
+    unsigned *__restrict__ oflow, long M, int Cpad, int Co, int relu,
+    const signed char *__restrict__ nsc, int *__restrict__ sacc, int ldo, long m0, int n0,
     int wm, int wn, int lane) {
-  const float qs = reinterpret_cast<const float *>(aq)[2];
-  const float qzf = reinterpret_cast<const float *>(aq)[3];
+  const float qs = kc.qs;
+  const float qzf = kc.qzf;
   // epilogue: the expressions of pwi8_kernel, then the output quantiser's code (or fp32 for a consumer
   // that wants pre-quantisation values)
   BadMask bad = 0;
   Code8 c8 = {1.f, 0.f};
-  if (R8) c8 = make_code8(rq, bad);
+  if (R8) {
+    c8.qs = kc.rqs;
+    c8.qz = kc.rqz;
+    if (!(fabsf(c8.qz) < 4.0e6f)) bad = 1;      // (make_code8's check)
+  }
   if (!(fabsf(qzf) < 4.0e6f)) bad = 1;
   const int qzi = (int)fminf(fmaxf(qzf, -4.0e6f), 4.0e6f);      // zero-point of the A codes: an integer
   // sum q*qw + zp*colsum is formed in int32: |sum q*qw| <= 128*8*Cpad and |zp*colsum| <= |zp|*8*Cpad, so a narrow
@@ -139,11 +175,11 @@ __device__ __forceinline__ void pwq8_epilogue(
     float bsv = 0.f, rinv = 0.f;
     int t128 = 0, nq = 0, oc = co;
     if (co < Co) {
-      if (bias) bsv = bias[co];
-      rinv = __fdiv_rn(1.0f, __fmul_rn(qs, wscale[co]));
-      t128 = qzi * wsum[co];
-      if (nsc) nq = nsc[co];
-      if (omap) oc = omap[co];
+      bsv = kc.bsv[j];
+      rinv = __fdiv_rn(1.0f, __fmul_rn(qs, kc.wsc[j]));
+      t128 = qzi * kc.wsm[j];
+      nq = kc.nq[j];
+      oc = kc.oc[j];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -199,6 +235,7 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
   // staging: 4 threads per 64-byte row segment
   const int lr = tid >> 2, lk = (tid & 3) * 16;
   i32x4 ra[AI], rb[BI];
+  const PwqConsts<TN> kc = pwq8_consts<TN>(aq, wscale, wsum, bias, R8 ? rq : nullptr, Co, nsc, omap, n0, wn, lane);
   auto load = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
@@ -241,8 +278,7 @@ pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
       }
     }
   }
-  pwq8_epilogue<TN>(acc, aq, wscale, wsum, bias, R8, Rf, rq, oflow, M, Cpad, Co, relu, nsc, sacc, ldo, omap, m0, n0, wm,
-                    wn, lane);
+  pwq8_epilogue<TN>(acc, kc, R8, Rf, oflow, M, Cpad, Co, relu, nsc, sacc, ldo, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -542,6 +578,7 @@ dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ a
     if (bad) atomicOr(oflow, 1u);
   }
   // ---- phase 2: the 1x1 conv on the resident A tile -----------------------------------------------------------
+  const PwqConsts<TN> kc = pwq8_consts<TN>(dq, wscale, wsum, bias, rq, Co, nullptr, omap, 0, wn, lane);
   i32x16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) acc[j] = (i32x16){0};
@@ -564,8 +601,7 @@ dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ a
       }
     }
   }
-  pwq8_epilogue<TN>(acc, dq, wscale, wsum, bias, R8, nullptr, rq, oflow, M, KP, Co, relu, nullptr, nullptr, ldo, omap,
-                    m0, 0, wm, wn, lane);
+  pwq8_epilogue<TN>(acc, kc, R8, nullptr, oflow, M, KP, Co, relu, nullptr, nullptr, ldo, m0, 0, wm, wn, lane);
 }
 
 // maxq8: MaxPool2d(3, stride 2, padding 1) of the "S2 + MaxPool" stems (shufflenetv2_dcn.py:209-214; README configs b and
