@@ -1949,48 +1949,10 @@ pwi8_body(const float *__restrict__ A, const unsigned *__restrict__ aq,
   CDN_STAMPR(2, 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WGN) * TM * 32, wn = (wave % WGN) * TN * 32;
-  const float qs = reinterpret_cast<const float *>(aq)[2];
-  const float qz = reinterpret_cast<const float *>(aq)[3];
-  if (aq[6]) {
-    // Codes too wide for the nibble split (the tracked range is far narrower than the batch: the first
-    // ~100 calls of a fresh EMA): this batch runs on f32 MFMA with the fake-quantised weights, inside
-    // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
-    // do).  Simple single-buffered 16-deep k-tiles in the int8 path's LDS arrays: the rare path.
-    static_assert(BM * 17 * 4 <= 2 * BM * kI8LD && BN * 17 * 4 <= 2 * BN * kI8LD, "LDS reuse");
-    pwi8_wide_path<BM, BN, WGM>(A, Wp, bias, R, rmm, qu, M, Cw, Co, relu, lda, ldo, omap, qs, qz,
-                                reinterpret_cast<float *>(&A0[0][0]), reinterpret_cast<float *>(&B0[0][0]),
-                                reinterpret_cast<float *>(&A1[0][0]), m0, n0, 1, pidx, npart);
-    return;
-  }
-  // as_uint(t + 1.5*2^23) = 0x4B400000 + rint(t) for |t| < 2^22 (guaranteed when state[6] == 0)
-  const int ioff = (int)qz + (2048 - 128) - 0x4B400000;
-  i32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (i32x16){0};
-  // Epilogue constants of this lane's TN output columns, requested NOW (branch-free, clamped column): read after
-  // the k loop they were 2 dependent round trips per column with the workgroup idle (the ISA waited for bias /
-  // scale / colsum, then for the channel map), ~3 us at the end of every launch.
-  float e_bias[TN], e_ws[TN];
-  int e_sum[TN], e_oc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn + j * 32 + (lane & 31);
-    const int cc = min(co, Co - 1);
-    e_ws[j] = wscale[cc];
-    e_sum[j] = wsum[cc];
-    e_bias[j] = 0.f;
-    e_oc[j] = co;
-  }
-  if (bias) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) e_bias[j] = bias[min(n0 + wn + j * 32 + (lane & 31), Co - 1)];
-  }
-  if (omap) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) e_oc[j] = omap[min(n0 + wn + j * 32 + (lane & 31), Co - 1)];
-  }
+  // Round 6: the first k tile and the epilogue constants go out BEFORE the input quantiser's state is read -- the branch
+  // on its wide-code flag below needs the state, and with the loads behind that branch every workgroup began with one
+  // memory round trip for three words and only then asked for its data (a second trip; the workgroups of these launches
+  // live for two to eight k tiles).  The wide path ignores what was loaded.
   const int lr = tid >> 3, lk = (tid & 7) * 4;      // A staging: row lr + 32*i, k quad lk
   const bool vec4 = !FAST && (C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   const int br = tid >> 1, bh = (tid & 1) * 16;     // B staging: row br + 128*i, 16-byte half bh
@@ -2026,6 +1988,52 @@ pwi8_body(const float *__restrict__ A, const unsigned *__restrict__ aq,
       b[i] = *reinterpret_cast<const i32x4 *>(Wq + (long)co * Cpad + k0 + bh);
     }
   };
+  // (128-row tiles keep the old order: their 16 + 8 registers of tile and row pointers live across the branch took the
+  // kernel from 108 to 140 VGPRs = from four to three workgroups per CU; they serve the small-M launches only)
+  constexpr bool kEarly = BM <= 64;
+  if (kEarly) load_tile(0);
+  // Epilogue constants of this lane's TN output columns, requested NOW (branch-free, clamped column): read after
+  // the k loop they were 2 dependent round trips per column with the workgroup idle (the ISA waited for bias /
+  // scale / colsum, then for the channel map), ~3 us at the end of every launch.
+  float e_bias[TN], e_ws[TN];
+  int e_sum[TN], e_oc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn + j * 32 + (lane & 31);
+    const int cc = min(co, Co - 1);
+    e_ws[j] = wscale[cc];
+    e_sum[j] = wsum[cc];
+    e_bias[j] = 0.f;
+    e_oc[j] = co;
+  }
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) e_bias[j] = bias[min(n0 + wn + j * 32 + (lane & 31), Co - 1)];
+  }
+  if (omap) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) e_oc[j] = omap[min(n0 + wn + j * 32 + (lane & 31), Co - 1)];
+  }
+  const float qs = reinterpret_cast<const float *>(aq)[2];
+  const float qz = reinterpret_cast<const float *>(aq)[3];
+  if (__builtin_amdgcn_readfirstlane((int)aq[6])) {      // (workgroup-uniform; said so: the loads above stay live past this branch)
+    // Codes too wide for the nibble split (the tracked range is far narrower than the batch: the first
+    // ~100 calls of a fresh EMA): this batch runs on f32 MFMA with the fake-quantised weights, inside
+    // the same launch (a separate fallback launch costs 4.3 us per stage even when it has nothing to
+    // do).  Simple single-buffered 16-deep k-tiles in the int8 path's LDS arrays: the rare path.
+    static_assert(BM * 17 * 4 <= 2 * BM * kI8LD && BN * 17 * 4 <= 2 * BN * kI8LD, "LDS reuse");
+    pwi8_wide_path<BM, BN, WGM>(A, Wp, bias, R, rmm, qu, M, Cw, Co, relu, lda, ldo, omap, qs, qz,
+                                reinterpret_cast<float *>(&A0[0][0]), reinterpret_cast<float *>(&B0[0][0]),
+                                reinterpret_cast<float *>(&A1[0][0]), m0, n0, 1, pidx, npart);
+    return;
+  }
+  // as_uint(t + 1.5*2^23) = 0x4B400000 + rint(t) for |t| < 2^22 (guaranteed when state[6] == 0)
+  const int ioff = (int)qz + (2048 - 128) - 0x4B400000;
+  i32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (i32x16){0};
   auto ucode = [&](float v, bool live) -> unsigned {
 #pragma clang fp contract(off)
 #if defined(CDN_DIAG) && CDN_DIAG == 7   // diagnostic build: no fp32 -> code arithmetic (wrong results)
@@ -2063,7 +2071,7 @@ pwi8_body(const float *__restrict__ A, const unsigned *__restrict__ aq,
       }
   };
 
-  load_tile(0);
+  if (!kEarly) load_tile(0);
   store_tile(0, 0);
   __syncthreads();
   CDN_STAMPR(2, 1);
