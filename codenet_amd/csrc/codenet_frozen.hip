@@ -98,7 +98,10 @@ __global__ void __launch_bounds__(256) frozen_params_kernel(FrozenList f) {
 // issued before the first wait -- for the backbone's K <= 512: 67-101 KB of LDS leave 1-2 workgroups per CU and nothing
 // to overlap a workgroup's load phase with; 0.97 ms against 0.73 ms over the 42 launches of the frozen network.  Nor
 // do 128-byte k tiles (half the round trips per workgroup, twice the loads in flight): 0.751 against 0.735 ms.  At
-// M = 16 k .. 262 k rows and K <= 464 these launches sit at 9-23 us whatever the tile pipeline does.)
+// M = 16 k .. 262 k rows and K <= 464 these launches sit at 9-23 us whatever the tile pipeline does.  Round 6: the
+// 64 x 64 tile asking for ALL its k tiles (K <= 256: at most four) before waiting for the first, in REGISTERS: 80 ->
+// 140 VGPRs = three instead of eight workgroups per CU, serving network 1.42 -> 1.59 ms -- what hides a workgroup's
+// round trips here is the other seven workgroups of its CU, not a deeper pipeline of its own.)
 // ------------------------------------------------------------------------------------------------------
 constexpr int kQK = 64, kQLD = kQK + 16;
 
