@@ -214,7 +214,7 @@ __device__ __forceinline__ void pwq8_epilogue(
 }
 
 template <int BM, int BN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BM == 64 && BN == 64) ? 8 : 1, 8)))
 pwq8_kernel(const signed char *__restrict__ A, const unsigned *__restrict__ aq,
             const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
             const float *__restrict__ bias, signed char *__restrict__ R8, float *__restrict__ Rf,
