@@ -479,8 +479,12 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
 //   phase 2  pwq8's MFMA loop with the A operand resident and the weights streamed in 64-byte k tiles, BN = all Co
 //            (<= 256: every column tile would recompute phase 1), pwq8's epilogue.
 // Bit-identical to dwq8_kernel followed by pwq8_kernel (tests/test_gpu_frozen.py).
+// (waves per SIMD asked of the register allocator: without the request it spends up to 312 VGPRs on the depthwise
+// phase's unrolled rows -- one wave per SIMD at 256 columns, two at 128 -- where 153-245 / 107-168 do without scratch:
+// serving network 1.402 -> see DESIGN 4.2; the two shapes that would spill keep two waves)
 template <int STRIDE, int SW, int TR, int BN>
 __global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu((BN == 256 || (STRIDE == 2 && TR == 4)) ? 2 : 3, 8)))
 dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq, const float *__restrict__ wdw,
               const float *__restrict__ bdw, int dw_relu, const unsigned *__restrict__ dq,
               const signed char *__restrict__ Wq, const float *__restrict__ wscale, const int *__restrict__ wsum,
