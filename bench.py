@@ -1037,7 +1037,31 @@ def _e2e_frozen_leg(args, model, images, replay, n_fresh=16, n_cal=8, sigmas=6.0
     if rate > 0:                            # the contract: an overflowed batch is recomputed on the fp32 frozen schedule
         recompute_ms = timed(fresh[:2], frozen_codes=False)[3]
     total = steady_b + rate * (recompute_ms or 0.0)
-    return {"ms_per_batch": total, "images_per_s": args.batch / total * 1e3, "per_rank": True,
+    # the reference's own operating point in serving mode: ONE image + its mirror per call (test.py --flip_test) on the
+    # byte schedule with the ranges calibrated above -- no range protocol between the ~55 launches of the chain
+    flip = None
+    try:
+        model.enable_fused(frozen_codes=True)
+        one = fresh[0][:1]
+        pair = torch.cat([one, torch.flip(one, [3])], 0)
+        rp = harness.capture_process(model, pair, flip_test=True)
+        for _ in range(10):
+            rp()
+        torch.cuda.synchronize()
+        model.frozen_overflowed()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            d2 = rp()[1]
+        torch.cuda.synchronize()
+        fms = (time.perf_counter() - t0) / 200 * 1e3
+        flip = {"graph_ms_per_call": fms, "images_per_s": 1e3 / fms, "overflow": bool(model.frozen_overflowed()),
+                "finite": bool(torch.isfinite(d2).all()),
+                "what": "one image + its mirror per call (batch 2, --flip_test) on the byte-code serving schedule, one "
+                        "HIP graph replay per call; e2e.latency_flip is the same call with running ranges"}
+        del rp
+    except Exception as exc:          # noqa: BLE001 -- an extra figure: the leg's numbers stand without it
+        flip = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    return {"ms_per_batch": total, "images_per_s": args.batch / total * 1e3, "per_rank": True, "latency_flip": flip,
             "fresh_batches": n_fresh, "overflow_rate": rate, "valid": rate < 0.02, "overflow": rate > 0,
             "byte_schedule_ms": steady_b, "byte_schedule_ms_per_fresh_batch_events": sum(ms_b) / len(ms_b),
             "fp32_recompute_ms": recompute_ms,
