@@ -423,6 +423,7 @@ namespace cdn {
 constexpr int kMaxPartials = 16384;
 // codenet_fused.hip, shared with the frozen-range schedule (codenet_frozen.hip)
 int stage_channel_chunk(int Hl, int Wl);
+int thin_channel_chunk(int cch, int64_t C, int64_t N);
 int launch_frozen_scale(const void *x, int x_kind, const unsigned *xq, const float *w_scale, const float *b_scale,
                         float *s_raw, int64_t N, int64_t C, int64_t HWl, float lo, float hi, hipStream_t st);
 // Frozen schedule, chained stages: the producer's pointwise epilogue leaves sums[m] = sum_co qw_s[co] * level_r[m][co]

@@ -3338,13 +3338,29 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
 }
 }  // namespace
 
+// The gather's channel chunk for THIS launch: the LDS-fit chunk (stage_channel_chunk), thinned while the grid is below one
+// workgroup per CU.  cfg2 (32 images of 256 x 256) ran stage 1 on 128 and stage 2 on 64 workgroups of 64 channels -- half
+// and a quarter of the GPU (in-kernel stamps, round 6); with chunks of 32 / 16: gather 13.0 -> 11.4 and 21.6 -> 12.7 us,
+// step 0.0937 -> 0.0835 ms; CoDeNet2x at 32 images per GPU 0.2154 -> 0.2026 ms.  Thinner than one workgroup per CU, or
+// chunks of 8, lose again (0.0866 / 0.0909).  The gather is per channel: the chunking changes no value.
+#ifndef CDN_THIN_CHUNK_MIN
+#define CDN_THIN_CHUNK_MIN 16      // (64 and 32 channels fetch the tap record with DPP, 16 and 8 with ds_bpermute)
+#endif
+int cdn::thin_channel_chunk(int cch, int64_t C, int64_t N) {
+#ifndef CDN_NO_THIN_CHUNKS
+  while (cch > CDN_THIN_CHUNK_MIN && cdn::ceil_div(C, (int64_t)cch) * N < (int64_t)cdn::kCUs) cch >>= 1;
+#endif
+  return cch;
+}
+
 int cdn::launch_frozen_dw(const void *x, int x_kind, const unsigned *xq, const float *s_raw, const unsigned *sq,
                           const float *wd, signed char *d8, unsigned *dstate, unsigned *oflow, int N, int C, int H,
                           int W, int up, hipStream_t st, cdn::ScaleFromSums si, int gmode) {
   if (si.sums && !(x_kind != 0 && up == 1))
     return cdn::fail(CDN_ERR_UNSUPPORTED, "scale sums are consumed by the up-sampled channels-last gather only");
-  const int cch = cdn::stage_channel_chunk(H >> up, W >> up);
+  int cch = cdn::stage_channel_chunk(H >> up, W >> up);
   if (cch == 0) return cdn::fail(CDN_ERR_UNSUPPORTED, "stored plane too large for the LDS-resident gather");
+  cch = cdn::thin_channel_chunk(cch, C, N);      // (few workgroups: see stage_fused_forward_impl)
   if ((long)cdn::ceil_div(C, cch) * N > cdn::kMaxPartials) return cdn::fail(CDN_ERR_UNSUPPORTED, "too many workgroups");
   auto fn = cch == 64 ? launch_frozen_dw_t<64> : cch == 32 ? launch_frozen_dw_t<32>
             : cch == 16 ? launch_frozen_dw_t<16> : launch_frozen_dw_t<8>;
@@ -3849,10 +3865,14 @@ static int stage_fused_forward_impl(
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
     rc = launch_dwg(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st);
   } else {
-    const int n_part_d = (int)(cdn::ceil_div(C, cch) * N);
+    // Few workgroups (cfg2: 32 images of 256 x 256 -- stage 1 had 128 and stage 2 64 workgroups of 64 channels on 256
+    // CUs; in-kernel stamps, round 6): thinner chunks while the grid is below one workgroup per CU.  The gather is
+    // per channel: the chunking changes no value.
+    const int cch_g = cdn::thin_channel_chunk(cch, C, N);
+    const int n_part_d = (int)(cdn::ceil_div(C, cch_g) * N);
     CDN_REQUIRE(n_part_d <= kMaxPartials, CDN_ERR_UNSUPPORTED, "too many gather workgroups");
     cdn::ProfScope ps(cdn::kProfDw, ptag, st);
-    auto fn = cch == 64 ? launch_dw2<64> : cch == 32 ? launch_dw2<32> : cch == 16 ? launch_dw2<16> : launch_dw2<8>;
+    auto fn = cch_g == 64 ? launch_dw2<64> : cch_g == 32 ? launch_dw2<32> : cch_g == 16 ? launch_dw2<16> : launch_dw2<8>;
     rc = fn(x_nhwc != 0, x, xq, s_raw, sst, w_dw, d, dmm, qu_d, (int)N, (int)C, (int)H, (int)W, x_up, st, gmode,
             (int)ldd, cdn::ScaleFromSums{nullptr, nullptr, b_scale, lo, hi, parts_in, n_parts_in});
   }
