@@ -3346,9 +3346,12 @@ int launch_frozen_dw_t(const float *x, int x_kind, const unsigned *xq, const flo
 #ifndef CDN_THIN_CHUNK_MIN
 #define CDN_THIN_CHUNK_MIN 16      // (64 and 32 channels fetch the tap record with DPP, 16 and 8 with ds_bpermute)
 #endif
+#ifndef CDN_THIN_CHUNK_FILL
+#define CDN_THIN_CHUNK_FILL 1      // workgroups per CU the thinning aims at (A/B: 2 loses at every shape tried)
+#endif
 int cdn::thin_channel_chunk(int cch, int64_t C, int64_t N) {
 #ifndef CDN_NO_THIN_CHUNKS
-  while (cch > CDN_THIN_CHUNK_MIN && cdn::ceil_div(C, (int64_t)cch) * N < (int64_t)cdn::kCUs) cch >>= 1;
+  while (cch > CDN_THIN_CHUNK_MIN && cdn::ceil_div(C, (int64_t)cch) * N < (int64_t)CDN_THIN_CHUNK_FILL * cdn::kCUs) cch >>= 1;
 #endif
   return cch;
 }
