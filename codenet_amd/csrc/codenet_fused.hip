@@ -3534,8 +3534,17 @@ static int launch_pointwise(const float *d, unsigned *dst, long M, int64_t C, in
                                                    (int)lda, (int)ldo, a_gen, out_map);          \
   } while (0)
     // streaming form when the rows are 16-byte aligned quads and the N tile's weights fit in LDS
-    const int tn = Co > 64 ? 4 : 2;
+    int tn = Co > 64 ? 4 : 2;
     const int Kp = (int)((C + 31) / 32 * 32);
+#if !defined(CDN_PWD3_NO_TN2_SMALLM)
+    // Round 6: 64-column tiles where the 128-column tile's B (> 80 KB: K = 464) leaves ONE workgroup per CU and M is too
+    // small for its 512-thread form -- layer 4's units at batch 64 ran 256 four-wave workgroups, one wave per SIMD; with
+    // 64 columns two workgroups share a CU and the grid doubles (the A rows are read four times instead of twice, from
+    // L2): 16384 x 464 -> 232 38.0 -> 35.6 us, whole network 2.509 -> 2.495 ms (three interleaved pairs)
+    if (tn == 4 && (size_t)32 * 4 * (Kp * 2 + 16) + (size_t)Kp * 16 > 80 * 1024 &&
+        cdn::ceil_div(M, 256) * cdn::ceil_div(Co, 128) < cdn::kCUs)
+      tn = 2;
+#endif
     const size_t lds_d3 = (size_t)32 * tn * (Kp * 2 + 16) + (size_t)Kp * 16;
     const long nblk_d3 = cdn::ceil_div(M, 128) * cdn::ceil_div(Co, 32 * tn);
     if ((C & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
