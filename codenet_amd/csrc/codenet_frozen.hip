@@ -482,7 +482,7 @@ dwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq,
 // (waves per SIMD asked of the register allocator: without the request it spends up to 312 VGPRs on the depthwise
 // phase's unrolled rows -- one wave per SIMD at 256 columns, two at 128 -- where 153-245 / 107-168 do without scratch:
 // serving network 1.402 -> see DESIGN 4.2; the two shapes that would spill keep two waves)
-template <int STRIDE, int SW, int TR, int BN>
+template <int STRIDE, int SW, int TR, int BN, int BM = 64>
 __global__ void __launch_bounds__(256)
     __attribute__((amdgpu_waves_per_eu((BN == 256 || (STRIDE == 2 && TR == 4)) ? 2 : 3, 8)))
 dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ aq, const float *__restrict__ wdw,
@@ -491,7 +491,10 @@ dwpwq8_kernel(const signed char *__restrict__ a8, const unsigned *__restrict__ a
               const float *__restrict__ bias, signed char *__restrict__ R8, const unsigned *__restrict__ rq,
               unsigned *__restrict__ oflow, long M, int C, int KP, int ld_in, int Hs, int Ws, int Ho, int Wo, int Co,
               int relu, int ldo, const int *__restrict__ omap) {
-  constexpr int BM = 64, WGN = 2, TN = BN / (32 * WGN), BI = BN * kQK / 16 / 256, NC = (SW - 1) * STRIDE + 3;      // (2 x 2 waves)
+  // (BM = 64: 2 x 2 waves; BM = 32, round 6: 1 x 4 waves -- the 16 x 16 planes of layer 4 at batch 64 are 256 tiles of 64
+  // pixels, one four-wave workgroup per CU: 32-pixel tiles put two on every CU)
+  constexpr int WGN = 4 / (BM / 32), TN = BN / (32 * WGN), BI = BN * kQK / 16 / 256, NC = (SW - 1) * STRIDE + 3;
+  static_assert(BM == 64 || (BM == 32 && BN >= 128), "tile shapes: 64 rows, or 32 rows x >= 128 columns");
   constexpr int Wseg = BM / TR;                    // columns of the tile (== Wo, or a 64-column segment of a row)
   static_assert(TN >= 1 && BI >= 1, "tile too small");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_dp[];
@@ -897,8 +900,11 @@ extern "C" int cdn_codenet_dwpw_q8_forward(
   const unsigned *rq = static_cast<const unsigned *>(r_state);
   const int KP = (int)((C + 63) / 64 * 64);
   const int bn = Co <= 64 ? 64 : (Co <= 128 ? 128 : 256);
-  const size_t lds = (size_t)64 * (KP + 16) + (size_t)bn * (kQK + 16);
-  const unsigned grid = (unsigned)(M / 64);
+  // 32-row tiles where 64-row tiles leave at most one workgroup per CU (all-Co tiles, small planes: layer 4)
+  const bool bm32 = bn == 256 && M / 64 <= (long)cdn::kCUs && (Wo == 8 || Wo == 16 || Wo == 32) && (Ho * Wo) % 32 == 0;
+  const int BMr = bm32 ? 32 : 64;
+  const size_t lds = (size_t)BMr * (KP + 16) + (size_t)bn * (kQK + 16);
+  const unsigned grid = (unsigned)(M / BMr);
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     kern<<<grid, 256, lds, st>>>(a8, aq, w_dw, b_dw, dw_relu, dq, w_codes, w_scale, w_colsum, bias, r8_out, rq, overflow,
@@ -910,6 +916,19 @@ extern "C" int cdn_codenet_dwpw_q8_forward(
     if (bn == 64) go(dwpwq8_kernel<S_, SW_, TR_, 64>);                  \
     else if (bn == 128) go(dwpwq8_kernel<S_, SW_, TR_, 128>);           \
     else go(dwpwq8_kernel<S_, SW_, TR_, 256>);                          \
+  }
+  if (bm32) {
+    const int tr32 = 32 / Wo;      // 4, 2 or 1 rows of 8, 16 or 32 columns
+    if (stride == 1) {
+      if (tr32 == 1) go(dwpwq8_kernel<1, 4, 1, 256, 32>);
+      else if (tr32 == 2) go(dwpwq8_kernel<1, 4, 2, 256, 32>);
+      else go(dwpwq8_kernel<1, 4, 4, 256, 32>);
+    } else {
+      if (tr32 == 1) go(dwpwq8_kernel<2, 2, 1, 256, 32>);
+      else if (tr32 == 2) go(dwpwq8_kernel<2, 2, 2, 256, 32>);
+      else go(dwpwq8_kernel<2, 2, 4, 256, 32>);
+    }
+    return cdn::check_launch("codenet depthwise + pointwise on byte codes");
   }
   const int tr = Wo >= 64 ? 1 : 64 / Wo;
   if (stride == 1) {
