@@ -901,7 +901,11 @@ extern "C" int cdn_codenet_dwpw_q8_forward(
   const int KP = (int)((C + 63) / 64 * 64);
   const int bn = Co <= 64 ? 64 : (Co <= 128 ? 128 : 256);
   // 32-row tiles where 64-row tiles leave at most one workgroup per CU (all-Co tiles, small planes: layer 4)
-  const bool bm32 = bn == 256 && M / 64 <= (long)cdn::kCUs && (Wo == 8 || Wo == 16 || Wo == 32) && (Ho * Wo) % 32 == 0;
+#ifndef CDN_DWPW_BM32_FILL
+#define CDN_DWPW_BM32_FILL 1
+#endif
+  const bool bm32 = bn >= 128 && M / 64 <= (long)CDN_DWPW_BM32_FILL * cdn::kCUs && (Wo == 8 || Wo == 16 || Wo == 32) &&
+                    (Ho * Wo) % 32 == 0;
   const int BMr = bm32 ? 32 : 64;
   const size_t lds = (size_t)BMr * (KP + 16) + (size_t)bn * (kQK + 16);
   const unsigned grid = (unsigned)(M / BMr);
@@ -919,15 +923,21 @@ extern "C" int cdn_codenet_dwpw_q8_forward(
   }
   if (bm32) {
     const int tr32 = 32 / Wo;      // 4, 2 or 1 rows of 8, 16 or 32 columns
+#define CDN_DP32(S_, SW_, TR_)                                          \
+  {                                                                     \
+    if (bn == 128) go(dwpwq8_kernel<S_, SW_, TR_, 128, 32>);            \
+    else go(dwpwq8_kernel<S_, SW_, TR_, 256, 32>);                      \
+  }
     if (stride == 1) {
-      if (tr32 == 1) go(dwpwq8_kernel<1, 4, 1, 256, 32>);
-      else if (tr32 == 2) go(dwpwq8_kernel<1, 4, 2, 256, 32>);
-      else go(dwpwq8_kernel<1, 4, 4, 256, 32>);
+      if (tr32 == 1) CDN_DP32(1, 4, 1)
+      else if (tr32 == 2) CDN_DP32(1, 4, 2)
+      else CDN_DP32(1, 4, 4)
     } else {
-      if (tr32 == 1) go(dwpwq8_kernel<2, 2, 1, 256, 32>);
-      else if (tr32 == 2) go(dwpwq8_kernel<2, 2, 2, 256, 32>);
-      else go(dwpwq8_kernel<2, 2, 4, 256, 32>);
+      if (tr32 == 1) CDN_DP32(2, 2, 1)
+      else if (tr32 == 2) CDN_DP32(2, 2, 2)
+      else CDN_DP32(2, 2, 4)
     }
+#undef CDN_DP32
     return cdn::check_launch("codenet depthwise + pointwise on byte codes");
   }
   const int tr = Wo >= 64 ? 1 : 64 / Wo;
