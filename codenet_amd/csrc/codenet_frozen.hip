@@ -46,11 +46,11 @@ __device__ __forceinline__ int act_code8(float v, const Code8 &c, BadMask &bad) 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// frozen_params_kernel: (scale, zero-point) of up to 48 frozen QuantActs from their x_min / x_max buffers
+// frozen_params_kernel: (scale, zero-point) of up to 64 frozen QuantActs from their x_min / x_max buffers
 // into state words [2], [3] (and [6] = 0) -- the expressions of cdn::quantact_update_device without the range update
 // (quant_utils.py:60-75).  One launch per step for the whole schedule.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kMaxFrozen = 48;
+constexpr int kMaxFrozen = 64;      // (round 6: the whole serving network's QuantActs in the step's first launch)
 struct FrozenList {
   const float *x_min[kMaxFrozen];
   const float *x_max[kMaxFrozen];

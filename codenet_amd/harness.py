@@ -190,7 +190,18 @@ class PoseShuffleNetV2(nn.Module):
                 stages = self._ffrozen
                 # every QuantAct of the backbone frozen too: byte codes end to end
                 if self._fzbackbone is not None and self._fzbackbone.still_frozen():
-                    feat8, fq, hw = self._fzbackbone(x)
+                    # the QuantAct parameters of the stages and the heads in the backbone's first launch (once their
+                    # buffers exist: from the second call on) -- two launches fewer in the chain
+                    also, sb = None, stages._bufs
+                    hb = self._fzheads._bufs if self._fzheads is not None else None
+                    if (sb is not None and hb is not None and hb.get("acts") is not None and sb.get("acts") is not None
+                            and getattr(self, "merge_frozen_params", True)):      # (A/B switch: tools/e2e_frozen_bench.py)
+                        also = (list(sb["acts"]) + list(hb["acts"]), sb.get("sums_all"))
+                    feat8, fq, hw = self._fzbackbone(x, also=also)
+                    cov = self._fzbackbone.covered
+                    if cov is not None:
+                        stages.params_covered = cov
+                        self._fzheads.params_covered = cov
                     r8, rq, last = stages.forward_codes(feat8, fq, hw)
                     if r8.dtype == torch.int8:
                         if self._fzheads is None:

@@ -360,8 +360,10 @@ class FusedHeads:
         M = Nb * Hs * Ws
         main = torch.cuda.current_stream(dev)
         bits, _, _ = uniform_act_settings(acts, "FusedHeads.forward_codes")
-        N_.check(lib.cdn_quantact_frozen_params(len(acts), *B["p"], bits, main.cuda_stream),
-                 "cdn_quantact_frozen_params")
+        cov, self.params_covered = getattr(self, "params_covered", None), None
+        if not (cov is not None and set(id(a) for a in acts) <= set(cov[0])):      # (else: FrozenBackbone's first launch)
+            N_.check(lib.cdn_quantact_frozen_params(len(acts), *B["p"], bits, main.cuda_stream),
+                     "cdn_quantact_frozen_params")
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         forked = []
         with torch.no_grad():

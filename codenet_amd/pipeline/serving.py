@@ -360,10 +360,13 @@ class FrozenHotPath:
         bits, _, _ = uniform_act_settings(B["acts"], "FrozenHotPath (all stages)")
         # (scale, zero-point) of all nine frozen QuantActs from their range buffers: one launch per step
         sa = B["sums_all"]
-        N_.check(lib.cdn_quantact_frozen_params_clear(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits,
-                                                      sa.data_ptr() if sa is not None else None,
-                                                      sa.numel() * 4 if sa is not None else 0, stream),
-                 "cdn_quantact_frozen_params_clear")
+        cov, self.params_covered = getattr(self, "params_covered", None), None
+        if not (cov is not None and cov[1] is sa and set(id(a) for a in B["acts"]) <= set(cov[0])):
+            # (not derived and cleared by the backbone's first launch, FrozenBackbone.__call__(also=...): this schedule's own)
+            N_.check(lib.cdn_quantact_frozen_params_clear(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits,
+                                                          sa.data_ptr() if sa is not None else None,
+                                                          sa.numel() * 4 if sa is not None else 0, stream),
+                     "cdn_quantact_frozen_params_clear")
         ws_ptr = (B["ws"].data_ptr() + 255) // 256 * 256
         ws_bytes = B["ws"].numel() - (ws_ptr - B["ws"].data_ptr())
         ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
@@ -637,7 +640,11 @@ class FrozenBackbone:
                          P["omapB"].data_ptr())
         return Y, ldc, qp(units[0]["sh"]), plan["logical"], Ho, Wo
 
-    def __call__(self, images):
+    def __call__(self, images, also=None):
+        """also: (acts, clear) of the schedules behind this one -- their QuantActs' (scale, zero-point) are derived, and
+        `clear` (the chained stages' integer scale sums, or None) is zeroed, in THIS call's first launch instead of in two
+        launches of their own; only when the bit widths agree and the list fits one launch (returns what it covered)."""
+        import ctypes
         from .. import _native as N_
         if not (images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3):
             raise NotImplementedError("FrozenBackbone needs a [N,3,H,W] float32 GPU tensor")
@@ -653,8 +660,28 @@ class FrozenBackbone:
         B = self._bufs
         st = torch.cuda.current_stream(dev).cuda_stream
         bits, _, _ = uniform_act_settings(B["acts"], "FrozenBackbone")
-        N_.check(lib.cdn_quantact_frozen_params(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits, st),
-                 "cdn_quantact_frozen_params")
+        self.covered = None
+        merged = None
+        if also is not None:
+            extra, clear = also
+            acts_all = list(B["acts"]) + [a for a in extra if all(a is not b for b in B["acts"])]
+            if len(acts_all) <= 64 and all(a.activation_bit == bits for a in extra):
+                mkey = tuple(p for a in acts_all for p in (a.x_min.data_ptr(), a.x_max.data_ptr()))
+                if B.get("merged_key") != mkey:
+                    arr = ctypes.c_void_p * len(acts_all)
+                    B["merged"] = (arr(*[a.x_min.data_ptr() for a in acts_all]), arr(*[a.x_max.data_ptr() for a in acts_all]),
+                                   arr(*[a._device_state(dev).data_ptr() for a in acts_all]))
+                    B["merged_key"] = mkey
+                merged = (len(acts_all),) + B["merged"]
+                self.covered = (tuple(id(a) for a in extra), clear)
+        if merged is not None:
+            clear = also[1]
+            N_.check(lib.cdn_quantact_frozen_params_clear(*merged, bits, clear.data_ptr() if clear is not None else None,
+                                                          clear.numel() * clear.element_size() if clear is not None else 0,
+                                                          st), "cdn_quantact_frozen_params_clear")
+        else:
+            N_.check(lib.cdn_quantact_frozen_params(B["n_acts"], B["p_min"], B["p_max"], B["p_state"], bits, st),
+                     "cdn_quantact_frozen_params")
         q0, act0 = m.layer0[0], m.layer0[1][1]
         q4, act4 = m.layer4[0], m.layer4[1][1]
         s0 = q0.conv.stride[0]

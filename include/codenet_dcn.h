@@ -563,7 +563,7 @@ int cdn_codenet_stage_fused_forward(
  * (a device word the caller zeroes) is set to 1 -- recompute that batch with cdn_codenet_stage_fused_forward
  * (running = 0), to which the results are otherwise bit-identical.
  *
- * cdn_quantact_frozen_params   state[i] words [2],[3] = (scale, zero-point) of x_min[i] / x_max[i] for up to 48
+ * cdn_quantact_frozen_params   state[i] words [2],[3] = (scale, zero-point) of x_min[i] / x_max[i] for up to 64
  *            QuantActs in ONE launch (host arrays of device pointers); word [6] (the running-range epilogues'
  *            wide-code flag) is cleared.  Call it once per step before the frozen kernels (or whenever a range
  *            buffer changed).

@@ -18,12 +18,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-merge-params", action="store_true", help="A/B: the stages' and the heads' QuantAct parameters in "
+                    "launches of their own instead of in the backbone's first launch")
     ap.add_argument("--stages-only", action="store_true", help="backbone on the fp32 kernels, stages on byte codes")
     ap.add_argument("--w2", action="store_true", help="CoDeNet2x (BASELINE cfg4's model; batch 32 per GPU there): stage 0 on "
                     "the fp32 frozen schedule, everything else on byte codes")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = harness.create_model(quantize=True, w2=a.w2).to(dev)
+    model.merge_frozen_params = not a.no_merge_params
     model.enable_fused()
     images = torch.randn(a.batch, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(dev)
     report = pipeline.prepare_serving(model, images, settle=30, margin=0.02)
