@@ -345,9 +345,9 @@ def test_argument_validation_of_round2_entry_points_without_gpu():
     assert lib.cdn_codenet_stage_frozen_forward(*args(kind=0, up=1)) == _native.CDN_ERR_UNSUPPORTED
     assert lib.cdn_codenet_stage_frozen_forward(*args(wsb=16)) == -6
     assert lib.cdn_codenet_stage_frozen_workspace_bytes(64, 1024, 16, 16, 0) == 64 * 256 * 4 + 64 * 256 * 1024
-    # frozen parameters: at most 48 QuantActs per call
-    arr = (ctypes.c_void_p * 49)(*([one] * 49))
-    assert lib.cdn_quantact_frozen_params(49, arr, arr, arr, 8, None) == -1
+    # frozen parameters: at most 64 QuantActs per call (round 6: the whole serving network's in one launch)
+    arr = (ctypes.c_void_p * 65)(*([one] * 65))
+    assert lib.cdn_quantact_frozen_params(65, arr, arr, arr, 8, None) == -1
     assert lib.cdn_quantact_frozen_params(0, None, None, None, 8, None) == 0
     # byte-code pointwise: exactly one output form; the byte form needs the output quantiser
     assert lib.cdn_codenet_pointwise_q8_forward(one * 4, one, 64, 64, 16, one * 4, one, one, None, 1, one, one * 4,
