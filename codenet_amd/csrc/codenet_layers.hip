@@ -1057,7 +1057,9 @@ head_small_kernel(const float *__restrict__ y1, const unsigned *__restrict__ q1,
                   int nstrips, int rps, int only_if_wide, unsigned *oflow = nullptr) {
   // MODE 2 (up to 32 classes on the int8 matrix cores) handles codes that fit the nibble split; a batch with
   // wider codes (state[6], the first calls of a fresh running range) is left to the MODE 1 launch behind it
-  if (MODE == 2 && q2[6]) return;
+  // (Y8, the serving schedule: frozen ranges have no wide batches -- state[6] is 0 by construction -- and the test would
+  // be a memory round trip in front of everything else in a launch that is one resident set of workgroups)
+  if (!Y8 && MODE == 2 && q2[6]) return;
   if (MODE == 1 && only_if_wide && !q2[6]) return;
   extern __shared__ float4 ring4[];          // [4][XS + 2][16]  (MODE 2: + A0 | A1 | B0 | B1 byte planes)
   constexpr int LPP = 16, XPT = 16, MAXL = 3, DEPTH = 2, NV = 4 * NCLS, C = 64;   // ring of 4 rows
