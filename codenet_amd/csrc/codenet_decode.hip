@@ -277,17 +277,23 @@ flip_merge_kernel(float *__restrict__ hm, const float *__restrict__ wh, float *_
 // Every thread of the workgroup calls it; nbins <= 2 * kSelThreads.  Results in *digit / *above (LDS).
 __device__ void find_digit(const unsigned *h, int nbins, unsigned need, unsigned *scan, int *digit,
                            unsigned *above) {
-  const int tid = threadIdx.x, np = nbins >> 1;
+  // Inclusive suffix sums over the threads' pair counts: inside a wave by shuffles, across the sixteen waves through
+  // LDS -- two barriers per call (round 6; the Hillis-Steele scan over 1024 LDS words it replaces took twenty, ~5 us
+  // of a kernel that is the last link of both graphs' critical paths and runs on 64 CUs)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, np = nbins >> 1;
   const unsigned lo = tid < np ? h[2 * tid] : 0u, hi = tid < np ? h[2 * tid + 1] : 0u;
-  scan[tid] = lo + hi;
-  __syncthreads();
-  for (int off = 1; off < kSelThreads; off <<= 1) {       // inclusive suffix sums
-    const unsigned v = tid + off < kSelThreads ? scan[tid + off] : 0u;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  unsigned v = lo + hi;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_down(v, off, 64);
+    if (lane + off < 64) v += t;
   }
-  const unsigned mine = scan[tid], next = tid + 1 < kSelThreads ? scan[tid + 1] : 0u;
+  __syncthreads();                                         // (scan[] may still be read by the previous call's threads)
+  if (lane == 0) scan[wave] = v;
+  __syncthreads();
+  unsigned tail = 0u;
+  for (int w = wave + 1; w < kSelThreads / 64; ++w) tail += scan[w];
+  const unsigned mine = v + tail, next = mine - (lo + hi);
   if (tid < np && mine >= need && next < need) {           // the pair that crosses `need`
     if (next + hi >= need) {
       *digit = 2 * tid + 1;
