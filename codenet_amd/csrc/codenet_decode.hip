@@ -322,6 +322,10 @@ decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__re
   // candidates the keys kernel counted (above cap: not all were stored).  ONE thread reads the counter and the
   // workgroup takes it from LDS behind a barrier: thread 0 resets the word below, and a wave that started late
   // would otherwise read 0 and disagree with the others about the workgroup-uniform `slow`.
+  // (the level-0 histogram is requested in the same round trip: it depends on nothing)
+  unsigned h0[kBins / kSelThreads];
+#pragma unroll
+  for (int u = 0; u < kBins / kSelThreads; ++u) h0[u] = gh[tid + u * kSelThreads];
   if (tid == 0) s_ncand = gh[kBins];
   __syncthreads();
   const unsigned ncand = s_ncand;
@@ -376,9 +380,10 @@ decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__re
       for (long i = tid; i < total; i += kSelThreads) fn(key_at(i), i);
     }
   };
-  for (int i = tid; i < kBins; i += kSelThreads) {
-    h[i] = gh[i];
-    gh[i] = 0;                                   // leave the global histogram zero for the next call
+#pragma unroll
+  for (int u = 0; u < kBins / kSelThreads; ++u) {
+    h[tid + u * kSelThreads] = h0[u];
+    gh[tid + u * kSelThreads] = 0;               // leave the global histogram zero for the next call
   }
   if (tid == 0) {
     gh[kBins] = 0;                               // ... and the candidate counter
@@ -469,12 +474,27 @@ decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__re
   }
   __syncthreads();
   const unsigned n = min(s_n, (unsigned)kCap);
+  // ---- descending order (score desc, index asc through the inverted index; the entries are distinct) -----------
+  constexpr unsigned kRankMax = 256;
+  if (n <= kRankMax) {
+    // few entries (the usual case: K plus the threshold group): every entry COUNTS the entries above it -- n broadcast
+    // LDS reads per thread, two barriers, against 28-45 barrier-separated steps of the bitonic network (round 6: the
+    // sort was 7 of this kernel's 20 us, and the kernel is the last link of both graphs)
+    const unsigned long long mine = (unsigned)tid < n ? list[tid] : 0ull;
+    unsigned rank = 0;
+    if ((unsigned)tid < n)
+      for (unsigned j = 0; j < n; ++j) rank += list[j] > mine ? 1u : 0u;
+    __syncthreads();
+    if ((unsigned)tid < n) list[rank] = mine;
+    else if (tid < K) list[tid] = 0ull;                  // below every real entry (fewer than K collected)
+    __syncthreads();
+  } else {
   int nsort = 2;
   while ((unsigned)nsort < n) nsort <<= 1;               // sort only as much as was collected
   for (int i = tid; i < nsort; i += kSelThreads)
     if ((unsigned)i >= n) list[i] = 0ull;                 // below every real entry
   __syncthreads();
-  // ---- bitonic sort, descending (score desc, index asc through the inverted index) -------------
+  // ---- bitonic sort, descending ----------------------------------------------------------------
   for (int k2 = 2; k2 <= nsort; k2 <<= 1)
     for (int j = k2 >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < nsort; i += kSelThreads) {
@@ -490,6 +510,7 @@ decode_select_kernel(const unsigned long long *__restrict__ cand, unsigned *__re
       }
       __syncthreads();
     }
+  }
   // ---- boxes ---------------------------------------------------------------------------------
   for (int k = tid; k < K; k += kSelThreads) {
     const unsigned long long e = list[k];
