@@ -37,7 +37,22 @@ BUDGET_LAYERS = {
 # gather needs 152 VGPRs (three waves per SIMD) instead of 99-106; dcn_generic.hip: the seam's parameter-gradient kernel
 # holds a 45-value record per lane under the 128-VGPR cap of its 1024-thread workgroups
 BUDGET_STAGE = {"dw4_kernelILb1E": 128, "dw4_kernelILb0E": 128}
-BUDGET_GENERIC = {"dwo_wgrad_kernelILi16E": 128, "dwo_wgrad_kernelILi8E": 128}
+BUDGET_GENERIC = {"dwo_wgrad_kernelILi16E": 128, "dwo_wgrad_kernelILi8E": 128,
+                  # round 6: the structured forward (four waves per SIMD: 170 VGPRs with a run-time test of the plane
+                  # pointer instead of the template parameter) and the structured backward_input kernels (1024-thread
+                  # workgroups: 128)
+                  "dwo4_kernelILb1E": 128, "dwo4_kernelILb0E": 128,
+                  # (the instantiations the CoDeNet stage shapes use: one pass with chunks of 16 / 8, the split form's
+                  # grad_input pass with 4 and grad_offset pass with 8; the thin-chunk one-pass forms spill a few VGPRs
+                  # and are never launched -- dwos_bwd_split)
+                  "dwos_bwd_kernelILi16ELi0E": 128, "dwos_bwd_kernelILi8ELi0E": 128, "dwos_bwd_kernelILi4ELi1E": 128,
+                  "dwos_bwd_kernelILi8ELi2E": 128}
+SGPR_SPILLS_OK_X = 32      # (SGPR spills go to VGPR lanes: tolerated in the kernels of the two tables below)
+# codenet_frozen.hip (round 6): the occupancy the serving network's small launches were measured with -- the 64 x 64
+# byte-code pointwise at eight waves per SIMD, the fused depthwise + pointwise at two (256 columns) / three
+BUDGET_FROZEN = {"pwq8_kernelILi64ELi64E": 64, "dwpwq8_kernelILi1ELi4ELi2ELi128E": 168, "dwpwq8_kernelILi1ELi4ELi1ELi64E": 168,
+                 "dwpwq8_kernelILi2ELi2ELi1ELi64E": 168, "dwpwq8_kernelILi2ELi2ELi2ELi128E": 168,
+                 "dwpwq8_kernelILi1ELi4ELi2ELi256ELi32E": 256, "dwpwq8_kernelILi2ELi2ELi2ELi256ELi32E": 256}
 
 
 def kernel_resources(src="codenet_fused.hip", extra=()):
@@ -71,14 +86,16 @@ def check():
             if r["vgpr"] > cap:
                 problems.append("%s uses %d VGPRs (budget %d)" % (n, r["vgpr"], cap))
     res.update(res_l)
-    for src, extra, budget in (("codenet_stage.hip", ("-fno-slp-vectorize",), BUDGET_STAGE), ("dcn_generic.hip", (), BUDGET_GENERIC)):
+    for src, extra, budget in (("codenet_stage.hip", ("-fno-slp-vectorize",), BUDGET_STAGE), ("dcn_generic.hip", (), BUDGET_GENERIC),
+                               ("codenet_frozen.hip", (), BUDGET_FROZEN)):
         res_x = kernel_resources(src, extra)
         for frag, cap in budget.items():
             hits = [(n, r) for n, r in res_x.items() if frag in n]
             if not hits:
                 problems.append("kernel %s not found" % frag)
+            sg_ok = 0 if budget is BUDGET_STAGE else SGPR_SPILLS_OK_X
             for n, r in hits:
-                if r["spill"] or r["scratch"] or r["sgpr_spill"]:
+                if r["spill"] or r["scratch"] or r["sgpr_spill"] > sg_ok:
                     problems.append("%s spills: %s" % (n, r))
                 if r["vgpr"] > cap:
                     problems.append("%s uses %d VGPRs (budget %d)" % (n, r["vgpr"], cap))
@@ -97,7 +114,7 @@ def check():
 
 if __name__ == "__main__":
     res, problems = check()
-    for frag in list(BUDGET) + list(BUDGET_STAGE) + list(BUDGET_GENERIC):
+    for frag in list(BUDGET) + list(BUDGET_STAGE) + list(BUDGET_GENERIC) + list(BUDGET_FROZEN):
         for n, r in res.items():
             if frag in n:
                 print("%-70s %s" % (n[18:88], r))
